@@ -1,0 +1,309 @@
+/*
+ * nvr.h — C ABI of the MI355X-native drop-in for nano-vllm-rs's paged-attention
+ * prefill/decode hot path and block-based KV cache.
+ *
+ * The reference (ssvgopal/nano-vllm-rs @ 2025-07-18) is pure Rust with no FFI of its own;
+ * its seam is the Rust public API re-exported at src/lib.rs:91-94, src/engine/mod.rs:14-17
+ * and src/layers/mod.rs:16-22.  Every entry point below names the reference item it
+ * replaces (file:line under the reference tree).  INTEGRATION.md shows the Rust-side
+ * `extern "C"` block + safe wrappers that keep the LLMEngine / ModelRunner / BlockManager
+ * surface.
+ *
+ * Conventions:
+ *  - plain pointers and sizes only; no C++/torch types; hipStream_t travels as void*.
+ *  - every fallible call returns an int status: NVR_OK (0) or a negative nvr_status;
+ *    nvr_last_error() returns a thread-local message carrying the reference's error text.
+ *    The reference's assert!/panic sites map to NVR_ERR_INVARIANT; nothing unwinds across
+ *    the ABI.
+ *  - handles are not internally synchronised (the reference wraps them in a Mutex,
+ *    src/engine/llm_engine.rs:25-28): one thread at a time per handle.
+ *  - the library owns all device memory it allocates (weights, KV pool, workspaces);
+ *    pointers handed out are borrowed and stay valid until the documented next call.
+ *  - the HIP path is the only compute path: if no gfx950 device is usable, device calls
+ *    fail with NVR_ERR_HIP.  There is no CPU fallback.
+ */
+#ifndef NVR_H
+#define NVR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NVR_API __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------ status ---- */
+typedef enum nvr_status {
+    NVR_OK = 0,
+    NVR_ERR_NO_FREE_BLOCKS = -1,     /* block_manager.rs:163,225,280 */
+    NVR_ERR_ALREADY_ALLOCATED = -2,  /* block_manager.rs:159 */
+    NVR_ERR_NOT_ALLOCATED = -3,      /* block_manager.rs:267 */
+    NVR_ERR_LEN_MISMATCH = -4,       /* scheduler.rs:236 */
+    NVR_ERR_NOTHING_TO_SCHEDULE = -5,/* scheduler.rs:219 */
+    NVR_ERR_INVARIANT = -6,          /* assert! sites: block_manager.rs:62,92-93,127,138 ... */
+    NVR_ERR_INVALID_ARG = -7,        /* config.rs:83-119, sampling_params.rs:91-119 */
+    NVR_ERR_HIP = -8,
+    NVR_ERR_RCCL = -9,
+    NVR_ERR_UNSUPPORTED = -10
+} nvr_status;
+
+NVR_API const char *nvr_last_error(void);
+NVR_API const char *nvr_version(void);
+
+/* ------------------------------------------------------------- plain structs ---- */
+/* SamplingParams, src/engine/sampling_params.rs:10-28 (Option<T> -> has_* flag) */
+typedef struct nvr_sampling_params {
+    float temperature;            /* default 1.0; 0.0 == greedy (:86-88) */
+    uint64_t max_tokens;          /* default 64 */
+    int32_t ignore_eos;
+    int32_t has_top_p;  float top_p;
+    int32_t has_top_k;  uint64_t top_k;
+    int32_t has_repetition_penalty; float repetition_penalty;
+} nvr_sampling_params;
+NVR_API void nvr_sampling_params_default(nvr_sampling_params *sp);   /* sampling_params.rs:30-41 */
+NVR_API int nvr_sampling_params_validate(const nvr_sampling_params *sp); /* :91-119 */
+
+/* Config, src/config.rs:16-52 (model_path omitted: synthetic weights; loader is §8f) */
+typedef struct nvr_config {
+    uint64_t max_num_batched_tokens;   /* 32768 */
+    uint64_t max_num_seqs;             /* 512 */
+    uint64_t max_model_len;            /* 4096 */
+    float gpu_memory_utilization;      /* 0.9 */
+    uint64_t tensor_parallel_size;     /* 1 (1..=8) */
+    int32_t enforce_eager;             /* 0: decode steps replay a captured hipGraph */
+    int32_t has_eos; int64_t eos_token_id;
+    uint64_t kvcache_block_size;       /* 256 */
+    int64_t num_kvcache_blocks;        /* -1 == None: scheduler default 1000 (scheduler.rs:71-74);
+                                          -2 == size the pool from free HBM * gpu_memory_utilization */
+    /* extensions that the reference hard-codes (model_runner.rs:75,405): */
+    uint64_t tensor_parallel_rank;     /* 0 */
+    int32_t device_ordinal;            /* HIP device index of this rank */
+    uint64_t sample_seed;              /* A-20 counter-RNG seed */
+    int32_t skip_block_size_check;     /* reference unit tests use block sizes 4/16 that
+                                          Config::validate would reject (config.rs:94) */
+} nvr_config;
+NVR_API void nvr_config_default(nvr_config *cfg);                    /* config.rs:54-71 */
+NVR_API int nvr_config_validate(const nvr_config *cfg);              /* config.rs:83-119 */
+
+/* Qwen3Config, src/models/qwen3.rs:26-125 (+ head_dim override, SURVEY A-17) */
+typedef struct nvr_model_config {
+    uint64_t vocab_size, hidden_size, intermediate_size, num_hidden_layers;
+    uint64_t num_attention_heads, num_key_value_heads;
+    uint64_t head_dim;                 /* 0 => hidden_size / num_attention_heads (:101-103) */
+    uint64_t max_position_embeddings;
+    float rms_norm_eps;
+    double rope_theta;
+    int32_t tie_word_embeddings;
+    float init_std;                    /* synthetic weights: N(0, std^2)-like, SURVEY §8d */
+    uint64_t seed;
+} nvr_model_config;
+NVR_API void nvr_model_config_default(nvr_model_config *mc);         /* qwen3.rs:70-89 */
+NVR_API void nvr_model_config_qwen3_0_6b(nvr_model_config *mc);
+NVR_API void nvr_model_config_qwen3_8b(nvr_model_config *mc);
+NVR_API int nvr_model_config_validate(const nvr_model_config *mc, uint64_t tp); /* :106-124 */
+
+/* ------------------------------------------------------------------ Sequence ---- */
+/* Sequence, src/engine/sequence.rs:50-237.  status values = SequenceStatus :15-27 */
+typedef struct nvr_seq nvr_seq_t;
+enum { NVR_SEQ_WAITING = 0, NVR_SEQ_RUNNING = 1, NVR_SEQ_FINISHED = 2, NVR_SEQ_PREEMPTED = 3, NVR_SEQ_ERROR = 4 };
+
+NVR_API nvr_seq_t *nvr_seq_create(const int64_t *prompt, size_t n, const nvr_sampling_params *sp,
+                                  size_t block_size);                 /* Sequence::new :84-101 (A-1) */
+NVR_API void nvr_seq_destroy(nvr_seq_t *s);   /* only for sequences never handed to a scheduler/engine */
+NVR_API void nvr_seq_reset_id_counter(void);                          /* SEQUENCE_COUNTER :12 (tests) */
+NVR_API uint64_t nvr_seq_id(const nvr_seq_t *s);
+NVR_API int32_t nvr_seq_status(const nvr_seq_t *s);
+NVR_API size_t nvr_seq_len(const nvr_seq_t *s);                       /* :104 */
+NVR_API size_t nvr_seq_num_prompt_tokens(const nvr_seq_t *s);
+NVR_API size_t nvr_seq_num_completion_tokens(const nvr_seq_t *s);     /* :135 */
+NVR_API size_t nvr_seq_num_cached_tokens(const nvr_seq_t *s);
+NVR_API int64_t nvr_seq_last_token(const nvr_seq_t *s);
+NVR_API size_t nvr_seq_num_blocks(const nvr_seq_t *s);                /* :157 */
+NVR_API size_t nvr_seq_last_block_num_tokens(const nvr_seq_t *s);     /* :167 */
+NVR_API void nvr_seq_token_ids(const nvr_seq_t *s, const int64_t **ptr, size_t *len);   /* borrowed */
+NVR_API void nvr_seq_block_table(const nvr_seq_t *s, const int32_t **ptr, size_t *len); /* borrowed */
+NVR_API void nvr_seq_append_token(nvr_seq_t *s, int64_t token);       /* :150 */
+NVR_API int nvr_seq_should_stop(const nvr_seq_t *s, int has_eos, int64_t eos); /* :189 */
+NVR_API void nvr_seq_preempt(nvr_seq_t *s);                           /* :213 */
+NVR_API void nvr_seq_finish(nvr_seq_t *s);                            /* :208 */
+
+/* -------------------------------------------------------------- BlockManager ---- */
+/* BlockManager, src/engine/block_manager.rs:69-361 */
+typedef struct nvr_block_manager nvr_block_manager_t;
+typedef struct nvr_bm_stats {          /* BlockManagerStats :325-332 */
+    uint64_t total_blocks, free_blocks, used_blocks, cached_blocks, block_size;
+} nvr_bm_stats;
+typedef struct nvr_block_info {        /* Block :12-24 */
+    uint64_t block_id, ref_count; int32_t has_hash; uint64_t hash; uint64_t num_tokens;
+} nvr_block_info;
+
+NVR_API nvr_block_manager_t *nvr_bm_create(size_t num_blocks, size_t block_size);      /* :91 */
+NVR_API void nvr_bm_destroy(nvr_block_manager_t *bm);
+NVR_API uint64_t nvr_bm_compute_hash(const int64_t *tokens, size_t n, int has_prefix, uint64_t prefix); /* :109 */
+NVR_API int nvr_bm_can_allocate(const nvr_block_manager_t *bm, const nvr_seq_t *s);    /* :152 -> 0/1 */
+NVR_API int nvr_bm_allocate(nvr_block_manager_t *bm, nvr_seq_t *s);                    /* :157 */
+NVR_API int nvr_bm_deallocate(nvr_block_manager_t *bm, nvr_seq_t *s);                  /* :240 */
+NVR_API int nvr_bm_can_append(const nvr_block_manager_t *bm, const nvr_seq_t *s);      /* :255 -> 0/1 */
+NVR_API int nvr_bm_may_append(nvr_block_manager_t *bm, nvr_seq_t *s);                  /* :265 */
+NVR_API int nvr_bm_get_stats(const nvr_block_manager_t *bm, nvr_bm_stats *out);        /* :307 */
+NVR_API int nvr_bm_get_block(const nvr_block_manager_t *bm, size_t block_id, nvr_block_info *out); /* :318 */
+NVR_API size_t nvr_bm_free_list(const nvr_block_manager_t *bm, int32_t *out, size_t cap); /* free_block_ids order (A-2) */
+
+/* ----------------------------------------------------------------- Scheduler ---- */
+/* Scheduler, src/engine/scheduler.rs:13-365 */
+typedef struct nvr_scheduler nvr_scheduler_t;
+typedef struct nvr_sched_stats {       /* SchedulerStats :38-66 */
+    uint64_t total_sequences, waiting_sequences, running_sequences, finished_sequences;
+    uint64_t preemptions, prefill_batches, decode_batches;
+    double avg_prefill_batch_size, avg_decode_batch_size;
+} nvr_sched_stats;
+
+NVR_API nvr_scheduler_t *nvr_sched_create(const nvr_config *cfg);                      /* :70 */
+NVR_API void nvr_sched_destroy(nvr_scheduler_t *sc);
+NVR_API int nvr_sched_add_sequence(nvr_scheduler_t *sc, nvr_seq_t *s);  /* :93; ownership moves to the scheduler */
+/* :103 — writes up to cap borrowed sequence handles (valid until they finish); *is_prefill 0/1 */
+NVR_API int nvr_sched_schedule(nvr_scheduler_t *sc, nvr_seq_t **out, size_t cap, size_t *n, int *is_prefill);
+NVR_API int nvr_sched_postprocess(nvr_scheduler_t *sc, nvr_seq_t *const *seqs, const int64_t *token_ids, size_t n); /* :234 */
+NVR_API int nvr_sched_is_finished(const nvr_scheduler_t *sc);                          /* :88 */
+NVR_API void nvr_sched_preempt_all(nvr_scheduler_t *sc);                               /* :314 */
+NVR_API int nvr_sched_get_stats(const nvr_scheduler_t *sc, nvr_sched_stats *out);      /* :299 */
+NVR_API int nvr_sched_get_block_stats(const nvr_scheduler_t *sc, nvr_bm_stats *out);   /* :304 */
+NVR_API void nvr_sched_queue_lengths(const nvr_scheduler_t *sc, size_t *waiting, size_t *running); /* :309 */
+NVR_API double nvr_sched_memory_pressure(const nvr_scheduler_t *sc);                   /* :322 */
+NVR_API nvr_block_manager_t *nvr_sched_block_manager(nvr_scheduler_t *sc);             /* borrowed */
+/* finished sequences stay owned by the scheduler until taken (SequenceOutput, sequence.rs:30-47) */
+NVR_API size_t nvr_sched_take_finished(nvr_scheduler_t *sc, nvr_seq_t **out, size_t cap); /* caller destroys */
+
+/* --------------------------------------------------------------- ModelRunner ---- */
+/* ModelRunner, src/engine/model_runner.rs:19-464 */
+typedef struct nvr_model_runner nvr_model_runner_t;
+
+NVR_API nvr_model_runner_t *nvr_runner_create(const nvr_config *cfg, const nvr_model_config *mc); /* :67 */
+NVR_API void nvr_runner_destroy(nvr_model_runner_t *r);
+/* :105 — logits_dev: borrowed device pointer to f32 [n, vocab/tp], valid until the next execute */
+NVR_API int nvr_runner_execute_model(nvr_model_runner_t *r, nvr_seq_t *const *seqs, size_t n, int is_prefill,
+                                     const float **logits_dev);
+/* :131 — samples from the logits of the last execute_model; writes n token ids (host) */
+NVR_API int nvr_runner_sample_tokens(nvr_model_runner_t *r, nvr_seq_t *const *seqs, size_t n, int64_t *out_ids);
+NVR_API int nvr_runner_copy_logits(nvr_model_runner_t *r, float *host_out, size_t rows); /* D2H, tests */
+NVR_API uint64_t nvr_runner_num_kvcache_blocks(const nvr_model_runner_t *r);
+/* KV pool of layer l (borrowed device pointers, fp16 [NB, bs, KVH/tp, D], model_runner.rs:364-396) */
+NVR_API int nvr_runner_kv_cache(nvr_model_runner_t *r, size_t layer, void **k_dev, void **v_dev);
+NVR_API void *nvr_runner_stream(nvr_model_runner_t *r);
+/* tensor-parallel wiring (the reference's TODO all-reduce/gather sites, linear.rs:236-238,
+ * embed_head.rs:130-139,321-336): rank 0 creates the 128-byte RCCL id, the host broadcasts it. */
+NVR_API int nvr_comm_unique_id(uint8_t id_out[128]);
+NVR_API int nvr_runner_init_comm(nvr_model_runner_t *r, const uint8_t id[128]);
+/* per-kernel-class device time of the last profiled steps (hipEvent based), microseconds */
+NVR_API int nvr_runner_set_profiling(nvr_model_runner_t *r, int on);
+
+/* -------------------------------------------------------------------- Engine ---- */
+/* LLMEngine::step loop, src/engine/llm_engine.rs:155-197 (driver of the hot path only) */
+typedef struct nvr_engine nvr_engine_t;
+typedef struct nvr_step_info {
+    int32_t is_prefill; uint64_t num_seqs; uint64_t num_tokens; uint64_t num_finished;
+} nvr_step_info;
+
+NVR_API nvr_engine_t *nvr_engine_create(const nvr_config *cfg, const nvr_model_config *mc); /* :34-63 */
+NVR_API void nvr_engine_destroy(nvr_engine_t *e);
+NVR_API int nvr_engine_add_request(nvr_engine_t *e, const int64_t *prompt, size_t n,
+                                   const nvr_sampling_params *sp, uint64_t *seq_id_out);   /* :200-217 */
+NVR_API int nvr_engine_step(nvr_engine_t *e, nvr_step_info *info);                         /* :155 */
+NVR_API int nvr_engine_is_finished(const nvr_engine_t *e);
+NVR_API nvr_scheduler_t *nvr_engine_scheduler(nvr_engine_t *e);     /* borrowed */
+NVR_API nvr_model_runner_t *nvr_engine_runner(nvr_engine_t *e);     /* borrowed */
+/* ids + tokens sampled by the last step (borrowed until the next step) */
+NVR_API void nvr_engine_last_step(const nvr_engine_t *e, const uint64_t **seq_ids, const int64_t **tokens, size_t *n);
+NVR_API size_t nvr_engine_take_finished(nvr_engine_t *e, nvr_seq_t **out, size_t cap);   /* caller destroys */
+
+/* --------------------------------------------------------- device utilities ---- */
+NVR_API int nvr_device_count(int *n);
+NVR_API int nvr_device_set(int ordinal);
+NVR_API int nvr_device_name(char *buf, size_t cap);
+NVR_API int nvr_device_mem_info(uint64_t *free_bytes, uint64_t *total_bytes);
+NVR_API int nvr_device_malloc(void **ptr, size_t bytes);
+NVR_API int nvr_device_free(void *ptr);
+NVR_API int nvr_device_memset(void *ptr, int value, size_t bytes);
+NVR_API int nvr_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes);
+NVR_API int nvr_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes);
+NVR_API int nvr_device_synchronize(void);
+NVR_API int nvr_stream_create(void **stream);
+NVR_API int nvr_stream_destroy(void *stream);
+NVR_API int nvr_stream_synchronize(void *stream);
+NVR_API int nvr_event_create(void **ev);
+NVR_API int nvr_event_destroy(void *ev);
+NVR_API int nvr_event_record(void *ev, void *stream);
+NVR_API int nvr_event_elapsed_ms(void *start, void *stop, float *ms);   /* synchronises on stop */
+
+/* ------------------------------------------------ stateless op entry points ---- */
+/* One per kernel-shaped op site of the hot path.  All tensors are
+ * device pointers; activations/weights/caches are fp16 (nvr_half = uint16_t bits) unless
+ * noted; math is f32 inside an op.  `stream` is a hipStream_t (NULL = default stream). */
+typedef uint16_t nvr_half;
+
+/* Attention metadata of one step = Context, src/utils/context.rs:11-35 (explicit, not global) */
+typedef struct nvr_attn_meta {
+    int32_t is_prefill;
+    const int32_t *cu_seqlens_q;   /* [B+1] device; prefill */
+    const int32_t *cu_seqlens_k;   /* [B+1] device; prefill (== q today, model_runner.rs:233-234) */
+    int32_t max_seqlen_q, max_seqlen_k;
+    const int32_t *slot_mapping;   /* [T] device; slot = block*bs + offset (A-6), <0 skips */
+    const int32_t *context_lens;   /* [B] device; decode */
+    const int32_t *block_tables;   /* [B, max_blocks] device, -1 padded; decode / prefix prefill */
+    int32_t max_blocks;
+    int32_t batch;                 /* B */
+    int32_t max_context_len;       /* host-side max of context_lens (decode grid sizing) */
+} nvr_attn_meta;
+
+/* K1 embedding gather, embed_head.rs:77-97 */
+NVR_API int nvr_embedding(const int64_t *ids, int64_t T, const nvr_half *E, int64_t Hd, nvr_half *out, void *stream);
+/* K2 RMSNorm, layernorm.rs:58-75 */
+NVR_API int nvr_rmsnorm(const nvr_half *x, const nvr_half *w, float eps, int64_t T, int64_t Hd, nvr_half *out, void *stream);
+/* K11+K2 fused: h = fp16(h + y) in place, out = rmsnorm(h)*w  (layernorm.rs:170-176) */
+NVR_API int nvr_add_rmsnorm(nvr_half *h, const nvr_half *y, const nvr_half *w, float eps, int64_t T, int64_t Hd,
+                            nvr_half *out, void *stream);
+/* K3/K10/K12/K14/K16 y = x·Wᵀ; x [T,K] (row stride ldx), W [N,K], y [T,N] fp16 or f32 */
+NVR_API int nvr_linear(const nvr_half *x, int64_t ldx, const nvr_half *W, int64_t T, int64_t K, int64_t N,
+                       void *y, int y_is_f32, void *stream);
+/* K5+K6 RoPE (rotary_embedding.rs:23-48) on the q and k heads of a packed qkv buffer
+ * [T, (H+2KVH)*D] in place, then store k,v rows to the caches at slot_mapping (attention.rs:150-174) */
+NVR_API int nvr_rope_store_kv(nvr_half *qkv, const int64_t *positions, const int32_t *slot_mapping, int64_t T,
+                              int64_t H, int64_t KVH, int64_t D, const float *cos_t, const float *sin_t,
+                              nvr_half *k_cache, nvr_half *v_cache, void *stream);
+NVR_API int nvr_rope_table(int64_t D, int64_t max_pos, double theta, float *cos_dev, float *sin_dev); /* rotary_embedding.rs:74-119 */
+/* K9 decode paged attention, attention.rs:225-235,264-318 (A-8).  q rows have stride ldq
+ * elements ([B, H, D] inside the packed qkv buffer).  workspace: nvr_paged_attn_workspace_bytes. */
+NVR_API size_t nvr_paged_attn_workspace_bytes(int64_t B, int64_t H, int64_t D, int64_t max_context_len);
+NVR_API int nvr_paged_attn_decode(const nvr_half *q, int64_t ldq, const nvr_half *k_cache, const nvr_half *v_cache,
+                                  const nvr_attn_meta *meta, int64_t H, int64_t KVH, int64_t D, int64_t block_size,
+                                  float scale, nvr_half *out, void *workspace, void *stream);
+/* K7 varlen causal prefill attention, attention.rs:177-208 (q,k,v inside packed qkv, stride ld) */
+NVR_API int nvr_attn_prefill_varlen(const nvr_half *q, const nvr_half *k, const nvr_half *v, int64_t ld,
+                                    const nvr_attn_meta *meta, int64_t T, int64_t H, int64_t KVH, int64_t D,
+                                    float scale, nvr_half *out, void *stream);
+/* K13 SiluAndMul, activation.rs:46-63: [T,2I] -> [T,I] */
+NVR_API int nvr_silu_and_mul(const nvr_half *x, int64_t T, int64_t I, nvr_half *out, void *stream);
+/* K15 last-token select, embed_head.rs:272-289 */
+NVR_API int nvr_select_last_tokens(const nvr_half *h, const int32_t *cu_seqlens_q, int64_t B, int64_t Hd,
+                                   nvr_half *out, void *stream);
+/* K17 greedy argmax over f32 logits [B,V] (lowest index wins, A-12) */
+NVR_API int nvr_argmax(const float *logits, int64_t B, int64_t V, int64_t *out_ids, void *stream);
+/* K18 temperature / top-k / top-p / Gumbel-max, sampler.rs:71-218 (A-18..A-20).  Per-row
+ * params are device arrays; top_k[i]==0 and top_p[i]<0 mean disabled; keys[i] = counter-RNG key. */
+NVR_API size_t nvr_sample_workspace_bytes(int64_t B, int64_t V);
+NVR_API int nvr_sample(const float *logits, int64_t B, int64_t V, const float *temperature, const int64_t *top_k,
+                       const float *top_p, const uint64_t *keys, int64_t *out_ids, void *workspace, void *stream);
+NVR_API uint64_t nvr_sample_key(uint64_t seed, uint64_t seq_id, uint64_t step);
+/* synthetic weights: dst[i*ld+j] = fp16(value(key, (row0+i)*global_cols + col0+j)) */
+NVR_API uint64_t nvr_weight_key(uint64_t seed, uint64_t tensor_id);
+NVR_API float nvr_weight_scale(double std);
+NVR_API int nvr_fill_weight(nvr_half *dst, int64_t rows, int64_t cols, int64_t ld, int64_t global_cols,
+                            int64_t row0, int64_t col0, uint64_t key, float scale, void *stream);
+NVR_API int nvr_fill_const(nvr_half *dst, int64_t n, float value, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NVR_H */

@@ -1,0 +1,13 @@
+#include "common.h"
+#include <atomic>
+#include "sequence.h"
+namespace nvr {
+std::string &last_error_slot() { static thread_local std::string s; return s; }
+int fail(int code, const char *fmt, ...) {
+    char buf[1024];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    last_error_slot() = buf;
+    return code;
+}
+std::atomic<uint64_t> g_sequence_counter{0};
+}

@@ -1,0 +1,261 @@
+// elementwise.hip — the HBM-bound row kernels of the hot path for gfx950 (wave64):
+// embedding gather (K1), RMSNorm and fused add+RMSNorm (K2, K11), RoPE + KV store (K5, K6),
+// SiluAndMul (K13), last-token select (K15), greedy argmax (K17), synthetic weight fill.
+// All activation traffic is 16 B per lane (8 fp16), one wave per row where a row reduction exists.
+#include "kernels.h"
+#include "device_utils.h"
+#include "../common.h"
+
+namespace nvr { namespace k {
+
+#define LAUNCH_CHECK()                                                                                   \
+    do {                                                                                                 \
+        hipError_t _e = hipGetLastError();                                                               \
+        if (_e != hipSuccess) return nvr::fail(NVR_ERR_HIP, "kernel launch failed: %s (%s:%d)",          \
+                                               hipGetErrorString(_e), __FILE__, __LINE__);               \
+    } while (0)
+
+// ---------------------------------------------------------------- K1 embedding
+// reference: VocabParallelEmbedding::forward, src/layers/embed_head.rs:77-97
+__global__ void embedding_kernel(const int64_t *__restrict__ ids, const half_t *__restrict__ E, int Hd,
+                                 half_t *__restrict__ out) {
+    const int t = blockIdx.x;
+    const half8_t *src = reinterpret_cast<const half8_t *>(E + (int64_t)ids[t] * Hd);
+    half8_t *dst = reinterpret_cast<half8_t *>(out + (int64_t)t * Hd);
+    for (int c = threadIdx.x; c < Hd / 8; c += blockDim.x) dst[c] = src[c];
+}
+int embedding(const int64_t *ids, int64_t T, const half_bits *E, int64_t Hd, half_bits *out, hipStream_t s) {
+    if (Hd % 8) return nvr::fail(NVR_ERR_UNSUPPORTED, "embedding: hidden size %ld not a multiple of 8", (long)Hd);
+    if (T == 0) return 0;
+    int threads = Hd / 8 >= 128 ? 128 : 64;
+    embedding_kernel<<<dim3((unsigned)T), dim3(threads), 0, s>>>(ids, (const half_t *)E, (int)Hd, (half_t *)out);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------- K2 / K11 RMSNorm
+// reference: RMSNorm::forward_simple, src/layers/layernorm.rs:58-75 — f32: rms = sqrt(mean(x^2)+eps),
+// out = (x / rms) * w; fused variant: OptimizedRMSNorm::forward_with_residual, :170-176 —
+// h <- fp16(h + y), out = rmsnorm(h).  One wave per row, 4 rows per workgroup.
+template <bool ADD>
+__global__ __launch_bounds__(256) void rmsnorm_kernel(half_t *__restrict__ h, const half_t *__restrict__ y,
+                                                      const half_t *__restrict__ w, float eps, int T, int Hd,
+                                                      half_t *__restrict__ out) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= T) return;
+    half_t *hr = h + (int64_t)row * Hd;
+    const half_t *yr = ADD ? y + (int64_t)row * Hd : nullptr;
+    float ss = 0.f;
+    for (int c = lane * 8; c < Hd; c += 512) {
+        half8_t v = *reinterpret_cast<const half8_t *>(hr + c);
+        if (ADD) {
+            half8_t u = *reinterpret_cast<const half8_t *>(yr + c);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (half_t)((float)v[j] + (float)u[j]);
+            *reinterpret_cast<half8_t *>(hr + c) = v;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { float f = (float)v[j]; ss += f * f; }
+    }
+    ss = wave_sum(ss);
+    const float rms = sqrtf(ss / (float)Hd + eps);
+    half_t *orow = out + (int64_t)row * Hd;
+    for (int c = lane * 8; c < Hd; c += 512) {
+        half8_t v = *reinterpret_cast<const half8_t *>(hr + c);   // own writes: same lane, L1/L2 hit
+        half8_t g = *reinterpret_cast<const half8_t *>(w + c);
+        half8_t o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (half_t)(__fdiv_rn((float)v[j], rms) * (float)g[j]);
+        *reinterpret_cast<half8_t *>(orow + c) = o;
+    }
+}
+int rmsnorm(const half_bits *x, const half_bits *w, float eps, int64_t T, int64_t Hd, half_bits *out, hipStream_t s) {
+    if (Hd % 8) return nvr::fail(NVR_ERR_UNSUPPORTED, "rmsnorm: hidden size %ld not a multiple of 8", (long)Hd);
+    if (T == 0) return 0;
+    rmsnorm_kernel<false><<<dim3((unsigned)((T + 3) / 4)), dim3(256), 0, s>>>(
+        (half_t *)x, nullptr, (const half_t *)w, eps, (int)T, (int)Hd, (half_t *)out);
+    LAUNCH_CHECK();
+    return 0;
+}
+int add_rmsnorm(half_bits *h, const half_bits *y, const half_bits *w, float eps, int64_t T, int64_t Hd,
+                half_bits *out, hipStream_t s) {
+    if (Hd % 8) return nvr::fail(NVR_ERR_UNSUPPORTED, "rmsnorm: hidden size %ld not a multiple of 8", (long)Hd);
+    if (T == 0) return 0;
+    rmsnorm_kernel<true><<<dim3((unsigned)((T + 3) / 4)), dim3(256), 0, s>>>(
+        (half_t *)h, (const half_t *)y, (const half_t *)w, eps, (int)T, (int)Hd, (half_t *)out);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------- K13 SiluAndMul
+// reference: SiluAndMul::forward, src/layers/activation.rs:46-63; silu(x) = x*sigmoid(x), :12-15
+__global__ void silu_mul_kernel(const half_t *__restrict__ x, int I, half_t *__restrict__ out, int64_t total8) {
+    const int per_row = I / 8;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total8; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t t = i / per_row; const int c = (int)(i % per_row) * 8;
+        half8_t g = *reinterpret_cast<const half8_t *>(x + t * 2 * I + c);
+        half8_t u = *reinterpret_cast<const half8_t *>(x + t * 2 * I + I + c);
+        half8_t o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float gf = (float)g[j];
+            float sg = 1.0f / (1.0f + __expf(-gf));
+            o[j] = (half_t)((gf * sg) * (float)u[j]);
+        }
+        *reinterpret_cast<half8_t *>(out + t * I + c) = o;
+    }
+}
+int silu_and_mul(const half_bits *x, int64_t T, int64_t I, half_bits *out, hipStream_t s) {
+    if (I % 8) return nvr::fail(NVR_ERR_UNSUPPORTED, "silu_and_mul: intermediate size %ld not a multiple of 8", (long)I);
+    int64_t total8 = T * (I / 8);
+    if (total8 == 0) return 0;
+    int64_t blocks = (total8 + 255) / 256; if (blocks > 4096) blocks = 4096;
+    silu_mul_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>((const half_t *)x, (int)I, (half_t *)out, total8);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------- K15 last-token select
+// reference: ParallelLMHead::extract_last_tokens, src/layers/embed_head.rs:272-289
+__global__ void select_last_kernel(const half_t *__restrict__ h, const int32_t *__restrict__ cu, int Hd,
+                                   half_t *__restrict__ out) {
+    const int b = blockIdx.x;
+    const int64_t row = (int64_t)cu[b + 1] - 1;
+    const half8_t *src = reinterpret_cast<const half8_t *>(h + row * Hd);
+    half8_t *dst = reinterpret_cast<half8_t *>(out + (int64_t)b * Hd);
+    for (int c = threadIdx.x; c < Hd / 8; c += blockDim.x) dst[c] = src[c];
+}
+int select_last_tokens(const half_bits *h, const int32_t *cu, int64_t B, int64_t Hd, half_bits *out, hipStream_t s) {
+    if (Hd % 8) return nvr::fail(NVR_ERR_UNSUPPORTED, "select_last: hidden size %ld not a multiple of 8", (long)Hd);
+    if (B == 0) return 0;
+    select_last_kernel<<<dim3((unsigned)B), dim3(128), 0, s>>>((const half_t *)h, cu, (int)Hd, (half_t *)out);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------- K5 + K6 RoPE + KV store
+// reference: apply_rotary_emb_single, src/layers/rotary_embedding.rs:23-48 (halves split at D/2,
+// out1 = x1*c - x2*s, out2 = x2*c + x1*s, f32 math per SURVEY A-14); store_kv_cache,
+// src/layers/attention.rs:150-174 with slot = block*bs + offset (A-6).  One workgroup per token:
+// work items are 8-wide pair chunks of the q and k heads followed by 8-wide chunks of v.
+__global__ __launch_bounds__(256) void rope_store_kernel(half_t *__restrict__ qkv, const int64_t *__restrict__ pos,
+                                                         const int32_t *__restrict__ slots, int H, int KVH, int D,
+                                                         const float *__restrict__ cos_t, const float *__restrict__ sin_t,
+                                                         half_t *__restrict__ kc, half_t *__restrict__ vc) {
+    const int t = blockIdx.x;
+    const int half_d = D / 2, cpp = half_d / 8;            // chunks per head (pairs)
+    const int n_rope = (H + KVH) * cpp, n_v = KVH * D / 8;
+    const int64_t ld = (int64_t)(H + 2 * KVH) * D;
+    half_t *row = qkv + t * ld;
+    const int64_t p = pos[t];
+    const int slot = slots ? slots[t] : -1;
+    const float *c = cos_t + p * half_d, *sn = sin_t + p * half_d;
+    for (int i = threadIdx.x; i < n_rope + n_v; i += blockDim.x) {
+        if (i < n_rope) {
+            const int head = i / cpp, j = (i % cpp) * 8;
+            half_t *x = row + head * D;
+            half8_t x1 = *reinterpret_cast<half8_t *>(x + j), x2 = *reinterpret_cast<half8_t *>(x + j + half_d);
+            half8_t o1, o2;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float a = (float)x1[e], b = (float)x2[e], cs = c[j + e], si = sn[j + e];
+                o1[e] = (half_t)__fsub_rn(__fmul_rn(a, cs), __fmul_rn(b, si));
+                o2[e] = (half_t)__fadd_rn(__fmul_rn(b, cs), __fmul_rn(a, si));
+            }
+            *reinterpret_cast<half8_t *>(x + j) = o1;
+            *reinterpret_cast<half8_t *>(x + j + half_d) = o2;
+            if (head >= H && slot >= 0) {
+                half_t *dst = kc + ((int64_t)slot * KVH + (head - H)) * D;
+                *reinterpret_cast<half8_t *>(dst + j) = o1;
+                *reinterpret_cast<half8_t *>(dst + j + half_d) = o2;
+            }
+        } else if (slot >= 0) {
+            const int e = (i - n_rope) * 8;
+            *reinterpret_cast<half8_t *>(vc + (int64_t)slot * KVH * D + e) =
+                *reinterpret_cast<const half8_t *>(row + (int64_t)(H + KVH) * D + e);
+        }
+    }
+}
+int rope_store_kv(half_bits *qkv, const int64_t *positions, const int32_t *slots, int64_t T, int64_t H, int64_t KVH,
+                  int64_t D, const float *cos_t, const float *sin_t, half_bits *k_cache, half_bits *v_cache,
+                  hipStream_t s) {
+    if (D % 16) return nvr::fail(NVR_ERR_UNSUPPORTED, "rope: head_dim %ld not a multiple of 16", (long)D);
+    if (T == 0) return 0;
+    rope_store_kernel<<<dim3((unsigned)T), dim3(256), 0, s>>>((half_t *)qkv, positions, slots, (int)H, (int)KVH, (int)D,
+                                                              cos_t, sin_t, (half_t *)k_cache, (half_t *)v_cache);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------- K17 greedy argmax
+// reference: Sampler::greedy_sample, src/layers/sampler.rs:109-112; ties -> lowest index (SURVEY A-12).
+// One 1024-thread workgroup per row; (value, index) pairs reduced through the wave then LDS.
+__device__ __forceinline__ void amax_merge(float &bv, int &bi, float v, int i) {
+    if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
+}
+__global__ __launch_bounds__(1024) void argmax_kernel(const float *__restrict__ logits, int V, int64_t *__restrict__ out_idx,
+                                                      float *__restrict__ out_val, int64_t idx_offset) {
+    const float *x = logits + (int64_t)blockIdx.x * V;
+    float bv = -INFINITY; int bi = 0x7fffffff;
+    const int V4 = ((reinterpret_cast<uintptr_t>(x) & 15) == 0) ? V / 4 : 0;
+    for (int i = threadIdx.x; i < V4; i += blockDim.x) {
+        float4_t v = *reinterpret_cast<const float4_t *>(x + 4 * i);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) amax_merge(bv, bi, v[j], 4 * i + j);
+    }
+    for (int i = V4 * 4 + threadIdx.x; i < V; i += blockDim.x) amax_merge(bv, bi, x[i], i);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        float ov = __shfl_xor(bv, o, 64); int oi = __shfl_xor(bi, o, 64);
+        amax_merge(bv, bi, ov, oi);
+    }
+    __shared__ float sv[16]; __shared__ int si[16];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) { sv[wave] = bv; si[wave] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w2 = 1; w2 < (int)(blockDim.x >> 6); ++w2) amax_merge(bv, bi, sv[w2], si[w2]);
+        out_idx[blockIdx.x] = (int64_t)bi + idx_offset;
+        if (out_val) out_val[blockIdx.x] = bv;
+    }
+}
+int argmax(const float *logits, int64_t B, int64_t V, int64_t *out_idx, float *out_val, int64_t idx_offset,
+           hipStream_t s) {
+    if (B == 0) return 0;
+    argmax_kernel<<<dim3((unsigned)B), dim3(1024), 0, s>>>(logits, (int)V, out_idx, out_val, idx_offset);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------- synthetic weights
+__global__ void fill_weight_kernel(half_t *__restrict__ dst, int64_t rows, int64_t cols, int64_t ld, int64_t gcols,
+                                   int64_t row0, int64_t col0, uint64_t key, float scale) {
+    const int64_t total = rows * cols;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / cols, c = i % cols;
+        dst[r * ld + c] = (half_t)weight_value(key, (uint64_t)((row0 + r) * gcols + (col0 + c)), scale);
+    }
+}
+int fill_weight(half_bits *dst, int64_t rows, int64_t cols, int64_t ld, int64_t global_cols, int64_t row0,
+                int64_t col0, uint64_t key, float scale, hipStream_t s) {
+    if (rows * cols == 0) return 0;
+    int64_t blocks = (rows * cols + 255) / 256; if (blocks > 8192) blocks = 8192;
+    fill_weight_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>((half_t *)dst, rows, cols, ld, global_cols, row0, col0,
+                                                                   key, scale);
+    LAUNCH_CHECK();
+    return 0;
+}
+__global__ void fill_const_kernel(half_t *__restrict__ dst, int64_t n, float v) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        dst[i] = (half_t)v;
+}
+int fill_const(half_bits *dst, int64_t n, float v, hipStream_t s) {
+    if (n == 0) return 0;
+    int64_t blocks = (n + 255) / 256; if (blocks > 4096) blocks = 4096;
+    fill_const_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>((half_t *)dst, n, v);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+}}  // namespace nvr::k

@@ -1,0 +1,55 @@
+// kernels.h — host-side launchers of the gfx950 kernels (one per kernel-shaped op site of the
+// hot path).  All functions enqueue on `stream` and return a hipError_t-like int
+// (0 = ok, NVR_ERR_UNSUPPORTED for shapes outside the kernels' contract).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace nvr { namespace k {
+
+typedef uint16_t half_bits;
+
+int embedding(const int64_t *ids, int64_t T, const half_bits *E, int64_t Hd, half_bits *out, hipStream_t s);
+int rmsnorm(const half_bits *x, const half_bits *w, float eps, int64_t T, int64_t Hd, half_bits *out, hipStream_t s);
+int add_rmsnorm(half_bits *h, const half_bits *y, const half_bits *w, float eps, int64_t T, int64_t Hd,
+                half_bits *out, hipStream_t s);
+int silu_and_mul(const half_bits *x, int64_t T, int64_t I, half_bits *out, hipStream_t s);
+int select_last_tokens(const half_bits *h, const int32_t *cu, int64_t B, int64_t Hd, half_bits *out, hipStream_t s);
+int rope_store_kv(half_bits *qkv, const int64_t *positions, const int32_t *slots, int64_t T, int64_t H, int64_t KVH,
+                  int64_t D, const float *cos_t, const float *sin_t, half_bits *k_cache, half_bits *v_cache,
+                  hipStream_t s);
+// argmax over f32 rows; out_val (nullable) receives the row maxima, idx_offset is added to indices
+int argmax(const float *logits, int64_t B, int64_t V, int64_t *out_idx, float *out_val, int64_t idx_offset,
+           hipStream_t s);
+int fill_weight(half_bits *dst, int64_t rows, int64_t cols, int64_t ld, int64_t global_cols, int64_t row0,
+                int64_t col0, uint64_t key, float scale, hipStream_t s);
+int fill_const(half_bits *dst, int64_t n, float v, hipStream_t s);
+
+// y[T,N] = x[T,K] (row stride ldx) · W[N,K]^T, f32 accumulate on MFMA; y fp16 or f32
+int linear(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t N, void *y,
+           bool y_f32, hipStream_t s);
+
+// Attention over rows of keys addressed either through a block table (paged) or contiguously.
+struct AttnArgs {
+    const half_bits *q; int64_t ldq;          // q[t] at q + t*ldq, heads contiguous [H, D]
+    const half_bits *k, *v;                    // paged: caches [NB, bs, KVH, D]; contiguous: rows with stride ldkv
+    int64_t ldkv;                              // contiguous only
+    const int32_t *ctx_lens;                   // [nq] keys visible to query t
+    const int32_t *seq_of_q;                   // paged: [nq] row of block_tables (nullptr = identity)
+    const int32_t *kv_base;                    // contiguous: [nq] first key row of query t
+    const int32_t *block_tables; int32_t max_blocks; int32_t block_size;
+    int32_t nq, H, KVH, D;
+    float scale;
+    int32_t max_ctx;                           // upper bound of ctx_lens (grid sizing)
+    half_bits *out;                            // [nq, H, D] fp16
+    void *workspace;                           // split-KV partials (paged decode)
+};
+size_t attn_workspace_bytes(int64_t nq, int64_t H, int64_t D, int64_t max_ctx);
+int attention(const AttnArgs &a, bool paged, hipStream_t s);
+
+// sampler (top-k / top-p / gumbel)
+size_t sample_workspace_bytes(int64_t B, int64_t V);
+int sample(const float *logits, int64_t B, int64_t V, const float *temperature, const int64_t *top_k,
+           const float *top_p, const uint64_t *keys, int64_t *out_ids, void *workspace, hipStream_t s);
+
+}}  // namespace nvr::k

@@ -1,0 +1,327 @@
+// model_runner.cpp — see model_runner.h.  Line cites: reference src/engine/model_runner.rs unless
+// another file is named.
+#include "model_runner.h"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include "common.h"
+#include "kernels/kernels.h"
+#include "kernels/device_utils.h"
+
+namespace k = nvr::k;
+
+// tensor ids of the synthetic weight generator (twin of oracle/model_oracle.py)
+enum { TID_QKV = 0, TID_O = 1, TID_GATE_UP = 2, TID_DOWN = 3 };
+static const uint64_t TID_EMBED = 1ull << 20, TID_LM_HEAD = (1ull << 20) + 1;
+
+uint64_t nvr_weight_key_impl(uint64_t seed, uint64_t tid) {
+    return nvr::splitmix64(nvr::splitmix64(seed) + tid * 0xD1B54A32D192ED03ULL);
+}
+float nvr_weight_scale_impl(double std) {
+    return (float)(std / std::sqrt(4.0 * (65536.0 * 65536.0 - 1.0) / 12.0));
+}
+
+#define RC(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
+
+template <class T>
+static int dmalloc(T **p, size_t count) {
+    NVR_HIP_CHECK(hipMalloc((void **)p, count * sizeof(T) > 0 ? count * sizeof(T) : 16));
+    return NVR_OK;
+}
+
+nvr_model_runner::~nvr_model_runner() {
+    if (stream) hipStreamSynchronize(stream);
+    for (auto &g : graphs) hipGraphExecDestroy(g.second);
+    comm.destroy();
+    for (auto &l : layers) { hipFree(l.qkv); hipFree(l.o); hipFree(l.gate_up); hipFree(l.down); hipFree(l.ln1); hipFree(l.ln2); }
+    void *ptrs[] = {embed, mc.tie_word_embeddings ? nullptr : lm_head, norm, cos_t, sin_t, kv_pool, h, n, qkv, attn,
+                    proj, gu, act, nlast, logits, attn_ws, in_dev, d_tok, d_maxval, d_temp, d_topk, d_topp, d_keys,
+                    sample_ws, d_gather_val, d_gather_idx};
+    for (void *p : ptrs) if (p) hipFree(p);
+    if (in_host) hipHostFree(in_host);
+    if (h_tok) hipHostFree(h_tok);
+    if (samp_host) hipHostFree(samp_host);
+    if (stream) hipStreamDestroy(stream);
+}
+
+int nvr_model_runner::init() {                                       // ModelRunner::new, :67-102
+    tp = (int64_t)cfg.tensor_parallel_size; rank = (int64_t)cfg.tensor_parallel_rank;
+    if (tp < 1 || rank >= tp) return nvr::fail(NVR_ERR_INVALID_ARG, "bad tensor parallel rank %ld of %ld", (long)rank, (long)tp);
+    RC(nvr_model_config_validate(&mc, (uint64_t)tp));
+    Hd = mc.hidden_size; L = mc.num_hidden_layers; V = mc.vocab_size;
+    D = mc.head_dim ? mc.head_dim : mc.hidden_size / mc.num_attention_heads;     // qwen3.rs:101-103 (+A-17)
+    H = mc.num_attention_heads / tp; KVH = mc.num_key_value_heads / tp;           // qwen3.rs:158-159
+    I = mc.intermediate_size / tp;
+    QKV = (H + 2 * KVH) * D;
+    Vl = V / tp; vocab_start = rank * Vl; if (rank == tp - 1) Vl = V - vocab_start;   // embed_head.rs:57-59
+    scale = 1.0f / std::sqrt((float)D);                                           // attention.rs:45
+    block_size = cfg.kvcache_block_size;
+    max_tokens = cfg.max_num_batched_tokens; max_seqs = cfg.max_num_seqs;
+    max_pos = std::min<int64_t>(mc.max_position_embeddings, std::max<int64_t>(cfg.max_model_len, 1));
+    max_blocks_per_seq = (max_pos + block_size - 1) / block_size + 1;
+
+    device = cfg.device_ordinal;
+    NVR_HIP_CHECK(hipSetDevice(device));
+    NVR_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+
+    RC(gen_weights());
+
+    // RoPE tables (rotary_embedding.rs:74-119, A-14): computed on the host in f64 from the f32 angle,
+    // so the oracle (same libm, same box) holds bit-identical tables.
+    {
+        const int64_t half = D / 2;
+        std::vector<float> c(max_pos * half), sn(max_pos * half);
+        for (int64_t p = 0; p < max_pos; ++p)
+            for (int64_t j = 0; j < half; ++j) {
+                float inv = (float)(1.0 / std::pow(mc.rope_theta, (double)(2 * j) / (double)D));
+                float ang = (float)p * inv;
+                c[p * half + j] = (float)std::cos((double)ang);
+                sn[p * half + j] = (float)std::sin((double)ang);
+            }
+        RC(dmalloc(&cos_t, c.size())); RC(dmalloc(&sin_t, sn.size()));
+        NVR_HIP_CHECK(hipMemcpy(cos_t, c.data(), c.size() * 4, hipMemcpyHostToDevice));
+        NVR_HIP_CHECK(hipMemcpy(sin_t, sn.data(), sn.size() * 4, hipMemcpyHostToDevice));
+    }
+
+    // activations (persistent: graph-replayable, no allocation on the step path)
+    RC(dmalloc(&h, max_tokens * Hd)); RC(dmalloc(&n, max_tokens * Hd)); RC(dmalloc(&qkv, max_tokens * QKV));
+    RC(dmalloc(&attn, max_tokens * H * D)); RC(dmalloc(&proj, max_tokens * Hd)); RC(dmalloc(&gu, max_tokens * 2 * I));
+    RC(dmalloc(&act, max_tokens * I)); RC(dmalloc(&nlast, max_seqs * Hd)); RC(dmalloc(&logits, max_seqs * Vl));
+    attn_ws_bytes = k::attn_workspace_bytes(max_seqs, H, D, max_pos);
+    NVR_HIP_CHECK(hipMalloc(&attn_ws, attn_ws_bytes));
+
+    // step-input arena
+    auto carve = [&](size_t &off, size_t bytes) { off = in_bytes; in_bytes += (bytes + 255) / 256 * 256; };
+    carve(off_ids, max_tokens * 8); carve(off_pos, max_tokens * 8); carve(off_slots, max_tokens * 4);
+    carve(off_cu, (max_seqs + 1) * 4); carve(off_ctx, std::max(max_tokens, max_seqs) * 4);
+    carve(off_kvbase, max_tokens * 4); carve(off_bt, max_seqs * max_blocks_per_seq * 4);
+    NVR_HIP_CHECK(hipHostMalloc((void **)&in_host, in_bytes, hipHostMallocDefault));
+    NVR_HIP_CHECK(hipMalloc((void **)&in_dev, in_bytes));
+    d_ids = (int64_t *)(in_dev + off_ids); d_pos = (int64_t *)(in_dev + off_pos); d_slots = (int32_t *)(in_dev + off_slots);
+    d_cu = (int32_t *)(in_dev + off_cu); d_ctx = (int32_t *)(in_dev + off_ctx); d_kvbase = (int32_t *)(in_dev + off_kvbase);
+    d_bt = (int32_t *)(in_dev + off_bt);
+
+    RC(dmalloc(&d_tok, max_seqs)); RC(dmalloc(&d_maxval, max_seqs));
+    NVR_HIP_CHECK(hipHostMalloc((void **)&h_tok, max_seqs * 8, hipHostMallocDefault));
+    RC(dmalloc(&d_temp, max_seqs)); RC(dmalloc(&d_topk, max_seqs)); RC(dmalloc(&d_topp, max_seqs)); RC(dmalloc(&d_keys, max_seqs));
+    NVR_HIP_CHECK(hipHostMalloc((void **)&samp_host, max_seqs * 24, hipHostMallocDefault));
+    NVR_HIP_CHECK(hipMalloc(&sample_ws, k::sample_workspace_bytes(max_seqs, Vl)));
+    if (tp > 1) { RC(dmalloc(&d_gather_val, tp * max_seqs)); RC(dmalloc(&d_gather_idx, tp * max_seqs)); }
+
+    // KV pool (create_kv_cache, :364-396): [NB, bs, KVH/tp, D] per layer per K/V, one allocation.
+    const size_t block_elems = (size_t)block_size * KVH * D;
+    if (cfg.num_kvcache_blocks >= 0) num_blocks = cfg.num_kvcache_blocks;
+    else if (cfg.num_kvcache_blocks == -1) num_blocks = 1000;                     // :85 unwrap_or(1000)
+    else {
+        // size from free HBM (the reference has the config field, config.rs:30, but no sizing code)
+        size_t free_b = 0, total_b = 0;
+        NVR_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+        double budget = (double)free_b - (1.0 - cfg.gpu_memory_utilization) * (double)total_b;
+        int64_t nb = (int64_t)(budget / (double)(block_elems * 2 * 2 * L));
+        if (nb < 1) return nvr::fail(NVR_ERR_HIP, "not enough free HBM for one KV block");
+        num_blocks = nb;
+    }
+    kv_layer_elems = (size_t)num_blocks * block_elems;
+    NVR_HIP_CHECK(hipMalloc((void **)&kv_pool, kv_layer_elems * 2 * L * sizeof(uint16_t)));
+    NVR_HIP_CHECK(hipMemsetAsync(kv_pool, 0, kv_layer_elems * 2 * L * sizeof(uint16_t), stream));   // Tensor::zeros :379-389
+    NVR_HIP_CHECK(hipStreamSynchronize(stream));
+    return NVR_OK;
+}
+
+int nvr_model_runner::gen_weights() {
+    const float sc = nvr_weight_scale_impl(mc.init_std);
+    const int64_t Hg = mc.num_attention_heads, KVHg = mc.num_key_value_heads, Ig = mc.intermediate_size;
+    layers.resize(L);
+    for (int64_t l = 0; l < L; ++l) {
+        Layer &w = layers[l];
+        auto key = [&](uint64_t tid) { return nvr_weight_key_impl(mc.seed, (uint64_t)l * 8 + tid); };
+        RC(dmalloc(&w.qkv, QKV * Hd)); RC(dmalloc(&w.o, Hd * H * D)); RC(dmalloc(&w.gate_up, 2 * I * Hd));
+        RC(dmalloc(&w.down, Hd * I)); RC(dmalloc(&w.ln1, Hd)); RC(dmalloc(&w.ln2, Hd));
+        // QKVParallelLinear, linear.rs:300-340: global rows [q heads | k heads | v heads], per-rank head slices
+        RC(k::fill_weight(w.qkv, H * D, Hd, Hd, Hd, rank * H * D, 0, key(TID_QKV), sc, stream));
+        RC(k::fill_weight(w.qkv + H * D * Hd, KVH * D, Hd, Hd, Hd, Hg * D + rank * KVH * D, 0, key(TID_QKV), sc, stream));
+        RC(k::fill_weight(w.qkv + (H + KVH) * D * Hd, KVH * D, Hd, Hd, Hd, (Hg + KVHg) * D + rank * KVH * D, 0, key(TID_QKV), sc, stream));
+        // RowParallelLinear o_proj, linear.rs:180-268: global [Hd, H*D], input columns sharded
+        RC(k::fill_weight(w.o, Hd, H * D, H * D, Hg * D, 0, rank * H * D, key(TID_O), sc, stream));
+        // MergedColumnParallelLinear, linear.rs:378-454: global rows [gate | up], each sharded
+        RC(k::fill_weight(w.gate_up, I, Hd, Hd, Hd, rank * I, 0, key(TID_GATE_UP), sc, stream));
+        RC(k::fill_weight(w.gate_up + I * Hd, I, Hd, Hd, Hd, Ig + rank * I, 0, key(TID_GATE_UP), sc, stream));
+        RC(k::fill_weight(w.down, Hd, I, I, Ig, 0, rank * I, key(TID_DOWN), sc, stream));
+        RC(k::fill_const(w.ln1, Hd, 1.0f, stream)); RC(k::fill_const(w.ln2, Hd, 1.0f, stream));   // layernorm.rs:29
+    }
+    // embedding replicated (SURVEY §8e skips C2); LM head vocab-sharded, tied when tie_word_embeddings (qwen3.rs:461-473)
+    RC(dmalloc(&embed, V * Hd));
+    RC(k::fill_weight(embed, V, Hd, Hd, Hd, 0, 0, nvr_weight_key_impl(mc.seed, TID_EMBED), sc, stream));
+    if (mc.tie_word_embeddings) lm_head = embed + vocab_start * Hd;
+    else {
+        RC(dmalloc(&lm_head, Vl * Hd));
+        RC(k::fill_weight(lm_head, Vl, Hd, Hd, Hd, vocab_start, 0, nvr_weight_key_impl(mc.seed, TID_LM_HEAD), sc, stream));
+    }
+    RC(dmalloc(&norm, Hd)); RC(k::fill_const(norm, Hd, 1.0f, stream));
+    NVR_HIP_CHECK(hipStreamSynchronize(stream));
+    return NVR_OK;
+}
+
+// Qwen3Model::forward, src/models/qwen3.rs:487-505; layer wiring :372-392; attention :208-240; MLP :305-314
+int nvr_model_runner::forward(int64_t T, int64_t B, bool is_prefill, int64_t max_ctx) {
+    RC(k::embedding(d_ids, T, embed, Hd, h, stream));
+    for (int64_t l = 0; l < L; ++l) {
+        const Layer &w = layers[l];
+        if (l == 0) RC(k::rmsnorm(h, w.ln1, mc.rms_norm_eps, T, Hd, n, stream));
+        else RC(k::add_rmsnorm(h, proj, w.ln1, mc.rms_norm_eps, T, Hd, n, stream));          // residual :389 + norm :378
+        RC(k::linear(n, Hd, w.qkv, T, Hd, QKV, qkv, false, stream));
+        RC(k::rope_store_kv(qkv, d_pos, d_slots, T, H, KVH, D, cos_t, sin_t, k_cache(l), v_cache(l), stream));
+        k::AttnArgs a{};
+        a.q = qkv; a.ldq = QKV; a.ctx_lens = d_ctx; a.nq = (int32_t)T; a.H = (int32_t)H; a.KVH = (int32_t)KVH; a.D = (int32_t)D;
+        a.scale = scale; a.max_ctx = (int32_t)max_ctx; a.out = attn;
+        if (is_prefill) {                                            // flash_attention_varlen, attention.rs:177-208
+            a.k = qkv + H * D; a.v = qkv + (H + KVH) * D; a.ldkv = QKV; a.kv_base = d_kvbase; a.workspace = nullptr;
+            RC(k::attention(a, false, stream));
+        } else {                                                     // flash_attention_decode, attention.rs:225-235
+            a.k = k_cache(l); a.v = v_cache(l); a.block_tables = d_bt; a.max_blocks = (int32_t)max_blocks_per_seq;
+            a.block_size = (int32_t)block_size; a.workspace = attn_ws;
+            RC(k::attention(a, true, stream));
+        }
+        RC(k::linear(attn, H * D, w.o, T, H * D, Hd, proj, false, stream));
+        if (comm.active()) RC(comm.all_reduce_sum_f16(proj, (size_t)(T * Hd), stream));     // linear.rs:236-238
+        RC(k::add_rmsnorm(h, proj, w.ln2, mc.rms_norm_eps, T, Hd, n, stream));               // residual :382 + norm :385
+        RC(k::linear(n, Hd, w.gate_up, T, Hd, 2 * I, gu, false, stream));
+        RC(k::silu_and_mul(gu, T, I, act, stream));
+        RC(k::linear(act, I, w.down, T, I, Hd, proj, false, stream));
+        if (comm.active()) RC(comm.all_reduce_sum_f16(proj, (size_t)(T * Hd), stream));
+    }
+    RC(k::add_rmsnorm(h, proj, norm, mc.rms_norm_eps, T, Hd, n, stream));                    // final residual + norm :501
+    const uint16_t *hl = n;
+    if (is_prefill) { RC(k::select_last_tokens(n, d_cu, B, Hd, nlast, stream)); hl = nlast; }   // embed_head.rs:272-289
+    RC(k::linear(hl, Hd, lm_head, B, Hd, Vl, logits, true, stream));                          // f32 logits (A-21)
+    return NVR_OK;
+}
+
+// execute_model :105-128 with prepare_*_inputs :172-210 and create_*_context :222-300
+int nvr_model_runner::execute(nvr_seq *const *seqs, size_t nseq, bool is_prefill) {
+    NVR_HIP_CHECK(hipSetDevice(device));
+    if (nseq == 0) return nvr::fail(NVR_ERR_INVALID_ARG, "execute_model: empty batch");
+    if ((int64_t)nseq > max_seqs) return nvr::fail(NVR_ERR_INVALID_ARG, "execute_model: %zu sequences > max_num_seqs %ld", nseq, (long)max_seqs);
+    int64_t *ids = (int64_t *)(in_host + off_ids), *pos = (int64_t *)(in_host + off_pos);
+    int32_t *slots = (int32_t *)(in_host + off_slots), *cu = (int32_t *)(in_host + off_cu), *ctx = (int32_t *)(in_host + off_ctx),
+            *kvb = (int32_t *)(in_host + off_kvbase), *bt = (int32_t *)(in_host + off_bt);
+    int64_t T = 0, max_ctx = 0;
+    const int64_t bs = block_size;
+    NVR_HIP_CHECK(hipStreamSynchronize(stream));   // staging arena is reused: previous uploads must have landed
+    if (is_prefill) {
+        // all tokens from position 0 (A-7), slot(pos) = table[pos/bs]*bs + pos%bs (A-6)
+        int64_t total = 0;
+        for (size_t b = 0; b < nseq; ++b) total += (int64_t)seqs[b]->len();
+        if (total > max_tokens) return nvr::fail(NVR_ERR_INVALID_ARG, "prefill of %ld tokens exceeds max_num_batched_tokens %ld", (long)total, (long)max_tokens);
+        cu[0] = 0;
+        for (size_t b = 0; b < nseq; ++b) {
+            const nvr_seq &s = *seqs[b];
+            const int64_t len = (int64_t)s.len();
+            if (len > max_pos) return nvr::fail(NVR_ERR_INVALID_ARG, "sequence of %ld tokens exceeds max_model_len %ld", (long)len, (long)max_pos);
+            if ((int64_t)s.block_table.size() * bs < len) return nvr::fail(NVR_ERR_NOT_ALLOCATED, "Sequence has no allocated blocks");
+            for (int64_t p = 0; p < len; ++p) {
+                ids[T] = s.token_ids[p]; pos[T] = p;
+                slots[T] = (int32_t)((int64_t)s.block_table[p / bs] * bs + p % bs);
+                ctx[T] = (int32_t)(p + 1); kvb[T] = cu[b];
+                ++T;
+            }
+            cu[b + 1] = (int32_t)T;
+            max_ctx = std::max(max_ctx, len);
+        }
+    } else {
+        for (size_t b = 0; b < nseq; ++b) {
+            const nvr_seq &s = *seqs[b];
+            const int64_t len = (int64_t)s.len();
+            if (len > max_pos) return nvr::fail(NVR_ERR_INVALID_ARG, "sequence of %ld tokens exceeds max_model_len %ld", (long)len, (long)max_pos);
+            if ((int64_t)s.block_table.size() * bs < len) return nvr::fail(NVR_ERR_NOT_ALLOCATED, "Sequence has no allocated blocks");
+            ids[b] = s.last_token; pos[b] = len - 1;                                      // :201-202
+            slots[b] = (int32_t)((int64_t)s.block_table[(len - 1) / bs] * bs + (len - 1) % bs);
+            ctx[b] = (int32_t)len;                                                        // :275
+            int32_t *row = bt + b * max_blocks_per_seq;                                   // -1 padded, :283-290
+            const size_t nb = s.block_table.size();
+            std::memcpy(row, s.block_table.data(), nb * 4);
+            for (int64_t j = (int64_t)nb; j < max_blocks_per_seq; ++j) row[j] = -1;
+            max_ctx = std::max(max_ctx, len);
+        }
+        T = (int64_t)nseq;
+    }
+    // one H2D per array actually used this step (K19)
+    auto up = [&](size_t off, size_t bytes) { return hipMemcpyAsync(in_dev + off, in_host + off, bytes, hipMemcpyHostToDevice, stream); };
+    NVR_HIP_CHECK(up(off_ids, T * 8)); NVR_HIP_CHECK(up(off_pos, T * 8)); NVR_HIP_CHECK(up(off_slots, T * 4));
+    NVR_HIP_CHECK(up(off_ctx, T * 4));
+    if (is_prefill) { NVR_HIP_CHECK(up(off_cu, (nseq + 1) * 4)); NVR_HIP_CHECK(up(off_kvbase, T * 4)); }
+    else NVR_HIP_CHECK(up(off_bt, nseq * max_blocks_per_seq * 4));
+
+    last_rows = nseq; last_prefill = is_prefill;
+    if (is_prefill || cfg.enforce_eager) return forward(T, (int64_t)nseq, is_prefill, max_ctx);
+
+    // decode: replay a hipGraph captured per (batch size, context bucket) — execute_with_cuda_graph :303-326
+    const int64_t bucket = (max_ctx + 255) / 256 * 256;
+    const uint64_t key = ((uint64_t)nseq << 32) | (uint64_t)bucket;
+    auto it = graphs.find(key);
+    if (it == graphs.end()) {
+        hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr;
+        NVR_HIP_CHECK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+        int rc = forward(T, (int64_t)nseq, false, bucket);
+        hipError_t e = hipStreamEndCapture(stream, &g);
+        if (rc) { if (g) hipGraphDestroy(g); return rc; }
+        if (e != hipSuccess) return nvr::fail(NVR_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
+        NVR_HIP_CHECK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+        hipGraphDestroy(g);
+        it = graphs.emplace(key, ge).first;
+    }
+    NVR_HIP_CHECK(hipGraphLaunch(it->second, stream));
+    return NVR_OK;
+}
+
+// sample_tokens :131-156 -> Sampler::batch_sample, src/layers/sampler.rs:221-254
+int nvr_model_runner::sample(nvr_seq *const *seqs, size_t nseq, int64_t *out) {
+    NVR_HIP_CHECK(hipSetDevice(device));
+    if (nseq != last_rows) return nvr::fail(NVR_ERR_LEN_MISMATCH, "sample_tokens: %zu sequences but logits hold %zu rows", nseq, last_rows);
+    bool all_greedy = true;
+    for (size_t i = 0; i < nseq; ++i) all_greedy &= (seqs[i]->sampling.temperature == 0.0f);
+    const int64_t B = (int64_t)nseq;
+    if (all_greedy) {
+        if (!comm.active()) {
+            RC(k::argmax(logits, B, Vl, d_tok, nullptr, 0, stream));
+        } else {
+            // vocab-sharded greedy (embed_head.rs:321-336): all-gather (max, argmax) pairs, then lowest index wins
+            RC(k::argmax(logits, B, Vl, d_tok, d_maxval, vocab_start, stream));
+            RC(comm.all_gather_bytes(d_maxval, d_gather_val, (size_t)B * 4, stream));
+            RC(comm.all_gather_bytes(d_tok, d_gather_idx, (size_t)B * 8, stream));
+            std::vector<float> gv(tp * B); std::vector<int64_t> gi(tp * B);
+            NVR_HIP_CHECK(hipMemcpyAsync(gv.data(), d_gather_val, gv.size() * 4, hipMemcpyDeviceToHost, stream));
+            NVR_HIP_CHECK(hipMemcpyAsync(gi.data(), d_gather_idx, gi.size() * 8, hipMemcpyDeviceToHost, stream));
+            NVR_HIP_CHECK(hipStreamSynchronize(stream));
+            for (int64_t b = 0; b < B; ++b) {
+                float bv = gv[b]; int64_t bi = gi[b];
+                for (int64_t r = 1; r < tp; ++r) {
+                    float v = gv[r * B + b]; int64_t i = gi[r * B + b];
+                    if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
+                }
+                out[b] = bi;
+            }
+            return NVR_OK;
+        }
+    } else {
+        if (comm.active()) return nvr::fail(NVR_ERR_UNSUPPORTED, "stochastic sampling with tensor_parallel_size>1 is not implemented yet");
+        float *t = (float *)samp_host; int64_t *tk = (int64_t *)(samp_host + max_seqs * 4);
+        float *tpv = (float *)(samp_host + max_seqs * 12); uint64_t *ky = (uint64_t *)(samp_host + max_seqs * 16);
+        for (size_t i = 0; i < nseq; ++i) {
+            const nvr_sampling_params &sp = seqs[i]->sampling;
+            t[i] = sp.temperature;
+            tk[i] = sp.has_top_k ? (int64_t)sp.top_k : 0;                                   // A-18
+            tpv[i] = sp.has_top_p ? sp.top_p : -1.0f;
+            ky[i] = nvr_sample_key(cfg.sample_seed, seqs[i]->seq_id, seqs[i]->num_completion_tokens());   // A-20
+        }
+        NVR_HIP_CHECK(hipMemcpyAsync(d_temp, t, B * 4, hipMemcpyHostToDevice, stream));
+        NVR_HIP_CHECK(hipMemcpyAsync(d_topk, tk, B * 8, hipMemcpyHostToDevice, stream));
+        NVR_HIP_CHECK(hipMemcpyAsync(d_topp, tpv, B * 4, hipMemcpyHostToDevice, stream));
+        NVR_HIP_CHECK(hipMemcpyAsync(d_keys, ky, B * 8, hipMemcpyHostToDevice, stream));
+        RC(k::sample(logits, B, Vl, d_temp, d_topk, d_topp, d_keys, d_tok, sample_ws, stream));
+    }
+    NVR_HIP_CHECK(hipMemcpyAsync(h_tok, d_tok, B * 8, hipMemcpyDeviceToHost, stream));      // to_vec1 :152
+    NVR_HIP_CHECK(hipStreamSynchronize(stream));
+    std::memcpy(out, h_tok, B * 8);
+    return NVR_OK;
+}

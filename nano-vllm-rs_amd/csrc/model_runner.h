@@ -1,0 +1,63 @@
+// model_runner.h — step execution on one MI355X (mirrors ModelRunner, reference
+// src/engine/model_runner.rs:19-464, and the Qwen3 graph it drives, src/models/qwen3.rs:208-505).
+//
+// Owns: fp16 weights (synthetic), the KV pool [L][K|V][NB, bs, KVH/tp, D] in one HBM
+// allocation (model_runner.rs:364-396), persistent activation workspaces, pinned step-input staging
+// and their fixed device twins (so a decode step is graph-replayable), and the hipGraph cache keyed
+// by (batch size, context bucket) that replaces the reference's stub (model_runner.rs:303-361).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <map>
+#include <vector>
+#include "sequence.h"
+#include "comm.h"
+
+struct nvr_model_runner {
+    nvr_config cfg{};
+    nvr_model_config mc{};
+    // derived, per rank (qwen3.rs:158-159, linear.rs:300-304)
+    int64_t tp = 1, rank = 0;
+    int64_t Hd = 0, H = 0, KVH = 0, D = 0, I = 0, V = 0, Vl = 0, vocab_start = 0, L = 0, QKV = 0;
+    int64_t block_size = 256, num_blocks = 0, max_tokens = 0, max_seqs = 0, max_blocks_per_seq = 0, max_pos = 0;
+    float scale = 1.f;
+    int device = 0;
+    hipStream_t stream = nullptr;
+
+    struct Layer { uint16_t *qkv, *o, *gate_up, *down, *ln1, *ln2; };
+    std::vector<Layer> layers;
+    uint16_t *embed = nullptr, *lm_head = nullptr, *norm = nullptr;
+    float *cos_t = nullptr, *sin_t = nullptr;
+    uint16_t *kv_pool = nullptr;
+    size_t kv_layer_elems = 0;             // elements of one K (or V) cache of one layer
+
+    // activations
+    uint16_t *h = nullptr, *n = nullptr, *qkv = nullptr, *attn = nullptr, *proj = nullptr, *gu = nullptr, *act = nullptr,
+             *nlast = nullptr;
+    float *logits = nullptr; void *attn_ws = nullptr; size_t attn_ws_bytes = 0;
+    // step inputs: one pinned host arena mirrored by one device arena
+    char *in_host = nullptr, *in_dev = nullptr; size_t in_bytes = 0;
+    int64_t *d_ids = nullptr, *d_pos = nullptr; int32_t *d_slots = nullptr, *d_cu = nullptr, *d_ctx = nullptr,
+            *d_kvbase = nullptr, *d_bt = nullptr;
+    size_t off_ids = 0, off_pos = 0, off_slots = 0, off_cu = 0, off_ctx = 0, off_kvbase = 0, off_bt = 0;
+    // sampling
+    int64_t *d_tok = nullptr, *h_tok = nullptr; float *d_maxval = nullptr;
+    float *d_temp = nullptr; int64_t *d_topk = nullptr; float *d_topp = nullptr; uint64_t *d_keys = nullptr;
+    char *samp_host = nullptr; void *sample_ws = nullptr;
+    // TP exchange buffers for the greedy (max, idx) merge
+    float *d_gather_val = nullptr; int64_t *d_gather_idx = nullptr;
+
+    std::map<uint64_t, hipGraphExec_t> graphs;
+    size_t last_rows = 0; bool last_prefill = false;
+    nvr::Comm comm;
+
+    ~nvr_model_runner();
+    int init();
+    int execute(nvr_seq *const *seqs, size_t nseq, bool is_prefill);
+    int sample(nvr_seq *const *seqs, size_t nseq, int64_t *out);
+    uint16_t *k_cache(size_t l) { return kv_pool + (2 * l) * kv_layer_elems; }
+    uint16_t *v_cache(size_t l) { return kv_pool + (2 * l + 1) * kv_layer_elems; }
+
+private:
+    int forward(int64_t T, int64_t B, bool is_prefill, int64_t max_ctx);
+    int gen_weights();
+};

@@ -1,0 +1,367 @@
+// nvr_api.cpp — the extern "C" boundary declared in include/nvr.h.  Thin: argument checks, handle
+// unwrapping, status codes; no logic of its own.  Nothing throws across the ABI.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstring>
+#include <new>
+#include "common.h"
+#include "engine.h"
+#include "kernels/kernels.h"
+#include "kernels/device_utils.h"
+
+namespace k = nvr::k;
+uint64_t nvr_weight_key_impl(uint64_t seed, uint64_t tid);
+float nvr_weight_scale_impl(double std);
+
+#define NVR_GUARD_BEGIN try {
+#define NVR_GUARD_END(ret)                                                                  \
+    } catch (const std::bad_alloc &) { nvr::fail(NVR_ERR_INVARIANT, "out of host memory"); return ret; } \
+      catch (const std::exception &e) { nvr::fail(NVR_ERR_INVARIANT, "%s", e.what()); return ret; }       \
+      catch (...) { nvr::fail(NVR_ERR_INVARIANT, "unknown exception"); return ret; }
+
+extern "C" {
+
+const char *nvr_last_error(void) { return nvr::last_error_slot().c_str(); }
+const char *nvr_version(void) { return "nano-vllm-rs_amd 0.1 (gfx950)"; }
+
+// ------------------------------------------------------------------ params / config
+void nvr_sampling_params_default(nvr_sampling_params *sp) {          // sampling_params.rs:30-41
+    std::memset(sp, 0, sizeof *sp);
+    sp->temperature = 1.0f; sp->max_tokens = 64;
+}
+int nvr_sampling_params_validate(const nvr_sampling_params *sp) {    // sampling_params.rs:91-119
+    if (sp->temperature < 0.0f) return nvr::fail(NVR_ERR_INVALID_ARG, "Temperature must be non-negative, got %g", sp->temperature);
+    if (sp->max_tokens == 0) return nvr::fail(NVR_ERR_INVALID_ARG, "Max tokens must be positive, got 0");
+    if (sp->has_top_p && !(sp->top_p >= 0.0f && sp->top_p <= 1.0f)) return nvr::fail(NVR_ERR_INVALID_ARG, "Top-p must be between 0.0 and 1.0, got %g", sp->top_p);
+    if (sp->has_top_k && sp->top_k == 0) return nvr::fail(NVR_ERR_INVALID_ARG, "Top-k must be positive, got 0");
+    if (sp->has_repetition_penalty && !(sp->repetition_penalty > 0.0f)) return nvr::fail(NVR_ERR_INVALID_ARG, "Repetition penalty must be positive, got %g", sp->repetition_penalty);
+    return NVR_OK;
+}
+void nvr_config_default(nvr_config *c) {                             // config.rs:54-71
+    std::memset(c, 0, sizeof *c);
+    c->max_num_batched_tokens = 32768; c->max_num_seqs = 512; c->max_model_len = 4096;
+    c->gpu_memory_utilization = 0.9f; c->tensor_parallel_size = 1; c->enforce_eager = 0;
+    c->has_eos = 0; c->kvcache_block_size = 256; c->num_kvcache_blocks = -1;
+}
+int nvr_config_validate(const nvr_config *c) {                       // config.rs:83-119 (model_path checks n/a)
+    if (!c->skip_block_size_check && c->kvcache_block_size % 256 != 0)
+        return nvr::fail(NVR_ERR_INVALID_ARG, "KV cache block size must be a multiple of 256, got %lu", (unsigned long)c->kvcache_block_size);
+    if (c->kvcache_block_size == 0) return nvr::fail(NVR_ERR_INVALID_ARG, "Block size must be positive");
+    if (c->tensor_parallel_size < 1 || c->tensor_parallel_size > 8)
+        return nvr::fail(NVR_ERR_INVALID_ARG, "Tensor parallel size must be between 1 and 8, got %lu", (unsigned long)c->tensor_parallel_size);
+    if (!(c->gpu_memory_utilization >= 0.0f && c->gpu_memory_utilization <= 1.0f))
+        return nvr::fail(NVR_ERR_INVALID_ARG, "GPU memory utilization must be between 0.0 and 1.0, got %g", c->gpu_memory_utilization);
+    return NVR_OK;
+}
+void nvr_model_config_default(nvr_model_config *m) {                 // qwen3.rs:70-89
+    std::memset(m, 0, sizeof *m);
+    m->vocab_size = 151936; m->hidden_size = 4096; m->intermediate_size = 11008; m->num_hidden_layers = 32;
+    m->num_attention_heads = 32; m->num_key_value_heads = 32; m->head_dim = 0; m->max_position_embeddings = 32768;
+    m->rms_norm_eps = 1e-6f; m->rope_theta = 10000.0; m->tie_word_embeddings = 0; m->init_std = 0.02f; m->seed = 0;
+}
+void nvr_model_config_qwen3_0_6b(nvr_model_config *m) {
+    nvr_model_config_default(m);
+    m->hidden_size = 1024; m->intermediate_size = 3072; m->num_hidden_layers = 28; m->num_attention_heads = 16;
+    m->num_key_value_heads = 8; m->head_dim = 128; m->rope_theta = 1e6; m->tie_word_embeddings = 1;
+}
+void nvr_model_config_qwen3_8b(nvr_model_config *m) {
+    nvr_model_config_default(m);
+    m->hidden_size = 4096; m->intermediate_size = 12288; m->num_hidden_layers = 36; m->num_attention_heads = 32;
+    m->num_key_value_heads = 8; m->head_dim = 128; m->rope_theta = 1e6; m->tie_word_embeddings = 0;
+}
+int nvr_model_config_validate(const nvr_model_config *m, uint64_t tp) {   // qwen3.rs:106-124
+    if (tp == 0) return nvr::fail(NVR_ERR_INVALID_ARG, "tensor parallel size must be positive");
+    if (m->num_attention_heads == 0 || m->num_key_value_heads == 0) return nvr::fail(NVR_ERR_INVALID_ARG, "head counts must be positive");
+    if (m->head_dim == 0 && m->hidden_size % m->num_attention_heads != 0)
+        return nvr::fail(NVR_ERR_INVALID_ARG, "Hidden size must be divisible by number of attention heads");
+    if (m->num_attention_heads % tp != 0) return nvr::fail(NVR_ERR_INVALID_ARG, "Number of attention heads must be divisible by tensor parallel size");
+    if (m->num_key_value_heads % tp != 0) return nvr::fail(NVR_ERR_INVALID_ARG, "Number of key-value heads must be divisible by tensor parallel size");
+    if (m->intermediate_size % tp != 0) return nvr::fail(NVR_ERR_INVALID_ARG, "Intermediate size must be divisible by tensor parallel size");
+    if ((m->num_attention_heads / tp) % (m->num_key_value_heads / tp) != 0)
+        return nvr::fail(NVR_ERR_INVALID_ARG, "attention heads must be a multiple of key-value heads");
+    return NVR_OK;
+}
+
+// ------------------------------------------------------------------ Sequence
+nvr_seq_t *nvr_seq_create(const int64_t *prompt, size_t n, const nvr_sampling_params *sp, size_t block_size) {
+    NVR_GUARD_BEGIN
+    nvr_seq *s = new nvr_seq();
+    s->seq_id = nvr::g_sequence_counter.fetch_add(1, std::memory_order_relaxed);   // sequence.rs:85
+    s->token_ids.assign(prompt, prompt + n);
+    s->last_token = n ? prompt[n - 1] : 0;                           // :87
+    s->num_tokens = s->num_prompt_tokens = n;
+    if (sp) s->sampling = *sp; else nvr_sampling_params_default(&s->sampling);
+    s->block_size = block_size ? block_size : 256;                   // :99 (A-1)
+    return s;
+    NVR_GUARD_END(nullptr)
+}
+void nvr_seq_destroy(nvr_seq_t *s) { if (s && !s->owned_by_scheduler) delete s; }
+void nvr_seq_reset_id_counter(void) { nvr::g_sequence_counter.store(0); }
+uint64_t nvr_seq_id(const nvr_seq_t *s) { return s->seq_id; }
+int32_t nvr_seq_status(const nvr_seq_t *s) { return s->status; }
+size_t nvr_seq_len(const nvr_seq_t *s) { return s->len(); }
+size_t nvr_seq_num_prompt_tokens(const nvr_seq_t *s) { return s->num_prompt_tokens; }
+size_t nvr_seq_num_completion_tokens(const nvr_seq_t *s) { return s->num_completion_tokens(); }
+size_t nvr_seq_num_cached_tokens(const nvr_seq_t *s) { return s->num_cached_tokens; }
+int64_t nvr_seq_last_token(const nvr_seq_t *s) { return s->last_token; }
+size_t nvr_seq_num_blocks(const nvr_seq_t *s) { return s->num_blocks(); }
+size_t nvr_seq_last_block_num_tokens(const nvr_seq_t *s) { return s->last_block_num_tokens(); }
+void nvr_seq_token_ids(const nvr_seq_t *s, const int64_t **p, size_t *len) { *p = s->token_ids.data(); *len = s->num_tokens; }
+void nvr_seq_block_table(const nvr_seq_t *s, const int32_t **p, size_t *len) { *p = s->block_table.data(); *len = s->block_table.size(); }
+void nvr_seq_append_token(nvr_seq_t *s, int64_t t) { s->append_token(t); }
+int nvr_seq_should_stop(const nvr_seq_t *s, int has_eos, int64_t eos) { return s->should_stop(has_eos != 0, eos) ? 1 : 0; }
+void nvr_seq_preempt(nvr_seq_t *s) { s->preempt(); }
+void nvr_seq_finish(nvr_seq_t *s) { s->status = NVR_SEQ_FINISHED; }
+
+// ------------------------------------------------------------------ BlockManager
+nvr_block_manager_t *nvr_bm_create(size_t num_blocks, size_t block_size) {
+    if (num_blocks == 0) { nvr::fail(NVR_ERR_INVARIANT, "Number of blocks must be positive"); return nullptr; }   // :92
+    if (block_size == 0) { nvr::fail(NVR_ERR_INVARIANT, "Block size must be positive"); return nullptr; }         // :93
+    NVR_GUARD_BEGIN
+    return new nvr_block_manager(num_blocks, block_size);
+    NVR_GUARD_END(nullptr)
+}
+void nvr_bm_destroy(nvr_block_manager_t *bm) { delete bm; }
+uint64_t nvr_bm_compute_hash(const int64_t *t, size_t n, int has_prefix, uint64_t prefix) {
+    return nvr::BlockManager::compute_hash(t, n, has_prefix != 0, prefix);
+}
+int nvr_bm_can_allocate(const nvr_block_manager_t *bm, const nvr_seq_t *s) { return bm->impl.can_allocate(*s) ? 1 : 0; }
+int nvr_bm_allocate(nvr_block_manager_t *bm, nvr_seq_t *s) { NVR_GUARD_BEGIN return bm->impl.allocate(*s); NVR_GUARD_END(NVR_ERR_INVARIANT) }
+int nvr_bm_deallocate(nvr_block_manager_t *bm, nvr_seq_t *s) { NVR_GUARD_BEGIN return bm->impl.deallocate(*s); NVR_GUARD_END(NVR_ERR_INVARIANT) }
+int nvr_bm_can_append(const nvr_block_manager_t *bm, const nvr_seq_t *s) { return bm->impl.can_append(*s) ? 1 : 0; }
+int nvr_bm_may_append(nvr_block_manager_t *bm, nvr_seq_t *s) { NVR_GUARD_BEGIN return bm->impl.may_append(*s); NVR_GUARD_END(NVR_ERR_INVARIANT) }
+int nvr_bm_get_stats(const nvr_block_manager_t *bm, nvr_bm_stats *o) { bm->impl.get_stats(o); return NVR_OK; }
+int nvr_bm_get_block(const nvr_block_manager_t *bm, size_t id, nvr_block_info *o) {
+    return bm->impl.get_block(id, o) ? NVR_OK : nvr::fail(NVR_ERR_INVALID_ARG, "block id %zu out of range", id);
+}
+size_t nvr_bm_free_list(const nvr_block_manager_t *bm, int32_t *out, size_t cap) { return bm->impl.free_list(out, cap); }
+
+// ------------------------------------------------------------------ Scheduler
+nvr_scheduler_t *nvr_sched_create(const nvr_config *cfg) {
+    if (cfg->kvcache_block_size == 0) { nvr::fail(NVR_ERR_INVARIANT, "Block size must be positive"); return nullptr; }
+    if (cfg->num_kvcache_blocks == 0) { nvr::fail(NVR_ERR_INVARIANT, "Number of blocks must be positive"); return nullptr; }
+    NVR_GUARD_BEGIN
+    return new nvr_scheduler(*cfg);
+    NVR_GUARD_END(nullptr)
+}
+void nvr_sched_destroy(nvr_scheduler_t *sc) { delete sc; }
+int nvr_sched_add_sequence(nvr_scheduler_t *sc, nvr_seq_t *s) {
+    if (s->owned_by_scheduler) return nvr::fail(NVR_ERR_INVALID_ARG, "sequence already belongs to a scheduler");
+    NVR_GUARD_BEGIN sc->impl.add_sequence(s); return NVR_OK; NVR_GUARD_END(NVR_ERR_INVARIANT)
+}
+int nvr_sched_schedule(nvr_scheduler_t *sc, nvr_seq_t **out, size_t cap, size_t *n, int *is_prefill) {
+    NVR_GUARD_BEGIN
+    static thread_local std::vector<nvr_seq *> tmp;
+    bool pf = false;
+    int rc = sc->impl.schedule(tmp, &pf);
+    if (rc) return rc;
+    if (tmp.size() > cap) return nvr::fail(NVR_ERR_INVALID_ARG, "schedule: output capacity %zu < batch %zu", cap, tmp.size());
+    std::memcpy(out, tmp.data(), tmp.size() * sizeof(nvr_seq *));
+    *n = tmp.size(); *is_prefill = pf ? 1 : 0;
+    return NVR_OK;
+    NVR_GUARD_END(NVR_ERR_INVARIANT)
+}
+int nvr_sched_postprocess(nvr_scheduler_t *sc, nvr_seq_t *const *seqs, const int64_t *toks, size_t n) {
+    NVR_GUARD_BEGIN return sc->impl.postprocess(seqs, toks, n); NVR_GUARD_END(NVR_ERR_INVARIANT)
+}
+int nvr_sched_is_finished(const nvr_scheduler_t *sc) { return sc->impl.is_finished() ? 1 : 0; }
+void nvr_sched_preempt_all(nvr_scheduler_t *sc) { sc->impl.preempt_all(); }
+int nvr_sched_get_stats(const nvr_scheduler_t *sc, nvr_sched_stats *o) { *o = sc->impl.stats(); return NVR_OK; }
+int nvr_sched_get_block_stats(const nvr_scheduler_t *sc, nvr_bm_stats *o) { sc->impl.block_manager().get_stats(o); return NVR_OK; }
+void nvr_sched_queue_lengths(const nvr_scheduler_t *sc, size_t *w, size_t *r) { *w = sc->impl.waiting_len(); *r = sc->impl.running_len(); }
+double nvr_sched_memory_pressure(const nvr_scheduler_t *sc) { return sc->impl.memory_pressure(); }
+nvr_block_manager_t *nvr_sched_block_manager(nvr_scheduler_t *sc) { return sc->impl.block_manager_handle(); }
+size_t nvr_sched_take_finished(nvr_scheduler_t *sc, nvr_seq_t **out, size_t cap) { return sc->impl.take_finished(out, cap); }
+
+// ------------------------------------------------------------------ ModelRunner
+nvr_model_runner_t *nvr_runner_create(const nvr_config *cfg, const nvr_model_config *mc) {
+    NVR_GUARD_BEGIN
+    if (nvr_config_validate(cfg)) return nullptr;
+    nvr_model_runner *r = new nvr_model_runner();
+    r->cfg = *cfg; r->mc = *mc;
+    if (r->init() != NVR_OK) { delete r; return nullptr; }
+    return r;
+    NVR_GUARD_END(nullptr)
+}
+void nvr_runner_destroy(nvr_model_runner_t *r) { delete r; }
+int nvr_runner_execute_model(nvr_model_runner_t *r, nvr_seq_t *const *seqs, size_t n, int is_prefill, const float **logits_dev) {
+    NVR_GUARD_BEGIN
+    int rc = r->execute(seqs, n, is_prefill != 0);
+    if (rc == NVR_OK && logits_dev) *logits_dev = r->logits;
+    return rc;
+    NVR_GUARD_END(NVR_ERR_INVARIANT)
+}
+int nvr_runner_sample_tokens(nvr_model_runner_t *r, nvr_seq_t *const *seqs, size_t n, int64_t *out) {
+    NVR_GUARD_BEGIN return r->sample(seqs, n, out); NVR_GUARD_END(NVR_ERR_INVARIANT)
+}
+int nvr_runner_copy_logits(nvr_model_runner_t *r, float *host_out, size_t rows) {
+    if (rows > r->last_rows) return nvr::fail(NVR_ERR_LEN_MISMATCH, "copy_logits: %zu rows requested, %zu available", rows, r->last_rows);
+    NVR_HIP_CHECK(hipSetDevice(r->device));
+    NVR_HIP_CHECK(hipMemcpyAsync(host_out, r->logits, rows * r->Vl * sizeof(float), hipMemcpyDeviceToHost, r->stream));
+    NVR_HIP_CHECK(hipStreamSynchronize(r->stream));
+    return NVR_OK;
+}
+uint64_t nvr_runner_num_kvcache_blocks(const nvr_model_runner_t *r) { return (uint64_t)r->num_blocks; }
+int nvr_runner_kv_cache(nvr_model_runner_t *r, size_t layer, void **kd, void **vd) {
+    if ((int64_t)layer >= r->L) return nvr::fail(NVR_ERR_INVALID_ARG, "layer %zu out of range", layer);
+    *kd = r->k_cache(layer); *vd = r->v_cache(layer);
+    return NVR_OK;
+}
+void *nvr_runner_stream(nvr_model_runner_t *r) { return r->stream; }
+int nvr_comm_unique_id(uint8_t id_out[128]) { return nvr::Comm::unique_id(id_out); }
+int nvr_runner_init_comm(nvr_model_runner_t *r, const uint8_t id[128]) {
+    NVR_HIP_CHECK(hipSetDevice(r->device));
+    return r->comm.init(id, (int)r->tp, (int)r->rank);
+}
+int nvr_runner_set_profiling(nvr_model_runner_t *, int) { return NVR_OK; }
+
+// ------------------------------------------------------------------ Engine
+nvr_engine_t *nvr_engine_create(const nvr_config *cfg, const nvr_model_config *mc) {
+    NVR_GUARD_BEGIN
+    if (nvr_config_validate(cfg)) return nullptr;
+    std::unique_ptr<nvr_engine> e(new nvr_engine());
+    e->cfg = *cfg;
+    e->runner.reset(nvr_runner_create(cfg, mc));
+    if (!e->runner) return nullptr;
+    nvr_config sc = *cfg;
+    sc.num_kvcache_blocks = (int64_t)e->runner->num_blocks;          // one pool size for scheduler and runner
+    e->scheduler.reset(new nvr_scheduler(sc));
+    return e.release();
+    NVR_GUARD_END(nullptr)
+}
+void nvr_engine_destroy(nvr_engine_t *e) { delete e; }
+int nvr_engine_add_request(nvr_engine_t *e, const int64_t *prompt, size_t n, const nvr_sampling_params *sp, uint64_t *id_out) {
+    NVR_GUARD_BEGIN
+    if (sp) { int rc = nvr_sampling_params_validate(sp); if (rc) return rc; }
+    if (n == 0) return nvr::fail(NVR_ERR_INVALID_ARG, "empty prompt");
+    nvr_seq *s = nvr_seq_create(prompt, n, sp, e->cfg.kvcache_block_size);
+    if (!s) return NVR_ERR_INVARIANT;
+    e->scheduler->impl.add_sequence(s);
+    if (id_out) *id_out = s->seq_id;
+    return NVR_OK;
+    NVR_GUARD_END(NVR_ERR_INVARIANT)
+}
+int nvr_engine_step(nvr_engine_t *e, nvr_step_info *info) { NVR_GUARD_BEGIN return e->step(info); NVR_GUARD_END(NVR_ERR_INVARIANT) }
+int nvr_engine_is_finished(const nvr_engine_t *e) { return e->scheduler->impl.is_finished() ? 1 : 0; }
+nvr_scheduler_t *nvr_engine_scheduler(nvr_engine_t *e) { return e->scheduler.get(); }
+nvr_model_runner_t *nvr_engine_runner(nvr_engine_t *e) { return e->runner.get(); }
+void nvr_engine_last_step(const nvr_engine_t *e, const uint64_t **ids, const int64_t **toks, size_t *n) {
+    *ids = e->last_ids.data(); *toks = e->last_tokens.data(); *n = e->last_ids.size();
+}
+size_t nvr_engine_take_finished(nvr_engine_t *e, nvr_seq_t **out, size_t cap) { return e->scheduler->impl.take_finished(out, cap); }
+
+// ------------------------------------------------------------------ device utilities
+int nvr_device_count(int *n) { NVR_HIP_CHECK(hipGetDeviceCount(n)); return NVR_OK; }
+int nvr_device_set(int o) { NVR_HIP_CHECK(hipSetDevice(o)); return NVR_OK; }
+int nvr_device_name(char *buf, size_t cap) {
+    int d = 0; NVR_HIP_CHECK(hipGetDevice(&d));
+    hipDeviceProp_t p; NVR_HIP_CHECK(hipGetDeviceProperties(&p, d));
+    std::snprintf(buf, cap, "%s (%s)", p.name, p.gcnArchName);
+    return NVR_OK;
+}
+int nvr_device_mem_info(uint64_t *f, uint64_t *t) { size_t a = 0, b = 0; NVR_HIP_CHECK(hipMemGetInfo(&a, &b)); *f = a; *t = b; return NVR_OK; }
+int nvr_device_malloc(void **p, size_t bytes) { NVR_HIP_CHECK(hipMalloc(p, bytes ? bytes : 16)); return NVR_OK; }
+int nvr_device_free(void *p) { NVR_HIP_CHECK(hipFree(p)); return NVR_OK; }
+int nvr_device_memset(void *p, int v, size_t bytes) { NVR_HIP_CHECK(hipMemset(p, v, bytes)); return NVR_OK; }
+int nvr_memcpy_h2d(void *d, const void *s, size_t b) { NVR_HIP_CHECK(hipMemcpy(d, s, b, hipMemcpyHostToDevice)); return NVR_OK; }
+int nvr_memcpy_d2h(void *d, const void *s, size_t b) { NVR_HIP_CHECK(hipMemcpy(d, s, b, hipMemcpyDeviceToHost)); return NVR_OK; }
+int nvr_device_synchronize(void) { NVR_HIP_CHECK(hipDeviceSynchronize()); return NVR_OK; }
+int nvr_stream_create(void **s) { hipStream_t st; NVR_HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking)); *s = st; return NVR_OK; }
+int nvr_stream_destroy(void *s) { NVR_HIP_CHECK(hipStreamDestroy((hipStream_t)s)); return NVR_OK; }
+int nvr_stream_synchronize(void *s) { NVR_HIP_CHECK(hipStreamSynchronize((hipStream_t)s)); return NVR_OK; }
+int nvr_event_create(void **e) { hipEvent_t ev; NVR_HIP_CHECK(hipEventCreate(&ev)); *e = ev; return NVR_OK; }
+int nvr_event_destroy(void *e) { NVR_HIP_CHECK(hipEventDestroy((hipEvent_t)e)); return NVR_OK; }
+int nvr_event_record(void *e, void *s) { NVR_HIP_CHECK(hipEventRecord((hipEvent_t)e, (hipStream_t)s)); return NVR_OK; }
+int nvr_event_elapsed_ms(void *a, void *b, float *ms) {
+    NVR_HIP_CHECK(hipEventSynchronize((hipEvent_t)b));
+    NVR_HIP_CHECK(hipEventElapsedTime(ms, (hipEvent_t)a, (hipEvent_t)b));
+    return NVR_OK;
+}
+
+// ------------------------------------------------------------------ stateless ops
+int nvr_embedding(const int64_t *ids, int64_t T, const nvr_half *E, int64_t Hd, nvr_half *out, void *s) {
+    return k::embedding(ids, T, E, Hd, out, (hipStream_t)s);
+}
+int nvr_rmsnorm(const nvr_half *x, const nvr_half *w, float eps, int64_t T, int64_t Hd, nvr_half *out, void *s) {
+    return k::rmsnorm(x, w, eps, T, Hd, out, (hipStream_t)s);
+}
+int nvr_add_rmsnorm(nvr_half *h, const nvr_half *y, const nvr_half *w, float eps, int64_t T, int64_t Hd, nvr_half *out, void *s) {
+    return k::add_rmsnorm(h, y, w, eps, T, Hd, out, (hipStream_t)s);
+}
+int nvr_linear(const nvr_half *x, int64_t ldx, const nvr_half *W, int64_t T, int64_t K, int64_t N, void *y, int f32, void *s) {
+    return k::linear(x, ldx, W, T, K, N, y, f32 != 0, (hipStream_t)s);
+}
+int nvr_rope_store_kv(nvr_half *qkv, const int64_t *pos, const int32_t *slots, int64_t T, int64_t H, int64_t KVH, int64_t D,
+                      const float *c, const float *sn, nvr_half *kc, nvr_half *vc, void *s) {
+    return k::rope_store_kv(qkv, pos, slots, T, H, KVH, D, c, sn, kc, vc, (hipStream_t)s);
+}
+int nvr_rope_table(int64_t D, int64_t max_pos, double theta, float *cos_dev, float *sin_dev) {   // rotary_embedding.rs:74-119 (A-14)
+    NVR_GUARD_BEGIN
+    const int64_t half = D / 2;
+    std::vector<float> c(max_pos * half), sn(max_pos * half);
+    for (int64_t p = 0; p < max_pos; ++p)
+        for (int64_t j = 0; j < half; ++j) {
+            float inv = (float)(1.0 / std::pow(theta, (double)(2 * j) / (double)D));
+            float ang = (float)p * inv;
+            c[p * half + j] = (float)std::cos((double)ang); sn[p * half + j] = (float)std::sin((double)ang);
+        }
+    NVR_HIP_CHECK(hipMemcpy(cos_dev, c.data(), c.size() * 4, hipMemcpyHostToDevice));
+    NVR_HIP_CHECK(hipMemcpy(sin_dev, sn.data(), sn.size() * 4, hipMemcpyHostToDevice));
+    return NVR_OK;
+    NVR_GUARD_END(NVR_ERR_INVARIANT)
+}
+size_t nvr_paged_attn_workspace_bytes(int64_t B, int64_t H, int64_t D, int64_t max_ctx) { return k::attn_workspace_bytes(B, H, D, max_ctx); }
+int nvr_paged_attn_decode(const nvr_half *q, int64_t ldq, const nvr_half *kc, const nvr_half *vc, const nvr_attn_meta *m,
+                          int64_t H, int64_t KVH, int64_t D, int64_t bs, float scale, nvr_half *out, void *ws, void *s) {
+    k::AttnArgs a{};
+    a.q = q; a.ldq = ldq; a.k = kc; a.v = vc; a.ctx_lens = m->context_lens; a.block_tables = m->block_tables;
+    a.max_blocks = m->max_blocks; a.block_size = (int32_t)bs; a.nq = m->batch; a.H = (int32_t)H; a.KVH = (int32_t)KVH;
+    a.D = (int32_t)D; a.scale = scale; a.max_ctx = m->max_context_len; a.out = out; a.workspace = ws;
+    return k::attention(a, true, (hipStream_t)s);
+}
+int nvr_attn_prefill_varlen(const nvr_half *q, const nvr_half *kk, const nvr_half *v, int64_t ld, const nvr_attn_meta *m,
+                            int64_t T, int64_t H, int64_t KVH, int64_t D, float scale, nvr_half *out, void *s) {
+    // per-token visible-key count and first key row are derived from cu_seqlens on the device side
+    // by the caller in the engine path; the stateless entry builds them here from host-visible meta.
+    NVR_GUARD_BEGIN
+    std::vector<int32_t> cu(m->batch + 1);
+    NVR_HIP_CHECK(hipMemcpy(cu.data(), m->cu_seqlens_q, cu.size() * 4, hipMemcpyDeviceToHost));
+    if (cu[m->batch] != T) return nvr::fail(NVR_ERR_LEN_MISMATCH, "cu_seqlens_q ends at %d but T=%ld", cu[m->batch], (long)T);
+    std::vector<int32_t> ctx(T), base(T);
+    for (int b = 0; b < m->batch; ++b)
+        for (int t = cu[b]; t < cu[b + 1]; ++t) { ctx[t] = t - cu[b] + 1; base[t] = cu[b]; }
+    int32_t *d = nullptr;
+    NVR_HIP_CHECK(hipMalloc((void **)&d, (size_t)(2 * T + 4) * 4));
+    NVR_HIP_CHECK(hipMemcpy(d, ctx.data(), T * 4, hipMemcpyHostToDevice));
+    NVR_HIP_CHECK(hipMemcpy(d + T, base.data(), T * 4, hipMemcpyHostToDevice));
+    k::AttnArgs a{};
+    a.q = q; a.ldq = ld; a.k = kk; a.v = v; a.ldkv = ld; a.ctx_lens = d; a.kv_base = d + T; a.nq = (int32_t)T;
+    a.H = (int32_t)H; a.KVH = (int32_t)KVH; a.D = (int32_t)D; a.scale = scale; a.max_ctx = m->max_seqlen_k; a.out = out;
+    int rc = k::attention(a, false, (hipStream_t)s);
+    hipStreamSynchronize((hipStream_t)s);
+    hipFree(d);
+    return rc;
+    NVR_GUARD_END(NVR_ERR_INVARIANT)
+}
+int nvr_silu_and_mul(const nvr_half *x, int64_t T, int64_t I, nvr_half *out, void *s) { return k::silu_and_mul(x, T, I, out, (hipStream_t)s); }
+int nvr_select_last_tokens(const nvr_half *h, const int32_t *cu, int64_t B, int64_t Hd, nvr_half *out, void *s) {
+    return k::select_last_tokens(h, cu, B, Hd, out, (hipStream_t)s);
+}
+int nvr_argmax(const float *logits, int64_t B, int64_t V, int64_t *out, void *s) { return k::argmax(logits, B, V, out, nullptr, 0, (hipStream_t)s); }
+size_t nvr_sample_workspace_bytes(int64_t B, int64_t V) { return k::sample_workspace_bytes(B, V); }
+int nvr_sample(const float *logits, int64_t B, int64_t V, const float *temp, const int64_t *top_k, const float *top_p,
+               const uint64_t *keys, int64_t *out, void *ws, void *s) {
+    return k::sample(logits, B, V, temp, top_k, top_p, keys, out, ws, (hipStream_t)s);
+}
+uint64_t nvr_sample_key(uint64_t seed, uint64_t seq_id, uint64_t step) {
+    return nvr::splitmix64(nvr_weight_key_impl(seed, seq_id) + step * 0xA24BAED4963EE407ULL);
+}
+uint64_t nvr_weight_key(uint64_t seed, uint64_t tid) { return nvr_weight_key_impl(seed, tid); }
+float nvr_weight_scale(double std) { return nvr_weight_scale_impl(std); }
+int nvr_fill_weight(nvr_half *dst, int64_t rows, int64_t cols, int64_t ld, int64_t gcols, int64_t row0, int64_t col0,
+                    uint64_t key, float scale, void *s) {
+    return k::fill_weight(dst, rows, cols, ld, gcols, row0, col0, key, scale, (hipStream_t)s);
+}
+int nvr_fill_const(nvr_half *dst, int64_t n, float v, void *s) { return k::fill_const(dst, n, v, (hipStream_t)s); }
+
+}  // extern "C"

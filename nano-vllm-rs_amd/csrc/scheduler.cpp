@@ -1,0 +1,148 @@
+// scheduler.cpp — see scheduler.h.  Line cites are into the reference's src/engine/scheduler.rs.
+#include "scheduler.h"
+#include <algorithm>
+#include "common.h"
+
+namespace nvr {
+
+Scheduler::Scheduler(const nvr_config &cfg)
+    : max_num_seqs_(cfg.max_num_seqs), max_num_batched_tokens_(cfg.max_num_batched_tokens),
+      has_eos_(cfg.has_eos != 0), eos_(cfg.eos_token_id),
+      bm_(new nvr_block_manager(cfg.num_kvcache_blocks >= 0 ? (size_t)cfg.num_kvcache_blocks : 1000,  // :71-74
+                                cfg.kvcache_block_size)) {}
+
+Scheduler::~Scheduler() {
+    for (auto *s : waiting_) delete s;
+    for (auto *s : running_) delete s;
+    for (auto *s : finished_) delete s;
+}
+
+void Scheduler::add_sequence(nvr_seq *s) {                           // :93-98
+    s->status = NVR_SEQ_WAITING;
+    s->owned_by_scheduler = true;
+    waiting_.push_back(s);
+    stats_.total_sequences += 1;
+    update_stats();
+}
+
+int Scheduler::schedule(std::vector<nvr_seq *> &out, bool *is_prefill) {   // :103-116
+    out.clear();
+    int rc = NVR_OK;
+    if (try_schedule_prefill(out, &rc)) {
+        stats_.prefill_batches += 1;
+        double n = (double)stats_.prefill_batches;                   // :283-288
+        stats_.avg_prefill_batch_size = (stats_.avg_prefill_batch_size * (n - 1.0) + (double)out.size()) / n;
+        *is_prefill = true;
+        return NVR_OK;
+    }
+    if (rc) return rc;
+    rc = try_schedule_decode(out);
+    if (rc) return rc;
+    stats_.decode_batches += 1;
+    double n = (double)stats_.decode_batches;                        // :291-296
+    stats_.avg_decode_batch_size = (stats_.avg_decode_batch_size * (n - 1.0) + (double)out.size()) / n;
+    *is_prefill = false;
+    return NVR_OK;
+}
+
+bool Scheduler::try_schedule_prefill(std::vector<nvr_seq *> &out, int *rc) {   // :119-168
+    if (waiting_.empty()) return false;
+    size_t num_seqs = 0, num_batched_tokens = 0;
+    BlockManager &bm = bm_->impl;
+    while (!waiting_.empty()) {
+        nvr_seq *s = waiting_.front();
+        if (num_seqs >= max_num_seqs_) break;                        // :131
+        size_t seq_tokens = s->len() - s->num_cached_tokens;         // :135
+        if (num_batched_tokens + seq_tokens > max_num_batched_tokens_) break;
+        if (!bm.can_allocate(*s)) break;                             // :141
+        waiting_.pop_front();
+        int r = bm.allocate(*s);                                     // :149
+        if (r) { waiting_.push_front(s); *rc = r; return false; }
+        num_seqs += 1;
+        num_batched_tokens += seq_tokens;
+        s->status = NVR_SEQ_RUNNING;
+        out.push_back(s);
+    }
+    if (out.empty()) return false;
+    for (nvr_seq *s : out) running_.push_back(s);                    // :163-165
+    return true;
+}
+
+int Scheduler::try_schedule_decode(std::vector<nvr_seq *> &out) {    // :171-223 (intent per SURVEY A-16)
+    BlockManager &bm = bm_->impl;
+    size_t num_seqs = 0;
+    std::vector<nvr_seq *> reschedule;
+    while (!running_.empty()) {
+        nvr_seq *s = running_.front(); running_.pop_front();
+        if (num_seqs >= max_num_seqs_) { reschedule.push_back(s); continue; }   // :179-182
+        bool self_preempted = false;
+        while (!bm.can_append(*s)) {                                 // :185-198
+            int rc;
+            if (!running_.empty()) { nvr_seq *v = running_.back(); running_.pop_back(); rc = preempt_sequence(v); }
+            else if (!out.empty()) { nvr_seq *v = out.back(); out.pop_back(); rc = preempt_sequence(v); }
+            else { rc = preempt_sequence(s); self_preempted = true; }
+            if (rc) return rc;
+            if (self_preempted) break;
+        }
+        if (!self_preempted && bm.can_append(*s)) {                  // :201-205
+            num_seqs += 1;
+            int rc = bm.may_append(*s);
+            if (rc) return rc;
+            out.push_back(s);
+        }
+    }
+    // running = scheduled ++ rescheduled (:208-216)
+    for (size_t i = reschedule.size(); i-- > 0;) running_.push_front(reschedule[i]);
+    for (size_t i = out.size(); i-- > 0;) running_.push_front(out[i]);
+    if (out.empty()) return fail(NVR_ERR_NOTHING_TO_SCHEDULE, "No sequences could be scheduled for decode");
+    return NVR_OK;
+}
+
+int Scheduler::preempt_sequence(nvr_seq *s) {                        // :226-231
+    s->status = NVR_SEQ_PREEMPTED;
+    int rc = bm_->impl.deallocate(*s);
+    waiting_.push_front(s);
+    stats_.preemptions += 1;
+    return rc;
+}
+
+int Scheduler::postprocess(nvr_seq *const *seqs, const int64_t *token_ids, size_t n) {   // :234-257
+    // (the reference's length check, :235-237, is enforced at the ABI: one n for both arrays)
+    for (size_t i = 0; i < n; ++i) {
+        nvr_seq *s = seqs[i];
+        s->append_token(token_ids[i]);
+        if (s->should_stop(has_eos_, eos_)) {
+            s->status = NVR_SEQ_FINISHED;
+            int rc = bm_->impl.deallocate(*s);
+            if (rc) return rc;
+            auto it = std::find(running_.begin(), running_.end(), s);   // remove_from_running :260-262
+            if (it != running_.end()) running_.erase(it);
+            finished_.push_back(s);
+            stats_.finished_sequences += 1;
+        } else if (std::find(running_.begin(), running_.end(), s) == running_.end()) {
+            running_.push_back(s);                                   // update_running_sequence fallback :272-273
+        }
+    }
+    update_stats();
+    return NVR_OK;
+}
+
+void Scheduler::preempt_all() {                                      // :314-319
+    std::vector<nvr_seq *> seqs(running_.begin(), running_.end());
+    running_.clear();
+    for (nvr_seq *s : seqs) preempt_sequence(s);
+}
+
+double Scheduler::memory_pressure() const {                          // :322-329
+    nvr_bm_stats st; bm_->impl.get_stats(&st);
+    return st.total_blocks == 0 ? 0.0 : 1.0 - (double)st.free_blocks / (double)st.total_blocks;
+}
+
+size_t Scheduler::take_finished(nvr_seq **out, size_t cap) {
+    size_t n = std::min(cap, finished_.size());
+    for (size_t i = 0; i < n; ++i) { out[i] = finished_[i]; out[i]->owned_by_scheduler = false; }
+    finished_.erase(finished_.begin(), finished_.begin() + n);
+    return n;
+}
+
+}  // namespace nvr

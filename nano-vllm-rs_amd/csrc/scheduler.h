@@ -1,0 +1,51 @@
+// scheduler.h — prefill-first continuous batching with recompute-style preemption (mirrors
+// Scheduler, reference src/engine/scheduler.rs:13-365).  Sequences are owned by the scheduler
+// from add_sequence until they are taken out as finished; the waiting/running queues hold
+// pointers (the reference clones whole Sequences in and out of its queues every step,
+// scheduler.rs:164,215, and scans them by seq_id, :260-274).
+#pragma once
+#include <deque>
+#include <memory>
+#include <vector>
+#include "block_manager.h"
+
+namespace nvr {
+
+class Scheduler {
+public:
+    explicit Scheduler(const nvr_config &cfg);
+    ~Scheduler();
+
+    bool is_finished() const { return waiting_.empty() && running_.empty(); }          // :88
+    void add_sequence(nvr_seq *s);                                                      // :93
+    int schedule(std::vector<nvr_seq *> &out, bool *is_prefill);                        // :103
+    int postprocess(nvr_seq *const *seqs, const int64_t *token_ids, size_t n);          // :234
+    void preempt_all();                                                                 // :314
+    const nvr_sched_stats &stats() const { return stats_; }
+    BlockManager &block_manager() { return bm_->impl; }
+    const BlockManager &block_manager() const { return bm_->impl; }
+    nvr_block_manager *block_manager_handle() { return bm_.get(); }
+    size_t waiting_len() const { return waiting_.size(); }
+    size_t running_len() const { return running_.size(); }
+    double memory_pressure() const;                                                     // :322
+    size_t take_finished(nvr_seq **out, size_t cap);
+    bool has_eos() const { return has_eos_; }
+    int64_t eos() const { return eos_; }
+
+private:
+    bool try_schedule_prefill(std::vector<nvr_seq *> &out, int *rc);                    // :119
+    int try_schedule_decode(std::vector<nvr_seq *> &out);                               // :171
+    int preempt_sequence(nvr_seq *s);                                                   // :226
+    void update_stats() { stats_.waiting_sequences = waiting_.size(); stats_.running_sequences = running_.size(); }
+
+    size_t max_num_seqs_, max_num_batched_tokens_;
+    bool has_eos_; int64_t eos_;
+    std::unique_ptr<nvr_block_manager> bm_;
+    std::deque<nvr_seq *> waiting_, running_;
+    std::vector<nvr_seq *> finished_;
+    nvr_sched_stats stats_{};
+};
+
+}  // namespace nvr
+
+struct nvr_scheduler { nvr::Scheduler impl; explicit nvr_scheduler(const nvr_config &c) : impl(c) {} };
