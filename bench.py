@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""bench.py — decode throughput of the paged-attention hot path on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (BASELINE.json configs[1]): Qwen3-0.6B shape, fp16, synthetic random-init weights, 32
+sequences with 1024-token synthetic prompts, greedy decode, block size 256, hipGraph decode steps.
+A "step" is one decode pass of the engine over the whole batch (schedule -> execute_model ->
+sample_tokens -> postprocess through the C ABI), i.e. 32 generated tokens.  The prefill of the
+32x1024 prompt tokens happens before the timed region; K steps are timed between barriers and
+device synchronisation; the maximum over ranks is reported.  N>1 shards heads / MLP columns / vocab
+across N ranks (tensor parallel, one process per GPU, RCCL all-reduce inside the captured graph):
+the job is the same 32 sequences, so scaling is "strong".
+
+The JSON line also carries
+  roofline     — the dominant kernel (paged decode attention): algorithmic K/V bytes per launch
+                 divided by its average launch duration, measured here with HIP events on the
+                 kernel's own stream over back-to-back launches on the live KV pool (all layers
+                 cycled, so every launch streams from HBM like in the real step);
+  cpu_baseline — the CPU oracle (a port: the reference's Rust path cannot be built)
+                 timed on this box's host cores on BASELINE.json configs[0] (bs=1, prompt 128, f32).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import nvr_import  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+BATCH, PROMPT_LEN, BLOCK = 32, 1024, 256
+
+
+def model_bytes_per_step(mc, ctx_mean: float) -> dict:
+    """Algorithmic HBM bytes of one decode step, fp16."""
+    Hd, L, H, KVH, D, I, V = (mc.hidden_size, mc.num_hidden_layers, mc.num_attention_heads, mc.num_key_value_heads,
+                              mc.head_dim or mc.hidden_size // mc.num_attention_heads, mc.intermediate_size, mc.vocab_size)
+    per_layer = 2 * ((H + 2 * KVH) * D * Hd + Hd * H * D + 2 * I * Hd + Hd * I + 2 * Hd)
+    weights = per_layer * L + 2 * Hd + 2 * V * Hd
+    kv_per_token = L * 2 * KVH * D * 2
+    return dict(weights=weights, kv_read=BATCH * ctx_mean * kv_per_token, kv_write=BATCH * kv_per_token,
+                kv_per_token_layer=2 * KVH * D * 2)
+
+
+def time_attention_kernel(nvr, eng, mc, reps: int) -> dict:
+    """Average duration of one decode paged-attention launch on the live KV pool (HIP events)."""
+    l = nvr.lib()
+    seqs = eng.last_batch()
+    B = len(seqs)
+    H, KVH = mc.c.num_attention_heads, mc.c.num_key_value_heads
+    D, L = mc.head_dim(), mc.c.num_hidden_layers
+    tp = eng.config.c.tensor_parallel_size
+    H, KVH = H // tp, KVH // tp
+    ctx = np.asarray([len(s) for s in seqs], np.int32)
+    max_blocks = max(s.num_blocks() for s in seqs) + 1
+    bt = -np.ones((B, max_blocks), np.int32)
+    for i, s in enumerate(seqs):
+        t = s.block_table
+        bt[i, :len(t)] = t
+    rng = np.random.default_rng(0)
+    d_q = nvr.DeviceBuffer.from_numpy(rng.standard_normal((B, H * D)).astype(np.float16))
+    d_ctx, d_bt = nvr.DeviceBuffer.from_numpy(ctx), nvr.DeviceBuffer.from_numpy(bt)
+    d_out = nvr.DeviceBuffer(B * H * D * 2)
+    bucket = (int(ctx.max()) + 255) // 256 * 256                 # same partitioning as the engine's graph
+    ws = nvr.DeviceBuffer(l.nvr_paged_attn_workspace_bytes(B, H, D, bucket))
+    meta = nvr.AttnMetaC()
+    meta.context_lens, meta.block_tables, meta.max_blocks, meta.batch, meta.max_context_len = d_ctx.ptr, d_bt.ptr, max_blocks, B, bucket
+    stream = C.c_void_p(); nvr.check(l.nvr_stream_create(C.byref(stream)))
+    e0, e1 = C.c_void_p(), C.c_void_p()
+    nvr.check(l.nvr_event_create(C.byref(e0))); nvr.check(l.nvr_event_create(C.byref(e1)))
+    caches = [eng.model_runner.kv_cache(i) for i in range(L)]
+    scale = float(1.0 / np.sqrt(np.float32(D)))
+
+    def sweep():
+        for kc, vc in caches:
+            nvr.check(l.nvr_paged_attn_decode(d_q.ptr, H * D, kc, vc, C.byref(meta), H, KVH, D, BLOCK, scale, d_out.ptr, ws.ptr, stream))
+    sweep()
+    nvr.check(l.nvr_stream_synchronize(stream))
+    nvr.check(l.nvr_event_record(e0, stream))
+    for _ in range(reps):
+        sweep()
+    nvr.check(l.nvr_event_record(e1, stream))
+    ms = C.c_float()
+    nvr.check(l.nvr_event_elapsed_ms(e0, e1, C.byref(ms)))
+    launches = reps * L
+    us = ms.value * 1e3 / launches
+    alg_bytes = float(ctx.sum()) * 2 * KVH * D * 2 + 2 * B * H * D * 2          # K+V rows read + q in + out
+    l.nvr_event_destroy(e0); l.nvr_event_destroy(e1); l.nvr_stream_destroy(stream)
+    return dict(us_per_launch=us, launches=launches, alg_bytes=alg_bytes, ctx_sum=int(ctx.sum()))
+
+
+def cpu_baseline(decode_steps: int = 12) -> dict:
+    """Oracle engine on BASELINE.json configs[0]: Qwen3-0.6B f32, bs=1, prompt 128, greedy (a port)."""
+    import oracle
+    from oracle import engine_oracle as eo, model_oracle as mo
+    cores = oracle.lib().nvo_num_threads()
+    mcfg = mo.qwen3_0_6b()
+    eo.reset_sequence_counter()
+    eng = mo.OracleEngine(mcfg, eo.Config(kvcache_block_size=256, num_kvcache_blocks=2, max_num_seqs=1,
+                                          max_num_batched_tokens=256, max_model_len=256), fp16=False, max_pos=256)
+    eng.add_request(oracle.fill_tokens(128, 1, 0, mcfg.vocab_size).tolist(),
+                    eo.SamplingParams(temperature=0.0, max_tokens=decode_steps + 1, ignore_eos=True))
+    t0 = time.perf_counter(); eng.step(); t_prefill = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for _ in range(decode_steps):
+        eng.step()
+    t_dec = time.perf_counter() - t0
+    return dict(value=round(decode_steps / t_dec, 3), unit="tokens/s", cores=int(cores), kind="port",
+                sample=f"oracle (CPU restatement; reference Rust path unbuildable) Qwen3-0.6B f32 bs=1: prefill 128 tokens "
+                       f"({128 / t_prefill:.1f} tok/s), then {decode_steps} greedy decode steps",
+                prefill_tokens_per_s=round(128 / t_prefill, 2))
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--attn-reps", type=int, default=8)
+    args = ap.parse_args()
+
+    nvr = nvr_import.load()                # loads libnvr.so (and the ROCm HIP runtime) before torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if args.gpus > 1:
+        if world != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run)")
+        import torch.distributed as dist   # control plane only (gloo): unique-id broadcast, barrier, max
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    total_new = args.warmup + args.steps + 1
+    cfg = nvr.Config(max_num_seqs=BATCH, max_num_batched_tokens=BATCH * PROMPT_LEN, max_model_len=PROMPT_LEN + total_new + 8,
+                     kvcache_block_size=BLOCK, num_kvcache_blocks=BATCH * ((PROMPT_LEN + total_new) // BLOCK + 2),
+                     tensor_parallel_size=args.gpus, tensor_parallel_rank=rank, device_ordinal=local_rank)
+    mc = nvr.ModelConfig("qwen3-0.6b")
+    nvr.check(nvr.lib().nvr_device_set(local_rank))
+    eng = nvr.LLMEngine(cfg, mc)
+    if args.gpus > 1:
+        import torch
+        uid = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0:
+            uid = torch.frombuffer(bytearray(nvr.comm_unique_id()), dtype=torch.uint8).clone()
+        dist.broadcast(uid, 0)
+        eng.model_runner.init_comm(bytes(uid.numpy().tobytes()))
+
+    for i in range(BATCH):                   # synthetic prompts, SURVEY §8d: seed 1, one stream per sequence
+        eng.add_request(nvr.synthetic_tokens(PROMPT_LEN, 1, i, mc.c.vocab_size).tolist(),
+                        nvr.SamplingParams(temperature=0.0, max_tokens=total_new, ignore_eos=True))
+
+    def barrier():
+        nvr.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    t0 = time.perf_counter()
+    info = eng.step()                        # prefill of 32 x 1024 tokens (untimed)
+    nvr.synchronize()
+    t_prefill = time.perf_counter() - t0
+    assert info["is_prefill"] and info["num_seqs"] == BATCH, info
+    for _ in range(args.warmup):
+        info = eng.step()
+        assert not info["is_prefill"] and info["num_seqs"] == BATCH
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.step()
+    nvr.synchronize()
+    elapsed = time.perf_counter() - t0
+    barrier()
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    ms_per_step = elapsed * 1e3 / args.steps
+    tokens_per_s = BATCH * args.steps / elapsed
+    ctx_mean = PROMPT_LEN + 1 + args.warmup + (args.steps - 1) / 2.0   # keys visible per sequence, averaged over timed steps
+    mb = model_bytes_per_step(mc.c, ctx_mean)
+    step_bytes = mb["weights"] + mb["kv_read"] + mb["kv_write"]
+    step_gbs = step_bytes / args.gpus / (ms_per_step * 1e-3) / 1e9       # per-GPU share of the algorithmic bytes
+
+    attn = time_attention_kernel(nvr, eng, mc, args.attn_reps)
+    achieved = attn["alg_bytes"] / (attn["us_per_launch"] * 1e-6) / 1e9
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_attn_latest.json")
+    if os.path.exists(pmc_path):
+        try:
+            traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    if rank == 0:
+        out = {
+            "metric": "decode tokens/s + %HBM-roofline, Qwen3-0.6B bs=32 seq=1024, 1/2/4/8 GPU",
+            "value": round(tokens_per_s, 2), "unit": "tokens/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f16", "data": "synthetic",
+            "config": {"workload": "Qwen3-0.6B fp16 random-init, bs=32 x 1024-token prompts, greedy paged-attention decode, "
+                                   "block_size=256, hipGraph decode steps (BASELINE.json configs[1])",
+                       "batch": BATCH, "prompt_len": PROMPT_LEN, "mean_context": ctx_mean,
+                       "parallelism": f"tp{args.gpus}", "prefill_s": round(t_prefill, 3)},
+            "step_hbm_frac": round(step_gbs / HBM_PEAK_GBS, 4),
+            "step_algorithmic_bytes": int(step_bytes),
+            "roofline": {"kernel": "attn_rows_kernel (paged decode attention, K9)", "bound": "hbm", "achieved": round(achieved, 1),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "us_per_launch": round(attn["us_per_launch"], 2), "launches_timed": attn["launches"],
+                         "algorithmic_bytes_per_launch": int(attn["alg_bytes"])},
+        }
+        if args.gpus == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    del eng
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

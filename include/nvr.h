@@ -196,8 +196,6 @@ NVR_API void *nvr_runner_stream(nvr_model_runner_t *r);
  * embed_head.rs:130-139,321-336): rank 0 creates the 128-byte RCCL id, the host broadcasts it. */
 NVR_API int nvr_comm_unique_id(uint8_t id_out[128]);
 NVR_API int nvr_runner_init_comm(nvr_model_runner_t *r, const uint8_t id[128]);
-/* per-kernel-class device time of the last profiled steps (hipEvent based), microseconds */
-NVR_API int nvr_runner_set_profiling(nvr_model_runner_t *r, int on);
 
 /* -------------------------------------------------------------------- Engine ---- */
 /* LLMEngine::step loop, src/engine/llm_engine.rs:155-197 (driver of the hot path only) */
@@ -217,6 +215,8 @@ NVR_API nvr_model_runner_t *nvr_engine_runner(nvr_engine_t *e);     /* borrowed 
 /* ids + tokens sampled by the last step (borrowed until the next step) */
 NVR_API void nvr_engine_last_step(const nvr_engine_t *e, const uint64_t **seq_ids, const int64_t **tokens, size_t *n);
 NVR_API size_t nvr_engine_take_finished(nvr_engine_t *e, nvr_seq_t **out, size_t cap);   /* caller destroys */
+/* sequences of the last step's batch (borrowed handles; finished ones are excluded) */
+NVR_API size_t nvr_engine_last_batch(const nvr_engine_t *e, nvr_seq_t **out, size_t cap);
 
 /* --------------------------------------------------------- device utilities ---- */
 NVR_API int nvr_device_count(int *n);

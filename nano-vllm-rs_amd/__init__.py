@@ -136,13 +136,14 @@ _SIGS = {
     "nvr_runner_num_kvcache_blocks": (C.c_uint64, [_P]),
     "nvr_runner_kv_cache": (C.c_int, [_P, C.c_size_t, C.POINTER(_P), C.POINTER(_P)]),
     "nvr_runner_stream": (_P, [_P]), "nvr_comm_unique_id": (C.c_int, [_P]),
-    "nvr_runner_init_comm": (C.c_int, [_P, _P]), "nvr_runner_set_profiling": (C.c_int, [_P, C.c_int]),
+    "nvr_runner_init_comm": (C.c_int, [_P, _P]),
     "nvr_engine_create": (_P, [C.POINTER(ConfigC), C.POINTER(ModelConfigC)]), "nvr_engine_destroy": (None, [_P]),
     "nvr_engine_add_request": (C.c_int, [_P, _P, C.c_size_t, C.POINTER(SamplingParamsC), C.POINTER(C.c_uint64)]),
     "nvr_engine_step": (C.c_int, [_P, C.POINTER(StepInfoC)]), "nvr_engine_is_finished": (C.c_int, [_P]),
     "nvr_engine_scheduler": (_P, [_P]), "nvr_engine_runner": (_P, [_P]),
     "nvr_engine_last_step": (None, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(C.c_size_t)]),
     "nvr_engine_take_finished": (C.c_size_t, [_P, C.POINTER(_P), C.c_size_t]),
+    "nvr_engine_last_batch": (C.c_size_t, [_P, C.POINTER(_P), C.c_size_t]),
     "nvr_device_count": (C.c_int, [C.POINTER(C.c_int)]), "nvr_device_set": (C.c_int, [C.c_int]),
     "nvr_device_name": (C.c_int, [C.c_char_p, C.c_size_t]),
     "nvr_device_mem_info": (C.c_int, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
@@ -553,6 +554,11 @@ class LLMEngine:
     def is_finished(self) -> bool:
         return bool(lib().nvr_engine_is_finished(self.h))
 
+    def last_batch(self) -> List[Sequence]:
+        out = (_P * 4096)()
+        n = lib().nvr_engine_last_batch(self.h, out, 4096)
+        return [Sequence(_handle=out[i]) for i in range(n)]
+
     def take_finished(self) -> List[Sequence]:
         return self.scheduler.take_finished()
 
@@ -587,6 +593,23 @@ class DeviceBuffer:
         if getattr(self, "ptr", None) and _lib is not None:
             _lib.nvr_device_free(self.ptr)
             self.ptr = None
+
+
+def _splitmix64(x: np.ndarray) -> np.ndarray:
+    x = (x + np.uint64(0x9E3779B97F4A7C15)).astype(np.uint64)
+    z = x
+    z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return z ^ (z >> np.uint64(31))
+
+
+def synthetic_tokens(n: int, seed: int, stream: int, vocab: int) -> np.ndarray:
+    """Deterministic prompt token ids uniform in [0, vocab): splitmix64(key ^ i) % vocab
+    with key = nvr_weight_key(seed, stream) — the same counter-based generator as the synthetic weights."""
+    key = np.uint64(lib().nvr_weight_key(seed, stream))
+    with np.errstate(over="ignore"):
+        r = _splitmix64(np.arange(n, dtype=np.uint64) ^ key)
+    return (r % np.uint64(vocab)).astype(np.int64)
 
 
 def device_count() -> int:

@@ -213,7 +213,6 @@ int nvr_runner_init_comm(nvr_model_runner_t *r, const uint8_t id[128]) {
     NVR_HIP_CHECK(hipSetDevice(r->device));
     return r->comm.init(id, (int)r->tp, (int)r->rank);
 }
-int nvr_runner_set_profiling(nvr_model_runner_t *, int) { return NVR_OK; }
 
 // ------------------------------------------------------------------ Engine
 nvr_engine_t *nvr_engine_create(const nvr_config *cfg, const nvr_model_config *mc) {
@@ -249,6 +248,11 @@ void nvr_engine_last_step(const nvr_engine_t *e, const uint64_t **ids, const int
     *ids = e->last_ids.data(); *toks = e->last_tokens.data(); *n = e->last_ids.size();
 }
 size_t nvr_engine_take_finished(nvr_engine_t *e, nvr_seq_t **out, size_t cap) { return e->scheduler->impl.take_finished(out, cap); }
+size_t nvr_engine_last_batch(const nvr_engine_t *e, nvr_seq_t **out, size_t cap) {
+    size_t n = 0;
+    for (nvr_seq *s : e->batch) if (s->status != NVR_SEQ_FINISHED && n < cap) out[n++] = s;
+    return n;
+}
 
 // ------------------------------------------------------------------ device utilities
 int nvr_device_count(int *n) { NVR_HIP_CHECK(hipGetDeviceCount(n)); return NVR_OK; }

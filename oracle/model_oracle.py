@@ -84,6 +84,15 @@ def tiny(**kw) -> ModelConfig:
     return ModelConfig(**d)
 
 
+def small(**kw) -> ModelConfig:
+    """Smallest shape the gfx950 kernels accept (head_dim 64, 16-multiples): GPU end-to-end parity."""
+    d = dict(vocab_size=1024, hidden_size=256, intermediate_size=512, num_hidden_layers=2,
+             num_attention_heads=4, num_key_value_heads=2, head_dim=64, rope_theta=10000.0,
+             tie_word_embeddings=False, max_position_embeddings=2048, init_std=0.05)
+    d.update(kw)
+    return ModelConfig(**d)
+
+
 class OracleModel:
     """One tensor-parallel rank of the Qwen3 graph with synthetic weights."""
 

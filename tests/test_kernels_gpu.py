@@ -1,0 +1,378 @@
+"""GPU parity tests (-m gpu): every HIP kernel of the hot path, called through the C ABI with raw
+device pointers, against the CPU oracle on the same seeded inputs.  fp16 storage on both sides
+(oracle in fp16-faithful mode), f32 math inside an op.  Tolerances are stated per test: integer
+outputs (token ids, cache contents of pure copies) are bit-exact; fp16 outputs may differ by
+fp16 rounding of f32 results that differ in summation order (<= 1-2 fp16 ulp)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import nvr_import
+import oracle
+
+nvr = nvr_import.load()
+pytestmark = pytest.mark.gpu
+
+F16 = np.float16
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _device():
+    assert nvr.device_count() >= 1, "no HIP device visible: the GPU tests must run on an MI355X"
+    nvr.check(nvr.lib().nvr_device_set(0))
+    yield
+    nvr.synchronize()
+
+
+def dev(a):
+    return nvr.DeviceBuffer.from_numpy(np.ascontiguousarray(a))
+
+
+def h16(a):
+    """fp16-representable f32 array + its fp16 bits"""
+    b = np.asarray(a, dtype=np.float32).astype(F16)
+    return b.astype(np.float32), b
+
+
+def assert_close_f16(got, ref, ulps=2, atol=1e-3, what=""):
+    got = np.asarray(got, np.float32); ref = np.asarray(ref, np.float32)
+    tol = atol + ulps * np.abs(ref) * 2.0 ** -10
+    bad = np.abs(got - ref) > tol
+    assert not bad.any(), f"{what}: {bad.sum()} / {bad.size} elements off, max err {np.abs(got - ref).max()}"
+
+
+# ------------------------------------------------------------------------------------------- K1
+def test_embedding_exact():
+    rng = np.random.default_rng(0)
+    V, Hd, T = 1000, 256, 37
+    E, Eb = h16(rng.standard_normal((V, Hd)))
+    ids = rng.integers(0, V, T).astype(np.int64)
+    d_out = nvr.DeviceBuffer(T * Hd * 2)
+    nvr.check(nvr.lib().nvr_embedding(dev(ids).ptr, T, dev(Eb).ptr, Hd, d_out.ptr, None))
+    got = d_out.to_numpy((T, Hd), F16)
+    assert np.array_equal(got.view(np.uint16), Eb[ids].view(np.uint16))
+
+
+# ------------------------------------------------------------------------------------------- K2 / K11
+@pytest.mark.parametrize("T,Hd", [(1, 64), (5, 1024), (33, 4096), (32, 1024)])
+def test_rmsnorm(T, Hd):
+    rng = np.random.default_rng(1)
+    x, xb = h16(rng.standard_normal((T, Hd)) * 3)
+    w, wb = h16(1 + 0.1 * rng.standard_normal(Hd))
+    d_out = nvr.DeviceBuffer(T * Hd * 2)
+    nvr.check(nvr.lib().nvr_rmsnorm(dev(xb).ptr, dev(wb).ptr, 1e-6, T, Hd, d_out.ptr, None))
+    ref = oracle.round_f16(oracle.rmsnorm(x, w, 1e-6))
+    assert_close_f16(d_out.to_numpy((T, Hd), F16), ref, ulps=1, atol=1e-6, what="rmsnorm")
+
+
+def test_rmsnorm_extreme_magnitudes_finite():        # layernorm.rs:277-311
+    for mag in (6e-5, 6e4):
+        xb = np.full((2, 64), mag, F16)
+        d_out = nvr.DeviceBuffer(2 * 64 * 2)
+        nvr.check(nvr.lib().nvr_rmsnorm(dev(xb).ptr, dev(np.ones(64, F16)).ptr, 1e-8, 2, 64, d_out.ptr, None))
+        assert np.isfinite(d_out.to_numpy((2, 64), F16).astype(np.float32)).all()
+
+
+@pytest.mark.parametrize("T,Hd", [(3, 64), (32, 1024)])
+def test_add_rmsnorm(T, Hd):
+    rng = np.random.default_rng(2)
+    h, hb = h16(rng.standard_normal((T, Hd)))
+    y, yb = h16(rng.standard_normal((T, Hd)))
+    w, wb = h16(1 + 0.1 * rng.standard_normal(Hd))
+    d_h, d_out = dev(hb), nvr.DeviceBuffer(T * Hd * 2)
+    nvr.check(nvr.lib().nvr_add_rmsnorm(d_h.ptr, dev(yb).ptr, dev(wb).ptr, 1e-6, T, Hd, d_out.ptr, None))
+    hn = oracle.add(h, y, round16=True)
+    assert np.array_equal(d_h.to_numpy((T, Hd), F16).astype(np.float32), hn), "residual add must be bit-exact"
+    assert_close_f16(d_out.to_numpy((T, Hd), F16), oracle.round_f16(oracle.rmsnorm(hn, w, 1e-6)), ulps=1, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------- linear
+@pytest.mark.parametrize("T,K,N,f32", [(1, 64, 64, False), (7, 128, 48, False), (32, 1024, 4096, False),
+                                       (32, 2048, 1024, False), (33, 1024, 256, False), (32, 3072, 1024, False),
+                                       (16, 1024, 6144, False), (4, 256, 1024, True), (32, 1024, 16 * 1187, True),
+                                       (100, 512, 512, False)])
+def test_linear(T, K, N, f32):
+    rng = np.random.default_rng(3)
+    x, xb = h16(rng.standard_normal((T, K)))
+    W, Wb = h16(rng.standard_normal((N, K)) * 0.05)
+    d_y = nvr.DeviceBuffer(T * N * (4 if f32 else 2))
+    nvr.check(nvr.lib().nvr_linear(dev(xb).ptr, K, dev(Wb).ptr, T, K, N, d_y.ptr, int(f32), None))
+    ref = oracle.linear(x, W)
+    if f32:
+        got = d_y.to_numpy((T, N), np.float32)
+        np.testing.assert_allclose(got, ref, rtol=2e-5, atol=2e-4)     # f32 accumulate, different order
+    else:
+        assert_close_f16(d_y.to_numpy((T, N), F16), oracle.round_f16(ref), ulps=1, atol=2e-4, what="linear")
+
+
+def test_linear_strided_input_and_errors():
+    rng = np.random.default_rng(4)
+    T, K, N, ld = 5, 64, 32, 192
+    buf, bb = h16(rng.standard_normal((T, ld)))
+    W, Wb = h16(rng.standard_normal((N, K)) * 0.1)
+    d_y = nvr.DeviceBuffer(T * N * 2)
+    d_x = dev(bb)
+    nvr.check(nvr.lib().nvr_linear(d_x.ptr + 64 * 2, ld, dev(Wb).ptr, T, K, N, d_y.ptr, 0, None))
+    assert_close_f16(d_y.to_numpy((T, N), F16), oracle.round_f16(oracle.linear(buf[:, 64:128], W)), ulps=1, atol=2e-4)
+    assert nvr.lib().nvr_linear(d_x.ptr, ld, dev(Wb).ptr, T, 40, N, d_y.ptr, 0, None) == -10   # K % 32 != 0
+
+
+# ------------------------------------------------------------------------------------------- K5 + K6
+@pytest.mark.parametrize("H,KVH,D,T", [(4, 2, 64, 9), (16, 8, 128, 32), (2, 2, 128, 3)])
+def test_rope_store_kv(H, KVH, D, T):
+    rng = np.random.default_rng(5)
+    NB, bs, max_pos = 6, 16, 200
+    QKV = (H + 2 * KVH) * D
+    qkv, qkvb = h16(rng.standard_normal((T, QKV)))
+    pos = rng.integers(0, max_pos, T).astype(np.int64)
+    slots = rng.permutation(NB * bs)[:T].astype(np.int32)
+    slots[0] = -1                                                   # skipped token
+    cos, sin = oracle.rope_table(D, max_pos, 1e6)
+    d_cos, d_sin = nvr.DeviceBuffer(cos.nbytes), nvr.DeviceBuffer(sin.nbytes)
+    nvr.check(nvr.lib().nvr_rope_table(D, max_pos, 1e6, d_cos.ptr, d_sin.ptr))
+    assert np.array_equal(d_cos.to_numpy(cos.shape, np.float32), cos), "RoPE tables must be bit-identical to the oracle's"
+    assert np.array_equal(d_sin.to_numpy(sin.shape, np.float32), sin)
+    d_qkv = dev(qkvb)
+    d_k, d_v = nvr.DeviceBuffer(NB * bs * KVH * D * 2), nvr.DeviceBuffer(NB * bs * KVH * D * 2)
+    d_k.zero(); d_v.zero()
+    nvr.check(nvr.lib().nvr_rope_store_kv(d_qkv.ptr, dev(pos).ptr, dev(slots).ptr, T, H, KVH, D, d_cos.ptr, d_sin.ptr,
+                                          d_k.ptr, d_v.ptr, None))
+    q = oracle.round_f16(oracle.rope_apply(qkv[:, :H * D].reshape(T, H, D), pos, cos, sin))
+    k = oracle.round_f16(oracle.rope_apply(qkv[:, H * D:(H + KVH) * D].reshape(T, KVH, D), pos, cos, sin))
+    v = np.ascontiguousarray(qkv[:, (H + KVH) * D:].reshape(T, KVH, D))
+    kc, vc = np.zeros((NB, bs, KVH, D), np.float32), np.zeros((NB, bs, KVH, D), np.float32)
+    oracle.kv_store(k, v, slots, kc, vc)
+    got = d_qkv.to_numpy((T, QKV), F16).astype(np.float32)
+    # no-contraction f32 math on both sides: rope is bit-exact
+    assert np.array_equal(got[:, :H * D].reshape(T, H, D), q)
+    assert np.array_equal(got[:, H * D:(H + KVH) * D].reshape(T, KVH, D), k)
+    assert np.array_equal(d_k.to_numpy(kc.shape, F16).astype(np.float32), kc)
+    assert np.array_equal(d_v.to_numpy(vc.shape, F16).astype(np.float32), vc)
+
+
+# ------------------------------------------------------------------------------------------- K9
+def _paged_case(rng, B, H, KVH, D, bs, ctx_lens, NB):
+    max_blocks = max((c + bs - 1) // bs for c in ctx_lens) + 1
+    kc, kcb = h16(rng.standard_normal((NB, bs, KVH, D)))
+    vc, vcb = h16(rng.standard_normal((NB, bs, KVH, D)))
+    bt = -np.ones((B, max_blocks), np.int32)
+    perm = rng.permutation(NB)
+    o = 0
+    for b, c in enumerate(ctx_lens):
+        nb = (c + bs - 1) // bs
+        bt[b, :nb] = perm[o:o + nb]; o += nb
+    return kc, kcb, vc, vcb, bt, max_blocks
+
+
+@pytest.mark.parametrize("B,H,KVH,D,bs,ctxs", [
+    (3, 4, 2, 64, 16, [1, 17, 40]),                     # partial last block, GQA 2:1, D=64
+    (4, 16, 8, 128, 256, [1, 255, 256, 700]),           # Qwen3-0.6B head shape, block size 256
+    (2, 32, 8, 128, 256, [513, 1024]),                  # Qwen3-8B group of 4
+    (5, 8, 8, 128, 16, [5, 16, 31, 32, 33]),            # MHA (group 1)
+    (32, 16, 8, 128, 256, [1024] * 32),                 # BASELINE config 2 decode shape (one layer)
+    (1, 16, 8, 128, 256, [3000]),                       # long context, single sequence: many partitions
+])
+def test_paged_attn_decode(B, H, KVH, D, bs, ctxs):
+    rng = np.random.default_rng(6)
+    NB = sum((c + bs - 1) // bs for c in ctxs) + 3
+    kc, kcb, vc, vcb, bt, max_blocks = _paged_case(rng, B, H, KVH, D, bs, ctxs, NB)
+    q, qb = h16(rng.standard_normal((B, H, D)))
+    ctx = np.asarray(ctxs, np.int32)
+    scale = float(np.float32(1.0) / np.sqrt(np.float32(D)))
+    meta = nvr.AttnMetaC()
+    d_ctx, d_bt = dev(ctx), dev(bt)
+    meta.is_prefill, meta.context_lens, meta.block_tables = 0, d_ctx.ptr, d_bt.ptr
+    meta.max_blocks, meta.batch, meta.max_context_len = max_blocks, B, int(max(ctxs))
+    ws = nvr.DeviceBuffer(nvr.lib().nvr_paged_attn_workspace_bytes(B, H, D, int(max(ctxs))))
+    d_out = nvr.DeviceBuffer(B * H * D * 2)
+    nvr.check(nvr.lib().nvr_paged_attn_decode(dev(qb).ptr, H * D, dev(kcb).ptr, dev(vcb).ptr, C.byref(meta), H, KVH, D, bs,
+                                              scale, d_out.ptr, ws.ptr, None))
+    ref = oracle.round_f16(oracle.attn_decode(q, kc, vc, bt, ctx, scale))
+    # tolerance: f32 online softmax vs two-pass softmax; outputs are O(1): 2 fp16 ulp + 1e-3 abs
+    assert_close_f16(d_out.to_numpy((B, H, D), F16), ref, ulps=2, atol=1e-3, what="paged decode attention")
+
+
+def test_paged_attn_ignores_garbage_beyond_context():
+    """A-8: exactly context_lens[b] keys are visible; poison everything else (incl. -1 padded table slots)."""
+    rng = np.random.default_rng(7)
+    B, H, KVH, D, bs = 2, 4, 2, 64, 16
+    ctxs = [19, 33]
+    NB = 8
+    kc, kcb, vc, vcb, bt, max_blocks = _paged_case(rng, B, H, KVH, D, bs, ctxs, NB)
+    q, qb = h16(rng.standard_normal((B, H, D)))
+    kcb2, vcb2 = kcb.copy(), vcb.copy()
+    for b, c in enumerate(ctxs):
+        blk, off = bt[b, c // bs], c % bs
+        if blk >= 0:
+            kcb2[blk, off:] = F16(6e4); vcb2[blk, off:] = F16(6e4)
+    used = set(bt[bt >= 0].tolist())
+    for blk in range(NB):
+        if blk not in used:
+            kcb2[blk] = F16(np.nan); vcb2[blk] = F16(np.nan)
+    scale = 0.125
+    outs = []
+    for kb, vb in ((kcb, vcb), (kcb2, vcb2)):
+        meta = nvr.AttnMetaC()
+        d_ctx, d_bt = dev(np.asarray(ctxs, np.int32)), dev(bt)
+        meta.context_lens, meta.block_tables, meta.max_blocks, meta.batch, meta.max_context_len = d_ctx.ptr, d_bt.ptr, max_blocks, B, 33
+        ws = nvr.DeviceBuffer(nvr.lib().nvr_paged_attn_workspace_bytes(B, H, D, 33))
+        d_out = nvr.DeviceBuffer(B * H * D * 2)
+        nvr.check(nvr.lib().nvr_paged_attn_decode(dev(qb).ptr, H * D, dev(kb).ptr, dev(vb).ptr, C.byref(meta), H, KVH, D, bs, scale,
+                                                  d_out.ptr, ws.ptr, None))
+        outs.append(d_out.to_numpy((B, H, D), F16))
+    assert np.array_equal(outs[0].view(np.uint16), outs[1].view(np.uint16))
+
+
+def test_online_softmax_rescale_branch_forced():
+    """cdna guide rule 26: force the running-max rescale with a spiked key late in the context."""
+    rng = np.random.default_rng(8)
+    B, H, KVH, D, bs, c = 1, 2, 1, 128, 16, 400
+    NB = c // bs + 2
+    kc, kcb, vc, vcb, bt, max_blocks = _paged_case(rng, B, H, KVH, D, bs, [c], NB)
+    q, qb = h16(rng.standard_normal((B, H, D)))
+    for tok in (70, 333):                               # keys aligned with q -> score jumps by ~ +|q|^2
+        blk, off = bt[0, tok // bs], tok % bs
+        kcb[blk, off, 0] = (q[0, 0] * (2.0 if tok == 333 else 1.0)).astype(F16)
+    kc = kcb.astype(np.float32)
+    scale = float(1 / np.sqrt(np.float32(D)))
+    meta = nvr.AttnMetaC()
+    d_ctx, d_bt = dev(np.asarray([c], np.int32)), dev(bt)
+    meta.context_lens, meta.block_tables, meta.max_blocks, meta.batch, meta.max_context_len = d_ctx.ptr, d_bt.ptr, max_blocks, B, c
+    ws = nvr.DeviceBuffer(nvr.lib().nvr_paged_attn_workspace_bytes(B, H, D, c))
+    d_out = nvr.DeviceBuffer(B * H * D * 2)
+    nvr.check(nvr.lib().nvr_paged_attn_decode(dev(qb).ptr, H * D, dev(kcb).ptr, dev(vcb).ptr, C.byref(meta), H, KVH, D, bs, scale,
+                                              d_out.ptr, ws.ptr, None))
+    ref = oracle.round_f16(oracle.attn_decode(q, kc, vc, bt, np.asarray([c], np.int32), scale))
+    assert_close_f16(d_out.to_numpy((B, H, D), F16), ref, ulps=2, atol=1e-3)
+
+
+# ------------------------------------------------------------------------------------------- K7
+@pytest.mark.parametrize("H,KVH,D,lens", [(4, 2, 64, [1, 5, 33]), (16, 8, 128, [70, 129]), (8, 8, 128, [17])])
+def test_attn_prefill_varlen(H, KVH, D, lens):
+    rng = np.random.default_rng(9)
+    T = sum(lens)
+    QKV = (H + 2 * KVH) * D
+    qkv, qkvb = h16(rng.standard_normal((T, QKV)))
+    cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    scale = float(np.float32(1.0) / np.sqrt(np.float32(D)))
+    d_qkv, d_cu, d_out = dev(qkvb), dev(cu), nvr.DeviceBuffer(T * H * D * 2)
+    meta = nvr.AttnMetaC()
+    meta.is_prefill, meta.cu_seqlens_q, meta.cu_seqlens_k = 1, d_cu.ptr, d_cu.ptr
+    meta.max_seqlen_q = meta.max_seqlen_k = int(max(lens)); meta.batch = len(lens)
+    nvr.check(nvr.lib().nvr_attn_prefill_varlen(d_qkv.ptr, d_qkv.ptr + H * D * 2, d_qkv.ptr + (H + KVH) * D * 2, QKV, C.byref(meta),
+                                                T, H, KVH, D, scale, d_out.ptr, None))
+    q = np.ascontiguousarray(qkv[:, :H * D].reshape(T, H, D))
+    k = np.ascontiguousarray(qkv[:, H * D:(H + KVH) * D].reshape(T, KVH, D))
+    v = np.ascontiguousarray(qkv[:, (H + KVH) * D:].reshape(T, KVH, D))
+    ref = oracle.round_f16(oracle.attn_prefill_varlen(q, k, v, cu, scale))
+    assert_close_f16(d_out.to_numpy((T, H, D), F16), ref, ulps=2, atol=1e-3, what="varlen prefill attention")
+
+
+# ------------------------------------------------------------------------------------------- K13 / K15
+def test_silu_and_mul():
+    rng = np.random.default_rng(10)
+    T, I = 32, 3072
+    x, xb = h16(rng.standard_normal((T, 2 * I)) * 2)
+    d_out = nvr.DeviceBuffer(T * I * 2)
+    nvr.check(nvr.lib().nvr_silu_and_mul(dev(xb).ptr, T, I, d_out.ptr, None))
+    # device __expf vs host expf: <= 1 fp16 ulp after rounding
+    assert_close_f16(d_out.to_numpy((T, I), F16), oracle.round_f16(oracle.silu_and_mul(x)), ulps=1, atol=1e-6)
+
+
+def test_select_last_tokens_exact():
+    rng = np.random.default_rng(11)
+    lens, Hd = [3, 1, 7], 128
+    h, hb = h16(rng.standard_normal((sum(lens), Hd)))
+    cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    d_out = nvr.DeviceBuffer(3 * Hd * 2)
+    nvr.check(nvr.lib().nvr_select_last_tokens(dev(hb).ptr, dev(cu).ptr, 3, Hd, d_out.ptr, None))
+    assert np.array_equal(d_out.to_numpy((3, Hd), F16).view(np.uint16), hb[cu[1:] - 1].view(np.uint16))
+
+
+# ------------------------------------------------------------------------------------------- K17 / K18
+def test_argmax_exact_with_ties():
+    rng = np.random.default_rng(12)
+    B, V = 33, 151936
+    x = rng.standard_normal((B, V)).astype(np.float32)
+    x[0, [5, 77777, 151935]] = 9.0                     # tie -> lowest index (A-12)
+    x[1, V - 1] = 50.0
+    x[2, 0] = 50.0
+    x[3] = -np.inf; x[3, 1234] = -1e30
+    d_out = nvr.DeviceBuffer(B * 8)
+    nvr.check(nvr.lib().nvr_argmax(dev(x).ptr, B, V, d_out.ptr, None))
+    got = d_out.to_numpy((B,), np.int64)
+    assert got.tolist() == [oracle.argmax(x[b]) for b in range(B)]
+    assert got[0] == 5 and got[1] == V - 1 and got[2] == 0 and got[3] == 1234
+    for kat, want in (([1.0, 2.0, 5.0, 1.5], 2), ([1.0, 2.0, 3.0], 2)):      # sampler.rs:333-356
+        nvr.check(nvr.lib().nvr_argmax(dev(np.asarray(kat, np.float32)).ptr, 1, len(kat), d_out.ptr, None))
+        assert d_out.to_numpy((1,), np.int64)[0] == want
+
+
+def _gpu_sample(x, temps, top_k, top_p, keys):
+    B, V = x.shape
+    ws = nvr.DeviceBuffer(nvr.lib().nvr_sample_workspace_bytes(B, V))
+    d_out = nvr.DeviceBuffer(B * 8)
+    nvr.check(nvr.lib().nvr_sample(dev(x).ptr, B, V, dev(np.asarray(temps, np.float32)).ptr,
+                                   dev(np.asarray(top_k, np.int64)).ptr, dev(np.asarray(top_p, np.float32)).ptr,
+                                   dev(np.asarray(keys, np.uint64)).ptr, d_out.ptr, ws.ptr, None))
+    return d_out.to_numpy((B,), np.int64), ws.to_numpy((B, V), np.float32)
+
+
+def test_sampler_filters_match_reference_kats():
+    # top-k=3 of [1,5,2,4,3] -> [-inf,5,-inf,4,3] (sampler.rs:359-374); top-p 0.9 of [0,10,5,1] keeps idx 1 (:377-389)
+    x = np.asarray([[1, 5, 2, 4, 3]], np.float32)
+    tok, w = _gpu_sample(x, [1.0], [3], [-1.0], [1])
+    assert w[0].tolist() == [-np.inf, 5.0, -np.inf, 4.0, 3.0] and tok[0] in (1, 3, 4)
+    x = np.asarray([[0, 10, 5, 1]], np.float32)
+    tok, w = _gpu_sample(x, [1.0], [0], [0.9], [1])
+    assert w[0, 1] == 10.0 and np.isinf(w[0, [0, 2, 3]]).all() and tok[0] == 1
+    # ties at the top-k threshold keep the lowest indices (stable sort, A-19)
+    x = np.asarray([[2, 7, 7, 7, 1, 7]], np.float32)
+    _, w = _gpu_sample(x, [1.0], [2], [-1.0], [1])
+    assert w[0].tolist() == [-np.inf, 7.0, 7.0, -np.inf, -np.inf, -np.inf]
+    assert w[0].tolist() == oracle.top_k(x[0], 2).tolist()
+
+
+@pytest.mark.parametrize("V", [1000, 151936])
+def test_sampler_matches_oracle(V):
+    rng = np.random.default_rng(13)
+    B = 12
+    x = (rng.standard_normal((B, V)) * 3).astype(np.float32)
+    temps = [0.0, 1.0, 0.7, 1.3, 1.0, 0.5, 1.0, 2.0, 1.0, 0.9, 1.0, 0.0]
+    top_k = [0, 0, 50, 0, 5, 0, 1, 0, 200, 40, V + 5, 7]
+    top_p = [-1, -1, -1, 0.9, 0.5, 0.95, -1, 0.3, 0.8, 1.0, -1, 0.5]
+    keys = [oracle.sample_key(123, b, 4) for b in range(B)]
+    assert [nvr.lib().nvr_sample_key(123, b, 4) for b in range(B)] == keys
+    tok, w = _gpu_sample(x, temps, top_k, top_p, keys)
+    exact = 0
+    for b in range(B):
+        ref = oracle.sample(x[b], temps[b], top_k[b], None if top_p[b] < 0 else top_p[b], keys[b])
+        if temps[b] == 0.0:
+            assert tok[b] == ref                         # greedy: bit-exact
+            continue
+        # the kept set must equal the oracle's, up to the single marginal element where an f32
+        # cumulative sum lands within rounding of p (A-19/A-20: stochastic path is tolerance-tested)
+        a = x[b] / np.float32(temps[b]) if temps[b] != 1.0 else x[b]
+        if top_k[b] > 0:
+            a = oracle.top_k(a, top_k[b])
+        if top_p[b] >= 0:
+            a = oracle.top_p(a, top_p[b])
+        kept_ref, kept_gpu = np.isfinite(a), np.isfinite(w[b])
+        assert (kept_ref != kept_gpu).sum() <= 1, f"row {b}: kept sets differ in {(kept_ref != kept_gpu).sum()} places"
+        exact += int(tok[b] == ref)
+        assert kept_gpu[tok[b]]
+    assert exact >= B - 3 - 2                            # Gumbel argmax over (nearly) identical sets
+
+
+def test_fill_weight_bit_exact_with_oracle():
+    rows, cols, gcols = 37, 96, 512
+    key = oracle.weight_key(7, 1234)
+    assert nvr.lib().nvr_weight_key(7, 1234) == key
+    sc = oracle.weight_scale(0.02)
+    assert nvr.lib().nvr_weight_scale(0.02) == np.float32(sc)
+    d = nvr.DeviceBuffer(rows * cols * 2)
+    nvr.check(nvr.lib().nvr_fill_weight(d.ptr, rows, cols, cols, gcols, 5, 64, key, sc, None))
+    ref = oracle.fill_weight(rows, cols, gcols, 5, 64, key, sc, True)
+    assert np.array_equal(d.to_numpy((rows, cols), F16).astype(np.float32), ref)
+    assert abs(ref.std() - 0.02) < 0.003
