@@ -144,8 +144,8 @@ def main() -> None:
         dist.init_process_group("gloo", rank=rank, world_size=world)
 
     total_new = args.warmup + args.steps + 1
-    cfg = nvr.Config(max_num_seqs=BATCH, max_num_batched_tokens=BATCH * PROMPT_LEN, max_model_len=PROMPT_LEN + total_new + 8,
-                     kvcache_block_size=BLOCK, num_kvcache_blocks=BATCH * ((PROMPT_LEN + total_new) // BLOCK + 2),
+    cfg = nvr.Config(max_num_seqs=BATCH, max_num_batched_tokens=BATCH * PROMPT_LEN, max_model_len=PROMPT_LEN + total_new + 16,
+                     kvcache_block_size=BLOCK, num_kvcache_blocks=BATCH * ((PROMPT_LEN + total_new + 16) // BLOCK + 2),
                      tensor_parallel_size=args.gpus, tensor_parallel_rank=rank, device_ordinal=local_rank)
     mc = nvr.ModelConfig("qwen3-0.6b")
     nvr.check(nvr.lib().nvr_device_set(local_rank))
@@ -160,7 +160,7 @@ def main() -> None:
 
     for i in range(BATCH):                   # synthetic prompts, SURVEY §8d: seed 1, one stream per sequence
         eng.add_request(nvr.synthetic_tokens(PROMPT_LEN, 1, i, mc.c.vocab_size).tolist(),
-                        nvr.SamplingParams(temperature=0.0, max_tokens=total_new, ignore_eos=True))
+                        nvr.SamplingParams(temperature=0.0, max_tokens=total_new + 8, ignore_eos=True))
 
     def barrier():
         nvr.synchronize()

@@ -25,8 +25,21 @@ def _device():
     nvr.synchronize()
 
 
+_KEEP = []          # device buffers stay alive until the test ends (a temporary would be hipFree'd
+                    # as soon as its .ptr has been read, before the asynchronous kernel runs)
+
+
 def dev(a):
-    return nvr.DeviceBuffer.from_numpy(np.ascontiguousarray(a))
+    b = nvr.DeviceBuffer.from_numpy(np.ascontiguousarray(a))
+    _KEEP.append(b)
+    return b
+
+
+@pytest.fixture(autouse=True)
+def _release_buffers():
+    yield
+    nvr.synchronize()
+    _KEEP.clear()
 
 
 def h16(a):
