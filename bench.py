@@ -104,7 +104,10 @@ def cpu_baseline(decode_steps: int = 12) -> dict:
     """Oracle engine on BASELINE.json configs[0]: Qwen3-0.6B f32, bs=1, prompt 128, greedy (a port)."""
     import oracle
     from oracle import engine_oracle as eo, model_oracle as mo
-    cores = oracle.lib().nvo_num_threads()
+    # threads actually used: the CPUs this process may run on (affinity and cgroup quota), capped at 32 —
+    # the GPU box reports 256 logical CPUs, but an OpenMP team wider than the usable cores only spins
+    cores = oracle.usable_cores()
+    oracle.lib().nvo_set_num_threads(cores)
     mcfg = mo.qwen3_0_6b()
     eo.reset_sequence_counter()
     eng = mo.OracleEngine(mcfg, eo.Config(kvcache_block_size=256, num_kvcache_blocks=2, max_num_seqs=1,

@@ -14,6 +14,14 @@ typedef float float16_t __attribute__((ext_vector_type(16)));
 
 constexpr int kWave = 64;
 
+// f32 -> fp16, round-to-nearest-even, as a standalone conversion.  The empty asm makes the f32 value
+// opaque so that hipcc (-ffp-contract=fast) cannot fold the producing multiply/add into a single-rounding
+// v_fma_mixlo_f16: the oracle rounds twice (f32 op, then fp16), and bit-exact parity needs the same.
+__device__ __forceinline__ half_t to_half_rn(float f) {
+    asm volatile("" : "+v"(f));
+    return (half_t)f;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

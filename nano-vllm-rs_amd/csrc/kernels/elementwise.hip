@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(half_t *__restrict__ h, co
         if (ADD) {
             half8_t u = *reinterpret_cast<const half8_t *>(yr + c);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = (half_t)((float)v[j] + (float)u[j]);
+            for (int j = 0; j < 8; ++j) v[j] = to_half_rn((float)v[j] + (float)u[j]);
             *reinterpret_cast<half8_t *>(hr + c) = v;
         }
 #pragma unroll
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(half_t *__restrict__ h, co
         half8_t g = *reinterpret_cast<const half8_t *>(w + c);
         half8_t o;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = (half_t)(__fdiv_rn((float)v[j], rms) * (float)g[j]);
+        for (int j = 0; j < 8; ++j) o[j] = to_half_rn(__fmul_rn(__fdiv_rn((float)v[j], rms), (float)g[j]));
         *reinterpret_cast<half8_t *>(orow + c) = o;
     }
 }
@@ -101,7 +101,7 @@ __global__ void silu_mul_kernel(const half_t *__restrict__ x, int I, half_t *__r
         for (int j = 0; j < 8; ++j) {
             float gf = (float)g[j];
             float sg = 1.0f / (1.0f + __expf(-gf));
-            o[j] = (half_t)((gf * sg) * (float)u[j]);
+            o[j] = to_half_rn(__fmul_rn(__fmul_rn(gf, sg), (float)u[j]));
         }
         *reinterpret_cast<half8_t *>(out + t * I + c) = o;
     }
@@ -160,8 +160,8 @@ __global__ __launch_bounds__(256) void rope_store_kernel(half_t *__restrict__ qk
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float a = (float)x1[e], b = (float)x2[e], cs = c[j + e], si = sn[j + e];
-                o1[e] = (half_t)__fsub_rn(__fmul_rn(a, cs), __fmul_rn(b, si));
-                o2[e] = (half_t)__fadd_rn(__fmul_rn(b, cs), __fmul_rn(a, si));
+                o1[e] = to_half_rn(__fsub_rn(__fmul_rn(a, cs), __fmul_rn(b, si)));
+                o2[e] = to_half_rn(__fadd_rn(__fmul_rn(b, cs), __fmul_rn(a, si)));
             }
             *reinterpret_cast<half8_t *>(x + j) = o1;
             *reinterpret_cast<half8_t *>(x + j + half_d) = o2;
@@ -234,7 +234,7 @@ __global__ void fill_weight_kernel(half_t *__restrict__ dst, int64_t rows, int64
     const int64_t total = rows * cols;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = i / cols, c = i % cols;
-        dst[r * ld + c] = (half_t)weight_value(key, (uint64_t)((row0 + r) * gcols + (col0 + c)), scale);
+        dst[r * ld + c] = to_half_rn(weight_value(key, (uint64_t)((row0 + r) * gcols + (col0 + c)), scale));
     }
 }
 int fill_weight(half_bits *dst, int64_t rows, int64_t cols, int64_t ld, int64_t global_cols, int64_t row0,

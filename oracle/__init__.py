@@ -25,6 +25,19 @@ def build(force: bool = False) -> str:
 _lib = None
 
 
+def usable_cores(cap: int = 32) -> int:
+    """CPUs this process may actually run on (affinity + cgroup quota), capped: an OpenMP team wider
+    than that only spins (the GPU box reports 256 logical CPUs to a container with far fewer)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, cap))
+
+
 def lib() -> C.CDLL:
     global _lib
     if _lib is None:
@@ -32,6 +45,7 @@ def lib() -> C.CDLL:
             build()
         _lib = C.CDLL(_LIB_PATH)
         _declare(_lib)
+        _lib.nvo_set_num_threads(usable_cores())
     return _lib
 
 
