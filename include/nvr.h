@@ -267,6 +267,16 @@ NVR_API int nvr_add_rmsnorm(nvr_half *h, const nvr_half *y, const nvr_half *w, f
 /* K3/K10/K12/K14/K16 y = x·Wᵀ; x [T,K] (row stride ldx), W [N,K], y [T,N] fp16 or f32 */
 NVR_API int nvr_linear(const nvr_half *x, int64_t ldx, const nvr_half *W, int64_t T, int64_t K, int64_t N,
                        void *y, int y_is_f32, void *stream);
+/* K12+K13 fused: out[T,I] = SiluAndMul(x · W_gate_upᵀ), W [2I,K] gate rows then up rows
+ * (MergedColumnParallelLinear::forward linear.rs:437-439 + SiluAndMul::forward activation.rs:46-63) */
+NVR_API int nvr_linear_silu_mul(const nvr_half *x, int64_t ldx, const nvr_half *W, int64_t T, int64_t K, int64_t I,
+                                nvr_half *out, void *stream);
+/* K3..K6 fused: qkv = x · W_qkvᵀ (QKVParallelLinear linear.rs:354-356), RoPE on the q and k heads
+ * (rotary_embedding.rs:145-158), k,v rows stored at slot_mapping (attention.rs:150-174) */
+NVR_API int nvr_linear_qkv_rope_store(const nvr_half *x, int64_t ldx, const nvr_half *W, int64_t T, int64_t K,
+                                      int64_t H, int64_t KVH, int64_t D, const int64_t *positions,
+                                      const int32_t *slot_mapping, const float *cos_t, const float *sin_t,
+                                      nvr_half *qkv, nvr_half *k_cache, nvr_half *v_cache, void *stream);
 /* K5+K6 RoPE (rotary_embedding.rs:23-48) on the q and k heads of a packed qkv buffer
  * [T, (H+2KVH)*D] in place, then store k,v rows to the caches at slot_mapping (attention.rs:150-174) */
 NVR_API int nvr_rope_store_kv(nvr_half *qkv, const int64_t *positions, const int32_t *slot_mapping, int64_t T,

@@ -159,6 +159,9 @@ _SIGS = {
     "nvr_rmsnorm": (C.c_int, [_P, _P, C.c_float, C.c_int64, C.c_int64, _P, _P]),
     "nvr_add_rmsnorm": (C.c_int, [_P, _P, _P, C.c_float, C.c_int64, C.c_int64, _P, _P]),
     "nvr_linear": (C.c_int, [_P, C.c_int64, _P, C.c_int64, C.c_int64, C.c_int64, _P, C.c_int, _P]),
+    "nvr_linear_silu_mul": (C.c_int, [_P, C.c_int64, _P, C.c_int64, C.c_int64, C.c_int64, _P, _P]),
+    "nvr_linear_qkv_rope_store": (C.c_int, [_P, C.c_int64, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _P, _P, _P, _P,
+                                            _P, _P, _P, _P]),
     "nvr_rope_store_kv": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _P, _P, _P, _P, _P]),
     "nvr_rope_table": (C.c_int, [C.c_int64, C.c_int64, C.c_double, _P, _P]),
     "nvr_paged_attn_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int64, C.c_int64]),

@@ -37,7 +37,7 @@ int embedding(const int64_t *ids, int64_t T, const half_bits *E, int64_t Hd, hal
 // reference: RMSNorm::forward_simple, src/layers/layernorm.rs:58-75 — f32: rms = sqrt(mean(x^2)+eps),
 // out = (x / rms) * w; fused variant: OptimizedRMSNorm::forward_with_residual, :170-176 —
 // h <- fp16(h + y), out = rmsnorm(h).  One wave per row, 4 rows per workgroup.
-template <bool ADD>
+template <bool ADD, int C>   // C = chunks of 512 elements per row kept in registers (0: re-read the row)
 __global__ __launch_bounds__(256) void rmsnorm_kernel(half_t *__restrict__ h, const half_t *__restrict__ y,
                                                       const half_t *__restrict__ w, float eps, int T, int Hd,
                                                       half_t *__restrict__ out) {
@@ -46,7 +46,47 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(half_t *__restrict__ h, co
     if (row >= T) return;
     half_t *hr = h + (int64_t)row * Hd;
     const half_t *yr = ADD ? y + (int64_t)row * Hd : nullptr;
+    half_t *orow = out + (int64_t)row * Hd;
     float ss = 0.f;
+    if (C > 0) {
+        // single pass: the row (and the weight) stay in registers; all loads are issued before the reduction
+        half8_t v[C > 0 ? C : 1], g[C > 0 ? C : 1], u[C > 0 ? C : 1];
+#pragma unroll
+        for (int i = 0; i < C; ++i) {
+            const int c = lane * 8 + i * 512;
+            if (c < Hd) {
+                v[i] = *reinterpret_cast<const half8_t *>(hr + c);
+                if (ADD) u[i] = *reinterpret_cast<const half8_t *>(yr + c);
+                g[i] = *reinterpret_cast<const half8_t *>(w + c);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < C; ++i) {
+            const int c = lane * 8 + i * 512;
+            if (c < Hd) {
+                if (ADD) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[i][j] = to_half_rn((float)v[i][j] + (float)u[i][j]);
+                    *reinterpret_cast<half8_t *>(hr + c) = v[i];
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { float f = (float)v[i][j]; ss += f * f; }
+            }
+        }
+        ss = wave_sum(ss);
+        const float rms = sqrtf(ss / (float)Hd + eps);
+#pragma unroll
+        for (int i = 0; i < C; ++i) {
+            const int c = lane * 8 + i * 512;
+            if (c < Hd) {
+                half8_t o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = to_half_rn(__fmul_rn(__fdiv_rn((float)v[i][j], rms), (float)g[i][j]));
+                *reinterpret_cast<half8_t *>(orow + c) = o;
+            }
+        }
+        return;
+    }
     for (int c = lane * 8; c < Hd; c += 512) {
         half8_t v = *reinterpret_cast<const half8_t *>(hr + c);
         if (ADD) {
@@ -60,7 +100,6 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(half_t *__restrict__ h, co
     }
     ss = wave_sum(ss);
     const float rms = sqrtf(ss / (float)Hd + eps);
-    half_t *orow = out + (int64_t)row * Hd;
     for (int c = lane * 8; c < Hd; c += 512) {
         half8_t v = *reinterpret_cast<const half8_t *>(hr + c);   // own writes: same lane, L1/L2 hit
         half8_t g = *reinterpret_cast<const half8_t *>(w + c);
@@ -70,11 +109,17 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(half_t *__restrict__ h, co
         *reinterpret_cast<half8_t *>(orow + c) = o;
     }
 }
+template <bool ADD>
+static void launch_rmsnorm(half_t *h, const half_t *y, const half_t *w, float eps, int T, int Hd, half_t *out, hipStream_t s) {
+    dim3 grid((unsigned)((T + 3) / 4)), block(256);
+    if (Hd <= 1024) rmsnorm_kernel<ADD, 2><<<grid, block, 0, s>>>(h, y, w, eps, T, Hd, out);
+    else if (Hd <= 4096) rmsnorm_kernel<ADD, 8><<<grid, block, 0, s>>>(h, y, w, eps, T, Hd, out);
+    else rmsnorm_kernel<ADD, 0><<<grid, block, 0, s>>>(h, y, w, eps, T, Hd, out);
+}
 int rmsnorm(const half_bits *x, const half_bits *w, float eps, int64_t T, int64_t Hd, half_bits *out, hipStream_t s) {
     if (Hd % 8) return nvr::fail(NVR_ERR_UNSUPPORTED, "rmsnorm: hidden size %ld not a multiple of 8", (long)Hd);
     if (T == 0) return 0;
-    rmsnorm_kernel<false><<<dim3((unsigned)((T + 3) / 4)), dim3(256), 0, s>>>(
-        (half_t *)x, nullptr, (const half_t *)w, eps, (int)T, (int)Hd, (half_t *)out);
+    launch_rmsnorm<false>((half_t *)x, nullptr, (const half_t *)w, eps, (int)T, (int)Hd, (half_t *)out, s);
     LAUNCH_CHECK();
     return 0;
 }
@@ -82,8 +127,7 @@ int add_rmsnorm(half_bits *h, const half_bits *y, const half_bits *w, float eps,
                 half_bits *out, hipStream_t s) {
     if (Hd % 8) return nvr::fail(NVR_ERR_UNSUPPORTED, "rmsnorm: hidden size %ld not a multiple of 8", (long)Hd);
     if (T == 0) return 0;
-    rmsnorm_kernel<true><<<dim3((unsigned)((T + 3) / 4)), dim3(256), 0, s>>>(
-        (half_t *)h, (const half_t *)y, (const half_t *)w, eps, (int)T, (int)Hd, (half_t *)out);
+    launch_rmsnorm<true>((half_t *)h, (const half_t *)y, (const half_t *)w, eps, (int)T, (int)Hd, (half_t *)out, s);
     LAUNCH_CHECK();
     return 0;
 }

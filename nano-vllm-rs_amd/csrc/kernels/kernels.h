@@ -29,6 +29,14 @@ int fill_const(half_bits *dst, int64_t n, float v, hipStream_t s);
 int linear(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t N, void *y,
            bool y_f32, hipStream_t s);
 
+// fused decode epilogues (same GEMM kernel): gate_up -> SiluAndMul, W [2I,K] -> out [T,I];
+// qkv -> RoPE(q,k) + KV store, W [(H+2KVH)D, K] -> qkv [T,(H+2KVH)D] (roped q,k; v) and cache rows at slots
+int linear_silu_mul(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t I,
+                    half_bits *out, hipStream_t s);
+int linear_qkv_rope_store(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t H,
+                          int64_t KVH, int64_t D, const int64_t *positions, const int32_t *slots, const float *cos_t,
+                          const float *sin_t, half_bits *qkv, half_bits *k_cache, half_bits *v_cache, hipStream_t s);
+
 // Attention over rows of keys addressed either through a block table (paged) or contiguously.
 struct AttnArgs {
     const half_bits *q; int64_t ldq;          // q[t] at q + t*ldq, heads contiguous [H, D]

@@ -1,39 +1,69 @@
-// linear.hip — y[T,N] = x[T,K] · W[N,K]^T on MFMA (K3/K10/K12/K14/K16).
-// reference call sites: QKVParallelLinear::forward src/layers/linear.rs:354-356, RowParallelLinear
-// :228-239, MergedColumnParallelLinear :437-439, ParallelLMHead::compute_logits
-// src/layers/embed_head.rs:292-306 (all `candle_nn::Linear::forward`, x·Wᵀ with W [out, in]).
+// linear.hip — y[T,N] = x[T,K] · W[N,K]^T on MFMA (K3/K10/K12/K14/K16), with the two epilogue fusions of
+// the decode path: gate_up -> SiluAndMul (K12+K13) and qkv -> RoPE + KV store (K3+K4+K5+K6).
+// reference call sites: QKVParallelLinear::forward src/layers/linear.rs:354-356 (+split_qkv :331-340),
+// RowParallelLinear :228-239, MergedColumnParallelLinear :437-439 (+SiluAndMul activation.rs:46-63),
+// ParallelLMHead::compute_logits src/layers/embed_head.rs:292-306; all `candle_nn::Linear::forward`,
+// x·Wᵀ with W [out, in]; RoPE src/layers/rotary_embedding.rs:23-48; store_kv_cache attention.rs:150-174.
 //
 // Weight-streaming kernel for the decode regime (T <= 64: every weight byte is read once from HBM
-// and the kernel is HBM-bound).  Roofline: algorithmic bytes = 2·N·K (weights) +
-// 2·T·K (x) + out; MFMA is used only because T=32 tokens x 8 k per 16-byte weight load exceeds
+// and the kernel is HBM/latency-bound).  Roofline: algorithmic bytes = 2·N·K (weights)
+// + 2·T·K (x) + out; MFMA is used only because T=32 tokens x 8 k per 16-byte weight load exceeds
 // the VALU rate at HBM speed (cdna_hip_programming.md §5 "GEMV / M <= 16" row: weights straight to
 // VGPRs, no LDS round trip).
 //
 // Tiling: v_mfma_f32_16x16x32_f16 with A = W tile (16 output columns n x 32 k: each lane loads 16
 // contiguous bytes of one W row, 4 lanes cover 64 B of the row) and B = x tile (16 tokens x 32 k,
-// L2 resident).  A workgroup = 4 waves owns NT*16 output columns for MT*16 tokens; the 4 waves
-// interleave 32-wide k steps (so together they read 256 contiguous bytes per W row per step) and
-// reduce their f32 partials through LDS.  Grid = (N/(16 NT), ceil(T/(16 MT))): for large T the
-// same kernel re-streams W from L2 per 16·MT-token slab (correct, not yet the tiled prefill GEMM).
+// L2 resident).  A workgroup = WAVES waves owns NT*16 output columns for MT*16 tokens; its waves
+// interleave 32-wide k steps (together they read 64·WAVES contiguous bytes per W row per step, all
+// k-steps of a small GEMM in flight at once) and reduce their f32 partials through LDS.
+// Grid = (N/(16 NT), ceil(T/(16 MT))): for large T the same kernel re-streams W from L2 per 16·MT-token
+// slab (correct, not yet the tiled prefill GEMM).
+//
+// Rounding points mirror the oracle (oracle/model_oracle.py): the f32 accumulator is rounded to fp16
+// where the unfused graph stores an fp16 tensor (qkv, gate_up), then the epilogue math runs in f32
+// without FMA contraction and is rounded again.
 #include "kernels.h"
 #include "device_utils.h"
 #include "../common.h"
 
 namespace nvr { namespace k {
 
-template <int NT, int MT, bool F32OUT>
-__global__ __launch_bounds__(256) void linear_skinny_kernel(const half_t *__restrict__ x, int64_t ldx,
-                                                            const half_t *__restrict__ W, int T, int K, int N,
-                                                            void *__restrict__ y) {
+enum { EPI_F16 = 0, EPI_F32 = 1, EPI_SILU = 2, EPI_ROPE = 3 };
+
+struct LinEpi {
+    // EPI_SILU: N is the intermediate size I; W holds gate rows [0,I) and up rows [I,2I)
+    // EPI_ROPE: qkv output [T, (H+2KVH)*D] + caches
+    const int64_t *pos; const int32_t *slots; const float *cos_t, *sin_t;
+    half_t *kc, *vc;
+    int32_t H, KVH, D;
+};
+
+// W row handled by local row r (0..15) of n-tile i of workgroup bx
+template <int EPI>
+__device__ __forceinline__ int w_row(int bx, int i, int NT, int r, int N, const LinEpi &e) {
+    if (EPI == EPI_SILU) return (i == 0 ? 0 : N) + bx * 16 + r;             // N == I here
+    if (EPI == EPI_ROPE) {
+        const int tph = e.D / 16, head = bx / tph, c = bx % tph;            // tiles per head
+        if (head < e.H + e.KVH) return head * e.D + (r < 8 ? c * 8 + r : e.D / 2 + c * 8 + (r - 8));
+        return head * e.D + c * 16 + r;
+    }
+    int n = (bx * NT + i) * 16 + r;
+    return n < N ? n : N - 1;
+}
+
+template <int NT, int MT, int WAVES, int EPI>
+__global__ __launch_bounds__(WAVES * 64) void linear_skinny_kernel(const half_t *__restrict__ x, int64_t ldx,
+                                                                   const half_t *__restrict__ W, int T, int K, int N,
+                                                                   void *__restrict__ y, LinEpi epi) {
     constexpr int U = 4;                                    // k-steps in flight per wave
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int r = lane & 15, q = lane >> 4;
-    const int n0 = blockIdx.x * (16 * NT), m0 = blockIdx.y * (16 * MT);
+    const int m0 = blockIdx.y * (16 * MT);
 
     const half_t *wrow[NT];
     const half_t *xrow[MT];
 #pragma unroll
-    for (int i = 0; i < NT; ++i) { int n = n0 + i * 16 + r; if (n > N - 1) n = N - 1; wrow[i] = W + (int64_t)n * K + q * 8; }
+    for (int i = 0; i < NT; ++i) wrow[i] = W + (int64_t)w_row<EPI>(blockIdx.x, i, NT, r, N, epi) * K + q * 8;
 #pragma unroll
     for (int i = 0; i < MT; ++i) { int m = m0 + i * 16 + r; if (m > T - 1) m = T - 1; xrow[i] = x + (int64_t)m * ldx + q * 8; }
 
@@ -43,14 +73,15 @@ __global__ __launch_bounds__(256) void linear_skinny_kernel(const half_t *__rest
 #pragma unroll
         for (int j = 0; j < MT; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
 
-    for (int k = wave * 32; k < K; k += 128 * U) {
+    constexpr int KS = 32 * WAVES;
+    for (int k = wave * 32; k < K; k += KS * U) {
         half8_t a[U][NT], b[U][MT];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int kk = k + u * 128;
+            const int kk = k + u * KS;
             if (kk < K) {
 #pragma unroll
-                for (int i = 0; i < NT; ++i) a[u][i] = *reinterpret_cast<const half8_t *>(wrow[i] + kk);
+                for (int i = 0; i < NT; ++i) a[u][i] = __builtin_nontemporal_load(reinterpret_cast<const half8_t *>(wrow[i] + kk));
 #pragma unroll
                 for (int j = 0; j < MT; ++j) b[u][j] = *reinterpret_cast<const half8_t *>(xrow[j] + kk);
             } else {
@@ -70,36 +101,105 @@ __global__ __launch_bounds__(256) void linear_skinny_kernel(const half_t *__rest
     }
 
     // cross-wave (split-k) reduction through LDS: part[wave][tile][lane] as float4
-    __shared__ float4_t part[4][NT * MT][64];
+    __shared__ float4_t part[WAVES][NT * MT][64];
 #pragma unroll
     for (int i = 0; i < NT; ++i)
 #pragma unroll
         for (int j = 0; j < MT; ++j) part[wave][i * MT + j][lane] = acc[i][j];
     __syncthreads();
-    for (int tile = wave; tile < NT * MT; tile += 4) {
+
+    auto reduce = [&](int tile) {
         float4_t s = part[0][tile][lane];
 #pragma unroll
-        for (int w2 = 1; w2 < 4; ++w2) { float4_t p = part[w2][tile][lane]; s += p; }
-        const int i = tile / MT, j = tile % MT;
-        // C layout of 16x16 MFMA: row (n) = q*4 + reg, col (token) = r
-        const int n = n0 + i * 16 + q * 4, m = m0 + j * 16 + r;
-        if (m < T && n < N) {
-            if (F32OUT) {
-                *reinterpret_cast<float4_t *>(reinterpret_cast<float *>(y) + (int64_t)m * N + n) = s;
-            } else {
-                half4_t h = {(half_t)s[0], (half_t)s[1], (half_t)s[2], (half_t)s[3]};
+        for (int w2 = 1; w2 < WAVES; ++w2) { float4_t pz = part[w2][tile][lane]; s += pz; }
+        return s;
+    };
+    // C layout of the 16x16 MFMA: row (n) = q*4 + reg, col (token) = r
+    if (EPI == EPI_F16 || EPI == EPI_F32) {
+        for (int tile = wave; tile < NT * MT; tile += WAVES) {
+            const float4_t s = reduce(tile);
+            const int i = tile / MT, j = tile % MT;
+            const int n = (blockIdx.x * NT + i) * 16 + q * 4, m = m0 + j * 16 + r;
+            if (m < T && n < N) {
+                if (EPI == EPI_F32) {
+                    *reinterpret_cast<float4_t *>(reinterpret_cast<float *>(y) + (int64_t)m * N + n) = s;
+                } else {
+                    half4_t h = {(half_t)s[0], (half_t)s[1], (half_t)s[2], (half_t)s[3]};
+                    *reinterpret_cast<half4_t *>(reinterpret_cast<half_t *>(y) + (int64_t)m * N + n) = h;
+                }
+            }
+        }
+    } else if (EPI == EPI_SILU) {
+        // tiles (0,j) = gate, (1,j) = up for the same 16 columns: act = fp16(silu(fp16 g) * fp16 u)
+        for (int j = wave; j < MT; j += WAVES) {
+            const float4_t g4 = reduce(j), u4 = reduce(MT + j);
+            const int n = blockIdx.x * 16 + q * 4, m = m0 + j * 16 + r;
+            if (m < T) {
+                half4_t h;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float gf = (float)to_half_rn(g4[e]), uf = (float)to_half_rn(u4[e]);
+                    const float sg = 1.0f / (1.0f + __expf(-gf));
+                    h[e] = to_half_rn(__fmul_rn(__fmul_rn(gf, sg), uf));
+                }
                 *reinterpret_cast<half4_t *>(reinterpret_cast<half_t *>(y) + (int64_t)m * N + n) = h;
+            }
+        }
+    } else {   // EPI_ROPE: NT == 1
+        const int tph = epi.D / 16, head = blockIdx.x / tph, c = blockIdx.x % tph, half_d = epi.D / 2;
+        const int64_t ldq = (int64_t)(epi.H + 2 * epi.KVH) * epi.D;
+        for (int j = wave; j < MT; j += WAVES) {
+            const float4_t s = reduce(j);
+            const int m = m0 + j * 16 + r;
+            const int mc = m < T ? m : T - 1;
+            float v[4], pv[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = (float)to_half_rn(s[e]); pv[e] = __shfl_xor(v[e], 32, 64); }
+            half4_t h;
+            int col;                                           // first of the lane's 4 consecutive head columns
+            if (head < epi.H + epi.KVH) {
+                const int jj = c * 8 + (q & 1) * 4;            // index inside the half dimension
+                const float4_t cs = *reinterpret_cast<const float4_t *>(epi.cos_t + epi.pos[mc] * half_d + jj);
+                const float4_t sn = *reinterpret_cast<const float4_t *>(epi.sin_t + epi.pos[mc] * half_d + jj);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    // rotary_embedding.rs:36-44: out1 = x1*c - x2*s ; out2 = x2*c + x1*s
+                    h[e] = (q < 2) ? to_half_rn(__fsub_rn(__fmul_rn(v[e], cs[e]), __fmul_rn(pv[e], sn[e])))
+                                   : to_half_rn(__fadd_rn(__fmul_rn(v[e], cs[e]), __fmul_rn(pv[e], sn[e])));
+                }
+                col = (q < 2) ? jj : half_d + jj;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) h[e] = to_half_rn(s[e]);
+                col = c * 16 + q * 4;
+            }
+            if (m < T) {
+                *reinterpret_cast<half4_t *>(reinterpret_cast<half_t *>(y) + (int64_t)m * ldq + head * epi.D + col) = h;
+                const int slot = epi.slots ? epi.slots[m] : -1;
+                if (slot >= 0 && head >= epi.H) {
+                    const bool is_k = head < epi.H + epi.KVH;
+                    const int kvh = is_k ? head - epi.H : head - epi.H - epi.KVH;
+                    half_t *dst = (is_k ? epi.kc : epi.vc) + ((int64_t)slot * epi.KVH + kvh) * epi.D + col;
+                    *reinterpret_cast<half4_t *>(dst) = h;
+                }
             }
         }
     }
 }
 
-template <int NT, int MT>
-static void launch(const half_t *x, int64_t ldx, const half_t *W, int T, int K, int N, void *y, bool f32,
-                   hipStream_t s) {
-    dim3 grid((unsigned)((N + 16 * NT - 1) / (16 * NT)), (unsigned)((T + 16 * MT - 1) / (16 * MT)));
-    if (f32) linear_skinny_kernel<NT, MT, true><<<grid, dim3(256), 0, s>>>(x, ldx, W, T, K, N, y);
-    else linear_skinny_kernel<NT, MT, false><<<grid, dim3(256), 0, s>>>(x, ldx, W, T, K, N, y);
+template <int NT, int MT, int WAVES, int EPI>
+static void launch(const half_t *x, int64_t ldx, const half_t *W, int T, int K, int N, void *y, const LinEpi &e,
+                   unsigned gx, hipStream_t s) {
+    dim3 grid(gx, (unsigned)((T + 16 * MT - 1) / (16 * MT)));
+    linear_skinny_kernel<NT, MT, WAVES, EPI><<<grid, dim3(WAVES * 64), 0, s>>>(x, ldx, W, T, K, N, y, e);
+}
+
+static inline int waves_for(int64_t K) { return K >= 2048 ? 16 : (K >= 1024 ? 8 : 4); }
+
+static int launch_check(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return nvr::fail(NVR_ERR_HIP, "%s launch failed: %s", what, hipGetErrorString(e));
+    return 0;
 }
 
 int linear(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t N, void *y,
@@ -109,19 +209,76 @@ int linear(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64
                          (long)K, (long)N, (long)ldx);
     if (T == 0) return 0;
     const half_t *xx = (const half_t *)x, *ww = (const half_t *)W;
+    const int t = (int)T, k = (int)K, n = (int)N;
+    const LinEpi e{};
     const int64_t mtiles = (T + 31) / 32;
+    // wide GEMMs (LM head, prefill slabs): 64 columns per workgroup amortise the x fragments; narrow ones keep
+    // 16 columns per workgroup (more workgroups) and split k over more waves (more bytes in flight per CU)
+    const bool wide = (N / 64) * (T <= 16 ? 1 : mtiles) >= 1024;
+    const int wv = waves_for(K);
+#define NVR_LIN(NT_, MT_, WV_)                                                                      \
+    do {                                                                                            \
+        const unsigned gx = (unsigned)((N + 16 * NT_ - 1) / (16 * NT_));                            \
+        if (y_f32) launch<NT_, MT_, WV_, EPI_F32>(xx, ldx, ww, t, k, n, y, e, gx, s);               \
+        else launch<NT_, MT_, WV_, EPI_F16>(xx, ldx, ww, t, k, n, y, e, gx, s);                     \
+    } while (0)
     if (T <= 16) {
-        if (N / 64 >= 1024) launch<4, 1>(xx, ldx, ww, (int)T, (int)K, (int)N, y, y_f32, s);
-        else if (N / 32 >= 512) launch<2, 1>(xx, ldx, ww, (int)T, (int)K, (int)N, y, y_f32, s);
-        else launch<1, 1>(xx, ldx, ww, (int)T, (int)K, (int)N, y, y_f32, s);
+        if (wide) NVR_LIN(4, 1, 4);
+        else if (wv == 16) NVR_LIN(1, 1, 16);
+        else if (wv == 8) NVR_LIN(1, 1, 8);
+        else NVR_LIN(1, 1, 4);
     } else {
-        if ((N / 64) * mtiles >= 1024) launch<4, 2>(xx, ldx, ww, (int)T, (int)K, (int)N, y, y_f32, s);
-        else if ((N / 32) * mtiles >= 512) launch<2, 2>(xx, ldx, ww, (int)T, (int)K, (int)N, y, y_f32, s);
-        else launch<1, 2>(xx, ldx, ww, (int)T, (int)K, (int)N, y, y_f32, s);
+        if (wide) NVR_LIN(4, 2, 4);
+        else if (wv == 16) NVR_LIN(1, 2, 16);
+        else if (wv == 8) NVR_LIN(1, 2, 8);
+        else NVR_LIN(1, 2, 4);
     }
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return nvr::fail(NVR_ERR_HIP, "linear launch failed: %s", hipGetErrorString(e));
-    return 0;
+#undef NVR_LIN
+    return launch_check("linear");
+}
+
+// gate_up GEMM + SiluAndMul: W [2I, K] (gate rows then up rows), out [T, I]
+int linear_silu_mul(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t I,
+                    half_bits *out, hipStream_t s) {
+    if (K % 32 || I % 16 || ldx % 8)
+        return nvr::fail(NVR_ERR_UNSUPPORTED, "linear_silu_mul: K=%ld must be a multiple of 32, I=%ld of 16", (long)K, (long)I);
+    if (T == 0) return 0;
+    const half_t *xx = (const half_t *)x, *ww = (const half_t *)W;
+    const LinEpi e{};
+    const unsigned gx = (unsigned)(I / 16);
+    const int wv = waves_for(K);
+    if (T <= 16) {
+        if (wv >= 8) launch<2, 1, 8, EPI_SILU>(xx, ldx, ww, (int)T, (int)K, (int)I, out, e, gx, s);
+        else launch<2, 1, 4, EPI_SILU>(xx, ldx, ww, (int)T, (int)K, (int)I, out, e, gx, s);
+    } else {
+        if (wv >= 8) launch<2, 2, 8, EPI_SILU>(xx, ldx, ww, (int)T, (int)K, (int)I, out, e, gx, s);
+        else launch<2, 2, 4, EPI_SILU>(xx, ldx, ww, (int)T, (int)K, (int)I, out, e, gx, s);
+    }
+    return launch_check("linear_silu_mul");
+}
+
+// qkv GEMM + RoPE on q,k heads + store of k,v rows into the paged caches
+int linear_qkv_rope_store(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t H,
+                          int64_t KVH, int64_t D, const int64_t *positions, const int32_t *slots, const float *cos_t,
+                          const float *sin_t, half_bits *qkv, half_bits *k_cache, half_bits *v_cache, hipStream_t s) {
+    if (K % 32 || D % 16 || ldx % 8)
+        return nvr::fail(NVR_ERR_UNSUPPORTED, "linear_qkv_rope_store: K=%ld must be a multiple of 32, D=%ld of 16", (long)K, (long)D);
+    if (T == 0) return 0;
+    const half_t *xx = (const half_t *)x, *ww = (const half_t *)W;
+    LinEpi e{};
+    e.pos = positions; e.slots = slots; e.cos_t = cos_t; e.sin_t = sin_t; e.kc = (half_t *)k_cache; e.vc = (half_t *)v_cache;
+    e.H = (int32_t)H; e.KVH = (int32_t)KVH; e.D = (int32_t)D;
+    const int N = (int)((H + 2 * KVH) * D);
+    const unsigned gx = (unsigned)(N / 16);
+    const int wv = waves_for(K);
+    if (T <= 16) {
+        if (wv >= 8) launch<1, 1, 8, EPI_ROPE>(xx, ldx, ww, (int)T, (int)K, N, qkv, e, gx, s);
+        else launch<1, 1, 4, EPI_ROPE>(xx, ldx, ww, (int)T, (int)K, N, qkv, e, gx, s);
+    } else {
+        if (wv >= 8) launch<1, 2, 8, EPI_ROPE>(xx, ldx, ww, (int)T, (int)K, N, qkv, e, gx, s);
+        else launch<1, 2, 4, EPI_ROPE>(xx, ldx, ww, (int)T, (int)K, N, qkv, e, gx, s);
+    }
+    return launch_check("linear_qkv_rope_store");
 }
 
 }}  // namespace nvr::k

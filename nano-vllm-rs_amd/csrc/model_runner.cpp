@@ -169,8 +169,8 @@ int nvr_model_runner::forward(int64_t T, int64_t B, bool is_prefill, int64_t max
         const Layer &w = layers[l];
         if (l == 0) RC(k::rmsnorm(h, w.ln1, mc.rms_norm_eps, T, Hd, n, stream));
         else RC(k::add_rmsnorm(h, proj, w.ln1, mc.rms_norm_eps, T, Hd, n, stream));          // residual :389 + norm :378
-        RC(k::linear(n, Hd, w.qkv, T, Hd, QKV, qkv, false, stream));
-        RC(k::rope_store_kv(qkv, d_pos, d_slots, T, H, KVH, D, cos_t, sin_t, k_cache(l), v_cache(l), stream));
+        // qkv GEMM with the RoPE + KV-store epilogue (K3..K6 in one launch)
+        RC(k::linear_qkv_rope_store(n, Hd, w.qkv, T, Hd, H, KVH, D, d_pos, d_slots, cos_t, sin_t, qkv, k_cache(l), v_cache(l), stream));
         k::AttnArgs a{};
         a.q = qkv; a.ldq = QKV; a.ctx_lens = d_ctx; a.nq = (int32_t)T; a.H = (int32_t)H; a.KVH = (int32_t)KVH; a.D = (int32_t)D;
         a.scale = scale; a.max_ctx = (int32_t)max_ctx; a.out = attn;
@@ -185,8 +185,7 @@ int nvr_model_runner::forward(int64_t T, int64_t B, bool is_prefill, int64_t max
         RC(k::linear(attn, H * D, w.o, T, H * D, Hd, proj, false, stream));
         if (comm.active()) RC(comm.all_reduce_sum_f16(proj, (size_t)(T * Hd), stream));     // linear.rs:236-238
         RC(k::add_rmsnorm(h, proj, w.ln2, mc.rms_norm_eps, T, Hd, n, stream));               // residual :382 + norm :385
-        RC(k::linear(n, Hd, w.gate_up, T, Hd, 2 * I, gu, false, stream));
-        RC(k::silu_and_mul(gu, T, I, act, stream));
+        RC(k::linear_silu_mul(n, Hd, w.gate_up, T, Hd, I, act, stream));                     // K12 + K13 in one launch
         RC(k::linear(act, I, w.down, T, I, Hd, proj, false, stream));
         if (comm.active()) RC(comm.all_reduce_sum_f16(proj, (size_t)(T * Hd), stream));
     }

@@ -295,6 +295,14 @@ int nvr_add_rmsnorm(nvr_half *h, const nvr_half *y, const nvr_half *w, float eps
 int nvr_linear(const nvr_half *x, int64_t ldx, const nvr_half *W, int64_t T, int64_t K, int64_t N, void *y, int f32, void *s) {
     return k::linear(x, ldx, W, T, K, N, y, f32 != 0, (hipStream_t)s);
 }
+int nvr_linear_silu_mul(const nvr_half *x, int64_t ldx, const nvr_half *W, int64_t T, int64_t K, int64_t I, nvr_half *out, void *s) {
+    return k::linear_silu_mul(x, ldx, W, T, K, I, out, (hipStream_t)s);
+}
+int nvr_linear_qkv_rope_store(const nvr_half *x, int64_t ldx, const nvr_half *W, int64_t T, int64_t K, int64_t H, int64_t KVH,
+                              int64_t D, const int64_t *pos, const int32_t *slots, const float *c, const float *sn,
+                              nvr_half *qkv, nvr_half *kc, nvr_half *vc, void *s) {
+    return k::linear_qkv_rope_store(x, ldx, W, T, K, H, KVH, D, pos, slots, c, sn, qkv, kc, vc, (hipStream_t)s);
+}
 int nvr_rope_store_kv(nvr_half *qkv, const int64_t *pos, const int32_t *slots, int64_t T, int64_t H, int64_t KVH, int64_t D,
                       const float *c, const float *sn, nvr_half *kc, nvr_half *vc, void *s) {
     return k::rope_store_kv(qkv, pos, slots, T, H, KVH, D, c, sn, kc, vc, (hipStream_t)s);

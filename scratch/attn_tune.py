@@ -1,0 +1,57 @@
+"""Microbenchmark of paged decode attention variants (NVR_ATTN_TUNE=U,waves,prefetch,nt,parts) at the
+BASELINE config-2 shape: B=32, ctx~1030, H=16, KVH=8, D=128, bs=256, 28 layers cycled (HBM-cold)."""
+import ctypes as C, os, sys
+sys.path.insert(0, '.')
+import numpy as np, nvr_import
+nvr = nvr_import.load(); l = nvr.lib(); nvr.check(l.nvr_device_set(0))
+B, H, KVH, D, bs, L = 32, 16, 8, 128, 256, 28
+ctx_len = int(os.environ.get("CTX", "1030"))
+nblk = (ctx_len + bs - 1) // bs
+NB = B * nblk
+layer_elems = NB * bs * KVH * D
+pool = nvr.DeviceBuffer(L * 2 * layer_elems * 2)
+key = l.nvr_weight_key(3, 77)
+nvr.check(l.nvr_fill_weight(pool.ptr, L * 2 * NB * bs, KVH * D, KVH * D, KVH * D, 0, 0, key, l.nvr_weight_scale(1.0), None))
+ctx = np.full(B, ctx_len, np.int32)
+rng = np.random.default_rng(0)
+bt = rng.permutation(NB).astype(np.int32).reshape(B, nblk)
+bt = np.concatenate([bt, -np.ones((B, 1), np.int32)], 1)
+q = nvr.DeviceBuffer.from_numpy(rng.standard_normal((B, H * D)).astype(np.float16))
+d_ctx, d_bt = nvr.DeviceBuffer.from_numpy(ctx), nvr.DeviceBuffer.from_numpy(bt)
+out = nvr.DeviceBuffer(B * H * D * 2)
+bucket = (ctx_len + 255) // 256 * 256
+ws = nvr.DeviceBuffer(l.nvr_paged_attn_workspace_bytes(B, H, D, bucket))
+meta = nvr.AttnMetaC(); meta.context_lens, meta.block_tables, meta.max_blocks, meta.batch, meta.max_context_len = d_ctx.ptr, d_bt.ptr, nblk + 1, B, bucket
+stream = C.c_void_p(); nvr.check(l.nvr_stream_create(C.byref(stream)))
+e0, e1 = C.c_void_p(), C.c_void_p(); l.nvr_event_create(C.byref(e0)); l.nvr_event_create(C.byref(e1))
+scale = float(1 / np.sqrt(np.float32(D)))
+def sweep():
+    for i in range(L):
+        kc = pool.ptr + (2 * i) * layer_elems * 2; vc = kc + layer_elems * 2
+        nvr.check(l.nvr_paged_attn_decode(q.ptr, H * D, kc, vc, C.byref(meta), H, KVH, D, bs, scale, out.ptr, ws.ptr, stream))
+def run(tune, reps=6):
+    if tune: os.environ["NVR_ATTN_TUNE"] = tune
+    else: os.environ.pop("NVR_ATTN_TUNE", None)
+    sweep(); nvr.check(l.nvr_stream_synchronize(stream))
+    res = out.to_numpy((B, H * D), np.float16).astype(np.float32)
+    l.nvr_event_record(e0, stream)
+    for _ in range(reps): sweep()
+    l.nvr_event_record(e1, stream)
+    ms = C.c_float(); nvr.check(l.nvr_event_elapsed_ms(e0, e1, C.byref(ms)))
+    return ms.value * 1e3 / (reps * L), res
+variants = sys.argv[1:] or ["", "4,4,0,0,1", "4,4,1,0,0", "8,4,0,0,0", "4,8,0,0,0", "4,8,1,0,0", "4,16,0,0,1", "4,16,1,0,1", "4,16,0,1,1", "4,16,1,1,1",
+                            "8,16,0,0,1", "2,16,1,0,1", "2,8,1,0,2", "4,8,1,0,2", "4,8,0,0,2", "4,4,0,1,0", "4,4,1,0,8", "4,4,1,0,2", "2,4,1,0,0", "4,8,1,1,2"]
+alg = float(ctx.sum()) * 2 * KVH * D * 2
+base = None
+best = {}
+for rnd in range(3):
+    for v in variants:
+        try:
+            us, res = run(v)
+        except Exception as ex:
+            print(v, "ERR", ex); continue
+        if base is None: base = res
+        err = float(np.abs(res - base).max())
+        best.setdefault(v, []).append(us)
+        if rnd == 2:
+            u = min(best[v]); print(f"{v or 'default':14s} min {u:7.2f} us  med {sorted(best[v])[1]:7.2f}  {alg / u / 1e3:7.1f} GB/s  maxdiff {err:.2e}")

@@ -389,3 +389,56 @@ def test_fill_weight_bit_exact_with_oracle():
     ref = oracle.fill_weight(rows, cols, gcols, 5, 64, key, sc, True)
     assert np.array_equal(d.to_numpy((rows, cols), F16).astype(np.float32), ref)
     assert abs(ref.std() - 0.02) < 0.003
+
+
+# ------------------------------------------------------------------------------------------- fused epilogues
+@pytest.mark.parametrize("T,K,I", [(32, 1024, 3072), (5, 256, 64), (40, 512, 128)])
+def test_linear_silu_mul_fused_equals_unfused_graph(T, K, I):
+    """gate_up GEMM + SiluAndMul in one launch must equal linear -> fp16 -> silu_and_mul -> fp16 (oracle order)."""
+    rng = np.random.default_rng(20)
+    x, xb = h16(rng.standard_normal((T, K)))
+    W, Wb = h16(rng.standard_normal((2 * I, K)) * 0.05)
+    d_out = nvr.DeviceBuffer(T * I * 2)
+    nvr.check(nvr.lib().nvr_linear_silu_mul(dev(xb).ptr, K, dev(Wb).ptr, T, K, I, d_out.ptr, None))
+    ref = oracle.round_f16(oracle.silu_and_mul(oracle.round_f16(oracle.linear(x, W))))
+    assert_close_f16(d_out.to_numpy((T, I), F16), ref, ulps=2, atol=3e-4, what="linear+silu_mul")
+
+
+@pytest.mark.parametrize("T,K,H,KVH,D", [(32, 1024, 16, 8, 128), (7, 256, 4, 2, 64), (33, 512, 2, 2, 128)])
+def test_linear_qkv_rope_store_fused(T, K, H, KVH, D):
+    rng = np.random.default_rng(21)
+    NB, bs, max_pos = 8, 16, 300
+    QKV = (H + 2 * KVH) * D
+    x, xb = h16(rng.standard_normal((T, K)))
+    W, Wb = h16(rng.standard_normal((QKV, K)) * 0.05)
+    pos = rng.integers(0, max_pos, T).astype(np.int64)
+    slots = rng.permutation(NB * bs)[:T].astype(np.int32)
+    slots[T // 2] = -1
+    cos, sin = oracle.rope_table(D, max_pos, 1e6)
+    d_qkv = nvr.DeviceBuffer(T * QKV * 2)
+    d_k, d_v = nvr.DeviceBuffer(NB * bs * KVH * D * 2), nvr.DeviceBuffer(NB * bs * KVH * D * 2)
+    d_k.zero(); d_v.zero()
+    nvr.check(nvr.lib().nvr_linear_qkv_rope_store(dev(xb).ptr, K, dev(Wb).ptr, T, K, H, KVH, D, dev(pos).ptr, dev(slots).ptr,
+                                                  dev(cos).ptr, dev(sin).ptr, d_qkv.ptr, d_k.ptr, d_v.ptr, None))
+    got = d_qkv.to_numpy((T, QKV), F16).astype(np.float32)
+    # the unfused kernels on the same inputs are the bit-exact twin (same GEMM tile order, same rope math)
+    d_qkv2 = nvr.DeviceBuffer(T * QKV * 2)
+    d_k2, d_v2 = nvr.DeviceBuffer(NB * bs * KVH * D * 2), nvr.DeviceBuffer(NB * bs * KVH * D * 2)
+    d_k2.zero(); d_v2.zero()
+    nvr.check(nvr.lib().nvr_linear(dev(xb).ptr, K, dev(Wb).ptr, T, K, QKV, d_qkv2.ptr, 0, None))
+    nvr.check(nvr.lib().nvr_rope_store_kv(d_qkv2.ptr, dev(pos).ptr, dev(slots).ptr, T, H, KVH, D, dev(cos).ptr, dev(sin).ptr,
+                                          d_k2.ptr, d_v2.ptr, None))
+    got2 = d_qkv2.to_numpy((T, QKV), F16).astype(np.float32)
+    assert np.array_equal(got, got2), "fused qkv+rope differs from linear followed by rope_store_kv"
+    assert np.array_equal(d_k.to_numpy((NB * bs, KVH * D), F16).view(np.uint16), d_k2.to_numpy((NB * bs, KVH * D), F16).view(np.uint16))
+    assert np.array_equal(d_v.to_numpy((NB * bs, KVH * D), F16).view(np.uint16), d_v2.to_numpy((NB * bs, KVH * D), F16).view(np.uint16))
+    # and against the oracle composition
+    qkv = oracle.round_f16(oracle.linear(x, W))
+    q = oracle.round_f16(oracle.rope_apply(qkv[:, :H * D].reshape(T, H, D), pos, cos, sin)).reshape(T, H * D)
+    kk = oracle.round_f16(oracle.rope_apply(qkv[:, H * D:(H + KVH) * D].reshape(T, KVH, D), pos, cos, sin))
+    vv = np.ascontiguousarray(qkv[:, (H + KVH) * D:].reshape(T, KVH, D))
+    assert_close_f16(got[:, :H * D], q, ulps=2, atol=3e-4, what="fused q")
+    kc, vc = np.zeros((NB, bs, KVH, D), np.float32), np.zeros((NB, bs, KVH, D), np.float32)
+    oracle.kv_store(kk, vv, slots, kc, vc)
+    assert_close_f16(d_k.to_numpy(kc.shape, F16), kc, ulps=2, atol=3e-4, what="fused k cache")
+    assert_close_f16(d_v.to_numpy(vc.shape, F16), vc, ulps=2, atol=3e-4, what="fused v cache")
