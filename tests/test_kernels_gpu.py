@@ -437,8 +437,10 @@ def test_linear_qkv_rope_store_fused(T, K, H, KVH, D):
     q = oracle.round_f16(oracle.rope_apply(qkv[:, :H * D].reshape(T, H, D), pos, cos, sin)).reshape(T, H * D)
     kk = oracle.round_f16(oracle.rope_apply(qkv[:, H * D:(H + KVH) * D].reshape(T, KVH, D), pos, cos, sin))
     vv = np.ascontiguousarray(qkv[:, (H + KVH) * D:].reshape(T, KVH, D))
-    assert_close_f16(got[:, :H * D], q, ulps=2, atol=3e-4, what="fused q")
+    # a 1-ulp fp16 difference in a GEMM output (f32 summation order) passes through the rotation, where the
+    # result can be much smaller than its inputs: the tolerance is absolute, one fp16 ulp of the inputs (|x| < 4)
+    assert_close_f16(got[:, :H * D], q, ulps=2, atol=4e-3, what="fused q")
     kc, vc = np.zeros((NB, bs, KVH, D), np.float32), np.zeros((NB, bs, KVH, D), np.float32)
     oracle.kv_store(kk, vv, slots, kc, vc)
-    assert_close_f16(d_k.to_numpy(kc.shape, F16), kc, ulps=2, atol=3e-4, what="fused k cache")
+    assert_close_f16(d_k.to_numpy(kc.shape, F16), kc, ulps=2, atol=4e-3, what="fused k cache")
     assert_close_f16(d_v.to_numpy(vc.shape, F16), vc, ulps=2, atol=3e-4, what="fused v cache")
