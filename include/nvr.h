@@ -267,6 +267,13 @@ NVR_API int nvr_add_rmsnorm(nvr_half *h, const nvr_half *y, const nvr_half *w, f
 /* K3/K10/K12/K14/K16 y = x·Wᵀ; x [T,K] (row stride ldx), W [N,K], y [T,N] fp16 or f32 */
 NVR_API int nvr_linear(const nvr_half *x, int64_t ldx, const nvr_half *W, int64_t T, int64_t K, int64_t N,
                        void *y, int y_is_f32, void *stream);
+/* split-k form of the narrow row-parallel GEMMs (o_proj / down_proj, linear.rs:228-239) for T <= 64:
+ * slabs[z][T][N] f32 partial sums over k-slice z, consumed by nvr_add_rmsnorm_slabs
+ * (h <- fp16(h + fp16(sum_z slabs[z])), out = rmsnorm(h)·w; layernorm.rs:170-176) */
+NVR_API int nvr_linear_splitk(const nvr_half *x, int64_t ldx, const nvr_half *W, int64_t T, int64_t K, int64_t N, int64_t S,
+                              float *slabs, void *stream);
+NVR_API int nvr_add_rmsnorm_slabs(nvr_half *h, const float *slabs, int64_t S, const nvr_half *w, float eps, int64_t T,
+                                  int64_t Hd, nvr_half *out, void *stream);
 /* K12+K13 fused: out[T,I] = SiluAndMul(x · W_gate_upᵀ), W [2I,K] gate rows then up rows
  * (MergedColumnParallelLinear::forward linear.rs:437-439 + SiluAndMul::forward activation.rs:46-63) */
 NVR_API int nvr_linear_silu_mul(const nvr_half *x, int64_t ldx, const nvr_half *W, int64_t T, int64_t K, int64_t I,

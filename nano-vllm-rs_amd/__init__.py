@@ -159,6 +159,8 @@ _SIGS = {
     "nvr_rmsnorm": (C.c_int, [_P, _P, C.c_float, C.c_int64, C.c_int64, _P, _P]),
     "nvr_add_rmsnorm": (C.c_int, [_P, _P, _P, C.c_float, C.c_int64, C.c_int64, _P, _P]),
     "nvr_linear": (C.c_int, [_P, C.c_int64, _P, C.c_int64, C.c_int64, C.c_int64, _P, C.c_int, _P]),
+    "nvr_linear_splitk": (C.c_int, [_P, C.c_int64, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _P, _P]),
+    "nvr_add_rmsnorm_slabs": (C.c_int, [_P, _P, C.c_int64, _P, C.c_float, C.c_int64, C.c_int64, _P, _P]),
     "nvr_linear_silu_mul": (C.c_int, [_P, C.c_int64, _P, C.c_int64, C.c_int64, C.c_int64, _P, _P]),
     "nvr_linear_qkv_rope_store": (C.c_int, [_P, C.c_int64, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _P, _P, _P, _P,
                                             _P, _P, _P, _P]),

@@ -29,6 +29,12 @@ int fill_const(half_bits *dst, int64_t n, float v, hipStream_t s);
 int linear(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t N, void *y,
            bool y_f32, hipStream_t s);
 
+int linear_splitk(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t N, int64_t S,
+                  float *slabs, hipStream_t s);
+// h = fp16(h + fp16(sum_z slabs[z])), out = rmsnorm(h)*w
+int add_rmsnorm_slabs(half_bits *h, const float *slabs, int64_t S, const half_bits *w, float eps, int64_t T, int64_t Hd,
+                      half_bits *out, hipStream_t s);
+
 // fused decode epilogues (same GEMM kernel): gate_up -> SiluAndMul, W [2I,K] -> out [T,I];
 // qkv -> RoPE(q,k) + KV store, W [(H+2KVH)D, K] -> qkv [T,(H+2KVH)D] (roped q,k; v) and cache rows at slots
 int linear_silu_mul(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t I,

@@ -28,7 +28,7 @@
 
 namespace nvr { namespace k {
 
-enum { EPI_F16 = 0, EPI_F32 = 1, EPI_SILU = 2, EPI_ROPE = 3 };
+enum { EPI_F16 = 0, EPI_F32 = 1, EPI_SILU = 2, EPI_ROPE = 3, EPI_SLAB = 4 };
 
 struct LinEpi {
     // EPI_SILU: N is the intermediate size I; W holds gate rows [0,I) and up rows [I,2I)
@@ -36,6 +36,8 @@ struct LinEpi {
     const int64_t *pos; const int32_t *slots; const float *cos_t, *sin_t;
     half_t *kc, *vc;
     int32_t H, KVH, D;
+    // EPI_SLAB: blockIdx.z owns k in [z*kslice, (z+1)*kslice) and writes its f32 partial tile to slab z
+    int32_t kslice; int64_t slab_stride;
 };
 
 // W row handled by local row r (0..15) of n-tile i of workgroup bx
@@ -74,7 +76,9 @@ __global__ __launch_bounds__(WAVES * 64) void linear_skinny_kernel(const half_t 
         for (int j = 0; j < MT; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
 
     constexpr int KS = 32 * WAVES;
-    for (int k = wave * 32; k < K; k += KS * U) {
+    const int kbeg = (EPI == EPI_SLAB) ? blockIdx.z * epi.kslice : 0;
+    if (EPI == EPI_SLAB) K = min(K, kbeg + epi.kslice);
+    for (int k = kbeg + wave * 32; k < K; k += KS * U) {
         half8_t a[U][NT], b[U][MT];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -115,7 +119,7 @@ __global__ __launch_bounds__(WAVES * 64) void linear_skinny_kernel(const half_t 
         return s;
     };
     // C layout of the 16x16 MFMA: row (n) = q*4 + reg, col (token) = r
-    if (EPI == EPI_F16 || EPI == EPI_F32) {
+    if (EPI == EPI_F16 || EPI == EPI_F32 || EPI == EPI_SLAB) {
         for (int tile = wave; tile < NT * MT; tile += WAVES) {
             const float4_t s = reduce(tile);
             const int i = tile / MT, j = tile % MT;
@@ -123,6 +127,8 @@ __global__ __launch_bounds__(WAVES * 64) void linear_skinny_kernel(const half_t 
             if (m < T && n < N) {
                 if (EPI == EPI_F32) {
                     *reinterpret_cast<float4_t *>(reinterpret_cast<float *>(y) + (int64_t)m * N + n) = s;
+                } else if (EPI == EPI_SLAB) {
+                    *reinterpret_cast<float4_t *>(reinterpret_cast<float *>(y) + blockIdx.z * epi.slab_stride + (int64_t)m * N + n) = s;
                 } else {
                     half4_t h = {(half_t)s[0], (half_t)s[1], (half_t)s[2], (half_t)s[3]};
                     *reinterpret_cast<half4_t *>(reinterpret_cast<half_t *>(y) + (int64_t)m * N + n) = h;
@@ -189,8 +195,8 @@ __global__ __launch_bounds__(WAVES * 64) void linear_skinny_kernel(const half_t 
 
 template <int NT, int MT, int WAVES, int EPI>
 static void launch(const half_t *x, int64_t ldx, const half_t *W, int T, int K, int N, void *y, const LinEpi &e,
-                   unsigned gx, hipStream_t s) {
-    dim3 grid(gx, (unsigned)((T + 16 * MT - 1) / (16 * MT)));
+                   unsigned gx, hipStream_t s, unsigned gz = 1) {
+    dim3 grid(gx, (unsigned)((T + 16 * MT - 1) / (16 * MT)), gz);
     linear_skinny_kernel<NT, MT, WAVES, EPI><<<grid, dim3(WAVES * 64), 0, s>>>(x, ldx, W, T, K, N, y, e);
 }
 
@@ -235,6 +241,21 @@ int linear(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64
     }
 #undef NVR_LIN
     return launch_check("linear");
+}
+
+// split-k over S workgroups per tile: slabs[z][T][N] f32 partial sums (summed by add_rmsnorm_slabs); the narrow
+// row-parallel GEMMs of the decode step (o_proj, down_proj: N = hidden) reach all 256 CUs this way
+int linear_splitk(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t N, int64_t S,
+                  float *slabs, hipStream_t s) {
+    if (K % (32 * S) || N % 16 || ldx % 8 || S < 1)
+        return nvr::fail(NVR_ERR_UNSUPPORTED, "linear_splitk: K=%ld must be a multiple of 32*S (S=%ld), N=%ld of 16", (long)K, (long)S, (long)N);
+    if (T == 0) return 0;
+    LinEpi e{};
+    e.kslice = (int32_t)(K / S); e.slab_stride = T * N;
+    const unsigned gx = (unsigned)(N / 16);
+    if (T <= 16) launch<1, 1, 4, EPI_SLAB>((const half_t *)x, ldx, (const half_t *)W, (int)T, (int)K, (int)N, slabs, e, gx, s, (unsigned)S);
+    else launch<1, 2, 4, EPI_SLAB>((const half_t *)x, ldx, (const half_t *)W, (int)T, (int)K, (int)N, slabs, e, gx, s, (unsigned)S);
+    return launch_check("linear_splitk");
 }
 
 // gate_up GEMM + SiluAndMul: W [2I, K] (gate rows then up rows), out [T, I]

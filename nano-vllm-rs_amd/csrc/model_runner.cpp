@@ -35,7 +35,7 @@ nvr_model_runner::~nvr_model_runner() {
     comm.destroy();
     for (auto &l : layers) { hipFree(l.qkv); hipFree(l.o); hipFree(l.gate_up); hipFree(l.down); hipFree(l.ln1); hipFree(l.ln2); }
     void *ptrs[] = {embed, mc.tie_word_embeddings ? nullptr : lm_head, norm, cos_t, sin_t, kv_pool, h, n, qkv, attn,
-                    proj, gu, act, nlast, logits, attn_ws, in_dev, d_tok, d_maxval, d_temp, d_topk, d_topp, d_keys,
+                    proj, gu, act, nlast, logits, attn_ws, slabs, in_dev, d_tok, d_maxval, d_temp, d_topk, d_topp, d_keys,
                     sample_ws, d_gather_val, d_gather_idx};
     for (void *p : ptrs) if (p) hipFree(p);
     if (in_host) hipHostFree(in_host);
@@ -87,6 +87,7 @@ int nvr_model_runner::init() {                                       // ModelRun
     RC(dmalloc(&h, max_tokens * Hd)); RC(dmalloc(&n, max_tokens * Hd)); RC(dmalloc(&qkv, max_tokens * QKV));
     RC(dmalloc(&attn, max_tokens * H * D)); RC(dmalloc(&proj, max_tokens * Hd)); RC(dmalloc(&gu, max_tokens * 2 * I));
     RC(dmalloc(&act, max_tokens * I)); RC(dmalloc(&nlast, max_seqs * Hd)); RC(dmalloc(&logits, max_seqs * Vl));
+    RC(dmalloc(&slabs, 4 * 64 * Hd));
     attn_ws_bytes = k::attn_workspace_bytes(max_seqs, H, D, max_pos);
     NVR_HIP_CHECK(hipMalloc(&attn_ws, attn_ws_bytes));
 
@@ -162,13 +163,34 @@ int nvr_model_runner::gen_weights() {
     return NVR_OK;
 }
 
+// RowParallelLinear::forward (o_proj / down_proj, linear.rs:228-239).  Decode-sized steps on one GPU split k over
+// S workgroups per output tile (f32 slabs, summed by the following add_rmsnorm_slabs) so that the N = hidden
+// GEMMs reach all 256 CUs; otherwise the plain kernel writes fp16 `proj` (+ all-reduce when tensor parallel).
+int nvr_model_runner::row_parallel(const uint16_t *x, int64_t K, const uint16_t *W, int64_t T, int64_t *S_out) {
+    int64_t S = 1;
+    if (!comm.active() && tp == 1 && T <= 64) {
+        const int64_t tiles = (Hd / 16) * ((T + 31) / 32);
+        while (S < 4 && tiles * S < 256 && K % (32 * S * 2) == 0 && K / (S * 2) >= 128) S *= 2;
+    }
+    *S_out = S;
+    if (S > 1) return k::linear_splitk(x, K, W, T, K, Hd, S, slabs, stream);
+    RC(k::linear(x, K, W, T, K, Hd, proj, false, stream));
+    if (comm.active()) RC(comm.all_reduce_sum_f16(proj, (size_t)(T * Hd), stream));         // linear.rs:236-238
+    return NVR_OK;
+}
+
 // Qwen3Model::forward, src/models/qwen3.rs:487-505; layer wiring :372-392; attention :208-240; MLP :305-314
 int nvr_model_runner::forward(int64_t T, int64_t B, bool is_prefill, int64_t max_ctx) {
     RC(k::embedding(d_ids, T, embed, Hd, h, stream));
+    int64_t S = 1;
+    auto add_norm = [&](const uint16_t *wn) -> int {                                       // residual add + next norm
+        if (S > 1) return k::add_rmsnorm_slabs(h, slabs, S, wn, mc.rms_norm_eps, T, Hd, n, stream);
+        return k::add_rmsnorm(h, proj, wn, mc.rms_norm_eps, T, Hd, n, stream);
+    };
     for (int64_t l = 0; l < L; ++l) {
         const Layer &w = layers[l];
         if (l == 0) RC(k::rmsnorm(h, w.ln1, mc.rms_norm_eps, T, Hd, n, stream));
-        else RC(k::add_rmsnorm(h, proj, w.ln1, mc.rms_norm_eps, T, Hd, n, stream));          // residual :389 + norm :378
+        else RC(add_norm(w.ln1));                                                            // residual :389 + norm :378
         // qkv GEMM with the RoPE + KV-store epilogue (K3..K6 in one launch)
         RC(k::linear_qkv_rope_store(n, Hd, w.qkv, T, Hd, H, KVH, D, d_pos, d_slots, cos_t, sin_t, qkv, k_cache(l), v_cache(l), stream));
         k::AttnArgs a{};
@@ -182,14 +204,12 @@ int nvr_model_runner::forward(int64_t T, int64_t B, bool is_prefill, int64_t max
             a.block_size = (int32_t)block_size; a.workspace = attn_ws;
             RC(k::attention(a, true, stream));
         }
-        RC(k::linear(attn, H * D, w.o, T, H * D, Hd, proj, false, stream));
-        if (comm.active()) RC(comm.all_reduce_sum_f16(proj, (size_t)(T * Hd), stream));     // linear.rs:236-238
-        RC(k::add_rmsnorm(h, proj, w.ln2, mc.rms_norm_eps, T, Hd, n, stream));               // residual :382 + norm :385
+        RC(row_parallel(attn, H * D, w.o, T, &S));
+        RC(add_norm(w.ln2));                                                                 // residual :382 + norm :385
         RC(k::linear_silu_mul(n, Hd, w.gate_up, T, Hd, I, act, stream));                     // K12 + K13 in one launch
-        RC(k::linear(act, I, w.down, T, I, Hd, proj, false, stream));
-        if (comm.active()) RC(comm.all_reduce_sum_f16(proj, (size_t)(T * Hd), stream));
+        RC(row_parallel(act, I, w.down, T, &S));
     }
-    RC(k::add_rmsnorm(h, proj, norm, mc.rms_norm_eps, T, Hd, n, stream));                    // final residual + norm :501
+    RC(add_norm(norm));                                                                      // final residual + norm :501
     const uint16_t *hl = n;
     if (is_prefill) { RC(k::select_last_tokens(n, d_cu, B, Hd, nlast, stream)); hl = nlast; }   // embed_head.rs:272-289
     RC(k::linear(hl, Hd, lm_head, B, Hd, Vl, logits, true, stream));                          // f32 logits (A-21)

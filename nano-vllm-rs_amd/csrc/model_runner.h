@@ -34,6 +34,7 @@ struct nvr_model_runner {
     uint16_t *h = nullptr, *n = nullptr, *qkv = nullptr, *attn = nullptr, *proj = nullptr, *gu = nullptr, *act = nullptr,
              *nlast = nullptr;
     float *logits = nullptr; void *attn_ws = nullptr; size_t attn_ws_bytes = 0;
+    float *slabs = nullptr;                // split-k partials of o_proj / down_proj for decode-sized steps: [4][64][Hd] f32
     // step inputs: one pinned host arena mirrored by one device arena
     char *in_host = nullptr, *in_dev = nullptr; size_t in_bytes = 0;
     int64_t *d_ids = nullptr, *d_pos = nullptr; int32_t *d_slots = nullptr, *d_cu = nullptr, *d_ctx = nullptr,
@@ -60,4 +61,5 @@ struct nvr_model_runner {
 private:
     int forward(int64_t T, int64_t B, bool is_prefill, int64_t max_ctx);
     int gen_weights();
+    int row_parallel(const uint16_t *x, int64_t K, const uint16_t *W, int64_t T, int64_t *S_out);
 };

@@ -295,6 +295,12 @@ int nvr_add_rmsnorm(nvr_half *h, const nvr_half *y, const nvr_half *w, float eps
 int nvr_linear(const nvr_half *x, int64_t ldx, const nvr_half *W, int64_t T, int64_t K, int64_t N, void *y, int f32, void *s) {
     return k::linear(x, ldx, W, T, K, N, y, f32 != 0, (hipStream_t)s);
 }
+int nvr_linear_splitk(const nvr_half *x, int64_t ldx, const nvr_half *W, int64_t T, int64_t K, int64_t N, int64_t S, float *slabs, void *s) {
+    return k::linear_splitk(x, ldx, W, T, K, N, S, slabs, (hipStream_t)s);
+}
+int nvr_add_rmsnorm_slabs(nvr_half *h, const float *slabs, int64_t S, const nvr_half *w, float eps, int64_t T, int64_t Hd, nvr_half *out, void *s) {
+    return k::add_rmsnorm_slabs(h, slabs, S, w, eps, T, Hd, out, (hipStream_t)s);
+}
 int nvr_linear_silu_mul(const nvr_half *x, int64_t ldx, const nvr_half *W, int64_t T, int64_t K, int64_t I, nvr_half *out, void *s) {
     return k::linear_silu_mul(x, ldx, W, T, K, I, out, (hipStream_t)s);
 }

@@ -444,3 +444,27 @@ def test_linear_qkv_rope_store_fused(T, K, H, KVH, D):
     oracle.kv_store(kk, vv, slots, kc, vc)
     assert_close_f16(d_k.to_numpy(kc.shape, F16), kc, ulps=2, atol=4e-3, what="fused k cache")
     assert_close_f16(d_v.to_numpy(vc.shape, F16), vc, ulps=2, atol=3e-4, what="fused v cache")
+
+
+@pytest.mark.parametrize("T,K,N,S", [(32, 2048, 1024, 4), (32, 3072, 1024, 4), (5, 256, 64, 2), (40, 512, 256, 4)])
+def test_linear_splitk_and_slab_norm(T, K, N, S):
+    """split-k slabs + add_rmsnorm_slabs == linear -> fp16 -> add -> rmsnorm (the unfused graph order)."""
+    rng = np.random.default_rng(22)
+    x, xb = h16(rng.standard_normal((T, K)))
+    W, Wb = h16(rng.standard_normal((N, K)) * 0.05)
+    h, hb = h16(rng.standard_normal((T, N)))
+    w, wb = h16(1 + 0.1 * rng.standard_normal(N))
+    d_slabs = nvr.DeviceBuffer(S * T * N * 4)
+    nvr.check(nvr.lib().nvr_linear_splitk(dev(xb).ptr, K, dev(Wb).ptr, T, K, N, S, d_slabs.ptr, None))
+    slabs = d_slabs.to_numpy((S, T, N), np.float32)
+    ref = oracle.linear(x, W)
+    np.testing.assert_allclose(slabs.sum(0), ref, rtol=2e-5, atol=3e-4)
+    d_h, d_out = dev(hb), nvr.DeviceBuffer(T * N * 2)
+    nvr.check(nvr.lib().nvr_add_rmsnorm_slabs(d_h.ptr, d_slabs.ptr, S, dev(wb).ptr, 1e-6, T, N, d_out.ptr, None))
+    y = slabs[0].copy()
+    for z in range(1, S):
+        y = y + slabs[z]                                    # same f32 order as the kernel
+    hn = oracle.add(h, oracle.round_f16(y), round16=True)
+    assert np.array_equal(d_h.to_numpy((T, N), F16).astype(np.float32), hn)
+    assert_close_f16(d_out.to_numpy((T, N), F16), oracle.round_f16(oracle.rmsnorm(hn, w, 1e-6)), ulps=1, atol=1e-6)
+    assert nvr.lib().nvr_linear_splitk(dev(xb).ptr, K, dev(Wb).ptr, T, K, N, 3, d_slabs.ptr, None) == -10
