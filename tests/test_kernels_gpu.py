@@ -467,4 +467,4 @@ def test_linear_splitk_and_slab_norm(T, K, N, S):
     hn = oracle.add(h, oracle.round_f16(y), round16=True)
     assert np.array_equal(d_h.to_numpy((T, N), F16).astype(np.float32), hn)
     assert_close_f16(d_out.to_numpy((T, N), F16), oracle.round_f16(oracle.rmsnorm(hn, w, 1e-6)), ulps=1, atol=1e-6)
-    assert nvr.lib().nvr_linear_splitk(dev(xb).ptr, K, dev(Wb).ptr, T, K, N, 3, d_slabs.ptr, None) == -10
+    assert nvr.lib().nvr_linear_splitk(dev(xb).ptr, K, dev(Wb).ptr, T, K, N, 5, d_slabs.ptr, None) == -10
