@@ -132,6 +132,8 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--attn-reps", type=int, default=8)
+    ap.add_argument("--microbatches", type=int, default=int(os.environ.get("NVR_MICROBATCHES", "1")),
+                    help="decode micro-batches run concurrently on their own HIP streams (nvr_config.decode_microbatches)")
     args = ap.parse_args()
 
     nvr = nvr_import.load()                # loads libnvr.so (and the ROCm HIP runtime) before torch
@@ -149,7 +151,8 @@ def main() -> None:
     total_new = args.warmup + args.steps + 1
     cfg = nvr.Config(max_num_seqs=BATCH, max_num_batched_tokens=BATCH * PROMPT_LEN, max_model_len=PROMPT_LEN + total_new + 16,
                      kvcache_block_size=BLOCK, num_kvcache_blocks=BATCH * ((PROMPT_LEN + total_new + 16) // BLOCK + 2),
-                     tensor_parallel_size=args.gpus, tensor_parallel_rank=rank, device_ordinal=local_rank)
+                     tensor_parallel_size=args.gpus, tensor_parallel_rank=rank, device_ordinal=local_rank,
+                     decode_microbatches=args.microbatches)
     mc = nvr.ModelConfig("qwen3-0.6b")
     nvr.check(nvr.lib().nvr_device_set(local_rank))
     eng = nvr.LLMEngine(cfg, mc)
@@ -217,7 +220,7 @@ def main() -> None:
             "config": {"workload": "Qwen3-0.6B fp16 random-init, bs=32 x 1024-token prompts, greedy paged-attention decode, "
                                    "block_size=256, hipGraph decode steps (BASELINE.json configs[1])",
                        "batch": BATCH, "prompt_len": PROMPT_LEN, "mean_context": ctx_mean,
-                       "parallelism": f"tp{args.gpus}", "prefill_s": round(t_prefill, 3)},
+                       "parallelism": f"tp{args.gpus}", "decode_microbatches": args.microbatches, "prefill_s": round(t_prefill, 3)},
             "step_hbm_frac": round(step_gbs / HBM_PEAK_GBS, 4),
             "step_algorithmic_bytes": int(step_bytes),
             "roofline": {"kernel": "attn_rows_kernel (paged decode attention, K9)", "bound": "hbm", "achieved": round(achieved, 1),

@@ -83,6 +83,8 @@ typedef struct nvr_config {
     uint64_t sample_seed;              /* A-20 counter-RNG seed */
     int32_t skip_block_size_check;     /* reference unit tests use block sizes 4/16 that
                                           Config::validate would reject (config.rs:94) */
+    uint32_t decode_microbatches;      /* 0/1: one kernel chain per decode step; 2..4: the batch rows are cut
+                                          into that many slices run concurrently on their own HIP streams */
 } nvr_config;
 NVR_API void nvr_config_default(nvr_config *cfg);                    /* config.rs:54-71 */
 NVR_API int nvr_config_validate(const nvr_config *cfg);              /* config.rs:83-119 */

@@ -286,7 +286,7 @@ static int launch_attn(const AttnArgs &a, bool paged, hipStream_t s) {
     if (a.workspace) {
         if (tn.parts > 0) { part_size = (int)(((mc + tn.parts - 1) / tn.parts + 63) / 64 * 64); np = (int)((mc + part_size - 1) / part_size); }
         else if (waves == 16) {
-            int64_t want = pairs >= 192 ? 1 : (256 + pairs - 1) / pairs;
+            int64_t want = pairs >= 96 ? 1 : (256 + pairs - 1) / pairs;
             int64_t ps = ((mc + want - 1) / want + 255) / 256 * 256;
             part_size = (int)ps; np = (int)((mc + ps - 1) / ps);
         } else np = parts_for(a.nq, a.KVH, mc, waves, &part_size);

@@ -33,6 +33,14 @@ nvr_model_runner::~nvr_model_runner() {
     if (stream) hipStreamSynchronize(stream);
     for (auto &g : graphs) hipGraphExecDestroy(g.second);
     comm.destroy();
+    for (size_t i = 1; i < lanes.size(); ++i) {
+        Lane &ln = lanes[i];
+        void *ps[] = {ln.h, ln.n, ln.qkv, ln.attn, ln.proj, ln.act, ln.slabs, ln.attn_ws};
+        for (void *p : ps) if (p) hipFree(p);
+        if (ln.done) hipEventDestroy(ln.done);
+        if (ln.stream) hipStreamDestroy(ln.stream);
+    }
+    if (fork_ev) hipEventDestroy(fork_ev);
     for (auto &l : layers) { hipFree(l.qkv); hipFree(l.o); hipFree(l.gate_up); hipFree(l.down); hipFree(l.ln1); hipFree(l.ln2); }
     void *ptrs[] = {embed, mc.tie_word_embeddings ? nullptr : lm_head, norm, cos_t, sin_t, kv_pool, h, n, qkv, attn,
                     proj, gu, act, nlast, logits, attn_ws, slabs, in_dev, d_tok, d_maxval, d_temp, d_topk, d_topp, d_keys,
@@ -90,6 +98,22 @@ int nvr_model_runner::init() {                                       // ModelRun
     RC(dmalloc(&slabs, 4 * 64 * Hd));
     attn_ws_bytes = k::attn_workspace_bytes(max_seqs, H, D, max_pos);
     NVR_HIP_CHECK(hipMalloc(&attn_ws, attn_ws_bytes));
+    {
+        int nl = (int)cfg.decode_microbatches; if (nl < 1) nl = 1; if (nl > 4) nl = 4;
+        lanes.resize(nl);
+        Lane &l0 = lanes[0];
+        l0.stream = stream; l0.h = h; l0.n = n; l0.qkv = qkv; l0.attn = attn; l0.proj = proj; l0.act = act; l0.slabs = slabs; l0.attn_ws = attn_ws;
+        NVR_HIP_CHECK(hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming));
+        for (int i = 1; i < nl; ++i) {                                  // decode-sized twins of the activation set
+            Lane &ln = lanes[i];
+            NVR_HIP_CHECK(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
+            NVR_HIP_CHECK(hipEventCreateWithFlags(&ln.done, hipEventDisableTiming));
+            RC(dmalloc(&ln.h, max_seqs * Hd)); RC(dmalloc(&ln.n, max_seqs * Hd)); RC(dmalloc(&ln.qkv, max_seqs * QKV));
+            RC(dmalloc(&ln.attn, max_seqs * H * D)); RC(dmalloc(&ln.proj, max_seqs * Hd)); RC(dmalloc(&ln.act, max_seqs * I));
+            RC(dmalloc(&ln.slabs, 4 * 64 * Hd));
+            NVR_HIP_CHECK(hipMalloc(&ln.attn_ws, attn_ws_bytes));
+        }
+    }
 
     // step-input arena
     auto carve = [&](size_t &off, size_t bytes) { off = in_bytes; in_bytes += (bytes + 255) / 256 * 256; };
@@ -166,53 +190,76 @@ int nvr_model_runner::gen_weights() {
 // RowParallelLinear::forward (o_proj / down_proj, linear.rs:228-239).  Decode-sized steps on one GPU split k over
 // S workgroups per output tile (f32 slabs, summed by the following add_rmsnorm_slabs) so that the N = hidden
 // GEMMs reach all 256 CUs; otherwise the plain kernel writes fp16 `proj` (+ all-reduce when tensor parallel).
-int nvr_model_runner::row_parallel(const uint16_t *x, int64_t K, const uint16_t *W, int64_t T, int64_t *S_out) {
+int nvr_model_runner::row_parallel(Lane &ln, const uint16_t *x, int64_t K, const uint16_t *W, int64_t T, int64_t *S_out) {
     int64_t S = 1;
     if (!comm.active() && tp == 1 && T <= 64) {
         const int64_t tiles = (Hd / 16) * ((T + 31) / 32);
         while (S < 4 && tiles * S < 256 && K % (32 * S * 2) == 0 && K / (S * 2) >= 128) S *= 2;
     }
     *S_out = S;
-    if (S > 1) return k::linear_splitk(x, K, W, T, K, Hd, S, slabs, stream);
-    RC(k::linear(x, K, W, T, K, Hd, proj, false, stream));
-    if (comm.active()) RC(comm.all_reduce_sum_f16(proj, (size_t)(T * Hd), stream));         // linear.rs:236-238
+    if (S > 1) return k::linear_splitk(x, K, W, T, K, Hd, S, ln.slabs, ln.stream);
+    RC(k::linear(x, K, W, T, K, Hd, ln.proj, false, ln.stream));
+    if (comm.active()) RC(comm.all_reduce_sum_f16(ln.proj, (size_t)(T * Hd), ln.stream));  // linear.rs:236-238
     return NVR_OK;
 }
 
-// Qwen3Model::forward, src/models/qwen3.rs:487-505; layer wiring :372-392; attention :208-240; MLP :305-314
-int nvr_model_runner::forward(int64_t T, int64_t B, bool is_prefill, int64_t max_ctx) {
-    RC(k::embedding(d_ids, T, embed, Hd, h, stream));
+// Qwen3Model::forward, src/models/qwen3.rs:487-505; layer wiring :372-392; attention :208-240; MLP :305-314.
+// Rows [row0, row0+T) of the step inputs (B sequences) run on lane `ln`.
+int nvr_model_runner::forward(Lane &ln, int64_t row0, int64_t T, int64_t B, bool is_prefill, int64_t max_ctx) {
+    hipStream_t st = ln.stream;
+    const int64_t *ids = d_ids + row0, *pos = d_pos + row0;
+    const int32_t *slots = d_slots + row0, *ctx = d_ctx + row0, *bt = d_bt + row0 * max_blocks_per_seq;
+    RC(k::embedding(ids, T, embed, Hd, ln.h, st));
     int64_t S = 1;
     auto add_norm = [&](const uint16_t *wn) -> int {                                       // residual add + next norm
-        if (S > 1) return k::add_rmsnorm_slabs(h, slabs, S, wn, mc.rms_norm_eps, T, Hd, n, stream);
-        return k::add_rmsnorm(h, proj, wn, mc.rms_norm_eps, T, Hd, n, stream);
+        if (S > 1) return k::add_rmsnorm_slabs(ln.h, ln.slabs, S, wn, mc.rms_norm_eps, T, Hd, ln.n, st);
+        return k::add_rmsnorm(ln.h, ln.proj, wn, mc.rms_norm_eps, T, Hd, ln.n, st);
     };
     for (int64_t l = 0; l < L; ++l) {
         const Layer &w = layers[l];
-        if (l == 0) RC(k::rmsnorm(h, w.ln1, mc.rms_norm_eps, T, Hd, n, stream));
+        if (l == 0) RC(k::rmsnorm(ln.h, w.ln1, mc.rms_norm_eps, T, Hd, ln.n, st));
         else RC(add_norm(w.ln1));                                                            // residual :389 + norm :378
         // qkv GEMM with the RoPE + KV-store epilogue (K3..K6 in one launch)
-        RC(k::linear_qkv_rope_store(n, Hd, w.qkv, T, Hd, H, KVH, D, d_pos, d_slots, cos_t, sin_t, qkv, k_cache(l), v_cache(l), stream));
+        RC(k::linear_qkv_rope_store(ln.n, Hd, w.qkv, T, Hd, H, KVH, D, pos, slots, cos_t, sin_t, ln.qkv, k_cache(l), v_cache(l), st));
         k::AttnArgs a{};
-        a.q = qkv; a.ldq = QKV; a.ctx_lens = d_ctx; a.nq = (int32_t)T; a.H = (int32_t)H; a.KVH = (int32_t)KVH; a.D = (int32_t)D;
-        a.scale = scale; a.max_ctx = (int32_t)max_ctx; a.out = attn;
+        a.q = ln.qkv; a.ldq = QKV; a.ctx_lens = ctx; a.nq = (int32_t)T; a.H = (int32_t)H; a.KVH = (int32_t)KVH; a.D = (int32_t)D;
+        a.scale = scale; a.max_ctx = (int32_t)max_ctx; a.out = ln.attn;
         if (is_prefill) {                                            // flash_attention_varlen, attention.rs:177-208
-            a.k = qkv + H * D; a.v = qkv + (H + KVH) * D; a.ldkv = QKV; a.kv_base = d_kvbase; a.workspace = nullptr;
-            RC(k::attention(a, false, stream));
+            a.k = ln.qkv + H * D; a.v = ln.qkv + (H + KVH) * D; a.ldkv = QKV; a.kv_base = d_kvbase; a.workspace = nullptr;
+            RC(k::attention(a, false, st));
         } else {                                                     // flash_attention_decode, attention.rs:225-235
-            a.k = k_cache(l); a.v = v_cache(l); a.block_tables = d_bt; a.max_blocks = (int32_t)max_blocks_per_seq;
-            a.block_size = (int32_t)block_size; a.workspace = attn_ws;
-            RC(k::attention(a, true, stream));
+            a.k = k_cache(l); a.v = v_cache(l); a.block_tables = bt; a.max_blocks = (int32_t)max_blocks_per_seq;
+            a.block_size = (int32_t)block_size; a.workspace = ln.attn_ws;
+            RC(k::attention(a, true, st));
         }
-        RC(row_parallel(attn, H * D, w.o, T, &S));
+        RC(row_parallel(ln, ln.attn, H * D, w.o, T, &S));
         RC(add_norm(w.ln2));                                                                 // residual :382 + norm :385
-        RC(k::linear_silu_mul(n, Hd, w.gate_up, T, Hd, I, act, stream));                     // K12 + K13 in one launch
-        RC(row_parallel(act, I, w.down, T, &S));
+        RC(k::linear_silu_mul(ln.n, Hd, w.gate_up, T, Hd, I, ln.act, st));                   // K12 + K13 in one launch
+        RC(row_parallel(ln, ln.act, I, w.down, T, &S));
     }
     RC(add_norm(norm));                                                                      // final residual + norm :501
-    const uint16_t *hl = n;
-    if (is_prefill) { RC(k::select_last_tokens(n, d_cu, B, Hd, nlast, stream)); hl = nlast; }   // embed_head.rs:272-289
-    RC(k::linear(hl, Hd, lm_head, B, Hd, Vl, logits, true, stream));                          // f32 logits (A-21)
+    const uint16_t *hl = ln.n;
+    if (is_prefill) { RC(k::select_last_tokens(ln.n, d_cu, B, Hd, nlast, st)); hl = nlast; }   // embed_head.rs:272-289
+    RC(k::linear(hl, Hd, lm_head, B, Hd, Vl, logits + row0 * Vl, true, st));                   // f32 logits (A-21)
+    return NVR_OK;
+}
+
+// One step over nl lanes: rows are cut into nl contiguous slices; lanes 1.. fork from and join into lane 0's
+// stream (capturable: the same code builds the hipGraph's parallel branches).
+int nvr_model_runner::forward_all(int64_t T, int64_t B, bool is_prefill, int64_t max_ctx, int nl) {
+    if (nl <= 1 || is_prefill) return forward(lanes[0], 0, T, B, is_prefill, max_ctx);
+    NVR_HIP_CHECK(hipEventRecord(fork_ev, stream));
+    for (int i = 1; i < nl; ++i) NVR_HIP_CHECK(hipStreamWaitEvent(lanes[i].stream, fork_ev, 0));
+    const int64_t per = (B + nl - 1) / nl;
+    for (int i = 0; i < nl; ++i) {
+        const int64_t r0 = i * per, cnt = std::min<int64_t>(per, B - r0);
+        if (cnt <= 0) continue;
+        RC(forward(lanes[i], r0, cnt, cnt, false, max_ctx));
+    }
+    for (int i = 1; i < nl; ++i) {
+        NVR_HIP_CHECK(hipEventRecord(lanes[i].done, lanes[i].stream));
+        NVR_HIP_CHECK(hipStreamWaitEvent(stream, lanes[i].done, 0));
+    }
     return NVR_OK;
 }
 
@@ -272,7 +319,8 @@ int nvr_model_runner::execute(nvr_seq *const *seqs, size_t nseq, bool is_prefill
     else NVR_HIP_CHECK(up(off_bt, nseq * max_blocks_per_seq * 4));
 
     last_rows = nseq; last_prefill = is_prefill;
-    if (is_prefill || cfg.enforce_eager) return forward(T, (int64_t)nseq, is_prefill, max_ctx);
+    const int nl = (!is_prefill && (int64_t)nseq >= 8 * (int64_t)lanes.size()) ? (int)lanes.size() : 1;
+    if (is_prefill || cfg.enforce_eager) return forward_all(T, (int64_t)nseq, is_prefill, max_ctx, nl);
 
     // decode: replay a hipGraph captured per (batch size, context bucket) — execute_with_cuda_graph :303-326
     const int64_t bucket = (max_ctx + 255) / 256 * 256;
@@ -281,7 +329,7 @@ int nvr_model_runner::execute(nvr_seq *const *seqs, size_t nseq, bool is_prefill
     if (it == graphs.end()) {
         hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr;
         NVR_HIP_CHECK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
-        int rc = forward(T, (int64_t)nseq, false, bucket);
+        int rc = forward_all(T, (int64_t)nseq, false, bucket, nl);
         hipError_t e = hipStreamEndCapture(stream, &g);
         if (rc) { if (g) hipGraphDestroy(g); return rc; }
         if (e != hipSuccess) return nvr::fail(NVR_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));

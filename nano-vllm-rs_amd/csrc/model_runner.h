@@ -47,6 +47,17 @@ struct nvr_model_runner {
     // TP exchange buffers for the greedy (max, idx) merge
     float *d_gather_val = nullptr; int64_t *d_gather_idx = nullptr;
 
+    // Decode micro-batching: the batch rows are cut into `lanes` slices that run the whole layer stack
+    // concurrently on their own streams (forked and joined inside the captured graph).  A decode step is a
+    // chain of ~200 short kernels whose fixed launch/drain latency, not HBM bandwidth, bounds the step
+    // (profiles/r01_decode_step_breakdown_v2.txt); two independent chains fill each other's bubbles.
+    struct Lane {
+        hipStream_t stream = nullptr; hipEvent_t done = nullptr;
+        uint16_t *h = nullptr, *n = nullptr, *qkv = nullptr, *attn = nullptr, *proj = nullptr, *act = nullptr;
+        float *slabs = nullptr; void *attn_ws = nullptr;
+    };
+    std::vector<Lane> lanes;
+    hipEvent_t fork_ev = nullptr;
     std::map<uint64_t, hipGraphExec_t> graphs;
     size_t last_rows = 0; bool last_prefill = false;
     nvr::Comm comm;
@@ -59,7 +70,8 @@ struct nvr_model_runner {
     uint16_t *v_cache(size_t l) { return kv_pool + (2 * l + 1) * kv_layer_elems; }
 
 private:
-    int forward(int64_t T, int64_t B, bool is_prefill, int64_t max_ctx);
+    int forward(Lane &ln, int64_t row0, int64_t T, int64_t B, bool is_prefill, int64_t max_ctx);
+    int forward_all(int64_t T, int64_t B, bool is_prefill, int64_t max_ctx, int nl);
     int gen_weights();
-    int row_parallel(const uint16_t *x, int64_t K, const uint16_t *W, int64_t T, int64_t *S_out);
+    int row_parallel(Lane &ln, const uint16_t *x, int64_t K, const uint16_t *W, int64_t T, int64_t *S_out);
 };
