@@ -134,46 +134,69 @@ int add_rmsnorm(half_bits *h, const half_bits *y, const half_bits *w, float eps,
 
 // split-k consumer: y = fp16(slab0 + slab1 + ...) (f32, fixed order), h <- fp16(h + y), out = rmsnorm(h)*w.
 // One wave per row (rows are short: Hd <= 8192), one row per workgroup so that 32 rows use 32 CUs.
-__global__ __launch_bounds__(64) void add_rmsnorm_slabs_kernel(half_t *__restrict__ h, const float *__restrict__ slabs, int S,
+template <int S, int C>   // S slabs, C chunks of 512 elements per row held in registers (all loads issued up front)
+__global__ __launch_bounds__(64) void add_rmsnorm_slabs_kernel(half_t *__restrict__ h, const float *__restrict__ slabs,
                                                               int64_t slab_stride, const half_t *__restrict__ w, float eps,
                                                               int Hd, half_t *__restrict__ out) {
     const int row = blockIdx.x, lane = threadIdx.x;
     half_t *hr = h + (int64_t)row * Hd;
     const float *sr = slabs + (int64_t)row * Hd;
     half_t *orow = out + (int64_t)row * Hd;
-    float ss = 0.f;
-    for (int c = lane * 8; c < Hd; c += 512) {
-        half8_t v = *reinterpret_cast<const half8_t *>(hr + c);
-        float4_t a0 = *reinterpret_cast<const float4_t *>(sr + c), a1 = *reinterpret_cast<const float4_t *>(sr + c + 4);
-        for (int z = 1; z < S; ++z) {
-            a0 += *reinterpret_cast<const float4_t *>(sr + z * slab_stride + c);
-            a1 += *reinterpret_cast<const float4_t *>(sr + z * slab_stride + c + 4);
-        }
+    half8_t v[C], g[C];
+    float4_t a[C][S][2];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float y = (float)to_half_rn(j < 4 ? a0[j] : a1[j - 4]);
-            v[j] = to_half_rn((float)v[j] + y);
-            const float f = (float)v[j]; ss += f * f;
+    for (int i = 0; i < C; ++i) {
+        const int c = lane * 8 + i * 512;
+        if (c < Hd) {
+            v[i] = *reinterpret_cast<const half8_t *>(hr + c);
+            g[i] = *reinterpret_cast<const half8_t *>(w + c);
+#pragma unroll
+            for (int z = 0; z < S; ++z) {
+                a[i][z][0] = *reinterpret_cast<const float4_t *>(sr + z * slab_stride + c);
+                a[i][z][1] = *reinterpret_cast<const float4_t *>(sr + z * slab_stride + c + 4);
+            }
         }
-        *reinterpret_cast<half8_t *>(hr + c) = v;
+    }
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < C; ++i) {
+        const int c = lane * 8 + i * 512;
+        if (c < Hd) {
+            float4_t a0 = a[i][0][0], a1 = a[i][0][1];
+#pragma unroll
+            for (int z = 1; z < S; ++z) { a0 += a[i][z][0]; a1 += a[i][z][1]; }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float y = (float)to_half_rn(j < 4 ? a0[j] : a1[j - 4]);
+                v[i][j] = to_half_rn((float)v[i][j] + y);
+                const float f = (float)v[i][j]; ss += f * f;
+            }
+            *reinterpret_cast<half8_t *>(hr + c) = v[i];
+        }
     }
     ss = wave_sum(ss);
     const float rms = sqrtf(ss / (float)Hd + eps);
-    for (int c = lane * 8; c < Hd; c += 512) {
-        half8_t v = *reinterpret_cast<const half8_t *>(hr + c);
-        half8_t g = *reinterpret_cast<const half8_t *>(w + c);
-        half8_t o;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = to_half_rn(__fmul_rn(__fdiv_rn((float)v[j], rms), (float)g[j]));
-        *reinterpret_cast<half8_t *>(orow + c) = o;
+    for (int i = 0; i < C; ++i) {
+        const int c = lane * 8 + i * 512;
+        if (c < Hd) {
+            half8_t o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = to_half_rn(__fmul_rn(__fdiv_rn((float)v[i][j], rms), (float)g[i][j]));
+            *reinterpret_cast<half8_t *>(orow + c) = o;
+        }
     }
 }
 int add_rmsnorm_slabs(half_bits *h, const float *slabs, int64_t S, const half_bits *w, float eps, int64_t T, int64_t Hd,
                       half_bits *out, hipStream_t s) {
-    if (Hd % 8) return nvr::fail(NVR_ERR_UNSUPPORTED, "rmsnorm: hidden size %ld not a multiple of 8", (long)Hd);
+    if (Hd % 8 || Hd > 2048) return nvr::fail(NVR_ERR_UNSUPPORTED, "add_rmsnorm_slabs: hidden size %ld must be a multiple of 8, <= 2048", (long)Hd);
+    if (S != 2 && S != 4) return nvr::fail(NVR_ERR_UNSUPPORTED, "add_rmsnorm_slabs: S=%ld must be 2 or 4", (long)S);
     if (T == 0) return 0;
-    add_rmsnorm_slabs_kernel<<<dim3((unsigned)T), dim3(64), 0, s>>>((half_t *)h, slabs, (int)S, T * Hd, (const half_t *)w, eps, (int)Hd,
-                                                                   (half_t *)out);
+    dim3 grid((unsigned)T), block(64);
+#define NVR_SLABN(SS, CC) add_rmsnorm_slabs_kernel<SS, CC><<<grid, block, 0, s>>>((half_t *)h, slabs, T * Hd, (const half_t *)w, eps, (int)Hd, (half_t *)out)
+    if (Hd <= 1024) { if (S == 2) NVR_SLABN(2, 2); else NVR_SLABN(4, 2); }
+    else { if (S == 2) NVR_SLABN(2, 4); else NVR_SLABN(4, 4); }
+#undef NVR_SLABN
     LAUNCH_CHECK();
     return 0;
 }

@@ -119,12 +119,22 @@ int nvr_model_runner::init() {                                       // ModelRun
     auto carve = [&](size_t &off, size_t bytes) { off = in_bytes; in_bytes += (bytes + 255) / 256 * 256; };
     carve(off_ids, max_tokens * 8); carve(off_pos, max_tokens * 8); carve(off_slots, max_tokens * 4);
     carve(off_cu, (max_seqs + 1) * 4); carve(off_ctx, std::max(max_tokens, max_seqs) * 4);
-    carve(off_kvbase, max_tokens * 4); carve(off_bt, max_seqs * max_blocks_per_seq * 4);
+    carve(off_kvbase, max_tokens * 4); carve(off_bt, 16);
+    {
+        size_t o = 0;
+        auto sub = [&](size_t &f, size_t bytes) { f = o; o += (bytes + 15) / 16 * 16; };
+        sub(dof_ids, max_seqs * 8); sub(dof_pos, max_seqs * 8); sub(dof_slots, max_seqs * 4); sub(dof_ctx, max_seqs * 4);
+        sub(dof_bt, max_seqs * max_blocks_per_seq * 4);
+        dec_bytes = o; carve(off_dec, dec_bytes);
+    }
     NVR_HIP_CHECK(hipHostMalloc((void **)&in_host, in_bytes, hipHostMallocDefault));
     NVR_HIP_CHECK(hipMalloc((void **)&in_dev, in_bytes));
     d_ids = (int64_t *)(in_dev + off_ids); d_pos = (int64_t *)(in_dev + off_pos); d_slots = (int32_t *)(in_dev + off_slots);
     d_cu = (int32_t *)(in_dev + off_cu); d_ctx = (int32_t *)(in_dev + off_ctx); d_kvbase = (int32_t *)(in_dev + off_kvbase);
     d_bt = (int32_t *)(in_dev + off_bt);
+    dd_ids = (int64_t *)(in_dev + off_dec + dof_ids); dd_pos = (int64_t *)(in_dev + off_dec + dof_pos);
+    dd_slots = (int32_t *)(in_dev + off_dec + dof_slots); dd_ctx = (int32_t *)(in_dev + off_dec + dof_ctx);
+    dd_bt = (int32_t *)(in_dev + off_dec + dof_bt);
 
     RC(dmalloc(&d_tok, max_seqs)); RC(dmalloc(&d_maxval, max_seqs));
     NVR_HIP_CHECK(hipHostMalloc((void **)&h_tok, max_seqs * 8, hipHostMallocDefault));
@@ -192,7 +202,7 @@ int nvr_model_runner::gen_weights() {
 // GEMMs reach all 256 CUs; otherwise the plain kernel writes fp16 `proj` (+ all-reduce when tensor parallel).
 int nvr_model_runner::row_parallel(Lane &ln, const uint16_t *x, int64_t K, const uint16_t *W, int64_t T, int64_t *S_out) {
     int64_t S = 1;
-    if (!comm.active() && tp == 1 && T <= 64) {
+    if (!comm.active() && tp == 1 && T <= 64 && Hd <= 2048) {
         const int64_t tiles = (Hd / 16) * ((T + 31) / 32);
         while (S < 4 && tiles * S < 256 && K % (32 * S * 2) == 0 && K / (S * 2) >= 128) S *= 2;
     }
@@ -207,8 +217,9 @@ int nvr_model_runner::row_parallel(Lane &ln, const uint16_t *x, int64_t K, const
 // Rows [row0, row0+T) of the step inputs (B sequences) run on lane `ln`.
 int nvr_model_runner::forward(Lane &ln, int64_t row0, int64_t T, int64_t B, bool is_prefill, int64_t max_ctx) {
     hipStream_t st = ln.stream;
-    const int64_t *ids = d_ids + row0, *pos = d_pos + row0;
-    const int32_t *slots = d_slots + row0, *ctx = d_ctx + row0, *bt = d_bt + row0 * max_blocks_per_seq;
+    const int64_t *ids = (is_prefill ? d_ids : dd_ids) + row0, *pos = (is_prefill ? d_pos : dd_pos) + row0;
+    const int32_t *slots = (is_prefill ? d_slots : dd_slots) + row0, *ctx = (is_prefill ? d_ctx : dd_ctx) + row0;
+    const int32_t *bt = dd_bt + row0 * max_blocks_per_seq;
     RC(k::embedding(ids, T, embed, Hd, ln.h, st));
     int64_t S = 1;
     auto add_norm = [&](const uint16_t *wn) -> int {                                       // residual add + next norm
@@ -268,9 +279,12 @@ int nvr_model_runner::execute(nvr_seq *const *seqs, size_t nseq, bool is_prefill
     NVR_HIP_CHECK(hipSetDevice(device));
     if (nseq == 0) return nvr::fail(NVR_ERR_INVALID_ARG, "execute_model: empty batch");
     if ((int64_t)nseq > max_seqs) return nvr::fail(NVR_ERR_INVALID_ARG, "execute_model: %zu sequences > max_num_seqs %ld", nseq, (long)max_seqs);
-    int64_t *ids = (int64_t *)(in_host + off_ids), *pos = (int64_t *)(in_host + off_pos);
-    int32_t *slots = (int32_t *)(in_host + off_slots), *cu = (int32_t *)(in_host + off_cu), *ctx = (int32_t *)(in_host + off_ctx),
-            *kvb = (int32_t *)(in_host + off_kvbase), *bt = (int32_t *)(in_host + off_bt);
+    char *hd = in_host + off_dec;
+    int64_t *ids = is_prefill ? (int64_t *)(in_host + off_ids) : (int64_t *)(hd + dof_ids);
+    int64_t *pos = is_prefill ? (int64_t *)(in_host + off_pos) : (int64_t *)(hd + dof_pos);
+    int32_t *slots = is_prefill ? (int32_t *)(in_host + off_slots) : (int32_t *)(hd + dof_slots);
+    int32_t *ctx = is_prefill ? (int32_t *)(in_host + off_ctx) : (int32_t *)(hd + dof_ctx);
+    int32_t *cu = (int32_t *)(in_host + off_cu), *kvb = (int32_t *)(in_host + off_kvbase), *bt = (int32_t *)(hd + dof_bt);
     int64_t T = 0, max_ctx = 0;
     const int64_t bs = block_size;
     NVR_HIP_CHECK(hipStreamSynchronize(stream));   // staging arena is reused: previous uploads must have landed
@@ -313,10 +327,10 @@ int nvr_model_runner::execute(nvr_seq *const *seqs, size_t nseq, bool is_prefill
     }
     // one H2D per array actually used this step (K19)
     auto up = [&](size_t off, size_t bytes) { return hipMemcpyAsync(in_dev + off, in_host + off, bytes, hipMemcpyHostToDevice, stream); };
-    NVR_HIP_CHECK(up(off_ids, T * 8)); NVR_HIP_CHECK(up(off_pos, T * 8)); NVR_HIP_CHECK(up(off_slots, T * 4));
-    NVR_HIP_CHECK(up(off_ctx, T * 4));
-    if (is_prefill) { NVR_HIP_CHECK(up(off_cu, (nseq + 1) * 4)); NVR_HIP_CHECK(up(off_kvbase, T * 4)); }
-    else NVR_HIP_CHECK(up(off_bt, nseq * max_blocks_per_seq * 4));
+    if (is_prefill) {
+        NVR_HIP_CHECK(up(off_ids, T * 8)); NVR_HIP_CHECK(up(off_pos, T * 8)); NVR_HIP_CHECK(up(off_slots, T * 4));
+        NVR_HIP_CHECK(up(off_ctx, T * 4)); NVR_HIP_CHECK(up(off_cu, (nseq + 1) * 4)); NVR_HIP_CHECK(up(off_kvbase, T * 4));
+    } else NVR_HIP_CHECK(up(off_dec, dof_bt + nseq * max_blocks_per_seq * 4));
 
     last_rows = nseq; last_prefill = is_prefill;
     const int nl = (!is_prefill && (int64_t)nseq >= 8 * (int64_t)lanes.size()) ? (int)lanes.size() : 1;
@@ -324,20 +338,44 @@ int nvr_model_runner::execute(nvr_seq *const *seqs, size_t nseq, bool is_prefill
 
     // decode: replay a hipGraph captured per (batch size, context bucket) — execute_with_cuda_graph :303-326
     const int64_t bucket = (max_ctx + 255) / 256 * 256;
-    const uint64_t key = ((uint64_t)nseq << 32) | (uint64_t)bucket;
-    auto it = graphs.find(key);
-    if (it == graphs.end()) {
-        hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr;
-        NVR_HIP_CHECK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
-        int rc = forward_all(T, (int64_t)nseq, false, bucket, nl);
-        hipError_t e = hipStreamEndCapture(stream, &g);
-        if (rc) { if (g) hipGraphDestroy(g); return rc; }
-        if (e != hipSuccess) return nvr::fail(NVR_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
-        NVR_HIP_CHECK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
-        hipGraphDestroy(g);
-        it = graphs.emplace(key, ge).first;
+    auto get_graph = [&](uint64_t key, hipStream_t cap, auto &&body, hipGraphExec_t *out) -> int {
+        auto it = graphs.find(key);
+        if (it == graphs.end()) {
+            hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr;
+            NVR_HIP_CHECK(hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal));
+            int rc = body();
+            hipError_t e = hipStreamEndCapture(cap, &g);
+            if (rc) { if (g) hipGraphDestroy(g); return rc; }
+            if (e != hipSuccess) return nvr::fail(NVR_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
+            NVR_HIP_CHECK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+            hipGraphDestroy(g);
+            it = graphs.emplace(key, ge).first;
+        }
+        *out = it->second;
+        return NVR_OK;
+    };
+    if (nl <= 1) {
+        hipGraphExec_t ge;
+        RC(get_graph(((uint64_t)nseq << 32) | (uint64_t)bucket, stream, [&] { return forward(lanes[0], 0, T, T, false, bucket); }, &ge));
+        NVR_HIP_CHECK(hipGraphLaunch(ge, stream));
+        return NVR_OK;
     }
-    NVR_HIP_CHECK(hipGraphLaunch(it->second, stream));
+    // micro-batches: one graph per lane, launched on the lane's own stream between a fork and a join event
+    const int64_t per = ((int64_t)nseq + nl - 1) / nl;
+    NVR_HIP_CHECK(hipEventRecord(fork_ev, stream));
+    for (int i = 0; i < nl; ++i) {
+        const int64_t r0 = i * per, cnt = std::min<int64_t>(per, (int64_t)nseq - r0);
+        if (cnt <= 0) continue;
+        hipGraphExec_t ge;
+        const uint64_t key = ((uint64_t)(i + 1) << 56) | ((uint64_t)r0 << 44) | ((uint64_t)cnt << 32) | (uint64_t)bucket;
+        RC(get_graph(key, lanes[i].stream, [&] { return forward(lanes[i], r0, cnt, cnt, false, bucket); }, &ge));
+        if (i > 0) NVR_HIP_CHECK(hipStreamWaitEvent(lanes[i].stream, fork_ev, 0));
+        NVR_HIP_CHECK(hipGraphLaunch(ge, lanes[i].stream));
+        if (i > 0) {
+            NVR_HIP_CHECK(hipEventRecord(lanes[i].done, lanes[i].stream));
+            NVR_HIP_CHECK(hipStreamWaitEvent(stream, lanes[i].done, 0));
+        }
+    }
     return NVR_OK;
 }
 
