@@ -198,6 +198,8 @@ NVR_API void *nvr_runner_stream(nvr_model_runner_t *r);
  * embed_head.rs:130-139,321-336): rank 0 creates the 128-byte RCCL id, the host broadcasts it. */
 NVR_API int nvr_comm_unique_id(uint8_t id_out[128]);
 NVR_API int nvr_runner_init_comm(nvr_model_runner_t *r, const uint8_t id[128]);
+/* collective self-check (all ranks call it): all-reduce of ones == tensor_parallel_size, all-gather of ranks */
+NVR_API int nvr_runner_comm_selftest(nvr_model_runner_t *r);
 
 /* -------------------------------------------------------------------- Engine ---- */
 /* LLMEngine::step loop, src/engine/llm_engine.rs:155-197 (driver of the hot path only) */

@@ -136,7 +136,7 @@ _SIGS = {
     "nvr_runner_num_kvcache_blocks": (C.c_uint64, [_P]),
     "nvr_runner_kv_cache": (C.c_int, [_P, C.c_size_t, C.POINTER(_P), C.POINTER(_P)]),
     "nvr_runner_stream": (_P, [_P]), "nvr_comm_unique_id": (C.c_int, [_P]),
-    "nvr_runner_init_comm": (C.c_int, [_P, _P]),
+    "nvr_runner_init_comm": (C.c_int, [_P, _P]), "nvr_runner_comm_selftest": (C.c_int, [_P]),
     "nvr_engine_create": (_P, [C.POINTER(ConfigC), C.POINTER(ModelConfigC)]), "nvr_engine_destroy": (None, [_P]),
     "nvr_engine_add_request": (C.c_int, [_P, _P, C.c_size_t, C.POINTER(SamplingParamsC), C.POINTER(C.c_uint64)]),
     "nvr_engine_step": (C.c_int, [_P, C.POINTER(StepInfoC)]), "nvr_engine_is_finished": (C.c_int, [_P]),
@@ -508,6 +508,9 @@ class ModelRunner:
         k, v = _P(), _P()
         check(lib().nvr_runner_kv_cache(self.h, layer, C.byref(k), C.byref(v)))
         return k.value, v.value
+
+    def comm_selftest(self) -> None:
+        check(lib().nvr_runner_comm_selftest(self.h))
 
     def init_comm(self, unique_id: bytes) -> None:
         buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)

@@ -1,6 +1,7 @@
 #include "comm.h"
 #include <dlfcn.h>
 #include <rccl/rccl.h>
+#include <cstdlib>
 #include <cstring>
 #include "common.h"
 
@@ -59,6 +60,7 @@ int Comm::init(const uint8_t idb[128], int nr, int rk) {
     ncclComm_t c = nullptr;
     NVR_NCCL(g_api.CommInitRank(&c, nr, id, rk));
     comm = c; nranks = nr; rank = rk;
+    if (const char *e = std::getenv("NVR_TP_FORCE_COMM")) force = (e[0] == '1');
     return NVR_OK;
 }
 

@@ -17,7 +17,8 @@ struct Comm {
 
     static int unique_id(uint8_t out[128]);
     int init(const uint8_t id[128], int nranks, int rank);
-    bool active() const { return comm != nullptr && nranks > 1; }
+    bool force = false;     // NVR_TP_FORCE_COMM=1: enqueue the collectives even with one rank (exercises RCCL on a 1-GPU box)
+    bool active() const { return comm != nullptr && (nranks > 1 || force); }
     int all_reduce_sum_f16(void *buf, size_t count, hipStream_t s);
     int all_gather_bytes(const void *send, void *recv, size_t bytes_per_rank, hipStream_t s);
     void destroy();

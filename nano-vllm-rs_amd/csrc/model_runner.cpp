@@ -141,7 +141,7 @@ int nvr_model_runner::init() {                                       // ModelRun
     RC(dmalloc(&d_temp, max_seqs)); RC(dmalloc(&d_topk, max_seqs)); RC(dmalloc(&d_topp, max_seqs)); RC(dmalloc(&d_keys, max_seqs));
     NVR_HIP_CHECK(hipHostMalloc((void **)&samp_host, max_seqs * 24, hipHostMallocDefault));
     NVR_HIP_CHECK(hipMalloc(&sample_ws, k::sample_workspace_bytes(max_seqs, Vl)));
-    if (tp > 1) { RC(dmalloc(&d_gather_val, tp * max_seqs)); RC(dmalloc(&d_gather_idx, tp * max_seqs)); }
+    RC(dmalloc(&d_gather_val, tp * max_seqs)); RC(dmalloc(&d_gather_idx, tp * max_seqs));   // (max, argmax) pairs of every rank
 
     // KV pool (create_kv_cache, :364-396): [NB, bs, KVH/tp, D] per layer per K/V, one allocation.
     const size_t block_elems = (size_t)block_size * KVH * D;
@@ -334,7 +334,7 @@ int nvr_model_runner::execute(nvr_seq *const *seqs, size_t nseq, bool is_prefill
 
     last_rows = nseq; last_prefill = is_prefill;
     const int nl = (!is_prefill && (int64_t)nseq >= 8 * (int64_t)lanes.size()) ? (int)lanes.size() : 1;
-    if (is_prefill || cfg.enforce_eager) return forward_all(T, (int64_t)nseq, is_prefill, max_ctx, nl);
+    if (is_prefill || cfg.enforce_eager || graphs_disabled) return forward_all(T, (int64_t)nseq, is_prefill, max_ctx, nl);
 
     // decode: replay a hipGraph captured per (batch size, context bucket) — execute_with_cuda_graph :303-326
     const int64_t bucket = (max_ctx + 255) / 256 * 256;
@@ -356,7 +356,13 @@ int nvr_model_runner::execute(nvr_seq *const *seqs, size_t nseq, bool is_prefill
     };
     if (nl <= 1) {
         hipGraphExec_t ge;
-        RC(get_graph(((uint64_t)nseq << 32) | (uint64_t)bucket, stream, [&] { return forward(lanes[0], 0, T, T, false, bucket); }, &ge));
+        int rc = get_graph(((uint64_t)nseq << 32) | (uint64_t)bucket, stream, [&] { return forward(lanes[0], 0, T, T, false, bucket); }, &ge);
+        if (rc && comm.active()) {            // a graph holding RCCL nodes could not be built on this stack: run eagerly
+            graphs_disabled = true;
+            (void)hipGetLastError();
+            return forward_all(T, (int64_t)nseq, false, max_ctx, 1);
+        }
+        if (rc) return rc;
         NVR_HIP_CHECK(hipGraphLaunch(ge, stream));
         return NVR_OK;
     }
@@ -375,6 +381,33 @@ int nvr_model_runner::execute(nvr_seq *const *seqs, size_t nseq, bool is_prefill
             NVR_HIP_CHECK(hipEventRecord(lanes[i].done, lanes[i].stream));
             NVR_HIP_CHECK(hipStreamWaitEvent(stream, lanes[i].done, 0));
         }
+    }
+    return NVR_OK;
+}
+
+// all-reduce and all-gather of a known pattern on this runner's communicator (tests; collective over all ranks)
+int nvr_model_runner::comm_selftest() {
+    NVR_HIP_CHECK(hipSetDevice(device));
+    if (!comm.comm) return nvr::fail(NVR_ERR_RCCL, "comm_selftest: communicator not initialised");
+    const int n = 4096;
+    std::vector<uint16_t> hbuf(n);
+    for (int i = 0; i < n; ++i) hbuf[i] = 0x3C00;                 // fp16 1.0
+    NVR_HIP_CHECK(hipMemcpyAsync(proj, hbuf.data(), n * 2, hipMemcpyHostToDevice, stream));
+    RC(comm.all_reduce_sum_f16(proj, n, stream));
+    NVR_HIP_CHECK(hipMemcpyAsync(hbuf.data(), proj, n * 2, hipMemcpyDeviceToHost, stream));
+    NVR_HIP_CHECK(hipStreamSynchronize(stream));
+    const uint16_t want[9] = {0, 0x3C00, 0x4000, 0x4200, 0x4400, 0x4500, 0x4600, 0x4700, 0x4800};   // fp16 of 0..8
+    for (int i = 0; i < n; ++i)
+        if (hbuf[i] != want[comm.nranks]) return nvr::fail(NVR_ERR_RCCL, "comm_selftest: all-reduce gave 0x%04x at %d, want 0x%04x", hbuf[i], i, want[comm.nranks]);
+    if (tp > 1) {
+        std::vector<int64_t> mine(8, rank), all(8 * tp, -1);
+        NVR_HIP_CHECK(hipMemcpyAsync(d_tok, mine.data(), 64, hipMemcpyHostToDevice, stream));
+        RC(comm.all_gather_bytes(d_tok, d_gather_idx, 64, stream));
+        NVR_HIP_CHECK(hipMemcpyAsync(all.data(), d_gather_idx, 64 * tp, hipMemcpyDeviceToHost, stream));
+        NVR_HIP_CHECK(hipStreamSynchronize(stream));
+        for (int64_t r = 0; r < tp; ++r)
+            for (int j = 0; j < 8; ++j)
+                if (all[r * 8 + j] != r) return nvr::fail(NVR_ERR_RCCL, "comm_selftest: all-gather slot %ld holds %ld", (long)r, (long)all[r * 8 + j]);
     }
     return NVR_OK;
 }

@@ -64,6 +64,8 @@ struct nvr_model_runner {
     std::map<uint64_t, hipGraphExec_t> graphs;
     size_t last_rows = 0; bool last_prefill = false;
     nvr::Comm comm;
+    bool graphs_disabled = false;   // set when capture with RCCL nodes fails: fall back to eager launches
+    int comm_selftest();
 
     ~nvr_model_runner();
     int init();
