@@ -207,7 +207,8 @@ def main() -> None:
     pmc_path = os.path.join(ROOT, "profiles", "pmc_attn_latest.json")
     if os.path.exists(pmc_path):
         try:
-            traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
+            # PMC pass (profiles/): HBM bytes / algorithmic bytes of this kernel, scaled to this run's launch
+            traffic = int(round(json.load(open(pmc_path))["traffic_over_algorithmic"] * attn["alg_bytes"]))
         except Exception:
             traffic = None
 

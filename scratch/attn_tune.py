@@ -1,7 +1,7 @@
 """Microbenchmark of paged decode attention variants (NVR_ATTN_TUNE=U,waves,prefetch,nt,parts) at the
 BASELINE config-2 shape: B=32, ctx~1030, H=16, KVH=8, D=128, bs=256, 28 layers cycled (HBM-cold)."""
 import ctypes as C, os, sys
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, nvr_import
 nvr = nvr_import.load(); l = nvr.lib(); nvr.check(l.nvr_device_set(0))
 B, H, KVH, D, bs, L = 32, 16, 8, 128, 256, 28
