@@ -1,0 +1,215 @@
+// gemm_tiled.hip — LDS-tiled MFMA GEMM for the prefill regime (T >= 128 tokens): y[T,N] = x[T,K]·W[N,K]^T
+// with the same three epilogues as the decode kernel (plain fp16, gate_up -> SiluAndMul, qkv -> RoPE + KV store).
+// reference call sites as in linear.hip (linear.rs:354-356,228-239,437-439; activation.rs:46-63;
+// rotary_embedding.rs:23-48; attention.rs:150-174).  Bound: MFMA (dense contraction, SURVEY §8d:
+// 880.8 MFLOP per prefill token for Qwen3-0.6B).
+//
+// Structure (cdna_hip_programming.md §5 "standard MFMA GEMM main loop", the 128x128 two-barrier form):
+//   workgroup = 4 waves = 128 (n) x 128 (m) output tile, BK = 64; wave (wn, wm) owns 64 x 64 = 4x4 MFMA tiles
+//   of v_mfma_f32_16x16x32_f16 (A = W rows, B = x rows, both K-contiguous in memory);
+//   both operand tiles are staged global -> LDS by global_load_lds_dwordx4 (16 B per lane, no VGPR round
+//   trip) into two buffers, the load of K-tile t+1 overlapping the MFMAs on tile t;
+//   LDS image = [row][8 chunks of 16 B] with chunk' = chunk ^ (row & 7): the swizzle is applied to the per-lane
+//   SOURCE address (the LDS destination of glds is lane-linear) and again on the ds_read_b128 address, so a
+//   16-lane fragment read touches 8 distinct 16-B slots (2-way instead of 16-way conflicts).
+// Row mapping of the A operand lets one lane hold what its epilogue needs: for SiluAndMul a wave's 4 n-tiles are
+// [gate c, gate c+16, up c, up c+16]; for RoPE an n-tile is 8 columns of the first half of a head and their 8
+// partners of the second half (the partner of lane l sits in lane l^32).
+#include "kernels.h"
+#include "device_utils.h"
+#include "../common.h"
+
+namespace nvr { namespace k {
+
+enum { TEPI_F16 = 0, TEPI_SILU = 2, TEPI_ROPE = 3 };
+
+struct TileEpi {
+    const int64_t *pos; const int32_t *slots; const float *cos_t, *sin_t;
+    half_t *kc, *vc;
+    int32_t H, KVH, D;
+};
+
+constexpr int BM = 128, BN = 128, BK = 64;
+
+// W row of local row r (0..15) of the workgroup's 16-row n-tile `t` (0..7)
+template <int EPI>
+__device__ __forceinline__ int tile_w_row(int bx, int t, int r, int N, const TileEpi &e) {
+    if (EPI == TEPI_SILU) {                       // N == I; the workgroup owns 64 output columns
+        const int wn = t >> 2, nt = t & 3;
+        return (nt >> 1) * N + bx * 64 + wn * 32 + (nt & 1) * 16 + r;
+    }
+    if (EPI == TEPI_ROPE) {
+        const int g = bx * 8 + t, tph = e.D / 16, head = g / tph, c = g % tph;
+        if (head < e.H + e.KVH) return head * e.D + (r < 8 ? c * 8 + r : e.D / 2 + c * 8 + (r - 8));
+        return head * e.D + c * 16 + r;
+    }
+    return bx * BN + t * 16 + r;
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_tiled_kernel(const half_t *__restrict__ x, int64_t ldx,
+                                                         const half_t *__restrict__ W, int T, int K, int N, int NW,
+                                                         half_t *__restrict__ y, TileEpi epi) {
+    // one LDS array (cdna guide §5 item 4a): [2 buffers][A 16 KiB | B 16 KiB]
+    __shared__ __attribute__((aligned(16))) char smem[2 * 2 * BM * BK * 2];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = lane & 15, q = lane >> 4;
+    const int wn = wave >> 1, wm = wave & 1;
+    const int m0 = blockIdx.y * BM;
+
+    // staging: thread t copies 16-byte piece idx = i*256 + t (row = idx/8, LDS chunk c' = idx%8) of each operand tile
+    const half_t *asrc[4], *bsrc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = i * 256 + threadIdx.x, row = idx >> 3, c = (idx & 7) ^ (row & 7);
+        int wr = tile_w_row<EPI>(blockIdx.x, row >> 4, row & 15, N, epi);
+        if (wr > NW - 1) wr = NW - 1;
+        int xr = m0 + row; if (xr > T - 1) xr = T - 1;
+        asrc[i] = W + (int64_t)wr * K + c * 8;
+        bsrc[i] = x + (int64_t)xr * ldx + c * 8;
+    }
+    auto stage = [&](int buf, int k0) {
+        char *a_dst = smem + buf * (2 * BM * BK * 2), *b_dst = a_dst + BM * BK * 2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int piece = (i * 256 + wave * 64) * 16;               // wave-uniform LDS base; hardware adds lane*16
+            __builtin_amdgcn_global_load_lds(asrc[i] + k0, (__attribute__((address_space(3))) void *)(a_dst + piece), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(bsrc[i] + k0, (__attribute__((address_space(3))) void *)(b_dst + piece), 16, 0, 0);
+        }
+    };
+
+    float4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
+
+    const int KT = K / BK;
+    stage(0, 0);
+    __syncthreads();                                                      // includes s_waitcnt vmcnt(0)
+    for (int kt = 0; kt < KT; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < KT) stage(cur ^ 1, (kt + 1) * BK);
+        const char *a_lds = smem + cur * (2 * BM * BK * 2), *b_lds = a_lds + BM * BK * 2;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            half8_t a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int arow = wn * 64 + i * 16 + r, brow = wm * 64 + i * 16 + r;
+                a[i] = *reinterpret_cast<const half8_t *>(a_lds + (arow * 8 + ((ks * 4 + q) ^ (arow & 7))) * 16);
+                b[i] = *reinterpret_cast<const half8_t *>(b_lds + (brow * 8 + ((ks * 4 + q) ^ (brow & 7))) * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // epilogue: C layout row (n) = q*4 + reg, col (token) = r
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = m0 + wm * 64 + j * 16 + r;
+        const int mc = m < T ? m : T - 1;
+        if (EPI == TEPI_F16) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int n = blockIdx.x * BN + wn * 64 + i * 16 + q * 4;
+                if (m < T && n < N) {
+                    half4_t h = {(half_t)acc[i][j][0], (half_t)acc[i][j][1], (half_t)acc[i][j][2], (half_t)acc[i][j][3]};
+                    *reinterpret_cast<half4_t *>(y + (int64_t)m * N + n) = h;
+                }
+            }
+        } else if (EPI == TEPI_SILU) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {                                 // tiles i (gate) and i+2 (up), same 16 columns
+                const int n = blockIdx.x * 64 + wn * 32 + i * 16 + q * 4;
+                half4_t h;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float gf = (float)to_half_rn(acc[i][j][e]), uf = (float)to_half_rn(acc[i + 2][j][e]);
+                    const float sg = 1.0f / (1.0f + __expf(-gf));
+                    h[e] = to_half_rn(__fmul_rn(__fmul_rn(gf, sg), uf));
+                }
+                if (m < T && n < N) *reinterpret_cast<half4_t *>(y + (int64_t)m * N + n) = h;
+            }
+        } else {                                                          // TEPI_ROPE
+            const int tph = epi.D / 16, half_d = epi.D / 2;
+            const int64_t ldq = (int64_t)(epi.H + 2 * epi.KVH) * epi.D;
+            const int64_t p = epi.pos[mc];
+            const int slot = epi.slots ? epi.slots[mc] : -1;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int g = blockIdx.x * 8 + wn * 4 + i, head = g / tph, c = g % tph;
+                if (head >= epi.H + 2 * epi.KVH) continue;
+                float v[4], pv[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] = (float)to_half_rn(acc[i][j][e]); pv[e] = __shfl_xor(v[e], 32, 64); }
+                half4_t h; int col;
+                if (head < epi.H + epi.KVH) {
+                    const int jj = c * 8 + (q & 1) * 4;
+                    const float4_t cs = *reinterpret_cast<const float4_t *>(epi.cos_t + p * half_d + jj);
+                    const float4_t sn = *reinterpret_cast<const float4_t *>(epi.sin_t + p * half_d + jj);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        h[e] = (q < 2) ? to_half_rn(__fsub_rn(__fmul_rn(v[e], cs[e]), __fmul_rn(pv[e], sn[e])))
+                                       : to_half_rn(__fadd_rn(__fmul_rn(v[e], cs[e]), __fmul_rn(pv[e], sn[e])));
+                    col = (q < 2) ? jj : half_d + jj;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) h[e] = to_half_rn(acc[i][j][e]);
+                    col = c * 16 + q * 4;
+                }
+                if (m < T) {
+                    *reinterpret_cast<half4_t *>(y + (int64_t)m * ldq + head * epi.D + col) = h;
+                    if (slot >= 0 && head >= epi.H) {
+                        const bool is_k = head < epi.H + epi.KVH;
+                        const int kvh = is_k ? head - epi.H : head - epi.H - epi.KVH;
+                        *reinterpret_cast<half4_t *>((is_k ? epi.kc : epi.vc) + ((int64_t)slot * epi.KVH + kvh) * epi.D + col) = h;
+                    }
+                }
+            }
+        }
+    }
+}
+
+static int tiled_check(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return nvr::fail(NVR_ERR_HIP, "%s launch failed: %s", what, hipGetErrorString(e));
+    return 0;
+}
+
+bool gemm_tiled_ok(int64_t T, int64_t K, int64_t N, int64_t ldx) { return T >= 128 && K % BK == 0 && N % 16 == 0 && ldx % 8 == 0; }
+
+int gemm_tiled(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t N, half_bits *y, hipStream_t s) {
+    if (!gemm_tiled_ok(T, K, N, ldx)) return nvr::fail(NVR_ERR_UNSUPPORTED, "gemm_tiled: T=%ld K=%ld N=%ld", (long)T, (long)K, (long)N);
+    dim3 grid((unsigned)((N + BN - 1) / BN), (unsigned)((T + BM - 1) / BM));
+    gemm_tiled_kernel<TEPI_F16><<<grid, dim3(256), 0, s>>>((const half_t *)x, ldx, (const half_t *)W, (int)T, (int)K, (int)N, (int)N,
+                                                           (half_t *)y, TileEpi{});
+    return tiled_check("gemm_tiled");
+}
+int gemm_tiled_silu_mul(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t I, half_bits *out, hipStream_t s) {
+    if (!gemm_tiled_ok(T, K, I, ldx) || I % 64) return nvr::fail(NVR_ERR_UNSUPPORTED, "gemm_tiled_silu_mul: T=%ld K=%ld I=%ld", (long)T, (long)K, (long)I);
+    dim3 grid((unsigned)(I / 64), (unsigned)((T + BM - 1) / BM));
+    gemm_tiled_kernel<TEPI_SILU><<<grid, dim3(256), 0, s>>>((const half_t *)x, ldx, (const half_t *)W, (int)T, (int)K, (int)I, (int)(2 * I),
+                                                            (half_t *)out, TileEpi{});
+    return tiled_check("gemm_tiled_silu_mul");
+}
+int gemm_tiled_qkv_rope_store(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t H, int64_t KVH, int64_t D,
+                              const int64_t *positions, const int32_t *slots, const float *cos_t, const float *sin_t, half_bits *qkv,
+                              half_bits *k_cache, half_bits *v_cache, hipStream_t s) {
+    const int64_t N = (H + 2 * KVH) * D;
+    if (!gemm_tiled_ok(T, K, N, ldx) || D % 16) return nvr::fail(NVR_ERR_UNSUPPORTED, "gemm_tiled_qkv_rope_store: T=%ld K=%ld D=%ld", (long)T, (long)K, (long)D);
+    TileEpi e{};
+    e.pos = positions; e.slots = slots; e.cos_t = cos_t; e.sin_t = sin_t; e.kc = (half_t *)k_cache; e.vc = (half_t *)v_cache;
+    e.H = (int32_t)H; e.KVH = (int32_t)KVH; e.D = (int32_t)D;
+    dim3 grid((unsigned)((N / 16 + 7) / 8), (unsigned)((T + BM - 1) / BM));
+    gemm_tiled_kernel<TEPI_ROPE><<<grid, dim3(256), 0, s>>>((const half_t *)x, ldx, (const half_t *)W, (int)T, (int)K, (int)N, (int)N,
+                                                            (half_t *)qkv, e);
+    return tiled_check("gemm_tiled_qkv_rope_store");
+}
+
+}}  // namespace nvr::k

@@ -43,6 +43,15 @@ int linear_qkv_rope_store(const half_bits *x, int64_t ldx, const half_bits *W, i
                           int64_t KVH, int64_t D, const int64_t *positions, const int32_t *slots, const float *cos_t,
                           const float *sin_t, half_bits *qkv, half_bits *k_cache, half_bits *v_cache, hipStream_t s);
 
+// LDS-tiled MFMA GEMM for the prefill regime (T >= 128): same results layout and epilogues as the kernels above
+bool gemm_tiled_ok(int64_t T, int64_t K, int64_t N, int64_t ldx);
+int gemm_tiled(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t N, half_bits *y, hipStream_t s);
+int gemm_tiled_silu_mul(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t I, half_bits *out,
+                        hipStream_t s);
+int gemm_tiled_qkv_rope_store(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t H, int64_t KVH,
+                              int64_t D, const int64_t *positions, const int32_t *slots, const float *cos_t, const float *sin_t,
+                              half_bits *qkv, half_bits *k_cache, half_bits *v_cache, hipStream_t s);
+
 // Attention over rows of keys addressed either through a block table (paged) or contiguously.
 struct AttnArgs {
     const half_bits *q; int64_t ldq;          // q[t] at q + t*ldq, heads contiguous [H, D]

@@ -214,6 +214,7 @@ int linear(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64
         return nvr::fail(NVR_ERR_UNSUPPORTED, "linear: K=%ld must be a multiple of 32, N=%ld of 16, ldx=%ld of 8",
                          (long)K, (long)N, (long)ldx);
     if (T == 0) return 0;
+    if (!y_f32 && gemm_tiled_ok(T, K, N, ldx)) return gemm_tiled(x, ldx, W, T, K, N, (half_bits *)y, s);   // prefill regime
     const half_t *xx = (const half_t *)x, *ww = (const half_t *)W;
     const int t = (int)T, k = (int)K, n = (int)N;
     const LinEpi e{};
@@ -264,6 +265,7 @@ int linear_silu_mul(const half_bits *x, int64_t ldx, const half_bits *W, int64_t
     if (K % 32 || I % 16 || ldx % 8)
         return nvr::fail(NVR_ERR_UNSUPPORTED, "linear_silu_mul: K=%ld must be a multiple of 32, I=%ld of 16", (long)K, (long)I);
     if (T == 0) return 0;
+    if (gemm_tiled_ok(T, K, I, ldx) && I % 64 == 0) return gemm_tiled_silu_mul(x, ldx, W, T, K, I, out, s);
     const half_t *xx = (const half_t *)x, *ww = (const half_t *)W;
     const LinEpi e{};
     const unsigned gx = (unsigned)(I / 16);
@@ -285,6 +287,8 @@ int linear_qkv_rope_store(const half_bits *x, int64_t ldx, const half_bits *W, i
     if (K % 32 || D % 16 || ldx % 8)
         return nvr::fail(NVR_ERR_UNSUPPORTED, "linear_qkv_rope_store: K=%ld must be a multiple of 32, D=%ld of 16", (long)K, (long)D);
     if (T == 0) return 0;
+    if (gemm_tiled_ok(T, K, (H + 2 * KVH) * D, ldx))
+        return gemm_tiled_qkv_rope_store(x, ldx, W, T, K, H, KVH, D, positions, slots, cos_t, sin_t, qkv, k_cache, v_cache, s);
     const half_t *xx = (const half_t *)x, *ww = (const half_t *)W;
     LinEpi e{};
     e.pos = positions; e.slots = slots; e.cos_t = cos_t; e.sin_t = sin_t; e.kc = (half_t *)k_cache; e.vc = (half_t *)v_cache;

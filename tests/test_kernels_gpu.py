@@ -104,7 +104,8 @@ def test_add_rmsnorm(T, Hd):
 @pytest.mark.parametrize("T,K,N,f32", [(1, 64, 64, False), (7, 128, 48, False), (32, 1024, 4096, False),
                                        (32, 2048, 1024, False), (33, 1024, 256, False), (32, 3072, 1024, False),
                                        (16, 1024, 6144, False), (4, 256, 1024, True), (32, 1024, 16 * 1187, True),
-                                       (100, 512, 512, False)])
+                                       (100, 512, 512, False), (128, 1024, 4096, False), (300, 2048, 1024, False),
+                                       (1000, 3072, 1024, False), (257, 64, 48, False)])
 def test_linear(T, K, N, f32):
     rng = np.random.default_rng(3)
     x, xb = h16(rng.standard_normal((T, K)))
@@ -392,7 +393,7 @@ def test_fill_weight_bit_exact_with_oracle():
 
 
 # ------------------------------------------------------------------------------------------- fused epilogues
-@pytest.mark.parametrize("T,K,I", [(32, 1024, 3072), (5, 256, 64), (40, 512, 128)])
+@pytest.mark.parametrize("T,K,I", [(32, 1024, 3072), (5, 256, 64), (40, 512, 128), (200, 1024, 3072), (129, 256, 64)])
 def test_linear_silu_mul_fused_equals_unfused_graph(T, K, I):
     """gate_up GEMM + SiluAndMul in one launch must equal linear -> fp16 -> silu_and_mul -> fp16 (oracle order)."""
     rng = np.random.default_rng(20)
@@ -404,10 +405,11 @@ def test_linear_silu_mul_fused_equals_unfused_graph(T, K, I):
     assert_close_f16(d_out.to_numpy((T, I), F16), ref, ulps=2, atol=3e-4, what="linear+silu_mul")
 
 
-@pytest.mark.parametrize("T,K,H,KVH,D", [(32, 1024, 16, 8, 128), (7, 256, 4, 2, 64), (33, 512, 2, 2, 128)])
+@pytest.mark.parametrize("T,K,H,KVH,D", [(32, 1024, 16, 8, 128), (7, 256, 4, 2, 64), (33, 512, 2, 2, 128), (130, 1024, 16, 8, 128),
+                                         (300, 256, 4, 2, 64), (128, 512, 2, 2, 128)])
 def test_linear_qkv_rope_store_fused(T, K, H, KVH, D):
     rng = np.random.default_rng(21)
-    NB, bs, max_pos = 8, 16, 300
+    NB, bs, max_pos = 24, 16, 300
     QKV = (H + 2 * KVH) * D
     x, xb = h16(rng.standard_normal((T, K)))
     W, Wb = h16(rng.standard_normal((QKV, K)) * 0.05)
