@@ -304,6 +304,12 @@ NVR_API int nvr_paged_attn_decode(const nvr_half *q, int64_t ldq, const nvr_half
 NVR_API int nvr_attn_prefill_varlen(const nvr_half *q, const nvr_half *k, const nvr_half *v, int64_t ld,
                                     const nvr_attn_meta *meta, int64_t T, int64_t H, int64_t KVH, int64_t D,
                                     float scale, nvr_half *out, void *stream);
+/* K8 prefix-cached prefill attention, attention.rs:211-222,264-318: the nq_b queries of sequence b (cu_seqlens_q) sit at
+ * positions context_lens[b]-nq_b .. context_lens[b]-1 and read K/V (cached prefix + the new tokens, already stored)
+ * through the block table; causal inside the new tokens */
+NVR_API int nvr_attn_prefill_paged(const nvr_half *q, int64_t ldq, const nvr_half *k_cache, const nvr_half *v_cache,
+                                   const nvr_attn_meta *meta, int64_t T, int64_t H, int64_t KVH, int64_t D, int64_t block_size,
+                                   float scale, nvr_half *out, void *stream);
 /* K13 SiluAndMul, activation.rs:46-63: [T,2I] -> [T,I] */
 NVR_API int nvr_silu_and_mul(const nvr_half *x, int64_t T, int64_t I, nvr_half *out, void *stream);
 /* K15 last-token select, embed_head.rs:272-289 */

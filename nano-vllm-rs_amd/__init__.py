@@ -171,6 +171,8 @@ _SIGS = {
                                         C.c_int64, C.c_float, _P, _P, _P]),
     "nvr_attn_prefill_varlen": (C.c_int, [_P, _P, _P, C.c_int64, C.POINTER(AttnMetaC), C.c_int64, C.c_int64, C.c_int64,
                                           C.c_int64, C.c_float, _P, _P]),
+    "nvr_attn_prefill_paged": (C.c_int, [_P, C.c_int64, _P, _P, C.POINTER(AttnMetaC), C.c_int64, C.c_int64, C.c_int64, C.c_int64,
+                                         C.c_int64, C.c_float, _P, _P]),
     "nvr_silu_and_mul": (C.c_int, [_P, C.c_int64, C.c_int64, _P, _P]),
     "nvr_select_last_tokens": (C.c_int, [_P, _P, C.c_int64, C.c_int64, _P, _P]),
     "nvr_argmax": (C.c_int, [_P, C.c_int64, C.c_int64, _P, _P]),

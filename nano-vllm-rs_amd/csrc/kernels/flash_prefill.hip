@@ -1,0 +1,196 @@
+// flash_prefill.hip — varlen causal prefill attention (K7) and its prefix-cached paged variant (K8) on MFMA.
+// reference: Attention::flash_attention_varlen + compute_attention + causal mask, src/layers/attention.rs:177-208,
+// 238-261,321-339; flash_attention_varlen_with_cache / gather_cached_kv :211-222,264-318; GQA :419-435.
+// Semantics (SURVEY A-9): per head softmax_f32(q·Kᵀ·D^-½ + causal mask)·V, query at absolute position p sees keys 0..p.
+// Bound: MFMA (4·D flop per query-key pair and head).
+//
+// One workgroup = 4 waves = one (tile of 64/G query positions, kv head); wave = 16 positions of one of the G query
+// heads of that kv head, so the K/V tiles staged in LDS (global_load_lds, 64 keys per step, double buffered) are
+// shared by all G heads.  Both products run with the QUERY on the lane:
+//   Sᵀ[key, q] = K·Qᵀ   A = K rows from LDS (ds_read_b128, XOR-swizzled image), B = the lane's Q row (registers);
+//                       the accumulator holds 4 keys x 1 query per 16-key tile, so the row max / sum are in-lane
+//                       plus two cross-group shuffles (no LDS, cdna guide §5.5 T12 "swapped QKᵀ");
+//   Oᵀ[d, q]  += Vᵀ·Pᵀ  B = exp'd Sᵀ accumulators converted to fp16 in place (k-slot (g,j) <-> key 16·(j/4)+4g+j%4:
+//                       the same permutation is used for A), A = Vᵀ read with ds_read_b64_tr_b16 (hardware
+//                       transpose of 4 keys x 16 d); the O accumulator again has the query on the lane, so the
+//                       online-softmax rescale is lane-local.
+#include "kernels.h"
+#include "device_utils.h"
+#include "../common.h"
+
+namespace nvr { namespace k {
+
+struct FlashParams {
+    const half_t *q; int64_t ldq;
+    const half_t *k, *v; int64_t ldkv;
+    const int32_t *block_tables; int32_t max_blocks, block_size, bs_shift;
+    const FlashTile *tiles;
+    int32_t H, KVH;
+    float scale;
+    half_t *out;
+};
+
+typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
+
+template <int D, int G, bool PAGED>
+__global__ __launch_bounds__(256) void flash_prefill_kernel(FlashParams p) {
+    constexpr int KT = 64;                       // keys per step
+    constexpr int CPR = D / 8;                   // 16-byte chunks per K/V row
+    constexpr int PIECES = KT * CPR / 256;       // 16-byte pieces per thread and operand
+    constexpr int NKS = D / 32, NDT = D / 16;
+    __shared__ __attribute__((aligned(16))) char smem[2 * 2 * KT * D * 2];     // [buf][K | V]
+
+    const int g = blockIdx.x % p.KVH;
+    const FlashTile tile = p.tiles[blockIdx.x / p.KVH];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = lane & 15, g4 = lane >> 4;
+    const int hh = wave % G, pb = wave / G;
+    const int qi = pb * 16 + r;                                   // query index inside the tile
+    const bool qvalid = qi < tile.nq;
+    const int qpos = tile.pos0 + (qvalid ? qi : tile.nq - 1);    // absolute position = last visible key
+    const int h = g * G + hh;
+    const int kv_end = tile.pos0 + tile.nq;
+
+    half8_t qf[NKS];
+    {
+        const half_t *qrow = p.q + (int64_t)(tile.q_row0 + (qvalid ? qi : tile.nq - 1)) * p.ldq + (int64_t)h * D + g4 * 8;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) qf[ks] = *reinterpret_cast<const half8_t *>(qrow + ks * 32);
+    }
+
+    auto stage = [&](int buf, int kt) {
+        char *kd = smem + buf * (2 * KT * D * 2), *vd = kd + KT * D * 2;
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) {
+            const int idx = i * 256 + threadIdx.x, row = idx / CPR, c = idx % CPR;
+            int key = kt + row; if (key > kv_end - 1) key = kv_end - 1;
+            int64_t off;
+            if (PAGED) {
+                int bi, bo;
+                if (p.bs_shift >= 0) { bi = key >> p.bs_shift; bo = key & (p.block_size - 1); }
+                else { bi = key / p.block_size; bo = key - bi * p.block_size; }
+                const int64_t rr = (int64_t)p.block_tables[(int64_t)tile.kv_ref * p.max_blocks + bi] * p.block_size + bo;
+                off = (rr * p.KVH + g) * D;
+            } else {
+                off = (int64_t)(tile.kv_ref + key) * p.ldkv + (int64_t)g * D;
+            }
+            const int piece = (i * 256 + wave * 64) * 16;
+            __builtin_amdgcn_global_load_lds(p.k + off + (c ^ (row & (CPR - 1))) * 8, (__attribute__((address_space(3))) void *)(kd + piece), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(p.v + off + c * 8, (__attribute__((address_space(3))) void *)(vd + piece), 16, 0, 0);
+        }
+    };
+
+    float4_t o[NDT];
+#pragma unroll
+    for (int i = 0; i < NDT; ++i) o[i] = (float4_t){0.f, 0.f, 0.f, 0.f};
+    float m = -INFINITY, lsum = 0.f;
+
+    const int nsteps = (kv_end + KT - 1) / KT;
+    stage(0, 0);
+    __syncthreads();
+    for (int it = 0; it < nsteps; ++it) {
+        const int cur = it & 1, kt = it * KT;
+        if (it + 1 < nsteps) stage(cur ^ 1, kt + KT);
+        const char *kl = smem + cur * (2 * KT * D * 2), *vl = kl + KT * D * 2;
+
+        // Sᵀ tiles: 4 x (16 keys x 16 queries)
+        float4_t s[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            s[mt] = (float4_t){0.f, 0.f, 0.f, 0.f};
+            const int row = mt * 16 + r;
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                const half8_t kf = *reinterpret_cast<const half8_t *>(kl + (row * CPR + ((ks * 4 + g4) ^ (row & (CPR - 1)))) * 16);
+                s[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[ks], s[mt], 0, 0, 0);
+            }
+        }
+        // scale, causal mask, online softmax (query on the lane; keys kt + mt*16 + g4*4 + e)
+        float mx = -INFINITY;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int key = kt + mt * 16 + g4 * 4 + e;
+                const float v = key <= qpos ? s[mt][e] * p.scale : -INFINITY;
+                s[mt][e] = v; mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mn = fmaxf(m, mx);                      // finite from the first step on (key 0 <= qpos)
+        const float alpha = __expf(m - mn);
+        m = mn;
+        float ps = 0.f;
+        half8_t pf[2];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float pr = __expf(s[mt][e] - mn);
+                ps += pr;
+                pf[mt >> 1][(mt & 1) * 4 + e] = (half_t)pr;
+            }
+        lsum = lsum * alpha + ps;
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) o[dt] *= alpha;
+        // Oᵀ += Vᵀ·Pᵀ over the two 32-key halves
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) {
+                const int col = dt * 16 + 4 * (r & 3);
+                const int row0 = (2 * k2) * 16 + g4 * 4 + (r >> 2), row1 = row0 + 16;
+                const fp16x4_t a0 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t *)(vl + (row0 * D + col) * 2));
+                const fp16x4_t a1 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t *)(vl + (row1 * D + col) * 2));
+                half8_t vf;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { vf[e] = (half_t)a0[e]; vf[4 + e] = (half_t)a1[e]; }
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[k2], o[dt], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+
+    lsum += __shfl_xor(lsum, 16, 64);
+    lsum += __shfl_xor(lsum, 32, 64);
+    if (qvalid) {
+        const float inv = lsum > 0.f ? 1.0f / lsum : 0.f;
+        half_t *orow = p.out + ((int64_t)(tile.q_row0 + qi) * p.H + h) * D + g4 * 4;
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) {
+            half4_t hv = {(half_t)(o[dt][0] * inv), (half_t)(o[dt][1] * inv), (half_t)(o[dt][2] * inv), (half_t)(o[dt][3] * inv)};
+            *reinterpret_cast<half4_t *>(orow + dt * 16) = hv;
+        }
+    }
+}
+
+bool flash_prefill_ok(int D, int H, int KVH) {
+    if (KVH <= 0 || H % KVH) return false;
+    const int G = H / KVH;
+    return (D == 64 || D == 128) && (G == 1 || G == 2 || G == 4);
+}
+int flash_tile_positions(int H, int KVH) { return 64 / (H / KVH); }
+
+int flash_prefill(const FlashArgs &a, bool paged, hipStream_t s) {
+    if (a.ntiles == 0) return 0;
+    if (!flash_prefill_ok(a.D, a.H, a.KVH)) return nvr::fail(NVR_ERR_UNSUPPORTED, "flash_prefill: D=%d H=%d KVH=%d", a.D, a.H, a.KVH);
+    FlashParams p{};
+    p.q = (const half_t *)a.q; p.ldq = a.ldq; p.k = (const half_t *)a.k; p.v = (const half_t *)a.v; p.ldkv = a.ldkv;
+    p.block_tables = a.block_tables; p.max_blocks = a.max_blocks; p.block_size = a.block_size;
+    p.bs_shift = (a.block_size > 0 && (a.block_size & (a.block_size - 1)) == 0) ? __builtin_ctz(a.block_size) : -1;
+    p.tiles = a.tiles; p.H = a.H; p.KVH = a.KVH; p.scale = a.scale; p.out = (half_t *)a.out;
+    const int G = a.H / a.KVH;
+    dim3 grid((unsigned)((int64_t)a.ntiles * a.KVH)), block(256);
+#define NVR_FLASH(DD, GG)                                                                             \
+    if (a.D == DD && G == GG) {                                                                       \
+        if (paged) flash_prefill_kernel<DD, GG, true><<<grid, block, 0, s>>>(p);                      \
+        else flash_prefill_kernel<DD, GG, false><<<grid, block, 0, s>>>(p);                           \
+    }
+    NVR_FLASH(128, 1) NVR_FLASH(128, 2) NVR_FLASH(128, 4) NVR_FLASH(64, 1) NVR_FLASH(64, 2) NVR_FLASH(64, 4)
+#undef NVR_FLASH
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return nvr::fail(NVR_ERR_HIP, "flash_prefill launch failed: %s", hipGetErrorString(e));
+    return 0;
+}
+
+}}  // namespace nvr::k

@@ -70,6 +70,21 @@ struct AttnArgs {
 size_t attn_workspace_bytes(int64_t nq, int64_t H, int64_t D, int64_t max_ctx);
 int attention(const AttnArgs &a, bool paged, hipStream_t s);
 
+// MFMA flash prefill attention.  A tile = up to 64/G consecutive query positions of one sequence.
+struct FlashTile { int32_t q_row0, nq, pos0, kv_ref; };   // first q row, #queries, absolute position of the first query,
+                                                          // contiguous: first key row of the sequence / paged: block-table row
+struct FlashArgs {
+    const half_bits *q; int64_t ldq;
+    const half_bits *k, *v; int64_t ldkv;                  // contiguous rows (stride ldkv) or paged caches [NB, bs, KVH, D]
+    const int32_t *block_tables; int32_t max_blocks, block_size;
+    const FlashTile *tiles; int32_t ntiles;                // device array
+    int32_t H, KVH, D; float scale;
+    half_bits *out;                                        // [rows, H, D]
+};
+bool flash_prefill_ok(int D, int H, int KVH);
+int flash_tile_positions(int H, int KVH);
+int flash_prefill(const FlashArgs &a, bool paged, hipStream_t s);
+
 // sampler (top-k / top-p / gumbel)
 size_t sample_workspace_bytes(int64_t B, int64_t V);
 int sample(const float *logits, int64_t B, int64_t V, const float *temperature, const int64_t *top_k,

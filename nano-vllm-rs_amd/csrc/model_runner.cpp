@@ -120,6 +120,7 @@ int nvr_model_runner::init() {                                       // ModelRun
     carve(off_ids, max_tokens * 8); carve(off_pos, max_tokens * 8); carve(off_slots, max_tokens * 4);
     carve(off_cu, (max_seqs + 1) * 4); carve(off_ctx, std::max(max_tokens, max_seqs) * 4);
     carve(off_kvbase, max_tokens * 4); carve(off_bt, 16);
+    carve(off_tiles, (size_t)(max_tokens / 16 + max_seqs + 1) * sizeof(k::FlashTile));
     {
         size_t o = 0;
         auto sub = [&](size_t &f, size_t bytes) { f = o; o += (bytes + 15) / 16 * 16; };
@@ -235,7 +236,13 @@ int nvr_model_runner::forward(Lane &ln, int64_t row0, int64_t T, int64_t B, bool
         k::AttnArgs a{};
         a.q = ln.qkv; a.ldq = QKV; a.ctx_lens = ctx; a.nq = (int32_t)T; a.H = (int32_t)H; a.KVH = (int32_t)KVH; a.D = (int32_t)D;
         a.scale = scale; a.max_ctx = (int32_t)max_ctx; a.out = ln.attn;
-        if (is_prefill) {                                            // flash_attention_varlen, attention.rs:177-208
+        if (is_prefill && n_tiles > 0) {                             // flash_attention_varlen, attention.rs:177-208 (MFMA)
+            k::FlashArgs f{};
+            f.q = ln.qkv; f.ldq = QKV; f.k = ln.qkv + H * D; f.v = ln.qkv + (H + KVH) * D; f.ldkv = QKV;
+            f.tiles = (const k::FlashTile *)(in_dev + off_tiles); f.ntiles = (int32_t)n_tiles;
+            f.H = (int32_t)H; f.KVH = (int32_t)KVH; f.D = (int32_t)D; f.scale = scale; f.out = ln.attn;
+            RC(k::flash_prefill(f, false, st));
+        } else if (is_prefill) {                                     // head shapes outside the MFMA kernel: row kernel
             a.k = ln.qkv + H * D; a.v = ln.qkv + (H + KVH) * D; a.ldkv = QKV; a.kv_base = d_kvbase; a.workspace = nullptr;
             RC(k::attention(a, false, st));
         } else {                                                     // flash_attention_decode, attention.rs:225-235
@@ -308,6 +315,15 @@ int nvr_model_runner::execute(nvr_seq *const *seqs, size_t nseq, bool is_prefill
             cu[b + 1] = (int32_t)T;
             max_ctx = std::max(max_ctx, len);
         }
+        n_tiles = 0;
+        if (k::flash_prefill_ok((int)D, (int)H, (int)KVH)) {
+            k::FlashTile *tl = (k::FlashTile *)(in_host + off_tiles);
+            const int qb = k::flash_tile_positions((int)H, (int)KVH);
+            for (size_t b = 0; b < nseq; ++b)                        // longest-context tiles of a sequence first
+                for (int64_t q0 = ((int64_t)seqs[b]->len() - 1) / qb * qb; q0 >= 0; q0 -= qb)
+                    tl[n_tiles++] = k::FlashTile{(int32_t)(cu[b] + q0), (int32_t)std::min<int64_t>(qb, (int64_t)seqs[b]->len() - q0),
+                                                 (int32_t)q0, cu[b]};
+        }
     } else {
         for (size_t b = 0; b < nseq; ++b) {
             const nvr_seq &s = *seqs[b];
@@ -330,6 +346,7 @@ int nvr_model_runner::execute(nvr_seq *const *seqs, size_t nseq, bool is_prefill
     if (is_prefill) {
         NVR_HIP_CHECK(up(off_ids, T * 8)); NVR_HIP_CHECK(up(off_pos, T * 8)); NVR_HIP_CHECK(up(off_slots, T * 4));
         NVR_HIP_CHECK(up(off_ctx, T * 4)); NVR_HIP_CHECK(up(off_cu, (nseq + 1) * 4)); NVR_HIP_CHECK(up(off_kvbase, T * 4));
+        if (n_tiles) NVR_HIP_CHECK(up(off_tiles, n_tiles * sizeof(k::FlashTile)));
     } else NVR_HIP_CHECK(up(off_dec, dof_bt + nseq * max_blocks_per_seq * 4));
 
     last_rows = nseq; last_prefill = is_prefill;

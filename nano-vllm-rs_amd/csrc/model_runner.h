@@ -39,7 +39,8 @@ struct nvr_model_runner {
     char *in_host = nullptr, *in_dev = nullptr; size_t in_bytes = 0;
     int64_t *d_ids = nullptr, *d_pos = nullptr; int32_t *d_slots = nullptr, *d_cu = nullptr, *d_ctx = nullptr,
             *d_kvbase = nullptr, *d_bt = nullptr;
-    size_t off_ids = 0, off_pos = 0, off_slots = 0, off_cu = 0, off_ctx = 0, off_kvbase = 0, off_bt = 0;
+    size_t off_ids = 0, off_pos = 0, off_slots = 0, off_cu = 0, off_ctx = 0, off_kvbase = 0, off_bt = 0, off_tiles = 0;
+    int64_t n_tiles = 0;                   // flash prefill tiles of the current step
     // decode steps use one compact region (ids|pos|slots|ctx|block tables) uploaded with a single memcpy (K19)
     size_t off_dec = 0, dec_bytes = 0, dof_ids = 0, dof_pos = 0, dof_slots = 0, dof_ctx = 0, dof_bt = 0;
     int64_t *dd_ids = nullptr, *dd_pos = nullptr; int32_t *dd_slots = nullptr, *dd_ctx = nullptr, *dd_bt = nullptr;

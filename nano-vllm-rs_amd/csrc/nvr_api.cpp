@@ -338,28 +338,66 @@ int nvr_paged_attn_decode(const nvr_half *q, int64_t ldq, const nvr_half *kc, co
     a.D = (int32_t)D; a.scale = scale; a.max_ctx = m->max_context_len; a.out = out; a.workspace = ws;
     return k::attention(a, true, (hipStream_t)s);
 }
-int nvr_attn_prefill_varlen(const nvr_half *q, const nvr_half *kk, const nvr_half *v, int64_t ld, const nvr_attn_meta *m,
-                            int64_t T, int64_t H, int64_t KVH, int64_t D, float scale, nvr_half *out, void *s) {
-    // per-token visible-key count and first key row are derived from cu_seqlens on the device side
-    // by the caller in the engine path; the stateless entry builds them here from host-visible meta.
-    NVR_GUARD_BEGIN
-    std::vector<int32_t> cu(m->batch + 1);
+// host-side tile list for the flash kernels from cu_seqlens_q (+ context lens for the paged variant)
+static int run_prefill_attn(const nvr_half *q, int64_t ldq, const nvr_half *kk, const nvr_half *v, int64_t ldkv, const nvr_attn_meta *m,
+                            bool paged, int64_t bs, int64_t T, int64_t H, int64_t KVH, int64_t D, float scale, nvr_half *out, hipStream_t st) {
+    std::vector<int32_t> cu(m->batch + 1), ctxl(m->batch);
     NVR_HIP_CHECK(hipMemcpy(cu.data(), m->cu_seqlens_q, cu.size() * 4, hipMemcpyDeviceToHost));
     if (cu[m->batch] != T) return nvr::fail(NVR_ERR_LEN_MISMATCH, "cu_seqlens_q ends at %d but T=%ld", cu[m->batch], (long)T);
-    std::vector<int32_t> ctx(T), base(T);
-    for (int b = 0; b < m->batch; ++b)
-        for (int t = cu[b]; t < cu[b + 1]; ++t) { ctx[t] = t - cu[b] + 1; base[t] = cu[b]; }
-    int32_t *d = nullptr;
-    NVR_HIP_CHECK(hipMalloc((void **)&d, (size_t)(2 * T + 4) * 4));
-    NVR_HIP_CHECK(hipMemcpy(d, ctx.data(), T * 4, hipMemcpyHostToDevice));
-    NVR_HIP_CHECK(hipMemcpy(d + T, base.data(), T * 4, hipMemcpyHostToDevice));
-    k::AttnArgs a{};
-    a.q = q; a.ldq = ld; a.k = kk; a.v = v; a.ldkv = ld; a.ctx_lens = d; a.kv_base = d + T; a.nq = (int32_t)T;
-    a.H = (int32_t)H; a.KVH = (int32_t)KVH; a.D = (int32_t)D; a.scale = scale; a.max_ctx = m->max_seqlen_k; a.out = out;
-    int rc = k::attention(a, false, (hipStream_t)s);
-    hipStreamSynchronize((hipStream_t)s);
-    hipFree(d);
+    if (paged) NVR_HIP_CHECK(hipMemcpy(ctxl.data(), m->context_lens, ctxl.size() * 4, hipMemcpyDeviceToHost));
+    int rc;
+    if (k::flash_prefill_ok((int)D, (int)H, (int)KVH)) {
+        const int qb = k::flash_tile_positions((int)H, (int)KVH);
+        std::vector<k::FlashTile> tiles;
+        for (int b = 0; b < m->batch; ++b) {
+            const int nq = cu[b + 1] - cu[b], p0 = paged ? ctxl[b] - nq : 0;      // query i sits at position p0 + i
+            if (p0 < 0) return nvr::fail(NVR_ERR_INVALID_ARG, "sequence %d: %d queries but context %d", b, nq, ctxl[b]);
+            for (int q0 = 0; q0 < nq; q0 += qb)
+                tiles.push_back(k::FlashTile{cu[b] + q0, std::min(qb, nq - q0), p0 + q0, paged ? b : cu[b]});
+        }
+        k::FlashTile *d = nullptr;
+        NVR_HIP_CHECK(hipMalloc((void **)&d, tiles.size() * sizeof(k::FlashTile) + 16));
+        NVR_HIP_CHECK(hipMemcpy(d, tiles.data(), tiles.size() * sizeof(k::FlashTile), hipMemcpyHostToDevice));
+        k::FlashArgs f{};
+        f.q = q; f.ldq = ldq; f.k = kk; f.v = v; f.ldkv = ldkv; f.block_tables = m->block_tables; f.max_blocks = m->max_blocks;
+        f.block_size = (int32_t)bs; f.tiles = d; f.ntiles = (int32_t)tiles.size(); f.H = (int32_t)H; f.KVH = (int32_t)KVH; f.D = (int32_t)D;
+        f.scale = scale; f.out = out;
+        rc = k::flash_prefill(f, paged, st);
+        hipStreamSynchronize(st);
+        hipFree(d);
+    } else {
+        std::vector<int32_t> ctx(T), ref(T);
+        int maxc = 1;
+        for (int b = 0; b < m->batch; ++b)
+            for (int t = cu[b]; t < cu[b + 1]; ++t) {
+                ctx[t] = (paged ? ctxl[b] - (cu[b + 1] - cu[b]) : 0) + (t - cu[b]) + 1; ref[t] = paged ? b : cu[b];
+                maxc = std::max(maxc, ctx[t]);
+            }
+        int32_t *d = nullptr;
+        NVR_HIP_CHECK(hipMalloc((void **)&d, (size_t)(2 * T + 4) * 4));
+        NVR_HIP_CHECK(hipMemcpy(d, ctx.data(), T * 4, hipMemcpyHostToDevice));
+        NVR_HIP_CHECK(hipMemcpy(d + T, ref.data(), T * 4, hipMemcpyHostToDevice));
+        k::AttnArgs a{};
+        a.q = q; a.ldq = ldq; a.k = kk; a.v = v; a.ldkv = ldkv; a.ctx_lens = d; a.nq = (int32_t)T;
+        if (paged) { a.seq_of_q = d + T; a.block_tables = m->block_tables; a.max_blocks = m->max_blocks; a.block_size = (int32_t)bs; }
+        else a.kv_base = d + T;
+        a.H = (int32_t)H; a.KVH = (int32_t)KVH; a.D = (int32_t)D; a.scale = scale; a.max_ctx = maxc; a.out = out;
+        rc = k::attention(a, paged, st);
+        hipStreamSynchronize(st);
+        hipFree(d);
+    }
     return rc;
+}
+int nvr_attn_prefill_varlen(const nvr_half *q, const nvr_half *kk, const nvr_half *v, int64_t ld, const nvr_attn_meta *m,
+                            int64_t T, int64_t H, int64_t KVH, int64_t D, float scale, nvr_half *out, void *s) {
+    NVR_GUARD_BEGIN
+    return run_prefill_attn(q, ld, kk, v, ld, m, false, 0, T, H, KVH, D, scale, out, (hipStream_t)s);
+    NVR_GUARD_END(NVR_ERR_INVARIANT)
+}
+int nvr_attn_prefill_paged(const nvr_half *q, int64_t ldq, const nvr_half *kc, const nvr_half *vc, const nvr_attn_meta *m, int64_t T,
+                           int64_t H, int64_t KVH, int64_t D, int64_t bs, float scale, nvr_half *out, void *s) {
+    NVR_GUARD_BEGIN
+    return run_prefill_attn(q, ldq, kc, vc, 0, m, true, bs, T, H, KVH, D, scale, out, (hipStream_t)s);
     NVR_GUARD_END(NVR_ERR_INVARIANT)
 }
 int nvr_silu_and_mul(const nvr_half *x, int64_t T, int64_t I, nvr_half *out, void *s) { return k::silu_and_mul(x, T, I, out, (hipStream_t)s); }

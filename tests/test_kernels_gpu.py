@@ -262,7 +262,8 @@ def test_online_softmax_rescale_branch_forced():
 
 
 # ------------------------------------------------------------------------------------------- K7
-@pytest.mark.parametrize("H,KVH,D,lens", [(4, 2, 64, [1, 5, 33]), (16, 8, 128, [70, 129]), (8, 8, 128, [17])])
+@pytest.mark.parametrize("H,KVH,D,lens", [(4, 2, 64, [1, 5, 33]), (16, 8, 128, [70, 129]), (8, 8, 128, [17]), (8, 2, 128, [100, 3, 64]),
+                                          (16, 8, 128, [300]), (16, 2, 128, [40])])
 def test_attn_prefill_varlen(H, KVH, D, lens):
     rng = np.random.default_rng(9)
     T = sum(lens)
@@ -280,7 +281,8 @@ def test_attn_prefill_varlen(H, KVH, D, lens):
     k = np.ascontiguousarray(qkv[:, H * D:(H + KVH) * D].reshape(T, KVH, D))
     v = np.ascontiguousarray(qkv[:, (H + KVH) * D:].reshape(T, KVH, D))
     ref = oracle.round_f16(oracle.attn_prefill_varlen(q, k, v, cu, scale))
-    assert_close_f16(d_out.to_numpy((T, H, D), F16), ref, ulps=2, atol=1e-3, what="varlen prefill attention")
+    # MFMA path: P is rounded to fp16 before P·V (relative 2^-11 per term): 2 fp16 ulp + 2e-3 absolute on O(1) outputs
+    assert_close_f16(d_out.to_numpy((T, H, D), F16), ref, ulps=2, atol=2e-3, what="varlen prefill attention")
 
 
 # ------------------------------------------------------------------------------------------- K13 / K15
@@ -470,3 +472,32 @@ def test_linear_splitk_and_slab_norm(T, K, N, S):
     assert np.array_equal(d_h.to_numpy((T, N), F16).astype(np.float32), hn)
     assert_close_f16(d_out.to_numpy((T, N), F16), oracle.round_f16(oracle.rmsnorm(hn, w, 1e-6)), ulps=1, atol=1e-6)
     assert nvr.lib().nvr_linear_splitk(dev(xb).ptr, K, dev(Wb).ptr, T, K, N, 5, d_slabs.ptr, None) == -10
+
+
+# ------------------------------------------------------------------------------------------- K8
+@pytest.mark.parametrize("H,KVH,D,bs,cases", [
+    (16, 8, 128, 16, [(40, 9), (100, 100), (33, 1)]),      # (context_len, new tokens): cached prefix + new, all new, decode-like
+    (4, 2, 64, 16, [(70, 6), (16, 16)]),
+    (8, 2, 128, 256, [(300, 44)]),
+])
+def test_attn_prefill_paged_prefix(H, KVH, D, bs, cases):
+    """Prefix-cached prefill (attention.rs:211-222): queries are the last nq tokens of each context, K/V via block table."""
+    rng = np.random.default_rng(23)
+    B = len(cases)
+    ctxs = [c for c, _ in cases]; nqs = [n for _, n in cases]
+    NB = sum((c + bs - 1) // bs for c in ctxs) + 2
+    kc, kcb, vc, vcb, bt, max_blocks = _paged_case(rng, B, H, KVH, D, bs, ctxs, NB)
+    T = sum(nqs)
+    q, qb = h16(rng.standard_normal((T, H, D)))
+    cu = np.concatenate([[0], np.cumsum(nqs)]).astype(np.int32)
+    ctx = np.asarray(ctxs, np.int32)
+    scale = float(np.float32(1.0) / np.sqrt(np.float32(D)))
+    meta = nvr.AttnMetaC()
+    d_cu, d_ctx, d_bt = dev(cu), dev(ctx), dev(bt)
+    meta.is_prefill, meta.cu_seqlens_q, meta.context_lens, meta.block_tables = 1, d_cu.ptr, d_ctx.ptr, d_bt.ptr
+    meta.max_blocks, meta.batch, meta.max_context_len = max_blocks, B, int(max(ctxs))
+    d_out = nvr.DeviceBuffer(T * H * D * 2)
+    nvr.check(nvr.lib().nvr_attn_prefill_paged(dev(qb).ptr, H * D, dev(kcb).ptr, dev(vcb).ptr, C.byref(meta), T, H, KVH, D, bs, scale,
+                                               d_out.ptr, None))
+    ref = oracle.round_f16(oracle.attn_paged(q, cu, kc, vc, bt, ctx, scale))
+    assert_close_f16(d_out.to_numpy((T, H, D), F16), ref, ulps=2, atol=2e-3, what="paged prefix prefill attention")
