@@ -194,6 +194,14 @@ def main() -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # prefill of the 32 x 1024 prompt tokens (one engine step, wall clock incl. host input preparation): MFMA-bound,
+    # 880.8 MFLOP/token of GEMM + 114 688*l flop/token of causal attention (+ LM head per sequence)
+    c = mc.c
+    Dh = c.head_dim or c.hidden_size // c.num_attention_heads
+    gemm_flop_tok = 2 * c.num_hidden_layers * ((c.num_attention_heads + 2 * c.num_key_value_heads) * Dh * c.hidden_size
+                                               + c.hidden_size * c.num_attention_heads * Dh + 3 * c.intermediate_size * c.hidden_size)
+    attn_flop = BATCH * sum(4 * c.num_attention_heads * Dh * (l + 1) // 2 * 2 for l in range(PROMPT_LEN)) * c.num_hidden_layers // 2
+    prefill_flop = BATCH * PROMPT_LEN * gemm_flop_tok + attn_flop + BATCH * 2 * c.vocab_size * c.hidden_size
     ms_per_step = elapsed * 1e3 / args.steps
     tokens_per_s = BATCH * args.steps / elapsed
     ctx_mean = PROMPT_LEN + 1 + args.warmup + (args.steps - 1) / 2.0   # keys visible per sequence, averaged over timed steps
@@ -221,7 +229,10 @@ def main() -> None:
             "config": {"workload": "Qwen3-0.6B fp16 random-init, bs=32 x 1024-token prompts, greedy paged-attention decode, "
                                    "block_size=256, hipGraph decode steps (BASELINE.json configs[1])",
                        "batch": BATCH, "prompt_len": PROMPT_LEN, "mean_context": ctx_mean,
-                       "parallelism": f"tp{args.gpus}", "decode_microbatches": args.microbatches, "prefill_s": round(t_prefill, 3)},
+                       "parallelism": f"tp{args.gpus}", "decode_microbatches": args.microbatches},
+            "prefill": {"tokens": BATCH * PROMPT_LEN, "seconds": round(t_prefill, 4), "tokens_per_s": round(BATCH * PROMPT_LEN / t_prefill, 1),
+                        "tflop_per_s": round(prefill_flop / t_prefill / 1e12, 1), "mfma_frac_of_2500": round(prefill_flop / t_prefill / 2.5e15, 4),
+                        "note": "one untimed engine prefill step (wall clock, includes host input preparation and upload)"},
             "step_hbm_frac": round(step_gbs / HBM_PEAK_GBS, 4),
             "step_algorithmic_bytes": int(step_bytes),
             "roofline": {"kernel": "attn_rows_kernel (paged decode attention, K9)", "bound": "hbm", "achieved": round(achieved, 1),

