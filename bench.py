@@ -134,12 +134,15 @@ def main() -> None:
     ap.add_argument("--attn-reps", type=int, default=8)
     ap.add_argument("--microbatches", type=int, default=int(os.environ.get("NVR_MICROBATCHES", "1")),
                     help="decode micro-batches run concurrently on their own HIP streams (nvr_config.decode_microbatches)")
+    ap.add_argument("--eager", action="store_true", help="enforce_eager: launch decode kernels one by one instead of replaying a hipGraph")
     args = ap.parse_args()
 
     nvr = nvr_import.load()                # loads libnvr.so (and the ROCm HIP runtime) before torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("NVR_BENCH_SHARED_GPU"):          # control-plane dry run of the multi-rank path on a 1-GPU box
+        local_rank = 0
     dist = None
     if args.gpus > 1:
         if world != args.gpus:
@@ -152,7 +155,7 @@ def main() -> None:
     cfg = nvr.Config(max_num_seqs=BATCH, max_num_batched_tokens=BATCH * PROMPT_LEN, max_model_len=PROMPT_LEN + total_new + 16,
                      kvcache_block_size=BLOCK, num_kvcache_blocks=BATCH * ((PROMPT_LEN + total_new + 16) // BLOCK + 2),
                      tensor_parallel_size=args.gpus, tensor_parallel_rank=rank, device_ordinal=local_rank,
-                     decode_microbatches=args.microbatches)
+                     decode_microbatches=args.microbatches, enforce_eager=args.eager)
     mc = nvr.ModelConfig("qwen3-0.6b")
     nvr.check(nvr.lib().nvr_device_set(local_rank))
     eng = nvr.LLMEngine(cfg, mc)
@@ -229,7 +232,7 @@ def main() -> None:
             "config": {"workload": "Qwen3-0.6B fp16 random-init, bs=32 x 1024-token prompts, greedy paged-attention decode, "
                                    "block_size=256, hipGraph decode steps (BASELINE.json configs[1])",
                        "batch": BATCH, "prompt_len": PROMPT_LEN, "mean_context": ctx_mean,
-                       "parallelism": f"tp{args.gpus}", "decode_microbatches": args.microbatches},
+                       "parallelism": f"tp{args.gpus}", "decode_microbatches": args.microbatches, "hipgraph": not args.eager},
             "prefill": {"tokens": BATCH * PROMPT_LEN, "seconds": round(t_prefill, 4), "tokens_per_s": round(BATCH * PROMPT_LEN / t_prefill, 1),
                         "tflop_per_s": round(prefill_flop / t_prefill / 1e12, 1), "mfma_frac_of_2500": round(prefill_flop / t_prefill / 2.5e15, 4),
                         "note": "one untimed engine prefill step (wall clock, includes host input preparation and upload)"},
