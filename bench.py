@@ -147,6 +147,7 @@ def main() -> None:
     if args.gpus > 1:
         if world != args.gpus:
             raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run)")
+        nvr.preload_rccl()                 # ROCm's librccl before torch's bundled copy can claim the soname
         import torch.distributed as dist   # control plane only (gloo): unique-id broadcast, barrier, max
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)

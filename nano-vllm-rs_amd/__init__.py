@@ -519,6 +519,18 @@ class ModelRunner:
         check(lib().nvr_runner_init_comm(self.h, buf))
 
 
+def preload_rccl() -> None:
+    """Load the ROCm RCCL of this image before anything else can bring its own copy under the same soname
+    (torch bundles one).  Call before `import torch` in multi-rank programs."""
+    lib()
+    for name in ("/opt/rocm/lib/librccl.so.1", "librccl.so.1"):
+        try:
+            C.CDLL(name, mode=C.RTLD_GLOBAL)
+            return
+        except OSError:
+            continue
+
+
 def comm_unique_id() -> bytes:
     buf = (C.c_uint8 * 128)()
     check(lib().nvr_comm_unique_id(buf))

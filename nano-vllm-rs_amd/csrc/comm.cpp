@@ -21,7 +21,9 @@ Api g_api;
 
 int load_api() {
     if (g_api.lib) return NVR_OK;
-    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    // the ROCm 7.2 copy first, by path: a process that imported torch already holds torch's bundled (ROCm 7.0)
+    // librccl under the same soname, and a bare-soname dlopen would return that one
+    const char *names[] = {"/opt/rocm/lib/librccl.so.1", "librccl.so.1", "librccl.so"};
     void *lib = nullptr;
     for (const char *n : names) { lib = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (lib) break; }
     if (!lib) return fail(NVR_ERR_RCCL, "cannot dlopen librccl: %s", dlerror());
