@@ -341,6 +341,23 @@ int argmax(const float *logits, int64_t B, int64_t V, int64_t *out_idx, float *o
     return 0;
 }
 
+// ---------------------------------------------------------------- vocab-shard concat (C3)
+// reference: ParallelLMHead::gather_logits, src/layers/embed_head.rs:321-336 (Tensor::cat along the vocab axis).
+// gathered [tp][B][Vl] (all-gather order) -> full [B][tp*Vl]
+__global__ void concat_vocab_kernel(const float *__restrict__ g, int tp, int B, int Vl, float *__restrict__ full) {
+    const int64_t total = (int64_t)tp * B * Vl;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int j = (int)(i % Vl); const int64_t rb = i / Vl; const int b = (int)(rb % B), r = (int)(rb / B);
+        full[(int64_t)b * tp * Vl + (int64_t)r * Vl + j] = g[i];
+    }
+}
+int concat_vocab_shards(const float *gathered, int64_t tp, int64_t B, int64_t Vl, float *full, hipStream_t s) {
+    if (tp * B * Vl == 0) return 0;
+    concat_vocab_kernel<<<dim3(2048), dim3(256), 0, s>>>(gathered, (int)tp, (int)B, (int)Vl, full);
+    LAUNCH_CHECK();
+    return 0;
+}
+
 // ---------------------------------------------------------------- synthetic weights
 __global__ void fill_weight_kernel(half_t *__restrict__ dst, int64_t rows, int64_t cols, int64_t ld, int64_t gcols,
                                    int64_t row0, int64_t col0, uint64_t key, float scale) {

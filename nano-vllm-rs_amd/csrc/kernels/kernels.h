@@ -24,6 +24,7 @@ int argmax(const float *logits, int64_t B, int64_t V, int64_t *out_idx, float *o
 int fill_weight(half_bits *dst, int64_t rows, int64_t cols, int64_t ld, int64_t global_cols, int64_t row0,
                 int64_t col0, uint64_t key, float scale, hipStream_t s);
 int fill_const(half_bits *dst, int64_t n, float v, hipStream_t s);
+int concat_vocab_shards(const float *gathered, int64_t tp, int64_t B, int64_t Vl, float *full, hipStream_t s);
 
 // y[T,N] = x[T,K] (row stride ldx) · W[N,K]^T, f32 accumulate on MFMA; y fp16 or f32
 int linear(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t N, void *y,

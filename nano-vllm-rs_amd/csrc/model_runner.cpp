@@ -44,7 +44,7 @@ nvr_model_runner::~nvr_model_runner() {
     for (auto &l : layers) { hipFree(l.qkv); hipFree(l.o); hipFree(l.gate_up); hipFree(l.down); hipFree(l.ln1); hipFree(l.ln2); }
     void *ptrs[] = {embed, mc.tie_word_embeddings ? nullptr : lm_head, norm, cos_t, sin_t, kv_pool, h, n, qkv, attn,
                     proj, gu, act, nlast, logits, attn_ws, slabs, in_dev, d_tok, d_maxval, d_temp, d_topk, d_topp, d_keys,
-                    sample_ws, d_gather_val, d_gather_idx};
+                    sample_ws, d_gather_val, d_gather_idx, d_gather_logits, d_full_logits, sample_ws_full};
     for (void *p : ptrs) if (p) hipFree(p);
     if (in_host) hipHostFree(in_host);
     if (h_tok) hipHostFree(h_tok);
@@ -459,7 +459,18 @@ int nvr_model_runner::sample(nvr_seq *const *seqs, size_t nseq, int64_t *out) {
             return NVR_OK;
         }
     } else {
-        if (comm.active()) return nvr::fail(NVR_ERR_UNSUPPORTED, "stochastic sampling with tensor_parallel_size>1 is not implemented yet");
+        const float *lg = logits; int64_t Vs = Vl; void *ws = sample_ws;
+        if (comm.active()) {
+            // gather the vocab shards on every rank (embed_head.rs:321-336) and sample identically everywhere (counter RNG)
+            if (V % tp) return nvr::fail(NVR_ERR_UNSUPPORTED, "stochastic sampling under tensor parallelism needs vocab %% tp == 0");
+            if (!d_full_logits) {
+                RC(dmalloc(&d_gather_logits, tp * max_seqs * Vl)); RC(dmalloc(&d_full_logits, max_seqs * V));
+                NVR_HIP_CHECK(hipMalloc(&sample_ws_full, k::sample_workspace_bytes(max_seqs, V)));
+            }
+            RC(comm.all_gather_bytes(logits, d_gather_logits, (size_t)(B * Vl) * 4, stream));
+            RC(k::concat_vocab_shards(d_gather_logits, tp, B, Vl, d_full_logits, stream));
+            lg = d_full_logits; Vs = V; ws = sample_ws_full;
+        }
         float *t = (float *)samp_host; int64_t *tk = (int64_t *)(samp_host + max_seqs * 4);
         float *tpv = (float *)(samp_host + max_seqs * 12); uint64_t *ky = (uint64_t *)(samp_host + max_seqs * 16);
         for (size_t i = 0; i < nseq; ++i) {
@@ -473,7 +484,7 @@ int nvr_model_runner::sample(nvr_seq *const *seqs, size_t nseq, int64_t *out) {
         NVR_HIP_CHECK(hipMemcpyAsync(d_topk, tk, B * 8, hipMemcpyHostToDevice, stream));
         NVR_HIP_CHECK(hipMemcpyAsync(d_topp, tpv, B * 4, hipMemcpyHostToDevice, stream));
         NVR_HIP_CHECK(hipMemcpyAsync(d_keys, ky, B * 8, hipMemcpyHostToDevice, stream));
-        RC(k::sample(logits, B, Vl, d_temp, d_topk, d_topp, d_keys, d_tok, sample_ws, stream));
+        RC(k::sample(lg, B, Vs, d_temp, d_topk, d_topp, d_keys, d_tok, ws, stream));
     }
     NVR_HIP_CHECK(hipMemcpyAsync(h_tok, d_tok, B * 8, hipMemcpyDeviceToHost, stream));      // to_vec1 :152
     NVR_HIP_CHECK(hipStreamSynchronize(stream));

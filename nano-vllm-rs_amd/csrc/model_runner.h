@@ -50,6 +50,7 @@ struct nvr_model_runner {
     char *samp_host = nullptr; void *sample_ws = nullptr;
     // TP exchange buffers for the greedy (max, idx) merge
     float *d_gather_val = nullptr; int64_t *d_gather_idx = nullptr;
+    float *d_gather_logits = nullptr, *d_full_logits = nullptr; void *sample_ws_full = nullptr;   // stochastic sampling under TP (lazy)
 
     // Decode micro-batching: the batch rows are cut into `lanes` slices that run the whole layer stack
     // concurrently on their own streams (forked and joined inside the captured graph).  A decode step is a

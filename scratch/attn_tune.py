@@ -4,7 +4,7 @@ import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, nvr_import
 nvr = nvr_import.load(); l = nvr.lib(); nvr.check(l.nvr_device_set(0))
-B, H, KVH, D, bs, L = 32, 16, 8, 128, 256, 28
+B, H, KVH, D, bs, L = 32, 16, 8, 128, 256, int(os.environ.get("LAYERS", "28"))
 ctx_len = int(os.environ.get("CTX", "1030"))
 nblk = (ctx_len + bs - 1) // bs
 NB = B * nblk

@@ -123,3 +123,22 @@ def test_config2_full_size_properties():
     assert a == b and len(a) == 6 and all(len(t) == 32 for t in a)
     assert all(0 <= t < 151936 for step in a for t in step)
     assert len({tuple(s) for s in zip(*a)}) > 16            # sequences do not collapse onto one stream
+
+
+@pytest.mark.gpu
+def test_kv_pool_sized_from_free_hbm():
+    """num_kvcache_blocks = auto: the pool is cut from free HBM * gpu_memory_utilization (the reference has the config
+    field, config.rs:30, but no sizing code); 28 MiB per block for Qwen3-0.6B."""
+    import ctypes as C
+    free, total = C.c_uint64(), C.c_uint64()
+    nvr.check(nvr.lib().nvr_device_set(0)); nvr.check(nvr.lib().nvr_device_mem_info(C.byref(free), C.byref(total)))
+    util = 0.05
+    eng = nvr.LLMEngine(nvr.Config(max_num_seqs=2, max_num_batched_tokens=512, max_model_len=512, num_kvcache_blocks="auto",
+                                   gpu_memory_utilization=util), nvr.ModelConfig("qwen3-0.6b"))
+    nb = eng.model_runner.num_kvcache_blocks()
+    budget = free.value - (1 - util) * total.value
+    assert budget > 0 and 0.8 * budget / (28 * 2 ** 20) - 200 < nb <= budget / (28 * 2 ** 20)
+    assert eng.scheduler.get_block_stats()["total_blocks"] == nb          # scheduler and runner share the pool size
+    eng.add_request(nvr.synthetic_tokens(20, 1, 0, 151936).tolist(), nvr.SamplingParams(temperature=0.0, max_tokens=2, ignore_eos=True))
+    while not eng.is_finished():
+        eng.step()

@@ -140,8 +140,10 @@ def test_rccl_collectives_inside_the_decode_graph_single_gpu():
         if force:
             eng.model_runner.init_comm(nvr.comm_unique_id())
             eng.model_runner.comm_selftest()
-        for p in prompts:
-            eng.add_request(p, nvr.SamplingParams(temperature=0.0, max_tokens=8, ignore_eos=True))
+        for i, p in enumerate(prompts):          # one greedy row (pair merge), one stochastic row (logits gather + concat)
+            sp = nvr.SamplingParams(temperature=0.0, max_tokens=8, ignore_eos=True) if i == 0 else \
+                nvr.SamplingParams(temperature=0.9, top_k=30, top_p=0.9, max_tokens=8, ignore_eos=True)
+            eng.add_request(p, sp)
         toks = []
         while not eng.is_finished():
             toks.append(eng.step()["tokens"])
