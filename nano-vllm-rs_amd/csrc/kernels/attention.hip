@@ -43,6 +43,22 @@ __device__ __forceinline__ half8_t load_row16(const half_t *p) {
     return *reinterpret_cast<const half8_t *>(p);
 }
 
+// sum over the LPR (= 16 or 8) consecutive lanes that hold one K row, result in every lane of the group: DPP row
+// rotations / quad permutes fused into v_add_f32 (no LDS traffic; __shfl_xor compiles to ds_bpermute_b32)
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float x) {
+    const int y = __builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, false);
+    return x + __int_as_float(y);
+}
+template <int LPR>
+__device__ __forceinline__ float row_sum(float x) {
+    if (LPR == 16) { x = dpp_add<0x128>(x); x = dpp_add<0x124>(x); }     // row_ror:8, row_ror:4
+    else x = dpp_add<0x141>(x);                                            // row_half_mirror (8 lanes: i <-> 7-i)
+    x = dpp_add<0x4E>(x);                                                  // quad_perm [2,3,0,1]
+    x = dpp_add<0xB1>(x);                                                  // quad_perm [1,0,3,2]
+    return x;
+}
+
 // U: row groups (wave-instructions of K and of V) per iteration; WAVES: waves per workgroup;
 // PREFETCH: request the next iteration's K/V rows before computing on the current ones; NT: non-temporal loads.
 template <int D, int G, bool PAGED, bool DIRECT_OUT, int U, int WAVES, bool PREFETCH, bool NT>
@@ -134,8 +150,7 @@ __global__ __launch_bounds__(WAVES * 64) void attn_rows_kernel(AttnParams p) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     d = __builtin_amdgcn_fdot2((half2_t){kk[u][2 * j], kk[u][2 * j + 1]}, qv[i][j], d, false);
-#pragma unroll
-                for (int o = 1; o < LPR; o <<= 1) d += __shfl_xor(d, o, 64);
+                d = row_sum<LPR>(d);
                 s[u][i] = valid ? d * p.scale : -INFINITY;
             }
         }
