@@ -501,3 +501,42 @@ def test_attn_prefill_paged_prefix(H, KVH, D, bs, cases):
                                                d_out.ptr, None))
     ref = oracle.round_f16(oracle.attn_paged(q, cu, kc, vc, bt, ctx, scale))
     assert_close_f16(d_out.to_numpy((T, H, D), F16), ref, ulps=2, atol=2e-3, what="paged prefix prefill attention")
+
+
+# ------------------------------------------------------------------------------------------- randomized sweeps
+def test_paged_attn_decode_random_geometries():
+    """40 random (batch, context, block size incl. non powers of two, head grouping, head dim) cases, ragged contexts."""
+    rng = np.random.default_rng(99)
+    for case in range(40):
+        D = int(rng.choice([64, 128])); G = int(rng.choice([1, 2, 4, 8])); KVH = int(rng.choice([1, 2, 8])); H = G * KVH
+        bs = int(rng.choice([16, 48, 256, 64])); B = int(rng.integers(1, 40))
+        ctxs = rng.integers(1, int(rng.choice([40, 300, 1500])), B).tolist()
+        NB = sum((c + bs - 1) // bs for c in ctxs) + 2
+        kc, kcb, vc, vcb, bt, max_blocks = _paged_case(rng, B, H, KVH, D, bs, ctxs, NB)
+        q, qb = h16(rng.standard_normal((B, H, D)))
+        ctx = np.asarray(ctxs, np.int32)
+        scale = float(np.float32(1.0) / np.sqrt(np.float32(D)))
+        meta = nvr.AttnMetaC()
+        d_ctx, d_bt = dev(ctx), dev(bt)
+        meta.context_lens, meta.block_tables, meta.max_blocks, meta.batch, meta.max_context_len = d_ctx.ptr, d_bt.ptr, max_blocks, B, int(max(ctxs))
+        ws = nvr.DeviceBuffer(nvr.lib().nvr_paged_attn_workspace_bytes(B, H, D, int(max(ctxs)))); _KEEP.append(ws)
+        d_out = nvr.DeviceBuffer(B * H * D * 2); _KEEP.append(d_out)
+        nvr.check(nvr.lib().nvr_paged_attn_decode(dev(qb).ptr, H * D, dev(kcb).ptr, dev(vcb).ptr, C.byref(meta), H, KVH, D, bs, scale,
+                                                  d_out.ptr, ws.ptr, None))
+        ref = oracle.round_f16(oracle.attn_decode(q, kc, vc, bt, ctx, scale))
+        assert_close_f16(d_out.to_numpy((B, H, D), F16), ref, ulps=2, atol=1e-3, what=f"case {case}: B={B} H={H} KVH={KVH} D={D} bs={bs}")
+        _KEEP.clear()
+
+
+def test_linear_random_shapes():
+    rng = np.random.default_rng(98)
+    for case in range(30):
+        T = int(rng.choice([1, 3, 16, 17, 32, 33, 64, 65, 127, 128, 129, 300]))
+        K = int(rng.choice([32, 64, 96, 256, 384, 1024, 2048, 3072])); N = 16 * int(rng.integers(1, 80))
+        x, xb = h16(rng.standard_normal((T, K)))
+        W, Wb = h16(rng.standard_normal((N, K)) * 0.05)
+        d_y = nvr.DeviceBuffer(T * N * 2); _KEEP.append(d_y)
+        rc = nvr.lib().nvr_linear(dev(xb).ptr, K, dev(Wb).ptr, T, K, N, d_y.ptr, 0, None)
+        assert rc == 0, nvr.last_error()
+        assert_close_f16(d_y.to_numpy((T, N), F16), oracle.round_f16(oracle.linear(x, W)), ulps=1, atol=3e-4, what=f"case {case}: T={T} K={K} N={N}")
+        _KEEP.clear()
