@@ -269,6 +269,11 @@ def main() -> None:
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+        # Two ROCm stacks live in a multi-rank process (this image's 7.2 libraries behind libnvr.so and the 7.0 copies
+        # bundled with torch); their static destructors abort at interpreter exit ("double free") after all work is
+        # done.  Everything is flushed and released above: leave without running them.
+        sys.stdout.flush(); sys.stderr.flush()
+        os._exit(0)
 
 
 if __name__ == "__main__":
