@@ -109,24 +109,27 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(const half_t *__restric
         __syncthreads();
     }
 
-    // epilogue: C layout row (n) = q*4 + reg, col (token) = r
+    // epilogue: C layout row (n) = q*4 + reg, col (token) = r.  Each lane produces 4 consecutive output columns of one
+    // token; they are staged in LDS (the operand buffers are free now; row stride 272 B keeps ds_read_b128 aligned)
+    // and written out as full 16-byte pieces of contiguous rows (a lane-per-row 8-byte store pattern is issue-bound).
+    constexpr int OST = 272;                                              // bytes per staged row (128 fp16 + pad)
+    constexpr int OUTC = (EPI == TEPI_SILU) ? 64 : 128;                   // output columns of this workgroup
+    char *ot = smem;
+    auto stash = [&](int ml, int lc, half4_t hv) { *reinterpret_cast<half4_t *>(ot + ml * OST + lc * 2) = hv; };
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int m = m0 + wm * 64 + j * 16 + r;
+        const int ml = wm * 64 + j * 16 + r;
+        const int m = m0 + ml;
         const int mc = m < T ? m : T - 1;
         if (EPI == TEPI_F16) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int n = blockIdx.x * BN + wn * 64 + i * 16 + q * 4;
-                if (m < T && n < N) {
-                    half4_t h = {(half_t)acc[i][j][0], (half_t)acc[i][j][1], (half_t)acc[i][j][2], (half_t)acc[i][j][3]};
-                    *reinterpret_cast<half4_t *>(y + (int64_t)m * N + n) = h;
-                }
+                half4_t h = {(half_t)acc[i][j][0], (half_t)acc[i][j][1], (half_t)acc[i][j][2], (half_t)acc[i][j][3]};
+                stash(ml, wn * 64 + i * 16 + q * 4, h);
             }
         } else if (EPI == TEPI_SILU) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {                                 // tiles i (gate) and i+2 (up), same 16 columns
-                const int n = blockIdx.x * 64 + wn * 32 + i * 16 + q * 4;
                 half4_t h;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -134,13 +137,11 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(const half_t *__restric
                     const float sg = 1.0f / (1.0f + __expf(-gf));
                     h[e] = to_half_rn(__fmul_rn(__fmul_rn(gf, sg), uf));
                 }
-                if (m < T && n < N) *reinterpret_cast<half4_t *>(y + (int64_t)m * N + n) = h;
+                stash(ml, wn * 32 + i * 16 + q * 4, h);
             }
         } else {                                                          // TEPI_ROPE
             const int tph = epi.D / 16, half_d = epi.D / 2;
-            const int64_t ldq = (int64_t)(epi.H + 2 * epi.KVH) * epi.D;
             const int64_t p = epi.pos[mc];
-            const int slot = epi.slots ? epi.slots[mc] : -1;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int g = blockIdx.x * 8 + wn * 4 + i, head = g / tph, c = g % tph;
@@ -163,13 +164,30 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(const half_t *__restric
                     for (int e = 0; e < 4; ++e) h[e] = to_half_rn(acc[i][j][e]);
                     col = c * 16 + q * 4;
                 }
-                if (m < T) {
-                    *reinterpret_cast<half4_t *>(y + (int64_t)m * ldq + head * epi.D + col) = h;
-                    if (slot >= 0 && head >= epi.H) {
-                        const bool is_k = head < epi.H + epi.KVH;
-                        const int kvh = is_k ? head - epi.H : head - epi.H - epi.KVH;
-                        *reinterpret_cast<half4_t *>((is_k ? epi.kc : epi.vc) + ((int64_t)slot * epi.KVH + kvh) * epi.D + col) = h;
-                    }
+                stash(ml, head * epi.D + col - blockIdx.x * 128, h);       // the 8 n-tiles cover 128 consecutive columns
+            }
+        }
+    }
+    __syncthreads();
+    // cooperative write-out: 16-byte pieces, consecutive threads -> consecutive pieces of a row
+    const int64_t ldy = (EPI == TEPI_ROPE) ? (int64_t)(epi.H + 2 * epi.KVH) * epi.D : (int64_t)N;
+    const int ncols = (EPI == TEPI_ROPE) ? (int)ldy : N;
+    constexpr int CPR = OUTC / 8;                                         // pieces per row
+#pragma unroll
+    for (int i = 0; i < (BM * CPR) / 256; ++i) {
+        const int pidx = i * 256 + threadIdx.x, row = pidx / CPR, ch = pidx % CPR;
+        const int m = m0 + row, col = blockIdx.x * OUTC + ch * 8;
+        if (m >= T || col >= ncols) continue;
+        const half8_t v8 = *reinterpret_cast<const half8_t *>(ot + row * OST + ch * 16);
+        *reinterpret_cast<half8_t *>(y + (int64_t)m * ldy + col) = v8;
+        if (EPI == TEPI_ROPE) {
+            const int head = col / epi.D;
+            if (head >= epi.H) {
+                const int slot = epi.slots ? epi.slots[m] : -1;
+                if (slot >= 0) {
+                    const bool is_k = head < epi.H + epi.KVH;
+                    const int kvh = is_k ? head - epi.H : head - epi.H - epi.KVH;
+                    *reinterpret_cast<half8_t *>((is_k ? epi.kc : epi.vc) + ((int64_t)slot * epi.KVH + kvh) * epi.D + (col - head * epi.D)) = v8;
                 }
             }
         }
@@ -202,7 +220,7 @@ int gemm_tiled_qkv_rope_store(const half_bits *x, int64_t ldx, const half_bits *
                               const int64_t *positions, const int32_t *slots, const float *cos_t, const float *sin_t, half_bits *qkv,
                               half_bits *k_cache, half_bits *v_cache, hipStream_t s) {
     const int64_t N = (H + 2 * KVH) * D;
-    if (!gemm_tiled_ok(T, K, N, ldx) || D % 16) return nvr::fail(NVR_ERR_UNSUPPORTED, "gemm_tiled_qkv_rope_store: T=%ld K=%ld D=%ld", (long)T, (long)K, (long)D);
+    if (!gemm_tiled_ok(T, K, N, ldx) || D % 16 || 128 % D) return nvr::fail(NVR_ERR_UNSUPPORTED, "gemm_tiled_qkv_rope_store: T=%ld K=%ld D=%ld", (long)T, (long)K, (long)D);
     TileEpi e{};
     e.pos = positions; e.slots = slots; e.cos_t = cos_t; e.sin_t = sin_t; e.kc = (half_t *)k_cache; e.vc = (half_t *)v_cache;
     e.H = (int32_t)H; e.KVH = (int32_t)KVH; e.D = (int32_t)D;

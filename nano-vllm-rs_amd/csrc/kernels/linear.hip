@@ -287,7 +287,7 @@ int linear_qkv_rope_store(const half_bits *x, int64_t ldx, const half_bits *W, i
     if (K % 32 || D % 16 || ldx % 8)
         return nvr::fail(NVR_ERR_UNSUPPORTED, "linear_qkv_rope_store: K=%ld must be a multiple of 32, D=%ld of 16", (long)K, (long)D);
     if (T == 0) return 0;
-    if (gemm_tiled_ok(T, K, (H + 2 * KVH) * D, ldx))
+    if (gemm_tiled_ok(T, K, (H + 2 * KVH) * D, ldx) && 128 % D == 0)
         return gemm_tiled_qkv_rope_store(x, ldx, W, T, K, H, KVH, D, positions, slots, cos_t, sin_t, qkv, k_cache, v_cache, s);
     const half_t *xx = (const half_t *)x, *ww = (const half_t *)W;
     LinEpi e{};
