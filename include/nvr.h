@@ -278,6 +278,12 @@ NVR_API int nvr_linear_splitk(const nvr_half *x, int64_t ldx, const nvr_half *W,
                               float *slabs, void *stream);
 NVR_API int nvr_add_rmsnorm_slabs(nvr_half *h, const float *slabs, int64_t S, const nvr_half *w, float eps, int64_t T,
                                   int64_t Hd, nvr_half *out, void *stream);
+/* both of the above in ONE launch (the decode path's form): the workgroups publish their partial tiles, count
+ * arrivals in sync[0] and workgroups 0..T-1 finish one row each.  sync = 4 zero-initialised uint32 in device memory
+ * (re-armed by the kernel; sync[2] != 0 afterwards means an arrival wait timed out).  N <= 2048, T <= 64. */
+NVR_API int nvr_linear_splitk_norm(const nvr_half *x, int64_t ldx, const nvr_half *W, int64_t T, int64_t K, int64_t N,
+                                   int64_t S, float *slabs, nvr_half *h, const nvr_half *w_norm, float eps,
+                                   nvr_half *out, uint32_t *sync, void *stream);
 /* K12+K13 fused: out[T,I] = SiluAndMul(x · W_gate_upᵀ), W [2I,K] gate rows then up rows
  * (MergedColumnParallelLinear::forward linear.rs:437-439 + SiluAndMul::forward activation.rs:46-63) */
 NVR_API int nvr_linear_silu_mul(const nvr_half *x, int64_t ldx, const nvr_half *W, int64_t T, int64_t K, int64_t I,

@@ -35,11 +35,12 @@ nvr_model_runner::~nvr_model_runner() {
     comm.destroy();
     for (size_t i = 1; i < lanes.size(); ++i) {
         Lane &ln = lanes[i];
-        void *ps[] = {ln.h, ln.n, ln.qkv, ln.attn, ln.proj, ln.act, ln.slabs, ln.attn_ws};
+        void *ps[] = {ln.h, ln.n, ln.qkv, ln.attn, ln.proj, ln.act, ln.slabs, ln.attn_ws, ln.sync};
         for (void *p : ps) if (p) hipFree(p);
         if (ln.done) hipEventDestroy(ln.done);
         if (ln.stream) hipStreamDestroy(ln.stream);
     }
+    if (!lanes.empty() && lanes[0].sync) hipFree(lanes[0].sync);
     if (fork_ev) hipEventDestroy(fork_ev);
     for (auto &l : layers) { hipFree(l.qkv); hipFree(l.o); hipFree(l.gate_up); hipFree(l.down); hipFree(l.ln1); hipFree(l.ln2); }
     void *ptrs[] = {embed, mc.tie_word_embeddings ? nullptr : lm_head, norm, cos_t, sin_t, kv_pool, h, n, qkv, attn,
@@ -96,6 +97,8 @@ int nvr_model_runner::init() {                                       // ModelRun
     RC(dmalloc(&attn, max_tokens * H * D)); RC(dmalloc(&proj, max_tokens * Hd)); RC(dmalloc(&gu, max_tokens * 2 * I));
     RC(dmalloc(&act, max_tokens * I)); RC(dmalloc(&nlast, max_seqs * Hd)); RC(dmalloc(&logits, max_seqs * Vl));
     RC(dmalloc(&slabs, 4 * 64 * Hd));
+    // measured slower than two launches (profiles/r01_fused_slabnorm_ablation.txt): opt-in only
+    { const char *e = getenv("NVR_FUSED_SLABNORM"); fused_slabnorm = e && e[0] == '1'; }
     attn_ws_bytes = k::attn_workspace_bytes(max_seqs, H, D, max_pos);
     NVR_HIP_CHECK(hipMalloc(&attn_ws, attn_ws_bytes));
     {
@@ -104,6 +107,10 @@ int nvr_model_runner::init() {                                       // ModelRun
         Lane &l0 = lanes[0];
         l0.stream = stream; l0.h = h; l0.n = n; l0.qkv = qkv; l0.attn = attn; l0.proj = proj; l0.act = act; l0.slabs = slabs; l0.attn_ws = attn_ws;
         NVR_HIP_CHECK(hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming));
+        for (int i = 0; i < nl; ++i) {                                   // arrival counters of linear_splitk_norm
+            NVR_HIP_CHECK(hipMalloc((void **)&lanes[i].sync, 16));
+            NVR_HIP_CHECK(hipMemset(lanes[i].sync, 0, 16));
+        }
         for (int i = 1; i < nl; ++i) {                                  // decode-sized twins of the activation set
             Lane &ln = lanes[i];
             NVR_HIP_CHECK(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
@@ -198,20 +205,28 @@ int nvr_model_runner::gen_weights() {
     return NVR_OK;
 }
 
-// RowParallelLinear::forward (o_proj / down_proj, linear.rs:228-239).  Decode-sized steps on one GPU split k over
-// S workgroups per output tile (f32 slabs, summed by the following add_rmsnorm_slabs) so that the N = hidden
-// GEMMs reach all 256 CUs; otherwise the plain kernel writes fp16 `proj` (+ all-reduce when tensor parallel).
-int nvr_model_runner::row_parallel(Lane &ln, const uint16_t *x, int64_t K, const uint16_t *W, int64_t T, int64_t *S_out) {
+// RowParallelLinear::forward (o_proj / down_proj, linear.rs:228-239) + the residual add and the next RMSNorm
+// (qwen3.rs:382-389).  Decode-sized steps on one GPU split k over S workgroups per output tile so that the
+// N = hidden GEMMs reach all 256 CUs; the f32 partial slabs are summed, added to the residual and normalised by the
+// following add_rmsnorm_slabs launch (or, with NVR_FUSED_SLABNORM=1, by the GEMM launch itself through an arrival
+// counter: bit-identical, but the cross-XCD write-through + atomic + poll round trips cost ~5 us more than the
+// kernel boundary they replace).  Otherwise the
+// plain kernel writes fp16 `proj` (+ all-reduce when tensor parallel) and add_rmsnorm follows.
+int nvr_model_runner::row_parallel_norm(Lane &ln, const uint16_t *x, int64_t K, const uint16_t *W, int64_t T, const uint16_t *wn) {
     int64_t S = 1;
     if (!comm.active() && tp == 1 && T <= 64 && Hd <= 2048) {
         const int64_t tiles = (Hd / 16) * ((T + 31) / 32);
         while (S < 4 && tiles * S < 256 && K % (32 * S * 2) == 0 && K / (S * 2) >= 128) S *= 2;
     }
-    *S_out = S;
-    if (S > 1) return k::linear_splitk(x, K, W, T, K, Hd, S, ln.slabs, ln.stream);
+    if (S > 1 && fused_slabnorm)
+        return k::linear_splitk_norm(x, K, W, T, K, Hd, S, ln.slabs, ln.h, wn, mc.rms_norm_eps, ln.n, ln.sync, ln.stream);
+    if (S > 1) {
+        RC(k::linear_splitk(x, K, W, T, K, Hd, S, ln.slabs, ln.stream));
+        return k::add_rmsnorm_slabs(ln.h, ln.slabs, S, wn, mc.rms_norm_eps, T, Hd, ln.n, ln.stream);
+    }
     RC(k::linear(x, K, W, T, K, Hd, ln.proj, false, ln.stream));
     if (comm.active()) RC(comm.all_reduce_sum_f16(ln.proj, (size_t)(T * Hd), ln.stream));  // linear.rs:236-238
-    return NVR_OK;
+    return k::add_rmsnorm(ln.h, ln.proj, wn, mc.rms_norm_eps, T, Hd, ln.n, ln.stream);
 }
 
 // Qwen3Model::forward, src/models/qwen3.rs:487-505; layer wiring :372-392; attention :208-240; MLP :305-314.
@@ -222,15 +237,9 @@ int nvr_model_runner::forward(Lane &ln, int64_t row0, int64_t T, int64_t B, bool
     const int32_t *slots = (is_prefill ? d_slots : dd_slots) + row0, *ctx = (is_prefill ? d_ctx : dd_ctx) + row0;
     const int32_t *bt = dd_bt + row0 * max_blocks_per_seq;
     RC(k::embedding(ids, T, embed, Hd, ln.h, st));
-    int64_t S = 1;
-    auto add_norm = [&](const uint16_t *wn) -> int {                                       // residual add + next norm
-        if (S > 1) return k::add_rmsnorm_slabs(ln.h, ln.slabs, S, wn, mc.rms_norm_eps, T, Hd, ln.n, st);
-        return k::add_rmsnorm(ln.h, ln.proj, wn, mc.rms_norm_eps, T, Hd, ln.n, st);
-    };
     for (int64_t l = 0; l < L; ++l) {
         const Layer &w = layers[l];
-        if (l == 0) RC(k::rmsnorm(ln.h, w.ln1, mc.rms_norm_eps, T, Hd, ln.n, st));
-        else RC(add_norm(w.ln1));                                                            // residual :389 + norm :378
+        if (l == 0) RC(k::rmsnorm(ln.h, w.ln1, mc.rms_norm_eps, T, Hd, ln.n, st));          // later layers: see down_proj
         // qkv GEMM with the RoPE + KV-store epilogue (K3..K6 in one launch)
         RC(k::linear_qkv_rope_store(ln.n, Hd, w.qkv, T, Hd, H, KVH, D, pos, slots, cos_t, sin_t, ln.qkv, k_cache(l), v_cache(l), st));
         k::AttnArgs a{};
@@ -250,12 +259,11 @@ int nvr_model_runner::forward(Lane &ln, int64_t row0, int64_t T, int64_t B, bool
             a.block_size = (int32_t)block_size; a.workspace = ln.attn_ws;
             RC(k::attention(a, true, st));
         }
-        RC(row_parallel(ln, ln.attn, H * D, w.o, T, &S));
-        RC(add_norm(w.ln2));                                                                 // residual :382 + norm :385
+        RC(row_parallel_norm(ln, ln.attn, H * D, w.o, T, w.ln2));                            // o_proj, residual :382, norm :385
         RC(k::linear_silu_mul(ln.n, Hd, w.gate_up, T, Hd, I, ln.act, st));                   // K12 + K13 in one launch
-        RC(row_parallel(ln, ln.act, I, w.down, T, &S));
+        // down_proj, residual :389 and the NEXT layer's input norm :378 (or the final norm :501)
+        RC(row_parallel_norm(ln, ln.act, I, w.down, T, l + 1 < L ? layers[l + 1].ln1 : norm));
     }
-    RC(add_norm(norm));                                                                      // final residual + norm :501
     const uint16_t *hl = ln.n;
     if (is_prefill) { RC(k::select_last_tokens(ln.n, d_cu, B, Hd, nlast, st)); hl = nlast; }   // embed_head.rs:272-289
     RC(k::linear(hl, Hd, lm_head, B, Hd, Vl, logits + row0 * Vl, true, st));                   // f32 logits (A-21)

@@ -59,7 +59,7 @@ struct nvr_model_runner {
     struct Lane {
         hipStream_t stream = nullptr; hipEvent_t done = nullptr;
         uint16_t *h = nullptr, *n = nullptr, *qkv = nullptr, *attn = nullptr, *proj = nullptr, *act = nullptr;
-        float *slabs = nullptr; void *attn_ws = nullptr;
+        float *slabs = nullptr; void *attn_ws = nullptr; unsigned int *sync = nullptr;
     };
     std::vector<Lane> lanes;
     hipEvent_t fork_ev = nullptr;
@@ -80,5 +80,6 @@ private:
     int forward(Lane &ln, int64_t row0, int64_t T, int64_t B, bool is_prefill, int64_t max_ctx);
     int forward_all(int64_t T, int64_t B, bool is_prefill, int64_t max_ctx, int nl);
     int gen_weights();
-    int row_parallel(Lane &ln, const uint16_t *x, int64_t K, const uint16_t *W, int64_t T, int64_t *S_out);
+    int row_parallel_norm(Lane &ln, const uint16_t *x, int64_t K, const uint16_t *W, int64_t T, const uint16_t *wn);
+    bool fused_slabnorm = false;
 };

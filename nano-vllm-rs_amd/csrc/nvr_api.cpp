@@ -309,6 +309,10 @@ int nvr_linear_splitk(const nvr_half *x, int64_t ldx, const nvr_half *W, int64_t
 int nvr_add_rmsnorm_slabs(nvr_half *h, const float *slabs, int64_t S, const nvr_half *w, float eps, int64_t T, int64_t Hd, nvr_half *out, void *s) {
     return k::add_rmsnorm_slabs(h, slabs, S, w, eps, T, Hd, out, (hipStream_t)s);
 }
+int nvr_linear_splitk_norm(const nvr_half *x, int64_t ldx, const nvr_half *W, int64_t T, int64_t K, int64_t N, int64_t S, float *slabs,
+                           nvr_half *h, const nvr_half *wn, float eps, nvr_half *out, uint32_t *sync, void *s) {
+    return k::linear_splitk_norm(x, ldx, W, T, K, N, S, slabs, h, wn, eps, out, sync, (hipStream_t)s);
+}
 int nvr_linear_silu_mul(const nvr_half *x, int64_t ldx, const nvr_half *W, int64_t T, int64_t K, int64_t I, nvr_half *out, void *s) {
     return k::linear_silu_mul(x, ldx, W, T, K, I, out, (hipStream_t)s);
 }

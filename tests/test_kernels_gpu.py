@@ -474,6 +474,43 @@ def test_linear_splitk_and_slab_norm(T, K, N, S):
     assert nvr.lib().nvr_linear_splitk(dev(xb).ptr, K, dev(Wb).ptr, T, K, N, 5, d_slabs.ptr, None) == -10
 
 
+@pytest.mark.parametrize("T,K,N,S", [(32, 2048, 1024, 4), (32, 3072, 1024, 4), (1, 2048, 1024, 4), (64, 1024, 2048, 2),
+                                     (17, 512, 256, 2), (5, 256, 1008, 2)])
+def test_linear_splitk_norm_one_launch(T, K, N, S):
+    """The one-launch form (arrival counter + row finishers) is bit-identical to linear_splitk -> add_rmsnorm_slabs,
+    launch after launch (the counters re-arm themselves) with the residual stream carried through."""
+    rng = np.random.default_rng(24)
+    x, xb = h16(rng.standard_normal((T, K)))
+    W, Wb = h16(rng.standard_normal((N, K)) * 0.05)
+    h, hb = h16(rng.standard_normal((T, N)))
+    w, wb = h16(1 + 0.1 * rng.standard_normal(N))
+    d_x, d_W, d_w = dev(xb), dev(Wb), dev(wb)
+    d_slabs_a, d_slabs_b = nvr.DeviceBuffer(S * T * N * 4), nvr.DeviceBuffer(S * T * N * 4)
+    d_ha, d_hb = dev(hb), dev(hb.copy())
+    d_oa, d_ob = nvr.DeviceBuffer(T * N * 2), nvr.DeviceBuffer(T * N * 2)
+    d_sync = dev(np.zeros(4, np.uint32))
+    for rep in range(5):
+        nvr.check(nvr.lib().nvr_linear_splitk(d_x.ptr, K, d_W.ptr, T, K, N, S, d_slabs_a.ptr, None))
+        nvr.check(nvr.lib().nvr_add_rmsnorm_slabs(d_ha.ptr, d_slabs_a.ptr, S, d_w.ptr, 1e-6, T, N, d_oa.ptr, None))
+        nvr.check(nvr.lib().nvr_linear_splitk_norm(d_x.ptr, K, d_W.ptr, T, K, N, S, d_slabs_b.ptr, d_hb.ptr, d_w.ptr, 1e-6,
+                                                   d_ob.ptr, d_sync.ptr, None))
+        assert np.array_equal(d_ha.to_numpy((T, N), np.uint16), d_hb.to_numpy((T, N), np.uint16)), rep
+        assert np.array_equal(d_oa.to_numpy((T, N), np.uint16), d_ob.to_numpy((T, N), np.uint16)), rep
+        assert list(d_sync.to_numpy((4,), np.uint32)) == [0, 0, 0, 0], rep          # re-armed, no timeout
+    # 200 back-to-back launches re-using the same slabs and counters (stale-cache / re-arm hazards), residual carried
+    for rep in range(200):
+        nvr.check(nvr.lib().nvr_linear_splitk_norm(d_x.ptr, K, d_W.ptr, T, K, N, S, d_slabs_b.ptr, d_hb.ptr, d_w.ptr, 1e-6,
+                                                   d_ob.ptr, d_sync.ptr, None))
+    for rep in range(200):
+        nvr.check(nvr.lib().nvr_linear_splitk(d_x.ptr, K, d_W.ptr, T, K, N, S, d_slabs_a.ptr, None))
+        nvr.check(nvr.lib().nvr_add_rmsnorm_slabs(d_ha.ptr, d_slabs_a.ptr, S, d_w.ptr, 1e-6, T, N, d_oa.ptr, None))
+    assert np.array_equal(d_ha.to_numpy((T, N), np.uint16), d_hb.to_numpy((T, N), np.uint16))
+    assert np.array_equal(d_oa.to_numpy((T, N), np.uint16), d_ob.to_numpy((T, N), np.uint16))
+    assert list(d_sync.to_numpy((4,), np.uint32)) == [0, 0, 0, 0]
+    assert nvr.lib().nvr_linear_splitk_norm(d_x.ptr, K, d_W.ptr, 65, K, N, S, d_slabs_b.ptr, d_hb.ptr, d_w.ptr, 1e-6,
+                                            d_ob.ptr, d_sync.ptr, None) == -10
+
+
 # ------------------------------------------------------------------------------------------- K8
 @pytest.mark.parametrize("H,KVH,D,bs,cases", [
     (16, 8, 128, 16, [(40, 9), (100, 100), (33, 1)]),      # (context_len, new tokens): cached prefix + new, all new, decode-like
