@@ -9,8 +9,7 @@
 // Qwen3-0.6B, 76 % of all decode bytes at ctx 1024), so the kernel is built around the load path:
 //  * K and V rows of one kv head are 2·D contiguous bytes; a wave reads whole rows, 16 B per lane,
 //    D/8 lanes per row (4 rows = 1 KiB per wave-instruction at D=128) — full 128-B lines, straight
-//    to VGPRs (no LDS round trip for a once-read stream), U such loads of K and of V in flight
-//    (2U with PREFETCH: the next iteration's rows are requested before this iteration's math).
+//    to VGPRs (no LDS round trip for a once-read stream), U such loads of K and of V requested back to back.
 //  * q·k: v_dot2_f32_f16 on the lane's 8-element slice, then a butterfly over the D/8 lanes of the
 //    row; softmax is online (running max / sum per wave, f32), p·v accumulates the lane's slice.
 //  * split-KV: one workgroup = WAVES waves owns (query, kv head, partition); its waves interleave
@@ -19,6 +18,7 @@
 //  * all G = H/KVH query heads of a kv head are processed together so K/V are read once.
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 #include "kernels.h"
 #include "device_utils.h"
 #include "../common.h"
@@ -59,20 +59,73 @@ __device__ __forceinline__ float row_sum(float x) {
     return x;
 }
 
-// U: row groups (wave-instructions of K and of V) per iteration; WAVES: waves per workgroup;
-// PREFETCH: request the next iteration's K/V rows before computing on the current ones; NT: non-temporal loads.
-template <int D, int G, bool PAGED, bool DIRECT_OUT, int U, int WAVES, bool PREFETCH, bool NT>
+// lane-wise butterflies across the 16-lane rows of a wave on the gfx950 lane-swap instructions (no LDS traffic):
+// v_permlane16_swap exchanges the odd rows of one register with the even rows of another, v_permlane32_swap the
+// upper half of one with the lower half of the other; fed the same value twice, the two results are x and its
+// xor-16 (xor-32) partner.
+__device__ __forceinline__ float xor16_partner_sum(float x) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float xor32_partner_sum(float x) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float xor16_partner_max(float x) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xor32_partner_max(float x) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+// sum / max over the 64/LPR row groups of the wave (lanes with equal lane % LPR), result in every lane
+template <int LPR>
+__device__ __forceinline__ float groups_sum(float x) {
+    if (LPR == 8) x = dpp_add<0x128>(x);                                   // row_ror:8 inside the 16-lane row
+    return xor32_partner_sum(xor16_partner_sum(x));
+}
+template <int LPR>
+__device__ __forceinline__ float groups_max(float x) {
+    if (LPR == 8) x = fmaxf(x, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x128, 0xF, 0xF, false)));
+    return xor32_partner_max(xor16_partner_max(x));
+}
+
+// A wave-instruction reads one ROW GROUP: RPI = 64/(D/8) consecutive tokens of one kv head, 16 B per lane (1 KiB).
+// The partition is cut into chunks of U row groups (TPI = U*RPI consecutive tokens); in a FULL round every wave of
+// the workgroup takes one complete chunk (chunk r*WAVES + wave: the waves' loads are neighbours in memory) and
+// requests its U groups of K and of V back to back before any arithmetic, with no validity tests.  What is left
+// after the last full round (< WAVES*U groups, the last one possibly partial) is dealt out group by group
+// (group j -> wave j % WAVES) and requested BEFORE the arithmetic of the last full round, so the remainder costs no
+// extra exposed memory round trip and no wave has more than one group more than another.
+// NT: non-temporal loads.  UB: block_size is a multiple of TPI, so a chunk lies inside ONE cache block: its
+// block-table entry is a scalar read (v_readlane) from a register copy of the table (lane j holds entry
+// 64*c + j) and the row address is scalar base + small lane offset -- no dependent table load sits between the row
+// loads.
+template <int D, int G, bool PAGED, bool DIRECT_OUT, int U, int WAVES, bool NT, bool UB>
 __global__ __launch_bounds__(WAVES * 64) void attn_rows_kernel(AttnParams p) {
     constexpr int LPR = D / 8;          // lanes per K/V row
-    constexpr int RPI = 64 / LPR;       // rows per wave-instruction
-    constexpr int TPI = RPI * U;        // tokens per wave iteration
+    constexpr int RPI = 64 / LPR;       // rows per wave-instruction (= tokens per row group)
+    constexpr int TPI = RPI * U;        // tokens per chunk
     const int part = blockIdx.x % p.num_parts, g = (blockIdx.x / p.num_parts) % p.KVH;
     const int t = blockIdx.x / (p.num_parts * p.KVH);
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int dc = lane % LPR, tg = lane / LPR;
+    const int p0 = part * p.part_size;
+
+    const int32_t *bt = PAGED ? p.block_tables + (int64_t)(p.seq_of_q ? p.seq_of_q[t] : t) * p.max_blocks : nullptr;
+    int bt_chunk = -1, bt_reg = 0;                   // UB: register copy of 64 block-table entries
+    auto load_bt_chunk = [&](int c) {
+        bt_chunk = c;
+        const int idx = (c << 6) + lane;
+        bt_reg = idx < p.max_blocks ? bt[idx] : 0;
+    };
+    if (PAGED && UB) {                               // requested together with ctx and q, ahead of their use
+        const int b0 = p.bs_shift >= 0 ? p0 >> p.bs_shift : p0 / p.block_size;
+        load_bt_chunk(b0 >> 6);
+    }
 
     const int ctx = p.ctx_lens[t];
-    const int p0 = part * p.part_size;
     if (p0 >= ctx && !(DIRECT_OUT)) return;          // empty partition: the merge kernel skips it too
     const int pend = min(ctx, p0 + p.part_size);
 
@@ -87,9 +140,31 @@ __global__ __launch_bounds__(WAVES * 64) void attn_rows_kernel(AttnParams p) {
             for (int j = 0; j < 4; ++j) qv[i][j] = (half2_t){h[2 * j], h[2 * j + 1]};
         }
     }
-    const int32_t *bt = PAGED ? p.block_tables + (int64_t)(p.seq_of_q ? p.seq_of_q[t] : t) * p.max_blocks : nullptr;
     const int64_t base_row = PAGED ? 0 : (int64_t)p.kv_base[t];
+    const int row_elems = p.KVH * D;
 
+    // element offset of (scalar token tb, kv head g, d = 0) through the register copy of the block table
+    auto block_base = [&](int tb) -> int64_t {
+        int bi, bo;
+        if (p.bs_shift >= 0) { bi = tb >> p.bs_shift; bo = tb & (p.block_size - 1); }
+        else { bi = tb / p.block_size; bo = tb - bi * p.block_size; }
+        if ((bi >> 6) != bt_chunk) load_bt_chunk(bi >> 6);
+        const int blk = __builtin_amdgcn_readlane(bt_reg, bi & 63);
+        return (((int64_t)blk * p.block_size + bo) * p.KVH + g) * D;
+    };
+    // per-lane form (contiguous K/V, or block sizes that are no multiple of the chunk)
+    auto lane_row = [&](int tok) -> int64_t {
+        if (PAGED) {
+            int bi, bo;
+            if (p.bs_shift >= 0) { bi = tok >> p.bs_shift; bo = tok & (p.block_size - 1); }
+            else { bi = tok / p.block_size; bo = tok - bi * p.block_size; }
+            return (((int64_t)bt[bi] * p.block_size + bo) * p.KVH + g) * D + dc * 8;
+        }
+        return (base_row + tok) * p.ldkv + (int64_t)g * D + dc * 8;
+    };
+
+    // online softmax state per head AND per row-group slot of the wave (the 64/LPR lane groups never exchange data
+    // inside the loop; they are merged once at the end)
     float m[G], l[G], acc[G][8];
 #pragma unroll
     for (int i = 0; i < G; ++i) {
@@ -98,52 +173,13 @@ __global__ __launch_bounds__(WAVES * 64) void attn_rows_kernel(AttnParams p) {
         for (int j = 0; j < 8; ++j) acc[i][j] = 0.f;
     }
 
-    // element offset of row `tok` (clamped into the partition) of this lane's 16-byte slice
-    auto row_off = [&](int tok) -> int64_t {
-        const int tc = tok < pend ? tok : pend - 1;
-        if (PAGED) {
-            int bi, bo;
-            if (p.bs_shift >= 0) { bi = tc >> p.bs_shift; bo = tc & (p.block_size - 1); }
-            else { bi = tc / p.block_size; bo = tc - bi * p.block_size; }
-            const int64_t row = (int64_t)bt[bi] * p.block_size + bo;
-            return (row * p.KVH + g) * D + dc * 8;
-        }
-        return (base_row + tc) * p.ldkv + (int64_t)g * D + dc * 8;
-    };
-
-    constexpr int STRIDE = WAVES * TPI;
-    int tb = p0 + wave * TPI;
-    half8_t kn[U], vn[U];
-    if (PREFETCH && tb < pend) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int64_t off = row_off(tb + u * RPI + tg);
-            kn[u] = load_row16<NT>(p.k + off); vn[u] = load_row16<NT>(p.v + off);
-        }
-    }
-    for (; tb < pend; tb += STRIDE) {
-        half8_t kk[U], vv[U];
-        if (PREFETCH) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) { kk[u] = kn[u]; vv[u] = vn[u]; }
-            if (tb + STRIDE < pend) {
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int64_t off = row_off(tb + STRIDE + u * RPI + tg);
-                    kn[u] = load_row16<NT>(p.k + off); vn[u] = load_row16<NT>(p.v + off);
-                }
-            }
-        } else {
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int64_t off = row_off(tb + u * RPI + tg);
-                kk[u] = load_row16<NT>(p.k + off); vv[u] = load_row16<NT>(p.v + off);
-            }
-        }
+    // scores, online softmax and p.v for U row groups; CHECK: slot u holds token tok0 + u*WAVES*RPI + tg, valid < pend
+    auto process = [&](auto check, const half8_t (&kk)[U], const half8_t (&vv)[U], int tok0) {
+        constexpr bool CHECK = decltype(check)::value;
         float s[U][G];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const bool valid = (tb + u * RPI + tg) < pend;
+            const bool valid = !CHECK || tok0 + u * (WAVES * RPI) + tg < pend;
 #pragma unroll
             for (int i = 0; i < G; ++i) {
                 float d = 0.f;
@@ -159,40 +195,86 @@ __global__ __launch_bounds__(WAVES * 64) void attn_rows_kernel(AttnParams p) {
             float mx = s[0][i];
 #pragma unroll
             for (int u = 1; u < U; ++u) mx = fmaxf(mx, s[u][i]);
-#pragma unroll
-            for (int o = LPR; o < 64; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-            const float mn = fmaxf(m[i], mx);            // finite: token tb (u=0, tg=0) is valid
-            const float alpha = __expf(m[i] - mn);       // m = -inf on first use -> 0
+            const float mn = fmaxf(m[i], mx);
+            const float ms = (CHECK && mn == -INFINITY) ? 0.f : mn;   // a slot that has seen no valid token yet
+            const float alpha = __expf(m[i] - ms);                    // m = -inf on first use -> 0
             m[i] = mn;
             float ps = 0.f;
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc[i][j] *= alpha;
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const float pr = __expf(s[u][i] - mn);
+                const float pr = __expf(s[u][i] - ms);
                 ps += pr;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) acc[i][j] = fmaf(pr, (float)vv[u][j], acc[i][j]);
             }
             l[i] = l[i] * alpha + ps;
         }
-    }
+    };
 
-    // merge the RPI row groups of the wave (m is wave-uniform), then the waves through LDS
+    const int ng = (pend - p0 + RPI - 1) / RPI;      // row groups of this partition, the last one possibly partial
+    const int R = (pend - p0) / (TPI * WAVES);       // full rounds: every wave gets a complete chunk
+    const int gt0 = R * (WAVES * U) + wave;          // this wave's remainder groups: gt0, gt0 + WAVES, ..
+    half8_t kt[U], vt[U];
+    auto issue_remainder = [&]() {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int gt = gt0 + u * WAVES;
+            if (gt < ng) {                           // uniform
+                const int tb = p0 + gt * RPI;
+                if (PAGED && UB) {
+                    const int64_t base = block_base(tb);
+                    const unsigned lo = (unsigned)(min(tg, pend - 1 - tb) * row_elems + dc * 8);
+                    kt[u] = load_row16<NT>(p.k + base + lo); vt[u] = load_row16<NT>(p.v + base + lo);
+                } else {
+                    const int64_t off = lane_row(min(tb + tg, pend - 1));
+                    kt[u] = load_row16<NT>(p.k + off); vt[u] = load_row16<NT>(p.v + off);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { kt[u][j] = (half_t)0.f; vt[u][j] = (half_t)0.f; }
+            }
+        }
+    };
+
+    if (R == 0) issue_remainder();
+    for (int r = 0; r < R; ++r) {
+        const int tb = p0 + (r * WAVES + wave) * TPI;
+        half8_t kk[U], vv[U];
+        if (PAGED && UB) {
+            const int64_t base = block_base(tb);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const unsigned lo = (unsigned)((u * RPI + tg) * row_elems + dc * 8);
+                kk[u] = load_row16<NT>(p.k + base + lo); vv[u] = load_row16<NT>(p.v + base + lo);
+            }
+        } else {
+            int64_t off[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) off[u] = lane_row(tb + u * RPI + tg);
+#pragma unroll
+            for (int u = 0; u < U; ++u) { kk[u] = load_row16<NT>(p.k + off[u]); vv[u] = load_row16<NT>(p.v + off[u]); }
+        }
+        if (r == R - 1) issue_remainder();
+        process(std::false_type{}, kk, vv, 0);
+    }
+    if (gt0 < ng) process(std::true_type{}, kt, vt, p0 + gt0 * RPI);
+
+    // bring the row-group slots of the wave to their common max and sum them, then merge the waves through LDS
     __shared__ float sm_acc[WAVES][G][D];
     __shared__ float sm_ml[WAVES][G][2];
 #pragma unroll
     for (int i = 0; i < G; ++i) {
+        const float M = groups_max<LPR>(m[i]);
+        const float w = (m[i] == -INFINITY) ? 0.f : __expf(m[i] - M);
+        l[i] = groups_sum<LPR>(l[i] * w);
 #pragma unroll
-        for (int o = LPR; o < 64; o <<= 1) {
-            l[i] += __shfl_xor(l[i], o, 64);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc[i][j] += __shfl_xor(acc[i][j], o, 64);
-        }
+        for (int j = 0; j < 8; ++j) acc[i][j] = groups_sum<LPR>(acc[i][j] * w);
         if (tg == 0) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) sm_acc[wave][i][dc * 8 + j] = acc[i][j];
-            if (dc == 0) { sm_ml[wave][i][0] = m[i]; sm_ml[wave][i][1] = l[i]; }
+            if (dc == 0) { sm_ml[wave][i][0] = M; sm_ml[wave][i][1] = l[i]; }
         }
     }
     __syncthreads();
@@ -240,10 +322,10 @@ __global__ void attn_merge_kernel(const float *__restrict__ part_o, const float 
 }
 
 // ---- launch configuration ------------------------------------------------------------------------
-struct Tune { int U, waves, prefetch, nt, parts; };          // parts: 0 = automatic
+struct Tune { int U, waves, unused, nt, parts; };            // parts: 0 = automatic; third field kept for old scripts
 static Tune env_tune() {
     Tune v{0, 0, 0, 0, 0};
-    if (const char *e = std::getenv("NVR_ATTN_TUNE")) std::sscanf(e, "%d,%d,%d,%d,%d", &v.U, &v.waves, &v.prefetch, &v.nt, &v.parts);
+    if (const char *e = std::getenv("NVR_ATTN_TUNE")) std::sscanf(e, "%d,%d,%d,%d,%d", &v.U, &v.waves, &v.unused, &v.nt, &v.parts);
     return v;
 }
 
@@ -267,15 +349,20 @@ size_t attn_workspace_bytes(int64_t nq, int64_t H, int64_t D, int64_t max_ctx) {
     return (size_t)(nq * H * max_parts * (D + 2) * sizeof(float));
 }
 
-template <int D, int G, int U, int WAVES, bool PF, bool NT>
+template <int D, int G, int U, int WAVES, bool NT>
 static void launch_cfg(const AttnParams &p, bool paged, bool direct, int64_t nwg, hipStream_t s) {
     dim3 grid((unsigned)nwg), block(WAVES * 64);
-    if (paged) {
-        if (direct) attn_rows_kernel<D, G, true, true, U, WAVES, PF, NT><<<grid, block, 0, s>>>(p);
-        else attn_rows_kernel<D, G, true, false, U, WAVES, PF, NT><<<grid, block, 0, s>>>(p);
+    constexpr int TPI = 64 / (D / 8) * U;
+    const bool ub = paged && p.block_size % TPI == 0 && (p.num_parts == 1 || p.part_size % TPI == 0);
+    if (ub) {
+        if (direct) attn_rows_kernel<D, G, true, true, U, WAVES, NT, true><<<grid, block, 0, s>>>(p);
+        else attn_rows_kernel<D, G, true, false, U, WAVES, NT, true><<<grid, block, 0, s>>>(p);
+    } else if (paged) {
+        if (direct) attn_rows_kernel<D, G, true, true, U, WAVES, NT, false><<<grid, block, 0, s>>>(p);
+        else attn_rows_kernel<D, G, true, false, U, WAVES, NT, false><<<grid, block, 0, s>>>(p);
     } else {
-        if (direct) attn_rows_kernel<D, G, false, true, U, WAVES, PF, NT><<<grid, block, 0, s>>>(p);
-        else attn_rows_kernel<D, G, false, false, U, WAVES, PF, NT><<<grid, block, 0, s>>>(p);
+        if (direct) attn_rows_kernel<D, G, false, true, U, WAVES, NT, false><<<grid, block, 0, s>>>(p);
+        else attn_rows_kernel<D, G, false, false, U, WAVES, NT, false><<<grid, block, 0, s>>>(p);
     }
 }
 
@@ -289,18 +376,19 @@ static int launch_attn(const AttnArgs &a, bool paged, hipStream_t s) {
     p.H = a.H; p.KVH = a.KVH; p.scale = a.scale; p.out = (half_t *)a.out;
     constexpr int DU = (D == 128) ? 4 : 2;           // default: 16 tokens per wave iteration
     const Tune tn = env_tune();
-    // Geometry (measured on MI355X at B=32, ctx 1030, KVH=8, D=128, profiles/r01_attn_tune.txt): one
-    // 16-wave workgroup per (query, kv head) with non-temporal K/V loads and no split (25.4 us, 5.3 TB/s)
-    // beats 4-wave workgroups over 4 partitions + merge kernel (33.0 us).  So: when there is enough
-    // work for >= ~192 sixteen-wave workgroups use them (splitting only to reach ~256 workgroups),
-    // otherwise fall back to 4-wave workgroups over 64-token-granular partitions.
+    // Geometry (measured on MI355X at B=32, ctx 1044, KVH=8, D=128, profiles/r01_attn_tune.txt): one 8-wave
+    // workgroup per (query, kv head) = one per CU, each wave with 2 row groups of K and of V in flight (32 KiB per
+    // CU), non-temporal loads and no split (23.6 us, 5.8 TB/s) beats 16 waves x 4 groups (25.0 us: more bytes in
+    // flight per CU is slower, as for a plain streaming read) and 4-wave workgroups over 4 partitions + merge
+    // kernel (29.6 us).  So: when there is enough work for >= ~192 such workgroups use them (splitting only to reach
+    // ~256 workgroups), otherwise fall back to 4-wave workgroups over 64-token-granular partitions.
     const int64_t mc = a.max_ctx > 0 ? a.max_ctx : 1;
     const int64_t pairs = (int64_t)a.nq * a.KVH;
-    int waves = tn.waves ? tn.waves : ((paged && a.workspace && pairs * ((mc + 255) / 256) >= 192) ? 16 : 4);
+    int waves = tn.waves ? tn.waves : ((paged && a.workspace && pairs * ((mc + 255) / 256) >= 192) ? 8 : 4);
     int part_size = 0x3fffffff, np = 1;
     if (a.workspace) {
         if (tn.parts > 0) { part_size = (int)(((mc + tn.parts - 1) / tn.parts + 63) / 64 * 64); np = (int)((mc + part_size - 1) / part_size); }
-        else if (waves == 16) {
+        else if (waves >= 8) {
             int64_t want = pairs >= 96 ? 1 : (256 + pairs - 1) / pairs;
             int64_t ps = ((mc + want - 1) / want + 255) / 256 * 256;
             part_size = (int)ps; np = (int)((mc + ps - 1) / ps);
@@ -317,20 +405,20 @@ static int launch_attn(const AttnArgs &a, bool paged, hipStream_t s) {
     bool done = false;
 #ifdef NVR_ATTN_EXPERIMENTS
     if (D == 128 && G == 2 && paged && tn.U) {
-#define NVR_TRY(UU, WW, PP, NN)                                                                          \
-        if (!done && tn.U == UU && waves == WW && tn.prefetch == PP && tn.nt == NN) {                    \
-            launch_cfg<D, G, UU, WW, PP != 0, NN != 0>(p, paged, direct, nwg, s); done = true; }
-        NVR_TRY(8, 4, 0, 0) NVR_TRY(4, 4, 1, 0) NVR_TRY(4, 8, 0, 0) NVR_TRY(4, 16, 0, 0) NVR_TRY(4, 16, 1, 0)
-        NVR_TRY(4, 4, 0, 1) NVR_TRY(4, 16, 0, 1) NVR_TRY(8, 16, 0, 0) NVR_TRY(4, 8, 1, 0) NVR_TRY(2, 16, 1, 0)
-        NVR_TRY(2, 8, 1, 0) NVR_TRY(4, 16, 1, 1) NVR_TRY(4, 8, 1, 1) NVR_TRY(2, 4, 1, 0)
+#define NVR_TRY(UU, WW, NN)                                                                              \
+        if (!done && tn.U == UU && waves == WW && tn.nt == NN) {                                         \
+            launch_cfg<D, G, UU, WW, NN != 0>(p, paged, direct, nwg, s); done = true; }
+        NVR_TRY(4, 16, 1) NVR_TRY(4, 16, 0) NVR_TRY(2, 16, 1) NVR_TRY(8, 16, 1) NVR_TRY(4, 8, 1) NVR_TRY(8, 8, 1)
+        NVR_TRY(2, 8, 1) NVR_TRY(4, 4, 1) NVR_TRY(8, 4, 1) NVR_TRY(1, 4, 1) NVR_TRY(1, 8, 1) NVR_TRY(1, 16, 1) NVR_TRY(2, 4, 1)
+        NVR_TRY(2, 8, 0) NVR_TRY(2, 6, 1) NVR_TRY(2, 10, 1) NVR_TRY(2, 12, 1) NVR_TRY(1, 12, 1) NVR_TRY(4, 6, 1) NVR_TRY(4, 3, 1) NVR_TRY(4, 5, 1)
 #undef NVR_TRY
         if (!done) return nvr::fail(NVR_ERR_UNSUPPORTED, "NVR_ATTN_TUNE names a variant that is not compiled in");
     }
 #endif
     if (!done) {
-        if (waves == 16) launch_cfg<D, G, DU, 16, false, true>(p, paged, direct, nwg, s);   // K/V streamed once: nt loads
-        else if (paged) launch_cfg<D, G, DU, 4, false, true>(p, paged, direct, nwg, s);
-        else launch_cfg<D, G, DU, 4, false, false>(p, paged, direct, nwg, s);             // prefill: rows re-read from L2
+        if (waves == 8) launch_cfg<D, G, DU / 2, 8, true>(p, paged, direct, nwg, s);        // K/V streamed once: nt loads
+        else if (paged) launch_cfg<D, G, DU, 4, true>(p, paged, direct, nwg, s);
+        else launch_cfg<D, G, DU, 4, false>(p, paged, direct, nwg, s);                     // prefill: rows re-read from L2
     }
     if (!direct)
         attn_merge_kernel<D><<<dim3((unsigned)((int64_t)a.H * a.nq)), dim3(D), 0, s>>>(p.part_o, p.part_ml, a.ctx_lens, a.H,
