@@ -35,6 +35,7 @@ struct AttnParams {
     int32_t part_size, num_parts;
     float *part_o; float *part_ml;     // [nq, H, num_parts, D], [nq, H, num_parts, 2]
     half_t *out;                       // [nq, H, D]
+    unsigned long long *stamps;        // NVR_ATTN_EXPERIMENTS: 5 wall_clock64 stamps per workgroup (or null)
 };
 
 template <bool NT>
@@ -125,6 +126,12 @@ __global__ __launch_bounds__(WAVES * 64) void attn_rows_kernel(AttnParams p) {
         load_bt_chunk(b0 >> 6);
     }
 
+#ifdef NVR_ATTN_EXPERIMENTS
+#define NVR_STAMP(i) if (p.stamps && threadIdx.x == 0) p.stamps[blockIdx.x * 5 + (i)] = wall_clock64();
+#else
+#define NVR_STAMP(i)
+#endif
+    NVR_STAMP(0)
     const int ctx = p.ctx_lens[t];
     if (p0 >= ctx && !(DIRECT_OUT)) return;          // empty partition: the merge kernel skips it too
     const int pend = min(ctx, p0 + p.part_size);
@@ -238,6 +245,7 @@ __global__ __launch_bounds__(WAVES * 64) void attn_rows_kernel(AttnParams p) {
         }
     };
 
+    NVR_STAMP(1)
     if (R == 0) issue_remainder();
     for (int r = 0; r < R; ++r) {
         const int tb = p0 + (r * WAVES + wave) * TPI;
@@ -258,8 +266,10 @@ __global__ __launch_bounds__(WAVES * 64) void attn_rows_kernel(AttnParams p) {
         }
         if (r == R - 1) issue_remainder();
         process(std::false_type{}, kk, vv, 0);
+        if (r == 0) { NVR_STAMP(2) }
     }
     if (gt0 < ng) process(std::true_type{}, kt, vt, p0 + gt0 * RPI);
+    NVR_STAMP(3)
 
     // bring the row-group slots of the wave to their common max and sum them, then merge the waves through LDS
     __shared__ float sm_acc[WAVES][G][D];
@@ -300,6 +310,8 @@ __global__ __launch_bounds__(WAVES * 64) void attn_rows_kernel(AttnParams p) {
             if (d == 0) { p.part_ml[slot * 2] = M; p.part_ml[slot * 2 + 1] = L; }
         }
     }
+    NVR_STAMP(4)
+#undef NVR_STAMP
 }
 
 // merge split-KV partitions: out = sum_p e^(m_p-M) o_p / sum_p e^(m_p-M) l_p
@@ -404,6 +416,7 @@ static int launch_attn(const AttnArgs &a, bool paged, hipStream_t s) {
     const int64_t nwg = (int64_t)p.num_parts * a.KVH * a.nq;
     bool done = false;
 #ifdef NVR_ATTN_EXPERIMENTS
+    if (direct && a.workspace && std::getenv("NVR_ATTN_STAMPS")) p.stamps = (unsigned long long *)a.workspace;
     if (D == 128 && G == 2 && paged && tn.U) {
 #define NVR_TRY(UU, WW, NN)                                                                              \
         if (!done && tn.U == UU && waves == WW && tn.nt == NN) {                                         \
