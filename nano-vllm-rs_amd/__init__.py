@@ -159,6 +159,8 @@ _SIGS = {
     "nvr_rmsnorm": (C.c_int, [_P, _P, C.c_float, C.c_int64, C.c_int64, _P, _P]),
     "nvr_add_rmsnorm": (C.c_int, [_P, _P, _P, C.c_float, C.c_int64, C.c_int64, _P, _P]),
     "nvr_linear": (C.c_int, [_P, C.c_int64, _P, C.c_int64, C.c_int64, C.c_int64, _P, C.c_int, _P]),
+    "nvr_lm_head": (C.c_int, [_P, C.c_int64, _P, C.c_int64, C.c_int64, C.c_int64, _P, _P, _P, _P, _P]),
+    "nvr_argmax_partials": (C.c_int, [_P, _P, C.c_int32, C.c_int64, _P, _P, C.c_int64, _P]),
     "nvr_linear_splitk": (C.c_int, [_P, C.c_int64, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _P, _P]),
     "nvr_linear_splitk_norm": (C.c_int, [_P, C.c_int64, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _P, _P, _P, C.c_float, _P, _P, _P]),
     "nvr_add_rmsnorm_slabs": (C.c_int, [_P, _P, C.c_int64, _P, C.c_float, C.c_int64, C.c_int64, _P, _P]),

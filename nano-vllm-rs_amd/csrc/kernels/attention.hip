@@ -127,9 +127,11 @@ __global__ __launch_bounds__(WAVES * 64) void attn_rows_kernel(AttnParams p) {
     }
 
 #ifdef NVR_ATTN_EXPERIMENTS
-#define NVR_STAMP(i) if (p.stamps && threadIdx.x == 0) p.stamps[blockIdx.x * 5 + (i)] = wall_clock64();
+#define NVR_STAMP(i) if (p.stamps && threadIdx.x == 0) p.stamps[blockIdx.x * 24 + (i)] = wall_clock64();
+#define NVR_STAMP_WAVE(i) if (p.stamps && lane == 0) p.stamps[blockIdx.x * 24 + (i) + wave] = wall_clock64();
 #else
 #define NVR_STAMP(i)
+#define NVR_STAMP_WAVE(i)
 #endif
     NVR_STAMP(0)
     const int ctx = p.ctx_lens[t];
@@ -270,6 +272,7 @@ __global__ __launch_bounds__(WAVES * 64) void attn_rows_kernel(AttnParams p) {
     }
     if (gt0 < ng) process(std::true_type{}, kt, vt, p0 + gt0 * RPI);
     NVR_STAMP(3)
+    NVR_STAMP_WAVE(8)
 
     // bring the row-group slots of the wave to their common max and sum them, then merge the waves through LDS
     __shared__ float sm_acc[WAVES][G][D];
@@ -288,6 +291,7 @@ __global__ __launch_bounds__(WAVES * 64) void attn_rows_kernel(AttnParams p) {
         }
     }
     __syncthreads();
+    NVR_STAMP(5)
     for (int idx = threadIdx.x; idx < G * D; idx += WAVES * 64) {
         const int i = idx / D, d = idx % D;
         float M = sm_ml[0][i][0];
@@ -312,6 +316,7 @@ __global__ __launch_bounds__(WAVES * 64) void attn_rows_kernel(AttnParams p) {
     }
     NVR_STAMP(4)
 #undef NVR_STAMP
+#undef NVR_STAMP_WAVE
 }
 
 // merge split-KV partitions: out = sum_p e^(m_p-M) o_p / sum_p e^(m_p-M) l_p

@@ -30,6 +30,17 @@ int concat_vocab_shards(const float *gathered, int64_t tp, int64_t B, int64_t Vl
 int linear(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t N, void *y,
            bool y_f32, hipStream_t s);
 
+// LM head for decode-sized batches (T <= 32, K <= 2048): f32 logits + per-workgroup greedy arg-max partials
+// ([*nparts][T] values and vocabulary indices, *nparts <= LM_HEAD_MAX_PARTS), finished by argmax_partials
+// (lowest index wins ties; idx_offset is added; out_val nullable)
+constexpr int LM_HEAD_MAX_PARTS = 1024;
+bool lm_head_ok(int64_t T, int64_t K, int64_t N, int64_t ldx);
+int32_t lm_head_parts(int64_t T, int64_t K, int64_t N, int64_t ldx);      // partials lm_head will write (0: unsupported shape)
+int lm_head(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t N, float *logits,
+            float *part_val, int32_t *part_idx, int32_t *nparts, hipStream_t s);
+int argmax_partials(const float *part_val, const int32_t *part_idx, int32_t nparts, int64_t T, int64_t *out_idx, float *out_val,
+                    int64_t idx_offset, hipStream_t s);
+
 int linear_splitk(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t N, int64_t S,
                   float *slabs, hipStream_t s);
 int linear_splitk_norm(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t N, int64_t S, float *slabs,

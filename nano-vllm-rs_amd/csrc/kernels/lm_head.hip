@@ -1,0 +1,216 @@
+// lm_head.hip — logits = h_last · W_lmᵀ (K16) for decode-sized batches, with the greedy arg-max folded into the
+// epilogue (K17's greedy branch).
+// reference: ParallelLMHead::compute_logits src/layers/embed_head.rs:292-306 (f32 logits per SURVEY A-21);
+// Sampler::sample greedy branch src/layers/sampler.rs:126-151 (argmax, lowest index on ties, A-17).
+//
+// Roofline: HBM.  Algorithmic bytes = 2·N·K (every weight byte once; 311 MB for Qwen3-0.6B) + 4·T·N logits out.
+// The weight matrix is the largest single stream of a decode step, so the kernel is persistent and shaped like the
+// decode attention: one workgroup per CU slot keeps the T x K activation block in LDS (XOR-swizzled 16-byte
+// chunks: ds_read_b128 of 16 rows at one k offset is conflict-free) for its whole life; each WAVE owns whole
+// 16-row weight tiles (tile j -> wave j % all_waves: neighbouring waves stream neighbouring 16·K·2-byte regions) and
+// runs the full k loop alone: U row-chunk loads of 1 KiB in flight per wave (A operand straight from HBM to VGPRs,
+// non-temporal), B operand from LDS, one v_mfma_f32_16x16x32_f16 per 16 tokens and k-step, no cross-wave
+// reduction and no barrier inside the stream.
+// Greedy arg-max: every lane keeps (best value, lowest index) of the logits it produced for its token; lanes, waves and
+// finally workgroups are merged with "greater value, else lower index", the workgroup results go to a small
+// partials array and argmax_partials finishes the job, instead of re-reading all 4·T·N logit bytes.
+#include "kernels.h"
+#include "device_utils.h"
+#include "../common.h"
+#include <cstdio>
+#include <cstdlib>
+
+namespace nvr { namespace k {
+
+__device__ __forceinline__ void take_better(float &bv, int &bi, float v, int i) {
+    if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
+}
+
+template <int MT, int WAVES, int U>
+__global__ __launch_bounds__(WAVES * 64) void lm_head_kernel(const half_t *__restrict__ x, int64_t ldx,
+                                                             const half_t *__restrict__ W, int T, int K, int N,
+                                                             float *__restrict__ y, float *__restrict__ pval,
+                                                             int32_t *__restrict__ pidx, int flags) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int ROWS = MT * 16;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 15, q = lane >> 4;
+    const int cpr = K / 8;                                       // 16-byte chunks per activation row
+    for (int c = tid; c < ROWS * cpr; c += WAVES * 64) {
+        const int row = c / cpr, ch = c - row * cpr;
+        const int m = row < T ? row : T - 1;
+        const half8_t v = *reinterpret_cast<const half8_t *>(x + (int64_t)m * ldx + ch * 8);
+        *reinterpret_cast<half8_t *>(smem + ((int64_t)row * cpr + (ch ^ (row & 7))) * 16) = v;
+    }
+    __syncthreads();
+
+    const int ntiles = N / 16, nw = gridDim.x * WAVES;
+    float best[MT]; int besti[MT];
+#pragma unroll
+    for (int j = 0; j < MT; ++j) { best[j] = -INFINITY; besti[j] = 0x7fffffff; }
+
+    for (int tile = blockIdx.x * WAVES + wave; tile < ntiles; tile += nw) {
+        const half_t *wr = W + ((int64_t)tile * 16 + r) * K + q * 8;
+        float4_t acc[MT];
+#pragma unroll
+        for (int j = 0; j < MT; ++j) acc[j] = (float4_t){0.f, 0.f, 0.f, 0.f};
+        for (int k0 = 0; k0 < K; k0 += 32 * U) {
+            half8_t a[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) a[u] = __builtin_nontemporal_load(reinterpret_cast<const half8_t *>(wr + k0 + u * 32));
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int ch = (k0 >> 3) + u * 4 + q;
+#pragma unroll
+                for (int j = 0; j < MT; ++j) {
+                    const int row = j * 16 + r;
+                    const half8_t b = *reinterpret_cast<const half8_t *>(smem + ((int64_t)row * cpr + (ch ^ (r & 7))) * 16);
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[u], b, acc[j], 0, 0, 0);
+                }
+            }
+        }
+        // C layout: rows n = q*4 + e (4 consecutive vocabulary entries), column = token r
+        const int n0 = tile * 16 + q * 4;
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+            const int m = j * 16 + r;
+            if (m < T && !(flags & 1)) *reinterpret_cast<float4_t *>(y + (int64_t)m * N + n0) = acc[j];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (acc[j][e] > best[j]) { best[j] = acc[j][e]; besti[j] = n0 + e; }     // tiles ascend: first maximum kept
+        }
+    }
+
+    // lanes r, r+16, r+32, r+48 hold the same token; then the waves through LDS (the activation image is dead)
+#pragma unroll
+    for (int j = 0; j < MT; ++j)
+#pragma unroll
+        for (int o = 16; o < 64; o <<= 1) {
+            const float v = __shfl_xor(best[j], o, 64);
+            const int i = __shfl_xor(besti[j], o, 64);
+            take_better(best[j], besti[j], v, i);
+        }
+    __syncthreads();
+    float *sv = reinterpret_cast<float *>(smem);
+    int *si = reinterpret_cast<int *>(smem + WAVES * ROWS * 4);
+    if (q == 0) {
+#pragma unroll
+        for (int j = 0; j < MT; ++j) { sv[wave * ROWS + j * 16 + r] = best[j]; si[wave * ROWS + j * 16 + r] = besti[j]; }
+    }
+    __syncthreads();
+    if (tid < T) {
+        float bv = sv[tid]; int bi = si[tid];
+        for (int w2 = 1; w2 < WAVES; ++w2) take_better(bv, bi, sv[w2 * ROWS + tid], si[w2 * ROWS + tid]);
+        pval[(int64_t)blockIdx.x * T + tid] = bv;
+        pidx[(int64_t)blockIdx.x * T + tid] = bi;
+    }
+}
+
+__global__ __launch_bounds__(64) void argmax_partials_kernel(const float *__restrict__ pval, const int32_t *__restrict__ pidx,
+                                                             int nparts, int T, int64_t *__restrict__ out_idx,
+                                                             float *__restrict__ out_val, int64_t idx_offset) {
+    const int m = blockIdx.x, lane = threadIdx.x;
+    float bv = -INFINITY; int bi = 0x7fffffff;
+    for (int p = lane; p < nparts; p += 64) take_better(bv, bi, pval[(int64_t)p * T + m], pidx[(int64_t)p * T + m]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float v = __shfl_xor(bv, o, 64);
+        const int i = __shfl_xor(bi, o, 64);
+        take_better(bv, bi, v, i);
+    }
+    if (lane == 0) {
+        out_idx[m] = (bi == 0x7fffffff ? 0 : (int64_t)bi) + idx_offset;
+        if (out_val) out_val[m] = bv;
+    }
+}
+
+bool lm_head_ok(int64_t T, int64_t K, int64_t N, int64_t ldx) {
+    return T >= 1 && T <= 32 && K % 256 == 0 && K <= 2048 && N % 16 == 0 && N >= 16 && ldx % 8 == 0 && N < (1ll << 31);
+}
+
+struct LmTune { int U, waves, per_cu; };
+static LmTune lm_env_tune() {
+    LmTune t{0, 0, 0};
+    if (const char *e = std::getenv("NVR_LMHEAD_TUNE")) std::sscanf(e, "%d,%d,%d", &t.U, &t.waves, &t.per_cu);
+    return t;
+}
+
+struct LmPlan { int mt, waves, U; int64_t nwg; };
+static LmPlan lm_plan(int64_t T, int64_t K, int64_t N) {
+    const LmTune tn = lm_env_tune();
+    LmPlan pl;
+    pl.mt = T <= 16 ? 1 : 2;
+    const size_t lds = (size_t)pl.mt * 16 * K * 2;
+    int per_cu = tn.per_cu ? tn.per_cu : 1;
+    if ((size_t)per_cu * lds > 160 * 1024) per_cu = (int)(160 * 1024 / lds);
+    pl.waves = tn.waves ? tn.waves : 8; pl.U = tn.U ? tn.U : 4;
+    pl.nwg = 256ll * per_cu;
+    const int64_t ntiles = N / 16;
+    if (pl.nwg * pl.waves > ntiles) pl.nwg = (ntiles + pl.waves - 1) / pl.waves;
+    if (pl.nwg > LM_HEAD_MAX_PARTS) pl.nwg = LM_HEAD_MAX_PARTS;
+    return pl;
+}
+int32_t lm_head_parts(int64_t T, int64_t K, int64_t N, int64_t ldx) {
+    return lm_head_ok(T, K, N, ldx) ? (int32_t)lm_plan(T, K, N).nwg : 0;
+}
+
+// every compiled (MT, WAVES, U) instance, as X(mt, waves, U)
+#define NVR_LM_INSTANCES(X) X(1, 8, 4) X(2, 8, 4) X(1, 4, 8) X(2, 4, 8) X(1, 4, 4) X(2, 4, 4) X(1, 8, 8) X(2, 8, 8) \
+                            X(1, 8, 2) X(2, 8, 2) X(2, 16, 2) X(2, 16, 4) X(2, 4, 2)
+
+// > 64 KiB of dynamic LDS needs an opt-in per kernel; done for all instances on the first (never captured: a
+// sequence is prefilled eagerly before any decode graph exists) call
+static int lm_allow_big_lds() {
+    static bool done = false;
+    if (done) return 0;
+#define NVR_LM_ATTR(MT_, WV_, U_)                                                                                     \
+    {                                                                                                                 \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&lm_head_kernel<MT_, WV_, U_>),             \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                   \
+        if (e != hipSuccess) return nvr::fail(NVR_ERR_HIP, "lm_head: hipFuncSetAttribute: %s", hipGetErrorString(e)); \
+    }
+    NVR_LM_INSTANCES(NVR_LM_ATTR)
+#undef NVR_LM_ATTR
+    done = true;
+    return 0;
+}
+
+// logits[T,N] (f32) = x·Wᵀ and per-workgroup arg-max partials: part_val/part_idx [*nparts][T], *nparts <= LM_HEAD_MAX_PARTS
+int lm_head(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t N, float *logits,
+            float *part_val, int32_t *part_idx, int32_t *nparts, hipStream_t s) {
+    if (!lm_head_ok(T, K, N, ldx))
+        return nvr::fail(NVR_ERR_UNSUPPORTED, "lm_head: T=%ld (1..32), K=%ld (multiple of 256, <= 2048), N=%ld (multiple of 16)",
+                         (long)T, (long)K, (long)N);
+    const LmPlan pl = lm_plan(T, K, N);
+    const int mt = pl.mt, waves = pl.waves, U = pl.U;
+    const int64_t nwg = pl.nwg;
+    *nparts = (int32_t)nwg;
+    const half_t *xx = (const half_t *)x, *ww = (const half_t *)W;
+    if (int rc0 = lm_allow_big_lds()) return rc0;
+    const size_t lds = (size_t)mt * 16 * K * 2;
+    bool launched = false;
+    const int dbg_flags = std::getenv("NVR_LM_DBG") ? std::atoi(std::getenv("NVR_LM_DBG")) : 0;
+#define NVR_LM(MT_, WV_, U_)                                                                                          \
+    if (!launched && mt == MT_ && waves == WV_ && U == U_) {                                                          \
+        lm_head_kernel<MT_, WV_, U_><<<dim3((unsigned)nwg), dim3(WV_ * 64), lds, s>>>(xx, ldx, ww, (int)T, (int)K, (int)N, logits, \
+                                                                                     part_val, part_idx, dbg_flags);  \
+        launched = true;                                                                                              \
+    }
+    NVR_LM_INSTANCES(NVR_LM)
+#undef NVR_LM
+    if (!launched) return nvr::fail(NVR_ERR_UNSUPPORTED, "lm_head: variant U=%d waves=%d is not compiled in", U, waves);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return nvr::fail(NVR_ERR_HIP, "lm_head launch failed: %s", hipGetErrorString(e));
+    return 0;
+}
+
+int argmax_partials(const float *part_val, const int32_t *part_idx, int32_t nparts, int64_t T, int64_t *out_idx, float *out_val,
+                    int64_t idx_offset, hipStream_t s) {
+    if (T == 0) return 0;
+    if (nparts < 1) return nvr::fail(NVR_ERR_INVALID_ARG, "argmax_partials: nparts=%d", nparts);
+    argmax_partials_kernel<<<dim3((unsigned)T), dim3(64), 0, s>>>(part_val, part_idx, nparts, (int)T, out_idx, out_val, idx_offset);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return nvr::fail(NVR_ERR_HIP, "argmax_partials launch failed: %s", hipGetErrorString(e));
+    return 0;
+}
+
+}}  // namespace nvr::k

@@ -45,7 +45,7 @@ nvr_model_runner::~nvr_model_runner() {
     for (auto &l : layers) { hipFree(l.qkv); hipFree(l.o); hipFree(l.gate_up); hipFree(l.down); hipFree(l.ln1); hipFree(l.ln2); }
     void *ptrs[] = {embed, mc.tie_word_embeddings ? nullptr : lm_head, norm, cos_t, sin_t, kv_pool, h, n, qkv, attn,
                     proj, gu, act, nlast, logits, attn_ws, slabs, in_dev, d_tok, d_maxval, d_temp, d_topk, d_topp, d_keys,
-                    sample_ws, d_gather_val, d_gather_idx, d_gather_logits, d_full_logits, sample_ws_full};
+                    sample_ws, d_gather_val, d_gather_idx, d_gather_logits, d_full_logits, sample_ws_full, d_lm_pval, d_lm_pidx};
     for (void *p : ptrs) if (p) hipFree(p);
     if (in_host) hipHostFree(in_host);
     if (h_tok) hipHostFree(h_tok);
@@ -99,6 +99,8 @@ int nvr_model_runner::init() {                                       // ModelRun
     RC(dmalloc(&slabs, 4 * 64 * Hd));
     // measured slower than two launches (profiles/r01_fused_slabnorm_ablation.txt): opt-in only
     { const char *e = getenv("NVR_FUSED_SLABNORM"); fused_slabnorm = e && e[0] == '1'; }
+    { const char *e = getenv("NVR_LM_FUSED"); lm_fused = !(e && e[0] == '0'); }
+    RC(dmalloc(&d_lm_pval, (size_t)k::LM_HEAD_MAX_PARTS * 32)); RC(dmalloc(&d_lm_pidx, (size_t)k::LM_HEAD_MAX_PARTS * 32));
     attn_ws_bytes = k::attn_workspace_bytes(max_seqs, H, D, max_pos);
     NVR_HIP_CHECK(hipMalloc(&attn_ws, attn_ws_bytes));
     {
@@ -266,7 +268,13 @@ int nvr_model_runner::forward(Lane &ln, int64_t row0, int64_t T, int64_t B, bool
     }
     const uint16_t *hl = ln.n;
     if (is_prefill) { RC(k::select_last_tokens(ln.n, d_cu, B, Hd, nlast, st)); hl = nlast; }   // embed_head.rs:272-289
-    RC(k::linear(hl, Hd, lm_head, B, Hd, Vl, logits + row0 * Vl, true, st));                   // f32 logits (A-21)
+    if (lm_parts > 0) {                                                                        // f32 logits (A-21) + arg-max partials
+        int32_t np = 0;
+        RC(k::lm_head(hl, Hd, lm_head, B, Hd, Vl, logits, d_lm_pval, d_lm_pidx, &np, st));
+        if (np != lm_parts) return nvr::fail(NVR_ERR_INVARIANT, "lm_head produced %d partials, planned %d", np, lm_parts);
+    } else {
+        RC(k::linear(hl, Hd, lm_head, B, Hd, Vl, logits + row0 * Vl, true, st));
+    }
     return NVR_OK;
 }
 
@@ -358,7 +366,10 @@ int nvr_model_runner::execute(nvr_seq *const *seqs, size_t nseq, bool is_prefill
     } else NVR_HIP_CHECK(up(off_dec, dof_bt + nseq * max_blocks_per_seq * 4));
 
     last_rows = nseq; last_prefill = is_prefill;
+    // arg-max partials come with the logits when the whole batch goes through one lm_head launch (a pure function of
+    // the shapes, so a replayed graph and this bookkeeping always agree)
     const int nl = (!is_prefill && (int64_t)nseq >= 8 * (int64_t)lanes.size()) ? (int)lanes.size() : 1;
+    lm_parts = (lm_fused && (is_prefill || nl == 1)) ? k::lm_head_parts((int64_t)nseq, Hd, Vl, Hd) : 0;
     if (is_prefill || cfg.enforce_eager || graphs_disabled) return forward_all(T, (int64_t)nseq, is_prefill, max_ctx, nl);
 
     // decode: replay a hipGraph captured per (batch size, context bucket) — execute_with_cuda_graph :303-326
@@ -446,10 +457,12 @@ int nvr_model_runner::sample(nvr_seq *const *seqs, size_t nseq, int64_t *out) {
     const int64_t B = (int64_t)nseq;
     if (all_greedy) {
         if (!comm.active()) {
-            RC(k::argmax(logits, B, Vl, d_tok, nullptr, 0, stream));
+            if (lm_parts > 0) RC(k::argmax_partials(d_lm_pval, d_lm_pidx, lm_parts, B, d_tok, nullptr, 0, stream));
+            else RC(k::argmax(logits, B, Vl, d_tok, nullptr, 0, stream));
         } else {
             // vocab-sharded greedy (embed_head.rs:321-336): all-gather (max, argmax) pairs, then lowest index wins
-            RC(k::argmax(logits, B, Vl, d_tok, d_maxval, vocab_start, stream));
+            if (lm_parts > 0) RC(k::argmax_partials(d_lm_pval, d_lm_pidx, lm_parts, B, d_tok, d_maxval, vocab_start, stream));
+            else RC(k::argmax(logits, B, Vl, d_tok, d_maxval, vocab_start, stream));
             RC(comm.all_gather_bytes(d_maxval, d_gather_val, (size_t)B * 4, stream));
             RC(comm.all_gather_bytes(d_tok, d_gather_idx, (size_t)B * 8, stream));
             std::vector<float> gv(tp * B); std::vector<int64_t> gi(tp * B);

@@ -82,4 +82,6 @@ private:
     int gen_weights();
     int row_parallel_norm(Lane &ln, const uint16_t *x, int64_t K, const uint16_t *W, int64_t T, const uint16_t *wn);
     bool fused_slabnorm = false;
+    bool lm_fused = true; int32_t lm_parts = 0;          // lm_head arg-max partials of the last step (0: none)
+    float *d_lm_pval = nullptr; int32_t *d_lm_pidx = nullptr;
 };

@@ -303,6 +303,15 @@ int nvr_add_rmsnorm(nvr_half *h, const nvr_half *y, const nvr_half *w, float eps
 int nvr_linear(const nvr_half *x, int64_t ldx, const nvr_half *W, int64_t T, int64_t K, int64_t N, void *y, int f32, void *s) {
     return k::linear(x, ldx, W, T, K, N, y, f32 != 0, (hipStream_t)s);
 }
+int nvr_lm_head(const nvr_half *x, int64_t ldx, const nvr_half *W, int64_t T, int64_t K, int64_t N, float *logits, float *part_val,
+                int32_t *part_idx, int32_t *nparts, void *s) {
+    if (!nparts) return nvr::fail(NVR_ERR_INVALID_ARG, "nvr_lm_head: nparts is null");
+    return k::lm_head(x, ldx, W, T, K, N, logits, part_val, part_idx, nparts, (hipStream_t)s);
+}
+int nvr_argmax_partials(const float *part_val, const int32_t *part_idx, int32_t nparts, int64_t T, int64_t *out_idx, float *out_val,
+                        int64_t idx_offset, void *s) {
+    return k::argmax_partials(part_val, part_idx, nparts, T, out_idx, out_val, idx_offset, (hipStream_t)s);
+}
 int nvr_linear_splitk(const nvr_half *x, int64_t ldx, const nvr_half *W, int64_t T, int64_t K, int64_t N, int64_t S, float *slabs, void *s) {
     return k::linear_splitk(x, ldx, W, T, K, N, S, slabs, (hipStream_t)s);
 }

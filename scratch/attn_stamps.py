@@ -17,7 +17,7 @@ q = nvr.DeviceBuffer.from_numpy(rng.standard_normal((B, H * D)).astype(np.float1
 d_ctx, d_bt = nvr.DeviceBuffer.from_numpy(np.full(B, ctx_len, np.int32)), nvr.DeviceBuffer.from_numpy(bt)
 out = nvr.DeviceBuffer(B * H * D * 2)
 bucket = (ctx_len + 255) // 256 * 256
-wsb = max(l.nvr_paged_attn_workspace_bytes(B, H, D, bucket), B * KVH * 40)
+wsb = max(l.nvr_paged_attn_workspace_bytes(B, H, D, bucket), B * KVH * 24 * 8)
 wss = [nvr.DeviceBuffer(wsb) for _ in range(L)]
 meta = nvr.AttnMetaC(); meta.context_lens, meta.block_tables, meta.max_blocks, meta.batch, meta.max_context_len = d_ctx.ptr, d_bt.ptr, nblk + 1, B, bucket
 stream = C.c_void_p(); nvr.check(l.nvr_stream_create(C.byref(stream)))
@@ -30,10 +30,13 @@ def sweep():
 for _ in range(3): sweep()
 nvr.check(l.nvr_stream_synchronize(stream))
 nwg = B * KVH
-st = np.stack([w.to_numpy((wsb // 8,), np.uint64)[:nwg * 5].reshape(nwg, 5).astype(np.int64) for w in wss[4:]])  # [layers, wg, 5]
+st = np.stack([w.to_numpy((wsb // 8,), np.uint64)[:nwg * 24].reshape(nwg, 24).astype(np.int64) for w in wss[4:]])  # [layers, wg, 5]
 t0 = st[:, :, 0].min(axis=1, keepdims=True)
 rel = (st - t0[:, :, None]) * 10.0 / 1e3       # us since first workgroup entry
-names = ["entry", "ctx known", "first round done", "loop+remainder done", "stored"]
+names = ["entry", "ctx known", "first round done", "loop+remainder done (wave 0)", "stored", "after barrier"]
 for i, n in enumerate(names):
     print(f"{n:22s} mean {rel[:, :, i].mean():6.2f} us   min {rel[:, :, i].min(axis=1).mean():6.2f}   max {rel[:, :, i].max(axis=1).mean():6.2f}")
-print("launch-to-launch (entry of first wg, consecutive layers):", np.diff(t0[:, 0, 0]).mean() * 10 / 1e3, "us")
+W = int((os.environ.get("NVR_ATTN_TUNE") or "2,8").split(",")[1])
+wv = rel[:, :, 8:8 + W]
+print(f"per-wave loop done: first wave {wv.min(axis=2).mean():6.2f}  last wave {wv.max(axis=2).mean():6.2f}  (last - first) mean {(wv.max(axis=2) - wv.min(axis=2)).mean():5.2f} us; latest anywhere {wv.max(axis=(1,2)).mean():6.2f}")
+#print("launch-to-launch (entry of first wg, consecutive layers):", np.diff(t0[:, 0, 0]).mean() * 10 / 1e3, "us")

@@ -325,6 +325,40 @@ def test_argmax_exact_with_ties():
         assert d_out.to_numpy((1,), np.int64)[0] == want
 
 
+@pytest.mark.parametrize("T,K,N", [(32, 1024, 151936), (7, 1024, 18992), (16, 2048, 4096), (17, 256, 48), (1, 512, 16), (32, 1024, 100000)])
+def test_lm_head_logits_and_argmax_partials(T, K, N):
+    """lm_head: f32 logits == oracle linear (f32 sums in another order), and the arg-max that rides along in the epilogue
+    is EXACTLY the lowest-index arg-max of the logits the kernel itself wrote (ties included)."""
+    rng = np.random.default_rng(31)
+    x, xb = h16(rng.standard_normal((T, K)))
+    W, Wb = h16(rng.standard_normal((N, K)) * 0.05)
+    W[N // 3] = W[5]; Wb[N // 3] = Wb[5]                   # identical rows: equal logits -> exact ties
+    W[N - 1] = W[5]; Wb[N - 1] = Wb[5]
+    x[0], xb[0] = h16(W[5] * 8)                            # make that tied logit the row maximum of token 0
+    d_x, d_W = dev(xb), dev(Wb)
+    d_y = nvr.DeviceBuffer(T * N * 4)
+    P = 1024
+    d_pv, d_pi = nvr.DeviceBuffer(P * 32 * 4), nvr.DeviceBuffer(P * 32 * 4)
+    nparts = C.c_int32(0)
+    nvr.check(nvr.lib().nvr_lm_head(d_x.ptr, K, d_W.ptr, T, K, N, d_y.ptr, d_pv.ptr, d_pi.ptr, C.byref(nparts), None))
+    assert 1 <= nparts.value <= P
+    y = d_y.to_numpy((T, N), np.float32)
+    np.testing.assert_allclose(y, oracle.linear(x, W), rtol=2e-5, atol=3e-4)
+    d_tok, d_val = nvr.DeviceBuffer(T * 8), nvr.DeviceBuffer(T * 4)
+    nvr.check(nvr.lib().nvr_argmax_partials(d_pv.ptr, d_pi.ptr, nparts.value, T, d_tok.ptr, d_val.ptr, 1000, None))
+    tok, val = d_tok.to_numpy((T,), np.int64), d_val.to_numpy((T,), np.float32)
+    want = np.asarray([oracle.argmax(y[t]) for t in range(T)])
+    assert (tok - 1000).tolist() == want.tolist()
+    assert np.array_equal(val, y[np.arange(T), want])
+    if N > 16:
+        assert want[0] == 5                                # three-way tie at rows 5, N//3, N-1 -> lowest index
+    # the plain arg-max kernel over the same logits agrees
+    d_t2 = nvr.DeviceBuffer(T * 8)
+    nvr.check(nvr.lib().nvr_argmax(d_y.ptr, T, N, d_t2.ptr, None))
+    assert d_t2.to_numpy((T,), np.int64).tolist() == want.tolist()
+    assert nvr.lib().nvr_lm_head(d_x.ptr, K, d_W.ptr, 33, K, N, d_y.ptr, d_pv.ptr, d_pi.ptr, C.byref(nparts), None) == -10
+
+
 def _gpu_sample(x, temps, top_k, top_p, keys):
     B, V = x.shape
     ws = nvr.DeviceBuffer(nvr.lib().nvr_sample_workspace_bytes(B, V))
