@@ -22,6 +22,7 @@
 // Rounding points mirror the oracle (oracle/model_oracle.py): the f32 accumulator is rounded to fp16
 // where the unfused graph stores an fp16 tensor (qkv, gate_up), then the epilogue math runs in f32
 // without FMA contraction and is rounded again.
+#include <cstdlib>
 #include "kernels.h"
 #include "device_utils.h"
 #include "../common.h"
@@ -310,7 +311,8 @@ int linear(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64
         if (y_f32) launch<NT_, MT_, WV_, EPI_F32>(xx, ldx, ww, t, k, n, y, e, gx, s);               \
         else launch<NT_, MT_, WV_, EPI_F16>(xx, ldx, ww, t, k, n, y, e, gx, s);                     \
     } while (0)
-    if (T <= 16) {
+    static const bool force_mt1 = std::getenv("NVR_LIN_MT1") != nullptr;      // experiment: 16-token workgroups for T > 16
+    if (T <= 16 || (force_mt1 && !wide)) {
         if (wide) NVR_LIN(4, 1, 4);
         else if (wv == 16) NVR_LIN(1, 1, 16);
         else if (wv == 8) NVR_LIN(1, 1, 8);
