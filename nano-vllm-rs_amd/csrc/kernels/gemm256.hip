@@ -1,0 +1,311 @@
+// gemm256.hip — 256x256x64 eight-wave MFMA GEMM for the prefill regime (T >= 256 tokens): y[T,N] = x[T,K]·W[N,K]^T,
+// with the three epilogues of the decode kernels (plain fp16, gate_up -> SiluAndMul, qkv -> RoPE + KV store).
+// reference call sites as in linear.hip (linear.rs:354-356,228-239,437-439; activation.rs:46-63;
+// rotary_embedding.rs:23-48; attention.rs:150-174).  Bound: MFMA (880.8 MFLOP per prefill token).
+//
+// Structure (after cdna_hip_programming.md "The 256² 8-phase template"; the phase choreography below is this
+// file's own and simpler: one barrier per phase, no wave stagger):
+//   * workgroup = 8 waves (2 along n x 4 along m) = 256 W rows (A operand) x 256 tokens (B operand), BK = 64.
+//     Each operand tile is two HALF-TILES of 128 rows (16 KiB: [row][8 chunks of 16 B], chunk' = chunk ^ (row & 7),
+//     conflict-free for the 4 x 16 lane groups of ds_read_b128).  LDS = 2 K-tile buffers x {A0, A1, B0, B1} = 128 KiB.
+//   * a wave owns 64 rows of EACH A half and 32 rows of EACH B half, so its 128 x 64 output splits into four
+//     quadrants (A half, B half) of 16 MFMAs (v_mfma_f32_16x16x32_f16, 4 n-tiles x 2 m-tiles x 2 k-steps) — one
+//     quadrant per PHASE, and each phase needs only the half-tiles named below.
+//   * a K-tile is four phases; every phase = { ds_read the fragments it is missing; global_load_lds ONE half-tile of
+//     the NEXT K-tile (2 x 16 B per thread) into the other buffer; 16 MFMAs; s_waitcnt vmcnt(4); s_barrier }:
+//         phase 0: quadrant (A0,B0)  reads A0 (8 fragments) + B0 (4)   stages A0'
+//         phase 1: quadrant (A0,B1)  reads B1 (4)                      stages B0'
+//         phase 2: quadrant (A1,B1)  reads A1 (8)                      stages B1'
+//         phase 3: quadrant (A1,B0)  reads B0 again (4)                stages A1'
+//     vmcnt(4) leaves the two youngest half-tiles in flight; every half-tile therefore has three phases (~3.5k clocks) to
+//     land before the barrier in front of its first reader (RAW: own loads counted, then the barrier), and it is written
+//     into the buffer whose last reader finished a whole K-tile earlier (WAR).  The loads never drain to 0 in the loop.
+//   * row maps put epilogue partners in ONE lane: SiLU — A0 = gate rows, A1 = up rows of the same 128 columns; RoPE —
+//     A0 = first halves, A1 = second halves of the same heads.
+//   * epilogue: results are staged in LDS (the operand buffers are dead) per 128-token half and written as 16-byte
+//     pieces of contiguous rows.
+#include <cstdlib>
+#include "kernels.h"
+#include "device_utils.h"
+#include "../common.h"
+
+namespace nvr { namespace k {
+
+enum { GEPI_F16 = 0, GEPI_SILU = 2, GEPI_ROPE = 3 };
+
+struct G256Epi {
+    const int64_t *pos; const int32_t *slots; const float *cos_t, *sin_t;
+    half_t *kc, *vc;
+    int32_t H, KVH, D;
+};
+
+constexpr int G_BK = 64, G_HT = 128, G_HALF = G_HT * G_BK * 2;          // 16 KiB per half-tile
+constexpr int G_BUF = 4 * G_HALF;                                         // A0 A1 B0 B1
+
+// W row behind local row rho (0..127) of A half hA of workgroup column bx
+template <int EPI>
+__device__ __forceinline__ int g_w_row(int bx, int hA, int rho, int N, const G256Epi &e) {
+    if (EPI == GEPI_SILU) return hA * N + bx * 128 + rho;                 // N == I; 128 output columns per workgroup
+    if (EPI == GEPI_ROPE) {
+        const int hd2 = e.D / 2, head = bx * (256 / e.D) + rho / hd2, col = rho % hd2;
+        return head * e.D + hA * hd2 + col;
+    }
+    return bx * 256 + hA * 128 + rho;
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm256_kernel(const half_t *__restrict__ x, int64_t ldx, const half_t *__restrict__ W,
+                                                      int T, int K, int N, int NW, half_t *__restrict__ y, G256Epi epi) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];           // 2 x G_BUF
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int r = lane & 15, q = lane >> 4;
+    const int wn = wave >> 2, wm = wave & 3;
+    const int m0 = blockIdx.y * 256;
+
+    // staging sources: thread copies pieces idx = i*512 + tid (i = 0,1) of each half-tile: row = idx/8, LDS slot idx%8
+    const half_t *asrc[2][2], *bsrc[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = i * 512 + tid, row = idx >> 3, c = (idx & 7) ^ (row & 7);
+            int wr = g_w_row<EPI>(blockIdx.x, h, row, N, epi);
+            if (wr > NW - 1) wr = NW - 1;
+            int xr = m0 + h * 128 + row; if (xr > T - 1) xr = T - 1;
+            asrc[h][i] = W + (int64_t)wr * K + c * 8;
+            bsrc[h][i] = x + (int64_t)xr * ldx + c * 8;
+        }
+    // half-tile ids: 0 = A0, 1 = A1, 2 = B0, 3 = B1
+    auto stage = [&](int ht, int kt) {
+        char *dst = smem + (kt & 1) * G_BUF + ht * G_HALF;
+        const int k0 = kt * G_BK;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const half_t *src = (ht < 2 ? asrc[ht & 1][i] : bsrc[ht & 1][i]) + k0;
+            __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void *)(dst + (i * 512 + wave * 64) * 16), 16, 0, 0);
+        }
+    };
+
+    float4_t acc[2][4][2][2];                                             // [A half][n-tile][B half][m-tile]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[a][i][b][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
+
+    half8_t af[4][2], bf[2][2];                                           // [tile][k-step]
+    auto read_a = [&](const char *buf, int hA) {
+        const char *base = buf + hA * G_HALF;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = wn * 64 + i * 16 + r;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                af[i][ks] = *reinterpret_cast<const half8_t *>(base + (row * 8 + ((ks * 4 + q) ^ (row & 7))) * 16);
+        }
+    };
+    auto read_b = [&](const char *buf, int hB) {
+        const char *base = buf + (2 + hB) * G_HALF;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int row = wm * 32 + j * 16 + r;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                bf[j][ks] = *reinterpret_cast<const half8_t *>(base + (row * 8 + ((ks * 4 + q) ^ (row & 7))) * 16);
+        }
+    };
+    auto mma = [&](float4_t (&c)[4][2][2], int hB) {                      // c = acc[hA]
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    c[i][hB][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][ks], bf[j][ks], c[i][hB][j], 0, 0, 0);
+    };
+
+    const int KT = K / G_BK;
+    stage(0, 0); stage(2, 0); stage(3, 0); stage(1, 0);                    // A0, B0, B1, A1 of K-tile 0
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+#define G256_PHASE_END(N_)                                                                                            \
+    asm volatile("s_waitcnt vmcnt(" #N_ ")" ::: "memory");                                                            \
+    __builtin_amdgcn_s_barrier();
+
+    for (int kt = 0; kt < KT; ++kt) {
+        const char *buf = smem + (kt & 1) * G_BUF;
+        const bool more = kt + 1 < KT;
+        // phase 0: (A0, B0)
+        read_b(buf, 0); read_a(buf, 0);
+        if (more) stage(0, kt + 1);
+        mma(acc[0], 0);
+        if (more) { G256_PHASE_END(4) } else { G256_PHASE_END(2) }
+        // phase 1: (A0, B1)
+        read_b(buf, 1);
+        if (more) stage(2, kt + 1);
+        mma(acc[0], 1);
+        if (more) { G256_PHASE_END(4) } else { G256_PHASE_END(0) }
+        // phase 2: (A1, B1)
+        read_a(buf, 1);
+        if (more) stage(3, kt + 1);
+        mma(acc[1], 1);
+        if (more) { G256_PHASE_END(4) } else { G256_PHASE_END(0) }
+        // phase 3: (A1, B0)
+        read_b(buf, 0);
+        if (more) stage(1, kt + 1);
+        mma(acc[1], 0);
+        if (more) { G256_PHASE_END(4) } else { G256_PHASE_END(0) }
+    }
+#undef G256_PHASE_END
+
+    // ---- epilogue: per 128-token half hB, stage [token][column] in LDS, then 16-byte row pieces -----------------------
+    constexpr int OUTC = (EPI == GEPI_SILU) ? 128 : 256;                  // output columns of this workgroup
+    constexpr int OST = OUTC * 2 + 16;                                    // staged row stride (bytes)
+    const int64_t ldy = (EPI == GEPI_ROPE) ? (int64_t)(epi.H + 2 * epi.KVH) * epi.D : (int64_t)N;
+    const int hd2 = (EPI == GEPI_ROPE) ? epi.D / 2 : 1;
+#pragma unroll
+    for (int hB = 0; hB < 2; ++hB) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int ml = wm * 32 + j * 16 + r;                          // token row inside the half
+            const int m = m0 + hB * 128 + ml, mc = m < T ? m : T - 1;
+            char *orow = smem + ml * OST;
+            if (EPI == GEPI_F16) {
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float4_t v = acc[a][i][hB][j];
+                        const half4_t h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+                        *reinterpret_cast<half4_t *>(orow + (a * 128 + wn * 64 + i * 16 + q * 4) * 2) = h;
+                    }
+            } else if (EPI == GEPI_SILU) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    half4_t h;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float gf = (float)to_half_rn(acc[0][i][hB][j][e]), uf = (float)to_half_rn(acc[1][i][hB][j][e]);
+                        const float sg = 1.0f / (1.0f + __expf(-gf));
+                        h[e] = to_half_rn(__fmul_rn(__fmul_rn(gf, sg), uf));
+                    }
+                    *reinterpret_cast<half4_t *>(orow + (wn * 64 + i * 16 + q * 4) * 2) = h;
+                }
+            } else {                                                      // GEPI_ROPE
+                const int64_t p = epi.pos[mc];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int rho = wn * 64 + i * 16 + q * 4;             // local row of both halves
+                    const int hl = rho / hd2, col = rho % hd2;            // head inside the tile, column inside the half head
+                    const int head = blockIdx.x * (256 / epi.D) + hl;
+                    half4_t h0, h1;
+                    if (head < epi.H + epi.KVH) {
+                        const float4_t cs = *reinterpret_cast<const float4_t *>(epi.cos_t + p * hd2 + col);
+                        const float4_t sn = *reinterpret_cast<const float4_t *>(epi.sin_t + p * hd2 + col);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float x1 = (float)to_half_rn(acc[0][i][hB][j][e]), x2 = (float)to_half_rn(acc[1][i][hB][j][e]);
+                            h0[e] = to_half_rn(__fsub_rn(__fmul_rn(x1, cs[e]), __fmul_rn(x2, sn[e])));
+                            h1[e] = to_half_rn(__fadd_rn(__fmul_rn(x2, cs[e]), __fmul_rn(x1, sn[e])));
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { h0[e] = to_half_rn(acc[0][i][hB][j][e]); h1[e] = to_half_rn(acc[1][i][hB][j][e]); }
+                    }
+                    *reinterpret_cast<half4_t *>(orow + (hl * epi.D + col) * 2) = h0;
+                    *reinterpret_cast<half4_t *>(orow + (hl * epi.D + hd2 + col) * 2) = h1;
+                }
+            }
+        }
+        __syncthreads();
+        constexpr int CPR = OUTC / 8;                                     // 16-byte pieces per row
+        for (int pidx = tid; pidx < 128 * CPR; pidx += 512) {
+            const int row = pidx / CPR, ch = pidx % CPR;
+            const int m = m0 + hB * 128 + row, col = blockIdx.x * OUTC + ch * 8;
+            if (m >= T || col >= ldy) continue;
+            const half8_t v8 = *reinterpret_cast<const half8_t *>(smem + row * OST + ch * 16);
+            *reinterpret_cast<half8_t *>(y + (int64_t)m * ldy + col) = v8;
+            if (EPI == GEPI_ROPE) {
+                const int head = col / epi.D;
+                if (head >= epi.H) {
+                    const int slot = epi.slots ? epi.slots[m] : -1;
+                    if (slot >= 0) {
+                        const bool is_k = head < epi.H + epi.KVH;
+                        const int kvh = is_k ? head - epi.H : head - epi.H - epi.KVH;
+                        *reinterpret_cast<half8_t *>((is_k ? epi.kc : epi.vc) + ((int64_t)slot * epi.KVH + kvh) * epi.D + (col - head * epi.D)) = v8;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+static int g256_prepare() {                                               // 128 KiB of dynamic LDS: opt-in once
+    static bool done = false;
+    if (done) return 0;
+    const void *fns[] = {reinterpret_cast<const void *>(&gemm256_kernel<GEPI_F16>), reinterpret_cast<const void *>(&gemm256_kernel<GEPI_SILU>),
+                         reinterpret_cast<const void *>(&gemm256_kernel<GEPI_ROPE>)};
+    for (const void *f : fns) {
+        hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G_BUF + 4096);
+        if (e != hipSuccess) return nvr::fail(NVR_ERR_HIP, "gemm256: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    }
+    done = true;
+    return 0;
+}
+static int g256_check(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return nvr::fail(NVR_ERR_HIP, "%s launch failed: %s", what, hipGetErrorString(e));
+    return 0;
+}
+static bool g256_enabled() {
+    static const bool on = !(std::getenv("NVR_GEMM256") && std::getenv("NVR_GEMM256")[0] == '0');
+    return on;
+}
+
+bool gemm256_ok(int64_t T, int64_t K, int64_t N, int64_t ldx) {
+    return g256_enabled() && T >= 256 && K % G_BK == 0 && K >= 2 * G_BK && N % 256 == 0 && ldx % 8 == 0;
+}
+bool gemm256_silu_ok(int64_t T, int64_t K, int64_t I, int64_t ldx) {
+    return g256_enabled() && T >= 256 && K % G_BK == 0 && K >= 2 * G_BK && I % 128 == 0 && ldx % 8 == 0;
+}
+bool gemm256_rope_ok(int64_t T, int64_t K, int64_t H, int64_t KVH, int64_t D, int64_t ldx) {
+    return g256_enabled() && T >= 256 && K % G_BK == 0 && K >= 2 * G_BK && (D == 128 || D == 64) && ((H + 2 * KVH) * D) % 256 == 0 && ldx % 8 == 0;
+}
+
+int gemm256(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t N, half_bits *y, hipStream_t s) {
+    if (!gemm256_ok(T, K, N, ldx)) return nvr::fail(NVR_ERR_UNSUPPORTED, "gemm256: T=%ld K=%ld N=%ld", (long)T, (long)K, (long)N);
+    if (int rc = g256_prepare()) return rc;
+    dim3 grid((unsigned)(N / 256), (unsigned)((T + 255) / 256));
+    gemm256_kernel<GEPI_F16><<<grid, dim3(512), 2 * G_BUF, s>>>((const half_t *)x, ldx, (const half_t *)W, (int)T, (int)K, (int)N, (int)N,
+                                                               (half_t *)y, G256Epi{});
+    return g256_check("gemm256");
+}
+int gemm256_silu_mul(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t I, half_bits *out, hipStream_t s) {
+    if (!gemm256_silu_ok(T, K, I, ldx)) return nvr::fail(NVR_ERR_UNSUPPORTED, "gemm256_silu_mul: T=%ld K=%ld I=%ld", (long)T, (long)K, (long)I);
+    if (int rc = g256_prepare()) return rc;
+    dim3 grid((unsigned)(I / 128), (unsigned)((T + 255) / 256));
+    gemm256_kernel<GEPI_SILU><<<grid, dim3(512), 2 * G_BUF, s>>>((const half_t *)x, ldx, (const half_t *)W, (int)T, (int)K, (int)I, (int)(2 * I),
+                                                                (half_t *)out, G256Epi{});
+    return g256_check("gemm256_silu_mul");
+}
+int gemm256_qkv_rope_store(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t H, int64_t KVH, int64_t D,
+                           const int64_t *positions, const int32_t *slots, const float *cos_t, const float *sin_t, half_bits *qkv,
+                           half_bits *k_cache, half_bits *v_cache, hipStream_t s) {
+    if (!gemm256_rope_ok(T, K, H, KVH, D, ldx)) return nvr::fail(NVR_ERR_UNSUPPORTED, "gemm256_qkv_rope_store: T=%ld K=%ld D=%ld", (long)T, (long)K, (long)D);
+    if (int rc = g256_prepare()) return rc;
+    const int64_t N = (H + 2 * KVH) * D;
+    G256Epi e{};
+    e.pos = positions; e.slots = slots; e.cos_t = cos_t; e.sin_t = sin_t; e.kc = (half_t *)k_cache; e.vc = (half_t *)v_cache;
+    e.H = (int32_t)H; e.KVH = (int32_t)KVH; e.D = (int32_t)D;
+    dim3 grid((unsigned)(N / 256), (unsigned)((T + 255) / 256));
+    gemm256_kernel<GEPI_ROPE><<<grid, dim3(512), 2 * G_BUF, s>>>((const half_t *)x, ldx, (const half_t *)W, (int)T, (int)K, (int)N, (int)N,
+                                                                (half_t *)qkv, e);
+    return g256_check("gemm256_qkv_rope_store");
+}
+
+}}  // namespace nvr::k

@@ -66,6 +66,17 @@ int gemm_tiled_qkv_rope_store(const half_bits *x, int64_t ldx, const half_bits *
                               int64_t D, const int64_t *positions, const int32_t *slots, const float *cos_t, const float *sin_t,
                               half_bits *qkv, half_bits *k_cache, half_bits *v_cache, hipStream_t s);
 
+// 256x256x64 eight-wave MFMA GEMM (T >= 256, N % 256 == 0 / I % 128 == 0 / whole heads per 256 rows): same results
+// layout and epilogues; preferred over gemm_tiled when its shape test passes
+bool gemm256_ok(int64_t T, int64_t K, int64_t N, int64_t ldx);
+bool gemm256_silu_ok(int64_t T, int64_t K, int64_t I, int64_t ldx);
+bool gemm256_rope_ok(int64_t T, int64_t K, int64_t H, int64_t KVH, int64_t D, int64_t ldx);
+int gemm256(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t N, half_bits *y, hipStream_t s);
+int gemm256_silu_mul(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t I, half_bits *out, hipStream_t s);
+int gemm256_qkv_rope_store(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t H, int64_t KVH, int64_t D,
+                           const int64_t *positions, const int32_t *slots, const float *cos_t, const float *sin_t, half_bits *qkv,
+                           half_bits *k_cache, half_bits *v_cache, hipStream_t s);
+
 // Attention over rows of keys addressed either through a block table (paged) or contiguously.
 struct AttnArgs {
     const half_bits *q; int64_t ldq;          // q[t] at q + t*ldq, heads contiguous [H, D]

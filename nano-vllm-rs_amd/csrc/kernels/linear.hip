@@ -296,7 +296,8 @@ int linear(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64
         return nvr::fail(NVR_ERR_UNSUPPORTED, "linear: K=%ld must be a multiple of 32, N=%ld of 16, ldx=%ld of 8",
                          (long)K, (long)N, (long)ldx);
     if (T == 0) return 0;
-    if (!y_f32 && gemm_tiled_ok(T, K, N, ldx)) return gemm_tiled(x, ldx, W, T, K, N, (half_bits *)y, s);   // prefill regime
+    if (!y_f32 && gemm256_ok(T, K, N, ldx)) return gemm256(x, ldx, W, T, K, N, (half_bits *)y, s);          // prefill regime
+    if (!y_f32 && gemm_tiled_ok(T, K, N, ldx)) return gemm_tiled(x, ldx, W, T, K, N, (half_bits *)y, s);
     const half_t *xx = (const half_t *)x, *ww = (const half_t *)W;
     const int t = (int)T, k = (int)K, n = (int)N;
     const LinEpi e{};
@@ -365,6 +366,7 @@ int linear_silu_mul(const half_bits *x, int64_t ldx, const half_bits *W, int64_t
     if (K % 32 || I % 16 || ldx % 8)
         return nvr::fail(NVR_ERR_UNSUPPORTED, "linear_silu_mul: K=%ld must be a multiple of 32, I=%ld of 16", (long)K, (long)I);
     if (T == 0) return 0;
+    if (gemm256_silu_ok(T, K, I, ldx)) return gemm256_silu_mul(x, ldx, W, T, K, I, out, s);
     if (gemm_tiled_ok(T, K, I, ldx) && I % 64 == 0) return gemm_tiled_silu_mul(x, ldx, W, T, K, I, out, s);
     const half_t *xx = (const half_t *)x, *ww = (const half_t *)W;
     const LinEpi e{};
@@ -387,6 +389,8 @@ int linear_qkv_rope_store(const half_bits *x, int64_t ldx, const half_bits *W, i
     if (K % 32 || D % 16 || ldx % 8)
         return nvr::fail(NVR_ERR_UNSUPPORTED, "linear_qkv_rope_store: K=%ld must be a multiple of 32, D=%ld of 16", (long)K, (long)D);
     if (T == 0) return 0;
+    if (gemm256_rope_ok(T, K, H, KVH, D, ldx))
+        return gemm256_qkv_rope_store(x, ldx, W, T, K, H, KVH, D, positions, slots, cos_t, sin_t, qkv, k_cache, v_cache, s);
     if (gemm_tiled_ok(T, K, (H + 2 * KVH) * D, ldx) && 128 % D == 0)
         return gemm_tiled_qkv_rope_store(x, ldx, W, T, K, H, KVH, D, positions, slots, cos_t, sin_t, qkv, k_cache, v_cache, s);
     const half_t *xx = (const half_t *)x, *ww = (const half_t *)W;
