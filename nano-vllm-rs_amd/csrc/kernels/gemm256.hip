@@ -3,16 +3,16 @@
 // reference call sites as in linear.hip (linear.rs:354-356,228-239,437-439; activation.rs:46-63;
 // rotary_embedding.rs:23-48; attention.rs:150-174).  Bound: MFMA (880.8 MFLOP per prefill token).
 //
-// Structure (after cdna_hip_programming.md "The 256² 8-phase template"; the phase choreography below is this
-// file's own and simpler: one barrier per phase, no wave stagger):
+// Structure (after cdna_hip_programming.md "The 256² 8-phase template"; the half-tile / phase assignment is this file's):
 //   * workgroup = 8 waves (2 along n x 4 along m) = 256 W rows (A operand) x 256 tokens (B operand), BK = 64.
 //     Each operand tile is two HALF-TILES of 128 rows (16 KiB: [row][8 chunks of 16 B], chunk' = chunk ^ (row & 7),
 //     conflict-free for the 4 x 16 lane groups of ds_read_b128).  LDS = 2 K-tile buffers x {A0, A1, B0, B1} = 128 KiB.
 //   * a wave owns 64 rows of EACH A half and 32 rows of EACH B half, so its 128 x 64 output splits into four
 //     quadrants (A half, B half) of 16 MFMAs (v_mfma_f32_16x16x32_f16, 4 n-tiles x 2 m-tiles x 2 k-steps) — one
 //     quadrant per PHASE, and each phase needs only the half-tiles named below.
-//   * a K-tile is four phases; every phase = { ds_read the fragments it is missing; global_load_lds ONE half-tile of
-//     the NEXT K-tile (2 x 16 B per thread) into the other buffer; 16 MFMAs; s_waitcnt vmcnt(4); s_barrier }:
+//   * a K-tile is four phases; every phase = R { ds_read the fragments it is missing; global_load_lds ONE half-tile of
+//     the NEXT K-tile (2 x 16 B per thread) into the other buffer; s_waitcnt vmcnt(4); s_barrier } + M { 16 MFMAs;
+//     s_barrier }, the two wave groups one barrier interval apart (reads of one overlap MFMAs of the other):
 //         phase 0: quadrant (A0,B0)  reads A0 (8 fragments) + B0 (4)   stages A0'
 //         phase 1: quadrant (A0,B1)  reads B1 (4)                      stages B0'
 //         phase 2: quadrant (A1,B1)  reads A1 (8)                      stages B1'
@@ -127,13 +127,27 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const half_t *__restrict__
                     c[i][hB][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][ks], bf[j][ks], c[i][hB][j], 0, 0, 0);
     };
 
+    // The two wave groups (waves 0-3 and 4-7: one wave of each per SIMD) run ONE barrier interval apart, and a phase is
+    // two intervals — R {ds_read, stage, s_waitcnt vmcnt, barrier} and M {16 MFMAs, barrier} — so that on every SIMD the
+    // fragment reads of one wave overlap the MFMAs of the other.  Group 1 takes one extra barrier before the loop, group
+    // 0 one after it.  Hazards with the stagger: a half-tile staged in phase p is first read in phase p+3; every wave
+    // counts its own loads at the end of R(p+2) (vmcnt(4): all but the two youngest half-tiles), i.e. group 0 in
+    // interval 2p+4 and group 1 in 2p+5, and the earliest reader (group 0, R(p+3)) runs in interval 2p+6.  A buffer is
+    // restaged no earlier than two phases after its last ds_read by either group.
+    const int grp = __builtin_amdgcn_readfirstlane(wave >> 2);
     const int KT = K / G_BK;
     stage(0, 0); stage(2, 0); stage(3, 0); stage(1, 0);                    // A0, B0, B1, A1 of K-tile 0
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();
 
-#define G256_PHASE_END(N_)                                                                                            \
+#define G256_R_END(N_)                                                                                                \
     asm volatile("s_waitcnt vmcnt(" #N_ ")" ::: "memory");                                                            \
+    __builtin_amdgcn_s_barrier();
+#define G256_M(C_, HB_)                                                                                               \
+    __builtin_amdgcn_s_setprio(1);                                                                                    \
+    mma(C_, HB_);                                                                                                     \
+    __builtin_amdgcn_s_setprio(0);                                                                                    \
     __builtin_amdgcn_s_barrier();
 
     for (int kt = 0; kt < KT; ++kt) {
@@ -141,26 +155,24 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const half_t *__restrict__
         const bool more = kt + 1 < KT;
         // phase 0: (A0, B0)
         read_b(buf, 0); read_a(buf, 0);
-        if (more) stage(0, kt + 1);
-        mma(acc[0], 0);
-        if (more) { G256_PHASE_END(4) } else { G256_PHASE_END(2) }
+        if (more) { stage(0, kt + 1); G256_R_END(4) } else { G256_R_END(2) }
+        G256_M(acc[0], 0)
         // phase 1: (A0, B1)
         read_b(buf, 1);
-        if (more) stage(2, kt + 1);
-        mma(acc[0], 1);
-        if (more) { G256_PHASE_END(4) } else { G256_PHASE_END(0) }
+        if (more) { stage(2, kt + 1); G256_R_END(4) } else { G256_R_END(0) }
+        G256_M(acc[0], 1)
         // phase 2: (A1, B1)
         read_a(buf, 1);
-        if (more) stage(3, kt + 1);
-        mma(acc[1], 1);
-        if (more) { G256_PHASE_END(4) } else { G256_PHASE_END(0) }
+        if (more) { stage(3, kt + 1); G256_R_END(4) } else { G256_R_END(0) }
+        G256_M(acc[1], 1)
         // phase 3: (A1, B0)
         read_b(buf, 0);
-        if (more) stage(1, kt + 1);
-        mma(acc[1], 0);
-        if (more) { G256_PHASE_END(4) } else { G256_PHASE_END(0) }
+        if (more) { stage(1, kt + 1); G256_R_END(4) } else { G256_R_END(0) }
+        G256_M(acc[1], 0)
     }
-#undef G256_PHASE_END
+#undef G256_R_END
+#undef G256_M
+    if (grp == 0) __builtin_amdgcn_s_barrier();
 
     // ---- epilogue: per 128-token half hB, stage [token][column] in LDS, then 16-byte row pieces -----------------------
     constexpr int OUTC = (EPI == GEPI_SILU) ? 128 : 256;                  // output columns of this workgroup
