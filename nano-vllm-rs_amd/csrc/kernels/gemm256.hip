@@ -55,29 +55,51 @@ __device__ __forceinline__ int g_w_row(int bx, int hA, int rho, int N, const G25
 
 template <int EPI>
 __global__ __launch_bounds__(512) void gemm256_kernel(const half_t *__restrict__ x, int64_t ldx, const half_t *__restrict__ W,
-                                                      int T, int K, int N, int NW, half_t *__restrict__ y, G256Epi epi) {
+                                                      int T, int K, int N, int NW, half_t *__restrict__ y, G256Epi epi,
+                                                      int tiles_x, int tiles_y, int CG) {
     extern __shared__ __attribute__((aligned(16))) char smem[];           // 2 x G_BUF
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int r = lane & 15, q = lane >> 4;
     const int wn = wave >> 2, wm = wave & 3;
-    const int m0 = blockIdx.y * 256;
+    const int grp = __builtin_amdgcn_readfirstlane(wave >> 2);
 
+    // Persistent workgroup.  The K-tile stream runs ACROSS its tiles: K-tile g of the stream lives in buffer g & 1, and the
+    // last K-tile of a tile already stages K-tile 0 of the next tile, so those loads fly during the epilogue.
+    // Tile order is XCD-aware (workgroup w runs on XCD w % 8, each XCD has its own 4 MiB L2): the 8 XCDs form CG column
+    // groups x 8/CG row groups; an XCD owns the columns of its group (its W slice stays L2-resident) and every
+    // (8/CG)-th row block, and its workgroups walk that set column-fastest, so the workgroups that share an x row block
+    // run on ONE XCD at the same time: x is fetched from HBM CG times instead of once per XCD that happens to see it.
+    const int tiles_total = tiles_x * tiles_y;
+    int xcd_step = 0, u = 0, nbx = 0, bx0 = 0, rg = 0, RG = 1, n_u = 0;
+    if (CG > 0) {
+        const int c = blockIdx.x & 7;
+        RG = 8 / CG; nbx = tiles_x / CG; bx0 = (c % CG) * nbx; rg = c / CG;
+        n_u = nbx * ((tiles_y - rg + RG - 1) / RG);                       // tiles of this XCD
+        u = blockIdx.x >> 3; xcd_step = gridDim.x >> 3;
+    }
+    auto tile_of = [&](int uu) { return CG > 0 ? (rg + RG * (uu / nbx)) * tiles_x + bx0 + uu % nbx : uu; };
+    auto have = [&](int uu) { return CG > 0 ? uu < n_u : uu < tiles_total; };
+    if (CG <= 0) { u = blockIdx.x; xcd_step = gridDim.x; }
+    if (!have(u)) return;
     // staging sources: thread copies pieces idx = i*512 + tid (i = 0,1) of each half-tile: row = idx/8, LDS slot idx%8
     const half_t *asrc[2][2], *bsrc[2][2];
+    auto set_sources = [&](int tile) {
+        const int bx = tile % tiles_x, m0 = (tile / tiles_x) * 256;
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
+        for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int idx = i * 512 + tid, row = idx >> 3, c = (idx & 7) ^ (row & 7);
-            int wr = g_w_row<EPI>(blockIdx.x, h, row, N, epi);
-            if (wr > NW - 1) wr = NW - 1;
-            int xr = m0 + h * 128 + row; if (xr > T - 1) xr = T - 1;
-            asrc[h][i] = W + (int64_t)wr * K + c * 8;
-            bsrc[h][i] = x + (int64_t)xr * ldx + c * 8;
-        }
-    // half-tile ids: 0 = A0, 1 = A1, 2 = B0, 3 = B1
-    auto stage = [&](int ht, int kt) {
-        char *dst = smem + (kt & 1) * G_BUF + ht * G_HALF;
+            for (int i = 0; i < 2; ++i) {
+                const int idx = i * 512 + tid, row = idx >> 3, c = (idx & 7) ^ (row & 7);
+                int wr = g_w_row<EPI>(bx, h, row, N, epi);
+                if (wr > NW - 1) wr = NW - 1;
+                int xr = m0 + h * 128 + row; if (xr > T - 1) xr = T - 1;
+                asrc[h][i] = W + (int64_t)wr * K + c * 8;
+                bsrc[h][i] = x + (int64_t)xr * ldx + c * 8;
+            }
+    };
+    // half-tile ids: 0 = A0, 1 = A1, 2 = B0, 3 = B1; kt = K-tile index inside the (current or next) tile, g = stream index
+    auto stage = [&](int ht, int kt, int g) {
+        char *dst = smem + (g & 1) * G_BUF + ht * G_HALF;
         const int k0 = kt * G_BK;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -87,15 +109,6 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const half_t *__restrict__
     };
 
     float4_t acc[2][4][2][2];                                             // [A half][n-tile][B half][m-tile]
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int b = 0; b < 2; ++b)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[a][i][b][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
-
     half8_t af[4][2], bf[2][2];                                           // [tile][k-step]
     auto read_a = [&](const char *buf, int hA) {
         const char *base = buf + hA * G_HALF;
@@ -129,17 +142,18 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const half_t *__restrict__
 
     // The two wave groups (waves 0-3 and 4-7: one wave of each per SIMD) run ONE barrier interval apart, and a phase is
     // two intervals — R {ds_read, stage, s_waitcnt vmcnt, barrier} and M {16 MFMAs, barrier} — so that on every SIMD the
-    // fragment reads of one wave overlap the MFMAs of the other.  Group 1 takes one extra barrier before the loop, group
-    // 0 one after it.  Hazards with the stagger: a half-tile staged in phase p is first read in phase p+3; every wave
-    // counts its own loads at the end of R(p+2) (vmcnt(4): all but the two youngest half-tiles), i.e. group 0 in
-    // interval 2p+4 and group 1 in 2p+5, and the earliest reader (group 0, R(p+3)) runs in interval 2p+6.  A buffer is
-    // restaged no earlier than two phases after its last ds_read by either group.
-    const int grp = __builtin_amdgcn_readfirstlane(wave >> 2);
+    // fragment reads of one wave overlap the MFMAs of the other.  Group 1 takes one extra barrier before each tile's
+    // K loop, group 0 one after it.  Hazards with the stagger: a half-tile staged in phase p is first read in phase p+3;
+    // every wave counts its own loads at the end of R(p+2) (vmcnt(4): all but the two youngest half-tiles; the
+    // epilogue's stores count too, which only makes the wait stricter), i.e. group 0 in interval 2p+4 and group 1 in
+    // 2p+5, and the earliest reader (group 0, R(p+3)) runs in interval 2p+6.  A buffer is restaged no earlier than two
+    // phases after its last ds_read by either group.
     const int KT = K / G_BK;
-    stage(0, 0); stage(2, 0); stage(3, 0); stage(1, 0);                    // A0, B0, B1, A1 of K-tile 0
+    int tile = tile_of(u);
+    set_sources(tile);
+    stage(0, 0, 0); stage(2, 0, 0); stage(3, 0, 0); stage(1, 0, 0);       // A0, B0, B1, A1 of the first K-tile
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (grp == 1) __builtin_amdgcn_s_barrier();
 
 #define G256_R_END(N_)                                                                                                \
     asm volatile("s_waitcnt vmcnt(" #N_ ")" ::: "memory");                                                            \
@@ -150,111 +164,153 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const half_t *__restrict__
     __builtin_amdgcn_s_setprio(0);                                                                                    \
     __builtin_amdgcn_s_barrier();
 
-    for (int kt = 0; kt < KT; ++kt) {
-        const char *buf = smem + (kt & 1) * G_BUF;
-        const bool more = kt + 1 < KT;
-        // phase 0: (A0, B0)
-        read_b(buf, 0); read_a(buf, 0);
-        if (more) { stage(0, kt + 1); G256_R_END(4) } else { G256_R_END(2) }
-        G256_M(acc[0], 0)
-        // phase 1: (A0, B1)
-        read_b(buf, 1);
-        if (more) { stage(2, kt + 1); G256_R_END(4) } else { G256_R_END(0) }
-        G256_M(acc[0], 1)
-        // phase 2: (A1, B1)
-        read_a(buf, 1);
-        if (more) { stage(3, kt + 1); G256_R_END(4) } else { G256_R_END(0) }
-        G256_M(acc[1], 1)
-        // phase 3: (A1, B0)
-        read_b(buf, 0);
-        if (more) { stage(1, kt + 1); G256_R_END(4) } else { G256_R_END(0) }
-        G256_M(acc[1], 0)
+    constexpr int OUTC = (EPI == GEPI_SILU) ? 128 : 256;                  // output columns of a tile
+    const int64_t ldy = (EPI == GEPI_ROPE) ? (int64_t)(epi.H + 2 * epi.KVH) * epi.D : (int64_t)N;
+    const int hd2 = (EPI == GEPI_ROPE) ? epi.D / 2 : 1;
+
+    for (int g = 0;; ) {
+        if (grp == 1) __builtin_amdgcn_s_barrier();                       // stagger
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[a][i][b][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
+        const bool have_next = have(u + xcd_step);
+        const int next_tile = have_next ? tile_of(u + xcd_step) : 0;
+        for (int kt = 0; kt < KT; ++kt, ++g) {
+            const char *buf = smem + (g & 1) * G_BUF;
+            const bool last = kt == KT - 1;
+            const bool more = !last || have_next;
+            if (last && more) set_sources(next_tile);                     // from here on the staging feeds the next tile
+            const int skt = last ? 0 : kt + 1;
+            // phase 0: (A0, B0)
+            read_b(buf, 0); read_a(buf, 0);
+            if (more) { stage(0, skt, g + 1); G256_R_END(4) } else { G256_R_END(2) }
+            G256_M(acc[0], 0)
+            // phase 1: (A0, B1)
+            read_b(buf, 1);
+            if (more) { stage(2, skt, g + 1); G256_R_END(4) } else { G256_R_END(0) }
+            G256_M(acc[0], 1)
+            // phase 2: (A1, B1)
+            read_a(buf, 1);
+            if (more) { stage(3, skt, g + 1); G256_R_END(4) } else { G256_R_END(0) }
+            G256_M(acc[1], 1)
+            // phase 3: (A1, B0)
+            read_b(buf, 0);
+            if (more) { stage(1, skt, g + 1); G256_R_END(4) } else { G256_R_END(0) }
+            G256_M(acc[1], 0)
+        }
+        if (grp == 0) __builtin_amdgcn_s_barrier();                       // re-align the groups
+
+        // ---- epilogue of `tile`: the buffer of the K-tile just consumed is dead: per 128-token half hB, stage
+        // [token][column] there (16-byte chunks XOR-swizzled by the row) and write 16-byte pieces of contiguous rows,
+        // while the next tile's first K-tile lands in the other buffer.
+        char *scratch = smem + ((g - 1) & 1) * G_BUF;
+        const int bx = tile % tiles_x, m0 = (tile / tiles_x) * 256;
+        auto put = [&](int ml, int col, half4_t h) {                      // 4 consecutive columns (col % 4 == 0) of token row ml
+            *reinterpret_cast<half4_t *>(scratch + ml * (OUTC * 2) + ((((col >> 3) ^ (ml & 15)) << 4) | ((col & 4) << 1))) = h;
+        };
+        // RoPE: positions of this lane's 4 token rows and the cache slots of the 16 rows this thread writes out, requested
+        // up front (a dependent slot load in front of every cache store costs an L2 round trip per 16-byte piece)
+        int64_t posv[2][2]; int slotv[2][8];
+        if (EPI == GEPI_ROPE) {
+#pragma unroll
+            for (int hB = 0; hB < 2; ++hB) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int m = m0 + hB * 128 + wm * 32 + j * 16 + r;
+                    posv[hB][j] = epi.pos[m < T ? m : T - 1];
+                }
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) {
+                    const int m = m0 + hB * 128 + (tid >> 5) + kk * 16;
+                    slotv[hB][kk] = (epi.slots && m < T) ? epi.slots[m] : -1;
+                }
+            }
+        }
+#pragma unroll
+        for (int hB = 0; hB < 2; ++hB) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int ml = wm * 32 + j * 16 + r;                      // token row inside the half
+                if (EPI == GEPI_F16) {
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const float4_t v = acc[a][i][hB][j];
+                            put(ml, a * 128 + wn * 64 + i * 16 + q * 4, (half4_t){(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]});
+                        }
+                } else if (EPI == GEPI_SILU) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        half4_t h;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float gf = (float)to_half_rn(acc[0][i][hB][j][e]), uf = (float)to_half_rn(acc[1][i][hB][j][e]);
+                            const float sg = 1.0f / (1.0f + __expf(-gf));
+                            h[e] = to_half_rn(__fmul_rn(__fmul_rn(gf, sg), uf));
+                        }
+                        put(ml, wn * 64 + i * 16 + q * 4, h);
+                    }
+                } else {                                                  // GEPI_ROPE
+                    const int64_t p = posv[hB][j];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int rho = wn * 64 + i * 16 + q * 4;         // local row of both halves
+                        const int hl = rho / hd2, col = rho % hd2;        // head inside the tile, column inside the half head
+                        const int head = bx * (256 / epi.D) + hl;
+                        half4_t h0, h1;
+                        if (head < epi.H + epi.KVH) {
+                            const float4_t cs = *reinterpret_cast<const float4_t *>(epi.cos_t + p * hd2 + col);
+                            const float4_t sn = *reinterpret_cast<const float4_t *>(epi.sin_t + p * hd2 + col);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float x1 = (float)to_half_rn(acc[0][i][hB][j][e]), x2 = (float)to_half_rn(acc[1][i][hB][j][e]);
+                                h0[e] = to_half_rn(__fsub_rn(__fmul_rn(x1, cs[e]), __fmul_rn(x2, sn[e])));
+                                h1[e] = to_half_rn(__fadd_rn(__fmul_rn(x2, cs[e]), __fmul_rn(x1, sn[e])));
+                            }
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { h0[e] = to_half_rn(acc[0][i][hB][j][e]); h1[e] = to_half_rn(acc[1][i][hB][j][e]); }
+                        }
+                        put(ml, hl * epi.D + col, h0);
+                        put(ml, hl * epi.D + hd2 + col, h1);
+                    }
+                }
+            }
+            __syncthreads();
+            constexpr int CPR = OUTC / 8;                                 // 16-byte pieces per row
+#pragma unroll
+            for (int kk = 0; kk < (128 * CPR) / 512; ++kk) {
+                const int pidx = tid + kk * 512;
+                const int row = pidx / CPR, ch = pidx % CPR;
+                const int m = m0 + hB * 128 + row, col = bx * OUTC + ch * 8;
+                if (m >= T || col >= ldy) continue;
+                const half8_t v8 = *reinterpret_cast<const half8_t *>(scratch + row * (OUTC * 2) + ((ch ^ (row & 15)) << 4));
+                *reinterpret_cast<half8_t *>(y + (int64_t)m * ldy + col) = v8;
+                if (EPI == GEPI_ROPE) {
+                    const int head = col / epi.D;
+                    if (head >= epi.H) {
+                        const int slot = slotv[hB][kk];                   // CPR = 32: row = tid/32 + 16*kk
+                        if (slot >= 0) {
+                            const bool is_k = head < epi.H + epi.KVH;
+                            const int kvh = is_k ? head - epi.H : head - epi.H - epi.KVH;
+                            *reinterpret_cast<half8_t *>((is_k ? epi.kc : epi.vc) + ((int64_t)slot * epi.KVH + kvh) * epi.D + (col - head * epi.D)) = v8;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        if (!have_next) break;
+        tile = next_tile; u += xcd_step;
     }
 #undef G256_R_END
 #undef G256_M
-    if (grp == 0) __builtin_amdgcn_s_barrier();
-
-    // ---- epilogue: per 128-token half hB, stage [token][column] in LDS, then 16-byte row pieces -----------------------
-    constexpr int OUTC = (EPI == GEPI_SILU) ? 128 : 256;                  // output columns of this workgroup
-    constexpr int OST = OUTC * 2 + 16;                                    // staged row stride (bytes)
-    const int64_t ldy = (EPI == GEPI_ROPE) ? (int64_t)(epi.H + 2 * epi.KVH) * epi.D : (int64_t)N;
-    const int hd2 = (EPI == GEPI_ROPE) ? epi.D / 2 : 1;
-#pragma unroll
-    for (int hB = 0; hB < 2; ++hB) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int ml = wm * 32 + j * 16 + r;                          // token row inside the half
-            const int m = m0 + hB * 128 + ml, mc = m < T ? m : T - 1;
-            char *orow = smem + ml * OST;
-            if (EPI == GEPI_F16) {
-#pragma unroll
-                for (int a = 0; a < 2; ++a)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const float4_t v = acc[a][i][hB][j];
-                        const half4_t h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-                        *reinterpret_cast<half4_t *>(orow + (a * 128 + wn * 64 + i * 16 + q * 4) * 2) = h;
-                    }
-            } else if (EPI == GEPI_SILU) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    half4_t h;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float gf = (float)to_half_rn(acc[0][i][hB][j][e]), uf = (float)to_half_rn(acc[1][i][hB][j][e]);
-                        const float sg = 1.0f / (1.0f + __expf(-gf));
-                        h[e] = to_half_rn(__fmul_rn(__fmul_rn(gf, sg), uf));
-                    }
-                    *reinterpret_cast<half4_t *>(orow + (wn * 64 + i * 16 + q * 4) * 2) = h;
-                }
-            } else {                                                      // GEPI_ROPE
-                const int64_t p = epi.pos[mc];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int rho = wn * 64 + i * 16 + q * 4;             // local row of both halves
-                    const int hl = rho / hd2, col = rho % hd2;            // head inside the tile, column inside the half head
-                    const int head = blockIdx.x * (256 / epi.D) + hl;
-                    half4_t h0, h1;
-                    if (head < epi.H + epi.KVH) {
-                        const float4_t cs = *reinterpret_cast<const float4_t *>(epi.cos_t + p * hd2 + col);
-                        const float4_t sn = *reinterpret_cast<const float4_t *>(epi.sin_t + p * hd2 + col);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float x1 = (float)to_half_rn(acc[0][i][hB][j][e]), x2 = (float)to_half_rn(acc[1][i][hB][j][e]);
-                            h0[e] = to_half_rn(__fsub_rn(__fmul_rn(x1, cs[e]), __fmul_rn(x2, sn[e])));
-                            h1[e] = to_half_rn(__fadd_rn(__fmul_rn(x2, cs[e]), __fmul_rn(x1, sn[e])));
-                        }
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { h0[e] = to_half_rn(acc[0][i][hB][j][e]); h1[e] = to_half_rn(acc[1][i][hB][j][e]); }
-                    }
-                    *reinterpret_cast<half4_t *>(orow + (hl * epi.D + col) * 2) = h0;
-                    *reinterpret_cast<half4_t *>(orow + (hl * epi.D + hd2 + col) * 2) = h1;
-                }
-            }
-        }
-        __syncthreads();
-        constexpr int CPR = OUTC / 8;                                     // 16-byte pieces per row
-        for (int pidx = tid; pidx < 128 * CPR; pidx += 512) {
-            const int row = pidx / CPR, ch = pidx % CPR;
-            const int m = m0 + hB * 128 + row, col = blockIdx.x * OUTC + ch * 8;
-            if (m >= T || col >= ldy) continue;
-            const half8_t v8 = *reinterpret_cast<const half8_t *>(smem + row * OST + ch * 16);
-            *reinterpret_cast<half8_t *>(y + (int64_t)m * ldy + col) = v8;
-            if (EPI == GEPI_ROPE) {
-                const int head = col / epi.D;
-                if (head >= epi.H) {
-                    const int slot = epi.slots ? epi.slots[m] : -1;
-                    if (slot >= 0) {
-                        const bool is_k = head < epi.H + epi.KVH;
-                        const int kvh = is_k ? head - epi.H : head - epi.H - epi.KVH;
-                        *reinterpret_cast<half8_t *>((is_k ? epi.kc : epi.vc) + ((int64_t)slot * epi.KVH + kvh) * epi.D + (col - head * epi.D)) = v8;
-                    }
-                }
-            }
-        }
-        __syncthreads();
-    }
 }
 
 static int g256_prepare() {                                               // 128 KiB of dynamic LDS: opt-in once
@@ -268,6 +324,17 @@ static int g256_prepare() {                                               // 128
     }
     done = true;
     return 0;
+}
+static int g256_grid(int tiles) { return tiles < 256 ? tiles : 256; }   // one persistent workgroup per CU (128 KiB of LDS each)
+// column groups CG for the XCD-aware tile order (0 = plain order).  Measured at T = 32768 (scratch/gemm_prefill_bench.py,
+// +-5 % run to run): the plain GEMMs and SiLU do not care (CG 0/1/2/4 within noise; CG = 8 loses 8 % at N = 6144), the
+// RoPE + KV-store epilogue gains 12 % with CG = 1 (an XCD writes whole output rows and cache rows at a time).
+static int g256_cg(int tiles_x, int tiles_y, bool rope) {
+    int cg = rope ? 1 : 0;
+    if (const char *e = std::getenv("NVR_G256_CG")) cg = std::atoi(e);
+    if (cg < 0 || cg > 8 || (cg & (cg - 1))) cg = 0;
+    if (cg && (tiles_x % cg || tiles_y < 8 / cg || tiles_x * tiles_y < 256)) cg = 0;
+    return cg;
 }
 static int g256_check(const char *what) {
     hipError_t e = hipGetLastError();
@@ -292,17 +359,17 @@ bool gemm256_rope_ok(int64_t T, int64_t K, int64_t H, int64_t KVH, int64_t D, in
 int gemm256(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t N, half_bits *y, hipStream_t s) {
     if (!gemm256_ok(T, K, N, ldx)) return nvr::fail(NVR_ERR_UNSUPPORTED, "gemm256: T=%ld K=%ld N=%ld", (long)T, (long)K, (long)N);
     if (int rc = g256_prepare()) return rc;
-    dim3 grid((unsigned)(N / 256), (unsigned)((T + 255) / 256));
-    gemm256_kernel<GEPI_F16><<<grid, dim3(512), 2 * G_BUF, s>>>((const half_t *)x, ldx, (const half_t *)W, (int)T, (int)K, (int)N, (int)N,
-                                                               (half_t *)y, G256Epi{});
+    const int tx = (int)(N / 256), tt = tx * (int)((T + 255) / 256);
+    gemm256_kernel<GEPI_F16><<<dim3((unsigned)g256_grid(tt)), dim3(512), 2 * G_BUF, s>>>((const half_t *)x, ldx, (const half_t *)W, (int)T, (int)K,
+                                                                                        (int)N, (int)N, (half_t *)y, G256Epi{}, tx, tt / tx, g256_cg(tx, tt / tx, false));
     return g256_check("gemm256");
 }
 int gemm256_silu_mul(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t I, half_bits *out, hipStream_t s) {
     if (!gemm256_silu_ok(T, K, I, ldx)) return nvr::fail(NVR_ERR_UNSUPPORTED, "gemm256_silu_mul: T=%ld K=%ld I=%ld", (long)T, (long)K, (long)I);
     if (int rc = g256_prepare()) return rc;
-    dim3 grid((unsigned)(I / 128), (unsigned)((T + 255) / 256));
-    gemm256_kernel<GEPI_SILU><<<grid, dim3(512), 2 * G_BUF, s>>>((const half_t *)x, ldx, (const half_t *)W, (int)T, (int)K, (int)I, (int)(2 * I),
-                                                                (half_t *)out, G256Epi{});
+    const int tx = (int)(I / 128), tt = tx * (int)((T + 255) / 256);
+    gemm256_kernel<GEPI_SILU><<<dim3((unsigned)g256_grid(tt)), dim3(512), 2 * G_BUF, s>>>((const half_t *)x, ldx, (const half_t *)W, (int)T, (int)K,
+                                                                                         (int)I, (int)(2 * I), (half_t *)out, G256Epi{}, tx, tt / tx, g256_cg(tx, tt / tx, false));
     return g256_check("gemm256_silu_mul");
 }
 int gemm256_qkv_rope_store(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t H, int64_t KVH, int64_t D,
@@ -314,9 +381,9 @@ int gemm256_qkv_rope_store(const half_bits *x, int64_t ldx, const half_bits *W, 
     G256Epi e{};
     e.pos = positions; e.slots = slots; e.cos_t = cos_t; e.sin_t = sin_t; e.kc = (half_t *)k_cache; e.vc = (half_t *)v_cache;
     e.H = (int32_t)H; e.KVH = (int32_t)KVH; e.D = (int32_t)D;
-    dim3 grid((unsigned)(N / 256), (unsigned)((T + 255) / 256));
-    gemm256_kernel<GEPI_ROPE><<<grid, dim3(512), 2 * G_BUF, s>>>((const half_t *)x, ldx, (const half_t *)W, (int)T, (int)K, (int)N, (int)N,
-                                                                (half_t *)qkv, e);
+    const int tx = (int)(N / 256), tt = tx * (int)((T + 255) / 256);
+    gemm256_kernel<GEPI_ROPE><<<dim3((unsigned)g256_grid(tt)), dim3(512), 2 * G_BUF, s>>>((const half_t *)x, ldx, (const half_t *)W, (int)T, (int)K,
+                                                                                         (int)N, (int)N, (half_t *)qkv, e, tx, tt / tx, g256_cg(tx, tt / tx, true));
     return g256_check("gemm256_qkv_rope_store");
 }
 

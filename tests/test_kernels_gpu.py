@@ -462,10 +462,10 @@ def test_linear_silu_mul_fused_equals_unfused_graph(T, K, I):
 
 
 @pytest.mark.parametrize("T,K,H,KVH,D", [(32, 1024, 16, 8, 128), (7, 256, 4, 2, 64), (33, 512, 2, 2, 128), (130, 1024, 16, 8, 128),
-                                         (300, 256, 4, 2, 64), (128, 512, 2, 2, 128), (600, 1024, 16, 8, 128), (257, 128, 2, 1, 128)])
+                                         (300, 256, 4, 2, 64), (128, 512, 2, 2, 128), (600, 1024, 16, 8, 128), (257, 128, 2, 1, 128), (8192, 512, 16, 8, 128)])
 def test_linear_qkv_rope_store_fused(T, K, H, KVH, D):
     rng = np.random.default_rng(21)
-    NB, bs, max_pos = max(24, T // 16 + 2), 16, 300
+    NB, bs, max_pos = max(24, T // 16 + 2), 16, 300          # the 8192-token case has >= 256 output tiles: XCD-aware tile order
     QKV = (H + 2 * KVH) * D
     x, xb = h16(rng.standard_normal((T, K)))
     W, Wb = h16(rng.standard_normal((QKV, K)) * 0.05)
