@@ -4,16 +4,23 @@
 // Semantics (SURVEY A-9): per head softmax_f32(q·Kᵀ·D^-½ + causal mask)·V, query at absolute position p sees keys 0..p.
 // Bound: MFMA (4·D flop per query-key pair and head).
 //
-// One workgroup = 4 waves = one (tile of 64/G query positions, kv head); wave = 16 positions of one of the G query
-// heads of that kv head, so the K/V tiles staged in LDS (global_load_lds, 64 keys per step, double buffered) are
-// shared by all G heads.  Both products run with the QUERY on the lane:
+// One workgroup = 4 waves = one (tile of 128/G query positions, kv head) = 128 query rows; a wave owns TWO 16-row
+// query tiles (G=1: two position blocks of the head; G=2: both heads of one position block; G=4: two of the four heads),
+// so every K fragment (ds_read_b128) and every V fragment (ds_read_b64_tr_b16) it reads from LDS feeds two MFMAs, and the
+// K/V tiles staged in LDS (global_load_lds, 64 keys per step, double buffered) are shared by all G heads.
+// Both products run with the QUERY on the lane:
 //   Sᵀ[key, q] = K·Qᵀ   A = K rows from LDS (ds_read_b128, XOR-swizzled image), B = the lane's Q row (registers);
 //                       the accumulator holds 4 keys x 1 query per 16-key tile, so the row max / sum are in-lane
 //                       plus two cross-group shuffles (no LDS, cdna guide §5.5 T12 "swapped QKᵀ");
 //   Oᵀ[d, q]  += Vᵀ·Pᵀ  B = exp'd Sᵀ accumulators converted to fp16 in place (k-slot (g,j) <-> key 16·(j/4)+4g+j%4:
 //                       the same permutation is used for A), A = Vᵀ read with ds_read_b64_tr_b16 (hardware
 //                       transpose of 4 keys x 16 d); the O accumulator again has the query on the lane, so the
-//                       online-softmax rescale is lane-local.
+//                       online-softmax rescale is lane-local (and skipped for a whole wave when no lane's max moved).
+// LDS images: K [key][16-byte chunks], chunk' = chunk ^ (key & (chunks-1)) — conflict-free for the 4 x 16 lane groups of
+// ds_read_b128; V [key][chunks] with the chunk PAIR index XORed by the key (256-byte rows: (key & 7) << 1; 128-byte
+// rows: ((key >> 1) & 3) << 1), so the 8 keys a 32-lane group of ds_read_b64_tr_b16 touches sit on 8 different
+// 32-byte bank segments (un-swizzled, all 8 keys share one segment: 8-way conflicts, the first version's bottleneck).
+// Steps whose 64 keys all precede the tile's first query skip the causal compare.
 #include "kernels.h"
 #include "device_utils.h"
 #include "../common.h"
@@ -32,30 +39,39 @@ struct FlashParams {
 
 typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
 
+template <int D>
+__device__ __forceinline__ int v_swz(int row) { return D == 128 ? ((row & 7) << 1) : (((row >> 1) & 3) << 1); }
+
 template <int D, int G, bool PAGED>
 __global__ __launch_bounds__(256) void flash_prefill_kernel(FlashParams p) {
     constexpr int KT = 64;                       // keys per step
     constexpr int CPR = D / 8;                   // 16-byte chunks per K/V row
     constexpr int PIECES = KT * CPR / 256;       // 16-byte pieces per thread and operand
-    constexpr int NKS = D / 32, NDT = D / 16;
+    constexpr int NKS = D / 32, NDT = D / 16, NQT = 2;
     __shared__ __attribute__((aligned(16))) char smem[2 * 2 * KT * D * 2];     // [buf][K | V]
 
     const int g = blockIdx.x % p.KVH;
     const FlashTile tile = p.tiles[blockIdx.x / p.KVH];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int r = lane & 15, g4 = lane >> 4;
-    const int hh = wave % G, pb = wave / G;
-    const int qi = pb * 16 + r;                                   // query index inside the tile
-    const bool qvalid = qi < tile.nq;
-    const int qpos = tile.pos0 + (qvalid ? qi : tile.nq - 1);    // absolute position = last visible key
-    const int h = g * G + hh;
     const int kv_end = tile.pos0 + tile.nq;
 
-    half8_t qf[NKS];
-    {
-        const half_t *qrow = p.q + (int64_t)(tile.q_row0 + (qvalid ? qi : tile.nq - 1)) * p.ldq + (int64_t)h * D + g4 * 8;
+    // the wave's two query tiles: head and position block
+    int qi[NQT], head[NQT], qpos[NQT]; bool qvalid[NQT];
+    half8_t qf[NQT][NKS];
 #pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) qf[ks] = *reinterpret_cast<const half8_t *>(qrow + ks * 32);
+    for (int t = 0; t < NQT; ++t) {
+        int pblk;
+        if (G == 1) { head[t] = g; pblk = wave * 2 + t; }
+        else if (G == 2) { head[t] = g * 2 + t; pblk = wave; }
+        else { head[t] = g * 4 + (wave & 1) * 2 + t; pblk = wave >> 1; }
+        qi[t] = pblk * 16 + r;
+        qvalid[t] = qi[t] < tile.nq;
+        const int qc = qvalid[t] ? qi[t] : tile.nq - 1;
+        qpos[t] = tile.pos0 + qc;                                 // absolute position = last visible key
+        const half_t *qrow = p.q + (int64_t)(tile.q_row0 + qc) * p.ldq + (int64_t)head[t] * D + g4 * 8;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) qf[t][ks] = *reinterpret_cast<const half8_t *>(qrow + ks * 32);
     }
 
     auto stage = [&](int buf, int kt) {
@@ -75,15 +91,20 @@ __global__ __launch_bounds__(256) void flash_prefill_kernel(FlashParams p) {
                 off = (int64_t)(tile.kv_ref + key) * p.ldkv + (int64_t)g * D;
             }
             const int piece = (i * 256 + wave * 64) * 16;
+            const int vsw = D == 128 ? ((row & 7) << 1) : (((row >> 1) & 3) << 1);      // = v_swz<D>(row), spelled out: a call here makes hipcc drop the host stub
             __builtin_amdgcn_global_load_lds(p.k + off + (c ^ (row & (CPR - 1))) * 8, (__attribute__((address_space(3))) void *)(kd + piece), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(p.v + off + c * 8, (__attribute__((address_space(3))) void *)(vd + piece), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(p.v + off + (c ^ vsw) * 8, (__attribute__((address_space(3))) void *)(vd + piece), 16, 0, 0);
         }
     };
 
-    float4_t o[NDT];
+    float4_t o[NQT][NDT];
+    float m[NQT], lsum[NQT];
 #pragma unroll
-    for (int i = 0; i < NDT; ++i) o[i] = (float4_t){0.f, 0.f, 0.f, 0.f};
-    float m = -INFINITY, lsum = 0.f;
+    for (int t = 0; t < NQT; ++t) {
+        m[t] = -INFINITY; lsum[t] = 0.f;
+#pragma unroll
+        for (int i = 0; i < NDT; ++i) o[t][i] = (float4_t){0.f, 0.f, 0.f, 0.f};
+    }
 
     const int nsteps = (kv_end + KT - 1) / KT;
     stage(0, 0);
@@ -93,73 +114,93 @@ __global__ __launch_bounds__(256) void flash_prefill_kernel(FlashParams p) {
         if (it + 1 < nsteps) stage(cur ^ 1, kt + KT);
         const char *kl = smem + cur * (2 * KT * D * 2), *vl = kl + KT * D * 2;
 
-        // Sᵀ tiles: 4 x (16 keys x 16 queries)
-        float4_t s[4];
+        // Sᵀ tiles: 4 x (16 keys x 16 queries) per query tile; one K fragment read feeds both
+        float4_t s[NQT][4];
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
-            s[mt] = (float4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < NQT; ++t) s[t][mt] = (float4_t){0.f, 0.f, 0.f, 0.f};
             const int row = mt * 16 + r;
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) {
                 const half8_t kf = *reinterpret_cast<const half8_t *>(kl + (row * CPR + ((ks * 4 + g4) ^ (row & (CPR - 1)))) * 16);
-                s[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[ks], s[mt], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < NQT; ++t) s[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[t][ks], s[t][mt], 0, 0, 0);
             }
         }
-        // scale, causal mask, online softmax (query on the lane; keys kt + mt*16 + g4*4 + e)
-        float mx = -INFINITY;
+        // scale, causal mask (only on steps that reach past the tile's first query), online softmax: query on the lane,
+        // keys kt + mt*16 + g4*4 + e
+        const bool diag = kt + KT - 1 > tile.pos0;
+        half8_t pf[NQT][2];
+        bool moved = false;
+        float alpha[NQT];
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+        for (int t = 0; t < NQT; ++t) {
+            float mx = -INFINITY;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int key = kt + mt * 16 + g4 * 4 + e;
-                const float v = key <= qpos ? s[mt][e] * p.scale : -INFINITY;
-                s[mt][e] = v; mx = fmaxf(mx, v);
-            }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float mn = fmaxf(m, mx);                      // finite from the first step on (key 0 <= qpos)
-        const float alpha = __expf(m - mn);
-        m = mn;
-        float ps = 0.f;
-        half8_t pf[2];
+            for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+                for (int e = 0; e < 4; ++e) {
+                    float v = s[t][mt][e] * p.scale;
+                    if (diag) { const int key = kt + mt * 16 + g4 * 4 + e; v = key <= qpos[t] ? v : -INFINITY; }
+                    s[t][mt][e] = v; mx = fmaxf(mx, v);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float mn = fmaxf(m[t], mx);                   // finite from the first step on (key 0 <= qpos)
+            alpha[t] = __expf(m[t] - mn);
+            moved |= mn != m[t];
+            m[t] = mn;
+            float ps = 0.f;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float pr = __expf(s[mt][e] - mn);
-                ps += pr;
-                pf[mt >> 1][(mt & 1) * 4 + e] = (half_t)pr;
-            }
-        lsum = lsum * alpha + ps;
+            for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-        for (int dt = 0; dt < NDT; ++dt) o[dt] *= alpha;
-        // Oᵀ += Vᵀ·Pᵀ over the two 32-key halves
+                for (int e = 0; e < 4; ++e) {
+                    const float pr = __expf(s[t][mt][e] - mn);
+                    ps += pr;
+                    pf[t][mt >> 1][(mt & 1) * 4 + e] = (half_t)pr;
+                }
+            lsum[t] = lsum[t] * alpha[t] + ps;
+        }
+        if (__any(moved)) {                                     // wave-uniform: the running max settles after a few steps
+#pragma unroll
+            for (int t = 0; t < NQT; ++t)
+#pragma unroll
+                for (int dt = 0; dt < NDT; ++dt) o[t][dt] *= alpha[t];
+        }
+        // Oᵀ += Vᵀ·Pᵀ over the two 32-key halves; one V fragment (two transposing reads) feeds both query tiles
 #pragma unroll
         for (int k2 = 0; k2 < 2; ++k2) {
+            const int row0 = (2 * k2) * 16 + g4 * 4 + (r >> 2), row1 = row0 + 16;
+            const int sw = v_swz<D>(row0);                      // same for row1 (row1 = row0 + 16)
 #pragma unroll
             for (int dt = 0; dt < NDT; ++dt) {
-                const int col = dt * 16 + 4 * (r & 3);
-                const int row0 = (2 * k2) * 16 + g4 * 4 + (r >> 2), row1 = row0 + 16;
-                const fp16x4_t a0 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t *)(vl + (row0 * D + col) * 2));
-                const fp16x4_t a1 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t *)(vl + (row1 * D + col) * 2));
+                const int cb = ((((dt * 2 + ((r & 3) >> 1)) ^ sw) << 4) | ((r & 1) << 3));   // byte offset inside the row
+                const fp16x4_t a0 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t *)(vl + row0 * (D * 2) + cb));
+                const fp16x4_t a1 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t *)(vl + row1 * (D * 2) + cb));
                 half8_t vf;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { vf[e] = (half_t)a0[e]; vf[4 + e] = (half_t)a1[e]; }
-                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[k2], o[dt], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < NQT; ++t) o[t][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[t][k2], o[t][dt], 0, 0, 0);
             }
         }
         __syncthreads();
     }
 
-    lsum += __shfl_xor(lsum, 16, 64);
-    lsum += __shfl_xor(lsum, 32, 64);
-    if (qvalid) {
-        const float inv = lsum > 0.f ? 1.0f / lsum : 0.f;
-        half_t *orow = p.out + ((int64_t)(tile.q_row0 + qi) * p.H + h) * D + g4 * 4;
 #pragma unroll
-        for (int dt = 0; dt < NDT; ++dt) {
-            half4_t hv = {(half_t)(o[dt][0] * inv), (half_t)(o[dt][1] * inv), (half_t)(o[dt][2] * inv), (half_t)(o[dt][3] * inv)};
-            *reinterpret_cast<half4_t *>(orow + dt * 16) = hv;
+    for (int t = 0; t < NQT; ++t) {
+        float ls = lsum[t];
+        ls += __shfl_xor(ls, 16, 64);
+        ls += __shfl_xor(ls, 32, 64);
+        if (qvalid[t]) {
+            const float inv = ls > 0.f ? 1.0f / ls : 0.f;
+            half_t *orow = p.out + ((int64_t)(tile.q_row0 + qi[t]) * p.H + head[t]) * D + g4 * 4;
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) {
+                half4_t hv = {(half_t)(o[t][dt][0] * inv), (half_t)(o[t][dt][1] * inv), (half_t)(o[t][dt][2] * inv), (half_t)(o[t][dt][3] * inv)};
+                *reinterpret_cast<half4_t *>(orow + dt * 16) = hv;
+            }
         }
     }
 }
@@ -169,7 +210,7 @@ bool flash_prefill_ok(int D, int H, int KVH) {
     const int G = H / KVH;
     return (D == 64 || D == 128) && (G == 1 || G == 2 || G == 4);
 }
-int flash_tile_positions(int H, int KVH) { return 64 / (H / KVH); }
+int flash_tile_positions(int H, int KVH) { return 128 / (H / KVH); }
 
 int flash_prefill(const FlashArgs &a, bool paged, hipStream_t s) {
     if (a.ntiles == 0) return 0;

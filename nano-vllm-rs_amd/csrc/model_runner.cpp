@@ -339,6 +339,8 @@ int nvr_model_runner::execute(nvr_seq *const *seqs, size_t nseq, bool is_prefill
                 for (int64_t q0 = ((int64_t)seqs[b]->len() - 1) / qb * qb; q0 >= 0; q0 -= qb)
                     tl[n_tiles++] = k::FlashTile{(int32_t)(cu[b] + q0), (int32_t)std::min<int64_t>(qb, (int64_t)seqs[b]->len() - q0),
                                                  (int32_t)q0, cu[b]};
+            // longest key ranges first over the whole batch: the grid is dispatched in order, so the long tiles start early
+            std::stable_sort(tl, tl + n_tiles, [](const k::FlashTile &a, const k::FlashTile &b) { return a.pos0 + a.nq > b.pos0 + b.nq; });
         }
     } else {
         for (size_t b = 0; b < nseq; ++b) {
