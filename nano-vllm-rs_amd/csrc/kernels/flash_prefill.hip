@@ -21,6 +21,7 @@
 // rows: ((key >> 1) & 3) << 1), so the 8 keys a 32-lane group of ds_read_b64_tr_b16 touches sit on 8 different
 // 32-byte bank segments (un-swizzled, all 8 keys share one segment: 8-way conflicts, the first version's bottleneck).
 // Steps whose 64 keys all precede the tile's first query skip the causal compare.
+#include <type_traits>
 #include "kernels.h"
 #include "device_utils.h"
 #include "../common.h"
@@ -43,7 +44,7 @@ template <int D>
 __device__ __forceinline__ int v_swz(int row) { return D == 128 ? ((row & 7) << 1) : (((row >> 1) & 3) << 1); }
 
 template <int D, int G, bool PAGED>
-__global__ __launch_bounds__(256) void flash_prefill_kernel(FlashParams p) {
+__global__ __launch_bounds__(256, 2) void flash_prefill_kernel(FlashParams p) {     // 2 workgroups per CU: <= 256 registers per lane
     constexpr int KT = 64;                       // keys per step
     constexpr int CPR = D / 8;                   // 16-byte chunks per K/V row
     constexpr int PIECES = KT * CPR / 256;       // 16-byte pieces per thread and operand
@@ -97,21 +98,26 @@ __global__ __launch_bounds__(256) void flash_prefill_kernel(FlashParams p) {
         }
     };
 
-    float4_t o[NQT][NDT];
-    float m[NQT], lsum[NQT];
+    // The softmax runs on RAW scores: m is the running max of q·k (the scale is positive), p = 2^((s - m)·c) with
+    // c = scale·log2(e) is one v_fma + one v_exp per element, and the row sums come from the matrix core (an all-ones A
+    // fragment against the same fp16 P fragments that multiply V), so the VALU work per 64-key step is ~55 instructions
+    // per query tile next to 36 MFMAs.
+    float4_t o[NQT][NDT], ol[NQT];
+    float m[NQT];
 #pragma unroll
     for (int t = 0; t < NQT; ++t) {
-        m[t] = -INFINITY; lsum[t] = 0.f;
+        m[t] = -INFINITY; ol[t] = (float4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < NDT; ++i) o[t][i] = (float4_t){0.f, 0.f, 0.f, 0.f};
     }
+    const float c2 = p.scale * 1.44269504088896340736f;
+    half8_t ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (half_t)1.0f;
 
-    const int nsteps = (kv_end + KT - 1) / KT;
-    stage(0, 0);
-    __syncthreads();
-    for (int it = 0; it < nsteps; ++it) {
-        const int cur = it & 1, kt = it * KT;
-        if (it + 1 < nsteps) stage(cur ^ 1, kt + KT);
+    auto step = [&](auto cur_c, int kt, bool more) {
+        constexpr int cur = decltype(cur_c)::value;
+        if (more) stage(cur ^ 1, kt + KT);
         const char *kl = smem + cur * (2 * KT * D * 2), *vl = kl + KT * D * 2;
 
         // Sᵀ tiles: 4 x (16 keys x 16 queries) per query tile; one K fragment read feeds both
@@ -128,51 +134,52 @@ __global__ __launch_bounds__(256) void flash_prefill_kernel(FlashParams p) {
                 for (int t = 0; t < NQT; ++t) s[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[t][ks], s[t][mt], 0, 0, 0);
             }
         }
-        // scale, causal mask (only on steps that reach past the tile's first query), online softmax: query on the lane,
-        // keys kt + mt*16 + g4*4 + e
-        const bool diag = kt + KT - 1 > tile.pos0;
+        // causal mask only on steps that reach past the tile's first query (keys kt + mt*16 + g4*4 + e)
+        if (kt + KT - 1 > tile.pos0) {
+#pragma unroll
+            for (int t = 0; t < NQT; ++t)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (kt + mt * 16 + g4 * 4 + e > qpos[t]) s[t][mt][e] = -INFINITY;
+        }
         half8_t pf[NQT][2];
         bool moved = false;
         float alpha[NQT];
 #pragma unroll
         for (int t = 0; t < NQT; ++t) {
-            float mx = -INFINITY;
+            float mx = fmaxf(fmaxf(s[t][0][0], s[t][0][1]), fmaxf(s[t][0][2], s[t][0][3]));
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float v = s[t][mt][e] * p.scale;
-                    if (diag) { const int key = kt + mt * 16 + g4 * 4 + e; v = key <= qpos[t] ? v : -INFINITY; }
-                    s[t][mt][e] = v; mx = fmaxf(mx, v);
-                }
+            for (int mt = 1; mt < 4; ++mt) mx = fmaxf(fmaxf(mx, s[t][mt][0]), fmaxf(fmaxf(s[t][mt][1], s[t][mt][2]), s[t][mt][3]));
             mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float mn = fmaxf(m[t], mx);                   // finite from the first step on (key 0 <= qpos)
-            alpha[t] = __expf(m[t] - mn);
+            alpha[t] = __builtin_amdgcn_exp2f((m[t] - mn) * c2);
             moved |= mn != m[t];
             m[t] = mn;
-            float ps = 0.f;
+            const float mc = -mn * c2;
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float pr = __expf(s[t][mt][e] - mn);
-                    ps += pr;
-                    pf[t][mt >> 1][(mt & 1) * 4 + e] = (half_t)pr;
-                }
-            lsum[t] = lsum[t] * alpha[t] + ps;
+                for (int e = 0; e < 4; ++e)
+                    pf[t][mt >> 1][(mt & 1) * 4 + e] = (half_t)__builtin_amdgcn_exp2f(fmaf(s[t][mt][e], c2, mc));
         }
         if (__any(moved)) {                                     // wave-uniform: the running max settles after a few steps
 #pragma unroll
-            for (int t = 0; t < NQT; ++t)
+            for (int t = 0; t < NQT; ++t) {
+                ol[t] *= alpha[t];
 #pragma unroll
                 for (int dt = 0; dt < NDT; ++dt) o[t][dt] *= alpha[t];
+            }
         }
         // Oᵀ += Vᵀ·Pᵀ over the two 32-key halves; one V fragment (two transposing reads) feeds both query tiles
 #pragma unroll
         for (int k2 = 0; k2 < 2; ++k2) {
             const int row0 = (2 * k2) * 16 + g4 * 4 + (r >> 2), row1 = row0 + 16;
             const int sw = v_swz<D>(row0);                      // same for row1 (row1 = row0 + 16)
+#pragma unroll
+            for (int t = 0; t < NQT; ++t) ol[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, pf[t][k2], ol[t], 0, 0, 0);
 #pragma unroll
             for (int dt = 0; dt < NDT; ++dt) {
                 const int cb = ((((dt * 2 + ((r & 3) >> 1)) ^ sw) << 4) | ((r & 1) << 3));   // byte offset inside the row
@@ -186,14 +193,20 @@ __global__ __launch_bounds__(256) void flash_prefill_kernel(FlashParams p) {
             }
         }
         __syncthreads();
+    };
+
+    const int nsteps = (kv_end + KT - 1) / KT;
+    stage(0, 0);
+    __syncthreads();
+    for (int it = 0; it < nsteps; it += 2) {                    // buffer index as a compile-time constant: LDS addresses fold
+        step(std::integral_constant<int, 0>{}, it * KT, it + 1 < nsteps);
+        if (it + 1 < nsteps) step(std::integral_constant<int, 1>{}, (it + 1) * KT, it + 2 < nsteps);
     }
 
 #pragma unroll
     for (int t = 0; t < NQT; ++t) {
-        float ls = lsum[t];
-        ls += __shfl_xor(ls, 16, 64);
-        ls += __shfl_xor(ls, 32, 64);
         if (qvalid[t]) {
+            const float ls = ol[t][0];                          // every row of the ones-product holds the query's sum
             const float inv = ls > 0.f ? 1.0f / ls : 0.f;
             half_t *orow = p.out + ((int64_t)(tile.q_row0 + qi[t]) * p.H + head[t]) * D + g4 * 4;
 #pragma unroll
