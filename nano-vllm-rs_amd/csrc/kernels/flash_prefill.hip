@@ -43,13 +43,19 @@ typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
 template <int D>
 __device__ __forceinline__ int v_swz(int row) { return D == 128 ? ((row & 7) << 1) : (((row >> 1) & 3) << 1); }
 
+#ifndef NVR_FLASH_KT
+#define NVR_FLASH_KT 64
+#define NVR_FLASH_NBUF 2
+#endif
 template <int D, int G, bool PAGED>
 __global__ __launch_bounds__(256, 2) void flash_prefill_kernel(FlashParams p) {     // 2 workgroups per CU: <= 256 registers per lane
-    constexpr int KT = 64;                       // keys per step
+    constexpr int KT = NVR_FLASH_KT;             // keys per step
+    constexpr int NBUF = NVR_FLASH_NBUF;         // K/V tiles in the LDS ring: NBUF-1 in flight ahead of the one in use
     constexpr int CPR = D / 8;                   // 16-byte chunks per K/V row
     constexpr int PIECES = KT * CPR / 256;       // 16-byte pieces per thread and operand
-    constexpr int NKS = D / 32, NDT = D / 16, NQT = 2;
-    __shared__ __attribute__((aligned(16))) char smem[2 * 2 * KT * D * 2];     // [buf][K | V]
+    constexpr int NKS = D / 32, NDT = D / 16, NQT = 2, NMT = KT / 16, NK2 = KT / 32;
+    constexpr int STAGE = 2 * KT * D * 2;        // bytes of one ring slot [K | V]
+    __shared__ __attribute__((aligned(16))) char smem[NBUF * STAGE];
 
     const int g = blockIdx.x % p.KVH;
     const FlashTile tile = p.tiles[blockIdx.x / p.KVH];
@@ -76,7 +82,7 @@ __global__ __launch_bounds__(256, 2) void flash_prefill_kernel(FlashParams p) { 
     }
 
     auto stage = [&](int buf, int kt) {
-        char *kd = smem + buf * (2 * KT * D * 2), *vd = kd + KT * D * 2;
+        char *kd = smem + buf * STAGE, *vd = kd + KT * D * 2;
 #pragma unroll
         for (int i = 0; i < PIECES; ++i) {
             const int idx = i * 256 + threadIdx.x, row = idx / CPR, c = idx % CPR;
@@ -115,15 +121,21 @@ __global__ __launch_bounds__(256, 2) void flash_prefill_kernel(FlashParams p) { 
 #pragma unroll
     for (int e = 0; e < 8; ++e) ones[e] = (half_t)1.0f;
 
-    auto step = [&](auto cur_c, int kt, bool more) {
+    const int nsteps = (kv_end + KT - 1) / KT;
+    // step `it` computes on ring slot it % NBUF while tile it+NBUF-1 is requested into the slot step it-1 just released;
+    // before its closing barrier every wave waits until only the loads of tiles it+2.. are outstanding, so tile it+1 has
+    // landed for all waves after the barrier and the global loads never drain inside the stream.
+    auto step = [&](auto cur_c, int it) {
         constexpr int cur = decltype(cur_c)::value;
-        if (more) stage(cur ^ 1, kt + KT);
-        const char *kl = smem + cur * (2 * KT * D * 2), *vl = kl + KT * D * 2;
+        const int kt = it * KT;
+        const bool more = it + NBUF - 1 < nsteps;
+        if (more) stage((cur + NBUF - 1) % NBUF, kt + (NBUF - 1) * KT);
+        const char *kl = smem + cur * STAGE, *vl = kl + KT * D * 2;
 
-        // Sᵀ tiles: 4 x (16 keys x 16 queries) per query tile; one K fragment read feeds both
-        float4_t s[NQT][4];
+        // Sᵀ tiles: NMT x (16 keys x 16 queries) per query tile; one K fragment read feeds both
+        float4_t s[NQT][NMT];
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
+        for (int mt = 0; mt < NMT; ++mt) {
 #pragma unroll
             for (int t = 0; t < NQT; ++t) s[t][mt] = (float4_t){0.f, 0.f, 0.f, 0.f};
             const int row = mt * 16 + r;
@@ -139,19 +151,19 @@ __global__ __launch_bounds__(256, 2) void flash_prefill_kernel(FlashParams p) { 
 #pragma unroll
             for (int t = 0; t < NQT; ++t)
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
+                for (int mt = 0; mt < NMT; ++mt)
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         if (kt + mt * 16 + g4 * 4 + e > qpos[t]) s[t][mt][e] = -INFINITY;
         }
-        half8_t pf[NQT][2];
+        half8_t pf[NQT][NK2];
         bool moved = false;
         float alpha[NQT];
 #pragma unroll
         for (int t = 0; t < NQT; ++t) {
             float mx = fmaxf(fmaxf(s[t][0][0], s[t][0][1]), fmaxf(s[t][0][2], s[t][0][3]));
 #pragma unroll
-            for (int mt = 1; mt < 4; ++mt) mx = fmaxf(fmaxf(mx, s[t][mt][0]), fmaxf(fmaxf(s[t][mt][1], s[t][mt][2]), s[t][mt][3]));
+            for (int mt = 1; mt < NMT; ++mt) mx = fmaxf(fmaxf(mx, s[t][mt][0]), fmaxf(fmaxf(s[t][mt][1], s[t][mt][2]), s[t][mt][3]));
             mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float mn = fmaxf(m[t], mx);                   // finite from the first step on (key 0 <= qpos)
@@ -160,7 +172,7 @@ __global__ __launch_bounds__(256, 2) void flash_prefill_kernel(FlashParams p) { 
             m[t] = mn;
             const float mc = -mn * c2;
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
+            for (int mt = 0; mt < NMT; ++mt)
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                     pf[t][mt >> 1][(mt & 1) * 4 + e] = (half_t)__builtin_amdgcn_exp2f(fmaf(s[t][mt][e], c2, mc));
@@ -173,9 +185,9 @@ __global__ __launch_bounds__(256, 2) void flash_prefill_kernel(FlashParams p) { 
                 for (int dt = 0; dt < NDT; ++dt) o[t][dt] *= alpha[t];
             }
         }
-        // Oᵀ += Vᵀ·Pᵀ over the two 32-key halves; one V fragment (two transposing reads) feeds both query tiles
+        // Oᵀ += Vᵀ·Pᵀ per 32-key half; one V fragment (two transposing reads) feeds both query tiles
 #pragma unroll
-        for (int k2 = 0; k2 < 2; ++k2) {
+        for (int k2 = 0; k2 < NK2; ++k2) {
             const int row0 = (2 * k2) * 16 + g4 * 4 + (r >> 2), row1 = row0 + 16;
             const int sw = v_swz<D>(row0);                      // same for row1 (row1 = row0 + 16)
 #pragma unroll
@@ -192,15 +204,32 @@ __global__ __launch_bounds__(256, 2) void flash_prefill_kernel(FlashParams p) { 
                 for (int t = 0; t < NQT; ++t) o[t][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[t][k2], o[t][dt], 0, 0, 0);
             }
         }
-        __syncthreads();
+        if (it + NBUF < nsteps) {                               // NBUF-1 younger tiles were requested: leave NBUF-2 of them flying
+            if (NBUF == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (NBUF == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 * 2 * PIECES) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * 2 * PIECES) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
     };
 
-    const int nsteps = (kv_end + KT - 1) / KT;
-    stage(0, 0);
-    __syncthreads();
-    for (int it = 0; it < nsteps; it += 2) {                    // buffer index as a compile-time constant: LDS addresses fold
-        step(std::integral_constant<int, 0>{}, it * KT, it + 1 < nsteps);
-        if (it + 1 < nsteps) step(std::integral_constant<int, 1>{}, (it + 1) * KT, it + 2 < nsteps);
+#pragma unroll
+    for (int b = 0; b < NBUF - 1; ++b)
+        if (b < nsteps) stage(b, b * KT);
+    if (NBUF - 1 < nsteps) {
+        if (NBUF == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (NBUF == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 * 2 * PIECES) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * 2 * PIECES) : "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    for (int it = 0; it < nsteps; it += NBUF) {                 // ring slot as a compile-time constant: LDS addresses fold
+        step(std::integral_constant<int, 0>{}, it);
+        if (it + 1 < nsteps) step(std::integral_constant<int, 1 % NBUF>{}, it + 1);
+        if (NBUF > 2 && it + 2 < nsteps) step(std::integral_constant<int, 2 % NBUF>{}, it + 2);
+        if (NBUF > 3 && it + 3 < nsteps) step(std::integral_constant<int, 3 % NBUF>{}, it + 3);
     }
 
 #pragma unroll

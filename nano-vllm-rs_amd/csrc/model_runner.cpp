@@ -339,8 +339,20 @@ int nvr_model_runner::execute(nvr_seq *const *seqs, size_t nseq, bool is_prefill
                 for (int64_t q0 = ((int64_t)seqs[b]->len() - 1) / qb * qb; q0 >= 0; q0 -= qb)
                     tl[n_tiles++] = k::FlashTile{(int32_t)(cu[b] + q0), (int32_t)std::min<int64_t>(qb, (int64_t)seqs[b]->len() - q0),
                                                  (int32_t)q0, cu[b]};
-            // longest key ranges first over the whole batch: the grid is dispatched in order, so the long tiles start early
-            std::stable_sort(tl, tl + n_tiles, [](const k::FlashTile &a, const k::FlashTile &b) { return a.pos0 + a.nq > b.pos0 + b.nq; });
+            // Dispatch order = array order.  Sequences are taken in groups of 4 and, inside a group, the tiles with the
+            // longest key ranges go first: the ~64 workgroups an XCD runs at a time (kv head g = blockIdx % KVH lands on
+            // XCD g) then share the K/V of 4 sequences (~2 MiB per head: L2-resident), and the short tiles fill the tail.
+            // (Longest-first over the WHOLE batch made every XCD touch all sequences at once: K/V re-streamed from HBM.)
+            {
+                size_t t0 = 0;
+                for (size_t b0 = 0; b0 < nseq; b0 += 4) {
+                    const int32_t row_end = cu[std::min(nseq, b0 + 4)];
+                    size_t t1 = t0;
+                    while (t1 < (size_t)n_tiles && tl[t1].q_row0 < row_end) ++t1;
+                    std::stable_sort(tl + t0, tl + t1, [](const k::FlashTile &a, const k::FlashTile &b) { return a.pos0 + a.nq > b.pos0 + b.nq; });
+                    t0 = t1;
+                }
+            }
         }
     } else {
         for (size_t b = 0; b < nseq; ++b) {
