@@ -85,6 +85,11 @@ typedef struct nvr_config {
                                           Config::validate would reject (config.rs:94) */
     uint32_t decode_microbatches;      /* 0/1: one kernel chain per decode step; 2..4: the batch rows are cut
                                           into that many slices run concurrently on their own HIP streams */
+    int32_t recompute_cached_prefix;   /* 0 (default): a prefill step computes only the tokens after a sequence's
+                                          cached prefix (num_cached_tokens, block_manager.rs:187) and attends to the
+                                          prefix through the block table (K8, attention.rs:211-222) — SURVEY §8f row 2;
+                                          1: the reference's prepare_prefill_inputs (model_runner.rs:176-182), which
+                                          recomputes every token from position 0 */
 } nvr_config;
 NVR_API void nvr_config_default(nvr_config *cfg);                    /* config.rs:54-71 */
 NVR_API int nvr_config_validate(const nvr_config *cfg);              /* config.rs:83-119 */

@@ -52,7 +52,8 @@ class ConfigC(C.Structure):
                 ("enforce_eager", C.c_int32), ("has_eos", C.c_int32), ("eos_token_id", C.c_int64),
                 ("kvcache_block_size", C.c_uint64), ("num_kvcache_blocks", C.c_int64),
                 ("tensor_parallel_rank", C.c_uint64), ("device_ordinal", C.c_int32), ("sample_seed", C.c_uint64),
-                ("skip_block_size_check", C.c_int32), ("decode_microbatches", C.c_uint32)]
+                ("skip_block_size_check", C.c_int32), ("decode_microbatches", C.c_uint32),
+                ("recompute_cached_prefix", C.c_int32)]
 
 
 class ModelConfigC(C.Structure):

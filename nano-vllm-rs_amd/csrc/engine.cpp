@@ -11,8 +11,8 @@ int nvr_engine::step(nvr_step_info *info) {                          // LLMEngin
     rc = runner->sample(batch.data(), batch.size(), last_tokens.data());   // :182-185
     if (rc) return rc;
     last_ids.resize(batch.size());
-    uint64_t ntok = 0;
-    for (size_t i = 0; i < batch.size(); ++i) { last_ids[i] = batch[i]->seq_id; ntok += is_prefill ? batch[i]->len() : 1; }
+    for (size_t i = 0; i < batch.size(); ++i) last_ids[i] = batch[i]->seq_id;
+    const uint64_t ntok = (uint64_t)runner->last_tokens;                 // rows fed through the model (a prefill skips cached prefixes)
     const uint64_t fin_before = scheduler->impl.stats().finished_sequences;
     rc = scheduler->impl.postprocess(batch.data(), last_tokens.data(), batch.size());   // :188-189
     if (rc) return rc;

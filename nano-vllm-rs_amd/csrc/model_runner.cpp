@@ -249,10 +249,14 @@ int nvr_model_runner::forward(Lane &ln, int64_t row0, int64_t T, int64_t B, bool
         a.scale = scale; a.max_ctx = (int32_t)max_ctx; a.out = ln.attn;
         if (is_prefill && n_tiles > 0) {                             // flash_attention_varlen, attention.rs:177-208 (MFMA)
             k::FlashArgs f{};
-            f.q = ln.qkv; f.ldq = QKV; f.k = ln.qkv + H * D; f.v = ln.qkv + (H + KVH) * D; f.ldkv = QKV;
+            f.q = ln.qkv; f.ldq = QKV;
+            if (prefill_paged) {                                     // cached prefixes: K/V through the block tables (K8)
+                f.k = k_cache(l); f.v = v_cache(l); f.block_tables = dd_bt; f.max_blocks = (int32_t)max_blocks_per_seq;
+                f.block_size = (int32_t)block_size;
+            } else { f.k = ln.qkv + H * D; f.v = ln.qkv + (H + KVH) * D; f.ldkv = QKV; }
             f.tiles = (const k::FlashTile *)(in_dev + off_tiles); f.ntiles = (int32_t)n_tiles;
             f.H = (int32_t)H; f.KVH = (int32_t)KVH; f.D = (int32_t)D; f.scale = scale; f.out = ln.attn;
-            RC(k::flash_prefill(f, false, st));
+            RC(k::flash_prefill(f, prefill_paged, st));
         } else if (is_prefill) {                                     // head shapes outside the MFMA kernel: row kernel
             a.k = ln.qkv + H * D; a.v = ln.qkv + (H + KVH) * D; a.ldkv = QKV; a.kv_base = d_kvbase; a.workspace = nullptr;
             RC(k::attention(a, false, st));
@@ -312,17 +316,34 @@ int nvr_model_runner::execute(nvr_seq *const *seqs, size_t nseq, bool is_prefill
     const int64_t bs = block_size;
     NVR_HIP_CHECK(hipStreamSynchronize(stream));   // staging arena is reused: previous uploads must have landed
     if (is_prefill) {
-        // all tokens from position 0 (A-7), slot(pos) = table[pos/bs]*bs + pos%bs (A-6)
+        // slot(pos) = table[pos/bs]*bs + pos%bs (A-6).  Tokens: the reference feeds every token from position 0
+        // (model_runner.rs:176-182, A-7); unless recompute_cached_prefix is set, a sequence's cached prefix
+        // (num_cached_tokens: whole blocks another live sequence already holds, block_manager.rs:181-187) is skipped —
+        // its K/V rows are in the cache (written by an earlier step, or by the owner's rows of THIS step's qkv launch,
+        // which precedes the attention launch of the layer) and the new tokens attend to them through the block table
+        // (K8, attention.rs:211-222).  At least the last token is always computed (its logits are the step's output).
+        const bool flash_ok = k::flash_prefill_ok((int)D, (int)H, (int)KVH);
+        prefill_paged = false;
         int64_t total = 0;
-        for (size_t b = 0; b < nseq; ++b) total += (int64_t)seqs[b]->len();
+        for (size_t b = 0; b < nseq; ++b) {
+            const int64_t len = (int64_t)seqs[b]->len();
+            int64_t c = (cfg.recompute_cached_prefix || !flash_ok) ? 0 : std::min<int64_t>((int64_t)seqs[b]->num_cached_tokens, len - 1);
+            if (c < 0) c = 0;
+            prefill_paged |= c > 0;
+            total += len - c;
+        }
         if (total > max_tokens) return nvr::fail(NVR_ERR_INVALID_ARG, "prefill of %ld tokens exceeds max_num_batched_tokens %ld", (long)total, (long)max_tokens);
         cu[0] = 0;
+        const int qb = flash_ok ? k::flash_tile_positions((int)H, (int)KVH) : 1;
+        k::FlashTile *tl = (k::FlashTile *)(in_host + off_tiles);
+        n_tiles = 0;
         for (size_t b = 0; b < nseq; ++b) {
             const nvr_seq &s = *seqs[b];
             const int64_t len = (int64_t)s.len();
             if (len > max_pos) return nvr::fail(NVR_ERR_INVALID_ARG, "sequence of %ld tokens exceeds max_model_len %ld", (long)len, (long)max_pos);
             if ((int64_t)s.block_table.size() * bs < len) return nvr::fail(NVR_ERR_NOT_ALLOCATED, "Sequence has no allocated blocks");
-            for (int64_t p = 0; p < len; ++p) {
+            const int64_t c0 = prefill_paged ? std::max<int64_t>(0, std::min<int64_t>((int64_t)s.num_cached_tokens, len - 1)) : 0;
+            for (int64_t p = c0; p < len; ++p) {
                 ids[T] = s.token_ids[p]; pos[T] = p;
                 slots[T] = (int32_t)((int64_t)s.block_table[p / bs] * bs + p % bs);
                 ctx[T] = (int32_t)(p + 1); kvb[T] = cu[b];
@@ -330,15 +351,18 @@ int nvr_model_runner::execute(nvr_seq *const *seqs, size_t nseq, bool is_prefill
             }
             cu[b + 1] = (int32_t)T;
             max_ctx = std::max(max_ctx, len);
+            if (prefill_paged) {
+                if ((int64_t)s.block_table.size() > max_blocks_per_seq) return nvr::fail(NVR_ERR_INVARIANT, "block table longer than max_model_len allows");
+                std::memcpy(bt + b * max_blocks_per_seq, s.block_table.data(), s.block_table.size() * 4);
+            }
+            if (flash_ok) {                                              // longest-context tiles of a sequence first
+                const int64_t nq = len - c0;
+                for (int64_t q0 = (nq - 1) / qb * qb; q0 >= 0; q0 -= qb)
+                    tl[n_tiles++] = k::FlashTile{(int32_t)(cu[b] + q0), (int32_t)std::min<int64_t>(qb, nq - q0), (int32_t)(c0 + q0),
+                                                 prefill_paged ? (int32_t)b : cu[b]};
+            }
         }
-        n_tiles = 0;
-        if (k::flash_prefill_ok((int)D, (int)H, (int)KVH)) {
-            k::FlashTile *tl = (k::FlashTile *)(in_host + off_tiles);
-            const int qb = k::flash_tile_positions((int)H, (int)KVH);
-            for (size_t b = 0; b < nseq; ++b)                        // longest-context tiles of a sequence first
-                for (int64_t q0 = ((int64_t)seqs[b]->len() - 1) / qb * qb; q0 >= 0; q0 -= qb)
-                    tl[n_tiles++] = k::FlashTile{(int32_t)(cu[b] + q0), (int32_t)std::min<int64_t>(qb, (int64_t)seqs[b]->len() - q0),
-                                                 (int32_t)q0, cu[b]};
+        if (flash_ok) {
             // Dispatch order = array order.  Sequences are taken in groups of 4 and, inside a group, the tiles with the
             // longest key ranges go first: the ~64 workgroups an XCD runs at a time (kv head g = blockIdx % KVH lands on
             // XCD g) then share the K/V of 4 sequences (~2 MiB per head: L2-resident), and the short tiles fill the tail.
@@ -377,9 +401,10 @@ int nvr_model_runner::execute(nvr_seq *const *seqs, size_t nseq, bool is_prefill
         NVR_HIP_CHECK(up(off_ids, T * 8)); NVR_HIP_CHECK(up(off_pos, T * 8)); NVR_HIP_CHECK(up(off_slots, T * 4));
         NVR_HIP_CHECK(up(off_ctx, T * 4)); NVR_HIP_CHECK(up(off_cu, (nseq + 1) * 4)); NVR_HIP_CHECK(up(off_kvbase, T * 4));
         if (n_tiles) NVR_HIP_CHECK(up(off_tiles, n_tiles * sizeof(k::FlashTile)));
+        if (prefill_paged) NVR_HIP_CHECK(up(off_dec + dof_bt, nseq * max_blocks_per_seq * 4));
     } else NVR_HIP_CHECK(up(off_dec, dof_bt + nseq * max_blocks_per_seq * 4));
 
-    last_rows = nseq; last_prefill = is_prefill;
+    last_rows = nseq; last_prefill = is_prefill; last_tokens = T;
     // arg-max partials come with the logits when the whole batch goes through one lm_head launch (a pure function of
     // the shapes, so a replayed graph and this bookkeeping always agree)
     const int nl = (!is_prefill && (int64_t)nseq >= 8 * (int64_t)lanes.size()) ? (int)lanes.size() : 1;

@@ -64,7 +64,7 @@ struct nvr_model_runner {
     std::vector<Lane> lanes;
     hipEvent_t fork_ev = nullptr;
     std::map<uint64_t, hipGraphExec_t> graphs;
-    size_t last_rows = 0; bool last_prefill = false;
+    size_t last_rows = 0; bool last_prefill = false; int64_t last_tokens = 0;
     nvr::Comm comm;
     bool graphs_disabled = false;   // set when capture with RCCL nodes fails: fall back to eager launches
     int comm_selftest();
@@ -82,6 +82,7 @@ private:
     int gen_weights();
     int row_parallel_norm(Lane &ln, const uint16_t *x, int64_t K, const uint16_t *W, int64_t T, const uint16_t *wn);
     bool fused_slabnorm = false;
+    bool prefill_paged = false;                          // this prefill step skips cached prefixes (K/V via block tables)
     bool lm_fused = true; int32_t lm_parts = 0;          // lm_head arg-max partials of the last step (0: none)
     float *d_lm_pval = nullptr; int32_t *d_lm_pidx = nullptr;
 };

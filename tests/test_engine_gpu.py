@@ -102,6 +102,45 @@ def test_preemption_and_prefix_cache_end_to_end():
     assert r["near_ties"] <= 3, r
 
 
+def _run_product(mcfg, ecfg, prompts, sps, **cfg_kw):
+    nvr.lib().nvr_seq_reset_id_counter()
+    p = nvr.LLMEngine(nvr.Config(skip_block_size_check=1, **ecfg, **cfg_kw), _model_cfgs(mcfg))
+    for pr, sp in zip(prompts, sps):
+        p.add_request(pr, nvr.SamplingParams(**sp))
+    trace = []
+    while not p.is_finished():
+        rec = p.step()
+        trace.append((rec["is_prefill"], rec["seq_ids"], rec["tokens"], rec["num_tokens"], p.model_runner.logits(rec["num_seqs"]).copy()))
+        assert len(trace) < 400
+    return trace
+
+
+def test_cached_prefix_skipping_is_bit_identical():
+    """a prefill step computes only the tokens after a sequence's cached prefix and reaches the prefix
+    through the block table.  The K/V rows are the same bits either way (a GEMM row depends only on its own input row)
+    and the flash kernel walks the keys in the same 64-key steps, so logits and tokens must be IDENTICAL to the
+    recompute-everything path of the reference (model_runner.rs:176-182) while far fewer rows go through the model."""
+    mcfg = mo.small(seed=8)
+    ecfg = dict(max_num_seqs=16, max_num_batched_tokens=1024, max_model_len=256, kvcache_block_size=16, num_kvcache_blocks=120)
+    shared = oracle.fill_tokens(64, 3, 77, mcfg.vocab_size).tolist()                 # 4 full blocks
+    prompts = [shared + oracle.fill_tokens(5 + 3 * i, 3, i, mcfg.vocab_size).tolist() for i in range(8)]
+    prompts.append(list(shared))                                                       # fully cached prompt: last token still computed
+    prompts.append(oracle.fill_tokens(40, 3, 500, mcfg.vocab_size).tolist())           # nothing shared
+    sps = [dict(temperature=0.0, max_tokens=12, ignore_eos=True)] * len(prompts)
+    skip = _run_product(mcfg, ecfg, prompts, sps)
+    full = _run_product(mcfg, ecfg, prompts, sps, recompute_cached_prefix=1)
+    assert len(skip) == len(full)
+    for a, b in zip(skip, full):
+        assert a[:3] == b[:3]
+        assert np.array_equal(a[4], b[4]), "logits differ between skipping and recomputing the cached prefix"
+    pre_skip = sum(t[3] for t in skip if t[0]); pre_full = sum(t[3] for t in full if t[0])
+    assert pre_full == sum(len(p) for p in prompts)
+    assert pre_skip == pre_full - 7 * 64 - 63, (pre_skip, pre_full)     # the first prompt fills the blocks; 7 more skip 64 tokens, the bare prefix 63
+    # and the skipping path against the oracle engine (which recomputes), teacher-forced
+    r = _run_pair(mcfg, ecfg, prompts, sps)
+    assert r["near_ties"] <= 2, r
+
+
 def test_gqa4_head_dim_128_model():
     """Qwen3-8B-like head geometry (32:8 grouping scaled down, D=128) and block size 256."""
     mcfg = mo.ModelConfig(vocab_size=2048, hidden_size=512, intermediate_size=1024, num_hidden_layers=2,

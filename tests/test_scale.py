@@ -126,6 +126,42 @@ def test_config2_full_size_properties():
 
 
 @pytest.mark.gpu
+def test_config5_full_size_prefix_skipping():
+    """BASELINE configs[4] at full size (Qwen3-0.6B, 512 sequences = one 512-token system prompt + 64 own tokens, block
+    size 256): with cached-prefix skipping the prefill feeds 576 + 511 x 64 rows through the model instead of 512 x 576,
+    the first sampled token of every sequence is identical to the recompute-everything path, and the prefill is several
+    times faster (both wall times are printed; the ratio is asserted loosely)."""
+    import time
+    mc = nvr.ModelConfig("qwen3-0.6b")
+    ecfg = dict(max_num_seqs=512, max_num_batched_tokens=32768, max_model_len=1024, kvcache_block_size=256, num_kvcache_blocks=600)
+    prefix = nvr.synthetic_tokens(512, 2, 0, 151936).tolist()
+    prompts = [prefix + nvr.synthetic_tokens(64, 1, i, 151936).tolist() for i in range(512)]
+
+    def run(**kw):
+        nvr.lib().nvr_seq_reset_id_counter()
+        eng = nvr.LLMEngine(nvr.Config(**ecfg, **kw), mc)
+        for pr in prompts:
+            eng.add_request(pr, nvr.SamplingParams(temperature=0.0, max_tokens=2, ignore_eos=True))
+        first, rows, nvr_sync = {}, 0, nvr.synchronize
+        nvr_sync(); t0 = time.perf_counter()
+        steps = 0
+        while True:
+            rec = eng.step()
+            if not rec["is_prefill"]:
+                break
+            rows += rec["num_tokens"]; steps += 1
+            first.update(zip(rec["seq_ids"], rec["tokens"]))
+        nvr_sync(); dt = time.perf_counter() - t0
+        return first, rows, steps, dt
+    f_skip, rows_skip, steps_skip, t_skip = run()
+    f_full, rows_full, steps_full, t_full = run(recompute_cached_prefix=1)
+    print(f"config 5 prefill: skipping {rows_skip} rows in {steps_skip} steps {t_skip * 1e3:.1f} ms; recomputing {rows_full} rows in {steps_full} steps {t_full * 1e3:.1f} ms")
+    assert rows_full == 512 * 576 and rows_skip == 576 + 511 * 64
+    assert f_skip == f_full and len(f_skip) == 512
+    assert t_full > 3 * t_skip
+
+
+@pytest.mark.gpu
 def test_kv_pool_sized_from_free_hbm():
     """num_kvcache_blocks = auto: the pool is cut from free HBM * gpu_memory_utilization (the reference has the config
     field, config.rs:30, but no sizing code); 28 MiB per block for Qwen3-0.6B."""
