@@ -135,7 +135,12 @@ def main() -> None:
     ap.add_argument("--microbatches", type=int, default=int(os.environ.get("NVR_MICROBATCHES", "1")),
                     help="decode micro-batches run concurrently on their own HIP streams (nvr_config.decode_microbatches)")
     ap.add_argument("--eager", action="store_true", help="enforce_eager: launch decode kernels one by one instead of replaying a hipGraph")
+    ap.add_argument("--materialize-logits", action="store_true",
+                    help="write the f32 logits of every step to HBM (default: a greedy batch takes its tokens from the arg-max "
+                         "partials of the LM-head epilogue and the logits are written only when someone asks for them)")
     args = ap.parse_args()
+    if args.materialize_logits:
+        os.environ["NVR_LAZY_LOGITS"] = "0"
 
     nvr = nvr_import.load()                # loads libnvr.so (and the ROCm HIP runtime) before torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -251,7 +256,8 @@ def main() -> None:
             "config": {"workload": "Qwen3-0.6B fp16 random-init, bs=32 x 1024-token prompts, greedy paged-attention decode, "
                                    "block_size=256, hipGraph decode steps (BASELINE.json configs[1])",
                        "batch": BATCH, "prompt_len": PROMPT_LEN, "mean_context": ctx_mean,
-                       "parallelism": parallelism, "decode_microbatches": args.microbatches, "hipgraph": not args.eager},
+                       "parallelism": parallelism, "decode_microbatches": args.microbatches, "hipgraph": not args.eager,
+                       "logits": "materialised every step" if args.materialize_logits else "greedy arg-max fused into the LM head; f32 logits on demand"},
             "prefill": {"tokens": BATCH * PROMPT_LEN, "seconds": round(t_prefill, 4), "tokens_per_s": round(BATCH * PROMPT_LEN / t_prefill, 1),
                         "tflop_per_s": round(prefill_flop / t_prefill / 1e12, 1), "mfma_frac_of_2500": round(prefill_flop / t_prefill / 2.5e15, 4),
                         "note": "one untimed engine prefill step (wall clock, includes host input preparation and upload)"},

@@ -280,7 +280,8 @@ NVR_API int nvr_linear(const nvr_half *x, int64_t ldx, const nvr_half *W, int64_
  * NVR_ERR_UNSUPPORTED: use nvr_linear): logits[T,N] f32 = x·Wᵀ (ParallelLMHead::compute_logits, embed_head.rs:292-306)
  * plus the greedy arg-max of every row folded into the epilogue (Sampler::sample greedy branch, sampler.rs:126-151):
  * part_val/part_idx [*nparts][T] hold per-workgroup (max, lowest index) pairs, *nparts <= NVR_LM_HEAD_MAX_PARTS;
- * nvr_argmax_partials merges them (ties -> lowest index), adds idx_offset, out_val nullable. */
+ * nvr_argmax_partials merges them (ties -> lowest index), adds idx_offset, out_val nullable.
+ * logits == NULL: only the partials are produced (a greedy batch never reads its 4·T·N logit bytes). */
 #define NVR_LM_HEAD_MAX_PARTS 1024
 NVR_API int nvr_lm_head(const nvr_half *x, int64_t ldx, const nvr_half *W, int64_t T, int64_t K, int64_t N, float *logits,
                         float *part_val, int32_t *part_idx, int32_t *nparts, void *stream);

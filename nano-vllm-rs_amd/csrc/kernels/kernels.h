@@ -36,8 +36,9 @@ int linear(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64
 constexpr int LM_HEAD_MAX_PARTS = 1024;
 bool lm_head_ok(int64_t T, int64_t K, int64_t N, int64_t ldx);
 int32_t lm_head_parts(int64_t T, int64_t K, int64_t N, int64_t ldx);      // partials lm_head will write (0: unsupported shape)
+// store_logits = false: only the partials are written (a greedy batch never reads its 4·T·N logit bytes)
 int lm_head(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t N, float *logits,
-            float *part_val, int32_t *part_idx, int32_t *nparts, hipStream_t s);
+            float *part_val, int32_t *part_idx, int32_t *nparts, hipStream_t s, bool store_logits = true);
 int argmax_partials(const float *part_val, const int32_t *part_idx, int32_t nparts, int64_t T, int64_t *out_idx, float *out_val,
                     int64_t idx_offset, hipStream_t s);
 

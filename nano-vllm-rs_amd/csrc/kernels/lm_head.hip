@@ -176,7 +176,7 @@ static int lm_allow_big_lds() {
 
 // logits[T,N] (f32) = x·Wᵀ and per-workgroup arg-max partials: part_val/part_idx [*nparts][T], *nparts <= LM_HEAD_MAX_PARTS
 int lm_head(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t N, float *logits,
-            float *part_val, int32_t *part_idx, int32_t *nparts, hipStream_t s) {
+            float *part_val, int32_t *part_idx, int32_t *nparts, hipStream_t s, bool store_logits) {
     if (!lm_head_ok(T, K, N, ldx))
         return nvr::fail(NVR_ERR_UNSUPPORTED, "lm_head: T=%ld (1..32), K=%ld (multiple of 256, <= 2048), N=%ld (multiple of 16)",
                          (long)T, (long)K, (long)N);
@@ -188,7 +188,7 @@ int lm_head(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int6
     if (int rc0 = lm_allow_big_lds()) return rc0;
     const size_t lds = (size_t)mt * 16 * K * 2;
     bool launched = false;
-    const int dbg_flags = std::getenv("NVR_LM_DBG") ? std::atoi(std::getenv("NVR_LM_DBG")) : 0;
+    const int dbg_flags = store_logits ? 0 : 1;                // bit 0: skip the f32 logit stores (arg-max partials only)
 #define NVR_LM(MT_, WV_, U_)                                                                                          \
     if (!launched && mt == MT_ && waves == WV_ && U == U_) {                                                          \
         lm_head_kernel<MT_, WV_, U_><<<dim3((unsigned)nwg), dim3(WV_ * 64), lds, s>>>(xx, ldx, ww, (int)T, (int)K, (int)N, logits, \

@@ -100,6 +100,7 @@ int nvr_model_runner::init() {                                       // ModelRun
     // measured slower than two launches (profiles/r01_fused_slabnorm_ablation.txt): opt-in only
     { const char *e = getenv("NVR_FUSED_SLABNORM"); fused_slabnorm = e && e[0] == '1'; }
     { const char *e = getenv("NVR_LM_FUSED"); lm_fused = !(e && e[0] == '0'); }
+    { const char *e = getenv("NVR_LAZY_LOGITS"); lazy_logits = !(e && e[0] == '0'); }
     RC(dmalloc(&d_lm_pval, (size_t)k::LM_HEAD_MAX_PARTS * 32)); RC(dmalloc(&d_lm_pidx, (size_t)k::LM_HEAD_MAX_PARTS * 32));
     attn_ws_bytes = k::attn_workspace_bytes(max_seqs, H, D, max_pos);
     NVR_HIP_CHECK(hipMalloc(&attn_ws, attn_ws_bytes));
@@ -274,7 +275,7 @@ int nvr_model_runner::forward(Lane &ln, int64_t row0, int64_t T, int64_t B, bool
     if (is_prefill) { RC(k::select_last_tokens(ln.n, d_cu, B, Hd, nlast, st)); hl = nlast; }   // embed_head.rs:272-289
     if (lm_parts > 0) {                                                                        // f32 logits (A-21) + arg-max partials
         int32_t np = 0;
-        RC(k::lm_head(hl, Hd, lm_head, B, Hd, Vl, logits, d_lm_pval, d_lm_pidx, &np, st));
+        RC(k::lm_head(hl, Hd, lm_head, B, Hd, Vl, logits, d_lm_pval, d_lm_pidx, &np, st, want_logits));
         if (np != lm_parts) return nvr::fail(NVR_ERR_INVARIANT, "lm_head produced %d partials, planned %d", np, lm_parts);
     } else {
         RC(k::linear(hl, Hd, lm_head, B, Hd, Vl, logits + row0 * Vl, true, st));
@@ -409,6 +410,12 @@ int nvr_model_runner::execute(nvr_seq *const *seqs, size_t nseq, bool is_prefill
     // the shapes, so a replayed graph and this bookkeeping always agree)
     const int nl = (!is_prefill && (int64_t)nseq >= 8 * (int64_t)lanes.size()) ? (int)lanes.size() : 1;
     lm_parts = (lm_fused && (is_prefill || nl == 1)) ? k::lm_head_parts((int64_t)nseq, Hd, Vl, Hd) : 0;
+    // a batch that samples greedily everywhere takes its tokens from the arg-max partials: the f32 logits are then written
+    // only on demand (ensure_logits: execute_model callers that ask for them, copy_logits)
+    want_logits = !lazy_logits || lm_parts == 0;
+    for (size_t i = 0; i < nseq && !want_logits; ++i) want_logits = seqs[i]->sampling.temperature != 0.0f;
+    logits_valid = want_logits;
+    lm_input = is_prefill ? nlast : lanes[0].n;                          // the rows the LM head reads this step (forward())
     if (is_prefill || cfg.enforce_eager || graphs_disabled) return forward_all(T, (int64_t)nseq, is_prefill, max_ctx, nl);
 
     // decode: replay a hipGraph captured per (batch size, context bucket) — execute_with_cuda_graph :303-326
@@ -431,7 +438,7 @@ int nvr_model_runner::execute(nvr_seq *const *seqs, size_t nseq, bool is_prefill
     };
     if (nl <= 1) {
         hipGraphExec_t ge;
-        int rc = get_graph(((uint64_t)nseq << 32) | (uint64_t)bucket, stream, [&] { return forward(lanes[0], 0, T, T, false, bucket); }, &ge);
+        int rc = get_graph(((uint64_t)want_logits << 60) | ((uint64_t)nseq << 32) | (uint64_t)bucket, stream, [&] { return forward(lanes[0], 0, T, T, false, bucket); }, &ge);
         if (rc && comm.active()) {            // a graph holding RCCL nodes could not be built on this stack: run eagerly
             graphs_disabled = true;
             (void)hipGetLastError();
@@ -488,6 +495,17 @@ int nvr_model_runner::comm_selftest() {
 }
 
 // sample_tokens :131-156 -> Sampler::batch_sample, src/layers/sampler.rs:221-254
+// the f32 logits of the last step, if that step skipped their stores: the LM-head launch is repeated on the same
+// (still resident) hidden rows with the stores on — same kernel, same bits
+int nvr_model_runner::ensure_logits() {
+    if (logits_valid) return NVR_OK;
+    NVR_HIP_CHECK(hipSetDevice(device));
+    int32_t np = 0;
+    RC(k::lm_head(lm_input, Hd, lm_head, (int64_t)last_rows, Hd, Vl, logits, d_lm_pval, d_lm_pidx, &np, stream, true));
+    logits_valid = true;
+    return NVR_OK;
+}
+
 int nvr_model_runner::sample(nvr_seq *const *seqs, size_t nseq, int64_t *out) {
     NVR_HIP_CHECK(hipSetDevice(device));
     if (nseq != last_rows) return nvr::fail(NVR_ERR_LEN_MISMATCH, "sample_tokens: %zu sequences but logits hold %zu rows", nseq, last_rows);
@@ -519,6 +537,7 @@ int nvr_model_runner::sample(nvr_seq *const *seqs, size_t nseq, int64_t *out) {
             return NVR_OK;
         }
     } else {
+        RC(ensure_logits());
         const float *lg = logits; int64_t Vs = Vl; void *ws = sample_ws;
         if (comm.active()) {
             // gather the vocab shards on every rank (embed_head.rs:321-336) and sample identically everywhere (counter RNG)

@@ -72,6 +72,7 @@ struct nvr_model_runner {
     ~nvr_model_runner();
     int init();
     int execute(nvr_seq *const *seqs, size_t nseq, bool is_prefill);
+    int ensure_logits();                                 // materialise the last step's f32 logits if it skipped their stores
     int sample(nvr_seq *const *seqs, size_t nseq, int64_t *out);
     uint16_t *k_cache(size_t l) { return kv_pool + (2 * l) * kv_layer_elems; }
     uint16_t *v_cache(size_t l) { return kv_pool + (2 * l + 1) * kv_layer_elems; }
@@ -83,6 +84,7 @@ private:
     int row_parallel_norm(Lane &ln, const uint16_t *x, int64_t K, const uint16_t *W, int64_t T, const uint16_t *wn);
     bool fused_slabnorm = false;
     bool prefill_paged = false;                          // this prefill step skips cached prefixes (K/V via block tables)
+    bool lazy_logits = true, want_logits = true, logits_valid = true; const uint16_t *lm_input = nullptr;
     bool lm_fused = true; int32_t lm_parts = 0;          // lm_head arg-max partials of the last step (0: none)
     float *d_lm_pval = nullptr; int32_t *d_lm_pidx = nullptr;
 };

@@ -188,7 +188,7 @@ void nvr_runner_destroy(nvr_model_runner_t *r) { delete r; }
 int nvr_runner_execute_model(nvr_model_runner_t *r, nvr_seq_t *const *seqs, size_t n, int is_prefill, const float **logits_dev) {
     NVR_GUARD_BEGIN
     int rc = r->execute(seqs, n, is_prefill != 0);
-    if (rc == NVR_OK && logits_dev) *logits_dev = r->logits;
+    if (rc == NVR_OK && logits_dev) { rc = r->ensure_logits(); *logits_dev = r->logits; }
     return rc;
     NVR_GUARD_END(NVR_ERR_INVARIANT)
 }
@@ -198,6 +198,7 @@ int nvr_runner_sample_tokens(nvr_model_runner_t *r, nvr_seq_t *const *seqs, size
 int nvr_runner_copy_logits(nvr_model_runner_t *r, float *host_out, size_t rows) {
     if (rows > r->last_rows) return nvr::fail(NVR_ERR_LEN_MISMATCH, "copy_logits: %zu rows requested, %zu available", rows, r->last_rows);
     NVR_HIP_CHECK(hipSetDevice(r->device));
+    if (int rc = r->ensure_logits()) return rc;
     NVR_HIP_CHECK(hipMemcpyAsync(host_out, r->logits, rows * r->Vl * sizeof(float), hipMemcpyDeviceToHost, r->stream));
     NVR_HIP_CHECK(hipStreamSynchronize(r->stream));
     return NVR_OK;
@@ -306,7 +307,7 @@ int nvr_linear(const nvr_half *x, int64_t ldx, const nvr_half *W, int64_t T, int
 int nvr_lm_head(const nvr_half *x, int64_t ldx, const nvr_half *W, int64_t T, int64_t K, int64_t N, float *logits, float *part_val,
                 int32_t *part_idx, int32_t *nparts, void *s) {
     if (!nparts) return nvr::fail(NVR_ERR_INVALID_ARG, "nvr_lm_head: nparts is null");
-    return k::lm_head(x, ldx, W, T, K, N, logits, part_val, part_idx, nparts, (hipStream_t)s);
+    return k::lm_head(x, ldx, W, T, K, N, logits, part_val, part_idx, nparts, (hipStream_t)s, logits != nullptr);
 }
 int nvr_argmax_partials(const float *part_val, const int32_t *part_idx, int32_t nparts, int64_t T, int64_t *out_idx, float *out_val,
                         int64_t idx_offset, void *s) {
