@@ -10,16 +10,16 @@
 //   * a wave owns 64 rows of EACH A half and 32 rows of EACH B half, so its 128 x 64 output splits into four
 //     quadrants (A half, B half) of 16 MFMAs (v_mfma_f32_16x16x32_f16, 4 n-tiles x 2 m-tiles x 2 k-steps) — one
 //     quadrant per PHASE, and each phase needs only the half-tiles named below.
-//   * a K-tile is four phases; every phase = R { ds_read the fragments it is missing; global_load_lds ONE half-tile of
-//     the NEXT K-tile (2 x 16 B per thread) into the other buffer; s_waitcnt vmcnt(4); s_barrier } + M { 16 MFMAs;
+//   * a K-tile is four phases; every phase = R { ds_read the fragments it is missing; s_waitcnt vmcnt(2); s_barrier } +
+//     M { global_load_lds ONE half-tile of the NEXT K-tile (2 x 16 B per thread) into the other buffer; 16 MFMAs;
 //     s_barrier }, the two wave groups one barrier interval apart (reads of one overlap MFMAs of the other):
 //         phase 0: quadrant (A0,B0)  reads A0 (8 fragments) + B0 (4)   stages A0'
 //         phase 1: quadrant (A0,B1)  reads B1 (4)                      stages B0'
 //         phase 2: quadrant (A1,B1)  reads A1 (8)                      stages B1'
 //         phase 3: quadrant (A1,B0)  reads B0 again (4)                stages A1'
-//     vmcnt(4) leaves the two youngest half-tiles in flight; every half-tile therefore has three phases (~3.5k clocks) to
-//     land before the barrier in front of its first reader (RAW: own loads counted, then the barrier), and it is written
-//     into the buffer whose last reader finished a whole K-tile earlier (WAR).  The loads never drain to 0 in the loop.
+//     vmcnt(2) leaves the youngest half-tile in flight; every half-tile has about two phases to land before the
+//     barrier in front of its first reader (RAW: own loads counted, then the barrier), and it is written into the
+//     buffer whose last reader finished a whole K-tile earlier (WAR).  The loads never drain to 0 in the loop.
 //   * row maps put epilogue partners in ONE lane: SiLU — A0 = gate rows, A1 = up rows of the same 128 columns; RoPE —
 //     A0 = first halves, A1 = second halves of the same heads.
 //   * epilogue: results are staged in LDS (the operand buffers are dead) per 128-token half and written as 16-byte
@@ -39,6 +39,9 @@ struct G256Epi {
     int32_t H, KVH, D;
 };
 
+#ifndef G256_ABLATE_STAGE
+#define G256_ABLATE_STAGE 0       // 1: timing experiment only (no K-tile staging after the prologue: wrong results)
+#endif
 constexpr int G_BK = 64, G_HT = 128, G_HALF = G_HT * G_BK * 2;          // 16 KiB per half-tile
 constexpr int G_BUF = 4 * G_HALF;                                         // A0 A1 B0 B1
 
@@ -141,13 +144,14 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const half_t *__restrict__
     };
 
     // The two wave groups (waves 0-3 and 4-7: one wave of each per SIMD) run ONE barrier interval apart, and a phase is
-    // two intervals — R {ds_read, stage, s_waitcnt vmcnt, barrier} and M {16 MFMAs, barrier} — so that on every SIMD the
-    // fragment reads of one wave overlap the MFMAs of the other.  Group 1 takes one extra barrier before each tile's
-    // K loop, group 0 one after it.  Hazards with the stagger: a half-tile staged in phase p is first read in phase p+3;
-    // every wave counts its own loads at the end of R(p+2) (vmcnt(4): all but the two youngest half-tiles; the
-    // epilogue's stores count too, which only makes the wait stricter), i.e. group 0 in interval 2p+4 and group 1 in
-    // 2p+5, and the earliest reader (group 0, R(p+3)) runs in interval 2p+6.  A buffer is restaged no earlier than two
-    // phases after its last ds_read by either group.
+    // two intervals — R {ds_read, s_waitcnt vmcnt, barrier} and M {stage one half-tile, 16 MFMAs, barrier} — so that on
+    // every SIMD the fragment reads of one wave overlap the MFMAs of the other, and the LDS-DMA issue (~100 clocks a
+    // piece inside a read phase, ~60 among MFMAs) sits in the interval that has issue slots to spare.  Group 1 takes one
+    // extra barrier before each tile's K loop, group 0 one after it.  Hazards with the stagger: a half-tile staged in
+    // M(p) is first read in R(p+3); every wave counts its own loads at the end of R(p+2) (vmcnt(2): all but the youngest
+    // half-tile, the one of M(p+1); the epilogue's stores count too, which only makes the wait stricter), i.e. group 0
+    // in interval 2p+4 and group 1 in 2p+5, and the earliest reader (group 0, R(p+3)) runs in interval 2p+6.  A buffer is
+    // restaged no earlier than two phases after its last ds_read by either group.
     const int KT = K / G_BK;
     int tile = tile_of(u);
     set_sources(tile);
@@ -158,7 +162,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const half_t *__restrict__
 #define G256_R_END(N_)                                                                                                \
     asm volatile("s_waitcnt vmcnt(" #N_ ")" ::: "memory");                                                            \
     __builtin_amdgcn_s_barrier();
-#define G256_M(C_, HB_)                                                                                               \
+#define G256_M(C_, HB_, HT_)                                                                                          \
+    if (more && !G256_ABLATE_STAGE) stage(HT_, skt, g + 1);                                                           \
     __builtin_amdgcn_s_setprio(1);                                                                                    \
     mma(C_, HB_);                                                                                                     \
     __builtin_amdgcn_s_setprio(0);                                                                                    \
@@ -188,20 +193,20 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const half_t *__restrict__
             const int skt = last ? 0 : kt + 1;
             // phase 0: (A0, B0)
             read_b(buf, 0); read_a(buf, 0);
-            if (more) { stage(0, skt, g + 1); G256_R_END(4) } else { G256_R_END(2) }
-            G256_M(acc[0], 0)
+            G256_R_END(2)
+            G256_M(acc[0], 0, 0)
             // phase 1: (A0, B1)
             read_b(buf, 1);
-            if (more) { stage(2, skt, g + 1); G256_R_END(4) } else { G256_R_END(0) }
-            G256_M(acc[0], 1)
+            if (more) { G256_R_END(2) } else { G256_R_END(0) }
+            G256_M(acc[0], 1, 2)
             // phase 2: (A1, B1)
             read_a(buf, 1);
-            if (more) { stage(3, skt, g + 1); G256_R_END(4) } else { G256_R_END(0) }
-            G256_M(acc[1], 1)
+            if (more) { G256_R_END(2) } else { G256_R_END(0) }
+            G256_M(acc[1], 1, 3)
             // phase 3: (A1, B0)
             read_b(buf, 0);
-            if (more) { stage(1, skt, g + 1); G256_R_END(4) } else { G256_R_END(0) }
-            G256_M(acc[1], 0)
+            if (more) { G256_R_END(2) } else { G256_R_END(0) }
+            G256_M(acc[1], 0, 1)
         }
         if (grp == 0) __builtin_amdgcn_s_barrier();                       // re-align the groups
 
