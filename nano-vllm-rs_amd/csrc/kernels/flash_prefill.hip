@@ -4,7 +4,7 @@
 // Semantics (SURVEY A-9): per head softmax_f32(q·Kᵀ·D^-½ + causal mask)·V, query at absolute position p sees keys 0..p.
 // Bound: MFMA (4·D flop per query-key pair and head).
 //
-// One workgroup = 4 waves = one (tile of 128/G query positions, kv head) = 128 query rows; a wave owns TWO 16-row
+// One workgroup = FLASH_WAVES (4) waves = one (tile of 128/G query positions, kv head) = 128 query rows; a wave owns TWO 16-row
 // query tiles (G=1: two position blocks of the head; G=2: both heads of one position block; G=4: two of the four heads),
 // so every K fragment (ds_read_b128) and every V fragment (ds_read_b64_tr_b16) it reads from LDS feeds two MFMAs, and the
 // K/V tiles staged in LDS (global_load_lds, 64 keys per step, double buffered) are shared by all G heads.
@@ -47,12 +47,17 @@ __device__ __forceinline__ int v_swz(int row) { return D == 128 ? ((row & 7) << 
 #define NVR_FLASH_KT 64
 #define NVR_FLASH_NBUF 2
 #endif
+#ifndef NVR_FLASH_WAVES
+#define NVR_FLASH_WAVES 4              // measured: 8 waves (one 256-row workgroup per CU) 252 us vs 4 waves x 2 workgroups 240 us per layer
+#endif
+constexpr int FLASH_WAVES = NVR_FLASH_WAVES;     // waves per workgroup: 32 query rows each share the staged K/V tiles
 template <int D, int G, bool PAGED>
-__global__ __launch_bounds__(256, 2) void flash_prefill_kernel(FlashParams p) {     // 2 workgroups per CU: <= 256 registers per lane
+__global__ __launch_bounds__(64 * FLASH_WAVES, 8 / FLASH_WAVES) void flash_prefill_kernel(FlashParams p) {   // 2 waves per SIMD: <= 256 registers per lane
+    constexpr int NT = 64 * FLASH_WAVES;         // threads
     constexpr int KT = NVR_FLASH_KT;             // keys per step
     constexpr int NBUF = NVR_FLASH_NBUF;         // K/V tiles in the LDS ring: NBUF-1 in flight ahead of the one in use
     constexpr int CPR = D / 8;                   // 16-byte chunks per K/V row
-    constexpr int PIECES = KT * CPR / 256;       // 16-byte pieces per thread and operand
+    constexpr int PIECES = KT * CPR / NT;        // 16-byte pieces per thread and operand
     constexpr int NKS = D / 32, NDT = D / 16, NQT = 2, NMT = KT / 16, NK2 = KT / 32;
     constexpr int STAGE = 2 * KT * D * 2;        // bytes of one ring slot [K | V]
     __shared__ __attribute__((aligned(16))) char smem[NBUF * STAGE];
@@ -81,11 +86,13 @@ __global__ __launch_bounds__(256, 2) void flash_prefill_kernel(FlashParams p) { 
         for (int ks = 0; ks < NKS; ++ks) qf[t][ks] = *reinterpret_cast<const half8_t *>(qrow + ks * 32);
     }
 
+    // last key any lane of this wave may attend to: a step that starts beyond it does no arithmetic in this wave
+    const int wave_last = __builtin_amdgcn_readfirstlane(tile.pos0 + min(tile.nq - 1, (G == 1 ? wave * 2 + 1 : (G == 2 ? wave : (wave >> 1))) * 16 + 15));
     auto stage = [&](int buf, int kt) {
         char *kd = smem + buf * STAGE, *vd = kd + KT * D * 2;
 #pragma unroll
         for (int i = 0; i < PIECES; ++i) {
-            const int idx = i * 256 + threadIdx.x, row = idx / CPR, c = idx % CPR;
+            const int idx = i * NT + threadIdx.x, row = idx / CPR, c = idx % CPR;
             int key = kt + row; if (key > kv_end - 1) key = kv_end - 1;
             int64_t off;
             if (PAGED) {
@@ -97,7 +104,7 @@ __global__ __launch_bounds__(256, 2) void flash_prefill_kernel(FlashParams p) { 
             } else {
                 off = (int64_t)(tile.kv_ref + key) * p.ldkv + (int64_t)g * D;
             }
-            const int piece = (i * 256 + wave * 64) * 16;
+            const int piece = (i * NT + wave * 64) * 16;
             const int vsw = D == 128 ? ((row & 7) << 1) : (((row >> 1) & 3) << 1);      // = v_swz<D>(row), spelled out: a call here makes hipcc drop the host stub
             __builtin_amdgcn_global_load_lds(p.k + off + (c ^ (row & (CPR - 1))) * 8, (__attribute__((address_space(3))) void *)(kd + piece), 16, 0, 0);
             __builtin_amdgcn_global_load_lds(p.v + off + (c ^ vsw) * 8, (__attribute__((address_space(3))) void *)(vd + piece), 16, 0, 0);
@@ -131,6 +138,7 @@ __global__ __launch_bounds__(256, 2) void flash_prefill_kernel(FlashParams p) { 
         const bool more = it + NBUF - 1 < nsteps;
         if (more) stage((cur + NBUF - 1) % NBUF, kt + (NBUF - 1) * KT);
         const char *kl = smem + cur * STAGE, *vl = kl + KT * D * 2;
+        if (kt <= wave_last) {
 
         // Sᵀ tiles: NMT x (16 keys x 16 queries) per query tile; one K fragment read feeds both
         float4_t s[NQT][NMT];
@@ -204,6 +212,7 @@ __global__ __launch_bounds__(256, 2) void flash_prefill_kernel(FlashParams p) { 
                 for (int t = 0; t < NQT; ++t) o[t][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[t][k2], o[t][dt], 0, 0, 0);
             }
         }
+        }   // kt <= wave_last
         if (it + NBUF < nsteps) {                               // NBUF-1 younger tiles were requested: leave NBUF-2 of them flying
             if (NBUF == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             else if (NBUF == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 * 2 * PIECES) : "memory");
@@ -252,7 +261,7 @@ bool flash_prefill_ok(int D, int H, int KVH) {
     const int G = H / KVH;
     return (D == 64 || D == 128) && (G == 1 || G == 2 || G == 4);
 }
-int flash_tile_positions(int H, int KVH) { return 128 / (H / KVH); }
+int flash_tile_positions(int H, int KVH) { return 32 * FLASH_WAVES / (H / KVH); }
 
 int flash_prefill(const FlashArgs &a, bool paged, hipStream_t s) {
     if (a.ntiles == 0) return 0;
@@ -263,7 +272,7 @@ int flash_prefill(const FlashArgs &a, bool paged, hipStream_t s) {
     p.bs_shift = (a.block_size > 0 && (a.block_size & (a.block_size - 1)) == 0) ? __builtin_ctz(a.block_size) : -1;
     p.tiles = a.tiles; p.H = a.H; p.KVH = a.KVH; p.scale = a.scale; p.out = (half_t *)a.out;
     const int G = a.H / a.KVH;
-    dim3 grid((unsigned)((int64_t)a.ntiles * a.KVH)), block(256);
+    dim3 grid((unsigned)((int64_t)a.ntiles * a.KVH)), block(64 * FLASH_WAVES);
 #define NVR_FLASH(DD, GG)                                                                             \
     if (a.D == DD && G == GG) {                                                                       \
         if (paged) flash_prefill_kernel<DD, GG, true><<<grid, block, 0, s>>>(p);                      \
