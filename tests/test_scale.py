@@ -126,6 +126,27 @@ def test_config2_full_size_properties():
 
 
 @pytest.mark.gpu
+def test_config2_long_decode_graph_equals_eager():
+    """BASELINE configs[1] geometry, 300 decode steps (context 1000 -> 1300): every sequence crosses a KV block boundary
+    (new block, block hashing) and the batch crosses a 256-token context bucket (a second hipGraph is captured); the
+    replayed graphs must produce exactly the token streams of kernel-by-kernel launches."""
+    mc = nvr.ModelConfig("qwen3-0.6b")
+    ecfg = dict(max_num_seqs=32, max_num_batched_tokens=32768, max_model_len=1400, kvcache_block_size=256, num_kvcache_blocks=200)
+
+    def run(**kw):
+        nvr.lib().nvr_seq_reset_id_counter()
+        eng = nvr.LLMEngine(nvr.Config(**ecfg, **kw), mc)
+        for i in range(32):
+            eng.add_request(nvr.synthetic_tokens(1000, 1, i, 151936).tolist(), nvr.SamplingParams(temperature=0.0, max_tokens=300, ignore_eos=True))
+        toks = []
+        while not eng.is_finished():
+            toks.append(tuple(eng.step()["tokens"]))
+        return toks
+    g, e = run(), run(enforce_eager=1)
+    assert len(g) == 300 and g == e
+
+
+@pytest.mark.gpu
 def test_config5_full_size_prefix_skipping():
     """BASELINE configs[4] at full size (Qwen3-0.6B, 512 sequences = one 512-token system prompt + 64 own tokens, block
     size 256): with cached-prefix skipping the prefill feeds 576 + 511 x 64 rows through the model instead of 512 x 576,
