@@ -100,6 +100,15 @@ def time_attention_kernel(nvr, eng, mc, reps: int) -> dict:
     return dict(us_per_launch=us, launches=launches, alg_bytes=alg_bytes, ctx_sum=int(ctx.sum()))
 
 
+def _pmc_prefill_busy():
+    """Counter-based MFMA utilisation of the prefill step (separate rocprofv3 --pmc pass, committed under profiles/)."""
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_mfma_prefill_latest.json")) as f:
+            return json.load(f).get("prefill_step_weighted")
+    except Exception:                                        # noqa: BLE001
+        return None
+
+
 def cpu_baseline(decode_steps: int = 12) -> dict:
     """Oracle engine on BASELINE.json configs[0]: Qwen3-0.6B f32, bs=1, prompt 128, greedy (a port)."""
     import oracle
@@ -260,7 +269,10 @@ def main() -> None:
                        "logits": "materialised every step" if args.materialize_logits else "greedy arg-max fused into the LM head; f32 logits on demand"},
             "prefill": {"tokens": BATCH * PROMPT_LEN, "seconds": round(t_prefill, 4), "tokens_per_s": round(BATCH * PROMPT_LEN / t_prefill, 1),
                         "tflop_per_s": round(prefill_flop / t_prefill / 1e12, 1), "mfma_frac_of_2500": round(prefill_flop / t_prefill / 2.5e15, 4),
-                        "note": "one untimed engine prefill step (wall clock, includes host input preparation and upload)"},
+                        "mfma_busy_frac_pmc": _pmc_prefill_busy(),
+                        "note": "one untimed engine prefill step (wall clock, includes host input preparation and upload); "
+                                "mfma_busy_frac_pmc = matrix-pipe busy cycles / available cycles at the clock the chip held, from the "
+                                "committed counter pass profiles/pmc_mfma_prefill_latest.json (tp1 kernels)"},
             "step_hbm_frac": round(step_gbs / HBM_PEAK_GBS, 4),
             "step_algorithmic_bytes": int(step_bytes),
             "roofline": {"kernel": "attn_rows_kernel (paged decode attention, K9)", "bound": "hbm", "achieved": round(achieved, 1),
