@@ -141,6 +141,27 @@ def test_cached_prefix_skipping_is_bit_identical():
     assert r["near_ties"] <= 2, r
 
 
+@pytest.mark.parametrize("shape", [
+    # hidden, inter, heads, kv heads, head_dim, vocab, block size, prompt lengths
+    dict(h=128, i=256, H=2, KVH=2, D=64, V=512, bs=4, lens=[3, 9, 21, 70]),          # G=1, tiny blocks (row groups straddle blocks)
+    dict(h=256, i=384, H=8, KVH=1, D=64, V=1008, bs=16, lens=[40, 5, 17]),           # G=8: outside the MFMA flash kernel (row-kernel prefill)
+    dict(h=512, i=768, H=4, KVH=4, D=128, V=2048, bs=48, lens=[100, 47, 140, 1]),    # non-power-of-two block size, G=1, D=128
+    dict(h=2048, i=1024, H=16, KVH=4, D=128, V=4096, bs=32, lens=[33, 64, 2]),       # hidden 2048 (16-wave GEMMs, 4 row chunks in the slab norm)
+    dict(h=4096, i=512, H=8, KVH=8, D=64, V=256, bs=16, lens=[20, 8]),               # hidden 4096: no split-k slabs, plain norm path, LM head K > 2048
+])
+def test_engine_parity_across_kernel_variants(shape):
+    """Model shapes that steer the runner through its other kernel variants (GQA group sizes, head dims, block sizes,
+    hidden sizes beyond the fused paths' limits): the engine must stay in parity with the oracle on all of them."""
+    mcfg = mo.ModelConfig(vocab_size=shape["V"], hidden_size=shape["h"], intermediate_size=shape["i"], num_hidden_layers=2,
+                          num_attention_heads=shape["H"], num_key_value_heads=shape["KVH"], head_dim=shape["D"], rms_norm_eps=1e-6,
+                          rope_theta=10000.0, tie_word_embeddings=False, max_position_embeddings=512, init_std=0.05, seed=21)
+    ecfg = dict(max_num_seqs=8, max_num_batched_tokens=512, max_model_len=256, kvcache_block_size=shape["bs"], num_kvcache_blocks=400 // shape["bs"] * 8)
+    prompts = [oracle.fill_tokens(n, 4, i, mcfg.vocab_size).tolist() for i, n in enumerate(shape["lens"])]
+    sps = [dict(temperature=0.0, max_tokens=10, ignore_eos=True)] * len(prompts)
+    r = _run_pair(mcfg, ecfg, prompts, sps)
+    assert r["near_ties"] <= 3, r
+
+
 def test_gqa4_head_dim_128_model():
     """Qwen3-8B-like head geometry (32:8 grouping scaled down, D=128) and block size 256."""
     mcfg = mo.ModelConfig(vocab_size=2048, hidden_size=512, intermediate_size=1024, num_hidden_layers=2,
