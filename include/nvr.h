@@ -195,6 +195,20 @@ NVR_API int nvr_runner_execute_model(nvr_model_runner_t *r, nvr_seq_t *const *se
 /* :131 — samples from the logits of the last execute_model; writes n token ids (host) */
 NVR_API int nvr_runner_sample_tokens(nvr_model_runner_t *r, nvr_seq_t *const *seqs, size_t n, int64_t *out_ids);
 NVR_API int nvr_runner_copy_logits(nvr_model_runner_t *r, float *host_out, size_t rows); /* D2H, tests */
+/* Weight loading (Qwen3Model::load_weights qwen3.rs:518-570, ModelLoader utils/loader.rs:43-198): one
+ * FULL (un-sharded) checkpoint tensor by its name — "embed_tokens.weight", "norm.weight", "lm_head.weight",
+ * "layers.N.input_layernorm.weight", "layers.N.post_attention_layernorm.weight", "layers.N.self_attn.{q,k,v,o,qkv}_proj.weight",
+ * "layers.N.mlp.{gate,up,gate_up,down}_proj.weight", with or without the HF "model." prefix — is converted to fp16
+ * (dtype: 0 = f16, 1 = bf16, 2 = f32; row-major, shape[ndim]) and this rank's slice is written into the packed device
+ * parameter by the reference's shard rules (ColumnParallelLinear::load_weight linear.rs:154-171 narrows dim 0,
+ * RowParallelLinear::load_weight :249-267 dim 1, VocabParallelEmbedding embed_head.rs:142-161).  A wrong shape is
+ * NVR_ERR_LEN_MISMATCH ("Partition weight shape mismatch"), a name outside the reference graph NVR_ERR_UNSUPPORTED.
+ * nvr_runner_copy_weight reads a LOCAL packed tensor back ("embed", "lm_head", "norm", "layers.N.{qkv,o,gate_up,down,ln1,ln2}");
+ * host_out may be NULL to query the shape. */
+NVR_API int nvr_runner_load_tensor(nvr_model_runner_t *r, const char *name, int dtype, const int64_t *shape, int ndim,
+                                   const void *host_data);
+NVR_API int nvr_runner_copy_weight(nvr_model_runner_t *r, const char *local_name, uint16_t *host_out, size_t cap_elems,
+                                   int64_t *rows, int64_t *cols);
 NVR_API uint64_t nvr_runner_num_kvcache_blocks(const nvr_model_runner_t *r);
 /* KV pool of layer l (borrowed device pointers, fp16 [NB, bs, KVH/tp, D], model_runner.rs:364-396) */
 NVR_API int nvr_runner_kv_cache(nvr_model_runner_t *r, size_t layer, void **k_dev, void **v_dev);

@@ -133,6 +133,8 @@ _SIGS = {
     "nvr_runner_create": (_P, [C.POINTER(ConfigC), C.POINTER(ModelConfigC)]), "nvr_runner_destroy": (None, [_P]),
     "nvr_runner_execute_model": (C.c_int, [_P, C.POINTER(_P), C.c_size_t, C.c_int, C.POINTER(_P)]),
     "nvr_runner_sample_tokens": (C.c_int, [_P, C.POINTER(_P), C.c_size_t, _P]),
+    "nvr_runner_load_tensor": (C.c_int, [_P, C.c_char_p, C.c_int, _P, C.c_int, _P]),
+    "nvr_runner_copy_weight": (C.c_int, [_P, C.c_char_p, _P, C.c_size_t, _P, _P]),
     "nvr_runner_copy_logits": (C.c_int, [_P, _P, C.c_size_t]),
     "nvr_runner_num_kvcache_blocks": (C.c_uint64, [_P]),
     "nvr_runner_kv_cache": (C.c_int, [_P, C.c_size_t, C.POINTER(_P), C.POINTER(_P)]),
@@ -506,6 +508,46 @@ class ModelRunner:
         out = np.empty((rows, v), dtype=np.float32)
         check(lib().nvr_runner_copy_logits(self.h, out.ctypes.data, rows))
         return out
+
+    # -- weight loading (Qwen3Model::load_weights qwen3.rs:518-570, utils/loader.rs) --------------------
+    def load_tensor(self, name: str, array: np.ndarray) -> None:
+        """One full (un-sharded) checkpoint tensor by name; this rank's slice lands in the packed device parameter."""
+        a = np.ascontiguousarray(array)
+        if a.dtype == np.float16:
+            dt = 0
+        elif a.dtype == np.float32:
+            dt = 2
+        elif a.dtype == np.uint16:          # bfloat16 bits (numpy has no bf16)
+            dt = 1
+        else:
+            a, dt = a.astype(np.float32), 2
+        shape = (C.c_int64 * a.ndim)(*a.shape)
+        check(lib().nvr_runner_load_tensor(self.h, name.encode(), dt, shape, a.ndim, a.ctypes.data))
+
+    def load_safetensors(self, path: str, strict: bool = False) -> List[str]:
+        """Every tensor of a .safetensors file (or of all such files in a directory).  Returns the names that are not part
+        of the reference's Qwen3 graph (q/k-norm, biases ...); strict=True raises on them instead."""
+        from safetensors import safe_open
+        files = sorted(os.path.join(path, f) for f in os.listdir(path) if f.endswith(".safetensors")) if os.path.isdir(path) else [path]
+        skipped = []
+        for fn in files:
+            with safe_open(fn, framework="np") as f:
+                for name in f.keys():
+                    try:
+                        self.load_tensor(name, f.get_tensor(name))
+                    except NvrError as e:
+                        if e.code != -10 or strict:
+                            raise
+                        skipped.append(name)
+        return skipped
+
+    def weight(self, local_name: str) -> np.ndarray:
+        """A local packed tensor as fp16: "embed", "lm_head", "norm", "layers.N.{qkv,o,gate_up,down,ln1,ln2}"."""
+        r, c = C.c_int64(), C.c_int64()
+        check(lib().nvr_runner_copy_weight(self.h, local_name.encode(), None, 0, C.byref(r), C.byref(c)))
+        out = np.empty((r.value, c.value), np.float16)
+        check(lib().nvr_runner_copy_weight(self.h, local_name.encode(), out.ctypes.data, out.size, C.byref(r), C.byref(c)))
+        return out[:, 0] if c.value == 1 else out
 
     def num_kvcache_blocks(self) -> int:
         return lib().nvr_runner_num_kvcache_blocks(self.h)

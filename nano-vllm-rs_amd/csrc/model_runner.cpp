@@ -3,7 +3,9 @@
 #include "model_runner.h"
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
+#include <vector>
 #include "common.h"
 #include "kernels/kernels.h"
 #include "kernels/device_utils.h"
@@ -205,6 +207,112 @@ int nvr_model_runner::gen_weights() {
     }
     RC(dmalloc(&norm, Hd)); RC(k::fill_const(norm, Hd, 1.0f, stream));
     NVR_HIP_CHECK(hipStreamSynchronize(stream));
+    return NVR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Weight loading.  The reference's loaders only narrow and shape-check (ColumnParallelLinear::load_weight
+// linear.rs:154-171: narrow(0, rank*out_per_partition); RowParallelLinear::load_weight :249-267: narrow(1,
+// rank*in_per_partition); VocabParallelEmbedding embed_head.rs:142-161; Qwen3Model::load_weights qwen3.rs:518-570 names
+// "embed_tokens.weight", "layers.N.input_layernorm.weight", ..., "norm.weight", "lm_head.weight") and never fill the
+// packed tensors; here the same shard rules write this rank's slice of qkv_proj ([q | k | v] rows), gate_up_proj
+// ([gate | up] rows), o_proj / down_proj (input columns) and the vocabulary shard of the LM head.
+namespace {
+inline uint16_t f32_to_f16_bits(float f) { _Float16 h = (_Float16)f; uint16_t b; std::memcpy(&b, &h, 2); return b; }
+inline float bf16_bits_to_f32(uint16_t b) { uint32_t u = (uint32_t)b << 16; float f; std::memcpy(&f, &u, 4); return f; }
+bool match_layer(const char *name, const char *suffix, int64_t *layer) {          // "layers.<l>.<suffix>"
+    if (std::strncmp(name, "layers.", 7) != 0) return false;
+    char *end = nullptr;
+    const long l = std::strtol(name + 7, &end, 10);
+    if (end == name + 7 || *end != '.') return false;
+    if (std::strcmp(end + 1, suffix) != 0) return false;
+    *layer = l;
+    return true;
+}
+}  // namespace
+
+int nvr_model_runner::load_tensor(const char *name_in, int dtype, const int64_t *shape, int ndim, const void *data) {
+    NVR_HIP_CHECK(hipSetDevice(device));
+    if (!name_in || !shape || !data || ndim < 1 || ndim > 2) return nvr::fail(NVR_ERR_INVALID_ARG, "load_tensor: bad arguments");
+    if (dtype < 0 || dtype > 2) return nvr::fail(NVR_ERR_INVALID_ARG, "load_tensor: dtype %d (0 = f16, 1 = bf16, 2 = f32)", dtype);
+    const char *name = std::strncmp(name_in, "model.", 6) == 0 ? name_in + 6 : name_in;
+    const int64_t R = shape[0], Cc = ndim == 2 ? shape[1] : 1;
+    const int64_t Hg = mc.num_attention_heads, KVHg = mc.num_key_value_heads, Ig = mc.intermediate_size;
+    auto want = [&](int64_t r, int64_t c) -> int {
+        if (R != r || Cc != c || (ndim == 1) != (c == 1 && ndim == 1))
+            return nvr::fail(NVR_ERR_LEN_MISMATCH, "Partition weight shape mismatch: %s expected [%ld, %ld], got [%ld, %ld]", name_in,
+                             (long)r, (long)c, (long)R, (long)Cc);
+        return NVR_OK;
+    };
+    // rows [r0, r0+nr) x columns [c0, c0+nc) of the source -> dst (row stride dst_ld)
+    auto put = [&](uint16_t *dst, int64_t dst_ld, int64_t r0, int64_t nr, int64_t c0, int64_t nc) -> int {
+        std::vector<uint16_t> st((size_t)(nr * nc));
+        for (int64_t r = 0; r < nr; ++r)
+            for (int64_t c = 0; c < nc; ++c) {
+                const size_t si = (size_t)((r0 + r) * Cc + c0 + c);
+                uint16_t b;
+                if (dtype == 0) b = ((const uint16_t *)data)[si];
+                else if (dtype == 1) b = f32_to_f16_bits(bf16_bits_to_f32(((const uint16_t *)data)[si]));
+                else b = f32_to_f16_bits(((const float *)data)[si]);
+                st[(size_t)(r * nc + c)] = b;
+            }
+        NVR_HIP_CHECK(hipStreamSynchronize(stream));
+        NVR_HIP_CHECK(hipMemcpy2D(dst, (size_t)dst_ld * 2, st.data(), (size_t)nc * 2, (size_t)nc * 2, (size_t)nr, hipMemcpyHostToDevice));
+        return NVR_OK;
+    };
+    int64_t l = -1;
+    if (!std::strcmp(name, "embed_tokens.weight")) { RC(want(V, Hd)); return put(embed, Hd, 0, V, 0, Hd); }           // replicated (§8e)
+    if (!std::strcmp(name, "norm.weight")) { if (ndim != 1) return want(-1, -1); RC(want(Hd, 1)); return put(norm, 1, 0, Hd, 0, 1); }
+    if (!std::strcmp(name, "lm_head.weight")) {
+        RC(want(V, Hd));
+        if (mc.tie_word_embeddings) return nvr::fail(NVR_ERR_UNSUPPORTED, "lm_head.weight: tie_word_embeddings is set (qwen3.rs:461-473), the head is the embedding");
+        return put(lm_head, Hd, vocab_start, Vl, 0, Hd);                                                              // embed_head.rs:57-59
+    }
+    auto layer_ok = [&]() -> int { return (l < 0 || l >= L) ? nvr::fail(NVR_ERR_INVALID_ARG, "%s: layer out of range (0..%ld)", name_in, (long)L - 1) : NVR_OK; };
+    if (match_layer(name, "input_layernorm.weight", &l)) { RC(layer_ok()); RC(want(Hd, 1)); return put(layers[l].ln1, 1, 0, Hd, 0, 1); }
+    if (match_layer(name, "post_attention_layernorm.weight", &l)) { RC(layer_ok()); RC(want(Hd, 1)); return put(layers[l].ln2, 1, 0, Hd, 0, 1); }
+    // QKVParallelLinear: local rows [q heads | k heads | v heads] (linear.rs:300-340), each a rank slice of its projection
+    if (match_layer(name, "self_attn.q_proj.weight", &l)) { RC(layer_ok()); RC(want(Hg * D, Hd)); return put(layers[l].qkv, Hd, rank * H * D, H * D, 0, Hd); }
+    if (match_layer(name, "self_attn.k_proj.weight", &l)) { RC(layer_ok()); RC(want(KVHg * D, Hd)); return put(layers[l].qkv + H * D * Hd, Hd, rank * KVH * D, KVH * D, 0, Hd); }
+    if (match_layer(name, "self_attn.v_proj.weight", &l)) { RC(layer_ok()); RC(want(KVHg * D, Hd)); return put(layers[l].qkv + (H + KVH) * D * Hd, Hd, rank * KVH * D, KVH * D, 0, Hd); }
+    if (match_layer(name, "self_attn.qkv_proj.weight", &l)) {                                                          // packed, global [q | k | v]
+        RC(layer_ok()); RC(want((Hg + 2 * KVHg) * D, Hd));
+        RC(put(layers[l].qkv, Hd, rank * H * D, H * D, 0, Hd));
+        RC(put(layers[l].qkv + H * D * Hd, Hd, Hg * D + rank * KVH * D, KVH * D, 0, Hd));
+        return put(layers[l].qkv + (H + KVH) * D * Hd, Hd, (Hg + KVHg) * D + rank * KVH * D, KVH * D, 0, Hd);
+    }
+    if (match_layer(name, "self_attn.o_proj.weight", &l)) { RC(layer_ok()); RC(want(Hd, Hg * D)); return put(layers[l].o, H * D, 0, Hd, rank * H * D, H * D); }   // :249-267
+    // MergedColumnParallelLinear: local rows [gate | up] (linear.rs:378-454)
+    if (match_layer(name, "mlp.gate_proj.weight", &l)) { RC(layer_ok()); RC(want(Ig, Hd)); return put(layers[l].gate_up, Hd, rank * I, I, 0, Hd); }
+    if (match_layer(name, "mlp.up_proj.weight", &l)) { RC(layer_ok()); RC(want(Ig, Hd)); return put(layers[l].gate_up + I * Hd, Hd, rank * I, I, 0, Hd); }
+    if (match_layer(name, "mlp.gate_up_proj.weight", &l)) {
+        RC(layer_ok()); RC(want(2 * Ig, Hd));
+        RC(put(layers[l].gate_up, Hd, rank * I, I, 0, Hd));
+        return put(layers[l].gate_up + I * Hd, Hd, Ig + rank * I, I, 0, Hd);
+    }
+    if (match_layer(name, "mlp.down_proj.weight", &l)) { RC(layer_ok()); RC(want(Hd, Ig)); return put(layers[l].down, I, 0, Hd, rank * I, I); }
+    return nvr::fail(NVR_ERR_UNSUPPORTED, "load_tensor: no parameter named '%s' in this graph (q/k-norm and biases are not part of the reference's Qwen3 graph, SURVEY A-17)", name_in);
+}
+
+int nvr_model_runner::copy_weight(const char *ln, uint16_t *out, size_t cap, int64_t *rows, int64_t *cols) {
+    NVR_HIP_CHECK(hipSetDevice(device));
+    const uint16_t *src = nullptr; int64_t r = 0, c = 0, l = -1;
+    if (!std::strcmp(ln, "embed")) { src = embed; r = V; c = Hd; }
+    else if (!std::strcmp(ln, "lm_head")) { src = lm_head; r = Vl; c = Hd; }
+    else if (!std::strcmp(ln, "norm")) { src = norm; r = Hd; c = 1; }
+    else if (match_layer(ln, "qkv", &l) && l >= 0 && l < L) { src = layers[l].qkv; r = QKV; c = Hd; }
+    else if (match_layer(ln, "o", &l) && l >= 0 && l < L) { src = layers[l].o; r = Hd; c = H * D; }
+    else if (match_layer(ln, "gate_up", &l) && l >= 0 && l < L) { src = layers[l].gate_up; r = 2 * I; c = Hd; }
+    else if (match_layer(ln, "down", &l) && l >= 0 && l < L) { src = layers[l].down; r = Hd; c = I; }
+    else if (match_layer(ln, "ln1", &l) && l >= 0 && l < L) { src = layers[l].ln1; r = Hd; c = 1; }
+    else if (match_layer(ln, "ln2", &l) && l >= 0 && l < L) { src = layers[l].ln2; r = Hd; c = 1; }
+    else return nvr::fail(NVR_ERR_INVALID_ARG, "copy_weight: unknown local tensor '%s'", ln);
+    if (rows) *rows = r;
+    if (cols) *cols = c;
+    if (!out) return NVR_OK;
+    if ((size_t)(r * c) > cap) return nvr::fail(NVR_ERR_LEN_MISMATCH, "copy_weight: %s has %ld elements, buffer holds %zu", ln, (long)(r * c), cap);
+    NVR_HIP_CHECK(hipStreamSynchronize(stream));
+    NVR_HIP_CHECK(hipMemcpy(out, src, (size_t)(r * c) * 2, hipMemcpyDeviceToHost));
     return NVR_OK;
 }
 

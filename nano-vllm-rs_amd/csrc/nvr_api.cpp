@@ -195,6 +195,12 @@ int nvr_runner_execute_model(nvr_model_runner_t *r, nvr_seq_t *const *seqs, size
 int nvr_runner_sample_tokens(nvr_model_runner_t *r, nvr_seq_t *const *seqs, size_t n, int64_t *out) {
     NVR_GUARD_BEGIN return r->sample(seqs, n, out); NVR_GUARD_END(NVR_ERR_INVARIANT)
 }
+int nvr_runner_load_tensor(nvr_model_runner_t *r, const char *name, int dtype, const int64_t *shape, int ndim, const void *data) {
+    NVR_GUARD_BEGIN return r->load_tensor(name, dtype, shape, ndim, data); NVR_GUARD_END(NVR_ERR_INVARIANT)
+}
+int nvr_runner_copy_weight(nvr_model_runner_t *r, const char *local_name, uint16_t *host_out, size_t cap, int64_t *rows, int64_t *cols) {
+    NVR_GUARD_BEGIN return r->copy_weight(local_name, host_out, cap, rows, cols); NVR_GUARD_END(NVR_ERR_INVARIANT)
+}
 int nvr_runner_copy_logits(nvr_model_runner_t *r, float *host_out, size_t rows) {
     if (rows > r->last_rows) return nvr::fail(NVR_ERR_LEN_MISMATCH, "copy_logits: %zu rows requested, %zu available", rows, r->last_rows);
     NVR_HIP_CHECK(hipSetDevice(r->device));

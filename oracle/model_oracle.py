@@ -151,6 +151,70 @@ class OracleModel:
                                        weight_key(c.seed, TID_LM_HEAD), sc, f16)
         self.norm = np.ones(Hd, np.float32)
 
+    # -- checkpoint tensors ---------------------------------------------------------------------------
+    def load_state_dict(self, sd: Dict[str, np.ndarray]) -> List[str]:
+        """Full (un-sharded) tensors by their HF / reference names (Qwen3Model::load_weights qwen3.rs:518-570) -> this rank's
+        slices by the reference's shard rules: ColumnParallelLinear::load_weight narrows dim 0 by rank*out_per_partition
+        (linear.rs:154-171), RowParallelLinear::load_weight dim 1 (:249-267), the LM head takes its vocabulary rows
+        (embed_head.rs:57-59,142-161); qkv_proj is [q | k | v] rows, gate_up_proj [gate | up] rows (linear.rs:300-340,
+        378-454).  Values are rounded to fp16 in fp16 mode.  Returns the names outside the reference graph."""
+        c, r = self.cfg, self.tp_rank
+        D, Hd, H, KVH, I = self.D, self.Hd, self.H, self.KVH, self.I
+        Hg, KVHg, Ig = c.num_attention_heads, c.num_key_value_heads, c.intermediate_size
+        skipped = []
+
+        def want(a, shape, name):
+            if tuple(a.shape) != tuple(shape):
+                raise ValueError(f"Partition weight shape mismatch: {name} expected {list(shape)}, got {list(a.shape)}")
+            return self._r(np.asarray(a, np.float32))
+        for full, a in sd.items():
+            name = full[6:] if full.startswith("model.") else full
+            parts = name.split(".")
+            if name == "embed_tokens.weight":
+                self.embed = want(a, (self.V, Hd), full)
+                if c.tie_word_embeddings:
+                    self.lm_head = self.embed[self.vocab_start:self.vocab_end]
+            elif name == "norm.weight":
+                self.norm = want(a, (Hd,), full)
+            elif name == "lm_head.weight":
+                if c.tie_word_embeddings:
+                    raise ValueError("lm_head.weight: tie_word_embeddings is set")
+                self.lm_head = want(a, (self.V, Hd), full)[self.vocab_start:self.vocab_end]
+            elif parts[0] == "layers" and parts[1].isdigit() and 0 <= int(parts[1]) < c.num_hidden_layers:
+                W, rest = self.layers[int(parts[1])], ".".join(parts[2:])
+                if rest == "input_layernorm.weight":
+                    W["ln1"] = want(a, (Hd,), full)
+                elif rest == "post_attention_layernorm.weight":
+                    W["ln2"] = want(a, (Hd,), full)
+                elif rest == "self_attn.q_proj.weight":
+                    W["qkv"][:H * D] = want(a, (Hg * D, Hd), full)[r * H * D:(r + 1) * H * D]
+                elif rest == "self_attn.k_proj.weight":
+                    W["qkv"][H * D:(H + KVH) * D] = want(a, (KVHg * D, Hd), full)[r * KVH * D:(r + 1) * KVH * D]
+                elif rest == "self_attn.v_proj.weight":
+                    W["qkv"][(H + KVH) * D:] = want(a, (KVHg * D, Hd), full)[r * KVH * D:(r + 1) * KVH * D]
+                elif rest == "self_attn.qkv_proj.weight":
+                    w = want(a, ((Hg + 2 * KVHg) * D, Hd), full)
+                    W["qkv"][:H * D] = w[r * H * D:(r + 1) * H * D]
+                    W["qkv"][H * D:(H + KVH) * D] = w[Hg * D + r * KVH * D:Hg * D + (r + 1) * KVH * D]
+                    W["qkv"][(H + KVH) * D:] = w[(Hg + KVHg) * D + r * KVH * D:(Hg + KVHg) * D + (r + 1) * KVH * D]
+                elif rest == "self_attn.o_proj.weight":
+                    W["o"] = np.ascontiguousarray(want(a, (Hd, Hg * D), full)[:, r * H * D:(r + 1) * H * D])
+                elif rest == "mlp.gate_proj.weight":
+                    W["gate_up"][:I] = want(a, (Ig, Hd), full)[r * I:(r + 1) * I]
+                elif rest == "mlp.up_proj.weight":
+                    W["gate_up"][I:] = want(a, (Ig, Hd), full)[r * I:(r + 1) * I]
+                elif rest == "mlp.gate_up_proj.weight":
+                    w = want(a, (2 * Ig, Hd), full)
+                    W["gate_up"][:I] = w[r * I:(r + 1) * I]
+                    W["gate_up"][I:] = w[Ig + r * I:Ig + (r + 1) * I]
+                elif rest == "mlp.down_proj.weight":
+                    W["down"] = np.ascontiguousarray(want(a, (Hd, Ig), full)[:, r * I:(r + 1) * I])
+                else:
+                    skipped.append(full)
+            else:
+                skipped.append(full)
+        return skipped
+
     def _r(self, x: np.ndarray) -> np.ndarray:
         return round_f16(x) if self.fp16 else x
 

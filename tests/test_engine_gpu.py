@@ -30,11 +30,16 @@ def _model_cfgs(mcfg: mo.ModelConfig):
     return m
 
 
-def _run_pair(mcfg, ecfg: dict, prompts, sps, max_steps=400, fp16=True, enforce_eager=False):
+def _run_pair(mcfg, ecfg: dict, prompts, sps, max_steps=400, fp16=True, enforce_eager=False, checkpoint=None):
     eo.reset_sequence_counter()
     nvr.lib().nvr_seq_reset_id_counter()
     o = mo.OracleEngine(mcfg, eo.Config(**ecfg), fp16=fp16, max_pos=ecfg["max_model_len"])
     p = nvr.LLMEngine(nvr.Config(skip_block_size_check=1, enforce_eager=enforce_eager, **ecfg), _model_cfgs(mcfg))
+    if checkpoint is not None:                       # (state dict, .safetensors path): same tensors into both engines
+        sd, path = checkpoint
+        for rk in o.ranks:
+            assert rk.load_state_dict(sd) == []
+        assert p.model_runner.load_safetensors(path) == []
     for pr, sp in zip(prompts, sps):
         o.add_request(pr, eo.SamplingParams(**sp))
         p.add_request(pr, nvr.SamplingParams(**sp))
@@ -160,6 +165,83 @@ def test_engine_parity_across_kernel_variants(shape):
     sps = [dict(temperature=0.0, max_tokens=10, ignore_eos=True)] * len(prompts)
     r = _run_pair(mcfg, ecfg, prompts, sps)
     assert r["near_ties"] <= 3, r
+
+
+def test_checkpoint_weights_end_to_end(tmp_path):
+    """a checkpoint in the HF / reference naming (separate q/k/v and gate/up projections, RMSNorm weights
+    that are NOT all ones, untied LM head; stored as f16, bf16 and f32 tensors) goes through a .safetensors file into the
+    packed device parameters, and the engine stays in parity with the oracle that loaded the same tensors."""
+    from safetensors.numpy import save_file
+    mcfg = mo.small(seed=3)
+    rng = np.random.default_rng(77)
+    Hd, I, H, KVH, D, V, L = mcfg.hidden_size, mcfg.intermediate_size, mcfg.num_attention_heads, mcfg.num_key_value_heads, mcfg.hd(), mcfg.vocab_size, mcfg.num_hidden_layers
+    w = lambda *shape: (rng.standard_normal(shape) * 0.05).astype(np.float16)
+    sd = {"model.embed_tokens.weight": w(V, Hd), "model.norm.weight": (1 + 0.2 * rng.standard_normal(Hd)).astype(np.float32),
+          "lm_head.weight": w(V, Hd).astype(np.float32)}
+    for l in range(L):
+        pre = f"model.layers.{l}."
+        sd[pre + "input_layernorm.weight"] = (1 + 0.2 * rng.standard_normal(Hd)).astype(np.float16)
+        sd[pre + "post_attention_layernorm.weight"] = (1 + 0.2 * rng.standard_normal(Hd)).astype(np.float16)
+        sd[pre + "self_attn.q_proj.weight"] = w(H * D, Hd)
+        sd[pre + "self_attn.k_proj.weight"] = w(KVH * D, Hd)
+        sd[pre + "self_attn.v_proj.weight"] = w(KVH * D, Hd).astype(np.float32)
+        sd[pre + "self_attn.o_proj.weight"] = w(Hd, H * D)
+        sd[pre + "mlp.gate_proj.weight"] = w(I, Hd)
+        sd[pre + "mlp.up_proj.weight"] = w(I, Hd)
+        sd[pre + "mlp.down_proj.weight"] = w(Hd, I)
+    path = str(tmp_path / "model.safetensors")
+    save_file(sd, path)
+    ecfg = dict(max_num_seqs=4, max_num_batched_tokens=256, max_model_len=128, kvcache_block_size=16, num_kvcache_blocks=40)
+    prompts = [oracle.fill_tokens(n, 6, i, V).tolist() for i, n in enumerate([19, 40, 7])]
+    sps = [dict(temperature=0.0, max_tokens=12, ignore_eos=True)] * 3
+    r = _run_pair(mcfg, ecfg, prompts, sps, checkpoint=(sd, path))
+    assert r["near_ties"] <= 2, r
+    # the synthetic-weight run of the same prompts gives other tokens: the checkpoint really is what ran
+    r0 = _run_pair(mcfg, ecfg, prompts, sps)
+    assert r0["finished"] != r["finished"]
+
+
+def test_checkpoint_shards_dtypes_and_errors():
+    """Tensor-parallel slices of a full checkpoint (no communicator needed to look at them): each rank's packed tensors
+    equal the oracle rank's, bit for bit; bf16 / f32 sources are converted to fp16 (RNE); wrong shapes and names outside
+    the reference graph are reported with the reference's error text / UNSUPPORTED."""
+    mcfg = mo.small(seed=3)
+    rng = np.random.default_rng(78)
+    Hd, I, H, KVH, D, V = mcfg.hidden_size, mcfg.intermediate_size, mcfg.num_attention_heads, mcfg.num_key_value_heads, mcfg.hd(), mcfg.vocab_size
+    f32 = lambda *shape: (rng.standard_normal(shape) * 0.05).astype(np.float32)
+    sd = {"layers.1.self_attn.qkv_proj.weight": f32((H + 2 * KVH) * D, Hd), "layers.1.self_attn.o_proj.weight": f32(Hd, H * D),
+          "layers.0.mlp.gate_up_proj.weight": f32(2 * I, Hd), "layers.0.mlp.down_proj.weight": f32(Hd, I),
+          "embed_tokens.weight": f32(V, Hd), "lm_head.weight": f32(V, Hd), "norm.weight": f32(Hd),
+          "layers.0.input_layernorm.weight": f32(Hd)}
+    for rank in range(2):
+        om = mo.OracleModel(mcfg, 4, 16, True, rank, 2)
+        assert om.load_state_dict(sd) == []
+        mr = nvr.ModelRunner(nvr.Config(skip_block_size_check=1, max_num_seqs=2, max_num_batched_tokens=64, max_model_len=64, kvcache_block_size=16,
+                                        num_kvcache_blocks=4, tensor_parallel_size=2, tensor_parallel_rank=rank), _model_cfgs(mcfg))
+        for k, v in sd.items():
+            mr.load_tensor(k, v)
+        for local, ref in [("layers.1.qkv", om.layers[1]["qkv"]), ("layers.1.o", om.layers[1]["o"]), ("layers.0.gate_up", om.layers[0]["gate_up"]),
+                           ("layers.0.down", om.layers[0]["down"]), ("embed", om.embed), ("lm_head", om.lm_head), ("norm", om.norm),
+                           ("layers.0.ln1", om.layers[0]["ln1"])]:
+            got = mr.weight(local).astype(np.float32)
+            assert got.shape == ref.shape and np.array_equal(got, ref), (rank, local)
+        # an untouched tensor keeps its synthetic values
+        assert np.array_equal(mr.weight("layers.0.qkv").astype(np.float32), om.layers[0]["qkv"])
+    # bf16 source: bits -> f32 -> fp16
+    vals = f32(Hd)
+    bf = (vals.view(np.uint32) >> 16).astype(np.uint16)
+    mr.load_tensor("model.layers.0.post_attention_layernorm.weight", bf)
+    back = (bf.astype(np.uint32) << 16).view(np.float32).astype(np.float16)
+    assert np.array_equal(mr.weight("layers.0.ln2"), back)
+    with pytest.raises(nvr.NvrError) as e:
+        mr.load_tensor("layers.0.mlp.down_proj.weight", f32(Hd, I + 16))
+    assert e.value.code == -4 and "Partition weight shape mismatch" in str(e.value)
+    with pytest.raises(nvr.NvrError) as e:
+        mr.load_tensor("layers.0.self_attn.q_norm.weight", f32(D))
+    assert e.value.code == -10
+    with pytest.raises(nvr.NvrError) as e:
+        mr.load_tensor("layers.9.mlp.down_proj.weight", f32(Hd, I))
+    assert e.value.code == -7
 
 
 def test_gqa4_head_dim_128_model():
