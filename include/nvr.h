@@ -234,6 +234,20 @@ NVR_API int nvr_engine_add_request(nvr_engine_t *e, const int64_t *prompt, size_
 NVR_API int nvr_engine_step(nvr_engine_t *e, nvr_step_info *info);                         /* :155 */
 NVR_API int nvr_engine_is_finished(const nvr_engine_t *e);
 NVR_API nvr_scheduler_t *nvr_engine_scheduler(nvr_engine_t *e);     /* borrowed */
+/* LLMEngine::get_stats / health_check / shutdown, llm_engine.rs:312-357 (EngineStats, MemoryStats, HealthStatus :360-398):
+ * scheduler counters + block-pool occupancy; utilization = used / total * 100 (block_manager.rs:345-351); healthy while the
+ * pool is < 95 % used; shutdown preempts every running sequence (scheduler.preempt_all) and clears is_running */
+typedef struct nvr_engine_stats {
+    nvr_sched_stats scheduler;
+    uint64_t total_blocks, free_blocks, used_blocks; double utilization;     /* MemoryStats */
+    int32_t is_running;
+} nvr_engine_stats;
+typedef struct nvr_health_status {
+    int32_t is_healthy; double memory_pressure; uint64_t active_sequences, waiting_sequences;
+} nvr_health_status;
+NVR_API int nvr_engine_get_stats(nvr_engine_t *e, nvr_engine_stats *out);
+NVR_API int nvr_engine_health_check(nvr_engine_t *e, nvr_health_status *out);
+NVR_API int nvr_engine_shutdown(nvr_engine_t *e);
 NVR_API nvr_model_runner_t *nvr_engine_runner(nvr_engine_t *e);     /* borrowed */
 /* ids + tokens sampled by the last step (borrowed until the next step) */
 NVR_API void nvr_engine_last_step(const nvr_engine_t *e, const uint64_t **seq_ids, const int64_t **tokens, size_t *n);

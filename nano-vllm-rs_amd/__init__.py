@@ -64,6 +64,15 @@ class ModelConfigC(C.Structure):
                 ("init_std", C.c_float), ("seed", C.c_uint64)]
 
 
+class EngineStatsC(C.Structure):
+    pass                                     # fields set below (needs SchedStatsC)
+
+
+class HealthStatusC(C.Structure):
+    _fields_ = [("is_healthy", C.c_int32), ("memory_pressure", C.c_double), ("active_sequences", C.c_uint64),
+                ("waiting_sequences", C.c_uint64)]
+
+
 class BmStatsC(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("total_blocks", "free_blocks", "used_blocks", "cached_blocks", "block_size")]
 
@@ -77,6 +86,10 @@ class SchedStatsC(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("total_sequences", "waiting_sequences", "running_sequences",
                                           "finished_sequences", "preemptions", "prefill_batches", "decode_batches")] + \
                [("avg_prefill_batch_size", C.c_double), ("avg_decode_batch_size", C.c_double)]
+
+
+EngineStatsC._fields_ = [("scheduler", SchedStatsC), ("total_blocks", C.c_uint64), ("free_blocks", C.c_uint64),
+                         ("used_blocks", C.c_uint64), ("utilization", C.c_double), ("is_running", C.c_int32)]
 
 
 class StepInfoC(C.Structure):
@@ -144,6 +157,7 @@ _SIGS = {
     "nvr_engine_add_request": (C.c_int, [_P, _P, C.c_size_t, C.POINTER(SamplingParamsC), C.POINTER(C.c_uint64)]),
     "nvr_engine_step": (C.c_int, [_P, C.POINTER(StepInfoC)]), "nvr_engine_is_finished": (C.c_int, [_P]),
     "nvr_engine_scheduler": (_P, [_P]), "nvr_engine_runner": (_P, [_P]),
+    "nvr_engine_get_stats": (C.c_int, [_P, _P]), "nvr_engine_health_check": (C.c_int, [_P, _P]), "nvr_engine_shutdown": (C.c_int, [_P]),
     "nvr_engine_last_step": (None, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(C.c_size_t)]),
     "nvr_engine_take_finished": (C.c_size_t, [_P, C.POINTER(_P), C.c_size_t]),
     "nvr_engine_last_batch": (C.c_size_t, [_P, C.POINTER(_P), C.c_size_t]),
@@ -621,6 +635,22 @@ class LLMEngine:
 
     def is_finished(self) -> bool:
         return bool(lib().nvr_engine_is_finished(self.h))
+
+    def get_stats(self) -> dict:                              # llm_engine.rs:312-327
+        st = EngineStatsC()
+        check(lib().nvr_engine_get_stats(self.h, C.byref(st)))
+        sch = {n: getattr(st.scheduler, n) for n, _ in SchedStatsC._fields_}
+        return dict(scheduler=sch, memory=dict(total_blocks=st.total_blocks, free_blocks=st.free_blocks, used_blocks=st.used_blocks,
+                                               utilization=st.utilization), is_running=bool(st.is_running))
+
+    def health_check(self) -> dict:                           # llm_engine.rs:330-342
+        h = HealthStatusC()
+        check(lib().nvr_engine_health_check(self.h, C.byref(h)))
+        return dict(is_healthy=bool(h.is_healthy), memory_pressure=h.memory_pressure, active_sequences=h.active_sequences,
+                    waiting_sequences=h.waiting_sequences)
+
+    def shutdown(self) -> None:                               # llm_engine.rs:345-357
+        check(lib().nvr_engine_shutdown(self.h))
 
     def last_batch(self) -> List[Sequence]:
         out = (_P * 4096)()

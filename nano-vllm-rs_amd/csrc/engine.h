@@ -14,5 +14,6 @@ struct nvr_engine {
     std::vector<nvr_seq *> batch;
     std::vector<uint64_t> last_ids;
     std::vector<int64_t> last_tokens;
+    bool is_running = true;                              // llm_engine.rs:37,353: cleared by shutdown()
     int step(nvr_step_info *info);
 };

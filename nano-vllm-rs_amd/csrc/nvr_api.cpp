@@ -259,6 +259,28 @@ int nvr_engine_step(nvr_engine_t *e, nvr_step_info *info) { NVR_GUARD_BEGIN retu
 int nvr_engine_is_finished(const nvr_engine_t *e) { return e->scheduler->impl.is_finished() ? 1 : 0; }
 nvr_scheduler_t *nvr_engine_scheduler(nvr_engine_t *e) { return e->scheduler.get(); }
 nvr_model_runner_t *nvr_engine_runner(nvr_engine_t *e) { return e->runner.get(); }
+int nvr_engine_get_stats(nvr_engine_t *e, nvr_engine_stats *o) {                         // llm_engine.rs:312-327
+    if (!o) return nvr::fail(NVR_ERR_INVALID_ARG, "nvr_engine_get_stats: out is null");
+    o->scheduler = e->scheduler->impl.stats();
+    nvr_bm_stats b{}; e->scheduler->impl.block_manager().get_stats(&b);
+    o->total_blocks = b.total_blocks; o->free_blocks = b.free_blocks; o->used_blocks = b.used_blocks;
+    o->utilization = b.total_blocks ? (double)b.used_blocks / (double)b.total_blocks * 100.0 : 0.0;   // block_manager.rs:345-351
+    o->is_running = e->is_running ? 1 : 0;
+    return NVR_OK;
+}
+int nvr_engine_health_check(nvr_engine_t *e, nvr_health_status *o) {                     // llm_engine.rs:330-342
+    if (!o) return nvr::fail(NVR_ERR_INVALID_ARG, "nvr_engine_health_check: out is null");
+    nvr_engine_stats st{};
+    nvr_engine_get_stats(e, &st);
+    o->memory_pressure = st.utilization; o->is_healthy = st.utilization < 95.0 ? 1 : 0;
+    o->active_sequences = st.scheduler.running_sequences; o->waiting_sequences = st.scheduler.waiting_sequences;
+    return NVR_OK;
+}
+int nvr_engine_shutdown(nvr_engine_t *e) {                                               // llm_engine.rs:345-357
+    e->scheduler->impl.preempt_all();
+    e->is_running = false;
+    return NVR_OK;
+}
 void nvr_engine_last_step(const nvr_engine_t *e, const uint64_t **ids, const int64_t **toks, size_t *n) {
     *ids = e->last_ids.data(); *toks = e->last_tokens.data(); *n = e->last_ids.size();
 }

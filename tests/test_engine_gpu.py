@@ -244,6 +244,29 @@ def test_checkpoint_shards_dtypes_and_errors():
     assert e.value.code == -7
 
 
+def test_engine_stats_health_and_shutdown():
+    """LLMEngine::get_stats / health_check / shutdown (llm_engine.rs:312-357) over the C ABI."""
+    mcfg = mo.small(seed=2)
+    nvr.lib().nvr_seq_reset_id_counter()
+    eng = nvr.LLMEngine(nvr.Config(skip_block_size_check=1, max_num_seqs=4, max_num_batched_tokens=256, max_model_len=128, kvcache_block_size=16,
+                                   num_kvcache_blocks=20), _model_cfgs(mcfg))
+    for i, n in enumerate([33, 17, 50]):
+        eng.add_request(oracle.fill_tokens(n, 7, i, mcfg.vocab_size).tolist(), nvr.SamplingParams(temperature=0.0, max_tokens=40, ignore_eos=True))
+    st = eng.get_stats()
+    assert st["is_running"] and st["scheduler"]["waiting_sequences"] == 3 and st["memory"] == dict(total_blocks=20, free_blocks=20, used_blocks=0, utilization=0.0)
+    eng.step(); eng.step()
+    st, h = eng.get_stats(), eng.health_check()
+    used = 3 + 2 + 4                                            # ceil(34/16) + ceil(18/16) + ceil(51/16) blocks after one decode step
+    assert st["memory"]["used_blocks"] == used and abs(st["memory"]["utilization"] - used / 20 * 100) < 1e-9
+    assert st["scheduler"]["running_sequences"] == 3 and st["scheduler"]["prefill_batches"] == 1 and st["scheduler"]["decode_batches"] == 1
+    assert h == dict(is_healthy=True, memory_pressure=st["memory"]["utilization"], active_sequences=3, waiting_sequences=0)
+    eng.shutdown()
+    st = eng.get_stats()
+    # preempt_all (scheduler.rs:314-319) does not refresh the queue-length snapshot in the stats; the queues themselves moved
+    assert not st["is_running"] and eng.scheduler.get_queue_lengths() == (3, 0)
+    assert st["memory"]["used_blocks"] == 0 and st["scheduler"]["preemptions"] == 3
+
+
 def test_gqa4_head_dim_128_model():
     """Qwen3-8B-like head geometry (32:8 grouping scaled down, D=128) and block size 256."""
     mcfg = mo.ModelConfig(vocab_size=2048, hidden_size=512, intermediate_size=1024, num_hidden_layers=2,
