@@ -10,7 +10,10 @@ namespace {
 struct HostTrace {
     bool on = std::getenv("NVR_TRACE_HOST") != nullptr;
     double acc[4] = {0, 0, 0, 0}; long n = 0;
+    double pacc[4] = {0, 0, 0, 0}; long pn = 0;
     ~HostTrace() {
+        if (on && pn) std::fprintf(stderr, "[nvr host trace] %ld prefill steps: schedule %.1f us, execute %.1f us, sample(+GPU wait) %.1f us, postprocess %.1f us\n",
+                                   pn, pacc[0] / pn, pacc[1] / pn, pacc[2] / pn, pacc[3] / pn);
         if (on && n) std::fprintf(stderr, "[nvr host trace] %ld decode steps: schedule %.2f us, execute %.2f us, sample(+GPU wait) %.2f us, postprocess %.2f us\n",
                                   n, acc[0] / n, acc[1] / n, acc[2] / n, acc[3] / n);
     }
@@ -37,9 +40,11 @@ int nvr_engine::step(nvr_step_info *info) {                          // LLMEngin
     const uint64_t fin_before = scheduler->impl.stats().finished_sequences;
     rc = scheduler->impl.postprocess(batch.data(), last_tokens.data(), batch.size());   // :188-189
     if (rc) return rc;
-    if (g_trace.on && !is_prefill) {
+    if (g_trace.on) {
         const double t4 = now_us();
-        g_trace.acc[0] += t1 - t0; g_trace.acc[1] += t2 - t1; g_trace.acc[2] += t3 - t2; g_trace.acc[3] += t4 - t3; ++g_trace.n;
+        double *a = is_prefill ? g_trace.pacc : g_trace.acc;
+        a[0] += t1 - t0; a[1] += t2 - t1; a[2] += t3 - t2; a[3] += t4 - t3;
+        ++(is_prefill ? g_trace.pn : g_trace.n);
     }
     if (info) {
         info->is_prefill = is_prefill; info->num_seqs = batch.size(); info->num_tokens = ntok;
