@@ -158,7 +158,18 @@ def main() -> None:
     if os.environ.get("NVR_BENCH_SHARED_GPU"):          # control-plane dry run of the multi-rank path on a 1-GPU box
         local_rank = 0
     dist = None
+    watchdog = None
     if args.gpus > 1:
+        # the multi-rank path cannot be exercised on the 1-GPU development boxes: never hang the driver — if a rank is still
+        # stuck (a collective that never completes, a rendezvous that never forms) after 10 minutes, every rank exits
+        import threading
+
+        def _bail():
+            print(f"[bench] rank {rank}: multi-GPU run made no progress for 600 s, giving up", file=sys.stderr, flush=True)
+            os._exit(4)
+        watchdog = threading.Timer(600.0, _bail)
+        watchdog.daemon = True
+        watchdog.start()
         if world != args.gpus:
             raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run)")
         nvr.preload_rccl()                 # ROCm's librccl before torch's bundled copy can claim the soname
@@ -290,6 +301,8 @@ def main() -> None:
         # Two ROCm stacks live in a multi-rank process (this image's 7.2 libraries behind libnvr.so and the 7.0 copies
         # bundled with torch); their static destructors abort at interpreter exit ("double free") after all work is
         # done.  Everything is flushed and released above: leave without running them.
+        if watchdog is not None:
+            watchdog.cancel()
         sys.stdout.flush(); sys.stderr.flush()
         os._exit(0)
 
