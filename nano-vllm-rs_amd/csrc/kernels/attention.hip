@@ -401,13 +401,17 @@ static int launch_attn(const AttnArgs &a, bool paged, hipStream_t s) {
     // ~256 workgroups), otherwise fall back to 4-wave workgroups over 64-token-granular partitions.
     const int64_t mc = a.max_ctx > 0 ? a.max_ctx : 1;
     const int64_t pairs = (int64_t)a.nq * a.KVH;
-    int waves = tn.waves ? tn.waves : ((paged && a.workspace && pairs * ((mc + 255) / 256) >= 192) ? 8 : 4);
+    // 8-wave workgroups whenever ~256 of them can be given >= 64 tokens each; with fewer than ~192 (query, kv head) pairs
+    // (small batches, tensor-parallel ranks that hold 1-4 kv heads) the context is cut into ceil(256 / pairs)
+    // 64-token-granular partitions + merge kernel (B=32, ctx 1044: KVH=1 10.9 us vs 14.6 us for the 4-wave path, KVH=2
+    // 12.7 vs 14.6, KVH=4 17.5 vs 19.7; scratch/attn_tp_shape.py)
+    int waves = tn.waves ? tn.waves : ((paged && a.workspace && pairs * ((mc + 63) / 64) >= 256) ? 8 : 4);
     int part_size = 0x3fffffff, np = 1;
     if (a.workspace) {
         if (tn.parts > 0) { part_size = (int)(((mc + tn.parts - 1) / tn.parts + 63) / 64 * 64); np = (int)((mc + part_size - 1) / part_size); }
         else if (waves >= 8) {
-            int64_t want = pairs >= 96 ? 1 : (256 + pairs - 1) / pairs;
-            int64_t ps = ((mc + want - 1) / want + 255) / 256 * 256;
+            int64_t want = pairs >= 192 ? 1 : (256 + pairs - 1) / pairs;
+            int64_t ps = ((mc + want - 1) / want + 63) / 64 * 64;
             part_size = (int)ps; np = (int)((mc + ps - 1) / ps);
         } else np = parts_for(a.nq, a.KVH, mc, waves, &part_size);
     }
