@@ -445,6 +445,20 @@ def test_prefill_gemm_large_repeatable():
         else: assert np.array_equal(got, first), rep
     rows = rng.choice(T, 256, replace=False)
     assert_close_f16(first.view(F16)[rows], oracle.round_f16(oracle.linear(x[rows], W)), ulps=1, atol=2e-4, what="gemm256")
+    # same screen for the SiLU epilogue on a persistent grid with more tiles than workgroups (T=8192, I=1024: 8 x 32 tiles x ...)
+    T2, I = 8192, 1024
+    x2, x2b = h16(rng.standard_normal((T2, K)))
+    W2, W2b = h16(rng.standard_normal((2 * I, K)) * 0.05)
+    d_x2, d_W2, d_o = dev(x2b), dev(W2b), nvr.DeviceBuffer(T2 * I * 2)
+    first = None
+    for rep in range(8):
+        nvr.check(nvr.lib().nvr_linear_silu_mul(d_x2.ptr, K, d_W2.ptr, T2, K, I, d_o.ptr, None))
+        got = d_o.to_numpy((T2, I), np.uint16)
+        if first is None: first = got
+        else: assert np.array_equal(got, first), rep
+    rows = rng.choice(T2, 128, replace=False)
+    ref = oracle.round_f16(oracle.silu_and_mul(oracle.round_f16(oracle.linear(x2[rows], W2))))
+    assert_close_f16(first.view(F16)[rows], ref, ulps=2, atol=3e-4, what="gemm256 silu")
 
 
 # ------------------------------------------------------------------------------------------- fused epilogues
