@@ -187,6 +187,10 @@ def _paged_case(rng, B, H, KVH, D, bs, ctx_lens, NB):
     (5, 8, 8, 128, 16, [5, 16, 31, 32, 33]),            # MHA (group 1)
     (32, 16, 8, 128, 256, [1024] * 32),                 # BASELINE config 2 decode shape (one layer)
     (1, 16, 8, 128, 256, [3000]),                       # long context, single sequence: many partitions
+    (3, 4, 2, 128, 16, [2500, 1030, 7]),                # > 64 blocks per sequence: the register copy of the block table is reloaded
+    (40, 16, 8, 128, 16, [1100 + 3 * i for i in range(40)]),   # same, on the one-workgroup-per-pair (direct) path
+    (2, 16, 8, 128, 256, [20000, 300]),                 # 79 blocks of 256 tokens
+    (3, 8, 4, 64, 8, [700, 64, 1]),                     # D=64 (8-token row groups), block size = one row group
 ])
 def test_paged_attn_decode(B, H, KVH, D, bs, ctxs):
     rng = np.random.default_rng(6)
@@ -264,7 +268,9 @@ def test_online_softmax_rescale_branch_forced():
 
 # ------------------------------------------------------------------------------------------- K7
 @pytest.mark.parametrize("H,KVH,D,lens", [(4, 2, 64, [1, 5, 33]), (16, 8, 128, [70, 129]), (8, 8, 128, [17]), (8, 2, 128, [100, 3, 64]),
-                                          (16, 8, 128, [300]), (16, 2, 128, [40])])
+                                          (16, 8, 128, [300]), (16, 2, 128, [40]),
+                                          (4, 2, 128, [1500, 129, 64, 1]),      # many 64-key steps, tiles of every fill level
+                                          (2, 2, 64, [700, 65]), (8, 2, 64, [260])])   # G=1 / G=4 at head_dim 64
 def test_attn_prefill_varlen(H, KVH, D, lens):
     rng = np.random.default_rng(9)
     T = sum(lens)
