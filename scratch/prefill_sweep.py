@@ -15,14 +15,14 @@ for L in [int(x) for x in (sys.argv[1:] or [128, 256, 512, 1024, 2048, 4096])]:
     eng = nvr.LLMEngine(cfg, mc)
     for i in range(nseq):
         eng.add_request(nvr.synthetic_tokens(L, 1, i, V).tolist(), nvr.SamplingParams(temperature=0.0, max_tokens=2, ignore_eos=True))
-    nvr.synchronize(); t0 = time.perf_counter(); steps = 0; rows = 0
+    nvr.synchronize(); steps = 0; rows = 0; dt = 0.0
     while True:
-        rec = eng.step()
-        if not rec["is_prefill"]: break
-        steps += 1; rows += rec["num_tokens"]
-    nvr.synchronize(); dt = time.perf_counter() - t0
-    # subtract nothing: the decode step that ended the loop is one 256-row step (~3 ms at L=4096), noted in the output
+        t0 = time.perf_counter()
+        rec = eng.step()                      # a step ends with the D2H of its tokens: the device is idle when it returns
+        t1 = time.perf_counter()
+        if not rec["is_prefill"]: break       # the first decode step (graph capture) is not part of the prefill time
+        steps += 1; rows += rec["num_tokens"]; dt += t1 - t0
     attn = 4 * H * D * (L + 1) / 2 * Lyr                                  # causal, per token
     flop = rows * (gemm_flop_per_token + attn) + nseq * 2 * V * Hd
-    print(f"L={L:5d}: {steps:3d} prefill steps, {rows} tokens, {dt * 1e3:8.1f} ms (incl. one decode step) -> {rows / dt / 1e3:7.1f} k tok/s, {flop / dt / 1e12:6.1f} TFLOP/s = {flop / dt / 2.5e15 * 100:4.1f} % of 2.5 PF", flush=True)
+    print(f"L={L:5d}: {steps:3d} prefill steps, {rows} tokens, {dt * 1e3:8.1f} ms -> {rows / dt / 1e3:7.1f} k tok/s, {flop / dt / 1e12:6.1f} TFLOP/s = {flop / dt / 2.5e15 * 100:4.1f} % of 2.5 PF", flush=True)
     del eng
