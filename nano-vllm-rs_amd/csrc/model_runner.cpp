@@ -531,6 +531,11 @@ int nvr_model_runner::execute(nvr_seq *const *seqs, size_t nseq, bool is_prefill
     auto get_graph = [&](uint64_t key, hipStream_t cap, auto &&body, hipGraphExec_t *out) -> int {
         auto it = graphs.find(key);
         if (it == graphs.end()) {
+            if (graphs.size() >= kMaxGraphs) {               // a long-lived engine sees many (batch size, bucket) pairs: bound the cache
+                NVR_HIP_CHECK(hipStreamSynchronize(stream));
+                for (auto &kv : graphs) hipGraphExecDestroy(kv.second);
+                graphs.clear();
+            }
             hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr;
             NVR_HIP_CHECK(hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal));
             int rc = body();

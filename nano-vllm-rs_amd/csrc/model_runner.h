@@ -86,6 +86,7 @@ private:
     int forward_all(int64_t T, int64_t B, bool is_prefill, int64_t max_ctx, int nl);
     int gen_weights();
     int row_parallel_norm(Lane &ln, const uint16_t *x, int64_t K, const uint16_t *W, int64_t T, const uint16_t *wn);
+    static constexpr size_t kMaxGraphs = 256;            // captured decode graphs kept before the cache is flushed
     bool fused_slabnorm = false;
     bool prefill_paged = false;                          // this prefill step skips cached prefixes (K/V via block tables)
     bool lazy_logits = true, want_logits = true, logits_valid = true; const uint16_t *lm_input = nullptr;
