@@ -142,17 +142,27 @@ __global__ __launch_bounds__(64 * FLASH_WAVES, 8 / FLASH_WAVES) void flash_prefi
 
         // Sᵀ tiles: NMT x (16 keys x 16 queries) per query tile; one K fragment read feeds both
         float4_t s[NQT][NMT];
-#pragma unroll
-        for (int mt = 0; mt < NMT; ++mt) {
-#pragma unroll
-            for (int t = 0; t < NQT; ++t) s[t][mt] = (float4_t){0.f, 0.f, 0.f, 0.f};
+        // K fragments of key tile mt+1 are requested before the MFMAs of key tile mt (two fragment sets in registers):
+        // without this the compiler emits {2 reads, wait, 4 MFMAs} eight times and every LDS latency is exposed
+        half8_t kf[2][NKS];
+        auto read_k = [&](int mt, half8_t (&dst)[NKS]) {
             const int row = mt * 16 + r;
 #pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) {
-                const half8_t kf = *reinterpret_cast<const half8_t *>(kl + (row * CPR + ((ks * 4 + g4) ^ (row & (CPR - 1)))) * 16);
+            for (int ks = 0; ks < NKS; ++ks)
+                dst[ks] = *reinterpret_cast<const half8_t *>(kl + (row * CPR + ((ks * 4 + g4) ^ (row & (CPR - 1)))) * 16);
+        };
+        read_k(0, kf[0]);
 #pragma unroll
-                for (int t = 0; t < NQT; ++t) s[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[t][ks], s[t][mt], 0, 0, 0);
-            }
+        for (int mt = 0; mt < NMT; ++mt) {
+            if (mt + 1 < NMT) read_k(mt + 1, kf[(mt + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < NQT; ++t) s[t][mt] = (float4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+                for (int t = 0; t < NQT; ++t) s[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[mt & 1][ks], qf[t][ks], s[t][mt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         // causal mask only on steps that reach past the tile's first query (keys kt + mt*16 + g4*4 + e)
         if (kt + KT - 1 > tile.pos0) {
