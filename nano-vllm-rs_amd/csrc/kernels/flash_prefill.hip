@@ -136,7 +136,9 @@ __global__ __launch_bounds__(64 * FLASH_WAVES, 8 / FLASH_WAVES) void flash_prefi
         constexpr int cur = decltype(cur_c)::value;
         const int kt = it * KT;
         const bool more = it + NBUF - 1 < nsteps;
+#ifndef NVR_FLASH_ABLATE_STAGE
         if (more) stage((cur + NBUF - 1) % NBUF, kt + (NBUF - 1) * KT);
+#endif
         const char *kl = smem + cur * STAGE, *vl = kl + KT * D * 2;
         if (kt <= wave_last) {
 
