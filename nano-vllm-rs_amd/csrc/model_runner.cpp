@@ -151,6 +151,8 @@ int nvr_model_runner::init() {                                       // ModelRun
 
     RC(dmalloc(&d_tok, max_seqs)); RC(dmalloc(&d_maxval, max_seqs));
     NVR_HIP_CHECK(hipHostMalloc((void **)&h_tok, max_seqs * 8, hipHostMallocDefault));
+    { const char *e = getenv("NVR_ZERO_COPY_TOKENS");
+      if (!(e && e[0] == '0') && hipHostGetDevicePointer((void **)&h_tok_dev, h_tok, 0) != hipSuccess) { h_tok_dev = nullptr; (void)hipGetLastError(); } }
     RC(dmalloc(&d_temp, max_seqs)); RC(dmalloc(&d_topk, max_seqs)); RC(dmalloc(&d_topp, max_seqs)); RC(dmalloc(&d_keys, max_seqs));
     NVR_HIP_CHECK(hipHostMalloc((void **)&samp_host, max_seqs * 24, hipHostMallocDefault));
     NVR_HIP_CHECK(hipMalloc(&sample_ws, k::sample_workspace_bytes(max_seqs, Vl)));
@@ -627,6 +629,14 @@ int nvr_model_runner::sample(nvr_seq *const *seqs, size_t nseq, int64_t *out) {
     const int64_t B = (int64_t)nseq;
     if (all_greedy) {
         if (!comm.active()) {
+            if (lm_parts > 0 && h_tok_dev) {
+                // the merge kernel writes the token ids straight into the pinned host buffer (device-visible mapping): no
+                // device-to-host copy (a blit kernel of its own) between the last kernel of the step and the host's wake-up
+                RC(k::argmax_partials(d_lm_pval, d_lm_pidx, lm_parts, B, h_tok_dev, nullptr, 0, stream));
+                NVR_HIP_CHECK(hipStreamSynchronize(stream));
+                std::memcpy(out, h_tok, B * 8);
+                return NVR_OK;
+            }
             if (lm_parts > 0) RC(k::argmax_partials(d_lm_pval, d_lm_pidx, lm_parts, B, d_tok, nullptr, 0, stream));
             else RC(k::argmax(logits, B, Vl, d_tok, nullptr, 0, stream));
         } else {
