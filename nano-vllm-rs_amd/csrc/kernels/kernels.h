@@ -58,6 +58,18 @@ int linear_qkv_rope_store(const half_bits *x, int64_t ldx, const half_bits *W, i
                           int64_t KVH, int64_t D, const int64_t *positions, const int32_t *slots, const float *cos_t,
                           const float *sin_t, half_bits *qkv, half_bits *k_cache, half_bits *v_cache, hipStream_t s);
 
+// decode GEMMs over large weights (T <= 32, K >= 2048, >= 24 MiB of weights): activation block in LDS, persistent workgroups
+// (linear_stream.hip); linear / linear_silu_mul / linear_qkv_rope_store route here when the shape test passes
+int linear_stream_prepare();                                                // LDS opt-in of every instance (call outside captures)
+bool linear_stream_ok(int64_t T, int64_t K, int64_t N, int64_t ldx);
+bool linear_stream_silu_ok(int64_t T, int64_t K, int64_t I, int64_t ldx);
+bool linear_stream_rope_ok(int64_t T, int64_t K, int64_t H, int64_t KVH, int64_t D, int64_t ldx);
+int linear_stream(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t N, half_bits *y, hipStream_t s);
+int linear_stream_silu_mul(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t I, half_bits *out, hipStream_t s);
+int linear_stream_qkv_rope_store(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t H, int64_t KVH, int64_t D,
+                                 const int64_t *positions, const int32_t *slots, const float *cos_t, const float *sin_t, half_bits *qkv,
+                                 half_bits *k_cache, half_bits *v_cache, hipStream_t s);
+
 // LDS-tiled MFMA GEMM for the prefill regime (T >= 128): same results layout and epilogues as the kernels above
 bool gemm_tiled_ok(int64_t T, int64_t K, int64_t N, int64_t ldx);
 int gemm_tiled(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t N, half_bits *y, hipStream_t s);

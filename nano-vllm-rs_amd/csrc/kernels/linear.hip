@@ -298,6 +298,7 @@ int linear(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64
     if (T == 0) return 0;
     if (!y_f32 && gemm256_ok(T, K, N, ldx)) return gemm256(x, ldx, W, T, K, N, (half_bits *)y, s);          // prefill regime
     if (!y_f32 && gemm_tiled_ok(T, K, N, ldx)) return gemm_tiled(x, ldx, W, T, K, N, (half_bits *)y, s);
+    if (!y_f32 && linear_stream_ok(T, K, N, ldx)) return linear_stream(x, ldx, W, T, K, N, (half_bits *)y, s);   // large weights
     const half_t *xx = (const half_t *)x, *ww = (const half_t *)W;
     const int t = (int)T, k = (int)K, n = (int)N;
     const LinEpi e{};
@@ -368,6 +369,7 @@ int linear_silu_mul(const half_bits *x, int64_t ldx, const half_bits *W, int64_t
     if (T == 0) return 0;
     if (gemm256_silu_ok(T, K, I, ldx)) return gemm256_silu_mul(x, ldx, W, T, K, I, out, s);
     if (gemm_tiled_ok(T, K, I, ldx) && I % 64 == 0) return gemm_tiled_silu_mul(x, ldx, W, T, K, I, out, s);
+    if (linear_stream_silu_ok(T, K, I, ldx)) return linear_stream_silu_mul(x, ldx, W, T, K, I, out, s);              // large weights
     const half_t *xx = (const half_t *)x, *ww = (const half_t *)W;
     const LinEpi e{};
     const unsigned gx = (unsigned)(I / 16);
@@ -393,6 +395,8 @@ int linear_qkv_rope_store(const half_bits *x, int64_t ldx, const half_bits *W, i
         return gemm256_qkv_rope_store(x, ldx, W, T, K, H, KVH, D, positions, slots, cos_t, sin_t, qkv, k_cache, v_cache, s);
     if (gemm_tiled_ok(T, K, (H + 2 * KVH) * D, ldx) && 128 % D == 0)
         return gemm_tiled_qkv_rope_store(x, ldx, W, T, K, H, KVH, D, positions, slots, cos_t, sin_t, qkv, k_cache, v_cache, s);
+    if (linear_stream_rope_ok(T, K, H, KVH, D, ldx))                                                                  // large weights
+        return linear_stream_qkv_rope_store(x, ldx, W, T, K, H, KVH, D, positions, slots, cos_t, sin_t, qkv, k_cache, v_cache, s);
     const half_t *xx = (const half_t *)x, *ww = (const half_t *)W;
     LinEpi e{};
     e.pos = positions; e.slots = slots; e.cos_t = cos_t; e.sin_t = sin_t; e.kc = (half_t *)k_cache; e.vc = (half_t *)v_cache;

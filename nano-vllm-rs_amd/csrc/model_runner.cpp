@@ -101,6 +101,7 @@ int nvr_model_runner::init() {                                       // ModelRun
     RC(dmalloc(&slabs, 4 * 64 * Hd));
     // measured slower than two launches (profiles/r01_fused_slabnorm_ablation.txt): opt-in only
     { const char *e = getenv("NVR_FUSED_SLABNORM"); fused_slabnorm = e && e[0] == '1'; }
+    RC(k::linear_stream_prepare());
     { const char *e = getenv("NVR_LM_FUSED"); lm_fused = !(e && e[0] == '0'); }
     { const char *e = getenv("NVR_LAZY_LOGITS"); lazy_logits = !(e && e[0] == '0'); }
     RC(dmalloc(&d_lm_pval, (size_t)k::LM_HEAD_MAX_PARTS * 32)); RC(dmalloc(&d_lm_pidx, (size_t)k::LM_HEAD_MAX_PARTS * 32));

@@ -435,6 +435,54 @@ def test_fill_weight_bit_exact_with_oracle():
     assert abs(ref.std() - 0.02) < 0.003
 
 
+@pytest.mark.parametrize("T", [32, 9])
+def test_decode_gemms_over_large_weights(T):
+    """linear_stream.hip (Qwen3-8B-class shapes: >= 24 MiB of weights, K >= 2048): plain, SiLU and RoPE+store epilogues
+    against the oracle compositions; several K chunks (K = 6144 -> 3 chunks of 2048 at T > 16) and several tiles per
+    workgroup (N = 8192 -> 512 tiles on 256 workgroups)."""
+    rng = np.random.default_rng(61)
+    # plain: K = 6144, N = 8192 (512 tiles: two per workgroup)
+    K, N = 6144, 8192
+    x, xb = h16(rng.standard_normal((T, K)))
+    W, Wb = h16(rng.standard_normal((N, K)) * 0.02)
+    d_y = nvr.DeviceBuffer(T * N * 2)
+    nvr.check(nvr.lib().nvr_linear(dev(xb).ptr, K, dev(Wb).ptr, T, K, N, d_y.ptr, 0, None))
+    assert_close_f16(d_y.to_numpy((T, N), F16), oracle.round_f16(oracle.linear(x, W)), ulps=1, atol=3e-4, what="stream plain")
+    # SiLU: K = 4096, I = 6144 (2 x 6144 rows = 96 MiB), 384 tile pairs
+    K, I = 4096, 6144
+    x, xb = h16(rng.standard_normal((T, K)))
+    W, Wb = h16(rng.standard_normal((2 * I, K)) * 0.02)
+    d_o = nvr.DeviceBuffer(T * I * 2)
+    nvr.check(nvr.lib().nvr_linear_silu_mul(dev(xb).ptr, K, dev(Wb).ptr, T, K, I, d_o.ptr, None))
+    ref = oracle.round_f16(oracle.silu_and_mul(oracle.round_f16(oracle.linear(x, W))))
+    assert_close_f16(d_o.to_numpy((T, I), F16), ref, ulps=2, atol=3e-4, what="stream silu")
+    # qkv + RoPE + store: Qwen3-8B heads (H=32, KVH=8, D=128, hidden 4096): 384 tiles
+    H, KVH, D, K = 32, 8, 128, 4096
+    QKV = (H + 2 * KVH) * D
+    NB, bs, max_pos = 8, 16, 300
+    x, xb = h16(rng.standard_normal((T, K)))
+    W, Wb = h16(rng.standard_normal((QKV, K)) * 0.02)
+    pos = rng.integers(0, max_pos, T).astype(np.int64)
+    slots = rng.permutation(NB * bs)[:T].astype(np.int32)
+    slots[T // 2] = -1
+    cos, sin = oracle.rope_table(D, max_pos, 1e6)
+    d_qkv = nvr.DeviceBuffer(T * QKV * 2)
+    d_k, d_v = nvr.DeviceBuffer(NB * bs * KVH * D * 2), nvr.DeviceBuffer(NB * bs * KVH * D * 2)
+    d_k.zero(); d_v.zero()
+    nvr.check(nvr.lib().nvr_linear_qkv_rope_store(dev(xb).ptr, K, dev(Wb).ptr, T, K, H, KVH, D, dev(pos).ptr, dev(slots).ptr,
+                                                  dev(cos).ptr, dev(sin).ptr, d_qkv.ptr, d_k.ptr, d_v.ptr, None))
+    got = d_qkv.to_numpy((T, QKV), F16).astype(np.float32)
+    qkv = oracle.round_f16(oracle.linear(x, W))
+    q = oracle.round_f16(oracle.rope_apply(qkv[:, :H * D].reshape(T, H, D), pos, cos, sin)).reshape(T, H * D)
+    kk = oracle.round_f16(oracle.rope_apply(qkv[:, H * D:(H + KVH) * D].reshape(T, KVH, D), pos, cos, sin))
+    vv = np.ascontiguousarray(qkv[:, (H + KVH) * D:].reshape(T, KVH, D))
+    assert_close_f16(got[:, :H * D], q, ulps=2, atol=6e-3, what="stream fused q")
+    kc, vc = np.zeros((NB, bs, KVH, D), np.float32), np.zeros((NB, bs, KVH, D), np.float32)
+    oracle.kv_store(kk, vv, slots, kc, vc)
+    assert_close_f16(d_k.to_numpy(kc.shape, F16), kc, ulps=2, atol=6e-3, what="stream fused k cache")
+    assert_close_f16(d_v.to_numpy(vc.shape, F16), vc, ulps=2, atol=4e-4, what="stream fused v cache")
+
+
 def test_prefill_gemm_large_repeatable():
     """The 256x256 eight-wave kernel keeps LDS-DMA loads in flight across barriers: screen it for races — many runs
     of a many-workgroup shape must be bit-identical to each other and match the oracle on sampled rows."""
