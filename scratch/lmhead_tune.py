@@ -19,7 +19,7 @@ def run(t):
         a, b = C.c_void_p(), C.c_void_p(); l.nvr_event_create(C.byref(a)); l.nvr_event_create(C.byref(b))
         l.nvr_event_record(a, st)
         if t == "old": nvr.check(l.nvr_linear(x.ptr, K, W.ptr, T, K, N, y.ptr, 1, st))
-        else: nvr.check(l.nvr_lm_head(x.ptr, K, W.ptr, T, K, N, y.ptr, pv.ptr, pi.ptr, C.byref(npart), st))
+        else: nvr.check(l.nvr_lm_head(x.ptr, K, W.ptr, T, K, N, None if os.environ.get('NOSTORE') else y.ptr, pv.ptr, pi.ptr, C.byref(npart), st))
         l.nvr_event_record(b, st)
         evs.append((a, b))
     nvr.check(l.nvr_stream_synchronize(st))
