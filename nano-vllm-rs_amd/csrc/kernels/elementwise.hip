@@ -187,9 +187,65 @@ __global__ __launch_bounds__(64) void add_rmsnorm_slabs_kernel(half_t *__restric
         }
     }
 }
+// the same for wide rows (2048 < Hd <= 8192): four waves per row, each thread one 8-element piece of every 2048-element chunk
+template <int S>
+__global__ __launch_bounds__(256) void add_rmsnorm_slabs_wide_kernel(half_t *__restrict__ h, const float *__restrict__ slabs,
+                                                                    int64_t slab_stride, const half_t *__restrict__ w, float eps,
+                                                                    int Hd, half_t *__restrict__ out) {
+    constexpr int C = 4;
+    const int row = blockIdx.x, tid = threadIdx.x;
+    half_t *hr = h + (int64_t)row * Hd;
+    const float *sr = slabs + (int64_t)row * Hd;
+    half8_t v[C], g[C];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < C; ++i) {
+        const int c = tid * 8 + i * 2048;
+        if (c < Hd) {
+            v[i] = *reinterpret_cast<const half8_t *>(hr + c);
+            g[i] = *reinterpret_cast<const half8_t *>(w + c);
+            float4_t a0 = *reinterpret_cast<const float4_t *>(sr + c), a1 = *reinterpret_cast<const float4_t *>(sr + c + 4);
+#pragma unroll
+            for (int z = 1; z < S; ++z) {
+                a0 += *reinterpret_cast<const float4_t *>(sr + z * slab_stride + c);
+                a1 += *reinterpret_cast<const float4_t *>(sr + z * slab_stride + c + 4);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float y = (float)to_half_rn(j < 4 ? a0[j] : a1[j - 4]);
+                v[i][j] = to_half_rn((float)v[i][j] + y);
+                const float f = (float)v[i][j]; ss += f * f;
+            }
+            *reinterpret_cast<half8_t *>(hr + c) = v[i];
+        }
+    }
+    __shared__ float sm[4];
+    ss = wave_sum(ss);
+    if ((tid & 63) == 0) sm[tid >> 6] = ss;
+    __syncthreads();
+    const float rms = sqrtf((sm[0] + sm[1] + sm[2] + sm[3]) / (float)Hd + eps);
+#pragma unroll
+    for (int i = 0; i < C; ++i) {
+        const int c = tid * 8 + i * 2048;
+        if (c < Hd) {
+            half8_t o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = to_half_rn(__fmul_rn(__fdiv_rn((float)v[i][j], rms), (float)g[i][j]));
+            *reinterpret_cast<half8_t *>(out + (int64_t)row * Hd + c) = o;
+        }
+    }
+}
+
 int add_rmsnorm_slabs(half_bits *h, const float *slabs, int64_t S, const half_bits *w, float eps, int64_t T, int64_t Hd,
                       half_bits *out, hipStream_t s) {
-    if (Hd % 8 || Hd > 2048) return nvr::fail(NVR_ERR_UNSUPPORTED, "add_rmsnorm_slabs: hidden size %ld must be a multiple of 8, <= 2048", (long)Hd);
+    if (Hd % 8 == 0 && Hd > 2048 && Hd <= 8192 && (S == 2 || S == 4)) {
+        if (T == 0) return 0;
+        if (S == 2) add_rmsnorm_slabs_wide_kernel<2><<<dim3((unsigned)T), dim3(256), 0, s>>>((half_t *)h, slabs, T * Hd, (const half_t *)w, eps, (int)Hd, (half_t *)out);
+        else add_rmsnorm_slabs_wide_kernel<4><<<dim3((unsigned)T), dim3(256), 0, s>>>((half_t *)h, slabs, T * Hd, (const half_t *)w, eps, (int)Hd, (half_t *)out);
+        LAUNCH_CHECK();
+        return 0;
+    }
+    if (Hd % 8 || Hd > 2048) return nvr::fail(NVR_ERR_UNSUPPORTED, "add_rmsnorm_slabs: hidden size %ld must be a multiple of 8, <= 8192", (long)Hd);
     if (S != 2 && S != 4) return nvr::fail(NVR_ERR_UNSUPPORTED, "add_rmsnorm_slabs: S=%ld must be 2 or 4", (long)S);
     if (T == 0) return 0;
     dim3 grid((unsigned)T), block(64);

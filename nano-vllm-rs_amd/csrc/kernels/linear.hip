@@ -339,6 +339,14 @@ int linear_splitk(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T
     LinEpi e{};
     e.kslice = (int32_t)(K / S); e.slab_stride = T * N;
     const unsigned gx = (unsigned)(N / 16);
+    if (N * K * 2 >= (24ll << 20) && N % 64 == 0) {
+        // large weights (Qwen3-8B o/down: N = 4096): 64 output columns per workgroup so that an x fragment feeds four weight
+        // tiles (x costs half the weight bytes instead of twice), 8 waves; with S = 4: 10.8 / 29.5 us vs 15.5 / 45 us for the
+        // 16-column kernel at K = 4096 / 12288 (scratch/splitk_8b.py)
+        if (T <= 16) launch<4, 1, 8, EPI_SLAB>((const half_t *)x, ldx, (const half_t *)W, (int)T, (int)K, (int)N, slabs, e, (unsigned)(N / 64), s, (unsigned)S);
+        else launch<4, 2, 8, EPI_SLAB>((const half_t *)x, ldx, (const half_t *)W, (int)T, (int)K, (int)N, slabs, e, (unsigned)(N / 64), s, (unsigned)S);
+        return launch_check("linear_splitk");
+    }
     if (T <= 16) launch<1, 1, 4, EPI_SLAB>((const half_t *)x, ldx, (const half_t *)W, (int)T, (int)K, (int)N, slabs, e, gx, s, (unsigned)S);
     else launch<1, 2, 4, EPI_SLAB>((const half_t *)x, ldx, (const half_t *)W, (int)T, (int)K, (int)N, slabs, e, gx, s, (unsigned)S);
     return launch_check("linear_splitk");

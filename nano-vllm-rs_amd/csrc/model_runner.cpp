@@ -331,6 +331,8 @@ int nvr_model_runner::row_parallel_norm(Lane &ln, const uint16_t *x, int64_t K, 
     if (!comm.active() && tp == 1 && T <= 64 && Hd <= 2048) {
         const int64_t tiles = (Hd / 16) * ((T + 31) / 32);
         while (S < 4 && tiles * S < 256 && K % (32 * S * 2) == 0 && K / (S * 2) >= 128) S *= 2;
+    } else if (!comm.active() && tp == 1 && T <= 32 && Hd <= 8192 && Hd % 64 == 0 && Hd * K * 2 >= (24ll << 20) && K % 128 == 0) {
+        S = 4;                                       // large weights: 64-column workgroups x 4 k-slices (linear_splitk)
     }
     if (S > 1 && fused_slabnorm)
         return k::linear_splitk_norm(x, K, W, T, K, Hd, S, ln.slabs, ln.h, wn, mc.rms_norm_eps, ln.n, ln.sync, ln.stream);

@@ -572,7 +572,8 @@ def test_linear_qkv_rope_store_fused(T, K, H, KVH, D):
     assert_close_f16(d_v.to_numpy(vc.shape, F16), vc, ulps=2, atol=3e-4, what="fused v cache")
 
 
-@pytest.mark.parametrize("T,K,N,S", [(32, 2048, 1024, 4), (32, 3072, 1024, 4), (5, 256, 64, 2), (40, 512, 256, 4)])
+@pytest.mark.parametrize("T,K,N,S", [(32, 2048, 1024, 4), (32, 3072, 1024, 4), (5, 256, 64, 2), (40, 512, 256, 4),
+                                     (32, 4096, 4096, 4), (9, 12288, 4096, 4), (32, 4096, 8192, 2)])   # large weights: 64-column workgroups, wide rows
 def test_linear_splitk_and_slab_norm(T, K, N, S):
     """split-k slabs + add_rmsnorm_slabs == linear -> fp16 -> add -> rmsnorm (the unfused graph order)."""
     rng = np.random.default_rng(22)
