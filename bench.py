@@ -144,6 +144,10 @@ def main() -> None:
     ap.add_argument("--microbatches", type=int, default=int(os.environ.get("NVR_MICROBATCHES", "1")),
                     help="decode micro-batches run concurrently on their own HIP streams (nvr_config.decode_microbatches)")
     ap.add_argument("--eager", action="store_true", help="enforce_eager: launch decode kernels one by one instead of replaying a hipGraph")
+    ap.add_argument("--parallel", choices=["tp", "replicas"], default=os.environ.get("NVR_BENCH_PARALLEL", "tp"),
+                    help="--gpus N > 1: 'tp' = one tensor-parallel engine over N GPUs (RCCL all-reduce, the north star's configuration, "
+                         "strong scaling: the same 32 sequences); 'replicas' = N independent engines, 32 sequences each, no exchange "
+                         "(weak scaling)")
     ap.add_argument("--materialize-logits", action="store_true",
                     help="write the f32 logits of every step to HBM (default: a greedy batch takes its tokens from the arg-max "
                          "partials of the LM-head epilogue and the logits are written only when someone asks for them)")
@@ -180,13 +184,15 @@ def main() -> None:
     total_new = args.warmup + args.steps + 1
     cfg = nvr.Config(max_num_seqs=BATCH, max_num_batched_tokens=BATCH * PROMPT_LEN, max_model_len=PROMPT_LEN + total_new + 16,
                      kvcache_block_size=BLOCK, num_kvcache_blocks=BATCH * ((PROMPT_LEN + total_new + 16) // BLOCK + 2),
-                     tensor_parallel_size=args.gpus, tensor_parallel_rank=rank, device_ordinal=local_rank,
-                     decode_microbatches=args.microbatches, enforce_eager=args.eager)
+                     tensor_parallel_size=(args.gpus if args.parallel == "tp" else 1), tensor_parallel_rank=(rank if args.parallel == "tp" else 0),
+                     device_ordinal=local_rank, decode_microbatches=args.microbatches, enforce_eager=args.eager)
     mc = nvr.ModelConfig("qwen3-0.6b")
     nvr.check(nvr.lib().nvr_device_set(local_rank))
     eng = nvr.LLMEngine(cfg, mc)
     parallelism, scaling, jobs = f"tp{args.gpus}", "strong", 1
-    if args.gpus > 1:
+    if args.gpus > 1 and args.parallel == "replicas":
+        parallelism, scaling, jobs = f"replicas{args.gpus}", "weak", args.gpus
+    if args.gpus > 1 and args.parallel == "tp":
         import torch
         uid = torch.zeros(128, dtype=torch.uint8)
         if rank == 0:
