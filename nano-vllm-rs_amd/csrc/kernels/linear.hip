@@ -313,8 +313,11 @@ int linear(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64
         if (y_f32) launch<NT_, MT_, WV_, EPI_F32>(xx, ldx, ww, t, k, n, y, e, gx, s);               \
         else launch<NT_, MT_, WV_, EPI_F16>(xx, ldx, ww, t, k, n, y, e, gx, s);                     \
     } while (0)
-    static const bool force_mt1 = std::getenv("NVR_LIN_MT1") != nullptr;      // experiment: 16-token workgroups for T > 16
-    if (T <= 16 || (force_mt1 && !wide)) {
+    // narrow outputs (N/16 < 128 column tiles: the row-parallel GEMMs of a tensor-parallel rank) with 17..32 tokens: 16-token
+    // workgroups double the workgroup count (the W tile of a column block is read by both token blocks from the same XCD's L2):
+    // 6.1 vs 8.2 us at K = 2048, N = 1024 (scratch/gemm_chain.py)
+    const bool mt1 = T <= 16 || (!wide && T <= 32 && N / 16 < 128);
+    if (mt1) {
         if (wide) NVR_LIN(4, 1, 4);
         else if (wv == 16) NVR_LIN(1, 1, 16);
         else if (wv == 8) NVR_LIN(1, 1, 8);
