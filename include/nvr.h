@@ -255,6 +255,46 @@ NVR_API size_t nvr_engine_take_finished(nvr_engine_t *e, nvr_seq_t **out, size_t
 /* sequences of the last step's batch (borrowed handles; finished ones are excluded) */
 NVR_API size_t nvr_engine_last_batch(const nvr_engine_t *e, nvr_seq_t **out, size_t cap);
 
+/* Text in, SequenceOutput out.  LLMEngine::tokenize (llm_engine.rs:220-230) is the reference's
+ * placeholder tokenizer: one token id per Unicode scalar value of the prompt, first 100 characters only (its `tokenizers`
+ * dependency is unused, Cargo.toml:21); nvr_tokenize restates it for UTF-8 input (malformed UTF-8, which a Rust String
+ * cannot hold, is NVR_ERR_INVALID_ARG) and nvr_detokenize is its inverse (ids that are not scalar values — surrogates,
+ * negatives, > 0x10FFFF — become U+FFFD).  out may be NULL to query the length. */
+#define NVR_TOKENIZE_MAX_CHARS 100
+NVR_API int nvr_tokenize(const char *utf8, size_t nbytes, int64_t *out, size_t cap, size_t *n);
+NVR_API int nvr_detokenize(const int64_t *ids, size_t n, char *out, size_t cap, size_t *nbytes);
+
+/* SequenceOutput, sequence.rs:30-47.  Pointers are borrowed from the engine: valid until the next generate /
+ * generate_stream call on it (inside a stream callback: until the callback returns). */
+typedef struct nvr_sequence_output {
+    uint64_t seq_id;
+    const char *text; size_t text_len;            /* detokenized completion, UTF-8 (also NUL-terminated) */
+    const int64_t *token_ids; size_t num_tokens;  /* prompt + completion */
+    const int64_t *completion_token_ids;          /* = token_ids + num_prompt_tokens */
+    size_t num_prompt_tokens, num_completion_tokens;
+    int32_t status;                               /* NVR_SEQ_* */
+} nvr_sequence_output;
+/* create_sequences for one prompt (llm_engine.rs:200-217): tokenize + Sequence::new + scheduler.add_sequence */
+NVR_API int nvr_engine_add_prompt(nvr_engine_t *e, const char *utf8, size_t nbytes, const nvr_sampling_params *sp,
+                                  uint64_t *seq_id_out);
+/* LLMEngine::generate (llm_engine.rs:70-97): tokenize the prompts, queue them with one SamplingParams, step until the
+ * scheduler is finished (run_inference_loop :131-152), return one output per prompt in prompt order (the reference leaves
+ * the collection as a "real implementation would" note, :188-196; this is that implementation).  n == 0 -> no outputs.
+ * Sequences queued earlier through add_request / add_prompt are stepped too and stay with take_finished. */
+NVR_API int nvr_engine_generate(nvr_engine_t *e, const char *const *prompts, const size_t *nbytes, size_t n,
+                                const nvr_sampling_params *sp, const nvr_sequence_output **outs, size_t *nout);
+/* the same over token-id prompts (the placeholder tokenizer cannot express ids that are not scalar values) */
+NVR_API int nvr_engine_generate_ids(nvr_engine_t *e, const int64_t *const *prompts, const size_t *lens, size_t n,
+                                    const nvr_sampling_params *sp, const nvr_sequence_output **outs, size_t *nout);
+/* LLMEngine::generate_stream (llm_engine.rs:100-128, run_streaming_inference :233-262): after every step the callback
+ * receives one cumulative output per sequence of the step's batch (status RUNNING, or FINISHED on its last one) — the
+ * items the reference sends through its mpsc channel; a non-zero return is the dropped receiver (:250-253): the loop
+ * stops, NVR_OK is returned and unfinished sequences stay queued (step / shutdown deal with them, as in the reference).
+ * The call is synchronous on the caller's thread (the Rust shim runs it inside its spawned task). */
+typedef int (*nvr_stream_fn)(const nvr_sequence_output *out, void *user);
+NVR_API int nvr_engine_generate_stream(nvr_engine_t *e, const char *const *prompts, const size_t *nbytes, size_t n,
+                                       const nvr_sampling_params *sp, nvr_stream_fn fn, void *user);
+
 /* --------------------------------------------------------- device utilities ---- */
 NVR_API int nvr_device_count(int *n);
 NVR_API int nvr_device_set(int ordinal);

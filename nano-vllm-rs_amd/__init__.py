@@ -15,6 +15,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 import subprocess
+from dataclasses import dataclass
 from typing import List, Optional, Sequence as Seq, Tuple
 
 import numpy as np
@@ -71,6 +72,15 @@ class EngineStatsC(C.Structure):
 class HealthStatusC(C.Structure):
     _fields_ = [("is_healthy", C.c_int32), ("memory_pressure", C.c_double), ("active_sequences", C.c_uint64),
                 ("waiting_sequences", C.c_uint64)]
+
+
+class SequenceOutputC(C.Structure):                          # nvr_sequence_output (SequenceOutput, sequence.rs:30-47)
+    _fields_ = [("seq_id", C.c_uint64), ("text", C.c_void_p), ("text_len", C.c_size_t), ("token_ids", C.c_void_p),
+                ("num_tokens", C.c_size_t), ("completion_token_ids", C.c_void_p), ("num_prompt_tokens", C.c_size_t),
+                ("num_completion_tokens", C.c_size_t), ("status", C.c_int32)]
+
+
+STREAM_FN = C.CFUNCTYPE(C.c_int, C.POINTER(SequenceOutputC), C.c_void_p)
 
 
 class BmStatsC(C.Structure):
@@ -158,6 +168,12 @@ _SIGS = {
     "nvr_engine_step": (C.c_int, [_P, C.POINTER(StepInfoC)]), "nvr_engine_is_finished": (C.c_int, [_P]),
     "nvr_engine_scheduler": (_P, [_P]), "nvr_engine_runner": (_P, [_P]),
     "nvr_engine_get_stats": (C.c_int, [_P, _P]), "nvr_engine_health_check": (C.c_int, [_P, _P]), "nvr_engine_shutdown": (C.c_int, [_P]),
+    "nvr_tokenize": (C.c_int, [C.c_char_p, C.c_size_t, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "nvr_detokenize": (C.c_int, [_P, C.c_size_t, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "nvr_engine_add_prompt": (C.c_int, [_P, C.c_char_p, C.c_size_t, _P, C.POINTER(C.c_uint64)]),
+    "nvr_engine_generate": (C.c_int, [_P, _P, _P, C.c_size_t, _P, C.POINTER(_P), C.POINTER(C.c_size_t)]),
+    "nvr_engine_generate_ids": (C.c_int, [_P, _P, _P, C.c_size_t, _P, C.POINTER(_P), C.POINTER(C.c_size_t)]),
+    "nvr_engine_generate_stream": (C.c_int, [_P, _P, _P, C.c_size_t, _P, STREAM_FN, _P]),
     "nvr_engine_last_step": (None, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(C.c_size_t)]),
     "nvr_engine_take_finished": (C.c_size_t, [_P, C.POINTER(_P), C.c_size_t]),
     "nvr_engine_last_batch": (C.c_size_t, [_P, C.POINTER(_P), C.c_size_t]),
@@ -597,6 +613,50 @@ def comm_unique_id() -> bytes:
     return bytes(buf)
 
 
+@dataclass
+class SequenceOutput:
+    """SequenceOutput, reference src/engine/sequence.rs:30-47."""
+    seq_id: int
+    text: str
+    token_ids: List[int]
+    completion_token_ids: List[int]
+    num_prompt_tokens: int
+    num_completion_tokens: int
+    status: int
+
+    @classmethod
+    def from_c(cls, c: SequenceOutputC) -> "SequenceOutput":
+        toks = np.ctypeslib.as_array(C.cast(c.token_ids, C.POINTER(C.c_int64)), (c.num_tokens,)).tolist() if c.num_tokens else []
+        text = C.string_at(c.text, c.text_len).decode("utf-8") if c.text_len else ""
+        return cls(c.seq_id, text, toks, toks[c.num_prompt_tokens:], c.num_prompt_tokens, c.num_completion_tokens, c.status)
+
+
+def tokenize(text: str) -> List[int]:
+    """LLMEngine::tokenize (llm_engine.rs:220-230): the reference's placeholder char tokenizer, through the C ABI."""
+    b = text if isinstance(text, bytes) else text.encode("utf-8")
+    out = (C.c_int64 * 100)()
+    n = C.c_size_t()
+    check(lib().nvr_tokenize(b, len(b), out, 100, C.byref(n)))
+    return list(out[:n.value])
+
+
+def detokenize(ids: Seq[int]) -> str:
+    a = np.ascontiguousarray(ids, dtype=np.int64)
+    n = C.c_size_t()
+    check(lib().nvr_detokenize(a.ctypes.data, a.size, None, 0, C.byref(n)))
+    buf = C.create_string_buffer(n.value + 1)
+    check(lib().nvr_detokenize(a.ctypes.data, a.size, buf, n.value + 1, C.byref(n)))
+    return buf.raw[:n.value].decode("utf-8")
+
+
+def _text_args(prompts):
+    enc = [p if isinstance(p, bytes) else p.encode("utf-8") for p in prompts]
+    bufs = [C.create_string_buffer(b, len(b) + 1) for b in enc]
+    ptrs = (_P * max(1, len(bufs)))(*[C.addressof(b) for b in bufs])
+    lens = (C.c_size_t * max(1, len(bufs)))(*[len(b) for b in enc])
+    return ptrs, lens, bufs
+
+
 class LLMEngine:
     """The hot loop of LLMEngine (reference src/engine/llm_engine.rs:155-197) over one ModelRunner."""
 
@@ -651,6 +711,56 @@ class LLMEngine:
 
     def shutdown(self) -> None:                               # llm_engine.rs:345-357
         check(lib().nvr_engine_shutdown(self.h))
+
+    # ---- text in, SequenceOutput out (llm_engine.rs:70-128,200-230)
+    def add_prompt(self, text: str, sp: Optional[SamplingParams] = None) -> int:
+        b = text.encode("utf-8")
+        sid = C.c_uint64()
+        spc = (sp or SamplingParams()).to_c()
+        check(lib().nvr_engine_add_prompt(self.h, b, len(b), C.byref(spc), C.byref(sid)))
+        return sid.value
+
+    def generate(self, prompts, sp: Optional[SamplingParams] = None) -> List["SequenceOutput"]:
+        """LLMEngine::generate: prompts are strings (placeholder char tokenizer) or token-id lists; one
+        SamplingParams for all; outputs in prompt order."""
+        prompts = list(prompts)
+        spc = (sp or SamplingParams()).to_c()
+        outs, n = _P(), C.c_size_t()
+        if prompts and not isinstance(prompts[0], (str, bytes)):
+            arrs = [np.ascontiguousarray(p, dtype=np.int64) for p in prompts]
+            ptrs = (_P * len(arrs))(*[a.ctypes.data for a in arrs])
+            lens = (C.c_size_t * len(arrs))(*[a.size for a in arrs])
+            check(lib().nvr_engine_generate_ids(self.h, ptrs, lens, len(arrs), C.byref(spc), C.byref(outs), C.byref(n)))
+        else:
+            ptrs, lens, keep = _text_args(prompts)
+            check(lib().nvr_engine_generate(self.h, ptrs, lens, len(prompts), C.byref(spc), C.byref(outs), C.byref(n)))
+        if not n.value:
+            return []
+        arr = C.cast(outs, C.POINTER(SequenceOutputC * n.value)).contents
+        return [SequenceOutput.from_c(arr[i]) for i in range(n.value)]
+
+    def generate_stream(self, prompts: Seq[str], sp: Optional[SamplingParams] = None, on_output=None) -> List["SequenceOutput"]:
+        """LLMEngine::generate_stream: on_output(SequenceOutput) is called for every sequence of every step's batch
+        (cumulative text / tokens); returning a truthy value stops the stream (the dropped receiver).  Returns the
+        list of everything delivered."""
+        prompts = list(prompts)
+        spc = (sp or SamplingParams()).to_c()
+        got: List[SequenceOutput] = []
+        err: List[BaseException] = []
+
+        def _cb(po, _user):
+            try:
+                o = SequenceOutput.from_c(po.contents)
+                got.append(o)
+                return 1 if (on_output is not None and on_output(o)) else 0
+            except BaseException as ex:                         # never unwind through the C frames
+                err.append(ex)
+                return 1
+        ptrs, lens, keep = _text_args(prompts)
+        check(lib().nvr_engine_generate_stream(self.h, ptrs, lens, len(prompts), C.byref(spc), STREAM_FN(_cb), None))
+        if err:
+            raise err[0]
+        return got
 
     def last_batch(self) -> List[Sequence]:
         out = (_P * 4096)()

@@ -52,3 +52,111 @@ int nvr_engine::step(nvr_step_info *info) {                          // LLMEngin
     }
     return NVR_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Callers around the hot loop: placeholder tokenizer, generate, generate_stream.
+
+// LLMEngine::tokenize, llm_engine.rs:220-230: text.chars().map(|c| c as u32 as i64).take(100)
+int nvr::tokenize(const char *utf8, size_t nbytes, std::vector<int64_t> &out) {
+    out.clear();
+    const unsigned char *p = (const unsigned char *)utf8;
+    size_t i = 0;
+    while (i < nbytes && out.size() < NVR_TOKENIZE_MAX_CHARS) {
+        const unsigned c = p[i];
+        unsigned cp; size_t len;
+        if (c < 0x80) { cp = c; len = 1; }
+        else if ((c & 0xE0) == 0xC0) { cp = c & 0x1F; len = 2; }
+        else if ((c & 0xF0) == 0xE0) { cp = c & 0x0F; len = 3; }
+        else if ((c & 0xF8) == 0xF0) { cp = c & 0x07; len = 4; }
+        else return nvr::fail(NVR_ERR_INVALID_ARG, "tokenize: invalid UTF-8 lead byte 0x%02x at offset %zu", c, i);
+        if (i + len > nbytes) return nvr::fail(NVR_ERR_INVALID_ARG, "tokenize: truncated UTF-8 sequence at offset %zu", i);
+        for (size_t k = 1; k < len; ++k) {
+            if ((p[i + k] & 0xC0) != 0x80) return nvr::fail(NVR_ERR_INVALID_ARG, "tokenize: invalid UTF-8 continuation byte at offset %zu", i + k);
+            cp = (cp << 6) | (p[i + k] & 0x3F);
+        }
+        // what a Rust String can never hold: overlong forms, surrogates, values past U+10FFFF
+        static const unsigned kMin[5] = {0, 0, 0x80, 0x800, 0x10000};
+        if (cp < kMin[len] || cp > 0x10FFFF || (cp >= 0xD800 && cp <= 0xDFFF))
+            return nvr::fail(NVR_ERR_INVALID_ARG, "tokenize: invalid UTF-8 scalar value U+%04X at offset %zu", cp, i);
+        out.push_back((int64_t)cp);
+        i += len;
+    }
+    return NVR_OK;
+}
+
+void nvr::detokenize(const int64_t *ids, size_t n, std::string &out) {
+    out.clear();
+    for (size_t i = 0; i < n; ++i) {
+        uint32_t cp = (ids[i] < 0 || ids[i] > 0x10FFFF || (ids[i] >= 0xD800 && ids[i] <= 0xDFFF)) ? 0xFFFDu : (uint32_t)ids[i];
+        if (cp < 0x80) out.push_back((char)cp);
+        else if (cp < 0x800) { out.push_back((char)(0xC0 | (cp >> 6))); out.push_back((char)(0x80 | (cp & 0x3F))); }
+        else if (cp < 0x10000) {
+            out.push_back((char)(0xE0 | (cp >> 12))); out.push_back((char)(0x80 | ((cp >> 6) & 0x3F))); out.push_back((char)(0x80 | (cp & 0x3F)));
+        } else {
+            out.push_back((char)(0xF0 | (cp >> 18))); out.push_back((char)(0x80 | ((cp >> 12) & 0x3F)));
+            out.push_back((char)(0x80 | ((cp >> 6) & 0x3F))); out.push_back((char)(0x80 | (cp & 0x3F)));
+        }
+    }
+}
+
+int nvr_engine::add_ids(const int64_t *prompt, size_t n, const nvr_sampling_params *sp, uint64_t *id_out) {
+    if (sp) { int rc = nvr_sampling_params_validate(sp); if (rc) return rc; }
+    if (n == 0) return nvr::fail(NVR_ERR_INVALID_ARG, "empty prompt");
+    for (size_t i = 0; i < n; ++i)                                        // a request the model cannot embed is refused here,
+        if ((uint64_t)prompt[i] >= (uint64_t)runner->V)                   // not when its batch reaches execute_model
+            return nvr::fail(NVR_ERR_INVALID_ARG, "token id %ld at position %zu is outside the vocabulary [0, %ld)", (long)prompt[i], i, (long)runner->V);
+    nvr_seq *s = nvr_seq_create(prompt, n, sp, cfg.kvcache_block_size);
+    if (!s) return NVR_ERR_INVARIANT;
+    scheduler->impl.add_sequence(s);
+    if (id_out) *id_out = s->seq_id;
+    return NVR_OK;
+}
+
+static void fill_output(nvr_engine::SeqOut &o, const nvr_seq &s) {
+    o.seq_id = s.seq_id; o.tokens = s.token_ids; o.nprompt = s.num_prompt_tokens; o.status = s.status;
+    nvr::detokenize(o.tokens.data() + o.nprompt, o.tokens.size() - o.nprompt, o.text);
+}
+static nvr_sequence_output view_of(const nvr_engine::SeqOut &o) {
+    nvr_sequence_output v{};
+    v.seq_id = o.seq_id; v.text = o.text.c_str(); v.text_len = o.text.size();
+    v.token_ids = o.tokens.data(); v.num_tokens = o.tokens.size();
+    v.completion_token_ids = o.tokens.data() + o.nprompt;
+    v.num_prompt_tokens = o.nprompt; v.num_completion_tokens = o.tokens.size() - o.nprompt; v.status = o.status;
+    return v;
+}
+
+// generate :70-97 / generate_stream :100-128 over already tokenized prompts
+int nvr_engine::generate(const std::vector<std::vector<int64_t>> &prompts, const nvr_sampling_params *sp, nvr_stream_fn fn, void *user) {
+    gen_store.clear(); gen_view.clear();
+    if (prompts.empty()) return NVR_OK;                                           // :76-78
+    // validate everything before the first sequence is queued: a bad prompt must not leave half a request behind
+    if (sp) { int rc = nvr_sampling_params_validate(sp); if (rc) return rc; }
+    for (size_t i = 0; i < prompts.size(); ++i) {
+        if (prompts[i].empty()) return nvr::fail(NVR_ERR_INVALID_ARG, "generate: prompt %zu is empty", i);
+        for (int64_t t : prompts[i])
+            if ((uint64_t)t >= (uint64_t)runner->V)
+                return nvr::fail(NVR_ERR_INVALID_ARG, "generate: prompt %zu holds token id %ld outside the vocabulary [0, %ld)", i, (long)t, (long)runner->V);
+    }
+    std::vector<uint64_t> ids(prompts.size());
+    for (size_t i = 0; i < prompts.size(); ++i) { int rc = add_ids(prompts[i].data(), prompts[i].size(), sp, &ids[i]); if (rc) return rc; }
+    SeqOut live;
+    while (!scheduler->impl.is_finished()) {                                      // run_inference_loop :131-152
+        int rc = step(nullptr);
+        if (rc) return rc;
+        if (!fn) continue;
+        for (nvr_seq *s : batch) {                                                // execute_streaming_step :265-301
+            fill_output(live, *s);
+            const nvr_sequence_output v = view_of(live);
+            if (fn(&v, user)) return NVR_OK;                                      // receiver dropped :250-253
+        }
+    }
+    gen_store.resize(prompts.size());
+    for (size_t i = 0; i < prompts.size(); ++i) {
+        nvr_seq *s = scheduler->impl.take_finished_id(ids[i]);
+        if (!s) return nvr::fail(NVR_ERR_INVARIANT, "generate: sequence %lu did not finish", (unsigned long)ids[i]);
+        fill_output(gen_store[i], *s);
+        delete s;
+    }
+    for (const SeqOut &o : gen_store) gen_view.push_back(view_of(o));
+    return NVR_OK;
+}

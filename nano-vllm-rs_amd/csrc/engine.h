@@ -1,8 +1,9 @@
 // engine.h — the hot loop of LLMEngine (reference src/engine/llm_engine.rs:155-197):
-// schedule -> execute_model -> sample_tokens -> postprocess.  Everything else in that file (tokio
-// streaming, builder, health, char tokenizer) is outside the hot path.
+// schedule -> execute_model -> sample_tokens -> postprocess, and the callers around it:
+// generate / generate_stream with the placeholder char tokenizer (:70-128,:200-230), stats / health (:312-357).
 #pragma once
 #include <memory>
+#include <string>
 #include <vector>
 #include "model_runner.h"
 #include "scheduler.h"
@@ -16,4 +17,16 @@ struct nvr_engine {
     std::vector<int64_t> last_tokens;
     bool is_running = true;                              // llm_engine.rs:37,353: cleared by shutdown()
     int step(nvr_step_info *info);
+
+    // SequenceOutput storage of the last generate / generate_stream call (sequence.rs:30-47)
+    struct SeqOut { uint64_t seq_id = 0; std::string text; std::vector<int64_t> tokens; size_t nprompt = 0; int32_t status = 0; };
+    std::vector<SeqOut> gen_store;
+    std::vector<nvr_sequence_output> gen_view;
+    int add_ids(const int64_t *prompt, size_t n, const nvr_sampling_params *sp, uint64_t *id_out);
+    int generate(const std::vector<std::vector<int64_t>> &prompts, const nvr_sampling_params *sp, nvr_stream_fn fn, void *user);
 };
+
+namespace nvr {
+int tokenize(const char *utf8, size_t nbytes, std::vector<int64_t> &out);      // llm_engine.rs:220-230
+void detokenize(const int64_t *ids, size_t n, std::string &out);
+}

@@ -458,6 +458,8 @@ int nvr_model_runner::execute(nvr_seq *const *seqs, size_t nseq, bool is_prefill
             if ((int64_t)s.block_table.size() * bs < len) return nvr::fail(NVR_ERR_NOT_ALLOCATED, "Sequence has no allocated blocks");
             const int64_t c0 = prefill_paged ? std::max<int64_t>(0, std::min<int64_t>((int64_t)s.num_cached_tokens, len - 1)) : 0;
             for (int64_t p = c0; p < len; ++p) {
+                if ((uint64_t)s.token_ids[p] >= (uint64_t)V)                 // candle's index_select rejects these (embed_head.rs:80)
+                    return nvr::fail(NVR_ERR_INVALID_ARG, "token id %ld at position %ld is outside the vocabulary [0, %ld)", (long)s.token_ids[p], (long)p, (long)V);
                 ids[T] = s.token_ids[p]; pos[T] = p;
                 slots[T] = (int32_t)((int64_t)s.block_table[p / bs] * bs + p % bs);
                 ctx[T] = (int32_t)(p + 1); kvb[T] = cu[b];
@@ -498,6 +500,8 @@ int nvr_model_runner::execute(nvr_seq *const *seqs, size_t nseq, bool is_prefill
             const int64_t len = (int64_t)s.len();
             if (len > max_pos) return nvr::fail(NVR_ERR_INVALID_ARG, "sequence of %ld tokens exceeds max_model_len %ld", (long)len, (long)max_pos);
             if ((int64_t)s.block_table.size() * bs < len) return nvr::fail(NVR_ERR_NOT_ALLOCATED, "Sequence has no allocated blocks");
+            if ((uint64_t)s.last_token >= (uint64_t)V)
+                return nvr::fail(NVR_ERR_INVALID_ARG, "token id %ld is outside the vocabulary [0, %ld)", (long)s.last_token, (long)V);
             ids[b] = s.last_token; pos[b] = len - 1;                                      // :201-202
             slots[b] = (int32_t)((int64_t)s.block_table[(len - 1) / bs] * bs + (len - 1) % bs);
             ctx[b] = (int32_t)len;                                                        // :275

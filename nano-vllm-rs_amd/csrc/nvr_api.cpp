@@ -246,13 +246,90 @@ nvr_engine_t *nvr_engine_create(const nvr_config *cfg, const nvr_model_config *m
 void nvr_engine_destroy(nvr_engine_t *e) { delete e; }
 int nvr_engine_add_request(nvr_engine_t *e, const int64_t *prompt, size_t n, const nvr_sampling_params *sp, uint64_t *id_out) {
     NVR_GUARD_BEGIN
-    if (sp) { int rc = nvr_sampling_params_validate(sp); if (rc) return rc; }
-    if (n == 0) return nvr::fail(NVR_ERR_INVALID_ARG, "empty prompt");
-    nvr_seq *s = nvr_seq_create(prompt, n, sp, e->cfg.kvcache_block_size);
-    if (!s) return NVR_ERR_INVARIANT;
-    e->scheduler->impl.add_sequence(s);
-    if (id_out) *id_out = s->seq_id;
+    return e->add_ids(prompt, n, sp, id_out);
+    NVR_GUARD_END(NVR_ERR_INVARIANT)
+}
+// ---- text in, SequenceOutput out (llm_engine.rs:70-128,200-230)
+int nvr_tokenize(const char *utf8, size_t nbytes, int64_t *out, size_t cap, size_t *n) {
+    NVR_GUARD_BEGIN
+    if (!utf8 && nbytes) return nvr::fail(NVR_ERR_INVALID_ARG, "nvr_tokenize: text is null");
+    std::vector<int64_t> ids;
+    int rc = nvr::tokenize(utf8, nbytes, ids);
+    if (rc) return rc;
+    if (n) *n = ids.size();
+    if (!out) return NVR_OK;
+    if (ids.size() > cap) return nvr::fail(NVR_ERR_LEN_MISMATCH, "nvr_tokenize: %zu tokens, buffer holds %zu", ids.size(), cap);
+    std::memcpy(out, ids.data(), ids.size() * sizeof(int64_t));
     return NVR_OK;
+    NVR_GUARD_END(NVR_ERR_INVARIANT)
+}
+int nvr_detokenize(const int64_t *ids, size_t n, char *out, size_t cap, size_t *nbytes) {
+    NVR_GUARD_BEGIN
+    if (!ids && n) return nvr::fail(NVR_ERR_INVALID_ARG, "nvr_detokenize: ids is null");
+    std::string t;
+    nvr::detokenize(ids, n, t);
+    if (nbytes) *nbytes = t.size();
+    if (!out) return NVR_OK;
+    if (t.size() > cap) return nvr::fail(NVR_ERR_LEN_MISMATCH, "nvr_detokenize: %zu bytes, buffer holds %zu", t.size(), cap);
+    std::memcpy(out, t.data(), t.size());
+    if (t.size() < cap) out[t.size()] = 0;
+    return NVR_OK;
+    NVR_GUARD_END(NVR_ERR_INVARIANT)
+}
+int nvr_engine_add_prompt(nvr_engine_t *e, const char *utf8, size_t nbytes, const nvr_sampling_params *sp, uint64_t *id_out) {
+    NVR_GUARD_BEGIN
+    std::vector<int64_t> ids;
+    int rc = nvr::tokenize(utf8, nbytes, ids);
+    if (rc) return rc;
+    return e->add_ids(ids.data(), ids.size(), sp, id_out);
+    NVR_GUARD_END(NVR_ERR_INVARIANT)
+}
+static int tokenize_all(const char *const *prompts, const size_t *nbytes, size_t n, std::vector<std::vector<int64_t>> &ids) {
+    if (n && (!prompts || !nbytes)) return nvr::fail(NVR_ERR_INVALID_ARG, "generate: prompts / nbytes is null");
+    ids.resize(n);
+    for (size_t i = 0; i < n; ++i) { int rc = nvr::tokenize(prompts[i], nbytes[i], ids[i]); if (rc) return rc; }
+    return NVR_OK;
+}
+static void hand_out(nvr_engine_t *e, const nvr_sequence_output **outs, size_t *nout) {
+    if (outs) *outs = e->gen_view.data();
+    if (nout) *nout = e->gen_view.size();
+}
+int nvr_engine_generate(nvr_engine_t *e, const char *const *prompts, const size_t *nbytes, size_t n, const nvr_sampling_params *sp,
+                        const nvr_sequence_output **outs, size_t *nout) {
+    NVR_GUARD_BEGIN
+    if (outs) *outs = nullptr;
+    if (nout) *nout = 0;
+    std::vector<std::vector<int64_t>> ids;
+    int rc = tokenize_all(prompts, nbytes, n, ids);
+    if (rc) return rc;
+    rc = e->generate(ids, sp, nullptr, nullptr);
+    if (rc) return rc;
+    hand_out(e, outs, nout);
+    return NVR_OK;
+    NVR_GUARD_END(NVR_ERR_INVARIANT)
+}
+int nvr_engine_generate_ids(nvr_engine_t *e, const int64_t *const *prompts, const size_t *lens, size_t n, const nvr_sampling_params *sp,
+                            const nvr_sequence_output **outs, size_t *nout) {
+    NVR_GUARD_BEGIN
+    if (outs) *outs = nullptr;
+    if (nout) *nout = 0;
+    if (n && (!prompts || !lens)) return nvr::fail(NVR_ERR_INVALID_ARG, "generate: prompts / lens is null");
+    std::vector<std::vector<int64_t>> ids(n);
+    for (size_t i = 0; i < n; ++i) ids[i].assign(prompts[i], prompts[i] + lens[i]);
+    int rc = e->generate(ids, sp, nullptr, nullptr);
+    if (rc) return rc;
+    hand_out(e, outs, nout);
+    return NVR_OK;
+    NVR_GUARD_END(NVR_ERR_INVARIANT)
+}
+int nvr_engine_generate_stream(nvr_engine_t *e, const char *const *prompts, const size_t *nbytes, size_t n, const nvr_sampling_params *sp,
+                               nvr_stream_fn fn, void *user) {
+    NVR_GUARD_BEGIN
+    if (!fn) return nvr::fail(NVR_ERR_INVALID_ARG, "generate_stream: callback is null");
+    std::vector<std::vector<int64_t>> ids;
+    int rc = tokenize_all(prompts, nbytes, n, ids);
+    if (rc) return rc;
+    return e->generate(ids, sp, fn, user);
     NVR_GUARD_END(NVR_ERR_INVARIANT)
 }
 int nvr_engine_step(nvr_engine_t *e, nvr_step_info *info) { NVR_GUARD_BEGIN return e->step(info); NVR_GUARD_END(NVR_ERR_INVARIANT) }

@@ -145,4 +145,15 @@ size_t Scheduler::take_finished(nvr_seq **out, size_t cap) {
     return n;
 }
 
+nvr_seq *Scheduler::take_finished_id(uint64_t seq_id) {
+    for (size_t i = 0; i < finished_.size(); ++i)
+        if (finished_[i]->seq_id == seq_id) {
+            nvr_seq *s = finished_[i];
+            finished_.erase(finished_.begin() + (long)i);
+            s->owned_by_scheduler = false;
+            return s;
+        }
+    return nullptr;
+}
+
 }  // namespace nvr

@@ -29,6 +29,7 @@ public:
     size_t running_len() const { return running_.size(); }
     double memory_pressure() const;                                                     // :322
     size_t take_finished(nvr_seq **out, size_t cap);
+    nvr_seq *take_finished_id(uint64_t seq_id);      // one finished sequence by id (nullptr: not finished / unknown)
     bool has_eos() const { return has_eos_; }
     int64_t eos() const { return eos_; }
 

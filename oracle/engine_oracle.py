@@ -566,3 +566,37 @@ def prepare_decode(seqs: List[Sequence], block_size: int) -> dict:
     bt = [list(s.block_table) + [-1] * (max_blocks - len(s.block_table)) for s in seqs]
     return dict(input_ids=ids, positions=pos, slot_mapping=slots, context_lens=ctx,
                 block_tables=bt, max_blocks=max_blocks)
+
+
+# ---------------------------------------------------------------------------
+# Text in, SequenceOutput out — src/engine/llm_engine.rs:70-128,200-230 and
+# src/engine/sequence.rs:30-47
+# ---------------------------------------------------------------------------
+TOKENIZE_MAX_CHARS = 100
+
+
+def tokenize(text: str) -> List[int]:
+    """LLMEngine::tokenize, llm_engine.rs:220-230 — the reference's placeholder:
+    text.chars().map(|c| c as u32 as i64).take(100)."""
+    return [ord(c) for c in text][:TOKENIZE_MAX_CHARS]
+
+
+def detokenize(ids: List[int]) -> str:
+    """Inverse of the placeholder tokenizer; ids that are not Unicode scalar values become U+FFFD."""
+    return "".join(chr(i) if 0 <= i <= 0x10FFFF and not 0xD800 <= i <= 0xDFFF else "\ufffd" for i in ids)
+
+
+@dataclass
+class SequenceOutput:                                   # sequence.rs:30-47
+    seq_id: int
+    text: str
+    token_ids: List[int]
+    completion_token_ids: List[int]
+    num_prompt_tokens: int
+    num_completion_tokens: int
+    status: int
+
+
+def sequence_output(seq: "Sequence") -> SequenceOutput:
+    comp = list(seq.completion_token_ids())
+    return SequenceOutput(seq.seq_id, detokenize(comp), list(seq.token_ids), comp, seq.num_prompt_tokens, len(comp), seq.status)

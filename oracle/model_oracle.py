@@ -20,6 +20,8 @@ from __future__ import annotations
 from dataclasses import dataclass, field, replace
 from typing import Dict, List, Optional
 
+import copy
+
 import numpy as np
 
 from . import (add, attn_paged, attn_prefill_varlen, embedding, fill_tokens, fill_weight, kv_store, linear,
@@ -304,6 +306,8 @@ class OracleEngine:
         self.sample_seed = sample_seed
         self.step_count = 0
         self.trace: List[dict] = []
+        self.finished: dict = {}               # seq_id -> finished Sequence (SequenceOutput emission, llm_engine.rs:188-196)
+        self.last_batch: list = []
 
     def add_request(self, prompt: List[int], sp: eo.SamplingParams, seq_id: Optional[int] = None) -> eo.Sequence:
         seq = eo.Sequence(prompt, sp, self.config.kvcache_block_size, seq_id)
@@ -333,7 +337,27 @@ class OracleEngine:
             toks = list(forced_tokens)
         self.scheduler.postprocess(seqs, toks)
         self.step_count += 1
+        self.last_batch = seqs                 # the step's (updated) sequences: what generate_stream reports
+        for s in seqs:
+            if s.is_finished():
+                self.finished[s.seq_id] = s
         return rec
+
+    def generate(self, prompts, sp: eo.SamplingParams, on_output=None) -> List[eo.SequenceOutput]:
+        """LLMEngine::generate / generate_stream (llm_engine.rs:70-128): string prompts go through the placeholder
+        tokenizer (:220-230), one SamplingParams for all, loop until the scheduler is finished (:131-152); outputs in
+        prompt order.  on_output(SequenceOutput) sees every sequence of every step's batch; truthy return = dropped
+        receiver (:250-253), the loop stops."""
+        if not prompts:
+            return []
+        seqs = [self.add_request(eo.tokenize(p) if isinstance(p, str) else list(p), copy.deepcopy(sp)) for p in prompts]
+        while not self.scheduler.is_finished():
+            self.step()
+            if on_output is not None:
+                for s in self.last_batch:
+                    if on_output(eo.sequence_output(s)):
+                        return []
+        return [eo.sequence_output(self.finished.pop(s.seq_id)) for s in seqs]
 
     def run(self, max_steps: int = 1 << 30) -> List[dict]:
         out = []

@@ -300,3 +300,98 @@ def test_eos_and_stochastic_sampling_paths():
             agree += int(tg == to); total += 1
     # same counter-RNG keys on both sides: the stochastic rows agree except at numerical near-ties
     assert agree >= total - 3, (agree, total)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# text in, SequenceOutput out (LLMEngine::generate / generate_stream, llm_engine.rs:70-128)
+_GEN_ECFG = dict(max_num_seqs=4, max_num_batched_tokens=256, max_model_len=256, kvcache_block_size=16, num_kvcache_blocks=40)
+_GEN_PROMPTS = ["hello world", "abc", "The quick brown fox jumps over the lazy dog", "x" * 140, "Zz"]
+
+
+def _gen_engine(mcfg, **kw):
+    nvr.lib().nvr_seq_reset_id_counter()
+    return nvr.LLMEngine(nvr.Config(skip_block_size_check=1, **{**_GEN_ECFG, **kw}), _model_cfgs(mcfg))
+
+
+def test_generate_returns_sequence_outputs_in_prompt_order():
+    """generate() == the same requests stepped by hand, == the oracle engine (teacher-forced run of _run_pair)."""
+    mcfg = mo.small(seed=5)
+    sp = dict(temperature=0.0, max_tokens=12, ignore_eos=True)
+    outs = _gen_engine(mcfg).generate(_GEN_PROMPTS, nvr.SamplingParams(**sp))
+    assert [o.seq_id for o in outs] == list(range(len(_GEN_PROMPTS)))                  # prompt order (5 prompts > max_num_seqs 4)
+    ids = [eo.tokenize(p) for p in _GEN_PROMPTS]
+    assert [o.num_prompt_tokens for o in outs] == [11, 3, 43, 100, 2]                  # the 140-char prompt is cut at 100 chars
+    r = _run_pair(mcfg, _GEN_ECFG, ids, [sp] * len(ids))                               # product stepped by hand vs oracle, per step
+    assert r["near_ties"] <= 2
+    for o, pid in zip(outs, ids):
+        assert o.token_ids == r["finished"][o.seq_id] and o.token_ids[:o.num_prompt_tokens] == pid
+        assert o.completion_token_ids == o.token_ids[o.num_prompt_tokens:] and o.num_completion_tokens == 12
+        assert o.text == eo.detokenize(o.completion_token_ids) == nvr.detokenize(o.completion_token_ids)
+        assert o.status == eo.FINISHED
+    # the oracle's own SequenceOutput emission over the teacher-forced sequences
+    exp = [eo.sequence_output(r["oracle"].finished[i]) for i in range(len(ids))]
+    assert [(e.seq_id, e.text, e.token_ids, e.completion_token_ids, e.num_prompt_tokens, e.num_completion_tokens, e.status) for e in exp] == \
+           [(o.seq_id, o.text, o.token_ids, o.completion_token_ids, o.num_prompt_tokens, o.num_completion_tokens, o.status) for o in outs]
+
+
+def test_generate_token_prompts_empty_list_and_errors():
+    mcfg = mo.small(seed=5)
+    eng = _gen_engine(mcfg)
+    assert eng.generate([]) == []                                                      # llm_engine.rs:76-78
+    sp = nvr.SamplingParams(temperature=0.0, max_tokens=5, ignore_eos=True)
+    a = eng.generate([[1, 2, 3], [1000, 7]], sp)
+    assert [o.token_ids[:o.num_prompt_tokens] for o in a] == [[1, 2, 3], [1000, 7]] and all(o.num_completion_tokens == 5 for o in a)
+    # a second call on the same engine starts from an empty scheduler and returns only its own prompts
+    b = eng.generate(["abc"], sp)
+    assert len(b) == 1 and b[0].num_prompt_tokens == 3 and eng.is_finished() and eng.take_finished() == []
+    # requests the model cannot embed are refused before anything is queued (vocab 1024: '€' = 8364)
+    for bad in (["ok", "caf€"], [[5, 1024]], [[5, -1]], ["ok", ""]):
+        with pytest.raises(nvr.NvrError):
+            eng.generate(bad, sp)
+        assert eng.is_finished() and eng.scheduler.get_queue_lengths() == (0, 0)
+    with pytest.raises(nvr.NvrError):
+        eng.add_request([1, 2, 4096])
+    with pytest.raises(nvr.NvrError):
+        eng.generate(["abc"], nvr.SamplingParams(temperature=-1.0))
+    assert eng.add_prompt("hi", sp) >= 0 and eng.scheduler.get_queue_lengths() == (1, 0)
+    # a sequence queued through add_prompt is stepped by generate too but stays with take_finished
+    c = eng.generate(["yo"], sp)
+    assert len(c) == 1 and [len(s.token_ids) for s in eng.take_finished()] == [2 + 5]
+
+
+def test_generate_stream_delivers_every_step_and_stops_when_the_receiver_drops():
+    mcfg = mo.small(seed=5)
+    sp = nvr.SamplingParams(temperature=0.0, max_tokens=6, ignore_eos=True)
+    prompts = _GEN_PROMPTS[:3]
+    final = {o.seq_id: o for o in _gen_engine(mcfg).generate(prompts, sp)}
+    eng = _gen_engine(mcfg)
+    got = eng.generate_stream(prompts, sp)
+    assert eng.is_finished() and len(got) == 3 * 6                                     # prefill step + 5 decode steps, 3 sequences each
+    per = {}
+    for o in got:
+        per.setdefault(o.seq_id, []).append(o)
+    for sid, lst in per.items():
+        assert [o.num_completion_tokens for o in lst] == [1, 2, 3, 4, 5, 6]            # cumulative, one token per step
+        assert [o.status for o in lst] == [eo.RUNNING] * 5 + [eo.FINISHED]
+        for o in lst:
+            assert o.token_ids == final[sid].token_ids[:len(o.token_ids)] and o.text == final[sid].text[:o.num_completion_tokens]
+        assert lst[-1] == final[sid]
+    # the oracle's stream reports the same sequence of (seq_id, completion length, status)
+    eo.reset_sequence_counter()
+    oe = mo.OracleEngine(mcfg, eo.Config(**_GEN_ECFG), fp16=True, max_pos=_GEN_ECFG["max_model_len"])
+    ostream = []
+    oe.generate(prompts, eo.SamplingParams(temperature=0.0, max_tokens=6, ignore_eos=True), on_output=lambda o: ostream.append(o) and False)
+    assert [(o.seq_id, o.num_completion_tokens, o.status) for o in ostream] == [(o.seq_id, o.num_completion_tokens, o.status) for o in got]
+    # dropped receiver (llm_engine.rs:250-253): the loop stops after the delivery that returned non-zero
+    eng = _gen_engine(mcfg)
+    seen = []
+    got = eng.generate_stream(prompts, sp, on_output=lambda o: seen.append(o) or len(seen) == 4)
+    assert len(got) == 4 and not eng.is_finished() and eng.scheduler.get_queue_lengths() == (0, 3)
+    while not eng.is_finished():                                                       # the queued sequences are still good
+        eng.step()
+    assert sorted(tuple(s.token_ids) for s in eng.take_finished()) == sorted(tuple(o.token_ids) for o in final.values())
+    # an exception inside the callback stops the stream and is re-raised on the Python side
+    eng = _gen_engine(mcfg)
+    with pytest.raises(ZeroDivisionError):
+        eng.generate_stream(prompts, sp, on_output=lambda o: 1 / 0)
+    eng.shutdown()
