@@ -362,7 +362,8 @@ NVR_API int nvr_linear_splitk(const nvr_half *x, int64_t ldx, const nvr_half *W,
                               float *slabs, void *stream);
 NVR_API int nvr_add_rmsnorm_slabs(nvr_half *h, const float *slabs, int64_t S, const nvr_half *w, float eps, int64_t T,
                                   int64_t Hd, nvr_half *out, void *stream);
-/* both of the above in ONE launch (the decode path's form): the workgroups publish their partial tiles, count
+/* both of the above in ONE launch (opt-in, NVR_FUSED_SLABNORM=1: measured slower than the two launches; same rounding
+ * points, normalised rows within 1 fp16 ulp of the two-launch form): the workgroups publish their partial tiles, count
  * arrivals in sync[0] and workgroups 0..T-1 finish one row each.  sync = 4 zero-initialised uint32 in device memory
  * (re-armed by the kernel; sync[2] != 0 afterwards means an arrival wait timed out).  N <= 2048, T <= 64. */
 NVR_API int nvr_linear_splitk_norm(const nvr_half *x, int64_t ldx, const nvr_half *W, int64_t T, int64_t K, int64_t N,

@@ -44,42 +44,6 @@ __device__ __forceinline__ half8_t load_row16(const half_t *p) {
     return *reinterpret_cast<const half8_t *>(p);
 }
 
-// sum over the LPR (= 16 or 8) consecutive lanes that hold one K row, result in every lane of the group: DPP row
-// rotations / quad permutes fused into v_add_f32 (no LDS traffic; __shfl_xor compiles to ds_bpermute_b32)
-template <int CTRL>
-__device__ __forceinline__ float dpp_add(float x) {
-    const int y = __builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, false);
-    return x + __int_as_float(y);
-}
-template <int LPR>
-__device__ __forceinline__ float row_sum(float x) {
-    if (LPR == 16) { x = dpp_add<0x128>(x); x = dpp_add<0x124>(x); }     // row_ror:8, row_ror:4
-    else x = dpp_add<0x141>(x);                                            // row_half_mirror (8 lanes: i <-> 7-i)
-    x = dpp_add<0x4E>(x);                                                  // quad_perm [2,3,0,1]
-    x = dpp_add<0xB1>(x);                                                  // quad_perm [1,0,3,2]
-    return x;
-}
-
-// lane-wise butterflies across the 16-lane rows of a wave on the gfx950 lane-swap instructions (no LDS traffic):
-// v_permlane16_swap exchanges the odd rows of one register with the even rows of another, v_permlane32_swap the
-// upper half of one with the lower half of the other; fed the same value twice, the two results are x and its
-// xor-16 (xor-32) partner.
-__device__ __forceinline__ float xor16_partner_sum(float x) {
-    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-__device__ __forceinline__ float xor32_partner_sum(float x) {
-    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-__device__ __forceinline__ float xor16_partner_max(float x) {
-    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
-}
-__device__ __forceinline__ float xor32_partner_max(float x) {
-    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
-}
 // sum / max over the 64/LPR row groups of the wave (lanes with equal lane % LPR), result in every lane
 template <int LPR>
 __device__ __forceinline__ float groups_sum(float x) {

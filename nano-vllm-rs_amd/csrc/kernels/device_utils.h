@@ -22,14 +22,52 @@ __device__ __forceinline__ half_t to_half_rn(float f) {
     return (half_t)f;
 }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+// sum over the LPR (= 16 or 8) consecutive lanes that hold one K row, result in every lane of the group: DPP row
+// rotations / quad permutes fused into v_add_f32 (no LDS traffic; __shfl_xor compiles to ds_bpermute_b32)
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float x) {
+    const int y = __builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, false);
+    return x + __int_as_float(y);
+}
+template <int LPR>
+__device__ __forceinline__ float row_sum(float x) {
+    if (LPR == 16) { x = dpp_add<0x128>(x); x = dpp_add<0x124>(x); }     // row_ror:8, row_ror:4
+    else x = dpp_add<0x141>(x);                                            // row_half_mirror (8 lanes: i <-> 7-i)
+    x = dpp_add<0x4E>(x);                                                  // quad_perm [2,3,0,1]
+    x = dpp_add<0xB1>(x);                                                  // quad_perm [1,0,3,2]
+    return x;
+}
+
+// lane-wise butterflies across the 16-lane rows of a wave on the gfx950 lane-swap instructions (no LDS traffic):
+// v_permlane16_swap exchanges the odd rows of one register with the even rows of another, v_permlane32_swap the
+// upper half of one with the lower half of the other; fed the same value twice, the two results are x and its
+// xor-16 (xor-32) partner.
+__device__ __forceinline__ float xor16_partner_sum(float x) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float xor32_partner_sum(float x) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float xor16_partner_max(float x) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xor32_partner_max(float x) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+// all-lane sum / max of a wave: xor-32 and xor-16 partners on the lane-swap instructions, then the 16-lane row on DPP —
+// the same pairing order as a 32,16,8,4,2,1 xor butterfly (bit-identical sums), without its six ds_bpermute round trips
+__device__ __forceinline__ float wave_sum(float v) { return row_sum<16>(xor16_partner_sum(xor32_partner_sum(v))); }
+template <int CTRL>
+__device__ __forceinline__ float dpp_max(float x) {
+    return fmaxf(x, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, false)));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    v = xor16_partner_max(xor32_partner_max(v));
+    v = dpp_max<0x128>(v); v = dpp_max<0x124>(v); v = dpp_max<0x4E>(v); v = dpp_max<0xB1>(v);
     return v;
 }
 

@@ -133,125 +133,72 @@ int add_rmsnorm(half_bits *h, const half_bits *y, const half_bits *w, float eps,
 }
 
 // split-k consumer: y = fp16(slab0 + slab1 + ...) (f32, fixed order), h <- fp16(h + y), out = rmsnorm(h)*w.
-// One wave per row (rows are short: Hd <= 8192), one row per workgroup so that 32 rows use 32 CUs.
-template <int S, int C>   // S slabs, C chunks of 512 elements per row held in registers (all loads issued up front)
-__global__ __launch_bounds__(64) void add_rmsnorm_slabs_kernel(half_t *__restrict__ h, const float *__restrict__ slabs,
-                                                              int64_t slab_stride, const half_t *__restrict__ w, float eps,
-                                                              int Hd, half_t *__restrict__ out) {
-    const int row = blockIdx.x, lane = threadIdx.x;
-    half_t *hr = h + (int64_t)row * Hd;
-    const float *sr = slabs + (int64_t)row * Hd;
-    half_t *orow = out + (int64_t)row * Hd;
-    half8_t v[C], g[C];
-    float4_t a[C][S][2];
-#pragma unroll
-    for (int i = 0; i < C; ++i) {
-        const int c = lane * 8 + i * 512;
-        if (c < Hd) {
-            v[i] = *reinterpret_cast<const half8_t *>(hr + c);
-            g[i] = *reinterpret_cast<const half8_t *>(w + c);
-#pragma unroll
-            for (int z = 0; z < S; ++z) {
-                a[i][z][0] = *reinterpret_cast<const float4_t *>(sr + z * slab_stride + c);
-                a[i][z][1] = *reinterpret_cast<const float4_t *>(sr + z * slab_stride + c + 4);
-            }
-        }
-    }
-    float ss = 0.f;
-#pragma unroll
-    for (int i = 0; i < C; ++i) {
-        const int c = lane * 8 + i * 512;
-        if (c < Hd) {
-            float4_t a0 = a[i][0][0], a1 = a[i][0][1];
-#pragma unroll
-            for (int z = 1; z < S; ++z) { a0 += a[i][z][0]; a1 += a[i][z][1]; }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float y = (float)to_half_rn(j < 4 ? a0[j] : a1[j - 4]);
-                v[i][j] = to_half_rn((float)v[i][j] + y);
-                const float f = (float)v[i][j]; ss += f * f;
-            }
-            *reinterpret_cast<half8_t *>(hr + c) = v[i];
-        }
-    }
-    ss = wave_sum(ss);
-    const float rms = sqrtf(ss / (float)Hd + eps);
-#pragma unroll
-    for (int i = 0; i < C; ++i) {
-        const int c = lane * 8 + i * 512;
-        if (c < Hd) {
-            half8_t o;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = to_half_rn(__fmul_rn(__fdiv_rn((float)v[i][j], rms), (float)g[i][j]));
-            *reinterpret_cast<half8_t *>(orow + c) = o;
-        }
-    }
-}
-// the same for wide rows (2048 < Hd <= 8192): four waves per row, each thread one 8-element piece of every 2048-element chunk
-template <int S>
-__global__ __launch_bounds__(256) void add_rmsnorm_slabs_wide_kernel(half_t *__restrict__ h, const float *__restrict__ slabs,
-                                                                    int64_t slab_stride, const half_t *__restrict__ w, float eps,
-                                                                    int Hd, half_t *__restrict__ out) {
-    constexpr int C = 4;
+// One row per workgroup (32 rows use 32 CUs), four waves per row: the launch is latency-bound (0.7 MB of data), what counts
+// is the arithmetic per wave between the loads and the stores — a quarter of a one-wave-per-row kernel's (-40 us per
+// Qwen3-0.6B decode step, profiles/r01_gemm_ablation.txt).  Each thread owns one P-element piece of every (256*P)-element
+// chunk; the row's sum of squares crosses the waves through LDS.
+template <int S, int WAVES, int C, int P = 8>   // P = 8 or 4 elements per thread and chunk
+__global__ __launch_bounds__(WAVES * 64) void add_rmsnorm_slabs_kernel(half_t *__restrict__ h, const float *__restrict__ slabs,
+                                                                            int64_t slab_stride, const half_t *__restrict__ w, float eps,
+                                                                            int Hd, half_t *__restrict__ out) {
+    typedef half_t hp_t __attribute__((ext_vector_type(P)));
     const int row = blockIdx.x, tid = threadIdx.x;
     half_t *hr = h + (int64_t)row * Hd;
     const float *sr = slabs + (int64_t)row * Hd;
-    half8_t v[C], g[C];
+    hp_t v[C], g[C];
     float ss = 0.f;
 #pragma unroll
     for (int i = 0; i < C; ++i) {
-        const int c = tid * 8 + i * 2048;
+        const int c = tid * P + i * (WAVES * 64 * P);
         if (c < Hd) {
-            v[i] = *reinterpret_cast<const half8_t *>(hr + c);
-            g[i] = *reinterpret_cast<const half8_t *>(w + c);
-            float4_t a0 = *reinterpret_cast<const float4_t *>(sr + c), a1 = *reinterpret_cast<const float4_t *>(sr + c + 4);
+            v[i] = *reinterpret_cast<const hp_t *>(hr + c);
+            g[i] = *reinterpret_cast<const hp_t *>(w + c);
+            float4_t a[P / 4];
 #pragma unroll
-            for (int z = 1; z < S; ++z) {
-                a0 += *reinterpret_cast<const float4_t *>(sr + z * slab_stride + c);
-                a1 += *reinterpret_cast<const float4_t *>(sr + z * slab_stride + c + 4);
-            }
+            for (int q = 0; q < P / 4; ++q) a[q] = *reinterpret_cast<const float4_t *>(sr + c + 4 * q);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float y = (float)to_half_rn(j < 4 ? a0[j] : a1[j - 4]);
+            for (int z = 1; z < S; ++z)
+#pragma unroll
+                for (int q = 0; q < P / 4; ++q) a[q] += *reinterpret_cast<const float4_t *>(sr + z * slab_stride + c + 4 * q);
+#pragma unroll
+            for (int j = 0; j < P; ++j) {
+                const float y = (float)to_half_rn(a[j / 4][j % 4]);
                 v[i][j] = to_half_rn((float)v[i][j] + y);
                 const float f = (float)v[i][j]; ss += f * f;
             }
-            *reinterpret_cast<half8_t *>(hr + c) = v[i];
+            *reinterpret_cast<hp_t *>(hr + c) = v[i];
         }
     }
-    __shared__ float sm[4];
+    __shared__ float sm[WAVES];
     ss = wave_sum(ss);
     if ((tid & 63) == 0) sm[tid >> 6] = ss;
     __syncthreads();
-    const float rms = sqrtf((sm[0] + sm[1] + sm[2] + sm[3]) / (float)Hd + eps);
+    float tot = sm[0];
+#pragma unroll
+    for (int k = 1; k < WAVES; ++k) tot += sm[k];
+    const float rms = sqrtf(tot / (float)Hd + eps);
 #pragma unroll
     for (int i = 0; i < C; ++i) {
-        const int c = tid * 8 + i * 2048;
+        const int c = tid * P + i * (WAVES * 64 * P);
         if (c < Hd) {
-            half8_t o;
+            hp_t o;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = to_half_rn(__fmul_rn(__fdiv_rn((float)v[i][j], rms), (float)g[i][j]));
-            *reinterpret_cast<half8_t *>(out + (int64_t)row * Hd + c) = o;
+            for (int j = 0; j < P; ++j) o[j] = to_half_rn(__fmul_rn(__fdiv_rn((float)v[i][j], rms), (float)g[i][j]));
+            *reinterpret_cast<hp_t *>(out + (int64_t)row * Hd + c) = o;
         }
     }
 }
 
 int add_rmsnorm_slabs(half_bits *h, const float *slabs, int64_t S, const half_bits *w, float eps, int64_t T, int64_t Hd,
                       half_bits *out, hipStream_t s) {
-    if (Hd % 8 == 0 && Hd > 2048 && Hd <= 8192 && (S == 2 || S == 4)) {
-        if (T == 0) return 0;
-        if (S == 2) add_rmsnorm_slabs_wide_kernel<2><<<dim3((unsigned)T), dim3(256), 0, s>>>((half_t *)h, slabs, T * Hd, (const half_t *)w, eps, (int)Hd, (half_t *)out);
-        else add_rmsnorm_slabs_wide_kernel<4><<<dim3((unsigned)T), dim3(256), 0, s>>>((half_t *)h, slabs, T * Hd, (const half_t *)w, eps, (int)Hd, (half_t *)out);
-        LAUNCH_CHECK();
-        return 0;
-    }
-    if (Hd % 8 || Hd > 2048) return nvr::fail(NVR_ERR_UNSUPPORTED, "add_rmsnorm_slabs: hidden size %ld must be a multiple of 8, <= 8192", (long)Hd);
+    if (Hd % 8 || Hd > 8192) return nvr::fail(NVR_ERR_UNSUPPORTED, "add_rmsnorm_slabs: hidden size %ld must be a multiple of 8, <= 8192", (long)Hd);
     if (S != 2 && S != 4) return nvr::fail(NVR_ERR_UNSUPPORTED, "add_rmsnorm_slabs: S=%ld must be 2 or 4", (long)S);
     if (T == 0) return 0;
-    dim3 grid((unsigned)T), block(64);
-#define NVR_SLABN(SS, CC) add_rmsnorm_slabs_kernel<SS, CC><<<grid, block, 0, s>>>((half_t *)h, slabs, T * Hd, (const half_t *)w, eps, (int)Hd, (half_t *)out)
-    if (Hd <= 1024) { if (S == 2) NVR_SLABN(2, 2); else NVR_SLABN(4, 2); }
-    else { if (S == 2) NVR_SLABN(2, 4); else NVR_SLABN(4, 4); }
+#define NVR_SLABN(SS, CC, PP) add_rmsnorm_slabs_kernel<SS, 4, CC, PP><<<dim3((unsigned)T), dim3(256), 0, s>>>( \
+        (half_t *)h, slabs, T * Hd, (const half_t *)w, eps, (int)Hd, (half_t *)out)
+    if (Hd <= 1024) { if (S == 2) NVR_SLABN(2, 1, 4); else NVR_SLABN(4, 1, 4); }
+    else if (Hd <= 2048) { if (S == 2) NVR_SLABN(2, 1, 8); else NVR_SLABN(4, 1, 8); }
+    else { if (S == 2) NVR_SLABN(2, 4, 8); else NVR_SLABN(4, 4, 8); }
 #undef NVR_SLABN
     LAUNCH_CHECK();
     return 0;

@@ -323,7 +323,7 @@ int nvr_model_runner::copy_weight(const char *ln, uint16_t *out, size_t cap, int
 // (qwen3.rs:382-389).  Decode-sized steps on one GPU split k over S workgroups per output tile so that the
 // N = hidden GEMMs reach all 256 CUs; the f32 partial slabs are summed, added to the residual and normalised by the
 // following add_rmsnorm_slabs launch (or, with NVR_FUSED_SLABNORM=1, by the GEMM launch itself through an arrival
-// counter: bit-identical, but the cross-XCD write-through + atomic + poll round trips cost ~5 us more than the
+// counter: same rounding points (normalised rows within 1 fp16 ulp), but the cross-XCD write-through + atomic + poll round trips cost ~5 us more than the
 // kernel boundary they replace).  Otherwise the
 // plain kernel writes fp16 `proj` (+ all-reduce when tensor parallel) and add_rmsnorm follows.
 int nvr_model_runner::row_parallel_norm(Lane &ln, const uint16_t *x, int64_t K, const uint16_t *W, int64_t T, const uint16_t *wn) {

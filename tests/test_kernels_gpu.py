@@ -600,8 +600,13 @@ def test_linear_splitk_and_slab_norm(T, K, N, S):
 @pytest.mark.parametrize("T,K,N,S", [(32, 2048, 1024, 4), (32, 3072, 1024, 4), (1, 2048, 1024, 4), (64, 1024, 2048, 2),
                                      (17, 512, 256, 2), (5, 256, 1008, 2)])
 def test_linear_splitk_norm_one_launch(T, K, N, S):
-    """The one-launch form (arrival counter + row finishers) is bit-identical to linear_splitk -> add_rmsnorm_slabs,
-    launch after launch (the counters re-arm themselves) with the residual stream carried through."""
+    """The one-launch form (arrival counter + row finishers) against linear_splitk -> add_rmsnorm_slabs, launch after launch
+    (the counters re-arm themselves) with the residual stream carried through: the residual rows are bit-identical; the
+    normalised rows agree to 1 fp16 ulp (same rounding points, but the finisher sums a row's squares in one wave and the
+    two-launch norm in four: the f32 sum of squares can differ in its last bit)."""
+
+    def same_norm(a, b):
+        assert_close_f16(a.to_numpy((T, N), F16), b.to_numpy((T, N), F16), ulps=1, atol=1e-6, what="normalised rows")
     rng = np.random.default_rng(24)
     x, xb = h16(rng.standard_normal((T, K)))
     W, Wb = h16(rng.standard_normal((N, K)) * 0.05)
@@ -618,7 +623,7 @@ def test_linear_splitk_norm_one_launch(T, K, N, S):
         nvr.check(nvr.lib().nvr_linear_splitk_norm(d_x.ptr, K, d_W.ptr, T, K, N, S, d_slabs_b.ptr, d_hb.ptr, d_w.ptr, 1e-6,
                                                    d_ob.ptr, d_sync.ptr, None))
         assert np.array_equal(d_ha.to_numpy((T, N), np.uint16), d_hb.to_numpy((T, N), np.uint16)), rep
-        assert np.array_equal(d_oa.to_numpy((T, N), np.uint16), d_ob.to_numpy((T, N), np.uint16)), rep
+        same_norm(d_oa, d_ob)
         assert list(d_sync.to_numpy((4,), np.uint32)) == [0, 0, 0, 0], rep          # re-armed, no timeout
     # 200 back-to-back launches re-using the same slabs and counters (stale-cache / re-arm hazards), residual carried
     for rep in range(200):
@@ -628,7 +633,7 @@ def test_linear_splitk_norm_one_launch(T, K, N, S):
         nvr.check(nvr.lib().nvr_linear_splitk(d_x.ptr, K, d_W.ptr, T, K, N, S, d_slabs_a.ptr, None))
         nvr.check(nvr.lib().nvr_add_rmsnorm_slabs(d_ha.ptr, d_slabs_a.ptr, S, d_w.ptr, 1e-6, T, N, d_oa.ptr, None))
     assert np.array_equal(d_ha.to_numpy((T, N), np.uint16), d_hb.to_numpy((T, N), np.uint16))
-    assert np.array_equal(d_oa.to_numpy((T, N), np.uint16), d_ob.to_numpy((T, N), np.uint16))
+    same_norm(d_oa, d_ob)
     assert list(d_sync.to_numpy((4,), np.uint32)) == [0, 0, 0, 0]
     assert nvr.lib().nvr_linear_splitk_norm(d_x.ptr, K, d_W.ptr, 65, K, N, S, d_slabs_b.ptr, d_hb.ptr, d_w.ptr, 1e-6,
                                             d_ob.ptr, d_sync.ptr, None) == -10
