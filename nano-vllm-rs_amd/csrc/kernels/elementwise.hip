@@ -109,8 +109,58 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(half_t *__restrict__ h, co
         *reinterpret_cast<half8_t *>(orow + c) = o;
     }
 }
+// decode-sized calls (T <= 64 rows): one row per workgroup, four waves per row — the launch is latency-bound and what counts
+// is the arithmetic per wave between the loads and the stores (see add_rmsnorm_slabs_kernel below)
+template <bool ADD, int C, int P>   // each thread owns one P-element piece of every (256*P)-element chunk, C chunks
+__global__ __launch_bounds__(256) void rmsnorm_row4_kernel(half_t *__restrict__ h, const half_t *__restrict__ y,
+                                                           const half_t *__restrict__ w, float eps, int Hd,
+                                                           half_t *__restrict__ out) {
+    typedef half_t hp_t __attribute__((ext_vector_type(P)));
+    const int row = blockIdx.x, tid = threadIdx.x;
+    half_t *hr = h + (int64_t)row * Hd;
+    hp_t v[C], g[C];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < C; ++i) {
+        const int c = tid * P + i * (256 * P);
+        if (c < Hd) {
+            v[i] = *reinterpret_cast<const hp_t *>(hr + c);
+            g[i] = *reinterpret_cast<const hp_t *>(w + c);
+            if (ADD) {
+                const hp_t u = *reinterpret_cast<const hp_t *>(y + (int64_t)row * Hd + c);
+#pragma unroll
+                for (int j = 0; j < P; ++j) v[i][j] = to_half_rn((float)v[i][j] + (float)u[j]);
+                *reinterpret_cast<hp_t *>(hr + c) = v[i];
+            }
+#pragma unroll
+            for (int j = 0; j < P; ++j) { const float f = (float)v[i][j]; ss += f * f; }
+        }
+    }
+    __shared__ float sm[4];
+    ss = wave_sum(ss);
+    if ((tid & 63) == 0) sm[tid >> 6] = ss;
+    __syncthreads();
+    const float rms = sqrtf((sm[0] + sm[1] + sm[2] + sm[3]) / (float)Hd + eps);
+#pragma unroll
+    for (int i = 0; i < C; ++i) {
+        const int c = tid * P + i * (256 * P);
+        if (c < Hd) {
+            hp_t o;
+#pragma unroll
+            for (int j = 0; j < P; ++j) o[j] = to_half_rn(__fmul_rn(__fdiv_rn((float)v[i][j], rms), (float)g[i][j]));
+            *reinterpret_cast<hp_t *>(out + (int64_t)row * Hd + c) = o;
+        }
+    }
+}
 template <bool ADD>
 static void launch_rmsnorm(half_t *h, const half_t *y, const half_t *w, float eps, int T, int Hd, half_t *out, hipStream_t s) {
+    if (T <= 64 && Hd <= 8192) {
+        dim3 grid((unsigned)T), block(256);
+        if (Hd <= 1024) rmsnorm_row4_kernel<ADD, 1, 4><<<grid, block, 0, s>>>(h, y, w, eps, Hd, out);
+        else if (Hd <= 2048) rmsnorm_row4_kernel<ADD, 1, 8><<<grid, block, 0, s>>>(h, y, w, eps, Hd, out);
+        else rmsnorm_row4_kernel<ADD, 4, 8><<<grid, block, 0, s>>>(h, y, w, eps, Hd, out);
+        return;
+    }
     dim3 grid((unsigned)((T + 3) / 4)), block(256);
     if (Hd <= 1024) rmsnorm_kernel<ADD, 2><<<grid, block, 0, s>>>(h, y, w, eps, T, Hd, out);
     else if (Hd <= 4096) rmsnorm_kernel<ADD, 8><<<grid, block, 0, s>>>(h, y, w, eps, T, Hd, out);

@@ -79,6 +79,21 @@ __global__ __launch_bounds__(WAVES * 64) void linear_skinny_kernel(const half_t 
 #pragma unroll
         for (int j = 0; j < MT; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
 
+    // EPI_ROPE: the epilogue of token tile j runs on wave j; its position / slot / cos / sin loads are issued here, ahead of the
+    // weight stream, instead of as a chain of dependent global loads (pos -> cos,sin) after the reduction barrier
+    float4_t rope_cs = (float4_t){0.f, 0.f, 0.f, 0.f}, rope_sn = rope_cs;
+    int rope_slot = -1;
+    if (EPI == EPI_ROPE && wave < MT) {
+        const int m = m0 + wave * 16 + r, mc = m < T ? m : T - 1;
+        const int tph = epi.D / 16, head = blockIdx.x / tph, c = blockIdx.x % tph, half_d = epi.D / 2;
+        if (head < epi.H + epi.KVH) {
+            const int jj = c * 8 + (q & 1) * 4;
+            const int64_t p = epi.pos[mc];
+            rope_cs = *reinterpret_cast<const float4_t *>(epi.cos_t + p * half_d + jj);
+            rope_sn = *reinterpret_cast<const float4_t *>(epi.sin_t + p * half_d + jj);
+        }
+        if (head >= epi.H && epi.slots && m < T) rope_slot = epi.slots[m];
+    }
     constexpr int KS = 32 * WAVES;
     constexpr bool SLABBED = (EPI == EPI_SLAB || EPI == EPI_SLABNORM);
     const int kbeg = SLABBED ? blockIdx.z * epi.kslice : 0;
@@ -247,8 +262,11 @@ __global__ __launch_bounds__(WAVES * 64) void linear_skinny_kernel(const half_t 
             int col;                                           // first of the lane's 4 consecutive head columns
             if (head < epi.H + epi.KVH) {
                 const int jj = c * 8 + (q & 1) * 4;            // index inside the half dimension
-                const float4_t cs = *reinterpret_cast<const float4_t *>(epi.cos_t + epi.pos[mc] * half_d + jj);
-                const float4_t sn = *reinterpret_cast<const float4_t *>(epi.sin_t + epi.pos[mc] * half_d + jj);
+                float4_t cs = rope_cs, sn = rope_sn;
+                if (MT > WAVES) {                               // never instantiated: every token tile has its own wave
+                    cs = *reinterpret_cast<const float4_t *>(epi.cos_t + epi.pos[mc] * half_d + jj);
+                    sn = *reinterpret_cast<const float4_t *>(epi.sin_t + epi.pos[mc] * half_d + jj);
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     // rotary_embedding.rs:36-44: out1 = x1*c - x2*s ; out2 = x2*c + x1*s
@@ -263,7 +281,7 @@ __global__ __launch_bounds__(WAVES * 64) void linear_skinny_kernel(const half_t 
             }
             if (m < T) {
                 *reinterpret_cast<half4_t *>(reinterpret_cast<half_t *>(y) + (int64_t)m * ldq + head * epi.D + col) = h;
-                const int slot = epi.slots ? epi.slots[m] : -1;
+                const int slot = MT > WAVES ? (epi.slots ? epi.slots[m] : -1) : rope_slot;
                 if (slot >= 0 && head >= epi.H) {
                     const bool is_k = head < epi.H + epi.KVH;
                     const int kvh = is_k ? head - epi.H : head - epi.H - epi.KVH;
