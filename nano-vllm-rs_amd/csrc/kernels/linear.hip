@@ -403,7 +403,12 @@ int linear_silu_mul(const half_bits *x, int64_t ldx, const half_bits *W, int64_t
     const LinEpi e{};
     const unsigned gx = (unsigned)(I / 16);
     const int wv = waves_for(K);
-    if (T <= 16) {
+    // few column tiles (the shard of a tensor-parallel rank): 16-token workgroups double the workgroup count (the second token
+    // block finds its W tile in the XCD's L2) and long rows are split over 16 waves — same rule as linear()
+    const bool narrow = I / 16 < 128 && T <= 32;
+    if (narrow && wv == 16) {
+        launch<2, 1, 16, EPI_SILU>(xx, ldx, ww, (int)T, (int)K, (int)I, out, e, gx, s);
+    } else if (T <= 16 || narrow) {
         if (wv >= 8) launch<2, 1, 8, EPI_SILU>(xx, ldx, ww, (int)T, (int)K, (int)I, out, e, gx, s);
         else launch<2, 1, 4, EPI_SILU>(xx, ldx, ww, (int)T, (int)K, (int)I, out, e, gx, s);
     } else {
@@ -433,7 +438,10 @@ int linear_qkv_rope_store(const half_bits *x, int64_t ldx, const half_bits *W, i
     const int N = (int)((H + 2 * KVH) * D);
     const unsigned gx = (unsigned)(N / 16);
     const int wv = waves_for(K);
-    if (T <= 16) {
+    const bool narrow = N / 16 < 128 && T <= 32;                 // see linear_silu_mul
+    if (narrow && wv == 16) {
+        launch<1, 1, 16, EPI_ROPE>(xx, ldx, ww, (int)T, (int)K, N, qkv, e, gx, s);
+    } else if (T <= 16 || narrow) {
         if (wv >= 8) launch<1, 1, 8, EPI_ROPE>(xx, ldx, ww, (int)T, (int)K, N, qkv, e, gx, s);
         else launch<1, 1, 4, EPI_ROPE>(xx, ldx, ww, (int)T, (int)K, N, qkv, e, gx, s);
     } else {

@@ -517,7 +517,9 @@ def test_prefill_gemm_large_repeatable():
 
 # ------------------------------------------------------------------------------------------- fused epilogues
 @pytest.mark.parametrize("T,K,I", [(32, 1024, 3072), (5, 256, 64), (40, 512, 128), (200, 1024, 3072), (129, 256, 64),
-                                   (300, 1024, 3072), (517, 512, 128), (256, 128, 384)])
+                                   (300, 1024, 3072), (517, 512, 128), (256, 128, 384),
+                                   # shards of a tensor-parallel rank (few column tiles): 16-token workgroups, 8 / 16 waves
+                                   (32, 1024, 384), (23, 4096, 1536), (32, 2048, 96)])
 def test_linear_silu_mul_fused_equals_unfused_graph(T, K, I):
     """gate_up GEMM + SiluAndMul in one launch must equal linear -> fp16 -> silu_and_mul -> fp16 (oracle order)."""
     rng = np.random.default_rng(20)
@@ -530,7 +532,9 @@ def test_linear_silu_mul_fused_equals_unfused_graph(T, K, I):
 
 
 @pytest.mark.parametrize("T,K,H,KVH,D", [(32, 1024, 16, 8, 128), (7, 256, 4, 2, 64), (33, 512, 2, 2, 128), (130, 1024, 16, 8, 128),
-                                         (300, 256, 4, 2, 64), (128, 512, 2, 2, 128), (600, 1024, 16, 8, 128), (257, 128, 2, 1, 128), (8192, 512, 16, 8, 128)])
+                                         (300, 256, 4, 2, 64), (128, 512, 2, 2, 128), (600, 1024, 16, 8, 128), (257, 128, 2, 1, 128), (8192, 512, 16, 8, 128),
+                                         # shards of a tensor-parallel rank: 16-token workgroups, 8 / 16 waves
+                                         (32, 1024, 2, 1, 128), (29, 4096, 4, 1, 128), (32, 2048, 4, 2, 64)])
 def test_linear_qkv_rope_store_fused(T, K, H, KVH, D):
     rng = np.random.default_rng(21)
     NB, bs, max_pos = max(24, T // 16 + 2), 16, 300          # the 8192-token case has >= 256 output tiles: XCD-aware tile order
