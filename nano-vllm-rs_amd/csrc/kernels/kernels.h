@@ -126,6 +126,7 @@ int flash_prefill(const FlashArgs &a, bool paged, hipStream_t s);
 // sampler (top-k / top-p / gumbel)
 size_t sample_workspace_bytes(int64_t B, int64_t V);
 int sample(const float *logits, int64_t B, int64_t V, const float *temperature, const int64_t *top_k,
-           const float *top_p, const uint64_t *keys, int64_t *out_ids, void *workspace, hipStream_t s);
+           const float *top_p, const uint64_t *keys, int64_t *out_ids, void *workspace, hipStream_t s,
+           bool store_filtered = true);   // store_filtered: write the filtered, temperature-scaled rows to the workspace (tests)
 
 }}  // namespace nvr::k

@@ -693,7 +693,7 @@ int nvr_model_runner::sample(nvr_seq *const *seqs, size_t nseq, int64_t *out) {
         NVR_HIP_CHECK(hipMemcpyAsync(d_topk, tk, B * 8, hipMemcpyHostToDevice, stream));
         NVR_HIP_CHECK(hipMemcpyAsync(d_topp, tpv, B * 4, hipMemcpyHostToDevice, stream));
         NVR_HIP_CHECK(hipMemcpyAsync(d_keys, ky, B * 8, hipMemcpyHostToDevice, stream));
-        RC(k::sample(lg, B, Vs, d_temp, d_topk, d_topp, d_keys, d_tok, ws, stream));
+        RC(k::sample(lg, B, Vs, d_temp, d_topk, d_topp, d_keys, d_tok, ws, stream, false));
     }
     NVR_HIP_CHECK(hipMemcpyAsync(h_tok, d_tok, B * 8, hipMemcpyDeviceToHost, stream));      // to_vec1 :152
     NVR_HIP_CHECK(hipStreamSynchronize(stream));
