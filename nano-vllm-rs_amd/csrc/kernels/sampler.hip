@@ -6,11 +6,15 @@
 // Decisions: SURVEY.md A-18 (k == 0 disables top-k), A-19 (ties keep the lower index), A-20
 // (counter-based RNG keyed by (seed, seq_id, step) instead of candle's global RNG).
 //
-// The reference sorts all 151 936 logits per row on the host.  Here one 1024-thread workgroup owns a
-// row and never sorts: both filters are 4-pass 8-bit radix *selects* over the row (LDS histograms),
-// followed by one index-ordered pass that resolves ties at the threshold exactly as a stable sort
-// would.  top-p sums probabilities in 2^-40 fixed point so the LDS atomics are order-independent
-// (bit-reproducible run to run).  The row (608 KB of f32) stays L2-resident between passes.
+// The reference sorts all 151 936 logits per row on the host.  Here nothing is sorted: both filters are 4-pass 8-bit radix
+// *selects* over the row (LDS histograms), followed by an index-ordered pass that resolves ties at the threshold exactly as
+// a stable sort would.  top-p sums probabilities in 2^-40 fixed point so the atomics are order-independent (bit-reproducible
+// run to run).  Two forms: sample_rows_kernel (<= 64 rows: up to 8 workgroups share a row, each holding its slice in
+// registers for all passes; histograms and softmax partials are combined through agent-scope atomics and a bounded arrival
+// barrier) and sample_kernel (one 1024-thread workgroup per row re-reading the L2-resident row every pass: more rows, or
+// rows too long for the register form).  The shared form needs its <= 256 workgroups co-resident: two such launches running
+// CONCURRENTLY on one GPU (two engines on two streams) could starve each other until the spin bound trips (RowHdr::timeout);
+// one engine issues its sampler launches in stream order.
 #include <cstdlib>
 #include "kernels.h"
 #include "device_utils.h"
