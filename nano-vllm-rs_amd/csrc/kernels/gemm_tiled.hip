@@ -15,6 +15,7 @@
 // Row mapping of the A operand lets one lane hold what its epilogue needs: for SiluAndMul a wave's 4 n-tiles are
 // [gate c, gate c+16, up c, up c+16]; for RoPE an n-tile is 8 columns of the first half of a head and their 8
 // partners of the second half (the partner of lane l sits in lane l^32).
+#include <cstdlib>
 #include "kernels.h"
 #include "device_utils.h"
 #include "../common.h"
@@ -200,7 +201,8 @@ static int tiled_check(const char *what) {
     return 0;
 }
 
-bool gemm_tiled_ok(int64_t T, int64_t K, int64_t N, int64_t ldx) { return T >= 128 && K % BK == 0 && N % 16 == 0 && ldx % 8 == 0; }
+static bool tiled_enabled() { static const bool on = [] { const char *e = getenv("NVR_GEMM_TILED"); return !(e && e[0] == '0'); }(); return on; }
+bool gemm_tiled_ok(int64_t T, int64_t K, int64_t N, int64_t ldx) { return tiled_enabled() && T >= 128 && K % BK == 0 && N % 16 == 0 && ldx % 8 == 0; }
 
 int gemm_tiled(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t N, half_bits *y, hipStream_t s) {
     if (!gemm_tiled_ok(T, K, N, ldx)) return nvr::fail(NVR_ERR_UNSUPPORTED, "gemm_tiled: T=%ld K=%ld N=%ld", (long)T, (long)K, (long)N);

@@ -300,6 +300,9 @@ static void launch(const half_t *x, int64_t ldx, const half_t *W, int T, int K, 
     linear_skinny_kernel<NT, MT, WAVES, EPI><<<grid, dim3(WAVES * 64), 0, s>>>(x, ldx, W, T, K, N, y, e);
 }
 
+static inline int64_t tiles256(int64_t T, int64_t N) { return ((N + 255) / 256) * ((T + 255) / 256); }
+// one rule for the plain and the fused launchers (N = output features), so that a fused GEMM and its unfused twin run the same kernel
+static inline bool prefer_stream(int64_t T, int64_t N) { return T <= 128 || T * N <= 384 * 1024; }
 static inline int waves_for(int64_t K) { return K >= 2048 ? 16 : (K >= 1024 ? 8 : 4); }
 
 static int launch_check(const char *what) {
@@ -314,8 +317,11 @@ int linear(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64
         return nvr::fail(NVR_ERR_UNSUPPORTED, "linear: K=%ld must be a multiple of 32, N=%ld of 16, ldx=%ld of 8",
                          (long)K, (long)N, (long)ldx);
     if (T == 0) return 0;
-    if (!y_f32 && gemm256_ok(T, K, N, ldx)) return gemm256(x, ldx, W, T, K, N, (half_bits *)y, s);          // prefill regime
-    if (!y_f32 && gemm_tiled_ok(T, K, N, ldx)) return gemm_tiled(x, ldx, W, T, K, N, (half_bits *)y, s);
+    // Routing by measured crossovers (scratch/gemm_route_sweep.py, profiles/r01_gemm_ablation.txt): the 256x256 kernel needs
+    // more than half a wave of tiles per CU to beat the 128x128 one (its single-tile latency is ~40 us); the 128x128 kernel's
+    // own single-tile latency (21-31 us) loses to the weight-streaming kernel run over 32-token blocks while T or T*N is small
+    if (!y_f32 && gemm256_ok(T, K, N, ldx) && tiles256(T, N) > 128) return gemm256(x, ldx, W, T, K, N, (half_bits *)y, s);   // prefill regime
+    if (!y_f32 && gemm_tiled_ok(T, K, N, ldx) && !prefer_stream(T, N)) return gemm_tiled(x, ldx, W, T, K, N, (half_bits *)y, s);
     if (!y_f32 && linear_stream_ok(T, K, N, ldx)) return linear_stream(x, ldx, W, T, K, N, (half_bits *)y, s);   // large weights
     const half_t *xx = (const half_t *)x, *ww = (const half_t *)W;
     const int t = (int)T, k = (int)K, n = (int)N;
@@ -396,8 +402,8 @@ int linear_silu_mul(const half_bits *x, int64_t ldx, const half_bits *W, int64_t
     if (K % 32 || I % 16 || ldx % 8)
         return nvr::fail(NVR_ERR_UNSUPPORTED, "linear_silu_mul: K=%ld must be a multiple of 32, I=%ld of 16", (long)K, (long)I);
     if (T == 0) return 0;
-    if (gemm256_silu_ok(T, K, I, ldx)) return gemm256_silu_mul(x, ldx, W, T, K, I, out, s);
-    if (gemm_tiled_ok(T, K, I, ldx) && I % 64 == 0) return gemm_tiled_silu_mul(x, ldx, W, T, K, I, out, s);
+    if (gemm256_silu_ok(T, K, I, ldx) && tiles256(T, 2 * I) > 128) return gemm256_silu_mul(x, ldx, W, T, K, I, out, s);   // see linear()
+    if (gemm_tiled_ok(T, K, I, ldx) && I % 64 == 0 && !prefer_stream(T, 2 * I)) return gemm_tiled_silu_mul(x, ldx, W, T, K, I, out, s);
     if (linear_stream_silu_ok(T, K, I, ldx)) return linear_stream_silu_mul(x, ldx, W, T, K, I, out, s);              // large weights
     const half_t *xx = (const half_t *)x, *ww = (const half_t *)W;
     const LinEpi e{};
@@ -425,9 +431,9 @@ int linear_qkv_rope_store(const half_bits *x, int64_t ldx, const half_bits *W, i
     if (K % 32 || D % 16 || ldx % 8)
         return nvr::fail(NVR_ERR_UNSUPPORTED, "linear_qkv_rope_store: K=%ld must be a multiple of 32, D=%ld of 16", (long)K, (long)D);
     if (T == 0) return 0;
-    if (gemm256_rope_ok(T, K, H, KVH, D, ldx))
+    if (gemm256_rope_ok(T, K, H, KVH, D, ldx) && tiles256(T, (H + 2 * KVH) * D) > 128)                                  // see linear()
         return gemm256_qkv_rope_store(x, ldx, W, T, K, H, KVH, D, positions, slots, cos_t, sin_t, qkv, k_cache, v_cache, s);
-    if (gemm_tiled_ok(T, K, (H + 2 * KVH) * D, ldx) && 128 % D == 0)
+    if (gemm_tiled_ok(T, K, (H + 2 * KVH) * D, ldx) && 128 % D == 0 && !prefer_stream(T, (H + 2 * KVH) * D))
         return gemm_tiled_qkv_rope_store(x, ldx, W, T, K, H, KVH, D, positions, slots, cos_t, sin_t, qkv, k_cache, v_cache, s);
     if (linear_stream_rope_ok(T, K, H, KVH, D, ldx))                                                                  // large weights
         return linear_stream_qkv_rope_store(x, ldx, W, T, K, H, KVH, D, positions, slots, cos_t, sin_t, qkv, k_cache, v_cache, s);

@@ -124,13 +124,16 @@ def test_cached_prefix_skipping_is_bit_identical():
     """a prefill step computes only the tokens after a sequence's cached prefix and reaches the prefix
     through the block table.  The K/V rows are the same bits either way (a GEMM row depends only on its own input row)
     and the flash kernel walks the keys in the same 64-key steps, so logits and tokens must be IDENTICAL to the
-    recompute-everything path of the reference (model_runner.rs:176-182) while far fewer rows go through the model."""
+    recompute-everything path of the reference (model_runner.rs:176-182) while far fewer rows go through the model.
+    Bit-identity needs both batches on the same GEMM kernels (the K-accumulation order differs between the weight-streaming
+    and the tiled kernels; linear.hip routes by T and T*N): 441 and 696 rows are on the same side of every threshold of this
+    model's shapes.  Across a routing boundary the two paths agree to fp16 rounding like any other pair of kernels."""
     mcfg = mo.small(seed=8)
     ecfg = dict(max_num_seqs=16, max_num_batched_tokens=1024, max_model_len=256, kvcache_block_size=16, num_kvcache_blocks=120)
-    shared = oracle.fill_tokens(64, 3, 77, mcfg.vocab_size).tolist()                 # 4 full blocks
-    prompts = [shared + oracle.fill_tokens(5 + 3 * i, 3, i, mcfg.vocab_size).tolist() for i in range(8)]
+    shared = oracle.fill_tokens(32, 3, 77, mcfg.vocab_size).tolist()                 # 2 full blocks
+    prompts = [shared + oracle.fill_tokens(40 + i, 3, i, mcfg.vocab_size).tolist() for i in range(8)]
     prompts.append(list(shared))                                                       # fully cached prompt: last token still computed
-    prompts.append(oracle.fill_tokens(40, 3, 500, mcfg.vocab_size).tolist())           # nothing shared
+    prompts.append(oracle.fill_tokens(60, 3, 500, mcfg.vocab_size).tolist())           # nothing shared
     sps = [dict(temperature=0.0, max_tokens=12, ignore_eos=True)] * len(prompts)
     skip = _run_product(mcfg, ecfg, prompts, sps)
     full = _run_product(mcfg, ecfg, prompts, sps, recompute_cached_prefix=1)
@@ -140,7 +143,7 @@ def test_cached_prefix_skipping_is_bit_identical():
         assert np.array_equal(a[4], b[4]), "logits differ between skipping and recomputing the cached prefix"
     pre_skip = sum(t[3] for t in skip if t[0]); pre_full = sum(t[3] for t in full if t[0])
     assert pre_full == sum(len(p) for p in prompts)
-    assert pre_skip == pre_full - 7 * 64 - 63, (pre_skip, pre_full)     # the first prompt fills the blocks; 7 more skip 64 tokens, the bare prefix 63
+    assert pre_full == 696 and pre_skip == pre_full - 7 * 32 - 31, (pre_skip, pre_full)   # the first prompt fills the blocks; 7 more skip 32 tokens, the bare prefix 31
     # and the skipping path against the oracle engine (which recomputes), teacher-forced
     r = _run_pair(mcfg, ecfg, prompts, sps)
     assert r["near_ties"] <= 2, r

@@ -527,7 +527,7 @@ def test_prefill_gemm_large_repeatable():
     """The 256x256 eight-wave kernel keeps LDS-DMA loads in flight across barriers: screen it for races — many runs
     of a many-workgroup shape must be bit-identical to each other and match the oracle on sampled rows."""
     rng = np.random.default_rng(41)
-    T, K, N = 4096, 1024, 2048
+    T, K, N = 8192, 1024, 2048                            # 8 x 32 = 256 tiles: routed to the 256x256 kernel (> 128 tiles)
     x, xb = h16(rng.standard_normal((T, K)))
     W, Wb = h16(rng.standard_normal((N, K)) * 0.05)
     d_x, d_W, d_y = dev(xb), dev(Wb), nvr.DeviceBuffer(T * N * 2)
