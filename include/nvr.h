@@ -344,13 +344,14 @@ NVR_API int nvr_add_rmsnorm(nvr_half *h, const nvr_half *y, const nvr_half *w, f
 /* K3/K10/K12/K14/K16 y = x·Wᵀ; x [T,K] (row stride ldx), W [N,K], y [T,N] fp16 or f32 */
 NVR_API int nvr_linear(const nvr_half *x, int64_t ldx, const nvr_half *W, int64_t T, int64_t K, int64_t N,
                        void *y, int y_is_f32, void *stream);
-/* K16 for decode-sized batches (T <= 32, K multiple of 256 and <= 2048, N multiple of 16; otherwise
- * NVR_ERR_UNSUPPORTED: use nvr_linear): logits[T,N] f32 = x·Wᵀ (ParallelLMHead::compute_logits, embed_head.rs:292-306)
- * plus the greedy arg-max of every row folded into the epilogue (Sampler::sample greedy branch, sampler.rs:126-151):
- * part_val/part_idx [*nparts][T] hold per-workgroup (max, lowest index) pairs, *nparts <= NVR_LM_HEAD_MAX_PARTS;
- * nvr_argmax_partials merges them (ties -> lowest index), adds idx_offset, out_val nullable.
+/* K16: logits[T,N] f32 = x·Wᵀ (ParallelLMHead::compute_logits, embed_head.rs:292-306) plus the greedy arg-max of every row
+ * folded into the epilogue (Sampler::sample greedy branch, sampler.rs:126-151): part_val/part_idx [*nparts][T] hold
+ * per-workgroup (max, lowest index) pairs, *nparts <= NVR_LM_HEAD_MAX_PARTS (size the buffers for that); nvr_argmax_partials
+ * merges them (ties -> lowest index), adds idx_offset, out_val nullable.  T <= 32 (K multiple of 256 and <= 2048): the
+ * weight-streaming decode kernel; T > 32 (K multiple of 64, N <= 128·NVR_LM_HEAD_MAX_PARTS): 128x128 MFMA tiles, one partial
+ * per 128 columns; N a multiple of 16; other shapes NVR_ERR_UNSUPPORTED (use nvr_linear + nvr_argmax).
  * logits == NULL: only the partials are produced (a greedy batch never reads its 4·T·N logit bytes). */
-#define NVR_LM_HEAD_MAX_PARTS 1024
+#define NVR_LM_HEAD_MAX_PARTS 2048
 NVR_API int nvr_lm_head(const nvr_half *x, int64_t ldx, const nvr_half *W, int64_t T, int64_t K, int64_t N, float *logits,
                         float *part_val, int32_t *part_idx, int32_t *nparts, void *stream);
 NVR_API int nvr_argmax_partials(const float *part_val, const int32_t *part_idx, int32_t nparts, int64_t T, int64_t *out_idx,

@@ -22,12 +22,15 @@
 
 namespace nvr { namespace k {
 
-enum { TEPI_F16 = 0, TEPI_SILU = 2, TEPI_ROPE = 3 };
+enum { TEPI_F16 = 0, TEPI_SILU = 2, TEPI_ROPE = 3, TEPI_LMHEAD = 4 };
 
 struct TileEpi {
     const int64_t *pos; const int32_t *slots; const float *cos_t, *sin_t;
     half_t *kc, *vc;
     int32_t H, KVH, D;
+    // TEPI_LMHEAD: f32 logits [T, N] (nullable) and the greedy arg-max of every row over this workgroup's 128 columns:
+    // pval / pidx [column tile][T] (maximum, lowest index), merged by argmax_partials
+    float *logits; float *pval; int32_t *pidx;
 };
 
 constexpr int BM = 128, BN = 128, BK = 64;
@@ -110,6 +113,42 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(const half_t *__restric
         __syncthreads();
     }
 
+    if (EPI == TEPI_LMHEAD) {
+        // C layout: row (n) = q*4 + reg, col (token) = r.  f32 logits go out as they are (embed_head.rs:292-306, A-21); the
+        // row maxima are taken over the f32 accumulators in increasing column order (ties keep the lowest index, A-12)
+        float *sv = reinterpret_cast<float *>(smem);                      // [2 (wn)][128 tokens]
+        int *si = reinterpret_cast<int *>(smem + 2 * BM * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ml = wm * 64 + j * 16 + r, m = m0 + ml;
+            float bv = -INFINITY; int bi = 0x7fffffff;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int n = blockIdx.x * BN + wn * 64 + i * 16 + q * 4;
+                if (epi.logits && m < T && n < N) *reinterpret_cast<float4_t *>(epi.logits + (int64_t)m * N + n) = acc[i][j];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = acc[i][j][e];
+                    if (n + e < N && (v > bv || (v == bv && n + e < bi))) { bv = v; bi = n + e; }
+                }
+            }
+#pragma unroll
+            for (int o = 16; o <= 32; o <<= 1) {                          // the four q groups of a token
+                const float v = __shfl_xor(bv, o, 64); const int i2 = __shfl_xor(bi, o, 64);
+                if (v > bv || (v == bv && i2 < bi)) { bv = v; bi = i2; }
+            }
+            if (q == 0) { sv[wn * BM + ml] = bv; si[wn * BM + ml] = bi; }
+        }
+        __syncthreads();
+        if (threadIdx.x < BM && m0 + threadIdx.x < T) {
+            float bv = sv[threadIdx.x]; int bi = si[threadIdx.x];
+            const float v = sv[BM + threadIdx.x]; const int i2 = si[BM + threadIdx.x];
+            if (v > bv || (v == bv && i2 < bi)) { bv = v; bi = i2; }
+            epi.pval[(int64_t)blockIdx.x * T + m0 + threadIdx.x] = bv;
+            epi.pidx[(int64_t)blockIdx.x * T + m0 + threadIdx.x] = bi;
+        }
+        return;
+    }
     // epilogue: C layout row (n) = q*4 + reg, col (token) = r.  Each lane produces 4 consecutive output columns of one
     // token; they are staged in LDS (the operand buffers are free now; row stride 272 B keeps ds_read_b128 aligned)
     // and written out as full 16-byte pieces of contiguous rows (a lane-per-row 8-byte store pattern is issue-bound).
@@ -202,6 +241,22 @@ static int tiled_check(const char *what) {
 }
 
 static bool tiled_enabled() { static const bool on = [] { const char *e = getenv("NVR_GEMM_TILED"); return !(e && e[0] == '0'); }(); return on; }
+// LM head for more than 32 rows (large decode batches, many-sequence prefills): weights streamed once per 128-row block
+bool gemm_tiled_lm_head_ok(int64_t T, int64_t K, int64_t N, int64_t ldx) {
+    return tiled_enabled() && T > 32 && T <= 65536 && K % BK == 0 && N % 16 == 0 && ldx % 8 == 0 && (N + BN - 1) / BN <= LM_HEAD_MAX_PARTS &&
+           N < (1ll << 31);
+}
+int gemm_tiled_lm_head(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t N, float *logits,
+                       float *part_val, int32_t *part_idx, int32_t *nparts, hipStream_t s) {
+    if (!gemm_tiled_lm_head_ok(T, K, N, ldx)) return nvr::fail(NVR_ERR_UNSUPPORTED, "gemm_tiled_lm_head: T=%ld K=%ld N=%ld", (long)T, (long)K, (long)N);
+    TileEpi e{};
+    e.logits = logits; e.pval = part_val; e.pidx = part_idx;
+    dim3 grid((unsigned)((N + BN - 1) / BN), (unsigned)((T + BM - 1) / BM));
+    *nparts = (int32_t)grid.x;
+    gemm_tiled_kernel<TEPI_LMHEAD><<<grid, dim3(256), 0, s>>>((const half_t *)x, ldx, (const half_t *)W, (int)T, (int)K, (int)N, (int)N, nullptr, e);
+    return tiled_check("gemm_tiled_lm_head");
+}
+
 bool gemm_tiled_ok(int64_t T, int64_t K, int64_t N, int64_t ldx) { return tiled_enabled() && T >= 128 && K % BK == 0 && N % 16 == 0 && ldx % 8 == 0; }
 
 int gemm_tiled(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t N, half_bits *y, hipStream_t s) {

@@ -33,7 +33,7 @@ int linear(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64
 // LM head for decode-sized batches (T <= 32, K <= 2048): f32 logits + per-workgroup greedy arg-max partials
 // ([*nparts][T] values and vocabulary indices, *nparts <= LM_HEAD_MAX_PARTS), finished by argmax_partials
 // (lowest index wins ties; idx_offset is added; out_val nullable)
-constexpr int LM_HEAD_MAX_PARTS = 1024;
+constexpr int LM_HEAD_MAX_PARTS = 2048;
 bool lm_head_ok(int64_t T, int64_t K, int64_t N, int64_t ldx);
 int32_t lm_head_parts(int64_t T, int64_t K, int64_t N, int64_t ldx);      // partials lm_head will write (0: unsupported shape)
 // store_logits = false: only the partials are written (a greedy batch never reads its 4·T·N logit bytes)
@@ -69,6 +69,11 @@ int linear_stream_silu_mul(const half_bits *x, int64_t ldx, const half_bits *W, 
 int linear_stream_qkv_rope_store(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t H, int64_t KVH, int64_t D,
                                  const int64_t *positions, const int32_t *slots, const float *cos_t, const float *sin_t, half_bits *qkv,
                                  half_bits *k_cache, half_bits *v_cache, hipStream_t s);
+
+// LM head over more than 32 rows: the 128x128 kernel with the logits / arg-max epilogue (one partial per 128-column tile)
+bool gemm_tiled_lm_head_ok(int64_t T, int64_t K, int64_t N, int64_t ldx);
+int gemm_tiled_lm_head(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t N, float *logits,
+                       float *part_val, int32_t *part_idx, int32_t *nparts, hipStream_t s);
 
 // LDS-tiled MFMA GEMM for the prefill regime (T >= 128): same results layout and epilogues as the kernels above
 bool gemm_tiled_ok(int64_t T, int64_t K, int64_t N, int64_t ldx);

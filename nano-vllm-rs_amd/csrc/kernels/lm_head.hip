@@ -150,7 +150,9 @@ static LmPlan lm_plan(int64_t T, int64_t K, int64_t N) {
     return pl;
 }
 int32_t lm_head_parts(int64_t T, int64_t K, int64_t N, int64_t ldx) {
-    return lm_head_ok(T, K, N, ldx) ? (int32_t)lm_plan(T, K, N).nwg : 0;
+    if (lm_head_ok(T, K, N, ldx)) return (int32_t)lm_plan(T, K, N).nwg;
+    if (gemm_tiled_lm_head_ok(T, K, N, ldx)) return (int32_t)((N + 127) / 128);          // one partial per 128-column tile
+    return 0;
 }
 
 // every compiled (MT, WAVES, U) instance, as X(mt, waves, U)
@@ -177,9 +179,12 @@ static int lm_allow_big_lds() {
 // logits[T,N] (f32) = x·Wᵀ and per-workgroup arg-max partials: part_val/part_idx [*nparts][T], *nparts <= LM_HEAD_MAX_PARTS
 int lm_head(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t N, float *logits,
             float *part_val, int32_t *part_idx, int32_t *nparts, hipStream_t s, bool store_logits) {
-    if (!lm_head_ok(T, K, N, ldx))
-        return nvr::fail(NVR_ERR_UNSUPPORTED, "lm_head: T=%ld (1..32), K=%ld (multiple of 256, <= 2048), N=%ld (multiple of 16)",
-                         (long)T, (long)K, (long)N);
+    if (!lm_head_ok(T, K, N, ldx)) {
+        if (gemm_tiled_lm_head_ok(T, K, N, ldx))                       // more than 32 rows: 128x128 tiles, same outputs
+            return gemm_tiled_lm_head(x, ldx, W, T, K, N, store_logits ? logits : nullptr, part_val, part_idx, nparts, s);
+        return nvr::fail(NVR_ERR_UNSUPPORTED, "lm_head: T=%ld K=%ld N=%ld (T <= 32: K multiple of 256 and <= 2048; T > 32: K multiple of 64, "
+                         "N <= 128 * %d; N multiple of 16)", (long)T, (long)K, (long)N, LM_HEAD_MAX_PARTS);
+    }
     const LmPlan pl = lm_plan(T, K, N);
     const int mt = pl.mt, waves = pl.waves, U = pl.U;
     const int64_t nwg = pl.nwg;

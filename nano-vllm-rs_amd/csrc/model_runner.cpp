@@ -104,7 +104,10 @@ int nvr_model_runner::init() {                                       // ModelRun
     RC(k::linear_stream_prepare());
     { const char *e = getenv("NVR_LM_FUSED"); lm_fused = !(e && e[0] == '0'); }
     { const char *e = getenv("NVR_LAZY_LOGITS"); lazy_logits = !(e && e[0] == '0'); }
-    RC(dmalloc(&d_lm_pval, (size_t)k::LM_HEAD_MAX_PARTS * 32)); RC(dmalloc(&d_lm_pidx, (size_t)k::LM_HEAD_MAX_PARTS * 32));
+    {   // arg-max partials [parts][rows]: <= LM_HEAD_MAX_PARTS x 32 rows (lm_head_kernel), or one per 128 vocabulary columns x all rows
+        const size_t pe = std::max<size_t>((size_t)k::LM_HEAD_MAX_PARTS * 32, (size_t)((Vl + 127) / 128) * (size_t)max_seqs);
+        RC(dmalloc(&d_lm_pval, pe)); RC(dmalloc(&d_lm_pidx, pe));
+    }
     attn_ws_bytes = k::attn_workspace_bytes(max_seqs, H, D, max_pos);
     NVR_HIP_CHECK(hipMalloc(&attn_ws, attn_ws_bytes));
     {

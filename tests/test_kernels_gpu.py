@@ -332,7 +332,9 @@ def test_argmax_exact_with_ties():
         assert d_out.to_numpy((1,), np.int64)[0] == want
 
 
-@pytest.mark.parametrize("T,K,N", [(32, 1024, 151936), (7, 1024, 18992), (16, 2048, 4096), (17, 256, 48), (1, 512, 16), (32, 1024, 100000)])
+@pytest.mark.parametrize("T,K,N", [(32, 1024, 151936), (7, 1024, 18992), (16, 2048, 4096), (17, 256, 48), (1, 512, 16), (32, 1024, 100000),
+                                   # more than 32 rows (large decode batches, many-sequence prefills): 128x128 tiles, one partial per tile
+                                   (128, 1024, 151936), (100, 512, 5008), (300, 256, 1000 * 16), (33, 4096, 2064)])
 def test_lm_head_logits_and_argmax_partials(T, K, N):
     """lm_head: f32 logits == oracle linear (f32 sums in another order), and the arg-max that rides along in the epilogue
     is EXACTLY the lowest-index arg-max of the logits the kernel itself wrote (ties included)."""
@@ -344,8 +346,8 @@ def test_lm_head_logits_and_argmax_partials(T, K, N):
     x[0], xb[0] = h16(W[5] * 8)                            # make that tied logit the row maximum of token 0
     d_x, d_W = dev(xb), dev(Wb)
     d_y = nvr.DeviceBuffer(T * N * 4)
-    P = 1024
-    d_pv, d_pi = nvr.DeviceBuffer(P * 32 * 4), nvr.DeviceBuffer(P * 32 * 4)
+    P = 2048                                               # NVR_LM_HEAD_MAX_PARTS
+    d_pv, d_pi = nvr.DeviceBuffer(P * T * 4), nvr.DeviceBuffer(P * T * 4)
     nparts = C.c_int32(0)
     nvr.check(nvr.lib().nvr_lm_head(d_x.ptr, K, d_W.ptr, T, K, N, d_y.ptr, d_pv.ptr, d_pi.ptr, C.byref(nparts), None))
     assert 1 <= nparts.value <= P
@@ -363,7 +365,8 @@ def test_lm_head_logits_and_argmax_partials(T, K, N):
     d_t2 = nvr.DeviceBuffer(T * 8)
     nvr.check(nvr.lib().nvr_argmax(d_y.ptr, T, N, d_t2.ptr, None))
     assert d_t2.to_numpy((T,), np.int64).tolist() == want.tolist()
-    assert nvr.lib().nvr_lm_head(d_x.ptr, K, d_W.ptr, 33, K, N, d_y.ptr, d_pv.ptr, d_pi.ptr, C.byref(nparts), None) == -10
+    # shapes neither kernel takes are refused, not approximated: N not a multiple of 16
+    assert nvr.lib().nvr_lm_head(d_x.ptr, K, d_W.ptr, T, K, N - 8, d_y.ptr, d_pv.ptr, d_pi.ptr, C.byref(nparts), None) == -10
 
 
 def _gpu_sample(x, temps, top_k, top_p, keys):
