@@ -50,12 +50,17 @@ __device__ __forceinline__ int tile_w_row(int bx, int t, int r, int N, const Til
     return bx * BN + t * 16 + r;
 }
 
-template <int EPI>
+// NS = 2: two LDS buffers (64 KiB, two workgroups per CU), the load of K-tile t+1 overlaps the MFMAs on tile t and is waited
+// for in full at the end of the step — right when tiles outnumber the CUs.  NS = 4: a ring of four buffers (128 KiB, one
+// workgroup per CU) with three K-tiles in flight and counted s_waitcnt vmcnt: when there are fewer tiles than CUs (decode
+// batches of 129..~1000 rows, short prefills) a workgroup is alone on its CU and every K-step of the NS = 2 form costs one
+// full memory latency (21 us for a K = 1024 tile); the ring hides it.
+template <int EPI, int NS>
 __global__ __launch_bounds__(256) void gemm_tiled_kernel(const half_t *__restrict__ x, int64_t ldx,
                                                          const half_t *__restrict__ W, int T, int K, int N, int NW,
                                                          half_t *__restrict__ y, TileEpi epi) {
-    // one LDS array (cdna guide §5 item 4a): [2 buffers][A 16 KiB | B 16 KiB]
-    __shared__ __attribute__((aligned(16))) char smem[2 * 2 * BM * BK * 2];
+    // one LDS array (cdna guide §5 item 4a): [NS buffers][A 16 KiB | B 16 KiB]
+    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int r = lane & 15, q = lane >> 4;
     const int wn = wave >> 1, wm = wave & 1;
@@ -89,11 +94,27 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(const half_t *__restric
         for (int j = 0; j < 4; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
 
     const int KT = K / BK;
-    stage(0, 0);
-    __syncthreads();                                                      // includes s_waitcnt vmcnt(0)
+    if (NS == 2) {
+        stage(0, 0);
+        __syncthreads();                                                  // includes s_waitcnt vmcnt(0)
+    } else {
+#pragma unroll
+        for (int st = 0; st < NS - 1; ++st) if (st < KT) stage(st, st * BK);
+    }
     for (int kt = 0; kt < KT; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < KT) stage(cur ^ 1, (kt + 1) * BK);
+        int cur = kt & 1;
+        if (NS == 2) {
+            if (kt + 1 < KT) stage(cur ^ 1, (kt + 1) * BK);
+        } else {
+            // K-tile kt has landed once at most the 8 loads per thread of each younger K-tile in flight are outstanding
+            const int younger = min(NS - 2, KT - 1 - kt);
+            if (younger >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else if (younger == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                                 // every thread's pieces are in; buffer (kt-1) % NS is free
+            cur = kt % NS;
+            if (kt + NS - 1 < KT) stage((kt + NS - 1) % NS, (kt + NS - 1) * BK);
+        }
         const char *a_lds = smem + cur * (2 * BM * BK * 2), *b_lds = a_lds + BM * BK * 2;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -110,8 +131,9 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(const half_t *__restric
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j], acc[i][j], 0, 0, 0);
         }
-        __syncthreads();
+        if (NS == 2) __syncthreads();
     }
+    if (NS != 2) __syncthreads();                                         // the epilogue reuses the operand buffers
 
     if (EPI == TEPI_LMHEAD) {
         // C layout: row (n) = q*4 + reg, col (token) = r.  f32 logits go out as they are (embed_head.rs:292-306, A-21); the
@@ -240,6 +262,31 @@ static int tiled_check(const char *what) {
     return 0;
 }
 
+// ring (NS = 4) when the grid leaves CUs idle anyway; NVR_TILED_RING=0/1 forces
+static bool tiled_ring(unsigned tiles) {
+    static const int force = [] { const char *e = getenv("NVR_TILED_RING"); return e ? atoi(e) : -1; }();
+    return force >= 0 ? force != 0 : tiles < 256;
+}
+constexpr size_t kStageBytes = 2 * BM * BK * 2;
+#define NVR_TILED_LAUNCH(EPI_, grid, ...)                                                                          \
+    do {                                                                                                           \
+        if (tiled_ring((grid).x * (grid).y)) gemm_tiled_kernel<EPI_, 4><<<grid, dim3(256), 4 * kStageBytes, s>>>(__VA_ARGS__); \
+        else gemm_tiled_kernel<EPI_, 2><<<grid, dim3(256), 2 * kStageBytes, s>>>(__VA_ARGS__);                   \
+    } while (0)
+// 128 KiB of dynamic LDS needs an opt-in per kernel instance; called at runner creation (never inside a stream capture)
+int gemm_tiled_prepare() {
+    static bool done = false;
+    if (done) return 0;
+#define NVR_TILED_ATTR(EPI_)                                                                                          \
+    { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_tiled_kernel<EPI_, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                         (int)(4 * kStageBytes));                                                    \
+      if (e != hipSuccess) return nvr::fail(NVR_ERR_HIP, "gemm_tiled: LDS opt-in failed: %s", hipGetErrorString(e)); }
+    NVR_TILED_ATTR(TEPI_F16) NVR_TILED_ATTR(TEPI_SILU) NVR_TILED_ATTR(TEPI_ROPE) NVR_TILED_ATTR(TEPI_LMHEAD)
+#undef NVR_TILED_ATTR
+    done = true;
+    return 0;
+}
+
 static bool tiled_enabled() { static const bool on = [] { const char *e = getenv("NVR_GEMM_TILED"); return !(e && e[0] == '0'); }(); return on; }
 // LM head for more than 32 rows (large decode batches, many-sequence prefills): weights streamed once per 128-row block
 bool gemm_tiled_lm_head_ok(int64_t T, int64_t K, int64_t N, int64_t ldx) {
@@ -253,7 +300,8 @@ int gemm_tiled_lm_head(const half_bits *x, int64_t ldx, const half_bits *W, int6
     e.logits = logits; e.pval = part_val; e.pidx = part_idx;
     dim3 grid((unsigned)((N + BN - 1) / BN), (unsigned)((T + BM - 1) / BM));
     *nparts = (int32_t)grid.x;
-    gemm_tiled_kernel<TEPI_LMHEAD><<<grid, dim3(256), 0, s>>>((const half_t *)x, ldx, (const half_t *)W, (int)T, (int)K, (int)N, (int)N, nullptr, e);
+    if (int rc = gemm_tiled_prepare()) return rc;
+    NVR_TILED_LAUNCH(TEPI_LMHEAD, grid, (const half_t *)x, ldx, (const half_t *)W, (int)T, (int)K, (int)N, (int)N, nullptr, e);
     return tiled_check("gemm_tiled_lm_head");
 }
 
@@ -262,15 +310,15 @@ bool gemm_tiled_ok(int64_t T, int64_t K, int64_t N, int64_t ldx) { return tiled_
 int gemm_tiled(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t N, half_bits *y, hipStream_t s) {
     if (!gemm_tiled_ok(T, K, N, ldx)) return nvr::fail(NVR_ERR_UNSUPPORTED, "gemm_tiled: T=%ld K=%ld N=%ld", (long)T, (long)K, (long)N);
     dim3 grid((unsigned)((N + BN - 1) / BN), (unsigned)((T + BM - 1) / BM));
-    gemm_tiled_kernel<TEPI_F16><<<grid, dim3(256), 0, s>>>((const half_t *)x, ldx, (const half_t *)W, (int)T, (int)K, (int)N, (int)N,
-                                                           (half_t *)y, TileEpi{});
+    if (int rc = gemm_tiled_prepare()) return rc;
+    NVR_TILED_LAUNCH(TEPI_F16, grid, (const half_t *)x, ldx, (const half_t *)W, (int)T, (int)K, (int)N, (int)N, (half_t *)y, TileEpi{});
     return tiled_check("gemm_tiled");
 }
 int gemm_tiled_silu_mul(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t I, half_bits *out, hipStream_t s) {
     if (!gemm_tiled_ok(T, K, I, ldx) || I % 64) return nvr::fail(NVR_ERR_UNSUPPORTED, "gemm_tiled_silu_mul: T=%ld K=%ld I=%ld", (long)T, (long)K, (long)I);
     dim3 grid((unsigned)(I / 64), (unsigned)((T + BM - 1) / BM));
-    gemm_tiled_kernel<TEPI_SILU><<<grid, dim3(256), 0, s>>>((const half_t *)x, ldx, (const half_t *)W, (int)T, (int)K, (int)I, (int)(2 * I),
-                                                            (half_t *)out, TileEpi{});
+    if (int rc = gemm_tiled_prepare()) return rc;
+    NVR_TILED_LAUNCH(TEPI_SILU, grid, (const half_t *)x, ldx, (const half_t *)W, (int)T, (int)K, (int)I, (int)(2 * I), (half_t *)out, TileEpi{});
     return tiled_check("gemm_tiled_silu_mul");
 }
 int gemm_tiled_qkv_rope_store(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t H, int64_t KVH, int64_t D,
@@ -282,8 +330,8 @@ int gemm_tiled_qkv_rope_store(const half_bits *x, int64_t ldx, const half_bits *
     e.pos = positions; e.slots = slots; e.cos_t = cos_t; e.sin_t = sin_t; e.kc = (half_t *)k_cache; e.vc = (half_t *)v_cache;
     e.H = (int32_t)H; e.KVH = (int32_t)KVH; e.D = (int32_t)D;
     dim3 grid((unsigned)((N / 16 + 7) / 8), (unsigned)((T + BM - 1) / BM));
-    gemm_tiled_kernel<TEPI_ROPE><<<grid, dim3(256), 0, s>>>((const half_t *)x, ldx, (const half_t *)W, (int)T, (int)K, (int)N, (int)N,
-                                                            (half_t *)qkv, e);
+    if (int rc = gemm_tiled_prepare()) return rc;
+    NVR_TILED_LAUNCH(TEPI_ROPE, grid, (const half_t *)x, ldx, (const half_t *)W, (int)T, (int)K, (int)N, (int)N, (half_t *)qkv, e);
     return tiled_check("gemm_tiled_qkv_rope_store");
 }
 

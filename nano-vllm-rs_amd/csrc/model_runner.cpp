@@ -102,6 +102,7 @@ int nvr_model_runner::init() {                                       // ModelRun
     // measured slower than two launches (profiles/r01_fused_slabnorm_ablation.txt): opt-in only
     { const char *e = getenv("NVR_FUSED_SLABNORM"); fused_slabnorm = e && e[0] == '1'; }
     RC(k::linear_stream_prepare());
+    RC(k::gemm_tiled_prepare());
     { const char *e = getenv("NVR_LM_FUSED"); lm_fused = !(e && e[0] == '0'); }
     { const char *e = getenv("NVR_LAZY_LOGITS"); lazy_logits = !(e && e[0] == '0'); }
     {   // arg-max partials [parts][rows]: <= LM_HEAD_MAX_PARTS x 32 rows (lm_head_kernel), or one per 128 vocabulary columns x all rows
