@@ -22,7 +22,7 @@
 
 namespace nvr { namespace k {
 
-enum { TEPI_F16 = 0, TEPI_SILU = 2, TEPI_ROPE = 3, TEPI_LMHEAD = 4 };
+enum { TEPI_F16 = 0, TEPI_SILU = 2, TEPI_ROPE = 3, TEPI_LMHEAD = 4, TEPI_SLAB = 5 };
 
 struct TileEpi {
     const int64_t *pos; const int32_t *slots; const float *cos_t, *sin_t;
@@ -31,6 +31,8 @@ struct TileEpi {
     // TEPI_LMHEAD: f32 logits [T, N] (nullable) and the greedy arg-max of every row over this workgroup's 128 columns:
     // pval / pidx [column tile][T] (maximum, lowest index), merged by argmax_partials
     float *logits; float *pval; int32_t *pidx;
+    // TEPI_SLAB: blockIdx.z owns k in [z*kslice, (z+1)*kslice) and writes its f32 partial tile to slabs[z][T][N]
+    float *slabs; int64_t slab_stride; int32_t kslice;
 };
 
 constexpr int BM = 128, BN = 128, BK = 64;
@@ -76,6 +78,7 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(const half_t *__restric
         int xr = m0 + row; if (xr > T - 1) xr = T - 1;
         asrc[i] = W + (int64_t)wr * K + c * 8;
         bsrc[i] = x + (int64_t)xr * ldx + c * 8;
+        if (EPI == TEPI_SLAB) { asrc[i] += (int64_t)blockIdx.z * epi.kslice; bsrc[i] += (int64_t)blockIdx.z * epi.kslice; }
     }
     auto stage = [&](int buf, int k0) {
         char *a_dst = smem + buf * (2 * BM * BK * 2), *b_dst = a_dst + BM * BK * 2;
@@ -93,7 +96,7 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(const half_t *__restric
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
 
-    const int KT = K / BK;
+    const int KT = (EPI == TEPI_SLAB ? epi.kslice : K) / BK;
     if (NS == 2) {
         stage(0, 0);
         __syncthreads();                                                  // includes s_waitcnt vmcnt(0)
@@ -135,6 +138,19 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(const half_t *__restric
     }
     if (NS != 2) __syncthreads();                                         // the epilogue reuses the operand buffers
 
+    if (EPI == TEPI_SLAB) {                                                // f32 partial sums, C layout: 4 consecutive columns of token r
+        float *sl = epi.slabs + (int64_t)blockIdx.z * epi.slab_stride;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = m0 + wm * 64 + j * 16 + r;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int n = blockIdx.x * BN + wn * 64 + i * 16 + q * 4;
+                if (m < T && n < N) *reinterpret_cast<float4_t *>(sl + (int64_t)m * N + n) = acc[i][j];
+            }
+        }
+        return;
+    }
     if (EPI == TEPI_LMHEAD) {
         // C layout: row (n) = q*4 + reg, col (token) = r.  f32 logits go out as they are (embed_head.rs:292-306, A-21); the
         // row maxima are taken over the f32 accumulators in increasing column order (ties keep the lowest index, A-12)
@@ -270,7 +286,7 @@ static bool tiled_ring(unsigned tiles) {
 constexpr size_t kStageBytes = 2 * BM * BK * 2;
 #define NVR_TILED_LAUNCH(EPI_, grid, ...)                                                                          \
     do {                                                                                                           \
-        if (tiled_ring((grid).x * (grid).y)) gemm_tiled_kernel<EPI_, 4><<<grid, dim3(256), 4 * kStageBytes, s>>>(__VA_ARGS__); \
+        if (tiled_ring((grid).x * (grid).y * (grid).z)) gemm_tiled_kernel<EPI_, 4><<<grid, dim3(256), 4 * kStageBytes, s>>>(__VA_ARGS__); \
         else gemm_tiled_kernel<EPI_, 2><<<grid, dim3(256), 2 * kStageBytes, s>>>(__VA_ARGS__);                   \
     } while (0)
 // 128 KiB of dynamic LDS needs an opt-in per kernel instance; called at runner creation (never inside a stream capture)
@@ -281,7 +297,7 @@ int gemm_tiled_prepare() {
     { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_tiled_kernel<EPI_, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                          (int)(4 * kStageBytes));                                                    \
       if (e != hipSuccess) return nvr::fail(NVR_ERR_HIP, "gemm_tiled: LDS opt-in failed: %s", hipGetErrorString(e)); }
-    NVR_TILED_ATTR(TEPI_F16) NVR_TILED_ATTR(TEPI_SILU) NVR_TILED_ATTR(TEPI_ROPE) NVR_TILED_ATTR(TEPI_LMHEAD)
+    NVR_TILED_ATTR(TEPI_F16) NVR_TILED_ATTR(TEPI_SILU) NVR_TILED_ATTR(TEPI_ROPE) NVR_TILED_ATTR(TEPI_LMHEAD) NVR_TILED_ATTR(TEPI_SLAB)
 #undef NVR_TILED_ATTR
     done = true;
     return 0;
@@ -303,6 +319,20 @@ int gemm_tiled_lm_head(const half_bits *x, int64_t ldx, const half_bits *W, int6
     if (int rc = gemm_tiled_prepare()) return rc;
     NVR_TILED_LAUNCH(TEPI_LMHEAD, grid, (const half_t *)x, ldx, (const half_t *)W, (int)T, (int)K, (int)N, (int)N, nullptr, e);
     return tiled_check("gemm_tiled_lm_head");
+}
+
+// split-k form for the narrow row-parallel GEMMs (o_proj / down_proj) at 65..1024 rows: slabs[z][T][N] f32, S slices of K
+bool gemm_tiled_splitk_ok(int64_t T, int64_t K, int64_t N, int64_t S, int64_t ldx) {
+    return tiled_enabled() && T > 64 && S >= 1 && K % (S * BK) == 0 && N % 16 == 0 && ldx % 8 == 0;
+}
+int gemm_tiled_splitk(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t N, int64_t S, float *slabs, hipStream_t s) {
+    if (!gemm_tiled_splitk_ok(T, K, N, S, ldx)) return nvr::fail(NVR_ERR_UNSUPPORTED, "gemm_tiled_splitk: T=%ld K=%ld N=%ld S=%ld", (long)T, (long)K, (long)N, (long)S);
+    if (int rc = gemm_tiled_prepare()) return rc;
+    TileEpi e{};
+    e.slabs = slabs; e.slab_stride = T * N; e.kslice = (int32_t)(K / S);
+    dim3 grid((unsigned)((N + BN - 1) / BN), (unsigned)((T + BM - 1) / BM), (unsigned)S);
+    NVR_TILED_LAUNCH(TEPI_SLAB, grid, (const half_t *)x, ldx, (const half_t *)W, (int)T, (int)K, (int)N, (int)N, nullptr, e);
+    return tiled_check("gemm_tiled_splitk");
 }
 
 bool gemm_tiled_ok(int64_t T, int64_t K, int64_t N, int64_t ldx) { return tiled_enabled() && T >= 128 && K % BK == 0 && N % 16 == 0 && ldx % 8 == 0; }

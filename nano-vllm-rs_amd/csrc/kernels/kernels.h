@@ -71,6 +71,8 @@ int linear_stream_qkv_rope_store(const half_bits *x, int64_t ldx, const half_bit
                                  half_bits *k_cache, half_bits *v_cache, hipStream_t s);
 
 // LM head over more than 32 rows: the 128x128 kernel with the logits / arg-max epilogue (one partial per 128-column tile)
+bool gemm_tiled_splitk_ok(int64_t T, int64_t K, int64_t N, int64_t S, int64_t ldx);
+int gemm_tiled_splitk(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t N, int64_t S, float *slabs, hipStream_t s);
 int gemm_tiled_prepare();                                                   // LDS opt-in of the ring instances (call outside captures)
 bool gemm_tiled_lm_head_ok(int64_t T, int64_t K, int64_t N, int64_t ldx);
 int gemm_tiled_lm_head(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t N, float *logits,

@@ -98,7 +98,8 @@ int nvr_model_runner::init() {                                       // ModelRun
     RC(dmalloc(&h, max_tokens * Hd)); RC(dmalloc(&n, max_tokens * Hd)); RC(dmalloc(&qkv, max_tokens * QKV));
     RC(dmalloc(&attn, max_tokens * H * D)); RC(dmalloc(&proj, max_tokens * Hd)); RC(dmalloc(&gu, max_tokens * 2 * I));
     RC(dmalloc(&act, max_tokens * I)); RC(dmalloc(&nlast, max_seqs * Hd)); RC(dmalloc(&logits, max_seqs * Vl));
-    RC(dmalloc(&slabs, 4 * 64 * Hd));
+    slab_rows = std::max<int64_t>(64, std::min<int64_t>(1024, std::max<int64_t>(max_seqs, 256)));
+    RC(dmalloc(&slabs, 4 * slab_rows * Hd));
     // measured slower than two launches (profiles/r01_fused_slabnorm_ablation.txt): opt-in only
     { const char *e = getenv("NVR_FUSED_SLABNORM"); fused_slabnorm = e && e[0] == '1'; }
     RC(k::linear_stream_prepare());
@@ -127,7 +128,7 @@ int nvr_model_runner::init() {                                       // ModelRun
             NVR_HIP_CHECK(hipEventCreateWithFlags(&ln.done, hipEventDisableTiming));
             RC(dmalloc(&ln.h, max_seqs * Hd)); RC(dmalloc(&ln.n, max_seqs * Hd)); RC(dmalloc(&ln.qkv, max_seqs * QKV));
             RC(dmalloc(&ln.attn, max_seqs * H * D)); RC(dmalloc(&ln.proj, max_seqs * Hd)); RC(dmalloc(&ln.act, max_seqs * I));
-            RC(dmalloc(&ln.slabs, 4 * 64 * Hd));
+            RC(dmalloc(&ln.slabs, 4 * slab_rows * Hd));
             NVR_HIP_CHECK(hipMalloc(&ln.attn_ws, attn_ws_bytes));
         }
     }
@@ -337,8 +338,12 @@ int nvr_model_runner::row_parallel_norm(Lane &ln, const uint16_t *x, int64_t K, 
         while (S < 4 && tiles * S < 256 && K % (32 * S * 2) == 0 && K / (S * 2) >= 128) S *= 2;
     } else if (!comm.active() && tp == 1 && T <= 32 && Hd <= 8192 && Hd % 64 == 0 && Hd * K * 2 >= (24ll << 20) && K % 128 == 0) {
         S = 4;                                       // large weights: 64-column workgroups x 4 k-slices (linear_splitk)
+    } else if (!comm.active() && tp == 1 && T > 128 && T <= slab_rows && Hd <= 8192 && ((Hd + 127) / 128) * ((T + 127) / 128) <= 64 &&
+               k::gemm_tiled_splitk_ok(T, K, Hd, 4, K)) {
+        S = 4;                                       // 129..1024 rows, few 128x128 tiles: k-split of the tiled kernel (gemm_tiled_splitk;
+                                                     // bs = 256 / 512 decode 4.04 -> 3.67 / 6.18 -> 5.33 ms; at 128 rows the streaming kernel still wins)
     }
-    if (S > 1 && fused_slabnorm)
+    if (S > 1 && fused_slabnorm && T <= 64)
         return k::linear_splitk_norm(x, K, W, T, K, Hd, S, ln.slabs, ln.h, wn, mc.rms_norm_eps, ln.n, ln.sync, ln.stream);
     if (S > 1) {
         RC(k::linear_splitk(x, K, W, T, K, Hd, S, ln.slabs, ln.stream));

@@ -88,6 +88,7 @@ private:
     int row_parallel_norm(Lane &ln, const uint16_t *x, int64_t K, const uint16_t *W, int64_t T, const uint16_t *wn);
     static constexpr size_t kMaxGraphs = 256;            // captured decode graphs kept before the cache is flushed
     int64_t *h_tok_dev = nullptr;                        // device-visible address of the pinned token buffer h_tok
+    int64_t slab_rows = 64;           // rows the split-k slab buffers hold (row_parallel_norm)
     bool fused_slabnorm = false;
     bool prefill_paged = false;                          // this prefill step skips cached prefixes (K/V via block tables)
     bool lazy_logits = true, want_logits = true, logits_valid = true; const uint16_t *lm_input = nullptr;

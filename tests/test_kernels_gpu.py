@@ -620,7 +620,8 @@ def test_linear_qkv_rope_store_fused(T, K, H, KVH, D):
 
 
 @pytest.mark.parametrize("T,K,N,S", [(32, 2048, 1024, 4), (32, 3072, 1024, 4), (5, 256, 64, 2), (40, 512, 256, 4),
-                                     (32, 4096, 4096, 4), (9, 12288, 4096, 4), (32, 4096, 8192, 2)])   # large weights: 64-column workgroups, wide rows
+                                     (32, 4096, 4096, 4), (9, 12288, 4096, 4), (32, 4096, 8192, 2),   # large weights: 64-column workgroups, wide rows
+                                     (130, 2048, 1024, 4), (300, 3072, 1024, 4), (70, 512, 256, 2), (512, 1024, 2048, 4)])   # > 64 rows: k-split of the 128x128 kernel
 def test_linear_splitk_and_slab_norm(T, K, N, S):
     """split-k slabs + add_rmsnorm_slabs == linear -> fp16 -> add -> rmsnorm (the unfused graph order)."""
     rng = np.random.default_rng(22)
