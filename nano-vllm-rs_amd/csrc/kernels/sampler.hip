@@ -567,8 +567,11 @@ int sample(const float *logits, int64_t B, int64_t V, const float *temperature, 
     static const bool rows_form = [] { const char *e = getenv("NVR_SAMPLE_ROWS"); return !(e && e[0] == '0'); }();
     if (rows_form && B <= 64) {
         const int rpx = (int)(B + 7) / 8;                            // rows per XCD
+        // the sharers of a row wait for each other: every workgroup of the grid must be resident at once, one 1024-thread
+        // workgroup per CU (128 VGPRs) -> no more workgroups than the device has CUs (256 on an MI355X, fewer in a partitioned mode)
+        static const int cus = [] { int d = 0; hipDeviceProp_t pr; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&pr, d) == hipSuccess) ? pr.multiProcessorCount : 0; }();
         int P = 1;
-        while (P * 2 <= kMaxParts && P * 2 * rpx * 8 <= 256) P *= 2;  // <= 256 workgroups: all co-resident
+        while (P * 2 <= kMaxParts && P * 2 * rpx * 8 <= cus) P *= 2;
         while (P > 1 && V / P < 4096) P /= 2;
         const int chunk = (int)(((V + P - 1) / P + kThreads - 1) / kThreads * kThreads);
         const int ept = chunk / kThreads;
