@@ -300,7 +300,16 @@ static void launch(const half_t *x, int64_t ldx, const half_t *W, int T, int K, 
     linear_skinny_kernel<NT, MT, WAVES, EPI><<<grid, dim3(WAVES * 64), 0, s>>>(x, ldx, W, T, K, N, y, e);
 }
 
-static inline int64_t tiles256(int64_t T, int64_t N) { return ((N + 255) / 256) * ((T + 255) / 256); }
+// 256x256 kernel or 128x128 kernel?  Fitted to the sweep (us, profiles/r01_gemm_ablation.txt): a wave of <= 256 tiles costs
+// 17*K/1024 + 20 on the 256x256 kernel (long single-tile latency); the 128x128 kernel costs 15*K/1024 while its tiles fit one per
+// CU and 21*K/1024 per wave of 512 (two workgroups per CU) beyond that, + 5 per launch.  N = W rows
+static inline bool prefer_256(int64_t T, int64_t K, int64_t N) {
+    const int64_t t256 = ((N + 255) / 256) * ((T + 255) / 256), t128 = ((N + 127) / 128) * ((T + 127) / 128);
+    const double kk = (double)K / 1024.0;
+    const double c256 = (double)((t256 + 255) / 256) * (17.0 * kk + 20.0);
+    const double c128 = (t128 <= 256 ? 15.0 * kk : (double)((t128 + 511) / 512) * 21.0 * kk) + 5.0;
+    return c256 < c128;
+}
 // one rule for the plain and the fused launchers (N = output features), so that a fused GEMM and its unfused twin run the same kernel
 static inline bool prefer_stream(int64_t T, int64_t N) { return T <= 128 || T * N <= 384 * 1024; }
 static inline int waves_for(int64_t K) { return K >= 2048 ? 16 : (K >= 1024 ? 8 : 4); }
@@ -317,10 +326,9 @@ int linear(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64
         return nvr::fail(NVR_ERR_UNSUPPORTED, "linear: K=%ld must be a multiple of 32, N=%ld of 16, ldx=%ld of 8",
                          (long)K, (long)N, (long)ldx);
     if (T == 0) return 0;
-    // Routing by measured crossovers (scratch/gemm_route_sweep.py, profiles/r01_gemm_ablation.txt): the 256x256 kernel needs
-    // more than half a wave of tiles per CU to beat the 128x128 one (its single-tile latency is ~40 us); the 128x128 kernel's
+    // Routing by measured crossovers (scratch/gemm_route_sweep.py, profiles/r01_gemm_ablation.txt): prefer_256 above; the 128x128 kernel's
     // own single-tile latency (21-31 us) loses to the weight-streaming kernel run over 32-token blocks while T or T*N is small
-    if (!y_f32 && gemm256_ok(T, K, N, ldx) && tiles256(T, N) > 128) return gemm256(x, ldx, W, T, K, N, (half_bits *)y, s);   // prefill regime
+    if (!y_f32 && gemm256_ok(T, K, N, ldx) && prefer_256(T, K, N)) return gemm256(x, ldx, W, T, K, N, (half_bits *)y, s);   // prefill regime
     if (!y_f32 && gemm_tiled_ok(T, K, N, ldx) && !prefer_stream(T, N)) return gemm_tiled(x, ldx, W, T, K, N, (half_bits *)y, s);
     if (!y_f32 && linear_stream_ok(T, K, N, ldx)) return linear_stream(x, ldx, W, T, K, N, (half_bits *)y, s);   // large weights
     const half_t *xx = (const half_t *)x, *ww = (const half_t *)W;
@@ -403,7 +411,7 @@ int linear_silu_mul(const half_bits *x, int64_t ldx, const half_bits *W, int64_t
     if (K % 32 || I % 16 || ldx % 8)
         return nvr::fail(NVR_ERR_UNSUPPORTED, "linear_silu_mul: K=%ld must be a multiple of 32, I=%ld of 16", (long)K, (long)I);
     if (T == 0) return 0;
-    if (gemm256_silu_ok(T, K, I, ldx) && tiles256(T, 2 * I) > 128) return gemm256_silu_mul(x, ldx, W, T, K, I, out, s);   // see linear()
+    if (gemm256_silu_ok(T, K, I, ldx) && prefer_256(T, K, 2 * I)) return gemm256_silu_mul(x, ldx, W, T, K, I, out, s);   // see linear()
     if (gemm_tiled_ok(T, K, I, ldx) && I % 64 == 0 && !prefer_stream(T, 2 * I)) return gemm_tiled_silu_mul(x, ldx, W, T, K, I, out, s);
     if (linear_stream_silu_ok(T, K, I, ldx)) return linear_stream_silu_mul(x, ldx, W, T, K, I, out, s);              // large weights
     const half_t *xx = (const half_t *)x, *ww = (const half_t *)W;
@@ -432,7 +440,7 @@ int linear_qkv_rope_store(const half_bits *x, int64_t ldx, const half_bits *W, i
     if (K % 32 || D % 16 || ldx % 8)
         return nvr::fail(NVR_ERR_UNSUPPORTED, "linear_qkv_rope_store: K=%ld must be a multiple of 32, D=%ld of 16", (long)K, (long)D);
     if (T == 0) return 0;
-    if (gemm256_rope_ok(T, K, H, KVH, D, ldx) && tiles256(T, (H + 2 * KVH) * D) > 128)                                  // see linear()
+    if (gemm256_rope_ok(T, K, H, KVH, D, ldx) && prefer_256(T, K, (H + 2 * KVH) * D))                                  // see linear()
         return gemm256_qkv_rope_store(x, ldx, W, T, K, H, KVH, D, positions, slots, cos_t, sin_t, qkv, k_cache, v_cache, s);
     if (gemm_tiled_ok(T, K, (H + 2 * KVH) * D, ldx) && 128 % D == 0 && !prefer_stream(T, (H + 2 * KVH) * D))
         return gemm_tiled_qkv_rope_store(x, ldx, W, T, K, H, KVH, D, positions, slots, cos_t, sin_t, qkv, k_cache, v_cache, s);
