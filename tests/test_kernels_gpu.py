@@ -556,6 +556,23 @@ def test_prefill_gemm_large_repeatable():
     rows = rng.choice(T2, 128, replace=False)
     ref = oracle.round_f16(oracle.silu_and_mul(oracle.round_f16(oracle.linear(x2[rows], W2))))
     assert_close_f16(first.view(F16)[rows], ref, ulps=2, atol=3e-4, what="gemm256 silu")
+    # the 128x128 kernel's 4-buffer ring (grids smaller than the chip: counted waits, LDS-DMA in flight across barriers) and
+    # its k-split: the same screen at a 48-tile shape
+    T3, K3, N3 = 384, 2048, 2048
+    x3, x3b = h16(rng.standard_normal((T3, K3)))
+    W3, W3b = h16(rng.standard_normal((N3, K3)) * 0.05)
+    d_x3, d_W3, d_y3 = dev(x3b), dev(W3b), nvr.DeviceBuffer(T3 * N3 * 2)
+    d_sl = nvr.DeviceBuffer(4 * T3 * N3 * 4)
+    first = first_sl = None
+    for rep in range(12):
+        nvr.check(nvr.lib().nvr_linear(d_x3.ptr, K3, d_W3.ptr, T3, K3, N3, d_y3.ptr, 0, None))
+        nvr.check(nvr.lib().nvr_linear_splitk(d_x3.ptr, K3, d_W3.ptr, T3, K3, N3, 4, d_sl.ptr, None))
+        got, gsl = d_y3.to_numpy((T3, N3), np.uint16), d_sl.to_numpy((4, T3, N3), np.float32)
+        if first is None: first, first_sl = got, gsl
+        else: assert np.array_equal(got, first) and np.array_equal(gsl, first_sl), rep
+    ref3 = oracle.linear(x3, W3)
+    assert_close_f16(first.view(F16), oracle.round_f16(ref3), ulps=1, atol=3e-4, what="gemm_tiled ring")
+    np.testing.assert_allclose(first_sl.sum(0), ref3, rtol=2e-5, atol=6e-4)
 
 
 # ------------------------------------------------------------------------------------------- fused epilogues
