@@ -10,8 +10,10 @@ A "step" is one decode pass of the engine over the whole batch (schedule -> exec
 sample_tokens -> postprocess through the C ABI), i.e. 32 generated tokens.  The prefill of the
 32x1024 prompt tokens happens before the timed region; K steps are timed between barriers and
 device synchronisation; the maximum over ranks is reported.  N>1 shards heads / MLP columns / vocab
-across N ranks (tensor parallel, one process per GPU, RCCL all-reduce inside the captured graph):
-the job is the same 32 sequences, so scaling is "strong".
+across N ranks (tensor parallel, one process per GPU, RCCL all-reduce): the job is the same 32
+sequences, so scaling is "strong".  Before that run every rank measures the no-exchange alternative
+(N independent engines, 32 sequences each) and the line carries it as "replicas" — it is also what
+is reported if the tensor-parallel communicator cannot be built or its phase does not finish.
 
 The JSON line also carries
   roofline     — the dominant kernel (paged decode attention): algorithmic K/V bytes per launch
@@ -163,6 +165,7 @@ def main() -> None:
         local_rank = 0
     dist = None
     watchdog = None
+    fallback_state: dict = {}
     if args.gpus > 1:
         # the multi-rank path cannot be exercised on the 1-GPU development boxes: never hang the driver — if a rank is still
         # stuck (a collective that never completes, a rendezvous that never forms) after 10 minutes, every rank exits
@@ -170,7 +173,17 @@ def main() -> None:
 
         def _bail():
             print(f"[bench] rank {rank}: multi-GPU run made no progress for 600 s, giving up", file=sys.stderr, flush=True)
-            os._exit(4)
+            rep = fallback_state.get("replicas")
+            if rank == 0 and rep is not None:
+                # the tensor-parallel phase hung after the replicas phase finished: report what was measured
+                print(json.dumps({"metric": "decode tokens/s + %HBM-roofline, Qwen3-0.6B bs=32 seq=1024, 1/2/4/8 GPU", "value": rep["value"],
+                                  "unit": "tokens/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+                                  "ms_per_step": rep["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                                  "dtype": "f16", "data": "synthetic",
+                                  "config": {"workload": "Qwen3-0.6B fp16 random-init, bs=32 x 1024-token prompts per GPU, greedy paged-attention decode",
+                                             "parallelism": rep["parallelism"] + " (the tensor-parallel phase did not complete within 600 s)"},
+                                  "roofline": None, "replicas": rep}), flush=True)
+            os._exit(0 if rep is not None else 4)      # a measured line went out: let the launcher finish normally
         watchdog = threading.Timer(600.0, _bail)
         watchdog.daemon = True
         watchdog.start()
@@ -182,70 +195,90 @@ def main() -> None:
         dist.init_process_group("gloo", rank=rank, world_size=world)
 
     total_new = args.warmup + args.steps + 1
-    cfg = nvr.Config(max_num_seqs=BATCH, max_num_batched_tokens=BATCH * PROMPT_LEN, max_model_len=PROMPT_LEN + total_new + 16,
-                     kvcache_block_size=BLOCK, num_kvcache_blocks=BATCH * ((PROMPT_LEN + total_new + 16) // BLOCK + 2),
-                     tensor_parallel_size=(args.gpus if args.parallel == "tp" else 1), tensor_parallel_rank=(rank if args.parallel == "tp" else 0),
-                     device_ordinal=local_rank, decode_microbatches=args.microbatches, enforce_eager=args.eager)
     mc = nvr.ModelConfig("qwen3-0.6b")
     nvr.check(nvr.lib().nvr_device_set(local_rank))
-    eng = nvr.LLMEngine(cfg, mc)
-    parallelism, scaling, jobs = f"tp{args.gpus}", "strong", 1
-    if args.gpus > 1 and args.parallel == "replicas":
-        parallelism, scaling, jobs = f"replicas{args.gpus}", "weak", args.gpus
-    if args.gpus > 1 and args.parallel == "tp":
-        import torch
-        uid = torch.zeros(128, dtype=torch.uint8)
-        if rank == 0:
-            uid = torch.frombuffer(bytearray(nvr.comm_unique_id()), dtype=torch.uint8).clone()
-        dist.broadcast(uid, 0)
-        ok, why = 1, ""
-        try:
-            eng.model_runner.init_comm(bytes(uid.numpy().tobytes()))   # RCCL communicator + collective self-test
-        except Exception as ex:                                          # noqa: BLE001
-            ok, why = 0, str(ex)
-        flag = torch.tensor([ok], dtype=torch.int32)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 0:
-            # The tensor-parallel communicator could not be built on this node: report it and measure N independent
-            # replicas (one full model and its own 32 sequences per GPU, no exchange) instead of producing no number.
-            if why:
-                print(f"[bench] rank {rank}: tensor-parallel init failed: {why}", file=sys.stderr, flush=True)
-            del eng
-            cfg = nvr.Config(max_num_seqs=BATCH, max_num_batched_tokens=BATCH * PROMPT_LEN, max_model_len=PROMPT_LEN + total_new + 16,
-                             kvcache_block_size=BLOCK, num_kvcache_blocks=BATCH * ((PROMPT_LEN + total_new + 16) // BLOCK + 2),
-                             device_ordinal=local_rank, decode_microbatches=args.microbatches, enforce_eager=args.eager)
-            eng = nvr.LLMEngine(cfg, mc)
-            parallelism, scaling, jobs = f"replicas{args.gpus} (tensor-parallel init failed)", "weak", args.gpus
 
-    for i in range(BATCH):                   # synthetic prompts, SURVEY §8d: seed 1, one stream per sequence
-        eng.add_request(nvr.synthetic_tokens(PROMPT_LEN, 1, i, mc.c.vocab_size).tolist(),
-                        nvr.SamplingParams(temperature=0.0, max_tokens=total_new + 8, ignore_eos=True))
+    def make_engine(tp_size: int, tp_rank: int):
+        cfg = nvr.Config(max_num_seqs=BATCH, max_num_batched_tokens=BATCH * PROMPT_LEN, max_model_len=PROMPT_LEN + total_new + 16,
+                         kvcache_block_size=BLOCK, num_kvcache_blocks=BATCH * ((PROMPT_LEN + total_new + 16) // BLOCK + 2),
+                         tensor_parallel_size=tp_size, tensor_parallel_rank=tp_rank,
+                         device_ordinal=local_rank, decode_microbatches=args.microbatches, enforce_eager=args.eager)
+        return nvr.LLMEngine(cfg, mc)
 
     def barrier():
         nvr.synchronize()
         if dist is not None:
             dist.barrier()
 
-    t0 = time.perf_counter()
-    info = eng.step()                        # prefill of 32 x 1024 tokens (untimed)
-    nvr.synchronize()
-    t_prefill = time.perf_counter() - t0
-    assert info["is_prefill"] and info["num_seqs"] == BATCH, info
-    for _ in range(args.warmup):
-        info = eng.step()
-        assert not info["is_prefill"] and info["num_seqs"] == BATCH
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        eng.step()
-    nvr.synchronize()
-    elapsed = time.perf_counter() - t0
-    barrier()
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def run_decode(eng):
+        """prefill (untimed), W warm-up steps, K timed steps between barriers; max over ranks"""
+        for i in range(BATCH):               # synthetic prompts, SURVEY §8d: seed 1, one stream per sequence
+            eng.add_request(nvr.synthetic_tokens(PROMPT_LEN, 1, i, mc.c.vocab_size).tolist(),
+                            nvr.SamplingParams(temperature=0.0, max_tokens=total_new + 8, ignore_eos=True))
+        t0 = time.perf_counter()
+        info = eng.step()                    # prefill of 32 x 1024 tokens (untimed)
+        nvr.synchronize()
+        t_pre = time.perf_counter() - t0
+        assert info["is_prefill"] and info["num_seqs"] == BATCH, info
+        for _ in range(args.warmup):
+            info = eng.step()
+            assert not info["is_prefill"] and info["num_seqs"] == BATCH
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            eng.step()
+        nvr.synchronize()
+        el = time.perf_counter() - t0
+        barrier()
+        if dist is not None:
+            import torch
+            t = torch.tensor([el], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, t_pre
+
+    parallelism, scaling, jobs = "tp1", "strong", 1
+    replicas = None                           # N > 1: the no-exchange measurement (N independent engines), always taken first
+    if args.gpus > 1:
+        eng = make_engine(1, 0)
+        r_el, r_pre = run_decode(eng)
+        replicas = {"value": round(args.gpus * BATCH * args.steps / r_el, 2), "unit": "tokens/s", "ms_per_step": round(r_el * 1e3 / args.steps, 4),
+                    "scaling": "weak", "parallelism": f"replicas{args.gpus}",
+                    "note": f"{args.gpus} independent engines (one full model and its own 32 sequences per GPU), no exchange between ranks"}
+        fallback_state["replicas"] = replicas
+        if args.parallel == "replicas":
+            parallelism, scaling, jobs = f"replicas{args.gpus}", "weak", args.gpus
+            elapsed, t_prefill = r_el, r_pre
+        else:
+            import torch
+            eng_rep = eng                     # kept alive (5.6 GB): its KV pool backs the attention timing if the TP phase fails
+            eng = make_engine(args.gpus, rank)
+            uid = torch.zeros(128, dtype=torch.uint8)
+            if rank == 0:
+                uid = torch.frombuffer(bytearray(nvr.comm_unique_id()), dtype=torch.uint8).clone()
+            dist.broadcast(uid, 0)
+            ok, why = 1, ""
+            try:
+                eng.model_runner.init_comm(bytes(uid.numpy().tobytes()))   # RCCL communicator + collective self-test
+            except Exception as ex:                                          # noqa: BLE001
+                ok, why = 0, str(ex)
+            flag = torch.tensor([ok], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                # The tensor-parallel communicator could not be built on this node: report it; the replicas measurement stands.
+                if why:
+                    print(f"[bench] rank {rank}: tensor-parallel init failed: {why}", file=sys.stderr, flush=True)
+                del eng
+                eng = eng_rep
+                parallelism, scaling, jobs = f"replicas{args.gpus} (tensor-parallel init failed)", "weak", args.gpus
+                elapsed, t_prefill = r_el, r_pre
+            else:
+                del eng_rep
+                parallelism, scaling, jobs = f"tp{args.gpus}", "strong", 1
+                elapsed, t_prefill = run_decode(eng)
+    else:
+        eng = make_engine(1, 0)
+        elapsed, t_prefill = run_decode(eng)
 
     # prefill of the 32 x 1024 prompt tokens (one engine step, wall clock incl. host input preparation): MFMA-bound,
     # SURVEY §8d: 880.8 MFLOP/token of GEMM + 114 688*l flop/token of causal attention (+ LM head per sequence)
@@ -297,6 +330,8 @@ def main() -> None:
                          "us_per_launch": round(attn["us_per_launch"], 2), "launches_timed": attn["launches"],
                          "algorithmic_bytes_per_launch": int(attn["alg_bytes"])},
         }
+        if replicas is not None:
+            out["replicas"] = replicas
         if args.gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
