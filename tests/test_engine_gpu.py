@@ -305,6 +305,49 @@ def test_eos_and_stochastic_sampling_paths():
     assert agree >= total - 3, (agree, total)
 
 
+_SOAK_SEEN = dict(preemptions=0, early_stops=0, runs=0)
+
+
+@pytest.mark.parametrize("seed", [101, 202, 303, 404, 505, 606])
+def test_random_workloads_end_to_end(seed):
+    """Randomised soak: prompt lengths from 1 token to several blocks, shared prefixes of whole blocks, mixed max_tokens, an
+    EOS id that some sequences honour, a KV pool small enough to force preemption on most seeds, more requests than
+    max_num_seqs.  Every step: same batch, same block tables (through the logits), logits within tolerance, tokens equal
+    outside numerical near-ties; at the end the same scheduler statistics and the same finished sequences."""
+    rng = np.random.default_rng(seed)
+    mcfg = mo.small(seed=seed % 7)
+    bs = int(rng.choice([16, 32]))
+    nreq = int(rng.integers(5, 11))
+    ecfg = dict(max_num_seqs=int(rng.integers(3, 7)), max_num_batched_tokens=int(rng.choice([160, 256, 512])), max_model_len=256,
+                kvcache_block_size=bs, num_kvcache_blocks=int(rng.integers(14, 30)) * (32 // bs), eos_token_id=int(rng.integers(0, mcfg.vocab_size)))
+    shared = oracle.fill_tokens(2 * bs, seed, 9999, mcfg.vocab_size).tolist()
+    prompts, sps = [], []
+    for i in range(nreq):
+        own = oracle.fill_tokens(int(rng.integers(1, 70)), seed, i, mcfg.vocab_size).tolist()
+        pr = (shared[:bs * int(rng.integers(1, 3))] + own) if rng.random() < 0.5 else own
+        pr = pr[:ecfg["max_num_batched_tokens"] - 1]
+        prompts.append(pr)
+        sps.append(dict(temperature=0.0, max_tokens=int(rng.integers(1, 40)), ignore_eos=bool(rng.random() < 0.6)))
+    r = _run_pair(mcfg, ecfg, prompts, sps, max_steps=2000)
+    assert len(r["finished"]) == nreq
+    assert r["near_ties"] <= 4, r
+    st = r["oracle"].scheduler.stats
+    _SOAK_SEEN["preemptions"] += st.preemptions
+    _SOAK_SEEN["early_stops"] += sum(len(t) - len(prompts[i]) < sps[i]["max_tokens"] for i, t in r["finished"].items())
+    _SOAK_SEEN["runs"] += 1
+    for sid, toks in r["finished"].items():
+        assert toks[:len(prompts[sid])] == prompts[sid]
+        assert 1 <= len(toks) - len(prompts[sid]) <= sps[sid]["max_tokens"]
+        if len(toks) - len(prompts[sid]) < sps[sid]["max_tokens"]:                     # stopped early: only the EOS rule allows that
+            assert not sps[sid]["ignore_eos"] and toks[-1] == ecfg["eos_token_id"]
+
+
+def test_random_workloads_did_exercise_preemption():
+    if _SOAK_SEEN["runs"] < 6:
+        pytest.skip("runs after the six soak cases")
+    assert _SOAK_SEEN["preemptions"] > 0, _SOAK_SEEN
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # SURVEY §8f row 3: text in, SequenceOutput out (LLMEngine::generate / generate_stream, llm_engine.rs:70-128)
 _GEN_ECFG = dict(max_num_seqs=4, max_num_batched_tokens=256, max_model_len=256, kvcache_block_size=16, num_kvcache_blocks=40)
