@@ -219,6 +219,14 @@ NVR_API int nvr_comm_unique_id(uint8_t id_out[128]);
 NVR_API int nvr_runner_init_comm(nvr_model_runner_t *r, const uint8_t id[128]);
 /* collective self-check (all ranks call it): all-reduce of ones == tensor_parallel_size, all-gather of ranks */
 NVR_API int nvr_runner_comm_selftest(nvr_model_runner_t *r);
+/* In-process stand-in for the communicator (tests / bring-up on a one-GPU box; no performance claim): the ranks are N runners
+ * of ONE process on ONE device, each driven by its own host thread; a collective is a host rendezvous plus a device sum /
+ * copies over the peers' buffers.  Same call sites and results as the RCCL path (linear.rs:236-238, embed_head.rs:321-336);
+ * decode steps run eagerly.  The group outlives its runners' use of it. */
+typedef struct nvr_local_group nvr_local_group_t;
+NVR_API nvr_local_group_t *nvr_local_group_create(int nranks);
+NVR_API void nvr_local_group_destroy(nvr_local_group_t *g);
+NVR_API int nvr_runner_init_comm_local(nvr_model_runner_t *r, nvr_local_group_t *g);
 
 /* -------------------------------------------------------------------- Engine ---- */
 /* LLMEngine::step loop, src/engine/llm_engine.rs:155-197 (driver of the hot path only) */

@@ -174,6 +174,8 @@ _SIGS = {
     "nvr_engine_generate": (C.c_int, [_P, _P, _P, C.c_size_t, _P, C.POINTER(_P), C.POINTER(C.c_size_t)]),
     "nvr_engine_generate_ids": (C.c_int, [_P, _P, _P, C.c_size_t, _P, C.POINTER(_P), C.POINTER(C.c_size_t)]),
     "nvr_engine_generate_stream": (C.c_int, [_P, _P, _P, C.c_size_t, _P, STREAM_FN, _P]),
+    "nvr_local_group_create": (_P, [C.c_int]), "nvr_local_group_destroy": (None, [_P]),
+    "nvr_runner_init_comm_local": (C.c_int, [_P, _P]),
     "nvr_engine_last_step": (None, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(C.c_size_t)]),
     "nvr_engine_take_finished": (C.c_size_t, [_P, C.POINTER(_P), C.c_size_t]),
     "nvr_engine_last_batch": (C.c_size_t, [_P, C.POINTER(_P), C.c_size_t]),
@@ -593,6 +595,25 @@ class ModelRunner:
     def init_comm(self, unique_id: bytes) -> None:
         buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
         check(lib().nvr_runner_init_comm(self.h, buf))
+
+
+class LocalGroup:
+    """In-process communicator (nvr_local_group_*): tensor-parallel ranks as runners of this process on one GPU,
+    one host thread per rank.  Tests and bring-up only."""
+
+    def __init__(self, nranks: int):
+        self.h = lib().nvr_local_group_create(nranks)
+        if not self.h:
+            raise NvrError(-7, last_error())
+        self.nranks = nranks
+
+    def attach(self, runner: "ModelRunner") -> None:
+        check(lib().nvr_runner_init_comm_local(runner.h, self.h))
+
+    def __del__(self):
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.nvr_local_group_destroy(self.h)
+            self.h = None
 
 
 def preload_rccl() -> None:

@@ -2,6 +2,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include "common.h"
 
@@ -66,17 +67,64 @@ int Comm::init(const uint8_t idb[128], int nr, int rk) {
     return NVR_OK;
 }
 
+// ---- in-process group (comm.h) ---------------------------------------------------------------------------------------
+int LocalGroup::rendezvous(int rank, const void *ptr) {
+    std::unique_lock<std::mutex> lk(m);
+    if (broken) return fail(NVR_ERR_RCCL, "local group: a rank timed out earlier");
+    ptrs[(size_t)rank] = ptr;
+    const uint64_t gen = generation;
+    if (++arrived == nranks) { arrived = 0; ++generation; cv.notify_all(); return NVR_OK; }
+    if (!cv.wait_for(lk, std::chrono::seconds(120), [&] { return generation != gen || broken; })) {
+        broken = true; cv.notify_all();
+        return fail(NVR_ERR_RCCL, "local group: rank %d waited 120 s for its peers", rank);
+    }
+    return broken ? fail(NVR_ERR_RCCL, "local group: a peer timed out") : NVR_OK;
+}
+int Comm::init_local(LocalGroup *g, int rk) {
+    if (!g || rk < 0 || rk >= g->nranks) return fail(NVR_ERR_INVALID_ARG, "init_local: rank %d of %d", rk, g ? g->nranks : 0);
+    local = g; nranks = g->nranks; rank = rk;
+    return NVR_OK;
+}
+int local_sum_f16(const void *const *ptrs, int n, void *out, size_t count, hipStream_t s);     // comm_local.hip
+
 int Comm::all_reduce_sum_f16(void *buf, size_t count, hipStream_t s) {
+    if (local) {
+        if (local_tmp_bytes < count * 2) {
+            if (local_tmp) (void)hipFree(local_tmp);
+            NVR_HIP_CHECK(hipMalloc(&local_tmp, count * 2)); local_tmp_bytes = count * 2;
+        }
+        NVR_HIP_CHECK(hipStreamSynchronize(s));                         // my partial sums are complete
+        if (int rc = local->rendezvous(rank, buf)) return rc;           // everyone's are, and their addresses are known
+        std::vector<const void *> peers;
+        { std::lock_guard<std::mutex> lk(local->m); peers = local->ptrs; }
+        if (int rc = local_sum_f16(peers.data(), nranks, local_tmp, count, s)) return rc;
+        NVR_HIP_CHECK(hipStreamSynchronize(s));
+        if (int rc = local->rendezvous(rank, buf)) return rc;           // every rank has read every input
+        NVR_HIP_CHECK(hipMemcpyAsync(buf, local_tmp, count * 2, hipMemcpyDeviceToDevice, s));
+        return NVR_OK;
+    }
     NVR_NCCL(g_api.AllReduce(buf, buf, count, ncclFloat16, ncclSum, (ncclComm_t)comm, s));
     return NVR_OK;
 }
 int Comm::all_gather_bytes(const void *send, void *recv, size_t bytes, hipStream_t s) {
+    if (local) {
+        NVR_HIP_CHECK(hipStreamSynchronize(s));
+        if (int rc = local->rendezvous(rank, send)) return rc;
+        std::vector<const void *> peers;
+        { std::lock_guard<std::mutex> lk(local->m); peers = local->ptrs; }
+        for (int r = 0; r < nranks; ++r)
+            NVR_HIP_CHECK(hipMemcpyAsync((char *)recv + (size_t)r * bytes, peers[(size_t)r], bytes, hipMemcpyDeviceToDevice, s));
+        NVR_HIP_CHECK(hipStreamSynchronize(s));
+        return local->rendezvous(rank, send);                           // nobody reuses its send buffer before all copies are done
+    }
     NVR_NCCL(g_api.AllGather(send, recv, bytes, ncclInt8, (ncclComm_t)comm, s));
     return NVR_OK;
 }
 void Comm::destroy() {
     if (comm && g_api.CommDestroy) g_api.CommDestroy((ncclComm_t)comm);
     comm = nullptr;
+    if (local_tmp) { (void)hipFree(local_tmp); local_tmp = nullptr; local_tmp_bytes = 0; }
+    local = nullptr;
 }
 
 }  // namespace nvr

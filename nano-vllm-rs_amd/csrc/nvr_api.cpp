@@ -229,6 +229,27 @@ int nvr_runner_init_comm(nvr_model_runner_t *r, const uint8_t id[128]) {
     return r->tp > 1 ? r->comm_selftest() : NVR_OK;            // also establishes every RCCL connection up front
 }
 
+// in-process communicator (comm.h LocalGroup): N runners of one process on one device, one host thread each
+struct nvr_local_group { nvr::LocalGroup g; explicit nvr_local_group(int n) : g(n) {} };
+nvr_local_group_t *nvr_local_group_create(int nranks) {
+    NVR_GUARD_BEGIN
+    if (nranks < 1 || nranks > 8) { nvr::fail(NVR_ERR_INVALID_ARG, "nvr_local_group_create: %d ranks (1..8)", nranks); return nullptr; }
+    return new nvr_local_group(nranks);
+    NVR_GUARD_END(nullptr)
+}
+void nvr_local_group_destroy(nvr_local_group_t *g) { delete g; }
+int nvr_runner_init_comm_local(nvr_model_runner_t *r, nvr_local_group_t *g) {
+    NVR_GUARD_BEGIN
+    if (!g) return nvr::fail(NVR_ERR_INVALID_ARG, "nvr_runner_init_comm_local: group is null");
+    if (g->g.nranks != (int)r->tp) return nvr::fail(NVR_ERR_INVALID_ARG, "local group of %d ranks for tensor_parallel_size %ld", g->g.nranks, (long)r->tp);
+    NVR_HIP_CHECK(hipSetDevice(r->device));
+    int rc = r->comm.init_local(&g->g, (int)r->rank);
+    if (rc) return rc;
+    r->graphs_disabled = true;                 // the collectives synchronise on the host: nothing to capture
+    return NVR_OK;
+    NVR_GUARD_END(NVR_ERR_INVARIANT)
+}
+
 // ------------------------------------------------------------------ Engine
 nvr_engine_t *nvr_engine_create(const nvr_config *cfg, const nvr_model_config *mc) {
     NVR_GUARD_BEGIN
