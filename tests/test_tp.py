@@ -239,9 +239,9 @@ def test_product_tensor_parallel_ranks_in_process_match_the_oracle(tp, temps):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("tp", [2, 8])
-def test_qwen3_0_6b_tensor_parallel_in_process_equals_single_rank(tp):
-    """The benchmark model at full size, sharded over tp in-process ranks (tp = 8: 2 query heads and 1 kv head, 384 MLP columns,
+@pytest.mark.parametrize("tp,model", [(2, "qwen3-0.6b"), (8, "qwen3-0.6b"), (8, "qwen3-8b-2layers"), (4, "qwen3-8b-2layers")])
+def test_full_size_tensor_parallel_in_process_equals_single_rank(tp, model):
+    """The benchmark model at full size (and the Qwen3-8B layer geometry of BASELINE configs[3], two layers), sharded over tp in-process ranks (tp = 8: 2 query heads and 1 kv head, 384 MLP columns,
     18 992 vocabulary rows per rank — the narrow-shard launch rules, partitioned attention + merge, sharded LM head and the
     (max, argmax) gather), against the single-rank product on the same prompts: the concatenated shard logits agree with the
     single-rank logits to fp16-pipeline tolerance and the greedy tokens agree outside near-ties; all ranks agree exactly."""
@@ -249,7 +249,12 @@ def test_qwen3_0_6b_tensor_parallel_in_process_equals_single_rank(tp):
     sys.path.insert(0, ROOT)
     import nvr_import
     nvr = nvr_import.load()
-    mc = nvr.ModelConfig("qwen3-0.6b")
+    if model == "qwen3-0.6b":
+        mc = nvr.ModelConfig("qwen3-0.6b")
+    else:                                       # BASELINE configs[3] geometry (Hd 4096, 32:8 heads, D 128, I 12288), two layers, small vocabulary
+        mc = nvr.ModelConfig(vocab_size=4096, hidden_size=4096, intermediate_size=12288, num_hidden_layers=2, num_attention_heads=32,
+                             num_key_value_heads=8, head_dim=128, max_position_embeddings=1024, rms_norm_eps=1e-6, rope_theta=1e6,
+                             tie_word_embeddings=False, init_std=0.02, seed=21)
     V = mc.c.vocab_size
     ecfg = dict(max_num_seqs=4, max_num_batched_tokens=1024, max_model_len=512, kvcache_block_size=256, num_kvcache_blocks=12)
     prompts = [nvr.synthetic_tokens(n, 1, i, V).tolist() for i, n in enumerate([24, 300, 9, 130])]
