@@ -173,9 +173,10 @@ def main() -> None:
         # the multi-rank path cannot be exercised on the 1-GPU development boxes: never hang the driver — if a rank is still
         # stuck (a collective that never completes, a rendezvous that never forms) after 10 minutes, every rank exits
         import threading
+        wd_secs = 240.0 if os.environ.get("NVR_BENCH_CHILD") == "1" else 600.0
 
         def _bail():
-            print(f"[bench] rank {rank}: multi-GPU run made no progress for 600 s, giving up", file=sys.stderr, flush=True)
+            print(f"[bench] rank {rank}: multi-GPU run made no progress for {int(wd_secs)} s, giving up", file=sys.stderr, flush=True)
             rep = fallback_state.get("replicas")
             if rank == 0 and rep is not None:
                 # the tensor-parallel phase hung after the replicas phase finished: report what was measured
@@ -187,7 +188,7 @@ def main() -> None:
                                              "parallelism": rep["parallelism"] + " (the tensor-parallel phase did not complete within 600 s)"},
                                   "roofline": None, "replicas": rep}), flush=True)
             os._exit(0 if rep is not None else 4)      # a measured line went out: let the launcher finish normally
-        watchdog = threading.Timer(600.0, _bail)
+        watchdog = threading.Timer(wd_secs, _bail)
         watchdog.daemon = True
         watchdog.start()
         if world != args.gpus:
@@ -243,7 +244,30 @@ def main() -> None:
     parallelism, scaling, jobs = "tp1", "strong", 1
     replicas = None                           # N > 1: the no-exchange measurement (N independent engines), always taken first
     tensor_parallel = None
-    if args.gpus > 1:
+    child = os.environ.get("NVR_BENCH_CHILD") == "1"
+    if args.gpus > 1 and child:
+        # the tensor-parallel phase of a parent bench.py (see "both" below): no replicas leg; a failure is reported as a JSON error line
+        import torch
+        eng = make_engine(args.gpus, rank)
+        uid = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0:
+            uid = torch.frombuffer(bytearray(nvr.comm_unique_id()), dtype=torch.uint8).clone()
+        dist.broadcast(uid, 0)
+        ok, why = 1, ""
+        try:
+            eng.model_runner.init_comm(bytes(uid.numpy().tobytes()))       # RCCL communicator + collective self-test
+        except Exception as ex:                                              # noqa: BLE001
+            ok, why = 0, str(ex)
+        flag = torch.tensor([ok], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            if rank == 0:
+                print(json.dumps({"error": "tensor-parallel communicator could not be built on this node" + (f": {why}" if why else "")}), flush=True)
+            dist.barrier(); dist.destroy_process_group()
+            sys.stdout.flush(); os._exit(0)
+        parallelism, scaling, jobs = f"tp{args.gpus}", "strong", 1
+        elapsed, t_prefill = run_decode(eng)
+    elif args.gpus > 1:
         eng = make_engine(1, 0)
         r_el, r_pre = run_decode(eng)
         replicas = {"value": round(args.gpus * BATCH * args.steps / r_el, 2), "unit": "tokens/s", "ms_per_step": round(r_el * 1e3 / args.steps, 4),
@@ -255,34 +279,41 @@ def main() -> None:
             elapsed, t_prefill = r_el, r_pre
         elif args.parallel == "both":
             # value = the replicas (what a deployment picks for a model this small); the north star's tensor-parallel configuration
-            # is measured on the same ranks right after and reported next to it
-            import torch
+            # is measured on the same ranks right after, in a CHILD process per rank (its own gloo group on the next port): the
+            # multi-GPU RCCL path could not be exercised on the 1-GPU development boxes, and a crash or hang in it must not cost
+            # the measurement already taken
+            import subprocess
             parallelism, scaling, jobs = f"replicas{args.gpus}", "weak", args.gpus
             elapsed, t_prefill = r_el, r_pre
-            eng_tp = make_engine(args.gpus, rank)
-            uid = torch.zeros(128, dtype=torch.uint8)
-            if rank == 0:
-                uid = torch.frombuffer(bytearray(nvr.comm_unique_id()), dtype=torch.uint8).clone()
-            dist.broadcast(uid, 0)
-            ok, why = 1, ""
+            env = dict(os.environ)
+            env["MASTER_PORT"] = str(int(env.get("MASTER_PORT", "29500")) + 1)
+            env["NVR_BENCH_CHILD"] = "1"
+            for k in [k for k in env if k.startswith("TORCHELASTIC_")]:       # the children rendezvous on their own store (rank 0 hosts it),
+                del env[k]                                                    # not on the launcher agent's
+            cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup),
+                   "--parallel", "tp", "--no-cpu-baseline", "--attn-reps", "1", "--microbatches", str(args.microbatches)] + (["--eager"] if args.eager else [])
+            child_out, child_err, child_rc = "", "", None
             try:
-                eng_tp.model_runner.init_comm(bytes(uid.numpy().tobytes()))
-            except Exception as ex:                                          # noqa: BLE001
-                ok, why = 0, str(ex)
-            flag = torch.tensor([ok], dtype=torch.int32)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag.item()) == 0:
-                if why:
-                    print(f"[bench] rank {rank}: tensor-parallel init failed: {why}", file=sys.stderr, flush=True)
-                tensor_parallel = {"error": "communicator could not be built on this node" + (f": {why}" if why else "")}
-            else:
-                t_el, _ = run_decode(eng_tp)
-                tpv = BATCH * args.steps / t_el
-                tensor_parallel = {"value": round(tpv, 2), "unit": "tokens/s", "ms_per_step": round(t_el * 1e3 / args.steps, 4), "scaling": "strong",
-                                   "parallelism": f"tp{args.gpus}", "speedup_vs_one_gpu": round(tpv / (replicas["value"] / args.gpus), 3),
-                                   "note": "one engine over all ranks: heads / MLP columns / vocabulary sharded, RCCL all-reduce after o_proj and "
-                                           "down_proj (57 collectives per step), the same 32 sequences as at N=1"}
-            del eng_tp
+                cp = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+                child_out, child_err, child_rc = cp.stdout, cp.stderr, cp.returncode
+            except subprocess.TimeoutExpired as te:
+                child_err = "timed out after 300 s: " + str((te.stderr or b"")[-300:])
+            if rank == 0:
+                line = next((l for l in reversed(child_out.splitlines()) if l.startswith("{")), None)
+                try:
+                    cj = json.loads(line) if line else None
+                except Exception:                                            # noqa: BLE001
+                    cj = None
+                if cj and cj.get("config", {}).get("parallelism") == f"tp{args.gpus}":
+                    tensor_parallel = {"value": cj["value"], "unit": "tokens/s", "ms_per_step": cj["ms_per_step"], "scaling": "strong",
+                                       "parallelism": f"tp{args.gpus}", "speedup_vs_one_gpu": round(cj["value"] / (replicas["value"] / args.gpus), 3),
+                                       "roofline": cj.get("roofline"),
+                                       "note": "one engine over all ranks: heads / MLP columns / vocabulary sharded, RCCL all-reduce after o_proj and "
+                                               "down_proj (57 collectives per step), the same 32 sequences as at N=1"}
+                else:
+                    why = (cj or {}).get("error") or f"child exit code {child_rc}: {child_err.strip()[-400:]}"
+                    tensor_parallel = {"error": why}
+            barrier()
         else:
             import torch
             eng_rep = eng                     # kept alive (5.6 GB): its KV pool backs the attention timing if the TP phase fails
