@@ -194,7 +194,6 @@ __global__ __launch_bounds__(WAVES * 64) void linear_skinny_kernel(const half_t 
                         hv[cc] = *reinterpret_cast<const half8_t *>(hr + col);
                         float4_t a0 = (float4_t){0.f, 0.f, 0.f, 0.f}, a1 = a0;
                         for (int z = 0; z < S; ++z) {
-                            typedef unsigned int u4 __attribute__((ext_vector_type(4)));
                             const int off = (int)((z * epi.slab_stride + (int64_t)row * N + col) * 4);
                             const float4_t p0 = __builtin_bit_cast(float4_t, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 16));
                             const float4_t p1 = __builtin_bit_cast(float4_t, __builtin_amdgcn_raw_buffer_load_b128(rs, off + 16, 0, 16));
