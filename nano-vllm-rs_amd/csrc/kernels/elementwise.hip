@@ -152,6 +152,56 @@ __global__ __launch_bounds__(256) void rmsnorm_row4_kernel(half_t *__restrict__ 
         }
     }
 }
+// K1 + K2 of a decode-sized step in one launch: h[row] = E[ids[row]] (VocabParallelEmbedding::forward, embed_head.rs:77-97),
+// out[row] = rmsnorm(h[row]) * w (the first layer's input norm) — same arithmetic as embedding followed by rmsnorm_row4_kernel
+template <int C, int P>
+__global__ __launch_bounds__(256) void embed_rmsnorm_kernel(const int64_t *__restrict__ ids, const half_t *__restrict__ E,
+                                                            const half_t *__restrict__ w, float eps, int Hd,
+                                                            half_t *__restrict__ h, half_t *__restrict__ out) {
+    typedef half_t hp_t __attribute__((ext_vector_type(P)));
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const half_t *src = E + ids[row] * (int64_t)Hd;
+    hp_t v[C], g[C];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < C; ++i) {
+        const int c = tid * P + i * (256 * P);
+        if (c < Hd) {
+            v[i] = *reinterpret_cast<const hp_t *>(src + c);
+            g[i] = *reinterpret_cast<const hp_t *>(w + c);
+            *reinterpret_cast<hp_t *>(h + (int64_t)row * Hd + c) = v[i];
+#pragma unroll
+            for (int j = 0; j < P; ++j) { const float f = (float)v[i][j]; ss += f * f; }
+        }
+    }
+    __shared__ float sm[4];
+    ss = wave_sum(ss);
+    if ((tid & 63) == 0) sm[tid >> 6] = ss;
+    __syncthreads();
+    const float rms = sqrtf((sm[0] + sm[1] + sm[2] + sm[3]) / (float)Hd + eps);
+#pragma unroll
+    for (int i = 0; i < C; ++i) {
+        const int c = tid * P + i * (256 * P);
+        if (c < Hd) {
+            hp_t o;
+#pragma unroll
+            for (int j = 0; j < P; ++j) o[j] = to_half_rn(__fmul_rn(__fdiv_rn((float)v[i][j], rms), (float)g[i][j]));
+            *reinterpret_cast<hp_t *>(out + (int64_t)row * Hd + c) = o;
+        }
+    }
+}
+bool embedding_rmsnorm_ok(int64_t T, int64_t Hd) { return T >= 1 && T <= 64 && Hd % 8 == 0 && Hd <= 8192; }
+int embedding_rmsnorm(const int64_t *ids, int64_t T, const half_bits *E, const half_bits *w, float eps, int64_t Hd, half_bits *h,
+                      half_bits *out, hipStream_t s) {
+    if (!embedding_rmsnorm_ok(T, Hd)) return nvr::fail(NVR_ERR_UNSUPPORTED, "embedding_rmsnorm: T=%ld (1..64), hidden size %ld", (long)T, (long)Hd);
+    dim3 grid((unsigned)T), block(256);
+    if (Hd <= 1024) embed_rmsnorm_kernel<1, 4><<<grid, block, 0, s>>>(ids, (const half_t *)E, (const half_t *)w, eps, (int)Hd, (half_t *)h, (half_t *)out);
+    else if (Hd <= 2048) embed_rmsnorm_kernel<1, 8><<<grid, block, 0, s>>>(ids, (const half_t *)E, (const half_t *)w, eps, (int)Hd, (half_t *)h, (half_t *)out);
+    else embed_rmsnorm_kernel<4, 8><<<grid, block, 0, s>>>(ids, (const half_t *)E, (const half_t *)w, eps, (int)Hd, (half_t *)h, (half_t *)out);
+    LAUNCH_CHECK();
+    return 0;
+}
+
 template <bool ADD>
 static void launch_rmsnorm(half_t *h, const half_t *y, const half_t *w, float eps, int T, int Hd, half_t *out, hipStream_t s) {
     if (T <= 64 && Hd <= 8192) {

@@ -10,6 +10,10 @@ namespace nvr { namespace k {
 typedef uint16_t half_bits;
 
 int embedding(const int64_t *ids, int64_t T, const half_bits *E, int64_t Hd, half_bits *out, hipStream_t s);
+// decode-sized steps (T <= 64): embedding + the first layer's input RMSNorm in one launch (same arithmetic as the two kernels)
+bool embedding_rmsnorm_ok(int64_t T, int64_t Hd);
+int embedding_rmsnorm(const int64_t *ids, int64_t T, const half_bits *E, const half_bits *w, float eps, int64_t Hd, half_bits *h,
+                      half_bits *out, hipStream_t s);
 int rmsnorm(const half_bits *x, const half_bits *w, float eps, int64_t T, int64_t Hd, half_bits *out, hipStream_t s);
 int add_rmsnorm(half_bits *h, const half_bits *y, const half_bits *w, float eps, int64_t T, int64_t Hd,
                 half_bits *out, hipStream_t s);

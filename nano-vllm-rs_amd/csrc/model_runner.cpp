@@ -361,10 +361,12 @@ int nvr_model_runner::forward(Lane &ln, int64_t row0, int64_t T, int64_t B, bool
     const int64_t *ids = (is_prefill ? d_ids : dd_ids) + row0, *pos = (is_prefill ? d_pos : dd_pos) + row0;
     const int32_t *slots = (is_prefill ? d_slots : dd_slots) + row0, *ctx = (is_prefill ? d_ctx : dd_ctx) + row0;
     const int32_t *bt = dd_bt + row0 * max_blocks_per_seq;
-    RC(k::embedding(ids, T, embed, Hd, ln.h, st));
+    const bool embed_norm = L > 0 && k::embedding_rmsnorm_ok(T, Hd);                          // decode-sized: K1 + the first norm in one launch
+    if (embed_norm) RC(k::embedding_rmsnorm(ids, T, embed, layers[0].ln1, mc.rms_norm_eps, Hd, ln.h, ln.n, st));
+    else RC(k::embedding(ids, T, embed, Hd, ln.h, st));
     for (int64_t l = 0; l < L; ++l) {
         const Layer &w = layers[l];
-        if (l == 0) RC(k::rmsnorm(ln.h, w.ln1, mc.rms_norm_eps, T, Hd, ln.n, st));          // later layers: see down_proj
+        if (l == 0 && !embed_norm) RC(k::rmsnorm(ln.h, w.ln1, mc.rms_norm_eps, T, Hd, ln.n, st));   // later layers: see down_proj
         // qkv GEMM with the RoPE + KV-store epilogue (K3..K6 in one launch)
         RC(k::linear_qkv_rope_store(ln.n, Hd, w.qkv, T, Hd, H, KVH, D, pos, slots, cos_t, sin_t, ln.qkv, k_cache(l), v_cache(l), st));
         k::AttnArgs a{};
