@@ -213,6 +213,9 @@ NVR_API uint64_t nvr_runner_num_kvcache_blocks(const nvr_model_runner_t *r);
 /* KV pool of layer l (borrowed device pointers, fp16 [NB, bs, KVH/tp, D], model_runner.rs:364-396) */
 NVR_API int nvr_runner_kv_cache(nvr_model_runner_t *r, size_t layer, void **k_dev, void **v_dev);
 NVR_API void *nvr_runner_stream(nvr_model_runner_t *r);
+/* diagnostic: re-launch the hipGraph of the last decode step n times back to back (same inputs, no host round trip; the caller
+ * synchronises): the GPU's launch chain without the host gap between engine steps (execute_with_cuda_graph, model_runner.rs:303-326) */
+NVR_API int nvr_runner_replay_last_decode_graph(nvr_model_runner_t *r, int n);
 /* tensor-parallel wiring (the reference's TODO all-reduce/gather sites, linear.rs:236-238,
  * embed_head.rs:130-139,321-336): rank 0 creates the 128-byte RCCL id, the host broadcasts it. */
 NVR_API int nvr_comm_unique_id(uint8_t id_out[128]);

@@ -174,6 +174,7 @@ _SIGS = {
     "nvr_engine_generate": (C.c_int, [_P, _P, _P, C.c_size_t, _P, C.POINTER(_P), C.POINTER(C.c_size_t)]),
     "nvr_engine_generate_ids": (C.c_int, [_P, _P, _P, C.c_size_t, _P, C.POINTER(_P), C.POINTER(C.c_size_t)]),
     "nvr_engine_generate_stream": (C.c_int, [_P, _P, _P, C.c_size_t, _P, STREAM_FN, _P]),
+    "nvr_runner_replay_last_decode_graph": (C.c_int, [_P, C.c_int]),
     "nvr_local_group_create": (_P, [C.c_int]), "nvr_local_group_destroy": (None, [_P]),
     "nvr_runner_init_comm_local": (C.c_int, [_P, _P]),
     "nvr_engine_last_step": (None, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(C.c_size_t)]),

@@ -578,6 +578,7 @@ int nvr_model_runner::execute(nvr_seq *const *seqs, size_t nseq, bool is_prefill
             return forward_all(T, (int64_t)nseq, false, max_ctx, 1);
         }
         if (rc) return rc;
+        last_decode_graph = ge;
         NVR_HIP_CHECK(hipGraphLaunch(ge, stream));
         return NVR_OK;
     }
@@ -598,6 +599,19 @@ int nvr_model_runner::execute(nvr_seq *const *seqs, size_t nseq, bool is_prefill
         }
     }
     return NVR_OK;
+}
+
+// Diagnostic: the decode graph of the last step launched n more times back to back on the runner's stream, with no host round
+// trip in between (same inputs: the step is recomputed in place, K/V rows are rewritten with the same values).  Timing this
+// against n engine steps separates the GPU's launch chain from the host gap between steps.
+int nvr_model_runner::replay_last_decode_graph(int n) {
+    NVR_HIP_CHECK(hipSetDevice(device));
+    if (!last_decode_graph) return nvr::fail(NVR_ERR_INVALID_ARG, "replay_last_decode_graph: no captured decode step yet");
+    for (auto &kv : graphs) if (kv.second == (hipGraphExec_t)last_decode_graph) {
+        for (int i = 0; i < n; ++i) NVR_HIP_CHECK(hipGraphLaunch((hipGraphExec_t)last_decode_graph, stream));
+        return NVR_OK;
+    }
+    return nvr::fail(NVR_ERR_INVALID_ARG, "replay_last_decode_graph: the graph was evicted");
 }
 
 // all-reduce and all-gather of a known pattern on this runner's communicator (tests; collective over all ranks)

@@ -76,6 +76,8 @@ struct nvr_model_runner {
     // device weights (dtype 0 = f16, 1 = bf16, 2 = f32); copy_weight reads a local tensor back (tests)
     int load_tensor(const char *name, int dtype, const int64_t *shape, int ndim, const void *data);
     int copy_weight(const char *local_name, uint16_t *host_out, size_t cap, int64_t *rows, int64_t *cols);
+    void *last_decode_graph = nullptr;   // hipGraphExec_t of the last single-lane decode step
+    int replay_last_decode_graph(int n); // diagnostic: launch chain without the host gap (nvr_runner_replay_last_decode_graph)
     int ensure_logits();                                 // materialise the last step's f32 logits if it skipped their stores
     int sample(nvr_seq *const *seqs, size_t nseq, int64_t *out);
     uint16_t *k_cache(size_t l) { return kv_pool + (2 * l) * kv_layer_elems; }

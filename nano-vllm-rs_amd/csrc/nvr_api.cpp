@@ -217,6 +217,7 @@ int nvr_runner_kv_cache(nvr_model_runner_t *r, size_t layer, void **kd, void **v
 }
 void *nvr_runner_stream(nvr_model_runner_t *r) { return r->stream; }
 int nvr_comm_unique_id(uint8_t id_out[128]) { return nvr::Comm::unique_id(id_out); }
+int nvr_runner_replay_last_decode_graph(nvr_model_runner_t *r, int n) { NVR_GUARD_BEGIN return r->replay_last_decode_graph(n); NVR_GUARD_END(NVR_ERR_INVARIANT) }
 int nvr_runner_comm_selftest(nvr_model_runner_t *r) { NVR_GUARD_BEGIN return r->comm_selftest(); NVR_GUARD_END(NVR_ERR_INVARIANT) }
 int nvr_runner_init_comm(nvr_model_runner_t *r, const uint8_t id[128]) {
     NVR_HIP_CHECK(hipSetDevice(r->device));
