@@ -394,7 +394,8 @@ def test_sampler_filters_match_reference_kats():
     assert w[0].tolist() == oracle.top_k(x[0], 2).tolist()
 
 
-@pytest.mark.parametrize("V,reps,scale", [(1000, 1, 3.0), (151936, 1, 3.0), (151936, 1, 0.05), (20000, 1, 3.0), (50001, 4, 1.0), (4097, 6, 3.0)])
+@pytest.mark.parametrize("V,reps,scale", [(1000, 1, 3.0), (151936, 1, 3.0), (151936, 1, 0.05), (20000, 1, 3.0), (50001, 4, 1.0), (4097, 6, 3.0),
+                                          (151936, 4, 3.0), (151936, 8, 1.0)])   # 48 rows: 4 sharers x 38 elements per thread; 96 rows: one workgroup per row
 def test_sampler_matches_oracle(V, reps, scale):
     """Rows of every filter combination; reps tiles them to B = 12 * reps rows (1..8 workgroups share a row depending on B and V;
     scale 0.05 = the nearly flat rows of a random-init model, where top-p keeps most of the vocabulary)."""
