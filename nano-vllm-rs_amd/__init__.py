@@ -506,6 +506,30 @@ class Scheduler:
         return res
 
 
+def iter_safetensors(fn: str):
+    """(name, array) for every tensor of one .safetensors file, read straight from the file: 8-byte little-endian header
+    length, JSON header {name: {dtype, shape, data_offsets}}, raw little-endian payload.  F16 -> float16, F32 -> float32,
+    BF16 -> uint16 bit patterns (numpy has no bfloat16; load_tensor passes them down as dtype 1 and the device side
+    converts).  The safetensors package's numpy front end cannot return bf16 at all."""
+    import json
+    kinds = {"F16": (np.float16, 2), "BF16": (np.uint16, 2), "F32": (np.float32, 4)}
+    with open(fn, "rb") as f:
+        hlen = int.from_bytes(f.read(8), "little")
+        header = json.loads(f.read(hlen).decode("utf-8"))
+    data = np.memmap(fn, dtype=np.uint8, mode="r", offset=8 + hlen)
+    for name, meta in header.items():
+        if name == "__metadata__":
+            continue
+        if meta["dtype"] not in kinds:
+            raise NvrError(-10, f"safetensors: {name} has dtype {meta['dtype']} (F16, BF16 and F32 are supported)")
+        dt, isz = kinds[meta["dtype"]]
+        b, e = meta["data_offsets"]
+        n = int(np.prod(meta["shape"], dtype=np.int64)) if meta["shape"] else 1
+        if e - b != n * isz or e > data.size:
+            raise NvrError(-4, f"safetensors: {name}: {e - b} bytes for shape {meta['shape']} of {meta['dtype']}")
+        yield name, np.frombuffer(data, dtype=dt, count=n, offset=b).reshape(meta["shape"])
+
+
 class ModelRunner:
     """ModelRunner, reference src/engine/model_runner.rs:19-464."""
 
@@ -558,20 +582,24 @@ class ModelRunner:
         check(lib().nvr_runner_load_tensor(self.h, name.encode(), dt, shape, a.ndim, a.ctypes.data))
 
     def load_safetensors(self, path: str, strict: bool = False) -> List[str]:
-        """Every tensor of a .safetensors file (or of all such files in a directory).  Returns the names that are not part
-        of the reference's Qwen3 graph (q/k-norm, biases ...); strict=True raises on them instead."""
-        from safetensors import safe_open
+        """Every tensor of a .safetensors file (or of all such files in a directory); bf16 — the dtype of the published
+        Qwen3 checkpoints — goes down as its 16-bit patterns and is converted on load (iter_safetensors).  Returns the names
+        that are not part of the reference's Qwen3 graph (q/k-norm, biases ...) and warns about them (a real Qwen3
+        checkpoint then runs WITHOUT its attention norms, SURVEY A-17); strict=True raises instead."""
+        import warnings
         files = sorted(os.path.join(path, f) for f in os.listdir(path) if f.endswith(".safetensors")) if os.path.isdir(path) else [path]
         skipped = []
         for fn in files:
-            with safe_open(fn, framework="np") as f:
-                for name in f.keys():
-                    try:
-                        self.load_tensor(name, f.get_tensor(name))
-                    except NvrError as e:
-                        if e.code != -10 or strict:
-                            raise
-                        skipped.append(name)
+            for name, arr in iter_safetensors(fn):
+                try:
+                    self.load_tensor(name, arr)
+                except NvrError as ex:
+                    if ex.code != -10 or strict:
+                        raise
+                    skipped.append(name)
+        if skipped:
+            warnings.warn(f"load_safetensors: {len(skipped)} tensors are outside the reference's Qwen3 graph and were NOT loaded "
+                          f"(e.g. {skipped[0]}): q/k-norm and biases are not applied (SURVEY A-17)", RuntimeWarning, stacklevel=2)
         return skipped
 
     def weight(self, local_name: str) -> np.ndarray:

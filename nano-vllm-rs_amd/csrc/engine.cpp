@@ -27,12 +27,15 @@ int nvr_engine::step(nvr_step_info *info) {                          // LLMEngin
     int rc = scheduler->impl.schedule(batch, &is_prefill);           // :160-166
     if (rc) return rc;
     const double t1 = g_trace.on ? now_us() : 0;
+    // A model step that fails after schedule() has allocated blocks and moved the batch to running must not wedge the engine
+    // (every later step would schedule the same sequences into the same failure): the batch is aborted — blocks returned,
+    // sequences parked as finished — and the error is reported once.
     rc = runner->execute(batch.data(), batch.size(), is_prefill);    // :176-179
-    if (rc) return rc;
+    if (rc) { scheduler->impl.abort_batch(batch.data(), batch.size()); return rc; }
     const double t2 = g_trace.on ? now_us() : 0;
     last_tokens.resize(batch.size());
     rc = runner->sample(batch.data(), batch.size(), last_tokens.data());   // :182-185
-    if (rc) return rc;
+    if (rc) { scheduler->impl.abort_batch(batch.data(), batch.size()); return rc; }
     const double t3 = g_trace.on ? now_us() : 0;
     last_ids.resize(batch.size());
     for (size_t i = 0; i < batch.size(); ++i) last_ids[i] = batch[i]->seq_id;
@@ -105,8 +108,17 @@ int nvr_engine::add_ids(const int64_t *prompt, size_t n, const nvr_sampling_para
     for (size_t i = 0; i < n; ++i)                                        // a request the model cannot embed is refused here,
         if ((uint64_t)prompt[i] >= (uint64_t)runner->V)                   // not when its batch reaches execute_model
             return nvr::fail(NVR_ERR_INVALID_ARG, "token id %ld at position %zu is outside the vocabulary [0, %ld)", (long)prompt[i], i, (long)runner->V);
+    // Admission (SURVEY A-24; the reference holds max_model_len, config.rs:27, and never checks it): a prompt the runner can
+    // never execute — longer than max_model_len (RoPE table, block-table width) or than one prefill batch — is refused here,
+    // and max_tokens is clamped so that the sequence's last decode step still fits max_model_len.
+    if ((int64_t)n > runner->max_pos)
+        return nvr::fail(NVR_ERR_INVALID_ARG, "prompt of %zu tokens exceeds max_model_len %ld", n, (long)runner->max_pos);
+    if ((int64_t)n > runner->max_tokens)
+        return nvr::fail(NVR_ERR_INVALID_ARG, "prompt of %zu tokens exceeds max_num_batched_tokens %ld", n, (long)runner->max_tokens);
     nvr_seq *s = nvr_seq_create(prompt, n, sp, cfg.kvcache_block_size);
     if (!s) return NVR_ERR_INVARIANT;
+    const uint64_t room = (uint64_t)(runner->max_pos - (int64_t)n) + 1;       // decode step c feeds position n + c - 1 < max_pos
+    if (s->sampling.max_tokens > room) s->sampling.max_tokens = room;
     scheduler->impl.add_sequence(s);
     if (id_out) *id_out = s->seq_id;
     return NVR_OK;
@@ -133,6 +145,9 @@ int nvr_engine::generate(const std::vector<std::vector<int64_t>> &prompts, const
     if (sp) { int rc = nvr_sampling_params_validate(sp); if (rc) return rc; }
     for (size_t i = 0; i < prompts.size(); ++i) {
         if (prompts[i].empty()) return nvr::fail(NVR_ERR_INVALID_ARG, "generate: prompt %zu is empty", i);
+        if ((int64_t)prompts[i].size() > runner->max_pos || (int64_t)prompts[i].size() > runner->max_tokens)
+            return nvr::fail(NVR_ERR_INVALID_ARG, "generate: prompt %zu has %zu tokens (max_model_len %ld, max_num_batched_tokens %ld)", i,
+                             prompts[i].size(), (long)runner->max_pos, (long)runner->max_tokens);
         for (int64_t t : prompts[i])
             if ((uint64_t)t >= (uint64_t)runner->V)
                 return nvr::fail(NVR_ERR_INVALID_ARG, "generate: prompt %zu holds token id %ld outside the vocabulary [0, %ld)", i, (long)t, (long)runner->V);

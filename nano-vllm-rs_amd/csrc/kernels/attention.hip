@@ -380,6 +380,9 @@ static int launch_attn(const AttnArgs &a, bool paged, hipStream_t s) {
         } else np = parts_for(a.nq, a.KVH, mc, waves, &part_size);
     }
     const bool direct = np <= 1;
+    if (!direct && a.workspace_bytes && (size_t)a.nq * a.H * np * (D + 2) * sizeof(float) > a.workspace_bytes)
+        return nvr::fail(NVR_ERR_INVALID_ARG, "attention: %d partitions of %d queries x %d heads need %zu workspace bytes, %zu given",
+                         np, a.nq, a.H, (size_t)a.nq * a.H * np * (D + 2) * sizeof(float), a.workspace_bytes);
     if (direct) { p.part_size = 0x3fffffff; p.num_parts = 1; }
     else {
         p.part_size = part_size; p.num_parts = np;

@@ -116,6 +116,7 @@ struct AttnArgs {
     int32_t max_ctx;                           // upper bound of ctx_lens (grid sizing)
     half_bits *out;                            // [nq, H, D] fp16
     void *workspace;                           // split-KV partials (paged decode)
+    size_t workspace_bytes;                    // size of `workspace` (0 = not checked)
 };
 size_t attn_workspace_bytes(int64_t nq, int64_t H, int64_t D, int64_t max_ctx);
 int attention(const AttnArgs &a, bool paged, hipStream_t s);

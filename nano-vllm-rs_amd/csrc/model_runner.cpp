@@ -102,6 +102,7 @@ int nvr_model_runner::init() {                                       // ModelRun
     RC(dmalloc(&slabs, 4 * slab_rows * Hd));
     // measured slower than two launches (profiles/r01_fused_slabnorm_ablation.txt): opt-in only
     { const char *e = getenv("NVR_FUSED_SLABNORM"); fused_slabnorm = e && e[0] == '1'; }
+    { const char *e = getenv("NVR_TP_NO_COMM"); allow_missing_comm = e && e[0] == '1'; }   // compute-only profiling of one rank
     RC(k::linear_stream_prepare());
     RC(k::gemm_tiled_prepare());
     { const char *e = getenv("NVR_LM_FUSED"); lm_fused = !(e && e[0] == '0'); }
@@ -110,7 +111,9 @@ int nvr_model_runner::init() {                                       // ModelRun
         const size_t pe = std::max<size_t>((size_t)k::LM_HEAD_MAX_PARTS * 32, (size_t)((Vl + 127) / 128) * (size_t)max_seqs);
         RC(dmalloc(&d_lm_pval, pe)); RC(dmalloc(&d_lm_pidx, pe));
     }
-    attn_ws_bytes = k::attn_workspace_bytes(max_seqs, H, D, max_pos);
+    // the hipGraph decode path launches attention with max_ctx = the 256-token context bucket, which can exceed max_pos:
+    // the split-KV workspace is sized for the largest bucket (launch_attn checks the bytes it is given)
+    attn_ws_bytes = k::attn_workspace_bytes(max_seqs, H, D, (max_pos + 255) / 256 * 256);
     NVR_HIP_CHECK(hipMalloc(&attn_ws, attn_ws_bytes));
     {
         int nl = (int)cfg.decode_microbatches; if (nl < 1) nl = 1; if (nl > 4) nl = 4;
@@ -387,7 +390,7 @@ int nvr_model_runner::forward(Lane &ln, int64_t row0, int64_t T, int64_t B, bool
             RC(k::attention(a, false, st));
         } else {                                                     // flash_attention_decode, attention.rs:225-235
             a.k = k_cache(l); a.v = v_cache(l); a.block_tables = bt; a.max_blocks = (int32_t)max_blocks_per_seq;
-            a.block_size = (int32_t)block_size; a.workspace = ln.attn_ws;
+            a.block_size = (int32_t)block_size; a.workspace = ln.attn_ws; a.workspace_bytes = attn_ws_bytes;
             RC(k::attention(a, true, st));
         }
         RC(row_parallel_norm(ln, ln.attn, H * D, w.o, T, w.ln2));                            // o_proj, residual :382, norm :385
@@ -429,6 +432,9 @@ int nvr_model_runner::forward_all(int64_t T, int64_t B, bool is_prefill, int64_t
 // execute_model :105-128 with prepare_*_inputs :172-210 and create_*_context :222-300
 int nvr_model_runner::execute(nvr_seq *const *seqs, size_t nseq, bool is_prefill) {
     NVR_HIP_CHECK(hipSetDevice(device));
+    if (tp > 1 && !comm.active() && !allow_missing_comm)
+        return nvr::fail(NVR_ERR_RCCL, "execute_model: tensor_parallel_size %ld but no communicator is attached (nvr_runner_init_comm / "
+                         "nvr_local_group_attach); partial sums would be returned as results", (long)tp);
     if (nseq == 0) return nvr::fail(NVR_ERR_INVALID_ARG, "execute_model: empty batch");
     if ((int64_t)nseq > max_seqs) return nvr::fail(NVR_ERR_INVALID_ARG, "execute_model: %zu sequences > max_num_seqs %ld", nseq, (long)max_seqs);
     char *hd = in_host + off_dec;
@@ -705,8 +711,8 @@ int nvr_model_runner::sample(nvr_seq *const *seqs, size_t nseq, int64_t *out) {
             RC(k::concat_vocab_shards(d_gather_logits, tp, B, Vl, d_full_logits, stream));
             lg = d_full_logits; Vs = V; ws = sample_ws_full;
         }
-        float *t = (float *)samp_host; int64_t *tk = (int64_t *)(samp_host + max_seqs * 4);
-        float *tpv = (float *)(samp_host + max_seqs * 12); uint64_t *ky = (uint64_t *)(samp_host + max_seqs * 16);
+        int64_t *tk = (int64_t *)samp_host; uint64_t *ky = (uint64_t *)(samp_host + max_seqs * 8);      // 8-byte arrays first
+        float *t = (float *)(samp_host + max_seqs * 16), *tpv = (float *)(samp_host + max_seqs * 20);
         for (size_t i = 0; i < nseq; ++i) {
             const nvr_sampling_params &sp = seqs[i]->sampling;
             t[i] = sp.temperature;

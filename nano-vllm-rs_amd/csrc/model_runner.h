@@ -48,6 +48,7 @@ struct nvr_model_runner {
     int64_t *d_tok = nullptr, *h_tok = nullptr; float *d_maxval = nullptr;
     float *d_temp = nullptr; int64_t *d_topk = nullptr; float *d_topp = nullptr; uint64_t *d_keys = nullptr;
     char *samp_host = nullptr; void *sample_ws = nullptr;
+    bool allow_missing_comm = false;                    // NVR_TP_NO_COMM=1: one rank's compute without its collectives (profiling only)
     // TP exchange buffers for the greedy (max, idx) merge
     float *d_gather_val = nullptr; int64_t *d_gather_idx = nullptr;
     float *d_gather_logits = nullptr, *d_full_logits = nullptr; void *sample_ws_full = nullptr;   // stochastic sampling under TP (lazy)

@@ -154,9 +154,12 @@ int nvr_sched_schedule(nvr_scheduler_t *sc, nvr_seq_t **out, size_t cap, size_t 
     NVR_GUARD_BEGIN
     static thread_local std::vector<nvr_seq *> tmp;
     bool pf = false;
+    // checked BEFORE scheduling: schedule() allocates blocks and moves sequences to running, a batch that does not fit the
+    // caller's array afterwards would be lost to it
+    if (cap < sc->impl.max_num_seqs())
+        return nvr::fail(NVR_ERR_INVALID_ARG, "schedule: output capacity %zu < max_num_seqs %zu", cap, sc->impl.max_num_seqs());
     int rc = sc->impl.schedule(tmp, &pf);
     if (rc) return rc;
-    if (tmp.size() > cap) return nvr::fail(NVR_ERR_INVALID_ARG, "schedule: output capacity %zu < batch %zu", cap, tmp.size());
     std::memcpy(out, tmp.data(), tmp.size() * sizeof(nvr_seq *));
     *n = tmp.size(); *is_prefill = pf ? 1 : 0;
     return NVR_OK;

@@ -127,6 +127,19 @@ int Scheduler::postprocess(nvr_seq *const *seqs, const int64_t *token_ids, size_
     return NVR_OK;
 }
 
+void Scheduler::abort_batch(nvr_seq *const *seqs, size_t n) {
+    for (size_t i = 0; i < n; ++i) {
+        nvr_seq *s = seqs[i];
+        auto it = std::find(running_.begin(), running_.end(), s);
+        if (it != running_.end()) running_.erase(it);
+        if (!s->block_table.empty()) (void)bm_->impl.deallocate(*s);
+        s->status = NVR_SEQ_FINISHED;
+        finished_.push_back(s);
+        stats_.finished_sequences += 1;
+    }
+    update_stats();
+}
+
 void Scheduler::preempt_all() {                                      // :314-319
     std::vector<nvr_seq *> seqs(running_.begin(), running_.end());
     running_.clear();

@@ -21,10 +21,14 @@ public:
     int schedule(std::vector<nvr_seq *> &out, bool *is_prefill);                        // :103
     int postprocess(nvr_seq *const *seqs, const int64_t *token_ids, size_t n);          // :234
     void preempt_all();                                                                 // :314
+    // a batch whose model step failed: its sequences leave the queues with their blocks returned (status FINISHED,
+    // parked with the finished ones) so that the next schedule() does not run into the same failure again
+    void abort_batch(nvr_seq *const *seqs, size_t n);
     const nvr_sched_stats &stats() const { return stats_; }
     BlockManager &block_manager() { return bm_->impl; }
     const BlockManager &block_manager() const { return bm_->impl; }
     nvr_block_manager *block_manager_handle() { return bm_.get(); }
+    size_t max_num_seqs() const { return max_num_seqs_; }
     size_t waiting_len() const { return waiting_.size(); }
     size_t running_len() const { return running_.size(); }
     double memory_pressure() const;                                                     // :322

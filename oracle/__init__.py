@@ -59,6 +59,7 @@ def _declare(l: C.CDLL) -> None:
     l.nvo_round_f16.restype = C.c_float
     l.nvo_round_f16.argtypes = [C.c_float]
     l.nvo_round_f16_array.argtypes = [_f32p, C.c_size_t]
+    l.nvo_round_f16_copy.argtypes = [_f32p, _f32p, C.c_size_t]
     l.nvo_f32_to_f16.argtypes = [_f32p, _u16p, C.c_size_t]
     l.nvo_f16_to_f32.argtypes = [_u16p, _f32p, C.c_size_t]
     l.nvo_num_threads.restype = C.c_int
@@ -122,9 +123,10 @@ def f32(a) -> np.ndarray:
 
 # ---- thin numpy wrappers ---------------------------------------------------
 def round_f16(a: np.ndarray) -> np.ndarray:
-    a = f32(a).copy()
-    lib().nvo_round_f16_array(_f(a), a.size)
-    return a
+    a = f32(a)
+    out = np.empty_like(a)
+    lib().nvo_round_f16_copy(_f(a), _f(out), a.size)
+    return out
 
 
 def to_f16_bits(a: np.ndarray) -> np.ndarray:

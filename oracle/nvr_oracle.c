@@ -48,10 +48,14 @@ static inline float f16_bits_to_f32(uint16_t h) { return _cvtsh_ss(h); }
 
 NVO_API float nvo_round_f16(float x) { return f16_bits_to_f32(f32_to_f16_bits(x)); }
 
-NVO_API void nvo_round_f16_array(float *x, size_t n) {
+NVO_API void nvo_round_f16_copy(const float *x, float *y, size_t n) {     /* y = f32(f16_rne(x)); x == y allowed */
+    const size_t n8 = n / 8;
 #pragma omp parallel for schedule(static) if (n > 65536)
-    for (size_t i = 0; i < n; ++i) x[i] = f16_bits_to_f32(f32_to_f16_bits(x[i]));
+    for (size_t i = 0; i < n8; ++i)
+        _mm256_storeu_ps(y + i * 8, _mm256_cvtph_ps(_mm256_cvtps_ph(_mm256_loadu_ps(x + i * 8), _MM_FROUND_TO_NEAREST_INT | _MM_FROUND_NO_EXC)));
+    for (size_t i = n8 * 8; i < n; ++i) y[i] = f16_bits_to_f32(f32_to_f16_bits(x[i]));
 }
+NVO_API void nvo_round_f16_array(float *x, size_t n) { nvo_round_f16_copy(x, x, n); }
 NVO_API void nvo_f32_to_f16(const float *x, uint16_t *y, size_t n) {
 #pragma omp parallel for schedule(static) if (n > 65536)
     for (size_t i = 0; i < n; ++i) y[i] = f32_to_f16_bits(x[i]);
@@ -240,36 +244,56 @@ static inline float dot_f32(const float *a, const float *b, int64_t K) {
 }
 NVO_API void nvo_linear(const float *x, const float *W, const float *bias,
                         int64_t T, int64_t K, int64_t N, float *y) {
-    /* 4 rows of W x 4 rows of x register block keeps W traffic at 1/4 for T>1. */
-    const int64_t TB = 4;
+    /* Every output is one 8-lane fmadd chain over k (in k order) followed by a fixed reduction tree, whatever
+     * the blocking: 4 rows of x x 2 rows of W per register block; (t, n) blocks sized so that a block of x rows
+     * stays in the core's L2 while the W rows of the block stream past it (BASELINE-size prefills, T = 32768). */
+    if (T < 4) {
 #pragma omp parallel for schedule(static)
-    for (int64_t n = 0; n < N; ++n) {
-        const float *w = W + n * K;
-        float b = bias ? bias[n] : 0.0f;
-        int64_t t = 0;
-        for (; t + TB <= T; t += TB) {
-            __m256 a0 = _mm256_setzero_ps(), a1 = a0, a2 = a0, a3 = a0;
-            const float *x0 = x + t * K, *x1 = x0 + K, *x2 = x1 + K, *x3 = x2 + K;
-            int64_t k = 0;
-            for (; k + 8 <= K; k += 8) {
-                __m256 wv = _mm256_loadu_ps(w + k);
-                a0 = _mm256_fmadd_ps(_mm256_loadu_ps(x0 + k), wv, a0);
-                a1 = _mm256_fmadd_ps(_mm256_loadu_ps(x1 + k), wv, a1);
-                a2 = _mm256_fmadd_ps(_mm256_loadu_ps(x2 + k), wv, a2);
-                a3 = _mm256_fmadd_ps(_mm256_loadu_ps(x3 + k), wv, a3);
+        for (int64_t n = 0; n < N; ++n)
+            for (int64_t t = 0; t < T; ++t) y[t * N + n] = dot_f32(x + t * K, W + n * K, K) + (bias ? bias[n] : 0.0f);
+        return;
+    }
+    int64_t TBLK = (256 * 1024) / (K * 4); TBLK = TBLK < 4 ? 4 : TBLK / 4 * 4;
+    const int64_t NBLK = 32;
+    const int64_t ntb = (T + TBLK - 1) / TBLK, nnb = (N + NBLK - 1) / NBLK;
+#pragma omp parallel for schedule(dynamic, 1) collapse(2)
+    for (int64_t tb = 0; tb < ntb; ++tb)
+      for (int64_t nb = 0; nb < nnb; ++nb) {
+        const int64_t t_end = (tb + 1) * TBLK < T ? (tb + 1) * TBLK : T, n_end = (nb + 1) * NBLK < N ? (nb + 1) * NBLK : N;
+        for (int64_t n = nb * NBLK; n < n_end; n += 2) {
+            const int two = n + 1 < n_end;
+            const float *w0 = W + n * K, *w1 = two ? w0 + K : w0;
+            const float b0 = bias ? bias[n] : 0.0f, b1 = (bias && two) ? bias[n + 1] : 0.0f;
+            int64_t t = tb * TBLK;
+            for (; t + 4 <= t_end; t += 4) {
+                __m256 a0 = _mm256_setzero_ps(), a1 = a0, a2 = a0, a3 = a0, c0 = a0, c1 = a0, c2 = a0, c3 = a0;
+                const float *x0 = x + t * K, *x1 = x0 + K, *x2 = x1 + K, *x3 = x2 + K;
+                int64_t k = 0;
+                for (; k + 8 <= K; k += 8) {
+                    const __m256 wv = _mm256_loadu_ps(w0 + k), wu = _mm256_loadu_ps(w1 + k);
+                    const __m256 v0 = _mm256_loadu_ps(x0 + k), v1 = _mm256_loadu_ps(x1 + k);
+                    const __m256 v2 = _mm256_loadu_ps(x2 + k), v3 = _mm256_loadu_ps(x3 + k);
+                    a0 = _mm256_fmadd_ps(v0, wv, a0); a1 = _mm256_fmadd_ps(v1, wv, a1);
+                    a2 = _mm256_fmadd_ps(v2, wv, a2); a3 = _mm256_fmadd_ps(v3, wv, a3);
+                    c0 = _mm256_fmadd_ps(v0, wu, c0); c1 = _mm256_fmadd_ps(v1, wu, c1);
+                    c2 = _mm256_fmadd_ps(v2, wu, c2); c3 = _mm256_fmadd_ps(v3, wu, c3);
+                }
+                float r[8][8];
+                _mm256_storeu_ps(r[0], a0); _mm256_storeu_ps(r[1], a1); _mm256_storeu_ps(r[2], a2); _mm256_storeu_ps(r[3], a3);
+                _mm256_storeu_ps(r[4], c0); _mm256_storeu_ps(r[5], c1); _mm256_storeu_ps(r[6], c2); _mm256_storeu_ps(r[7], c3);
+                for (int i = 0; i < (two ? 8 : 4); ++i) {
+                    float s = ((r[i][0] + r[i][4]) + (r[i][1] + r[i][5])) + ((r[i][2] + r[i][6]) + (r[i][3] + r[i][7]));
+                    const float *xi = x + (t + (i & 3)) * K, *w = i < 4 ? w0 : w1;
+                    for (int64_t kk = k; kk < K; ++kk) s += xi[kk] * w[kk];
+                    y[(t + (i & 3)) * N + n + (i >> 2)] = s + (i < 4 ? b0 : b1);
+                }
             }
-            float r[4][8];
-            _mm256_storeu_ps(r[0], a0); _mm256_storeu_ps(r[1], a1);
-            _mm256_storeu_ps(r[2], a2); _mm256_storeu_ps(r[3], a3);
-            for (int i = 0; i < 4; ++i) {
-                float s = ((r[i][0] + r[i][4]) + (r[i][1] + r[i][5])) + ((r[i][2] + r[i][6]) + (r[i][3] + r[i][7]));
-                const float *xi = x + (t + i) * K;
-                for (int64_t kk = k; kk < K; ++kk) s += xi[kk] * w[kk];
-                y[(t + i) * N + n] = s + b;
+            for (; t < t_end; ++t) {
+                y[t * N + n] = dot_f32(x + t * K, w0, K) + b0;
+                if (two) y[t * N + n + 1] = dot_f32(x + t * K, w1, K) + b1;
             }
         }
-        for (; t < T; ++t) y[t * N + n] = dot_f32(x + t * K, w, K) + b;
-    }
+      }
 }
 
 /* ------------------------------------------------------------------------- */
@@ -340,6 +364,29 @@ static void attn_row(const float *q, int64_t D, float scale, int64_t nkeys,
     double l = 0.0;
     for (int64_t j = 0; j < nkeys; ++j) { float e = expf(scores[j] - m); scores[j] = e; l += e; }
     float inv = (float)(1.0 / l);
+    if (D % 64 == 0) {
+        /* same arithmetic per element as the scalar loop below (out[d] = out[d] + p*vr[d], one f32 multiply and
+         * one f32 add, keys in order), 64 output columns at a time held in registers */
+        for (int64_t d0 = 0; d0 < D; d0 += 64) {
+            __m256 a0 = _mm256_setzero_ps(), a1 = a0, a2 = a0, a3 = a0, a4 = a0, a5 = a0, a6 = a0, a7 = a0;
+            for (int64_t j = 0; j < nkeys; ++j) {
+                const __m256 p = _mm256_set1_ps(scores[j] * inv);
+                const float *vr = vbase + row_off[j] + d0;
+                a0 = _mm256_add_ps(a0, _mm256_mul_ps(p, _mm256_loadu_ps(vr)));
+                a1 = _mm256_add_ps(a1, _mm256_mul_ps(p, _mm256_loadu_ps(vr + 8)));
+                a2 = _mm256_add_ps(a2, _mm256_mul_ps(p, _mm256_loadu_ps(vr + 16)));
+                a3 = _mm256_add_ps(a3, _mm256_mul_ps(p, _mm256_loadu_ps(vr + 24)));
+                a4 = _mm256_add_ps(a4, _mm256_mul_ps(p, _mm256_loadu_ps(vr + 32)));
+                a5 = _mm256_add_ps(a5, _mm256_mul_ps(p, _mm256_loadu_ps(vr + 40)));
+                a6 = _mm256_add_ps(a6, _mm256_mul_ps(p, _mm256_loadu_ps(vr + 48)));
+                a7 = _mm256_add_ps(a7, _mm256_mul_ps(p, _mm256_loadu_ps(vr + 56)));
+            }
+            _mm256_storeu_ps(out + d0, a0); _mm256_storeu_ps(out + d0 + 8, a1); _mm256_storeu_ps(out + d0 + 16, a2);
+            _mm256_storeu_ps(out + d0 + 24, a3); _mm256_storeu_ps(out + d0 + 32, a4); _mm256_storeu_ps(out + d0 + 40, a5);
+            _mm256_storeu_ps(out + d0 + 48, a6); _mm256_storeu_ps(out + d0 + 56, a7);
+        }
+        return;
+    }
     for (int64_t d = 0; d < D; ++d) out[d] = 0.0f;
     for (int64_t j = 0; j < nkeys; ++j) {
         float p = scores[j] * inv;

@@ -1,0 +1,132 @@
+"""Oracle parity ON the BASELINE.json workloads themselves (-m gpu).
+
+Each test runs the product (C++ engine + HIP kernels, through the C ABI) and the CPU oracle on the SAME full-size
+Qwen3-0.6B synthetic model and the same seeded prompts (token ids uniform in [0, V), seed 1, one stream per
+sequence) and compares, per step: batch composition and block tables (bit-exact), f32 logits of every row
+(|d| < LOGIT_TOL), greedy token ids (equal wherever the oracle's top-1/top-2 margin exceeds 2*LOGIT_TOL; every smaller
+margin is a numerical tie between two fp16 pipelines, COUNTED, bounded by the assertion and written to the report).
+The oracle is teacher-forced with the product's tokens so a tie cannot cascade.
+
+  configs[0]  bs 1, 128-token prompt, 64 greedy steps       vs the fp16-faithful oracle AND vs the f32 "CPU path" oracle
+  configs[1]  bs 32 x 1024-token prompts, prefill + 4 decode steps (hipGraph decode, 8-wave attention, V = 151 936 head)
+  configs[2]  one 32 768-token prefill batch mixing 4 x 4096 ... 16 x 128 (42 sequences, the reference's token budget,
+              config.rs:58) + one decode step
+A JSON summary of what was measured lands in gpurun_out/parity_r02.json (copied to profiles/ by hand)."""
+import json
+import os
+import time
+
+import numpy as np
+import pytest
+
+import nvr_import
+import oracle
+from oracle import engine_oracle as eo
+from oracle import model_oracle as mo
+
+nvr = nvr_import.load()
+pytestmark = pytest.mark.gpu
+
+LOGIT_TOL = 2e-2            # product fp16 pipeline vs fp16-faithful oracle (f32 logits, fp16 activations)
+CPU_PATH_TOL = 8e-2         # product fp16 pipeline vs the reference's f32 CPU path (weights and activations unrounded)
+V = 151936
+
+
+def _report(name, rec):
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        path = os.path.join(out, "parity_r02.json")
+        cur = json.load(open(path)) if os.path.exists(path) else {}
+        cur[name] = rec
+        json.dump(cur, open(path, "w"), indent=1, sort_keys=True)
+    except OSError:
+        pass
+    print(f"[parity] {name}: {json.dumps(rec)}")
+
+
+def _pair(ecfg, prompts, max_tokens, fp16=True, tol=LOGIT_TOL, **kw):
+    eo.reset_sequence_counter(); nvr.lib().nvr_seq_reset_id_counter()
+    mcfg = mo.qwen3_0_6b()
+    t0 = time.time()
+    o = mo.OracleEngine(mcfg, eo.Config(**ecfg), fp16=fp16, max_pos=ecfg["max_model_len"])
+    p = nvr.LLMEngine(nvr.Config(**ecfg, **kw), nvr.ModelConfig("qwen3-0.6b"))
+    t_build = time.time() - t0
+    for pr in prompts:
+        sp = dict(temperature=0.0, max_tokens=max_tokens, ignore_eos=True)
+        o.add_request(pr, eo.SamplingParams(**sp)); p.add_request(pr, nvr.SamplingParams(**sp))
+    st = dict(steps=0, prefill_steps=0, rows=0, near_ties=0, id_mismatch_outside_ties=0, max_abs_logit_err=0.0,
+              min_margin=float("inf"), oracle_s=0.0, build_s=round(t_build, 1))
+    while not p.is_finished():
+        rec = p.step()
+        logits = p.model_runner.logits(rec["num_seqs"])
+        t0 = time.time()
+        orec = o.step(forced_tokens=rec["tokens"])
+        st["oracle_s"] += time.time() - t0
+        assert orec["seq_ids"] == rec["seq_ids"] and orec["is_prefill"] == rec["is_prefill"], f"step {st['steps']}: batch differs"
+        for ot, ps in zip(orec["block_tables"], p.last_batch()):          # a finished sequence has been deallocated (empty table)
+            pt = list(ps.block_table)
+            assert not pt or pt == ot, f"step {st['steps']}: block tables differ"
+        err = float(np.abs(logits - orec["logits"]).max())
+        st["max_abs_logit_err"] = max(st["max_abs_logit_err"], err)
+        assert err < tol, f"step {st['steps']}: logits differ from the oracle by {err}"
+        srt = np.sort(orec["logits"], axis=1)
+        margin = srt[:, -1] - srt[:, -2]
+        st["min_margin"] = min(st["min_margin"], float(margin.min()))
+        for i, (a, b) in enumerate(zip(rec["tokens"], orec["tokens"])):
+            if a != b:
+                if margin[i] <= 2 * tol:
+                    st["near_ties"] += 1
+                else:
+                    st["id_mismatch_outside_ties"] += 1
+        st["steps"] += 1; st["prefill_steps"] += int(rec["is_prefill"]); st["rows"] += rec["num_seqs"]
+    st["oracle_s"] = round(st["oracle_s"], 1)
+    st["tol"] = tol
+    assert st["id_mismatch_outside_ties"] == 0, st
+    return st, o, p
+
+
+def test_configs0_bs1_prompt128_greedy64_vs_oracle():
+    """BASELINE configs[0] on the HIP path: one sequence, 128 prompt tokens, 64 greedy tokens, against the fp16-faithful
+    oracle (tight) and against the f32 CPU-path oracle (the reference's device="cpu" arithmetic; looser: the weights
+    themselves differ by fp16 rounding)."""
+    ecfg = dict(max_num_seqs=1, max_num_batched_tokens=256, max_model_len=256, kvcache_block_size=256, num_kvcache_blocks=2)
+    prompt = [nvr.synthetic_tokens(128, 1, 0, V).tolist()]
+    st, o, p = _pair(ecfg, prompt, 64)
+    assert st["steps"] == 64 and st["prefill_steps"] == 1
+    assert st["near_ties"] <= 1, st
+    ids_fp16 = list(next(iter(o.finished.values())).token_ids)
+    _report("configs0_vs_fp16_oracle", st)
+    del o, p
+    st32, o32, p32 = _pair(ecfg, prompt, 64, fp16=False, tol=CPU_PATH_TOL)
+    assert st32["steps"] == 64
+    assert st32["near_ties"] <= 2, st32
+    _report("configs0_vs_f32_cpu_path_oracle", st32)
+    # same product both times: the two runs' token streams are the same stream
+    assert list(next(iter(o32.finished.values())).token_ids) == ids_fp16
+
+
+def test_configs1_bs32_seq1024_full_size_vs_oracle():
+    """BASELINE configs[1] at full size: 32 x 1024-token prompts through the 256^2 MFMA GEMMs and the flash prefill kernel
+    over 28 layers, then 4 hipGraph decode steps at context ~1025 (8-wave paged attention, skinny GEMMs, fused LM head)."""
+    ecfg = dict(max_num_seqs=32, max_num_batched_tokens=32768, max_model_len=1040, kvcache_block_size=256, num_kvcache_blocks=170)
+    prompts = [nvr.synthetic_tokens(1024, 1, i, V).tolist() for i in range(32)]
+    st, o, p = _pair(ecfg, prompts, 5)
+    assert st["steps"] == 5 and st["prefill_steps"] == 1 and st["rows"] == 160
+    assert st["near_ties"] <= 2, st
+    _report("configs1_bs32_seq1024", st)
+
+
+def test_configs2_mixed_length_32768_token_prefill_vs_oracle():
+    """BASELINE configs[2]: the prefill sweep's lengths in ONE budget-bound batch — 4 x 4096, 2 x 2048, 4 x 1024, 8 x 512,
+    8 x 256, 16 x 128 = 32 768 tokens = max_num_batched_tokens (config.rs:58), 42 sequences — last-token logits of every
+    sequence against the oracle, then one decode step over the 42 ragged contexts."""
+    lens = [4096] * 4 + [2048] * 2 + [1024] * 4 + [512] * 8 + [256] * 8 + [128] * 16
+    assert sum(lens) == 32768
+    nblk = sum((n + 1 + 255) // 256 for n in lens) + 2
+    ecfg = dict(max_num_seqs=64, max_num_batched_tokens=32768, max_model_len=4100, kvcache_block_size=256, num_kvcache_blocks=nblk)
+    prompts = [nvr.synthetic_tokens(n, 1, i, V).tolist() for i, n in enumerate(lens)]
+    st, o, p = _pair(ecfg, prompts, 2)
+    assert st["steps"] == 2 and st["prefill_steps"] == 1 and st["rows"] == 84
+    assert st["near_ties"] <= 2, st
+    _report("configs2_mixed_32768", st)

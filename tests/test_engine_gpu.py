@@ -247,6 +247,40 @@ def test_checkpoint_shards_dtypes_and_errors():
     assert e.value.code == -7
 
 
+def test_checkpoint_bf16_safetensors_file(tmp_path):
+    """a BF16 .safetensors file (the dtype of the published Qwen3 checkpoints) loads through load_safetensors
+    (bits -> f32 -> fp16 RNE on the way in); a tensor outside the reference graph (q_norm) is reported AND warned about."""
+    import json
+    import warnings
+    mcfg = mo.small(seed=3)
+    rng = np.random.default_rng(79)
+    Hd, I = mcfg.hidden_size, mcfg.intermediate_size
+    tens = {"model.layers.0.mlp.down_proj.weight": (rng.standard_normal((Hd, I)) * 0.05).astype(np.float32),
+            "model.norm.weight": (1 + 0.2 * rng.standard_normal(Hd)).astype(np.float32),
+            "model.layers.0.self_attn.q_norm.weight": np.ones(mcfg.hd(), np.float32)}
+    header, blobs, off = {}, [], 0
+    for name, a in tens.items():
+        raw = (a.view(np.uint32) >> 16).astype(np.uint16).tobytes()
+        header[name] = dict(dtype="BF16", shape=list(a.shape), data_offsets=[off, off + len(raw)])
+        blobs.append(raw); off += len(raw)
+    hj = json.dumps(header).encode(); hj += b" " * (-len(hj) % 8)
+    path = str(tmp_path / "bf16.safetensors")
+    with open(path, "wb") as f:
+        f.write(len(hj).to_bytes(8, "little")); f.write(hj); f.write(b"".join(blobs))
+    mr = nvr.ModelRunner(nvr.Config(skip_block_size_check=1, max_num_seqs=2, max_num_batched_tokens=64, max_model_len=64, kvcache_block_size=16,
+                                    num_kvcache_blocks=4), _model_cfgs(mcfg))
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        skipped = mr.load_safetensors(path)
+    assert skipped == ["model.layers.0.self_attn.q_norm.weight"] and any("q/k-norm" in str(x.message) for x in w)
+    for local, name in [("layers.0.down", "model.layers.0.mlp.down_proj.weight"), ("norm", "model.norm.weight")]:
+        a = tens[name]
+        back = ((a.view(np.uint32) >> 16) << 16).view(np.float32).astype(np.float16)
+        assert np.array_equal(mr.weight(local), back), local
+    with pytest.raises(nvr.NvrError):
+        mr.load_safetensors(path, strict=True)
+
+
 def test_engine_stats_health_and_shutdown():
     """LLMEngine::get_stats / health_check / shutdown (llm_engine.rs:312-357) over the C ABI."""
     mcfg = mo.small(seed=2)
@@ -441,3 +475,41 @@ def test_generate_stream_delivers_every_step_and_stops_when_the_receiver_drops()
     with pytest.raises(ZeroDivisionError):
         eng.generate_stream(prompts, sp, on_output=lambda o: 1 / 0)
     eng.shutdown()
+
+
+def test_admission_limits_and_length_clamp():
+    """ADVICE r01 (engine.cpp): a prompt longer than max_model_len or than one prefill batch is refused when it is added (it
+    could never execute and would wedge the scheduler); max_tokens is clamped so that a sequence stops when its next decode
+    step would pass max_model_len; requests around it keep running."""
+    mcfg = mo.small()
+    ecfg = dict(max_num_seqs=4, max_num_batched_tokens=64, max_model_len=48, kvcache_block_size=16, num_kvcache_blocks=16)
+    p = nvr.LLMEngine(nvr.Config(skip_block_size_check=1, **ecfg), _model_cfgs(mcfg))
+    with pytest.raises(nvr.NvrError, match="max_model_len"):
+        p.add_request(oracle.fill_tokens(49, 1, 0, mcfg.vocab_size).tolist(), nvr.SamplingParams(temperature=0.0, max_tokens=4))
+    p2 = nvr.LLMEngine(nvr.Config(skip_block_size_check=1, **dict(ecfg, max_model_len=128, num_kvcache_blocks=40)), _model_cfgs(mcfg))
+    with pytest.raises(nvr.NvrError, match="max_num_batched_tokens"):
+        p2.add_request(oracle.fill_tokens(65, 1, 0, mcfg.vocab_size).tolist(), nvr.SamplingParams(temperature=0.0, max_tokens=4))
+    # 40-token prompt, max_tokens 64 -> clamped to 48 - 40 + 1 = 9 tokens; a short neighbour is unaffected
+    a = p.add_request(oracle.fill_tokens(40, 1, 1, mcfg.vocab_size).tolist(), nvr.SamplingParams(temperature=0.0, max_tokens=64, ignore_eos=True))
+    b = p.add_request(oracle.fill_tokens(5, 1, 2, mcfg.vocab_size).tolist(), nvr.SamplingParams(temperature=0.0, max_tokens=12, ignore_eos=True))
+    steps = 0
+    while not p.is_finished():
+        p.step(); steps += 1
+        assert steps < 40
+    fin = {s.seq_id: s for s in p.take_finished()}
+    assert len(fin[a].token_ids) == 49 and len(fin[b].token_ids) == 17
+    assert p.scheduler.get_block_stats()["used_blocks"] == 0
+
+
+@pytest.mark.parametrize("mml", [100, 120, 128])
+def test_graph_decode_small_max_model_len_full_batch(mml):
+    """ADVICE r01 (model_runner.cpp:113): the graph path launches attention with the 256-token context bucket, which exceeds
+    a small max_model_len; the split-KV workspace must cover that bucket (it was sized from max_model_len and the partials of
+    a full batch ran past it).  Graph == eager token streams, and the logits stay within tolerance of the oracle."""
+    mcfg = mo.small()
+    ecfg = dict(max_num_seqs=4, max_num_batched_tokens=512, max_model_len=mml, kvcache_block_size=16, num_kvcache_blocks=40)
+    prompts = [oracle.fill_tokens(n, 1, i, mcfg.vocab_size).tolist() for i, n in enumerate([70, 66, 80, 75])]
+    sps = [dict(temperature=0.0, max_tokens=16, ignore_eos=True)] * 4
+    g = _run_pair(mcfg, ecfg, prompts, sps)
+    e = _run_pair(mcfg, ecfg, prompts, sps, enforce_eager=True)
+    assert g["finished"] == e["finished"] and g["near_ties"] <= 2

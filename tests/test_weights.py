@@ -63,3 +63,43 @@ def test_oracle_loader_errors_and_unknown_names():
     assert np.array_equal(ot.lm_head, e.astype(np.float32))
     with pytest.raises(ValueError, match="tie_word_embeddings"):
         ot.load_state_dict({"lm_head.weight": e})
+
+
+def _write_safetensors(path, tensors):
+    """Minimal writer (the format: u64 header length, JSON header, payload) so that a BF16 file exists without torch."""
+    import json
+    header, blobs, off = {}, [], 0
+    for name, (tag, arr) in tensors.items():
+        raw = np.ascontiguousarray(arr).tobytes()
+        header[name] = dict(dtype=tag, shape=list(arr.shape), data_offsets=[off, off + len(raw)])
+        blobs.append(raw); off += len(raw)
+    hj = json.dumps(header).encode()
+    hj += b" " * (-len(hj) % 8)
+    with open(path, "wb") as f:
+        f.write(len(hj).to_bytes(8, "little")); f.write(hj)
+        for b in blobs:
+            f.write(b)
+
+
+def test_safetensors_reader_bf16_f16_f32(tmp_path):
+    """safetensors' numpy front end raises on BF16 (the dtype of the published Qwen3 checkpoints); the
+    package's own reader hands bf16 down as 16-bit patterns and agrees with the safetensors package on f16 / f32."""
+    import nvr_import
+    nvr = nvr_import.load()
+    rng = np.random.default_rng(3)
+    f32 = rng.standard_normal((5, 8)).astype(np.float32)
+    bf = (f32.view(np.uint32) >> 16).astype(np.uint16)                      # truncated bf16 bit patterns
+    f16 = rng.standard_normal((3, 4)).astype(np.float16)
+    path = str(tmp_path / "m.safetensors")
+    _write_safetensors(path, {"a.weight": ("BF16", bf), "b.weight": ("F16", f16), "c.weight": ("F32", f32), "d": ("F32", np.float32(2.5).reshape(()))})
+    got = dict(nvr.iter_safetensors(path))
+    assert got["a.weight"].dtype == np.uint16 and np.array_equal(got["a.weight"], bf)
+    assert np.array_equal(got["b.weight"], f16) and np.array_equal(got["c.weight"], f32) and got["d"].shape == ()
+    from safetensors.numpy import load_file, save_file
+    p2 = str(tmp_path / "n.safetensors")
+    save_file({"x": f16, "y": f32}, p2)
+    ref, mine = load_file(p2), dict(nvr.iter_safetensors(p2))
+    assert all(np.array_equal(ref[k], mine[k]) for k in ref)
+    _write_safetensors(path, {"q": ("I64", np.arange(4))})
+    with pytest.raises(nvr.NvrError):
+        list(nvr.iter_safetensors(path))
