@@ -62,6 +62,19 @@ int linear_qkv_rope_store(const half_bits *x, int64_t ldx, const half_bits *W, i
                           int64_t KVH, int64_t D, const int64_t *positions, const int32_t *slots, const float *cos_t,
                           const float *sin_t, half_bits *qkv, half_bits *k_cache, half_bits *v_cache, hipStream_t s);
 
+// The decode chain in four launches per layer (linear_decode.hip): the residual add rides on the split-k reduction of the
+// row-parallel GEMMs (last arriver of a tile), the RMSNorm in the prologue of the GEMM that consumes it.
+bool decode_chain_ok(int64_t T, int64_t Hd, int64_t qkv_rows, int64_t I, int64_t D);
+int decode_splitk_slices(int64_t T, int64_t K, int64_t N);
+// h[T,N] <- fp16(h + fp16(x·Wᵀ)); slabs [S][T][N] f32 scratch; cnt: (N/16)*ceil(T/32) zeroed counters (left zeroed)
+int linear_resid(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t N, int64_t S, float *slabs,
+                 unsigned int *cnt, half_bits *h, hipStream_t s);
+int linear_silu_mul_normed(const half_bits *h, int64_t ldx, const half_bits *wn, float eps, const half_bits *W, int64_t T, int64_t K,
+                           int64_t I, half_bits *out, hipStream_t s);
+int linear_qkv_rope_store_normed(const half_bits *h, int64_t ldx, const half_bits *wn, float eps, const half_bits *W, int64_t T, int64_t K,
+                                 int64_t H, int64_t KVH, int64_t D, const int64_t *positions, const int32_t *slots, const float *cos_t,
+                                 const float *sin_t, half_bits *qkv, half_bits *k_cache, half_bits *v_cache, hipStream_t s);
+
 // decode GEMMs over large weights (T <= 32, K >= 2048, >= 24 MiB of weights): activation block in LDS, persistent workgroups
 // (linear_stream.hip); linear / linear_silu_mul / linear_qkv_rope_store route here when the shape test passes
 int linear_stream_prepare();                                                // LDS opt-in of every instance (call outside captures)
