@@ -145,8 +145,6 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--attn-reps", type=int, default=8)
-    ap.add_argument("--microbatches", type=int, default=int(os.environ.get("NVR_MICROBATCHES", "1")),
-                    help="decode micro-batches run concurrently on their own HIP streams (nvr_config.decode_microbatches)")
     ap.add_argument("--eager", action="store_true", help="enforce_eager: launch decode kernels one by one instead of replaying a hipGraph")
     ap.add_argument("--parallel", choices=["both", "tp", "replicas"], default=os.environ.get("NVR_BENCH_PARALLEL", "both"),
                     help="--gpus N > 1: 'replicas' = N independent engines, 32 sequences each, no exchange between ranks (sequences are "
@@ -206,7 +204,7 @@ def main() -> None:
         cfg = nvr.Config(max_num_seqs=BATCH, max_num_batched_tokens=BATCH * PROMPT_LEN, max_model_len=PROMPT_LEN + total_new + 16,
                          kvcache_block_size=BLOCK, num_kvcache_blocks=BATCH * ((PROMPT_LEN + total_new + 16) // BLOCK + 2),
                          tensor_parallel_size=tp_size, tensor_parallel_rank=tp_rank,
-                         device_ordinal=local_rank, decode_microbatches=args.microbatches, enforce_eager=args.eager)
+                         device_ordinal=local_rank, enforce_eager=args.eager)
         return nvr.LLMEngine(cfg, mc)
 
     def barrier():
@@ -291,7 +289,7 @@ def main() -> None:
             for k in [k for k in env if k.startswith("TORCHELASTIC_")]:       # the children rendezvous on their own store (rank 0 hosts it),
                 del env[k]                                                    # not on the launcher agent's
             cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup),
-                   "--parallel", "tp", "--no-cpu-baseline", "--attn-reps", "1", "--microbatches", str(args.microbatches)] + (["--eager"] if args.eager else [])
+                   "--parallel", "tp", "--no-cpu-baseline", "--attn-reps", "1"] + (["--eager"] if args.eager else [])
             child_out, child_err, child_rc = "", "", None
             try:
                 cp = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
@@ -380,7 +378,7 @@ def main() -> None:
             "config": {"workload": "Qwen3-0.6B fp16 random-init, bs=32 x 1024-token prompts, greedy paged-attention decode, "
                                    "block_size=256, hipGraph decode steps (BASELINE.json configs[1])",
                        "batch": BATCH, "prompt_len": PROMPT_LEN, "mean_context": ctx_mean,
-                       "parallelism": parallelism, "decode_microbatches": args.microbatches, "hipgraph": not args.eager,
+                       "parallelism": parallelism, "hipgraph": not args.eager,
                        "logits": "materialised every step" if args.materialize_logits else "greedy arg-max fused into the LM head; f32 logits on demand"},
             "prefill": {"tokens": BATCH * PROMPT_LEN, "seconds": round(t_prefill, 4), "tokens_per_s": round(BATCH * PROMPT_LEN / t_prefill, 1),
                         "tflop_per_s": round(prefill_flop / t_prefill / 1e12, 1), "mfma_frac_of_2500": round(prefill_flop / t_prefill / 2.5e15, 4),

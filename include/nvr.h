@@ -50,6 +50,7 @@ typedef enum nvr_status {
 } nvr_status;
 
 NVR_API const char *nvr_last_error(void);
+NVR_API int nvr_last_status(void);          /* status code that came with nvr_last_error (constructors return NULL: the code is here) */
 NVR_API const char *nvr_version(void);
 
 /* ------------------------------------------------------------- plain structs ---- */
@@ -83,13 +84,21 @@ typedef struct nvr_config {
     uint64_t sample_seed;              /* A-20 counter-RNG seed */
     int32_t skip_block_size_check;     /* reference unit tests use block sizes 4/16 that
                                           Config::validate would reject (config.rs:94) */
-    uint32_t decode_microbatches;      /* 0/1: one kernel chain per decode step; 2..4: the batch rows are cut
-                                          into that many slices run concurrently on their own HIP streams */
+    uint32_t decode_chain;             /* GEMM / norm chain of single-rank decode steps: 0 or 6 = six launches per layer (qkv+RoPE,
+                                          o_proj split-k, add+RMSNorm, gate_up+SiLU, down split-k, add+RMSNorm; default: measured
+                                          0.8 % faster per step), 4 = four launches (kernels/linear_decode.hip: norms in the GEMM
+                                          prologues, residual adds on the split-k reductions); profiles/r02_decode_chain_ablation.txt */
     int32_t recompute_cached_prefix;   /* 0 (default): a prefill step computes only the tokens after a sequence's
                                           cached prefix (num_cached_tokens, block_manager.rs:187) and attends to the
                                           prefix through the block table (K8, attention.rs:211-222) — SURVEY §8f row 2;
                                           1: the reference's prepare_prefill_inputs (model_runner.rs:176-182), which
                                           recomputes every token from position 0 */
+    char device[16];                   /* config.rs:48, validated like :108-111 plus "hip": "hip" (default) | "cuda" (the reference's
+                                          default, taken as "the GPU") | "cpu" | "metal"; a runner exists only for "hip" / "cuda" —
+                                          there is no CPU path in this library (NVR_ERR_UNSUPPORTED) */
+    char dtype[16];                    /* config.rs:51,:113-116: "float16" (default) | "bfloat16" | "float32"; the kernels compute in
+                                          fp16 storage / f32 accumulate only (others: NVR_ERR_UNSUPPORTED at runner creation;
+                                          bf16 / f32 checkpoints are converted on load) */
 } nvr_config;
 NVR_API void nvr_config_default(nvr_config *cfg);                    /* config.rs:54-71 */
 NVR_API int nvr_config_validate(const nvr_config *cfg);              /* config.rs:83-119 */
@@ -324,6 +333,12 @@ NVR_API int nvr_event_create(void **ev);
 NVR_API int nvr_event_destroy(void *ev);
 NVR_API int nvr_event_record(void *ev, void *stream);
 NVR_API int nvr_event_elapsed_ms(void *start, void *stop, float *ms);   /* synchronises on stop */
+/* hipGraph capture of stateless-op calls on a caller-created stream (measurement harnesses; the engine captures its own decode
+ * steps, execute_with_cuda_graph model_runner.rs:303-326): ops enqueued between begin and end become one replayable graph */
+NVR_API int nvr_graph_capture_begin(void *stream);
+NVR_API int nvr_graph_capture_end(void *stream, void **graph_exec);
+NVR_API int nvr_graph_launch(void *graph_exec, void *stream);
+NVR_API int nvr_graph_destroy(void *graph_exec);
 
 /* ------------------------------------------------ stateless op entry points ---- */
 /* One per kernel-shaped op site of the hot path.  All tensors are
@@ -374,13 +389,24 @@ NVR_API int nvr_linear_splitk(const nvr_half *x, int64_t ldx, const nvr_half *W,
                               float *slabs, void *stream);
 NVR_API int nvr_add_rmsnorm_slabs(nvr_half *h, const float *slabs, int64_t S, const nvr_half *w, float eps, int64_t T,
                                   int64_t Hd, nvr_half *out, void *stream);
-/* both of the above in ONE launch (opt-in, NVR_FUSED_SLABNORM=1: measured slower than the two launches; same rounding
- * points, normalised rows within 1 fp16 ulp of the two-launch form): the workgroups publish their partial tiles, count
- * arrivals in sync[0] and workgroups 0..T-1 finish one row each.  sync = 4 zero-initialised uint32 in device memory
- * (re-armed by the kernel; sync[2] != 0 afterwards means an arrival wait timed out).  N <= 2048, T <= 64. */
-NVR_API int nvr_linear_splitk_norm(const nvr_half *x, int64_t ldx, const nvr_half *W, int64_t T, int64_t K, int64_t N,
-                                   int64_t S, float *slabs, nvr_half *h, const nvr_half *w_norm, float eps,
-                                   nvr_half *out, uint32_t *sync, void *stream);
+/* The decode chain in four launches per layer (kernels/linear_decode.hip; Qwen3DecoderLayer::forward qwen3.rs:372-392):
+ * nvr_linear_resid: h[T,N] <- fp16(h + fp16(x · Wᵀ)) — RowParallelLinear::forward (linear.rs:228-239) plus the residual add
+ * (qwen3.rs:382,389) in one launch: k is split over S workgroups per 16-column tile (S = nvr_decode_splitk_slices), each
+ * publishes its f32 partial tile in slabs[S][T][N] and takes a ticket from the tile's counter; the workgroup that draws the
+ * last ticket sums the slabs in slab order (bit-identical to nvr_linear_splitk + the add of nvr_add_rmsnorm_slabs) and adds
+ * the residual.  counters: (N/16)*ceil(T/32) zero-initialised uint32 (left zeroed).  T <= 64, K/S <= 2048.
+ * nvr_linear_silu_mul_normed / nvr_linear_qkv_rope_store_normed: nvr_linear_silu_mul / nvr_linear_qkv_rope_store with
+ * RMSNorm::forward_simple (layernorm.rs:58-75) of their input rows in the prologue (x = the residual stream h, w_norm the
+ * norm weight): n = fp16(h * (1/rms) * w) per fragment, within 1 fp16 ulp of nvr_rmsnorm's rows.  T <= 64, K <= 2048. */
+NVR_API int nvr_linear_resid(const nvr_half *x, int64_t ldx, const nvr_half *W, int64_t T, int64_t K, int64_t N, int64_t S,
+                             float *slabs, uint32_t *counters, nvr_half *h, void *stream);
+NVR_API int nvr_decode_splitk_slices(int64_t T, int64_t K, int64_t N);
+NVR_API int nvr_linear_silu_mul_normed(const nvr_half *h, int64_t ldx, const nvr_half *w_norm, float eps, const nvr_half *W,
+                                       int64_t T, int64_t K, int64_t I, nvr_half *out, void *stream);
+NVR_API int nvr_linear_qkv_rope_store_normed(const nvr_half *h, int64_t ldx, const nvr_half *w_norm, float eps, const nvr_half *W,
+                                             int64_t T, int64_t K, int64_t H, int64_t KVH, int64_t D, const int64_t *positions,
+                                             const int32_t *slot_mapping, const float *cos_t, const float *sin_t,
+                                             nvr_half *qkv, nvr_half *k_cache, nvr_half *v_cache, void *stream);
 /* K12+K13 fused: out[T,I] = SiluAndMul(x · W_gate_upᵀ), W [2I,K] gate rows then up rows
  * (MergedColumnParallelLinear::forward linear.rs:437-439 + SiluAndMul::forward activation.rs:46-63) */
 NVR_API int nvr_linear_silu_mul(const nvr_half *x, int64_t ldx, const nvr_half *W, int64_t T, int64_t K, int64_t I,

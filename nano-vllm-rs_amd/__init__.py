@@ -53,8 +53,8 @@ class ConfigC(C.Structure):
                 ("enforce_eager", C.c_int32), ("has_eos", C.c_int32), ("eos_token_id", C.c_int64),
                 ("kvcache_block_size", C.c_uint64), ("num_kvcache_blocks", C.c_int64),
                 ("tensor_parallel_rank", C.c_uint64), ("device_ordinal", C.c_int32), ("sample_seed", C.c_uint64),
-                ("skip_block_size_check", C.c_int32), ("decode_microbatches", C.c_uint32),
-                ("recompute_cached_prefix", C.c_int32)]
+                ("skip_block_size_check", C.c_int32), ("decode_chain", C.c_uint32),
+                ("recompute_cached_prefix", C.c_int32), ("device", C.c_char * 16), ("dtype", C.c_char * 16)]
 
 
 class ModelConfigC(C.Structure):
@@ -118,7 +118,7 @@ _lib: Optional[C.CDLL] = None
 _P = C.c_void_p
 _SIGS = {
     # name: (restype, argtypes)
-    "nvr_last_error": (C.c_char_p, []), "nvr_version": (C.c_char_p, []),
+    "nvr_last_error": (C.c_char_p, []), "nvr_last_status": (C.c_int, []), "nvr_version": (C.c_char_p, []),
     "nvr_sampling_params_default": (None, [C.POINTER(SamplingParamsC)]),
     "nvr_sampling_params_validate": (C.c_int, [C.POINTER(SamplingParamsC)]),
     "nvr_config_default": (None, [C.POINTER(ConfigC)]), "nvr_config_validate": (C.c_int, [C.POINTER(ConfigC)]),
@@ -189,6 +189,8 @@ _SIGS = {
     "nvr_device_synchronize": (C.c_int, []),
     "nvr_stream_create": (C.c_int, [C.POINTER(_P)]), "nvr_stream_destroy": (C.c_int, [_P]),
     "nvr_stream_synchronize": (C.c_int, [_P]),
+    "nvr_graph_capture_begin": (C.c_int, [_P]), "nvr_graph_capture_end": (C.c_int, [_P, C.POINTER(_P)]),
+    "nvr_graph_launch": (C.c_int, [_P, _P]), "nvr_graph_destroy": (C.c_int, [_P]),
     "nvr_event_create": (C.c_int, [C.POINTER(_P)]), "nvr_event_destroy": (C.c_int, [_P]),
     "nvr_event_record": (C.c_int, [_P, _P]), "nvr_event_elapsed_ms": (C.c_int, [_P, _P, C.POINTER(C.c_float)]),
     "nvr_embedding": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, _P]),
@@ -198,7 +200,11 @@ _SIGS = {
     "nvr_lm_head": (C.c_int, [_P, C.c_int64, _P, C.c_int64, C.c_int64, C.c_int64, _P, _P, _P, _P, _P]),
     "nvr_argmax_partials": (C.c_int, [_P, _P, C.c_int32, C.c_int64, _P, _P, C.c_int64, _P]),
     "nvr_linear_splitk": (C.c_int, [_P, C.c_int64, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _P, _P]),
-    "nvr_linear_splitk_norm": (C.c_int, [_P, C.c_int64, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _P, _P, _P, C.c_float, _P, _P, _P]),
+    "nvr_linear_resid": (C.c_int, [_P, C.c_int64, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _P, _P, _P, _P]),
+    "nvr_decode_splitk_slices": (C.c_int, [C.c_int64, C.c_int64, C.c_int64]),
+    "nvr_linear_silu_mul_normed": (C.c_int, [_P, C.c_int64, _P, C.c_float, _P, C.c_int64, C.c_int64, C.c_int64, _P, _P]),
+    "nvr_linear_qkv_rope_store_normed": (C.c_int, [_P, C.c_int64, _P, C.c_float, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _P, _P,
+                                                   _P, _P, _P, _P, _P, _P]),
     "nvr_add_rmsnorm_slabs": (C.c_int, [_P, _P, C.c_int64, _P, C.c_float, C.c_int64, C.c_int64, _P, _P]),
     "nvr_linear_silu_mul": (C.c_int, [_P, C.c_int64, _P, C.c_int64, C.c_int64, C.c_int64, _P, _P]),
     "nvr_linear_qkv_rope_store": (C.c_int, [_P, C.c_int64, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _P, _P, _P, _P,
@@ -290,7 +296,7 @@ class Config:
         for k, v in kw.items():
             if not hasattr(c, k):
                 raise AttributeError(f"Config has no field {k}")
-            setattr(c, k, int(v) if isinstance(v, bool) else v)
+            setattr(c, k, int(v) if isinstance(v, bool) else (v.encode() if isinstance(v, str) else v))
 
     def validate(self) -> None:
         check(lib().nvr_config_validate(C.byref(self.c)))
@@ -540,7 +546,7 @@ class ModelRunner:
             return
         self.h = lib().nvr_runner_create(C.byref(config.c), C.byref(model_config.c))
         if not self.h:
-            raise NvrError(-8, last_error())
+            raise NvrError(lib().nvr_last_status() or -8, last_error())
         self.owned = True
 
     def __del__(self):
@@ -714,7 +720,7 @@ class LLMEngine:
         config.validate()
         self.h = lib().nvr_engine_create(C.byref(config.c), C.byref(model_config.c))
         if not self.h:
-            raise NvrError(-8, last_error())
+            raise NvrError(lib().nvr_last_status() or -8, last_error())
         self.config, self.model_config = config, model_config
         self.scheduler = Scheduler(config, _handle=lib().nvr_engine_scheduler(self.h))
         self.model_runner = ModelRunner(config, model_config, _handle=lib().nvr_engine_runner(self.h))

@@ -8,6 +8,7 @@
 namespace nvr {
 
 std::string &last_error_slot();
+int &last_status_slot();
 int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 
 }  // namespace nvr

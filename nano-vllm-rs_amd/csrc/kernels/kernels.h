@@ -48,8 +48,6 @@ int argmax_partials(const float *part_val, const int32_t *part_idx, int32_t npar
 
 int linear_splitk(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t N, int64_t S,
                   float *slabs, hipStream_t s);
-int linear_splitk_norm(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t N, int64_t S, float *slabs,
-                       half_bits *h, const half_bits *wn, float eps, half_bits *nout, unsigned int *sync, hipStream_t s);
 // h = fp16(h + fp16(sum_z slabs[z])), out = rmsnorm(h)*w
 int add_rmsnorm_slabs(half_bits *h, const float *slabs, int64_t S, const half_bits *w, float eps, int64_t T, int64_t Hd,
                       half_bits *out, hipStream_t s);

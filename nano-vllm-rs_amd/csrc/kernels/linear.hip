@@ -29,7 +29,7 @@
 
 namespace nvr { namespace k {
 
-enum { EPI_F16 = 0, EPI_F32 = 1, EPI_SILU = 2, EPI_ROPE = 3, EPI_SLAB = 4, EPI_SLABNORM = 5 };
+enum { EPI_F16 = 0, EPI_F32 = 1, EPI_SILU = 2, EPI_ROPE = 3, EPI_SLAB = 4 };
 
 struct LinEpi {
     // EPI_SILU: N is the intermediate size I; W holds gate rows [0,I) and up rows [I,2I)
@@ -39,9 +39,6 @@ struct LinEpi {
     int32_t H, KVH, D;
     // EPI_SLAB: blockIdx.z owns k in [z*kslice, (z+1)*kslice) and writes its f32 partial tile to slab z
     int32_t kslice; int64_t slab_stride;
-    // EPI_SLABNORM: after all partial tiles are published, workgroups 0..T-1 finish rows in the same launch:
-    // h <- fp16(h + fp16(sum_z slab_z)), nout = rmsnorm(h)*wn.  sync: {arrivals, rows done, timeout flag, -}
-    half_t *h; const half_t *wn; half_t *nout; float eps; unsigned int *sync;
 };
 
 // W row handled by local row r (0..15) of n-tile i of workgroup bx
@@ -95,7 +92,7 @@ __global__ __launch_bounds__(WAVES * 64) void linear_skinny_kernel(const half_t 
         if (head >= epi.H && epi.slots && m < T) rope_slot = epi.slots[m];
     }
     constexpr int KS = 32 * WAVES;
-    constexpr bool SLABBED = (EPI == EPI_SLAB || EPI == EPI_SLABNORM);
+    constexpr bool SLABBED = EPI == EPI_SLAB;
     const int kbeg = SLABBED ? blockIdx.z * epi.kslice : 0;
     if (SLABBED) K = min(K, kbeg + epi.kslice);
     for (int k = kbeg + wave * 32; k < K; k += KS * U) {
@@ -152,82 +149,6 @@ __global__ __launch_bounds__(WAVES * 64) void linear_skinny_kernel(const half_t 
                 } else {
                     half4_t h = {(half_t)s[0], (half_t)s[1], (half_t)s[2], (half_t)s[3]};
                     *reinterpret_cast<half4_t *>(reinterpret_cast<half_t *>(y) + (int64_t)m * N + n) = h;
-                }
-            }
-        }
-    } else if (EPI == EPI_SLABNORM) {
-        // (1) publish the partial tile write-through (sc1: no release fence needed, cdna guide G16 R1)
-        const auto rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float *>(y), 0, (int)(gridDim.z * epi.slab_stride * 4), 0x00020000);
-        for (int tile = wave; tile < NT * MT; tile += WAVES) {
-            const float4_t sv = reduce(tile);
-            const int i = tile / MT, j = tile % MT;
-            const int n = (blockIdx.x * NT + i) * 16 + q * 4, m = m0 + j * 16 + r;
-            if (m < T && n < N) {
-                typedef unsigned int u4 __attribute__((ext_vector_type(4)));
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, sv), rs,
-                                                       (int)((blockIdx.z * epi.slab_stride + (int64_t)m * N + n) * 4), 0, 16);
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // every storing wave drains its stores
-        __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_fetch_add(&epi.sync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // (2) row finishers: one wave per row, rows strided over the workgroups; all workgroups are co-resident
-        //     (grid <= 256 x 2 workgroups of <= 256 threads), every spin is bounded
-        const unsigned total = gridDim.x * gridDim.y * gridDim.z;
-        const unsigned wg = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-        if (wave == 0 && wg < (unsigned)T) {
-            unsigned spins = 0;
-            while (__hip_atomic_load(&epi.sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < total) {
-                if (++spins > (1u << 22)) { if (lane == 0) __hip_atomic_store(&epi.sync[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");         // keeps the sc1 loads below the poll
-            constexpr int C = 4;                                           // 512-element chunks per row (N <= 2048)
-            const int S = gridDim.z;
-            for (int row = wg; row < T; row += total) {
-                half_t *hr = epi.h + (int64_t)row * N;
-                float ss = 0.f;
-                half8_t hv[C];
-#pragma unroll
-                for (int cc = 0; cc < C; ++cc) {
-                    const int col = lane * 8 + cc * 512;
-                    if (col < N) {
-                        hv[cc] = *reinterpret_cast<const half8_t *>(hr + col);
-                        float4_t a0 = (float4_t){0.f, 0.f, 0.f, 0.f}, a1 = a0;
-                        for (int z = 0; z < S; ++z) {
-                            const int off = (int)((z * epi.slab_stride + (int64_t)row * N + col) * 4);
-                            const float4_t p0 = __builtin_bit_cast(float4_t, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 16));
-                            const float4_t p1 = __builtin_bit_cast(float4_t, __builtin_amdgcn_raw_buffer_load_b128(rs, off + 16, 0, 16));
-                            if (z == 0) { a0 = p0; a1 = p1; } else { a0 += p0; a1 += p1; }
-                        }
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            const float yv = (float)to_half_rn(e < 4 ? a0[e] : a1[e - 4]);
-                            hv[cc][e] = to_half_rn((float)hv[cc][e] + yv);
-                            const float f = (float)hv[cc][e]; ss += f * f;
-                        }
-                        *reinterpret_cast<half8_t *>(hr + col) = hv[cc];
-                    }
-                }
-                ss = wave_sum(ss);
-                const float rms = sqrtf(ss / (float)N + epi.eps);
-#pragma unroll
-                for (int cc = 0; cc < C; ++cc) {
-                    const int col = lane * 8 + cc * 512;
-                    if (col < N) {
-                        const half8_t g = *reinterpret_cast<const half8_t *>(epi.wn + col);
-                        half8_t o;
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) o[e] = to_half_rn(__fmul_rn(__fdiv_rn((float)hv[cc][e], rms), (float)g[e]));
-                        *reinterpret_cast<half8_t *>(epi.nout + (int64_t)row * N + col) = o;
-                    }
-                }
-            }
-            // (3) the last finisher re-arms the counters for the next launch
-            if (lane == 0) {
-                const unsigned nfin = (unsigned)T < total ? (unsigned)T : total;
-                if (__hip_atomic_fetch_add(&epi.sync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nfin - 1) {
-                    __hip_atomic_store(&epi.sync[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(&epi.sync[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
         }
@@ -385,23 +306,6 @@ int linear_splitk(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T
     if (T <= 16) launch<1, 1, 4, EPI_SLAB>((const half_t *)x, ldx, (const half_t *)W, (int)T, (int)K, (int)N, slabs, e, gx, s, (unsigned)S);
     else launch<1, 2, 4, EPI_SLAB>((const half_t *)x, ldx, (const half_t *)W, (int)T, (int)K, (int)N, slabs, e, gx, s, (unsigned)S);
     return launch_check("linear_splitk");
-}
-
-// split-k GEMM + residual add + RMSNorm in ONE launch (decode, T <= 64, N = hidden <= 2048): the partial tiles are
-// published write-through, the workgroups count their arrivals and workgroups 0..T-1 then finish one row each.
-// Same arithmetic and rounding points as linear_splitk followed by add_rmsnorm_slabs.
-int linear_splitk_norm(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t N, int64_t S, float *slabs,
-                       half_bits *h, const half_bits *wn, float eps, half_bits *nout, unsigned int *sync, hipStream_t s) {
-    if (K % (32 * S) || N % 16 || ldx % 8 || S < 1 || N > 2048 || N % 8 || T > 64)
-        return nvr::fail(NVR_ERR_UNSUPPORTED, "linear_splitk_norm: K=%ld S=%ld N=%ld T=%ld", (long)K, (long)S, (long)N, (long)T);
-    if (T == 0) return 0;
-    LinEpi e{};
-    e.kslice = (int32_t)(K / S); e.slab_stride = T * N;
-    e.h = (half_t *)h; e.wn = (const half_t *)wn; e.nout = (half_t *)nout; e.eps = eps; e.sync = sync;
-    const unsigned gx = (unsigned)(N / 16);
-    if (T <= 16) launch<1, 1, 4, EPI_SLABNORM>((const half_t *)x, ldx, (const half_t *)W, (int)T, (int)K, (int)N, slabs, e, gx, s, (unsigned)S);
-    else launch<1, 2, 4, EPI_SLABNORM>((const half_t *)x, ldx, (const half_t *)W, (int)T, (int)K, (int)N, slabs, e, gx, s, (unsigned)S);
-    return launch_check("linear_splitk_norm");
 }
 
 // gate_up GEMM + SiluAndMul: W [2I, K] (gate rows then up rows), out [T, I]

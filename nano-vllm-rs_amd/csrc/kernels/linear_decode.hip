@@ -54,8 +54,27 @@ __device__ __forceinline__ int dec_w_row(int bx, int i, int NT, int r, int N, co
     return n < N ? n : N - 1;
 }
 
-// KI: k-steps of 32 per wave (all in flight at once); the k range of the workgroup is <= 32*WAVES*KI
-template <int NT, int MT, int WAVES, int KI, int EPI, bool NORM>
+// normalise 8 fp16 elements: n = fp16(h * inv * w).  Contraction is allowed here (v_fma_mix_f32 / v_fma_mixlo_f16 read the fp16
+// operands directly: two instructions per element): the product h*inv is rounded to f32, (that)*w once to fp16 — within 1 fp16
+// ulp of the oracle's (h / rms) * w, like the division-free quotient itself (DESIGN A-25).
+__device__ __forceinline__ half8_t norm8(half8_t v, float inv, half8_t g) {
+#pragma clang fp contract(fast)
+    half8_t o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const float t = (float)v[e] * inv; o[e] = (half_t)(t * (float)g[e]); }
+    return o;
+}
+__device__ __forceinline__ float sumsq8(half8_t v, float s) {
+#pragma clang fp contract(fast)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s += (float)v[e] * (float)v[e];
+    return s;
+}
+
+// KI: k-steps of 32 per wave (all in flight at once); the k range of the workgroup is <= 32*WAVES*KI (EXACT: equal, no guards).
+// HALF (DEPI_RESID, no k split): 8 weight rows per workgroup (MFMA rows 8..15 repeat rows 0..7 and are dropped), so that the
+// N = hidden GEMMs reach 2N/16 workgroups without cutting k.
+template <int NT, int MT, int WAVES, int KI, int EPI, bool NORM, bool EXACT, bool HALF>
 __global__ __launch_bounds__(WAVES * 64) void decode_linear_kernel(const half_t *__restrict__ x, int64_t ldx,
                                                                    const half_t *__restrict__ W, int T, int K, int N,
                                                                    half_t *__restrict__ y, DecEpi epi) {
@@ -69,39 +88,40 @@ __global__ __launch_bounds__(WAVES * 64) void decode_linear_kernel(const half_t 
     const half_t *wrow[NT];
     const half_t *xrow[MT];
 #pragma unroll
-    for (int i = 0; i < NT; ++i) wrow[i] = W + (int64_t)dec_w_row<EPI>(blockIdx.x, i, NT, r, N, epi) * K + q * 8;
+    for (int i = 0; i < NT; ++i) {
+        const int row = HALF ? min(blockIdx.x * 8 + (r & 7), N - 1) : dec_w_row<EPI>(blockIdx.x, i, NT, r, N, epi);
+        wrow[i] = W + (int64_t)row * K + q * 8;
+    }
 #pragma unroll
     for (int j = 0; j < MT; ++j) { int m = m0 + j * 16 + r; if (m > T - 1) m = T - 1; xrow[j] = x + (int64_t)m * ldx + q * 8; }
 
-    // every load of the workgroup's k range is requested here: weights (HBM, once-read: non-temporal) first
+    // Request order = the order the data is needed in (s_waitcnt vmcnt counts in issue order): the RoPE position (its cos / sin
+    // loads depend on it), the activation rows and norm weights (L2), cos / sin, the residual tile, and LAST the weights (HBM):
+    // the norm prologue then runs under the weight stream's latency.
+    float4_t rope_cs = (float4_t){0.f, 0.f, 0.f, 0.f}, rope_sn = rope_cs;
+    int rope_slot = -1;
+    int64_t rope_pos = 0;
+    const bool rope_lane = EPI == DEPI_ROPE && wave < MT;
+    if (rope_lane) {
+        const int m = m0 + wave * 16 + r, mc = m < T ? m : T - 1;
+        rope_pos = epi.pos[mc];
+        if (blockIdx.x / (epi.D / 16) >= epi.H && epi.slots && m < T) rope_slot = epi.slots[m];
+    }
     half8_t a[KI][NT], b[KI][MT], gw[NORM ? KI : 1];
 #pragma unroll
     for (int u = 0; u < KI; ++u) {
         const int kk = kbeg + wave * 32 + u * KS;
 #pragma unroll
-        for (int i = 0; i < NT; ++i)
-            a[u][i] = kk < kend ? __builtin_nontemporal_load(reinterpret_cast<const half8_t *>(wrow[i] + kk)) : (half8_t)(half_t)0;
+        for (int j = 0; j < MT; ++j) b[u][j] = (EXACT || kk < kend) ? *reinterpret_cast<const half8_t *>(xrow[j] + kk) : (half8_t)(half_t)0;
+        if constexpr (NORM) gw[u] = (EXACT || kk < kend) ? *reinterpret_cast<const half8_t *>(epi.wn + kk + q * 8) : (half8_t)(half_t)0;
     }
-#pragma unroll
-    for (int u = 0; u < KI; ++u) {
-        const int kk = kbeg + wave * 32 + u * KS;
-#pragma unroll
-        for (int j = 0; j < MT; ++j) b[u][j] = kk < kend ? *reinterpret_cast<const half8_t *>(xrow[j] + kk) : (half8_t)(half_t)0;
-        if constexpr (NORM) gw[u] = kk < kend ? *reinterpret_cast<const half8_t *>(epi.wn + kk + q * 8) : (half8_t)(half_t)0;
-    }
-    // DEPI_ROPE: the epilogue of token tile j runs on wave j; its position -> cos / sin / slot loads are issued ahead too
-    float4_t rope_cs = (float4_t){0.f, 0.f, 0.f, 0.f}, rope_sn = rope_cs;
-    int rope_slot = -1;
-    if (EPI == DEPI_ROPE && wave < MT) {
-        const int m = m0 + wave * 16 + r, mc = m < T ? m : T - 1;
+    if (rope_lane) {
         const int tph = epi.D / 16, head = blockIdx.x / tph, c = blockIdx.x % tph, half_d = epi.D / 2;
         if (head < epi.H + epi.KVH) {
             const int jj = c * 8 + (q & 1) * 4;
-            const int64_t p = epi.pos[mc];
-            rope_cs = *reinterpret_cast<const float4_t *>(epi.cos_t + p * half_d + jj);
-            rope_sn = *reinterpret_cast<const float4_t *>(epi.sin_t + p * half_d + jj);
+            rope_cs = *reinterpret_cast<const float4_t *>(epi.cos_t + rope_pos * half_d + jj);
+            rope_sn = *reinterpret_cast<const float4_t *>(epi.sin_t + rope_pos * half_d + jj);
         }
-        if (head >= epi.H && epi.slots && m < T) rope_slot = epi.slots[m];
     }
     // DEPI_RESID: the residual tile this workgroup adds IF it turns out to be the tile's last arriver (nobody else writes it)
     constexpr int TT = (NT * MT + WAVES - 1) / WAVES;          // output tiles per wave in the epilogue
@@ -111,11 +131,21 @@ __global__ __launch_bounds__(WAVES * 64) void decode_linear_kernel(const half_t 
         for (int tt = 0; tt < TT; ++tt) {
             const int tile = wave + tt * WAVES;
             const int i = tile / MT, j = tile % MT;
-            const int n = (blockIdx.x * NT + i) * 16 + q * 4, m = m0 + j * 16 + r;
+            const int n = HALF ? blockIdx.x * 8 + (q & 1) * 4 : (blockIdx.x * NT + i) * 16 + q * 4, m = m0 + j * 16 + r;
             hres[tt] = (tile < NT * MT && m < T && n < N) ? *reinterpret_cast<const half4_t *>(epi.h + (int64_t)m * N + n)
                                                           : (half4_t){(half_t)0, (half_t)0, (half_t)0, (half_t)0};
         }
     }
+#pragma unroll
+    for (int u = 0; u < KI; ++u) {
+        const int kk = kbeg + wave * 32 + u * KS;
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+            a[u][i] = (EXACT || kk < kend) ? __builtin_nontemporal_load(reinterpret_cast<const half8_t *>(wrow[i] + kk)) : (half8_t)(half_t)0;
+    }
+    // every request is out before anything is waited for (hipcc otherwise sinks loads below the first use of an earlier one:
+    // weight loads behind the norm's waits, or one HBM round trip per MFMA)
+    __builtin_amdgcn_sched_barrier(0);
 
     __shared__ float4_t part[WAVES][NT * MT][64];
     __shared__ float red[WAVES][MT * 16];
@@ -129,9 +159,7 @@ __global__ __launch_bounds__(WAVES * 64) void decode_linear_kernel(const half_t 
         for (int j = 0; j < MT; ++j) {
             float s = 0.f;
 #pragma unroll
-            for (int u = 0; u < KI; ++u)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { const float f = (float)b[u][j][e]; s += f * f; }
+            for (int u = 0; u < KI; ++u) s = sumsq8(b[u][j], s);
             ss[j] = xor32_partner_sum(xor16_partner_sum(s));
         }
         if (q == 0) {
@@ -146,10 +174,7 @@ __global__ __launch_bounds__(WAVES * 64) void decode_linear_kernel(const half_t 
             for (int w2 = 1; w2 < WAVES; ++w2) tot += red[w2][j * 16 + r];
             const float inv = __fdiv_rn(1.0f, sqrtf(tot / (float)K + epi.eps));
 #pragma unroll
-            for (int u = 0; u < KI; ++u)
-#pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    b[u][j][e] = to_half_rn(__fmul_rn(__fmul_rn((float)b[u][j][e], inv), (float)gw[u][e]));
+            for (int u = 0; u < KI; ++u) b[u][j] = norm8(b[u][j], inv, gw[u]);
         }
     }
 
@@ -191,8 +216,8 @@ __global__ __launch_bounds__(WAVES * 64) void decode_linear_kernel(const half_t 
                 if (tile >= NT * MT) continue;
                 const float4_t s = reduce(tile);
                 const int i = tile / MT, j = tile % MT;
-                const int n = (blockIdx.x * NT + i) * 16 + q * 4, m = m0 + j * 16 + r;
-                if (m < T && n < N) {
+                const int n = HALF ? blockIdx.x * 8 + q * 4 : (blockIdx.x * NT + i) * 16 + q * 4, m = m0 + j * 16 + r;
+                if (m < T && n < N && (!HALF || q < 2)) {
                     half4_t o;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] = to_half_rn((float)hres[tt][e] + (float)to_half_rn(s[e]));
@@ -228,12 +253,15 @@ __global__ __launch_bounds__(WAVES * 64) void decode_linear_kernel(const half_t 
             const int i = tile / MT, j = tile % MT;
             const int n = (blockIdx.x * NT + i) * 16 + q * 4, m = m0 + j * 16 + r;
             if (m < T && n < N) {
-                float4_t sum = (float4_t){0.f, 0.f, 0.f, 0.f};
-                for (int z = 0; z < S; ++z) {
-                    const float4_t pz = __builtin_bit_cast(float4_t, __builtin_amdgcn_raw_buffer_load_b128(
-                        rs, (int)((z * epi.slab_stride + (int64_t)m * N + n) * 4), 0, 16));
-                    if (z == 0) sum = pz; else sum += pz;
-                }
+                float4_t pz[4];                                       // S <= 4: all slab loads in flight together
+#pragma unroll
+                for (int z = 0; z < 4; ++z)
+                    pz[z] = z < S ? __builtin_bit_cast(float4_t, __builtin_amdgcn_raw_buffer_load_b128(
+                                        rs, (int)((z * epi.slab_stride + (int64_t)m * N + n) * 4), 0, 16))
+                                  : (float4_t){0.f, 0.f, 0.f, 0.f};
+                float4_t sum = pz[0];
+#pragma unroll
+                for (int z = 1; z < 4; ++z) if (z < S) sum += pz[z];
                 half4_t o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = to_half_rn((float)hres[tt][e] + (float)to_half_rn(sum[e]));
@@ -302,11 +330,13 @@ static int dec_launch_check(const char *what) {
     return 0;
 }
 
-template <int NT, int MT, int WAVES, int KI, int EPI, bool NORM>
+template <int NT, int MT, int WAVES, int KI, int EPI, bool NORM, bool HALF = false>
 static void dec_launch(const half_t *x, int64_t ldx, const half_t *W, int T, int K, int N, half_t *y, const DecEpi &e, unsigned gx,
                        unsigned gz, hipStream_t s) {
     dim3 grid(gx, (unsigned)((T + 16 * MT - 1) / (16 * MT)), gz);
-    decode_linear_kernel<NT, MT, WAVES, KI, EPI, NORM><<<grid, dim3(WAVES * 64), 0, s>>>(x, ldx, W, T, K, N, y, e);
+    const int kr = EPI == DEPI_RESID ? e.kslice : K;
+    if (kr == 32 * WAVES * KI) decode_linear_kernel<NT, MT, WAVES, KI, EPI, NORM, true, HALF><<<grid, dim3(WAVES * 64), 0, s>>>(x, ldx, W, T, K, N, y, e);
+    else decode_linear_kernel<NT, MT, WAVES, KI, EPI, NORM, false, HALF><<<grid, dim3(WAVES * 64), 0, s>>>(x, ldx, W, T, K, N, y, e);
 }
 
 // (waves, k-steps per wave) for a workgroup k range: the r01 geometry (8 waves at K = 1024, 16 at 2048, 4-wave k-slices)
@@ -334,11 +364,25 @@ int decode_splitk_slices(int64_t T, int64_t K, int64_t N) {
 // h[T,N] <- fp16(h + fp16(x[T,K]·W[N,K]ᵀ)); S k-slices, slabs [S][T][N] f32, cnt: one zeroed counter per (column tile, token tile)
 int linear_resid(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t N, int64_t S, float *slabs,
                  unsigned int *cnt, half_bits *h, hipStream_t s) {
-    if (S < 1 || K % (32 * S) || N % 16 || ldx % 8 || T > 64 || K / S > 2048)
+    if (S < 1 || S > 4 || K % (32 * S) || N % 16 || ldx % 8 || T > 64 || K / S > 2048)
         return nvr::fail(NVR_ERR_UNSUPPORTED, "linear_resid: K=%ld S=%ld N=%ld T=%ld ldx=%ld", (long)K, (long)S, (long)N, (long)T, (long)ldx);
     if (T == 0) return 0;
     DecEpi e{};
     e.kslice = (int32_t)(K / S); e.slab_stride = T * N; e.slabs = slabs; e.h = (half_t *)h; e.cnt = cnt;
+    static const bool half_tiles = [] { const char *v = std::getenv("NVR_RESID_HALF"); return v && v[0] == '1'; }();
+    if (half_tiles && N % 8 == 0 && K <= 4096) {
+        // 8-row weight tiles, 16 tokens per workgroup, no k split: N/8 x ceil(T/16) workgroups, no slabs, no tickets
+        e.kslice = (int32_t)K;
+        const unsigned gx8 = (unsigned)(N / 8);
+#define HBODY(WV, KI_) dec_launch<1, 1, WV, KI_, DEPI_RESID, false, true>((const half_t *)x, ldx, (const half_t *)W, (int)T, (int)K, (int)N, nullptr, e, gx8, 1, s)
+        if (K <= 512) HBODY(4, 4);
+        else if (K <= 1024) HBODY(8, 4);
+        else if (K <= 2048) HBODY(16, 4);
+        else if (K <= 3072) HBODY(16, 6);
+        else HBODY(16, 8);
+#undef HBODY
+        return dec_launch_check("linear_resid (half tiles)");
+    }
     const unsigned gx = (unsigned)(N / 16);
     const int64_t kr = K / S;
 #define BODY(WV, KI_)                                                                                                              \

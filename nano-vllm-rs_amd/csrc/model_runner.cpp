@@ -35,15 +35,7 @@ nvr_model_runner::~nvr_model_runner() {
     if (stream) hipStreamSynchronize(stream);
     for (auto &g : graphs) hipGraphExecDestroy(g.second);
     comm.destroy();
-    for (size_t i = 1; i < lanes.size(); ++i) {
-        Lane &ln = lanes[i];
-        void *ps[] = {ln.h, ln.n, ln.qkv, ln.attn, ln.proj, ln.act, ln.slabs, ln.attn_ws, ln.sync};
-        for (void *p : ps) if (p) hipFree(p);
-        if (ln.done) hipEventDestroy(ln.done);
-        if (ln.stream) hipStreamDestroy(ln.stream);
-    }
-    if (!lanes.empty() && lanes[0].sync) hipFree(lanes[0].sync);
-    if (fork_ev) hipEventDestroy(fork_ev);
+    if (chain_cnt) hipFree(chain_cnt);
     for (auto &l : layers) { hipFree(l.qkv); hipFree(l.o); hipFree(l.gate_up); hipFree(l.down); hipFree(l.ln1); hipFree(l.ln2); }
     void *ptrs[] = {embed, mc.tie_word_embeddings ? nullptr : lm_head, norm, cos_t, sin_t, kv_pool, h, n, qkv, attn,
                     proj, gu, act, nlast, logits, attn_ws, slabs, in_dev, d_tok, d_maxval, d_temp, d_topk, d_topp, d_keys,
@@ -100,8 +92,10 @@ int nvr_model_runner::init() {                                       // ModelRun
     RC(dmalloc(&act, max_tokens * I)); RC(dmalloc(&nlast, max_seqs * Hd)); RC(dmalloc(&logits, max_seqs * Vl));
     slab_rows = std::max<int64_t>(64, std::min<int64_t>(1024, std::max<int64_t>(max_seqs, 256)));
     RC(dmalloc(&slabs, 4 * slab_rows * Hd));
-    // measured slower than two launches (profiles/r01_fused_slabnorm_ablation.txt): opt-in only
-    { const char *e = getenv("NVR_FUSED_SLABNORM"); fused_slabnorm = e && e[0] == '1'; }
+    chain4 = cfg.decode_chain == 4;
+    if (const char *e = getenv("NVR_DECODE_CHAIN")) chain4 = e[0] == '4';              // A/B measurements of an unchanged caller
+    NVR_HIP_CHECK(hipMalloc((void **)&chain_cnt, 4096 * sizeof(unsigned int)));
+    NVR_HIP_CHECK(hipMemset(chain_cnt, 0, 4096 * sizeof(unsigned int)));
     { const char *e = getenv("NVR_TP_NO_COMM"); allow_missing_comm = e && e[0] == '1'; }   // compute-only profiling of one rank
     RC(k::linear_stream_prepare());
     RC(k::gemm_tiled_prepare());
@@ -115,27 +109,6 @@ int nvr_model_runner::init() {                                       // ModelRun
     // the split-KV workspace is sized for the largest bucket (launch_attn checks the bytes it is given)
     attn_ws_bytes = k::attn_workspace_bytes(max_seqs, H, D, (max_pos + 255) / 256 * 256);
     NVR_HIP_CHECK(hipMalloc(&attn_ws, attn_ws_bytes));
-    {
-        int nl = (int)cfg.decode_microbatches; if (nl < 1) nl = 1; if (nl > 4) nl = 4;
-        lanes.resize(nl);
-        Lane &l0 = lanes[0];
-        l0.stream = stream; l0.h = h; l0.n = n; l0.qkv = qkv; l0.attn = attn; l0.proj = proj; l0.act = act; l0.slabs = slabs; l0.attn_ws = attn_ws;
-        NVR_HIP_CHECK(hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming));
-        for (int i = 0; i < nl; ++i) {                                   // arrival counters of linear_splitk_norm
-            NVR_HIP_CHECK(hipMalloc((void **)&lanes[i].sync, 16));
-            NVR_HIP_CHECK(hipMemset(lanes[i].sync, 0, 16));
-        }
-        for (int i = 1; i < nl; ++i) {                                  // decode-sized twins of the activation set
-            Lane &ln = lanes[i];
-            NVR_HIP_CHECK(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
-            NVR_HIP_CHECK(hipEventCreateWithFlags(&ln.done, hipEventDisableTiming));
-            RC(dmalloc(&ln.h, max_seqs * Hd)); RC(dmalloc(&ln.n, max_seqs * Hd)); RC(dmalloc(&ln.qkv, max_seqs * QKV));
-            RC(dmalloc(&ln.attn, max_seqs * H * D)); RC(dmalloc(&ln.proj, max_seqs * Hd)); RC(dmalloc(&ln.act, max_seqs * I));
-            RC(dmalloc(&ln.slabs, 4 * slab_rows * Hd));
-            NVR_HIP_CHECK(hipMalloc(&ln.attn_ws, attn_ws_bytes));
-        }
-    }
-
     // step-input arena
     auto carve = [&](size_t &off, size_t bytes) { off = in_bytes; in_bytes += (bytes + 255) / 256 * 256; };
     carve(off_ids, max_tokens * 8); carve(off_pos, max_tokens * 8); carve(off_slots, max_tokens * 4);
@@ -328,17 +301,14 @@ int nvr_model_runner::copy_weight(const char *ln, uint16_t *out, size_t cap, int
 }
 
 // RowParallelLinear::forward (o_proj / down_proj, linear.rs:228-239) + the residual add and the next RMSNorm
-// (qwen3.rs:382-389).  Decode-sized steps on one GPU split k over S workgroups per output tile so that the
-// N = hidden GEMMs reach all 256 CUs; the f32 partial slabs are summed, added to the residual and normalised by the
-// following add_rmsnorm_slabs launch (or, with NVR_FUSED_SLABNORM=1, by the GEMM launch itself through an arrival
-// counter: same rounding points (normalised rows within 1 fp16 ulp), but the cross-XCD write-through + atomic + poll round trips cost ~5 us more than the
-// kernel boundary they replace).  Otherwise the
-// plain kernel writes fp16 `proj` (+ all-reduce when tensor parallel) and add_rmsnorm follows.
-int nvr_model_runner::row_parallel_norm(Lane &ln, const uint16_t *x, int64_t K, const uint16_t *W, int64_t T, const uint16_t *wn) {
+// (qwen3.rs:382-389) of the SIX-launch chain (prefill, tensor-parallel ranks, large models, NVR_DECODE_CHAIN=6): decode-sized
+// steps on one GPU split k over S workgroups per output tile so that the N = hidden GEMMs reach all 256 CUs; the f32 partial
+// slabs are summed, added to the residual and normalised by the following add_rmsnorm_slabs launch.  Otherwise the plain kernel
+// writes fp16 `proj` (+ all-reduce when tensor parallel) and add_rmsnorm follows.
+int nvr_model_runner::row_parallel_norm(const uint16_t *x, int64_t K, const uint16_t *W, int64_t T, const uint16_t *wn) {
     int64_t S = 1;
     if (!comm.active() && tp == 1 && T <= 64 && Hd <= 2048) {
-        const int64_t tiles = (Hd / 16) * ((T + 31) / 32);
-        while (S < 4 && tiles * S < 256 && K % (32 * S * 2) == 0 && K / (S * 2) >= 128) S *= 2;
+        S = k::decode_splitk_slices(T, K, Hd);
     } else if (!comm.active() && tp == 1 && T <= 32 && Hd <= 8192 && Hd % 64 == 0 && Hd * K * 2 >= (24ll << 20) && K % 128 == 0) {
         S = 4;                                       // large weights: 64-column workgroups x 4 k-slices (linear_splitk)
     } else if (!comm.active() && tp == 1 && T > 128 && T <= slab_rows && Hd <= 8192 && ((Hd + 127) / 128) * ((T + 127) / 128) <= 64 &&
@@ -346,85 +316,86 @@ int nvr_model_runner::row_parallel_norm(Lane &ln, const uint16_t *x, int64_t K, 
         S = 4;                                       // 129..1024 rows, few 128x128 tiles: k-split of the tiled kernel (gemm_tiled_splitk;
                                                      // bs = 256 / 512 decode 4.04 -> 3.67 / 6.18 -> 5.33 ms; at 128 rows the streaming kernel still wins)
     }
-    if (S > 1 && fused_slabnorm && T <= 64)
-        return k::linear_splitk_norm(x, K, W, T, K, Hd, S, ln.slabs, ln.h, wn, mc.rms_norm_eps, ln.n, ln.sync, ln.stream);
     if (S > 1) {
-        RC(k::linear_splitk(x, K, W, T, K, Hd, S, ln.slabs, ln.stream));
-        return k::add_rmsnorm_slabs(ln.h, ln.slabs, S, wn, mc.rms_norm_eps, T, Hd, ln.n, ln.stream);
+        RC(k::linear_splitk(x, K, W, T, K, Hd, S, slabs, stream));
+        return k::add_rmsnorm_slabs(h, slabs, S, wn, mc.rms_norm_eps, T, Hd, n, stream);
     }
-    RC(k::linear(x, K, W, T, K, Hd, ln.proj, false, ln.stream));
-    if (comm.active()) RC(comm.all_reduce_sum_f16(ln.proj, (size_t)(T * Hd), ln.stream));  // linear.rs:236-238
-    return k::add_rmsnorm(ln.h, ln.proj, wn, mc.rms_norm_eps, T, Hd, ln.n, ln.stream);
+    RC(k::linear(x, K, W, T, K, Hd, proj, false, stream));
+    if (comm.active()) RC(comm.all_reduce_sum_f16(proj, (size_t)(T * Hd), stream));  // linear.rs:236-238
+    return k::add_rmsnorm(h, proj, wn, mc.rms_norm_eps, T, Hd, n, stream);
+}
+
+// The four-launch decode chain (kernels/linear_decode.hip) runs single-rank decode-sized steps of models whose hidden rows fit
+// the norm-prologue kernels; everything else (prefill, tensor-parallel ranks with their all-reduce between GEMM and residual,
+// Qwen3-8B-class weights with their streaming kernels) keeps the six-launch chain.
+bool nvr_model_runner::use_chain4(int64_t T, bool is_prefill) const {
+    return chain4 && !is_prefill && tp == 1 && !comm.active() && k::decode_chain_ok(T, Hd, QKV, I, D) &&
+           H * D <= 4096 && I <= 8192 && Hd * std::max(H * D, I) * 2 < (24ll << 20);
 }
 
 // Qwen3Model::forward, src/models/qwen3.rs:487-505; layer wiring :372-392; attention :208-240; MLP :305-314.
-// Rows [row0, row0+T) of the step inputs (B sequences) run on lane `ln`.
-int nvr_model_runner::forward(Lane &ln, int64_t row0, int64_t T, int64_t B, bool is_prefill, int64_t max_ctx) {
-    hipStream_t st = ln.stream;
-    const int64_t *ids = (is_prefill ? d_ids : dd_ids) + row0, *pos = (is_prefill ? d_pos : dd_pos) + row0;
-    const int32_t *slots = (is_prefill ? d_slots : dd_slots) + row0, *ctx = (is_prefill ? d_ctx : dd_ctx) + row0;
-    const int32_t *bt = dd_bt + row0 * max_blocks_per_seq;
-    const bool embed_norm = L > 0 && k::embedding_rmsnorm_ok(T, Hd);                          // decode-sized: K1 + the first norm in one launch
-    if (embed_norm) RC(k::embedding_rmsnorm(ids, T, embed, layers[0].ln1, mc.rms_norm_eps, Hd, ln.h, ln.n, st));
-    else RC(k::embedding(ids, T, embed, Hd, ln.h, st));
+int nvr_model_runner::forward(int64_t T, int64_t B, bool is_prefill, int64_t max_ctx) {
+    hipStream_t st = stream;
+    const int64_t *ids = is_prefill ? d_ids : dd_ids, *pos = is_prefill ? d_pos : dd_pos;
+    const int32_t *slots = is_prefill ? d_slots : dd_slots, *ctx = is_prefill ? d_ctx : dd_ctx;
+    const int32_t *bt = dd_bt;
+    const bool c4 = use_chain4(T, is_prefill);
+    const bool embed_norm = !c4 && L > 0 && k::embedding_rmsnorm_ok(T, Hd);                    // decode-sized: K1 + the first norm in one launch
+    if (embed_norm) RC(k::embedding_rmsnorm(ids, T, embed, layers[0].ln1, mc.rms_norm_eps, Hd, h, n, st));
+    else RC(k::embedding(ids, T, embed, Hd, h, st));
     for (int64_t l = 0; l < L; ++l) {
         const Layer &w = layers[l];
-        if (l == 0 && !embed_norm) RC(k::rmsnorm(ln.h, w.ln1, mc.rms_norm_eps, T, Hd, ln.n, st));   // later layers: see down_proj
-        // qkv GEMM with the RoPE + KV-store epilogue (K3..K6 in one launch)
-        RC(k::linear_qkv_rope_store(ln.n, Hd, w.qkv, T, Hd, H, KVH, D, pos, slots, cos_t, sin_t, ln.qkv, k_cache(l), v_cache(l), st));
+        if (c4) {                                    // input norm :378 in the prologue of the qkv GEMM (K2..K6 in one launch)
+            RC(k::linear_qkv_rope_store_normed(h, Hd, w.ln1, mc.rms_norm_eps, w.qkv, T, Hd, H, KVH, D, pos, slots, cos_t, sin_t, qkv,
+                                               k_cache(l), v_cache(l), st));
+        } else {
+            if (l == 0 && !embed_norm) RC(k::rmsnorm(h, w.ln1, mc.rms_norm_eps, T, Hd, n, st));   // later layers: see down_proj
+            // qkv GEMM with the RoPE + KV-store epilogue (K3..K6 in one launch)
+            RC(k::linear_qkv_rope_store(n, Hd, w.qkv, T, Hd, H, KVH, D, pos, slots, cos_t, sin_t, qkv, k_cache(l), v_cache(l), st));
+        }
         k::AttnArgs a{};
-        a.q = ln.qkv; a.ldq = QKV; a.ctx_lens = ctx; a.nq = (int32_t)T; a.H = (int32_t)H; a.KVH = (int32_t)KVH; a.D = (int32_t)D;
-        a.scale = scale; a.max_ctx = (int32_t)max_ctx; a.out = ln.attn;
+        a.q = qkv; a.ldq = QKV; a.ctx_lens = ctx; a.nq = (int32_t)T; a.H = (int32_t)H; a.KVH = (int32_t)KVH; a.D = (int32_t)D;
+        a.scale = scale; a.max_ctx = (int32_t)max_ctx; a.out = attn;
         if (is_prefill && n_tiles > 0) {                             // flash_attention_varlen, attention.rs:177-208 (MFMA)
             k::FlashArgs f{};
-            f.q = ln.qkv; f.ldq = QKV;
+            f.q = qkv; f.ldq = QKV;
             if (prefill_paged) {                                     // cached prefixes: K/V through the block tables (K8)
                 f.k = k_cache(l); f.v = v_cache(l); f.block_tables = dd_bt; f.max_blocks = (int32_t)max_blocks_per_seq;
                 f.block_size = (int32_t)block_size;
-            } else { f.k = ln.qkv + H * D; f.v = ln.qkv + (H + KVH) * D; f.ldkv = QKV; }
+            } else { f.k = qkv + H * D; f.v = qkv + (H + KVH) * D; f.ldkv = QKV; }
             f.tiles = (const k::FlashTile *)(in_dev + off_tiles); f.ntiles = (int32_t)n_tiles;
-            f.H = (int32_t)H; f.KVH = (int32_t)KVH; f.D = (int32_t)D; f.scale = scale; f.out = ln.attn;
+            f.H = (int32_t)H; f.KVH = (int32_t)KVH; f.D = (int32_t)D; f.scale = scale; f.out = attn;
             RC(k::flash_prefill(f, prefill_paged, st));
         } else if (is_prefill) {                                     // head shapes outside the MFMA kernel: row kernel
-            a.k = ln.qkv + H * D; a.v = ln.qkv + (H + KVH) * D; a.ldkv = QKV; a.kv_base = d_kvbase; a.workspace = nullptr;
+            a.k = qkv + H * D; a.v = qkv + (H + KVH) * D; a.ldkv = QKV; a.kv_base = d_kvbase; a.workspace = nullptr;
             RC(k::attention(a, false, st));
         } else {                                                     // flash_attention_decode, attention.rs:225-235
             a.k = k_cache(l); a.v = v_cache(l); a.block_tables = bt; a.max_blocks = (int32_t)max_blocks_per_seq;
-            a.block_size = (int32_t)block_size; a.workspace = ln.attn_ws; a.workspace_bytes = attn_ws_bytes;
+            a.block_size = (int32_t)block_size; a.workspace = attn_ws; a.workspace_bytes = attn_ws_bytes;
             RC(k::attention(a, true, st));
         }
-        RC(row_parallel_norm(ln, ln.attn, H * D, w.o, T, w.ln2));                            // o_proj, residual :382, norm :385
-        RC(k::linear_silu_mul(ln.n, Hd, w.gate_up, T, Hd, I, ln.act, st));                   // K12 + K13 in one launch
-        // down_proj, residual :389 and the NEXT layer's input norm :378 (or the final norm :501)
-        RC(row_parallel_norm(ln, ln.act, I, w.down, T, l + 1 < L ? layers[l + 1].ln1 : norm));
+        if (c4) {
+            // o_proj + residual :382 (the split-k reduction's last arriver adds h); post-attention norm :385 in the prologue of
+            // gate_up + SiluAndMul; down_proj + residual :389.  The next layer's input norm is the next qkv launch's prologue.
+            RC(k::linear_resid(attn, H * D, w.o, T, H * D, Hd, k::decode_splitk_slices(T, H * D, Hd), slabs, chain_cnt, h, st));
+            RC(k::linear_silu_mul_normed(h, Hd, w.ln2, mc.rms_norm_eps, w.gate_up, T, Hd, I, act, st));
+            RC(k::linear_resid(act, I, w.down, T, I, Hd, k::decode_splitk_slices(T, I, Hd), slabs, chain_cnt, h, st));
+        } else {
+            RC(row_parallel_norm(attn, H * D, w.o, T, w.ln2));                                // o_proj, residual :382, norm :385
+            RC(k::linear_silu_mul(n, Hd, w.gate_up, T, Hd, I, act, st));                      // K12 + K13 in one launch
+            // down_proj, residual :389 and the NEXT layer's input norm :378 (or the final norm :501)
+            RC(row_parallel_norm(act, I, w.down, T, l + 1 < L ? layers[l + 1].ln1 : norm));
+        }
     }
-    const uint16_t *hl = ln.n;
-    if (is_prefill) { RC(k::select_last_tokens(ln.n, d_cu, B, Hd, nlast, st)); hl = nlast; }   // embed_head.rs:272-289
+    if (c4 || L == 0) RC(k::rmsnorm(h, norm, mc.rms_norm_eps, T, Hd, n, st));                  // final norm :501
+    const uint16_t *hl = n;
+    if (is_prefill) { RC(k::select_last_tokens(n, d_cu, B, Hd, nlast, st)); hl = nlast; }      // embed_head.rs:272-289
     if (lm_parts > 0) {                                                                        // f32 logits (A-21) + arg-max partials
         int32_t np = 0;
         RC(k::lm_head(hl, Hd, lm_head, B, Hd, Vl, logits, d_lm_pval, d_lm_pidx, &np, st, want_logits));
         if (np != lm_parts) return nvr::fail(NVR_ERR_INVARIANT, "lm_head produced %d partials, planned %d", np, lm_parts);
     } else {
-        RC(k::linear(hl, Hd, lm_head, B, Hd, Vl, logits + row0 * Vl, true, st));
-    }
-    return NVR_OK;
-}
-
-// One step over nl lanes: rows are cut into nl contiguous slices; lanes 1.. fork from and join into lane 0's
-// stream (capturable: the same code builds the hipGraph's parallel branches).
-int nvr_model_runner::forward_all(int64_t T, int64_t B, bool is_prefill, int64_t max_ctx, int nl) {
-    if (nl <= 1 || is_prefill) return forward(lanes[0], 0, T, B, is_prefill, max_ctx);
-    NVR_HIP_CHECK(hipEventRecord(fork_ev, stream));
-    for (int i = 1; i < nl; ++i) NVR_HIP_CHECK(hipStreamWaitEvent(lanes[i].stream, fork_ev, 0));
-    const int64_t per = (B + nl - 1) / nl;
-    for (int i = 0; i < nl; ++i) {
-        const int64_t r0 = i * per, cnt = std::min<int64_t>(per, B - r0);
-        if (cnt <= 0) continue;
-        RC(forward(lanes[i], r0, cnt, cnt, false, max_ctx));
-    }
-    for (int i = 1; i < nl; ++i) {
-        NVR_HIP_CHECK(hipEventRecord(lanes[i].done, lanes[i].stream));
-        NVR_HIP_CHECK(hipStreamWaitEvent(stream, lanes[i].done, 0));
+        RC(k::linear(hl, Hd, lm_head, B, Hd, Vl, logits, true, st));
     }
     return NVR_OK;
 }
@@ -542,68 +513,42 @@ int nvr_model_runner::execute(nvr_seq *const *seqs, size_t nseq, bool is_prefill
     last_rows = nseq; last_prefill = is_prefill; last_tokens = T;
     // arg-max partials come with the logits when the whole batch goes through one lm_head launch (a pure function of
     // the shapes, so a replayed graph and this bookkeeping always agree)
-    const int nl = (!is_prefill && (int64_t)nseq >= 8 * (int64_t)lanes.size()) ? (int)lanes.size() : 1;
-    lm_parts = (lm_fused && (is_prefill || nl == 1)) ? k::lm_head_parts((int64_t)nseq, Hd, Vl, Hd) : 0;
+    lm_parts = lm_fused ? k::lm_head_parts((int64_t)nseq, Hd, Vl, Hd) : 0;
     // a batch that samples greedily everywhere takes its tokens from the arg-max partials: the f32 logits are then written
     // only on demand (ensure_logits: execute_model callers that ask for them, copy_logits)
     want_logits = !lazy_logits || lm_parts == 0;
     for (size_t i = 0; i < nseq && !want_logits; ++i) want_logits = seqs[i]->sampling.temperature != 0.0f;
     logits_valid = want_logits;
-    lm_input = is_prefill ? nlast : lanes[0].n;                          // the rows the LM head reads this step (forward())
-    if (is_prefill || cfg.enforce_eager || graphs_disabled) return forward_all(T, (int64_t)nseq, is_prefill, max_ctx, nl);
+    lm_input = is_prefill ? nlast : n;                                   // the rows the LM head reads this step (forward())
+    if (is_prefill || cfg.enforce_eager || graphs_disabled) return forward(T, (int64_t)nseq, is_prefill, max_ctx);
 
     // decode: replay a hipGraph captured per (batch size, context bucket) — execute_with_cuda_graph :303-326
     const int64_t bucket = (max_ctx + 255) / 256 * 256;
-    auto get_graph = [&](uint64_t key, hipStream_t cap, auto &&body, hipGraphExec_t *out) -> int {
-        auto it = graphs.find(key);
-        if (it == graphs.end()) {
-            if (graphs.size() >= kMaxGraphs) {               // a long-lived engine sees many (batch size, bucket) pairs: bound the cache
-                NVR_HIP_CHECK(hipStreamSynchronize(stream));
-                for (auto &kv : graphs) hipGraphExecDestroy(kv.second);
-                graphs.clear();
-            }
-            hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr;
-            NVR_HIP_CHECK(hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal));
-            int rc = body();
-            hipError_t e = hipStreamEndCapture(cap, &g);
-            if (rc) { if (g) hipGraphDestroy(g); return rc; }
-            if (e != hipSuccess) return nvr::fail(NVR_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
-            NVR_HIP_CHECK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
-            hipGraphDestroy(g);
-            it = graphs.emplace(key, ge).first;
+    const uint64_t key = ((uint64_t)want_logits << 60) | ((uint64_t)nseq << 32) | (uint64_t)bucket;
+    auto it = graphs.find(key);
+    if (it == graphs.end()) {
+        if (graphs.size() >= kMaxGraphs) {               // a long-lived engine sees many (batch size, bucket) pairs: bound the cache
+            NVR_HIP_CHECK(hipStreamSynchronize(stream));
+            for (auto &kv : graphs) hipGraphExecDestroy(kv.second);
+            graphs.clear();
         }
-        *out = it->second;
-        return NVR_OK;
-    };
-    if (nl <= 1) {
-        hipGraphExec_t ge;
-        int rc = get_graph(((uint64_t)want_logits << 60) | ((uint64_t)nseq << 32) | (uint64_t)bucket, stream, [&] { return forward(lanes[0], 0, T, T, false, bucket); }, &ge);
-        if (rc && comm.active()) {            // a graph holding RCCL nodes could not be built on this stack: run eagerly
+        hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr;
+        NVR_HIP_CHECK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+        int rc = forward(T, T, false, bucket);
+        hipError_t e = hipStreamEndCapture(stream, &g);
+        if (!rc && e != hipSuccess) rc = nvr::fail(NVR_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
+        if (!rc && hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) != hipSuccess) rc = nvr::fail(NVR_ERR_HIP, "hipGraphInstantiate failed");
+        if (g) hipGraphDestroy(g);
+        if (rc && comm.active()) {            // a graph holding collective nodes could not be built on this stack: run eagerly
             graphs_disabled = true;
             (void)hipGetLastError();
-            return forward_all(T, (int64_t)nseq, false, max_ctx, 1);
+            return forward(T, (int64_t)nseq, false, max_ctx);
         }
         if (rc) return rc;
-        last_decode_graph = ge;
-        NVR_HIP_CHECK(hipGraphLaunch(ge, stream));
-        return NVR_OK;
+        it = graphs.emplace(key, ge).first;
     }
-    // micro-batches: one graph per lane, launched on the lane's own stream between a fork and a join event
-    const int64_t per = ((int64_t)nseq + nl - 1) / nl;
-    NVR_HIP_CHECK(hipEventRecord(fork_ev, stream));
-    for (int i = 0; i < nl; ++i) {
-        const int64_t r0 = i * per, cnt = std::min<int64_t>(per, (int64_t)nseq - r0);
-        if (cnt <= 0) continue;
-        hipGraphExec_t ge;
-        const uint64_t key = ((uint64_t)(i + 1) << 56) | ((uint64_t)r0 << 44) | ((uint64_t)cnt << 32) | (uint64_t)bucket;
-        RC(get_graph(key, lanes[i].stream, [&] { return forward(lanes[i], r0, cnt, cnt, false, bucket); }, &ge));
-        if (i > 0) NVR_HIP_CHECK(hipStreamWaitEvent(lanes[i].stream, fork_ev, 0));
-        NVR_HIP_CHECK(hipGraphLaunch(ge, lanes[i].stream));
-        if (i > 0) {
-            NVR_HIP_CHECK(hipEventRecord(lanes[i].done, lanes[i].stream));
-            NVR_HIP_CHECK(hipStreamWaitEvent(stream, lanes[i].done, 0));
-        }
-    }
+    last_decode_graph = it->second;
+    NVR_HIP_CHECK(hipGraphLaunch(it->second, stream));
     return NVR_OK;
 }
 

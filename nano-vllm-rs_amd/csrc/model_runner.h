@@ -53,17 +53,9 @@ struct nvr_model_runner {
     float *d_gather_val = nullptr; int64_t *d_gather_idx = nullptr;
     float *d_gather_logits = nullptr, *d_full_logits = nullptr; void *sample_ws_full = nullptr;   // stochastic sampling under TP (lazy)
 
-    // Decode micro-batching: the batch rows are cut into `lanes` slices that run the whole layer stack
-    // concurrently on their own streams (forked and joined inside the captured graph).  A decode step is a
-    // chain of ~200 short kernels whose fixed launch/drain latency, not HBM bandwidth, bounds the step
-    // (profiles/r01_decode_step_breakdown_v2.txt); two independent chains fill each other's bubbles.
-    struct Lane {
-        hipStream_t stream = nullptr; hipEvent_t done = nullptr;
-        uint16_t *h = nullptr, *n = nullptr, *qkv = nullptr, *attn = nullptr, *proj = nullptr, *act = nullptr;
-        float *slabs = nullptr; void *attn_ws = nullptr; unsigned int *sync = nullptr;
-    };
-    std::vector<Lane> lanes;
-    hipEvent_t fork_ev = nullptr;
+    // decode chain (kernels/linear_decode.hip): one ticket counter per (column tile, token tile) of the row-parallel GEMMs
+    unsigned int *chain_cnt = nullptr;
+    bool chain4 = false;                   // nvr_config.decode_chain == 4 (or NVR_DECODE_CHAIN=4): the four-launch chain of linear_decode.hip
     std::map<uint64_t, hipGraphExec_t> graphs;
     size_t last_rows = 0; bool last_prefill = false; int64_t last_tokens = 0;
     nvr::Comm comm;
@@ -77,7 +69,7 @@ struct nvr_model_runner {
     // device weights (dtype 0 = f16, 1 = bf16, 2 = f32); copy_weight reads a local tensor back (tests)
     int load_tensor(const char *name, int dtype, const int64_t *shape, int ndim, const void *data);
     int copy_weight(const char *local_name, uint16_t *host_out, size_t cap, int64_t *rows, int64_t *cols);
-    void *last_decode_graph = nullptr;   // hipGraphExec_t of the last single-lane decode step
+    void *last_decode_graph = nullptr;   // hipGraphExec_t of the last decode step
     int replay_last_decode_graph(int n); // diagnostic: launch chain without the host gap (nvr_runner_replay_last_decode_graph)
     int ensure_logits();                                 // materialise the last step's f32 logits if it skipped their stores
     int sample(nvr_seq *const *seqs, size_t nseq, int64_t *out);
@@ -85,14 +77,13 @@ struct nvr_model_runner {
     uint16_t *v_cache(size_t l) { return kv_pool + (2 * l + 1) * kv_layer_elems; }
 
 private:
-    int forward(Lane &ln, int64_t row0, int64_t T, int64_t B, bool is_prefill, int64_t max_ctx);
-    int forward_all(int64_t T, int64_t B, bool is_prefill, int64_t max_ctx, int nl);
+    int forward(int64_t T, int64_t B, bool is_prefill, int64_t max_ctx);
     int gen_weights();
-    int row_parallel_norm(Lane &ln, const uint16_t *x, int64_t K, const uint16_t *W, int64_t T, const uint16_t *wn);
+    int row_parallel_norm(const uint16_t *x, int64_t K, const uint16_t *W, int64_t T, const uint16_t *wn);
+    bool use_chain4(int64_t T, bool is_prefill) const;
     static constexpr size_t kMaxGraphs = 256;            // captured decode graphs kept before the cache is flushed
     int64_t *h_tok_dev = nullptr;                        // device-visible address of the pinned token buffer h_tok
     int64_t slab_rows = 64;           // rows the split-k slab buffers hold (row_parallel_norm)
-    bool fused_slabnorm = false;
     bool prefill_paged = false;                          // this prefill step skips cached prefixes (K/V via block tables)
     bool lazy_logits = true, want_logits = true, logits_valid = true; const uint16_t *lm_input = nullptr;
     bool lm_fused = true; int32_t lm_parts = 0;          // lm_head arg-max partials of the last step (0: none)

@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <initializer_list>
 #include <new>
 #include "common.h"
 #include "engine.h"
@@ -23,6 +24,7 @@ float nvr_weight_scale_impl(double std);
 extern "C" {
 
 const char *nvr_last_error(void) { return nvr::last_error_slot().c_str(); }
+int nvr_last_status(void) { return nvr::last_status_slot(); }
 const char *nvr_version(void) { return "nano-vllm-rs_amd 0.1 (gfx950)"; }
 
 // ------------------------------------------------------------------ params / config
@@ -43,6 +45,20 @@ void nvr_config_default(nvr_config *c) {                             // config.r
     c->max_num_batched_tokens = 32768; c->max_num_seqs = 512; c->max_model_len = 4096;
     c->gpu_memory_utilization = 0.9f; c->tensor_parallel_size = 1; c->enforce_eager = 0;
     c->has_eos = 0; c->kvcache_block_size = 256; c->num_kvcache_blocks = -1;
+    std::strcpy(c->device, "hip"); std::strcpy(c->dtype, "float16");     // config.rs:67-68 ("cuda" there)
+}
+static bool cfg_str_in(const char *v, size_t cap, std::initializer_list<const char *> set) {
+    if (!std::memchr(v, 0, cap)) return false;
+    for (const char *s : set) if (!std::strcmp(v, s)) return true;
+    return false;
+}
+// a runner / engine can be built for this config (the HIP path, fp16): validate() only checks the names, like the reference
+static int nvr_config_runnable(const nvr_config *c) {
+    if (!cfg_str_in(c->device, sizeof c->device, {"hip", "cuda"}))
+        return nvr::fail(NVR_ERR_UNSUPPORTED, "device '%s': this library is the MI355X (HIP) path; there is no CPU or Metal path", c->device);
+    if (std::strcmp(c->dtype, "float16") != 0)
+        return nvr::fail(NVR_ERR_UNSUPPORTED, "dtype '%s': the kernels compute on fp16 storage with f32 accumulation (bf16 / f32 checkpoints are converted on load)", c->dtype);
+    return NVR_OK;
 }
 int nvr_config_validate(const nvr_config *c) {                       // config.rs:83-119 (model_path checks n/a)
     if (!c->skip_block_size_check && c->kvcache_block_size % 256 != 0)
@@ -52,6 +68,12 @@ int nvr_config_validate(const nvr_config *c) {                       // config.r
         return nvr::fail(NVR_ERR_INVALID_ARG, "Tensor parallel size must be between 1 and 8, got %lu", (unsigned long)c->tensor_parallel_size);
     if (!(c->gpu_memory_utilization >= 0.0f && c->gpu_memory_utilization <= 1.0f))
         return nvr::fail(NVR_ERR_INVALID_ARG, "GPU memory utilization must be between 0.0 and 1.0, got %g", c->gpu_memory_utilization);
+    if (!cfg_str_in(c->device, sizeof c->device, {"hip", "cuda", "cpu", "metal"}))                       // config.rs:108-111 (+ "hip")
+        return nvr::fail(NVR_ERR_INVALID_ARG, "Unsupported device: %.15s", c->device);
+    if (!cfg_str_in(c->dtype, sizeof c->dtype, {"float16", "bfloat16", "float32"}))                      // config.rs:113-116
+        return nvr::fail(NVR_ERR_INVALID_ARG, "Unsupported dtype: %.15s", c->dtype);
+    if (c->decode_chain != 0 && c->decode_chain != 4 && c->decode_chain != 6)
+        return nvr::fail(NVR_ERR_INVALID_ARG, "decode_chain must be 0, 4 or 6, got %u", c->decode_chain);
     return NVR_OK;
 }
 void nvr_model_config_default(nvr_model_config *m) {                 // qwen3.rs:70-89
@@ -180,7 +202,7 @@ size_t nvr_sched_take_finished(nvr_scheduler_t *sc, nvr_seq_t **out, size_t cap)
 // ------------------------------------------------------------------ ModelRunner
 nvr_model_runner_t *nvr_runner_create(const nvr_config *cfg, const nvr_model_config *mc) {
     NVR_GUARD_BEGIN
-    if (nvr_config_validate(cfg)) return nullptr;
+    if (nvr_config_validate(cfg) || nvr_config_runnable(cfg)) return nullptr;
     nvr_model_runner *r = new nvr_model_runner();
     r->cfg = *cfg; r->mc = *mc;
     if (r->init() != NVR_OK) { delete r; return nullptr; }
@@ -257,7 +279,7 @@ int nvr_runner_init_comm_local(nvr_model_runner_t *r, nvr_local_group_t *g) {
 // ------------------------------------------------------------------ Engine
 nvr_engine_t *nvr_engine_create(const nvr_config *cfg, const nvr_model_config *mc) {
     NVR_GUARD_BEGIN
-    if (nvr_config_validate(cfg)) return nullptr;
+    if (nvr_config_validate(cfg) || nvr_config_runnable(cfg)) return nullptr;
     std::unique_ptr<nvr_engine> e(new nvr_engine());
     e->cfg = *cfg;
     e->runner.reset(nvr_runner_create(cfg, mc));
@@ -420,6 +442,20 @@ int nvr_event_elapsed_ms(void *a, void *b, float *ms) {
     NVR_HIP_CHECK(hipEventElapsedTime(ms, (hipEvent_t)a, (hipEvent_t)b));
     return NVR_OK;
 }
+// hipGraph capture of the stateless ops below on a caller stream (measurement harnesses: a chain of ops replayed with the
+// kernel boundaries of the engine's captured decode step, without a host launch per kernel)
+int nvr_graph_capture_begin(void *s) { NVR_HIP_CHECK(hipStreamBeginCapture((hipStream_t)s, hipStreamCaptureModeThreadLocal)); return NVR_OK; }
+int nvr_graph_capture_end(void *s, void **exec) {
+    hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr;
+    NVR_HIP_CHECK(hipStreamEndCapture((hipStream_t)s, &g));
+    hipError_t e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+    hipGraphDestroy(g);
+    if (e != hipSuccess) return nvr::fail(NVR_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e));
+    *exec = ge;
+    return NVR_OK;
+}
+int nvr_graph_launch(void *exec, void *s) { NVR_HIP_CHECK(hipGraphLaunch((hipGraphExec_t)exec, (hipStream_t)s)); return NVR_OK; }
+int nvr_graph_destroy(void *exec) { NVR_HIP_CHECK(hipGraphExecDestroy((hipGraphExec_t)exec)); return NVR_OK; }
 
 // ------------------------------------------------------------------ stateless ops
 int nvr_embedding(const int64_t *ids, int64_t T, const nvr_half *E, int64_t Hd, nvr_half *out, void *s) {
@@ -449,9 +485,19 @@ int nvr_linear_splitk(const nvr_half *x, int64_t ldx, const nvr_half *W, int64_t
 int nvr_add_rmsnorm_slabs(nvr_half *h, const float *slabs, int64_t S, const nvr_half *w, float eps, int64_t T, int64_t Hd, nvr_half *out, void *s) {
     return k::add_rmsnorm_slabs(h, slabs, S, w, eps, T, Hd, out, (hipStream_t)s);
 }
-int nvr_linear_splitk_norm(const nvr_half *x, int64_t ldx, const nvr_half *W, int64_t T, int64_t K, int64_t N, int64_t S, float *slabs,
-                           nvr_half *h, const nvr_half *wn, float eps, nvr_half *out, uint32_t *sync, void *s) {
-    return k::linear_splitk_norm(x, ldx, W, T, K, N, S, slabs, h, wn, eps, out, sync, (hipStream_t)s);
+int nvr_linear_resid(const nvr_half *x, int64_t ldx, const nvr_half *W, int64_t T, int64_t K, int64_t N, int64_t S, float *slabs,
+                     uint32_t *counters, nvr_half *h, void *s) {
+    return k::linear_resid(x, ldx, W, T, K, N, S, slabs, counters, h, (hipStream_t)s);
+}
+int nvr_decode_splitk_slices(int64_t T, int64_t K, int64_t N) { return k::decode_splitk_slices(T, K, N); }
+int nvr_linear_silu_mul_normed(const nvr_half *h, int64_t ldx, const nvr_half *wn, float eps, const nvr_half *W, int64_t T, int64_t K,
+                               int64_t I, nvr_half *out, void *s) {
+    return k::linear_silu_mul_normed(h, ldx, wn, eps, W, T, K, I, out, (hipStream_t)s);
+}
+int nvr_linear_qkv_rope_store_normed(const nvr_half *h, int64_t ldx, const nvr_half *wn, float eps, const nvr_half *W, int64_t T, int64_t K,
+                                     int64_t H, int64_t KVH, int64_t D, const int64_t *pos, const int32_t *slots, const float *cos_t,
+                                     const float *sin_t, nvr_half *qkv, nvr_half *kc, nvr_half *vc, void *s) {
+    return k::linear_qkv_rope_store_normed(h, ldx, wn, eps, W, T, K, H, KVH, D, pos, slots, cos_t, sin_t, qkv, kc, vc, (hipStream_t)s);
 }
 int nvr_linear_silu_mul(const nvr_half *x, int64_t ldx, const nvr_half *W, int64_t T, int64_t K, int64_t I, nvr_half *out, void *s) {
     return k::linear_silu_mul(x, ldx, W, T, K, I, out, (hipStream_t)s);

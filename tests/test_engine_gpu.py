@@ -513,3 +513,53 @@ def test_graph_decode_small_max_model_len_full_batch(mml):
     g = _run_pair(mcfg, ecfg, prompts, sps)
     e = _run_pair(mcfg, ecfg, prompts, sps, enforce_eager=True)
     assert g["finished"] == e["finished"] and g["near_ties"] <= 2
+
+
+def test_four_launch_decode_chain_engine_parity():
+    """nvr_config.decode_chain = 4 (kernels/linear_decode.hip: norms in the GEMM prologues, residual adds on the split-k
+    reductions) against the oracle engine, and against the default six-launch chain: the greedy token streams of the two chains
+    are identical outside numerical near-ties (their normalised rows may differ by 1 fp16 ulp), hipGraph and eager alike."""
+    mcfg = mo.small()
+    ecfg = dict(max_num_seqs=8, max_num_batched_tokens=512, max_model_len=512, kvcache_block_size=16, num_kvcache_blocks=64)
+    prompts = [oracle.fill_tokens(n, 1, i, mcfg.vocab_size).tolist() for i, n in enumerate([5, 16, 17, 40, 1, 33])]
+    sps = [dict(temperature=0.0, max_tokens=20, ignore_eos=True)] * len(prompts)
+
+    def run(chain, eager):
+        eo.reset_sequence_counter(); nvr.lib().nvr_seq_reset_id_counter()
+        o = mo.OracleEngine(mcfg, eo.Config(**ecfg), fp16=True, max_pos=ecfg["max_model_len"])
+        p = nvr.LLMEngine(nvr.Config(skip_block_size_check=1, decode_chain=chain, enforce_eager=eager, **ecfg), _model_cfgs(mcfg))
+        for pr, sp in zip(prompts, sps):
+            o.add_request(pr, eo.SamplingParams(**sp)); p.add_request(pr, nvr.SamplingParams(**sp))
+        ties, worst = 0, 0.0
+        while not p.is_finished():
+            rec = p.step()
+            logits = p.model_runner.logits(rec["num_seqs"])
+            orec = o.step(forced_tokens=rec["tokens"])
+            assert orec["seq_ids"] == rec["seq_ids"]
+            worst = max(worst, float(np.abs(logits - orec["logits"]).max()))
+            srt = np.sort(orec["logits"], axis=1)
+            for i, (a, b) in enumerate(zip(rec["tokens"], orec["tokens"])):
+                if a != b:
+                    assert srt[i, -1] - srt[i, -2] <= 2 * LOGIT_TOL
+                    ties += 1
+        assert worst < LOGIT_TOL, worst
+        return {s.seq_id: s.token_ids for s in p.take_finished()}, ties
+    g4, t4 = run(4, False)
+    e4, _ = run(4, True)
+    g6, t6 = run(6, False)
+    assert g4 == e4 and t4 <= 2 and t6 <= 2
+    same = sum(g4[k] == g6[k] for k in g4)
+    assert same >= len(g4) - 1, (same, len(g4))          # a near-tie may send one sequence down another path
+
+
+def test_config_device_and_dtype_gate_the_runner():
+    """Config.device / Config.dtype (config.rs:48-51): the names validate like the reference's; a runner exists only for the
+    HIP device and fp16 — anything else fails loudly instead of falling back."""
+    mcfg = mo.small()
+    base = dict(skip_block_size_check=1, max_num_seqs=2, max_num_batched_tokens=64, max_model_len=64, kvcache_block_size=16, num_kvcache_blocks=4)
+    for ok in (dict(), dict(device="cuda"), dict(device="hip", dtype="float16")):
+        nvr.ModelRunner(nvr.Config(**base, **ok), _model_cfgs(mcfg))
+    for bad in (dict(device="cpu"), dict(device="metal"), dict(dtype="bfloat16"), dict(dtype="float32")):
+        with pytest.raises(nvr.NvrError) as e:
+            nvr.ModelRunner(nvr.Config(**base, **bad), _model_cfgs(mcfg))
+        assert e.value.code == -10

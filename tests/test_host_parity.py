@@ -54,6 +54,21 @@ def test_config_and_params_validation():             # config.rs:194-217, sampli
         nvr.Config(kvcache_block_size=100).validate()
     with pytest.raises(nvr.NvrError):
         nvr.Config(tensor_parallel_size=10).validate()
+    # device / dtype strings (config.rs:48-51, validated like :108-116 plus "hip"); same verdicts as the oracle's Config
+    assert (c.c.device, c.c.dtype) == (b"hip", b"float16")
+    for dev in ("hip", "cuda", "cpu", "metal"):
+        nvr.Config(device=dev).validate()
+    for dt in ("float16", "bfloat16", "float32"):
+        nvr.Config(dtype=dt).validate()
+        eo.Config(dtype=dt).validate()
+    with pytest.raises(nvr.NvrError, match="Unsupported device: tpu"):
+        nvr.Config(device="tpu").validate()
+    with pytest.raises(ValueError, match="Unsupported device: tpu"):
+        eo.Config(device="tpu").validate()
+    with pytest.raises(nvr.NvrError, match="Unsupported dtype: int8"):
+        nvr.Config(dtype="int8").validate()
+    with pytest.raises(nvr.NvrError):
+        nvr.Config(decode_chain=5).validate()
     for bad in (dict(temperature=-1.0), dict(max_tokens=0), dict(top_p=1.5), dict(top_k=0)):
         with pytest.raises(nvr.NvrError):
             nvr.SamplingParams(**bad).validate()

@@ -663,46 +663,142 @@ def test_linear_splitk_and_slab_norm(T, K, N, S):
     assert nvr.lib().nvr_linear_splitk(dev(xb).ptr, K, dev(Wb).ptr, T, K, N, 5, d_slabs.ptr, None) == -10
 
 
-@pytest.mark.parametrize("T,K,N,S", [(32, 2048, 1024, 4), (32, 3072, 1024, 4), (1, 2048, 1024, 4), (64, 1024, 2048, 2),
-                                     (17, 512, 256, 2), (5, 256, 1008, 2)])
-def test_linear_splitk_norm_one_launch(T, K, N, S):
-    """The one-launch form (arrival counter + row finishers) against linear_splitk -> add_rmsnorm_slabs, launch after launch
-    (the counters re-arm themselves) with the residual stream carried through: the residual rows are bit-identical; the
-    normalised rows agree to 1 fp16 ulp (same rounding points, but the finisher sums a row's squares in one wave and the
-    two-launch norm in four: the f32 sum of squares can differ in its last bit)."""
-
-    def same_norm(a, b):
-        assert_close_f16(a.to_numpy((T, N), F16), b.to_numpy((T, N), F16), ulps=1, atol=1e-6, what="normalised rows")
+@pytest.mark.parametrize("T,K,N,S", [(32, 2048, 1024, 4), (32, 3072, 1024, 4), (1, 2048, 1024, 4), (64, 1024, 2048, 2), (33, 2048, 1024, 4),
+                                     (17, 512, 256, 2), (5, 256, 1008, 2), (32, 2048, 1024, 1), (9, 256, 256, 1), (32, 3072, 1024, 2)])
+def test_linear_resid_last_arriver(T, K, N, S):
+    """nvr_linear_resid (split-k GEMM whose last-arriving workgroup per tile sums the slabs and adds the residual) against the
+    two-launch form nvr_linear_splitk -> nvr_add_rmsnorm_slabs: the residual stream is carried through launch after launch
+    and must stay BIT-identical (same slab order, same rounding points); the ticket counters end every launch at zero.
+    Then 200 back-to-back launches on one stream while a second stream keeps the chip busy with a 300 MB weight stream
+    (uneven load, the slabs and counters re-used: stale-line / re-arm hazards)."""
     rng = np.random.default_rng(24)
     x, xb = h16(rng.standard_normal((T, K)))
     W, Wb = h16(rng.standard_normal((N, K)) * 0.05)
     h, hb = h16(rng.standard_normal((T, N)))
-    w, wb = h16(1 + 0.1 * rng.standard_normal(N))
+    w, wb = h16(np.ones(N))
     d_x, d_W, d_w = dev(xb), dev(Wb), dev(wb)
-    d_slabs_a, d_slabs_b = nvr.DeviceBuffer(S * T * N * 4), nvr.DeviceBuffer(S * T * N * 4)
+    d_slabs_a, d_slabs_b = nvr.DeviceBuffer(max(S, 2) * T * N * 4), nvr.DeviceBuffer(max(S, 2) * T * N * 4)
+    _KEEP.extend([d_slabs_a, d_slabs_b])
     d_ha, d_hb = dev(hb), dev(hb.copy())
-    d_oa, d_ob = nvr.DeviceBuffer(T * N * 2), nvr.DeviceBuffer(T * N * 2)
-    d_sync = dev(np.zeros(4, np.uint32))
-    for rep in range(5):
-        nvr.check(nvr.lib().nvr_linear_splitk(d_x.ptr, K, d_W.ptr, T, K, N, S, d_slabs_a.ptr, None))
-        nvr.check(nvr.lib().nvr_add_rmsnorm_slabs(d_ha.ptr, d_slabs_a.ptr, S, d_w.ptr, 1e-6, T, N, d_oa.ptr, None))
-        nvr.check(nvr.lib().nvr_linear_splitk_norm(d_x.ptr, K, d_W.ptr, T, K, N, S, d_slabs_b.ptr, d_hb.ptr, d_w.ptr, 1e-6,
-                                                   d_ob.ptr, d_sync.ptr, None))
-        assert np.array_equal(d_ha.to_numpy((T, N), np.uint16), d_hb.to_numpy((T, N), np.uint16)), rep
-        same_norm(d_oa, d_ob)
-        assert list(d_sync.to_numpy((4,), np.uint32)) == [0, 0, 0, 0], rep          # re-armed, no timeout
-    # 200 back-to-back launches re-using the same slabs and counters (stale-cache / re-arm hazards), residual carried
+    d_oa = nvr.DeviceBuffer(T * N * 2); _KEEP.append(d_oa)
+    ntiles = (N // 16) * ((T + 31) // 32)
+    d_cnt = dev(np.zeros(ntiles, np.uint32))
+
+    def two_launch():
+        if S > 1:
+            nvr.check(nvr.lib().nvr_linear_splitk(d_x.ptr, K, d_W.ptr, T, K, N, S, d_slabs_a.ptr, None))
+            nvr.check(nvr.lib().nvr_add_rmsnorm_slabs(d_ha.ptr, d_slabs_a.ptr, S, d_w.ptr, 1e-6, T, N, d_oa.ptr, None))
+        else:                                   # no split: fp16 GEMM output, then the residual add of add_rmsnorm
+            nvr.check(nvr.lib().nvr_linear(d_x.ptr, K, d_W.ptr, T, K, N, d_slabs_a.ptr, 0, None))
+            nvr.check(nvr.lib().nvr_add_rmsnorm(d_ha.ptr, d_slabs_a.ptr, d_w.ptr, 1e-6, T, N, d_oa.ptr, None))
+    # k-slices of <= 768 columns run on four waves like nvr_linear_splitk (same k interleave, same f32 summation order):
+    # bit-identical; longer slices use 8 / 16 waves and agree to fp16 rounding of the different summation order
+    exact = K // S <= 768
+    for rep in range(5 if exact else 1):
+        two_launch()
+        nvr.check(nvr.lib().nvr_linear_resid(d_x.ptr, K, d_W.ptr, T, K, N, S, d_slabs_b.ptr, d_cnt.ptr, d_hb.ptr, None))
+        if exact:
+            assert np.array_equal(d_ha.to_numpy((T, N), np.uint16), d_hb.to_numpy((T, N), np.uint16)), rep
+        else:
+            assert_close_f16(d_hb.to_numpy((T, N), F16), d_ha.to_numpy((T, N), F16), ulps=2, atol=2e-3, what=f"rep {rep}")
+        assert not d_cnt.to_numpy((ntiles,), np.uint32).any(), rep                  # re-armed
+    # oracle: h1 = fp16(h + fp16(x W^T)) after ONE launch from the initial h
+    d_h1 = dev(hb.copy())
+    nvr.check(nvr.lib().nvr_linear_resid(d_x.ptr, K, d_W.ptr, T, K, N, S, d_slabs_b.ptr, d_cnt.ptr, d_h1.ptr, None))
+    ref = oracle.add(h, oracle.round_f16(oracle.linear(x, W)), round16=True)
+    assert_close_f16(d_h1.to_numpy((T, N), F16), ref, ulps=2, atol=2e-3, what="h + x W^T")
+    # busy neighbour on a second stream + 200 launches back to back
+    s2 = C.c_void_p()
+    nvr.check(nvr.lib().nvr_stream_create(C.byref(s2)))
+    big_W = nvr.DeviceBuffer(151936 * 1024 * 2); big_x = dev(h16(rng.standard_normal((32, 1024)))[1]); big_y = nvr.DeviceBuffer(32 * 151936 * 4)
+    _KEEP.extend([big_W, big_y])
     for rep in range(200):
-        nvr.check(nvr.lib().nvr_linear_splitk_norm(d_x.ptr, K, d_W.ptr, T, K, N, S, d_slabs_b.ptr, d_hb.ptr, d_w.ptr, 1e-6,
-                                                   d_ob.ptr, d_sync.ptr, None))
+        if rep % 8 == 0:
+            nvr.check(nvr.lib().nvr_linear(big_x.ptr, 1024, big_W.ptr, 32, 1024, 151936, big_y.ptr, 1, s2))
+        nvr.check(nvr.lib().nvr_linear_resid(d_x.ptr, K, d_W.ptr, T, K, N, S, d_slabs_b.ptr, d_cnt.ptr, d_hb.ptr, None))
+    nvr.check(nvr.lib().nvr_stream_synchronize(s2)); nvr.synchronize()
     for rep in range(200):
-        nvr.check(nvr.lib().nvr_linear_splitk(d_x.ptr, K, d_W.ptr, T, K, N, S, d_slabs_a.ptr, None))
-        nvr.check(nvr.lib().nvr_add_rmsnorm_slabs(d_ha.ptr, d_slabs_a.ptr, S, d_w.ptr, 1e-6, T, N, d_oa.ptr, None))
-    assert np.array_equal(d_ha.to_numpy((T, N), np.uint16), d_hb.to_numpy((T, N), np.uint16))
-    same_norm(d_oa, d_ob)
-    assert list(d_sync.to_numpy((4,), np.uint32)) == [0, 0, 0, 0]
-    assert nvr.lib().nvr_linear_splitk_norm(d_x.ptr, K, d_W.ptr, 65, K, N, S, d_slabs_b.ptr, d_hb.ptr, d_w.ptr, 1e-6,
-                                            d_ob.ptr, d_sync.ptr, None) == -10
+        two_launch()
+    nvr.synchronize()
+    if exact:
+        assert np.array_equal(d_ha.to_numpy((T, N), np.uint16), d_hb.to_numpy((T, N), np.uint16))
+    assert not d_cnt.to_numpy((ntiles,), np.uint32).any()
+    nvr.check(nvr.lib().nvr_stream_destroy(s2))
+    assert nvr.lib().nvr_linear_resid(d_x.ptr, K, d_W.ptr, 65, K, N, S, d_slabs_b.ptr, d_cnt.ptr, d_hb.ptr, None) == -10
+    if S > 1:
+        assert nvr.lib().nvr_decode_splitk_slices(32, 2048, 1024) == 4 and nvr.lib().nvr_decode_splitk_slices(32, 3072, 1024) == 4
+
+
+@pytest.mark.parametrize("T,K,I", [(32, 1024, 3072), (16, 1024, 3072), (1, 1024, 3072), (33, 1024, 512), (7, 256, 512), (32, 512, 256),
+                                   (64, 2048, 1024), (20, 2048, 768)])
+def test_linear_silu_mul_normed(T, K, I):
+    """RMSNorm in the prologue of the gate_up GEMM (+ SiluAndMul epilogue) against the oracle's rmsnorm -> linear -> silu_and_mul
+    with fp16 rounding between the ops, and against the product's own two-launch form (nvr_rmsnorm -> nvr_linear_silu_mul):
+    the normalised rows may differ by 1 fp16 ulp (h * (1/rms) instead of h / rms), which moves an output by a few ulps."""
+    rng = np.random.default_rng(31)
+    h, hb = h16(rng.standard_normal((T, K)) * 2.0)
+    w, wb = h16(1 + 0.2 * rng.standard_normal(K))
+    W, Wb = h16(rng.standard_normal((2 * I, K)) * 0.05)
+    d_h, d_w, d_W = dev(hb), dev(wb), dev(Wb)
+    d_out, d_n, d_ref = nvr.DeviceBuffer(T * I * 2), nvr.DeviceBuffer(T * K * 2), nvr.DeviceBuffer(T * I * 2)
+    _KEEP.extend([d_out, d_n, d_ref])
+    nvr.check(nvr.lib().nvr_linear_silu_mul_normed(d_h.ptr, K, d_w.ptr, 1e-6, d_W.ptr, T, K, I, d_out.ptr, None))
+    n = oracle.round_f16(oracle.rmsnorm(h, w, 1e-6))
+    ref = oracle.round_f16(oracle.silu_and_mul(oracle.round_f16(oracle.linear(n, W))))
+    got = d_out.to_numpy((T, I), F16)
+    assert_close_f16(got, ref, ulps=4, atol=2e-3, what="fused vs oracle")
+    nvr.check(nvr.lib().nvr_rmsnorm(d_h.ptr, d_w.ptr, 1e-6, T, K, d_n.ptr, None))
+    nvr.check(nvr.lib().nvr_linear_silu_mul(d_n.ptr, K, d_W.ptr, T, K, I, d_ref.ptr, None))
+    assert_close_f16(got, d_ref.to_numpy((T, I), F16), ulps=4, atol=2e-3, what="fused vs two launches")
+    assert np.array_equal(d_h.to_numpy((T, K), np.uint16), hb.view(np.uint16))          # the residual stream is only read
+    assert nvr.lib().nvr_linear_silu_mul_normed(d_h.ptr, K, d_w.ptr, 1e-6, d_W.ptr, 65, K, I, d_out.ptr, None) == -10
+
+
+@pytest.mark.parametrize("T,Hd,H,KVH,D", [(32, 1024, 16, 8, 128), (16, 1024, 16, 8, 128), (3, 1024, 16, 8, 128), (40, 256, 4, 2, 64),
+                                          (32, 2048, 8, 2, 128), (9, 512, 2, 2, 64)])
+def test_linear_qkv_rope_store_normed(T, Hd, H, KVH, D):
+    """RMSNorm in the prologue of the qkv GEMM with the RoPE + KV-store epilogue, against the oracle chain rmsnorm -> linear ->
+    rope -> kv_store (fp16 between the ops) and the two-launch product form."""
+    rng = np.random.default_rng(32)
+    N = (H + 2 * KVH) * D
+    h, hb = h16(rng.standard_normal((T, Hd)) * 1.5)
+    w, wb = h16(1 + 0.2 * rng.standard_normal(Hd))
+    W, Wb = h16(rng.standard_normal((N, Hd)) * 0.05)
+    pos = rng.integers(0, 500, T).astype(np.int64)
+    nslots = 2 * T + 8
+    slots = rng.permutation(nslots)[:T].astype(np.int32)
+    if T > 2:
+        slots[1] = -1                                  # a token that is not cached
+    cos, sin = oracle.rope_table(D, 512, 1e6)
+    d_h, d_w, d_W, d_pos, d_slots, d_cos, d_sin = dev(hb), dev(wb), dev(Wb), dev(pos), dev(slots), dev(cos), dev(sin)
+    bufs = [nvr.DeviceBuffer(T * N * 2), nvr.DeviceBuffer(nslots * KVH * D * 2), nvr.DeviceBuffer(nslots * KVH * D * 2),
+            nvr.DeviceBuffer(T * N * 2), nvr.DeviceBuffer(nslots * KVH * D * 2), nvr.DeviceBuffer(nslots * KVH * D * 2), nvr.DeviceBuffer(T * Hd * 2)]
+    _KEEP.extend(bufs)
+    d_qkv, d_kc, d_vc, d_qkv2, d_kc2, d_vc2, d_n = bufs
+    for b in (d_kc, d_vc, d_kc2, d_vc2):
+        b.zero()
+    nvr.check(nvr.lib().nvr_linear_qkv_rope_store_normed(d_h.ptr, Hd, d_w.ptr, 1e-6, d_W.ptr, T, Hd, H, KVH, D, d_pos.ptr, d_slots.ptr,
+                                                         d_cos.ptr, d_sin.ptr, d_qkv.ptr, d_kc.ptr, d_vc.ptr, None))
+    nvr.check(nvr.lib().nvr_rmsnorm(d_h.ptr, d_w.ptr, 1e-6, T, Hd, d_n.ptr, None))
+    nvr.check(nvr.lib().nvr_linear_qkv_rope_store(d_n.ptr, Hd, d_W.ptr, T, Hd, H, KVH, D, d_pos.ptr, d_slots.ptr, d_cos.ptr, d_sin.ptr,
+                                                  d_qkv2.ptr, d_kc2.ptr, d_vc2.ptr, None))
+    got, two = d_qkv.to_numpy((T, N), F16), d_qkv2.to_numpy((T, N), F16)
+    assert_close_f16(got, two, ulps=4, atol=3e-3, what="fused vs two launches")
+    n = oracle.round_f16(oracle.rmsnorm(h, w, 1e-6))
+    qkv = oracle.round_f16(oracle.linear(n, W))
+    q = oracle.round_f16(oracle.rope_apply(qkv[:, :H * D].reshape(T, H, D), pos, cos, sin)).reshape(T, H * D)
+    k = oracle.round_f16(oracle.rope_apply(qkv[:, H * D:(H + KVH) * D].reshape(T, KVH, D), pos, cos, sin)).reshape(T, KVH * D)
+    ref = np.concatenate([q, k, qkv[:, (H + KVH) * D:]], 1)
+    assert_close_f16(got, ref, ulps=4, atol=3e-3, what="fused vs oracle")
+    # cache rows are exactly the k / v columns of the qkv output at their slots; untouched slots stay zero
+    kc, vc = d_kc.to_numpy((nslots, KVH * D), np.uint16), d_vc.to_numpy((nslots, KVH * D), np.uint16)
+    gb = got.view(np.uint16)
+    seen = np.zeros(nslots, bool)
+    for t in range(T):
+        if slots[t] >= 0:
+            assert np.array_equal(kc[slots[t]], gb[t, H * D:(H + KVH) * D]) and np.array_equal(vc[slots[t]], gb[t, (H + KVH) * D:])
+            seen[slots[t]] = True
+    assert not kc[~seen].any() and not vc[~seen].any()
 
 
 # ------------------------------------------------------------------------------------------- K8

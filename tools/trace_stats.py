@@ -16,6 +16,15 @@ span = (int(sel[-1]["End_Timestamp"]) - int(sel[0]["Start_Timestamp"])) / 1e3
 print(f"{nsteps} decode steps: kernel time {tot_k / nsteps:.1f} us/step, wall span {span / nsteps:.1f} us/step")
 for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
     print(f"{sum(v) / nsteps:9.1f} us/step  n={len(v) // nsteps:4d}  avg {sum(v) / len(v):7.2f}  min {min(v):7.2f}  max {max(v):7.2f}  {k}")
+# wall cost per kernel type = start of the NEXT kernel - start of this one (duration + boundary), over the selected steps
+wall = collections.defaultdict(list)
+for a, b in zip(sel, sel[1:]):
+    if "argmax" in a["Kernel_Name"]:
+        continue
+    wall[short(a["Kernel_Name"])].append((int(b["Start_Timestamp"]) - int(a["Start_Timestamp"])) / 1e3)
+print("start-to-start (duration + boundary) per kernel type:")
+for k, v in sorted(wall.items(), key=lambda kv: -sum(kv[1])):
+    print(f"{sum(v) / nsteps:9.1f} us/step  n={len(v) // nsteps:4d}  avg {sum(v) / len(v):7.2f}  {k}")
 # gaps inside the last step
 last = rows[ends[-2] + 1:ends[-1] + 1]
 gaps = [(int(b["Start_Timestamp"]) - int(a["End_Timestamp"])) / 1e3 for a, b in zip(last, last[1:])]
