@@ -239,6 +239,18 @@ typedef struct nvr_local_group nvr_local_group_t;
 NVR_API nvr_local_group_t *nvr_local_group_create(int nranks);
 NVR_API void nvr_local_group_destroy(nvr_local_group_t *g);
 NVR_API int nvr_runner_init_comm_local(nvr_model_runner_t *r, nvr_local_group_t *g);
+/* 1 (default): the group's collectives are the product's one-shot peer-to-peer kernels over the ranks' arenas (the code path of
+ * real multi-GPU ranks, minus the hipIpc mapping); 0: host-rendezvous collectives.  Call before any rank attaches. */
+NVR_API int nvr_local_group_set_p2p(nvr_local_group_t *g, int on);
+/* One-shot all-reduce (+ residual + RMSNorm) and small all-gather over peer-mapped HBM (xGMI), kernels/comm_p2p.hip: the
+ * exchange sites the reference leaves as TODOs (RowParallelLinear::forward linear.rs:236-238; ParallelLMHead::gather_logits
+ * embed_head.rs:321-336), as plain kernels that capture into the decode hipGraph.  Each rank exports the hipIpc handle of its
+ * arena; the caller's control plane gathers all handles (rank order) and the ranks' HIP device ordinals and attaches them on
+ * every rank.  Messages larger than a slot (1 MiB, prefill) keep using the RCCL communicator when one exists. */
+NVR_API int nvr_runner_p2p_export(nvr_model_runner_t *r, uint8_t handle[64]);
+NVR_API int nvr_runner_p2p_attach(nvr_model_runner_t *r, const uint8_t *handles /* [tp][64] */, const int32_t *devices /* [tp] or NULL */);
+NVR_API int nvr_runner_p2p_disable(nvr_model_runner_t *r);
+NVR_API int nvr_runner_p2p_active(const nvr_model_runner_t *r);
 
 /* -------------------------------------------------------------------- Engine ---- */
 /* LLMEngine::step loop, src/engine/llm_engine.rs:155-197 (driver of the hot path only) */

@@ -176,7 +176,9 @@ _SIGS = {
     "nvr_engine_generate_stream": (C.c_int, [_P, _P, _P, C.c_size_t, _P, STREAM_FN, _P]),
     "nvr_runner_replay_last_decode_graph": (C.c_int, [_P, C.c_int]),
     "nvr_local_group_create": (_P, [C.c_int]), "nvr_local_group_destroy": (None, [_P]),
-    "nvr_runner_init_comm_local": (C.c_int, [_P, _P]),
+    "nvr_runner_init_comm_local": (C.c_int, [_P, _P]), "nvr_local_group_set_p2p": (C.c_int, [_P, C.c_int]),
+    "nvr_runner_p2p_export": (C.c_int, [_P, _P]), "nvr_runner_p2p_attach": (C.c_int, [_P, _P, _P]),
+    "nvr_runner_p2p_disable": (C.c_int, [_P]), "nvr_runner_p2p_active": (C.c_int, [_P]),
     "nvr_engine_last_step": (None, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(C.c_size_t)]),
     "nvr_engine_take_finished": (C.c_size_t, [_P, C.POINTER(_P), C.c_size_t]),
     "nvr_engine_last_batch": (C.c_size_t, [_P, C.POINTER(_P), C.c_size_t]),
@@ -631,16 +633,34 @@ class ModelRunner:
         buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
         check(lib().nvr_runner_init_comm(self.h, buf))
 
+    # one-shot peer-to-peer collectives (kernels/comm_p2p.hip): export my arena's hipIpc handle, attach everybody's
+    def p2p_export(self) -> bytes:
+        buf = (C.c_uint8 * 64)()
+        check(lib().nvr_runner_p2p_export(self.h, buf))
+        return bytes(buf)
+
+    def p2p_attach(self, handles: Seq[bytes], devices: Optional[Seq[int]] = None) -> None:
+        blob = (C.c_uint8 * (64 * len(handles))).from_buffer_copy(b"".join(handles))
+        dv = (C.c_int32 * len(handles))(*devices) if devices is not None else None
+        check(lib().nvr_runner_p2p_attach(self.h, blob, dv))
+
+    def p2p_disable(self) -> None:
+        check(lib().nvr_runner_p2p_disable(self.h))
+
+    def p2p_active(self) -> bool:
+        return bool(lib().nvr_runner_p2p_active(self.h))
+
 
 class LocalGroup:
     """In-process communicator (nvr_local_group_*): tensor-parallel ranks as runners of this process on one GPU,
     one host thread per rank.  Tests and bring-up only."""
 
-    def __init__(self, nranks: int):
+    def __init__(self, nranks: int, p2p: bool = True):
         self.h = lib().nvr_local_group_create(nranks)
         if not self.h:
             raise NvrError(-7, last_error())
         self.nranks = nranks
+        check(lib().nvr_local_group_set_p2p(self.h, 1 if p2p else 0))
 
     def attach(self, runner: "ModelRunner") -> None:
         check(lib().nvr_runner_init_comm_local(runner.h, self.h))

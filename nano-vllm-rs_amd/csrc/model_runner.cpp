@@ -321,7 +321,13 @@ int nvr_model_runner::row_parallel_norm(const uint16_t *x, int64_t K, const uint
         return k::add_rmsnorm_slabs(h, slabs, S, wn, mc.rms_norm_eps, T, Hd, n, stream);
     }
     RC(k::linear(x, K, W, T, K, Hd, proj, false, stream));
-    if (comm.active()) RC(comm.all_reduce_sum_f16(proj, (size_t)(T * Hd), stream));  // linear.rs:236-238
+    // linear.rs:236-238 (all-reduce) + qwen3.rs:382-389 (residual, norm): one launch over the peer-mapped arenas when the
+    // message fits a slot (decode-sized steps), else the communicator's all-reduce followed by add+RMSNorm
+    // (T <= 64: the fused kernel reduces a row's squares exactly like the decode-sized add+RMSNorm kernel, so fused and unfused
+    // steps agree bit for bit; larger steps take the plain one-shot all-reduce and the row kernels of their size)
+    if (comm.active() && T <= 64 && comm.p2p_usable((size_t)(T * Hd)))
+        return comm.all_reduce_add_rmsnorm(proj, h, wn, mc.rms_norm_eps, (int)T, (int)Hd, n, stream);
+    if (comm.active()) RC(comm.all_reduce_sum_f16(proj, (size_t)(T * Hd), stream));
     return k::add_rmsnorm(h, proj, wn, mc.rms_norm_eps, T, Hd, n, stream);
 }
 
@@ -403,6 +409,7 @@ int nvr_model_runner::forward(int64_t T, int64_t B, bool is_prefill, int64_t max
 // execute_model :105-128 with prepare_*_inputs :172-210 and create_*_context :222-300
 int nvr_model_runner::execute(nvr_seq *const *seqs, size_t nseq, bool is_prefill) {
     NVR_HIP_CHECK(hipSetDevice(device));
+    if (tp > 1) RC(comm.prepare());
     if (tp > 1 && !comm.active() && !allow_missing_comm)
         return nvr::fail(NVR_ERR_RCCL, "execute_model: tensor_parallel_size %ld but no communicator is attached (nvr_runner_init_comm / "
                          "nvr_local_group_attach); partial sums would be returned as results", (long)tp);
@@ -568,7 +575,8 @@ int nvr_model_runner::replay_last_decode_graph(int n) {
 // all-reduce and all-gather of a known pattern on this runner's communicator (tests; collective over all ranks)
 int nvr_model_runner::comm_selftest() {
     NVR_HIP_CHECK(hipSetDevice(device));
-    if (!comm.comm) return nvr::fail(NVR_ERR_RCCL, "comm_selftest: communicator not initialised");
+    if (tp > 1) RC(comm.prepare());
+    if (!comm.comm && !comm.local && !comm.p2p_ready) return nvr::fail(NVR_ERR_RCCL, "comm_selftest: communicator not initialised");
     const int n = 4096;
     std::vector<uint16_t> hbuf(n);
     for (int i = 0; i < n; ++i) hbuf[i] = 0x3C00;                 // fp16 1.0
@@ -589,7 +597,7 @@ int nvr_model_runner::comm_selftest() {
             for (int j = 0; j < 8; ++j)
                 if (all[r * 8 + j] != r) return nvr::fail(NVR_ERR_RCCL, "comm_selftest: all-gather slot %ld holds %ld", (long)r, (long)all[r * 8 + j]);
     }
-    return NVR_OK;
+    return comm.p2p_check_error(stream);
 }
 
 // sample_tokens :131-156 -> Sampler::batch_sample, src/layers/sampler.rs:221-254
@@ -631,6 +639,7 @@ int nvr_model_runner::sample(nvr_seq *const *seqs, size_t nseq, int64_t *out) {
             std::vector<float> gv(tp * B); std::vector<int64_t> gi(tp * B);
             NVR_HIP_CHECK(hipMemcpyAsync(gv.data(), d_gather_val, gv.size() * 4, hipMemcpyDeviceToHost, stream));
             NVR_HIP_CHECK(hipMemcpyAsync(gi.data(), d_gather_idx, gi.size() * 8, hipMemcpyDeviceToHost, stream));
+            RC(comm.p2p_check_error(stream));                            // (synchronises) a peer that never arrived this step
             NVR_HIP_CHECK(hipStreamSynchronize(stream));
             for (int64_t b = 0; b < B; ++b) {
                 float bv = gv[b]; int64_t bi = gi[b];

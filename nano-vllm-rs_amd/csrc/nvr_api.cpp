@@ -248,12 +248,34 @@ int nvr_runner_init_comm(nvr_model_runner_t *r, const uint8_t id[128]) {
     NVR_HIP_CHECK(hipSetDevice(r->device));
     int rc = r->comm.init(id, (int)r->tp, (int)r->rank);
     if (rc) return rc;
-    // Multi-rank decode steps are launched eagerly by default: measured on one MI355X the eager chain costs the same
-    // as graph replay (1.774 vs 1.762 ms/step: the step is bound by kernel latency, the host keeps ahead), and a graph
-    // holding RCCL nodes could not be exercised on the 1-GPU development boxes.  NVR_TP_GRAPH=1 opts in to capture.
-    if (r->tp > 1 && !std::getenv("NVR_TP_GRAPH")) r->graphs_disabled = true;
+    // Multi-rank decode steps replay a captured hipGraph like single-rank ones (the one-shot peer-to-peer collectives are plain
+    // kernel nodes; ncclAllReduce nodes capture too).  If the capture cannot be built the runner falls back to eager launches
+    // (execute()); NVR_TP_GRAPH=0 forces eager.
+    if (const char *e = std::getenv("NVR_TP_GRAPH")) if (e[0] == '0' && r->tp > 1) r->graphs_disabled = true;
     return r->tp > 1 ? r->comm_selftest() : NVR_OK;            // also establishes every RCCL connection up front
 }
+// One-shot peer-to-peer collectives (kernels/comm_p2p.hip): every rank allocates an arena and exports its hipIpc handle; the
+// caller's control plane gathers the handles (and the ranks' HIP device ordinals) and hands all of them to every rank.
+int nvr_runner_p2p_export(nvr_model_runner_t *r, uint8_t handle[64]) {
+    NVR_GUARD_BEGIN
+    NVR_HIP_CHECK(hipSetDevice(r->device));
+    if (int rc = r->comm.p2p_alloc((int)r->tp, (int)r->rank)) return rc;
+    return r->comm.p2p_export(handle);
+    NVR_GUARD_END(NVR_ERR_INVARIANT)
+}
+int nvr_runner_p2p_attach(nvr_model_runner_t *r, const uint8_t *handles, const int32_t *devices) {
+    NVR_GUARD_BEGIN
+    NVR_HIP_CHECK(hipSetDevice(r->device));
+    if (!handles) return nvr::fail(NVR_ERR_INVALID_ARG, "nvr_runner_p2p_attach: handles is null");
+    std::vector<int> dv;
+    if (devices) dv.assign(devices, devices + r->tp);
+    if (int rc = r->comm.p2p_attach_ipc(handles, devices ? dv.data() : nullptr)) return rc;
+    if (!r->comm.comm && !r->comm.local) { r->comm.nranks = (int)r->tp; r->comm.rank = (int)r->rank; }
+    return NVR_OK;
+    NVR_GUARD_END(NVR_ERR_INVARIANT)
+}
+int nvr_runner_p2p_disable(nvr_model_runner_t *r) { r->comm.p2p_ready = false; return NVR_OK; }
+int nvr_runner_p2p_active(const nvr_model_runner_t *r) { return r->comm.p2p_ready ? 1 : 0; }
 
 // in-process communicator (comm.h LocalGroup): N runners of one process on one device, one host thread each
 struct nvr_local_group { nvr::LocalGroup g; explicit nvr_local_group(int n) : g(n) {} };
@@ -264,6 +286,12 @@ nvr_local_group_t *nvr_local_group_create(int nranks) {
     NVR_GUARD_END(nullptr)
 }
 void nvr_local_group_destroy(nvr_local_group_t *g) { delete g; }
+int nvr_local_group_set_p2p(nvr_local_group_t *g, int on) {
+    if (!g) return nvr::fail(NVR_ERR_INVALID_ARG, "nvr_local_group_set_p2p: group is null");
+    if (g->g.registered) return nvr::fail(NVR_ERR_INVALID_ARG, "nvr_local_group_set_p2p: ranks are already attached");
+    g->g.use_p2p = on != 0;
+    return NVR_OK;
+}
 int nvr_runner_init_comm_local(nvr_model_runner_t *r, nvr_local_group_t *g) {
     NVR_GUARD_BEGIN
     if (!g) return nvr::fail(NVR_ERR_INVALID_ARG, "nvr_runner_init_comm_local: group is null");
@@ -271,7 +299,7 @@ int nvr_runner_init_comm_local(nvr_model_runner_t *r, nvr_local_group_t *g) {
     NVR_HIP_CHECK(hipSetDevice(r->device));
     int rc = r->comm.init_local(&g->g, (int)r->rank);
     if (rc) return rc;
-    r->graphs_disabled = true;                 // the collectives synchronise on the host: nothing to capture
+    r->graphs_disabled = !g->g.use_p2p;        // host-rendezvous collectives synchronise on the host: nothing to capture
     return NVR_OK;
     NVR_GUARD_END(NVR_ERR_INVARIANT)
 }

@@ -271,7 +271,9 @@ def test_full_size_tensor_parallel_in_process_equals_single_rank(tp, model):
         return out
     ref = run_single()
 
-    group = nvr.LocalGroup(tp)
+    # tp <= 4: the one-shot peer-to-peer collectives (ranks wait for each other inside kernels, one hardware queue each);
+    # tp = 8: the host-rendezvous collectives (eight spinning kernels of one process would share the GPU's queues)
+    group = nvr.LocalGroup(tp, p2p=tp <= 4)
     engines = []
     for r in range(tp):
         e = nvr.LLMEngine(nvr.Config(tensor_parallel_size=tp, tensor_parallel_rank=r, **ecfg), mc)
@@ -309,3 +311,66 @@ def test_full_size_tensor_parallel_in_process_equals_single_rank(tp, model):
                 if i == 0:
                     assert srt[b, -1] - srt[b, -2] <= 6e-2
     assert near <= 2, near
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tp", [2, 4])
+def test_one_shot_p2p_collectives_equal_host_rendezvous(tp):
+    """The one-shot peer-to-peer all-reduce + residual + RMSNorm and the small all-gather (kernels/comm_p2p.hip: push into the
+    peers' arenas, epoch flags, rank-ordered f32 sum) against the host-rendezvous collectives of the same in-process ranks:
+    same summation order and rounding points, so the shard logits of every step and the token streams are BIT-identical; the
+    p2p ranks replay captured hipGraphs (the collectives are plain kernel nodes), the rendezvous ranks launch eagerly.
+    Also: the communicator self-test (all-reduce of ones, all-gather of rank ids) through the arenas."""
+    import threading
+    sys.path.insert(0, ROOT)
+    import nvr_import
+    import oracle
+    from oracle import model_oracle as mo
+    nvr = nvr_import.load()
+    m = mo.small(seed=6, num_attention_heads=8, num_key_value_heads=4, head_dim=64, hidden_size=256, intermediate_size=512)
+    mc = nvr.ModelConfig(vocab_size=m.vocab_size, hidden_size=m.hidden_size, intermediate_size=m.intermediate_size,
+                         num_hidden_layers=m.num_hidden_layers, num_attention_heads=m.num_attention_heads,
+                         num_key_value_heads=m.num_key_value_heads, head_dim=m.head_dim, max_position_embeddings=m.max_position_embeddings,
+                         rms_norm_eps=m.rms_norm_eps, rope_theta=m.rope_theta, tie_word_embeddings=m.tie_word_embeddings,
+                         init_std=m.init_std, seed=m.seed)
+    ecfg = dict(max_num_seqs=8, max_num_batched_tokens=256, max_model_len=128, kvcache_block_size=16, num_kvcache_blocks=40)
+    prompts = [oracle.fill_tokens(n, 5, i, m.vocab_size).tolist() for i, n in enumerate([9, 40, 17, 3, 26])]
+
+    def run(p2p, eager):
+        group = nvr.LocalGroup(tp, p2p=p2p)
+        engines = []
+        for r in range(tp):
+            e = nvr.LLMEngine(nvr.Config(skip_block_size_check=1, tensor_parallel_size=tp, tensor_parallel_rank=r, enforce_eager=eager, **ecfg), mc)
+            group.attach(e.model_runner)
+            nvr.lib().nvr_seq_reset_id_counter()
+            for pr in prompts:
+                e.add_request(pr, nvr.SamplingParams(temperature=0.0, max_tokens=24, ignore_eos=True))
+            engines.append(e)
+        traces, errors = [[] for _ in range(tp)], []
+
+        def drive(r):
+            try:
+                e = engines[r]
+                e.model_runner.comm_selftest()
+                while not e.is_finished():
+                    rec = e.step(); rec["logits"] = e.model_runner.logits(rec["num_seqs"]).copy(); traces[r].append(rec)
+                assert e.model_runner.p2p_active() == p2p
+            except BaseException as ex:                                                 # noqa: BLE001
+                errors.append((r, ex))
+        threads = [threading.Thread(target=drive, args=(r,)) for r in range(tp)]
+        for t in threads: t.start()
+        for t in threads: t.join(300)
+        assert not errors, errors
+        return traces
+    # eager on both sides for the bit comparison (a captured step partitions the attention by its 256-token context bucket,
+    # an eager one by the real context: different split-KV merge order, same tokens)
+    a, b = run(True, True), run(False, True)
+    assert len(a[0]) == len(b[0]) > 20
+    for r in range(tp):
+        for sa, sb in zip(a[r], b[r]):
+            assert sa["tokens"] == sb["tokens"] and sa["seq_ids"] == sb["seq_ids"]
+            assert np.array_equal(sa["logits"], sb["logits"]), "p2p and host-rendezvous collectives differ in bits"
+    g = run(True, False)                                 # p2p collectives inside replayed hipGraphs
+    for step in zip(*g):
+        assert all(s["tokens"] == step[0]["tokens"] for s in step)
+    assert [s["tokens"] for s in g[0]] == [s["tokens"] for s in a[0]]
