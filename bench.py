@@ -9,13 +9,15 @@ sequences with 1024-token synthetic prompts, greedy decode, block size 256, hipG
 A "step" is one decode pass of the engine over the whole batch (schedule -> execute_model ->
 sample_tokens -> postprocess through the C ABI), i.e. 32 generated tokens.  The prefill of the
 32x1024 prompt tokens happens before the timed region; K steps are timed between barriers and
-device synchronisation; the maximum over ranks is reported.  N>1 shards heads / MLP columns / vocab
-across N ranks.  Sequences are independent units, so N>1 first measures N replicas (one engine and
-its own 32 sequences per GPU, no exchange: "scaling": "weak") — that is `value` — and then, on the
-same ranks, the north star's tensor-parallel configuration (heads / MLP columns / vocabulary sharded,
-RCCL all-reduce: the same 32 sequences, "strong"), attached as "tensor_parallel".  `--parallel tp`
-makes the tensor-parallel run the value instead; if its communicator cannot be built or its phase
-does not finish, the replicas measurement is what is reported.
+device synchronisation; the maximum over ranks is reported.  N>1: `value` is the north star's TENSOR-PARALLEL
+configuration — one engine over the N GPUs (heads / MLP columns / vocabulary sharded, the same 32 sequences: "scaling":
+"strong"), its exchanges done by the one-shot peer-to-peer kernels over xGMI (kernels/comm_p2p.hip; RCCL for messages
+that do not fit an arena slot, and as the fallback when the peer mapping cannot be built).  Decode sequences are also
+independent units, so the no-exchange deployment (N replicas, one engine with its own 32 sequences per GPU, "weak") is
+measured first on the same ranks and attached as "replicas".  The tensor-parallel phase runs in a child process per
+rank: the multi-GPU path cannot be exercised on the 1-GPU development boxes, and a crash or hang in it must not cost the
+measurement already taken — if it fails twice (with and without the peer-to-peer kernels), the replicas number is
+reported as `value`, labelled as such, with the error attached.
 
 The JSON line also carries
   roofline     — the dominant kernel (paged decode attention): algorithmic K/V bytes per launch
@@ -104,6 +106,63 @@ def time_attention_kernel(nvr, eng, mc, reps: int) -> dict:
     return dict(us_per_launch=us, launches=launches, alg_bytes=alg_bytes, ctx_sum=int(ctx.sum()))
 
 
+def time_decode_chain(nvr, mc, reps: int = 20) -> dict:
+    """The decode step's GEMM / norm chain without attention (per layer: qkv+RoPE+store, o_proj split-k, add+RMSNorm,
+    gate_up+SiLU, down split-k, add+RMSNorm — the six launches of the default chain) as one captured hipGraph of L layers with
+    their own weights (HBM-cold every replay), replayed back to back on its own stream: microseconds per layer."""
+    l = nvr.lib()
+    c = mc.c
+    T, Hd, H, KVH, D, I, L = BATCH, c.hidden_size, c.num_attention_heads, c.num_key_value_heads, mc.head_dim(), c.intermediate_size, c.num_hidden_layers
+    QKV = (H + 2 * KVH) * D
+    st = C.c_void_p(); nvr.check(l.nvr_stream_create(C.byref(st)))
+    e0, e1 = C.c_void_p(), C.c_void_p(); nvr.check(l.nvr_event_create(C.byref(e0))); nvr.check(l.nvr_event_create(C.byref(e1)))
+    keep = []
+
+    def buf(nbytes):
+        b = nvr.DeviceBuffer(nbytes); keep.append(b); return b
+
+    def arr(a):
+        b = nvr.DeviceBuffer.from_numpy(np.ascontiguousarray(a)); keep.append(b); return b
+
+    def weights(rows, cols):
+        ws = [buf(rows * cols * 2) for _ in range(L)]
+        for i, w in enumerate(ws):
+            nvr.check(l.nvr_fill_weight(w.ptr, rows, cols, cols, cols, 0, 0, 5 + i, 1e-6, None))
+        return ws
+    Wqkv, Wo, Wgu, Wd = weights(QKV, Hd), weights(Hd, H * D), weights(2 * I, Hd), weights(Hd, I)
+    rng = np.random.default_rng(0)
+    h = arr(rng.standard_normal((T, Hd)).astype(np.float16)); n = buf(T * Hd * 2); g = arr(np.ones(Hd, np.float16))
+    qkv, attn, act = buf(T * QKV * 2), arr(rng.standard_normal((T, H * D)).astype(np.float16) * 0.1), buf(T * I * 2)
+    slabs = buf(4 * T * Hd * 4)
+    pos = arr(np.arange(T, dtype=np.int64) + 1000); slots = arr(np.arange(T, dtype=np.int32))
+    cos = arr(np.ones((2048, D // 2), np.float32)); sin = arr(np.zeros((2048, D // 2), np.float32))
+    kc, vc = buf(64 * KVH * D * 2), buf(64 * KVH * D * 2)
+    So, Sd = l.nvr_decode_splitk_slices(T, H * D, Hd), l.nvr_decode_splitk_slices(T, I, Hd)
+    nvr.synchronize()
+    ge = C.c_void_p()
+    nvr.check(l.nvr_graph_capture_begin(st))
+    for i in range(L):
+        nvr.check(l.nvr_linear_qkv_rope_store(n.ptr, Hd, Wqkv[i].ptr, T, Hd, H, KVH, D, pos.ptr, slots.ptr, cos.ptr, sin.ptr, qkv.ptr, kc.ptr, vc.ptr, st))
+        nvr.check(l.nvr_linear_splitk(attn.ptr, H * D, Wo[i].ptr, T, H * D, Hd, So, slabs.ptr, st))
+        nvr.check(l.nvr_add_rmsnorm_slabs(h.ptr, slabs.ptr, So, g.ptr, 1e-6, T, Hd, n.ptr, st))
+        nvr.check(l.nvr_linear_silu_mul(n.ptr, Hd, Wgu[i].ptr, T, Hd, I, act.ptr, st))
+        nvr.check(l.nvr_linear_splitk(act.ptr, I, Wd[i].ptr, T, I, Hd, Sd, slabs.ptr, st))
+        nvr.check(l.nvr_add_rmsnorm_slabs(h.ptr, slabs.ptr, Sd, g.ptr, 1e-6, T, Hd, n.ptr, st))
+    nvr.check(l.nvr_graph_capture_end(st, C.byref(ge)))
+    for _ in range(3):
+        nvr.check(l.nvr_graph_launch(ge, st))
+    nvr.check(l.nvr_stream_synchronize(st))
+    nvr.check(l.nvr_event_record(e0, st))
+    for _ in range(reps):
+        nvr.check(l.nvr_graph_launch(ge, st))
+    nvr.check(l.nvr_event_record(e1, st))
+    ms = C.c_float(); nvr.check(l.nvr_event_elapsed_ms(e0, e1, C.byref(ms)))
+    us_layer = ms.value * 1e3 / reps / L
+    nvr.check(l.nvr_graph_destroy(ge)); l.nvr_event_destroy(e0); l.nvr_event_destroy(e1); l.nvr_stream_destroy(st)
+    alg = 2.0 * (QKV * Hd + Hd * H * D + 2 * I * Hd + Hd * I)                  # weight bytes of one layer, read once
+    return dict(us_per_layer=us_layer, alg_bytes_per_layer=alg, layers=L, replays=reps)
+
+
 def _pmc_prefill_busy():
     """Counter-based MFMA utilisation of the prefill step (separate rocprofv3 --pmc pass, committed under profiles/)."""
     try:
@@ -145,12 +204,12 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--attn-reps", type=int, default=8)
+    ap.add_argument("--no-chain", action="store_true", help="skip the GEMM / norm chain timing (roofline_chain)")
     ap.add_argument("--eager", action="store_true", help="enforce_eager: launch decode kernels one by one instead of replaying a hipGraph")
     ap.add_argument("--parallel", choices=["both", "tp", "replicas"], default=os.environ.get("NVR_BENCH_PARALLEL", "both"),
-                    help="--gpus N > 1: 'replicas' = N independent engines, 32 sequences each, no exchange between ranks (sequences are "
-                         "independent units: weak scaling); 'tp' = one tensor-parallel engine over N GPUs (RCCL all-reduce, strong scaling: "
-                         "the same 32 sequences) as the reported value; 'both' (default) = value from the replicas, the tensor-parallel run "
-                         "measured right after and attached as \"tensor_parallel\"")
+                    help="--gpus N > 1: 'both' (default) = N replicas measured first (attached as \"replicas\"), then the tensor-parallel "
+                         "engine over the N GPUs in child processes: its tokens/s is the value ('strong' scaling); 'tp' = only the "
+                         "tensor-parallel run, in this process; 'replicas' = only the N independent engines ('weak' scaling)")
     ap.add_argument("--materialize-logits", action="store_true",
                     help="write the f32 logits of every step to HBM (default: a greedy batch takes its tokens from the arg-max "
                          "partials of the LM-head epilogue and the logits are written only when someone asks for them)")
@@ -171,7 +230,7 @@ def main() -> None:
         # the multi-rank path cannot be exercised on the 1-GPU development boxes: never hang the driver — if a rank is still
         # stuck (a collective that never completes, a rendezvous that never forms) after 10 minutes, every rank exits
         import threading
-        wd_secs = 240.0 if os.environ.get("NVR_BENCH_CHILD") == "1" else 600.0
+        wd_secs = 200.0 if os.environ.get("NVR_BENCH_CHILD") == "1" else 560.0
 
         def _bail():
             print(f"[bench] rank {rank}: multi-GPU run made no progress for {int(wd_secs)} s, giving up", file=sys.stderr, flush=True)
@@ -183,7 +242,7 @@ def main() -> None:
                                   "ms_per_step": rep["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                                   "dtype": "f16", "data": "synthetic",
                                   "config": {"workload": "Qwen3-0.6B fp16 random-init, bs=32 x 1024-token prompts per GPU, greedy paged-attention decode",
-                                             "parallelism": rep["parallelism"] + " (the tensor-parallel phase did not complete within 600 s)"},
+                                             "parallelism": rep["parallelism"] + " (the tensor-parallel phase did not complete in time)"},
                                   "roofline": None, "replicas": rep}), flush=True)
             os._exit(0 if rep is not None else 4)      # a measured line went out: let the launcher finish normally
         watchdog = threading.Timer(wd_secs, _bail)
@@ -242,27 +301,70 @@ def main() -> None:
     parallelism, scaling, jobs = "tp1", "strong", 1
     replicas = None                           # N > 1: the no-exchange measurement (N independent engines), always taken first
     tensor_parallel = None
+    collective = None
     child = os.environ.get("NVR_BENCH_CHILD") == "1"
-    if args.gpus > 1 and child:
-        # the tensor-parallel phase of a parent bench.py (see "both" below): no replicas leg; a failure is reported as a JSON error line
+
+    def init_tensor_parallel(eng):
+        """Communicators of a tensor-parallel engine: RCCL (large messages, fallback) and the one-shot peer-to-peer arenas
+        (hipIpc handles gathered over the gloo control plane).  Every decision is agreed by all ranks (MIN over ranks).
+        Returns (ok, description)."""
         import torch
-        eng = make_engine(args.gpus, rank)
+
+        def all_ok(flag: bool) -> bool:
+            t = torch.tensor([1 if flag else 0], dtype=torch.int32)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return bool(int(t.item()))
         uid = torch.zeros(128, dtype=torch.uint8)
         if rank == 0:
-            uid = torch.frombuffer(bytearray(nvr.comm_unique_id()), dtype=torch.uint8).clone()
+            try:
+                uid = torch.frombuffer(bytearray(nvr.comm_unique_id()), dtype=torch.uint8).clone()
+            except Exception:                                                    # noqa: BLE001
+                pass
         dist.broadcast(uid, 0)
-        ok, why = 1, ""
+        rccl_ok, why = True, ""
         try:
-            eng.model_runner.init_comm(bytes(uid.numpy().tobytes()))       # RCCL communicator + collective self-test
-        except Exception as ex:                                              # noqa: BLE001
-            ok, why = 0, str(ex)
-        flag = torch.tensor([ok], dtype=torch.int32)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 0:
+            if os.environ.get("NVR_BENCH_RCCL", "1") == "0":
+                raise RuntimeError("disabled by NVR_BENCH_RCCL=0")
+            eng.model_runner.init_comm(bytes(uid.numpy().tobytes()))             # RCCL communicator + collective self-test
+        except Exception as ex:                                                  # noqa: BLE001
+            rccl_ok, why = False, str(ex)
+        rccl_ok = all_ok(rccl_ok)
+        p2p_ok, why2 = os.environ.get("NVR_BENCH_P2P", "1") != "0", "disabled by NVR_BENCH_P2P=0"
+        if p2p_ok:
+            try:
+                handle = eng.model_runner.p2p_export()
+            except Exception as ex:                                              # noqa: BLE001
+                handle, p2p_ok, why2 = b"\0" * 64, False, str(ex)
+            gathered = [None] * world
+            dist.all_gather_object(gathered, (handle, local_rank))
+            if all_ok(p2p_ok):
+                try:
+                    eng.model_runner.p2p_attach([g[0] for g in gathered], [g[1] for g in gathered])
+                    dist.barrier()                                               # every rank has mapped every arena
+                    eng.model_runner.comm_selftest()                             # all-reduce + all-gather through the arenas
+                except Exception as ex:                                          # noqa: BLE001
+                    p2p_ok, why2 = False, str(ex)
+            else:
+                p2p_ok = False
+            p2p_ok = all_ok(p2p_ok)
+            if not p2p_ok:
+                eng.model_runner.p2p_disable()
+        if not rccl_ok and not p2p_ok:
+            return False, f"no collective backend: RCCL: {why or 'a peer failed'}; peer-to-peer: {why2 or 'a peer failed'}"
+        desc = ("one-shot peer-to-peer kernels over xGMI (all-reduce + residual + RMSNorm in one launch, captured in the decode graph)"
+                + ("; RCCL for messages larger than an arena slot" if rccl_ok else "")) if p2p_ok else "RCCL all-reduce (peer-to-peer arenas unavailable: " + (why2 or "a peer failed") + ")"
+        return True, desc
+
+    if args.gpus > 1 and (child or args.parallel == "tp"):
+        # the tensor-parallel engine over all ranks (as the child of a "both" parent, or directly with --parallel tp);
+        # a failure to build the communicators is reported as a JSON error line
+        eng = make_engine(args.gpus, rank)
+        ok, collective = init_tensor_parallel(eng)
+        if not ok:
             if rank == 0:
-                print(json.dumps({"error": "tensor-parallel communicator could not be built on this node" + (f": {why}" if why else "")}), flush=True)
+                print(json.dumps({"error": "tensor-parallel communicators could not be built on this node: " + collective}), flush=True)
             dist.barrier(); dist.destroy_process_group()
-            sys.stdout.flush(); os._exit(0)
+            sys.stdout.flush(); os._exit(0 if child else 3)
         parallelism, scaling, jobs = f"tp{args.gpus}", "strong", 1
         elapsed, t_prefill = run_decode(eng)
     elif args.gpus > 1:
@@ -272,73 +374,48 @@ def main() -> None:
                     "scaling": "weak", "parallelism": f"replicas{args.gpus}",
                     "note": f"{args.gpus} independent engines (one full model and its own 32 sequences per GPU), no exchange between ranks"}
         fallback_state["replicas"] = replicas
-        if args.parallel == "replicas":
-            parallelism, scaling, jobs = f"replicas{args.gpus}", "weak", args.gpus
-            elapsed, t_prefill = r_el, r_pre
-        elif args.parallel == "both":
-            # value = the replicas (what a deployment picks for a model this small); the north star's tensor-parallel configuration
-            # is measured on the same ranks right after, in a CHILD process per rank (its own gloo group on the next port): the
-            # multi-GPU RCCL path could not be exercised on the 1-GPU development boxes, and a crash or hang in it must not cost
-            # the measurement already taken
+        parallelism, scaling, jobs = f"replicas{args.gpus}", "weak", args.gpus
+        elapsed, t_prefill = r_el, r_pre
+        if args.parallel == "both":
+            # the north star's tensor-parallel configuration, measured on the same ranks right after in a CHILD process per rank
+            # (its own gloo group on the next port); first with the peer-to-peer kernels, then — if that attempt died — RCCL only
             import subprocess
-            parallelism, scaling, jobs = f"replicas{args.gpus}", "weak", args.gpus
-            elapsed, t_prefill = r_el, r_pre
-            env = dict(os.environ)
-            env["MASTER_PORT"] = str(int(env.get("MASTER_PORT", "29500")) + 1)
-            env["NVR_BENCH_CHILD"] = "1"
-            for k in [k for k in env if k.startswith("TORCHELASTIC_")]:       # the children rendezvous on their own store (rank 0 hosts it),
-                del env[k]                                                    # not on the launcher agent's
-            cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup),
-                   "--parallel", "tp", "--no-cpu-baseline", "--attn-reps", "1"] + (["--eager"] if args.eager else [])
-            child_out, child_err, child_rc = "", "", None
-            try:
-                cp = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
-                child_out, child_err, child_rc = cp.stdout, cp.stderr, cp.returncode
-            except subprocess.TimeoutExpired as te:
-                child_err = "timed out after 300 s: " + str((te.stderr or b"")[-300:])
-            if rank == 0:
-                line = next((l for l in reversed(child_out.splitlines()) if l.startswith("{")), None)
+            tp_errors = []
+            for attempt, extra_env in enumerate(({}, {"NVR_BENCH_P2P": "0"})):
+                env = dict(os.environ)
+                env["MASTER_PORT"] = str(int(env.get("MASTER_PORT", "29500")) + 1 + attempt)
+                env["NVR_BENCH_CHILD"] = "1"
+                env.update(extra_env)
+                for k in [k for k in env if k.startswith("TORCHELASTIC_")]:   # the children rendezvous on their own store (rank 0 hosts it),
+                    del env[k]                                                # not on the launcher agent's
+                cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup),
+                       "--parallel", "tp", "--no-cpu-baseline", "--attn-reps", "1"] + (["--eager"] if args.eager else [])
+                child_out, child_err, child_rc = "", "", None
                 try:
-                    cj = json.loads(line) if line else None
-                except Exception:                                            # noqa: BLE001
-                    cj = None
-                if cj and cj.get("config", {}).get("parallelism") == f"tp{args.gpus}":
-                    tensor_parallel = {"value": cj["value"], "unit": "tokens/s", "ms_per_step": cj["ms_per_step"], "scaling": "strong",
-                                       "parallelism": f"tp{args.gpus}", "speedup_vs_one_gpu": round(cj["value"] / (replicas["value"] / args.gpus), 3),
-                                       "roofline": cj.get("roofline"),
-                                       "note": "one engine over all ranks: heads / MLP columns / vocabulary sharded, RCCL all-reduce after o_proj and "
-                                               "down_proj (57 collectives per step), the same 32 sequences as at N=1"}
-                else:
-                    why = (cj or {}).get("error") or f"child exit code {child_rc}: {child_err.strip()[-400:]}"
-                    tensor_parallel = {"error": why}
-            barrier()
-        else:
-            import torch
-            eng_rep = eng                     # kept alive (5.6 GB): its KV pool backs the attention timing if the TP phase fails
-            eng = make_engine(args.gpus, rank)
-            uid = torch.zeros(128, dtype=torch.uint8)
-            if rank == 0:
-                uid = torch.frombuffer(bytearray(nvr.comm_unique_id()), dtype=torch.uint8).clone()
-            dist.broadcast(uid, 0)
-            ok, why = 1, ""
-            try:
-                eng.model_runner.init_comm(bytes(uid.numpy().tobytes()))   # RCCL communicator + collective self-test
-            except Exception as ex:                                          # noqa: BLE001
-                ok, why = 0, str(ex)
-            flag = torch.tensor([ok], dtype=torch.int32)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag.item()) == 0:
-                # The tensor-parallel communicator could not be built on this node: report it; the replicas measurement stands.
-                if why:
-                    print(f"[bench] rank {rank}: tensor-parallel init failed: {why}", file=sys.stderr, flush=True)
-                del eng
-                eng = eng_rep
-                parallelism, scaling, jobs = f"replicas{args.gpus} (tensor-parallel init failed)", "weak", args.gpus
-                elapsed, t_prefill = r_el, r_pre
-            else:
-                del eng_rep
-                parallelism, scaling, jobs = f"tp{args.gpus}", "strong", 1
-                elapsed, t_prefill = run_decode(eng)
+                    cp = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=230)
+                    child_out, child_err, child_rc = cp.stdout, cp.stderr, cp.returncode
+                except subprocess.TimeoutExpired as te:
+                    child_err = "timed out after 230 s: " + str((te.stderr or b"")[-300:])
+                done = 0
+                if rank == 0:
+                    line = next((l for l in reversed(child_out.splitlines()) if l.startswith("{")), None)
+                    try:
+                        cj = json.loads(line) if line else None
+                    except Exception:                                        # noqa: BLE001
+                        cj = None
+                    if cj and cj.get("config", {}).get("parallelism") == f"tp{args.gpus}":
+                        tensor_parallel = cj
+                        done = 1
+                    else:
+                        tp_errors.append((cj or {}).get("error") or f"child exit code {child_rc}: {child_err.strip()[-400:]}")
+                import torch
+                t = torch.tensor([done], dtype=torch.int32)
+                dist.broadcast(t, 0)
+                barrier()
+                if int(t.item()):
+                    break
+            if rank == 0 and tensor_parallel is None:
+                tensor_parallel = {"error": " | ".join(tp_errors)}
     else:
         eng = make_engine(1, 0)
         elapsed, t_prefill = run_decode(eng)
@@ -359,6 +436,12 @@ def main() -> None:
     step_gbs = step_bytes / (args.gpus / jobs) / (ms_per_step * 1e-3) / 1e9   # per-GPU share of the algorithmic bytes
 
     attn = time_attention_kernel(nvr, eng, mc, args.attn_reps)
+    chain = None
+    if args.gpus == 1 and rank == 0 and not args.no_chain:
+        try:
+            chain = time_decode_chain(nvr, mc)
+        except Exception as ex:                                              # noqa: BLE001
+            print(f"[bench] decode chain timing failed: {ex}", file=sys.stderr, flush=True)
     achieved = attn["alg_bytes"] / (attn["us_per_launch"] * 1e-6) / 1e9
     traffic = None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_attn_latest.json")
@@ -393,13 +476,34 @@ def main() -> None:
                          "us_per_launch": round(attn["us_per_launch"], 2), "launches_timed": attn["launches"],
                          "algorithmic_bytes_per_launch": int(attn["alg_bytes"])},
         }
-        if replicas is not None:
-            out["replicas"] = replicas
-        if tensor_parallel is not None:
-            out["tensor_parallel"] = tensor_parallel
+        if traffic is not None:
+            out["roofline"]["traffic_source"] = ("profiles/pmc_attn_latest.json (separate rocprofv3 --pmc FETCH_SIZE pass of this kernel: HBM bytes / "
+                                                 "algorithmic bytes), scaled by this run's algorithmic bytes — not counted in this run")
+        out["prefill"]["mfma_busy_frac_pmc_source"] = "profiles/pmc_mfma_prefill_latest.json (separate rocprofv3 --pmc pass, not counted in this run)"
+        if collective is not None:
+            out["config"]["collectives"] = collective
+        if chain is not None:
+            gbs = chain["alg_bytes_per_layer"] / (chain["us_per_layer"] * 1e-6) / 1e9
+            out["roofline_chain"] = {"kernel": "decode GEMM / norm chain, 6 launches per layer (linear_skinny_kernel x4, add_rmsnorm_slabs_kernel x2), "
+                                               "no attention", "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                     "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "us_per_layer": round(chain["us_per_layer"], 2),
+                                     "algorithmic_bytes_per_layer": int(chain["alg_bytes_per_layer"]),
+                                     "note": "one hipGraph of 28 layers with their own weights (HBM-cold), replayed back to back (HIP events on its stream)"}
         if args.gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out), flush=True)
+        if replicas is not None and tensor_parallel is not None and "error" not in tensor_parallel:
+            # N > 1: the tensor-parallel engine's line is the result; the replicas measured on the same ranks ride along
+            tp_line = dict(tensor_parallel)
+            tp_line["replicas"] = replicas
+            tp_line["speedup_vs_one_replica"] = round(tp_line["value"] / (replicas["value"] / args.gpus), 3)
+            print(json.dumps(tp_line), flush=True)
+        else:
+            if replicas is not None:
+                out["replicas"] = replicas
+            if tensor_parallel is not None:                                 # both tensor-parallel attempts failed: say so in the line
+                out["tensor_parallel"] = tensor_parallel
+                out["config"]["parallelism"] = parallelism + " (the tensor-parallel phase failed: see tensor_parallel.error)"
+            print(json.dumps(out), flush=True)
     del eng
     if dist is not None:
         dist.barrier()
