@@ -93,6 +93,10 @@ typedef struct nvr_config {
                                           prefix through the block table (K8, attention.rs:211-222) — SURVEY §8f row 2;
                                           1: the reference's prepare_prefill_inputs (model_runner.rs:176-182), which
                                           recomputes every token from position 0 */
+    int32_t enable_chunked_prefill;    /* extension A-23 (0 = the reference's whole-sequence prefill batches, scheduler.rs:135-138): the head
+                                          of the waiting queue is scheduled for min(remaining, token budget left) tokens; later chunks
+                                          attend to the earlier ones through the block table (K8); a step samples a token only for
+                                          sequences whose prompt it finished (others report token -1) */
     char device[16];                   /* config.rs:48, validated like :108-111 plus "hip": "hip" (default) | "cuda" (the reference's
                                           default, taken as "the GPU") | "cpu" | "metal"; a runner exists only for "hip" / "cuda" —
                                           there is no CPU path in this library (NVR_ERR_UNSUPPORTED) */
@@ -135,6 +139,9 @@ NVR_API size_t nvr_seq_len(const nvr_seq_t *s);                       /* :104 */
 NVR_API size_t nvr_seq_num_prompt_tokens(const nvr_seq_t *s);
 NVR_API size_t nvr_seq_num_completion_tokens(const nvr_seq_t *s);     /* :135 */
 NVR_API size_t nvr_seq_num_cached_tokens(const nvr_seq_t *s);
+/* chunked prefill (A-23): tokens already in the cache, and the token range of the step the sequence was last scheduled into */
+NVR_API size_t nvr_seq_num_computed_tokens(const nvr_seq_t *s);
+NVR_API void nvr_seq_chunk(const nvr_seq_t *s, size_t *start, size_t *len);
 NVR_API int64_t nvr_seq_last_token(const nvr_seq_t *s);
 NVR_API size_t nvr_seq_num_blocks(const nvr_seq_t *s);                /* :157 */
 NVR_API size_t nvr_seq_last_block_num_tokens(const nvr_seq_t *s);     /* :167 */

@@ -54,7 +54,7 @@ class ConfigC(C.Structure):
                 ("kvcache_block_size", C.c_uint64), ("num_kvcache_blocks", C.c_int64),
                 ("tensor_parallel_rank", C.c_uint64), ("device_ordinal", C.c_int32), ("sample_seed", C.c_uint64),
                 ("skip_block_size_check", C.c_int32), ("decode_chain", C.c_uint32),
-                ("recompute_cached_prefix", C.c_int32), ("device", C.c_char * 16), ("dtype", C.c_char * 16)]
+                ("recompute_cached_prefix", C.c_int32), ("enable_chunked_prefill", C.c_int32), ("device", C.c_char * 16), ("dtype", C.c_char * 16)]
 
 
 class ModelConfigC(C.Structure):
@@ -131,6 +131,7 @@ _SIGS = {
     "nvr_seq_id": (C.c_uint64, [_P]), "nvr_seq_status": (C.c_int32, [_P]), "nvr_seq_len": (C.c_size_t, [_P]),
     "nvr_seq_num_prompt_tokens": (C.c_size_t, [_P]), "nvr_seq_num_completion_tokens": (C.c_size_t, [_P]),
     "nvr_seq_num_cached_tokens": (C.c_size_t, [_P]), "nvr_seq_last_token": (C.c_int64, [_P]),
+    "nvr_seq_num_computed_tokens": (C.c_size_t, [_P]), "nvr_seq_chunk": (None, [_P, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "nvr_seq_num_blocks": (C.c_size_t, [_P]), "nvr_seq_last_block_num_tokens": (C.c_size_t, [_P]),
     "nvr_seq_token_ids": (None, [_P, C.POINTER(_P), C.POINTER(C.c_size_t)]),
     "nvr_seq_block_table": (None, [_P, C.POINTER(_P), C.POINTER(C.c_size_t)]),
@@ -356,6 +357,15 @@ class Sequence:
     status = property(lambda s: lib().nvr_seq_status(s.h))
     num_prompt_tokens = property(lambda s: lib().nvr_seq_num_prompt_tokens(s.h))
     num_cached_tokens = property(lambda s: lib().nvr_seq_num_cached_tokens(s.h))
+    num_computed_tokens = property(lambda s: lib().nvr_seq_num_computed_tokens(s.h))
+
+    @property
+    def chunk(self) -> Tuple[int, int]:
+        """(start, length) of the token range of the step this sequence was last scheduled into (chunked prefill, A-23)"""
+        a, n = C.c_size_t(), C.c_size_t()
+        lib().nvr_seq_chunk(self.h, C.byref(a), C.byref(n))
+        return a.value, n.value
+
     last_token = property(lambda s: lib().nvr_seq_last_token(s.h))
     token_ids = property(lambda s: _read_array(lib().nvr_seq_token_ids, s.h, np.int64))
     block_table = property(lambda s: _read_array(lib().nvr_seq_block_table, s.h, np.int32))

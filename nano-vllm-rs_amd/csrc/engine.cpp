@@ -37,6 +37,8 @@ int nvr_engine::step(nvr_step_info *info) {                          // LLMEngin
     rc = runner->sample(batch.data(), batch.size(), last_tokens.data());   // :182-185
     if (rc) { scheduler->impl.abort_batch(batch.data(), batch.size()); return rc; }
     const double t3 = g_trace.on ? now_us() : 0;
+    for (size_t i = 0; i < batch.size(); ++i)                            // A-23: a prompt this step did not finish has no token yet
+        if (batch[i]->chunk_is_partial()) last_tokens[i] = -1;
     last_ids.resize(batch.size());
     for (size_t i = 0; i < batch.size(); ++i) last_ids[i] = batch[i]->seq_id;
     const uint64_t ntok = (uint64_t)runner->last_tokens;                 // rows fed through the model (a prefill skips cached prefixes)
@@ -113,7 +115,7 @@ int nvr_engine::add_ids(const int64_t *prompt, size_t n, const nvr_sampling_para
     // and max_tokens is clamped so that the sequence's last decode step still fits max_model_len.
     if ((int64_t)n > runner->max_pos)
         return nvr::fail(NVR_ERR_INVALID_ARG, "prompt of %zu tokens exceeds max_model_len %ld", n, (long)runner->max_pos);
-    if ((int64_t)n > runner->max_tokens)
+    if ((int64_t)n > runner->max_tokens && !cfg.enable_chunked_prefill)      // (chunked prefill, A-23, cuts such a prompt into batches)
         return nvr::fail(NVR_ERR_INVALID_ARG, "prompt of %zu tokens exceeds max_num_batched_tokens %ld", n, (long)runner->max_tokens);
     nvr_seq *s = nvr_seq_create(prompt, n, sp, cfg.kvcache_block_size);
     if (!s) return NVR_ERR_INVARIANT;
@@ -145,7 +147,7 @@ int nvr_engine::generate(const std::vector<std::vector<int64_t>> &prompts, const
     if (sp) { int rc = nvr_sampling_params_validate(sp); if (rc) return rc; }
     for (size_t i = 0; i < prompts.size(); ++i) {
         if (prompts[i].empty()) return nvr::fail(NVR_ERR_INVALID_ARG, "generate: prompt %zu is empty", i);
-        if ((int64_t)prompts[i].size() > runner->max_pos || (int64_t)prompts[i].size() > runner->max_tokens)
+        if ((int64_t)prompts[i].size() > runner->max_pos || ((int64_t)prompts[i].size() > runner->max_tokens && !cfg.enable_chunked_prefill))
             return nvr::fail(NVR_ERR_INVALID_ARG, "generate: prompt %zu has %zu tokens (max_model_len %ld, max_num_batched_tokens %ld)", i,
                              prompts[i].size(), (long)runner->max_pos, (long)runner->max_tokens);
         for (int64_t t : prompts[i])

@@ -431,15 +431,27 @@ int nvr_model_runner::execute(nvr_seq *const *seqs, size_t nseq, bool is_prefill
         // its K/V rows are in the cache (written by an earlier step, or by the owner's rows of THIS step's qkv launch,
         // which precedes the attention launch of the layer) and the new tokens attend to them through the block table
         // (K8, attention.rs:211-222).  At least the last token is always computed (its logits are the step's output).
+        // With enable_chunked_prefill (A-23) a sequence contributes the token range [chunk_start, chunk_start + chunk_len) the
+        // scheduler gave it; earlier tokens are reached through the block table exactly like a cached prefix.
         const bool flash_ok = k::flash_prefill_ok((int)D, (int)H, (int)KVH);
+        const bool chunked = cfg.enable_chunked_prefill != 0;
+        auto range_of = [&](const nvr_seq &sq, int64_t *lo, int64_t *hi) {        // rows fed through the model for this sequence
+            const int64_t len = (int64_t)sq.len();
+            int64_t a0 = 0, b0 = len;
+            if (chunked && sq.chunk_len > 0) { a0 = (int64_t)sq.chunk_start; b0 = a0 + (int64_t)sq.chunk_len; }
+            int64_t c = (cfg.recompute_cached_prefix || !flash_ok) ? 0 : std::min<int64_t>((int64_t)sq.num_cached_tokens, b0 - 1);
+            if (!flash_ok) a0 = 0;                                                // (row-kernel attention has no paged prefill form)
+            *lo = std::max<int64_t>(a0, std::max<int64_t>(c, 0)); *hi = b0;
+        };
+        if (chunked && !flash_ok)
+            for (size_t b = 0; b < nseq; ++b)
+                if (seqs[b]->chunk_start > 0) return nvr::fail(NVR_ERR_UNSUPPORTED, "chunked prefill needs the paged flash kernel (head_dim 64/128)");
         prefill_paged = false;
         int64_t total = 0;
         for (size_t b = 0; b < nseq; ++b) {
-            const int64_t len = (int64_t)seqs[b]->len();
-            int64_t c = (cfg.recompute_cached_prefix || !flash_ok) ? 0 : std::min<int64_t>((int64_t)seqs[b]->num_cached_tokens, len - 1);
-            if (c < 0) c = 0;
-            prefill_paged |= c > 0;
-            total += len - c;
+            int64_t lo, hi; range_of(*seqs[b], &lo, &hi);
+            prefill_paged |= lo > 0;
+            total += hi - lo;
         }
         if (total > max_tokens) return nvr::fail(NVR_ERR_INVALID_ARG, "prefill of %ld tokens exceeds max_num_batched_tokens %ld", (long)total, (long)max_tokens);
         cu[0] = 0;
@@ -448,11 +460,11 @@ int nvr_model_runner::execute(nvr_seq *const *seqs, size_t nseq, bool is_prefill
         n_tiles = 0;
         for (size_t b = 0; b < nseq; ++b) {
             const nvr_seq &s = *seqs[b];
-            const int64_t len = (int64_t)s.len();
-            if (len > max_pos) return nvr::fail(NVR_ERR_INVALID_ARG, "sequence of %ld tokens exceeds max_model_len %ld", (long)len, (long)max_pos);
-            if ((int64_t)s.block_table.size() * bs < len) return nvr::fail(NVR_ERR_NOT_ALLOCATED, "Sequence has no allocated blocks");
-            const int64_t c0 = prefill_paged ? std::max<int64_t>(0, std::min<int64_t>((int64_t)s.num_cached_tokens, len - 1)) : 0;
-            for (int64_t p = c0; p < len; ++p) {
+            int64_t c0, end; range_of(s, &c0, &end);
+            if (!prefill_paged) c0 = 0;
+            if (end > max_pos) return nvr::fail(NVR_ERR_INVALID_ARG, "sequence of %ld tokens exceeds max_model_len %ld", (long)end, (long)max_pos);
+            if ((int64_t)s.block_table.size() * bs < end) return nvr::fail(NVR_ERR_NOT_ALLOCATED, "Sequence has no allocated blocks");
+            for (int64_t p = c0; p < end; ++p) {
                 if ((uint64_t)s.token_ids[p] >= (uint64_t)V)                 // candle's index_select rejects these (embed_head.rs:80)
                     return nvr::fail(NVR_ERR_INVALID_ARG, "token id %ld at position %ld is outside the vocabulary [0, %ld)", (long)s.token_ids[p], (long)p, (long)V);
                 ids[T] = s.token_ids[p]; pos[T] = p;
@@ -461,13 +473,13 @@ int nvr_model_runner::execute(nvr_seq *const *seqs, size_t nseq, bool is_prefill
                 ++T;
             }
             cu[b + 1] = (int32_t)T;
-            max_ctx = std::max(max_ctx, len);
+            max_ctx = std::max(max_ctx, end);
             if (prefill_paged) {
                 if ((int64_t)s.block_table.size() > max_blocks_per_seq) return nvr::fail(NVR_ERR_INVARIANT, "block table longer than max_model_len allows");
                 std::memcpy(bt + b * max_blocks_per_seq, s.block_table.data(), s.block_table.size() * 4);
             }
             if (flash_ok) {                                              // longest-context tiles of a sequence first
-                const int64_t nq = len - c0;
+                const int64_t nq = end - c0;
                 for (int64_t q0 = (nq - 1) / qb * qb; q0 >= 0; q0 -= qb)
                     tl[n_tiles++] = k::FlashTile{(int32_t)(cu[b] + q0), (int32_t)std::min<int64_t>(qb, nq - q0), (int32_t)(c0 + q0),
                                                  prefill_paged ? (int32_t)b : cu[b]};

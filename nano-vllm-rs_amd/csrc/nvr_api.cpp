@@ -126,6 +126,8 @@ size_t nvr_seq_len(const nvr_seq_t *s) { return s->len(); }
 size_t nvr_seq_num_prompt_tokens(const nvr_seq_t *s) { return s->num_prompt_tokens; }
 size_t nvr_seq_num_completion_tokens(const nvr_seq_t *s) { return s->num_completion_tokens(); }
 size_t nvr_seq_num_cached_tokens(const nvr_seq_t *s) { return s->num_cached_tokens; }
+size_t nvr_seq_num_computed_tokens(const nvr_seq_t *s) { return s->num_computed_tokens; }
+void nvr_seq_chunk(const nvr_seq_t *s, size_t *start, size_t *len) { if (start) *start = s->chunk_start; if (len) *len = s->chunk_len; }
 int64_t nvr_seq_last_token(const nvr_seq_t *s) { return s->last_token; }
 size_t nvr_seq_num_blocks(const nvr_seq_t *s) { return s->num_blocks(); }
 size_t nvr_seq_last_block_num_tokens(const nvr_seq_t *s) { return s->last_block_num_tokens(); }

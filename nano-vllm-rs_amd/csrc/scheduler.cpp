@@ -7,7 +7,7 @@ namespace nvr {
 
 Scheduler::Scheduler(const nvr_config &cfg)
     : max_num_seqs_(cfg.max_num_seqs), max_num_batched_tokens_(cfg.max_num_batched_tokens),
-      has_eos_(cfg.has_eos != 0), eos_(cfg.eos_token_id),
+      has_eos_(cfg.has_eos != 0), eos_(cfg.eos_token_id), chunked_(cfg.enable_chunked_prefill != 0),
       bm_(new nvr_block_manager(cfg.num_kvcache_blocks >= 0 ? (size_t)cfg.num_kvcache_blocks : 1000,  // :71-74
                                 cfg.kvcache_block_size)) {}
 
@@ -45,7 +45,45 @@ int Scheduler::schedule(std::vector<nvr_seq *> &out, bool *is_prefill) {   // :1
     return NVR_OK;
 }
 
+// Extension A-23 — intra-sequence chunked prefill on top of :119-168 (twin of oracle/engine_oracle.py::_try_schedule_prefill_chunked):
+// the head of the waiting queue is scheduled for min(remaining, budget left) tokens instead of being held back until its whole
+// remainder fits the token budget.  Its blocks are allocated for the whole prompt when its first chunk is scheduled
+// (can_allocate / allocate as :141-149); a sequence whose prompt is not finished stays at the FRONT of the waiting queue with its
+// blocks and closes the batch; its last chunk moves it to running like :152-165.
+bool Scheduler::try_schedule_prefill_chunked(std::vector<nvr_seq *> &out, int *rc) {
+    if (waiting_.empty()) return false;
+    size_t num_seqs = 0, num_batched_tokens = 0;
+    BlockManager &bm = bm_->impl;
+    std::vector<nvr_seq *> done;
+    while (!waiting_.empty()) {
+        nvr_seq *s = waiting_.front();
+        if (num_seqs >= max_num_seqs_) break;
+        if (num_batched_tokens >= max_num_batched_tokens_) break;
+        const size_t budget_left = max_num_batched_tokens_ - num_batched_tokens;
+        if (s->block_table.empty()) {                                // first chunk: blocks for the whole prompt
+            if (!bm.can_allocate(*s)) break;
+            int r = bm.allocate(*s);
+            if (r) { *rc = r; return false; }
+            s->num_computed_tokens = 0;
+        }
+        const size_t remaining = s->len() - s->num_computed_tokens;
+        const size_t chunk = std::min(remaining, budget_left);
+        s->chunk_start = s->num_computed_tokens; s->chunk_len = chunk;
+        num_seqs += 1;
+        num_batched_tokens += chunk;
+        out.push_back(s);
+        if (chunk < remaining) break;                                // budget exhausted inside this prompt
+        waiting_.pop_front();
+        s->status = NVR_SEQ_RUNNING;
+        done.push_back(s);
+    }
+    if (out.empty()) return false;
+    for (nvr_seq *s : done) running_.push_back(s);
+    return true;
+}
+
 bool Scheduler::try_schedule_prefill(std::vector<nvr_seq *> &out, int *rc) {   // :119-168
+    if (chunked_) return try_schedule_prefill_chunked(out, rc);
     if (waiting_.empty()) return false;
     size_t num_seqs = 0, num_batched_tokens = 0;
     BlockManager &bm = bm_->impl;
@@ -61,6 +99,7 @@ bool Scheduler::try_schedule_prefill(std::vector<nvr_seq *> &out, int *rc) {   /
         num_seqs += 1;
         num_batched_tokens += seq_tokens;
         s->status = NVR_SEQ_RUNNING;
+        s->chunk_start = 0; s->chunk_len = s->len();
         out.push_back(s);
     }
     if (out.empty()) return false;
@@ -88,6 +127,7 @@ int Scheduler::try_schedule_decode(std::vector<nvr_seq *> &out) {    // :171-223
             num_seqs += 1;
             int rc = bm.may_append(*s);
             if (rc) return rc;
+            s->chunk_start = s->len() - 1; s->chunk_len = 1;
             out.push_back(s);
         }
     }
@@ -110,6 +150,8 @@ int Scheduler::postprocess(nvr_seq *const *seqs, const int64_t *token_ids, size_
     // (the reference's length check, :235-237, is enforced at the ABI: one n for both arrays)
     for (size_t i = 0; i < n; ++i) {
         nvr_seq *s = seqs[i];
+        s->num_computed_tokens = s->chunk_start + s->chunk_len;
+        if (s->num_computed_tokens < s->len()) continue;             // A-23: a prefill chunk that does not finish the prompt
         s->append_token(token_ids[i]);
         if (s->should_stop(has_eos_, eos_)) {
             s->status = NVR_SEQ_FINISHED;
@@ -132,6 +174,8 @@ void Scheduler::abort_batch(nvr_seq *const *seqs, size_t n) {
         nvr_seq *s = seqs[i];
         auto it = std::find(running_.begin(), running_.end(), s);
         if (it != running_.end()) running_.erase(it);
+        it = std::find(waiting_.begin(), waiting_.end(), s);          // a partially prefilled prompt lives at the front of waiting
+        if (it != waiting_.end()) waiting_.erase(it);
         if (!s->block_table.empty()) (void)bm_->impl.deallocate(*s);
         s->status = NVR_SEQ_FINISHED;
         finished_.push_back(s);
@@ -144,6 +188,8 @@ void Scheduler::preempt_all() {                                      // :314-319
     std::vector<nvr_seq *> seqs(running_.begin(), running_.end());
     running_.clear();
     for (nvr_seq *s : seqs) preempt_sequence(s);
+    for (nvr_seq *s : waiting_)                                       // A-23: a partially prefilled prompt gives its blocks back too
+        if (!s->block_table.empty()) { (void)bm_->impl.deallocate(*s); s->num_computed_tokens = 0; }
 }
 
 double Scheduler::memory_pressure() const {                          // :322-329

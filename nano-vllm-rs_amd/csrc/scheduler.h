@@ -39,12 +39,14 @@ public:
 
 private:
     bool try_schedule_prefill(std::vector<nvr_seq *> &out, int *rc);                    // :119
+    bool try_schedule_prefill_chunked(std::vector<nvr_seq *> &out, int *rc);            // extension A-23
     int try_schedule_decode(std::vector<nvr_seq *> &out);                               // :171
     int preempt_sequence(nvr_seq *s);                                                   // :226
     void update_stats() { stats_.waiting_sequences = waiting_.size(); stats_.running_sequences = running_.size(); }
 
     size_t max_num_seqs_, max_num_batched_tokens_;
     bool has_eos_; int64_t eos_;
+    bool chunked_ = false;                       // nvr_config.enable_chunked_prefill
     std::unique_ptr<nvr_block_manager> bm_;
     std::deque<nvr_seq *> waiting_, running_;
     std::vector<nvr_seq *> finished_;

@@ -19,6 +19,10 @@ struct nvr_seq {
     nvr_sampling_params sampling{};
     size_t block_size = 256;
     bool owned_by_scheduler = false;
+    // chunked prefill (extension A-23; the reference schedules whole sequences, scheduler.rs:135-138): tokens whose K/V are in
+    // the cache, and the token range [chunk_start, chunk_start + chunk_len) the sequence contributes to the step it is in
+    size_t num_computed_tokens = 0, chunk_start = 0, chunk_len = 0;
+    bool chunk_is_partial() const { return chunk_start + chunk_len < num_tokens; }
 
     size_t len() const { return num_tokens; }                                        // :104
     size_t num_completion_tokens() const { return num_tokens - num_prompt_tokens; }  // :135
@@ -42,7 +46,7 @@ struct nvr_seq {
         if (!sampling.ignore_eos && has_eos && last_token == eos) return true;
         return false;
     }
-    void preempt() { status = NVR_SEQ_PREEMPTED; block_table.clear(); num_cached_tokens = 0; }  // :213
+    void preempt() { status = NVR_SEQ_PREEMPTED; block_table.clear(); num_cached_tokens = 0; num_computed_tokens = 0; }  // :213
 };
 
 namespace nvr {

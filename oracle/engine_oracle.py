@@ -138,6 +138,11 @@ class Sequence:
         self.block_table: List[int] = []
         self.sampling_params = sampling_params
         self.block_size = block_size
+        # chunked prefill (extension A-23; the reference schedules whole sequences, scheduler.rs:135-138): tokens whose K/V
+        # are in the cache, and the token range [chunk_start, chunk_start + chunk_len) of the step the sequence is in
+        self.num_computed_tokens = 0
+        self.chunk_start = 0
+        self.chunk_len = 0
 
     def __len__(self) -> int:                       # :104-106
         return self.num_tokens
@@ -189,6 +194,7 @@ class Sequence:
         self.status = PREEMPTED
         self.block_table.clear()
         self.num_cached_tokens = 0
+        self.num_computed_tokens = 0
 
     def clone(self) -> "Sequence":                  # #[derive(Clone)] :49
         c = copy.copy(self)
@@ -365,6 +371,7 @@ class Config:
     num_kvcache_blocks: Optional[int] = None
     device: str = "cuda"
     dtype: str = "float16"
+    enable_chunked_prefill: bool = False      # extension A-23 (the reference has no intra-sequence chunking)
 
     def validate(self) -> None:                               # config.rs:83-119 (path checks omitted)
         if self.kvcache_block_size % 256 != 0:
@@ -403,6 +410,7 @@ class Scheduler:
         self.max_num_seqs = config.max_num_seqs
         self.max_num_batched_tokens = config.max_num_batched_tokens
         self.eos_token_id = config.eos_token_id
+        self.chunked = bool(getattr(config, "enable_chunked_prefill", False))
         self.waiting: deque = deque()
         self.running: deque = deque()
         self.stats = SchedulerStats()
@@ -431,7 +439,51 @@ class Scheduler:
             self.stats.avg_decode_batch_size * (n - 1.0) + float(len(seqs))) / n
         return seqs, False
 
+    def _try_schedule_prefill_chunked(self) -> Optional[List[Sequence]]:
+        """Extension A-23 — intra-sequence chunked prefill on top of :119-168: the head of the waiting queue is scheduled for
+        min(remaining, budget left) tokens instead of being held back until its whole remainder fits the token budget.  Its
+        blocks are allocated for the whole prompt when its first chunk is scheduled (can_allocate / allocate exactly as
+        :141-149); a sequence whose prompt is not finished stays at the FRONT of the waiting queue with its blocks and closes
+        the batch; its last chunk moves it to running like :152-165.  A step samples a token only for sequences whose
+        prefill completed in it."""
+        if not self.waiting:
+            return None
+        scheduled: List[Sequence] = []
+        finished_prefill: List[Sequence] = []
+        num_seqs = 0
+        num_batched_tokens = 0
+        while self.waiting:
+            seq = self.waiting[0]
+            if num_seqs >= self.max_num_seqs:
+                break
+            budget_left = self.max_num_batched_tokens - num_batched_tokens
+            if budget_left <= 0:
+                break
+            if not seq.block_table:                       # first chunk: blocks for the whole prompt
+                if not self.block_manager.can_allocate(seq):
+                    break
+                self.block_manager.allocate(seq)
+                seq.num_computed_tokens = 0
+            remaining = len(seq) - seq.num_computed_tokens
+            chunk = min(remaining, budget_left)
+            seq.chunk_start, seq.chunk_len = seq.num_computed_tokens, chunk
+            num_seqs += 1
+            num_batched_tokens += chunk
+            scheduled.append(seq)
+            if chunk < remaining:                         # budget exhausted inside this prompt
+                break
+            self.waiting.popleft()
+            seq.status = RUNNING
+            finished_prefill.append(seq)
+        if not scheduled:
+            return None
+        for seq in finished_prefill:
+            self.running.append(seq.clone())
+        return scheduled
+
     def _try_schedule_prefill(self) -> Optional[List[Sequence]]:   # :119-168
+        if self.chunked:
+            return self._try_schedule_prefill_chunked()
         if not self.waiting:
             return None
         scheduled: List[Sequence] = []
@@ -451,6 +503,7 @@ class Scheduler:
             num_seqs += 1
             num_batched_tokens += seq_tokens
             seq.status = RUNNING
+            seq.chunk_start, seq.chunk_len = 0, len(seq)
             scheduled.append(seq)
         if not scheduled:
             return None
@@ -480,6 +533,7 @@ class Scheduler:
             if not self_preempted and self.block_manager.can_append(seq):
                 num_seqs += 1
                 self.block_manager.may_append(seq)
+                seq.chunk_start, seq.chunk_len = len(seq) - 1, 1
                 scheduled.append(seq)
         for seq in reversed(to_reschedule):
             self.running.appendleft(seq)
@@ -499,6 +553,9 @@ class Scheduler:
         if len(sequences) != len(token_ids):
             raise RuntimeError("Mismatch between sequences and token_ids length")
         for seq, token_id in zip(sequences, token_ids):
+            seq.num_computed_tokens = seq.chunk_start + seq.chunk_len
+            if seq.num_computed_tokens < len(seq):        # A-23: a prefill chunk that does not finish the prompt — no token yet
+                continue
             seq.append_token(token_id)
             if seq.should_stop(self.eos_token_id):
                 seq.finish()
@@ -523,6 +580,10 @@ class Scheduler:
         self.running.clear()
         for seq in seqs:
             self._preempt_sequence(seq)
+        for seq in self.waiting:                          # A-23: a partially prefilled prompt gives its blocks back too
+            if seq.block_table:
+                self.block_manager.deallocate(seq)
+                seq.num_computed_tokens = 0
 
     def memory_pressure(self) -> float:                       # :322-329
         st = self.block_manager.get_stats()
@@ -543,6 +604,19 @@ def slot_of(seq: Sequence, pos: int, block_size: int) -> int:
 def prepare_prefill(seqs: List[Sequence], block_size: int) -> dict:
     """prepare_prefill_inputs :172-193 + create_prefill_context :222-263 (A-7: all
     tokens from position 0; slot mapping per A-6)."""
+    if any(s.chunk_len and (s.chunk_start != 0 or s.chunk_len != len(s)) for s in seqs):
+        # A-23: token ranges [chunk_start, chunk_start + chunk_len); earlier tokens are reached through the block table
+        # (flash_attention_varlen_with_cache, attention.rs:211-222): context_lens = end of the chunk
+        ids, pos, cu, slots, ctx = [], [], [0], [], []
+        for s in seqs:
+            a, b = s.chunk_start, s.chunk_start + s.chunk_len
+            ids.extend(s.token_ids[a:b]); pos.extend(range(a, b)); cu.append(cu[-1] + (b - a))
+            slots.extend(slot_of(s, p, block_size) for p in range(a, b))
+            ctx.append(b)
+        max_blocks = max([len(s.block_table) for s in seqs] or [1])
+        bt = [list(s.block_table) + [-1] * (max_blocks - len(s.block_table)) for s in seqs]
+        return dict(input_ids=ids, positions=pos, cu_seqlens_q=cu, slot_mapping=slots, context_lens=ctx, block_tables=bt,
+                    max_blocks=max_blocks)
     ids, pos, cu, slots = [], [], [0], []
     max_len = 0
     for s in seqs:

@@ -285,6 +285,8 @@ def build_meta(seqs: List[eo.Sequence], is_prefill: bool, block_size: int) -> tu
         p = eo.prepare_prefill(seqs, block_size)
         meta = dict(is_prefill=True, cu_seqlens_q=np.asarray(p["cu_seqlens_q"], np.int32),
                     slot_mapping=np.asarray(p["slot_mapping"], np.int32), block_tables=None)
+        if "block_tables" in p:                              # A-23 chunks: earlier tokens through the block table (K8)
+            meta.update(block_tables=np.asarray(p["block_tables"], np.int32), context_lens=np.asarray(p["context_lens"], np.int32))
     else:
         p = eo.prepare_decode(seqs, block_size)
         meta = dict(is_prefill=False, slot_mapping=np.asarray(p["slot_mapping"], np.int32),
@@ -333,6 +335,10 @@ class OracleEngine:
         toks = self.sample_tokens(logits, seqs)
         rec = dict(is_prefill=is_prefill, seq_ids=[s.seq_id for s in seqs],
                    block_tables=[list(s.block_table) for s in seqs], tokens=list(toks), logits=logits)
+        partial = [s.chunk_start + s.chunk_len < len(s) for s in seqs]     # A-23: prompts not finished by this step
+        if any(partial):
+            rec["tokens"] = [-1 if pt else t for t, pt in zip(rec["tokens"], partial)]
+            toks = list(rec["tokens"])
         if forced_tokens is not None:          # teacher forcing for near-tie analysis
             toks = list(forced_tokens)
         self.scheduler.postprocess(seqs, toks)

@@ -563,3 +563,52 @@ def test_config_device_and_dtype_gate_the_runner():
         with pytest.raises(nvr.NvrError) as e:
             nvr.ModelRunner(nvr.Config(**base, **bad), _model_cfgs(mcfg))
         assert e.value.code == -10
+
+
+def test_chunked_prefill_engine_parity():
+    """Extension A-23 (enable_chunked_prefill): prompts longer than the token budget are cut into several prefill steps; later
+    chunks reach the earlier ones through the block table (paged flash kernel).  Product vs the oracle's chunked engine:
+    batch composition, chunk ranges (through the logits of the rows they feed), block tables, -1 tokens for unfinished prompts,
+    logits within tolerance on every finishing row, greedy tokens equal outside near-ties; then chunked == unchunked tokens."""
+    mcfg = mo.small()
+    ecfg = dict(max_num_seqs=6, max_num_batched_tokens=48, max_model_len=256, kvcache_block_size=16, num_kvcache_blocks=80)
+    prompts = [oracle.fill_tokens(n, 1, i, mcfg.vocab_size).tolist() for i, n in enumerate([130, 20, 75, 48, 3, 49])]
+    sps = [dict(temperature=0.0, max_tokens=8, ignore_eos=True)] * len(prompts)
+
+    def run(chunked, budget):
+        eo.reset_sequence_counter(); nvr.lib().nvr_seq_reset_id_counter()
+        cfg = dict(ecfg, max_num_batched_tokens=budget, enable_chunked_prefill=chunked)
+        o = mo.OracleEngine(mcfg, eo.Config(**cfg), fp16=True, max_pos=cfg["max_model_len"])
+        p = nvr.LLMEngine(nvr.Config(skip_block_size_check=1, **cfg), _model_cfgs(mcfg))
+        for pr, sp in zip(prompts, sps):
+            o.add_request(pr, eo.SamplingParams(**sp)); p.add_request(pr, nvr.SamplingParams(**sp))
+        ties, partial_rows, steps = 0, 0, 0
+        while not p.is_finished():
+            rec = p.step()
+            logits = p.model_runner.logits(rec["num_seqs"])
+            orec = o.step(forced_tokens=rec["tokens"])
+            assert orec["seq_ids"] == rec["seq_ids"] and orec["is_prefill"] == rec["is_prefill"], f"step {steps}"
+            assert [t == -1 for t in rec["tokens"]] == [t == -1 for t in orec["tokens"]], f"step {steps}: unfinished prompts differ"
+            srt = np.sort(orec["logits"], axis=1)
+            for i, (a, b) in enumerate(zip(rec["tokens"], orec["tokens"])):
+                if a == -1:
+                    partial_rows += 1
+                    continue
+                assert np.abs(logits[i] - orec["logits"][i]).max() < LOGIT_TOL, f"step {steps} row {i}"
+                if a != b:
+                    assert srt[i, -1] - srt[i, -2] <= 2 * LOGIT_TOL
+                    ties += 1
+            steps += 1
+            assert steps < 200
+        assert o.scheduler.is_finished()
+        return {s.seq_id: s.token_ids for s in p.take_finished()}, ties, partial_rows, steps
+    fc, ties, partial, steps_c = run(True, 48)
+    assert partial >= 4 and ties <= 2                      # 130 / 75 / 49-token prompts against a 48-token budget
+    fu, ties_u, partial_u, steps_u = run(False, 512)
+    assert partial_u == 0 and ties_u <= 2
+    same = sum(fc[k] == fu[k] for k in fc)
+    assert same >= len(fc) - 1, (same, len(fc))             # same greedy continuations whatever the chunking
+    # a prompt longer than the budget is refused without chunking, accepted with it
+    p2 = nvr.LLMEngine(nvr.Config(skip_block_size_check=1, **dict(ecfg, max_num_batched_tokens=48)), _model_cfgs(mcfg))
+    with pytest.raises(nvr.NvrError, match="max_num_batched_tokens"):
+        p2.add_request(prompts[0], nvr.SamplingParams(temperature=0.0, max_tokens=2))

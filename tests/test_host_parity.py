@@ -177,6 +177,7 @@ def test_scheduler_reference_scenarios():            # scheduler.rs:417-578
 def _snapshot_oracle(sc: eo.Scheduler, seqs, pf):
     st = sc.stats
     return dict(pf=pf, ids=[s.seq_id for s in seqs], tables=[list(s.block_table) for s in seqs],
+                chunks=[(s.chunk_start, s.chunk_len) for s in seqs],
                 cached=[s.num_cached_tokens for s in seqs], lens=[len(s) for s in seqs],
                 free=list(sc.block_manager.free_block_ids), bm=sc.block_manager.get_stats(),
                 q=sc.get_queue_lengths(),
@@ -187,17 +188,19 @@ def _snapshot_oracle(sc: eo.Scheduler, seqs, pf):
 def _snapshot_product(sc, seqs, pf):
     st = sc.get_stats()
     return dict(pf=pf, ids=[s.seq_id for s in seqs], tables=[s.block_table for s in seqs],
+                chunks=[s.chunk for s in seqs],
                 cached=[s.num_cached_tokens for s in seqs], lens=[len(s) for s in seqs],
                 free=sc.block_manager.free_list(), bm=sc.block_manager.get_stats(), q=sc.get_queue_lengths(),
                 stats=(st["total_sequences"], st["finished_sequences"], st["preemptions"], st["prefill_batches"],
                        st["decode_batches"], st["avg_prefill_batch_size"], st["avg_decode_batch_size"]))
 
 
+@pytest.mark.parametrize("chunked", [False, True])
 @pytest.mark.parametrize("seed,bs,nblocks,nseq,max_seqs,budget", [
     (0, 4, 24, 12, 6, 64), (1, 4, 12, 10, 8, 40), (2, 16, 40, 16, 16, 256), (3, 8, 9, 6, 3, 1000),
-    (4, 4, 64, 20, 5, 30), (5, 256, 12, 6, 6, 4096), (6, 2, 30, 25, 7, 20),
+    (4, 4, 64, 20, 5, 30), (5, 256, 12, 6, 6, 4096), (6, 2, 30, 25, 7, 20), (7, 4, 40, 14, 6, 9), (8, 8, 30, 10, 4, 13),
 ])
-def test_scheduler_trace_parity(seed, bs, nblocks, nseq, max_seqs, budget):
+def test_scheduler_trace_parity(seed, bs, nblocks, nseq, max_seqs, budget, chunked):
     """Drive oracle and product with the same requests and the same 'sampled' tokens; every step must
     agree on batch, block tables, free-list order and statistics (covers prefix hits, mid-stream
     arrivals, block exhaustion, victim preemption from running / scheduled / self, EOS and max_tokens)."""
@@ -205,13 +208,14 @@ def test_scheduler_trace_parity(seed, bs, nblocks, nseq, max_seqs, budget):
     eo.reset_sequence_counter()
     nvr.lib().nvr_seq_reset_id_counter()
     cfg = dict(max_num_seqs=max_seqs, max_num_batched_tokens=budget, eos_token_id=7, kvcache_block_size=bs,
-               num_kvcache_blocks=nblocks)
+               num_kvcache_blocks=nblocks, enable_chunked_prefill=chunked)
     o = eo.Scheduler(eo.Config(**cfg))
     p = nvr.Scheduler(nvr.Config(skip_block_size_check=1, **cfg))
     shared = rng.integers(8, 50, 3 * bs).tolist()
     pending = []
     for i in range(nseq):
-        plen = int(rng.integers(1, min(budget, 5 * bs)))
+        # chunked (extension A-23): prompts may exceed the token budget and are cut into several prefill steps
+        plen = int(rng.integers(1, 5 * bs if chunked else min(budget, 5 * bs)))
         if rng.random() < 0.5:
             k = int(rng.integers(0, 3)) * bs
             prompt = (shared[:k] + rng.integers(8, 50, max(1, plen)).tolist())[:max(1, plen)]
@@ -219,7 +223,7 @@ def test_scheduler_trace_parity(seed, bs, nblocks, nseq, max_seqs, budget):
             prompt = rng.integers(8, 50, plen).tolist()
         sp = dict(max_tokens=int(rng.integers(1, 3 * bs)), ignore_eos=bool(rng.random() < 0.3))
         pending.append((prompt, sp, int(rng.integers(0, 6))))      # arrival step
-    step, steps_done = 0, 0
+    step, steps_done, partial_steps = 0, 0, 0
     while True:
         for prompt, sp, arrive in [x for x in pending if x[2] == step]:
             o.add_sequence(eo.Sequence(prompt, eo.SamplingParams(**sp), bs))
@@ -239,6 +243,7 @@ def test_scheduler_trace_parity(seed, bs, nblocks, nseq, max_seqs, budget):
             break
         pseqs, ppf = p.schedule()
         assert _snapshot_oracle(o, oseqs, opf) == _snapshot_product(p, pseqs, ppf), f"step {step}"
+        partial_steps += int(any(s.chunk_start + s.chunk_len < len(s) for s in oseqs))
         toks = [int((s.seq_id * 131 + len(s) * 17 + seed) % 43) + 5 for s in oseqs]   # 7 == EOS sometimes
         o.postprocess(oseqs, toks)
         p.postprocess(pseqs, toks)
@@ -247,6 +252,7 @@ def test_scheduler_trace_parity(seed, bs, nblocks, nseq, max_seqs, budget):
         steps_done += 1
         assert steps_done < 5000
     assert steps_done > 3
+    assert partial_steps == 0 if not chunked else (partial_steps > 0 or budget >= 5 * bs)   # chunked traces do cut prompts
     ost, pst = o.stats, p.get_stats()
     assert ost.finished_sequences == pst["finished_sequences"] and ost.preemptions == pst["preemptions"]
     fin = p.take_finished()

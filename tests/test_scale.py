@@ -199,3 +199,37 @@ def test_kv_pool_sized_from_free_hbm():
     eng.add_request(nvr.synthetic_tokens(20, 1, 0, 151936).tolist(), nvr.SamplingParams(temperature=0.0, max_tokens=2, ignore_eos=True))
     while not eng.is_finished():
         eng.step()
+
+
+@pytest.mark.gpu
+def test_chunked_prefill_full_size_bit_identity():
+    """Extension A-23 at BASELINE configs[2] sizes (Qwen3-0.6B): two 4096-token prompts and one of 1500 prefilled in chunks
+    against a 2048-token budget, versus one whole-prompt batch.  A GEMM row depends only on its own input row and the flash
+    kernel walks a row's keys in the same 64-key steps whether they come from this step's rows or from the cache, so the
+    last-token logits — and with them the first sampled tokens and the following decode steps — are BIT-identical."""
+    mc = nvr.ModelConfig("qwen3-0.6b")
+    base = dict(max_num_seqs=4, max_model_len=4200, kvcache_block_size=256, num_kvcache_blocks=40)
+    prompts = [nvr.synthetic_tokens(n, 1, i, 151936).tolist() for i, n in enumerate([4096, 1500, 4096])]
+
+    def run(**kw):
+        nvr.lib().nvr_seq_reset_id_counter()
+        eng = nvr.LLMEngine(nvr.Config(**base, **kw), mc)
+        for pr in prompts:
+            eng.add_request(pr, nvr.SamplingParams(temperature=0.0, max_tokens=4, ignore_eos=True))
+        first_logits, toks, prefill_steps = {}, {}, 0
+        while not eng.is_finished():
+            rec = eng.step()
+            lg = eng.model_runner.logits(rec["num_seqs"])
+            prefill_steps += int(rec["is_prefill"])
+            for i, (sid, t) in enumerate(zip(rec["seq_ids"], rec["tokens"])):
+                if t == -1:
+                    continue
+                first_logits.setdefault(sid, lg[i].copy())
+                toks.setdefault(sid, []).append(t)
+        return first_logits, toks, prefill_steps
+    lc, tc, sc = run(max_num_batched_tokens=2048, enable_chunked_prefill=1)
+    lu, tu, su = run(max_num_batched_tokens=16384)
+    assert sc == 5 and su == 1                              # 4096 + 1500 + 4096 tokens in 2048-token steps: 5 prefill steps
+    assert tc == tu
+    for sid in lu:
+        assert np.array_equal(lc[sid], lu[sid]), f"sequence {sid}: chunked and whole-prompt prefill differ in bits"
