@@ -7,6 +7,7 @@
 #include <vector>
 #include "model_runner.h"
 #include "scheduler.h"
+#include "tokenizer.h"
 
 struct nvr_engine {
     nvr_config cfg;
@@ -26,7 +27,3 @@ struct nvr_engine {
     int generate(const std::vector<std::vector<int64_t>> &prompts, const nvr_sampling_params *sp, nvr_stream_fn fn, void *user);
 };
 
-namespace nvr {
-int tokenize(const char *utf8, size_t nbytes, std::vector<int64_t> &out);      // llm_engine.rs:220-230
-void detokenize(const int64_t *ids, size_t n, std::string &out);
-}

@@ -683,7 +683,10 @@ int nvr_model_runner::sample(nvr_seq *const *seqs, size_t nseq, int64_t *out) {
             const nvr_sampling_params &sp = seqs[i]->sampling;
             t[i] = sp.temperature;
             tk[i] = sp.has_top_k ? (int64_t)sp.top_k : 0;                                   // A-18
-            tpv[i] = sp.has_top_p ? sp.top_p : -1.0f;
+            // sampler.rs:233-240: in a batch where any row sets top_p the others get unwrap_or(1.0) and are filtered with p = 1.0,
+            // which keeps every token in exact arithmetic: p >= 1.0 is "no filter" here (decision A-26, tested against the
+            // oracle's literal restatement)
+            tpv[i] = (sp.has_top_p && sp.top_p < 1.0f) ? sp.top_p : -1.0f;
             ky[i] = nvr_sample_key(cfg.sample_seed, seqs[i]->seq_id, seqs[i]->num_completion_tokens());   // A-20
         }
         NVR_HIP_CHECK(hipMemcpyAsync(d_temp, t, B * 4, hipMemcpyHostToDevice, stream));

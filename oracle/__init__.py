@@ -41,9 +41,10 @@ def usable_cores(cap: int = 32) -> int:
 def lib() -> C.CDLL:
     global _lib
     if _lib is None:
-        if not os.path.exists(_LIB_PATH):
+        path = os.environ.get("NVO_ORACLE_LIB") or _LIB_PATH          # NVO_ORACLE_LIB: the sanitizer build (tests/test_sanitizers.py)
+        if path == _LIB_PATH and not os.path.exists(_LIB_PATH):
             build()
-        _lib = C.CDLL(_LIB_PATH)
+        _lib = C.CDLL(path)
         _declare(_lib)
         _lib.nvo_set_num_threads(usable_cores())
     return _lib

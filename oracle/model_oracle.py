@@ -322,11 +322,18 @@ class OracleEngine:
 
     def sample_tokens(self, logits: np.ndarray, seqs) -> List[int]:
         """ModelRunner::sample_tokens, model_runner.rs:131-156 -> Sampler::batch_sample."""
+        # Sampler::batch_sample, sampler.rs:221-254: when ANY row of the batch sets top_p, the rows that do not are given
+        # top_p.unwrap_or(1.0) and still go through apply_top_p (:233-240); likewise top_k.unwrap_or(0) (:243-247), which A-18
+        # reads as "disabled".  Restated literally here; the product treats p >= 1.0 as "no filter" (decision A-26: in exact
+        # arithmetic p = 1.0 keeps every token; the f32 cumulative sum of :168-177 can only cut a tail of ~1e-7 total mass —
+        # tests/test_oracle_kat.py::test_top_p_one_is_no_filter, tests/test_kernels_gpu.py::test_sampler_mixed_batch_defaults).
+        any_top_p = any(s.sampling_params.top_p is not None for s in seqs)
         out = []
         for i, s in enumerate(seqs):
             sp = s.sampling_params
             key = sample_key(self.sample_seed, s.seq_id, s.num_completion_tokens())
-            out.append(sample(logits[i], sp.temperature, sp.top_k or 0, sp.top_p, key))
+            top_p = sp.top_p if sp.top_p is not None else (1.0 if any_top_p else None)
+            out.append(sample(logits[i], sp.temperature, sp.top_k or 0, top_p, key))
         return out
 
     def step(self, forced_tokens: Optional[List[int]] = None) -> dict:

@@ -319,3 +319,24 @@ def test_linear_shape_rules():                   # linear.rs:476-559 (TP shape p
     x = np.random.default_rng(0).standard_normal((3, 16)).astype(np.float32)
     W = np.random.default_rng(1).standard_normal((10, 16)).astype(np.float32)
     np.testing.assert_allclose(oracle.linear(x, W), x @ W.T, rtol=1e-5, atol=1e-5)
+
+
+def test_top_p_one_is_no_filter():
+    """Decision A-26.  Sampler::batch_sample (sampler.rs:233-240) gives rows without top_p the value 1.0 whenever another row of
+    the batch sets top_p, and still runs apply_top_p on them.  In exact arithmetic p = 1.0 keeps every token; the f32 cumulative
+    sum of :168-177 can reach 1.0 early and cut a tail.  The literal restatement (oracle.top_p / oracle.sample with p = 1.0)
+    must then (i) only ever drop a tail of negligible total probability and (ii) sample the same token as no filter at all —
+    which is how the product treats p >= 1.0."""
+    rng = np.random.default_rng(99)
+    dropped_mass, trials = 0.0, 0
+    for V, scale in [(50, 3.0), (1000, 1.0), (1000, 6.0), (20000, 2.0), (151936, 0.3), (151936, 3.0)]:
+        for rep in range(40 if V <= 20000 else 6):
+            x = (rng.standard_normal(V) * scale).astype(np.float32)
+            kept = np.isfinite(oracle.top_p(x, 1.0))
+            p = np.exp(x.astype(np.float64) - x.max()); p /= p.sum()
+            dropped_mass = max(dropped_mass, float(p[~kept].sum()))
+            for temp in (1.0, 0.7):
+                key = oracle.sample_key(5, rep, V % 97)
+                assert oracle.sample(x, temp, 0, 1.0, key) == oracle.sample(x, temp, 0, None, key)
+                trials += 1
+    assert trials > 200 and dropped_mass < 1e-5, dropped_mass
