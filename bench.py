@@ -205,6 +205,9 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--attn-reps", type=int, default=8)
     ap.add_argument("--no-chain", action="store_true", help="skip the GEMM / norm chain timing (roofline_chain)")
+    ap.add_argument("--sync-decode", action="store_true",
+                    help="nvr_config.async_decode = 0: wait for every step's tokens on the host before the next step is scheduled "
+                         "(default: the next greedy decode step is launched ahead; same batches, tokens and statistics)")
     ap.add_argument("--eager", action="store_true", help="enforce_eager: launch decode kernels one by one instead of replaying a hipGraph")
     ap.add_argument("--parallel", choices=["both", "tp", "replicas"], default=os.environ.get("NVR_BENCH_PARALLEL", "both"),
                     help="--gpus N > 1: 'both' (default) = N replicas measured first (attached as \"replicas\"), then the tensor-parallel "
@@ -263,7 +266,7 @@ def main() -> None:
         cfg = nvr.Config(max_num_seqs=BATCH, max_num_batched_tokens=BATCH * PROMPT_LEN, max_model_len=PROMPT_LEN + total_new + 16,
                          kvcache_block_size=BLOCK, num_kvcache_blocks=BATCH * ((PROMPT_LEN + total_new + 16) // BLOCK + 2),
                          tensor_parallel_size=tp_size, tensor_parallel_rank=tp_rank,
-                         device_ordinal=local_rank, enforce_eager=args.eager)
+                         device_ordinal=local_rank, enforce_eager=args.eager, async_decode=0 if (args.sync_decode or tp_size > 1) else 1)
         return nvr.LLMEngine(cfg, mc)
 
     def barrier():
@@ -462,6 +465,7 @@ def main() -> None:
                                    "block_size=256, hipGraph decode steps (BASELINE.json configs[1])",
                        "batch": BATCH, "prompt_len": PROMPT_LEN, "mean_context": ctx_mean,
                        "parallelism": parallelism, "hipgraph": not args.eager,
+                       "async_decode": not args.sync_decode and args.gpus == 1 or (not args.sync_decode and parallelism.startswith("replicas")),
                        "logits": "materialised every step" if args.materialize_logits else "greedy arg-max fused into the LM head; f32 logits on demand"},
             "prefill": {"tokens": BATCH * PROMPT_LEN, "seconds": round(t_prefill, 4), "tokens_per_s": round(BATCH * PROMPT_LEN / t_prefill, 1),
                         "tflop_per_s": round(prefill_flop / t_prefill / 1e12, 1), "mfma_frac_of_2500": round(prefill_flop / t_prefill / 2.5e15, 4),

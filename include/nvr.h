@@ -97,6 +97,12 @@ typedef struct nvr_config {
                                           of the waiting queue is scheduled for min(remaining, token budget left) tokens; later chunks
                                           attend to the earlier ones through the block table (K8); a step samples a token only for
                                           sequences whose prompt it finished (others report token -1) */
+    int32_t async_decode;              /* 1: LLMEngine::step launches the NEXT greedy decode step before this step's tokens have reached
+                                          the host (their ids go device to device; positions / slots / block tables follow from the
+                                          lengths), whenever that is provably the step the reference would schedule: nothing waiting,
+                                          no sequence able to stop, no block boundary.  Same batches, tokens and statistics as 0 (a
+                                          request added in between cancels the step launched ahead); the logits accessors then refer to
+                                          the newest launched step.  Default 0. */
     char device[16];                   /* config.rs:48, validated like :108-111 plus "hip": "hip" (default) | "cuda" (the reference's
                                           default, taken as "the GPU") | "cpu" | "metal"; a runner exists only for "hip" / "cuda" —
                                           there is no CPU path in this library (NVR_ERR_UNSUPPORTED) */

@@ -54,7 +54,7 @@ class ConfigC(C.Structure):
                 ("kvcache_block_size", C.c_uint64), ("num_kvcache_blocks", C.c_int64),
                 ("tensor_parallel_rank", C.c_uint64), ("device_ordinal", C.c_int32), ("sample_seed", C.c_uint64),
                 ("skip_block_size_check", C.c_int32), ("decode_chain", C.c_uint32),
-                ("recompute_cached_prefix", C.c_int32), ("enable_chunked_prefill", C.c_int32), ("device", C.c_char * 16), ("dtype", C.c_char * 16)]
+                ("recompute_cached_prefix", C.c_int32), ("enable_chunked_prefill", C.c_int32), ("async_decode", C.c_int32), ("device", C.c_char * 16), ("dtype", C.c_char * 16)]
 
 
 class ModelConfigC(C.Structure):

@@ -21,7 +21,101 @@ struct HostTrace {
 inline double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 }
 
+// ---- launch-ahead (nvr_config.async_decode) -------------------------------------------------------------------------------
+// A decode step's batch, positions, slots and block tables follow from the sequence LENGTHS; only its input ids are the
+// previous step's sampled tokens, and those can stay on the device.  So when the step after the current one is provably the
+// decode step the reference's scheduler would build whatever the tokens turn out to be — nothing waiting, the running queue
+// is the current batch, no sequence can stop on this token (max_tokens not reached, EOS ignored or not configured), no block
+// boundary (no new block, no block hash, which needs the token values: may_append is then a no-op) — it is scheduled with
+// placeholder tokens and enqueued BEFORE the host waits for the current step's tokens; the placeholders are patched when they
+// arrive.  The GPU never idles between steps (the host gap was 35-40 us of a 1.53 ms step, profiles/r01 step_gap).
+bool nvr_engine::can_launch_ahead(const std::vector<nvr_seq *> &cur) const {
+    if (!cfg.async_decode || !runner->ahead_capable() || cur.empty()) return false;
+    const nvr::Scheduler &sc = scheduler->impl;
+    if (!sc.next_is_decode_of(cur.data(), cur.size())) return false;
+    const size_t bs = cfg.kvcache_block_size;
+    for (const nvr_seq *s : cur) {
+        if (s->chunk_is_partial() || s->sampling.temperature != 0.0f) return false;
+        if (s->num_completion_tokens() + 1 >= s->sampling.max_tokens) return false;          // this token could be the last
+        if (!s->sampling.ignore_eos && sc.has_eos()) return false;                           // ... or an EOS
+        const size_t L = s->len() + 1;                                                       // length the next step sees
+        if (L % bs == 0 || L % bs == 1 || (int64_t)L > runner->max_pos) return false;        // may_append would hash / allocate
+    }
+    return true;
+}
+
+void nvr_engine::cancel_ahead() {
+    if (!ahead.pending) return;
+    // the step in flight is abandoned: its K/V rows are the ones a rescheduled step writes again, its tokens are never read;
+    // on the host side only the scheduler's counters moved (may_append was a no-op by construction)
+    scheduler->impl.restore_stats(ahead.stats_before);
+    ahead.pending = false;
+}
+
+int nvr_engine::step_async(nvr_step_info *info) {
+    bool is_prefill = false;
+    int parity;
+    if (ahead.pending) {                                                 // this step was enqueued during the previous call
+        batch = ahead.batch; parity = ahead.parity; ahead.pending = false;
+    } else {
+        int rc = scheduler->impl.schedule(batch, &is_prefill);
+        if (rc) return rc;
+        rc = runner->execute(batch.data(), batch.size(), is_prefill);
+        if (rc) { scheduler->impl.abort_batch(batch.data(), batch.size()); return rc; }
+        bool greedy = runner->ahead_capable() && runner->lm_parts_of_last_step() > 0;
+        for (const nvr_seq *s : batch) greedy = greedy && s->sampling.temperature == 0.0f;
+        if (!greedy) {                                                   // stochastic rows: the ordinary synchronous tail
+            last_tokens.resize(batch.size());
+            rc = runner->sample(batch.data(), batch.size(), last_tokens.data());
+            if (rc) { scheduler->impl.abort_batch(batch.data(), batch.size()); return rc; }
+            parity = -1;
+        } else {
+            parity = 0;
+            rc = runner->sample_launch(batch.data(), batch.size(), parity);
+            if (rc) { scheduler->impl.abort_batch(batch.data(), batch.size()); return rc; }
+        }
+    }
+    const uint64_t ntok = is_prefill ? (uint64_t)runner->last_tokens : (uint64_t)batch.size();
+    const uint64_t fin_before = scheduler->impl.stats().finished_sequences;
+    last_tokens.resize(batch.size());
+    if (parity >= 0 && can_launch_ahead(batch)) {
+        // schedule the next step on placeholder tokens and enqueue it, THEN wait for this step's tokens
+        std::vector<int64_t> placeholder(batch.size(), -1);
+        int rc = scheduler->impl.postprocess(batch.data(), placeholder.data(), batch.size());
+        if (rc) return rc;
+        ahead.stats_before = scheduler->impl.stats();
+        bool pf = false;
+        rc = scheduler->impl.schedule(ahead.batch, &pf);
+        if (rc) return rc;
+        if (pf || ahead.batch != batch) return nvr::fail(NVR_ERR_INVARIANT, "launch-ahead: the scheduler built another batch than predicted");
+        ahead.parity = parity ^ 1;
+        rc = runner->execute_decode_ahead(ahead.batch.data(), ahead.batch.size(), ahead.parity);
+        if (!rc) rc = runner->sample_launch(ahead.batch.data(), ahead.batch.size(), ahead.parity);
+        if (rc) return rc;
+        ahead.pending = true;
+        rc = runner->sample_wait(batch.size(), parity, last_tokens.data());
+        if (rc) return rc;
+        for (size_t i = 0; i < batch.size(); ++i) {                      // the placeholders become the sampled tokens
+            nvr_seq *s = batch[i];
+            s->token_ids[s->num_tokens - 1] = last_tokens[i]; s->last_token = last_tokens[i];
+        }
+    } else {
+        if (parity >= 0) { int rc = runner->sample_wait(batch.size(), parity, last_tokens.data()); if (rc) return rc; }
+        for (size_t i = 0; i < batch.size(); ++i) if (batch[i]->chunk_is_partial()) last_tokens[i] = -1;
+        int rc = scheduler->impl.postprocess(batch.data(), last_tokens.data(), batch.size());
+        if (rc) return rc;
+    }
+    last_ids.resize(batch.size());
+    for (size_t i = 0; i < batch.size(); ++i) last_ids[i] = batch[i]->seq_id;
+    if (info) {
+        info->is_prefill = is_prefill; info->num_seqs = batch.size(); info->num_tokens = ntok;
+        info->num_finished = (ahead.pending ? ahead.stats_before.finished_sequences : scheduler->impl.stats().finished_sequences) - fin_before;
+    }
+    return NVR_OK;
+}
+
 int nvr_engine::step(nvr_step_info *info) {                          // LLMEngine::step, llm_engine.rs:155-197
+    if (cfg.async_decode) return step_async(info);
     bool is_prefill = false;
     const double t0 = g_trace.on ? now_us() : 0;
     int rc = scheduler->impl.schedule(batch, &is_prefill);           // :160-166
@@ -74,6 +168,7 @@ int nvr_engine::add_ids(const int64_t *prompt, size_t n, const nvr_sampling_para
         return nvr::fail(NVR_ERR_INVALID_ARG, "prompt of %zu tokens exceeds max_model_len %ld", n, (long)runner->max_pos);
     if ((int64_t)n > runner->max_tokens && !cfg.enable_chunked_prefill)      // (chunked prefill, A-23, cuts such a prompt into batches)
         return nvr::fail(NVR_ERR_INVALID_ARG, "prompt of %zu tokens exceeds max_num_batched_tokens %ld", n, (long)runner->max_tokens);
+    cancel_ahead();                                      // the next step must see this request (prefill-first scheduling, scheduler.rs:103-116)
     nvr_seq *s = nvr_seq_create(prompt, n, sp, cfg.kvcache_block_size);
     if (!s) return NVR_ERR_INVARIANT;
     const uint64_t room = (uint64_t)(runner->max_pos - (int64_t)n) + 1;       // decode step c feeds position n + c - 1 < max_pos

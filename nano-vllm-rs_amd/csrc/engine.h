@@ -18,6 +18,11 @@ struct nvr_engine {
     std::vector<int64_t> last_tokens;
     bool is_running = true;                              // llm_engine.rs:37,353: cleared by shutdown()
     int step(nvr_step_info *info);
+    // launch-ahead of greedy decode steps (nvr_config.async_decode): the step enqueued behind the one being reported
+    struct Ahead { bool pending = false; std::vector<nvr_seq *> batch; int parity = 0; nvr_sched_stats stats_before{}; } ahead;
+    int step_async(nvr_step_info *info);
+    bool can_launch_ahead(const std::vector<nvr_seq *> &cur) const;
+    void cancel_ahead();                                 // a request arrived (or the engine shuts down) while a step is in flight
 
     // SequenceOutput storage of the last generate / generate_stream call (sequence.rs:30-47)
     struct SeqOut { uint64_t seq_id = 0; std::string text; std::vector<int64_t> tokens; size_t nprompt = 0; int32_t status = 0; };

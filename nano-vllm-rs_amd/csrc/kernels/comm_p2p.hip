@@ -92,10 +92,8 @@ __global__ __launch_bounds__(256) void p2p_allreduce_kernel(P2PArgs a) {
                     if (r >= a.nranks || (r != a.rank && !ok)) { for (int j = 0; j < P; ++j) x[r][j] = (half_t)0.f; }
                     else if (r == a.rank) x[r] = *reinterpret_cast<const hp_t *>(a.in + rbase + c);
                     else if constexpr (P == 8) {
-                        typedef unsigned int u4 __attribute__((ext_vector_type(4)));
                         x[r] = __builtin_bit_cast(hp_t, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(((size_t)r * slot_elems + rbase + c) * 2), 0, 17));
                     } else {
-                        typedef unsigned int u2 __attribute__((ext_vector_type(2)));
                         x[r] = __builtin_bit_cast(hp_t, __builtin_amdgcn_raw_buffer_load_b64(rs, (int)(((size_t)r * slot_elems + rbase + c) * 2), 0, 17));
                     }
                 }

@@ -44,7 +44,7 @@ int32_t lm_head_parts(int64_t T, int64_t K, int64_t N, int64_t ldx);      // par
 int lm_head(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t N, float *logits,
             float *part_val, int32_t *part_idx, int32_t *nparts, hipStream_t s, bool store_logits = true);
 int argmax_partials(const float *part_val, const int32_t *part_idx, int32_t nparts, int64_t T, int64_t *out_idx, float *out_val,
-                    int64_t idx_offset, hipStream_t s);
+                    int64_t idx_offset, hipStream_t s, int64_t *out_idx2 = nullptr);
 
 int linear_splitk(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t N, int64_t S,
                   float *slabs, hipStream_t s);

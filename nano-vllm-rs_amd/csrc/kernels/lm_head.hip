@@ -107,7 +107,7 @@ __global__ __launch_bounds__(WAVES * 64) void lm_head_kernel(const half_t *__res
 
 __global__ __launch_bounds__(64) void argmax_partials_kernel(const float *__restrict__ pval, const int32_t *__restrict__ pidx,
                                                              int nparts, int T, int64_t *__restrict__ out_idx,
-                                                             float *__restrict__ out_val, int64_t idx_offset) {
+                                                             float *__restrict__ out_val, int64_t idx_offset, int64_t *__restrict__ out_idx2) {
     const int m = blockIdx.x, lane = threadIdx.x;
     float bv = -INFINITY; int bi = 0x7fffffff;
     for (int p = lane; p < nparts; p += 64) take_better(bv, bi, pval[(int64_t)p * T + m], pidx[(int64_t)p * T + m]);
@@ -118,7 +118,9 @@ __global__ __launch_bounds__(64) void argmax_partials_kernel(const float *__rest
         take_better(bv, bi, v, i);
     }
     if (lane == 0) {
-        out_idx[m] = (bi == 0x7fffffff ? 0 : (int64_t)bi) + idx_offset;
+        const int64_t tok = (bi == 0x7fffffff ? 0 : (int64_t)bi) + idx_offset;
+        out_idx[m] = tok;
+        if (out_idx2) out_idx2[m] = tok;                         // e.g. the NEXT decode step's input ids, already on the device
         if (out_val) out_val[m] = bv;
     }
 }
@@ -209,10 +211,10 @@ int lm_head(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int6
 }
 
 int argmax_partials(const float *part_val, const int32_t *part_idx, int32_t nparts, int64_t T, int64_t *out_idx, float *out_val,
-                    int64_t idx_offset, hipStream_t s) {
+                    int64_t idx_offset, hipStream_t s, int64_t *out_idx2) {
     if (T == 0) return 0;
     if (nparts < 1) return nvr::fail(NVR_ERR_INVALID_ARG, "argmax_partials: nparts=%d", nparts);
-    argmax_partials_kernel<<<dim3((unsigned)T), dim3(64), 0, s>>>(part_val, part_idx, nparts, (int)T, out_idx, out_val, idx_offset);
+    argmax_partials_kernel<<<dim3((unsigned)T), dim3(64), 0, s>>>(part_val, part_idx, nparts, (int)T, out_idx, out_val, idx_offset, out_idx2);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return nvr::fail(NVR_ERR_HIP, "argmax_partials launch failed: %s", hipGetErrorString(e));
     return 0;

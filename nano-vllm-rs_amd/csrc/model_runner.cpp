@@ -2,6 +2,8 @@
 // another file is named.
 #include "model_runner.h"
 #include <algorithm>
+#include <chrono>
+#include <climits>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -43,6 +45,7 @@ nvr_model_runner::~nvr_model_runner() {
     for (void *p : ptrs) if (p) hipFree(p);
     if (in_host) hipHostFree(in_host);
     if (h_tok) hipHostFree(h_tok);
+    for (int i = 0; i < 2; ++i) { if (ahead_tok[i]) hipHostFree(ahead_tok[i]); if (ahead_host[i]) hipHostFree(ahead_host[i]); }
     if (samp_host) hipHostFree(samp_host);
     if (stream) hipStreamDestroy(stream);
 }
@@ -135,6 +138,13 @@ int nvr_model_runner::init() {                                       // ModelRun
     NVR_HIP_CHECK(hipHostMalloc((void **)&h_tok, max_seqs * 8, hipHostMallocDefault));
     { const char *e = getenv("NVR_ZERO_COPY_TOKENS");
       if (!(e && e[0] == '0') && hipHostGetDevicePointer((void **)&h_tok_dev, h_tok, 0) != hipSuccess) { h_tok_dev = nullptr; (void)hipGetLastError(); } }
+    if (cfg.async_decode && h_tok_dev) {                                 // launch-ahead: one token buffer and one input twin per step in flight
+        for (int i = 0; i < 2; ++i) {
+            NVR_HIP_CHECK(hipHostMalloc((void **)&ahead_tok[i], max_seqs * 8, hipHostMallocDefault));
+            NVR_HIP_CHECK(hipHostGetDevicePointer((void **)&ahead_tok_dev[i], ahead_tok[i], 0));
+            NVR_HIP_CHECK(hipHostMalloc((void **)&ahead_host[i], dec_bytes, hipHostMallocDefault));
+        }
+    }
     RC(dmalloc(&d_temp, max_seqs)); RC(dmalloc(&d_topk, max_seqs)); RC(dmalloc(&d_topp, max_seqs)); RC(dmalloc(&d_keys, max_seqs));
     NVR_HIP_CHECK(hipHostMalloc((void **)&samp_host, max_seqs * 24, hipHostMallocDefault));
     NVR_HIP_CHECK(hipMalloc(&sample_ws, k::sample_workspace_bytes(max_seqs, Vl)));
@@ -568,6 +578,88 @@ int nvr_model_runner::execute(nvr_seq *const *seqs, size_t nseq, bool is_prefill
     }
     last_decode_graph = it->second;
     NVR_HIP_CHECK(hipGraphLaunch(it->second, stream));
+    return NVR_OK;
+}
+
+// ---- launch-ahead of greedy decode steps (nvr_config.async_decode) ---------------------------------------------------------
+// The step whose tokens the host has not seen yet is already followed on the stream by the next one: its input ids were
+// written on the device by the previous step's arg-max merge (sample_launch), positions / slots / context lengths / block
+// tables follow from the sequence lengths alone.  Nothing here synchronises the stream.
+int nvr_model_runner::execute_decode_ahead(nvr_seq *const *seqs, size_t nseq, int parity) {
+    NVR_HIP_CHECK(hipSetDevice(device));
+    if (!ahead_capable()) return nvr::fail(NVR_ERR_INVARIANT, "execute_decode_ahead: runner not set up for launch-ahead");
+    if (nseq == 0 || (int64_t)nseq > max_seqs) return nvr::fail(NVR_ERR_INVALID_ARG, "execute_decode_ahead: %zu sequences", nseq);
+    char *hd = ahead_host[parity & 1];
+    int64_t *pos = (int64_t *)(hd + dof_pos);
+    int32_t *slots = (int32_t *)(hd + dof_slots), *ctx = (int32_t *)(hd + dof_ctx), *bt = (int32_t *)(hd + dof_bt);
+    const int64_t bs = block_size;
+    int64_t max_ctx = 0;
+    for (size_t b = 0; b < nseq; ++b) {
+        const nvr_seq &s = *seqs[b];
+        const int64_t len = (int64_t)s.len();                             // includes the token the host has not seen yet
+        if (len > max_pos) return nvr::fail(NVR_ERR_INVALID_ARG, "sequence of %ld tokens exceeds max_model_len %ld", (long)len, (long)max_pos);
+        if ((int64_t)s.block_table.size() * bs < len) return nvr::fail(NVR_ERR_NOT_ALLOCATED, "Sequence has no allocated blocks");
+        pos[b] = len - 1;
+        slots[b] = (int32_t)((int64_t)s.block_table[(len - 1) / bs] * bs + (len - 1) % bs);
+        ctx[b] = (int32_t)len;
+        int32_t *row = bt + b * max_blocks_per_seq;
+        const size_t nb = s.block_table.size();
+        std::memcpy(row, s.block_table.data(), nb * 4);
+        for (int64_t j = (int64_t)nb; j < max_blocks_per_seq; ++j) row[j] = -1;
+        max_ctx = std::max(max_ctx, len);
+    }
+    NVR_HIP_CHECK(hipMemcpyAsync(in_dev + off_dec + dof_pos, hd + dof_pos, dof_bt + nseq * max_blocks_per_seq * 4 - dof_pos, hipMemcpyHostToDevice, stream));
+    last_rows = nseq; last_prefill = false; last_tokens = (int64_t)nseq;
+    lm_parts = k::lm_head_parts((int64_t)nseq, Hd, Vl, Hd);
+    if (lm_parts <= 0) return nvr::fail(NVR_ERR_UNSUPPORTED, "execute_decode_ahead: the fused LM head does not take this batch");
+    want_logits = !lazy_logits; logits_valid = want_logits; lm_input = n;
+    const int64_t T = (int64_t)nseq;
+    if (cfg.enforce_eager || graphs_disabled) return forward(T, T, false, max_ctx);
+    const int64_t bucket = (max_ctx + 255) / 256 * 256;
+    const uint64_t key = ((uint64_t)want_logits << 60) | ((uint64_t)nseq << 32) | (uint64_t)bucket;
+    auto it = graphs.find(key);
+    if (it == graphs.end()) {
+        if (graphs.size() >= kMaxGraphs) return nvr::fail(NVR_ERR_UNSUPPORTED, "execute_decode_ahead: graph cache full");   // (flushing needs an idle stream)
+        hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr;
+        NVR_HIP_CHECK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+        int rc = forward(T, T, false, bucket);
+        hipError_t e = hipStreamEndCapture(stream, &g);
+        if (!rc && e != hipSuccess) rc = nvr::fail(NVR_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
+        if (!rc && hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) != hipSuccess) rc = nvr::fail(NVR_ERR_HIP, "hipGraphInstantiate failed");
+        if (g) hipGraphDestroy(g);
+        if (rc) return rc;
+        it = graphs.emplace(key, ge).first;
+    }
+    last_decode_graph = it->second;
+    NVR_HIP_CHECK(hipGraphLaunch(it->second, stream));
+    return NVR_OK;
+}
+
+int nvr_model_runner::sample_launch(nvr_seq *const *seqs, size_t nseq, int parity) {
+    NVR_HIP_CHECK(hipSetDevice(device));
+    if (!ahead_capable() || lm_parts <= 0) return nvr::fail(NVR_ERR_INVARIANT, "sample_launch: runner not set up for launch-ahead");
+    if (nseq != last_rows) return nvr::fail(NVR_ERR_LEN_MISMATCH, "sample_tokens: %zu sequences but logits hold %zu rows", nseq, last_rows);
+    int64_t *ht = ahead_tok[parity & 1];
+    for (size_t i = 0; i < nseq; ++i) ht[i] = INT64_MIN;                  // (the kernel below has not been enqueued yet)
+    // greedy_sample, sampler.rs:109-112: token ids to the pinned host buffer (device-visible mapping) AND to the next decode
+    // step's input ids on the device
+    return k::argmax_partials(d_lm_pval, d_lm_pidx, lm_parts, (int64_t)nseq, ahead_tok_dev[parity & 1], nullptr, 0, stream, dd_ids);
+}
+
+int nvr_model_runner::sample_wait(size_t nseq, int parity, int64_t *out) {
+    const volatile int64_t *ht = ahead_tok[parity & 1];
+    const auto t0 = std::chrono::steady_clock::now();
+    for (size_t i = 0; i < nseq; ++i) {
+        unsigned spins = 0;
+        while (ht[i] == INT64_MIN) {
+            __builtin_ia32_pause();
+            if ((++spins & 0xFFFF) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30)) {
+                hipError_t e = hipStreamQuery(stream);
+                return nvr::fail(NVR_ERR_HIP, "sample_wait: no tokens after 30 s (stream: %s)", hipGetErrorString(e));
+            }
+        }
+        out[i] = ht[i];
+    }
     return NVR_OK;
 }
 

@@ -71,6 +71,15 @@ struct nvr_model_runner {
     int copy_weight(const char *local_name, uint16_t *host_out, size_t cap, int64_t *rows, int64_t *cols);
     void *last_decode_graph = nullptr;   // hipGraphExec_t of the last decode step
     int replay_last_decode_graph(int n); // diagnostic: launch chain without the host gap (nvr_runner_replay_last_decode_graph)
+    // Launch-ahead of greedy decode steps (nvr_config.async_decode, engine.cpp): the sampled tokens of step k go straight into
+    // step k+1's device-side input ids, and step k+1 is enqueued before step k's tokens have reached the host.
+    int32_t lm_parts_of_last_step() const { return lm_parts; }
+    bool ahead_capable() const { return tp == 1 && !comm.active() && lm_fused && h_tok_dev != nullptr && ahead_tok[0] != nullptr; }
+    int sample_launch(nvr_seq *const *seqs, size_t nseq, int parity);        // greedy rows: arg-max merge -> pinned ahead_tok[parity] and dd_ids
+    int sample_wait(size_t nseq, int parity, int64_t *out);                  // spins on the pinned buffer (no stream synchronisation)
+    int execute_decode_ahead(nvr_seq *const *seqs, size_t nseq, int parity); // decode step whose ids are already on the device
+    int64_t *ahead_tok[2] = {nullptr, nullptr}, *ahead_tok_dev[2] = {nullptr, nullptr};
+    char *ahead_host[2] = {nullptr, nullptr};            // pinned twins of the decode input region (one per step in flight)
     int ensure_logits();                                 // materialise the last step's f32 logits if it skipped their stores
     int sample(nvr_seq *const *seqs, size_t nseq, int64_t *out);
     uint16_t *k_cache(size_t l) { return kv_pool + (2 * l) * kv_layer_elems; }

@@ -370,6 +370,10 @@ nvr_model_runner_t *nvr_engine_runner(nvr_engine_t *e) { return e->runner.get();
 int nvr_engine_get_stats(nvr_engine_t *e, nvr_engine_stats *o) {                         // llm_engine.rs:312-327
     if (!o) return nvr::fail(NVR_ERR_INVALID_ARG, "nvr_engine_get_stats: out is null");
     o->scheduler = e->scheduler->impl.stats();
+    if (e->ahead.pending) {                          // a step launched ahead has not been reported yet: its batch is not counted
+        const nvr_sched_stats &sb = e->ahead.stats_before;
+        o->scheduler.decode_batches = sb.decode_batches; o->scheduler.avg_decode_batch_size = sb.avg_decode_batch_size;
+    }
     nvr_bm_stats b{}; e->scheduler->impl.block_manager().get_stats(&b);
     o->total_blocks = b.total_blocks; o->free_blocks = b.free_blocks; o->used_blocks = b.used_blocks;
     o->utilization = b.total_blocks ? (double)b.used_blocks / (double)b.total_blocks * 100.0 : 0.0;   // block_manager.rs:345-351
@@ -385,6 +389,7 @@ int nvr_engine_health_check(nvr_engine_t *e, nvr_health_status *o) {            
     return NVR_OK;
 }
 int nvr_engine_shutdown(nvr_engine_t *e) {                                               // llm_engine.rs:345-357
+    e->cancel_ahead();
     e->scheduler->impl.preempt_all();
     e->is_running = false;
     return NVR_OK;

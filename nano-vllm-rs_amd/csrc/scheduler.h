@@ -25,6 +25,13 @@ public:
     // parked with the finished ones) so that the next schedule() does not run into the same failure again
     void abort_batch(nvr_seq *const *seqs, size_t n);
     const nvr_sched_stats &stats() const { return stats_; }
+    void restore_stats(const nvr_sched_stats &st) { stats_ = st; }                      // a cancelled launch-ahead step (engine.cpp)
+    // the next schedule() is a decode step over exactly `seqs`, in this order (nothing waiting, everything running fits)
+    bool next_is_decode_of(nvr_seq *const *seqs, size_t n) const {
+        if (!waiting_.empty() || running_.size() != n || n > max_num_seqs_) return false;
+        for (size_t i = 0; i < n; ++i) if (running_[i] != seqs[i]) return false;
+        return true;
+    }
     BlockManager &block_manager() { return bm_->impl; }
     const BlockManager &block_manager() const { return bm_->impl; }
     nvr_block_manager *block_manager_handle() { return bm_.get(); }

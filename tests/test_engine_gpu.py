@@ -612,3 +612,45 @@ def test_chunked_prefill_engine_parity():
     p2 = nvr.LLMEngine(nvr.Config(skip_block_size_check=1, **dict(ecfg, max_num_batched_tokens=48)), _model_cfgs(mcfg))
     with pytest.raises(nvr.NvrError, match="max_num_batched_tokens"):
         p2.add_request(prompts[0], nvr.SamplingParams(temperature=0.0, max_tokens=2))
+
+
+@pytest.mark.parametrize("bs,eos,nblocks", [(16, None, 64), (16, 5, 64), (4, None, 40), (256, None, 6)])
+def test_async_decode_is_transparent(bs, eos, nblocks):
+    """nvr_config.async_decode = 1 (the next greedy decode step is enqueued before this step's tokens reach the host; ids go device
+    to device) against async_decode = 0 on the same requests: every step reports the same batch, the same tokens, the same
+    finished sequences and statistics — including steps around block boundaries (no launch-ahead there), sequences that stop on
+    max_tokens at different steps, EOS-honouring sequences (never launched ahead), requests added between steps (the step in
+    flight is cancelled so that the prefill comes first, as in the reference) and pool pressure with preemption."""
+    mcfg = mo.small(seed=9)
+    ecfg = dict(max_num_seqs=6, max_num_batched_tokens=512, max_model_len=400, kvcache_block_size=bs, num_kvcache_blocks=nblocks)
+    if eos is not None:
+        ecfg["eos_token_id"] = eos
+    rng = np.random.default_rng(bs + (eos or 0))
+    first = [(oracle.fill_tokens(int(n), 3, i, mcfg.vocab_size).tolist(), int(mt), bool(ig)) for i, (n, mt, ig) in
+             enumerate([(9, 40, 1), (31, 17, 1), (5, 33, 1), (18, 40, eos is None)])]
+    late = [(oracle.fill_tokens(12, 3, 9, mcfg.vocab_size).tolist(), 21, True), (oracle.fill_tokens(3, 3, 10, mcfg.vocab_size).tolist(), 9, True)]
+
+    def run(async_on):
+        nvr.lib().nvr_seq_reset_id_counter()
+        p = nvr.LLMEngine(nvr.Config(skip_block_size_check=1, async_decode=async_on, **ecfg), _model_cfgs(mcfg))
+        for pr, mt, ig in first:
+            p.add_request(pr, nvr.SamplingParams(temperature=0.0, max_tokens=mt, ignore_eos=ig))
+        trace, steps = [], 0
+        while not p.is_finished():
+            if steps in (7, 15):                                        # arrivals between steps
+                pr, mt, ig = late[0 if steps == 7 else 1]
+                p.add_request(pr, nvr.SamplingParams(temperature=0.0, max_tokens=mt, ignore_eos=ig))
+            rec = p.step()
+            st = p.get_stats()["scheduler"]
+            trace.append((rec["is_prefill"], tuple(rec["seq_ids"]), tuple(rec["tokens"]), rec["num_finished"], st["decode_batches"],
+                          st["prefill_batches"], st["finished_sequences"], st["preemptions"]))
+            steps += 1
+            assert steps < 400
+        fin = {s.seq_id: s.token_ids for s in p.take_finished()}
+        return trace, fin, p.get_stats()
+    ta, fa, sa = run(1)
+    ts, fs, ss = run(0)
+    assert len(ta) == len(ts)
+    for i, (a, b) in enumerate(zip(ta, ts)):
+        assert a == b, f"step {i}: async {a} != sync {b}"
+    assert fa == fs and sa == ss and len(fa) == 6
