@@ -3,6 +3,7 @@ and the product's C++ Sequence / BlockManager / Scheduler are bit-exact with the
 restatement of the reference (block ids, block tables, cached-token counts, batch composition,
 preemption order, statistics) — on the reference's own unit-test scenarios (file:line cited) and on
 randomised traces with prefix sharing, block pressure and preemption."""
+import os
 import re
 
 import numpy as np
@@ -313,3 +314,20 @@ def test_trace_scenarios_do_exercise_preemption_and_prefix_hits():
         cached += sum(s.num_cached_tokens for s in seqs) if pf else 0
         o.postprocess(seqs, [9] * len(seqs))
     assert o.stats.preemptions > 0 and cached > 0
+
+
+def test_rust_ffi_is_in_sync_with_the_header():
+    """integration/rust/src/ffi.rs (the extern "C" block for the reference crate) is generated from include/nvr.h: it must be
+    the generator's current output, declare every symbol the header declares, and the hand-written wrappers (hip.rs) may only
+    call functions it declares.  (No Rust toolchain in the image: the files are checked as text.)"""
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call([sys.executable, os.path.join(root, "tools", "gen_rust_ffi.py"), "--check"])
+    ffi = open(os.path.join(root, "integration", "rust", "src", "ffi.rs")).read()
+    declared = set(re.findall(r"pub fn (nvr_\w+)\(", ffi))
+    header = set(re.findall(r"NVR_API[^;(]*?\b(nvr_\w+)\s*\(", open(os.path.join(root, "include", "nvr.h")).read()))
+    assert declared == header and len(declared) > 140
+    used = set(re.findall(r"ffi::(nvr_\w+)\(", open(os.path.join(root, "integration", "rust", "src", "hip.rs")).read()))
+    assert used and used <= declared, used - declared
