@@ -1,0 +1,40 @@
+# Counter passes of the bench command (run on the GPU box through gpurun): per-kernel HBM traffic of the decode step.
+#   bash tools/pmc_pass.sh <tag>
+# Separate rocprofv3 --pmc passes with --kernel-trace only (never combined with --stats / sys-trace): FETCH_SIZE, then WRITE_SIZE.
+# gfx950: FETCH_SIZE (KiB) counts 64 B per 128-B request of a 16 B/lane streaming read -> bytes = FETCH_SIZE * 1024 * 2
+# (MI355X_MICROARCH.md, HBM); WRITE_SIZE (KiB) reads exactly for 16-B-per-lane streaming stores.
+tag=$1
+cd /tmp && export TMPDIR=/tmp
+out=$GRAFT_REPO_ROOT/gpurun_out/pmc_$tag
+rm -rf $out && mkdir -p $out
+cd $GRAFT_REPO_ROOT
+for ctr in FETCH_SIZE WRITE_SIZE; do
+  timeout 600 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $out/$ctr -o pmc -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-chain --sync-decode --eager > $out/$ctr.log 2>&1
+  echo "$ctr rc=$?"
+done
+python3 - $out <<'PY'
+import csv, glob, json, sys, collections
+out = sys.argv[1]
+res = collections.defaultdict(dict)
+for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+    files = glob.glob(f"{out}/{ctr}/**/*counter_collection.csv", recursive=True)
+    if not files:
+        continue
+    rows = list(csv.DictReader(open(files[0])))
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    # decode steps only: kernels after the last gemm256 (prefill) dispatch
+    last_prefill = max((i for i, r in enumerate(rows) if "gemm256" in r["Kernel_Name"] or "flash_prefill" in r["Kernel_Name"]), default=-1)
+    agg = collections.defaultdict(list)
+    for r in rows[last_prefill + 1:]:
+        if r["Counter_Name"] == ctr:
+            agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    for k, v in agg.items():
+        v.sort()
+        res[k][ctr + "_KiB_median"] = v[len(v) // 2]
+        res[k]["dispatches_" + ctr] = len(v)
+json.dump(res, open(f"{out}/summary.json", "w"), indent=1)
+for k, v in sorted(res.items(), key=lambda kv: -kv[1].get("FETCH_SIZE_KiB_median", 0))[:14]:
+    f, w = v.get("FETCH_SIZE_KiB_median", 0), v.get("WRITE_SIZE_KiB_median", 0)
+    print(f"{f * 2048 / 1e6:9.2f} MB read (x2 corrected)  {w * 1024 / 1e6:8.3f} MB written   n={v.get('dispatches_FETCH_SIZE', 0):4d}  {k[:100]}")
+PY
+find $out -name "*.csv" -size +2M -delete
