@@ -414,6 +414,12 @@ NVR_API int nvr_linear_splitk(const nvr_half *x, int64_t ldx, const nvr_half *W,
                               float *slabs, void *stream);
 NVR_API int nvr_add_rmsnorm_slabs(nvr_half *h, const float *slabs, int64_t S, const nvr_half *w, float eps, int64_t T,
                                   int64_t Hd, nvr_half *out, void *stream);
+/* Tiled copy of a row-major weight W[N][K] for the weight-streaming decode kernels: dst[N/16][K/32][16 rows][32 k], so that one
+ * 16x32 MFMA operand tile is 1 KiB contiguous (the runner keeps such copies of qkv / o / gate_up / down / LM head next to the
+ * row-major parameters and reads them in decode-sized steps: same values, same summation order, same bits).  mode 0: tile t =
+ * rows 16t..16t+15; mode 1: the qkv row order of the RoPE epilogue (rotation partners of a q / k head in one tile; needs H, KVH, D). */
+NVR_API int nvr_retile_weight(const nvr_half *src, nvr_half *dst, int64_t N, int64_t K, int mode, int64_t H, int64_t KVH, int64_t D,
+                              void *stream);
 /* The decode chain in four launches per layer (kernels/linear_decode.hip; Qwen3DecoderLayer::forward qwen3.rs:372-392):
  * nvr_linear_resid: h[T,N] <- fp16(h + fp16(x · Wᵀ)) — RowParallelLinear::forward (linear.rs:228-239) plus the residual add
  * (qwen3.rs:382,389) in one launch: k is split over S workgroups per 16-column tile (S = nvr_decode_splitk_slices), each

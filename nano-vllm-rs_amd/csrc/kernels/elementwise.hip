@@ -461,6 +461,39 @@ int concat_vocab_shards(const float *gathered, int64_t tp, int64_t B, int64_t Vl
     return 0;
 }
 
+// ---------------------------------------------------------------- decode-side weight layout
+// The weight-streaming decode kernels feed v_mfma_f32_16x16x32_f16 with 16-row x 32-k tiles of W, 16 B per lane.  From the
+// row-major [N][K] parameter one wave-instruction gathers 16 pieces of 64 B, 2·K bytes apart; from the TILED copy
+// [N/16][K/32][16 rows][32 k] the same tile is 1 KiB contiguous, consecutive k-steps are consecutive KiB, and a workgroup's
+// whole stream is one contiguous range (decode GEMM chain 28.0 -> 25.6 us per layer, profiles/r02_tiled_weights.txt).
+// mode 0: tile t holds rows 16t..16t+15.  mode 1 (qkv with the RoPE epilogue): tile (head, c) of a q / k head holds columns
+// c*8..c*8+7 of the first half and of the second half of the head (rotation partners in one MFMA tile), v heads as mode 0 —
+// the row order linear_skinny_kernel<EPI_ROPE> reads.
+__global__ void retile_weight_kernel(const half_t *__restrict__ src, half_t *__restrict__ dst, int N, int K, int mode, int H, int KVH, int D) {
+    const int64_t chunks = (int64_t)N * K / 8;
+    const int ksteps = K / 32;
+    for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < chunks; c += (int64_t)gridDim.x * blockDim.x) {
+        const int q = (int)(c & 3), r = (int)((c >> 2) & 15);
+        const int64_t t2 = c >> 6;
+        const int ks = (int)(t2 % ksteps), tile = (int)(t2 / ksteps);
+        int row = tile * 16 + r;
+        if (mode == 1) {
+            const int tph = D / 16, head = tile / tph, cc = tile % tph;
+            if (head < H + KVH) row = head * D + (r < 8 ? cc * 8 + r : D / 2 + cc * 8 + (r - 8));
+        }
+        *reinterpret_cast<half8_t *>(dst + c * 8) = *reinterpret_cast<const half8_t *>(src + (int64_t)row * K + ks * 32 + q * 8);
+    }
+}
+int retile_weight(const half_bits *src, half_bits *dst, int64_t N, int64_t K, int mode, int64_t H, int64_t KVH, int64_t D, hipStream_t s) {
+    if (N % 16 || K % 32 || (mode == 1 && (D % 16 || N != (H + 2 * KVH) * D)))
+        return nvr::fail(NVR_ERR_UNSUPPORTED, "retile_weight: N=%ld (multiple of 16), K=%ld (multiple of 32), mode %d", (long)N, (long)K, mode);
+    if (N * K == 0) return 0;
+    int64_t blocks = (N * K / 8 + 255) / 256; if (blocks > 8192) blocks = 8192;
+    retile_weight_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>((const half_t *)src, (half_t *)dst, (int)N, (int)K, mode, (int)H, (int)KVH, (int)D);
+    LAUNCH_CHECK();
+    return 0;
+}
+
 // ---------------------------------------------------------------- synthetic weights
 __global__ void fill_weight_kernel(half_t *__restrict__ dst, int64_t rows, int64_t cols, int64_t ld, int64_t gcols,
                                    int64_t row0, int64_t col0, uint64_t key, float scale) {

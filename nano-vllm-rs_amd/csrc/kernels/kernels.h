@@ -28,11 +28,14 @@ int argmax(const float *logits, int64_t B, int64_t V, int64_t *out_idx, float *o
 int fill_weight(half_bits *dst, int64_t rows, int64_t cols, int64_t ld, int64_t global_cols, int64_t row0,
                 int64_t col0, uint64_t key, float scale, hipStream_t s);
 int fill_const(half_bits *dst, int64_t n, float v, hipStream_t s);
+// tiled copy of a row-major [N][K] weight for the decode kernels: [N/16][K/32][16][32]; mode 1 = the qkv row order of the RoPE epilogue
+int retile_weight(const half_bits *src, half_bits *dst, int64_t N, int64_t K, int mode, int64_t H, int64_t KVH, int64_t D, hipStream_t s);
 int concat_vocab_shards(const float *gathered, int64_t tp, int64_t B, int64_t Vl, float *full, hipStream_t s);
 
 // y[T,N] = x[T,K] (row stride ldx) · W[N,K]^T, f32 accumulate on MFMA; y fp16 or f32
+// Wt (optional): the tiled copy of W (retile_weight mode 0 / 1): read instead of W when the weight-streaming kernel takes the shape
 int linear(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t N, void *y,
-           bool y_f32, hipStream_t s);
+           bool y_f32, hipStream_t s, const half_bits *Wt = nullptr);
 
 // LM head for decode-sized batches (T <= 32, K <= 2048): f32 logits + per-workgroup greedy arg-max partials
 // ([*nparts][T] values and vocabulary indices, *nparts <= LM_HEAD_MAX_PARTS), finished by argmax_partials
@@ -42,12 +45,12 @@ bool lm_head_ok(int64_t T, int64_t K, int64_t N, int64_t ldx);
 int32_t lm_head_parts(int64_t T, int64_t K, int64_t N, int64_t ldx);      // partials lm_head will write (0: unsupported shape)
 // store_logits = false: only the partials are written (a greedy batch never reads its 4·T·N logit bytes)
 int lm_head(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t N, float *logits,
-            float *part_val, int32_t *part_idx, int32_t *nparts, hipStream_t s, bool store_logits = true);
+            float *part_val, int32_t *part_idx, int32_t *nparts, hipStream_t s, bool store_logits = true, const half_bits *Wt = nullptr);
 int argmax_partials(const float *part_val, const int32_t *part_idx, int32_t nparts, int64_t T, int64_t *out_idx, float *out_val,
                     int64_t idx_offset, hipStream_t s, int64_t *out_idx2 = nullptr);
 
 int linear_splitk(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t N, int64_t S,
-                  float *slabs, hipStream_t s);
+                  float *slabs, hipStream_t s, const half_bits *Wt = nullptr);
 // h = fp16(h + fp16(sum_z slabs[z])), out = rmsnorm(h)*w
 int add_rmsnorm_slabs(half_bits *h, const float *slabs, int64_t S, const half_bits *w, float eps, int64_t T, int64_t Hd,
                       half_bits *out, hipStream_t s);
@@ -55,10 +58,11 @@ int add_rmsnorm_slabs(half_bits *h, const float *slabs, int64_t S, const half_bi
 // fused decode epilogues (same GEMM kernel): gate_up -> SiluAndMul, W [2I,K] -> out [T,I];
 // qkv -> RoPE(q,k) + KV store, W [(H+2KVH)D, K] -> qkv [T,(H+2KVH)D] (roped q,k; v) and cache rows at slots
 int linear_silu_mul(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t I,
-                    half_bits *out, hipStream_t s);
+                    half_bits *out, hipStream_t s, const half_bits *Wt = nullptr);
 int linear_qkv_rope_store(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t H,
                           int64_t KVH, int64_t D, const int64_t *positions, const int32_t *slots, const float *cos_t,
-                          const float *sin_t, half_bits *qkv, half_bits *k_cache, half_bits *v_cache, hipStream_t s);
+                          const float *sin_t, half_bits *qkv, half_bits *k_cache, half_bits *v_cache, hipStream_t s,
+                          const half_bits *Wt = nullptr);
 
 // The decode chain in four launches per layer (linear_decode.hip): the residual add rides on the split-k reduction of the
 // row-parallel GEMMs (last arriver of a tile), the RMSNorm in the prologue of the GEMM that consumes it.

@@ -39,6 +39,8 @@ struct LinEpi {
     int32_t H, KVH, D;
     // EPI_SLAB: blockIdx.z owns k in [z*kslice, (z+1)*kslice) and writes its f32 partial tile to slab z
     int32_t kslice; int64_t slab_stride;
+    // W is the TILED copy [N/16][K/32][16][32] (retile_weight): one wave-instruction reads 1 KiB contiguous
+    int32_t tiled;
 };
 
 // W row handled by local row r (0..15) of n-tile i of workgroup bx
@@ -66,7 +68,16 @@ __global__ __launch_bounds__(WAVES * 64) void linear_skinny_kernel(const half_t 
     const half_t *wrow[NT];
     const half_t *xrow[MT];
 #pragma unroll
-    for (int i = 0; i < NT; ++i) wrow[i] = W + (int64_t)w_row<EPI>(blockIdx.x, i, NT, r, N, epi) * K + q * 8;
+    for (int i = 0; i < NT; ++i) {
+        if (epi.tiled) {
+            // tile index in the tiled copy: SiLU — gate tile bx, up tile I/16 + bx; RoPE — tile bx of the permuted row order;
+            // else tile bx*NT + i (clamped like w_row clamps its rows)
+            int64_t tile = EPI == EPI_SILU ? (i == 0 ? (int64_t)blockIdx.x : (int64_t)(N / 16) + blockIdx.x) : (int64_t)blockIdx.x * NT + i;
+            if (EPI != EPI_SILU && EPI != EPI_ROPE && tile > N / 16 - 1) tile = N / 16 - 1;
+            wrow[i] = W + tile * (int64_t)(K / 32) * 512 + r * 32 + q * 8;
+        } else wrow[i] = W + (int64_t)w_row<EPI>(blockIdx.x, i, NT, r, N, epi) * K + q * 8;
+    }
+    const int kmul = epi.tiled ? 16 : 1;                            // k -> element offset: (k / 32) * 512 in the tiled copy
 #pragma unroll
     for (int i = 0; i < MT; ++i) { int m = m0 + i * 16 + r; if (m > T - 1) m = T - 1; xrow[i] = x + (int64_t)m * ldx + q * 8; }
 
@@ -102,7 +113,7 @@ __global__ __launch_bounds__(WAVES * 64) void linear_skinny_kernel(const half_t 
             const int kk = k + u * KS;
             if (kk < K) {
 #pragma unroll
-                for (int i = 0; i < NT; ++i) a[u][i] = __builtin_nontemporal_load(reinterpret_cast<const half8_t *>(wrow[i] + kk));
+                for (int i = 0; i < NT; ++i) a[u][i] = __builtin_nontemporal_load(reinterpret_cast<const half8_t *>(wrow[i] + (int64_t)kk * kmul));
 #pragma unroll
                 for (int j = 0; j < MT; ++j) b[u][j] = *reinterpret_cast<const half8_t *>(xrow[j] + kk);
             } else {
@@ -241,7 +252,7 @@ static int launch_check(const char *what) {
 }
 
 int linear(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t N, void *y,
-           bool y_f32, hipStream_t s) {
+           bool y_f32, hipStream_t s, const half_bits *Wt) {
     if (K % 32 || N % 16 || ldx % 8)
         return nvr::fail(NVR_ERR_UNSUPPORTED, "linear: K=%ld must be a multiple of 32, N=%ld of 16, ldx=%ld of 8",
                          (long)K, (long)N, (long)ldx);
@@ -251,9 +262,10 @@ int linear(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64
     if (!y_f32 && gemm256_ok(T, K, N, ldx) && prefer_256(T, K, N)) return gemm256(x, ldx, W, T, K, N, (half_bits *)y, s);   // prefill regime
     if (!y_f32 && gemm_tiled_ok(T, K, N, ldx) && !prefer_stream(T, N)) return gemm_tiled(x, ldx, W, T, K, N, (half_bits *)y, s);
     if (!y_f32 && linear_stream_ok(T, K, N, ldx)) return linear_stream(x, ldx, W, T, K, N, (half_bits *)y, s);   // large weights
-    const half_t *xx = (const half_t *)x, *ww = (const half_t *)W;
+    const half_t *xx = (const half_t *)x, *ww = (const half_t *)(Wt ? Wt : W);
     const int t = (int)T, k = (int)K, n = (int)N;
-    const LinEpi e{};
+    LinEpi e{};
+    e.tiled = Wt != nullptr;
     const int64_t mtiles = (T + 31) / 32;
     // wide GEMMs (LM head, prefill slabs): 64 columns per workgroup amortise the x fragments; narrow ones keep
     // 16 columns per workgroup (more workgroups) and split k over more waves (more bytes in flight per CU)
@@ -287,13 +299,14 @@ int linear(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64
 // split-k over S workgroups per tile: slabs[z][T][N] f32 partial sums (summed by add_rmsnorm_slabs); the narrow
 // row-parallel GEMMs of the decode step (o_proj, down_proj: N = hidden) reach all 256 CUs this way
 int linear_splitk(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t N, int64_t S,
-                  float *slabs, hipStream_t s) {
+                  float *slabs, hipStream_t s, const half_bits *Wt) {
     if (K % (32 * S) || N % 16 || ldx % 8 || S < 1)
         return nvr::fail(NVR_ERR_UNSUPPORTED, "linear_splitk: K=%ld must be a multiple of 32*S (S=%ld), N=%ld of 16", (long)K, (long)S, (long)N);
     if (T == 0) return 0;
     if (gemm_tiled_splitk_ok(T, K, N, S, ldx)) return gemm_tiled_splitk(x, ldx, W, T, K, N, S, slabs, s);   // more than 64 rows: 128x128 tiles
     LinEpi e{};
     e.kslice = (int32_t)(K / S); e.slab_stride = T * N;
+    if (Wt) { W = Wt; e.tiled = 1; }
     const unsigned gx = (unsigned)(N / 16);
     if (N * K * 2 >= (24ll << 20) && N % 64 == 0) {
         // large weights (Qwen3-8B o/down: N = 4096): 64 output columns per workgroup so that an x fragment feeds four weight
@@ -310,15 +323,16 @@ int linear_splitk(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T
 
 // gate_up GEMM + SiluAndMul: W [2I, K] (gate rows then up rows), out [T, I]
 int linear_silu_mul(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t I,
-                    half_bits *out, hipStream_t s) {
+                    half_bits *out, hipStream_t s, const half_bits *Wt) {
     if (K % 32 || I % 16 || ldx % 8)
         return nvr::fail(NVR_ERR_UNSUPPORTED, "linear_silu_mul: K=%ld must be a multiple of 32, I=%ld of 16", (long)K, (long)I);
     if (T == 0) return 0;
     if (gemm256_silu_ok(T, K, I, ldx) && prefer_256(T, K, 2 * I)) return gemm256_silu_mul(x, ldx, W, T, K, I, out, s);   // see linear()
     if (gemm_tiled_ok(T, K, I, ldx) && I % 64 == 0 && !prefer_stream(T, 2 * I)) return gemm_tiled_silu_mul(x, ldx, W, T, K, I, out, s);
     if (linear_stream_silu_ok(T, K, I, ldx)) return linear_stream_silu_mul(x, ldx, W, T, K, I, out, s);              // large weights
-    const half_t *xx = (const half_t *)x, *ww = (const half_t *)W;
-    const LinEpi e{};
+    const half_t *xx = (const half_t *)x, *ww = (const half_t *)(Wt ? Wt : W);
+    LinEpi e{};
+    e.tiled = Wt != nullptr;
     const unsigned gx = (unsigned)(I / 16);
     const int wv = waves_for(K);
     // few column tiles (the shard of a tensor-parallel rank): 16-token workgroups double the workgroup count (the second token
@@ -339,7 +353,7 @@ int linear_silu_mul(const half_bits *x, int64_t ldx, const half_bits *W, int64_t
 // qkv GEMM + RoPE on q,k heads + store of k,v rows into the paged caches
 int linear_qkv_rope_store(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t H,
                           int64_t KVH, int64_t D, const int64_t *positions, const int32_t *slots, const float *cos_t,
-                          const float *sin_t, half_bits *qkv, half_bits *k_cache, half_bits *v_cache, hipStream_t s) {
+                          const float *sin_t, half_bits *qkv, half_bits *k_cache, half_bits *v_cache, hipStream_t s, const half_bits *Wt) {
     if (K % 32 || D % 16 || ldx % 8)
         return nvr::fail(NVR_ERR_UNSUPPORTED, "linear_qkv_rope_store: K=%ld must be a multiple of 32, D=%ld of 16", (long)K, (long)D);
     if (T == 0) return 0;
@@ -349,8 +363,9 @@ int linear_qkv_rope_store(const half_bits *x, int64_t ldx, const half_bits *W, i
         return gemm_tiled_qkv_rope_store(x, ldx, W, T, K, H, KVH, D, positions, slots, cos_t, sin_t, qkv, k_cache, v_cache, s);
     if (linear_stream_rope_ok(T, K, H, KVH, D, ldx))                                                                  // large weights
         return linear_stream_qkv_rope_store(x, ldx, W, T, K, H, KVH, D, positions, slots, cos_t, sin_t, qkv, k_cache, v_cache, s);
-    const half_t *xx = (const half_t *)x, *ww = (const half_t *)W;
+    const half_t *xx = (const half_t *)x, *ww = (const half_t *)(Wt ? Wt : W);
     LinEpi e{};
+    e.tiled = Wt != nullptr;
     e.pos = positions; e.slots = slots; e.cos_t = cos_t; e.sin_t = sin_t; e.kc = (half_t *)k_cache; e.vc = (half_t *)v_cache;
     e.H = (int32_t)H; e.KVH = (int32_t)KVH; e.D = (int32_t)D;
     const int N = (int)((H + 2 * KVH) * D);

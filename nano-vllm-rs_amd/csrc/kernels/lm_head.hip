@@ -49,14 +49,17 @@ __global__ __launch_bounds__(WAVES * 64) void lm_head_kernel(const half_t *__res
     for (int j = 0; j < MT; ++j) { best[j] = -INFINITY; besti[j] = 0x7fffffff; }
 
     for (int tile = blockIdx.x * WAVES + wave; tile < ntiles; tile += nw) {
-        const half_t *wr = W + ((int64_t)tile * 16 + r) * K + q * 8;
+        // flags bit 1: W is the tiled copy [N/16][K/32][16][32] (retile_weight): 1 KiB contiguous per wave-instruction
+        const bool tiled = flags & 2;
+        const half_t *wr = tiled ? W + (int64_t)tile * (K / 32) * 512 + r * 32 + q * 8 : W + ((int64_t)tile * 16 + r) * K + q * 8;
+        const int kmul = tiled ? 16 : 1;
         float4_t acc[MT];
 #pragma unroll
         for (int j = 0; j < MT; ++j) acc[j] = (float4_t){0.f, 0.f, 0.f, 0.f};
         for (int k0 = 0; k0 < K; k0 += 32 * U) {
             half8_t a[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) a[u] = __builtin_nontemporal_load(reinterpret_cast<const half8_t *>(wr + k0 + u * 32));
+            for (int u = 0; u < U; ++u) a[u] = __builtin_nontemporal_load(reinterpret_cast<const half8_t *>(wr + (int64_t)(k0 + u * 32) * kmul));
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int ch = (k0 >> 3) + u * 4 + q;
@@ -180,7 +183,7 @@ static int lm_allow_big_lds() {
 
 // logits[T,N] (f32) = x·Wᵀ and per-workgroup arg-max partials: part_val/part_idx [*nparts][T], *nparts <= LM_HEAD_MAX_PARTS
 int lm_head(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t N, float *logits,
-            float *part_val, int32_t *part_idx, int32_t *nparts, hipStream_t s, bool store_logits) {
+            float *part_val, int32_t *part_idx, int32_t *nparts, hipStream_t s, bool store_logits, const half_bits *Wt) {
     if (!lm_head_ok(T, K, N, ldx)) {
         if (gemm_tiled_lm_head_ok(T, K, N, ldx))                       // more than 32 rows: 128x128 tiles, same outputs
             return gemm_tiled_lm_head(x, ldx, W, T, K, N, store_logits ? logits : nullptr, part_val, part_idx, nparts, s);
@@ -191,11 +194,11 @@ int lm_head(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int6
     const int mt = pl.mt, waves = pl.waves, U = pl.U;
     const int64_t nwg = pl.nwg;
     *nparts = (int32_t)nwg;
-    const half_t *xx = (const half_t *)x, *ww = (const half_t *)W;
+    const half_t *xx = (const half_t *)x, *ww = (const half_t *)(Wt ? Wt : W);
     if (int rc0 = lm_allow_big_lds()) return rc0;
     const size_t lds = (size_t)mt * 16 * K * 2;
     bool launched = false;
-    const int dbg_flags = store_logits ? 0 : 1;                // bit 0: skip the f32 logit stores (arg-max partials only)
+    const int dbg_flags = (store_logits ? 0 : 1) | (Wt ? 2 : 0);   // bit 0: skip the f32 logit stores (arg-max partials only); bit 1: tiled W
 #define NVR_LM(MT_, WV_, U_)                                                                                          \
     if (!launched && mt == MT_ && waves == WV_ && U == U_) {                                                          \
         lm_head_kernel<MT_, WV_, U_><<<dim3((unsigned)nwg), dim3(WV_ * 64), lds, s>>>(xx, ldx, ww, (int)T, (int)K, (int)N, logits, \

@@ -38,7 +38,9 @@ nvr_model_runner::~nvr_model_runner() {
     for (auto &g : graphs) hipGraphExecDestroy(g.second);
     comm.destroy();
     if (chain_cnt) hipFree(chain_cnt);
-    for (auto &l : layers) { hipFree(l.qkv); hipFree(l.o); hipFree(l.gate_up); hipFree(l.down); hipFree(l.ln1); hipFree(l.ln2); }
+    for (auto &l : layers) { hipFree(l.qkv); hipFree(l.o); hipFree(l.gate_up); hipFree(l.down); hipFree(l.ln1); hipFree(l.ln2);
+                             void *ts[] = {l.qkv_t, l.o_t, l.gate_up_t, l.down_t}; for (void *t : ts) if (t) hipFree(t); }
+    if (lm_head_t) hipFree(lm_head_t);
     void *ptrs[] = {embed, mc.tie_word_embeddings ? nullptr : lm_head, norm, cos_t, sin_t, kv_pool, h, n, qkv, attn,
                     proj, gu, act, nlast, logits, attn_ws, slabs, in_dev, d_tok, d_maxval, d_temp, d_topk, d_topp, d_keys,
                     sample_ws, d_gather_val, d_gather_idx, d_gather_logits, d_full_logits, sample_ws_full, d_lm_pval, d_lm_pidx};
@@ -170,8 +172,28 @@ int nvr_model_runner::init() {                                       // ModelRun
     return NVR_OK;
 }
 
+// Tiled copies of the GEMM weights for the decode kernels (kernels/elementwise.hip: retile_weight): +1x the weight bytes
+// (1.2 GB at Qwen3-0.6B of 288 GB), rebuilt whenever a parameter changed.  Shapes the tiled reader does not cover keep null.
+int nvr_model_runner::retile_all() {
+    tiled_dirty = false;
+    if (!tiled_weights) return NVR_OK;
+    const bool gemm_ok = Hd % 32 == 0 && (H * D) % 32 == 0 && I % 32 == 0 && QKV % 16 == 0 && Hd % 16 == 0 && I % 16 == 0 && D % 16 == 0;
+    for (auto &w : layers) {
+        if (!gemm_ok || !w.qkv_t) continue;
+        RC(k::retile_weight(w.qkv, w.qkv_t, QKV, Hd, 1, H, KVH, D, stream));
+        RC(k::retile_weight(w.o, w.o_t, Hd, H * D, 0, 0, 0, 0, stream));
+        RC(k::retile_weight(w.gate_up, w.gate_up_t, 2 * I, Hd, 0, 0, 0, 0, stream));
+        RC(k::retile_weight(w.down, w.down_t, Hd, I, 0, 0, 0, 0, stream));
+    }
+    if (lm_head_t) RC(k::retile_weight(lm_head, lm_head_t, Vl, Hd, 0, 0, 0, 0, stream));
+    NVR_HIP_CHECK(hipStreamSynchronize(stream));
+    return NVR_OK;
+}
+
 int nvr_model_runner::gen_weights() {
     const float sc = nvr_weight_scale_impl(mc.init_std);
+    { const char *e = getenv("NVR_TILED_WEIGHTS"); tiled_weights = !(e && e[0] == '0'); }
+    if (Hd % 32 || (H * D) % 32 || I % 32 || QKV % 16 || D % 16) tiled_weights = false;
     const int64_t Hg = mc.num_attention_heads, KVHg = mc.num_key_value_heads, Ig = mc.intermediate_size;
     layers.resize(L);
     for (int64_t l = 0; l < L; ++l) {
@@ -179,6 +201,10 @@ int nvr_model_runner::gen_weights() {
         auto key = [&](uint64_t tid) { return nvr_weight_key_impl(mc.seed, (uint64_t)l * 8 + tid); };
         RC(dmalloc(&w.qkv, QKV * Hd)); RC(dmalloc(&w.o, Hd * H * D)); RC(dmalloc(&w.gate_up, 2 * I * Hd));
         RC(dmalloc(&w.down, Hd * I)); RC(dmalloc(&w.ln1, Hd)); RC(dmalloc(&w.ln2, Hd));
+        w.qkv_t = w.o_t = w.gate_up_t = w.down_t = nullptr;
+        if (tiled_weights) {
+            RC(dmalloc(&w.qkv_t, QKV * Hd)); RC(dmalloc(&w.o_t, Hd * H * D)); RC(dmalloc(&w.gate_up_t, 2 * I * Hd)); RC(dmalloc(&w.down_t, Hd * I));
+        }
         // QKVParallelLinear, linear.rs:300-340: global rows [q heads | k heads | v heads], per-rank head slices
         RC(k::fill_weight(w.qkv, H * D, Hd, Hd, Hd, rank * H * D, 0, key(TID_QKV), sc, stream));
         RC(k::fill_weight(w.qkv + H * D * Hd, KVH * D, Hd, Hd, Hd, Hg * D + rank * KVH * D, 0, key(TID_QKV), sc, stream));
@@ -200,8 +226,9 @@ int nvr_model_runner::gen_weights() {
         RC(k::fill_weight(lm_head, Vl, Hd, Hd, Hd, vocab_start, 0, nvr_weight_key_impl(mc.seed, TID_LM_HEAD), sc, stream));
     }
     RC(dmalloc(&norm, Hd)); RC(k::fill_const(norm, Hd, 1.0f, stream));
+    if (tiled_weights && Vl % 16 == 0) RC(dmalloc(&lm_head_t, Vl * Hd));
     NVR_HIP_CHECK(hipStreamSynchronize(stream));
-    return NVR_OK;
+    return retile_all();
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -229,6 +256,7 @@ int nvr_model_runner::load_tensor(const char *name_in, int dtype, const int64_t 
     NVR_HIP_CHECK(hipSetDevice(device));
     if (!name_in || !shape || !data || ndim < 1 || ndim > 2) return nvr::fail(NVR_ERR_INVALID_ARG, "load_tensor: bad arguments");
     if (dtype < 0 || dtype > 2) return nvr::fail(NVR_ERR_INVALID_ARG, "load_tensor: dtype %d (0 = f16, 1 = bf16, 2 = f32)", dtype);
+    tiled_dirty = true;                                                   // the tiled copies are rebuilt before the next step
     const char *name = std::strncmp(name_in, "model.", 6) == 0 ? name_in + 6 : name_in;
     const int64_t R = shape[0], Cc = ndim == 2 ? shape[1] : 1;
     const int64_t Hg = mc.num_attention_heads, KVHg = mc.num_key_value_heads, Ig = mc.intermediate_size;
@@ -315,7 +343,7 @@ int nvr_model_runner::copy_weight(const char *ln, uint16_t *out, size_t cap, int
 // steps on one GPU split k over S workgroups per output tile so that the N = hidden GEMMs reach all 256 CUs; the f32 partial
 // slabs are summed, added to the residual and normalised by the following add_rmsnorm_slabs launch.  Otherwise the plain kernel
 // writes fp16 `proj` (+ all-reduce when tensor parallel) and add_rmsnorm follows.
-int nvr_model_runner::row_parallel_norm(const uint16_t *x, int64_t K, const uint16_t *W, int64_t T, const uint16_t *wn) {
+int nvr_model_runner::row_parallel_norm(const uint16_t *x, int64_t K, const uint16_t *W, const uint16_t *Wt, int64_t T, const uint16_t *wn) {
     int64_t S = 1;
     if (!comm.active() && tp == 1 && T <= 64 && Hd <= 2048) {
         S = k::decode_splitk_slices(T, K, Hd);
@@ -327,10 +355,10 @@ int nvr_model_runner::row_parallel_norm(const uint16_t *x, int64_t K, const uint
                                                      // bs = 256 / 512 decode 4.04 -> 3.67 / 6.18 -> 5.33 ms; at 128 rows the streaming kernel still wins)
     }
     if (S > 1) {
-        RC(k::linear_splitk(x, K, W, T, K, Hd, S, slabs, stream));
+        RC(k::linear_splitk(x, K, W, T, K, Hd, S, slabs, stream, Wt));
         return k::add_rmsnorm_slabs(h, slabs, S, wn, mc.rms_norm_eps, T, Hd, n, stream);
     }
-    RC(k::linear(x, K, W, T, K, Hd, proj, false, stream));
+    RC(k::linear(x, K, W, T, K, Hd, proj, false, stream, Wt));
     // linear.rs:236-238 (all-reduce) + qwen3.rs:382-389 (residual, norm): one launch over the peer-mapped arenas when the
     // message fits a slot (decode-sized steps), else the communicator's all-reduce followed by add+RMSNorm
     // (T <= 64: the fused kernel reduces a row's squares exactly like the decode-sized add+RMSNorm kernel, so fused and unfused
@@ -356,6 +384,7 @@ int nvr_model_runner::forward(int64_t T, int64_t B, bool is_prefill, int64_t max
     const int32_t *slots = is_prefill ? d_slots : dd_slots, *ctx = is_prefill ? d_ctx : dd_ctx;
     const int32_t *bt = dd_bt;
     const bool c4 = use_chain4(T, is_prefill);
+    const bool tl = tiled_weights && T <= 64;                            // decode-sized steps stream the tiled weight copies
     const bool embed_norm = !c4 && L > 0 && k::embedding_rmsnorm_ok(T, Hd);                    // decode-sized: K1 + the first norm in one launch
     if (embed_norm) RC(k::embedding_rmsnorm(ids, T, embed, layers[0].ln1, mc.rms_norm_eps, Hd, h, n, st));
     else RC(k::embedding(ids, T, embed, Hd, h, st));
@@ -367,7 +396,7 @@ int nvr_model_runner::forward(int64_t T, int64_t B, bool is_prefill, int64_t max
         } else {
             if (l == 0 && !embed_norm) RC(k::rmsnorm(h, w.ln1, mc.rms_norm_eps, T, Hd, n, st));   // later layers: see down_proj
             // qkv GEMM with the RoPE + KV-store epilogue (K3..K6 in one launch)
-            RC(k::linear_qkv_rope_store(n, Hd, w.qkv, T, Hd, H, KVH, D, pos, slots, cos_t, sin_t, qkv, k_cache(l), v_cache(l), st));
+            RC(k::linear_qkv_rope_store(n, Hd, w.qkv, T, Hd, H, KVH, D, pos, slots, cos_t, sin_t, qkv, k_cache(l), v_cache(l), st, tl ? w.qkv_t : nullptr));
         }
         k::AttnArgs a{};
         a.q = qkv; a.ldq = QKV; a.ctx_lens = ctx; a.nq = (int32_t)T; a.H = (int32_t)H; a.KVH = (int32_t)KVH; a.D = (int32_t)D;
@@ -397,10 +426,10 @@ int nvr_model_runner::forward(int64_t T, int64_t B, bool is_prefill, int64_t max
             RC(k::linear_silu_mul_normed(h, Hd, w.ln2, mc.rms_norm_eps, w.gate_up, T, Hd, I, act, st));
             RC(k::linear_resid(act, I, w.down, T, I, Hd, k::decode_splitk_slices(T, I, Hd), slabs, chain_cnt, h, st));
         } else {
-            RC(row_parallel_norm(attn, H * D, w.o, T, w.ln2));                                // o_proj, residual :382, norm :385
-            RC(k::linear_silu_mul(n, Hd, w.gate_up, T, Hd, I, act, st));                      // K12 + K13 in one launch
+            RC(row_parallel_norm(attn, H * D, w.o, tl ? w.o_t : nullptr, T, w.ln2));         // o_proj, residual :382, norm :385
+            RC(k::linear_silu_mul(n, Hd, w.gate_up, T, Hd, I, act, st, tl ? w.gate_up_t : nullptr));   // K12 + K13 in one launch
             // down_proj, residual :389 and the NEXT layer's input norm :378 (or the final norm :501)
-            RC(row_parallel_norm(act, I, w.down, T, l + 1 < L ? layers[l + 1].ln1 : norm));
+            RC(row_parallel_norm(act, I, w.down, tl ? w.down_t : nullptr, T, l + 1 < L ? layers[l + 1].ln1 : norm));
         }
     }
     if (c4 || L == 0) RC(k::rmsnorm(h, norm, mc.rms_norm_eps, T, Hd, n, st));                  // final norm :501
@@ -408,7 +437,7 @@ int nvr_model_runner::forward(int64_t T, int64_t B, bool is_prefill, int64_t max
     if (is_prefill) { RC(k::select_last_tokens(n, d_cu, B, Hd, nlast, st)); hl = nlast; }      // embed_head.rs:272-289
     if (lm_parts > 0) {                                                                        // f32 logits (A-21) + arg-max partials
         int32_t np = 0;
-        RC(k::lm_head(hl, Hd, lm_head, B, Hd, Vl, logits, d_lm_pval, d_lm_pidx, &np, st, want_logits));
+        RC(k::lm_head(hl, Hd, lm_head, B, Hd, Vl, logits, d_lm_pval, d_lm_pidx, &np, st, want_logits, (tiled_weights && B <= 32) ? lm_head_t : nullptr));
         if (np != lm_parts) return nvr::fail(NVR_ERR_INVARIANT, "lm_head produced %d partials, planned %d", np, lm_parts);
     } else {
         RC(k::linear(hl, Hd, lm_head, B, Hd, Vl, logits, true, st));
@@ -419,6 +448,7 @@ int nvr_model_runner::forward(int64_t T, int64_t B, bool is_prefill, int64_t max
 // execute_model :105-128 with prepare_*_inputs :172-210 and create_*_context :222-300
 int nvr_model_runner::execute(nvr_seq *const *seqs, size_t nseq, bool is_prefill) {
     NVR_HIP_CHECK(hipSetDevice(device));
+    if (tiled_dirty) RC(retile_all());
     if (tp > 1) RC(comm.prepare());
     if (tp > 1 && !comm.active() && !allow_missing_comm)
         return nvr::fail(NVR_ERR_RCCL, "execute_model: tensor_parallel_size %ld but no communicator is attached (nvr_runner_init_comm / "
@@ -711,7 +741,8 @@ int nvr_model_runner::ensure_logits() {
     if (logits_valid) return NVR_OK;
     NVR_HIP_CHECK(hipSetDevice(device));
     int32_t np = 0;
-    RC(k::lm_head(lm_input, Hd, lm_head, (int64_t)last_rows, Hd, Vl, logits, d_lm_pval, d_lm_pidx, &np, stream, true));
+    RC(k::lm_head(lm_input, Hd, lm_head, (int64_t)last_rows, Hd, Vl, logits, d_lm_pval, d_lm_pidx, &np, stream, true,
+                  (tiled_weights && last_rows <= 32) ? lm_head_t : nullptr));
     logits_valid = true;
     return NVR_OK;
 }

@@ -23,9 +23,13 @@ struct nvr_model_runner {
     int device = 0;
     hipStream_t stream = nullptr;
 
-    struct Layer { uint16_t *qkv, *o, *gate_up, *down, *ln1, *ln2; };
+    struct Layer { uint16_t *qkv, *o, *gate_up, *down, *ln1, *ln2;
+                   uint16_t *qkv_t, *o_t, *gate_up_t, *down_t; };   // *_t: tiled copies for the decode kernels (retile_weight), or null
     std::vector<Layer> layers;
     uint16_t *embed = nullptr, *lm_head = nullptr, *norm = nullptr;
+    uint16_t *lm_head_t = nullptr;         // tiled copy of the LM head (decode-sized steps)
+    bool tiled_weights = true, tiled_dirty = true;   // NVR_TILED_WEIGHTS=0 keeps the row-major parameters only
+    int retile_all();                      // (re)build the tiled copies from the row-major parameters (init, after load_tensor)
     float *cos_t = nullptr, *sin_t = nullptr;
     uint16_t *kv_pool = nullptr;
     size_t kv_layer_elems = 0;             // elements of one K (or V) cache of one layer
@@ -88,7 +92,7 @@ struct nvr_model_runner {
 private:
     int forward(int64_t T, int64_t B, bool is_prefill, int64_t max_ctx);
     int gen_weights();
-    int row_parallel_norm(const uint16_t *x, int64_t K, const uint16_t *W, int64_t T, const uint16_t *wn);
+    int row_parallel_norm(const uint16_t *x, int64_t K, const uint16_t *W, const uint16_t *Wt, int64_t T, const uint16_t *wn);
     bool use_chain4(int64_t T, bool is_prefill) const;
     static constexpr size_t kMaxGraphs = 256;            // captured decode graphs kept before the cache is flushed
     int64_t *h_tok_dev = nullptr;                        // device-visible address of the pinned token buffer h_tok

@@ -474,6 +474,9 @@ int nvr_linear_splitk(const nvr_half *x, int64_t ldx, const nvr_half *W, int64_t
 int nvr_add_rmsnorm_slabs(nvr_half *h, const float *slabs, int64_t S, const nvr_half *w, float eps, int64_t T, int64_t Hd, nvr_half *out, void *s) {
     return k::add_rmsnorm_slabs(h, slabs, S, w, eps, T, Hd, out, (hipStream_t)s);
 }
+int nvr_retile_weight(const nvr_half *src, nvr_half *dst, int64_t N, int64_t K, int mode, int64_t H, int64_t KVH, int64_t D, void *s) {
+    return k::retile_weight(src, dst, N, K, mode, H, KVH, D, (hipStream_t)s);
+}
 int nvr_linear_resid(const nvr_half *x, int64_t ldx, const nvr_half *W, int64_t T, int64_t K, int64_t N, int64_t S, float *slabs,
                      uint32_t *counters, nvr_half *h, void *s) {
     return k::linear_resid(x, ldx, W, T, K, N, S, slabs, counters, h, (hipStream_t)s);

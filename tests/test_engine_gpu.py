@@ -6,6 +6,8 @@ logits within LOGIT_TOL of the fp16-faithful oracle; greedy token ids identical 
 oracle's top-1/top-2 margin exceeds 2*LOGIT_TOL (a smaller margin is a numerical tie between two
 fp16 pipelines that differ only in f32 summation order; it is counted and bounded, never silently
 accepted).  The oracle is teacher-forced with the product's tokens so one near-tie cannot cascade."""
+import os
+
 import numpy as np
 import pytest
 
@@ -654,3 +656,34 @@ def test_async_decode_is_transparent(bs, eos, nblocks):
     for i, (a, b) in enumerate(zip(ta, ts)):
         assert a == b, f"step {i}: async {a} != sync {b}"
     assert fa == fs and sa == ss and len(fa) == 6
+
+
+def test_tiled_weight_copies_do_not_change_a_bit():
+    """Decode-sized steps stream tiled copies of the GEMM weights ([N/16][K/32][16][32]: 1 KiB contiguous per MFMA operand tile)
+    instead of the row-major parameters: same values in the same summation order, so every step's logits are BIT-identical to a
+    runner built with NVR_TILED_WEIGHTS=0 — including after checkpoint tensors were loaded (the copies are rebuilt)."""
+    mcfg = mo.small(seed=4)
+    ecfg = dict(max_num_seqs=6, max_num_batched_tokens=256, max_model_len=128, kvcache_block_size=16, num_kvcache_blocks=40)
+    prompts = [oracle.fill_tokens(n, 2, i, mcfg.vocab_size).tolist() for i, n in enumerate([7, 30, 17, 1, 25])]
+    rng = np.random.default_rng(12)
+    newW = (rng.standard_normal((mcfg.hidden_size, mcfg.intermediate_size)) * 0.05).astype(np.float16)
+
+    def run(tiled):
+        os.environ["NVR_TILED_WEIGHTS"] = "1" if tiled else "0"
+        try:
+            nvr.lib().nvr_seq_reset_id_counter()
+            p = nvr.LLMEngine(nvr.Config(skip_block_size_check=1, **ecfg), _model_cfgs(mcfg))
+        finally:
+            os.environ.pop("NVR_TILED_WEIGHTS", None)
+        p.model_runner.load_tensor("layers.1.mlp.down_proj.weight", newW)
+        for pr in prompts:
+            p.add_request(pr, nvr.SamplingParams(temperature=0.0, max_tokens=10, ignore_eos=True))
+        out = []
+        while not p.is_finished():
+            rec = p.step()
+            out.append((rec["tokens"], p.model_runner.logits(rec["num_seqs"]).copy()))
+        return out
+    a, b = run(True), run(False)
+    assert len(a) == len(b) > 8
+    for (ta, la), (tb, lb) in zip(a, b):
+        assert ta == tb and np.array_equal(la, lb)

@@ -867,3 +867,25 @@ def test_linear_random_shapes():
         assert rc == 0, nvr.last_error()
         assert_close_f16(d_y.to_numpy((T, N), F16), oracle.round_f16(oracle.linear(x, W)), ulps=1, atol=3e-4, what=f"case {case}: T={T} K={K} N={N}")
         _KEEP.clear()
+
+
+@pytest.mark.parametrize("N,K,mode,H,KVH,D", [(64, 128, 0, 0, 0, 0), (1024, 3072, 0, 0, 0, 0), (4096, 1024, 1, 16, 8, 128), (512, 256, 1, 4, 2, 64)])
+def test_retile_weight_layout(N, K, mode, H, KVH, D):
+    """nvr_retile_weight against a numpy restatement of the tiled layout [N/16][K/32][16][32] (mode 1: the qkv row order of the
+    RoPE epilogue: first-half / second-half rotation partners of a head share a tile)."""
+    rng = np.random.default_rng(3)
+    W = rng.integers(0, 65535, (N, K)).astype(np.uint16)
+    d_src, d_dst = dev(W), nvr.DeviceBuffer(N * K * 2)
+    _KEEP.append(d_dst)
+    nvr.check(nvr.lib().nvr_retile_weight(d_src.ptr, d_dst.ptr, N, K, mode, H, KVH, D, None))
+    got = d_dst.to_numpy((N // 16, K // 32, 16, 32), np.uint16)
+    rows = np.arange(N).reshape(N // 16, 16)
+    if mode == 1:
+        tph = D // 16
+        for t in range(N // 16):
+            head, c = t // tph, t % tph
+            if head < H + KVH:
+                rows[t] = [head * D + (c * 8 + r if r < 8 else D // 2 + c * 8 + r - 8) for r in range(16)]
+    ref = W[rows].reshape(N // 16, 16, K // 32, 32).transpose(0, 2, 1, 3)
+    assert np.array_equal(got, ref)
+    assert nvr.lib().nvr_retile_weight(d_src.ptr, d_dst.ptr, N, K + 8, mode, H, KVH, D, None) == -10
