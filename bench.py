@@ -130,6 +130,15 @@ def time_decode_chain(nvr, mc, reps: int = 20) -> dict:
             nvr.check(l.nvr_fill_weight(w.ptr, rows, cols, cols, cols, 0, 0, 5 + i, 1e-6, None))
         return ws
     Wqkv, Wo, Wgu, Wd = weights(QKV, Hd), weights(Hd, H * D), weights(2 * I, Hd), weights(Hd, I)
+
+    def tiled(ws, rows, cols, mode):                      # the runner's tiled copies: what the decode kernels read
+        if os.environ.get("NVR_TILED_WEIGHTS", "1") == "0":
+            return [C.c_void_p(None)] * len(ws)
+        ts = [buf(rows * cols * 2) for _ in ws]
+        for w, t in zip(ws, ts):
+            nvr.check(l.nvr_retile_weight(w.ptr, t.ptr, rows, cols, mode, H, KVH, D, None))
+        return [t.ptr for t in ts]
+    Tqkv, To, Tgu, Td = tiled(Wqkv, QKV, Hd, 1), tiled(Wo, Hd, H * D, 0), tiled(Wgu, 2 * I, Hd, 0), tiled(Wd, Hd, I, 0)
     rng = np.random.default_rng(0)
     h = arr(rng.standard_normal((T, Hd)).astype(np.float16)); n = buf(T * Hd * 2); g = arr(np.ones(Hd, np.float16))
     qkv, attn, act = buf(T * QKV * 2), arr(rng.standard_normal((T, H * D)).astype(np.float16) * 0.1), buf(T * I * 2)
@@ -142,11 +151,12 @@ def time_decode_chain(nvr, mc, reps: int = 20) -> dict:
     ge = C.c_void_p()
     nvr.check(l.nvr_graph_capture_begin(st))
     for i in range(L):
-        nvr.check(l.nvr_linear_qkv_rope_store(n.ptr, Hd, Wqkv[i].ptr, T, Hd, H, KVH, D, pos.ptr, slots.ptr, cos.ptr, sin.ptr, qkv.ptr, kc.ptr, vc.ptr, st))
-        nvr.check(l.nvr_linear_splitk(attn.ptr, H * D, Wo[i].ptr, T, H * D, Hd, So, slabs.ptr, st))
+        nvr.check(l.nvr_linear_qkv_rope_store_tiled(n.ptr, Hd, Wqkv[i].ptr, Tqkv[i], T, Hd, H, KVH, D, pos.ptr, slots.ptr, cos.ptr, sin.ptr,
+                                                    qkv.ptr, kc.ptr, vc.ptr, st))
+        nvr.check(l.nvr_linear_splitk_tiled(attn.ptr, H * D, Wo[i].ptr, To[i], T, H * D, Hd, So, slabs.ptr, st))
         nvr.check(l.nvr_add_rmsnorm_slabs(h.ptr, slabs.ptr, So, g.ptr, 1e-6, T, Hd, n.ptr, st))
-        nvr.check(l.nvr_linear_silu_mul(n.ptr, Hd, Wgu[i].ptr, T, Hd, I, act.ptr, st))
-        nvr.check(l.nvr_linear_splitk(act.ptr, I, Wd[i].ptr, T, I, Hd, Sd, slabs.ptr, st))
+        nvr.check(l.nvr_linear_silu_mul_tiled(n.ptr, Hd, Wgu[i].ptr, Tgu[i], T, Hd, I, act.ptr, st))
+        nvr.check(l.nvr_linear_splitk_tiled(act.ptr, I, Wd[i].ptr, Td[i], T, I, Hd, Sd, slabs.ptr, st))
         nvr.check(l.nvr_add_rmsnorm_slabs(h.ptr, slabs.ptr, Sd, g.ptr, 1e-6, T, Hd, n.ptr, st))
     nvr.check(l.nvr_graph_capture_end(st, C.byref(ge)))
     for _ in range(3):

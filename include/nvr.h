@@ -420,6 +420,21 @@ NVR_API int nvr_add_rmsnorm_slabs(nvr_half *h, const float *slabs, int64_t S, co
  * rows 16t..16t+15; mode 1: the qkv row order of the RoPE epilogue (rotation partners of a q / k head in one tile; needs H, KVH, D). */
 NVR_API int nvr_retile_weight(const nvr_half *src, nvr_half *dst, int64_t N, int64_t K, int mode, int64_t H, int64_t KVH, int64_t D,
                               void *stream);
+/* The same ops reading a tiled copy: W stays the row-major weight (taken when the shape routes to a tile GEMM, T > 64), Wt is its
+ * nvr_retile_weight copy (mode 1 for qkv, mode 0 otherwise) and is what the weight-streaming decode kernels read.  Results are
+ * bit-identical to the row-major entry points (tests/test_kernels_gpu.py::test_tiled_entry_points_match_row_major). */
+NVR_API int nvr_linear_tiled(const nvr_half *x, int64_t ldx, const nvr_half *W, const nvr_half *Wt, int64_t T, int64_t K, int64_t N,
+                             void *y, int y_is_f32, void *stream);
+NVR_API int nvr_linear_splitk_tiled(const nvr_half *x, int64_t ldx, const nvr_half *W, const nvr_half *Wt, int64_t T, int64_t K,
+                                    int64_t N, int64_t S, float *slabs, void *stream);
+NVR_API int nvr_linear_silu_mul_tiled(const nvr_half *x, int64_t ldx, const nvr_half *W, const nvr_half *Wt, int64_t T, int64_t K,
+                                      int64_t I, nvr_half *out, void *stream);
+NVR_API int nvr_linear_qkv_rope_store_tiled(const nvr_half *x, int64_t ldx, const nvr_half *W, const nvr_half *Wt, int64_t T,
+                                            int64_t K, int64_t H, int64_t KVH, int64_t D, const int64_t *positions,
+                                            const int32_t *slot_mapping, const float *cos_t, const float *sin_t,
+                                            nvr_half *qkv, nvr_half *k_cache, nvr_half *v_cache, void *stream);
+NVR_API int nvr_lm_head_tiled(const nvr_half *x, int64_t ldx, const nvr_half *W, const nvr_half *Wt, int64_t T, int64_t K, int64_t N,
+                              float *logits, float *part_val, int32_t *part_idx, int32_t *nparts, void *stream);
 /* The decode chain in four launches per layer (kernels/linear_decode.hip; Qwen3DecoderLayer::forward qwen3.rs:372-392):
  * nvr_linear_resid: h[T,N] <- fp16(h + fp16(x · Wᵀ)) — RowParallelLinear::forward (linear.rs:228-239) plus the residual add
  * (qwen3.rs:382,389) in one launch: k is split over S workgroups per 16-column tile (S = nvr_decode_splitk_slices), each

@@ -203,6 +203,12 @@ _SIGS = {
     "nvr_lm_head": (C.c_int, [_P, C.c_int64, _P, C.c_int64, C.c_int64, C.c_int64, _P, _P, _P, _P, _P]),
     "nvr_argmax_partials": (C.c_int, [_P, _P, C.c_int32, C.c_int64, _P, _P, C.c_int64, _P]),
     "nvr_linear_splitk": (C.c_int, [_P, C.c_int64, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _P, _P]),
+    "nvr_linear_tiled": (C.c_int, [_P, C.c_int64, _P, _P, C.c_int64, C.c_int64, C.c_int64, _P, C.c_int, _P]),
+    "nvr_linear_splitk_tiled": (C.c_int, [_P, C.c_int64, _P, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _P, _P]),
+    "nvr_linear_silu_mul_tiled": (C.c_int, [_P, C.c_int64, _P, _P, C.c_int64, C.c_int64, C.c_int64, _P, _P]),
+    "nvr_linear_qkv_rope_store_tiled": (C.c_int, [_P, C.c_int64, _P, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _P, _P, _P, _P,
+                                                  _P, _P, _P, _P]),
+    "nvr_lm_head_tiled": (C.c_int, [_P, C.c_int64, _P, _P, C.c_int64, C.c_int64, C.c_int64, _P, _P, _P, _P, _P]),
     "nvr_retile_weight": (C.c_int, [_P, _P, C.c_int64, C.c_int64, C.c_int, C.c_int64, C.c_int64, C.c_int64, _P]),
     "nvr_linear_resid": (C.c_int, [_P, C.c_int64, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _P, _P, _P, _P]),
     "nvr_decode_splitk_slices": (C.c_int, [C.c_int64, C.c_int64, C.c_int64]),

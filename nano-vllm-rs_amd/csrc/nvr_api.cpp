@@ -474,6 +474,28 @@ int nvr_linear_splitk(const nvr_half *x, int64_t ldx, const nvr_half *W, int64_t
 int nvr_add_rmsnorm_slabs(nvr_half *h, const float *slabs, int64_t S, const nvr_half *w, float eps, int64_t T, int64_t Hd, nvr_half *out, void *s) {
     return k::add_rmsnorm_slabs(h, slabs, S, w, eps, T, Hd, out, (hipStream_t)s);
 }
+int nvr_linear_tiled(const nvr_half *x, int64_t ldx, const nvr_half *W, const nvr_half *Wt, int64_t T, int64_t K, int64_t N, void *y, int f32,
+                     void *s) {
+    return k::linear(x, ldx, W, T, K, N, y, f32 != 0, (hipStream_t)s, Wt);
+}
+int nvr_linear_splitk_tiled(const nvr_half *x, int64_t ldx, const nvr_half *W, const nvr_half *Wt, int64_t T, int64_t K, int64_t N, int64_t S,
+                            float *slabs, void *s) {
+    return k::linear_splitk(x, ldx, W, T, K, N, S, slabs, (hipStream_t)s, Wt);
+}
+int nvr_linear_silu_mul_tiled(const nvr_half *x, int64_t ldx, const nvr_half *W, const nvr_half *Wt, int64_t T, int64_t K, int64_t I,
+                              nvr_half *out, void *s) {
+    return k::linear_silu_mul(x, ldx, W, T, K, I, out, (hipStream_t)s, Wt);
+}
+int nvr_linear_qkv_rope_store_tiled(const nvr_half *x, int64_t ldx, const nvr_half *W, const nvr_half *Wt, int64_t T, int64_t K, int64_t H,
+                                    int64_t KVH, int64_t D, const int64_t *pos, const int32_t *slots, const float *c, const float *sn,
+                                    nvr_half *qkv, nvr_half *kc, nvr_half *vc, void *s) {
+    return k::linear_qkv_rope_store(x, ldx, W, T, K, H, KVH, D, pos, slots, c, sn, qkv, kc, vc, (hipStream_t)s, Wt);
+}
+int nvr_lm_head_tiled(const nvr_half *x, int64_t ldx, const nvr_half *W, const nvr_half *Wt, int64_t T, int64_t K, int64_t N, float *logits,
+                      float *part_val, int32_t *part_idx, int32_t *nparts, void *s) {
+    if (!nparts) return nvr::fail(NVR_ERR_INVALID_ARG, "nvr_lm_head_tiled: nparts is null");
+    return k::lm_head(x, ldx, W, T, K, N, logits, part_val, part_idx, nparts, (hipStream_t)s, logits != nullptr, Wt);
+}
 int nvr_retile_weight(const nvr_half *src, nvr_half *dst, int64_t N, int64_t K, int mode, int64_t H, int64_t KVH, int64_t D, void *s) {
     return k::retile_weight(src, dst, N, K, mode, H, KVH, D, (hipStream_t)s);
 }

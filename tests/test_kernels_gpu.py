@@ -889,3 +889,69 @@ def test_retile_weight_layout(N, K, mode, H, KVH, D):
     ref = W[rows].reshape(N // 16, 16, K // 32, 32).transpose(0, 2, 1, 3)
     assert np.array_equal(got, ref)
     assert nvr.lib().nvr_retile_weight(d_src.ptr, d_dst.ptr, N, K + 8, mode, H, KVH, D, None) == -10
+
+
+@pytest.mark.parametrize("T", [1, 32, 64, 200])
+def test_tiled_entry_points_match_row_major(T):
+    """Every *_tiled entry point against its row-major twin on the Qwen3-0.6B shapes: identical bits (the tiled copy changes where
+    a weight byte lives, never which bytes meet in an MFMA or in which order they are summed); T = 200 takes the tile GEMMs, which
+    read the row-major W and ignore Wt."""
+    rng = np.random.default_rng(17 + T)
+    l = nvr.lib()
+    Hd, H, KVH, D, I = 1024, 16, 8, 128, 3072
+    QKV = (H + 2 * KVH) * D
+
+    def tiled(Wb, N, K, mode):
+        d_W, d_T = dev(Wb), nvr.DeviceBuffer(N * K * 2)
+        _KEEP.append(d_T)
+        nvr.check(l.nvr_retile_weight(d_W.ptr, d_T.ptr, N, K, mode, H, KVH, D, None))
+        return d_W, d_T
+    # plain linear and split-k (o_proj shape)
+    _, xb = h16(rng.standard_normal((T, H * D)) * 0.3)
+    _, Wb = h16(rng.standard_normal((Hd, H * D)) * 0.05)
+    d_x = dev(xb); d_W, d_T = tiled(Wb, Hd, H * D, 0)
+    ya, yb = nvr.DeviceBuffer(T * Hd * 2), nvr.DeviceBuffer(T * Hd * 2)
+    nvr.check(l.nvr_linear(d_x.ptr, H * D, d_W.ptr, T, H * D, Hd, ya.ptr, 0, None))
+    nvr.check(l.nvr_linear_tiled(d_x.ptr, H * D, d_W.ptr, d_T.ptr, T, H * D, Hd, yb.ptr, 0, None))
+    assert np.array_equal(ya.to_numpy((T, Hd), np.uint16), yb.to_numpy((T, Hd), np.uint16))
+    S = l.nvr_decode_splitk_slices(T, H * D, Hd)
+    if S > 0:
+        sa, sb = nvr.DeviceBuffer(S * T * Hd * 4), nvr.DeviceBuffer(S * T * Hd * 4)
+        nvr.check(l.nvr_linear_splitk(d_x.ptr, H * D, d_W.ptr, T, H * D, Hd, S, sa.ptr, None))
+        nvr.check(l.nvr_linear_splitk_tiled(d_x.ptr, H * D, d_W.ptr, d_T.ptr, T, H * D, Hd, S, sb.ptr, None))
+        assert np.array_equal(sa.to_numpy((S, T, Hd), np.uint32), sb.to_numpy((S, T, Hd), np.uint32))
+    # gate_up + SiLU·mul
+    _, xb = h16(rng.standard_normal((T, Hd)) * 0.5)
+    _, Wb = h16(rng.standard_normal((2 * I, Hd)) * 0.05)
+    d_x = dev(xb); d_W, d_T = tiled(Wb, 2 * I, Hd, 0)
+    oa, ob = nvr.DeviceBuffer(T * I * 2), nvr.DeviceBuffer(T * I * 2)
+    nvr.check(l.nvr_linear_silu_mul(d_x.ptr, Hd, d_W.ptr, T, Hd, I, oa.ptr, None))
+    nvr.check(l.nvr_linear_silu_mul_tiled(d_x.ptr, Hd, d_W.ptr, d_T.ptr, T, Hd, I, ob.ptr, None))
+    assert np.array_equal(oa.to_numpy((T, I), np.uint16), ob.to_numpy((T, I), np.uint16))
+    # qkv + RoPE + KV store (mode 1 copy)
+    _, Wb = h16(rng.standard_normal((QKV, Hd)) * 0.05)
+    d_W, d_T = tiled(Wb, QKV, Hd, 1)
+    pos = rng.integers(0, 512, T).astype(np.int64); slots = rng.permutation(256)[:T].astype(np.int32)
+    cos, sin = oracle.rope_table(D, 512, 1e6)
+    d_pos, d_slots, d_cos, d_sin = dev(pos), dev(slots), dev(cos), dev(sin)
+    outs = []
+    for fn, extra in ((l.nvr_linear_qkv_rope_store, ()), (l.nvr_linear_qkv_rope_store_tiled, (d_T.ptr,))):
+        q, kc, vc = nvr.DeviceBuffer(T * QKV * 2), dev(np.zeros((256, KVH, D), np.uint16)), dev(np.zeros((256, KVH, D), np.uint16))
+        nvr.check(fn(d_x.ptr, Hd, d_W.ptr, *extra, T, Hd, H, KVH, D, d_pos.ptr, d_slots.ptr, d_cos.ptr, d_sin.ptr, q.ptr, kc.ptr, vc.ptr, None))
+        outs.append((q.to_numpy((T, QKV), np.uint16), kc.to_numpy((256, KVH, D), np.uint16), vc.to_numpy((256, KVH, D), np.uint16)))
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
+    # LM head (+ arg-max partials)
+    if T <= 64:
+        N = 151936 // 4
+        _, Wb = h16(rng.standard_normal((N, Hd)) * 0.05)
+        d_W, d_T = tiled(Wb, N, Hd, 0)
+        res = []
+        for fn, extra in ((l.nvr_lm_head, ()), (l.nvr_lm_head_tiled, (d_T.ptr,))):
+            y, pv, pi = nvr.DeviceBuffer(T * N * 4), nvr.DeviceBuffer(2048 * T * 4), nvr.DeviceBuffer(2048 * T * 4)
+            nparts = C.c_int32(0)
+            nvr.check(fn(d_x.ptr, Hd, d_W.ptr, *extra, T, Hd, N, y.ptr, pv.ptr, pi.ptr, C.byref(nparts), None))
+            tok = nvr.DeviceBuffer(T * 8)
+            nvr.check(l.nvr_argmax_partials(pv.ptr, pi.ptr, nparts.value, T, tok.ptr, None, 0, None))
+            res.append((y.to_numpy((T, N), np.uint32), tok.to_numpy((T,), np.int64)))
+        assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])

@@ -36,6 +36,16 @@ def weights(rows, cols):
 
 
 Wqkv, Wo, Wgu, Wd = weights(QKV, Hd), weights(Hd, H * D), weights(2 * I, Hd), weights(Hd, I)
+
+
+def tiled(ws, rows, cols, mode):                      # the runner's tiled copies [N/16][K/32][16][32]
+    ts = [buf(rows * cols * 2) for _ in ws]
+    for w, t in zip(ws, ts):
+        nvr.check(l.nvr_retile_weight(w.ptr, t.ptr, rows, cols, mode, H, KVH, D, None))
+    return ts
+
+
+Tqkv, To, Tgu, Td = tiled(Wqkv, QKV, Hd, 1), tiled(Wo, Hd, H * D, 0), tiled(Wgu, 2 * I, Hd, 0), tiled(Wd, Hd, I, 0)
 h = arr(rng.standard_normal((T, Hd)).astype(np.float16)); n = buf(T * Hd * 2)
 g = arr(np.ones(Hd, np.float16))
 qkv, attn, act = buf(T * QKV * 2), arr(rng.standard_normal((T, H * D)).astype(np.float16) * 0.1), buf(T * I * 2)
@@ -55,9 +65,14 @@ ops = {
     "slabnorm": lambda i: l.nvr_add_rmsnorm_slabs(h.ptr, slabs.ptr, 4, g.ptr, 1e-6, T, Hd, n.ptr, st),
     "silu": lambda i: l.nvr_linear_silu_mul(n.ptr, Hd, Wgu[i].ptr, T, Hd, I, act.ptr, st),
     "splitk_down": lambda i: l.nvr_linear_splitk(act.ptr, I, Wd[i].ptr, T, I, Hd, Sd, slabs.ptr, st),
+    "qkv_t": lambda i: l.nvr_linear_qkv_rope_store_tiled(n.ptr, Hd, Wqkv[i].ptr, Tqkv[i].ptr, T, Hd, H, KVH, D, pos.ptr, slots.ptr, cos.ptr, sin.ptr, qkv.ptr, kc.ptr, vc.ptr, st),
+    "splitk_o_t": lambda i: l.nvr_linear_splitk_tiled(attn.ptr, H * D, Wo[i].ptr, To[i].ptr, T, H * D, Hd, So, slabs.ptr, st),
+    "silu_t": lambda i: l.nvr_linear_silu_mul_tiled(n.ptr, Hd, Wgu[i].ptr, Tgu[i].ptr, T, Hd, I, act.ptr, st),
+    "splitk_down_t": lambda i: l.nvr_linear_splitk_tiled(act.ptr, I, Wd[i].ptr, Td[i].ptr, T, I, Hd, Sd, slabs.ptr, st),
     "rmsnorm": lambda i: l.nvr_rmsnorm(h.ptr, g.ptr, 1e-6, T, Hd, n.ptr, st),
 }
 chains = {
+    "c6t (c6 reading the tiled weight copies: the product's default)": ["qkv_t", "splitk_o_t", "slabnorm", "silu_t", "splitk_down_t", "slabnorm"],
     "c4 (qkv_normed, resid_o, silu_normed, resid_down)": ["qkv_normed", "resid_o", "silu_normed", "resid_down"],
     "c6 (qkv, splitk_o, slabnorm, silu, splitk_down, slabnorm)": ["qkv", "splitk_o", "slabnorm", "silu", "splitk_down", "slabnorm"],
 }
