@@ -124,6 +124,9 @@ typedef struct nvr_model_config {
     int32_t tie_word_embeddings;
     float init_std;                    /* synthetic weights: N(0, std^2)-like, SURVEY §8d */
     uint64_t seed;
+    int32_t qk_norm;                   /* extension (0 = the reference graph): RMSNorm over head_dim on every q and k head before
+                                        * RoPE, weights "layers.N.self_attn.q_norm.weight" / "k_norm.weight" (real Qwen3 checkpoints;
+                                        * SURVEY §8f row 1, DESIGN A-27) */
 } nvr_model_config;
 NVR_API void nvr_model_config_default(nvr_model_config *mc);         /* qwen3.rs:70-89 */
 NVR_API void nvr_model_config_qwen3_0_6b(nvr_model_config *mc);
@@ -357,6 +360,7 @@ NVR_API int nvr_stream_synchronize(void *stream);
 NVR_API int nvr_event_create(void **ev);
 NVR_API int nvr_event_destroy(void *ev);
 NVR_API int nvr_event_record(void *ev, void *stream);
+NVR_API int nvr_stream_wait_event(void *stream, void *ev);   /* also forks / joins streams inside a graph capture */
 NVR_API int nvr_event_elapsed_ms(void *start, void *stop, float *ms);   /* synchronises on stop */
 /* hipGraph capture of stateless-op calls on a caller-created stream (measurement harnesses; the engine captures its own decode
  * steps, execute_with_cuda_graph model_runner.rs:303-326): ops enqueued between begin and end become one replayable graph */
@@ -443,14 +447,16 @@ NVR_API int nvr_lm_head_tiled(const nvr_half *x, int64_t ldx, const nvr_half *W,
  * the residual.  counters: (N/16)*ceil(T/32) zero-initialised uint32 (left zeroed).  T <= 64, K/S <= 2048.
  * nvr_linear_silu_mul_normed / nvr_linear_qkv_rope_store_normed: nvr_linear_silu_mul / nvr_linear_qkv_rope_store with
  * RMSNorm::forward_simple (layernorm.rs:58-75) of their input rows in the prologue (x = the residual stream h, w_norm the
- * norm weight): n = fp16(h * (1/rms) * w) per fragment, within 1 fp16 ulp of nvr_rmsnorm's rows.  T <= 64, K <= 2048. */
-NVR_API int nvr_linear_resid(const nvr_half *x, int64_t ldx, const nvr_half *W, int64_t T, int64_t K, int64_t N, int64_t S,
-                             float *slabs, uint32_t *counters, nvr_half *h, void *stream);
+ * norm weight): n = fp16(h * (1/rms) * w) per fragment, within 1 fp16 ulp of nvr_rmsnorm's rows.  T <= 64, K <= 2048.
+ * Wt (may be NULL): the nvr_retile_weight copy of W (mode 1 for qkv, else 0), read instead of W; same bits either way.
+ * nvr_linear_resid with S = 0: 8-row weight tiles, one workgroup per (8 columns, 16 tokens), no k split, slabs / counters unused. */
+NVR_API int nvr_linear_resid(const nvr_half *x, int64_t ldx, const nvr_half *W, const nvr_half *Wt, int64_t T, int64_t K, int64_t N,
+                             int64_t S, float *slabs, uint32_t *counters, nvr_half *h, void *stream);
 NVR_API int nvr_decode_splitk_slices(int64_t T, int64_t K, int64_t N);
 NVR_API int nvr_linear_silu_mul_normed(const nvr_half *h, int64_t ldx, const nvr_half *w_norm, float eps, const nvr_half *W,
-                                       int64_t T, int64_t K, int64_t I, nvr_half *out, void *stream);
+                                       const nvr_half *Wt, int64_t T, int64_t K, int64_t I, nvr_half *out, void *stream);
 NVR_API int nvr_linear_qkv_rope_store_normed(const nvr_half *h, int64_t ldx, const nvr_half *w_norm, float eps, const nvr_half *W,
-                                             int64_t T, int64_t K, int64_t H, int64_t KVH, int64_t D, const int64_t *positions,
+                                             const nvr_half *Wt, int64_t T, int64_t K, int64_t H, int64_t KVH, int64_t D, const int64_t *positions,
                                              const int32_t *slot_mapping, const float *cos_t, const float *sin_t,
                                              nvr_half *qkv, nvr_half *k_cache, nvr_half *v_cache, void *stream);
 /* K12+K13 fused: out[T,I] = SiluAndMul(x · W_gate_upᵀ), W [2I,K] gate rows then up rows
@@ -468,6 +474,12 @@ NVR_API int nvr_linear_qkv_rope_store(const nvr_half *x, int64_t ldx, const nvr_
 NVR_API int nvr_rope_store_kv(nvr_half *qkv, const int64_t *positions, const int32_t *slot_mapping, int64_t T,
                               int64_t H, int64_t KVH, int64_t D, const float *cos_t, const float *sin_t,
                               nvr_half *k_cache, nvr_half *v_cache, void *stream);
+/* the same with RMSNorm::forward_simple (layernorm.rs:58-75) over head_dim on every q and k head in front of the rotation
+ * (nvr_model_config.qk_norm; q_norm_w / k_norm_w [D]) */
+NVR_API int nvr_qk_norm_rope_store_kv(nvr_half *qkv, const int64_t *positions, const int32_t *slot_mapping, int64_t T,
+                                      int64_t H, int64_t KVH, int64_t D, const float *cos_t, const float *sin_t,
+                                      const nvr_half *q_norm_w, const nvr_half *k_norm_w, float eps,
+                                      nvr_half *k_cache, nvr_half *v_cache, void *stream);
 NVR_API int nvr_rope_table(int64_t D, int64_t max_pos, double theta, float *cos_dev, float *sin_dev); /* rotary_embedding.rs:74-119 */
 /* K9 decode paged attention, attention.rs:225-235,264-318 (A-8).  q rows have stride ldq
  * elements ([B, H, D] inside the packed qkv buffer).  workspace: nvr_paged_attn_workspace_bytes. */

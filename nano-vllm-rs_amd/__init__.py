@@ -62,7 +62,7 @@ class ModelConfigC(C.Structure):
                 ("num_hidden_layers", C.c_uint64), ("num_attention_heads", C.c_uint64),
                 ("num_key_value_heads", C.c_uint64), ("head_dim", C.c_uint64), ("max_position_embeddings", C.c_uint64),
                 ("rms_norm_eps", C.c_float), ("rope_theta", C.c_double), ("tie_word_embeddings", C.c_int32),
-                ("init_std", C.c_float), ("seed", C.c_uint64)]
+                ("init_std", C.c_float), ("seed", C.c_uint64), ("qk_norm", C.c_int32)]
 
 
 class EngineStatsC(C.Structure):
@@ -195,7 +195,7 @@ _SIGS = {
     "nvr_graph_capture_begin": (C.c_int, [_P]), "nvr_graph_capture_end": (C.c_int, [_P, C.POINTER(_P)]),
     "nvr_graph_launch": (C.c_int, [_P, _P]), "nvr_graph_destroy": (C.c_int, [_P]),
     "nvr_event_create": (C.c_int, [C.POINTER(_P)]), "nvr_event_destroy": (C.c_int, [_P]),
-    "nvr_event_record": (C.c_int, [_P, _P]), "nvr_event_elapsed_ms": (C.c_int, [_P, _P, C.POINTER(C.c_float)]),
+    "nvr_event_record": (C.c_int, [_P, _P]), "nvr_stream_wait_event": (C.c_int, [_P, _P]), "nvr_event_elapsed_ms": (C.c_int, [_P, _P, C.POINTER(C.c_float)]),
     "nvr_embedding": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, _P]),
     "nvr_rmsnorm": (C.c_int, [_P, _P, C.c_float, C.c_int64, C.c_int64, _P, _P]),
     "nvr_add_rmsnorm": (C.c_int, [_P, _P, _P, C.c_float, C.c_int64, C.c_int64, _P, _P]),
@@ -210,16 +210,17 @@ _SIGS = {
                                                   _P, _P, _P, _P]),
     "nvr_lm_head_tiled": (C.c_int, [_P, C.c_int64, _P, _P, C.c_int64, C.c_int64, C.c_int64, _P, _P, _P, _P, _P]),
     "nvr_retile_weight": (C.c_int, [_P, _P, C.c_int64, C.c_int64, C.c_int, C.c_int64, C.c_int64, C.c_int64, _P]),
-    "nvr_linear_resid": (C.c_int, [_P, C.c_int64, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _P, _P, _P, _P]),
+    "nvr_linear_resid": (C.c_int, [_P, C.c_int64, _P, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _P, _P, _P, _P]),
     "nvr_decode_splitk_slices": (C.c_int, [C.c_int64, C.c_int64, C.c_int64]),
-    "nvr_linear_silu_mul_normed": (C.c_int, [_P, C.c_int64, _P, C.c_float, _P, C.c_int64, C.c_int64, C.c_int64, _P, _P]),
-    "nvr_linear_qkv_rope_store_normed": (C.c_int, [_P, C.c_int64, _P, C.c_float, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _P, _P,
+    "nvr_linear_silu_mul_normed": (C.c_int, [_P, C.c_int64, _P, C.c_float, _P, _P, C.c_int64, C.c_int64, C.c_int64, _P, _P]),
+    "nvr_linear_qkv_rope_store_normed": (C.c_int, [_P, C.c_int64, _P, C.c_float, _P, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _P, _P,
                                                    _P, _P, _P, _P, _P, _P]),
     "nvr_add_rmsnorm_slabs": (C.c_int, [_P, _P, C.c_int64, _P, C.c_float, C.c_int64, C.c_int64, _P, _P]),
     "nvr_linear_silu_mul": (C.c_int, [_P, C.c_int64, _P, C.c_int64, C.c_int64, C.c_int64, _P, _P]),
     "nvr_linear_qkv_rope_store": (C.c_int, [_P, C.c_int64, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _P, _P, _P, _P,
                                             _P, _P, _P, _P]),
     "nvr_rope_store_kv": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _P, _P, _P, _P, _P]),
+    "nvr_qk_norm_rope_store_kv": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _P, _P, _P, _P, C.c_float, _P, _P, _P]),
     "nvr_rope_table": (C.c_int, [C.c_int64, C.c_int64, C.c_double, _P, _P]),
     "nvr_paged_attn_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int64, C.c_int64]),
     "nvr_paged_attn_decode": (C.c_int, [_P, C.c_int64, _P, _P, C.POINTER(AttnMetaC), C.c_int64, C.c_int64, C.c_int64,
@@ -609,8 +610,8 @@ class ModelRunner:
     def load_safetensors(self, path: str, strict: bool = False) -> List[str]:
         """Every tensor of a .safetensors file (or of all such files in a directory); bf16 — the dtype of the published
         Qwen3 checkpoints — goes down as its 16-bit patterns and is converted on load (iter_safetensors).  Returns the names
-        that are not part of the reference's Qwen3 graph (q/k-norm, biases ...) and warns about them (a real Qwen3
-        checkpoint then runs WITHOUT its attention norms, SURVEY A-17); strict=True raises instead."""
+        that are not part of the graph (biases; q_norm / k_norm unless ModelConfig(qk_norm=1), A-27) and warns about them (a
+        real Qwen3 checkpoint loaded without qk_norm runs WITHOUT its attention norms, SURVEY A-17); strict=True raises."""
         import warnings
         files = sorted(os.path.join(path, f) for f in os.listdir(path) if f.endswith(".safetensors")) if os.path.isdir(path) else [path]
         skipped = []
@@ -624,7 +625,7 @@ class ModelRunner:
                     skipped.append(name)
         if skipped:
             warnings.warn(f"load_safetensors: {len(skipped)} tensors are outside the reference's Qwen3 graph and were NOT loaded "
-                          f"(e.g. {skipped[0]}): q/k-norm and biases are not applied (SURVEY A-17)", RuntimeWarning, stacklevel=2)
+                          f"(e.g. {skipped[0]}): biases are not applied, q/k-norm only with ModelConfig(qk_norm=1) (SURVEY A-17)", RuntimeWarning, stacklevel=2)
         return skipped
 
     def weight(self, local_name: str) -> np.ndarray:

@@ -393,11 +393,58 @@ __global__ __launch_bounds__(256) void rope_store_kernel(half_t *__restrict__ qk
         }
     }
 }
+// The same with an RMSNorm over head_dim on every q and k head in front of the rotation (real Qwen3 checkpoints:
+// self_attn.q_norm / k_norm; an extension of the reference graph, DESIGN A-27): n = fp16((x / rms) * w) with the arithmetic of
+// rmsnorm_kernel (RMSNorm::forward_simple, layernorm.rs:58-75), then RoPE on n.  One wave per head, one lane per rotation pair.
+__global__ __launch_bounds__(256) void qknorm_rope_store_kernel(half_t *__restrict__ qkv, const int64_t *__restrict__ pos,
+                                                                const int32_t *__restrict__ slots, int H, int KVH, int D,
+                                                                const float *__restrict__ cos_t, const float *__restrict__ sin_t,
+                                                                const half_t *__restrict__ qw, const half_t *__restrict__ kw, float eps,
+                                                                half_t *__restrict__ kc, half_t *__restrict__ vc) {
+    const int t = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int half_d = D / 2;
+    const int64_t ld = (int64_t)(H + 2 * KVH) * D;
+    half_t *row = qkv + t * ld;
+    const int64_t p = pos[t];
+    const int slot = slots ? slots[t] : -1;
+    for (int head = wave; head < H + KVH; head += 4) {
+        half_t *x = row + head * D;
+        const half_t *g = head < H ? qw : kw;
+        float ss = 0.f;
+        for (int j = lane; j < half_d; j += 64) { const float a = (float)x[j], b = (float)x[j + half_d]; ss += a * a + b * b; }
+        ss = wave_sum(ss);
+        const float rms = sqrtf(ss / (float)D + eps);
+        for (int j = lane; j < half_d; j += 64) {
+            const float a = (float)to_half_rn(__fmul_rn(__fdiv_rn((float)x[j], rms), (float)g[j]));
+            const float b = (float)to_half_rn(__fmul_rn(__fdiv_rn((float)x[j + half_d], rms), (float)g[j + half_d]));
+            const float cs = cos_t[p * half_d + j], si = sin_t[p * half_d + j];
+            const half_t o1 = to_half_rn(__fsub_rn(__fmul_rn(a, cs), __fmul_rn(b, si)));
+            const half_t o2 = to_half_rn(__fadd_rn(__fmul_rn(b, cs), __fmul_rn(a, si)));
+            x[j] = o1; x[j + half_d] = o2;
+            if (head >= H && slot >= 0) {
+                half_t *dst = kc + ((int64_t)slot * KVH + (head - H)) * D;
+                dst[j] = o1; dst[j + half_d] = o2;
+            }
+        }
+    }
+    if (slot >= 0)
+        for (int e = threadIdx.x * 8; e < KVH * D; e += 256 * 8)
+            *reinterpret_cast<half8_t *>(vc + (int64_t)slot * KVH * D + e) = *reinterpret_cast<const half8_t *>(row + (int64_t)(H + KVH) * D + e);
+}
+
 int rope_store_kv(half_bits *qkv, const int64_t *positions, const int32_t *slots, int64_t T, int64_t H, int64_t KVH,
                   int64_t D, const float *cos_t, const float *sin_t, half_bits *k_cache, half_bits *v_cache,
-                  hipStream_t s) {
+                  hipStream_t s, const half_bits *q_norm_w, const half_bits *k_norm_w, float eps) {
     if (D % 16) return nvr::fail(NVR_ERR_UNSUPPORTED, "rope: head_dim %ld not a multiple of 16", (long)D);
     if (T == 0) return 0;
+    if (q_norm_w || k_norm_w) {
+        if (!q_norm_w || !k_norm_w) return nvr::fail(NVR_ERR_INVALID_ARG, "rope_store_kv: q and k norm weights come together");
+        qknorm_rope_store_kernel<<<dim3((unsigned)T), dim3(256), 0, s>>>((half_t *)qkv, positions, slots, (int)H, (int)KVH, (int)D, cos_t, sin_t,
+                                                                         (const half_t *)q_norm_w, (const half_t *)k_norm_w, eps,
+                                                                         (half_t *)k_cache, (half_t *)v_cache);
+        LAUNCH_CHECK();
+        return 0;
+    }
     rope_store_kernel<<<dim3((unsigned)T), dim3(256), 0, s>>>((half_t *)qkv, positions, slots, (int)H, (int)KVH, (int)D,
                                                               cos_t, sin_t, (half_t *)k_cache, (half_t *)v_cache);
     LAUNCH_CHECK();

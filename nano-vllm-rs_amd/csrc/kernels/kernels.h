@@ -21,7 +21,7 @@ int silu_and_mul(const half_bits *x, int64_t T, int64_t I, half_bits *out, hipSt
 int select_last_tokens(const half_bits *h, const int32_t *cu, int64_t B, int64_t Hd, half_bits *out, hipStream_t s);
 int rope_store_kv(half_bits *qkv, const int64_t *positions, const int32_t *slots, int64_t T, int64_t H, int64_t KVH,
                   int64_t D, const float *cos_t, const float *sin_t, half_bits *k_cache, half_bits *v_cache,
-                  hipStream_t s);
+                  hipStream_t s, const half_bits *q_norm_w = nullptr, const half_bits *k_norm_w = nullptr, float eps = 0.f);
 // argmax over f32 rows; out_val (nullable) receives the row maxima, idx_offset is added to indices
 int argmax(const float *logits, int64_t B, int64_t V, int64_t *out_idx, float *out_val, int64_t idx_offset,
            hipStream_t s);
@@ -70,12 +70,13 @@ bool decode_chain_ok(int64_t T, int64_t Hd, int64_t qkv_rows, int64_t I, int64_t
 int decode_splitk_slices(int64_t T, int64_t K, int64_t N);
 // h[T,N] <- fp16(h + fp16(x·Wᵀ)); slabs [S][T][N] f32 scratch; cnt: (N/16)*ceil(T/32) zeroed counters (left zeroed)
 int linear_resid(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t N, int64_t S, float *slabs,
-                 unsigned int *cnt, half_bits *h, hipStream_t s);
+                 unsigned int *cnt, half_bits *h, hipStream_t s, const half_bits *Wt = nullptr);
 int linear_silu_mul_normed(const half_bits *h, int64_t ldx, const half_bits *wn, float eps, const half_bits *W, int64_t T, int64_t K,
-                           int64_t I, half_bits *out, hipStream_t s);
+                           int64_t I, half_bits *out, hipStream_t s, const half_bits *Wt = nullptr);
 int linear_qkv_rope_store_normed(const half_bits *h, int64_t ldx, const half_bits *wn, float eps, const half_bits *W, int64_t T, int64_t K,
                                  int64_t H, int64_t KVH, int64_t D, const int64_t *positions, const int32_t *slots, const float *cos_t,
-                                 const float *sin_t, half_bits *qkv, half_bits *k_cache, half_bits *v_cache, hipStream_t s);
+                                 const float *sin_t, half_bits *qkv, half_bits *k_cache, half_bits *v_cache, hipStream_t s,
+                                 const half_bits *Wt = nullptr);
 
 // decode GEMMs over large weights (T <= 32, K >= 2048, >= 24 MiB of weights): activation block in LDS, persistent workgroups
 // (linear_stream.hip); linear / linear_silu_mul / linear_qkv_rope_store route here when the shape test passes

@@ -40,6 +40,8 @@ struct DecEpi {
     int32_t kslice; int64_t slab_stride; float *slabs; half_t *h; unsigned int *cnt;
     // NORM prologue: x is the residual stream h; wn the RMSNorm weight
     const half_t *wn; float eps;
+    // W is the tiled copy [N/16][K/32][16][32] (retile_weight; DEPI_ROPE: mode 1, tiles already in dec_w_row order)
+    int32_t tiled;
 };
 
 template <int EPI>
@@ -72,9 +74,10 @@ __device__ __forceinline__ float sumsq8(half8_t v, float s) {
 }
 
 // KI: k-steps of 32 per wave (all in flight at once); the k range of the workgroup is <= 32*WAVES*KI (EXACT: equal, no guards).
-// HALF (DEPI_RESID, no k split): 8 weight rows per workgroup (MFMA rows 8..15 repeat rows 0..7 and are dropped), so that the
-// N = hidden GEMMs reach 2N/16 workgroups without cutting k.
-template <int NT, int MT, int WAVES, int KI, int EPI, bool NORM, bool EXACT, bool HALF>
+// RT (DEPI_RESID, no k split): weight rows per workgroup, 16 (a whole MFMA tile), 8 or 4 (the MFMA's rows RT..15 repeat rows
+// 0..RT-1 — same addresses, no extra traffic — and are dropped), so that the N = hidden GEMMs reach N/RT workgroups without
+// cutting k: no slabs, no tickets, nothing to hand over inside the launch.
+template <int NT, int MT, int WAVES, int KI, int EPI, bool NORM, bool EXACT, int RT>
 __global__ __launch_bounds__(WAVES * 64) void decode_linear_kernel(const half_t *__restrict__ x, int64_t ldx,
                                                                    const half_t *__restrict__ W, int T, int K, int N,
                                                                    half_t *__restrict__ y, DecEpi epi) {
@@ -89,23 +92,33 @@ __global__ __launch_bounds__(WAVES * 64) void decode_linear_kernel(const half_t 
     const half_t *xrow[MT];
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
-        const int row = HALF ? min(blockIdx.x * 8 + (r & 7), N - 1) : dec_w_row<EPI>(blockIdx.x, i, NT, r, N, epi);
-        wrow[i] = W + (int64_t)row * K + q * 8;
+        if (epi.tiled) {          // one 16x32 operand tile = 1 KiB contiguous; consecutive k tiles of a row tile follow each other
+            constexpr int PER = 16 / RT;                     // workgroups sharing one 16-row tile
+            const int tile = RT < 16 ? blockIdx.x / PER : EPI == DEPI_SILU ? (i == 0 ? 0 : N / 16) + blockIdx.x : EPI == DEPI_ROPE ? blockIdx.x : blockIdx.x * NT + i;
+            const int rr = RT < 16 ? (blockIdx.x % PER) * RT + (r & (RT - 1)) : r;
+            wrow[i] = W + (int64_t)tile * (K / 32) * 512 + rr * 32 + q * 8;
+        } else {
+            const int row = RT < 16 ? min(blockIdx.x * RT + (r & (RT - 1)), N - 1) : dec_w_row<EPI>(blockIdx.x, i, NT, r, N, epi);
+            wrow[i] = W + (int64_t)row * K + q * 8;
+        }
     }
+    const int kmul = epi.tiled ? 16 : 1;                     // k advances 32 halfs in a row, 512 halfs (one tile) in the tiled copy
 #pragma unroll
     for (int j = 0; j < MT; ++j) { int m = m0 + j * 16 + r; if (m > T - 1) m = T - 1; xrow[j] = x + (int64_t)m * ldx + q * 8; }
 
-    // Request order = the order the data is needed in (s_waitcnt vmcnt counts in issue order): the RoPE position (its cos / sin
-    // loads depend on it), the activation rows and norm weights (L2), cos / sin, the residual tile, and LAST the weights (HBM):
+    // Request order = the order the data is needed in (s_waitcnt vmcnt counts in issue order): the RoPE position, the activation
+    // rows and norm weights (L2), the residual tile, then the weights (HBM) — all back to back, nothing waited for in between:
     // the norm prologue then runs under the weight stream's latency.
     float4_t rope_cs = (float4_t){0.f, 0.f, 0.f, 0.f}, rope_sn = rope_cs;
     int rope_slot = -1;
     int64_t rope_pos = 0;
-    const bool rope_lane = EPI == DEPI_ROPE && wave < MT;
-    if (rope_lane) {
-        const int m = m0 + wave * 16 + r, mc = m < T ? m : T - 1;
+    // every wave requests a position and (below) its cos / sin row — waves >= MT redundantly — so that no load sits under a
+    // divergent branch: s_waitcnt counts at a join assume the shorter queue and over-wait on the longer one (r02: the norm
+    // prologue of the two epilogue waves waited for two weight loads)
+    if (EPI == DEPI_ROPE) {
+        const int m = m0 + (wave % MT) * 16 + r, mc = m < T ? m : T - 1;
         rope_pos = epi.pos[mc];
-        if (blockIdx.x / (epi.D / 16) >= epi.H && epi.slots && m < T) rope_slot = epi.slots[m];
+        if (wave < MT && blockIdx.x / (epi.D / 16) >= epi.H && epi.slots && m < T) rope_slot = epi.slots[m];
     }
     half8_t a[KI][NT], b[KI][MT], gw[NORM ? KI : 1];
 #pragma unroll
@@ -115,14 +128,6 @@ __global__ __launch_bounds__(WAVES * 64) void decode_linear_kernel(const half_t 
         for (int j = 0; j < MT; ++j) b[u][j] = (EXACT || kk < kend) ? *reinterpret_cast<const half8_t *>(xrow[j] + kk) : (half8_t)(half_t)0;
         if constexpr (NORM) gw[u] = (EXACT || kk < kend) ? *reinterpret_cast<const half8_t *>(epi.wn + kk + q * 8) : (half8_t)(half_t)0;
     }
-    if (rope_lane) {
-        const int tph = epi.D / 16, head = blockIdx.x / tph, c = blockIdx.x % tph, half_d = epi.D / 2;
-        if (head < epi.H + epi.KVH) {
-            const int jj = c * 8 + (q & 1) * 4;
-            rope_cs = *reinterpret_cast<const float4_t *>(epi.cos_t + rope_pos * half_d + jj);
-            rope_sn = *reinterpret_cast<const float4_t *>(epi.sin_t + rope_pos * half_d + jj);
-        }
-    }
     // DEPI_RESID: the residual tile this workgroup adds IF it turns out to be the tile's last arriver (nobody else writes it)
     constexpr int TT = (NT * MT + WAVES - 1) / WAVES;          // output tiles per wave in the epilogue
     half4_t hres[TT];
@@ -131,7 +136,7 @@ __global__ __launch_bounds__(WAVES * 64) void decode_linear_kernel(const half_t 
         for (int tt = 0; tt < TT; ++tt) {
             const int tile = wave + tt * WAVES;
             const int i = tile / MT, j = tile % MT;
-            const int n = HALF ? blockIdx.x * 8 + (q & 1) * 4 : (blockIdx.x * NT + i) * 16 + q * 4, m = m0 + j * 16 + r;
+            const int n = RT < 16 ? blockIdx.x * RT + (q & (RT / 4 - 1)) * 4 : (blockIdx.x * NT + i) * 16 + q * 4, m = m0 + j * 16 + r;
             hres[tt] = (tile < NT * MT && m < T && n < N) ? *reinterpret_cast<const half4_t *>(epi.h + (int64_t)m * N + n)
                                                           : (half4_t){(half_t)0, (half_t)0, (half_t)0, (half_t)0};
         }
@@ -141,11 +146,21 @@ __global__ __launch_bounds__(WAVES * 64) void decode_linear_kernel(const half_t 
         const int kk = kbeg + wave * 32 + u * KS;
 #pragma unroll
         for (int i = 0; i < NT; ++i)
-            a[u][i] = (EXACT || kk < kend) ? __builtin_nontemporal_load(reinterpret_cast<const half8_t *>(wrow[i] + kk)) : (half8_t)(half_t)0;
+            a[u][i] = (EXACT || kk < kend) ? __builtin_nontemporal_load(reinterpret_cast<const half8_t *>(wrow[i] + (int64_t)kk * kmul)) : (half8_t)(half_t)0;
     }
     // every request is out before anything is waited for (hipcc otherwise sinks loads below the first use of an earlier one:
     // weight loads behind the norm's waits, or one HBM round trip per MFMA)
     __builtin_amdgcn_sched_barrier(0);
+    // RoPE cos / sin rows: their address hangs on the position loaded first, so they are requested only now — behind the
+    // weights in issue order (waiting for the position BEFORE the weight requests would start the HBM stream one L2 round trip
+    // late: +1.0 us on the qkv launch, r02).  The position is the oldest request and arrives with the activation rows the norm
+    // prologue waits for anyway; cos / sin then fly under the prologue, the weight wait, the MFMAs and the LDS reduction.
+    if (EPI == DEPI_ROPE) {                                   // (v heads load a row too and never use it)
+        const int c = blockIdx.x % (epi.D / 16), half_d = epi.D / 2, jj = c * 8 + (q & 1) * 4;
+        rope_cs = *reinterpret_cast<const float4_t *>(epi.cos_t + rope_pos * half_d + jj);
+        rope_sn = *reinterpret_cast<const float4_t *>(epi.sin_t + rope_pos * half_d + jj);
+        __builtin_amdgcn_sched_barrier(0);
+    }
 
     __shared__ float4_t part[WAVES][NT * MT][64];
     __shared__ float red[WAVES][MT * 16];
@@ -216,8 +231,8 @@ __global__ __launch_bounds__(WAVES * 64) void decode_linear_kernel(const half_t 
                 if (tile >= NT * MT) continue;
                 const float4_t s = reduce(tile);
                 const int i = tile / MT, j = tile % MT;
-                const int n = HALF ? blockIdx.x * 8 + q * 4 : (blockIdx.x * NT + i) * 16 + q * 4, m = m0 + j * 16 + r;
-                if (m < T && n < N && (!HALF || q < 2)) {
+                const int n = RT < 16 ? blockIdx.x * RT + q * 4 : (blockIdx.x * NT + i) * 16 + q * 4, m = m0 + j * 16 + r;
+                if (m < T && n < N && q < RT / 4) {
                     half4_t o;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] = to_half_rn((float)hres[tt][e] + (float)to_half_rn(s[e]));
@@ -330,13 +345,13 @@ static int dec_launch_check(const char *what) {
     return 0;
 }
 
-template <int NT, int MT, int WAVES, int KI, int EPI, bool NORM, bool HALF = false>
+template <int NT, int MT, int WAVES, int KI, int EPI, bool NORM, int RT = 16>
 static void dec_launch(const half_t *x, int64_t ldx, const half_t *W, int T, int K, int N, half_t *y, const DecEpi &e, unsigned gx,
                        unsigned gz, hipStream_t s) {
     dim3 grid(gx, (unsigned)((T + 16 * MT - 1) / (16 * MT)), gz);
     const int kr = EPI == DEPI_RESID ? e.kslice : K;
-    if (kr == 32 * WAVES * KI) decode_linear_kernel<NT, MT, WAVES, KI, EPI, NORM, true, HALF><<<grid, dim3(WAVES * 64), 0, s>>>(x, ldx, W, T, K, N, y, e);
-    else decode_linear_kernel<NT, MT, WAVES, KI, EPI, NORM, false, HALF><<<grid, dim3(WAVES * 64), 0, s>>>(x, ldx, W, T, K, N, y, e);
+    if (kr == 32 * WAVES * KI) decode_linear_kernel<NT, MT, WAVES, KI, EPI, NORM, true, RT><<<grid, dim3(WAVES * 64), 0, s>>>(x, ldx, W, T, K, N, y, e);
+    else decode_linear_kernel<NT, MT, WAVES, KI, EPI, NORM, false, RT><<<grid, dim3(WAVES * 64), 0, s>>>(x, ldx, W, T, K, N, y, e);
 }
 
 // (waves, k-steps per wave) for a workgroup k range: the r01 geometry (8 waves at K = 1024, 16 at 2048, 4-wave k-slices)
@@ -363,25 +378,32 @@ int decode_splitk_slices(int64_t T, int64_t K, int64_t N) {
 
 // h[T,N] <- fp16(h + fp16(x[T,K]·W[N,K]ᵀ)); S k-slices, slabs [S][T][N] f32, cnt: one zeroed counter per (column tile, token tile)
 int linear_resid(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t N, int64_t S, float *slabs,
-                 unsigned int *cnt, half_bits *h, hipStream_t s) {
-    if (S < 1 || S > 4 || K % (32 * S) || N % 16 || ldx % 8 || T > 64 || K / S > 2048)
+                 unsigned int *cnt, half_bits *h, hipStream_t s, const half_bits *Wt) {
+    static const bool half_env = [] { const char *v = std::getenv("NVR_RESID_HALF"); return v && v[0] == '1'; }();
+    const bool half_tiles = S == 0 || half_env;             // S = 0: 8-row weight tiles, no k split, no slabs, no tickets
+    if (half_tiles) S = 1;
+    if (S < 1 || S > 4 || K % (32 * S) || N % 16 || ldx % 8 || T > 64 || (!half_tiles && K / S > 2048))
         return nvr::fail(NVR_ERR_UNSUPPORTED, "linear_resid: K=%ld S=%ld N=%ld T=%ld ldx=%ld", (long)K, (long)S, (long)N, (long)T, (long)ldx);
     if (T == 0) return 0;
     DecEpi e{};
     e.kslice = (int32_t)(K / S); e.slab_stride = T * N; e.slabs = slabs; e.h = (half_t *)h; e.cnt = cnt;
-    static const bool half_tiles = [] { const char *v = std::getenv("NVR_RESID_HALF"); return v && v[0] == '1'; }();
-    if (half_tiles && N % 8 == 0 && K <= 4096) {
-        // 8-row weight tiles, 16 tokens per workgroup, no k split: N/8 x ceil(T/16) workgroups, no slabs, no tickets
+    if (Wt && N % 16 == 0) { W = Wt; e.tiled = 1; }
+    if (half_tiles) {
+        // 8-row weight tiles, 16 tokens per workgroup, no k split: N/8 x ceil(T/16) workgroups, no slabs, no tickets.
+        // (4-row tiles with both token tiles in one workgroup — every weight byte requested once — measured 6.98 / 9.25 us
+        // against 5.18 / 6.50 us for o_proj / down_proj: each workgroup then pulls the WHOLE [32, K] activation block, 128-192 KB,
+        // through its CU's 64 B/clk L1 fill path; profiles/r02_decode_chain_ablation.txt)
+        if (N % 8 || K > 4096) return nvr::fail(NVR_ERR_UNSUPPORTED, "linear_resid (row tiles): K=%ld N=%ld", (long)K, (long)N);
         e.kslice = (int32_t)K;
         const unsigned gx8 = (unsigned)(N / 8);
-#define HBODY(WV, KI_) dec_launch<1, 1, WV, KI_, DEPI_RESID, false, true>((const half_t *)x, ldx, (const half_t *)W, (int)T, (int)K, (int)N, nullptr, e, gx8, 1, s)
+#define HBODY(WV, KI_) dec_launch<1, 1, WV, KI_, DEPI_RESID, false, 8>((const half_t *)x, ldx, (const half_t *)W, (int)T, (int)K, (int)N, nullptr, e, gx8, 1, s)
         if (K <= 512) HBODY(4, 4);
         else if (K <= 1024) HBODY(8, 4);
         else if (K <= 2048) HBODY(16, 4);
         else if (K <= 3072) HBODY(16, 6);
         else HBODY(16, 8);
 #undef HBODY
-        return dec_launch_check("linear_resid (half tiles)");
+        return dec_launch_check("linear_resid (row tiles)");
     }
     const unsigned gx = (unsigned)(N / 16);
     const int64_t kr = K / S;
@@ -395,12 +417,13 @@ int linear_resid(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T,
 
 // act[T,I] = SiluAndMul(RMSNorm(h; wn)·W[2I,K]ᵀ)
 int linear_silu_mul_normed(const half_bits *h, int64_t ldx, const half_bits *wn, float eps, const half_bits *W, int64_t T, int64_t K,
-                           int64_t I, half_bits *out, hipStream_t s) {
+                           int64_t I, half_bits *out, hipStream_t s, const half_bits *Wt) {
     if (K % 32 || I % 16 || ldx % 8 || T > 64 || K > 2048)
         return nvr::fail(NVR_ERR_UNSUPPORTED, "linear_silu_mul_normed: K=%ld I=%ld T=%ld", (long)K, (long)I, (long)T);
     if (T == 0) return 0;
     DecEpi e{};
     e.wn = (const half_t *)wn; e.eps = eps;
+    if (Wt) { W = Wt; e.tiled = 1; }
     const unsigned gx = (unsigned)(I / 16);
 #define BODY(WV, KI_)                                                                                                              \
     if (T <= 16) dec_launch<2, 1, WV, KI_, DEPI_SILU, true>((const half_t *)h, ldx, (const half_t *)W, (int)T, (int)K, (int)I, (half_t *)out, e, gx, 1, s); \
@@ -413,7 +436,8 @@ int linear_silu_mul_normed(const half_bits *h, int64_t ldx, const half_bits *wn,
 // qkv[T,(H+2KVH)D] = RoPE(RMSNorm(h; wn)·Wᵀ) (+ k, v rows stored at slots)
 int linear_qkv_rope_store_normed(const half_bits *h, int64_t ldx, const half_bits *wn, float eps, const half_bits *W, int64_t T, int64_t K,
                                  int64_t H, int64_t KVH, int64_t D, const int64_t *positions, const int32_t *slots, const float *cos_t,
-                                 const float *sin_t, half_bits *qkv, half_bits *k_cache, half_bits *v_cache, hipStream_t s) {
+                                 const float *sin_t, half_bits *qkv, half_bits *k_cache, half_bits *v_cache, hipStream_t s,
+                                 const half_bits *Wt) {
     if (K % 32 || D % 16 || ldx % 8 || T > 64 || K > 2048)
         return nvr::fail(NVR_ERR_UNSUPPORTED, "linear_qkv_rope_store_normed: K=%ld D=%ld T=%ld", (long)K, (long)D, (long)T);
     if (T == 0) return 0;
@@ -421,6 +445,7 @@ int linear_qkv_rope_store_normed(const half_bits *h, int64_t ldx, const half_bit
     e.pos = positions; e.slots = slots; e.cos_t = cos_t; e.sin_t = sin_t; e.kc = (half_t *)k_cache; e.vc = (half_t *)v_cache;
     e.H = (int32_t)H; e.KVH = (int32_t)KVH; e.D = (int32_t)D;
     e.wn = (const half_t *)wn; e.eps = eps;
+    if (Wt) { W = Wt; e.tiled = 1; }
     const int N = (int)((H + 2 * KVH) * D);
     const unsigned gx = (unsigned)(N / 16);
 #define BODY(WV, KI_)                                                                                                              \

@@ -39,7 +39,7 @@ nvr_model_runner::~nvr_model_runner() {
     comm.destroy();
     if (chain_cnt) hipFree(chain_cnt);
     for (auto &l : layers) { hipFree(l.qkv); hipFree(l.o); hipFree(l.gate_up); hipFree(l.down); hipFree(l.ln1); hipFree(l.ln2);
-                             void *ts[] = {l.qkv_t, l.o_t, l.gate_up_t, l.down_t}; for (void *t : ts) if (t) hipFree(t); }
+                             void *ts[] = {l.qkv_t, l.o_t, l.gate_up_t, l.down_t, l.q_norm, l.k_norm}; for (void *t : ts) if (t) hipFree(t); }
     if (lm_head_t) hipFree(lm_head_t);
     void *ptrs[] = {embed, mc.tie_word_embeddings ? nullptr : lm_head, norm, cos_t, sin_t, kv_pool, h, n, qkv, attn,
                     proj, gu, act, nlast, logits, attn_ws, slabs, in_dev, d_tok, d_maxval, d_temp, d_topk, d_topp, d_keys,
@@ -180,7 +180,7 @@ int nvr_model_runner::retile_all() {
     const bool gemm_ok = Hd % 32 == 0 && (H * D) % 32 == 0 && I % 32 == 0 && QKV % 16 == 0 && Hd % 16 == 0 && I % 16 == 0 && D % 16 == 0;
     for (auto &w : layers) {
         if (!gemm_ok || !w.qkv_t) continue;
-        RC(k::retile_weight(w.qkv, w.qkv_t, QKV, Hd, 1, H, KVH, D, stream));
+        RC(k::retile_weight(w.qkv, w.qkv_t, QKV, Hd, mc.qk_norm ? 0 : 1, H, KVH, D, stream));   // qk_norm: plain GEMM, rows in place
         RC(k::retile_weight(w.o, w.o_t, Hd, H * D, 0, 0, 0, 0, stream));
         RC(k::retile_weight(w.gate_up, w.gate_up_t, 2 * I, Hd, 0, 0, 0, 0, stream));
         RC(k::retile_weight(w.down, w.down_t, Hd, I, 0, 0, 0, 0, stream));
@@ -201,7 +201,11 @@ int nvr_model_runner::gen_weights() {
         auto key = [&](uint64_t tid) { return nvr_weight_key_impl(mc.seed, (uint64_t)l * 8 + tid); };
         RC(dmalloc(&w.qkv, QKV * Hd)); RC(dmalloc(&w.o, Hd * H * D)); RC(dmalloc(&w.gate_up, 2 * I * Hd));
         RC(dmalloc(&w.down, Hd * I)); RC(dmalloc(&w.ln1, Hd)); RC(dmalloc(&w.ln2, Hd));
-        w.qkv_t = w.o_t = w.gate_up_t = w.down_t = nullptr;
+        w.qkv_t = w.o_t = w.gate_up_t = w.down_t = w.q_norm = w.k_norm = nullptr;
+        if (mc.qk_norm) {
+            RC(dmalloc(&w.q_norm, D)); RC(dmalloc(&w.k_norm, D));
+            RC(k::fill_const(w.q_norm, D, 1.0f, stream)); RC(k::fill_const(w.k_norm, D, 1.0f, stream));
+        }
         if (tiled_weights) {
             RC(dmalloc(&w.qkv_t, QKV * Hd)); RC(dmalloc(&w.o_t, Hd * H * D)); RC(dmalloc(&w.gate_up_t, 2 * I * Hd)); RC(dmalloc(&w.down_t, Hd * I));
         }
@@ -293,6 +297,9 @@ int nvr_model_runner::load_tensor(const char *name_in, int dtype, const int64_t 
     auto layer_ok = [&]() -> int { return (l < 0 || l >= L) ? nvr::fail(NVR_ERR_INVALID_ARG, "%s: layer out of range (0..%ld)", name_in, (long)L - 1) : NVR_OK; };
     if (match_layer(name, "input_layernorm.weight", &l)) { RC(layer_ok()); RC(want(Hd, 1)); return put(layers[l].ln1, 1, 0, Hd, 0, 1); }
     if (match_layer(name, "post_attention_layernorm.weight", &l)) { RC(layer_ok()); RC(want(Hd, 1)); return put(layers[l].ln2, 1, 0, Hd, 0, 1); }
+    // head_dim norms of the real checkpoints (replicated on every rank): part of the graph only with mc.qk_norm (A-27)
+    if (mc.qk_norm && match_layer(name, "self_attn.q_norm.weight", &l)) { RC(layer_ok()); RC(want(D, 1)); return put(layers[l].q_norm, 1, 0, D, 0, 1); }
+    if (mc.qk_norm && match_layer(name, "self_attn.k_norm.weight", &l)) { RC(layer_ok()); RC(want(D, 1)); return put(layers[l].k_norm, 1, 0, D, 0, 1); }
     // QKVParallelLinear: local rows [q heads | k heads | v heads] (linear.rs:300-340), each a rank slice of its projection
     if (match_layer(name, "self_attn.q_proj.weight", &l)) { RC(layer_ok()); RC(want(Hg * D, Hd)); return put(layers[l].qkv, Hd, rank * H * D, H * D, 0, Hd); }
     if (match_layer(name, "self_attn.k_proj.weight", &l)) { RC(layer_ok()); RC(want(KVHg * D, Hd)); return put(layers[l].qkv + H * D * Hd, Hd, rank * KVH * D, KVH * D, 0, Hd); }
@@ -313,7 +320,7 @@ int nvr_model_runner::load_tensor(const char *name_in, int dtype, const int64_t 
         return put(layers[l].gate_up + I * Hd, Hd, Ig + rank * I, I, 0, Hd);
     }
     if (match_layer(name, "mlp.down_proj.weight", &l)) { RC(layer_ok()); RC(want(Hd, Ig)); return put(layers[l].down, I, 0, Hd, rank * I, I); }
-    return nvr::fail(NVR_ERR_UNSUPPORTED, "load_tensor: no parameter named '%s' in this graph (q/k-norm and biases are not part of the reference's Qwen3 graph, SURVEY A-17)", name_in);
+    return nvr::fail(NVR_ERR_UNSUPPORTED, "load_tensor: no parameter named '%s' in this graph (biases are not part of the reference's Qwen3 graph; q_norm / k_norm need nvr_model_config.qk_norm, SURVEY A-17)", name_in);
 }
 
 int nvr_model_runner::copy_weight(const char *ln, uint16_t *out, size_t cap, int64_t *rows, int64_t *cols) {
@@ -328,6 +335,8 @@ int nvr_model_runner::copy_weight(const char *ln, uint16_t *out, size_t cap, int
     else if (match_layer(ln, "down", &l) && l >= 0 && l < L) { src = layers[l].down; r = Hd; c = I; }
     else if (match_layer(ln, "ln1", &l) && l >= 0 && l < L) { src = layers[l].ln1; r = Hd; c = 1; }
     else if (match_layer(ln, "ln2", &l) && l >= 0 && l < L) { src = layers[l].ln2; r = Hd; c = 1; }
+    else if (mc.qk_norm && match_layer(ln, "q_norm", &l) && l >= 0 && l < L) { src = layers[l].q_norm; r = D; c = 1; }
+    else if (mc.qk_norm && match_layer(ln, "k_norm", &l) && l >= 0 && l < L) { src = layers[l].k_norm; r = D; c = 1; }
     else return nvr::fail(NVR_ERR_INVALID_ARG, "copy_weight: unknown local tensor '%s'", ln);
     if (rows) *rows = r;
     if (cols) *cols = c;
@@ -373,7 +382,7 @@ int nvr_model_runner::row_parallel_norm(const uint16_t *x, int64_t K, const uint
 // the norm-prologue kernels; everything else (prefill, tensor-parallel ranks with their all-reduce between GEMM and residual,
 // Qwen3-8B-class weights with their streaming kernels) keeps the six-launch chain.
 bool nvr_model_runner::use_chain4(int64_t T, bool is_prefill) const {
-    return chain4 && !is_prefill && tp == 1 && !comm.active() && k::decode_chain_ok(T, Hd, QKV, I, D) &&
+    return chain4 && !mc.qk_norm && !is_prefill && tp == 1 && !comm.active() && k::decode_chain_ok(T, Hd, QKV, I, D) &&
            H * D <= 4096 && I <= 8192 && Hd * std::max(H * D, I) * 2 < (24ll << 20);
 }
 
@@ -392,11 +401,16 @@ int nvr_model_runner::forward(int64_t T, int64_t B, bool is_prefill, int64_t max
         const Layer &w = layers[l];
         if (c4) {                                    // input norm :378 in the prologue of the qkv GEMM (K2..K6 in one launch)
             RC(k::linear_qkv_rope_store_normed(h, Hd, w.ln1, mc.rms_norm_eps, w.qkv, T, Hd, H, KVH, D, pos, slots, cos_t, sin_t, qkv,
-                                               k_cache(l), v_cache(l), st));
+                                               k_cache(l), v_cache(l), st, tl ? w.qkv_t : nullptr));
         } else {
             if (l == 0 && !embed_norm) RC(k::rmsnorm(h, w.ln1, mc.rms_norm_eps, T, Hd, n, st));   // later layers: see down_proj
-            // qkv GEMM with the RoPE + KV-store epilogue (K3..K6 in one launch)
-            RC(k::linear_qkv_rope_store(n, Hd, w.qkv, T, Hd, H, KVH, D, pos, slots, cos_t, sin_t, qkv, k_cache(l), v_cache(l), st, tl ? w.qkv_t : nullptr));
+            if (mc.qk_norm) {                        // A-27: the head norms sit between the projection and RoPE: plain GEMM, then one
+                RC(k::linear(n, Hd, w.qkv, T, Hd, QKV, qkv, false, st, tl ? w.qkv_t : nullptr));      // norm + RoPE + KV-store launch
+                RC(k::rope_store_kv(qkv, pos, slots, T, H, KVH, D, cos_t, sin_t, k_cache(l), v_cache(l), st, w.q_norm, w.k_norm, mc.rms_norm_eps));
+            } else {
+                // qkv GEMM with the RoPE + KV-store epilogue (K3..K6 in one launch)
+                RC(k::linear_qkv_rope_store(n, Hd, w.qkv, T, Hd, H, KVH, D, pos, slots, cos_t, sin_t, qkv, k_cache(l), v_cache(l), st, tl ? w.qkv_t : nullptr));
+            }
         }
         k::AttnArgs a{};
         a.q = qkv; a.ldq = QKV; a.ctx_lens = ctx; a.nq = (int32_t)T; a.H = (int32_t)H; a.KVH = (int32_t)KVH; a.D = (int32_t)D;
@@ -422,9 +436,9 @@ int nvr_model_runner::forward(int64_t T, int64_t B, bool is_prefill, int64_t max
         if (c4) {
             // o_proj + residual :382 (the split-k reduction's last arriver adds h); post-attention norm :385 in the prologue of
             // gate_up + SiluAndMul; down_proj + residual :389.  The next layer's input norm is the next qkv launch's prologue.
-            RC(k::linear_resid(attn, H * D, w.o, T, H * D, Hd, k::decode_splitk_slices(T, H * D, Hd), slabs, chain_cnt, h, st));
-            RC(k::linear_silu_mul_normed(h, Hd, w.ln2, mc.rms_norm_eps, w.gate_up, T, Hd, I, act, st));
-            RC(k::linear_resid(act, I, w.down, T, I, Hd, k::decode_splitk_slices(T, I, Hd), slabs, chain_cnt, h, st));
+            RC(k::linear_resid(attn, H * D, w.o, T, H * D, Hd, k::decode_splitk_slices(T, H * D, Hd), slabs, chain_cnt, h, st, tl ? w.o_t : nullptr));
+            RC(k::linear_silu_mul_normed(h, Hd, w.ln2, mc.rms_norm_eps, w.gate_up, T, Hd, I, act, st, tl ? w.gate_up_t : nullptr));
+            RC(k::linear_resid(act, I, w.down, T, I, Hd, k::decode_splitk_slices(T, I, Hd), slabs, chain_cnt, h, st, tl ? w.down_t : nullptr));
         } else {
             RC(row_parallel_norm(attn, H * D, w.o, tl ? w.o_t : nullptr, T, w.ln2));         // o_proj, residual :382, norm :385
             RC(k::linear_silu_mul(n, Hd, w.gate_up, T, Hd, I, act, st, tl ? w.gate_up_t : nullptr));   // K12 + K13 in one launch

@@ -24,7 +24,8 @@ struct nvr_model_runner {
     hipStream_t stream = nullptr;
 
     struct Layer { uint16_t *qkv, *o, *gate_up, *down, *ln1, *ln2;
-                   uint16_t *qkv_t, *o_t, *gate_up_t, *down_t; };   // *_t: tiled copies for the decode kernels (retile_weight), or null
+                   uint16_t *qkv_t, *o_t, *gate_up_t, *down_t;      // *_t: tiled copies for the decode kernels (retile_weight), or null
+                   uint16_t *q_norm, *k_norm; };                    // mc.qk_norm: [D] each (ones until loaded), else null
     std::vector<Layer> layers;
     uint16_t *embed = nullptr, *lm_head = nullptr, *norm = nullptr;
     uint16_t *lm_head_t = nullptr;         // tiled copy of the LM head (decode-sized steps)

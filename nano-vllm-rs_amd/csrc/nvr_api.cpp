@@ -426,6 +426,7 @@ int nvr_stream_synchronize(void *s) { NVR_HIP_CHECK(hipStreamSynchronize((hipStr
 int nvr_event_create(void **e) { hipEvent_t ev; NVR_HIP_CHECK(hipEventCreate(&ev)); *e = ev; return NVR_OK; }
 int nvr_event_destroy(void *e) { NVR_HIP_CHECK(hipEventDestroy((hipEvent_t)e)); return NVR_OK; }
 int nvr_event_record(void *e, void *s) { NVR_HIP_CHECK(hipEventRecord((hipEvent_t)e, (hipStream_t)s)); return NVR_OK; }
+int nvr_stream_wait_event(void *s, void *e) { NVR_HIP_CHECK(hipStreamWaitEvent((hipStream_t)s, (hipEvent_t)e, 0)); return NVR_OK; }
 int nvr_event_elapsed_ms(void *a, void *b, float *ms) {
     NVR_HIP_CHECK(hipEventSynchronize((hipEvent_t)b));
     NVR_HIP_CHECK(hipEventElapsedTime(ms, (hipEvent_t)a, (hipEvent_t)b));
@@ -499,19 +500,19 @@ int nvr_lm_head_tiled(const nvr_half *x, int64_t ldx, const nvr_half *W, const n
 int nvr_retile_weight(const nvr_half *src, nvr_half *dst, int64_t N, int64_t K, int mode, int64_t H, int64_t KVH, int64_t D, void *s) {
     return k::retile_weight(src, dst, N, K, mode, H, KVH, D, (hipStream_t)s);
 }
-int nvr_linear_resid(const nvr_half *x, int64_t ldx, const nvr_half *W, int64_t T, int64_t K, int64_t N, int64_t S, float *slabs,
-                     uint32_t *counters, nvr_half *h, void *s) {
-    return k::linear_resid(x, ldx, W, T, K, N, S, slabs, counters, h, (hipStream_t)s);
+int nvr_linear_resid(const nvr_half *x, int64_t ldx, const nvr_half *W, const nvr_half *Wt, int64_t T, int64_t K, int64_t N, int64_t S,
+                     float *slabs, uint32_t *counters, nvr_half *h, void *s) {
+    return k::linear_resid(x, ldx, W, T, K, N, S, slabs, counters, h, (hipStream_t)s, Wt);
 }
 int nvr_decode_splitk_slices(int64_t T, int64_t K, int64_t N) { return k::decode_splitk_slices(T, K, N); }
-int nvr_linear_silu_mul_normed(const nvr_half *h, int64_t ldx, const nvr_half *wn, float eps, const nvr_half *W, int64_t T, int64_t K,
-                               int64_t I, nvr_half *out, void *s) {
-    return k::linear_silu_mul_normed(h, ldx, wn, eps, W, T, K, I, out, (hipStream_t)s);
+int nvr_linear_silu_mul_normed(const nvr_half *h, int64_t ldx, const nvr_half *wn, float eps, const nvr_half *W, const nvr_half *Wt, int64_t T,
+                               int64_t K, int64_t I, nvr_half *out, void *s) {
+    return k::linear_silu_mul_normed(h, ldx, wn, eps, W, T, K, I, out, (hipStream_t)s, Wt);
 }
-int nvr_linear_qkv_rope_store_normed(const nvr_half *h, int64_t ldx, const nvr_half *wn, float eps, const nvr_half *W, int64_t T, int64_t K,
-                                     int64_t H, int64_t KVH, int64_t D, const int64_t *pos, const int32_t *slots, const float *cos_t,
-                                     const float *sin_t, nvr_half *qkv, nvr_half *kc, nvr_half *vc, void *s) {
-    return k::linear_qkv_rope_store_normed(h, ldx, wn, eps, W, T, K, H, KVH, D, pos, slots, cos_t, sin_t, qkv, kc, vc, (hipStream_t)s);
+int nvr_linear_qkv_rope_store_normed(const nvr_half *h, int64_t ldx, const nvr_half *wn, float eps, const nvr_half *W, const nvr_half *Wt,
+                                     int64_t T, int64_t K, int64_t H, int64_t KVH, int64_t D, const int64_t *pos, const int32_t *slots,
+                                     const float *cos_t, const float *sin_t, nvr_half *qkv, nvr_half *kc, nvr_half *vc, void *s) {
+    return k::linear_qkv_rope_store_normed(h, ldx, wn, eps, W, T, K, H, KVH, D, pos, slots, cos_t, sin_t, qkv, kc, vc, (hipStream_t)s, Wt);
 }
 int nvr_linear_silu_mul(const nvr_half *x, int64_t ldx, const nvr_half *W, int64_t T, int64_t K, int64_t I, nvr_half *out, void *s) {
     return k::linear_silu_mul(x, ldx, W, T, K, I, out, (hipStream_t)s);
@@ -524,6 +525,12 @@ int nvr_linear_qkv_rope_store(const nvr_half *x, int64_t ldx, const nvr_half *W,
 int nvr_rope_store_kv(nvr_half *qkv, const int64_t *pos, const int32_t *slots, int64_t T, int64_t H, int64_t KVH, int64_t D,
                       const float *c, const float *sn, nvr_half *kc, nvr_half *vc, void *s) {
     return k::rope_store_kv(qkv, pos, slots, T, H, KVH, D, c, sn, kc, vc, (hipStream_t)s);
+}
+int nvr_qk_norm_rope_store_kv(nvr_half *qkv, const int64_t *pos, const int32_t *slots, int64_t T, int64_t H, int64_t KVH, int64_t D,
+                              const float *c, const float *sn, const nvr_half *qw, const nvr_half *kw, float eps, nvr_half *kc, nvr_half *vc,
+                              void *s) {
+    if (!qw || !kw) return nvr::fail(NVR_ERR_INVALID_ARG, "nvr_qk_norm_rope_store_kv: norm weights are null");
+    return k::rope_store_kv(qkv, pos, slots, T, H, KVH, D, c, sn, kc, vc, (hipStream_t)s, qw, kw, eps);
 }
 int nvr_rope_table(int64_t D, int64_t max_pos, double theta, float *cos_dev, float *sin_dev) {   // rotary_embedding.rs:74-119 (A-14)
     NVR_GUARD_BEGIN

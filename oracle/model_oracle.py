@@ -51,6 +51,10 @@ class ModelConfig:
     tie_word_embeddings: bool = False
     init_std: float = 0.02
     seed: int = 0
+    # Extension (DESIGN A-27; False = the reference graph, which has no such layers): the real Qwen3
+    # checkpoints carry self_attn.q_norm / k_norm, an RMSNorm over head_dim on every q and k head between the projection and
+    # RoPE.  They are restated with the reference's own RMSNorm::forward_simple (layernorm.rs:58-75) and rms_norm_eps.
+    qk_norm: bool = False
 
     def hd(self) -> int:                       # qwen3.rs:101-103
         return self.head_dim if self.head_dim else self.hidden_size // self.num_attention_heads
@@ -139,7 +143,8 @@ class OracleModel:
             # down_proj row-parallel: global [Hd, I], columns sharded
             d = fill_weight(Hd, self.I, Ig, 0, r * self.I, key(TID_DOWN), sc, f16)
             self.layers.append(dict(qkv=np.concatenate([q, k, v], 0), o=o, gate_up=np.concatenate([g, u], 0),
-                                    down=d, ln1=np.ones(Hd, np.float32), ln2=np.ones(Hd, np.float32)))
+                                    down=d, ln1=np.ones(Hd, np.float32), ln2=np.ones(Hd, np.float32),
+                                    q_norm=np.ones(D, np.float32), k_norm=np.ones(D, np.float32)))
         # Embedding replicated on every rank (skip C2); LM head vocab-sharded
         # (embed_head.rs:57-59), tied to the embedding when tie_word_embeddings (qwen3.rs:461-473).
         self.embed = fill_weight(self.V, Hd, Hd, 0, 0, weight_key(c.seed, TID_EMBED), sc, f16)
@@ -188,6 +193,8 @@ class OracleModel:
                     W["ln1"] = want(a, (Hd,), full)
                 elif rest == "post_attention_layernorm.weight":
                     W["ln2"] = want(a, (Hd,), full)
+                elif rest in ("self_attn.q_norm.weight", "self_attn.k_norm.weight") and c.qk_norm:
+                    W["q_norm" if ".q_norm." in rest else "k_norm"] = want(a, (D,), full)      # per head_dim: replicated on every rank
                 elif rest == "self_attn.q_proj.weight":
                     W["qkv"][:H * D] = want(a, (Hg * D, Hd), full)[r * H * D:(r + 1) * H * D]
                 elif rest == "self_attn.k_proj.weight":
@@ -231,6 +238,10 @@ class OracleModel:
         q = qkv[:, :qd].reshape(T, self.H, self.D)                       # split_qkv linear.rs:331-340
         k = qkv[:, qd:qd + kd].reshape(T, self.KVH, self.D)
         v = np.ascontiguousarray(qkv[:, qd + kd:].reshape(T, self.KVH, self.D))
+        if self.cfg.qk_norm:                                             # A-27: RMSNorm over head_dim, fp16 out, before RoPE
+            eps = self.cfg.rms_norm_eps
+            q = self._r(rmsnorm(np.ascontiguousarray(q).reshape(T * self.H, self.D), W["q_norm"], eps)).reshape(T, self.H, self.D)
+            k = self._r(rmsnorm(np.ascontiguousarray(k).reshape(T * self.KVH, self.D), W["k_norm"], eps)).reshape(T, self.KVH, self.D)
         q = self._r(rope_apply(q, positions, self.cos, self.sin))        # rotary_embedding.rs:145-158
         k = self._r(rope_apply(k, positions, self.cos, self.sin))
         kv_store(k, v, meta["slot_mapping"], self.k_cache[l], self.v_cache[l])   # attention.rs:150-174

@@ -28,7 +28,8 @@ def _model_cfgs(mcfg: mo.ModelConfig):
                         num_attention_heads=mcfg.num_attention_heads, num_key_value_heads=mcfg.num_key_value_heads,
                         head_dim=mcfg.head_dim or 0, max_position_embeddings=mcfg.max_position_embeddings,
                         rms_norm_eps=mcfg.rms_norm_eps, rope_theta=mcfg.rope_theta,
-                        tie_word_embeddings=mcfg.tie_word_embeddings, init_std=mcfg.init_std, seed=mcfg.seed)
+                        tie_word_embeddings=mcfg.tie_word_embeddings, init_std=mcfg.init_std, seed=mcfg.seed,
+                        qk_norm=mcfg.qk_norm)
     return m
 
 
@@ -687,3 +688,41 @@ def test_tiled_weight_copies_do_not_change_a_bit():
     assert len(a) == len(b) > 8
     for (ta, la), (tb, lb) in zip(a, b):
         assert ta == tb and np.array_equal(la, lb)
+
+
+@pytest.mark.parametrize("shape", ["small", "gqa2_d128"])
+def test_qk_norm_checkpoint_end_to_end(tmp_path, shape):
+    """A-27: a checkpoint with self_attn.q_norm / k_norm weights (real Qwen3 layout) runs with
+    nvr_model_config.qk_norm = 1 — plain qkv GEMM, then one head-norm + RoPE + KV-store launch — in parity with the oracle that
+    applies the reference's own RMSNorm to every q and k head before RoPE; graph and eager decode agree; without the flag the
+    same tensors are refused (they are not part of the reference graph)."""
+    from safetensors.numpy import save_file
+    mcfg = mo.small(seed=5, qk_norm=True) if shape == "small" else \
+        mo.small(seed=6, qk_norm=True, hidden_size=512, num_attention_heads=4, num_key_value_heads=2, head_dim=128, intermediate_size=768)
+    rng = np.random.default_rng(78)
+    D, L, V = mcfg.hd(), mcfg.num_hidden_layers, mcfg.vocab_size
+    sd = {}
+    for l in range(L):
+        sd[f"model.layers.{l}.self_attn.q_norm.weight"] = (1 + 0.3 * rng.standard_normal(D)).astype(np.float16)
+        sd[f"model.layers.{l}.self_attn.k_norm.weight"] = (1 + 0.3 * rng.standard_normal(D)).astype(np.float32)
+    path = str(tmp_path / "qk.safetensors")
+    save_file(sd, path)
+    ecfg = dict(max_num_seqs=4, max_num_batched_tokens=256, max_model_len=128, kvcache_block_size=16, num_kvcache_blocks=40)
+    prompts = [oracle.fill_tokens(n, 8, i, V).tolist() for i, n in enumerate([23, 70, 5])]
+    sps = [dict(temperature=0.0, max_tokens=14, ignore_eos=True)] * 3
+    r = _run_pair(mcfg, ecfg, prompts, sps, checkpoint=(sd, path))
+    assert r["near_ties"] <= 2 and r["decode_steps"] >= 13, r
+    e = _run_pair(mcfg, ecfg, prompts, sps, checkpoint=(sd, path), enforce_eager=True)
+    assert e["finished"] == r["finished"]
+    # norm weights of all ones (no checkpoint) are still a different graph from the reference's
+    plain = _run_pair(mo.small(seed=5) if shape == "small" else
+                      mo.small(seed=6, hidden_size=512, num_attention_heads=4, num_key_value_heads=2, head_dim=128, intermediate_size=768),
+                      ecfg, prompts, sps)
+    ones = _run_pair(mcfg, ecfg, prompts, sps)
+    assert ones["finished"] != plain["finished"] and ones["finished"] != r["finished"]
+    # the reference graph has no such parameters
+    p = nvr.LLMEngine(nvr.Config(skip_block_size_check=1, **ecfg), _model_cfgs(mo.small(seed=5)))
+    with pytest.warns(RuntimeWarning):
+        assert sorted(p.model_runner.load_safetensors(path)) == sorted(sd)
+    with pytest.raises(nvr.NvrError):
+        p.model_runner.load_safetensors(path, strict=True)

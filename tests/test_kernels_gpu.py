@@ -637,6 +637,14 @@ def test_linear_qkv_rope_store_fused(T, K, H, KVH, D):
     assert_close_f16(d_v.to_numpy(vc.shape, F16), vc, ulps=2, atol=3e-4, what="fused v cache")
 
 
+def _retiled(d_W, N, K, mode=0, H=0, KVH=0, D=0):
+    """Device pointer of the nvr_retile_weight copy of d_W [N, K]."""
+    d_T = nvr.DeviceBuffer(N * K * 2)
+    _KEEP.append(d_T)
+    nvr.check(nvr.lib().nvr_retile_weight(d_W.ptr, d_T.ptr, N, K, mode, H, KVH, D, None))
+    return d_T.ptr
+
+
 @pytest.mark.parametrize("T,K,N,S", [(32, 2048, 1024, 4), (32, 3072, 1024, 4), (5, 256, 64, 2), (40, 512, 256, 4),
                                      (32, 4096, 4096, 4), (9, 12288, 4096, 4), (32, 4096, 8192, 2),   # large weights: 64-column workgroups, wide rows
                                      (130, 2048, 1024, 4), (300, 3072, 1024, 4), (70, 512, 256, 2), (512, 1024, 2048, 4)])   # > 64 rows: k-split of the 128x128 kernel
@@ -664,11 +672,14 @@ def test_linear_splitk_and_slab_norm(T, K, N, S):
 
 
 @pytest.mark.parametrize("T,K,N,S", [(32, 2048, 1024, 4), (32, 3072, 1024, 4), (1, 2048, 1024, 4), (64, 1024, 2048, 2), (33, 2048, 1024, 4),
-                                     (17, 512, 256, 2), (5, 256, 1008, 2), (32, 2048, 1024, 1), (9, 256, 256, 1), (32, 3072, 1024, 2)])
-def test_linear_resid_last_arriver(T, K, N, S):
+                                     (17, 512, 256, 2), (5, 256, 1008, 2), (32, 2048, 1024, 1), (9, 256, 256, 1), (32, 3072, 1024, 2),
+                                     (32, 2048, 1024, 0), (32, 3072, 1024, 0), (9, 256, 256, 0)])
+@pytest.mark.parametrize("tiled", [False, True])
+def test_linear_resid_last_arriver(T, K, N, S, tiled):
     """nvr_linear_resid (split-k GEMM whose last-arriving workgroup per tile sums the slabs and adds the residual) against the
     two-launch form nvr_linear_splitk -> nvr_add_rmsnorm_slabs: the residual stream is carried through launch after launch
     and must stay BIT-identical (same slab order, same rounding points); the ticket counters end every launch at zero.
+    S = 0: the 8-row-tile form without k split (no slabs, no tickets).  tiled: reading the nvr_retile_weight copy.
     Then 200 back-to-back launches on one stream while a second stream keeps the chip busy with a 300 MB weight stream
     (uneven load, the slabs and counters re-used: stale-line / re-arm hazards)."""
     rng = np.random.default_rng(24)
@@ -677,6 +688,7 @@ def test_linear_resid_last_arriver(T, K, N, S):
     h, hb = h16(rng.standard_normal((T, N)))
     w, wb = h16(np.ones(N))
     d_x, d_W, d_w = dev(xb), dev(Wb), dev(wb)
+    wt = _retiled(d_W, N, K) if tiled else None
     d_slabs_a, d_slabs_b = nvr.DeviceBuffer(max(S, 2) * T * N * 4), nvr.DeviceBuffer(max(S, 2) * T * N * 4)
     _KEEP.extend([d_slabs_a, d_slabs_b])
     d_ha, d_hb = dev(hb), dev(hb.copy())
@@ -693,10 +705,10 @@ def test_linear_resid_last_arriver(T, K, N, S):
             nvr.check(nvr.lib().nvr_add_rmsnorm(d_ha.ptr, d_slabs_a.ptr, d_w.ptr, 1e-6, T, N, d_oa.ptr, None))
     # k-slices of <= 768 columns run on four waves like nvr_linear_splitk (same k interleave, same f32 summation order):
     # bit-identical; longer slices use 8 / 16 waves and agree to fp16 rounding of the different summation order
-    exact = K // S <= 768
+    exact = S > 0 and K // S <= 768
     for rep in range(5 if exact else 1):
         two_launch()
-        nvr.check(nvr.lib().nvr_linear_resid(d_x.ptr, K, d_W.ptr, T, K, N, S, d_slabs_b.ptr, d_cnt.ptr, d_hb.ptr, None))
+        nvr.check(nvr.lib().nvr_linear_resid(d_x.ptr, K, d_W.ptr, wt, T, K, N, S, d_slabs_b.ptr, d_cnt.ptr, d_hb.ptr, None))
         if exact:
             assert np.array_equal(d_ha.to_numpy((T, N), np.uint16), d_hb.to_numpy((T, N), np.uint16)), rep
         else:
@@ -704,7 +716,7 @@ def test_linear_resid_last_arriver(T, K, N, S):
         assert not d_cnt.to_numpy((ntiles,), np.uint32).any(), rep                  # re-armed
     # oracle: h1 = fp16(h + fp16(x W^T)) after ONE launch from the initial h
     d_h1 = dev(hb.copy())
-    nvr.check(nvr.lib().nvr_linear_resid(d_x.ptr, K, d_W.ptr, T, K, N, S, d_slabs_b.ptr, d_cnt.ptr, d_h1.ptr, None))
+    nvr.check(nvr.lib().nvr_linear_resid(d_x.ptr, K, d_W.ptr, wt, T, K, N, S, d_slabs_b.ptr, d_cnt.ptr, d_h1.ptr, None))
     ref = oracle.add(h, oracle.round_f16(oracle.linear(x, W)), round16=True)
     assert_close_f16(d_h1.to_numpy((T, N), F16), ref, ulps=2, atol=2e-3, what="h + x W^T")
     # busy neighbour on a second stream + 200 launches back to back
@@ -715,7 +727,7 @@ def test_linear_resid_last_arriver(T, K, N, S):
     for rep in range(200):
         if rep % 8 == 0:
             nvr.check(nvr.lib().nvr_linear(big_x.ptr, 1024, big_W.ptr, 32, 1024, 151936, big_y.ptr, 1, s2))
-        nvr.check(nvr.lib().nvr_linear_resid(d_x.ptr, K, d_W.ptr, T, K, N, S, d_slabs_b.ptr, d_cnt.ptr, d_hb.ptr, None))
+        nvr.check(nvr.lib().nvr_linear_resid(d_x.ptr, K, d_W.ptr, wt, T, K, N, S, d_slabs_b.ptr, d_cnt.ptr, d_hb.ptr, None))
     nvr.check(nvr.lib().nvr_stream_synchronize(s2)); nvr.synchronize()
     for rep in range(200):
         two_launch()
@@ -724,14 +736,15 @@ def test_linear_resid_last_arriver(T, K, N, S):
         assert np.array_equal(d_ha.to_numpy((T, N), np.uint16), d_hb.to_numpy((T, N), np.uint16))
     assert not d_cnt.to_numpy((ntiles,), np.uint32).any()
     nvr.check(nvr.lib().nvr_stream_destroy(s2))
-    assert nvr.lib().nvr_linear_resid(d_x.ptr, K, d_W.ptr, 65, K, N, S, d_slabs_b.ptr, d_cnt.ptr, d_hb.ptr, None) == -10
+    assert nvr.lib().nvr_linear_resid(d_x.ptr, K, d_W.ptr, wt, 65, K, N, S, d_slabs_b.ptr, d_cnt.ptr, d_hb.ptr, None) == -10
     if S > 1:
         assert nvr.lib().nvr_decode_splitk_slices(32, 2048, 1024) == 4 and nvr.lib().nvr_decode_splitk_slices(32, 3072, 1024) == 4
 
 
 @pytest.mark.parametrize("T,K,I", [(32, 1024, 3072), (16, 1024, 3072), (1, 1024, 3072), (33, 1024, 512), (7, 256, 512), (32, 512, 256),
                                    (64, 2048, 1024), (20, 2048, 768)])
-def test_linear_silu_mul_normed(T, K, I):
+@pytest.mark.parametrize("tiled", [False, True])
+def test_linear_silu_mul_normed(T, K, I, tiled):
     """RMSNorm in the prologue of the gate_up GEMM (+ SiluAndMul epilogue) against the oracle's rmsnorm -> linear -> silu_and_mul
     with fp16 rounding between the ops, and against the product's own two-launch form (nvr_rmsnorm -> nvr_linear_silu_mul):
     the normalised rows may differ by 1 fp16 ulp (h * (1/rms) instead of h / rms), which moves an output by a few ulps."""
@@ -740,9 +753,10 @@ def test_linear_silu_mul_normed(T, K, I):
     w, wb = h16(1 + 0.2 * rng.standard_normal(K))
     W, Wb = h16(rng.standard_normal((2 * I, K)) * 0.05)
     d_h, d_w, d_W = dev(hb), dev(wb), dev(Wb)
+    wt = _retiled(d_W, 2 * I, K) if tiled else None
     d_out, d_n, d_ref = nvr.DeviceBuffer(T * I * 2), nvr.DeviceBuffer(T * K * 2), nvr.DeviceBuffer(T * I * 2)
     _KEEP.extend([d_out, d_n, d_ref])
-    nvr.check(nvr.lib().nvr_linear_silu_mul_normed(d_h.ptr, K, d_w.ptr, 1e-6, d_W.ptr, T, K, I, d_out.ptr, None))
+    nvr.check(nvr.lib().nvr_linear_silu_mul_normed(d_h.ptr, K, d_w.ptr, 1e-6, d_W.ptr, wt, T, K, I, d_out.ptr, None))
     n = oracle.round_f16(oracle.rmsnorm(h, w, 1e-6))
     ref = oracle.round_f16(oracle.silu_and_mul(oracle.round_f16(oracle.linear(n, W))))
     got = d_out.to_numpy((T, I), F16)
@@ -751,12 +765,13 @@ def test_linear_silu_mul_normed(T, K, I):
     nvr.check(nvr.lib().nvr_linear_silu_mul(d_n.ptr, K, d_W.ptr, T, K, I, d_ref.ptr, None))
     assert_close_f16(got, d_ref.to_numpy((T, I), F16), ulps=4, atol=2e-3, what="fused vs two launches")
     assert np.array_equal(d_h.to_numpy((T, K), np.uint16), hb.view(np.uint16))          # the residual stream is only read
-    assert nvr.lib().nvr_linear_silu_mul_normed(d_h.ptr, K, d_w.ptr, 1e-6, d_W.ptr, 65, K, I, d_out.ptr, None) == -10
+    assert nvr.lib().nvr_linear_silu_mul_normed(d_h.ptr, K, d_w.ptr, 1e-6, d_W.ptr, wt, 65, K, I, d_out.ptr, None) == -10
 
 
 @pytest.mark.parametrize("T,Hd,H,KVH,D", [(32, 1024, 16, 8, 128), (16, 1024, 16, 8, 128), (3, 1024, 16, 8, 128), (40, 256, 4, 2, 64),
                                           (32, 2048, 8, 2, 128), (9, 512, 2, 2, 64)])
-def test_linear_qkv_rope_store_normed(T, Hd, H, KVH, D):
+@pytest.mark.parametrize("tiled", [False, True])
+def test_linear_qkv_rope_store_normed(T, Hd, H, KVH, D, tiled):
     """RMSNorm in the prologue of the qkv GEMM with the RoPE + KV-store epilogue, against the oracle chain rmsnorm -> linear ->
     rope -> kv_store (fp16 between the ops) and the two-launch product form."""
     rng = np.random.default_rng(32)
@@ -771,13 +786,14 @@ def test_linear_qkv_rope_store_normed(T, Hd, H, KVH, D):
         slots[1] = -1                                  # a token that is not cached
     cos, sin = oracle.rope_table(D, 512, 1e6)
     d_h, d_w, d_W, d_pos, d_slots, d_cos, d_sin = dev(hb), dev(wb), dev(Wb), dev(pos), dev(slots), dev(cos), dev(sin)
+    wt = _retiled(d_W, N, Hd, 1, H, KVH, D) if tiled else None
     bufs = [nvr.DeviceBuffer(T * N * 2), nvr.DeviceBuffer(nslots * KVH * D * 2), nvr.DeviceBuffer(nslots * KVH * D * 2),
             nvr.DeviceBuffer(T * N * 2), nvr.DeviceBuffer(nslots * KVH * D * 2), nvr.DeviceBuffer(nslots * KVH * D * 2), nvr.DeviceBuffer(T * Hd * 2)]
     _KEEP.extend(bufs)
     d_qkv, d_kc, d_vc, d_qkv2, d_kc2, d_vc2, d_n = bufs
     for b in (d_kc, d_vc, d_kc2, d_vc2):
         b.zero()
-    nvr.check(nvr.lib().nvr_linear_qkv_rope_store_normed(d_h.ptr, Hd, d_w.ptr, 1e-6, d_W.ptr, T, Hd, H, KVH, D, d_pos.ptr, d_slots.ptr,
+    nvr.check(nvr.lib().nvr_linear_qkv_rope_store_normed(d_h.ptr, Hd, d_w.ptr, 1e-6, d_W.ptr, wt, T, Hd, H, KVH, D, d_pos.ptr, d_slots.ptr,
                                                          d_cos.ptr, d_sin.ptr, d_qkv.ptr, d_kc.ptr, d_vc.ptr, None))
     nvr.check(nvr.lib().nvr_rmsnorm(d_h.ptr, d_w.ptr, 1e-6, T, Hd, d_n.ptr, None))
     nvr.check(nvr.lib().nvr_linear_qkv_rope_store(d_n.ptr, Hd, d_W.ptr, T, Hd, H, KVH, D, d_pos.ptr, d_slots.ptr, d_cos.ptr, d_sin.ptr,
@@ -955,3 +971,41 @@ def test_tiled_entry_points_match_row_major(T):
             nvr.check(l.nvr_argmax_partials(pv.ptr, pi.ptr, nparts.value, T, tok.ptr, None, 0, None))
             res.append((y.to_numpy((T, N), np.uint32), tok.to_numpy((T,), np.int64)))
         assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+
+
+@pytest.mark.parametrize("T,H,KVH,D", [(5, 4, 2, 64), (33, 16, 8, 128), (1, 2, 2, 128), (300, 4, 4, 64)])
+def test_qk_norm_rope_store(T, H, KVH, D):
+    """nvr_qk_norm_rope_store_kv (A-27): RMSNorm over head_dim on the q and k heads, then RoPE and the cache store, against
+    the oracle ops in that order (fp16 between them); v rows and slots as in nvr_rope_store_kv."""
+    rng = np.random.default_rng(41)
+    N = (H + 2 * KVH) * D
+    x, xb = h16(rng.standard_normal((T, N)) * 1.5)
+    qw, qwb = h16(1 + 0.3 * rng.standard_normal(D)); kw, kwb = h16(1 + 0.3 * rng.standard_normal(D))
+    pos = rng.integers(0, 400, T).astype(np.int64)
+    nslots = 2 * T + 4
+    slots = rng.permutation(nslots)[:T].astype(np.int32)
+    if T > 2:
+        slots[2] = -1
+    cos, sin = oracle.rope_table(D, 512, 1e6)
+    d_x, d_kc, d_vc = dev(xb.copy()), nvr.DeviceBuffer(nslots * KVH * D * 2), nvr.DeviceBuffer(nslots * KVH * D * 2)
+    _KEEP.extend([d_kc, d_vc]); d_kc.zero(); d_vc.zero()
+    nvr.check(nvr.lib().nvr_qk_norm_rope_store_kv(d_x.ptr, dev(pos).ptr, dev(slots).ptr, T, H, KVH, D, dev(cos).ptr, dev(sin).ptr,
+                                                  dev(qwb).ptr, dev(kwb).ptr, 1e-6, d_kc.ptr, d_vc.ptr, None))
+    got = d_x.to_numpy((T, N), F16)
+    q = oracle.round_f16(oracle.rmsnorm(x[:, :H * D].reshape(T * H, D), qw, 1e-6)).reshape(T, H, D)
+    k = oracle.round_f16(oracle.rmsnorm(x[:, H * D:(H + KVH) * D].reshape(T * KVH, D), kw, 1e-6)).reshape(T, KVH, D)
+    q = oracle.round_f16(oracle.rope_apply(q, pos, cos, sin)).reshape(T, H * D)
+    k = oracle.round_f16(oracle.rope_apply(k, pos, cos, sin)).reshape(T, KVH * D)
+    ref = np.concatenate([q, k, x[:, (H + KVH) * D:]], 1)
+    assert_close_f16(got, ref, ulps=3, atol=2e-3, what="norm + rope")
+    assert np.array_equal(got.view(np.uint16)[:, (H + KVH) * D:], xb[:, (H + KVH) * D:].view(np.uint16))      # v untouched
+    kc, vc = d_kc.to_numpy((nslots, KVH * D), np.uint16), d_vc.to_numpy((nslots, KVH * D), np.uint16)
+    gb = got.view(np.uint16)
+    seen = np.zeros(nslots, bool)
+    for t in range(T):
+        if slots[t] >= 0:
+            assert np.array_equal(kc[slots[t]], gb[t, H * D:(H + KVH) * D]) and np.array_equal(vc[slots[t]], gb[t, (H + KVH) * D:])
+            seen[slots[t]] = True
+    assert not kc[~seen].any() and not vc[~seen].any()
+    assert nvr.lib().nvr_qk_norm_rope_store_kv(d_x.ptr, dev(pos).ptr, dev(slots).ptr, T, H, KVH, D, dev(cos).ptr, dev(sin).ptr,
+                                               None, dev(kwb).ptr, 1e-6, d_kc.ptr, d_vc.ptr, None) == -7

@@ -340,3 +340,24 @@ def test_top_p_one_is_no_filter():
                 assert oracle.sample(x, temp, 0, 1.0, key) == oracle.sample(x, temp, 0, None, key)
                 trials += 1
     assert trials > 200 and dropped_mass < 1e-5, dropped_mass
+
+
+def test_qk_norm_extension_is_off_by_default_and_changes_the_graph():
+    """A-27: ModelConfig.qk_norm is False in every preset (the reference graph has no q/k norms); when on, the oracle applies
+    the reference's RMSNorm over head_dim to q and k before RoPE and accepts the real checkpoints' q_norm / k_norm tensors."""
+    from oracle import model_oracle as mo
+    assert not mo.qwen3_0_6b().qk_norm and not mo.qwen3_8b().qk_norm and not mo.tiny().qk_norm
+    rng = np.random.default_rng(3)
+    ids = np.asarray([5, 9, 200, 31], np.int64)
+    meta = dict(is_prefill=True, cu_seqlens_q=np.asarray([0, 4], np.int32), slot_mapping=np.arange(4, dtype=np.int32),
+                block_tables=None, context_lens=None)
+    out = {}
+    for on in (False, True):
+        m = mo.OracleModel(mo.tiny(qk_norm=on), num_blocks=2, block_size=16, fp16=True, max_pos=64)
+        sd = {f"model.layers.{l}.self_attn.{n}_norm.weight": (1 + 0.3 * rng.standard_normal(m.D)).astype(np.float32)
+              for l in range(2) for n in "qk"}
+        skipped = m.load_state_dict(sd)
+        assert (skipped == []) if on else (sorted(skipped) == sorted(sd))
+        h = m.embed_tokens(ids)
+        out[on] = m.attn_part(0, h, np.arange(4, dtype=np.int64), meta)
+    assert np.abs(out[True] - out[False]).max() > 1e-3

@@ -56,15 +56,21 @@ kc, vc = buf(64 * KVH * D * 2), buf(64 * KVH * D * 2)
 So, Sd = l.nvr_decode_splitk_slices(T, H * D, Hd), l.nvr_decode_splitk_slices(T, I, Hd)
 
 ops = {
-    "qkv_normed": lambda i: l.nvr_linear_qkv_rope_store_normed(h.ptr, Hd, g.ptr, 1e-6, Wqkv[i].ptr, T, Hd, H, KVH, D, pos.ptr, slots.ptr, cos.ptr, sin.ptr, qkv.ptr, kc.ptr, vc.ptr, st),
-    "resid_o": lambda i: l.nvr_linear_resid(attn.ptr, H * D, Wo[i].ptr, T, H * D, Hd, So, slabs.ptr, cnt.ptr, h.ptr, st),
-    "silu_normed": lambda i: l.nvr_linear_silu_mul_normed(h.ptr, Hd, g.ptr, 1e-6, Wgu[i].ptr, T, Hd, I, act.ptr, st),
-    "resid_down": lambda i: l.nvr_linear_resid(act.ptr, I, Wd[i].ptr, T, I, Hd, Sd, slabs.ptr, cnt.ptr, h.ptr, st),
+    "qkv_normed": lambda i: l.nvr_linear_qkv_rope_store_normed(h.ptr, Hd, g.ptr, 1e-6, Wqkv[i].ptr, None, T, Hd, H, KVH, D, pos.ptr, slots.ptr, cos.ptr, sin.ptr, qkv.ptr, kc.ptr, vc.ptr, st),
+    "resid_o": lambda i: l.nvr_linear_resid(attn.ptr, H * D, Wo[i].ptr, None, T, H * D, Hd, So, slabs.ptr, cnt.ptr, h.ptr, st),
+    "silu_normed": lambda i: l.nvr_linear_silu_mul_normed(h.ptr, Hd, g.ptr, 1e-6, Wgu[i].ptr, None, T, Hd, I, act.ptr, st),
+    "resid_down": lambda i: l.nvr_linear_resid(act.ptr, I, Wd[i].ptr, None, T, I, Hd, Sd, slabs.ptr, cnt.ptr, h.ptr, st),
     "qkv": lambda i: l.nvr_linear_qkv_rope_store(n.ptr, Hd, Wqkv[i].ptr, T, Hd, H, KVH, D, pos.ptr, slots.ptr, cos.ptr, sin.ptr, qkv.ptr, kc.ptr, vc.ptr, st),
     "splitk_o": lambda i: l.nvr_linear_splitk(attn.ptr, H * D, Wo[i].ptr, T, H * D, Hd, So, slabs.ptr, st),
     "slabnorm": lambda i: l.nvr_add_rmsnorm_slabs(h.ptr, slabs.ptr, 4, g.ptr, 1e-6, T, Hd, n.ptr, st),
     "silu": lambda i: l.nvr_linear_silu_mul(n.ptr, Hd, Wgu[i].ptr, T, Hd, I, act.ptr, st),
     "splitk_down": lambda i: l.nvr_linear_splitk(act.ptr, I, Wd[i].ptr, T, I, Hd, Sd, slabs.ptr, st),
+    "qkv_normed_t": lambda i: l.nvr_linear_qkv_rope_store_normed(h.ptr, Hd, g.ptr, 1e-6, Wqkv[i].ptr, Tqkv[i].ptr, T, Hd, H, KVH, D, pos.ptr, slots.ptr, cos.ptr, sin.ptr, qkv.ptr, kc.ptr, vc.ptr, st),
+    "resid_o_t": lambda i: l.nvr_linear_resid(attn.ptr, H * D, Wo[i].ptr, To[i].ptr, T, H * D, Hd, So, slabs.ptr, cnt.ptr, h.ptr, st),
+    "silu_normed_t": lambda i: l.nvr_linear_silu_mul_normed(h.ptr, Hd, g.ptr, 1e-6, Wgu[i].ptr, Tgu[i].ptr, T, Hd, I, act.ptr, st),
+    "resid_down_t": lambda i: l.nvr_linear_resid(act.ptr, I, Wd[i].ptr, Td[i].ptr, T, I, Hd, Sd, slabs.ptr, cnt.ptr, h.ptr, st),
+    "resid_o_ht": lambda i: l.nvr_linear_resid(attn.ptr, H * D, Wo[i].ptr, To[i].ptr, T, H * D, Hd, 0, None, None, h.ptr, st),
+    "resid_down_ht": lambda i: l.nvr_linear_resid(act.ptr, I, Wd[i].ptr, Td[i].ptr, T, I, Hd, 0, None, None, h.ptr, st),
     "qkv_t": lambda i: l.nvr_linear_qkv_rope_store_tiled(n.ptr, Hd, Wqkv[i].ptr, Tqkv[i].ptr, T, Hd, H, KVH, D, pos.ptr, slots.ptr, cos.ptr, sin.ptr, qkv.ptr, kc.ptr, vc.ptr, st),
     "splitk_o_t": lambda i: l.nvr_linear_splitk_tiled(attn.ptr, H * D, Wo[i].ptr, To[i].ptr, T, H * D, Hd, So, slabs.ptr, st),
     "silu_t": lambda i: l.nvr_linear_silu_mul_tiled(n.ptr, Hd, Wgu[i].ptr, Tgu[i].ptr, T, Hd, I, act.ptr, st),
@@ -73,6 +79,8 @@ ops = {
 }
 chains = {
     "c6t (c6 reading the tiled weight copies: the product's default)": ["qkv_t", "splitk_o_t", "slabnorm", "silu_t", "splitk_down_t", "slabnorm"],
+    "c4t (four launches, tiled, split-k + last arriver)": ["qkv_normed_t", "resid_o_t", "silu_normed_t", "resid_down_t"],
+    "c4ht (four launches, tiled, 8-row tiles without k split)": ["qkv_normed_t", "resid_o_ht", "silu_normed_t", "resid_down_ht"],
     "c4 (qkv_normed, resid_o, silu_normed, resid_down)": ["qkv_normed", "resid_o", "silu_normed", "resid_down"],
     "c6 (qkv, splitk_o, slabnorm, silu, splitk_down, slabnorm)": ["qkv", "splitk_o", "slabnorm", "silu", "splitk_down", "slabnorm"],
 }
