@@ -500,7 +500,8 @@ int nvr_model_runner::execute(nvr_seq *const *seqs, size_t nseq, bool is_prefill
         if (chunked && !flash_ok)
             for (size_t b = 0; b < nseq; ++b)
                 if (seqs[b]->chunk_start > 0) return nvr::fail(NVR_ERR_UNSUPPORTED, "chunked prefill needs the paged flash kernel (head_dim 64/128)");
-        prefill_paged = false;
+        static const bool always_paged = [] { const char *e = getenv("NVR_PREFILL_PAGED"); return e && e[0] == '1'; }();
+        prefill_paged = always_paged && flash_ok;
         int64_t total = 0;
         for (size_t b = 0; b < nseq; ++b) {
             int64_t lo, hi; range_of(*seqs[b], &lo, &hi);
