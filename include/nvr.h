@@ -103,6 +103,10 @@ typedef struct nvr_config {
                                           no sequence able to stop, no block boundary.  Same batches, tokens and statistics as 0 (a
                                           request added in between cancels the step launched ahead); the logits accessors then refer to
                                           the newest launched step.  Default 0. */
+    int32_t shared_prefix_min_seqs;    /* decode batches of at least this many sequences that ALL begin with the same cache blocks
+                                          (prefix-cache hits, block_manager.rs:181-197; BASELINE configs[4]) attend to those blocks in one
+                                          MFMA pass for the whole batch (nvr_paged_attn_decode_shared) instead of once per sequence; same
+                                          results within the attention tolerance.  0 = default (32), < 0 = never */
     char device[16];                   /* config.rs:48, validated like :108-111 plus "hip": "hip" (default) | "cuda" (the reference's
                                           default, taken as "the GPU") | "cpu" | "metal"; a runner exists only for "hip" / "cuda" —
                                           there is no CPU path in this library (NVR_ERR_UNSUPPORTED) */
@@ -267,6 +271,8 @@ NVR_API int nvr_runner_p2p_export(nvr_model_runner_t *r, uint8_t handle[64]);
 NVR_API int nvr_runner_p2p_attach(nvr_model_runner_t *r, const uint8_t *handles /* [tp][64] */, const int32_t *devices /* [tp] or NULL */);
 NVR_API int nvr_runner_p2p_disable(nvr_model_runner_t *r);
 NVR_API int nvr_runner_p2p_active(const nvr_model_runner_t *r);
+/* tokens of the last decode step that went through the shared-prefix attention pass (nvr_config.shared_prefix_min_seqs); 0 = plain */
+NVR_API int64_t nvr_runner_last_shared_prefix_len(const nvr_model_runner_t *r);
 
 /* -------------------------------------------------------------------- Engine ---- */
 /* LLMEngine::step loop, src/engine/llm_engine.rs:155-197 (driver of the hot path only) */
@@ -487,6 +493,13 @@ NVR_API size_t nvr_paged_attn_workspace_bytes(int64_t B, int64_t H, int64_t D, i
 NVR_API int nvr_paged_attn_decode(const nvr_half *q, int64_t ldq, const nvr_half *k_cache, const nvr_half *v_cache,
                                   const nvr_attn_meta *meta, int64_t H, int64_t KVH, int64_t D, int64_t block_size,
                                   float scale, nvr_half *out, void *workspace, void *stream);
+/* The same when EVERY sequence of the batch holds its first shared_len tokens (a multiple of block_size) in the cache blocks that
+ * block-table row 0 starts with (prefix-cache hits of BlockManager::allocate, block_manager.rs:181-197; BASELINE configs[4]): the
+ * shared keys go through one MFMA pass for the whole batch, the remainder per sequence, merged as split-KV partials.  Same
+ * semantics as nvr_paged_attn_decode (A-8); workspace sized by nvr_paged_attn_workspace_bytes. */
+NVR_API int nvr_paged_attn_decode_shared(const nvr_half *q, int64_t ldq, const nvr_half *k_cache, const nvr_half *v_cache,
+                                         const nvr_attn_meta *meta, int64_t H, int64_t KVH, int64_t D, int64_t block_size,
+                                         float scale, int64_t shared_len, nvr_half *out, void *workspace, void *stream);
 /* K7 varlen causal prefill attention, attention.rs:177-208 (q,k,v inside packed qkv, stride ld) */
 NVR_API int nvr_attn_prefill_varlen(const nvr_half *q, const nvr_half *k, const nvr_half *v, int64_t ld,
                                     const nvr_attn_meta *meta, int64_t T, int64_t H, int64_t KVH, int64_t D,

@@ -54,7 +54,8 @@ class ConfigC(C.Structure):
                 ("kvcache_block_size", C.c_uint64), ("num_kvcache_blocks", C.c_int64),
                 ("tensor_parallel_rank", C.c_uint64), ("device_ordinal", C.c_int32), ("sample_seed", C.c_uint64),
                 ("skip_block_size_check", C.c_int32), ("decode_chain", C.c_uint32),
-                ("recompute_cached_prefix", C.c_int32), ("enable_chunked_prefill", C.c_int32), ("async_decode", C.c_int32), ("device", C.c_char * 16), ("dtype", C.c_char * 16)]
+                ("recompute_cached_prefix", C.c_int32), ("enable_chunked_prefill", C.c_int32), ("async_decode", C.c_int32), ("shared_prefix_min_seqs", C.c_int32),
+                ("device", C.c_char * 16), ("dtype", C.c_char * 16)]
 
 
 class ModelConfigC(C.Structure):
@@ -180,6 +181,7 @@ _SIGS = {
     "nvr_runner_init_comm_local": (C.c_int, [_P, _P]), "nvr_local_group_set_p2p": (C.c_int, [_P, C.c_int]),
     "nvr_runner_p2p_export": (C.c_int, [_P, _P]), "nvr_runner_p2p_attach": (C.c_int, [_P, _P, _P]),
     "nvr_runner_p2p_disable": (C.c_int, [_P]), "nvr_runner_p2p_active": (C.c_int, [_P]),
+    "nvr_runner_last_shared_prefix_len": (C.c_int64, [_P]),
     "nvr_engine_last_step": (None, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(C.c_size_t)]),
     "nvr_engine_take_finished": (C.c_size_t, [_P, C.POINTER(_P), C.c_size_t]),
     "nvr_engine_last_batch": (C.c_size_t, [_P, C.POINTER(_P), C.c_size_t]),
@@ -225,6 +227,8 @@ _SIGS = {
     "nvr_paged_attn_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int64, C.c_int64]),
     "nvr_paged_attn_decode": (C.c_int, [_P, C.c_int64, _P, _P, C.POINTER(AttnMetaC), C.c_int64, C.c_int64, C.c_int64,
                                         C.c_int64, C.c_float, _P, _P, _P]),
+    "nvr_paged_attn_decode_shared": (C.c_int, [_P, C.c_int64, _P, _P, C.POINTER(AttnMetaC), C.c_int64, C.c_int64, C.c_int64,
+                                               C.c_int64, C.c_float, C.c_int64, _P, _P, _P]),
     "nvr_attn_prefill_varlen": (C.c_int, [_P, _P, _P, C.c_int64, C.POINTER(AttnMetaC), C.c_int64, C.c_int64, C.c_int64,
                                           C.c_int64, C.c_float, _P, _P]),
     "nvr_attn_prefill_paged": (C.c_int, [_P, C.c_int64, _P, _P, C.POINTER(AttnMetaC), C.c_int64, C.c_int64, C.c_int64, C.c_int64,
@@ -667,6 +671,10 @@ class ModelRunner:
 
     def p2p_active(self) -> bool:
         return bool(lib().nvr_runner_p2p_active(self.h))
+
+    def last_shared_prefix_len(self) -> int:
+        """Tokens of the last decode step that went through the shared-prefix attention pass (0: plain paged attention)."""
+        return int(lib().nvr_runner_last_shared_prefix_len(self.h))
 
 
 class LocalGroup:

@@ -16,6 +16,7 @@
 //    row groups and merge through LDS.  With one partition the workgroup writes the fp16 result
 //    itself; otherwise f32 partials go to a workspace and a second tiny kernel merges them.
 //  * all G = H/KVH query heads of a kv head are processed together so K/V are read once.
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <type_traits>
@@ -33,6 +34,8 @@ struct AttnParams {
     int32_t H, KVH;
     float scale;
     int32_t part_size, num_parts;
+    int32_t part0, kv0;                // shared-prefix decode: partitions 0..part0-1 hold the batch's shared keys [0, kv0) (written by
+                                       // flash_shared_prefix); this launch covers partition part0 + i = keys [kv0 + i*part_size, ..)
     float *part_o; float *part_ml;     // [nq, H, num_parts, D], [nq, H, num_parts, 2]
     half_t *out;                       // [nq, H, D]
     unsigned long long *stamps;        // NVR_ATTN_EXPERIMENTS: 5 wall_clock64 stamps per workgroup (or null)
@@ -72,11 +75,12 @@ __global__ __launch_bounds__(WAVES * 64) void attn_rows_kernel(AttnParams p) {
     constexpr int LPR = D / 8;          // lanes per K/V row
     constexpr int RPI = 64 / LPR;       // rows per wave-instruction (= tokens per row group)
     constexpr int TPI = RPI * U;        // tokens per chunk
-    const int part = blockIdx.x % p.num_parts, g = (blockIdx.x / p.num_parts) % p.KVH;
-    const int t = blockIdx.x / (p.num_parts * p.KVH);
+    const int lparts = p.num_parts - p.part0;        // partitions of this launch
+    const int part = p.part0 + blockIdx.x % lparts, g = (blockIdx.x / lparts) % p.KVH;
+    const int t = blockIdx.x / (lparts * p.KVH);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int dc = lane % LPR, tg = lane / LPR;
-    const int p0 = part * p.part_size;
+    const int p0 = p.kv0 + (part - p.part0) * p.part_size;
 
     const int32_t *bt = PAGED ? p.block_tables + (int64_t)(p.seq_of_q ? p.seq_of_q[t] : t) * p.max_blocks : nullptr;
     int bt_chunk = -1, bt_reg = 0;                   // UB: register copy of 64 block-table entries
@@ -284,22 +288,48 @@ __global__ __launch_bounds__(WAVES * 64) void attn_rows_kernel(AttnParams p) {
 }
 
 // merge split-KV partitions: out = sum_p e^(m_p-M) o_p / sum_p e^(m_p-M) l_p
+// 32 (D = 128) or 16 (D = 64) threads per (query, head), 4 columns each; the partials of up to 8 partitions are requested together
+// (a runtime-count loop of dependent loads would pay one round trip per partition).  Sums run over the partitions in ascending
+// order for every column, as before.
 template <int D>
-__global__ void attn_merge_kernel(const float *__restrict__ part_o, const float *__restrict__ part_ml,
-                                  const int32_t *__restrict__ ctx_lens, int H, int part_size, int num_parts,
-                                  half_t *__restrict__ out) {
-    const int h = blockIdx.x % H, t = blockIdx.x / H, d = threadIdx.x;
-    const int np = min(num_parts, (ctx_lens[t] + part_size - 1) / part_size);
-    const int64_t base = ((int64_t)t * H + h) * num_parts;
+__global__ __launch_bounds__(256) void attn_merge_kernel(const float *__restrict__ part_o, const float *__restrict__ part_ml,
+                                                         const int32_t *__restrict__ ctx_lens, int H, int part_size, int num_parts,
+                                                         int part0, int kv0, int64_t pairs, half_t *__restrict__ out) {
+    constexpr int TPP = D / 4;                                   // threads per (query, head) pair
+    const int64_t pair = (int64_t)blockIdx.x * (256 / TPP) + threadIdx.x / TPP;
+    if (pair >= pairs) return;
+    const int t = (int)(pair / H), d = (threadIdx.x % TPP) * 4;
+    const int np = min(num_parts, part0 + (max(ctx_lens[t] - kv0, 0) + part_size - 1) / part_size);
+    const int64_t base = pair * num_parts;
     float M = -INFINITY;
-    for (int i = 0; i < np; ++i) M = fmaxf(M, part_ml[(base + i) * 2]);
-    float o = 0.f, L = 0.f;
-    for (int i = 0; i < np; ++i) {
-        const float w = __expf(part_ml[(base + i) * 2] - M);
-        o += w * part_o[(base + i) * D + d];
-        L += w * part_ml[(base + i) * 2 + 1];
+    float4_t o = {0.f, 0.f, 0.f, 0.f};
+    float L = 0.f;
+    for (int i0 = 0; i0 < np; i0 += 8) {
+        float2_t ml[8]; float4_t po[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = min(i0 + u, np - 1);
+            ml[u] = *reinterpret_cast<const float2_t *>(part_ml + (base + i) * 2);
+            po[u] = *reinterpret_cast<const float4_t *>(part_o + (base + i) * D + d);
+        }
+        float Mn = M;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (i0 + u < np) Mn = fmaxf(Mn, ml[u][0]);
+        if (i0 > 0 && Mn != M) { const float r = __expf(M - Mn); o *= r; L *= r; }     // (more than 8 partitions: rescale what is summed)
+        M = Mn;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (i0 + u < np) {
+                const float w = __expf(ml[u][0] - M);
+                o += w * po[u];
+                L += w * ml[u][1];
+            }
+        }
     }
-    out[((int64_t)t * H + h) * D + d] = (half_t)(L > 0.f ? o / L : 0.f);
+    half4_t hv;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) hv[e] = (half_t)(L > 0.f ? o[e] / L : 0.f);
+    *reinterpret_cast<half4_t *>(out + pair * D + d) = hv;
 }
 
 // ---- launch configuration ------------------------------------------------------------------------
@@ -370,8 +400,27 @@ static int launch_attn(const AttnArgs &a, bool paged, hipStream_t s) {
     // 64-token-granular partitions + merge kernel (B=32, ctx 1044: KVH=1 10.9 us vs 14.6 us for the 4-wave path, KVH=2
     // 12.7 vs 14.6, KVH=4 17.5 vs 19.7; scratch/attn_tp_shape.py)
     int waves = tn.waves ? tn.waves : ((paged && a.workspace && pairs * ((mc + 63) / 64) >= 256) ? 8 : 4);
-    int part_size = 0x3fffffff, np = 1;
-    if (a.workspace) {
+    int part_size = 0x3fffffff, np = 1, sparts = 0, shared_part = 0;
+    const bool shared = a.shared_len > 0;
+    if (shared) {
+        // partitions of shared_len tokens: number 0 (the same K/V for every query) goes through the MFMA kernel, 1.. through
+        // the row kernel below; always merged (np >= 2 keeps the partial format even when nobody has own tokens yet)
+        if (!paged || !a.workspace || a.seq_of_q || a.shared_len % a.block_size || a.shared_len % 64)
+            return nvr::fail(NVR_ERR_INVALID_ARG, "attention: shared_len needs paged decode with a workspace (shared_len %d, block_size %d)", a.shared_len, a.block_size);
+        // the shared keys [0, shared_len) are cut into sparts equal partitions (64-key granularity) until the MFMA launch has ~256
+        // workgroups; the keys behind them are partitioned like a context of their own (one partition per pair when there are
+        // enough pairs, else ~256 workgroups)
+        const int qb = flash_tile_positions(a.H, a.KVH);
+        const int64_t wgs = (int64_t)((a.nq + qb - 1) / qb) * a.KVH, n64 = a.shared_len / 64;
+        int64_t c = std::min<int64_t>(std::max<int64_t>(1, (256 + wgs - 1) / wgs), n64);
+        while (n64 % c) --c;
+        sparts = (int)c; shared_part = a.shared_len / sparts;
+        const int64_t rest = std::max<int64_t>(mc - a.shared_len, 64);
+        const int64_t want = pairs >= 192 ? 1 : (256 + pairs - 1) / pairs;
+        part_size = (int)(((rest + want - 1) / want + 63) / 64 * 64);
+        np = sparts + (int)((rest + part_size - 1) / part_size);
+        waves = tn.waves ? tn.waves : 4;
+    } else if (a.workspace) {
         if (tn.parts > 0) { part_size = (int)(((mc + tn.parts - 1) / tn.parts + 63) / 64 * 64); np = (int)((mc + part_size - 1) / part_size); }
         else if (waves >= 8) {
             int64_t want = pairs >= 192 ? 1 : (256 + pairs - 1) / pairs;
@@ -389,7 +438,11 @@ static int launch_attn(const AttnArgs &a, bool paged, hipStream_t s) {
         p.part_o = (float *)a.workspace;
         p.part_ml = p.part_o + (int64_t)a.nq * a.H * np * D;
     }
-    const int64_t nwg = (int64_t)p.num_parts * a.KVH * a.nq;
+    p.part0 = sparts; p.kv0 = shared ? a.shared_len : 0;
+    const int64_t nwg = (int64_t)(p.num_parts - p.part0) * a.KVH * a.nq;
+    if (shared)
+        if (int rc = flash_shared_prefix(a.q, a.ldq, a.k, a.v, a.block_tables, a.max_blocks, a.block_size, a.nq, a.H, a.KVH, a.D, a.scale,
+                                         shared_part, sparts, np, p.part_o, p.part_ml, s)) return rc;
     bool done = false;
 #ifdef NVR_ATTN_EXPERIMENTS
     if (direct && a.workspace && std::getenv("NVR_ATTN_STAMPS")) p.stamps = (unsigned long long *)a.workspace;
@@ -410,8 +463,8 @@ static int launch_attn(const AttnArgs &a, bool paged, hipStream_t s) {
         else launch_cfg<D, G, DU, 4, false>(p, paged, direct, nwg, s);                     // prefill: rows re-read from L2
     }
     if (!direct)
-        attn_merge_kernel<D><<<dim3((unsigned)((int64_t)a.H * a.nq)), dim3(D), 0, s>>>(p.part_o, p.part_ml, a.ctx_lens, a.H,
-                                                                                  part_size, np, p.out);
+        attn_merge_kernel<D><<<dim3((unsigned)(((int64_t)a.H * a.nq + 256 / (D / 4) - 1) / (256 / (D / 4)))), dim3(256), 0, s>>>(
+            p.part_o, p.part_ml, a.ctx_lens, a.H, part_size, np, p.part0, p.kv0, (int64_t)a.H * a.nq, p.out);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return nvr::fail(NVR_ERR_HIP, "attention launch failed: %s", hipGetErrorString(e));
     return 0;

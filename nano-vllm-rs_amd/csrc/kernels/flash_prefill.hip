@@ -36,6 +36,11 @@ struct FlashParams {
     int32_t H, KVH;
     float scale;
     half_t *out;
+    // SHARED (decode over a prefix every sequence of the batch shares): queries = one row per sequence, keys = the first
+    // shared tokens through block-table row 0, shared_len of them per blockIdx.y; results are split-KV partials (slot (row, head,
+    // partition blockIdx.y))
+    int32_t nq_total, shared_len, num_parts;
+    float *part_o, *part_ml;
 };
 
 typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
@@ -55,7 +60,13 @@ constexpr int FLASH_WAVES = NVR_FLASH_WAVES;     // waves per workgroup: 32 quer
 // block-table entry is a scalar read (v_readlane) from a register copy of the table (lane j holds entry 64·c + j) — no
 // dependent table load in front of the LDS-DMA requests (r02, 32 x 1024 through the block tables: 348 us per layer with a lookup per
 // piece, 260 us with this; the contiguous form: 250 us).
-template <int D, int G, bool PAGED, bool UB = false>
+// SHARED: the decode step's attention over a prefix that EVERY sequence of the batch holds in the same cache blocks (BASELINE
+// configs[4]: 512 sequences behind one 512-token system prompt).  The row kernel re-reads those K/V rows once per sequence (from
+// L2, but latency-paced: 113 us per layer at 512 x ~600); here the batch's query rows form the M dimension of the same MFMA
+// schedule — 128/G sequences per workgroup, no causal mask, every key of [0, shared_len) visible to every row — and the result
+// leaves as the split-KV partial of partition 0 (unnormalised f32 o, scaled max, sum), merged with the per-sequence remainder
+// by attn_merge_kernel.
+template <int D, int G, bool PAGED, bool UB = false, bool SHARED = false>
 __global__ __launch_bounds__(64 * FLASH_WAVES, 8 / FLASH_WAVES) void flash_prefill_kernel(FlashParams p) {   // 2 waves per SIMD: <= 256 registers per lane
     constexpr int NT = 64 * FLASH_WAVES;         // threads
     constexpr int KT = NVR_FLASH_KT;             // keys per step
@@ -67,10 +78,18 @@ __global__ __launch_bounds__(64 * FLASH_WAVES, 8 / FLASH_WAVES) void flash_prefi
     __shared__ __attribute__((aligned(16))) char smem[NBUF * STAGE];
 
     const int g = blockIdx.x % p.KVH;
-    const FlashTile tile = p.tiles[blockIdx.x / p.KVH];
+    FlashTile tile;
+    if (SHARED) {
+        constexpr int QB = 32 * FLASH_WAVES / G;                      // sequences per workgroup
+        tile.q_row0 = (int)(blockIdx.x / p.KVH) * QB;
+        tile.nq = min(QB, p.nq_total - tile.q_row0);
+        tile.pos0 = 0x3fffffff; tile.kv_ref = 0;
+    } else tile = p.tiles[blockIdx.x / p.KVH];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int r = lane & 15, g4 = lane >> 4;
-    const int kv_end = tile.pos0 + tile.nq;
+    // SHARED: blockIdx.y cuts the shared keys into partitions of shared_len tokens (more workgroups than 8 per kv head at 512 sequences)
+    const int kv_start = SHARED ? (int)blockIdx.y * p.shared_len : 0;
+    const int kv_end = SHARED ? kv_start + p.shared_len : tile.pos0 + tile.nq;
 
     // the wave's two query tiles: head and position block
     int qi[NQT], head[NQT], qpos[NQT]; bool qvalid[NQT];
@@ -84,14 +103,15 @@ __global__ __launch_bounds__(64 * FLASH_WAVES, 8 / FLASH_WAVES) void flash_prefi
         qi[t] = pblk * 16 + r;
         qvalid[t] = qi[t] < tile.nq;
         const int qc = qvalid[t] ? qi[t] : tile.nq - 1;
-        qpos[t] = tile.pos0 + qc;                                 // absolute position = last visible key
+        qpos[t] = SHARED ? 0x3fffffff : tile.pos0 + qc;           // absolute position = last visible key
         const half_t *qrow = p.q + (int64_t)(tile.q_row0 + qc) * p.ldq + (int64_t)head[t] * D + g4 * 8;
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) qf[t][ks] = *reinterpret_cast<const half8_t *>(qrow + ks * 32);
     }
 
     // last key any lane of this wave may attend to: a step that starts beyond it does no arithmetic in this wave
-    const int wave_last = __builtin_amdgcn_readfirstlane(tile.pos0 + min(tile.nq - 1, (G == 1 ? wave * 2 + 1 : (G == 2 ? wave : (wave >> 1))) * 16 + 15));
+    const int wave_last = SHARED ? kv_end - 1
+        : __builtin_amdgcn_readfirstlane(tile.pos0 + min(tile.nq - 1, (G == 1 ? wave * 2 + 1 : (G == 2 ? wave : (wave >> 1))) * 16 + 15));
     int bt_reg = 0, bt_chunk = -1;                                    // UB: register copy of 64 block-table entries
     auto load_bt_chunk = [&](int c) {
         bt_chunk = c;
@@ -147,13 +167,13 @@ __global__ __launch_bounds__(64 * FLASH_WAVES, 8 / FLASH_WAVES) void flash_prefi
 #pragma unroll
     for (int e = 0; e < 8; ++e) ones[e] = (half_t)1.0f;
 
-    const int nsteps = (kv_end + KT - 1) / KT;
+    const int nsteps = (kv_end - kv_start + KT - 1) / KT;
     // step `it` computes on ring slot it % NBUF while tile it+NBUF-1 is requested into the slot step it-1 just released;
     // before its closing barrier every wave waits until only the loads of tiles it+2.. are outstanding, so tile it+1 has
     // landed for all waves after the barrier and the global loads never drain inside the stream.
     auto step = [&](auto cur_c, int it) {
         constexpr int cur = decltype(cur_c)::value;
-        const int kt = it * KT;
+        const int kt = kv_start + it * KT;
         const bool more = it + NBUF - 1 < nsteps;
 #ifndef NVR_FLASH_ABLATE_STAGE
         if (more) stage((cur + NBUF - 1) % NBUF, kt + (NBUF - 1) * KT);
@@ -186,7 +206,7 @@ __global__ __launch_bounds__(64 * FLASH_WAVES, 8 / FLASH_WAVES) void flash_prefi
             __builtin_amdgcn_sched_barrier(0);
         }
         // causal mask only on steps that reach past the tile's first query (keys kt + mt*16 + g4*4 + e)
-        if (kt + KT - 1 > tile.pos0) {
+        if (!SHARED && kt + KT - 1 > tile.pos0) {
 #pragma unroll
             for (int t = 0; t < NQT; ++t)
 #pragma unroll
@@ -256,7 +276,7 @@ __global__ __launch_bounds__(64 * FLASH_WAVES, 8 / FLASH_WAVES) void flash_prefi
 
 #pragma unroll
     for (int b = 0; b < NBUF - 1; ++b)
-        if (b < nsteps) stage(b, b * KT);
+        if (b < nsteps) stage(b, kv_start + b * KT);
     if (NBUF - 1 < nsteps) {
         if (NBUF == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else if (NBUF == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 * 2 * PIECES) : "memory");
@@ -272,6 +292,18 @@ __global__ __launch_bounds__(64 * FLASH_WAVES, 8 / FLASH_WAVES) void flash_prefi
         if (NBUF > 3 && it + 3 < nsteps) step(std::integral_constant<int, 3 % NBUF>{}, it + 3);
     }
 
+    if (SHARED) {                                               // partial of partition 0: (o, m * scale, l) as attn_rows_kernel writes them
+#pragma unroll
+        for (int t = 0; t < NQT; ++t) {
+            if (!qvalid[t]) continue;
+            const int64_t slot = ((int64_t)(tile.q_row0 + qi[t]) * p.H + head[t]) * p.num_parts + blockIdx.y;
+            float *po = p.part_o + slot * D + g4 * 4;
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) *reinterpret_cast<float4_t *>(po + dt * 16) = o[t][dt];
+            if (g4 == 0) { p.part_ml[slot * 2] = m[t] * p.scale; p.part_ml[slot * 2 + 1] = ol[t][0]; }
+        }
+        return;
+    }
 #pragma unroll
     for (int t = 0; t < NQT; ++t) {
         if (qvalid[t]) {
@@ -315,6 +347,32 @@ int flash_prefill(const FlashArgs &a, bool paged, hipStream_t s) {
 #undef NVR_FLASH
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return nvr::fail(NVR_ERR_HIP, "flash_prefill launch failed: %s", hipGetErrorString(e));
+    return 0;
+}
+
+// Partitions 0..sparts-1 (part_len tokens each, a multiple of the 64-key step) of a decode step whose sequences all share their
+// first sparts*part_len cached tokens (block-table row 0 names the blocks): part_o [nq, H, num_parts, D] / part_ml [nq, H,
+// num_parts, 2] slots (row, head, partition).
+int flash_shared_prefix(const half_bits *q, int64_t ldq, const half_bits *k_cache, const half_bits *v_cache, const int32_t *block_tables,
+                        int32_t max_blocks, int32_t block_size, int32_t nq, int32_t H, int32_t KVH, int32_t D, float scale,
+                        int32_t part_len, int32_t sparts, int32_t num_parts, float *part_o, float *part_ml, hipStream_t s) {
+    if (nq == 0) return 0;
+    const bool pow2 = block_size > 0 && (block_size & (block_size - 1)) == 0;
+    const int32_t shared_len = part_len;
+    if (!flash_prefill_ok(D, H, KVH) || !pow2 || block_size % NVR_FLASH_KT || part_len <= 0 || part_len % NVR_FLASH_KT || sparts < 1 || sparts > num_parts)
+        return nvr::fail(NVR_ERR_UNSUPPORTED, "flash_shared_prefix: D=%d H=%d KVH=%d block_size=%d part_len=%d x %d", D, H, KVH, block_size, part_len, sparts);
+    FlashParams p{};
+    p.q = (const half_t *)q; p.ldq = ldq; p.k = (const half_t *)k_cache; p.v = (const half_t *)v_cache;
+    p.block_tables = block_tables; p.max_blocks = max_blocks; p.block_size = block_size; p.bs_shift = __builtin_ctz(block_size);
+    p.H = H; p.KVH = KVH; p.scale = scale; p.nq_total = nq; p.shared_len = shared_len; p.num_parts = num_parts;
+    p.part_o = part_o; p.part_ml = part_ml;
+    const int G = H / KVH, qb = flash_tile_positions(H, KVH);
+    dim3 grid((unsigned)((int64_t)((nq + qb - 1) / qb) * KVH), (unsigned)sparts), block(64 * FLASH_WAVES);
+#define NVR_FLASH_S(DD, GG) if (D == DD && G == GG) flash_prefill_kernel<DD, GG, true, true, true><<<grid, block, 0, s>>>(p);
+    NVR_FLASH_S(128, 1) NVR_FLASH_S(128, 2) NVR_FLASH_S(128, 4) NVR_FLASH_S(64, 1) NVR_FLASH_S(64, 2) NVR_FLASH_S(64, 4)
+#undef NVR_FLASH_S
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return nvr::fail(NVR_ERR_HIP, "flash_shared_prefix launch failed: %s", hipGetErrorString(e));
     return 0;
 }
 

@@ -386,6 +386,32 @@ bool nvr_model_runner::use_chain4(int64_t T, bool is_prefill) const {
            H * D <= 4096 && I <= 8192 && Hd * std::max(H * D, I) * 2 < (24ll << 20);
 }
 
+// Decode batches whose sequences ALL start with the same cache blocks (prefix-cache hits of BlockManager::allocate,
+// block_manager.rs:181-197: one system prompt in front of every request, BASELINE configs[4]): the length of that common run of
+// full blocks.  The attention launch then sends those keys through one MFMA pass for the whole batch (kernels/flash_prefill.hip,
+// SHARED) instead of once per sequence.  Batches under nvr_config.shared_prefix_min_seqs sequences (default 32) and block sizes
+// the kernel does not take keep the plain kernel.
+int64_t nvr_model_runner::shared_prefix_len(nvr_seq *const *seqs, size_t nseq) const {
+    const int64_t min_seqs = cfg.shared_prefix_min_seqs == 0 ? 32 : cfg.shared_prefix_min_seqs;
+    if (min_seqs < 0 || (int64_t)nseq < min_seqs || nseq < 2) return 0;
+    if (block_size < 64 || (block_size & (block_size - 1)) || !k::flash_prefill_ok((int)D, (int)H, (int)KVH)) return 0;
+    const auto &t0 = seqs[0]->block_table;
+    size_t common = std::min<size_t>(t0.size(), (size_t)(((int64_t)seqs[0]->len() - 1) / block_size));   // full blocks below the last token
+    for (size_t b = 1; b < nseq && common > 0; ++b) {
+        const auto &t = seqs[b]->block_table;
+        common = std::min<size_t>(common, std::min<size_t>(t.size(), (size_t)(((int64_t)seqs[b]->len() - 1) / block_size)));
+        size_t j = 0;
+        while (j < common && t[j] == t0[j]) ++j;
+        common = j;
+    }
+    return (int64_t)common * block_size;
+}
+
+// a captured decode step is a function of (batch size, context bucket, shared-prefix length, logits wanted)
+static inline uint64_t graph_key(bool want_logits, size_t nseq, int64_t bucket, int64_t shared_len) {
+    return ((uint64_t)want_logits << 63) | ((uint64_t)nseq << 44) | ((uint64_t)(shared_len / 64) << 24) | (uint64_t)(bucket / 256);
+}
+
 // Qwen3Model::forward, src/models/qwen3.rs:487-505; layer wiring :372-392; attention :208-240; MLP :305-314.
 int nvr_model_runner::forward(int64_t T, int64_t B, bool is_prefill, int64_t max_ctx) {
     hipStream_t st = stream;
@@ -431,6 +457,7 @@ int nvr_model_runner::forward(int64_t T, int64_t B, bool is_prefill, int64_t max
         } else {                                                     // flash_attention_decode, attention.rs:225-235
             a.k = k_cache(l); a.v = v_cache(l); a.block_tables = bt; a.max_blocks = (int32_t)max_blocks_per_seq;
             a.block_size = (int32_t)block_size; a.workspace = attn_ws; a.workspace_bytes = attn_ws_bytes;
+            a.shared_len = (int32_t)decode_shared_len;
             RC(k::attention(a, true, st));
         }
         if (c4) {
@@ -574,6 +601,7 @@ int nvr_model_runner::execute(nvr_seq *const *seqs, size_t nseq, bool is_prefill
             max_ctx = std::max(max_ctx, len);
         }
         T = (int64_t)nseq;
+        decode_shared_len = shared_prefix_len(seqs, nseq);
     }
     // one H2D per array actually used this step (K19)
     auto up = [&](size_t off, size_t bytes) { return hipMemcpyAsync(in_dev + off, in_host + off, bytes, hipMemcpyHostToDevice, stream); };
@@ -598,7 +626,7 @@ int nvr_model_runner::execute(nvr_seq *const *seqs, size_t nseq, bool is_prefill
 
     // decode: replay a hipGraph captured per (batch size, context bucket) — execute_with_cuda_graph :303-326
     const int64_t bucket = (max_ctx + 255) / 256 * 256;
-    const uint64_t key = ((uint64_t)want_logits << 60) | ((uint64_t)nseq << 32) | (uint64_t)bucket;
+    const uint64_t key = graph_key(want_logits, nseq, bucket, decode_shared_len);
     auto it = graphs.find(key);
     if (it == graphs.end()) {
         if (graphs.size() >= kMaxGraphs) {               // a long-lived engine sees many (batch size, bucket) pairs: bound the cache
@@ -654,6 +682,7 @@ int nvr_model_runner::execute_decode_ahead(nvr_seq *const *seqs, size_t nseq, in
         max_ctx = std::max(max_ctx, len);
     }
     NVR_HIP_CHECK(hipMemcpyAsync(in_dev + off_dec + dof_pos, hd + dof_pos, dof_bt + nseq * max_blocks_per_seq * 4 - dof_pos, hipMemcpyHostToDevice, stream));
+    decode_shared_len = shared_prefix_len(seqs, nseq);
     last_rows = nseq; last_prefill = false; last_tokens = (int64_t)nseq;
     lm_parts = k::lm_head_parts((int64_t)nseq, Hd, Vl, Hd);
     if (lm_parts <= 0) return nvr::fail(NVR_ERR_UNSUPPORTED, "execute_decode_ahead: the fused LM head does not take this batch");
@@ -661,7 +690,7 @@ int nvr_model_runner::execute_decode_ahead(nvr_seq *const *seqs, size_t nseq, in
     const int64_t T = (int64_t)nseq;
     if (cfg.enforce_eager || graphs_disabled) return forward(T, T, false, max_ctx);
     const int64_t bucket = (max_ctx + 255) / 256 * 256;
-    const uint64_t key = ((uint64_t)want_logits << 60) | ((uint64_t)nseq << 32) | (uint64_t)bucket;
+    const uint64_t key = graph_key(want_logits, nseq, bucket, decode_shared_len);
     auto it = graphs.find(key);
     if (it == graphs.end()) {
         if (graphs.size() >= kMaxGraphs) return nvr::fail(NVR_ERR_UNSUPPORTED, "execute_decode_ahead: graph cache full");   // (flushing needs an idle stream)

@@ -63,6 +63,7 @@ struct nvr_model_runner {
     bool chain4 = false;                   // nvr_config.decode_chain == 4 (or NVR_DECODE_CHAIN=4): the four-launch chain of linear_decode.hip
     std::map<uint64_t, hipGraphExec_t> graphs;
     size_t last_rows = 0; bool last_prefill = false; int64_t last_tokens = 0;
+    int64_t decode_shared_len = 0;                       // the last decode step: tokens every sequence holds in the same leading blocks
     nvr::Comm comm;
     bool graphs_disabled = false;   // set when capture with RCCL nodes fails: fall back to eager launches
     int comm_selftest();
@@ -98,6 +99,7 @@ private:
     static constexpr size_t kMaxGraphs = 256;            // captured decode graphs kept before the cache is flushed
     int64_t *h_tok_dev = nullptr;                        // device-visible address of the pinned token buffer h_tok
     int64_t slab_rows = 64;           // rows the split-k slab buffers hold (row_parallel_norm)
+    int64_t shared_prefix_len(nvr_seq *const *seqs, size_t nseq) const;   // (0 = none / batch too small: plain paged attention)
     bool prefill_paged = false;                          // this prefill step skips cached prefixes (K/V via block tables)
     bool lazy_logits = true, want_logits = true, logits_valid = true; const uint16_t *lm_input = nullptr;
     bool lm_fused = true; int32_t lm_parts = 0;          // lm_head arg-max partials of the last step (0: none)

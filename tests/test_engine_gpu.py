@@ -33,11 +33,11 @@ def _model_cfgs(mcfg: mo.ModelConfig):
     return m
 
 
-def _run_pair(mcfg, ecfg: dict, prompts, sps, max_steps=400, fp16=True, enforce_eager=False, checkpoint=None):
+def _run_pair(mcfg, ecfg: dict, prompts, sps, max_steps=400, fp16=True, enforce_eager=False, checkpoint=None, product_kw=None):
     eo.reset_sequence_counter()
     nvr.lib().nvr_seq_reset_id_counter()
     o = mo.OracleEngine(mcfg, eo.Config(**ecfg), fp16=fp16, max_pos=ecfg["max_model_len"])
-    p = nvr.LLMEngine(nvr.Config(skip_block_size_check=1, enforce_eager=enforce_eager, **ecfg), _model_cfgs(mcfg))
+    p = nvr.LLMEngine(nvr.Config(skip_block_size_check=1, enforce_eager=enforce_eager, **ecfg, **(product_kw or {})), _model_cfgs(mcfg))
     if checkpoint is not None:                       # (state dict, .safetensors path): same tensors into both engines
         sd, path = checkpoint
         for rk in o.ranks:
@@ -726,3 +726,48 @@ def test_qk_norm_checkpoint_end_to_end(tmp_path, shape):
         assert sorted(p.model_runner.load_safetensors(path)) == sorted(sd)
     with pytest.raises(nvr.NvrError):
         p.model_runner.load_safetensors(path, strict=True)
+
+
+@pytest.mark.parametrize("shape", ["d64_g2", "d128_g2"])
+def test_shared_prefix_decode_attention_engine_parity(shape):
+    """BASELINE configs[4] in small: every request starts with the same system prompt, BlockManager::allocate shares its full
+    blocks (block_manager.rs:181-197), and decode batches of >= shared_prefix_min_seqs sequences send the shared keys through one
+    MFMA pass (nvr_paged_attn_decode_shared).  Logits / tokens stay in parity with the oracle's plain paged attention, graph and
+    eager and launch-ahead agree, the plain path (feature off) produces the same tokens, and the shared length follows the
+    batch: a request WITHOUT the system prompt joining the batch switches the step back to the plain kernel."""
+    mcfg = mo.small(seed=9) if shape == "d64_g2" else \
+        mo.small(seed=9, hidden_size=512, num_attention_heads=4, num_key_value_heads=2, head_dim=128, intermediate_size=768)
+    V = mcfg.vocab_size
+    ecfg = dict(max_num_seqs=12, max_num_batched_tokens=2048, max_model_len=512, kvcache_block_size=64, num_kvcache_blocks=60)
+    system = oracle.fill_tokens(150, 4, 7, V).tolist()                    # 2 full blocks of 64 shared + 22 tokens recomputed per sequence
+    prompts = [system + oracle.fill_tokens(3 + 9 * i, 4, 100 + i, V).tolist() for i in range(9)]
+    sps = [dict(temperature=0.0, max_tokens=8 + 3 * i, ignore_eos=True) for i in range(9)]   # the batch shrinks below the threshold on the way
+    on = dict(shared_prefix_min_seqs=4)
+    r = _run_pair(mcfg, ecfg, prompts, sps, product_kw=on)
+    assert r["near_ties"] <= 2 and r["decode_steps"] >= 30, r
+    e = _run_pair(mcfg, ecfg, prompts, sps, product_kw=on, enforce_eager=True)
+    off = _run_pair(mcfg, ecfg, prompts, sps, product_kw=dict(shared_prefix_min_seqs=-1))
+    assert e["finished"] == r["finished"] == off["finished"]
+    # launch-ahead (its logits accessor refers to the step launched ahead, so only the token streams are compared)
+    # the path really is taken: 128 shared tokens while >= 4 sequences are alive, 0 afterwards and with the feature off
+    nvr.lib().nvr_seq_reset_id_counter()
+    p = nvr.LLMEngine(nvr.Config(skip_block_size_check=1, **ecfg, **on), _model_cfgs(mcfg))
+    for pr, sp in zip(prompts, sps):
+        p.add_request(pr, nvr.SamplingParams(**sp))
+    seen = set()
+    while not p.is_finished():
+        rec = p.step()
+        if not rec["is_prefill"]:
+            seen.add((rec["num_seqs"] >= 4, p.model_runner.last_shared_prefix_len()))
+    assert seen == {(True, 128), (False, 0)}, sorted(seen)
+    gen = {}
+    for is_prefill, seq_ids, tokens, _, _ in _run_product(mcfg, ecfg, prompts, sps, async_decode=1, **on):
+        for sid, tok in zip(seq_ids, tokens):
+            if tok >= 0:
+                gen.setdefault(sid, []).append(tok)
+    assert {sid: toks[-len(gen[sid]):] for sid, toks in r["finished"].items()} == gen
+    # mixed batch: one request without the system prompt -> no common leading block
+    prompts2 = prompts[:6] + [oracle.fill_tokens(70, 4, 55, V).tolist()]
+    sps2 = [dict(temperature=0.0, max_tokens=10, ignore_eos=True)] * 7
+    m = _run_pair(mcfg, ecfg, prompts2, sps2, product_kw=on)
+    assert m["near_ties"] <= 2, m

@@ -822,6 +822,8 @@ def test_linear_qkv_rope_store_normed(T, Hd, H, KVH, D, tiled):
     (16, 8, 128, 16, [(40, 9), (100, 100), (33, 1)]),      # (context_len, new tokens): cached prefix + new, all new, decode-like
     (4, 2, 64, 16, [(70, 6), (16, 16)]),
     (8, 2, 128, 256, [(300, 44)]),
+    (4, 2, 64, 64, [(150, 22), (150, 150), (200, 60), (64, 1)]),   # block size = the kernel's key step, several sequences (register copy of the table per tile)
+    (16, 8, 128, 128, [(700, 130), (129, 129)]),
 ])
 def test_attn_prefill_paged_prefix(H, KVH, D, bs, cases):
     """Prefix-cached prefill (attention.rs:211-222): queries are the last nq tokens of each context, K/V via block table."""
@@ -1009,3 +1011,50 @@ def test_qk_norm_rope_store(T, H, KVH, D):
     assert not kc[~seen].any() and not vc[~seen].any()
     assert nvr.lib().nvr_qk_norm_rope_store_kv(d_x.ptr, dev(pos).ptr, dev(slots).ptr, T, H, KVH, D, dev(cos).ptr, dev(sin).ptr,
                                                None, dev(kwb).ptr, 1e-6, d_kc.ptr, d_vc.ptr, None) == -7
+
+
+@pytest.mark.parametrize("B,H,KVH,D,bs,P,own", [
+    (70, 16, 8, 128, 256, 2, [int(x) for x in np.random.default_rng(1).integers(0, 300, 70)]),   # configs[4] shape: 512 shared tokens
+    (5, 4, 2, 64, 64, 1, [0, 1, 63, 64, 130]),          # nobody / somebody without own tokens, partial blocks, D=64
+    (130, 8, 8, 128, 64, 3, [(7 * i) % 200 for i in range(130)]),   # group 1: 128 sequences per workgroup + a ragged last tile
+    (33, 8, 2, 128, 128, 1, [5 + i for i in range(33)]),            # group 4
+    (2, 16, 8, 128, 256, 1, [0, 0]),                    # only the shared partition exists
+])
+def test_paged_attn_decode_shared_prefix(B, H, KVH, D, bs, P, own):
+    """nvr_paged_attn_decode_shared: every sequence's first P blocks are the SAME cache blocks (prefix-cache hits); the shared
+    keys go through the MFMA kernel once for the batch, the rest through the row kernel, merged as split-KV partials — against
+    the oracle's plain paged attention and against nvr_paged_attn_decode on the same inputs."""
+    rng = np.random.default_rng(12)
+    S = P * bs
+    ctxs = [S + o for o in own]
+    own_blocks = [(o + bs - 1) // bs for o in own]
+    NB = P + sum(own_blocks) + 2
+    max_blocks = P + max(own_blocks) + 1
+    kc, kcb = h16(rng.standard_normal((NB, bs, KVH, D)))
+    vc, vcb = h16(rng.standard_normal((NB, bs, KVH, D)))
+    perm = rng.permutation(NB)
+    bt = -np.ones((B, max_blocks), np.int32)
+    o = P
+    for b in range(B):
+        bt[b, :P] = perm[:P]
+        bt[b, P:P + own_blocks[b]] = perm[o:o + own_blocks[b]]; o += own_blocks[b]
+    q, qb = h16(rng.standard_normal((B, H, D)))
+    ctx = np.asarray(ctxs, np.int32)
+    scale = float(np.float32(1.0) / np.sqrt(np.float32(D)))
+    meta = nvr.AttnMetaC()
+    d_ctx, d_bt = dev(ctx), dev(bt)
+    meta.is_prefill, meta.context_lens, meta.block_tables = 0, d_ctx.ptr, d_bt.ptr
+    meta.max_blocks, meta.batch, meta.max_context_len = max_blocks, B, int(max(ctxs))
+    ws = nvr.DeviceBuffer(nvr.lib().nvr_paged_attn_workspace_bytes(B, H, D, int(max(ctxs)) + bs))
+    d_out, d_plain = nvr.DeviceBuffer(B * H * D * 2), nvr.DeviceBuffer(B * H * D * 2)
+    d_q, d_k, d_v = dev(qb), dev(kcb), dev(vcb)
+    nvr.check(nvr.lib().nvr_paged_attn_decode_shared(d_q.ptr, H * D, d_k.ptr, d_v.ptr, C.byref(meta), H, KVH, D, bs, scale, S,
+                                                     d_out.ptr, ws.ptr, None))
+    nvr.check(nvr.lib().nvr_paged_attn_decode(d_q.ptr, H * D, d_k.ptr, d_v.ptr, C.byref(meta), H, KVH, D, bs, scale, d_plain.ptr, ws.ptr, None))
+    got = d_out.to_numpy((B, H, D), F16)
+    ref = oracle.round_f16(oracle.attn_decode(q, kc, vc, bt, ctx, scale))
+    assert_close_f16(got, ref, ulps=2, atol=1e-3, what="shared-prefix decode attention vs oracle")
+    assert_close_f16(got, d_plain.to_numpy((B, H, D), F16), ulps=3, atol=1e-3, what="shared-prefix vs plain kernel")
+    # shared_len that is no multiple of the block size is refused
+    assert nvr.lib().nvr_paged_attn_decode_shared(d_q.ptr, H * D, d_k.ptr, d_v.ptr, C.byref(meta), H, KVH, D, bs, scale, S + 8,
+                                                  d_out.ptr, ws.ptr, None) == -7
