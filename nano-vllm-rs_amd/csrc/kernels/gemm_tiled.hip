@@ -57,16 +57,21 @@ __device__ __forceinline__ int tile_w_row(int bx, int t, int r, int N, const Til
 // workgroup per CU) with three K-tiles in flight and counted s_waitcnt vmcnt: when there are fewer tiles than CUs (decode
 // batches of 129..~1000 rows, short prefills) a workgroup is alone on its CU and every K-step of the NS = 2 form costs one
 // full memory latency (21 us for a K = 1024 tile); the ring hides it.
-template <int EPI, int NS>
+// MT: 16-token m-tiles per wave.  4 = the 128-token tile; 2 = a 64-token tile for batches of 129..~1000 rows, where 128 x 128 tiles
+// leave half the CUs without a workgroup (T = 512: 128 / 96 / 128 workgroups for qkv / gate_up / the split-k GEMMs; 23 / 16 / 12 us):
+// twice the workgroups, each with the same 128 W rows and half the tokens.
+template <int EPI, int NS, int MT = 4>
 __global__ __launch_bounds__(256) void gemm_tiled_kernel(const half_t *__restrict__ x, int64_t ldx,
                                                          const half_t *__restrict__ W, int T, int K, int N, int NW,
                                                          half_t *__restrict__ y, TileEpi epi) {
-    // one LDS array (cdna guide §5 item 4a): [NS buffers][A 16 KiB | B 16 KiB]
+    // one LDS array (cdna guide §5 item 4a): [NS buffers][A 16 KiB | B 16 or 8 KiB]
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int BMt = 32 * MT;                                          // tokens per workgroup
+    constexpr int BUF = (BN + BMt) * BK * 2;                              // bytes of one LDS buffer
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int r = lane & 15, q = lane >> 4;
     const int wn = wave >> 1, wm = wave & 1;
-    const int m0 = blockIdx.y * BM;
+    const int m0 = blockIdx.y * BMt;
 
     // staging: thread t copies 16-byte piece idx = i*256 + t (row = idx/8, LDS chunk c' = idx%8) of each operand tile
     const half_t *asrc[4], *bsrc[4];
@@ -77,24 +82,24 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(const half_t *__restric
         if (wr > NW - 1) wr = NW - 1;
         int xr = m0 + row; if (xr > T - 1) xr = T - 1;
         asrc[i] = W + (int64_t)wr * K + c * 8;
-        bsrc[i] = x + (int64_t)xr * ldx + c * 8;
+        bsrc[i] = x + (int64_t)xr * ldx + c * 8;                          // (rows >= BMt: unused)
         if (EPI == TEPI_SLAB) { asrc[i] += (int64_t)blockIdx.z * epi.kslice; bsrc[i] += (int64_t)blockIdx.z * epi.kslice; }
     }
     auto stage = [&](int buf, int k0) {
-        char *a_dst = smem + buf * (2 * BM * BK * 2), *b_dst = a_dst + BM * BK * 2;
+        char *a_dst = smem + buf * BUF, *b_dst = a_dst + BN * BK * 2;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int piece = (i * 256 + wave * 64) * 16;               // wave-uniform LDS base; hardware adds lane*16
             __builtin_amdgcn_global_load_lds(asrc[i] + k0, (__attribute__((address_space(3))) void *)(a_dst + piece), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(bsrc[i] + k0, (__attribute__((address_space(3))) void *)(b_dst + piece), 16, 0, 0);
+            if (i < MT) __builtin_amdgcn_global_load_lds(bsrc[i] + k0, (__attribute__((address_space(3))) void *)(b_dst + piece), 16, 0, 0);
         }
     };
 
-    float4_t acc[4][4];
+    float4_t acc[4][MT];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < MT; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
 
     const int KT = (EPI == TEPI_SLAB ? epi.kslice : K) / BK;
     if (NS == 2) {
@@ -109,29 +114,33 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(const half_t *__restric
         if (NS == 2) {
             if (kt + 1 < KT) stage(cur ^ 1, (kt + 1) * BK);
         } else {
-            // K-tile kt has landed once at most the 8 loads per thread of each younger K-tile in flight are outstanding
+            // K-tile kt has landed once at most the 4 + MT loads per thread of each younger K-tile in flight are outstanding
             const int younger = min(NS - 2, KT - 1 - kt);
-            if (younger >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-            else if (younger == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (4 + MT)) : "memory");
+            else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + MT) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                                 // every thread's pieces are in; buffer (kt-1) % NS is free
             cur = kt % NS;
             if (kt + NS - 1 < KT) stage((kt + NS - 1) % NS, (kt + NS - 1) * BK);
         }
-        const char *a_lds = smem + cur * (2 * BM * BK * 2), *b_lds = a_lds + BM * BK * 2;
+        const char *a_lds = smem + cur * BUF, *b_lds = a_lds + BN * BK * 2;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            half8_t a[4], b[4];
+            half8_t a[4], b[MT];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int arow = wn * 64 + i * 16 + r, brow = wm * 64 + i * 16 + r;
+                const int arow = wn * 64 + i * 16 + r;
                 a[i] = *reinterpret_cast<const half8_t *>(a_lds + (arow * 8 + ((ks * 4 + q) ^ (arow & 7))) * 16);
-                b[i] = *reinterpret_cast<const half8_t *>(b_lds + (brow * 8 + ((ks * 4 + q) ^ (brow & 7))) * 16);
+            }
+#pragma unroll
+            for (int j = 0; j < MT; ++j) {
+                const int brow = wm * (16 * MT) + j * 16 + r;
+                b[j] = *reinterpret_cast<const half8_t *>(b_lds + (brow * 8 + ((ks * 4 + q) ^ (brow & 7))) * 16);
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < MT; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j], acc[i][j], 0, 0, 0);
         }
         if (NS == 2) __syncthreads();
@@ -141,8 +150,8 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(const half_t *__restric
     if (EPI == TEPI_SLAB) {                                                // f32 partial sums, C layout: 4 consecutive columns of token r
         float *sl = epi.slabs + (int64_t)blockIdx.z * epi.slab_stride;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int m = m0 + wm * 64 + j * 16 + r;
+        for (int j = 0; j < MT; ++j) {
+            const int m = m0 + wm * (16 * MT) + j * 16 + r;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int n = blockIdx.x * BN + wn * 64 + i * 16 + q * 4;
@@ -154,11 +163,11 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(const half_t *__restric
     if (EPI == TEPI_LMHEAD) {
         // C layout: row (n) = q*4 + reg, col (token) = r.  f32 logits go out as they are (embed_head.rs:292-306, A-21); the
         // row maxima are taken over the f32 accumulators in increasing column order (ties keep the lowest index, A-12)
-        float *sv = reinterpret_cast<float *>(smem);                      // [2 (wn)][128 tokens]
-        int *si = reinterpret_cast<int *>(smem + 2 * BM * 4);
+        float *sv = reinterpret_cast<float *>(smem);                      // [2 (wn)][BMt tokens]
+        int *si = reinterpret_cast<int *>(smem + 2 * BMt * 4);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int ml = wm * 64 + j * 16 + r, m = m0 + ml;
+        for (int j = 0; j < MT; ++j) {
+            const int ml = wm * (16 * MT) + j * 16 + r, m = m0 + ml;
             float bv = -INFINITY; int bi = 0x7fffffff;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -175,12 +184,12 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(const half_t *__restric
                 const float v = __shfl_xor(bv, o, 64); const int i2 = __shfl_xor(bi, o, 64);
                 if (v > bv || (v == bv && i2 < bi)) { bv = v; bi = i2; }
             }
-            if (q == 0) { sv[wn * BM + ml] = bv; si[wn * BM + ml] = bi; }
+            if (q == 0) { sv[wn * BMt + ml] = bv; si[wn * BMt + ml] = bi; }
         }
         __syncthreads();
-        if (threadIdx.x < BM && m0 + threadIdx.x < T) {
+        if (threadIdx.x < BMt && m0 + threadIdx.x < T) {
             float bv = sv[threadIdx.x]; int bi = si[threadIdx.x];
-            const float v = sv[BM + threadIdx.x]; const int i2 = si[BM + threadIdx.x];
+            const float v = sv[BMt + threadIdx.x]; const int i2 = si[BMt + threadIdx.x];
             if (v > bv || (v == bv && i2 < bi)) { bv = v; bi = i2; }
             epi.pval[(int64_t)blockIdx.x * T + m0 + threadIdx.x] = bv;
             epi.pidx[(int64_t)blockIdx.x * T + m0 + threadIdx.x] = bi;
@@ -195,8 +204,8 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(const half_t *__restric
     char *ot = smem;
     auto stash = [&](int ml, int lc, half4_t hv) { *reinterpret_cast<half4_t *>(ot + ml * OST + lc * 2) = hv; };
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int ml = wm * 64 + j * 16 + r;
+    for (int j = 0; j < MT; ++j) {
+        const int ml = wm * (16 * MT) + j * 16 + r;
         const int m = m0 + ml;
         const int mc = m < T ? m : T - 1;
         if (EPI == TEPI_F16) {
@@ -252,7 +261,7 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(const half_t *__restric
     const int ncols = (EPI == TEPI_ROPE) ? (int)ldy : N;
     constexpr int CPR = OUTC / 8;                                         // pieces per row
 #pragma unroll
-    for (int i = 0; i < (BM * CPR) / 256; ++i) {
+    for (int i = 0; i < (BMt * CPR) / 256; ++i) {
         const int pidx = i * 256 + threadIdx.x, row = pidx / CPR, ch = pidx % CPR;
         const int m = m0 + row, col = blockIdx.x * OUTC + ch * 8;
         if (m >= T || col >= ncols) continue;
@@ -283,19 +292,36 @@ static bool tiled_ring(unsigned tiles) {
     static const int force = [] { const char *e = getenv("NVR_TILED_RING"); return e ? atoi(e) : -1; }();
     return force >= 0 ? force != 0 : tiles < 256;
 }
-constexpr size_t kStageBytes = 2 * BM * BK * 2;
-#define NVR_TILED_LAUNCH(EPI_, grid, ...)                                                                          \
+// 64-token tiles when 128-token tiles would leave CUs without a workgroup (NVR_TILED_BM64=0/1 forces)
+static bool tiled_bm64(int64_t T, int64_t nx_nz) {
+    static const int force = [] { const char *e = getenv("NVR_TILED_BM64"); return e ? atoi(e) : -1; }();
+    if (force >= 0) return force != 0;
+    return T > 64 && nx_nz * ((T + BM - 1) / BM) < 192;      // (192 workgroups of 128 tokens beat 384 of 64: 15.6 vs 19.3 us, gate_up at T = 512)
+}
+constexpr size_t kStageBytes = 2 * BM * BK * 2;                          // MT = 4
+constexpr size_t kStageBytes64 = (BN + 64) * BK * 2;                     // MT = 2
+// grid: x = column tiles, y is filled in here (token tiles of 128 or 64), z = k slices
+#define NVR_TILED_LAUNCH(EPI_, grid, T_, ...)                                                                      \
     do {                                                                                                           \
-        if (tiled_ring((grid).x * (grid).y * (grid).z)) gemm_tiled_kernel<EPI_, 4><<<grid, dim3(256), 4 * kStageBytes, s>>>(__VA_ARGS__); \
-        else gemm_tiled_kernel<EPI_, 2><<<grid, dim3(256), 2 * kStageBytes, s>>>(__VA_ARGS__);                   \
+        if (tiled_bm64((T_), (int64_t)(grid).x * (grid).z)) {                                                      \
+            (grid).y = (unsigned)(((T_) + 63) / 64);                                                               \
+            if (tiled_ring((grid).x * (grid).y * (grid).z / 2)) gemm_tiled_kernel<EPI_, 4, 2><<<grid, dim3(256), 4 * kStageBytes64, s>>>(__VA_ARGS__); \
+            else gemm_tiled_kernel<EPI_, 2, 2><<<grid, dim3(256), 2 * kStageBytes64, s>>>(__VA_ARGS__);           \
+        } else {                                                                                                   \
+            (grid).y = (unsigned)(((T_) + BM - 1) / BM);                                                           \
+            if (tiled_ring((grid).x * (grid).y * (grid).z)) gemm_tiled_kernel<EPI_, 4><<<grid, dim3(256), 4 * kStageBytes, s>>>(__VA_ARGS__); \
+            else gemm_tiled_kernel<EPI_, 2><<<grid, dim3(256), 2 * kStageBytes, s>>>(__VA_ARGS__);                 \
+        }                                                                                                          \
     } while (0)
-// 128 KiB of dynamic LDS needs an opt-in per kernel instance; called at runner creation (never inside a stream capture)
+// > 64 KiB of dynamic LDS needs an opt-in per kernel instance; called at runner creation (never inside a stream capture)
 int gemm_tiled_prepare() {
     static bool done = false;
     if (done) return 0;
 #define NVR_TILED_ATTR(EPI_)                                                                                          \
     { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_tiled_kernel<EPI_, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                          (int)(4 * kStageBytes));                                                    \
+      if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_tiled_kernel<EPI_, 4, 2>),   \
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * kStageBytes64)); \
       if (e != hipSuccess) return nvr::fail(NVR_ERR_HIP, "gemm_tiled: LDS opt-in failed: %s", hipGetErrorString(e)); }
     NVR_TILED_ATTR(TEPI_F16) NVR_TILED_ATTR(TEPI_SILU) NVR_TILED_ATTR(TEPI_ROPE) NVR_TILED_ATTR(TEPI_LMHEAD) NVR_TILED_ATTR(TEPI_SLAB)
 #undef NVR_TILED_ATTR
@@ -317,7 +343,7 @@ int gemm_tiled_lm_head(const half_bits *x, int64_t ldx, const half_bits *W, int6
     dim3 grid((unsigned)((N + BN - 1) / BN), (unsigned)((T + BM - 1) / BM));
     *nparts = (int32_t)grid.x;
     if (int rc = gemm_tiled_prepare()) return rc;
-    NVR_TILED_LAUNCH(TEPI_LMHEAD, grid, (const half_t *)x, ldx, (const half_t *)W, (int)T, (int)K, (int)N, (int)N, nullptr, e);
+    NVR_TILED_LAUNCH(TEPI_LMHEAD, grid, T, (const half_t *)x, ldx, (const half_t *)W, (int)T, (int)K, (int)N, (int)N, nullptr, e);
     return tiled_check("gemm_tiled_lm_head");
 }
 
@@ -331,7 +357,7 @@ int gemm_tiled_splitk(const half_bits *x, int64_t ldx, const half_bits *W, int64
     TileEpi e{};
     e.slabs = slabs; e.slab_stride = T * N; e.kslice = (int32_t)(K / S);
     dim3 grid((unsigned)((N + BN - 1) / BN), (unsigned)((T + BM - 1) / BM), (unsigned)S);
-    NVR_TILED_LAUNCH(TEPI_SLAB, grid, (const half_t *)x, ldx, (const half_t *)W, (int)T, (int)K, (int)N, (int)N, nullptr, e);
+    NVR_TILED_LAUNCH(TEPI_SLAB, grid, T, (const half_t *)x, ldx, (const half_t *)W, (int)T, (int)K, (int)N, (int)N, nullptr, e);
     return tiled_check("gemm_tiled_splitk");
 }
 
@@ -341,14 +367,14 @@ int gemm_tiled(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, i
     if (!gemm_tiled_ok(T, K, N, ldx)) return nvr::fail(NVR_ERR_UNSUPPORTED, "gemm_tiled: T=%ld K=%ld N=%ld", (long)T, (long)K, (long)N);
     dim3 grid((unsigned)((N + BN - 1) / BN), (unsigned)((T + BM - 1) / BM));
     if (int rc = gemm_tiled_prepare()) return rc;
-    NVR_TILED_LAUNCH(TEPI_F16, grid, (const half_t *)x, ldx, (const half_t *)W, (int)T, (int)K, (int)N, (int)N, (half_t *)y, TileEpi{});
+    NVR_TILED_LAUNCH(TEPI_F16, grid, T, (const half_t *)x, ldx, (const half_t *)W, (int)T, (int)K, (int)N, (int)N, (half_t *)y, TileEpi{});
     return tiled_check("gemm_tiled");
 }
 int gemm_tiled_silu_mul(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t I, half_bits *out, hipStream_t s) {
     if (!gemm_tiled_ok(T, K, I, ldx) || I % 64) return nvr::fail(NVR_ERR_UNSUPPORTED, "gemm_tiled_silu_mul: T=%ld K=%ld I=%ld", (long)T, (long)K, (long)I);
     dim3 grid((unsigned)(I / 64), (unsigned)((T + BM - 1) / BM));
     if (int rc = gemm_tiled_prepare()) return rc;
-    NVR_TILED_LAUNCH(TEPI_SILU, grid, (const half_t *)x, ldx, (const half_t *)W, (int)T, (int)K, (int)I, (int)(2 * I), (half_t *)out, TileEpi{});
+    NVR_TILED_LAUNCH(TEPI_SILU, grid, T, (const half_t *)x, ldx, (const half_t *)W, (int)T, (int)K, (int)I, (int)(2 * I), (half_t *)out, TileEpi{});
     return tiled_check("gemm_tiled_silu_mul");
 }
 int gemm_tiled_qkv_rope_store(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t H, int64_t KVH, int64_t D,
@@ -361,7 +387,7 @@ int gemm_tiled_qkv_rope_store(const half_bits *x, int64_t ldx, const half_bits *
     e.H = (int32_t)H; e.KVH = (int32_t)KVH; e.D = (int32_t)D;
     dim3 grid((unsigned)((N / 16 + 7) / 8), (unsigned)((T + BM - 1) / BM));
     if (int rc = gemm_tiled_prepare()) return rc;
-    NVR_TILED_LAUNCH(TEPI_ROPE, grid, (const half_t *)x, ldx, (const half_t *)W, (int)T, (int)K, (int)N, (int)N, (half_t *)qkv, e);
+    NVR_TILED_LAUNCH(TEPI_ROPE, grid, T, (const half_t *)x, ldx, (const half_t *)W, (int)T, (int)K, (int)N, (int)N, (half_t *)qkv, e);
     return tiled_check("gemm_tiled_qkv_rope_store");
 }
 
