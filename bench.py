@@ -173,6 +173,40 @@ def time_decode_chain(nvr, mc, reps: int = 20) -> dict:
     return dict(us_per_layer=us_layer, alg_bytes_per_layer=alg, layers=L, replays=reps)
 
 
+def shared_prefix_decode(nvr, mc, nseq: int = 512, steps: int = 24) -> dict:
+    """BASELINE.json configs[4] as a side measurement of the N = 1 line: nseq sequences = the same 512-token system prompt + 64 own
+    tokens each (BlockManager::allocate shares the two full prefix blocks, block_manager.rs:181-197), greedy decode through the engine
+    with hipGraph steps; decode batches whose block tables all start with the same blocks attend to them in one MFMA pass."""
+    eng = nvr.LLMEngine(nvr.Config(max_num_seqs=nseq, max_num_batched_tokens=65536, max_model_len=1024, kvcache_block_size=BLOCK,
+                                   num_kvcache_blocks=nseq * 2 + 16, async_decode=1), mc)
+    shared = nvr.synthetic_tokens(512, 2, 0, mc.c.vocab_size).tolist()
+    for i in range(nseq):
+        eng.add_request(shared + nvr.synthetic_tokens(64, 1, i, mc.c.vocab_size).tolist(),
+                        nvr.SamplingParams(temperature=0.0, max_tokens=steps + 12, ignore_eos=True))
+    nvr.synchronize(); t0 = time.perf_counter(); npre = 0
+    while True:
+        rec = eng.step()
+        if not rec["is_prefill"]:
+            break
+        npre += 1
+    nvr.synchronize(); t_pre = time.perf_counter() - t0
+    for _ in range(4):
+        eng.step()
+    nvr.synchronize(); t0 = time.perf_counter()
+    for _ in range(steps):
+        eng.step()
+    nvr.synchronize(); dt = (time.perf_counter() - t0) / steps
+    st = eng.scheduler.block_manager.get_stats()
+    out = dict(workload=f"{nseq} sequences x (512 shared + 64 own prompt tokens), greedy decode (BASELINE.json configs[4])",
+               ms_per_step=round(dt * 1e3, 4), tokens_per_s=round(nseq / dt, 1), steps=steps,
+               shared_prefix_tokens=eng.model_runner.last_shared_prefix_len(), prefill_steps=npre,
+               prefill_seconds=round(t_pre, 4), prompt_tokens=nseq * 576)
+    if st:
+        out["kv_blocks_used"] = int(st.get("used_blocks", 0))
+    del eng
+    return out
+
+
 def _pmc_prefill_busy():
     """Counter-based MFMA utilisation of the prefill step (separate rocprofv3 --pmc pass, committed under profiles/)."""
     try:
@@ -215,6 +249,7 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--attn-reps", type=int, default=8)
     ap.add_argument("--no-chain", action="store_true", help="skip the GEMM / norm chain timing (roofline_chain)")
+    ap.add_argument("--no-shared-prefix", action="store_true", help="skip the configs[4] side measurement (shared_prefix)")
     ap.add_argument("--sync-decode", action="store_true",
                     help="nvr_config.async_decode = 0: wait for every step's tokens on the host before the next step is scheduled "
                          "(default: the next greedy decode step is launched ahead; same batches, tokens and statistics)")
@@ -455,6 +490,12 @@ def main() -> None:
             chain = time_decode_chain(nvr, mc)
         except Exception as ex:                                              # noqa: BLE001
             print(f"[bench] decode chain timing failed: {ex}", file=sys.stderr, flush=True)
+    shared_prefix = None
+    if args.gpus == 1 and rank == 0 and not args.no_shared_prefix:
+        try:
+            shared_prefix = shared_prefix_decode(nvr, mc)
+        except Exception as ex:                                              # noqa: BLE001
+            shared_prefix = {"error": str(ex)[:300]}
     achieved = attn["alg_bytes"] / (attn["us_per_launch"] * 1e-6) / 1e9
     traffic = None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_attn_latest.json")
@@ -503,6 +544,8 @@ def main() -> None:
                                      "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "us_per_layer": round(chain["us_per_layer"], 2),
                                      "algorithmic_bytes_per_layer": int(chain["alg_bytes_per_layer"]),
                                      "note": "one hipGraph of 28 layers with their own weights (HBM-cold), replayed back to back (HIP events on its stream)"}
+        if shared_prefix is not None:
+            out["shared_prefix"] = shared_prefix
         if args.gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         if replicas is not None and tensor_parallel is not None and "error" not in tensor_parallel:
