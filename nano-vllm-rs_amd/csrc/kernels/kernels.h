@@ -84,11 +84,13 @@ int linear_stream_prepare();                                                // L
 bool linear_stream_ok(int64_t T, int64_t K, int64_t N, int64_t ldx);
 bool linear_stream_silu_ok(int64_t T, int64_t K, int64_t I, int64_t ldx);
 bool linear_stream_rope_ok(int64_t T, int64_t K, int64_t H, int64_t KVH, int64_t D, int64_t ldx);
-int linear_stream(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t N, half_bits *y, hipStream_t s);
-int linear_stream_silu_mul(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t I, half_bits *out, hipStream_t s);
+int linear_stream(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t N, half_bits *y, hipStream_t s,
+                  const half_bits *Wt = nullptr);
+int linear_stream_silu_mul(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t I, half_bits *out, hipStream_t s,
+                           const half_bits *Wt = nullptr);
 int linear_stream_qkv_rope_store(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t H, int64_t KVH, int64_t D,
                                  const int64_t *positions, const int32_t *slots, const float *cos_t, const float *sin_t, half_bits *qkv,
-                                 half_bits *k_cache, half_bits *v_cache, hipStream_t s);
+                                 half_bits *k_cache, half_bits *v_cache, hipStream_t s, const half_bits *Wt = nullptr);
 
 // LM head over more than 32 rows: the 128x128 kernel with the logits / arg-max epilogue (one partial per 128-column tile)
 bool gemm_tiled_splitk_ok(int64_t T, int64_t K, int64_t N, int64_t S, int64_t ldx);

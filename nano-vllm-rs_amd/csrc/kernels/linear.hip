@@ -261,7 +261,7 @@ int linear(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64
     // own single-tile latency (21-31 us) loses to the weight-streaming kernel run over 32-token blocks while T or T*N is small
     if (!y_f32 && gemm256_ok(T, K, N, ldx) && prefer_256(T, K, N)) return gemm256(x, ldx, W, T, K, N, (half_bits *)y, s);   // prefill regime
     if (!y_f32 && gemm_tiled_ok(T, K, N, ldx) && !prefer_stream(T, N)) return gemm_tiled(x, ldx, W, T, K, N, (half_bits *)y, s);
-    if (!y_f32 && linear_stream_ok(T, K, N, ldx)) return linear_stream(x, ldx, W, T, K, N, (half_bits *)y, s);   // large weights
+    if (!y_f32 && linear_stream_ok(T, K, N, ldx)) return linear_stream(x, ldx, W, T, K, N, (half_bits *)y, s, Wt);   // large weights
     const half_t *xx = (const half_t *)x, *ww = (const half_t *)(Wt ? Wt : W);
     const int t = (int)T, k = (int)K, n = (int)N;
     LinEpi e{};
@@ -329,7 +329,7 @@ int linear_silu_mul(const half_bits *x, int64_t ldx, const half_bits *W, int64_t
     if (T == 0) return 0;
     if (gemm256_silu_ok(T, K, I, ldx) && prefer_256(T, K, 2 * I)) return gemm256_silu_mul(x, ldx, W, T, K, I, out, s);   // see linear()
     if (gemm_tiled_ok(T, K, I, ldx) && I % 64 == 0 && !prefer_stream(T, 2 * I)) return gemm_tiled_silu_mul(x, ldx, W, T, K, I, out, s);
-    if (linear_stream_silu_ok(T, K, I, ldx)) return linear_stream_silu_mul(x, ldx, W, T, K, I, out, s);              // large weights
+    if (linear_stream_silu_ok(T, K, I, ldx)) return linear_stream_silu_mul(x, ldx, W, T, K, I, out, s, Wt);              // large weights
     const half_t *xx = (const half_t *)x, *ww = (const half_t *)(Wt ? Wt : W);
     LinEpi e{};
     e.tiled = Wt != nullptr;
@@ -362,7 +362,7 @@ int linear_qkv_rope_store(const half_bits *x, int64_t ldx, const half_bits *W, i
     if (gemm_tiled_ok(T, K, (H + 2 * KVH) * D, ldx) && 128 % D == 0 && !prefer_stream(T, (H + 2 * KVH) * D))
         return gemm_tiled_qkv_rope_store(x, ldx, W, T, K, H, KVH, D, positions, slots, cos_t, sin_t, qkv, k_cache, v_cache, s);
     if (linear_stream_rope_ok(T, K, H, KVH, D, ldx))                                                                  // large weights
-        return linear_stream_qkv_rope_store(x, ldx, W, T, K, H, KVH, D, positions, slots, cos_t, sin_t, qkv, k_cache, v_cache, s);
+        return linear_stream_qkv_rope_store(x, ldx, W, T, K, H, KVH, D, positions, slots, cos_t, sin_t, qkv, k_cache, v_cache, s, Wt);
     const half_t *xx = (const half_t *)x, *ww = (const half_t *)(Wt ? Wt : W);
     LinEpi e{};
     e.tiled = Wt != nullptr;

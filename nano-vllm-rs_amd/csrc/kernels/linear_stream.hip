@@ -26,6 +26,7 @@ struct StreamEpi {
     const int64_t *pos; const int32_t *slots; const float *cos_t, *sin_t;
     half_t *kc, *vc;
     int32_t H, KVH, D;
+    int32_t tiled;                       // W is the retile_weight copy [N/16][K/32][16][32] (SEPI_ROPE: mode 1, tiles in s_w_row order)
 };
 
 // W row behind local row r (0..15) of part nt (SiLU: 0 = gate, 1 = up) of tile t
@@ -72,7 +73,10 @@ __global__ __launch_bounds__(WAVES * 64) void linear_stream_kernel(const half_t 
             if (tile >= ntiles) break;
             const half_t *wr[NTT];
 #pragma unroll
-            for (int nt = 0; nt < NTT; ++nt) wr[nt] = W + (int64_t)s_w_row<EPI>(tile, nt, r, N, epi) * K + kc0 + q * 8;
+            for (int nt = 0; nt < NTT; ++nt)
+                wr[nt] = epi.tiled ? W + ((int64_t)(EPI == SEPI_SILU ? nt * (N / 16) + tile : tile) * (K / 32) + kc0 / 32) * 512 + r * 32 + q * 8
+                                   : W + (int64_t)s_w_row<EPI>(tile, nt, r, N, epi) * K + kc0 + q * 8;
+            const int kmul = epi.tiled ? 16 : 1;                             // a k-step of 32 halfs is one 512-half tile further in the tiled copy
             for (int kb = wave * 32; kb < KC; kb += WAVES * 32 * U) {
                 half8_t a[U][NTT];
 #pragma unroll
@@ -80,7 +84,7 @@ __global__ __launch_bounds__(WAVES * 64) void linear_stream_kernel(const half_t 
                     const int kk = kb + u * WAVES * 32;
 #pragma unroll
                     for (int nt = 0; nt < NTT; ++nt)
-                        a[u][nt] = kk < KC ? __builtin_nontemporal_load(reinterpret_cast<const half8_t *>(wr[nt] + kk)) : (half8_t)(half_t)0;
+                        a[u][nt] = kk < KC ? __builtin_nontemporal_load(reinterpret_cast<const half8_t *>(wr[nt] + (int64_t)kk * kmul)) : (half8_t)(half_t)0;
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
@@ -235,25 +239,29 @@ int linear_stream_prepare() {
     return 0;
 }
 
-int linear_stream(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t N, half_bits *y, hipStream_t s) {
+int linear_stream(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t N, half_bits *y, hipStream_t s, const half_bits *Wt) {
     if (!linear_stream_ok(T, K, N, ldx)) return nvr::fail(NVR_ERR_UNSUPPORTED, "linear_stream: T=%ld K=%ld N=%ld", (long)T, (long)K, (long)N);
-    const StreamEpi e{};
+    StreamEpi e{};
+    if (Wt) { W = Wt; e.tiled = 1; }
     if (T <= 16) return stream_launch<1, 1, 4, SEPI_F16>((const half_t *)x, ldx, (const half_t *)W, (int)T, (int)K, (int)N, (int)(N / 16), (half_t *)y, e, s);
     return stream_launch<1, 2, 4, SEPI_F16>((const half_t *)x, ldx, (const half_t *)W, (int)T, (int)K, (int)N, (int)(N / 16), (half_t *)y, e, s);
 }
-int linear_stream_silu_mul(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t I, half_bits *out, hipStream_t s) {
+int linear_stream_silu_mul(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t I, half_bits *out, hipStream_t s,
+                           const half_bits *Wt) {
     if (!linear_stream_silu_ok(T, K, I, ldx)) return nvr::fail(NVR_ERR_UNSUPPORTED, "linear_stream_silu_mul: T=%ld K=%ld I=%ld", (long)T, (long)K, (long)I);
-    const StreamEpi e{};
+    StreamEpi e{};
+    if (Wt) { W = Wt; e.tiled = 1; }
     if (T <= 16) return stream_launch<2, 1, 2, SEPI_SILU>((const half_t *)x, ldx, (const half_t *)W, (int)T, (int)K, (int)I, (int)(I / 16), (half_t *)out, e, s);
     return stream_launch<2, 2, 2, SEPI_SILU>((const half_t *)x, ldx, (const half_t *)W, (int)T, (int)K, (int)I, (int)(I / 16), (half_t *)out, e, s);
 }
 int linear_stream_qkv_rope_store(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t H, int64_t KVH, int64_t D,
                                  const int64_t *positions, const int32_t *slots, const float *cos_t, const float *sin_t, half_bits *qkv,
-                                 half_bits *k_cache, half_bits *v_cache, hipStream_t s) {
+                                 half_bits *k_cache, half_bits *v_cache, hipStream_t s, const half_bits *Wt) {
     if (!linear_stream_rope_ok(T, K, H, KVH, D, ldx)) return nvr::fail(NVR_ERR_UNSUPPORTED, "linear_stream_qkv_rope_store: T=%ld K=%ld D=%ld", (long)T, (long)K, (long)D);
     StreamEpi e{};
     e.pos = positions; e.slots = slots; e.cos_t = cos_t; e.sin_t = sin_t; e.kc = (half_t *)k_cache; e.vc = (half_t *)v_cache;
     e.H = (int32_t)H; e.KVH = (int32_t)KVH; e.D = (int32_t)D;
+    if (Wt) { W = Wt; e.tiled = 1; }
     const int N = (int)((H + 2 * KVH) * D);
     if (T <= 16) return stream_launch<1, 1, 4, SEPI_ROPE>((const half_t *)x, ldx, (const half_t *)W, (int)T, (int)K, N, N / 16, (half_t *)qkv, e, s);
     return stream_launch<1, 2, 4, SEPI_ROPE>((const half_t *)x, ldx, (const half_t *)W, (int)T, (int)K, N, N / 16, (half_t *)qkv, e, s);
