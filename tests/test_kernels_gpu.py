@@ -1058,3 +1058,50 @@ def test_paged_attn_decode_shared_prefix(B, H, KVH, D, bs, P, own):
     # shared_len that is no multiple of the block size is refused
     assert nvr.lib().nvr_paged_attn_decode_shared(d_q.ptr, H * D, d_k.ptr, d_v.ptr, C.byref(meta), H, KVH, D, bs, scale, S + 8,
                                                   d_out.ptr, ws.ptr, None) == -7
+
+
+@pytest.mark.parametrize("T", [8, 32])
+def test_tiled_entry_points_match_row_major_stream_shapes(T):
+    """The same on Qwen3-8B shapes, where linear / silu / qkv route to linear_stream_kernel (>= 24 MiB of weights, K = 4096): the
+    tiled copy must give the bits of the row-major weights there too."""
+    rng = np.random.default_rng(23 + T)
+    l = nvr.lib()
+    Hd, H, KVH, D, I = 4096, 32, 8, 128, 12288
+    QKV = (H + 2 * KVH) * D
+
+    def tiled(Wb, N, K, mode):
+        d_W, d_T = dev(Wb), nvr.DeviceBuffer(N * K * 2)
+        _KEEP.append(d_T)
+        nvr.check(l.nvr_retile_weight(d_W.ptr, d_T.ptr, N, K, mode, H, KVH, D, None))
+        return d_W, d_T
+    _, xb = h16(rng.standard_normal((T, Hd)) * 0.5)
+    d_x = dev(xb)
+    Wb = (rng.standard_normal((QKV, Hd)) * 0.03).astype(F16)
+    # plain
+    d_W, d_T = tiled(Wb, QKV, Hd, 0)
+    ya, yb = nvr.DeviceBuffer(T * QKV * 2), nvr.DeviceBuffer(T * QKV * 2)
+    nvr.check(l.nvr_linear(d_x.ptr, Hd, d_W.ptr, T, Hd, QKV, ya.ptr, 0, None))
+    nvr.check(l.nvr_linear_tiled(d_x.ptr, Hd, d_W.ptr, d_T.ptr, T, Hd, QKV, yb.ptr, 0, None))
+    assert np.array_equal(ya.to_numpy((T, QKV), np.uint16), yb.to_numpy((T, QKV), np.uint16))
+    # qkv + RoPE + KV store (mode 1 copy)
+    d_W, d_T = tiled(Wb, QKV, Hd, 1)
+    pos = rng.integers(0, 512, T).astype(np.int64); slots = rng.permutation(64)[:T].astype(np.int32)
+    cos, sin = oracle.rope_table(D, 512, 1e6)
+    d_pos, d_slots, d_cos, d_sin = dev(pos), dev(slots), dev(cos), dev(sin)
+    outs = []
+    for fn, extra in ((l.nvr_linear_qkv_rope_store, ()), (l.nvr_linear_qkv_rope_store_tiled, (d_T.ptr,))):
+        q, kc, vc = nvr.DeviceBuffer(T * QKV * 2), dev(np.zeros((64, KVH, D), np.uint16)), dev(np.zeros((64, KVH, D), np.uint16))
+        nvr.check(fn(d_x.ptr, Hd, d_W.ptr, *extra, T, Hd, H, KVH, D, d_pos.ptr, d_slots.ptr, d_cos.ptr, d_sin.ptr, q.ptr, kc.ptr, vc.ptr, None))
+        outs.append((q.to_numpy((T, QKV), np.uint16), kc.to_numpy((64, KVH, D), np.uint16), vc.to_numpy((64, KVH, D), np.uint16)))
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
+    # gate_up + SiLU·mul
+    Wg = (rng.standard_normal((2 * I, Hd)) * 0.03).astype(F16)
+    d_W, d_T = tiled(Wg, 2 * I, Hd, 0)
+    oa, ob = nvr.DeviceBuffer(T * I * 2), nvr.DeviceBuffer(T * I * 2)
+    nvr.check(l.nvr_linear_silu_mul(d_x.ptr, Hd, d_W.ptr, T, Hd, I, oa.ptr, None))
+    nvr.check(l.nvr_linear_silu_mul_tiled(d_x.ptr, Hd, d_W.ptr, d_T.ptr, T, Hd, I, ob.ptr, None))
+    assert np.array_equal(oa.to_numpy((T, I), np.uint16), ob.to_numpy((T, I), np.uint16))
+    # (and against the oracle, a few columns)
+    ref = oracle.round_f16(oracle.silu_and_mul(oracle.round_f16(oracle.linear(xb.astype(np.float32), np.concatenate([Wg[:64], Wg[I:I + 64]]).astype(np.float32)))))
+    assert_close_f16(ob.to_numpy((T, I), F16)[:, :64], ref, ulps=2, atol=3e-4, what="stream silu tiled vs oracle")
