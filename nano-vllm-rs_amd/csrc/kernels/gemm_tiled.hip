@@ -57,7 +57,7 @@ __device__ __forceinline__ int tile_w_row(int bx, int t, int r, int N, const Til
 // workgroup per CU) with three K-tiles in flight and counted s_waitcnt vmcnt: when there are fewer tiles than CUs (decode
 // batches of 129..~1000 rows, short prefills) a workgroup is alone on its CU and every K-step of the NS = 2 form costs one
 // full memory latency (21 us for a K = 1024 tile); the ring hides it.
-// MT: 16-token m-tiles per wave.  4 = the 128-token tile; 2 = a 64-token tile for batches of 129..~1000 rows, where 128 x 128 tiles
+// MT: 16-token m-tiles per wave.  4 = the 128-token tile; 2 / 1 = a 64- / 32-token tile for batches of 65..~1000 rows, where 128 x 128 tiles
 // leave half the CUs without a workgroup (T = 512: 128 / 96 / 128 workgroups for qkv / gate_up / the split-k GEMMs; 23 / 16 / 12 us):
 // twice the workgroups, each with the same 128 W rows and half the tokens.
 template <int EPI, int NS, int MT = 4>
@@ -292,24 +292,35 @@ static bool tiled_ring(unsigned tiles) {
     static const int force = [] { const char *e = getenv("NVR_TILED_RING"); return e ? atoi(e) : -1; }();
     return force >= 0 ? force != 0 : tiles < 256;
 }
-// 64-token tiles when 128-token tiles would leave CUs without a workgroup (NVR_TILED_BM64=0/1 forces)
-static bool tiled_bm64(int64_t T, int64_t nx_nz) {
-    static const int force = [] { const char *e = getenv("NVR_TILED_BM64"); return e ? atoi(e) : -1; }();
-    if (force >= 0) return force != 0;
-    return T > 64 && nx_nz * ((T + BM - 1) / BM) < 192;      // (192 workgroups of 128 tokens beat 384 of 64: 15.6 vs 19.3 us, gate_up at T = 512)
+// 64- or 32-token tiles when 128-token tiles would leave CUs without a workgroup: the largest tile that reaches ~192 workgroups
+// (NVR_TILED_BM=128/64/32 forces).  Returns the m-tiles per wave (4, 2, 1).
+static int tiled_mt(int64_t T, int64_t nx_nz) {
+    static const int force = [] { const char *e = getenv("NVR_TILED_BM"); return e ? atoi(e) : 0; }();
+    if (force == 128) return 4;
+    if (force == 64) return 2;
+    if (force == 32) return 1;
+    if (T <= 64 || nx_nz * ((T + 127) / 128) >= 192) return 4;   // (192 workgroups of 128 tokens beat 384 of 64: 15.6 vs 19.3 us, gate_up at T = 512)
+    if (nx_nz * ((T + 63) / 64) >= 192) return 2;
+    return 1;
 }
 constexpr size_t kStageBytes = 2 * BM * BK * 2;                          // MT = 4
 constexpr size_t kStageBytes64 = (BN + 64) * BK * 2;                     // MT = 2
-// grid: x = column tiles, y is filled in here (token tiles of 128 or 64), z = k slices
+constexpr size_t kStageBytes32 = (BN + 32) * BK * 2;                     // MT = 1
+// grid: x = column tiles, y is filled in here (token tiles of 128, 64 or 32), z = k slices; the 4-buffer ring whenever a
+// workgroup is alone on its CU (the smaller tiles fit two workgroups per CU even with the ring)
 #define NVR_TILED_LAUNCH(EPI_, grid, T_, ...)                                                                      \
     do {                                                                                                           \
-        if (tiled_bm64((T_), (int64_t)(grid).x * (grid).z)) {                                                      \
-            (grid).y = (unsigned)(((T_) + 63) / 64);                                                               \
-            if (tiled_ring((grid).x * (grid).y * (grid).z / 2)) gemm_tiled_kernel<EPI_, 4, 2><<<grid, dim3(256), 4 * kStageBytes64, s>>>(__VA_ARGS__); \
+        const int mt_ = tiled_mt((T_), (int64_t)(grid).x * (grid).z);                                              \
+        (grid).y = (unsigned)(((T_) + 32 * mt_ - 1) / (32 * mt_));                                                 \
+        const unsigned wgs_ = (grid).x * (grid).y * (grid).z;                                                      \
+        if (mt_ == 1) {                                                                                            \
+            if (tiled_ring(wgs_ / 2)) gemm_tiled_kernel<EPI_, 4, 1><<<grid, dim3(256), 4 * kStageBytes32, s>>>(__VA_ARGS__); \
+            else gemm_tiled_kernel<EPI_, 2, 1><<<grid, dim3(256), 2 * kStageBytes32, s>>>(__VA_ARGS__);           \
+        } else if (mt_ == 2) {                                                                                     \
+            if (tiled_ring(wgs_ / 2)) gemm_tiled_kernel<EPI_, 4, 2><<<grid, dim3(256), 4 * kStageBytes64, s>>>(__VA_ARGS__); \
             else gemm_tiled_kernel<EPI_, 2, 2><<<grid, dim3(256), 2 * kStageBytes64, s>>>(__VA_ARGS__);           \
         } else {                                                                                                   \
-            (grid).y = (unsigned)(((T_) + BM - 1) / BM);                                                           \
-            if (tiled_ring((grid).x * (grid).y * (grid).z)) gemm_tiled_kernel<EPI_, 4><<<grid, dim3(256), 4 * kStageBytes, s>>>(__VA_ARGS__); \
+            if (tiled_ring(wgs_)) gemm_tiled_kernel<EPI_, 4><<<grid, dim3(256), 4 * kStageBytes, s>>>(__VA_ARGS__); \
             else gemm_tiled_kernel<EPI_, 2><<<grid, dim3(256), 2 * kStageBytes, s>>>(__VA_ARGS__);                 \
         }                                                                                                          \
     } while (0)
@@ -322,6 +333,8 @@ int gemm_tiled_prepare() {
                                          (int)(4 * kStageBytes));                                                    \
       if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_tiled_kernel<EPI_, 4, 2>),   \
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * kStageBytes64)); \
+      if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_tiled_kernel<EPI_, 4, 1>),   \
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * kStageBytes32)); \
       if (e != hipSuccess) return nvr::fail(NVR_ERR_HIP, "gemm_tiled: LDS opt-in failed: %s", hipGetErrorString(e)); }
     NVR_TILED_ATTR(TEPI_F16) NVR_TILED_ATTR(TEPI_SILU) NVR_TILED_ATTR(TEPI_ROPE) NVR_TILED_ATTR(TEPI_LMHEAD) NVR_TILED_ATTR(TEPI_SLAB)
 #undef NVR_TILED_ATTR
@@ -361,7 +374,7 @@ int gemm_tiled_splitk(const half_bits *x, int64_t ldx, const half_bits *W, int64
     return tiled_check("gemm_tiled_splitk");
 }
 
-bool gemm_tiled_ok(int64_t T, int64_t K, int64_t N, int64_t ldx) { return tiled_enabled() && T >= 128 && K % BK == 0 && N % 16 == 0 && ldx % 8 == 0; }
+bool gemm_tiled_ok(int64_t T, int64_t K, int64_t N, int64_t ldx) { return tiled_enabled() && T > 64 && K % BK == 0 && N % 16 == 0 && ldx % 8 == 0; }
 
 int gemm_tiled(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t N, half_bits *y, hipStream_t s) {
     if (!gemm_tiled_ok(T, K, N, ldx)) return nvr::fail(NVR_ERR_UNSUPPORTED, "gemm_tiled: T=%ld K=%ld N=%ld", (long)T, (long)K, (long)N);

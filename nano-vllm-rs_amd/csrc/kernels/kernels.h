@@ -49,6 +49,7 @@ int lm_head(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int6
 int argmax_partials(const float *part_val, const int32_t *part_idx, int32_t nparts, int64_t T, int64_t *out_idx, float *out_val,
                     int64_t idx_offset, hipStream_t s, int64_t *out_idx2 = nullptr);
 
+int64_t stream_row_limit();    // rows up to which the weight-streaming kernels are preferred over the LDS-tiled GEMM (linear.hip)
 int linear_splitk(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t N, int64_t S,
                   float *slabs, hipStream_t s, const half_bits *Wt = nullptr);
 // h = fp16(h + fp16(sum_z slabs[z])), out = rmsnorm(h)*w

@@ -242,7 +242,15 @@ static inline bool prefer_256(int64_t T, int64_t K, int64_t N) {
     return c256 < c128;
 }
 // one rule for the plain and the fused launchers (N = output features), so that a fused GEMM and its unfused twin run the same kernel
-static inline bool prefer_stream(int64_t T, int64_t N) { return T <= 128 || T * N <= 384 * 1024; }
+int64_t stream_row_limit() {
+    static const int64_t tmax = [] { const char *e = std::getenv("NVR_PREFER_STREAM_T"); return e ? (int64_t)atoll(e) : (int64_t)64; }();
+    return tmax;
+}
+static inline bool prefer_stream(int64_t T, int64_t N) {
+    // up to 64 rows the weight-streaming kernel; beyond, the LDS-tiled kernel with 32- / 64-token tiles and the 4-buffer ring (r02,
+    // ctx 256: bs 66 2.20 -> 1.83 ms/step, bs 96 2.48 -> 2.15, bs 128 2.82 -> 2.23).  NVR_PREFER_STREAM_T moves the boundary.
+    return T <= stream_row_limit() || T * N <= 384 * 1024;
+}
 static inline int waves_for(int64_t K) { return K >= 2048 ? 16 : (K >= 1024 ? 8 : 4); }
 
 static int launch_check(const char *what) {

@@ -358,10 +358,11 @@ int nvr_model_runner::row_parallel_norm(const uint16_t *x, int64_t K, const uint
         S = k::decode_splitk_slices(T, K, Hd);
     } else if (!comm.active() && tp == 1 && T <= 32 && Hd <= 8192 && Hd % 64 == 0 && Hd * K * 2 >= (24ll << 20) && K % 128 == 0) {
         S = 4;                                       // large weights: 64-column workgroups x 4 k-slices (linear_splitk)
-    } else if (!comm.active() && tp == 1 && T > 128 && T <= slab_rows && Hd <= 8192 && ((Hd + 127) / 128) * ((T + 127) / 128) <= 64 &&
+    } else if (!comm.active() && tp == 1 && T > k::stream_row_limit() && T <= slab_rows && Hd <= 8192 && ((Hd + 127) / 128) * ((T + 127) / 128) <= 64 &&
                k::gemm_tiled_splitk_ok(T, K, Hd, 4, K)) {
-        S = 4;                                       // 129..1024 rows, few 128x128 tiles: k-split of the tiled kernel (gemm_tiled_splitk;
-                                                     // bs = 256 / 512 decode 4.04 -> 3.67 / 6.18 -> 5.33 ms; at 128 rows the streaming kernel still wins)
+        S = 4;                                       // 97..1024 rows, few 128x128 tiles: k-split of the tiled kernel (gemm_tiled_splitk;
+                                                     // bs = 256 / 512 decode 4.04 -> 3.67 / 6.18 -> 5.33 ms in r01; with the 32- / 64-token
+                                                     // tiles of r02 it also wins from 97 rows on: same boundary as prefer_stream, linear.hip)
     }
     if (S > 1) {
         RC(k::linear_splitk(x, K, W, T, K, Hd, S, slabs, stream, Wt));
