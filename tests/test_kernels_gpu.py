@@ -1105,3 +1105,52 @@ def test_tiled_entry_points_match_row_major_stream_shapes(T):
     # (and against the oracle, a few columns)
     ref = oracle.round_f16(oracle.silu_and_mul(oracle.round_f16(oracle.linear(xb.astype(np.float32), np.concatenate([Wg[:64], Wg[I:I + 64]]).astype(np.float32)))))
     assert_close_f16(ob.to_numpy((T, I), F16)[:, :64], ref, ulps=2, atol=3e-4, what="stream silu tiled vs oracle")
+
+
+@pytest.mark.parametrize("T", [70, 100, 200, 512])
+def test_gemm_tiled_tile_heights(T):
+    """Decode batches of 65..512 rows take the LDS-tiled GEMM with 32-, 64- or 128-token tiles (the largest that reaches ~192
+    workgroups: T = 70 / 100 -> 32-token tiles for qkv, T = 512 -> 64-token tiles, gate_up at 512 -> 128): plain, SiLU, RoPE + KV
+    store and split-k epilogues on the Qwen3-0.6B shapes against the oracle."""
+    rng = np.random.default_rng(60 + T)
+    l = nvr.lib()
+    Hd, H, KVH, D, I = 1024, 16, 8, 128, 3072
+    QKV = (H + 2 * KVH) * D
+    x, xb = h16(rng.standard_normal((T, Hd)) * 0.5)
+    d_x = dev(xb)
+    # plain
+    W, Wb = h16(rng.standard_normal((QKV, Hd)) * 0.05)
+    d_W = dev(Wb)
+    d_y = nvr.DeviceBuffer(T * QKV * 2)
+    nvr.check(l.nvr_linear(d_x.ptr, Hd, d_W.ptr, T, Hd, QKV, d_y.ptr, 0, None))
+    lin = oracle.round_f16(oracle.linear(x, W))
+    assert_close_f16(d_y.to_numpy((T, QKV), F16), lin, ulps=1, atol=3e-4, what="plain")
+    # qkv + RoPE + store
+    pos = rng.integers(0, 500, T).astype(np.int64)
+    nslots = T + 9
+    slots = rng.permutation(nslots)[:T].astype(np.int32)
+    cos, sin = oracle.rope_table(D, 512, 1e6)
+    d_q, d_kc, d_vc = nvr.DeviceBuffer(T * QKV * 2), nvr.DeviceBuffer(nslots * KVH * D * 2), nvr.DeviceBuffer(nslots * KVH * D * 2)
+    _KEEP.extend([d_q, d_kc, d_vc]); d_kc.zero(); d_vc.zero()
+    nvr.check(l.nvr_linear_qkv_rope_store(d_x.ptr, Hd, d_W.ptr, T, Hd, H, KVH, D, dev(pos).ptr, dev(slots).ptr, dev(cos).ptr, dev(sin).ptr,
+                                          d_q.ptr, d_kc.ptr, d_vc.ptr, None))
+    q = oracle.round_f16(oracle.rope_apply(lin[:, :H * D].reshape(T, H, D), pos, cos, sin)).reshape(T, H * D)
+    k = oracle.round_f16(oracle.rope_apply(lin[:, H * D:(H + KVH) * D].reshape(T, KVH, D), pos, cos, sin)).reshape(T, KVH * D)
+    got = d_q.to_numpy((T, QKV), F16)
+    assert_close_f16(got, np.concatenate([q, k, lin[:, (H + KVH) * D:]], 1), ulps=2, atol=3e-3, what="rope")
+    kc, gb = d_kc.to_numpy((nslots, KVH * D), np.uint16), got.view(np.uint16)
+    vc = d_vc.to_numpy((nslots, KVH * D), np.uint16)
+    for t in range(T):
+        assert np.array_equal(kc[slots[t]], gb[t, H * D:(H + KVH) * D]) and np.array_equal(vc[slots[t]], gb[t, (H + KVH) * D:])
+    # gate_up + SiLU * up
+    Wg, Wgb = h16(rng.standard_normal((2 * I, Hd)) * 0.05)
+    d_o = nvr.DeviceBuffer(T * I * 2)
+    nvr.check(l.nvr_linear_silu_mul(d_x.ptr, Hd, dev(Wgb).ptr, T, Hd, I, d_o.ptr, None))
+    ref = oracle.round_f16(oracle.silu_and_mul(oracle.round_f16(oracle.linear(x, Wg))))
+    assert_close_f16(d_o.to_numpy((T, I), F16), ref, ulps=2, atol=3e-4, what="silu")
+    # split-k slabs (o_proj shape)
+    a, ab = h16(rng.standard_normal((T, H * D)) * 0.3)
+    Wo, Wob = h16(rng.standard_normal((Hd, H * D)) * 0.05)
+    d_sl = nvr.DeviceBuffer(4 * T * Hd * 4)
+    nvr.check(l.nvr_linear_splitk(dev(ab).ptr, H * D, dev(Wob).ptr, T, H * D, Hd, 4, d_sl.ptr, None))
+    np.testing.assert_allclose(d_sl.to_numpy((4, T, Hd), np.float32).sum(0), oracle.linear(a, Wo), rtol=2e-5, atol=3e-4)
