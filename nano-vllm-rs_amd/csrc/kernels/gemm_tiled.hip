@@ -299,7 +299,7 @@ static int tiled_mt(int64_t T, int64_t nx_nz) {
     if (force == 128) return 4;
     if (force == 64) return 2;
     if (force == 32) return 1;
-    if (T <= 64 || nx_nz * ((T + 127) / 128) >= 192) return 4;   // (192 workgroups of 128 tokens beat 384 of 64: 15.6 vs 19.3 us, gate_up at T = 512)
+    if (T <= 32 || nx_nz * ((T + 127) / 128) >= 192) return 4;   // (192 workgroups of 128 tokens beat 384 of 64: 15.6 vs 19.3 us, gate_up at T = 512)
     if (nx_nz * ((T + 63) / 64) >= 192) return 2;
     return 1;
 }
@@ -362,7 +362,7 @@ int gemm_tiled_lm_head(const half_bits *x, int64_t ldx, const half_bits *W, int6
 
 // split-k form for the narrow row-parallel GEMMs (o_proj / down_proj) at 65..1024 rows: slabs[z][T][N] f32, S slices of K
 bool gemm_tiled_splitk_ok(int64_t T, int64_t K, int64_t N, int64_t S, int64_t ldx) {
-    return tiled_enabled() && T > 64 && S >= 1 && K % (S * BK) == 0 && N % 16 == 0 && ldx % 8 == 0;
+    return tiled_enabled() && T > 32 && S >= 1 && K % (S * BK) == 0 && N % 16 == 0 && ldx % 8 == 0;
 }
 int gemm_tiled_splitk(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t N, int64_t S, float *slabs, hipStream_t s) {
     if (!gemm_tiled_splitk_ok(T, K, N, S, ldx)) return nvr::fail(NVR_ERR_UNSUPPORTED, "gemm_tiled_splitk: T=%ld K=%ld N=%ld S=%ld", (long)T, (long)K, (long)N, (long)S);
@@ -374,7 +374,7 @@ int gemm_tiled_splitk(const half_bits *x, int64_t ldx, const half_bits *W, int64
     return tiled_check("gemm_tiled_splitk");
 }
 
-bool gemm_tiled_ok(int64_t T, int64_t K, int64_t N, int64_t ldx) { return tiled_enabled() && T > 64 && K % BK == 0 && N % 16 == 0 && ldx % 8 == 0; }
+bool gemm_tiled_ok(int64_t T, int64_t K, int64_t N, int64_t ldx) { return tiled_enabled() && T > 32 && K % BK == 0 && N % 16 == 0 && ldx % 8 == 0; }
 
 int gemm_tiled(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t N, half_bits *y, hipStream_t s) {
     if (!gemm_tiled_ok(T, K, N, ldx)) return nvr::fail(NVR_ERR_UNSUPPORTED, "gemm_tiled: T=%ld K=%ld N=%ld", (long)T, (long)K, (long)N);

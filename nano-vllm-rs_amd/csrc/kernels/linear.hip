@@ -311,7 +311,7 @@ int linear_splitk(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T
     if (K % (32 * S) || N % 16 || ldx % 8 || S < 1)
         return nvr::fail(NVR_ERR_UNSUPPORTED, "linear_splitk: K=%ld must be a multiple of 32*S (S=%ld), N=%ld of 16", (long)K, (long)S, (long)N);
     if (T == 0) return 0;
-    if (gemm_tiled_splitk_ok(T, K, N, S, ldx)) return gemm_tiled_splitk(x, ldx, W, T, K, N, S, slabs, s);   // more than 64 rows: 128x128 tiles
+    if (T > stream_row_limit() && gemm_tiled_splitk_ok(T, K, N, S, ldx)) return gemm_tiled_splitk(x, ldx, W, T, K, N, S, slabs, s);   // more than 64 rows: LDS tiles
     LinEpi e{};
     e.kslice = (int32_t)(K / S); e.slab_stride = T * N;
     if (Wt) { W = Wt; e.tiled = 1; }

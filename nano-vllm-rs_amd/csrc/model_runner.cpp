@@ -354,7 +354,7 @@ int nvr_model_runner::copy_weight(const char *ln, uint16_t *out, size_t cap, int
 // writes fp16 `proj` (+ all-reduce when tensor parallel) and add_rmsnorm follows.
 int nvr_model_runner::row_parallel_norm(const uint16_t *x, int64_t K, const uint16_t *W, const uint16_t *Wt, int64_t T, const uint16_t *wn) {
     int64_t S = 1;
-    if (!comm.active() && tp == 1 && T <= 64 && Hd <= 2048) {
+    if (!comm.active() && tp == 1 && T <= 64 && T <= k::stream_row_limit() && Hd <= 2048) {
         S = k::decode_splitk_slices(T, K, Hd);
     } else if (!comm.active() && tp == 1 && T <= 32 && Hd <= 8192 && Hd % 64 == 0 && Hd * K * 2 >= (24ll << 20) && K % 128 == 0) {
         S = 4;                                       // large weights: 64-column workgroups x 4 k-slices (linear_splitk)
