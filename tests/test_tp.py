@@ -156,38 +156,28 @@ def test_rccl_collectives_inside_the_decode_graph_single_gpu():
         os.environ.pop("NVR_TP_FORCE_COMM", None)
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("tp,temps", [(2, [0.0, 0.0, 0.0]), (2, [0.0, 0.8, 1.0]), (4, [0.0, 0.0, 0.0])])
-def test_product_tensor_parallel_ranks_in_process_match_the_oracle(tp, temps):
-    """The PRODUCT's tensor-parallel path end to end on one GPU: tp runners of this process (rank r holds its head / column /
-    vocab shard, linear.rs:300-304,421-433,202, embed_head.rs:57-59), one host thread per rank, exchanging at the reference's
-    sites (all-reduce after o_proj and down_proj, (max, argmax) pairs or logits shards for the sampler) through the in-process
-    communicator — the same call sites as RCCL, with a host rendezvous instead of xGMI.  Every rank must schedule the same
-    batches and sample the same tokens as the others, and they must be the oracle's tensor-parallel engine's (teacher-forced):
-    shard logits within tolerance, greedy tokens equal outside numerical near-ties."""
+def _tp_ranks_vs_oracle(tp, m, ecfg, prompts, sps, product_kw=None, min_steps=5):
+    """tp in-process product ranks against each other and against the oracle's tensor-parallel engine (teacher-forced)."""
     import threading
     sys.path.insert(0, ROOT)
     import nvr_import
-    import oracle
     from oracle import engine_oracle as eo, model_oracle as mo
     nvr = nvr_import.load()
-    m = mo.small(seed=6, num_attention_heads=8, num_key_value_heads=4, head_dim=64, hidden_size=256, intermediate_size=512)
     mc = nvr.ModelConfig(vocab_size=m.vocab_size, hidden_size=m.hidden_size, intermediate_size=m.intermediate_size,
                          num_hidden_layers=m.num_hidden_layers, num_attention_heads=m.num_attention_heads,
                          num_key_value_heads=m.num_key_value_heads, head_dim=m.head_dim, max_position_embeddings=m.max_position_embeddings,
                          rms_norm_eps=m.rms_norm_eps, rope_theta=m.rope_theta, tie_word_embeddings=m.tie_word_embeddings,
-                         init_std=m.init_std, seed=m.seed)
-    ecfg = dict(max_num_seqs=4, max_num_batched_tokens=256, max_model_len=128, kvcache_block_size=16, num_kvcache_blocks=24)
-    prompts = [oracle.fill_tokens(n, 5, i, m.vocab_size).tolist() for i, n in enumerate([9, 40, 17])]
-    sps = [dict(temperature=t, max_tokens=10, ignore_eos=True, **({} if t == 0.0 else dict(top_k=30))) for t in temps]
-
+                         init_std=m.init_std, seed=m.seed, qk_norm=m.qk_norm)
+    temps = [sp["temperature"] for sp in sps]
+    product_kw = product_kw or {}
     group = nvr.LocalGroup(tp)
     engines = []
     for r in range(tp):
-        e = nvr.LLMEngine(nvr.Config(skip_block_size_check=1, tensor_parallel_size=tp, tensor_parallel_rank=r, sample_seed=11, **ecfg), mc)
+        e = nvr.LLMEngine(nvr.Config(skip_block_size_check=1, tensor_parallel_size=tp, tensor_parallel_rank=r, sample_seed=11, **ecfg, **product_kw), mc)
         group.attach(e.model_runner)
         engines.append(e)
     traces = [[] for _ in range(tp)]
+    shared_seen = set()
     errors = []
 
     def drive(r):
@@ -196,6 +186,8 @@ def test_product_tensor_parallel_ranks_in_process_match_the_oracle(tp, temps):
             while not e.is_finished():
                 rec = e.step()
                 rec["logits"] = e.model_runner.logits(rec["num_seqs"]).copy()           # this rank's vocab shard
+                if not rec["is_prefill"]:
+                    shared_seen.add(e.model_runner.last_shared_prefix_len())
                 traces[r].append(rec)
         except BaseException as ex:                                                     # noqa: BLE001
             errors.append((r, ex))
@@ -210,14 +202,14 @@ def test_product_tensor_parallel_ranks_in_process_match_the_oracle(tp, temps):
     for t in threads: t.start()
     for t in threads: t.join(300)
     assert not errors, errors
-    assert all(len(tr) == len(traces[0]) and len(tr) > 5 for tr in traces)
+    assert all(len(tr) == len(traces[0]) and len(tr) > min_steps for tr in traces)
     greedy_rows_only = all(t == 0.0 for t in temps)
     for step in zip(*traces):
         assert all(s["is_prefill"] == step[0]["is_prefill"] and s["num_seqs"] == step[0]["num_seqs"] for s in step)
         assert all(s["tokens"] == step[0]["tokens"] and s["seq_ids"] == step[0]["seq_ids"] for s in step), "ranks disagree on the sampled tokens"
     # the oracle's tensor-parallel engine, teacher-forced with rank 0's tokens
     eo.reset_sequence_counter()
-    o = mo.OracleEngine(m, eo.Config(**ecfg), fp16=True, tp_size=tp, max_pos=128, sample_seed=11)
+    o = mo.OracleEngine(m, eo.Config(**ecfg), fp16=True, tp_size=tp, max_pos=ecfg["max_model_len"], sample_seed=11)
     for pr, sp in zip(prompts, sps):
         o.add_request(pr, eo.SamplingParams(**sp))
     near = 0
@@ -236,6 +228,48 @@ def test_product_tensor_parallel_ranks_in_process_match_the_oracle(tp, temps):
                     near += 1
     assert near <= 2
     assert o.scheduler.is_finished()
+    return shared_seen
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tp,temps", [(2, [0.0, 0.0, 0.0]), (2, [0.0, 0.8, 1.0]), (4, [0.0, 0.0, 0.0])])
+def test_product_tensor_parallel_ranks_in_process_match_the_oracle(tp, temps):
+    """The PRODUCT's tensor-parallel path end to end on one GPU: tp runners of this process (rank r holds its head / column /
+    vocab shard, linear.rs:300-304,421-433,202, embed_head.rs:57-59), one host thread per rank, exchanging at the reference's
+    sites (all-reduce after o_proj and down_proj, (max, argmax) pairs or logits shards for the sampler) through the in-process
+    communicator — the same call sites as RCCL, with a host rendezvous instead of xGMI.  Every rank must schedule the same
+    batches and sample the same tokens as the others, and they must be the oracle's tensor-parallel engine's (teacher-forced):
+    shard logits within tolerance, greedy tokens equal outside numerical near-ties."""
+    import oracle
+    from oracle import model_oracle as mo
+    m = mo.small(seed=6, num_attention_heads=8, num_key_value_heads=4, head_dim=64, hidden_size=256, intermediate_size=512)
+    ecfg = dict(max_num_seqs=4, max_num_batched_tokens=256, max_model_len=128, kvcache_block_size=16, num_kvcache_blocks=24)
+    prompts = [oracle.fill_tokens(n, 5, i, m.vocab_size).tolist() for i, n in enumerate([9, 40, 17])]
+    sps = [dict(temperature=t, max_tokens=10, ignore_eos=True, **({} if t == 0.0 else dict(top_k=30))) for t in temps]
+    _tp_ranks_vs_oracle(tp, m, ecfg, prompts, sps)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("feature", ["qk_norm", "shared_prefix"])
+def test_tensor_parallel_ranks_with_r02_graph_extensions(feature):
+    """The r02 graph extensions on tensor-parallel ranks (tp = 2, in-process): q/k head norms (norm weights replicated, heads
+    sharded) and the shared-prefix decode attention pass (every rank sees the same block tables, so every rank takes it)."""
+    import oracle
+    from oracle import model_oracle as mo
+    V = 1024
+    if feature == "qk_norm":
+        m = mo.small(seed=7, num_attention_heads=8, num_key_value_heads=4, head_dim=64, hidden_size=256, intermediate_size=512, qk_norm=True)
+        ecfg = dict(max_num_seqs=4, max_num_batched_tokens=256, max_model_len=128, kvcache_block_size=16, num_kvcache_blocks=24)
+        prompts = [oracle.fill_tokens(n, 5, i, V).tolist() for i, n in enumerate([9, 40, 17])]
+        sps = [dict(temperature=0.0, max_tokens=10, ignore_eos=True)] * 3
+        assert _tp_ranks_vs_oracle(2, m, ecfg, prompts, sps) == {0}
+    else:
+        m = mo.small(seed=8, num_attention_heads=8, num_key_value_heads=4, head_dim=64, hidden_size=256, intermediate_size=512)
+        ecfg = dict(max_num_seqs=8, max_num_batched_tokens=2048, max_model_len=384, kvcache_block_size=64, num_kvcache_blocks=40)
+        system = oracle.fill_tokens(140, 4, 3, V).tolist()
+        prompts = [system + oracle.fill_tokens(4 + 7 * i, 4, 50 + i, V).tolist() for i in range(6)]
+        sps = [dict(temperature=0.0, max_tokens=9, ignore_eos=True)] * 6
+        assert _tp_ranks_vs_oracle(2, m, ecfg, prompts, sps, product_kw=dict(shared_prefix_min_seqs=3)) == {128}
 
 
 @pytest.mark.gpu
