@@ -130,3 +130,22 @@ def test_configs2_mixed_length_32768_token_prefill_vs_oracle():
     assert st["steps"] == 2 and st["prefill_steps"] == 1 and st["rows"] == 84
     assert st["near_ties"] <= 2, st
     _report("configs2_mixed_32768", st)
+
+
+def test_configs4_shared_system_prompt_vs_oracle():
+    """BASELINE configs[4] geometry at the real model size (48 of the 512 sequences, so that the oracle finishes in a minute): every
+    request = the same 512-token system prompt + 64 own tokens.  BlockManager::allocate must share the two prefix blocks exactly as the
+    oracle's does (block tables compared every step), the prefill skips the cached prefix, and the decode steps take the shared-prefix
+    attention pass (one MFMA pass over the 512 shared keys for the whole batch + the per-sequence remainder) — logits and greedy ids
+    against the oracle's plain paged attention."""
+    n = 48
+    ecfg = dict(max_num_seqs=n, max_num_batched_tokens=32768, max_model_len=640, kvcache_block_size=256, num_kvcache_blocks=n + 8)
+    shared = nvr.synthetic_tokens(512, 2, 0, V).tolist()
+    prompts = [shared + nvr.synthetic_tokens(64, 1, i, V).tolist() for i in range(n)]
+    st, o, p = _pair(ecfg, prompts, 4)
+    assert st["steps"] == 4 and st["prefill_steps"] == 1 and st["rows"] == 4 * n
+    assert st["near_ties"] <= 2, st
+    assert p.model_runner.last_shared_prefix_len() == 512                   # the decode steps did take the shared pass
+    bm = p.scheduler.block_manager.get_stats()
+    st["kv_blocks_total"] = int(bm["total_blocks"])
+    _report("configs4_shared_prefix_48seqs", st)
