@@ -46,9 +46,10 @@ def _run_pair(mcfg, ecfg: dict, prompts, sps, max_steps=400, fp16=True, enforce_
     for pr, sp in zip(prompts, sps):
         o.add_request(pr, eo.SamplingParams(**sp))
         p.add_request(pr, nvr.SamplingParams(**sp))
-    near_ties, steps, max_err, decode_steps = 0, 0, 0.0, 0
+    near_ties, steps, max_err, decode_steps, shared_steps = 0, 0, 0.0, 0, 0
     while not p.is_finished():
         rec = p.step()
+        shared_steps += int(not rec["is_prefill"] and p.model_runner.last_shared_prefix_len() > 0)
         logits = p.model_runner.logits(rec["num_seqs"])
         orec = o.step(forced_tokens=rec["tokens"])
         assert orec["is_prefill"] == rec["is_prefill"] and orec["seq_ids"] == rec["seq_ids"], f"step {steps}: batch differs"
@@ -69,7 +70,7 @@ def _run_pair(mcfg, ecfg: dict, prompts, sps, max_steps=400, fp16=True, enforce_
     assert (ost.finished_sequences, ost.preemptions, ost.prefill_batches, ost.decode_batches) == \
            (pst["finished_sequences"], pst["preemptions"], pst["prefill_batches"], pst["decode_batches"])
     fin = {s.seq_id: s.token_ids for s in p.take_finished()}
-    return dict(steps=steps, decode_steps=decode_steps, near_ties=near_ties, max_err=max_err, finished=fin, oracle=o)
+    return dict(steps=steps, decode_steps=decode_steps, near_ties=near_ties, max_err=max_err, finished=fin, oracle=o, shared_steps=shared_steps)
 
 
 def test_small_model_greedy_end_to_end():
@@ -771,3 +772,37 @@ def test_shared_prefix_decode_attention_engine_parity(shape):
     sps2 = [dict(temperature=0.0, max_tokens=10, ignore_eos=True)] * 7
     m = _run_pair(mcfg, ecfg, prompts2, sps2, product_kw=on)
     assert m["near_ties"] <= 2, m
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13, 14])
+def test_random_workloads_with_shared_prefix_pass(seed):
+    """Randomised soak of the r02 decode extensions together: 64-token blocks, most requests behind one system prompt of 1-3 full
+    blocks (some not: the batch-wide shared length then drops to 0 or to what the batch has in common), shared_prefix_min_seqs = 2,
+    chunked prefill on odd seeds, preemption pressure from a small pool.  Same per-step comparison against the oracle as above."""
+    rng = np.random.default_rng(seed)
+    mcfg = mo.small(seed=seed % 5)
+    V = mcfg.vocab_size
+    nreq = int(rng.integers(6, 12))
+    ecfg = dict(max_num_seqs=int(rng.integers(4, 9)), max_num_batched_tokens=int(rng.choice([512, 1024])), max_model_len=512,
+                kvcache_block_size=64, num_kvcache_blocks=int(rng.integers(16, 30)), enable_chunked_prefill=bool(seed & 1))
+    system = oracle.fill_tokens(64 * 3, seed, 4242, V).tolist()
+    prompts, sps = [], []
+    for i in range(nreq):
+        own = oracle.fill_tokens(int(rng.integers(1, 90)), seed, i, V).tolist()
+        pr = (system[:64 * int(rng.integers(1, 4))] + own) if rng.random() < 0.75 else own
+        prompts.append(pr[:ecfg["max_num_batched_tokens"] - 1])
+        sps.append(dict(temperature=0.0, max_tokens=int(rng.integers(2, 30)), ignore_eos=True))
+    r = _run_pair(mcfg, ecfg, prompts, sps, max_steps=3000, product_kw=dict(shared_prefix_min_seqs=2))
+    assert len(r["finished"]) == nreq
+    assert r["near_ties"] <= 4, r
+    off = _run_pair(mcfg, ecfg, prompts, sps, max_steps=3000, product_kw=dict(shared_prefix_min_seqs=-1))
+    assert off["finished"] == r["finished"] and off["shared_steps"] == 0
+    _SOAK_SEEN["shared_steps"] = _SOAK_SEEN.get("shared_steps", 0) + r["shared_steps"]
+    _SOAK_SEEN["shared_runs"] = _SOAK_SEEN.get("shared_runs", 0) + 1
+    _SOAK_SEEN["shared_preemptions"] = _SOAK_SEEN.get("shared_preemptions", 0) + r["oracle"].scheduler.stats.preemptions
+
+
+def test_random_workloads_did_take_the_shared_prefix_pass():
+    if _SOAK_SEEN.get("shared_runs", 0) < 4:
+        pytest.skip("runs after the four shared-prefix soak cases")
+    assert _SOAK_SEEN["shared_steps"] > 20, _SOAK_SEEN
