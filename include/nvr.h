@@ -459,6 +459,11 @@ NVR_API int nvr_lm_head_tiled(const nvr_half *x, int64_t ldx, const nvr_half *W,
 NVR_API int nvr_linear_resid(const nvr_half *x, int64_t ldx, const nvr_half *W, const nvr_half *Wt, int64_t T, int64_t K, int64_t N,
                              int64_t S, float *slabs, uint32_t *counters, nvr_half *h, void *stream);
 NVR_API int nvr_decode_splitk_slices(int64_t T, int64_t K, int64_t N);
+/* Prefill-sized twin of nvr_linear_resid: h[T,N] <- fp16(h + fp16(x · Wᵀ)) with the residual add (qwen3.rs:382,389) in the epilogue of the
+ * 256x256 MFMA GEMM; only for shapes that kernel takes (T >= 256, N % 256 == 0, K % 64 == 0 and preferred by the routing of nvr_linear:
+ * NVR_ERR_UNSUPPORTED otherwise).  Bit-identical to nvr_linear into a scratch tensor followed by the add of nvr_add_rmsnorm. */
+NVR_API int nvr_linear_add_residual(const nvr_half *x, int64_t ldx, const nvr_half *W, int64_t T, int64_t K, int64_t N, nvr_half *h,
+                                    void *stream);
 NVR_API int nvr_linear_silu_mul_normed(const nvr_half *h, int64_t ldx, const nvr_half *w_norm, float eps, const nvr_half *W,
                                        const nvr_half *Wt, int64_t T, int64_t K, int64_t I, nvr_half *out, void *stream);
 NVR_API int nvr_linear_qkv_rope_store_normed(const nvr_half *h, int64_t ldx, const nvr_half *w_norm, float eps, const nvr_half *W,

@@ -214,6 +214,7 @@ _SIGS = {
     "nvr_retile_weight": (C.c_int, [_P, _P, C.c_int64, C.c_int64, C.c_int, C.c_int64, C.c_int64, C.c_int64, _P]),
     "nvr_linear_resid": (C.c_int, [_P, C.c_int64, _P, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _P, _P, _P, _P]),
     "nvr_decode_splitk_slices": (C.c_int, [C.c_int64, C.c_int64, C.c_int64]),
+    "nvr_linear_add_residual": (C.c_int, [_P, C.c_int64, _P, C.c_int64, C.c_int64, C.c_int64, _P, _P]),
     "nvr_linear_silu_mul_normed": (C.c_int, [_P, C.c_int64, _P, C.c_float, _P, _P, C.c_int64, C.c_int64, C.c_int64, _P, _P]),
     "nvr_linear_qkv_rope_store_normed": (C.c_int, [_P, C.c_int64, _P, C.c_float, _P, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _P, _P,
                                                    _P, _P, _P, _P, _P, _P]),

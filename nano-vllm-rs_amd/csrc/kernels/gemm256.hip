@@ -31,7 +31,7 @@
 
 namespace nvr { namespace k {
 
-enum { GEPI_F16 = 0, GEPI_SILU = 2, GEPI_ROPE = 3 };
+enum { GEPI_F16 = 0, GEPI_RESID = 1, GEPI_SILU = 2, GEPI_ROPE = 3 };   // RESID: y is the residual stream: y <- fp16(y + fp16(x·Wᵀ)) (qwen3.rs:382,389)
 
 struct G256Epi {
     const int64_t *pos; const int32_t *slots; const float *cos_t, *sin_t;
@@ -238,10 +238,22 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const half_t *__restrict__
         }
 #pragma unroll
         for (int hB = 0; hB < 2; ++hB) {
+            // GEPI_RESID: the residual pieces this thread will add to are requested first; their latency runs under the conversion
+            // of the accumulators, the LDS staging and the barrier
+            constexpr int RPC = (EPI == GEPI_RESID) ? (128 * (OUTC / 8)) / 512 : 1;
+            half8_t hres[RPC];
+            if (EPI == GEPI_RESID) {
+#pragma unroll
+                for (int kk = 0; kk < RPC; ++kk) {
+                    const int pidx = tid + kk * 512, row = pidx / (OUTC / 8), ch = pidx % (OUTC / 8);
+                    const int m = m0 + hB * 128 + row, col = bx * OUTC + ch * 8;
+                    hres[kk] = (m < T && col < ldy) ? *reinterpret_cast<const half8_t *>(y + (int64_t)m * ldy + col) : (half8_t)(half_t)0;
+                }
+            }
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int ml = wm * 32 + j * 16 + r;                      // token row inside the half
-                if (EPI == GEPI_F16) {
+                if (EPI == GEPI_F16 || EPI == GEPI_RESID) {
 #pragma unroll
                     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -289,6 +301,22 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const half_t *__restrict__
             }
             __syncthreads();
             constexpr int CPR = OUTC / 8;                                 // 16-byte pieces per row
+            if (EPI == GEPI_RESID) {
+                // h <- fp16(h + fp16(acc)): the rounding points of add_rmsnorm's add
+#pragma unroll
+                for (int kk = 0; kk < (128 * CPR) / 512; ++kk) {
+                    const int pidx = tid + kk * 512, row = pidx / CPR, ch = pidx % CPR;
+                    const int m = m0 + hB * 128 + row, col = bx * OUTC + ch * 8;
+                    if (m >= T || col >= ldy) continue;
+                    const half8_t v8 = *reinterpret_cast<const half8_t *>(scratch + row * (OUTC * 2) + ((ch ^ (row & 15)) << 4));
+                    half8_t o8;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o8[e] = to_half_rn((float)hres[kk][e] + (float)v8[e]);
+                    *reinterpret_cast<half8_t *>(y + (int64_t)m * ldy + col) = o8;
+                }
+                __syncthreads();
+                continue;
+            }
 #pragma unroll
             for (int kk = 0; kk < (128 * CPR) / 512; ++kk) {
                 const int pidx = tid + kk * 512;
@@ -322,7 +350,7 @@ static int g256_prepare() {                                               // 128
     static bool done = false;
     if (done) return 0;
     const void *fns[] = {reinterpret_cast<const void *>(&gemm256_kernel<GEPI_F16>), reinterpret_cast<const void *>(&gemm256_kernel<GEPI_SILU>),
-                         reinterpret_cast<const void *>(&gemm256_kernel<GEPI_ROPE>)};
+                         reinterpret_cast<const void *>(&gemm256_kernel<GEPI_ROPE>), reinterpret_cast<const void *>(&gemm256_kernel<GEPI_RESID>)};
     for (const void *f : fns) {
         hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G_BUF + 4096);
         if (e != hipSuccess) return nvr::fail(NVR_ERR_HIP, "gemm256: hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -368,6 +396,16 @@ int gemm256(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int6
     gemm256_kernel<GEPI_F16><<<dim3((unsigned)g256_grid(tt)), dim3(512), 2 * G_BUF, s>>>((const half_t *)x, ldx, (const half_t *)W, (int)T, (int)K,
                                                                                         (int)N, (int)N, (half_t *)y, G256Epi{}, tx, tt / tx, g256_cg(tx, tt / tx, false));
     return g256_check("gemm256");
+}
+// h[T,N] <- fp16(h + fp16(x·Wᵀ)): the row-parallel GEMM with the residual add of qwen3.rs:382,389 in its epilogue (prefill steps on one
+// rank: the following norm then reads ONE tensor instead of h and the projection)
+int gemm256_resid(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t N, half_bits *h, hipStream_t s) {
+    if (!gemm256_ok(T, K, N, ldx)) return nvr::fail(NVR_ERR_UNSUPPORTED, "gemm256_resid: T=%ld K=%ld N=%ld", (long)T, (long)K, (long)N);
+    if (int rc = g256_prepare()) return rc;
+    const int tx = (int)(N / 256), tt = tx * (int)((T + 255) / 256);
+    gemm256_kernel<GEPI_RESID><<<dim3((unsigned)g256_grid(tt)), dim3(512), 2 * G_BUF, s>>>((const half_t *)x, ldx, (const half_t *)W, (int)T, (int)K,
+                                                                                          (int)N, (int)N, (half_t *)h, G256Epi{}, tx, tt / tx, g256_cg(tx, tt / tx, false));
+    return g256_check("gemm256_resid");
 }
 int gemm256_silu_mul(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t I, half_bits *out, hipStream_t s) {
     if (!gemm256_silu_ok(T, K, I, ldx)) return nvr::fail(NVR_ERR_UNSUPPORTED, "gemm256_silu_mul: T=%ld K=%ld I=%ld", (long)T, (long)K, (long)I);

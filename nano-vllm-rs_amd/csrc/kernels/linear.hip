@@ -242,6 +242,7 @@ static inline bool prefer_256(int64_t T, int64_t K, int64_t N) {
     return c256 < c128;
 }
 // one rule for the plain and the fused launchers (N = output features), so that a fused GEMM and its unfused twin run the same kernel
+bool gemm256_preferred(int64_t T, int64_t K, int64_t N, int64_t ldx) { return gemm256_ok(T, K, N, ldx) && prefer_256(T, K, N); }
 int64_t stream_row_limit() {
     static const int64_t tmax = [] { const char *e = std::getenv("NVR_PREFER_STREAM_T"); return e ? (int64_t)atoll(e) : (int64_t)64; }();
     return tmax;

@@ -501,6 +501,11 @@ int nvr_lm_head_tiled(const nvr_half *x, int64_t ldx, const nvr_half *W, const n
 int nvr_retile_weight(const nvr_half *src, nvr_half *dst, int64_t N, int64_t K, int mode, int64_t H, int64_t KVH, int64_t D, void *s) {
     return k::retile_weight(src, dst, N, K, mode, H, KVH, D, (hipStream_t)s);
 }
+int nvr_linear_add_residual(const nvr_half *x, int64_t ldx, const nvr_half *W, int64_t T, int64_t K, int64_t N, nvr_half *h, void *s) {
+    if (!k::gemm256_preferred(T, K, N, ldx))
+        return nvr::fail(NVR_ERR_UNSUPPORTED, "nvr_linear_add_residual: T=%ld K=%ld N=%ld is not a shape of the 256x256 prefill GEMM", (long)T, (long)K, (long)N);
+    return k::gemm256_resid(x, ldx, W, T, K, N, h, (hipStream_t)s);
+}
 int nvr_linear_resid(const nvr_half *x, int64_t ldx, const nvr_half *W, const nvr_half *Wt, int64_t T, int64_t K, int64_t N, int64_t S,
                      float *slabs, uint32_t *counters, nvr_half *h, void *s) {
     return k::linear_resid(x, ldx, W, T, K, N, S, slabs, counters, h, (hipStream_t)s, Wt);

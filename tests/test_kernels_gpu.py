@@ -1154,3 +1154,29 @@ def test_gemm_tiled_tile_heights(T):
     d_sl = nvr.DeviceBuffer(4 * T * Hd * 4)
     nvr.check(l.nvr_linear_splitk(dev(ab).ptr, H * D, dev(Wob).ptr, T, H * D, Hd, 4, d_sl.ptr, None))
     np.testing.assert_allclose(d_sl.to_numpy((4, T, Hd), np.float32).sum(0), oracle.linear(a, Wo), rtol=2e-5, atol=3e-4)
+
+
+@pytest.mark.parametrize("T,K,N", [(16384, 2048, 1024), (16384, 3072, 1024), (1000, 1024, 512)])
+def test_linear_add_residual_prefill(T, K, N):
+    """nvr_linear_add_residual (256x256 GEMM with the residual add in its epilogue) == nvr_linear into a scratch tensor followed by
+    nvr_add_rmsnorm's add, bit for bit (same fp16 rounding points), and within GEMM tolerance of the oracle; shapes the 256x256
+    kernel does not take are refused."""
+    rng = np.random.default_rng(90)
+    x, xb = h16(rng.standard_normal((T, K)) * 0.3)
+    W, Wb = h16(rng.standard_normal((N, K)) * 0.05)
+    h, hb = h16(rng.standard_normal((T, N)))
+    w1 = dev(h16(np.ones(N))[1])
+    d_x, d_W = dev(xb), dev(Wb)
+    d_h1, d_h2, d_y, d_n = dev(hb.copy()), dev(hb.copy()), nvr.DeviceBuffer(T * N * 2), nvr.DeviceBuffer(T * N * 2)
+    _KEEP.extend([d_y, d_n])
+    rc = nvr.lib().nvr_linear_add_residual(d_x.ptr, K, d_W.ptr, T, K, N, d_h1.ptr, None)
+    if T < 2048:                                       # small tile counts go to the 128x128 kernel: not this entry point's business
+        assert rc == -10
+        return
+    nvr.check(rc)
+    nvr.check(nvr.lib().nvr_linear(d_x.ptr, K, d_W.ptr, T, K, N, d_y.ptr, 0, None))
+    nvr.check(nvr.lib().nvr_add_rmsnorm(d_h2.ptr, d_y.ptr, w1.ptr, 1e-6, T, N, d_n.ptr, None))
+    assert np.array_equal(d_h1.to_numpy((T, N), np.uint16), d_h2.to_numpy((T, N), np.uint16))
+    ref = oracle.add(h, oracle.round_f16(oracle.linear(x[:64], W)), round16=True) if False else None
+    part = oracle.round_f16(oracle.linear(x[:64], W))
+    assert_close_f16(d_h1.to_numpy((T, N), F16)[:64], oracle.add(h[:64], part, round16=True), ulps=2, atol=2e-3, what="h + x W^T")
