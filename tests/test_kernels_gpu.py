@@ -1180,3 +1180,40 @@ def test_linear_add_residual_prefill(T, K, N):
     ref = oracle.add(h, oracle.round_f16(oracle.linear(x[:64], W)), round16=True) if False else None
     part = oracle.round_f16(oracle.linear(x[:64], W))
     assert_close_f16(d_h1.to_numpy((T, N), F16)[:64], oracle.add(h[:64], part, round16=True), ulps=2, atol=2e-3, what="h + x W^T")
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_paged_attn_decode_shared_prefix_random_geometries(seed):
+    """Random geometries of the shared-prefix decode attention: head_dim 64 / 128, group 1 / 2 / 4, block size 64 / 128 / 256, 1-4 shared
+    blocks, 2-200 sequences with 0-3 blocks of own tokens (some with none), against the plain kernel on the same inputs."""
+    rng = np.random.default_rng(700 + seed)
+    D = int(rng.choice([64, 128])); G = int(rng.choice([1, 2, 4])); KVH = int(rng.choice([1, 2, 4])); H = G * KVH
+    bs = int(rng.choice([64, 128, 256])); P = int(rng.integers(1, 5)); B = int(rng.integers(2, 201))
+    own = [int(x) for x in rng.integers(0, 3 * bs, B)]
+    for i in rng.integers(0, B, max(1, B // 8)):
+        own[int(i)] = 0
+    S = P * bs
+    ctxs = [S + o for o in own]
+    own_blocks = [(o + bs - 1) // bs for o in own]
+    NB = P + sum(own_blocks) + 2
+    max_blocks = P + max(own_blocks) + 1
+    kcb = (rng.standard_normal((NB, bs, KVH, D))).astype(F16); vcb = (rng.standard_normal((NB, bs, KVH, D))).astype(F16)
+    perm = rng.permutation(NB)
+    bt = -np.ones((B, max_blocks), np.int32)
+    o = P
+    for b in range(B):
+        bt[b, :P] = perm[:P]
+        bt[b, P:P + own_blocks[b]] = perm[o:o + own_blocks[b]]; o += own_blocks[b]
+    qb = (rng.standard_normal((B, H, D))).astype(F16)
+    scale = float(np.float32(1.0) / np.sqrt(np.float32(D)))
+    meta = nvr.AttnMetaC()
+    d_ctx, d_bt = dev(np.asarray(ctxs, np.int32)), dev(bt)
+    meta.is_prefill, meta.context_lens, meta.block_tables = 0, d_ctx.ptr, d_bt.ptr
+    meta.max_blocks, meta.batch, meta.max_context_len = max_blocks, B, int(max(ctxs))
+    ws = nvr.DeviceBuffer(nvr.lib().nvr_paged_attn_workspace_bytes(B, H, D, int(max(ctxs)) + bs))
+    d_out, d_plain = nvr.DeviceBuffer(B * H * D * 2), nvr.DeviceBuffer(B * H * D * 2)
+    d_q, d_k, d_v = dev(qb), dev(kcb), dev(vcb)
+    nvr.check(nvr.lib().nvr_paged_attn_decode_shared(d_q.ptr, H * D, d_k.ptr, d_v.ptr, C.byref(meta), H, KVH, D, bs, scale, S, d_out.ptr, ws.ptr, None))
+    nvr.check(nvr.lib().nvr_paged_attn_decode(d_q.ptr, H * D, d_k.ptr, d_v.ptr, C.byref(meta), H, KVH, D, bs, scale, d_plain.ptr, ws.ptr, None))
+    assert_close_f16(d_out.to_numpy((B, H, D), F16), d_plain.to_numpy((B, H, D), F16), ulps=3, atol=1e-3,
+                     what=f"D={D} G={G} KVH={KVH} bs={bs} P={P} B={B}")
