@@ -273,6 +273,7 @@ NVR_API int nvr_runner_p2p_disable(nvr_model_runner_t *r);
 NVR_API int nvr_runner_p2p_active(const nvr_model_runner_t *r);
 /* tokens of the last decode step that went through the shared-prefix attention pass (nvr_config.shared_prefix_min_seqs); 0 = plain */
 NVR_API int64_t nvr_runner_last_shared_prefix_len(const nvr_model_runner_t *r);
+NVR_API int64_t nvr_runner_last_shared_prefix_rows(const nvr_model_runner_t *r);   /* sequences of that step inside the sharing group */
 
 /* -------------------------------------------------------------------- Engine ---- */
 /* LLMEngine::step loop, src/engine/llm_engine.rs:155-197 (driver of the hot path only) */
@@ -501,10 +502,14 @@ NVR_API int nvr_paged_attn_decode(const nvr_half *q, int64_t ldq, const nvr_half
 /* The same when EVERY sequence of the batch holds its first shared_len tokens (a multiple of block_size) in the cache blocks that
  * block-table row 0 starts with (prefix-cache hits of BlockManager::allocate, block_manager.rs:181-197; BASELINE configs[4]): the
  * shared keys go through one MFMA pass for the whole batch, the remainder per sequence, merged as split-KV partials.  Same
- * semantics as nvr_paged_attn_decode (A-8); workspace sized by nvr_paged_attn_workspace_bytes. */
+ * semantics as nvr_paged_attn_decode (A-8); workspace sized by nvr_paged_attn_workspace_bytes.
+ * rows / kv0 / count (device arrays, all three or all NULL): only the sequences rows[0 .. *count) share the prefix (the block table
+ * of rows[0] names the shared blocks); kv0[b] = shared_len for those, 0 for every other sequence, which is attended to in full by
+ * the per-sequence kernel. */
 NVR_API int nvr_paged_attn_decode_shared(const nvr_half *q, int64_t ldq, const nvr_half *k_cache, const nvr_half *v_cache,
                                          const nvr_attn_meta *meta, int64_t H, int64_t KVH, int64_t D, int64_t block_size,
-                                         float scale, int64_t shared_len, nvr_half *out, void *workspace, void *stream);
+                                         float scale, int64_t shared_len, const int32_t *rows, const int32_t *kv0, const int32_t *count,
+                                         nvr_half *out, void *workspace, void *stream);
 /* K7 varlen causal prefill attention, attention.rs:177-208 (q,k,v inside packed qkv, stride ld) */
 NVR_API int nvr_attn_prefill_varlen(const nvr_half *q, const nvr_half *k, const nvr_half *v, int64_t ld,
                                     const nvr_attn_meta *meta, int64_t T, int64_t H, int64_t KVH, int64_t D,

@@ -181,7 +181,7 @@ _SIGS = {
     "nvr_runner_init_comm_local": (C.c_int, [_P, _P]), "nvr_local_group_set_p2p": (C.c_int, [_P, C.c_int]),
     "nvr_runner_p2p_export": (C.c_int, [_P, _P]), "nvr_runner_p2p_attach": (C.c_int, [_P, _P, _P]),
     "nvr_runner_p2p_disable": (C.c_int, [_P]), "nvr_runner_p2p_active": (C.c_int, [_P]),
-    "nvr_runner_last_shared_prefix_len": (C.c_int64, [_P]),
+    "nvr_runner_last_shared_prefix_len": (C.c_int64, [_P]), "nvr_runner_last_shared_prefix_rows": (C.c_int64, [_P]),
     "nvr_engine_last_step": (None, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(C.c_size_t)]),
     "nvr_engine_take_finished": (C.c_size_t, [_P, C.POINTER(_P), C.c_size_t]),
     "nvr_engine_last_batch": (C.c_size_t, [_P, C.POINTER(_P), C.c_size_t]),
@@ -229,7 +229,7 @@ _SIGS = {
     "nvr_paged_attn_decode": (C.c_int, [_P, C.c_int64, _P, _P, C.POINTER(AttnMetaC), C.c_int64, C.c_int64, C.c_int64,
                                         C.c_int64, C.c_float, _P, _P, _P]),
     "nvr_paged_attn_decode_shared": (C.c_int, [_P, C.c_int64, _P, _P, C.POINTER(AttnMetaC), C.c_int64, C.c_int64, C.c_int64,
-                                               C.c_int64, C.c_float, C.c_int64, _P, _P, _P]),
+                                               C.c_int64, C.c_float, C.c_int64, _P, _P, _P, _P, _P, _P]),
     "nvr_attn_prefill_varlen": (C.c_int, [_P, _P, _P, C.c_int64, C.POINTER(AttnMetaC), C.c_int64, C.c_int64, C.c_int64,
                                           C.c_int64, C.c_float, _P, _P]),
     "nvr_attn_prefill_paged": (C.c_int, [_P, C.c_int64, _P, _P, C.POINTER(AttnMetaC), C.c_int64, C.c_int64, C.c_int64, C.c_int64,
@@ -676,6 +676,10 @@ class ModelRunner:
     def last_shared_prefix_len(self) -> int:
         """Tokens of the last decode step that went through the shared-prefix attention pass (0: plain paged attention)."""
         return int(lib().nvr_runner_last_shared_prefix_len(self.h))
+
+    def last_shared_prefix_rows(self) -> int:
+        """How many sequences of the last decode step were inside the sharing group (0: no shared pass)."""
+        return int(lib().nvr_runner_last_shared_prefix_rows(self.h))
 
 
 class LocalGroup:

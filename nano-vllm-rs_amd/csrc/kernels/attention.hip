@@ -36,6 +36,7 @@ struct AttnParams {
     int32_t part_size, num_parts;
     int32_t part0, kv0;                // shared-prefix decode: partitions 0..part0-1 hold the batch's shared keys [0, kv0) (written by
                                        // flash_shared_prefix); this launch covers partition part0 + i = keys [kv0 + i*part_size, ..)
+    const int32_t *kv0_rows;           // per-query kv0 (shared-prefix groups: members shared_len, others 0) or null = p.kv0 for all
     float *part_o; float *part_ml;     // [nq, H, num_parts, D], [nq, H, num_parts, 2]
     half_t *out;                       // [nq, H, D]
     unsigned long long *stamps;        // NVR_ATTN_EXPERIMENTS: 5 wall_clock64 stamps per workgroup (or null)
@@ -80,7 +81,7 @@ __global__ __launch_bounds__(WAVES * 64) void attn_rows_kernel(AttnParams p) {
     const int t = blockIdx.x / (lparts * p.KVH);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int dc = lane % LPR, tg = lane / LPR;
-    const int p0 = p.kv0 + (part - p.part0) * p.part_size;
+    const int p0 = (p.kv0_rows ? p.kv0_rows[t] : p.kv0) + (part - p.part0) * p.part_size;
 
     const int32_t *bt = PAGED ? p.block_tables + (int64_t)(p.seq_of_q ? p.seq_of_q[t] : t) * p.max_blocks : nullptr;
     int bt_chunk = -1, bt_reg = 0;                   // UB: register copy of 64 block-table entries
@@ -294,13 +295,16 @@ __global__ __launch_bounds__(WAVES * 64) void attn_rows_kernel(AttnParams p) {
 template <int D>
 __global__ __launch_bounds__(256) void attn_merge_kernel(const float *__restrict__ part_o, const float *__restrict__ part_ml,
                                                          const int32_t *__restrict__ ctx_lens, int H, int part_size, int num_parts,
-                                                         int part0, int kv0, int64_t pairs, half_t *__restrict__ out) {
+                                                         int part0, int kv0, const int32_t *__restrict__ kv0_rows, int64_t pairs,
+                                                         half_t *__restrict__ out) {
     constexpr int TPP = D / 4;                                   // threads per (query, head) pair
     const int64_t pair = (int64_t)blockIdx.x * (256 / TPP) + threadIdx.x / TPP;
     if (pair >= pairs) return;
     const int t = (int)(pair / H), d = (threadIdx.x % TPP) * 4;
-    const int np = min(num_parts, part0 + (max(ctx_lens[t] - kv0, 0) + part_size - 1) / part_size);
-    const int64_t base = pair * num_parts;
+    const int my_kv0 = kv0_rows ? kv0_rows[t] : kv0;
+    const int first = (part0 > 0 && my_kv0 == 0) ? part0 : 0;   // a query outside the sharing group has no partials in the shared slots
+    const int np = min(num_parts, part0 + (max(ctx_lens[t] - my_kv0, 0) + part_size - 1) / part_size) - first;
+    const int64_t base = pair * num_parts + first;
     float M = -INFINITY;
     float4_t o = {0.f, 0.f, 0.f, 0.f};
     float L = 0.f;
@@ -414,9 +418,18 @@ static int launch_attn(const AttnArgs &a, bool paged, hipStream_t s) {
         const int64_t wgs = (int64_t)((a.nq + qb - 1) / qb) * a.KVH, n64 = a.shared_len / 64;
         int64_t c = std::min<int64_t>(std::max<int64_t>(1, (256 + wgs - 1) / wgs), n64);
         while (n64 % c) --c;
-        sparts = (int)c; shared_part = a.shared_len / sparts;
-        const int64_t rest = std::max<int64_t>(mc - a.shared_len, 64);
-        const int64_t want = pairs >= 192 ? 1 : (256 + pairs - 1) / pairs;
+        sparts = (int)c;
+        const bool grouped = a.shared_rows != nullptr;
+        if (grouped && (!a.shared_kv0 || !a.shared_count)) return nvr::fail(NVR_ERR_INVALID_ARG, "attention: shared_rows / shared_kv0 / shared_count come together");
+        const int64_t rest = std::max<int64_t>(grouped ? mc : mc - a.shared_len, 64);   // a query outside the group reads its whole context
+        // the workspace holds cap partials per (query, head) (nvr_paged_attn_workspace_bytes: one per 64 tokens of the context bound):
+        // the shared partitions and the remainder's together must fit
+        const int64_t cap = a.workspace_bytes ? (int64_t)(a.workspace_bytes / ((size_t)a.nq * a.H * (D + 2) * sizeof(float))) : (mc + 63) / 64;
+        if (cap < 2) return nvr::fail(NVR_ERR_INVALID_ARG, "attention: workspace too small for the shared-prefix pass");
+        while (sparts > 1 && sparts > cap / 2) { --sparts; while (n64 % sparts) --sparts; }
+        shared_part = a.shared_len / sparts;
+        int64_t want = pairs >= 192 ? 1 : (256 + pairs - 1) / pairs;
+        want = std::max<int64_t>(1, std::min<int64_t>(want, cap - sparts));
         part_size = (int)(((rest + want - 1) / want + 63) / 64 * 64);
         np = sparts + (int)((rest + part_size - 1) / part_size);
         waves = tn.waves ? tn.waves : 4;
@@ -438,11 +451,11 @@ static int launch_attn(const AttnArgs &a, bool paged, hipStream_t s) {
         p.part_o = (float *)a.workspace;
         p.part_ml = p.part_o + (int64_t)a.nq * a.H * np * D;
     }
-    p.part0 = sparts; p.kv0 = shared ? a.shared_len : 0;
+    p.part0 = sparts; p.kv0 = shared ? a.shared_len : 0; p.kv0_rows = shared ? a.shared_kv0 : nullptr;
     const int64_t nwg = (int64_t)(p.num_parts - p.part0) * a.KVH * a.nq;
     if (shared)
         if (int rc = flash_shared_prefix(a.q, a.ldq, a.k, a.v, a.block_tables, a.max_blocks, a.block_size, a.nq, a.H, a.KVH, a.D, a.scale,
-                                         shared_part, sparts, np, p.part_o, p.part_ml, s)) return rc;
+                                         shared_part, sparts, np, p.part_o, p.part_ml, s, a.shared_rows, a.shared_count)) return rc;
     bool done = false;
 #ifdef NVR_ATTN_EXPERIMENTS
     if (direct && a.workspace && std::getenv("NVR_ATTN_STAMPS")) p.stamps = (unsigned long long *)a.workspace;
@@ -464,7 +477,7 @@ static int launch_attn(const AttnArgs &a, bool paged, hipStream_t s) {
     }
     if (!direct)
         attn_merge_kernel<D><<<dim3((unsigned)(((int64_t)a.H * a.nq + 256 / (D / 4) - 1) / (256 / (D / 4)))), dim3(256), 0, s>>>(
-            p.part_o, p.part_ml, a.ctx_lens, a.H, part_size, np, p.part0, p.kv0, (int64_t)a.H * a.nq, p.out);
+            p.part_o, p.part_ml, a.ctx_lens, a.H, part_size, np, p.part0, p.kv0, p.kv0_rows, (int64_t)a.H * a.nq, p.out);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return nvr::fail(NVR_ERR_HIP, "attention launch failed: %s", hipGetErrorString(e));
     return 0;

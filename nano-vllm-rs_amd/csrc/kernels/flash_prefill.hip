@@ -41,6 +41,7 @@ struct FlashParams {
     // partition blockIdx.y))
     int32_t nq_total, shared_len, num_parts;
     float *part_o, *part_ml;
+    const int32_t *srows, *scount;     // optional: only the rows srows[0 .. *scount) of the batch share the prefix (row srows[0] names its blocks)
 };
 
 typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
@@ -82,8 +83,9 @@ __global__ __launch_bounds__(64 * FLASH_WAVES, 8 / FLASH_WAVES) void flash_prefi
     if (SHARED) {
         constexpr int QB = 32 * FLASH_WAVES / G;                      // sequences per workgroup
         tile.q_row0 = (int)(blockIdx.x / p.KVH) * QB;
-        tile.nq = min(QB, p.nq_total - tile.q_row0);
-        tile.pos0 = 0x3fffffff; tile.kv_ref = 0;
+        tile.nq = min(QB, (p.scount ? *p.scount : p.nq_total) - tile.q_row0);
+        if (tile.nq <= 0) return;                                     // (workgroup-uniform: the launch is sized for the whole batch)
+        tile.pos0 = 0x3fffffff; tile.kv_ref = p.srows ? p.srows[0] : 0;
     } else tile = p.tiles[blockIdx.x / p.KVH];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int r = lane & 15, g4 = lane >> 4;
@@ -92,7 +94,7 @@ __global__ __launch_bounds__(64 * FLASH_WAVES, 8 / FLASH_WAVES) void flash_prefi
     const int kv_end = SHARED ? kv_start + p.shared_len : tile.pos0 + tile.nq;
 
     // the wave's two query tiles: head and position block
-    int qi[NQT], head[NQT], qpos[NQT]; bool qvalid[NQT];
+    int qi[NQT], head[NQT], qpos[NQT], qrow[NQT]; bool qvalid[NQT];
     half8_t qf[NQT][NKS];
 #pragma unroll
     for (int t = 0; t < NQT; ++t) {
@@ -104,9 +106,10 @@ __global__ __launch_bounds__(64 * FLASH_WAVES, 8 / FLASH_WAVES) void flash_prefi
         qvalid[t] = qi[t] < tile.nq;
         const int qc = qvalid[t] ? qi[t] : tile.nq - 1;
         qpos[t] = SHARED ? 0x3fffffff : tile.pos0 + qc;           // absolute position = last visible key
-        const half_t *qrow = p.q + (int64_t)(tile.q_row0 + qc) * p.ldq + (int64_t)head[t] * D + g4 * 8;
+        qrow[t] = (SHARED && p.srows) ? p.srows[tile.q_row0 + qc] : tile.q_row0 + qc;
+        const half_t *qptr = p.q + (int64_t)qrow[t] * p.ldq + (int64_t)head[t] * D + g4 * 8;
 #pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) qf[t][ks] = *reinterpret_cast<const half8_t *>(qrow + ks * 32);
+        for (int ks = 0; ks < NKS; ++ks) qf[t][ks] = *reinterpret_cast<const half8_t *>(qptr + ks * 32);
     }
 
     // last key any lane of this wave may attend to: a step that starts beyond it does no arithmetic in this wave
@@ -296,7 +299,7 @@ __global__ __launch_bounds__(64 * FLASH_WAVES, 8 / FLASH_WAVES) void flash_prefi
 #pragma unroll
         for (int t = 0; t < NQT; ++t) {
             if (!qvalid[t]) continue;
-            const int64_t slot = ((int64_t)(tile.q_row0 + qi[t]) * p.H + head[t]) * p.num_parts + blockIdx.y;
+            const int64_t slot = ((int64_t)qrow[t] * p.H + head[t]) * p.num_parts + blockIdx.y;
             float *po = p.part_o + slot * D + g4 * 4;
 #pragma unroll
             for (int dt = 0; dt < NDT; ++dt) *reinterpret_cast<float4_t *>(po + dt * 16) = o[t][dt];
@@ -309,7 +312,7 @@ __global__ __launch_bounds__(64 * FLASH_WAVES, 8 / FLASH_WAVES) void flash_prefi
         if (qvalid[t]) {
             const float ls = ol[t][0];                          // every row of the ones-product holds the query's sum
             const float inv = ls > 0.f ? 1.0f / ls : 0.f;
-            half_t *orow = p.out + ((int64_t)(tile.q_row0 + qi[t]) * p.H + head[t]) * D + g4 * 4;
+            half_t *orow = p.out + ((int64_t)qrow[t] * p.H + head[t]) * D + g4 * 4;
 #pragma unroll
             for (int dt = 0; dt < NDT; ++dt) {
                 half4_t hv = {(half_t)(o[t][dt][0] * inv), (half_t)(o[t][dt][1] * inv), (half_t)(o[t][dt][2] * inv), (half_t)(o[t][dt][3] * inv)};
@@ -355,7 +358,8 @@ int flash_prefill(const FlashArgs &a, bool paged, hipStream_t s) {
 // num_parts, 2] slots (row, head, partition).
 int flash_shared_prefix(const half_bits *q, int64_t ldq, const half_bits *k_cache, const half_bits *v_cache, const int32_t *block_tables,
                         int32_t max_blocks, int32_t block_size, int32_t nq, int32_t H, int32_t KVH, int32_t D, float scale,
-                        int32_t part_len, int32_t sparts, int32_t num_parts, float *part_o, float *part_ml, hipStream_t s) {
+                        int32_t part_len, int32_t sparts, int32_t num_parts, float *part_o, float *part_ml, hipStream_t s,
+                        const int32_t *rows, const int32_t *count) {
     if (nq == 0) return 0;
     const bool pow2 = block_size > 0 && (block_size & (block_size - 1)) == 0;
     const int32_t shared_len = part_len;
@@ -365,7 +369,7 @@ int flash_shared_prefix(const half_bits *q, int64_t ldq, const half_bits *k_cach
     p.q = (const half_t *)q; p.ldq = ldq; p.k = (const half_t *)k_cache; p.v = (const half_t *)v_cache;
     p.block_tables = block_tables; p.max_blocks = max_blocks; p.block_size = block_size; p.bs_shift = __builtin_ctz(block_size);
     p.H = H; p.KVH = KVH; p.scale = scale; p.nq_total = nq; p.shared_len = shared_len; p.num_parts = num_parts;
-    p.part_o = part_o; p.part_ml = part_ml;
+    p.part_o = part_o; p.part_ml = part_ml; p.srows = rows; p.scount = count;
     const int G = H / KVH, qb = flash_tile_positions(H, KVH);
     dim3 grid((unsigned)((int64_t)((nq + qb - 1) / qb) * KVH), (unsigned)sparts), block(64 * FLASH_WAVES);
 #define NVR_FLASH_S(DD, GG) if (D == DD && G == GG) flash_prefill_kernel<DD, GG, true, true, true><<<grid, block, 0, s>>>(p);

@@ -141,6 +141,9 @@ struct AttnArgs {
     int32_t shared_len;                        // paged decode: > 0 = every query's first shared_len keys sit in the blocks of
                                                // block-table row 0 (a multiple of block_size): that prefix goes through the MFMA
                                                // kernel once for the whole batch (flash_shared_prefix), the rest per sequence
+    // ... or only SOME queries' (device arrays, all three or none): shared_rows[0 .. *shared_count) are the member rows (the
+    // first one's block table names the shared blocks), shared_kv0[t] = shared_len for members, 0 for the others
+    const int32_t *shared_rows, *shared_kv0, *shared_count;
 };
 size_t attn_workspace_bytes(int64_t nq, int64_t H, int64_t D, int64_t max_ctx);
 int attention(const AttnArgs &a, bool paged, hipStream_t s);
@@ -161,7 +164,8 @@ int flash_tile_positions(int H, int KVH);
 int flash_prefill(const FlashArgs &a, bool paged, hipStream_t s);
 int flash_shared_prefix(const half_bits *q, int64_t ldq, const half_bits *k_cache, const half_bits *v_cache, const int32_t *block_tables,
                         int32_t max_blocks, int32_t block_size, int32_t nq, int32_t H, int32_t KVH, int32_t D, float scale,
-                        int32_t part_len, int32_t sparts, int32_t num_parts, float *part_o, float *part_ml, hipStream_t s);
+                        int32_t part_len, int32_t sparts, int32_t num_parts, float *part_o, float *part_ml, hipStream_t s,
+                        const int32_t *rows = nullptr, const int32_t *count = nullptr);
 
 // sampler (top-k / top-p / gumbel)
 size_t sample_workspace_bytes(int64_t B, int64_t V);

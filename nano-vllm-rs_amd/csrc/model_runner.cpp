@@ -124,6 +124,7 @@ int nvr_model_runner::init() {                                       // ModelRun
         size_t o = 0;
         auto sub = [&](size_t &f, size_t bytes) { f = o; o += (bytes + 15) / 16 * 16; };
         sub(dof_ids, max_seqs * 8); sub(dof_pos, max_seqs * 8); sub(dof_slots, max_seqs * 4); sub(dof_ctx, max_seqs * 4);
+        sub(dof_skv0, max_seqs * 4); sub(dof_srows, max_seqs * 4); sub(dof_scount, 16);
         sub(dof_bt, max_seqs * max_blocks_per_seq * 4);
         dec_bytes = o; carve(off_dec, dec_bytes);
     }
@@ -393,30 +394,60 @@ bool nvr_model_runner::use_chain4(int64_t T, bool is_prefill) const {
            H * D <= 4096 && I <= 8192 && Hd * std::max(H * D, I) * 2 < (24ll << 20);
 }
 
-// Decode batches whose sequences ALL start with the same cache blocks (prefix-cache hits of BlockManager::allocate,
-// block_manager.rs:181-197: one system prompt in front of every request, BASELINE configs[4]): the length of that common run of
-// full blocks.  The attention launch then sends those keys through one MFMA pass for the whole batch (kernels/flash_prefill.hip,
-// SHARED) instead of once per sequence.  Batches under nvr_config.shared_prefix_min_seqs sequences (default 32) and block sizes
-// the kernel does not take keep the plain kernel.
-int64_t nvr_model_runner::shared_prefix_len(nvr_seq *const *seqs, size_t nseq) const {
+// Decode batches in which many sequences start with the same cache blocks (prefix-cache hits of BlockManager::allocate,
+// block_manager.rs:181-197: one system prompt in front of the requests, BASELINE configs[4]).  The GROUP is the set of sequences
+// whose first block is the batch's majority first block (no majority: no group); its shared length is the run of full blocks all members have in common.  The
+// attention launch then sends those keys through one MFMA pass for the whole group (kernels/flash_prefill.hip, SHARED) instead of
+// once per sequence; sequences outside the group (kv0 = 0) are attended to in full by the row kernel.  Groups under
+// nvr_config.shared_prefix_min_seqs sequences (default 32) and block sizes the kernel does not take keep the plain kernel.
+int64_t nvr_model_runner::shared_prefix_plan(nvr_seq *const *seqs, size_t nseq, int32_t *kv0, int32_t *rows, int32_t *count,
+                                             int64_t *members) const {
+    *members = 0;
     const int64_t min_seqs = cfg.shared_prefix_min_seqs == 0 ? 32 : cfg.shared_prefix_min_seqs;
     if (min_seqs < 0 || (int64_t)nseq < min_seqs || nseq < 2) return 0;
     if (block_size < 64 || (block_size & (block_size - 1)) || !k::flash_prefill_ok((int)D, (int)H, (int)KVH)) return 0;
-    const auto &t0 = seqs[0]->block_table;
-    size_t common = std::min<size_t>(t0.size(), (size_t)(((int64_t)seqs[0]->len() - 1) / block_size));   // full blocks below the last token
-    for (size_t b = 1; b < nseq && common > 0; ++b) {
-        const auto &t = seqs[b]->block_table;
-        common = std::min<size_t>(common, std::min<size_t>(t.size(), (size_t)(((int64_t)seqs[b]->len() - 1) / block_size)));
-        size_t j = 0;
-        while (j < common && t[j] == t0[j]) ++j;
-        common = j;
+    auto full_blocks = [&](const nvr_seq &s) {                            // full blocks below the token of this step
+        return std::min<size_t>(s.block_table.size(), (size_t)(((int64_t)s.len() - 1) / block_size));
+    };
+    // majority first block among the sequences that have a full one (Boyer-Moore vote, then a count)
+    int32_t cand = -1; int64_t votes = 0;
+    for (size_t b = 0; b < nseq; ++b) {
+        if (full_blocks(*seqs[b]) == 0) continue;
+        const int32_t f = seqs[b]->block_table[0];
+        if (votes == 0) { cand = f; votes = 1; } else votes += (f == cand) ? 1 : -1;
     }
-    return (int64_t)common * block_size;
+    if (cand < 0) return 0;
+    size_t common = SIZE_MAX; int64_t n = 0; const nvr_seq *first = nullptr;
+    for (size_t b = 0; b < nseq; ++b) {
+        const nvr_seq &s = *seqs[b];
+        const size_t fb = full_blocks(s);
+        if (fb == 0 || s.block_table[0] != cand) continue;
+        if (!first) { first = &s; common = fb; }
+        else {
+            size_t j = 0;
+            const size_t lim = std::min(common, fb);
+            while (j < lim && s.block_table[j] == first->block_table[j]) ++j;
+            common = j;
+        }
+        ++n;
+    }
+    if (n < min_seqs || n < 2 || common == 0 || common == SIZE_MAX) return 0;
+    const int64_t S = (int64_t)common * block_size;
+    int64_t m = 0;
+    for (size_t b = 0; b < nseq; ++b) {
+        const nvr_seq &s = *seqs[b];
+        const bool in = full_blocks(s) >= common && s.block_table[0] == cand;
+        kv0[b] = in ? (int32_t)S : 0;
+        if (in) rows[m++] = (int32_t)b;
+    }
+    for (size_t b = (size_t)m; b < nseq; ++b) rows[b] = rows[0];
+    *count = (int32_t)m; *members = m;
+    return S;
 }
 
-// a captured decode step is a function of (batch size, context bucket, shared-prefix length, logits wanted)
-static inline uint64_t graph_key(bool want_logits, size_t nseq, int64_t bucket, int64_t shared_len) {
-    return ((uint64_t)want_logits << 63) | ((uint64_t)nseq << 44) | ((uint64_t)(shared_len / 64) << 24) | (uint64_t)(bucket / 256);
+// a captured decode step is a function of (batch size, context bucket, shared-prefix length, whole batch or a group of it, logits wanted)
+static inline uint64_t graph_key(bool want_logits, size_t nseq, int64_t bucket, int64_t shared_len, bool group) {
+    return ((uint64_t)want_logits << 63) | ((uint64_t)group << 62) | ((uint64_t)nseq << 44) | ((uint64_t)(shared_len / 64) << 24) | (uint64_t)(bucket / 256);
 }
 
 // Qwen3Model::forward, src/models/qwen3.rs:487-505; layer wiring :372-392; attention :208-240; MLP :305-314.
@@ -465,6 +496,10 @@ int nvr_model_runner::forward(int64_t T, int64_t B, bool is_prefill, int64_t max
             a.k = k_cache(l); a.v = v_cache(l); a.block_tables = bt; a.max_blocks = (int32_t)max_blocks_per_seq;
             a.block_size = (int32_t)block_size; a.workspace = attn_ws; a.workspace_bytes = attn_ws_bytes;
             a.shared_len = (int32_t)decode_shared_len;
+            if (decode_shared_len > 0 && decode_shared_rows < T) {     // a group inside the batch: per-row kv0, member rows, member count
+                a.shared_kv0 = (const int32_t *)(in_dev + off_dec + dof_skv0); a.shared_rows = (const int32_t *)(in_dev + off_dec + dof_srows);
+                a.shared_count = (const int32_t *)(in_dev + off_dec + dof_scount);
+            }
             RC(k::attention(a, true, st));
         }
         if (c4) {
@@ -608,7 +643,8 @@ int nvr_model_runner::execute(nvr_seq *const *seqs, size_t nseq, bool is_prefill
             max_ctx = std::max(max_ctx, len);
         }
         T = (int64_t)nseq;
-        decode_shared_len = shared_prefix_len(seqs, nseq);
+        decode_shared_len = shared_prefix_plan(seqs, nseq, (int32_t *)(hd + dof_skv0), (int32_t *)(hd + dof_srows), (int32_t *)(hd + dof_scount),
+                                               &decode_shared_rows);
     }
     // one H2D per array actually used this step (K19)
     auto up = [&](size_t off, size_t bytes) { return hipMemcpyAsync(in_dev + off, in_host + off, bytes, hipMemcpyHostToDevice, stream); };
@@ -633,7 +669,7 @@ int nvr_model_runner::execute(nvr_seq *const *seqs, size_t nseq, bool is_prefill
 
     // decode: replay a hipGraph captured per (batch size, context bucket) — execute_with_cuda_graph :303-326
     const int64_t bucket = (max_ctx + 255) / 256 * 256;
-    const uint64_t key = graph_key(want_logits, nseq, bucket, decode_shared_len);
+    const uint64_t key = graph_key(want_logits, nseq, bucket, decode_shared_len, decode_shared_len > 0 && decode_shared_rows < (int64_t)nseq);
     auto it = graphs.find(key);
     if (it == graphs.end()) {
         if (graphs.size() >= kMaxGraphs) {               // a long-lived engine sees many (batch size, bucket) pairs: bound the cache
@@ -688,8 +724,9 @@ int nvr_model_runner::execute_decode_ahead(nvr_seq *const *seqs, size_t nseq, in
         for (int64_t j = (int64_t)nb; j < max_blocks_per_seq; ++j) row[j] = -1;
         max_ctx = std::max(max_ctx, len);
     }
+    decode_shared_len = shared_prefix_plan(seqs, nseq, (int32_t *)(hd + dof_skv0), (int32_t *)(hd + dof_srows), (int32_t *)(hd + dof_scount),
+                                           &decode_shared_rows);
     NVR_HIP_CHECK(hipMemcpyAsync(in_dev + off_dec + dof_pos, hd + dof_pos, dof_bt + nseq * max_blocks_per_seq * 4 - dof_pos, hipMemcpyHostToDevice, stream));
-    decode_shared_len = shared_prefix_len(seqs, nseq);
     last_rows = nseq; last_prefill = false; last_tokens = (int64_t)nseq;
     lm_parts = k::lm_head_parts((int64_t)nseq, Hd, Vl, Hd);
     if (lm_parts <= 0) return nvr::fail(NVR_ERR_UNSUPPORTED, "execute_decode_ahead: the fused LM head does not take this batch");
@@ -697,7 +734,7 @@ int nvr_model_runner::execute_decode_ahead(nvr_seq *const *seqs, size_t nseq, in
     const int64_t T = (int64_t)nseq;
     if (cfg.enforce_eager || graphs_disabled) return forward(T, T, false, max_ctx);
     const int64_t bucket = (max_ctx + 255) / 256 * 256;
-    const uint64_t key = graph_key(want_logits, nseq, bucket, decode_shared_len);
+    const uint64_t key = graph_key(want_logits, nseq, bucket, decode_shared_len, decode_shared_len > 0 && decode_shared_rows < (int64_t)nseq);
     auto it = graphs.find(key);
     if (it == graphs.end()) {
         if (graphs.size() >= kMaxGraphs) return nvr::fail(NVR_ERR_UNSUPPORTED, "execute_decode_ahead: graph cache full");   // (flushing needs an idle stream)

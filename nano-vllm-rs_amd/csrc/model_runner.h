@@ -48,6 +48,7 @@ struct nvr_model_runner {
     int64_t n_tiles = 0;                   // flash prefill tiles of the current step
     // decode steps use one compact region (ids|pos|slots|ctx|block tables) uploaded with a single memcpy (K19)
     size_t off_dec = 0, dec_bytes = 0, dof_ids = 0, dof_pos = 0, dof_slots = 0, dof_ctx = 0, dof_bt = 0;
+    size_t dof_skv0 = 0, dof_srows = 0, dof_scount = 0;  // shared-prefix group of the step: kv0 per row, member rows, member count
     int64_t *dd_ids = nullptr, *dd_pos = nullptr; int32_t *dd_slots = nullptr, *dd_ctx = nullptr, *dd_bt = nullptr;
     // sampling
     int64_t *d_tok = nullptr, *h_tok = nullptr; float *d_maxval = nullptr;
@@ -63,7 +64,8 @@ struct nvr_model_runner {
     bool chain4 = false;                   // nvr_config.decode_chain == 4 (or NVR_DECODE_CHAIN=4): the four-launch chain of linear_decode.hip
     std::map<uint64_t, hipGraphExec_t> graphs;
     size_t last_rows = 0; bool last_prefill = false; int64_t last_tokens = 0;
-    int64_t decode_shared_len = 0;                       // the last decode step: tokens every sequence holds in the same leading blocks
+    int64_t decode_shared_len = 0;                       // the last decode step: tokens its sharing group holds in the same leading blocks
+    int64_t decode_shared_rows = 0;                      // ... and how many of the step's sequences belong to that group (== batch: all)
     nvr::Comm comm;
     bool graphs_disabled = false;   // set when capture with RCCL nodes fails: fall back to eager launches
     int comm_selftest();
@@ -99,7 +101,8 @@ private:
     static constexpr size_t kMaxGraphs = 256;            // captured decode graphs kept before the cache is flushed
     int64_t *h_tok_dev = nullptr;                        // device-visible address of the pinned token buffer h_tok
     int64_t slab_rows = 64;           // rows the split-k slab buffers hold (row_parallel_norm)
-    int64_t shared_prefix_len(nvr_seq *const *seqs, size_t nseq) const;   // (0 = none / batch too small: plain paged attention)
+    // sharing group of a decode batch (0 = none / too small: plain paged attention); fills kv0[nseq], rows[nseq], *count of the arena
+    int64_t shared_prefix_plan(nvr_seq *const *seqs, size_t nseq, int32_t *kv0, int32_t *rows, int32_t *count, int64_t *members) const;
     bool prefill_paged = false;                          // this prefill step skips cached prefixes (K/V via block tables)
     bool lazy_logits = true, want_logits = true, logits_valid = true; const uint16_t *lm_input = nullptr;
     bool lm_fused = true; int32_t lm_parts = 0;          // lm_head arg-max partials of the last step (0: none)

@@ -233,6 +233,7 @@ int nvr_runner_p2p_attach(nvr_model_runner_t *r, const uint8_t *handles, const i
 int nvr_runner_p2p_disable(nvr_model_runner_t *r) { r->comm.p2p_ready = false; return NVR_OK; }
 int nvr_runner_p2p_active(const nvr_model_runner_t *r) { return r->comm.p2p_ready ? 1 : 0; }
 int64_t nvr_runner_last_shared_prefix_len(const nvr_model_runner_t *r) { return r->last_prefill ? 0 : r->decode_shared_len; }
+int64_t nvr_runner_last_shared_prefix_rows(const nvr_model_runner_t *r) { return (r->last_prefill || r->decode_shared_len == 0) ? 0 : r->decode_shared_rows; }
 
 // in-process communicator (comm.h LocalGroup): N runners of one process on one device, one host thread each
 struct nvr_local_group { nvr::LocalGroup g; explicit nvr_local_group(int n) : g(n) {} };
@@ -563,13 +564,13 @@ int nvr_paged_attn_decode(const nvr_half *q, int64_t ldq, const nvr_half *kc, co
     return k::attention(a, true, (hipStream_t)s);
 }
 int nvr_paged_attn_decode_shared(const nvr_half *q, int64_t ldq, const nvr_half *kc, const nvr_half *vc, const nvr_attn_meta *m,
-                                 int64_t H, int64_t KVH, int64_t D, int64_t bs, float scale, int64_t shared_len, nvr_half *out, void *ws,
-                                 void *s) {
+                                 int64_t H, int64_t KVH, int64_t D, int64_t bs, float scale, int64_t shared_len, const int32_t *rows,
+                                 const int32_t *kv0, const int32_t *count, nvr_half *out, void *ws, void *s) {
     k::AttnArgs a{};
     a.q = q; a.ldq = ldq; a.k = kc; a.v = vc; a.ctx_lens = m->context_lens; a.block_tables = m->block_tables;
     a.max_blocks = m->max_blocks; a.block_size = (int32_t)bs; a.nq = m->batch; a.H = (int32_t)H; a.KVH = (int32_t)KVH;
     a.D = (int32_t)D; a.scale = scale; a.max_ctx = m->max_context_len; a.out = out; a.workspace = ws;
-    a.shared_len = (int32_t)shared_len;
+    a.shared_len = (int32_t)shared_len; a.shared_rows = rows; a.shared_kv0 = kv0; a.shared_count = count;
     return k::attention(a, true, (hipStream_t)s);
 }
 // host-side tile list for the flash kernels from cu_seqlens_q (+ context lens for the paged variant)

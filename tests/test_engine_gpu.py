@@ -735,7 +735,7 @@ def test_shared_prefix_decode_attention_engine_parity(shape):
     blocks (block_manager.rs:181-197), and decode batches of >= shared_prefix_min_seqs sequences send the shared keys through one
     MFMA pass (nvr_paged_attn_decode_shared).  Logits / tokens stay in parity with the oracle's plain paged attention, graph and
     eager and launch-ahead agree, the plain path (feature off) produces the same tokens, and the shared length follows the
-    batch: a request WITHOUT the system prompt joining the batch switches the step back to the plain kernel."""
+    batch: a request WITHOUT the system prompt in the batch is attended to in full by the row kernel while the others keep the pass."""
     mcfg = mo.small(seed=9) if shape == "d64_g2" else \
         mo.small(seed=9, hidden_size=512, num_attention_heads=4, num_key_value_heads=2, head_dim=128, intermediate_size=768)
     V = mcfg.vocab_size
@@ -772,6 +772,17 @@ def test_shared_prefix_decode_attention_engine_parity(shape):
     sps2 = [dict(temperature=0.0, max_tokens=10, ignore_eos=True)] * 7
     m = _run_pair(mcfg, ecfg, prompts2, sps2, product_kw=on)
     assert m["near_ties"] <= 2, m
+    # ... and the six that do have it still take the shared pass as a group inside the batch of seven
+    nvr.lib().nvr_seq_reset_id_counter()
+    p = nvr.LLMEngine(nvr.Config(skip_block_size_check=1, **ecfg, **on), _model_cfgs(mcfg))
+    for pr, sp in zip(prompts2, sps2):
+        p.add_request(pr, nvr.SamplingParams(**sp))
+    seen = set()
+    while not p.is_finished():
+        rec = p.step()
+        if not rec["is_prefill"]:
+            seen.add((rec["num_seqs"], p.model_runner.last_shared_prefix_len(), p.model_runner.last_shared_prefix_rows()))
+    assert (7, 128, 6) in seen, seen
 
 
 @pytest.mark.parametrize("seed", [11, 12, 13, 14])
@@ -796,7 +807,9 @@ def test_random_workloads_with_shared_prefix_pass(seed):
     assert len(r["finished"]) == nreq
     assert r["near_ties"] <= 4, r
     off = _run_pair(mcfg, ecfg, prompts, sps, max_steps=3000, product_kw=dict(shared_prefix_min_seqs=-1))
-    assert off["finished"] == r["finished"] and off["shared_steps"] == 0
+    assert off["shared_steps"] == 0
+    # both runs are in parity with the oracle step by step; their token streams can only part at a counted numerical near-tie
+    assert off["finished"] == r["finished"] or r["near_ties"] + off["near_ties"] > 0, (r["near_ties"], off["near_ties"])
     _SOAK_SEEN["shared_steps"] = _SOAK_SEEN.get("shared_steps", 0) + r["shared_steps"]
     _SOAK_SEEN["shared_runs"] = _SOAK_SEEN.get("shared_runs", 0) + 1
     _SOAK_SEEN["shared_preemptions"] = _SOAK_SEEN.get("shared_preemptions", 0) + r["oracle"].scheduler.stats.preemptions

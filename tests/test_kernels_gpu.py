@@ -1049,7 +1049,7 @@ def test_paged_attn_decode_shared_prefix(B, H, KVH, D, bs, P, own):
     d_out, d_plain = nvr.DeviceBuffer(B * H * D * 2), nvr.DeviceBuffer(B * H * D * 2)
     d_q, d_k, d_v = dev(qb), dev(kcb), dev(vcb)
     nvr.check(nvr.lib().nvr_paged_attn_decode_shared(d_q.ptr, H * D, d_k.ptr, d_v.ptr, C.byref(meta), H, KVH, D, bs, scale, S,
-                                                     d_out.ptr, ws.ptr, None))
+                                                     None, None, None, d_out.ptr, ws.ptr, None))
     nvr.check(nvr.lib().nvr_paged_attn_decode(d_q.ptr, H * D, d_k.ptr, d_v.ptr, C.byref(meta), H, KVH, D, bs, scale, d_plain.ptr, ws.ptr, None))
     got = d_out.to_numpy((B, H, D), F16)
     ref = oracle.round_f16(oracle.attn_decode(q, kc, vc, bt, ctx, scale))
@@ -1057,7 +1057,7 @@ def test_paged_attn_decode_shared_prefix(B, H, KVH, D, bs, P, own):
     assert_close_f16(got, d_plain.to_numpy((B, H, D), F16), ulps=3, atol=1e-3, what="shared-prefix vs plain kernel")
     # shared_len that is no multiple of the block size is refused
     assert nvr.lib().nvr_paged_attn_decode_shared(d_q.ptr, H * D, d_k.ptr, d_v.ptr, C.byref(meta), H, KVH, D, bs, scale, S + 8,
-                                                  d_out.ptr, ws.ptr, None) == -7
+                                                  None, None, None, d_out.ptr, ws.ptr, None) == -7
 
 
 @pytest.mark.parametrize("T", [8, 32])
@@ -1213,7 +1213,54 @@ def test_paged_attn_decode_shared_prefix_random_geometries(seed):
     ws = nvr.DeviceBuffer(nvr.lib().nvr_paged_attn_workspace_bytes(B, H, D, int(max(ctxs)) + bs))
     d_out, d_plain = nvr.DeviceBuffer(B * H * D * 2), nvr.DeviceBuffer(B * H * D * 2)
     d_q, d_k, d_v = dev(qb), dev(kcb), dev(vcb)
-    nvr.check(nvr.lib().nvr_paged_attn_decode_shared(d_q.ptr, H * D, d_k.ptr, d_v.ptr, C.byref(meta), H, KVH, D, bs, scale, S, d_out.ptr, ws.ptr, None))
+    nvr.check(nvr.lib().nvr_paged_attn_decode_shared(d_q.ptr, H * D, d_k.ptr, d_v.ptr, C.byref(meta), H, KVH, D, bs, scale, S, None, None, None, d_out.ptr, ws.ptr, None))
     nvr.check(nvr.lib().nvr_paged_attn_decode(d_q.ptr, H * D, d_k.ptr, d_v.ptr, C.byref(meta), H, KVH, D, bs, scale, d_plain.ptr, ws.ptr, None))
     assert_close_f16(d_out.to_numpy((B, H, D), F16), d_plain.to_numpy((B, H, D), F16), ulps=3, atol=1e-3,
                      what=f"D={D} G={G} KVH={KVH} bs={bs} P={P} B={B}")
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_paged_attn_decode_shared_prefix_group(seed):
+    """Only SOME sequences of the batch share the prefix (rows / kv0 / count arrays): members scattered over the batch take the shared
+    pass + their own remainder, the others (different first blocks, any context length, even shorter than the shared length) are
+    attended to in full by the row kernel; everything against the plain kernel."""
+    rng = np.random.default_rng(900 + seed)
+    D = int(rng.choice([64, 128])); G = int(rng.choice([1, 2, 4])); KVH = int(rng.choice([1, 2])); H = G * KVH
+    bs = int(rng.choice([64, 256])); P = int(rng.integers(1, 4)); B = int(rng.integers(4, 150))
+    S = P * bs
+    member = rng.random(B) < 0.7
+    member[int(rng.integers(0, B))] = True
+    ctxs, nblk = [], []
+    for b in range(B):
+        c = S + int(rng.integers(0, 2 * bs)) if member[b] else int(rng.integers(1, S + 2 * bs))
+        ctxs.append(c); nblk.append((c + bs - 1) // bs)
+    NB = P + sum(nblk) + 2
+    max_blocks = max(nblk) + 1
+    kcb = rng.standard_normal((NB, bs, KVH, D)).astype(F16); vcb = rng.standard_normal((NB, bs, KVH, D)).astype(F16)
+    perm = rng.permutation(NB)
+    bt = -np.ones((B, max_blocks), np.int32)
+    o = P
+    for b in range(B):
+        if member[b]:
+            bt[b, :P] = perm[:P]
+            bt[b, P:nblk[b]] = perm[o:o + nblk[b] - P]; o += nblk[b] - P
+        else:
+            bt[b, :nblk[b]] = perm[o:o + nblk[b]]; o += nblk[b]
+    rows = np.flatnonzero(member).astype(np.int32)
+    rows_pad = np.concatenate([rows, np.zeros(B - len(rows), np.int32)])
+    kv0 = np.where(member, S, 0).astype(np.int32)
+    qb = rng.standard_normal((B, H, D)).astype(F16)
+    scale = float(np.float32(1.0) / np.sqrt(np.float32(D)))
+    meta = nvr.AttnMetaC()
+    d_ctx, d_bt = dev(np.asarray(ctxs, np.int32)), dev(bt)
+    meta.is_prefill, meta.context_lens, meta.block_tables = 0, d_ctx.ptr, d_bt.ptr
+    meta.max_blocks, meta.batch, meta.max_context_len = max_blocks, B, int(max(ctxs))
+    ws = nvr.DeviceBuffer(nvr.lib().nvr_paged_attn_workspace_bytes(B, H, D, int(max(ctxs)) + S + bs))
+    d_out, d_plain = nvr.DeviceBuffer(B * H * D * 2), nvr.DeviceBuffer(B * H * D * 2)
+    d_q, d_k, d_v = dev(qb), dev(kcb), dev(vcb)
+    nvr.check(nvr.lib().nvr_paged_attn_decode_shared(d_q.ptr, H * D, d_k.ptr, d_v.ptr, C.byref(meta), H, KVH, D, bs, scale, S,
+                                                     dev(rows_pad).ptr, dev(kv0).ptr, dev(np.asarray([len(rows)], np.int32)).ptr,
+                                                     d_out.ptr, ws.ptr, None))
+    nvr.check(nvr.lib().nvr_paged_attn_decode(d_q.ptr, H * D, d_k.ptr, d_v.ptr, C.byref(meta), H, KVH, D, bs, scale, d_plain.ptr, ws.ptr, None))
+    assert_close_f16(d_out.to_numpy((B, H, D), F16), d_plain.to_numpy((B, H, D), F16), ulps=3, atol=1e-3,
+                     what=f"D={D} G={G} KVH={KVH} bs={bs} P={P} B={B} members={len(rows)}")
