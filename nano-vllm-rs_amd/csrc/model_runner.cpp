@@ -396,7 +396,7 @@ bool nvr_model_runner::use_chain4(int64_t T, bool is_prefill) const {
 
 // Decode batches in which many sequences start with the same cache blocks (prefix-cache hits of BlockManager::allocate,
 // block_manager.rs:181-197: one system prompt in front of the requests, BASELINE configs[4]).  The GROUP is the set of sequences
-// whose first block is the batch's majority first block (no majority: no group); its shared length is the run of full blocks all members have in common.  The
+// whose first block is the batch's most common first block; its shared length is the run of full blocks all members have in common.  The
 // attention launch then sends those keys through one MFMA pass for the whole group (kernels/flash_prefill.hip, SHARED) instead of
 // once per sequence; sequences outside the group (kv0 = 0) are attended to in full by the row kernel.  Groups under
 // nvr_config.shared_prefix_min_seqs sequences (default 32) and block sizes the kernel does not take keep the plain kernel.
@@ -409,12 +409,21 @@ int64_t nvr_model_runner::shared_prefix_plan(nvr_seq *const *seqs, size_t nseq, 
     auto full_blocks = [&](const nvr_seq &s) {                            // full blocks below the token of this step
         return std::min<size_t>(s.block_table.size(), (size_t)(((int64_t)s.len() - 1) / block_size));
     };
-    // majority first block among the sequences that have a full one (Boyer-Moore vote, then a count)
-    int32_t cand = -1; int64_t votes = 0;
-    for (size_t b = 0; b < nseq; ++b) {
-        if (full_blocks(*seqs[b]) == 0) continue;
-        const int32_t f = seqs[b]->block_table[0];
-        if (votes == 0) { cand = f; votes = 1; } else votes += (f == cand) ? 1 : -1;
+    // the most common first block among the sequences that have a full one (a small open-addressing count table)
+    int32_t cand = -1;
+    {
+        size_t cap = 16;
+        while (cap < 2 * nseq) cap <<= 1;
+        plan_keys.assign(cap, -1); plan_cnt.assign(cap, 0);
+        int32_t best = 0;
+        for (size_t b = 0; b < nseq; ++b) {
+            if (full_blocks(*seqs[b]) == 0) continue;
+            const int32_t f = seqs[b]->block_table[0];
+            size_t i = ((uint32_t)f * 2654435761u) & (cap - 1);
+            while (plan_keys[i] != -1 && plan_keys[i] != f) i = (i + 1) & (cap - 1);
+            plan_keys[i] = f;
+            if (++plan_cnt[i] > best) { best = plan_cnt[i]; cand = f; }
+        }
     }
     if (cand < 0) return 0;
     size_t common = SIZE_MAX; int64_t n = 0; const nvr_seq *first = nullptr;

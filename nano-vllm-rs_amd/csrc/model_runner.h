@@ -103,6 +103,7 @@ private:
     int64_t slab_rows = 64;           // rows the split-k slab buffers hold (row_parallel_norm)
     // sharing group of a decode batch (0 = none / too small: plain paged attention); fills kv0[nseq], rows[nseq], *count of the arena
     int64_t shared_prefix_plan(nvr_seq *const *seqs, size_t nseq, int32_t *kv0, int32_t *rows, int32_t *count, int64_t *members) const;
+    mutable std::vector<int32_t> plan_keys, plan_cnt;    // scratch of the plan (first-block id -> count)
     bool prefill_paged = false;                          // this prefill step skips cached prefixes (K/V via block tables)
     bool lazy_logits = true, want_logits = true, logits_valid = true; const uint16_t *lm_input = nullptr;
     bool lm_fused = true; int32_t lm_parts = 0;          // lm_head arg-max partials of the last step (0: none)

@@ -819,3 +819,31 @@ def test_random_workloads_did_take_the_shared_prefix_pass():
     if _SOAK_SEEN.get("shared_runs", 0) < 4:
         pytest.skip("runs after the four shared-prefix soak cases")
     assert _SOAK_SEEN["shared_steps"] > 20, _SOAK_SEEN
+
+
+def test_shared_prefix_group_is_the_most_common_prompt():
+    """Three system prompts in one batch (5 / 4 / 3 requests) + one request without any: no prompt has a majority, the group is the
+    most common one (5 rows); everybody stays in parity with the oracle."""
+    mcfg = mo.small(seed=10)
+    V = mcfg.vocab_size
+    ecfg = dict(max_num_seqs=16, max_num_batched_tokens=4096, max_model_len=512, kvcache_block_size=64, num_kvcache_blocks=90)
+    systems = [oracle.fill_tokens(64 * n, 4, 70 + i, V).tolist() for i, n in enumerate([2, 1, 3])]
+    prompts = []
+    for i, cnt in enumerate([5, 4, 3]):
+        prompts += [systems[i] + oracle.fill_tokens(5 + 3 * j, 4, 300 + 10 * i + j, V).tolist() for j in range(cnt)]
+    prompts.append(oracle.fill_tokens(90, 4, 999, V).tolist())
+    order = np.random.default_rng(4).permutation(len(prompts))
+    prompts = [prompts[i] for i in order]
+    sps = [dict(temperature=0.0, max_tokens=6, ignore_eos=True)] * len(prompts)
+    r = _run_pair(mcfg, ecfg, prompts, sps, product_kw=dict(shared_prefix_min_seqs=4))
+    assert r["near_ties"] <= 2 and r["shared_steps"] >= 4, r
+    nvr.lib().nvr_seq_reset_id_counter()
+    p = nvr.LLMEngine(nvr.Config(skip_block_size_check=1, shared_prefix_min_seqs=4, **ecfg), _model_cfgs(mcfg))
+    for pr, sp in zip(prompts, sps):
+        p.add_request(pr, nvr.SamplingParams(**sp))
+    seen = set()
+    while not p.is_finished():
+        rec = p.step()
+        if not rec["is_prefill"]:
+            seen.add((rec["num_seqs"], p.model_runner.last_shared_prefix_len(), p.model_runner.last_shared_prefix_rows()))
+    assert (13, 128, 5) in seen, seen
