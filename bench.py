@@ -276,9 +276,9 @@ def main() -> None:
     fallback_state: dict = {}
     if args.gpus > 1:
         # the multi-rank path cannot be exercised on the 1-GPU development boxes: never hang the driver — if a rank is still
-        # stuck (a collective that never completes, a rendezvous that never forms) after 10 minutes, every rank exits
+        # stuck (a collective that never completes, a rendezvous that never forms) after 7 minutes (a tensor-parallel child: 110 s), every rank exits
         import threading
-        wd_secs = 200.0 if os.environ.get("NVR_BENCH_CHILD") == "1" else 560.0
+        wd_secs = 110.0 if os.environ.get("NVR_BENCH_CHILD") == "1" else 420.0
 
         def _bail():
             print(f"[bench] rank {rank}: multi-GPU run made no progress for {int(wd_secs)} s, giving up", file=sys.stderr, flush=True)
@@ -440,10 +440,10 @@ def main() -> None:
                        "--parallel", "tp", "--no-cpu-baseline", "--attn-reps", "1"] + (["--eager"] if args.eager else [])
                 child_out, child_err, child_rc = "", "", None
                 try:
-                    cp = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=230)
+                    cp = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
                     child_out, child_err, child_rc = cp.stdout, cp.stderr, cp.returncode
                 except subprocess.TimeoutExpired as te:
-                    child_err = "timed out after 230 s: " + str((te.stderr or b"")[-300:])
+                    child_err = "timed out after 120 s: " + str((te.stderr or b"")[-300:])
                 done = 0
                 if rank == 0:
                     line = next((l for l in reversed(child_out.splitlines()) if l.startswith("{")), None)
