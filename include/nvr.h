@@ -199,7 +199,9 @@ typedef struct nvr_sched_stats {       /* SchedulerStats :38-66 */
 NVR_API nvr_scheduler_t *nvr_sched_create(const nvr_config *cfg);                      /* :70 */
 NVR_API void nvr_sched_destroy(nvr_scheduler_t *sc);
 NVR_API int nvr_sched_add_sequence(nvr_scheduler_t *sc, nvr_seq_t *s);  /* :93; ownership moves to the scheduler */
-/* :103 — writes up to cap borrowed sequence handles (valid until they finish); *is_prefill 0/1 */
+/* :103 — writes up to cap borrowed sequence handles (valid until they finish); *is_prefill 0/1.  cap must be at least
+ * min(max_num_seqs, waiting + running sequences) — the largest batch this call can build; it is checked BEFORE anything is
+ * scheduled (NVR_ERR_INVALID_ARG, nothing moved) */
 NVR_API int nvr_sched_schedule(nvr_scheduler_t *sc, nvr_seq_t **out, size_t cap, size_t *n, int *is_prefill);
 NVR_API int nvr_sched_postprocess(nvr_scheduler_t *sc, nvr_seq_t *const *seqs, const int64_t *token_ids, size_t n); /* :234 */
 NVR_API int nvr_sched_is_finished(const nvr_scheduler_t *sc);                          /* :88 */
@@ -271,6 +273,14 @@ NVR_API int nvr_runner_p2p_export(nvr_model_runner_t *r, uint8_t handle[64]);
 NVR_API int nvr_runner_p2p_attach(nvr_model_runner_t *r, const uint8_t *handles /* [tp][64] */, const int32_t *devices /* [tp] or NULL */);
 NVR_API int nvr_runner_p2p_disable(nvr_model_runner_t *r);
 NVR_API int nvr_runner_p2p_active(const nvr_model_runner_t *r);
+/* A collective whose peer never arrived (bounded wait, NVR_P2P_TIMEOUT_MS, default 20 s) fails its step with NVR_ERR_RCCL on the
+ * waiting rank (the batch is aborted, linear.rs:236-238 has no error path of its own).  The ranks' epochs then differ: the caller's
+ * control plane tells EVERY rank to abort that batch (nvr_engine_abort_last_batch), to call nvr_runner_p2p_reset (epoch words and
+ * arrival flags back to their initial values; drains the device first) and then barriers; the group is usable again. */
+NVR_API int nvr_runner_p2p_reset(nvr_model_runner_t *r);
+/* forget this rank's RCCL communicator: the group agreed (control plane) that RCCL is not used because a peer failed to build its
+ * own — otherwise the ranks would pick different backends for messages larger than an arena slot */
+NVR_API int nvr_runner_comm_drop_rccl(nvr_model_runner_t *r);
 /* tokens of the last decode step that went through the shared-prefix attention pass (nvr_config.shared_prefix_min_seqs); 0 = plain */
 NVR_API int64_t nvr_runner_last_shared_prefix_len(const nvr_model_runner_t *r);
 NVR_API int64_t nvr_runner_last_shared_prefix_rows(const nvr_model_runner_t *r);   /* sequences of that step inside the sharing group */
@@ -307,6 +317,13 @@ NVR_API nvr_model_runner_t *nvr_engine_runner(nvr_engine_t *e);     /* borrowed 
 /* ids + tokens sampled by the last step (borrowed until the next step) */
 NVR_API void nvr_engine_last_step(const nvr_engine_t *e, const uint64_t **seq_ids, const int64_t **tokens, size_t *n);
 NVR_API size_t nvr_engine_take_finished(nvr_engine_t *e, nvr_seq_t **out, size_t cap);   /* caller destroys */
+/* Control-plane abort (tensor-parallel ranks after a peer reported NVR_ERR_RCCL; the reference's step has no error path,
+ * llm_engine.rs:155-197): the sequences of the batch this engine scheduled last that are still alive leave the engine as finished,
+ * their blocks returned — what a failed model step does on the rank that saw the failure.  Call before taking that step's
+ * finished sequences. */
+NVR_API int nvr_engine_abort_last_batch(nvr_engine_t *e);
+/* nvr_config.async_decode: decode steps whose successor could not be enqueued ahead and therefore ran synchronously (diagnostic) */
+NVR_API uint64_t nvr_engine_ahead_declined(const nvr_engine_t *e);
 /* sequences of the last step's batch (borrowed handles; finished ones are excluded) */
 NVR_API size_t nvr_engine_last_batch(const nvr_engine_t *e, nvr_seq_t **out, size_t cap);
 

@@ -181,6 +181,8 @@ _SIGS = {
     "nvr_runner_init_comm_local": (C.c_int, [_P, _P]), "nvr_local_group_set_p2p": (C.c_int, [_P, C.c_int]),
     "nvr_runner_p2p_export": (C.c_int, [_P, _P]), "nvr_runner_p2p_attach": (C.c_int, [_P, _P, _P]),
     "nvr_runner_p2p_disable": (C.c_int, [_P]), "nvr_runner_p2p_active": (C.c_int, [_P]),
+    "nvr_runner_p2p_reset": (C.c_int, [_P]), "nvr_runner_comm_drop_rccl": (C.c_int, [_P]),
+    "nvr_engine_abort_last_batch": (C.c_int, [_P]), "nvr_engine_ahead_declined": (C.c_uint64, [_P]),
     "nvr_runner_last_shared_prefix_len": (C.c_int64, [_P]), "nvr_runner_last_shared_prefix_rows": (C.c_int64, [_P]),
     "nvr_engine_last_step": (None, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(C.c_size_t)]),
     "nvr_engine_take_finished": (C.c_size_t, [_P, C.POINTER(_P), C.c_size_t]),
@@ -673,6 +675,14 @@ class ModelRunner:
     def p2p_active(self) -> bool:
         return bool(lib().nvr_runner_p2p_active(self.h))
 
+    def p2p_reset(self) -> None:
+        """After a collective timed out (NVR_ERR_RCCL): epochs and arrival flags back to their initial state; every rank calls it,
+        then the control plane barriers."""
+        check(lib().nvr_runner_p2p_reset(self.h))
+
+    def comm_drop_rccl(self) -> None:
+        check(lib().nvr_runner_comm_drop_rccl(self.h))
+
     def last_shared_prefix_len(self) -> int:
         """Tokens of the last decode step that went through the shared-prefix attention pass (0: plain paged attention)."""
         return int(lib().nvr_runner_last_shared_prefix_len(self.h))
@@ -876,6 +886,13 @@ class LLMEngine:
 
     def take_finished(self) -> List[Sequence]:
         return self.scheduler.take_finished()
+
+    def abort_last_batch(self) -> None:
+        """Control-plane abort of the batch scheduled last (tensor-parallel ranks after a peer's NVR_ERR_RCCL)."""
+        check(lib().nvr_engine_abort_last_batch(self.h))
+
+    def ahead_declined(self) -> int:
+        return int(lib().nvr_engine_ahead_declined(self.h))
 
 
 # ---------------------------------------------------------------------------------- device helpers

@@ -64,7 +64,6 @@ int Comm::init(const uint8_t idb[128], int nr, int rk) {
     ncclComm_t c = nullptr;
     NVR_NCCL(g_api.CommInitRank(&c, nr, id, rk));
     comm = c; nranks = nr; rank = rk;
-    if (const char *e = std::getenv("NVR_TP_FORCE_COMM")) force = (e[0] == '1');
     return NVR_OK;
 }
 
@@ -175,7 +174,9 @@ static void p2p_fill(const Comm &c, P2PArgs &a) {
     a.slots = (p2p_half *)c.arena; a.flags = (unsigned int *)((char *)c.arena + p2p_flags_offset());
     a.nranks = c.nranks; a.rank = c.rank; a.slot_bytes = Comm::kP2PSlotBytes;
     a.epoch = c.p2p_words; a.done = c.p2p_words + 1; a.err = c.p2p_words + 2;
-    a.timeout_cycles = 6000000000ull;                                    // ~2.5-3 s of shader clock: a peer that never arrives
+    // a peer that never arrives: far longer than any host-side stall of a live peer (graph instantiation, first-launch code
+    // loading), so that a slow rank is waited for and only a dead one sets the error word
+    a.timeout_ticks = (unsigned long long)c.timeout_ms * 100000ull;      // wall clock at 100 MHz
 }
 int Comm::all_reduce_add_rmsnorm(const void *in, void *h, const void *wn, float eps, int rows, int Hd, void *out, hipStream_t s) {
     if (!p2p_usable((size_t)rows * Hd)) return fail(NVR_ERR_INVALID_ARG, "all_reduce_add_rmsnorm: peer arenas not attached or message too large");
@@ -238,6 +239,8 @@ int Comm::all_reduce_sum_f16(void *buf, size_t count, hipStream_t s) {
         NVR_HIP_CHECK(hipMemcpyAsync(buf, local_tmp, count * 2, hipMemcpyDeviceToDevice, s));
         return NVR_OK;
     }
+    if (!comm || !g_api.AllReduce)
+        return fail(NVR_ERR_RCCL, "all-reduce of %zu fp16 values: no RCCL communicator, and the peer-to-peer arenas take multiples of 4 values only", count);
     NVR_NCCL(g_api.AllReduce(buf, buf, count, ncclFloat16, ncclSum, (ncclComm_t)comm, s));
     return NVR_OK;
 }
@@ -246,6 +249,22 @@ int Comm::all_gather_bytes(const void *send, void *recv, size_t bytes, hipStream
         P2PArgs a{};
         p2p_fill(*this, a);
         return p2p_allgather_launch(a, send, recv, bytes, s);
+    }
+    if (p2p_ready && !comm && bytes % 8 == 0) {
+        // no other backend (peer-to-peer arenas only): a large record (vocabulary-shard logits of stochastic sampling, greedy
+        // batches over 512 rows) goes through the all-reduce slots in its all-gather form, one slot-sized piece per launch
+        const size_t total = bytes / 2, chunk = kP2PSlotBytes / 2;                  // in fp16-sized units
+        for (size_t off = 0; off < total; off += chunk) {
+            const size_t cnt = std::min(chunk, total - off);
+            int Hd = 4096;
+            while (cnt % (size_t)Hd) Hd /= 2;                                        // >= 4: bytes % 8 == 0
+            P2PArgs a{};
+            p2p_fill(*this, a);
+            a.in = (const p2p_half *)send + off; a.count = cnt; a.Hd = Hd;
+            a.out = (p2p_half *)recv + off; a.gather_stride = total;
+            if (int rc = p2p_allreduce_launch(a, (int)(cnt / (size_t)Hd), s)) return rc;
+        }
+        return NVR_OK;
     }
     if (local) {
         NVR_HIP_CHECK(hipStreamSynchronize(s));
@@ -257,8 +276,24 @@ int Comm::all_gather_bytes(const void *send, void *recv, size_t bytes, hipStream
         NVR_HIP_CHECK(hipStreamSynchronize(s));
         return local->rendezvous(rank, send);                           // nobody reuses its send buffer before all copies are done
     }
+    if (!comm || !g_api.AllGather)
+        return fail(NVR_ERR_RCCL, "all-gather of %zu bytes per rank: no RCCL communicator (the peer-to-peer arenas take multiples of 8 bytes)", bytes);
     NVR_NCCL(g_api.AllGather(send, recv, bytes, ncclInt8, (ncclComm_t)comm, s));
     return NVR_OK;
+}
+int Comm::p2p_reset() {
+    if (!arena) return NVR_OK;
+    NVR_HIP_CHECK(hipDeviceSynchronize());                               // nothing of mine is still polling or pushing
+    NVR_HIP_CHECK(hipMemset((char *)arena + p2p_flags_offset(), 0, 1024));
+    NVR_HIP_CHECK(hipMemset((char *)arena + p2p_gflags_offset(), 0, 1024));
+    const unsigned int init[4] = {1u, 0u, 0u, 0u};
+    NVR_HIP_CHECK(hipMemcpy(p2p_words, init, sizeof init, hipMemcpyHostToDevice));
+    NVR_HIP_CHECK(hipDeviceSynchronize());
+    return NVR_OK;
+}
+void Comm::drop_rccl() {
+    if (comm && g_api.CommDestroy) g_api.CommDestroy((ncclComm_t)comm);
+    comm = nullptr;
 }
 void Comm::destroy() {
     if (comm && g_api.CommDestroy) g_api.CommDestroy((ncclComm_t)comm);

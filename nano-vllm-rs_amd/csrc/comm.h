@@ -49,7 +49,8 @@ struct P2PArgs {
     int nranks, rank, Hd;
     size_t slot_bytes;
     unsigned int *epoch, *done, *err;                            // private device words
-    unsigned long long timeout_cycles;
+    unsigned long long timeout_ticks;                            // of the 100 MHz wall clock (s_memrealtime)
+    size_t gather_stride;                                        // all-gather form (h == nullptr): out[r * gather_stride + i] = rank r's in[i]; 0 = all-reduce
     p2p_half *h; const p2p_half *wn; float eps;                  // fused residual + RMSNorm (h == nullptr: plain all-reduce into out)
     p2p_half *out;
 };
@@ -74,6 +75,11 @@ struct Comm {
     int all_reduce_add_rmsnorm(const void *in, void *h, const void *wn, float eps, int rows, int Hd, void *out, hipStream_t s);
     int prepare();                                               // in-process group: attach the peers' arenas once all ranks registered
     int p2p_check_error(hipStream_t s);                          // NVR_ERR_RCCL if a collective since the last check timed out
+    int timeout_ms = 20000;                                      // how long a collective waits for a peer (Env::p2p_timeout_ms)
+    // After a timed-out collective the ranks' epoch words differ: every rank calls p2p_reset (epoch, flags and error word back to
+    // their initial values; the device is drained first), the caller's control plane barriers, and the group is usable again.
+    int p2p_reset();
+    void drop_rccl();                                            // forget the RCCL communicator (the group agreed not to use it)
 
     void *lib = nullptr;
     void *comm = nullptr;

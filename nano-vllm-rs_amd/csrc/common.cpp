@@ -1,5 +1,6 @@
 #include "common.h"
 #include <atomic>
+#include <cstdlib>
 #include "sequence.h"
 namespace nvr {
 std::string &last_error_slot() { static thread_local std::string s; return s; }
@@ -12,4 +13,23 @@ int fail(int code, const char *fmt, ...) {
     return code;
 }
 std::atomic<uint64_t> g_sequence_counter{0};
+Env Env::read() {
+    Env e;
+    auto flag = [](const char *name, bool dflt) { const char *v = std::getenv(name); return v && v[0] ? v[0] != '0' : dflt; };
+    auto num = [](const char *name, int dflt, int lo, int hi) {
+        const char *v = std::getenv(name);
+        if (!v || !v[0]) return dflt;
+        long x = std::strtol(v, nullptr, 10);
+        return (int)(x < lo ? lo : x > hi ? hi : x);
+    };
+    e.trace_host = flag("NVR_TRACE_HOST", false);
+    e.tiled_weights = flag("NVR_TILED_WEIGHTS", true);
+    e.lazy_logits = flag("NVR_LAZY_LOGITS", true);
+    e.tp_no_comm = flag("NVR_TP_NO_COMM", false);
+    e.tp_force_comm = flag("NVR_TP_FORCE_COMM", false);
+    e.tp_graph = flag("NVR_TP_GRAPH", true);
+    e.max_graphs = num("NVR_MAX_GRAPHS", 256, 1, 1 << 20);
+    e.p2p_timeout_ms = num("NVR_P2P_TIMEOUT_MS", 20000, 1, 3600000);
+    return e;
+}
 }

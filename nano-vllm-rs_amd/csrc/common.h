@@ -11,6 +11,20 @@ std::string &last_error_slot();
 int &last_status_slot();
 int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 
+// Every NVR_* environment switch of the product, read ONCE when a runner / engine is created (never on a launch path).
+// Diagnostics and test hooks only: the defaults are the product.
+struct Env {
+    bool trace_host = false;      // NVR_TRACE_HOST=1     host time per step phase, printed when the engine is destroyed
+    bool tiled_weights = true;    // NVR_TILED_WEIGHTS=0  decode kernels read the row-major parameters (bit-identical; tests)
+    bool lazy_logits = true;      // NVR_LAZY_LOGITS=0    greedy steps store their f32 logits too (tests)
+    bool tp_no_comm = false;      // NVR_TP_NO_COMM=1     one tensor-parallel rank's compute without its collectives (profiling)
+    bool tp_force_comm = false;   // NVR_TP_FORCE_COMM=1  enqueue the RCCL collectives even with one rank (tests on a 1-GPU box)
+    bool tp_graph = true;         // NVR_TP_GRAPH=0       tensor-parallel decode steps run eagerly
+    int max_graphs = 256;         // NVR_MAX_GRAPHS=n     captured decode graphs kept before the cache is flushed (test hook)
+    int p2p_timeout_ms = 20000;   // NVR_P2P_TIMEOUT_MS=n how long a peer-to-peer collective waits for a peer before it gives up
+    static Env read();
+};
+
 }  // namespace nvr
 
 #define NVR_HIP_CHECK(expr)                                                                     \

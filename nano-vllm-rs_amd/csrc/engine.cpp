@@ -4,20 +4,15 @@
 #include <cstdio>
 #include <cstdlib>
 
-// NVR_TRACE_HOST=1: average host time per decode step spent in schedule / execute (input prep + upload + launch) /
-// sample (arg-max merge launch + D2H + wait for the GPU) / postprocess, printed when the engine is destroyed
+// NVR_TRACE_HOST=1 (read once when the engine is created): average host time per step spent in schedule / execute (input prep +
+// upload + launch) / sample (arg-max merge launch + D2H + wait for the GPU) / postprocess, printed when the engine is destroyed
+nvr_engine::HostTrace::~HostTrace() {
+    if (on && pn) std::fprintf(stderr, "[nvr host trace] %ld prefill steps: schedule %.1f us, execute %.1f us, sample(+GPU wait) %.1f us, postprocess %.1f us\n",
+                               pn, pacc[0] / pn, pacc[1] / pn, pacc[2] / pn, pacc[3] / pn);
+    if (on && n) std::fprintf(stderr, "[nvr host trace] %ld decode steps: schedule %.2f us, execute %.2f us, sample(+GPU wait) %.2f us, postprocess %.2f us\n",
+                              n, acc[0] / n, acc[1] / n, acc[2] / n, acc[3] / n);
+}
 namespace {
-struct HostTrace {
-    bool on = std::getenv("NVR_TRACE_HOST") != nullptr;
-    double acc[4] = {0, 0, 0, 0}; long n = 0;
-    double pacc[4] = {0, 0, 0, 0}; long pn = 0;
-    ~HostTrace() {
-        if (on && pn) std::fprintf(stderr, "[nvr host trace] %ld prefill steps: schedule %.1f us, execute %.1f us, sample(+GPU wait) %.1f us, postprocess %.1f us\n",
-                                   pn, pacc[0] / pn, pacc[1] / pn, pacc[2] / pn, pacc[3] / pn);
-        if (on && n) std::fprintf(stderr, "[nvr host trace] %ld decode steps: schedule %.2f us, execute %.2f us, sample(+GPU wait) %.2f us, postprocess %.2f us\n",
-                                  n, acc[0] / n, acc[1] / n, acc[2] / n, acc[3] / n);
-    }
-} g_trace;
 inline double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 }
 
@@ -79,25 +74,41 @@ int nvr_engine::step_async(nvr_step_info *info) {
     const uint64_t fin_before = scheduler->impl.stats().finished_sequences;
     last_tokens.resize(batch.size());
     if (parity >= 0 && can_launch_ahead(batch)) {
-        // schedule the next step on placeholder tokens and enqueue it, THEN wait for this step's tokens
+        // schedule the next step on placeholder tokens and enqueue it, THEN wait for this step's tokens.  Whatever happens to the
+        // step launched ahead, the CURRENT step ends like a synchronous one: its tokens are collected and patched in.  If the
+        // step behind it could not be enqueued (graph cache full, capture failure, ...) the speculative schedule is rolled back
+        // (cancel_ahead semantics: may_append was a no-op by construction, only the counters moved) and the next call takes the
+        // synchronous path, which reports a persistent failure itself and aborts ITS batch.
         std::vector<int64_t> placeholder(batch.size(), -1);
         int rc = scheduler->impl.postprocess(batch.data(), placeholder.data(), batch.size());
-        if (rc) return rc;
+        if (rc) return rc;                                               // (cannot happen: nobody can stop on this token)
         ahead.stats_before = scheduler->impl.stats();
         bool pf = false;
-        rc = scheduler->impl.schedule(ahead.batch, &pf);
-        if (rc) return rc;
-        if (pf || ahead.batch != batch) return nvr::fail(NVR_ERR_INVARIANT, "launch-ahead: the scheduler built another batch than predicted");
-        ahead.parity = parity ^ 1;
-        rc = runner->execute_decode_ahead(ahead.batch.data(), ahead.batch.size(), ahead.parity);
-        if (!rc) rc = runner->sample_launch(ahead.batch.data(), ahead.batch.size(), ahead.parity);
-        if (rc) return rc;
-        ahead.pending = true;
+        int arc = scheduler->impl.schedule(ahead.batch, &pf);
+        const bool scheduled = arc == NVR_OK;
+        if (scheduled && (pf || ahead.batch != batch)) arc = nvr::fail(NVR_ERR_INVARIANT, "launch-ahead: the scheduler built another batch than predicted");
+        if (!arc) {
+            ahead.parity = parity ^ 1;
+            arc = runner->execute_decode_ahead(ahead.batch.data(), ahead.batch.size(), ahead.parity);
+            if (!arc) arc = runner->sample_launch(ahead.batch.data(), ahead.batch.size(), ahead.parity);
+        }
+        std::string ahead_err; int ahead_status = 0;
+        if (arc) { ahead_err = nvr::last_error_slot(); ahead_status = nvr::last_status_slot(); }
         rc = runner->sample_wait(batch.size(), parity, last_tokens.data());
-        if (rc) return rc;
+        if (rc) {                                                        // the device never delivered: this batch is lost
+            if (scheduled) scheduler->impl.restore_stats(ahead.stats_before);
+            scheduler->impl.abort_batch(batch.data(), batch.size());
+            return rc;
+        }
         for (size_t i = 0; i < batch.size(); ++i) {                      // the placeholders become the sampled tokens
             nvr_seq *s = batch[i];
             s->token_ids[s->num_tokens - 1] = last_tokens[i]; s->last_token = last_tokens[i];
+        }
+        if (!arc) ahead.pending = true;
+        else {
+            if (scheduled) scheduler->impl.restore_stats(ahead.stats_before);
+            if (arc == NVR_ERR_INVARIANT) { nvr::last_error_slot() = ahead_err; nvr::last_status_slot() = ahead_status; return arc; }
+            ++ahead_declined;                                            // (diagnostic counter; the step itself succeeded)
         }
     } else {
         if (parity >= 0) { int rc = runner->sample_wait(batch.size(), parity, last_tokens.data()); if (rc) return rc; }
@@ -114,23 +125,33 @@ int nvr_engine::step_async(nvr_step_info *info) {
     return NVR_OK;
 }
 
+// A batch that must not go on (a tensor-parallel peer reported a failed collective: every rank drops the same batch): the step
+// launched ahead is cancelled and the sequences of the last scheduled batch leave the engine with their blocks returned.
+void nvr_engine::abort_last_batch() {
+    cancel_ahead();
+    std::vector<nvr_seq *> live;
+    for (nvr_seq *s : batch) if (s->status != NVR_SEQ_FINISHED) live.push_back(s);
+    if (!live.empty()) scheduler->impl.abort_batch(live.data(), live.size());
+    batch.clear();
+}
+
 int nvr_engine::step(nvr_step_info *info) {                          // LLMEngine::step, llm_engine.rs:155-197
     if (cfg.async_decode) return step_async(info);
     bool is_prefill = false;
-    const double t0 = g_trace.on ? now_us() : 0;
+    const double t0 = trace.on ? now_us() : 0;
     int rc = scheduler->impl.schedule(batch, &is_prefill);           // :160-166
     if (rc) return rc;
-    const double t1 = g_trace.on ? now_us() : 0;
+    const double t1 = trace.on ? now_us() : 0;
     // A model step that fails after schedule() has allocated blocks and moved the batch to running must not wedge the engine
     // (every later step would schedule the same sequences into the same failure): the batch is aborted — blocks returned,
     // sequences parked as finished — and the error is reported once.
     rc = runner->execute(batch.data(), batch.size(), is_prefill);    // :176-179
     if (rc) { scheduler->impl.abort_batch(batch.data(), batch.size()); return rc; }
-    const double t2 = g_trace.on ? now_us() : 0;
+    const double t2 = trace.on ? now_us() : 0;
     last_tokens.resize(batch.size());
     rc = runner->sample(batch.data(), batch.size(), last_tokens.data());   // :182-185
     if (rc) { scheduler->impl.abort_batch(batch.data(), batch.size()); return rc; }
-    const double t3 = g_trace.on ? now_us() : 0;
+    const double t3 = trace.on ? now_us() : 0;
     for (size_t i = 0; i < batch.size(); ++i)                            // A-23: a prompt this step did not finish has no token yet
         if (batch[i]->chunk_is_partial()) last_tokens[i] = -1;
     last_ids.resize(batch.size());
@@ -139,11 +160,11 @@ int nvr_engine::step(nvr_step_info *info) {                          // LLMEngin
     const uint64_t fin_before = scheduler->impl.stats().finished_sequences;
     rc = scheduler->impl.postprocess(batch.data(), last_tokens.data(), batch.size());   // :188-189
     if (rc) return rc;
-    if (g_trace.on) {
+    if (trace.on) {
         const double t4 = now_us();
-        double *a = is_prefill ? g_trace.pacc : g_trace.acc;
+        double *a = is_prefill ? trace.pacc : trace.acc;
         a[0] += t1 - t0; a[1] += t2 - t1; a[2] += t3 - t2; a[3] += t4 - t3;
-        ++(is_prefill ? g_trace.pn : g_trace.n);
+        ++(is_prefill ? trace.pn : trace.n);
     }
     if (info) {
         info->is_prefill = is_prefill; info->num_seqs = batch.size(); info->num_tokens = ntok;

@@ -17,12 +17,15 @@ struct nvr_engine {
     std::vector<uint64_t> last_ids;
     std::vector<int64_t> last_tokens;
     bool is_running = true;                              // llm_engine.rs:37,353: cleared by shutdown()
+    struct HostTrace { bool on = false; double acc[4] = {0, 0, 0, 0}; long n = 0; double pacc[4] = {0, 0, 0, 0}; long pn = 0; ~HostTrace(); } trace;
     int step(nvr_step_info *info);
     // launch-ahead of greedy decode steps (nvr_config.async_decode): the step enqueued behind the one being reported
     struct Ahead { bool pending = false; std::vector<nvr_seq *> batch; int parity = 0; nvr_sched_stats stats_before{}; } ahead;
     int step_async(nvr_step_info *info);
     bool can_launch_ahead(const std::vector<nvr_seq *> &cur) const;
     void cancel_ahead();                                 // a request arrived (or the engine shuts down) while a step is in flight
+    uint64_t ahead_declined = 0;                         // steps whose successor could not be enqueued ahead (they then ran synchronously)
+    void abort_last_batch();                             // control-plane abort of the batch the engine scheduled last (tensor-parallel ranks)
 
     // SequenceOutput storage of the last generate / generate_stream call (sequence.rs:30-47)
     struct SeqOut { uint64_t seq_id = 0; std::string text; std::vector<int64_t> tokens; size_t nprompt = 0; int32_t status = 0; };

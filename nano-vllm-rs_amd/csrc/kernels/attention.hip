@@ -39,7 +39,6 @@ struct AttnParams {
     const int32_t *kv0_rows;           // per-query kv0 (shared-prefix groups: members shared_len, others 0) or null = p.kv0 for all
     float *part_o; float *part_ml;     // [nq, H, num_parts, D], [nq, H, num_parts, 2]
     half_t *out;                       // [nq, H, D]
-    unsigned long long *stamps;        // NVR_ATTN_EXPERIMENTS: 5 wall_clock64 stamps per workgroup (or null)
 };
 
 template <bool NT>
@@ -95,14 +94,6 @@ __global__ __launch_bounds__(WAVES * 64) void attn_rows_kernel(AttnParams p) {
         load_bt_chunk(b0 >> 6);
     }
 
-#ifdef NVR_ATTN_EXPERIMENTS
-#define NVR_STAMP(i) if (p.stamps && threadIdx.x == 0) p.stamps[blockIdx.x * 24 + (i)] = wall_clock64();
-#define NVR_STAMP_WAVE(i) if (p.stamps && lane == 0) p.stamps[blockIdx.x * 24 + (i) + wave] = wall_clock64();
-#else
-#define NVR_STAMP(i)
-#define NVR_STAMP_WAVE(i)
-#endif
-    NVR_STAMP(0)
     const int ctx = p.ctx_lens[t];
     if (p0 >= ctx && !(DIRECT_OUT)) return;          // empty partition: the merge kernel skips it too
     const int pend = min(ctx, p0 + p.part_size);
@@ -216,7 +207,6 @@ __global__ __launch_bounds__(WAVES * 64) void attn_rows_kernel(AttnParams p) {
         }
     };
 
-    NVR_STAMP(1)
     if (R == 0) issue_remainder();
     for (int r = 0; r < R; ++r) {
         const int tb = p0 + (r * WAVES + wave) * TPI;
@@ -237,11 +227,8 @@ __global__ __launch_bounds__(WAVES * 64) void attn_rows_kernel(AttnParams p) {
         }
         if (r == R - 1) issue_remainder();
         process(std::false_type{}, kk, vv, 0);
-        if (r == 0) { NVR_STAMP(2) }
     }
     if (gt0 < ng) process(std::true_type{}, kt, vt, p0 + gt0 * RPI);
-    NVR_STAMP(3)
-    NVR_STAMP_WAVE(8)
 
     // bring the row-group slots of the wave to their common max and sum them, then merge the waves through LDS
     __shared__ float sm_acc[WAVES][G][D];
@@ -260,7 +247,6 @@ __global__ __launch_bounds__(WAVES * 64) void attn_rows_kernel(AttnParams p) {
         }
     }
     __syncthreads();
-    NVR_STAMP(5)
     for (int idx = threadIdx.x; idx < G * D; idx += WAVES * 64) {
         const int i = idx / D, d = idx % D;
         float M = sm_ml[0][i][0];
@@ -283,9 +269,6 @@ __global__ __launch_bounds__(WAVES * 64) void attn_rows_kernel(AttnParams p) {
             if (d == 0) { p.part_ml[slot * 2] = M; p.part_ml[slot * 2 + 1] = L; }
         }
     }
-    NVR_STAMP(4)
-#undef NVR_STAMP
-#undef NVR_STAMP_WAVE
 }
 
 // merge split-KV partitions: out = sum_p e^(m_p-M) o_p / sum_p e^(m_p-M) l_p
@@ -337,13 +320,6 @@ __global__ __launch_bounds__(256) void attn_merge_kernel(const float *__restrict
 }
 
 // ---- launch configuration ------------------------------------------------------------------------
-struct Tune { int U, waves, unused, nt, parts; };            // parts: 0 = automatic; third field kept for old scripts
-static Tune env_tune() {
-    Tune v{0, 0, 0, 0, 0};
-    if (const char *e = std::getenv("NVR_ATTN_TUNE")) std::sscanf(e, "%d,%d,%d,%d,%d", &v.U, &v.waves, &v.unused, &v.nt, &v.parts);
-    return v;
-}
-
 static inline int parts_for(int64_t nq, int64_t KVH, int64_t max_ctx, int waves, int *part_size) {
     // aim at ~4096 waves over the 256 CUs; partitions are multiples of 64 tokens
     const int64_t want_wgs = 4096 / waves;
@@ -390,7 +366,6 @@ static int launch_attn(const AttnArgs &a, bool paged, hipStream_t s) {
     p.bs_shift = (a.block_size > 0 && (a.block_size & (a.block_size - 1)) == 0) ? __builtin_ctz(a.block_size) : -1;
     p.H = a.H; p.KVH = a.KVH; p.scale = a.scale; p.out = (half_t *)a.out;
     constexpr int DU = (D == 128) ? 4 : 2;           // default: 16 tokens per wave iteration
-    const Tune tn = env_tune();
     // Geometry (measured on MI355X at B=32, ctx 1044, KVH=8, D=128, profiles/r01_attn_tune.txt): one 8-wave
     // workgroup per (query, kv head) = one per CU, each wave with 2 row groups of K and of V in flight (32 KiB per
     // CU), non-temporal loads and no split (23.6 us, 5.8 TB/s) beats 16 waves x 4 groups (25.0 us: more bytes in
@@ -403,7 +378,7 @@ static int launch_attn(const AttnArgs &a, bool paged, hipStream_t s) {
     // (small batches, tensor-parallel ranks that hold 1-4 kv heads) the context is cut into ceil(256 / pairs)
     // 64-token-granular partitions + merge kernel (B=32, ctx 1044: KVH=1 10.9 us vs 14.6 us for the 4-wave path, KVH=2
     // 12.7 vs 14.6, KVH=4 17.5 vs 19.7; scratch/attn_tp_shape.py)
-    int waves = tn.waves ? tn.waves : ((paged && a.workspace && pairs * ((mc + 63) / 64) >= 256) ? 8 : 4);
+    int waves = (paged && a.workspace && pairs * ((mc + 63) / 64) >= 256) ? 8 : 4;
     int part_size = 0x3fffffff, np = 1, sparts = 0, shared_part = 0;
     const bool shared = a.shared_len > 0;
     if (shared) {
@@ -432,10 +407,9 @@ static int launch_attn(const AttnArgs &a, bool paged, hipStream_t s) {
         want = std::max<int64_t>(1, std::min<int64_t>(want, cap - sparts));
         part_size = (int)(((rest + want - 1) / want + 63) / 64 * 64);
         np = sparts + (int)((rest + part_size - 1) / part_size);
-        waves = tn.waves ? tn.waves : 4;
+        waves = 4;
     } else if (a.workspace) {
-        if (tn.parts > 0) { part_size = (int)(((mc + tn.parts - 1) / tn.parts + 63) / 64 * 64); np = (int)((mc + part_size - 1) / part_size); }
-        else if (waves >= 8) {
+        if (waves >= 8) {
             int64_t want = pairs >= 192 ? 1 : (256 + pairs - 1) / pairs;
             int64_t ps = ((mc + want - 1) / want + 63) / 64 * 64;
             part_size = (int)ps; np = (int)((mc + ps - 1) / ps);
@@ -456,21 +430,7 @@ static int launch_attn(const AttnArgs &a, bool paged, hipStream_t s) {
     if (shared)
         if (int rc = flash_shared_prefix(a.q, a.ldq, a.k, a.v, a.block_tables, a.max_blocks, a.block_size, a.nq, a.H, a.KVH, a.D, a.scale,
                                          shared_part, sparts, np, p.part_o, p.part_ml, s, a.shared_rows, a.shared_count)) return rc;
-    bool done = false;
-#ifdef NVR_ATTN_EXPERIMENTS
-    if (direct && a.workspace && std::getenv("NVR_ATTN_STAMPS")) p.stamps = (unsigned long long *)a.workspace;
-    if (D == 128 && G == 2 && paged && tn.U) {
-#define NVR_TRY(UU, WW, NN)                                                                              \
-        if (!done && tn.U == UU && waves == WW && tn.nt == NN) {                                         \
-            launch_cfg<D, G, UU, WW, NN != 0>(p, paged, direct, nwg, s); done = true; }
-        NVR_TRY(4, 16, 1) NVR_TRY(4, 16, 0) NVR_TRY(2, 16, 1) NVR_TRY(8, 16, 1) NVR_TRY(4, 8, 1) NVR_TRY(8, 8, 1)
-        NVR_TRY(2, 8, 1) NVR_TRY(4, 4, 1) NVR_TRY(8, 4, 1) NVR_TRY(1, 4, 1) NVR_TRY(1, 8, 1) NVR_TRY(1, 16, 1) NVR_TRY(2, 4, 1)
-        NVR_TRY(2, 8, 0) NVR_TRY(2, 6, 1) NVR_TRY(2, 10, 1) NVR_TRY(2, 12, 1) NVR_TRY(1, 12, 1) NVR_TRY(4, 6, 1) NVR_TRY(4, 3, 1) NVR_TRY(4, 5, 1)
-#undef NVR_TRY
-        if (!done) return nvr::fail(NVR_ERR_UNSUPPORTED, "NVR_ATTN_TUNE names a variant that is not compiled in");
-    }
-#endif
-    if (!done) {
+    {
         if (waves == 8) launch_cfg<D, G, DU / 2, 8, true>(p, paged, direct, nwg, s);        // K/V streamed once: nt loads
         else if (paged) launch_cfg<D, G, DU, 4, true>(p, paged, direct, nwg, s);
         else launch_cfg<D, G, DU, 4, false>(p, paged, direct, nwg, s);                     // prefill: rows re-read from L2

@@ -26,7 +26,7 @@
 
 namespace nvr {
 
-__device__ __forceinline__ unsigned long long p2p_now() { return __builtin_readcyclecounter(); }   // s_memtime (shader clock)
+__device__ __forceinline__ unsigned long long p2p_now() { return wall_clock64(); }   // s_memrealtime: 100 MHz, independent of the shader clock
 
 template <int P>   // P = 8 or 4 fp16 elements per thread and chunk
 __global__ __launch_bounds__(256) void p2p_allreduce_kernel(P2PArgs a) {
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void p2p_allreduce_kernel(P2PArgs a) {
                 const unsigned long long t0 = p2p_now();
                 while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != epoch) {
                     __builtin_amdgcn_s_sleep(2);
-                    if (p2p_now() - t0 > a.timeout_cycles) { ok = false; break; }
+                    if (p2p_now() - t0 > a.timeout_ticks) { ok = false; break; }
                 }
             }
             ok = __all(ok);
@@ -96,6 +96,12 @@ __global__ __launch_bounds__(256) void p2p_allreduce_kernel(P2PArgs a) {
                     } else {
                         x[r] = __builtin_bit_cast(hp_t, __builtin_amdgcn_raw_buffer_load_b64(rs, (int)(((size_t)r * slot_elems + rbase + c) * 2), 0, 17));
                     }
+                }
+                if (a.gather_stride) {                                             // all-gather form: every rank's piece, unreduced
+#pragma unroll
+                    for (int r = 0; r < 8; ++r)
+                        if (r < a.nranks) *reinterpret_cast<hp_t *>(a.out + (size_t)r * a.gather_stride + rbase + c) = x[r];
+                    continue;
                 }
                 float acc[P];                                                      // rank order: the same sum on every rank
 #pragma unroll
@@ -177,7 +183,7 @@ __global__ __launch_bounds__(256) void p2p_allgather_kernel(P2PArgs a, const cha
                 const unsigned long long t0 = p2p_now();
                 while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != epoch) {
                     __builtin_amdgcn_s_sleep(2);
-                    if (p2p_now() - t0 > a.timeout_cycles) { ok = false; break; }
+                    if (p2p_now() - t0 > a.timeout_ticks) { ok = false; break; }
                 }
             }
             ok = __all(ok);

@@ -364,8 +364,6 @@ static int g256_grid(int tiles) { return tiles < 256 ? tiles : 256; }   // one p
 // RoPE + KV-store epilogue gains 12 % with CG = 1 (an XCD writes whole output rows and cache rows at a time).
 static int g256_cg(int tiles_x, int tiles_y, bool rope) {
     int cg = rope ? 1 : 0;
-    if (const char *e = std::getenv("NVR_G256_CG")) cg = std::atoi(e);
-    if (cg < 0 || cg > 8 || (cg & (cg - 1))) cg = 0;
     if (cg && (tiles_x % cg || tiles_y < 8 / cg || tiles_x * tiles_y < 256)) cg = 0;
     return cg;
 }
@@ -374,10 +372,7 @@ static int g256_check(const char *what) {
     if (e != hipSuccess) return nvr::fail(NVR_ERR_HIP, "%s launch failed: %s", what, hipGetErrorString(e));
     return 0;
 }
-static bool g256_enabled() {
-    static const bool on = !(std::getenv("NVR_GEMM256") && std::getenv("NVR_GEMM256")[0] == '0');
-    return on;
-}
+static constexpr bool g256_enabled() { return true; }
 
 bool gemm256_ok(int64_t T, int64_t K, int64_t N, int64_t ldx) {
     return g256_enabled() && T >= 256 && K % G_BK == 0 && K >= 2 * G_BK && N % 256 == 0 && ldx % 8 == 0;

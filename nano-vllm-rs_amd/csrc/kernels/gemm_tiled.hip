@@ -287,18 +287,11 @@ static int tiled_check(const char *what) {
     return 0;
 }
 
-// ring (NS = 4) when the grid leaves CUs idle anyway; NVR_TILED_RING=0/1 forces
-static bool tiled_ring(unsigned tiles) {
-    static const int force = [] { const char *e = getenv("NVR_TILED_RING"); return e ? atoi(e) : -1; }();
-    return force >= 0 ? force != 0 : tiles < 256;
-}
+// ring (NS = 4) when the grid leaves CUs idle anyway
+static bool tiled_ring(unsigned tiles) { return tiles < 256; }
 // 64- or 32-token tiles when 128-token tiles would leave CUs without a workgroup: the largest tile that reaches ~192 workgroups
-// (NVR_TILED_BM=128/64/32 forces).  Returns the m-tiles per wave (4, 2, 1).
+// Returns the m-tiles per wave (4, 2, 1).
 static int tiled_mt(int64_t T, int64_t nx_nz) {
-    static const int force = [] { const char *e = getenv("NVR_TILED_BM"); return e ? atoi(e) : 0; }();
-    if (force == 128) return 4;
-    if (force == 64) return 2;
-    if (force == 32) return 1;
     if (T <= 32 || nx_nz * ((T + 127) / 128) >= 192) return 4;   // (192 workgroups of 128 tokens beat 384 of 64: 15.6 vs 19.3 us, gate_up at T = 512)
     if (nx_nz * ((T + 63) / 64) >= 192) return 2;
     return 1;
@@ -342,7 +335,7 @@ int gemm_tiled_prepare() {
     return 0;
 }
 
-static bool tiled_enabled() { static const bool on = [] { const char *e = getenv("NVR_GEMM_TILED"); return !(e && e[0] == '0'); }(); return on; }
+static constexpr bool tiled_enabled() { return true; }
 // LM head for more than 32 rows (large decode batches, many-sequence prefills): weights streamed once per 128-row block
 bool gemm_tiled_lm_head_ok(int64_t T, int64_t K, int64_t N, int64_t ldx) {
     return tiled_enabled() && T > 32 && T <= 65536 && K % BK == 0 && N % 16 == 0 && ldx % 8 == 0 && (N + BN - 1) / BN <= LM_HEAD_MAX_PARTS &&

@@ -243,13 +243,10 @@ static inline bool prefer_256(int64_t T, int64_t K, int64_t N) {
 }
 // one rule for the plain and the fused launchers (N = output features), so that a fused GEMM and its unfused twin run the same kernel
 bool gemm256_preferred(int64_t T, int64_t K, int64_t N, int64_t ldx) { return gemm256_ok(T, K, N, ldx) && prefer_256(T, K, N); }
-int64_t stream_row_limit() {
-    static const int64_t tmax = [] { const char *e = std::getenv("NVR_PREFER_STREAM_T"); return e ? (int64_t)atoll(e) : (int64_t)64; }();
-    return tmax;
-}
+int64_t stream_row_limit() { return 64; }
 static inline bool prefer_stream(int64_t T, int64_t N) {
     // up to 64 rows the weight-streaming kernel; beyond, the LDS-tiled kernel with 32- / 64-token tiles and the 4-buffer ring (r02,
-    // ctx 256: bs 66 2.20 -> 1.83 ms/step, bs 96 2.48 -> 2.15, bs 128 2.82 -> 2.23).  NVR_PREFER_STREAM_T moves the boundary.
+    // ctx 256: bs 66 2.20 -> 1.83 ms/step, bs 96 2.48 -> 2.15, bs 128 2.82 -> 2.23).
     return T <= stream_row_limit() || T * N <= 384 * 1024;
 }
 static inline int waves_for(int64_t K) { return K >= 2048 ? 16 : (K >= 1024 ? 8 : 4); }

@@ -379,8 +379,7 @@ int decode_splitk_slices(int64_t T, int64_t K, int64_t N) {
 // h[T,N] <- fp16(h + fp16(x[T,K]·W[N,K]ᵀ)); S k-slices, slabs [S][T][N] f32, cnt: one zeroed counter per (column tile, token tile)
 int linear_resid(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t N, int64_t S, float *slabs,
                  unsigned int *cnt, half_bits *h, hipStream_t s, const half_bits *Wt) {
-    static const bool half_env = [] { const char *v = std::getenv("NVR_RESID_HALF"); return v && v[0] == '1'; }();
-    const bool half_tiles = S == 0 || half_env;             // S = 0: 8-row weight tiles, no k split, no slabs, no tickets
+    const bool half_tiles = S == 0;            // S = 0: 8-row weight tiles, no k split, no slabs, no tickets
     if (half_tiles) S = 1;
     if (S < 1 || S > 4 || K % (32 * S) || N % 16 || ldx % 8 || T > 64 || (!half_tiles && K / S > 2048))
         return nvr::fail(NVR_ERR_UNSUPPORTED, "linear_resid: K=%ld S=%ld N=%ld T=%ld ldx=%ld", (long)K, (long)S, (long)N, (long)T, (long)ldx);

@@ -187,10 +187,7 @@ __global__ __launch_bounds__(WAVES * 64) void linear_stream_kernel(const half_t 
 
 // ---- host side -------------------------------------------------------------------------------------------------------
 constexpr int S_WAVES = 8, S_TMAX = 4;
-static bool stream_enabled() {
-    static const bool on = !(std::getenv("NVR_STREAM_GEMM") && std::getenv("NVR_STREAM_GEMM")[0] == '0');
-    return on;
-}
+static constexpr bool stream_enabled() { return true; }
 static int stream_kc(int64_t T, int64_t K) {                                 // K chunk held in LDS (<= 128 KiB image)
     const int64_t cap = T <= 16 ? 4096 : 2048;
     return (int)(K <= cap ? K : cap);

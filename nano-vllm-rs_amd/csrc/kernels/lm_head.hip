@@ -132,22 +132,14 @@ bool lm_head_ok(int64_t T, int64_t K, int64_t N, int64_t ldx) {
     return T >= 1 && T <= 32 && K % 256 == 0 && K <= 2048 && N % 16 == 0 && N >= 16 && ldx % 8 == 0 && N < (1ll << 31);
 }
 
-struct LmTune { int U, waves, per_cu; };
-static LmTune lm_env_tune() {
-    LmTune t{0, 0, 0};
-    if (const char *e = std::getenv("NVR_LMHEAD_TUNE")) std::sscanf(e, "%d,%d,%d", &t.U, &t.waves, &t.per_cu);
-    return t;
-}
-
 struct LmPlan { int mt, waves, U; int64_t nwg; };
 static LmPlan lm_plan(int64_t T, int64_t K, int64_t N) {
-    const LmTune tn = lm_env_tune();
     LmPlan pl;
     pl.mt = T <= 16 ? 1 : 2;
     const size_t lds = (size_t)pl.mt * 16 * K * 2;
-    int per_cu = tn.per_cu ? tn.per_cu : 1;
+    int per_cu = 1;
     if ((size_t)per_cu * lds > 160 * 1024) per_cu = (int)(160 * 1024 / lds);
-    pl.waves = tn.waves ? tn.waves : 8; pl.U = tn.U ? tn.U : 4;
+    pl.waves = 8; pl.U = 4;
     pl.nwg = 256ll * per_cu;
     const int64_t ntiles = N / 16;
     if (pl.nwg * pl.waves > ntiles) pl.nwg = (ntiles + pl.waves - 1) / pl.waves;

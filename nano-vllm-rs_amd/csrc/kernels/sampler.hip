@@ -564,8 +564,7 @@ int sample(const float *logits, int64_t B, int64_t V, const float *temperature, 
            const float *top_p, const uint64_t *keys, int64_t *out_ids, void *workspace, hipStream_t s, bool store_filtered) {
     if (B == 0) return 0;
     if (!workspace || !temperature) return nvr::fail(NVR_ERR_INVALID_ARG, "sample: workspace and temperature are required");
-    static const bool rows_form = [] { const char *e = getenv("NVR_SAMPLE_ROWS"); return !(e && e[0] == '0'); }();
-    if (rows_form && B <= 64) {
+    if (B <= 64) {
         const int rpx = (int)(B + 7) / 8;                            // rows per XCD
         // the sharers of a row wait for each other: every workgroup of the grid must be resident at once, one 1024-thread
         // workgroup per CU (128 VGPRs) -> no more workgroups than the device has CUs (256 on an MI355X, fewer in a partitioned mode)

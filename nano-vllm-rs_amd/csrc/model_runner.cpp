@@ -53,6 +53,7 @@ nvr_model_runner::~nvr_model_runner() {
 }
 
 int nvr_model_runner::init() {                                       // ModelRunner::new, :67-102
+    env = nvr::Env::read();                                          // the only place the runner looks at the environment
     tp = (int64_t)cfg.tensor_parallel_size; rank = (int64_t)cfg.tensor_parallel_rank;
     if (tp < 1 || rank >= tp) return nvr::fail(NVR_ERR_INVALID_ARG, "bad tensor parallel rank %ld of %ld", (long)rank, (long)tp);
     RC(nvr_model_config_validate(&mc, (uint64_t)tp));
@@ -98,14 +99,14 @@ int nvr_model_runner::init() {                                       // ModelRun
     slab_rows = std::max<int64_t>(64, std::min<int64_t>(1024, std::max<int64_t>(max_seqs, 256)));
     RC(dmalloc(&slabs, 4 * slab_rows * Hd));
     chain4 = cfg.decode_chain == 4;
-    if (const char *e = getenv("NVR_DECODE_CHAIN")) chain4 = e[0] == '4';              // A/B measurements of an unchanged caller
     NVR_HIP_CHECK(hipMalloc((void **)&chain_cnt, 4096 * sizeof(unsigned int)));
     NVR_HIP_CHECK(hipMemset(chain_cnt, 0, 4096 * sizeof(unsigned int)));
-    { const char *e = getenv("NVR_TP_NO_COMM"); allow_missing_comm = e && e[0] == '1'; }   // compute-only profiling of one rank
+    allow_missing_comm = env.tp_no_comm;                                               // compute-only profiling of one rank
+    if (!env.tp_graph && tp > 1) graphs_disabled = true;
+    comm.force = env.tp_force_comm; comm.timeout_ms = env.p2p_timeout_ms;
     RC(k::linear_stream_prepare());
     RC(k::gemm_tiled_prepare());
-    { const char *e = getenv("NVR_LM_FUSED"); lm_fused = !(e && e[0] == '0'); }
-    { const char *e = getenv("NVR_LAZY_LOGITS"); lazy_logits = !(e && e[0] == '0'); }
+    lazy_logits = env.lazy_logits;
     {   // arg-max partials [parts][rows]: <= LM_HEAD_MAX_PARTS x 32 rows (lm_head_kernel), or one per 128 vocabulary columns x all rows
         const size_t pe = std::max<size_t>((size_t)k::LM_HEAD_MAX_PARTS * 32, (size_t)((Vl + 127) / 128) * (size_t)max_seqs);
         RC(dmalloc(&d_lm_pval, pe)); RC(dmalloc(&d_lm_pidx, pe));
@@ -139,8 +140,7 @@ int nvr_model_runner::init() {                                       // ModelRun
 
     RC(dmalloc(&d_tok, max_seqs)); RC(dmalloc(&d_maxval, max_seqs));
     NVR_HIP_CHECK(hipHostMalloc((void **)&h_tok, max_seqs * 8, hipHostMallocDefault));
-    { const char *e = getenv("NVR_ZERO_COPY_TOKENS");
-      if (!(e && e[0] == '0') && hipHostGetDevicePointer((void **)&h_tok_dev, h_tok, 0) != hipSuccess) { h_tok_dev = nullptr; (void)hipGetLastError(); } }
+    if (hipHostGetDevicePointer((void **)&h_tok_dev, h_tok, 0) != hipSuccess) { h_tok_dev = nullptr; (void)hipGetLastError(); }
     if (cfg.async_decode && h_tok_dev) {                                 // launch-ahead: one token buffer and one input twin per step in flight
         for (int i = 0; i < 2; ++i) {
             NVR_HIP_CHECK(hipHostMalloc((void **)&ahead_tok[i], max_seqs * 8, hipHostMallocDefault));
@@ -193,7 +193,7 @@ int nvr_model_runner::retile_all() {
 
 int nvr_model_runner::gen_weights() {
     const float sc = nvr_weight_scale_impl(mc.init_std);
-    { const char *e = getenv("NVR_TILED_WEIGHTS"); tiled_weights = !(e && e[0] == '0'); }
+    tiled_weights = env.tiled_weights;
     if (Hd % 32 || (H * D) % 32 || I % 32 || QKV % 16 || D % 16) tiled_weights = false;
     const int64_t Hg = mc.num_attention_heads, KVHg = mc.num_key_value_heads, Ig = mc.intermediate_size;
     layers.resize(L);
@@ -578,8 +578,7 @@ int nvr_model_runner::execute(nvr_seq *const *seqs, size_t nseq, bool is_prefill
         if (chunked && !flash_ok)
             for (size_t b = 0; b < nseq; ++b)
                 if (seqs[b]->chunk_start > 0) return nvr::fail(NVR_ERR_UNSUPPORTED, "chunked prefill needs the paged flash kernel (head_dim 64/128)");
-        static const bool always_paged = [] { const char *e = getenv("NVR_PREFILL_PAGED"); return e && e[0] == '1'; }();
-        prefill_paged = always_paged && flash_ok;
+        prefill_paged = false;
         int64_t total = 0;
         for (size_t b = 0; b < nseq; ++b) {
             int64_t lo, hi; range_of(*seqs[b], &lo, &hi);
@@ -681,7 +680,7 @@ int nvr_model_runner::execute(nvr_seq *const *seqs, size_t nseq, bool is_prefill
     const uint64_t key = graph_key(want_logits, nseq, bucket, decode_shared_len, decode_shared_len > 0 && decode_shared_rows < (int64_t)nseq);
     auto it = graphs.find(key);
     if (it == graphs.end()) {
-        if (graphs.size() >= kMaxGraphs) {               // a long-lived engine sees many (batch size, bucket) pairs: bound the cache
+        if (graphs.size() >= (size_t)env.max_graphs) {   // a long-lived engine sees many (batch size, bucket) pairs: bound the cache
             NVR_HIP_CHECK(hipStreamSynchronize(stream));
             for (auto &kv : graphs) hipGraphExecDestroy(kv.second);
             graphs.clear();
@@ -712,7 +711,8 @@ int nvr_model_runner::execute(nvr_seq *const *seqs, size_t nseq, bool is_prefill
 // tables follow from the sequence lengths alone.  Nothing here synchronises the stream.
 int nvr_model_runner::execute_decode_ahead(nvr_seq *const *seqs, size_t nseq, int parity) {
     NVR_HIP_CHECK(hipSetDevice(device));
-    if (!ahead_capable()) return nvr::fail(NVR_ERR_INVARIANT, "execute_decode_ahead: runner not set up for launch-ahead");
+    if (!ahead_capable()) return nvr::fail(NVR_ERR_UNSUPPORTED, "execute_decode_ahead: runner not set up for launch-ahead");
+    if (tiled_dirty) return nvr::fail(NVR_ERR_UNSUPPORTED, "execute_decode_ahead: parameters changed, the tiled copies are rebuilt by a synchronous step");
     if (nseq == 0 || (int64_t)nseq > max_seqs) return nvr::fail(NVR_ERR_INVALID_ARG, "execute_decode_ahead: %zu sequences", nseq);
     char *hd = ahead_host[parity & 1];
     int64_t *pos = (int64_t *)(hd + dof_pos);
@@ -746,7 +746,9 @@ int nvr_model_runner::execute_decode_ahead(nvr_seq *const *seqs, size_t nseq, in
     const uint64_t key = graph_key(want_logits, nseq, bucket, decode_shared_len, decode_shared_len > 0 && decode_shared_rows < (int64_t)nseq);
     auto it = graphs.find(key);
     if (it == graphs.end()) {
-        if (graphs.size() >= kMaxGraphs) return nvr::fail(NVR_ERR_UNSUPPORTED, "execute_decode_ahead: graph cache full");   // (flushing needs an idle stream)
+        // flushing the cache needs an idle stream, and the current step is still running: decline — the engine rolls the
+        // speculative schedule back and the synchronous path of the next call flushes and captures (engine.cpp)
+        if (graphs.size() >= (size_t)env.max_graphs) return nvr::fail(NVR_ERR_UNSUPPORTED, "execute_decode_ahead: graph cache full");
         hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr;
         NVR_HIP_CHECK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
         int rc = forward(T, T, false, bucket);
@@ -894,6 +896,7 @@ int nvr_model_runner::sample(nvr_seq *const *seqs, size_t nseq, int64_t *out) {
                 NVR_HIP_CHECK(hipMalloc(&sample_ws_full, k::sample_workspace_bytes(max_seqs, V)));
             }
             RC(comm.all_gather_bytes(logits, d_gather_logits, (size_t)(B * Vl) * 4, stream));
+            RC(comm.p2p_check_error(stream));                            // (synchronises) a peer that never arrived this step
             RC(k::concat_vocab_shards(d_gather_logits, tp, B, Vl, d_full_logits, stream));
             lg = d_full_logits; Vs = V; ws = sample_ws_full;
         }

@@ -11,8 +11,10 @@
 #include <vector>
 #include "sequence.h"
 #include "comm.h"
+#include "common.h"
 
 struct nvr_model_runner {
+    nvr::Env env;                          // NVR_* switches, read once in init()
     nvr_config cfg{};
     nvr_model_config mc{};
     // derived, per rank (qwen3.rs:158-159, linear.rs:300-304)
@@ -29,7 +31,7 @@ struct nvr_model_runner {
     std::vector<Layer> layers;
     uint16_t *embed = nullptr, *lm_head = nullptr, *norm = nullptr;
     uint16_t *lm_head_t = nullptr;         // tiled copy of the LM head (decode-sized steps)
-    bool tiled_weights = true, tiled_dirty = true;   // NVR_TILED_WEIGHTS=0 keeps the row-major parameters only
+    bool tiled_weights = true, tiled_dirty = true;   // env.tiled_weights = false keeps the row-major parameters only
     int retile_all();                      // (re)build the tiled copies from the row-major parameters (init, after load_tensor)
     float *cos_t = nullptr, *sin_t = nullptr;
     uint16_t *kv_pool = nullptr;
@@ -98,7 +100,6 @@ private:
     int gen_weights();
     int row_parallel_norm(const uint16_t *x, int64_t K, const uint16_t *W, const uint16_t *Wt, int64_t T, const uint16_t *wn);
     bool use_chain4(int64_t T, bool is_prefill) const;
-    static constexpr size_t kMaxGraphs = 256;            // captured decode graphs kept before the cache is flushed
     int64_t *h_tok_dev = nullptr;                        // device-visible address of the pinned token buffer h_tok
     int64_t slab_rows = 64;           // rows the split-k slab buffers hold (row_parallel_norm)
     // sharing group of a decode batch (0 = none / too small: plain paged attention); fills kv0[nseq], rows[nseq], *count of the arena

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <initializer_list>
 #include <new>
@@ -133,9 +134,11 @@ int nvr_sched_schedule(nvr_scheduler_t *sc, nvr_seq_t **out, size_t cap, size_t 
     static thread_local std::vector<nvr_seq *> tmp;
     bool pf = false;
     // checked BEFORE scheduling: schedule() allocates blocks and moves sequences to running, a batch that does not fit the
-    // caller's array afterwards would be lost to it
-    if (cap < sc->impl.max_num_seqs())
-        return nvr::fail(NVR_ERR_INVALID_ARG, "schedule: output capacity %zu < max_num_seqs %zu", cap, sc->impl.max_num_seqs());
+    // caller's array afterwards would be lost to it.  A batch never holds more than min(max_num_seqs, live sequences) entries.
+    const size_t need = std::min(sc->impl.max_num_seqs(), sc->impl.waiting_len() + sc->impl.running_len());
+    if (cap < need)
+        return nvr::fail(NVR_ERR_INVALID_ARG, "schedule: output capacity %zu < min(max_num_seqs %zu, %zu live sequences)", cap,
+                         sc->impl.max_num_seqs(), sc->impl.waiting_len() + sc->impl.running_len());
     int rc = sc->impl.schedule(tmp, &pf);
     if (rc) return rc;
     std::memcpy(out, tmp.data(), tmp.size() * sizeof(nvr_seq *));
@@ -170,6 +173,8 @@ int nvr_runner_execute_model(nvr_model_runner_t *r, nvr_seq_t *const *seqs, size
     NVR_GUARD_BEGIN
     int rc = r->execute(seqs, n, is_prefill != 0);
     if (rc == NVR_OK && logits_dev) { rc = r->ensure_logits(); *logits_dev = r->logits; }
+    // a tensor-parallel step whose peer never arrived holds zeros in place of the peer's sums: never hand that out as a result
+    if (rc == NVR_OK && logits_dev && r->tp > 1) rc = r->comm.p2p_check_error(r->stream);
     return rc;
     NVR_GUARD_END(NVR_ERR_INVARIANT)
 }
@@ -186,6 +191,7 @@ int nvr_runner_copy_logits(nvr_model_runner_t *r, float *host_out, size_t rows) 
     if (rows > r->last_rows) return nvr::fail(NVR_ERR_LEN_MISMATCH, "copy_logits: %zu rows requested, %zu available", rows, r->last_rows);
     NVR_HIP_CHECK(hipSetDevice(r->device));
     if (int rc = r->ensure_logits()) return rc;
+    if (r->tp > 1) { if (int rc = r->comm.p2p_check_error(r->stream)) return rc; }
     NVR_HIP_CHECK(hipMemcpyAsync(host_out, r->logits, rows * r->Vl * sizeof(float), hipMemcpyDeviceToHost, r->stream));
     NVR_HIP_CHECK(hipStreamSynchronize(r->stream));
     return NVR_OK;
@@ -207,7 +213,6 @@ int nvr_runner_init_comm(nvr_model_runner_t *r, const uint8_t id[128]) {
     // Multi-rank decode steps replay a captured hipGraph like single-rank ones (the one-shot peer-to-peer collectives are plain
     // kernel nodes; ncclAllReduce nodes capture too).  If the capture cannot be built the runner falls back to eager launches
     // (execute()); NVR_TP_GRAPH=0 forces eager.
-    if (const char *e = std::getenv("NVR_TP_GRAPH")) if (e[0] == '0' && r->tp > 1) r->graphs_disabled = true;
     return r->tp > 1 ? r->comm_selftest() : NVR_OK;            // also establishes every RCCL connection up front
 }
 // One-shot peer-to-peer collectives (kernels/comm_p2p.hip): every rank allocates an arena and exports its hipIpc handle; the
@@ -232,6 +237,13 @@ int nvr_runner_p2p_attach(nvr_model_runner_t *r, const uint8_t *handles, const i
 }
 int nvr_runner_p2p_disable(nvr_model_runner_t *r) { r->comm.p2p_ready = false; return NVR_OK; }
 int nvr_runner_p2p_active(const nvr_model_runner_t *r) { return r->comm.p2p_ready ? 1 : 0; }
+int nvr_runner_p2p_reset(nvr_model_runner_t *r) {
+    NVR_GUARD_BEGIN
+    NVR_HIP_CHECK(hipSetDevice(r->device));
+    return r->comm.p2p_reset();
+    NVR_GUARD_END(NVR_ERR_INVARIANT)
+}
+int nvr_runner_comm_drop_rccl(nvr_model_runner_t *r) { r->comm.drop_rccl(); return NVR_OK; }
 int64_t nvr_runner_last_shared_prefix_len(const nvr_model_runner_t *r) { return r->last_prefill ? 0 : r->decode_shared_len; }
 int64_t nvr_runner_last_shared_prefix_rows(const nvr_model_runner_t *r) { return (r->last_prefill || r->decode_shared_len == 0) ? 0 : r->decode_shared_rows; }
 
@@ -273,6 +285,7 @@ nvr_engine_t *nvr_engine_create(const nvr_config *cfg, const nvr_model_config *m
     nvr_config sc = *cfg;
     sc.num_kvcache_blocks = (int64_t)e->runner->num_blocks;          // one pool size for scheduler and runner
     e->scheduler.reset(new nvr_scheduler(sc));
+    e->trace.on = e->runner->env.trace_host;
     return e.release();
     NVR_GUARD_END(nullptr)
 }
@@ -400,6 +413,8 @@ void nvr_engine_last_step(const nvr_engine_t *e, const uint64_t **ids, const int
     *ids = e->last_ids.data(); *toks = e->last_tokens.data(); *n = e->last_ids.size();
 }
 size_t nvr_engine_take_finished(nvr_engine_t *e, nvr_seq_t **out, size_t cap) { return e->scheduler->impl.take_finished(out, cap); }
+int nvr_engine_abort_last_batch(nvr_engine_t *e) { NVR_GUARD_BEGIN e->abort_last_batch(); return NVR_OK; NVR_GUARD_END(NVR_ERR_INVARIANT) }
+uint64_t nvr_engine_ahead_declined(const nvr_engine_t *e) { return e->ahead_declined; }
 size_t nvr_engine_last_batch(const nvr_engine_t *e, nvr_seq_t **out, size_t cap) {
     size_t n = 0;
     for (nvr_seq *s : e->batch) if (s->status != NVR_SEQ_FINISHED && n < cap) out[n++] = s;

@@ -141,6 +141,7 @@ int Scheduler::try_schedule_decode(std::vector<nvr_seq *> &out) {    // :171-223
 int Scheduler::preempt_sequence(nvr_seq *s) {                        // :226-231
     s->status = NVR_SEQ_PREEMPTED;
     int rc = bm_->impl.deallocate(*s);
+    s->num_computed_tokens = 0; s->chunk_start = s->chunk_len = 0;  // recompute-style preemption: nothing of it is in the cache any more
     waiting_.push_front(s);
     stats_.preemptions += 1;
     return rc;
@@ -150,8 +151,14 @@ int Scheduler::postprocess(nvr_seq *const *seqs, const int64_t *token_ids, size_
     // (the reference's length check, :235-237, is enforced at the ABI: one n for both arrays)
     for (size_t i = 0; i < n; ++i) {
         nvr_seq *s = seqs[i];
-        s->num_computed_tokens = s->chunk_start + s->chunk_len;
-        if (s->num_computed_tokens < s->len()) continue;             // A-23: a prefill chunk that does not finish the prompt
+        // A-23: a prefill chunk that does not finish its prompt yields no token.  Only a sequence THIS scheduler stamped with a
+        // partial chunk can be in that state (chunked prefill on, not yet moved to running: status WAITING or PREEMPTED); every other sequence
+        // gets its token appended exactly as the reference does (:240-242), whatever its chunk fields hold.
+        if (chunked_ && s->status != NVR_SEQ_RUNNING && s->status != NVR_SEQ_FINISHED && s->chunk_len > 0 && s->chunk_start + s->chunk_len < s->len()) {
+            s->num_computed_tokens = s->chunk_start + s->chunk_len;
+            continue;
+        }
+        s->num_computed_tokens = s->len();
         s->append_token(token_ids[i]);
         if (s->should_stop(has_eos_, eos_)) {
             s->status = NVR_SEQ_FINISHED;

@@ -46,7 +46,7 @@ struct nvr_seq {
         if (!sampling.ignore_eos && has_eos && last_token == eos) return true;
         return false;
     }
-    void preempt() { status = NVR_SEQ_PREEMPTED; block_table.clear(); num_cached_tokens = 0; num_computed_tokens = 0; }  // :213
+    void preempt() { status = NVR_SEQ_PREEMPTED; block_table.clear(); num_cached_tokens = 0; num_computed_tokens = 0; chunk_start = chunk_len = 0; }  // :213
 };
 
 namespace nvr {

@@ -660,6 +660,51 @@ def test_async_decode_is_transparent(bs, eos, nblocks):
     assert fa == fs and sa == ss and len(fa) == 6
 
 
+def test_async_decode_survives_a_full_graph_cache():
+    """Launch-ahead error path (engine.cpp): with the graph cache limited to 2 entries (NVR_MAX_GRAPHS, read once when the runner is
+    created) and batch sizes that keep changing (sequences finish at different steps, new ones arrive: a new graph key every few
+    steps), the step behind the current one regularly cannot be enqueued ahead.  The current step must still deliver its tokens, the
+    speculative schedule must be rolled back, and the next call must take the synchronous path (which flushes the cache): every
+    step's batch, tokens, finished sets and statistics equal those of the synchronous engine, and nothing is left holding the
+    placeholder token."""
+    mcfg = mo.small(seed=21)
+    ecfg = dict(max_num_seqs=8, max_num_batched_tokens=512, max_model_len=300, kvcache_block_size=64, num_kvcache_blocks=48)
+    reqs = [(oracle.fill_tokens(int(n), 3, i, mcfg.vocab_size).tolist(), int(mt)) for i, (n, mt) in
+            enumerate([(9, 30), (20, 11), (5, 23), (18, 37), (11, 7), (30, 19)])]
+    late = {6: (oracle.fill_tokens(12, 3, 9, mcfg.vocab_size).tolist(), 25), 14: (oracle.fill_tokens(4, 3, 10, mcfg.vocab_size).tolist(), 15)}
+
+    def run(async_on, max_graphs):
+        os.environ["NVR_MAX_GRAPHS"] = str(max_graphs)
+        try:
+            nvr.lib().nvr_seq_reset_id_counter()
+            p = nvr.LLMEngine(nvr.Config(skip_block_size_check=1, async_decode=async_on, **ecfg), _model_cfgs(mcfg))
+        finally:
+            os.environ.pop("NVR_MAX_GRAPHS", None)
+        for pr, mt in reqs:
+            p.add_request(pr, nvr.SamplingParams(temperature=0.0, max_tokens=mt, ignore_eos=True))
+        trace, steps = [], 0
+        while not p.is_finished():
+            if steps in late:
+                p.add_request(late[steps][0], nvr.SamplingParams(temperature=0.0, max_tokens=late[steps][1], ignore_eos=True))
+            rec = p.step()
+            assert all(t >= 0 for t in rec["tokens"]), rec
+            st = p.get_stats()["scheduler"]
+            trace.append((rec["is_prefill"], tuple(rec["seq_ids"]), tuple(rec["tokens"]), rec["num_finished"], st["decode_batches"],
+                          st["finished_sequences"]))
+            steps += 1
+            assert steps < 300
+        fin = {s.seq_id: s.token_ids for s in p.take_finished()}
+        assert all(t >= 0 for toks in fin.values() for t in toks)
+        return trace, fin, p.ahead_declined()
+    ta, fa, declined = run(1, 2)
+    ts, fs, _ = run(0, 256)
+    assert declined > 0, "the scenario never filled the graph cache: the error path was not exercised"
+    assert len(ta) == len(ts)
+    for i, (a, b) in enumerate(zip(ta, ts)):
+        assert a == b, f"step {i}: async {a} != sync {b}"
+    assert fa == fs and len(fa) == 8
+
+
 def test_tiled_weight_copies_do_not_change_a_bit():
     """Decode-sized steps stream tiled copies of the GEMM weights ([N/16][K/32][16][32]: 1 KiB contiguous per MFMA operand tile)
     instead of the row-major parameters: same values in the same summation order, so every step's logits are BIT-identical to a

@@ -331,3 +331,39 @@ def test_rust_ffi_is_in_sync_with_the_header():
     assert declared == header and len(declared) > 140
     used = set(re.findall(r"ffi::(nvr_\w+)\(", open(os.path.join(root, "integration", "rust", "src", "hip.rs")).read()))
     assert used and used <= declared, used - declared
+
+
+def test_postprocess_appends_for_sequences_the_scheduler_did_not_stamp():
+    """scheduler.rs:234-257 appends one token per sequence, whatever called it.  The chunked-prefill extension (A-23) skips the
+    append only for a prompt THIS scheduler cut (chunking on, not yet running); a sequence handed to postprocess without having
+    been stamped by schedule() (chunk fields zero or stale) still gets its token."""
+    for chunked in (0, 1):
+        sc = nvr.Scheduler(nvr.Config(max_num_seqs=4, max_num_batched_tokens=64, kvcache_block_size=4, num_kvcache_blocks=16,
+                                      skip_block_size_check=1, enable_chunked_prefill=chunked))
+        a = nvr.Sequence([1, 2, 3, 4, 5], nvr.SamplingParams(temperature=0.0, max_tokens=4, ignore_eos=True), 4)
+        sc.add_sequence(a)
+        seqs, pf = sc.schedule()
+        assert pf and len(seqs) == 1
+        sc.postprocess(seqs, [7])
+        assert len(seqs[0]) == 6 and seqs[0].token_ids[-1] == 7
+        # a stranger: never scheduled here, chunk_len == 0 (the fallback of update_running_sequence, scheduler.rs:272-273)
+        b = nvr.Sequence([9, 9, 9], nvr.SamplingParams(temperature=0.0, max_tokens=4, ignore_eos=True), 4)
+        assert tuple(b.chunk) == (0, 0)
+        sc.postprocess([b], [5])                 # joins the running queue (scheduler.rs:272-273): the scheduler owns it from here on
+        b.owned = False
+        assert len(b) == 4 and b.token_ids[-1] == 5
+
+
+def test_schedule_capacity_is_bounded_by_live_sequences():
+    """nvr_sched_schedule refuses an output array that cannot hold the batch BEFORE anything moves; the bound is
+    min(max_num_seqs, live sequences), so a caller with two requests does not need a 512-entry array."""
+    import ctypes as C
+    l = nvr.lib()
+    sc = nvr.Scheduler(nvr.Config(max_num_seqs=512, max_num_batched_tokens=64, kvcache_block_size=4, num_kvcache_blocks=16, skip_block_size_check=1))
+    for p in ([1, 2, 3], [4, 5]):
+        sc.add_sequence(nvr.Sequence(p, nvr.SamplingParams(temperature=0.0, max_tokens=2, ignore_eos=True), 4))
+    out = (C.c_void_p * 2)(); n = C.c_size_t(); pf = C.c_int()
+    assert l.nvr_sched_schedule(sc.h, out, 1, C.byref(n), C.byref(pf)) == -7            # NVR_ERR_INVALID_ARG, nothing scheduled
+    assert sc.get_queue_lengths() == (2, 0)
+    nvr.check(l.nvr_sched_schedule(sc.h, out, 2, C.byref(n), C.byref(pf)))
+    assert n.value == 2 and pf.value == 1

@@ -408,3 +408,93 @@ def test_one_shot_p2p_collectives_equal_host_rendezvous(tp):
     for step in zip(*g):
         assert all(s["tokens"] == step[0]["tokens"] for s in step)
     assert [s["tokens"] for s in g[0]] == [s["tokens"] for s in a[0]]
+
+
+@pytest.mark.gpu
+def test_peer_that_never_arrives_fails_the_step_and_the_group_recovers():
+    """Negative path of the one-shot collectives (kernels/comm_p2p.hip): rank 1 never enters a decode step that rank 0 runs.  Rank 0's
+    reduce workgroups wait a bounded time (NVR_P2P_TIMEOUT_MS, read when the runner is created), set the error word and finish —
+    the GPU does not hang — and the step fails with NVR_ERR_RCCL at the ABI instead of returning sums with zeros in place of the
+    peer's (the batch is aborted on the failing rank).  Recovery as nvr.h documents it: every rank aborts that batch
+    (nvr_engine_abort_last_batch), resets its arena words (nvr_runner_p2p_reset), the control plane barriers, and the SAME engines
+    serve new requests: both ranks sample the same tokens, equal to the single-rank product's."""
+    import threading
+    import oracle
+    from oracle import model_oracle as mo
+    sys.path.insert(0, ROOT)
+    import nvr_import
+    nvr = nvr_import.load()
+    m = mo.small(seed=16, num_attention_heads=8, num_key_value_heads=4, head_dim=64, hidden_size=256, intermediate_size=512)
+    mc = nvr.ModelConfig(vocab_size=m.vocab_size, hidden_size=m.hidden_size, intermediate_size=m.intermediate_size,
+                         num_hidden_layers=m.num_hidden_layers, num_attention_heads=m.num_attention_heads,
+                         num_key_value_heads=m.num_key_value_heads, head_dim=m.head_dim, max_position_embeddings=m.max_position_embeddings,
+                         rms_norm_eps=m.rms_norm_eps, rope_theta=m.rope_theta, tie_word_embeddings=m.tie_word_embeddings,
+                         init_std=m.init_std, seed=m.seed)
+    ecfg = dict(max_num_seqs=4, max_num_batched_tokens=256, max_model_len=128, kvcache_block_size=16, num_kvcache_blocks=24, skip_block_size_check=1)
+    first = [oracle.fill_tokens(n, 5, i, m.vocab_size).tolist() for i, n in enumerate([9, 21])]
+    second = [oracle.fill_tokens(n, 5, 10 + i, m.vocab_size).tolist() for i, n in enumerate([13, 6, 30])]
+    sp = dict(temperature=0.0, max_tokens=8, ignore_eos=True)
+
+    os.environ["NVR_P2P_TIMEOUT_MS"] = "150"
+    try:
+        group = nvr.LocalGroup(2)
+        engines = []
+        for r in range(2):
+            e = nvr.LLMEngine(nvr.Config(tensor_parallel_size=2, tensor_parallel_rank=r, **ecfg), mc)
+            group.attach(e.model_runner)
+            engines.append(e)
+    finally:
+        os.environ.pop("NVR_P2P_TIMEOUT_MS", None)
+
+    def both(fn):
+        out, errs = [None, None], []
+
+        def go(r):
+            try:
+                out[r] = fn(engines[r])
+            except BaseException as ex:                                                 # noqa: BLE001
+                errs.append((r, ex))
+        ts = [threading.Thread(target=go, args=(r,)) for r in range(2)]
+        for t in ts: t.start()
+        for t in ts: t.join(120)
+        assert not errs, errs
+        return out
+
+    for e in engines:
+        nvr.lib().nvr_seq_reset_id_counter()
+        for pr in first:
+            e.add_request(pr, nvr.SamplingParams(**sp))
+    a, b = both(lambda e: [e.step()["tokens"] for _ in range(3)])       # prefill + 2 decode steps together
+    assert a == b
+    # rank 1 stays away from the next step
+    t0 = __import__("time").perf_counter()
+    with pytest.raises(nvr.NvrError) as ei:
+        engines[0].step()
+    assert ei.value.code == -9, ei.value                                 # NVR_ERR_RCCL
+    assert "did not arrive" in str(ei.value)
+    assert __import__("time").perf_counter() - t0 < 30.0                 # bounded: a handful of collectives x 150 ms
+    assert engines[0].is_finished()                                      # the failing rank aborted its batch
+    # recovery, driven by the caller's control plane
+    engines[1].abort_last_batch()
+    assert engines[1].is_finished()
+    for e in engines:
+        e.take_finished()
+        e.model_runner.p2p_reset()
+
+    def serve(e):
+        for pr in second:
+            e.add_request(pr, nvr.SamplingParams(**sp))
+        recs = []
+        while not e.is_finished():
+            recs.append(e.step()["tokens"])
+        return recs
+    nvr.lib().nvr_seq_reset_id_counter()
+    a, b = both(serve)
+    assert a == b and len(a) >= 8
+    nvr.lib().nvr_seq_reset_id_counter()
+    single = nvr.LLMEngine(nvr.Config(**ecfg), mc)
+    ref = serve(single)
+    assert len(ref) == len(a)
+    # (a numerical near-tie between the sharded and the single-rank sums may send ONE sequence down another path)
+    diverged = {col for ra, rr in zip(a, ref) for col, (x, y) in enumerate(zip(ra, rr)) if x != y}
+    assert len(diverged) <= 1, (a, ref)
