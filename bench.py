@@ -46,6 +46,7 @@ import nvr_import  # noqa: E402
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
 BATCH, PROMPT_LEN, BLOCK = 32, 1024, 256
+TP_ASYNC = False          # launch-ahead on tensor-parallel ranks (set once the runner supports it)
 
 
 def model_bytes_per_step(mc, ctx_mean: float) -> dict:
@@ -207,6 +208,108 @@ def shared_prefix_decode(nvr, mc, nseq: int = 512, steps: int = 24) -> dict:
     return out
 
 
+MODELS = {"qwen3-0.6b": dict(batch=32, prompt_len=1024, label="Qwen3-0.6B", baseline_config=1),
+          "qwen3-8b": dict(batch=32, prompt_len=2048, label="Qwen3-8B", baseline_config=3)}
+
+
+def prefill_flops(c, lens) -> float:
+    """Algorithmic FLOPs of prefilling sequences of the given lengths: GEMMs per token, causal attention, one LM-head row
+    per sequence."""
+    Dh = c.head_dim or c.hidden_size // c.num_attention_heads
+    gemm_tok = 2 * c.num_hidden_layers * ((c.num_attention_heads + 2 * c.num_key_value_heads) * Dh * c.hidden_size
+                                          + c.hidden_size * c.num_attention_heads * Dh + 3 * c.intermediate_size * c.hidden_size)
+    attn = sum(4 * c.num_attention_heads * Dh * (n * (n + 1) // 2) for n in lens) * c.num_hidden_layers
+    return float(sum(lens)) * gemm_tok + attn + len(lens) * 2 * c.vocab_size * c.hidden_size
+
+
+def side_decode(nvr, preset: str, steps: int = 16, warmup: int = 4, tp_size: int = 1, tp_rank: int = 0, device: int = 0,
+                attach=None, barrier=None, reduce_max=None) -> dict:
+    """One more BASELINE workload measured next to the headline (same engine path: prefill untimed, W warm-up steps, K timed decode
+    steps): used for BASELINE.json configs[3] (Qwen3-8B, bs 32 x 2048; src/models/qwen3.rs:70-125 with the 8B numbers) on one GPU and,
+    in a tensor-parallel child, over the N GPUs (attach = communicator set-up of the engine's runner)."""
+    w = MODELS[preset]
+    B, P = w["batch"], w["prompt_len"]
+    mc = nvr.ModelConfig(preset)
+    total_new = warmup + steps + 1
+    t0 = time.perf_counter()
+    eng = nvr.LLMEngine(nvr.Config(max_num_seqs=B, max_num_batched_tokens=32768, max_model_len=P + total_new + 16, kvcache_block_size=BLOCK,
+                                   num_kvcache_blocks=B * ((P + total_new + 16) // BLOCK + 2), tensor_parallel_size=tp_size,
+                                   tensor_parallel_rank=tp_rank, device_ordinal=device, async_decode=1), mc)
+    if attach is not None:
+        ok, desc = attach(eng)
+        if not ok:
+            return {"error": desc}
+    nvr.synchronize(); t_init = time.perf_counter() - t0
+    for i in range(B):
+        eng.add_request(nvr.synthetic_tokens(P, 1, i, mc.c.vocab_size).tolist(),
+                        nvr.SamplingParams(temperature=0.0, max_tokens=total_new + 8, ignore_eos=True))
+    nvr.synchronize(); t0 = time.perf_counter(); npre = 0
+    while True:
+        rec = eng.step()
+        if not rec["is_prefill"]:
+            break
+        npre += 1
+    nvr.synchronize(); t_pre = time.perf_counter() - t0       # (includes the first decode step and its graph capture)
+    for _ in range(warmup - 1):
+        eng.step()
+    if barrier: barrier()
+    nvr.synchronize(); t0 = time.perf_counter()
+    for _ in range(steps):
+        eng.step()
+    nvr.synchronize(); el = time.perf_counter() - t0
+    if barrier: barrier()
+    if reduce_max: el = reduce_max(el)
+    c = mc.c
+    ctx_mean = P + 1 + warmup + (steps - 1) / 2.0
+    Dh = c.head_dim or c.hidden_size // c.num_attention_heads
+    per_layer = 2 * ((c.num_attention_heads + 2 * c.num_key_value_heads) * Dh * c.hidden_size + c.hidden_size * c.num_attention_heads * Dh
+                     + 3 * c.intermediate_size * c.hidden_size + 2 * c.hidden_size)
+    weights = per_layer * c.num_hidden_layers + 2 * c.hidden_size + 2 * c.vocab_size * c.hidden_size
+    kv_tok = c.num_hidden_layers * 2 * c.num_key_value_heads * Dh * 2
+    step_bytes = weights + B * ctx_mean * kv_tok + B * kv_tok
+    ms = el * 1e3 / steps
+    out = dict(workload=f"{w['label']} fp16 random-init, bs={B} x {P}-token prompts, greedy paged-attention decode, hipGraph steps "
+                        f"(BASELINE.json configs[{w['baseline_config']}]), {'one GPU' if tp_size == 1 else f'tensor parallel over {tp_size} GPUs'}",
+               parallelism=f"tp{tp_size}", ms_per_step=round(ms, 4), tokens_per_s=round(B * steps / el, 1), steps=steps, warmup=warmup,
+               step_algorithmic_bytes=int(step_bytes), step_hbm_frac_per_gpu=round(step_bytes / tp_size / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+               prefill_steps=npre, prefill_plus_first_decode_seconds=round(t_pre, 3),
+               prefill_tflop_per_s_lower_bound=round(prefill_flops(c, [P] * B) / t_pre / 1e12, 1), init_seconds=round(t_init, 1),
+               async_decode="opt-in (default 0), on here")
+    del eng
+    return out
+
+
+def prefill_sweep(nvr, lens=(128, 256, 512, 1024, 2048, 4096), nseq: int = 256) -> dict:
+    """BASELINE.json configs[2]: Qwen3-0.6B fp16, 256 sequences at L in {128 .. 4096} through the engine under the reference's 32 768-token
+    prefill budget (config.rs:58; Scheduler::try_schedule_prefill, scheduler.rs:119-168, batches whole sequences), and again with the
+    chunked-prefill extension (A-23: the budget is filled to the last token).  Wall time of the prefill steps only (a step ends with the
+    D2H of its tokens, so the device is idle when it returns); model FLOPs per SURVEY §8d against 2.5 PFLOP/s dense fp16."""
+    mc = nvr.ModelConfig("qwen3-0.6b")
+    rows = []
+    for L in lens:
+        rec = {"len": L, "sequences": nseq, "tokens": nseq * L}
+        for chunked in (0, 1):
+            nblk = (L + 2 + BLOCK - 1) // BLOCK + 1
+            nvr.lib().nvr_seq_reset_id_counter()
+            eng = nvr.LLMEngine(nvr.Config(max_num_seqs=nseq, max_num_batched_tokens=32768, max_model_len=L + 16, kvcache_block_size=BLOCK,
+                                           num_kvcache_blocks=nseq * nblk + 8, enable_chunked_prefill=chunked), mc)
+            for i in range(nseq):
+                eng.add_request(nvr.synthetic_tokens(L, 1, i, mc.c.vocab_size).tolist(), nvr.SamplingParams(temperature=0.0, max_tokens=2, ignore_eos=True))
+            nvr.synchronize(); steps = 0; dt = 0.0
+            while True:
+                t0 = time.perf_counter(); r = eng.step(); t1 = time.perf_counter()
+                if not r["is_prefill"]:
+                    break
+                steps += 1; dt += t1 - t0
+            fl = prefill_flops(mc.c, [L] * nseq)
+            rec["chunked" if chunked else "whole_sequences"] = dict(prefill_steps=steps, ms=round(dt * 1e3, 2), k_tokens_per_s=round(nseq * L / dt / 1e3, 1),
+                                                                     tflop_per_s=round(fl / dt / 1e12, 1), mfma_frac_of_2500=round(fl / dt / 2.5e15, 4))
+            del eng
+        rows.append(rec)
+    return {"workload": "Qwen3-0.6B fp16, 256 sequences x L prompt tokens, 32 768-token prefill budget (BASELINE.json configs[2])", "rows": rows}
+
+
+
 def _pmc_prefill_busy():
     """Counter-based MFMA utilisation of the prefill step (separate rocprofv3 --pmc pass, committed under profiles/)."""
     try:
@@ -250,6 +353,11 @@ def main() -> None:
     ap.add_argument("--attn-reps", type=int, default=8)
     ap.add_argument("--no-chain", action="store_true", help="skip the GEMM / norm chain timing (roofline_chain)")
     ap.add_argument("--no-shared-prefix", action="store_true", help="skip the configs[4] side measurement (shared_prefix)")
+    ap.add_argument("--model", choices=sorted(MODELS), default="qwen3-0.6b",
+                    help="headline workload: qwen3-0.6b = BASELINE.json configs[1] (bs 32 x 1024, the metric's config); qwen3-8b = configs[3] "
+                         "(bs 32 x 2048; --gpus 1: the whole model on one GPU, --gpus 8: tensor parallel over xGMI)")
+    ap.add_argument("--no-configs3", action="store_true", help="skip the Qwen3-8B side measurement (configs3 block of the default line)")
+    ap.add_argument("--no-prefill-sweep", action="store_true", help="skip the configs[2] prefill sweep (prefill_sweep block)")
     ap.add_argument("--sync-decode", action="store_true",
                     help="nvr_config.async_decode = 0: wait for every step's tokens on the host before the next step is scheduled "
                          "(default: the next greedy decode step is launched ahead; same batches, tokens and statistics)")
@@ -262,6 +370,8 @@ def main() -> None:
                     help="write the f32 logits of every step to HBM (default: a greedy batch takes its tokens from the arg-max "
                          "partials of the LM-head epilogue and the logits are written only when someone asks for them)")
     args = ap.parse_args()
+    global BATCH, PROMPT_LEN
+    BATCH, PROMPT_LEN = MODELS[args.model]["batch"], MODELS[args.model]["prompt_len"]
     if args.materialize_logits:
         os.environ["NVR_LAZY_LOGITS"] = "0"
 
@@ -304,11 +414,11 @@ def main() -> None:
         dist.init_process_group("gloo", rank=rank, world_size=world)
 
     total_new = args.warmup + args.steps + 1
-    mc = nvr.ModelConfig("qwen3-0.6b")
+    mc = nvr.ModelConfig(args.model)
     nvr.check(nvr.lib().nvr_device_set(local_rank))
 
     def make_engine(tp_size: int, tp_rank: int):
-        cfg = nvr.Config(max_num_seqs=BATCH, max_num_batched_tokens=BATCH * PROMPT_LEN, max_model_len=PROMPT_LEN + total_new + 16,
+        cfg = nvr.Config(max_num_seqs=BATCH, max_num_batched_tokens=min(BATCH * PROMPT_LEN, 32768), max_model_len=PROMPT_LEN + total_new + 16,
                          kvcache_block_size=BLOCK, num_kvcache_blocks=BATCH * ((PROMPT_LEN + total_new + 16) // BLOCK + 2),
                          tensor_parallel_size=tp_size, tensor_parallel_rank=tp_rank,
                          device_ordinal=local_rank, enforce_eager=args.eager, async_decode=0 if (args.sync_decode or tp_size > 1) else 1)
@@ -325,10 +435,13 @@ def main() -> None:
             eng.add_request(nvr.synthetic_tokens(PROMPT_LEN, 1, i, mc.c.vocab_size).tolist(),
                             nvr.SamplingParams(temperature=0.0, max_tokens=total_new + 8, ignore_eos=True))
         t0 = time.perf_counter()
-        info = eng.step()                    # prefill of 32 x 1024 tokens (untimed)
+        pre_seqs = 0
+        while pre_seqs < BATCH:              # prefill of the prompt tokens (untimed): one step per 32 768-token budget (config.rs:58)
+            info = eng.step()
+            assert info["is_prefill"], info
+            pre_seqs += info["num_seqs"]
         nvr.synchronize()
         t_pre = time.perf_counter() - t0
-        assert info["is_prefill"] and info["num_seqs"] == BATCH, info
         for _ in range(args.warmup):
             info = eng.step()
             assert not info["is_prefill"] and info["num_seqs"] == BATCH
@@ -470,12 +583,7 @@ def main() -> None:
 
     # prefill of the 32 x 1024 prompt tokens (one engine step, wall clock incl. host input preparation): MFMA-bound,
     # 880.8 MFLOP/token of GEMM + 114 688*l flop/token of causal attention (+ LM head per sequence)
-    c = mc.c
-    Dh = c.head_dim or c.hidden_size // c.num_attention_heads
-    gemm_flop_tok = 2 * c.num_hidden_layers * ((c.num_attention_heads + 2 * c.num_key_value_heads) * Dh * c.hidden_size
-                                               + c.hidden_size * c.num_attention_heads * Dh + 3 * c.intermediate_size * c.hidden_size)
-    attn_flop = BATCH * sum(4 * c.num_attention_heads * Dh * (l + 1) // 2 * 2 for l in range(PROMPT_LEN)) * c.num_hidden_layers // 2
-    prefill_flop = BATCH * PROMPT_LEN * gemm_flop_tok + attn_flop + BATCH * 2 * c.vocab_size * c.hidden_size
+    prefill_flop = prefill_flops(mc.c, [PROMPT_LEN] * BATCH)
     ms_per_step = elapsed * 1e3 / args.steps
     tokens_per_s = jobs * BATCH * args.steps / elapsed
     ctx_mean = PROMPT_LEN + 1 + args.warmup + (args.steps - 1) / 2.0   # keys visible per sequence, averaged over timed steps
@@ -485,17 +593,29 @@ def main() -> None:
 
     attn = time_attention_kernel(nvr, eng, mc, args.attn_reps)
     chain = None
-    if args.gpus == 1 and rank == 0 and not args.no_chain:
+    if args.gpus == 1 and rank == 0 and not args.no_chain and args.model == "qwen3-0.6b":
         try:
             chain = time_decode_chain(nvr, mc)
         except Exception as ex:                                              # noqa: BLE001
             print(f"[bench] decode chain timing failed: {ex}", file=sys.stderr, flush=True)
     shared_prefix = None
-    if args.gpus == 1 and rank == 0 and not args.no_shared_prefix:
+    if args.gpus == 1 and rank == 0 and not args.no_shared_prefix and args.model == "qwen3-0.6b":
         try:
             shared_prefix = shared_prefix_decode(nvr, mc)
         except Exception as ex:                                              # noqa: BLE001
             shared_prefix = {"error": str(ex)[:300]}
+    configs3 = None
+    if args.gpus == 1 and rank == 0 and not args.no_configs3 and args.model == "qwen3-0.6b":
+        try:
+            configs3 = side_decode(nvr, "qwen3-8b")
+        except Exception as ex:                                              # noqa: BLE001
+            configs3 = {"error": str(ex)[:300]}
+    sweep = None
+    if args.gpus == 1 and rank == 0 and not args.no_prefill_sweep and args.model == "qwen3-0.6b":
+        try:
+            sweep = prefill_sweep(nvr)
+        except Exception as ex:                                              # noqa: BLE001
+            sweep = {"error": str(ex)[:300]}
     achieved = attn["alg_bytes"] / (attn["us_per_launch"] * 1e-6) / 1e9
     traffic = None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_attn_latest.json")
@@ -512,11 +632,12 @@ def main() -> None:
             "value": round(tokens_per_s, 2), "unit": "tokens/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f16", "data": "synthetic",
-            "config": {"workload": "Qwen3-0.6B fp16 random-init, bs=32 x 1024-token prompts, greedy paged-attention decode, "
-                                   "block_size=256, hipGraph decode steps (BASELINE.json configs[1])",
+            "config": {"workload": f"{MODELS[args.model]['label']} fp16 random-init, bs={BATCH} x {PROMPT_LEN}-token prompts, greedy paged-attention decode, "
+                                   f"block_size=256, hipGraph decode steps (BASELINE.json configs[{MODELS[args.model]['baseline_config']}])",
                        "batch": BATCH, "prompt_len": PROMPT_LEN, "mean_context": ctx_mean,
                        "parallelism": parallelism, "hipgraph": not args.eager,
-                       "async_decode": not args.sync_decode and args.gpus == 1 or (not args.sync_decode and parallelism.startswith("replicas")),
+                       "async_decode": ("opt-in (nvr_config.async_decode, default 0): "
+                                        + ("on" if (not args.sync_decode and (args.gpus == 1 or parallelism.startswith("replicas") or TP_ASYNC)) else "off")),
                        "logits": "materialised every step" if args.materialize_logits else "greedy arg-max fused into the LM head; f32 logits on demand"},
             "prefill": {"tokens": BATCH * PROMPT_LEN, "seconds": round(t_prefill, 4), "tokens_per_s": round(BATCH * PROMPT_LEN / t_prefill, 1),
                         "tflop_per_s": round(prefill_flop / t_prefill / 1e12, 1), "mfma_frac_of_2500": round(prefill_flop / t_prefill / 2.5e15, 4),
@@ -546,6 +667,10 @@ def main() -> None:
                                      "note": "one hipGraph of 28 layers with their own weights (HBM-cold), replayed back to back (HIP events on its stream)"}
         if shared_prefix is not None:
             out["shared_prefix"] = shared_prefix
+        if configs3 is not None:
+            out["configs3"] = configs3
+        if sweep is not None:
+            out["prefill_sweep"] = sweep
         if args.gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         if replicas is not None and tensor_parallel is not None and "error" not in tensor_parallel:

@@ -99,12 +99,27 @@ def small(**kw) -> ModelConfig:
     return ModelConfig(**d)
 
 
+class _CompactLayer(dict):
+    """Layer weights kept as IEEE fp16 in host memory and widened to f32 when an op asks for them (exact: in fp16 mode every
+    weight is an fp16 value already).  Halves the oracle's footprint so that Qwen3-8B (BASELINE configs[3]) fits a test box."""
+
+    def __setitem__(self, k, v):
+        super().__setitem__(k, v.astype(np.float16) if isinstance(v, np.ndarray) and v.ndim == 2 else v)
+
+    def __getitem__(self, k):
+        v = super().__getitem__(k)
+        return v.astype(np.float32) if isinstance(v, np.ndarray) and v.dtype == np.float16 else v
+
+
 class OracleModel:
     """One tensor-parallel rank of the Qwen3 graph with synthetic weights."""
 
     def __init__(self, cfg: ModelConfig, num_blocks: int, block_size: int, fp16: bool = True,
-                 tp_rank: int = 0, tp_size: int = 1, max_pos: Optional[int] = None):
+                 tp_rank: int = 0, tp_size: int = 1, max_pos: Optional[int] = None, compact: bool = False):
         cfg.validate(tp_size)
+        if compact and not fp16:
+            raise ValueError("compact weight storage is exact only in fp16 mode")
+        self.compact = compact
         self.cfg, self.fp16, self.tp_rank, self.tp_size = cfg, fp16, tp_rank, tp_size
         self.D = cfg.hd()
         self.H = cfg.num_attention_heads // tp_size          # qwen3.rs:158
@@ -142,9 +157,12 @@ class OracleModel:
             u = fill_weight(self.I, Hd, Hd, Ig + r * self.I, 0, key(TID_GATE_UP), sc, f16)
             # down_proj row-parallel: global [Hd, I], columns sharded
             d = fill_weight(Hd, self.I, Ig, 0, r * self.I, key(TID_DOWN), sc, f16)
-            self.layers.append(dict(qkv=np.concatenate([q, k, v], 0), o=o, gate_up=np.concatenate([g, u], 0),
-                                    down=d, ln1=np.ones(Hd, np.float32), ln2=np.ones(Hd, np.float32),
-                                    q_norm=np.ones(D, np.float32), k_norm=np.ones(D, np.float32)))
+            W = _CompactLayer() if self.compact else {}
+            for name, val in dict(qkv=np.concatenate([q, k, v], 0), o=o, gate_up=np.concatenate([g, u], 0), down=d,
+                                  ln1=np.ones(Hd, np.float32), ln2=np.ones(Hd, np.float32),
+                                  q_norm=np.ones(D, np.float32), k_norm=np.ones(D, np.float32)).items():
+                W[name] = val
+            self.layers.append(W)
         # Embedding replicated on every rank (skip C2); LM head vocab-sharded
         # (embed_head.rs:57-59), tied to the embedding when tie_word_embeddings (qwen3.rs:461-473).
         self.embed = fill_weight(self.V, Hd, Hd, 0, 0, weight_key(c.seed, TID_EMBED), sc, f16)
@@ -165,6 +183,8 @@ class OracleModel:
         (linear.rs:154-171), RowParallelLinear::load_weight dim 1 (:249-267), the LM head takes its vocabulary rows
         (embed_head.rs:57-59,142-161); qkv_proj is [q | k | v] rows, gate_up_proj [gate | up] rows (linear.rs:300-340,
         378-454).  Values are rounded to fp16 in fp16 mode.  Returns the names outside the reference graph."""
+        if self.compact:
+            raise ValueError("load_state_dict: not available with compact weight storage (slices are assigned in place)")
         c, r = self.cfg, self.tp_rank
         D, Hd, H, KVH, I = self.D, self.Hd, self.H, self.KVH, self.I
         Hg, KVHg, Ig = c.num_attention_heads, c.num_key_value_heads, c.intermediate_size
@@ -310,11 +330,11 @@ class OracleEngine:
     """LLMEngine::step loop (llm_engine.rs:155-197): schedule -> execute -> sample -> postprocess."""
 
     def __init__(self, cfg: ModelConfig, config: eo.Config, fp16: bool = True, tp_size: int = 1,
-                 sample_seed: int = 0, max_pos: Optional[int] = None):
+                 sample_seed: int = 0, max_pos: Optional[int] = None, compact: bool = False):
         self.config = config
         self.scheduler = eo.Scheduler(config)
         nb = config.num_kvcache_blocks if config.num_kvcache_blocks is not None else 1000
-        self.ranks = [OracleModel(cfg, nb, config.kvcache_block_size, fp16, r, tp_size, max_pos)
+        self.ranks = [OracleModel(cfg, nb, config.kvcache_block_size, fp16, r, tp_size, max_pos, compact)
                       for r in range(tp_size)]
         self.sample_seed = sample_seed
         self.step_count = 0

@@ -11,7 +11,9 @@ The oracle is teacher-forced with the product's tokens so a tie cannot cascade.
   configs[1]  bs 32 x 1024-token prompts, prefill + 4 decode steps (hipGraph decode, 8-wave attention, V = 151 936 head)
   configs[2]  one 32 768-token prefill batch mixing 4 x 4096 ... 16 x 128 (42 sequences, the reference's token budget,
               config.rs:58) + one decode step
-A JSON summary of what was measured lands in gpurun_out/parity_r02.json (copied to profiles/ by hand)."""
+  configs[3]  Qwen3-8B (36 layers, V = 151 936) on one GPU: product vs oracle at full depth on a reduced batch (2 x 256 + 3 decode
+              steps), and the full 32 x 2048 workload as in-process tensor-parallel ranks (tp 8) against the single-rank product
+A JSON summary of what was measured lands in gpurun_out/parity_r03.json (copied to profiles/ by hand)."""
 import json
 import os
 import time
@@ -36,7 +38,7 @@ def _report(name, rec):
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     try:
         os.makedirs(out, exist_ok=True)
-        path = os.path.join(out, "parity_r02.json")
+        path = os.path.join(out, "parity_r03.json")
         cur = json.load(open(path)) if os.path.exists(path) else {}
         cur[name] = rec
         json.dump(cur, open(path, "w"), indent=1, sort_keys=True)
@@ -45,12 +47,12 @@ def _report(name, rec):
     print(f"[parity] {name}: {json.dumps(rec)}")
 
 
-def _pair(ecfg, prompts, max_tokens, fp16=True, tol=LOGIT_TOL, **kw):
+def _pair(ecfg, prompts, max_tokens, fp16=True, tol=LOGIT_TOL, model="qwen3-0.6b", **kw):
     eo.reset_sequence_counter(); nvr.lib().nvr_seq_reset_id_counter()
-    mcfg = mo.qwen3_0_6b()
+    mcfg = mo.qwen3_0_6b() if model == "qwen3-0.6b" else mo.qwen3_8b()
     t0 = time.time()
-    o = mo.OracleEngine(mcfg, eo.Config(**ecfg), fp16=fp16, max_pos=ecfg["max_model_len"])
-    p = nvr.LLMEngine(nvr.Config(**ecfg, **kw), nvr.ModelConfig("qwen3-0.6b"))
+    o = mo.OracleEngine(mcfg, eo.Config(**ecfg), fp16=fp16, max_pos=ecfg["max_model_len"], compact=(model != "qwen3-0.6b"))
+    p = nvr.LLMEngine(nvr.Config(**ecfg, **kw), nvr.ModelConfig(model))
     t_build = time.time() - t0
     for pr in prompts:
         sp = dict(temperature=0.0, max_tokens=max_tokens, ignore_eos=True)
@@ -149,3 +151,96 @@ def test_configs4_shared_system_prompt_vs_oracle():
     bm = p.scheduler.block_manager.get_stats()
     st["kv_blocks_total"] = int(bm["total_blocks"])
     _report("configs4_shared_prefix_48seqs", st)
+
+
+def test_configs3_qwen3_8b_full_depth_vs_oracle():
+    """BASELINE configs[3]'s model at FULL depth (Qwen3-8B shape: 36 layers, hidden 4096, 32:8 heads x 128, intermediate 12 288,
+    V = 151 936, untied LM head; src/models/qwen3.rs:70-125 with the 8B numbers) on one GPU against the fp16-faithful oracle on a
+    reduced batch: 2 x 256-token prompts + 3 decode steps (the streaming decode GEMMs of 8B-class weights, the 256^2 prefill GEMMs
+    at K = 4096 / 12 288, 36 layers of residual stream).  The oracle keeps its 8.2 G weights as fp16 in host memory (exact)."""
+    ecfg = dict(max_num_seqs=2, max_num_batched_tokens=512, max_model_len=272, kvcache_block_size=256, num_kvcache_blocks=6)
+    prompts = [nvr.synthetic_tokens(256, 1, i, V).tolist() for i in range(2)]
+    st, o, p = _pair(ecfg, prompts, 4, model="qwen3-8b")
+    assert st["steps"] == 4 and st["prefill_steps"] == 1 and st["rows"] == 8
+    assert st["near_ties"] <= 1, st
+    _report("configs3_qwen3_8b_full_depth_2x256", st)
+
+
+def test_configs3_qwen3_8b_bs32_seq2048_tp8_in_process_equals_tp1():
+    """BASELINE configs[3] at full size on ONE GPU: Qwen3-8B (36 layers, V 151 936), 32 x 2048-token prompts (two prefill batches under
+    the reference's 32 768-token budget, config.rs:58) + 3 decode steps, run (a) by the single-rank product and (b) by 8 tensor-parallel
+    ranks of this process (4 query heads + 1 kv head, 1536 MLP columns, 18 992 vocabulary rows per rank; linear.rs:228-239,300-304,
+    421-433, embed_head.rs:57-59) exchanging at the reference's sites through the in-process communicator.  All ranks agree exactly;
+    the concatenated shard logits equal the single-rank logits within the fp16-pipeline tolerance; tokens equal outside near-ties."""
+    import threading
+    mc = nvr.ModelConfig("qwen3-8b")
+    nseq, plen, new = 32, 2048, 4
+    ecfg = dict(max_num_seqs=nseq, max_num_batched_tokens=32768, max_model_len=plen + new + 8, kvcache_block_size=256,
+                num_kvcache_blocks=nseq * ((plen + new + 8 + 255) // 256) + 2)
+    prompts = [nvr.synthetic_tokens(plen, 1, i, V).tolist() for i in range(nseq)]
+    sp = dict(temperature=0.0, max_tokens=new, ignore_eos=True)
+
+    def drive(e, out):
+        while not e.is_finished():
+            rec = e.step(); rec["logits"] = e.model_runner.logits(rec["num_seqs"]).copy(); out.append(rec)
+    t0 = time.time()
+    nvr.lib().nvr_seq_reset_id_counter()
+    e = nvr.LLMEngine(nvr.Config(**ecfg), mc)
+    for pr in prompts:
+        e.add_request(pr, nvr.SamplingParams(**sp))
+    ref = []
+    drive(e, ref)
+    del e
+    t_single = time.time() - t0
+    assert [r["is_prefill"] for r in ref] == [True, True, False, False, False] and all(r["num_seqs"] == (16 if r["is_prefill"] else 32) for r in ref)
+
+    tp = 8
+    t0 = time.time()
+    group = nvr.LocalGroup(tp, p2p=False)          # eight kernels of one process spinning on each other would share the GPU's queues
+    engines = []
+    for r in range(tp):
+        e = nvr.LLMEngine(nvr.Config(tensor_parallel_size=tp, tensor_parallel_rank=r, **ecfg), mc)
+        group.attach(e.model_runner)
+        nvr.lib().nvr_seq_reset_id_counter()
+        for pr in prompts:
+            e.add_request(pr, nvr.SamplingParams(**sp))
+        engines.append(e)
+    traces, errors = [[] for _ in range(tp)], []
+
+    def go(r):
+        try:
+            drive(engines[r], traces[r])
+        except BaseException as ex:                                                     # noqa: BLE001
+            errors.append((r, ex))
+    threads = [threading.Thread(target=go, args=(r,)) for r in range(tp)]
+    for t in threads: t.start()
+    for t in threads: t.join(900)
+    assert not errors, errors
+    t_tp = time.time() - t0
+    assert all(len(tr) == len(ref) for tr in traces)
+    st = dict(steps=len(ref), rows=0, near_ties=0, id_mismatch_outside_ties=0, max_abs_logit_err=0.0, single_s=round(t_single, 1), tp8_s=round(t_tp, 1))
+    tol = 3e-2                                       # two fp16 pipelines with different summation trees over K = 4096 / 12 288
+    diverged = set()
+    for i, rec in enumerate(ref):
+        step = [tr[i] for tr in traces]
+        assert all(s["tokens"] == step[0]["tokens"] and s["seq_ids"] == step[0]["seq_ids"] and s["is_prefill"] == rec["is_prefill"] for s in step), \
+            f"step {i}: ranks disagree"
+        full = np.concatenate([s["logits"] for s in step], axis=1)
+        assert full.shape == rec["logits"].shape
+        srt = np.sort(rec["logits"], axis=1)
+        margin = srt[:, -1] - srt[:, -2]
+        for b, sid in enumerate(rec["seq_ids"]):
+            if sid in diverged:
+                continue                                                               # another history: not the same inputs any more
+            err = float(np.abs(full[b] - rec["logits"][b]).max())
+            st["max_abs_logit_err"] = max(st["max_abs_logit_err"], err)
+            assert err < tol, f"step {i} row {b}: logits differ by {err}"
+            st["rows"] += 1
+            if step[0]["tokens"][b] != rec["tokens"][b]:
+                diverged.add(sid)
+                if margin[b] <= 2 * tol:
+                    st["near_ties"] += 1
+                else:
+                    st["id_mismatch_outside_ties"] += 1
+    assert st["id_mismatch_outside_ties"] == 0 and st["near_ties"] <= 2, st
+    _report("configs3_qwen3_8b_bs32_seq2048_tp8_in_process_vs_tp1", st)
