@@ -661,17 +661,17 @@ def test_async_decode_is_transparent(bs, eos, nblocks):
 
 
 def test_async_decode_survives_a_full_graph_cache():
-    """Launch-ahead error path (engine.cpp): with the graph cache limited to 2 entries (NVR_MAX_GRAPHS, read once when the runner is
-    created) and batch sizes that keep changing (sequences finish at different steps, new ones arrive: a new graph key every few
-    steps), the step behind the current one regularly cannot be enqueued ahead.  The current step must still deliver its tokens, the
-    speculative schedule must be rolled back, and the next call must take the synchronous path (which flushes the cache): every
-    step's batch, tokens, finished sets and statistics equal those of the synchronous engine, and nothing is left holding the
-    placeholder token."""
+    """Launch-ahead error path (engine.cpp): the graph cache is limited to 2 entries (NVR_MAX_GRAPHS, read once when the runner is
+    created) and holds (3 sequences, bucket 256) and (2 sequences, bucket 256) when the longest sequence grows past 256 tokens in the
+    middle of a cache block (block size 48: launch-ahead is allowed there): the step behind the current one needs a third graph and
+    cannot be enqueued ahead.  The current step must still deliver its tokens, the speculative schedule must be rolled back, and the next
+    call must take the synchronous path (which flushes the cache): every step's batch, tokens, finished sets and statistics equal those
+    of the synchronous engine, and nothing is left holding the placeholder token."""
     mcfg = mo.small(seed=21)
-    ecfg = dict(max_num_seqs=8, max_num_batched_tokens=512, max_model_len=300, kvcache_block_size=64, num_kvcache_blocks=48)
+    ecfg = dict(max_num_seqs=8, max_num_batched_tokens=512, max_model_len=320, kvcache_block_size=48, num_kvcache_blocks=24)
     reqs = [(oracle.fill_tokens(int(n), 3, i, mcfg.vocab_size).tolist(), int(mt)) for i, (n, mt) in
-            enumerate([(9, 30), (20, 11), (5, 23), (18, 37), (11, 7), (30, 19)])]
-    late = {6: (oracle.fill_tokens(12, 3, 9, mcfg.vocab_size).tolist(), 25), 14: (oracle.fill_tokens(4, 3, 10, mcfg.vocab_size).tolist(), 15)}
+            enumerate([(9, 6), (240, 45), (20, 45)])]
+    late = {30: (oracle.fill_tokens(12, 3, 9, mcfg.vocab_size).tolist(), 25)}
 
     def run(async_on, max_graphs):
         os.environ["NVR_MAX_GRAPHS"] = str(max_graphs)
@@ -702,7 +702,7 @@ def test_async_decode_survives_a_full_graph_cache():
     assert len(ta) == len(ts)
     for i, (a, b) in enumerate(zip(ta, ts)):
         assert a == b, f"step {i}: async {a} != sync {b}"
-    assert fa == fs and len(fa) == 8
+    assert fa == fs and len(fa) == 4
 
 
 def test_tiled_weight_copies_do_not_change_a_bit():
