@@ -21,7 +21,7 @@ from typing import List, Optional, Sequence as Seq, Tuple
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnvr.so")
+LIB_PATH = os.environ.get("NVR_LIBNVR") or os.path.join(_HERE, "libnvr.so")   # NVR_LIBNVR: another build of the library (A/B measurements)
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "nvr.h")
 
 

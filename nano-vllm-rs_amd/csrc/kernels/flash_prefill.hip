@@ -49,6 +49,52 @@ typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
 template <int D>
 __device__ __forceinline__ int v_swz(int row) { return D == 128 ? ((row & 7) << 1) : (((row >> 1) & 3) << 1); }
 
+// One K/V tile into LDS by LDS-DMA (global_load_lds_dwordx4: 16 B per lane, 1 KiB per wave-instruction, lane-linear at M0), written as
+// inline asm ON PURPOSE: hipcc treats the builtin as a pending write to LDS and drains it (s_waitcnt vmcnt(0)) in front of the first
+// transposing read (ds_read_b64_tr_b16) of the tile IN USE, i.e. in the middle of every step, 1-2 k cycles after the requests went
+// out (r02 .s: the stall behind the 27 % MFMA-busy figure).  As asm the requests are invisible to its wait insertion; they are
+// counted by hand at the end of the step (s_waitcnt vmcnt + barrier in step()), one whole step after they were issued.  N pieces of
+// 4 KiB-apart LDS destinations starting at `lds` (wave-uniform byte address); M0 is saved and restored inside the statement.
+template <int N>
+__device__ __forceinline__ void glds_pieces(const half_t *const (&src)[N], unsigned lds) {
+    static_assert(N == 4 || N == 8, "2 or 4 pieces per operand");
+    unsigned keep;
+    if constexpr (N == 8) {
+        asm volatile("s_mov_b32 %0, m0\n\t"
+                     "s_mov_b32 m0, %9\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+                     "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\t"
+                     "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, off\n\t"
+                     "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, off\n\t"
+                     "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %5, off\n\t"
+                     "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %6, off\n\t"
+                     "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %7, off\n\t"
+                     "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %8, off\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(src[0]), "v"(src[1]), "v"(src[2]), "v"(src[3]), "v"(src[4]), "v"(src[5]), "v"(src[6]), "v"(src[7]), "s"(lds)
+                     : "memory", "scc");
+    } else {
+        asm volatile("s_mov_b32 %0, m0\n\t"
+                     "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+                     "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\t"
+                     "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, off\n\t"
+                     "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, off\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(src[0]), "v"(src[1]), "v"(src[2]), "v"(src[3]), "s"(lds)
+                     : "memory", "scc");
+    }
+}
+
+// max over the four 16-lane rows of a wave (the 4 key quads of a query), in the vector ALU: v_permlane16_swap / v_permlane32_swap of a
+// value with itself leave {own, partner} in the two results (an LDS round trip per ds_bpermute before: two dependent ones per step)
+__device__ __forceinline__ float max_over_rows(float v) {
+    const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+
 #ifndef NVR_FLASH_KT
 #define NVR_FLASH_KT 64
 #define NVR_FLASH_NBUF 2
@@ -122,35 +168,69 @@ __global__ __launch_bounds__(64 * FLASH_WAVES, 8 / FLASH_WAVES) void flash_prefi
         bt_reg = idx < p.max_blocks ? p.block_tables[(int64_t)tile.kv_ref * p.max_blocks + idx] : 0;
     };
     if (PAGED && UB) load_bt_chunk(0);
-    auto stage = [&](int buf, int kt) {
-        char *kd = smem + buf * STAGE, *vd = kd + KT * D * 2;
-        int64_t blk_row0 = 0;
-        if (PAGED && UB) {
-            const int bi = kt >> p.bs_shift;                              // uniform: every key of the step (clamped ones too) is in this block
-            if ((bi >> 6) != bt_chunk) load_bt_chunk(bi >> 6);
-            blk_row0 = (int64_t)__builtin_amdgcn_readlane(bt_reg, bi & 63) * p.block_size;
-        }
+    // Source addresses of a tile.  Contiguous K/V and block-aligned paged steps (UB) are "scalar base of the step + a per-thread
+    // constant": one 64-bit add per 16-byte piece (the general form below costs a 64-bit multiply chain per piece, ~50 VALU
+    // instructions per step next to 68 MFMAs).  Keys beyond the last visible one (the final step of a tile) are clamped to it.
+    constexpr int V_OFF = KT * D * 2;            // V image behind the K image of a ring slot
+    static_assert(NT * 16 == 0x1000 && V_OFF == PIECES * 0x1000, "glds_pieces walks 4 KiB-apart pieces: K image, then V image");
+    const unsigned lds_ring = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    int64_t kconst[PIECES], vconst[PIECES];      // element offsets of this thread's pieces inside a step
 #pragma unroll
-        for (int i = 0; i < PIECES; ++i) {
-            const int idx = i * NT + threadIdx.x, row = idx / CPR, c = idx % CPR;
-            int key = kt + row; if (key > kv_end - 1) key = kv_end - 1;
-            int64_t off;
+    for (int i = 0; i < PIECES; ++i) {
+        const int idx = i * NT + threadIdx.x, row = idx / CPR, c = idx % CPR;
+        const int vsw = D == 128 ? ((row & 7) << 1) : (((row >> 1) & 3) << 1);      // = v_swz<D>(row), spelled out: a call here makes hipcc drop the host stub
+        const int64_t rowoff = (PAGED && UB) ? ((int64_t)row * p.KVH + g) * D : (int64_t)row * p.ldkv + (int64_t)g * D;
+        kconst[i] = rowoff + (c ^ (row & (CPR - 1))) * 8;
+        vconst[i] = rowoff + (c ^ vsw) * 8;
+    }
+    // the query fragments must have LANDED before the first LDS-DMA goes out: hipcc would otherwise keep its own wait for them inside the
+    // step loop (it cannot prove they arrived before the loop), and in hardware that vmcnt(0) also waits for the hidden LDS-DMA
+#pragma unroll
+    for (int t = 0; t < NQT; ++t)
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) asm volatile("" :: "v"(qf[t][ks]));
+    auto stage = [&](int buf, int kt) {
+        const half_t *src[2 * PIECES];
+        const bool whole = kt + KT <= kv_end;                             // uniform: no key of this step is clamped
+        if ((!PAGED || UB) && whole) {
+            int64_t sbase;
+            if (PAGED) {
+                const int bi = kt >> p.bs_shift;                              // every key of the step is in this block
+                if ((bi >> 6) != bt_chunk) load_bt_chunk(bi >> 6);
+                sbase = ((int64_t)__builtin_amdgcn_readlane(bt_reg, bi & 63) * p.block_size + (kt & (p.block_size - 1))) * p.KVH * D;
+            } else sbase = (int64_t)(tile.kv_ref + kt) * p.ldkv;
+#pragma unroll
+            for (int i = 0; i < PIECES; ++i) { src[i] = p.k + sbase + kconst[i]; src[PIECES + i] = p.v + sbase + vconst[i]; }
+        } else {
+            int64_t blk_row0 = 0;
             if (PAGED && UB) {
-                off = ((blk_row0 + (key & (p.block_size - 1))) * p.KVH + g) * D;
-            } else if (PAGED) {
-                int bi, bo;
-                if (p.bs_shift >= 0) { bi = key >> p.bs_shift; bo = key & (p.block_size - 1); }
-                else { bi = key / p.block_size; bo = key - bi * p.block_size; }
-                const int64_t rr = (int64_t)p.block_tables[(int64_t)tile.kv_ref * p.max_blocks + bi] * p.block_size + bo;
-                off = (rr * p.KVH + g) * D;
-            } else {
-                off = (int64_t)(tile.kv_ref + key) * p.ldkv + (int64_t)g * D;
+                const int bi = kt >> p.bs_shift;
+                if ((bi >> 6) != bt_chunk) load_bt_chunk(bi >> 6);
+                blk_row0 = (int64_t)__builtin_amdgcn_readlane(bt_reg, bi & 63) * p.block_size;
             }
-            const int piece = (i * NT + wave * 64) * 16;
-            const int vsw = D == 128 ? ((row & 7) << 1) : (((row >> 1) & 3) << 1);      // = v_swz<D>(row), spelled out: a call here makes hipcc drop the host stub
-            __builtin_amdgcn_global_load_lds(p.k + off + (c ^ (row & (CPR - 1))) * 8, (__attribute__((address_space(3))) void *)(kd + piece), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(p.v + off + (c ^ vsw) * 8, (__attribute__((address_space(3))) void *)(vd + piece), 16, 0, 0);
+#pragma unroll
+            for (int i = 0; i < PIECES; ++i) {
+                const int idx = i * NT + threadIdx.x, row = idx / CPR, c = idx % CPR;
+                int key = kt + row; if (key > kv_end - 1) key = kv_end - 1;
+                int64_t off;
+                if (PAGED && UB) {
+                    off = ((blk_row0 + (key & (p.block_size - 1))) * p.KVH + g) * D;
+                } else if (PAGED) {
+                    int bi, bo;
+                    if (p.bs_shift >= 0) { bi = key >> p.bs_shift; bo = key & (p.block_size - 1); }
+                    else { bi = key / p.block_size; bo = key - bi * p.block_size; }
+                    const int64_t rr = (int64_t)p.block_tables[(int64_t)tile.kv_ref * p.max_blocks + bi] * p.block_size + bo;
+                    off = (rr * p.KVH + g) * D;
+                } else {
+                    off = (int64_t)(tile.kv_ref + key) * p.ldkv + (int64_t)g * D;
+                }
+                const int vsw = D == 128 ? ((row & 7) << 1) : (((row >> 1) & 3) << 1);
+                src[i] = p.k + off + (c ^ (row & (CPR - 1))) * 8;
+                src[PIECES + i] = p.v + off + (c ^ vsw) * 8;
+            }
         }
+        glds_pieces<2 * PIECES>(src, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_ring + buf * STAGE + wave_u * 1024)));
     };
 
     // The softmax runs on RAW scores: m is the running max of q·k (the scale is positive), p = 2^((s - m)·c) with
@@ -178,9 +258,7 @@ __global__ __launch_bounds__(64 * FLASH_WAVES, 8 / FLASH_WAVES) void flash_prefi
         constexpr int cur = decltype(cur_c)::value;
         const int kt = kv_start + it * KT;
         const bool more = it + NBUF - 1 < nsteps;
-#ifndef NVR_FLASH_ABLATE_STAGE
         if (more) stage((cur + NBUF - 1) % NBUF, kt + (NBUF - 1) * KT);
-#endif
         const char *kl = smem + cur * STAGE, *vl = kl + KT * D * 2;
         if (kt <= wave_last) {
 
@@ -226,8 +304,7 @@ __global__ __launch_bounds__(64 * FLASH_WAVES, 8 / FLASH_WAVES) void flash_prefi
             float mx = fmaxf(fmaxf(s[t][0][0], s[t][0][1]), fmaxf(s[t][0][2], s[t][0][3]));
 #pragma unroll
             for (int mt = 1; mt < NMT; ++mt) mx = fmaxf(fmaxf(mx, s[t][mt][0]), fmaxf(fmaxf(s[t][mt][1], s[t][mt][2]), s[t][mt][3]));
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            mx = max_over_rows(mx);
             const float mn = fmaxf(m[t], mx);                   // finite from the first step on (key 0 <= qpos)
             alpha[t] = __builtin_amdgcn_exp2f((m[t] - mn) * c2);
             moved |= mn != m[t];

@@ -10,14 +10,15 @@
 //   * a wave owns 64 rows of EACH A half and 32 rows of EACH B half, so its 128 x 64 output splits into four
 //     quadrants (A half, B half) of 16 MFMAs (v_mfma_f32_16x16x32_f16, 4 n-tiles x 2 m-tiles x 2 k-steps) — one
 //     quadrant per PHASE, and each phase needs only the half-tiles named below.
-//   * a K-tile is four phases; every phase = R { ds_read the fragments it is missing; s_waitcnt vmcnt(2); s_barrier } +
-//     M { global_load_lds ONE half-tile of the NEXT K-tile (2 x 16 B per thread) into the other buffer; 16 MFMAs;
-//     s_barrier }, the two wave groups one barrier interval apart (reads of one overlap MFMAs of the other):
+//   * a K-tile is four phases; every phase = R { ds_read the fragments it is missing; global_load_lds ONE half-tile of the NEXT
+//     K-tile (2 x 16 B per thread) into the other buffer; s_waitcnt vmcnt(4); s_barrier } + M { 16 MFMAs; s_barrier }, the two wave
+//     groups one barrier interval apart (reads and LDS-DMA issue of one overlap MFMAs of the other; r03: the requests moved from
+//     M to R, where the wave only waits for the other group's MFMAs: -2..3 % per K-tile):
 //         phase 0: quadrant (A0,B0)  reads A0 (8 fragments) + B0 (4)   stages A0'
 //         phase 1: quadrant (A0,B1)  reads B1 (4)                      stages B0'
 //         phase 2: quadrant (A1,B1)  reads A1 (8)                      stages B1'
 //         phase 3: quadrant (A1,B0)  reads B0 again (4)                stages A1'
-//     vmcnt(2) leaves the youngest half-tile in flight; every half-tile has about two phases to land before the
+//     vmcnt(4) leaves the two youngest half-tiles in flight; every half-tile has two phases to land before the
 //     barrier in front of its first reader (RAW: own loads counted, then the barrier), and it is written into the
 //     buffer whose last reader finished a whole K-tile earlier (WAR).  The loads never drain to 0 in the loop.
 //   * row maps put epilogue partners in ONE lane: SiLU — A0 = gate rows, A1 = up rows of the same 128 columns; RoPE —
@@ -39,24 +40,37 @@ struct G256Epi {
     int32_t H, KVH, D;
 };
 
-#ifndef G256_ABLATE_STAGE
-#define G256_ABLATE_STAGE 0       // 1: timing experiment only (no K-tile staging after the prologue: wrong results)
+#ifndef G256_STAMPS
+#define G256_STAMPS 0             // 1: diagnostic build only (shader-clock stamps of workgroup 0 into g256_dbg; never shipped): scratch/gemm_stamps.py
+#endif
+#if G256_STAMPS
+__device__ unsigned long long g256_dbg[2 * 64 * 8];
+#define G256_STAMP(i) if (blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 4) && tile_no < 64) g256_dbg[((wave >> 2) * 64 + tile_no) * 8 + (i)] = __builtin_readcyclecounter();
+#else
+#define G256_STAMP(i)
 #endif
 constexpr int G_BK = 64, G_HT = 128, G_HALF = G_HT * G_BK * 2;          // 16 KiB per half-tile
 constexpr int G_BUF = 4 * G_HALF;                                         // A0 A1 B0 B1
 
-// W row behind local row rho (0..127) of A half hA of workgroup column bx
-template <int EPI>
-__device__ __forceinline__ int g_w_row(int bx, int hA, int rho, int N, const G256Epi &e) {
-    if (EPI == GEPI_SILU) return hA * N + bx * 128 + rho;                 // N == I; 128 output columns per workgroup
-    if (EPI == GEPI_ROPE) {
-        const int hd2 = e.D / 2, head = bx * (256 / e.D) + rho / hd2, col = rho % hd2;
-        return head * e.D + hA * hd2 + col;
-    }
-    return bx * 256 + hA * 128 + rho;
+// W row behind local row rho = r0 + 64 i (r0 = 0..63, i = 0, 1) of A half hA of workgroup column bx, split into the part that depends
+// on the thread (r0), the part that is uniform in the workgroup (hA, i) and the tile's column term (bx x 256 rows; SiLU: bx x 128):
+//   plain / residual: bx*256 + hA*128 + rho          SiLU (N == I): hA*N + bx*128 + rho
+//   RoPE: head = bx*(256/D) + rho/hd2, row = head*D + hA*hd2 + rho%hd2  (hd2 = D/2 divides 64: rho/hd2 = r0/hd2 + i*(64/hd2))
+template <int EPI, int RD>
+__device__ __forceinline__ int g_w_thr(int r0) {
+    if (EPI == GEPI_ROPE) { constexpr int hd2 = RD / 2 > 0 ? RD / 2 : 1; return (r0 / hd2) * RD + r0 % hd2; }
+    return r0;
+}
+template <int EPI, int RD>
+__device__ __forceinline__ int g_w_uni(int hA, int i, int N) {
+    if (EPI == GEPI_SILU) return hA * N + i * 64;
+    if (EPI == GEPI_ROPE) return i * 128 + hA * (RD / 2);
+    return hA * 128 + i * 64;
 }
 
-template <int EPI>
+// RD: head_dim of the RoPE variant as a compile-time constant (64 or 128; 0 for the other epilogues): its row map and pair geometry
+// fold to shifts, and the scalar registers they needed in the K loop are what pushed that variant into SGPR -> VGPR spills
+template <int EPI, int RD = 0>
 __global__ __launch_bounds__(512) void gemm256_kernel(const half_t *__restrict__ x, int64_t ldx, const half_t *__restrict__ W,
                                                       int T, int K, int N, int NW, half_t *__restrict__ y, G256Epi epi,
                                                       int tiles_x, int tiles_y, int CG) {
@@ -84,21 +98,19 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const half_t *__restrict__
     auto have = [&](int uu) { return CG > 0 ? uu < n_u : uu < tiles_total; };
     if (CG <= 0) { u = blockIdx.x; xcd_step = gridDim.x; }
     if (!have(u)) return;
-    // staging sources: thread copies pieces idx = i*512 + tid (i = 0,1) of each half-tile: row = idx/8, LDS slot idx%8
-    const half_t *asrc[2][2], *bsrc[2][2];
+    // staging sources: thread copies pieces idx = i*512 + tid (i = 0,1) of each half-tile: row = idx/8 = r0 + 64 i, LDS slot idx%8.
+    // Address = tile base (scalar) + uniform row term of (half, i) (scalar) + ONE thread constant per operand: two 64-bit registers
+    // instead of eight pointers that had to be rebuilt, with the RoPE row map's divisions, inside the last K-tile of every tile
+    // (r03: that rebuild spilled ~80 registers to scratch in the RoPE variant — global-memory round trips in the K loop).
+    const int r0 = tid >> 3, cch = ((tid & 7) ^ (r0 & 7)) * 8;            // row inside a 64-row group, swizzled 16-byte chunk (elements)
+    const int64_t a_thr = (int64_t)g_w_thr<EPI, RD>(r0) * K + cch, b_thr = (int64_t)r0 * ldx + cch;
+    const half_t *wb = W, *xb = x;                                         // of the tile being STAGED (the next one during a tile's last K-tile)
+    int rows_left = 0x3fffffff;                                            // T - 1 - m0 when the tile's row block is ragged
     auto set_sources = [&](int tile) {
         const int bx = tile % tiles_x, m0 = (tile / tiles_x) * 256;
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int idx = i * 512 + tid, row = idx >> 3, c = (idx & 7) ^ (row & 7);
-                int wr = g_w_row<EPI>(bx, h, row, N, epi);
-                if (wr > NW - 1) wr = NW - 1;
-                int xr = m0 + h * 128 + row; if (xr > T - 1) xr = T - 1;
-                asrc[h][i] = W + (int64_t)wr * K + c * 8;
-                bsrc[h][i] = x + (int64_t)xr * ldx + c * 8;
-            }
+        wb = W + (int64_t)bx * ((EPI == GEPI_SILU) ? 128 : 256) * K;
+        xb = x + (int64_t)m0 * ldx;
+        rows_left = m0 + 256 > T ? T - 1 - m0 : 0x3fffffff;
     };
     // half-tile ids: 0 = A0, 1 = A1, 2 = B0, 3 = B1; kt = K-tile index inside the (current or next) tile, g = stream index
     auto stage = [&](int ht, int kt, int g) {
@@ -106,7 +118,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const half_t *__restrict__
         const int k0 = kt * G_BK;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const half_t *src = (ht < 2 ? asrc[ht & 1][i] : bsrc[ht & 1][i]) + k0;
+            const half_t *src;
+            if (ht < 2) src = wb + (int64_t)g_w_uni<EPI, RD>(ht & 1, i, N) * K + a_thr + k0;
+            else {
+                const int rowu = (ht & 1) * 128 + i * 64;
+                src = xb + (int64_t)rowu * ldx + b_thr + k0;
+                if (rows_left != 0x3fffffff && rowu + r0 > rows_left) src = xb + (int64_t)rows_left * ldx + cch + k0;   // ragged last row block: clamp
+            }
             __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void *)(dst + (i * 512 + wave * 64) * 16), 16, 0, 0);
         }
     };
@@ -144,17 +162,31 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const half_t *__restrict__
     };
 
     // The two wave groups (waves 0-3 and 4-7: one wave of each per SIMD) run ONE barrier interval apart, and a phase is
-    // two intervals — R {ds_read, s_waitcnt vmcnt, barrier} and M {stage one half-tile, 16 MFMAs, barrier} — so that on
-    // every SIMD the fragment reads of one wave overlap the MFMAs of the other, and the LDS-DMA issue (~100 clocks a
-    // piece inside a read phase, ~60 among MFMAs) sits in the interval that has issue slots to spare.  Group 1 takes one
-    // extra barrier before each tile's K loop, group 0 one after it.  Hazards with the stagger: a half-tile staged in
-    // M(p) is first read in R(p+3); every wave counts its own loads at the end of R(p+2) (vmcnt(2): all but the youngest
-    // half-tile, the one of M(p+1); the epilogue's stores count too, which only makes the wait stricter), i.e. group 0
-    // in interval 2p+4 and group 1 in 2p+5, and the earliest reader (group 0, R(p+3)) runs in interval 2p+6.  A buffer is
-    // restaged no earlier than two phases after its last ds_read by either group.
+    // two intervals — R {ds_read, stage one half-tile, s_waitcnt vmcnt, barrier} and M {16 MFMAs, barrier} — so that on every
+    // SIMD the fragment reads and the LDS-DMA issue of one wave (~100 clocks a piece) overlap the MFMAs of the other.  Group 1
+    // takes one extra barrier before each tile's K loop, group 0 one after it.  Hazards with the stagger: a half-tile staged in
+    // R(p) is first read in R(p+3); every wave counts its own loads at the end of R(p+2) (vmcnt(4): all but the two youngest
+    // half-tiles, those of R(p+1) and R(p+2); the epilogue's stores count too, which only makes the wait stricter), i.e. group
+    // 0 in interval 2p+4 and group 1 in 2p+5, and the earliest reader (group 0, R(p+3)) runs in interval 2p+6.  A half-tile is
+    // restaged no earlier than the interval after its last ds_read by either group has returned (group 1's R(3) reads B0 while
+    // group 0's R(0) of the next K-tile stages A0; B0 is restaged two intervals later).
+    // RoPE: positions (low dwords of the int64 entries) and cache slots of a tile's 256 token rows travel to LDS behind the K-tile ring
+    // by LDS-DMA, 4 bytes per lane (waves 0-3: 64 rows each), into one of two 2 KiB slots by tile parity.  They are requested one tile
+    // AHEAD, at the start of the previous tile's epilogue (whose first barrier drains the wave's requests anyway): asked for at the
+    // start of their own tile they sat in front of that tile's first staging waits (s_waitcnt vmcnt is in issue order) and stalled
+    // every tile's first K-tile by a memory round trip.
+    auto request_rows = [&](int tile_, int slot) {
+        if (EPI == GEPI_ROPE && grp == 0) {
+            int m = (tile_ / tiles_x) * 256 + wave * 64 + lane; if (m > T - 1) m = T - 1;
+            char *dst = smem + 2 * G_BUF + slot * 2048 + wave * 256;
+            __builtin_amdgcn_global_load_lds(epi.pos + m, (__attribute__((address_space(3))) void *)dst, 4, 0, 0);
+            if (epi.slots) __builtin_amdgcn_global_load_lds(epi.slots + m, (__attribute__((address_space(3))) void *)(dst + 1024), 4, 0, 0);
+        }
+    };
     const int KT = K / G_BK;
     int tile = tile_of(u);
     set_sources(tile);
+    request_rows(tile, 0);
     stage(0, 0, 0); stage(2, 0, 0); stage(3, 0, 0); stage(1, 0, 0);       // A0, B0, B1, A1 of the first K-tile
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -162,18 +194,21 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const half_t *__restrict__
 #define G256_R_END(N_)                                                                                                \
     asm volatile("s_waitcnt vmcnt(" #N_ ")" ::: "memory");                                                            \
     __builtin_amdgcn_s_barrier();
-#define G256_M(C_, HB_, HT_)                                                                                          \
-    if (more && !G256_ABLATE_STAGE) stage(HT_, skt, g + 1);                                                           \
+#define G256_M(C_, HB_)                                                                                               \
     __builtin_amdgcn_s_setprio(1);                                                                                    \
     mma(C_, HB_);                                                                                                     \
     __builtin_amdgcn_s_setprio(0);                                                                                    \
     __builtin_amdgcn_s_barrier();
+#define G256_S(HT_) if (more) stage(HT_, skt, g + 1);
+#define G256_W(NOMORE_) if (more) { G256_R_END(4) } else { G256_R_END(NOMORE_) }
 
     constexpr int OUTC = (EPI == GEPI_SILU) ? 128 : 256;                  // output columns of a tile
-    const int64_t ldy = (EPI == GEPI_ROPE) ? (int64_t)(epi.H + 2 * epi.KVH) * epi.D : (int64_t)N;
-    const int hd2 = (EPI == GEPI_ROPE) ? epi.D / 2 : 1;
+    const int64_t ldy = (EPI == GEPI_ROPE) ? (int64_t)(epi.H + 2 * epi.KVH) * RD : (int64_t)N;
+    constexpr int hd2 = (EPI == GEPI_ROPE) ? RD / 2 : 1;
 
+    int tile_no = 0;
     for (int g = 0;; ) {
+        G256_STAMP(0)
         if (grp == 1) __builtin_amdgcn_s_barrier();                       // stagger
 #pragma unroll
         for (int a = 0; a < 2; ++a)
@@ -193,48 +228,81 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const half_t *__restrict__
             const int skt = last ? 0 : kt + 1;
             // phase 0: (A0, B0)
             read_b(buf, 0); read_a(buf, 0);
-            G256_R_END(2)
-            G256_M(acc[0], 0, 0)
+            G256_S(0)
+            G256_W(2)
+            if (kt == 0) { G256_STAMP(1) }
+            G256_M(acc[0], 0)
             // phase 1: (A0, B1)
             read_b(buf, 1);
-            if (more) { G256_R_END(2) } else { G256_R_END(0) }
-            G256_M(acc[0], 1, 2)
+            G256_S(2)
+            G256_W(0)
+            G256_M(acc[0], 1)
             // phase 2: (A1, B1)
             read_a(buf, 1);
-            if (more) { G256_R_END(2) } else { G256_R_END(0) }
-            G256_M(acc[1], 1, 3)
+            G256_S(3)
+            G256_W(0)
+            G256_M(acc[1], 1)
             // phase 3: (A1, B0)
             read_b(buf, 0);
-            if (more) { G256_R_END(2) } else { G256_R_END(0) }
-            G256_M(acc[1], 0, 1)
+            G256_S(1)
+            G256_W(0)
+            G256_M(acc[1], 0)
+            if (kt == 0) { G256_STAMP(2) }
         }
         if (grp == 0) __builtin_amdgcn_s_barrier();                       // re-align the groups
+        G256_STAMP(3)
 
         // ---- epilogue of `tile`: the buffer of the K-tile just consumed is dead: per 128-token half hB, stage
         // [token][column] there (16-byte chunks XOR-swizzled by the row) and write 16-byte pieces of contiguous rows,
         // while the next tile's first K-tile lands in the other buffer.
+        {   // (scope: the epilogue works on shadow copies of the thread coordinates, see etid)
         char *scratch = smem + ((g - 1) & 1) * G_BUF;
         const int bx = tile % tiles_x, m0 = (tile / tiles_x) * 256;
+        // The thread coordinates of the epilogue come from a value the compiler cannot see through: otherwise it hoists the epilogue's
+        // address arithmetic (LDS offsets of the 16 puts and the read-back pieces, row / column terms of the stores: ~70 registers of
+        // loop invariants) out of the persistent tile loop, where they cannot all stay in registers next to the K loop's 176 — they
+        // were spilled to scratch at kernel start and reloaded in every epilogue, one global-memory round trip after the other
+        // (RoPE variant, r03: 72-89 spilled registers).  Recomputing them per tile is ~100 VALU instructions.
+        int etid = tid;
+        asm volatile("" : "+v"(etid));
+        const int tid = etid, wave = tid >> 6, lane = tid & 63, r = lane & 15, q = lane >> 4, wn = wave >> 2, wm = wave & 3;
+        (void)wave; (void)lane;
         auto put = [&](int ml, int col, half4_t h) {                      // 4 consecutive columns (col % 4 == 0) of token row ml
             *reinterpret_cast<half4_t *>(scratch + ml * (OUTC * 2) + ((((col >> 3) ^ (ml & 15)) << 4) | ((col & 4) << 1))) = h;
         };
-        // RoPE: positions of this lane's 4 token rows and the cache slots of the 16 rows this thread writes out, requested
-        // up front (a dependent slot load in front of every cache store costs an L2 round trip per 16-byte piece)
-        int64_t posv[2][2]; int slotv[2][8];
-        if (EPI == GEPI_ROPE) {
+        // RoPE (r03): the accumulators are staged as plain fp16 like GEPI_F16 and the rotation happens in the STORE phase, on pairs of
+        // 16-byte pieces (x1 = 8 columns of a head's first half, x2 = the same columns of its second half) read back from the LDS
+        // image: there the accumulators of the half are dead, so the cos / sin values of a thread's four pairs (16 x 16 B) are
+        // requested as ONE batch behind the staging barrier.  Rotating at the accumulators needed them one by one in front of each
+        // use (each waited for with vmcnt(0) while LDS-DMA was pending) inside 256 registers with spills: 23 k of a tile's 93 k
+        // cycles (profiles/r03_prefill_gemm_epilogue.txt).  Same arithmetic on the same fp16-rounded GEMM outputs: bit-identical.
+        // The tile's 256 positions and cache slots were brought into LDS by LDS-DMA when the tile started (below the tile loop's
+        // head), so the requests for the cos / sin rows leave right after a half's conversion and fly across its staging barrier.
+        if (have_next) request_rows(next_tile, (tile_no + 1) & 1);
+        const int *lds_pos = reinterpret_cast<const int *>(smem + 2 * G_BUF + (tile_no & 1) * 2048), *lds_slot = lds_pos + 256;
+        constexpr int hp = (EPI == GEPI_ROPE) ? RD / 16 : 1;               // 16-byte pieces per half head
+        const int pc = tid & 15, head_l = pc / hp, pcc = pc % hp;         // this thread's pair inside a row (16 pairs per 256 columns)
+        const int ch1 = head_l * 2 * hp + pcc, ch2 = ch1 + hp;
+        const int rhead = (EPI == GEPI_ROPE) ? bx * (256 / (RD > 0 ? RD : 256)) + head_l : 0;
+        const bool rot = (EPI == GEPI_ROPE) && rhead < epi.H + epi.KVH;   // q and k heads rotate, v heads pass through
+        int rslot[4];
+        float4_t cs[4][2], sn[4][2];
+        // plain / residual / RoPE epilogues: all 128 accumulator registers become 64 registers of packed fp16 at once (the values the
+        // halves stage below), so that the second half's results do not sit in f32 under the first half's store phase: the RoPE
+        // store phase holds 64 registers of cos / sin next to them, and a spill here is a global-memory round trip (scratch)
+        half4_t pk[2][4][2][2];
+        if (EPI != GEPI_SILU) {
 #pragma unroll
-            for (int hB = 0; hB < 2; ++hB) {
+            for (int a = 0; a < 2; ++a)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int m = m0 + hB * 128 + wm * 32 + j * 16 + r;
-                    posv[hB][j] = epi.pos[m < T ? m : T - 1];
-                }
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int kk = 0; kk < 8; ++kk) {
-                    const int m = m0 + hB * 128 + (tid >> 5) + kk * 16;
-                    slotv[hB][kk] = (epi.slots && m < T) ? epi.slots[m] : -1;
-                }
-            }
+                    for (int b = 0; b < 2; ++b)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const float4_t v = acc[a][i][b][j];
+                            pk[a][i][b][j] = (half4_t){(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+                        }
         }
 #pragma unroll
         for (int hB = 0; hB < 2; ++hB) {
@@ -253,13 +321,14 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const half_t *__restrict__
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int ml = wm * 32 + j * 16 + r;                      // token row inside the half
-                if (EPI == GEPI_F16 || EPI == GEPI_RESID) {
+                if (EPI == GEPI_F16 || EPI == GEPI_RESID || EPI == GEPI_ROPE) {
 #pragma unroll
                     for (int a = 0; a < 2; ++a)
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
-                            const float4_t v = acc[a][i][hB][j];
-                            put(ml, a * 128 + wn * 64 + i * 16 + q * 4, (half4_t){(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]});
+                            const int rho = wn * 64 + i * 16 + q * 4;     // local W row; RoPE: A0 / A1 hold the first / second halves of the heads
+                            const int colo = (EPI == GEPI_ROPE) ? (rho / hd2) * RD + a * hd2 + rho % hd2 : a * 128 + rho;
+                            put(ml, colo, pk[a][i][hB][j]);
                         }
                 } else if (EPI == GEPI_SILU) {
 #pragma unroll
@@ -273,33 +342,25 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const half_t *__restrict__
                         }
                         put(ml, wn * 64 + i * 16 + q * 4, h);
                     }
-                } else {                                                  // GEPI_ROPE
-                    const int64_t p = posv[hB][j];
+                }
+            }
+            if (EPI == GEPI_ROPE) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int rho = wn * 64 + i * 16 + q * 4;         // local row of both halves
-                        const int hl = rho / hd2, col = rho % hd2;        // head inside the tile, column inside the half head
-                        const int head = bx * (256 / epi.D) + hl;
-                        half4_t h0, h1;
-                        if (head < epi.H + epi.KVH) {
-                            const float4_t cs = *reinterpret_cast<const float4_t *>(epi.cos_t + p * hd2 + col);
-                            const float4_t sn = *reinterpret_cast<const float4_t *>(epi.sin_t + p * hd2 + col);
+                for (int kk = 0; kk < 4; ++kk) {
+                    const int row = hB * 128 + (tid >> 4) + kk * 32;
+                    const int pos = lds_pos[row];
+                    rslot[kk] = epi.slots ? lds_slot[row] : -1;
+                    if (rot) {
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                const float x1 = (float)to_half_rn(acc[0][i][hB][j][e]), x2 = (float)to_half_rn(acc[1][i][hB][j][e]);
-                                h0[e] = to_half_rn(__fsub_rn(__fmul_rn(x1, cs[e]), __fmul_rn(x2, sn[e])));
-                                h1[e] = to_half_rn(__fadd_rn(__fmul_rn(x2, cs[e]), __fmul_rn(x1, sn[e])));
-                            }
-                        } else {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) { h0[e] = to_half_rn(acc[0][i][hB][j][e]); h1[e] = to_half_rn(acc[1][i][hB][j][e]); }
+                        for (int hh = 0; hh < 2; ++hh) {
+                            cs[kk][hh] = *reinterpret_cast<const float4_t *>(epi.cos_t + (int64_t)pos * hd2 + pcc * 8 + hh * 4);
+                            sn[kk][hh] = *reinterpret_cast<const float4_t *>(epi.sin_t + (int64_t)pos * hd2 + pcc * 8 + hh * 4);
                         }
-                        put(ml, hl * epi.D + col, h0);
-                        put(ml, hl * epi.D + hd2 + col, h1);
                     }
                 }
             }
             __syncthreads();
+            if (hB == 0) { G256_STAMP(4) }
             constexpr int CPR = OUTC / 8;                                 // 16-byte pieces per row
             if (EPI == GEPI_RESID) {
                 // h <- fp16(h + fp16(acc)): the rounding points of add_rmsnorm's add
@@ -317,6 +378,37 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const half_t *__restrict__
                 __syncthreads();
                 continue;
             }
+            if (EPI == GEPI_ROPE) {
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const int row = (tid >> 4) + kk * 32, m = m0 + hB * 128 + row;
+                    const half8_t x1 = *reinterpret_cast<const half8_t *>(scratch + row * (OUTC * 2) + ((ch1 ^ (row & 15)) << 4));
+                    const half8_t x2 = *reinterpret_cast<const half8_t *>(scratch + row * (OUTC * 2) + ((ch2 ^ (row & 15)) << 4));
+                    half8_t o1 = x1, o2 = x2;
+                    if (rot) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float a = (float)x1[e], b = (float)x2[e], cc = cs[kk][e >> 2][e & 3], ss = sn[kk][e >> 2][e & 3];
+                            o1[e] = to_half_rn(__fsub_rn(__fmul_rn(a, cc), __fmul_rn(b, ss)));
+                            o2[e] = to_half_rn(__fadd_rn(__fmul_rn(b, cc), __fmul_rn(a, ss)));
+                        }
+                    }
+                    if (m >= T) continue;
+                    half_t *yrow = y + (int64_t)m * ldy + bx * OUTC;
+                    *reinterpret_cast<half8_t *>(yrow + ch1 * 8) = o1;
+                    *reinterpret_cast<half8_t *>(yrow + ch2 * 8) = o2;
+                    if (rhead >= epi.H && rslot[kk] >= 0) {
+                        const bool is_k = rhead < epi.H + epi.KVH;
+                        const int kvh = is_k ? rhead - epi.H : rhead - epi.H - epi.KVH;
+                        half_t *crow = (is_k ? epi.kc : epi.vc) + ((int64_t)rslot[kk] * epi.KVH + kvh) * RD;
+                        *reinterpret_cast<half8_t *>(crow + pcc * 8) = o1;
+                        *reinterpret_cast<half8_t *>(crow + (hp + pcc) * 8) = o2;
+                    }
+                }
+                __syncthreads();
+                if (hB == 0) { G256_STAMP(5) } else { G256_STAMP(6) }
+                continue;
+            }
 #pragma unroll
             for (int kk = 0; kk < (128 * CPR) / 512; ++kk) {
                 const int pidx = tid + kk * 512;
@@ -325,32 +417,26 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const half_t *__restrict__
                 if (m >= T || col >= ldy) continue;
                 const half8_t v8 = *reinterpret_cast<const half8_t *>(scratch + row * (OUTC * 2) + ((ch ^ (row & 15)) << 4));
                 *reinterpret_cast<half8_t *>(y + (int64_t)m * ldy + col) = v8;
-                if (EPI == GEPI_ROPE) {
-                    const int head = col / epi.D;
-                    if (head >= epi.H) {
-                        const int slot = slotv[hB][kk];                   // CPR = 32: row = tid/32 + 16*kk
-                        if (slot >= 0) {
-                            const bool is_k = head < epi.H + epi.KVH;
-                            const int kvh = is_k ? head - epi.H : head - epi.H - epi.KVH;
-                            *reinterpret_cast<half8_t *>((is_k ? epi.kc : epi.vc) + ((int64_t)slot * epi.KVH + kvh) * epi.D + (col - head * epi.D)) = v8;
-                        }
-                    }
-                }
             }
             __syncthreads();
         }
+        }   // epilogue scope
+        ++tile_no;
         if (!have_next) break;
         tile = next_tile; u += xcd_step;
     }
 #undef G256_R_END
 #undef G256_M
+#undef G256_S
+#undef G256_W
 }
 
 static int g256_prepare() {                                               // 128 KiB of dynamic LDS: opt-in once
     static bool done = false;
     if (done) return 0;
     const void *fns[] = {reinterpret_cast<const void *>(&gemm256_kernel<GEPI_F16>), reinterpret_cast<const void *>(&gemm256_kernel<GEPI_SILU>),
-                         reinterpret_cast<const void *>(&gemm256_kernel<GEPI_ROPE>), reinterpret_cast<const void *>(&gemm256_kernel<GEPI_RESID>)};
+                         reinterpret_cast<const void *>(&gemm256_kernel<GEPI_ROPE, 128>), reinterpret_cast<const void *>(&gemm256_kernel<GEPI_ROPE, 64>),
+                         reinterpret_cast<const void *>(&gemm256_kernel<GEPI_RESID>)};
     for (const void *f : fns) {
         hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G_BUF + 4096);
         if (e != hipSuccess) return nvr::fail(NVR_ERR_HIP, "gemm256: hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -420,9 +506,18 @@ int gemm256_qkv_rope_store(const half_bits *x, int64_t ldx, const half_bits *W, 
     e.pos = positions; e.slots = slots; e.cos_t = cos_t; e.sin_t = sin_t; e.kc = (half_t *)k_cache; e.vc = (half_t *)v_cache;
     e.H = (int32_t)H; e.KVH = (int32_t)KVH; e.D = (int32_t)D;
     const int tx = (int)(N / 256), tt = tx * (int)((T + 255) / 256);
-    gemm256_kernel<GEPI_ROPE><<<dim3((unsigned)g256_grid(tt)), dim3(512), 2 * G_BUF, s>>>((const half_t *)x, ldx, (const half_t *)W, (int)T, (int)K,
-                                                                                         (int)N, (int)N, (half_t *)qkv, e, tx, tt / tx, g256_cg(tx, tt / tx, true));
+    if (D == 128)
+        gemm256_kernel<GEPI_ROPE, 128><<<dim3((unsigned)g256_grid(tt)), dim3(512), 2 * G_BUF + 4096, s>>>((const half_t *)x, ldx, (const half_t *)W, (int)T, (int)K,
+                                                                                                  (int)N, (int)N, (half_t *)qkv, e, tx, tt / tx, g256_cg(tx, tt / tx, true));
+    else
+        gemm256_kernel<GEPI_ROPE, 64><<<dim3((unsigned)g256_grid(tt)), dim3(512), 2 * G_BUF + 4096, s>>>((const half_t *)x, ldx, (const half_t *)W, (int)T, (int)K,
+                                                                                                 (int)N, (int)N, (half_t *)qkv, e, tx, tt / tx, g256_cg(tx, tt / tx, true));
     return g256_check("gemm256_qkv_rope_store");
 }
 
+#if G256_STAMPS
+extern "C" __attribute__((visibility("default"))) int nvr_debug_g256_stamps(unsigned long long *out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g256_dbg), sizeof(g256_dbg));
+}
+#endif
 }}  // namespace nvr::k
