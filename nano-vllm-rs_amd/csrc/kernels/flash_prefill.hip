@@ -54,34 +54,43 @@ __device__ __forceinline__ int v_swz(int row) { return D == 128 ? ((row & 7) << 
 // transposing read (ds_read_b64_tr_b16) of the tile IN USE, i.e. in the middle of every step, 1-2 k cycles after the requests went
 // out (r02 .s: the stall behind the 27 % MFMA-busy figure).  As asm the requests are invisible to its wait insertion; they are
 // counted by hand at the end of the step (s_waitcnt vmcnt + barrier in step()), one whole step after they were issued.  N pieces of
-// 4 KiB-apart LDS destinations starting at `lds` (wave-uniform byte address); M0 is saved and restored inside the statement.
-template <int N>
+// STRIDE-apart LDS destinations (STRIDE = 16 B x the workgroup's threads) starting at `lds` (wave-uniform byte address); M0 is saved and
+// restored inside the statement.
+template <int N, int STRIDE>
 __device__ __forceinline__ void glds_pieces(const half_t *const (&src)[N], unsigned lds) {
-    static_assert(N == 4 || N == 8, "2 or 4 pieces per operand");
+    static_assert(N == 2 || N == 4 || N == 8, "1, 2 or 4 pieces per operand");
     unsigned keep;
     if constexpr (N == 8) {
         asm volatile("s_mov_b32 %0, m0\n\t"
                      "s_mov_b32 m0, %9\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
-                     "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\t"
-                     "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, off\n\t"
-                     "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, off\n\t"
-                     "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %5, off\n\t"
-                     "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %6, off\n\t"
-                     "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %7, off\n\t"
-                     "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %8, off\n\t"
+                     "s_add_u32 m0, m0, %[st]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\t"
+                     "s_add_u32 m0, m0, %[st]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, off\n\t"
+                     "s_add_u32 m0, m0, %[st]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, off\n\t"
+                     "s_add_u32 m0, m0, %[st]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %5, off\n\t"
+                     "s_add_u32 m0, m0, %[st]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %6, off\n\t"
+                     "s_add_u32 m0, m0, %[st]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %7, off\n\t"
+                     "s_add_u32 m0, m0, %[st]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %8, off\n\t"
                      "s_mov_b32 m0, %0"
                      : "=&s"(keep)
-                     : "v"(src[0]), "v"(src[1]), "v"(src[2]), "v"(src[3]), "v"(src[4]), "v"(src[5]), "v"(src[6]), "v"(src[7]), "s"(lds)
+                     : "v"(src[0]), "v"(src[1]), "v"(src[2]), "v"(src[3]), "v"(src[4]), "v"(src[5]), "v"(src[6]), "v"(src[7]), "s"(lds), [st] "n"(STRIDE)
+                     : "memory", "scc");
+    } else if constexpr (N == 2) {
+        asm volatile("s_mov_b32 %0, m0\n\t"
+                     "s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+                     "s_add_u32 m0, m0, %[st]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(src[0]), "v"(src[1]), "s"(lds), [st] "n"(STRIDE)
                      : "memory", "scc");
     } else {
         asm volatile("s_mov_b32 %0, m0\n\t"
                      "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
-                     "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\t"
-                     "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, off\n\t"
-                     "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, off\n\t"
+                     "s_add_u32 m0, m0, %[st]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\t"
+                     "s_add_u32 m0, m0, %[st]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, off\n\t"
+                     "s_add_u32 m0, m0, %[st]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, off\n\t"
                      "s_mov_b32 m0, %0"
                      : "=&s"(keep)
-                     : "v"(src[0]), "v"(src[1]), "v"(src[2]), "v"(src[3]), "s"(lds)
+                     : "v"(src[0]), "v"(src[1]), "v"(src[2]), "v"(src[3]), "s"(lds), [st] "n"(STRIDE)
                      : "memory", "scc");
     }
 }
@@ -172,7 +181,7 @@ __global__ __launch_bounds__(64 * FLASH_WAVES, 8 / FLASH_WAVES) void flash_prefi
     // constant": one 64-bit add per 16-byte piece (the general form below costs a 64-bit multiply chain per piece, ~50 VALU
     // instructions per step next to 68 MFMAs).  Keys beyond the last visible one (the final step of a tile) are clamped to it.
     constexpr int V_OFF = KT * D * 2;            // V image behind the K image of a ring slot
-    static_assert(NT * 16 == 0x1000 && V_OFF == PIECES * 0x1000, "glds_pieces walks 4 KiB-apart pieces: K image, then V image");
+    static_assert(V_OFF == PIECES * NT * 16, "glds_pieces walks the pieces of the K image, then of the V image, NT * 16 bytes apart");
     const unsigned lds_ring = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     int64_t kconst[PIECES], vconst[PIECES];      // element offsets of this thread's pieces inside a step
@@ -230,7 +239,7 @@ __global__ __launch_bounds__(64 * FLASH_WAVES, 8 / FLASH_WAVES) void flash_prefi
                 src[PIECES + i] = p.v + off + (c ^ vsw) * 8;
             }
         }
-        glds_pieces<2 * PIECES>(src, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_ring + buf * STAGE + wave_u * 1024)));
+        glds_pieces<2 * PIECES, NT * 16>(src, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_ring + buf * STAGE + wave_u * 1024)));
     };
 
     // The softmax runs on RAW scores: m is the running max of q·k (the scale is positive), p = 2^((s - m)·c) with

@@ -117,6 +117,8 @@ int nvr_model_runner::init() {                                       // ModelRun
     NVR_HIP_CHECK(hipMalloc(&attn_ws, attn_ws_bytes));
     // step-input arena
     auto carve = [&](size_t &off, size_t bytes) { off = in_bytes; in_bytes += (bytes + 255) / 256 * 256; };
+    // prefill region (the start of the arena): capacity for the largest step; a step lays its arrays out back to back for its own
+    // token count (execute()), so these offsets are only the initial layout
     carve(off_ids, max_tokens * 8); carve(off_pos, max_tokens * 8); carve(off_slots, max_tokens * 4);
     carve(off_cu, (max_seqs + 1) * 4); carve(off_ctx, std::max(max_tokens, max_seqs) * 4);
     carve(off_kvbase, max_tokens * 4); carve(off_bt, 16);
@@ -548,11 +550,10 @@ int nvr_model_runner::execute(nvr_seq *const *seqs, size_t nseq, bool is_prefill
     if (nseq == 0) return nvr::fail(NVR_ERR_INVALID_ARG, "execute_model: empty batch");
     if ((int64_t)nseq > max_seqs) return nvr::fail(NVR_ERR_INVALID_ARG, "execute_model: %zu sequences > max_num_seqs %ld", nseq, (long)max_seqs);
     char *hd = in_host + off_dec;
-    int64_t *ids = is_prefill ? (int64_t *)(in_host + off_ids) : (int64_t *)(hd + dof_ids);
-    int64_t *pos = is_prefill ? (int64_t *)(in_host + off_pos) : (int64_t *)(hd + dof_pos);
-    int32_t *slots = is_prefill ? (int32_t *)(in_host + off_slots) : (int32_t *)(hd + dof_slots);
-    int32_t *ctx = is_prefill ? (int32_t *)(in_host + off_ctx) : (int32_t *)(hd + dof_ctx);
-    int32_t *cu = (int32_t *)(in_host + off_cu), *kvb = (int32_t *)(in_host + off_kvbase), *bt = (int32_t *)(hd + dof_bt);
+    int64_t *ids = (int64_t *)(hd + dof_ids), *pos = (int64_t *)(hd + dof_pos);
+    int32_t *slots = (int32_t *)(hd + dof_slots), *ctx = (int32_t *)(hd + dof_ctx);
+    int32_t *cu = nullptr, *kvb = nullptr, *bt = (int32_t *)(hd + dof_bt);
+    size_t prefill_bytes = 0;                                            // bytes of the prefill region this step uploads (one copy)
     int64_t T = 0, max_ctx = 0;
     const int64_t bs = block_size;
     NVR_HIP_CHECK(hipStreamSynchronize(stream));   // staging arena is reused: previous uploads must have landed
@@ -586,8 +587,21 @@ int nvr_model_runner::execute(nvr_seq *const *seqs, size_t nseq, bool is_prefill
             total += hi - lo;
         }
         if (total > max_tokens) return nvr::fail(NVR_ERR_INVALID_ARG, "prefill of %ld tokens exceeds max_num_batched_tokens %ld", (long)total, (long)max_tokens);
-        cu[0] = 0;
         const int qb = flash_ok ? k::flash_tile_positions((int)H, (int)KVH) : 1;
+        {   // the step's arrays back to back at the start of the arena (sized by THIS step's token count): one upload instead of seven
+            size_t o = 0;
+            auto sub = [&](size_t &f, size_t bytes) { f = o; o += (bytes + 63) / 64 * 64; };
+            sub(off_ids, (size_t)total * 8); sub(off_pos, (size_t)total * 8); sub(off_slots, (size_t)total * 4); sub(off_ctx, (size_t)total * 4);
+            sub(off_kvbase, (size_t)total * 4); sub(off_cu, (nseq + 1) * 4);
+            sub(off_tiles, (size_t)(total / qb + (int64_t)nseq + 1) * sizeof(k::FlashTile));
+            prefill_bytes = o;
+            if (prefill_bytes > off_dec) return nvr::fail(NVR_ERR_INVARIANT, "prefill input region: %zu bytes needed, %zu carved", prefill_bytes, off_dec);
+            d_ids = (int64_t *)(in_dev + off_ids); d_pos = (int64_t *)(in_dev + off_pos); d_slots = (int32_t *)(in_dev + off_slots);
+            d_ctx = (int32_t *)(in_dev + off_ctx); d_kvbase = (int32_t *)(in_dev + off_kvbase); d_cu = (int32_t *)(in_dev + off_cu);
+            ids = (int64_t *)(in_host + off_ids); pos = (int64_t *)(in_host + off_pos); slots = (int32_t *)(in_host + off_slots);
+            ctx = (int32_t *)(in_host + off_ctx); kvb = (int32_t *)(in_host + off_kvbase); cu = (int32_t *)(in_host + off_cu);
+        }
+        cu[0] = 0;
         k::FlashTile *tl = (k::FlashTile *)(in_host + off_tiles);
         n_tiles = 0;
         for (size_t b = 0; b < nseq; ++b) {
@@ -596,13 +610,25 @@ int nvr_model_runner::execute(nvr_seq *const *seqs, size_t nseq, bool is_prefill
             if (!prefill_paged) c0 = 0;
             if (end > max_pos) return nvr::fail(NVR_ERR_INVALID_ARG, "sequence of %ld tokens exceeds max_model_len %ld", (long)end, (long)max_pos);
             if ((int64_t)s.block_table.size() * bs < end) return nvr::fail(NVR_ERR_NOT_ALLOCATED, "Sequence has no allocated blocks");
-            for (int64_t p = c0; p < end; ++p) {
-                if ((uint64_t)s.token_ids[p] >= (uint64_t)V)                 // candle's index_select rejects these (embed_head.rs:80)
+            {   // rows [c0, end) of this sequence, array by array (tight loops the compiler vectorises; one division per block, not per token)
+                const int64_t n = end - c0, *tok = s.token_ids.data() + c0;
+                uint64_t worst = 0;
+                for (int64_t i = 0; i < n; ++i) { const uint64_t t = (uint64_t)tok[i]; worst = t > worst ? t : worst; ids[T + i] = (int64_t)t; }
+                if (worst >= (uint64_t)V) {                                   // candle's index_select rejects these (embed_head.rs:80)
+                    int64_t p = c0; while ((uint64_t)s.token_ids[p] < (uint64_t)V) ++p;
                     return nvr::fail(NVR_ERR_INVALID_ARG, "token id %ld at position %ld is outside the vocabulary [0, %ld)", (long)s.token_ids[p], (long)p, (long)V);
-                ids[T] = s.token_ids[p]; pos[T] = p;
-                slots[T] = (int32_t)((int64_t)s.block_table[p / bs] * bs + p % bs);
-                ctx[T] = (int32_t)(p + 1); kvb[T] = cu[b];
-                ++T;
+                }
+                for (int64_t i = 0; i < n; ++i) pos[T + i] = c0 + i;
+                for (int64_t i = 0; i < n; ++i) ctx[T + i] = (int32_t)(c0 + i + 1);
+                const int32_t cub = cu[b];
+                for (int64_t i = 0; i < n; ++i) kvb[T + i] = cub;
+                for (int64_t p = c0; p < end;) {                              // slot(pos) = table[pos / bs] * bs + pos % bs, block by block
+                    const int64_t blk = p / bs, stop = std::min(end, (blk + 1) * bs);
+                    const int32_t base = (int32_t)((int64_t)s.block_table[blk] * bs - blk * bs);
+                    for (int64_t q = p; q < stop; ++q) slots[T + (q - c0)] = base + (int32_t)q;
+                    p = stop;
+                }
+                T += n;
             }
             cu[b + 1] = (int32_t)T;
             max_ctx = std::max(max_ctx, end);
@@ -657,9 +683,7 @@ int nvr_model_runner::execute(nvr_seq *const *seqs, size_t nseq, bool is_prefill
     // one H2D per array actually used this step (K19)
     auto up = [&](size_t off, size_t bytes) { return hipMemcpyAsync(in_dev + off, in_host + off, bytes, hipMemcpyHostToDevice, stream); };
     if (is_prefill) {
-        NVR_HIP_CHECK(up(off_ids, T * 8)); NVR_HIP_CHECK(up(off_pos, T * 8)); NVR_HIP_CHECK(up(off_slots, T * 4));
-        NVR_HIP_CHECK(up(off_ctx, T * 4)); NVR_HIP_CHECK(up(off_cu, (nseq + 1) * 4)); NVR_HIP_CHECK(up(off_kvbase, T * 4));
-        if (n_tiles) NVR_HIP_CHECK(up(off_tiles, n_tiles * sizeof(k::FlashTile)));
+        NVR_HIP_CHECK(up(0, n_tiles ? off_tiles + (size_t)n_tiles * sizeof(k::FlashTile) : prefill_bytes));   // ids | pos | slots | ctx | kv base | cu | tiles
         if (prefill_paged) NVR_HIP_CHECK(up(off_dec + dof_bt, nseq * max_blocks_per_seq * 4));
     } else NVR_HIP_CHECK(up(off_dec, dof_bt + nseq * max_blocks_per_seq * 4));
 
