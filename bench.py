@@ -46,7 +46,7 @@ import nvr_import  # noqa: E402
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
 BATCH, PROMPT_LEN, BLOCK = 32, 1024, 256
-TP_ASYNC = False          # launch-ahead on tensor-parallel ranks (set once the runner supports it)
+TP_ASYNC = True           # launch-ahead also runs on tensor-parallel ranks (device-side cross-rank arg-max merge, r03)
 
 
 def model_bytes_per_step(mc, ctx_mean: float) -> dict:
@@ -384,6 +384,7 @@ def main() -> None:
     dist = None
     watchdog = None
     fallback_state: dict = {}
+    arm = lambda phase, secs=None: None                                  # noqa: E731 (N == 1: no watchdog)
     if args.gpus > 1:
         # the multi-rank path cannot be exercised on the 1-GPU development boxes: never hang the driver — if a rank is still
         # stuck (a collective that never completes, a rendezvous that never forms) after 7 minutes (a tensor-parallel child: 110 s), every rank exits
@@ -391,9 +392,11 @@ def main() -> None:
         wd_secs = 110.0 if os.environ.get("NVR_BENCH_CHILD") == "1" else 420.0
 
         def _bail():
-            print(f"[bench] rank {rank}: multi-GPU run made no progress for {int(wd_secs)} s, giving up", file=sys.stderr, flush=True)
-            rep = fallback_state.get("replicas")
-            if rank == 0 and rep is not None:
+            print(f"[bench] rank {rank}: multi-GPU run made no progress in its current phase ({fallback_state.get('phase', '?')}), giving up", file=sys.stderr, flush=True)
+            line, rep = fallback_state.get("line"), fallback_state.get("replicas")
+            if rank == 0 and line is not None:
+                print(json.dumps(line), flush=True)                     # a complete measurement exists (e.g. the side block hung): report it
+            elif rank == 0 and rep is not None:
                 # the tensor-parallel phase hung after the replicas phase finished: report what was measured
                 print(json.dumps({"metric": "decode tokens/s + %HBM-roofline, Qwen3-0.6B bs=32 seq=1024, 1/2/4/8 GPU", "value": rep["value"],
                                   "unit": "tokens/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
@@ -402,10 +405,18 @@ def main() -> None:
                                   "config": {"workload": "Qwen3-0.6B fp16 random-init, bs=32 x 1024-token prompts per GPU, greedy paged-attention decode",
                                              "parallelism": rep["parallelism"] + " (the tensor-parallel phase did not complete in time)"},
                                   "roofline": None, "replicas": rep}), flush=True)
-            os._exit(0 if rep is not None else 4)      # a measured line went out: let the launcher finish normally
-        watchdog = threading.Timer(wd_secs, _bail)
-        watchdog.daemon = True
-        watchdog.start()
+            os._exit(0 if (line is not None or rep is not None) else 4)   # a measured line went out: let the launcher finish normally
+
+        def arm(phase: str, secs: float = None):
+            """(re)start the no-progress timer at a phase boundary"""
+            nonlocal watchdog
+            if watchdog is not None:
+                watchdog.cancel()
+            fallback_state["phase"] = phase
+            watchdog = threading.Timer(secs or wd_secs, _bail)
+            watchdog.daemon = True
+            watchdog.start()
+        arm("rendezvous")
         if world != args.gpus:
             raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run)")
         nvr.preload_rccl()                 # ROCm's librccl before torch's bundled copy can claim the soname
@@ -421,7 +432,7 @@ def main() -> None:
         cfg = nvr.Config(max_num_seqs=BATCH, max_num_batched_tokens=min(BATCH * PROMPT_LEN, 32768), max_model_len=PROMPT_LEN + total_new + 16,
                          kvcache_block_size=BLOCK, num_kvcache_blocks=BATCH * ((PROMPT_LEN + total_new + 16) // BLOCK + 2),
                          tensor_parallel_size=tp_size, tensor_parallel_rank=tp_rank,
-                         device_ordinal=local_rank, enforce_eager=args.eager, async_decode=0 if (args.sync_decode or tp_size > 1) else 1)
+                         device_ordinal=local_rank, enforce_eager=args.eager, async_decode=0 if args.sync_decode else 1)
         return nvr.LLMEngine(cfg, mc)
 
     def barrier():
@@ -496,27 +507,34 @@ def main() -> None:
             eng.model_runner.init_comm(bytes(uid.numpy().tobytes()))             # RCCL communicator + collective self-test
         except Exception as ex:                                                  # noqa: BLE001
             rccl_ok, why = False, str(ex)
+        mine = rccl_ok
         rccl_ok = all_ok(rccl_ok)
+        if mine and not rccl_ok:
+            eng.model_runner.comm_drop_rccl()        # a peer has no communicator: nobody uses RCCL (or the ranks would pick different backends)
+        # every rank goes through the SAME sequence of control-plane collectives below, whatever fails locally
         p2p_ok, why2 = os.environ.get("NVR_BENCH_P2P", "1") != "0", "disabled by NVR_BENCH_P2P=0"
+        try:
+            handle = eng.model_runner.p2p_export() if p2p_ok else b"\0" * 64
+        except Exception as ex:                                                  # noqa: BLE001
+            handle, p2p_ok, why2 = b"\0" * 64, False, str(ex)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (handle, local_rank))
+        p2p_ok = all_ok(p2p_ok)
         if p2p_ok:
             try:
-                handle = eng.model_runner.p2p_export()
+                eng.model_runner.p2p_attach([g[0] for g in gathered], [g[1] for g in gathered])
             except Exception as ex:                                              # noqa: BLE001
-                handle, p2p_ok, why2 = b"\0" * 64, False, str(ex)
-            gathered = [None] * world
-            dist.all_gather_object(gathered, (handle, local_rank))
-            if all_ok(p2p_ok):
-                try:
-                    eng.model_runner.p2p_attach([g[0] for g in gathered], [g[1] for g in gathered])
-                    dist.barrier()                                               # every rank has mapped every arena
-                    eng.model_runner.comm_selftest()                             # all-reduce + all-gather through the arenas
-                except Exception as ex:                                          # noqa: BLE001
-                    p2p_ok, why2 = False, str(ex)
-            else:
-                p2p_ok = False
-            p2p_ok = all_ok(p2p_ok)
-            if not p2p_ok:
-                eng.model_runner.p2p_disable()
+                p2p_ok, why2 = False, str(ex)
+        p2p_ok = all_ok(p2p_ok)
+        dist.barrier()                                                           # every rank has mapped every arena (or nobody uses them)
+        if p2p_ok:
+            try:
+                eng.model_runner.comm_selftest()                                 # all-reduce + all-gather through the arenas
+            except Exception as ex:                                              # noqa: BLE001
+                p2p_ok, why2 = False, str(ex)
+        p2p_ok = all_ok(p2p_ok)
+        if not p2p_ok:
+            eng.model_runner.p2p_disable()
         if not rccl_ok and not p2p_ok:
             return False, f"no collective backend: RCCL: {why or 'a peer failed'}; peer-to-peer: {why2 or 'a peer failed'}"
         desc = ("one-shot peer-to-peer kernels over xGMI (all-reduce + residual + RMSNorm in one launch, captured in the decode graph)"
@@ -534,6 +552,7 @@ def main() -> None:
             dist.barrier(); dist.destroy_process_group()
             sys.stdout.flush(); os._exit(0 if child else 3)
         parallelism, scaling, jobs = f"tp{args.gpus}", "strong", 1
+        arm("tensor-parallel decode")
         elapsed, t_prefill = run_decode(eng)
     elif args.gpus > 1:
         eng = make_engine(1, 0)
@@ -617,6 +636,7 @@ def main() -> None:
             configs3 = side_decode(nvr, "qwen3-8b")
         except Exception as ex:                                              # noqa: BLE001
             configs3 = {"error": str(ex)[:300]}
+    configs3_tp = args.gpus > 1 and parallelism.startswith("tp") and not args.no_configs3 and args.model == "qwen3-0.6b"
     sweep = None
     if args.gpus == 1 and rank == 0 and not args.no_prefill_sweep and args.model == "qwen3-0.6b":
         try:
@@ -633,6 +653,7 @@ def main() -> None:
         except Exception:
             traffic = None
 
+    line = None
     if rank == 0:
         out = {
             "metric": "decode tokens/s + %HBM-roofline, Qwen3-0.6B bs=32 seq=1024, 1/2/4/8 GPU",
@@ -686,15 +707,34 @@ def main() -> None:
             tp_line = dict(tensor_parallel)
             tp_line["replicas"] = replicas
             tp_line["speedup_vs_one_replica"] = round(tp_line["value"] / (replicas["value"] / args.gpus), 3)
-            print(json.dumps(tp_line), flush=True)
+            line = tp_line
         else:
             if replicas is not None:
                 out["replicas"] = replicas
             if tensor_parallel is not None:                                 # both tensor-parallel attempts failed: say so in the line
                 out["tensor_parallel"] = tensor_parallel
                 out["config"]["parallelism"] = parallelism + " (the tensor-parallel phase failed: see tensor_parallel.error)"
-            print(json.dumps(out), flush=True)
+            line = out
     del eng
+    if configs3_tp:
+        # BASELINE.json configs[3] on the same ranks: Qwen3-8B, bs 32 x 2048, tensor parallel over the N GPUs (every rank takes part;
+        # a hang here costs nothing already measured: the watchdog prints the line as it stands)
+        fallback_state["line"] = line
+        arm("configs[3] tensor-parallel side block", 90.0)
+
+        def rmax(v):
+            import torch
+            t = torch.tensor([v], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+        try:
+            c3 = side_decode(nvr, "qwen3-8b", tp_size=args.gpus, tp_rank=rank, device=local_rank, attach=init_tensor_parallel, barrier=barrier, reduce_max=rmax)
+        except Exception as ex:                                              # noqa: BLE001
+            c3 = {"error": str(ex)[:300]}
+        if line is not None:
+            line["configs3"] = c3
+    if rank == 0 and line is not None:
+        print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

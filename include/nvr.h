@@ -324,6 +324,7 @@ NVR_API size_t nvr_engine_take_finished(nvr_engine_t *e, nvr_seq_t **out, size_t
 NVR_API int nvr_engine_abort_last_batch(nvr_engine_t *e);
 /* nvr_config.async_decode: decode steps whose successor could not be enqueued ahead and therefore ran synchronously (diagnostic) */
 NVR_API uint64_t nvr_engine_ahead_declined(const nvr_engine_t *e);
+NVR_API uint64_t nvr_engine_ahead_launched(const nvr_engine_t *e);   /* decode steps that were enqueued ahead */
 /* sequences of the last step's batch (borrowed handles; finished ones are excluded) */
 NVR_API size_t nvr_engine_last_batch(const nvr_engine_t *e, nvr_seq_t **out, size_t cap);
 

@@ -182,7 +182,7 @@ _SIGS = {
     "nvr_runner_p2p_export": (C.c_int, [_P, _P]), "nvr_runner_p2p_attach": (C.c_int, [_P, _P, _P]),
     "nvr_runner_p2p_disable": (C.c_int, [_P]), "nvr_runner_p2p_active": (C.c_int, [_P]),
     "nvr_runner_p2p_reset": (C.c_int, [_P]), "nvr_runner_comm_drop_rccl": (C.c_int, [_P]),
-    "nvr_engine_abort_last_batch": (C.c_int, [_P]), "nvr_engine_ahead_declined": (C.c_uint64, [_P]),
+    "nvr_engine_abort_last_batch": (C.c_int, [_P]), "nvr_engine_ahead_declined": (C.c_uint64, [_P]), "nvr_engine_ahead_launched": (C.c_uint64, [_P]),
     "nvr_runner_last_shared_prefix_len": (C.c_int64, [_P]), "nvr_runner_last_shared_prefix_rows": (C.c_int64, [_P]),
     "nvr_engine_last_step": (None, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(C.c_size_t)]),
     "nvr_engine_take_finished": (C.c_size_t, [_P, C.POINTER(_P), C.c_size_t]),
@@ -893,6 +893,9 @@ class LLMEngine:
 
     def ahead_declined(self) -> int:
         return int(lib().nvr_engine_ahead_declined(self.h))
+
+    def ahead_launched(self) -> int:
+        return int(lib().nvr_engine_ahead_launched(self.h))
 
 
 # ---------------------------------------------------------------------------------- device helpers

@@ -25,7 +25,7 @@ inline double now_us() { return std::chrono::duration<double, std::micro>(std::c
 // placeholder tokens and enqueued BEFORE the host waits for the current step's tokens; the placeholders are patched when they
 // arrive.  The GPU never idles between steps (the host gap was 35-40 us of a 1.53 ms step, profiles/r01 step_gap).
 bool nvr_engine::can_launch_ahead(const std::vector<nvr_seq *> &cur) const {
-    if (!cfg.async_decode || !runner->ahead_capable() || cur.empty()) return false;
+    if (!cfg.async_decode || cur.empty() || !runner->ahead_ok(cur.size())) return false;
     const nvr::Scheduler &sc = scheduler->impl;
     if (!sc.next_is_decode_of(cur.data(), cur.size())) return false;
     const size_t bs = cfg.kvcache_block_size;
@@ -57,7 +57,7 @@ int nvr_engine::step_async(nvr_step_info *info) {
         if (rc) return rc;
         rc = runner->execute(batch.data(), batch.size(), is_prefill);
         if (rc) { scheduler->impl.abort_batch(batch.data(), batch.size()); return rc; }
-        bool greedy = runner->ahead_capable() && runner->lm_parts_of_last_step() > 0;
+        bool greedy = runner->ahead_ok(batch.size()) && runner->lm_parts_of_last_step() > 0;
         for (const nvr_seq *s : batch) greedy = greedy && s->sampling.temperature == 0.0f;
         if (!greedy) {                                                   // stochastic rows: the ordinary synchronous tail
             last_tokens.resize(batch.size());
@@ -104,7 +104,7 @@ int nvr_engine::step_async(nvr_step_info *info) {
             nvr_seq *s = batch[i];
             s->token_ids[s->num_tokens - 1] = last_tokens[i]; s->last_token = last_tokens[i];
         }
-        if (!arc) ahead.pending = true;
+        if (!arc) { ahead.pending = true; ++ahead_launched; }
         else {
             if (scheduled) scheduler->impl.restore_stats(ahead.stats_before);
             if (arc == NVR_ERR_INVARIANT) { nvr::last_error_slot() = ahead_err; nvr::last_status_slot() = ahead_status; return arc; }

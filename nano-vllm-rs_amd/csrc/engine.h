@@ -24,6 +24,7 @@ struct nvr_engine {
     int step_async(nvr_step_info *info);
     bool can_launch_ahead(const std::vector<nvr_seq *> &cur) const;
     void cancel_ahead();                                 // a request arrived (or the engine shuts down) while a step is in flight
+    uint64_t ahead_launched = 0;                         // decode steps enqueued ahead of their predecessor's tokens
     uint64_t ahead_declined = 0;                         // steps whose successor could not be enqueued ahead (they then ran synchronously)
     void abort_last_batch();                             // control-plane abort of the batch the engine scheduled last (tensor-parallel ranks)
 

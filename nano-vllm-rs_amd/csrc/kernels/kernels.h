@@ -46,8 +46,13 @@ int32_t lm_head_parts(int64_t T, int64_t K, int64_t N, int64_t ldx);      // par
 // store_logits = false: only the partials are written (a greedy batch never reads its 4·T·N logit bytes)
 int lm_head(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t N, float *logits,
             float *part_val, int32_t *part_idx, int32_t *nparts, hipStream_t s, bool store_logits = true, const half_bits *Wt = nullptr);
+struct TpArgmaxRec { float val; int32_t pad; int64_t idx; };           // 16 B: a rank's (max, global arg-max) of one row
 int argmax_partials(const float *part_val, const int32_t *part_idx, int32_t nparts, int64_t T, int64_t *out_idx, float *out_val,
-                    int64_t idx_offset, hipStream_t s, int64_t *out_idx2 = nullptr);
+                    int64_t idx_offset, hipStream_t s, int64_t *out_idx2 = nullptr, TpArgmaxRec *out_rec = nullptr);
+// cross-rank merge of gathered records recs[tp][B] (largest value, lowest index on ties, rank order): token ids to out_host (and out_dev),
+// *err (the collectives' error word, nullable) to *err_out (nullable) before token 0
+int tp_argmax_merge(const TpArgmaxRec *recs, int tp, int64_t B, int64_t *out_host, int64_t *out_dev, const unsigned int *err, int64_t *err_out,
+                    hipStream_t s);
 
 int64_t stream_row_limit();    // rows up to which the weight-streaming kernels are preferred over the LDS-tiled GEMM (linear.hip)
 int linear_splitk(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t N, int64_t S,

@@ -110,7 +110,8 @@ __global__ __launch_bounds__(WAVES * 64) void lm_head_kernel(const half_t *__res
 
 __global__ __launch_bounds__(64) void argmax_partials_kernel(const float *__restrict__ pval, const int32_t *__restrict__ pidx,
                                                              int nparts, int T, int64_t *__restrict__ out_idx,
-                                                             float *__restrict__ out_val, int64_t idx_offset, int64_t *__restrict__ out_idx2) {
+                                                             float *__restrict__ out_val, int64_t idx_offset, int64_t *__restrict__ out_idx2,
+                                                             TpArgmaxRec *__restrict__ out_rec) {
     const int m = blockIdx.x, lane = threadIdx.x;
     float bv = -INFINITY; int bi = 0x7fffffff;
     for (int p = lane; p < nparts; p += 64) take_better(bv, bi, pval[(int64_t)p * T + m], pidx[(int64_t)p * T + m]);
@@ -125,7 +126,30 @@ __global__ __launch_bounds__(64) void argmax_partials_kernel(const float *__rest
         out_idx[m] = tok;
         if (out_idx2) out_idx2[m] = tok;                         // e.g. the NEXT decode step's input ids, already on the device
         if (out_val) out_val[m] = bv;
+        if (out_rec) { TpArgmaxRec rc; rc.val = bv; rc.pad = 0; rc.idx = tok; out_rec[m] = rc; }   // one record per row for the cross-rank merge
     }
+}
+
+// Vocabulary-sharded greedy sampling (ParallelLMHead::gather_logits + Sampler::greedy, reference src/layers/embed_head.rs:321-336,
+// src/layers/sampler.rs:109-112): every rank holds every rank's (max, global arg-max) record of every row (all-gather); the merge takes
+// the largest value, lowest index on ties, in RANK ORDER — the same decision on every rank — and writes the token to the host-visible
+// buffer, to the next decode step's device-side input ids (launch-ahead) and the collectives' error word next to the tokens.
+__global__ __launch_bounds__(256) void tp_argmax_merge_kernel(const TpArgmaxRec *__restrict__ recs, int tp, int B, int64_t *__restrict__ out_host,
+                                                              int64_t *__restrict__ out_dev, const unsigned int *__restrict__ err,
+                                                              int64_t *__restrict__ err_out) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b == 0 && err_out) {                                      // before token 0: a reader that has seen token 0 sees this word
+        *err_out = err ? (int64_t)*err : 0;
+        __threadfence_system();
+    }
+    if (b >= B) return;
+    float bv = recs[b].val; int64_t bi = recs[b].idx;
+    for (int r = 1; r < tp; ++r) {
+        const float v = recs[(int64_t)r * B + b].val; const int64_t i = recs[(int64_t)r * B + b].idx;
+        if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
+    }
+    if (out_dev) out_dev[b] = bi;
+    out_host[b] = bi;
 }
 
 bool lm_head_ok(int64_t T, int64_t K, int64_t N, int64_t ldx) {
@@ -205,11 +229,20 @@ int lm_head(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int6
     return 0;
 }
 
+int tp_argmax_merge(const TpArgmaxRec *recs, int tp, int64_t B, int64_t *out_host, int64_t *out_dev, const unsigned int *err, int64_t *err_out,
+                    hipStream_t s) {
+    if (B == 0) return 0;
+    tp_argmax_merge_kernel<<<dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s>>>(recs, tp, (int)B, out_host, out_dev, err, err_out);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return nvr::fail(NVR_ERR_HIP, "tp_argmax_merge launch failed: %s", hipGetErrorString(e));
+    return 0;
+}
+
 int argmax_partials(const float *part_val, const int32_t *part_idx, int32_t nparts, int64_t T, int64_t *out_idx, float *out_val,
-                    int64_t idx_offset, hipStream_t s, int64_t *out_idx2) {
+                    int64_t idx_offset, hipStream_t s, int64_t *out_idx2, TpArgmaxRec *out_rec) {
     if (T == 0) return 0;
     if (nparts < 1) return nvr::fail(NVR_ERR_INVALID_ARG, "argmax_partials: nparts=%d", nparts);
-    argmax_partials_kernel<<<dim3((unsigned)T), dim3(64), 0, s>>>(part_val, part_idx, nparts, (int)T, out_idx, out_val, idx_offset, out_idx2);
+    argmax_partials_kernel<<<dim3((unsigned)T), dim3(64), 0, s>>>(part_val, part_idx, nparts, (int)T, out_idx, out_val, idx_offset, out_idx2, out_rec);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return nvr::fail(NVR_ERR_HIP, "argmax_partials launch failed: %s", hipGetErrorString(e));
     return 0;

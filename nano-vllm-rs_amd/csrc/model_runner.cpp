@@ -43,7 +43,7 @@ nvr_model_runner::~nvr_model_runner() {
     if (lm_head_t) hipFree(lm_head_t);
     void *ptrs[] = {embed, mc.tie_word_embeddings ? nullptr : lm_head, norm, cos_t, sin_t, kv_pool, h, n, qkv, attn,
                     proj, gu, act, nlast, logits, attn_ws, slabs, in_dev, d_tok, d_maxval, d_temp, d_topk, d_topp, d_keys,
-                    sample_ws, d_gather_val, d_gather_idx, d_gather_logits, d_full_logits, sample_ws_full, d_lm_pval, d_lm_pidx};
+                    sample_ws, d_gather_val, d_gather_idx, d_gather_logits, d_full_logits, sample_ws_full, d_lm_pval, d_lm_pidx, d_rec, d_gather_rec};
     for (void *p : ptrs) if (p) hipFree(p);
     if (in_host) hipHostFree(in_host);
     if (h_tok) hipHostFree(h_tok);
@@ -145,7 +145,7 @@ int nvr_model_runner::init() {                                       // ModelRun
     if (hipHostGetDevicePointer((void **)&h_tok_dev, h_tok, 0) != hipSuccess) { h_tok_dev = nullptr; (void)hipGetLastError(); }
     if (cfg.async_decode && h_tok_dev) {                                 // launch-ahead: one token buffer and one input twin per step in flight
         for (int i = 0; i < 2; ++i) {
-            NVR_HIP_CHECK(hipHostMalloc((void **)&ahead_tok[i], max_seqs * 8, hipHostMallocDefault));
+            NVR_HIP_CHECK(hipHostMalloc((void **)&ahead_tok[i], (max_seqs + 1) * 8, hipHostMallocDefault));   // + the collectives' error word
             NVR_HIP_CHECK(hipHostGetDevicePointer((void **)&ahead_tok_dev[i], ahead_tok[i], 0));
             NVR_HIP_CHECK(hipHostMalloc((void **)&ahead_host[i], dec_bytes, hipHostMallocDefault));
         }
@@ -154,6 +154,7 @@ int nvr_model_runner::init() {                                       // ModelRun
     NVR_HIP_CHECK(hipHostMalloc((void **)&samp_host, max_seqs * 24, hipHostMallocDefault));
     NVR_HIP_CHECK(hipMalloc(&sample_ws, k::sample_workspace_bytes(max_seqs, Vl)));
     RC(dmalloc(&d_gather_val, tp * max_seqs)); RC(dmalloc(&d_gather_idx, tp * max_seqs));   // (max, argmax) pairs of every rank
+    if (tp > 1) { RC(dmalloc(&d_rec, max_seqs)); RC(dmalloc(&d_gather_rec, tp * max_seqs)); }
 
     // KV pool (create_kv_cache, :364-396): [NB, bs, KVH/tp, D] per layer per K/V, one allocation.
     const size_t block_elems = (size_t)block_size * KVH * D;
@@ -735,7 +736,8 @@ int nvr_model_runner::execute(nvr_seq *const *seqs, size_t nseq, bool is_prefill
 // tables follow from the sequence lengths alone.  Nothing here synchronises the stream.
 int nvr_model_runner::execute_decode_ahead(nvr_seq *const *seqs, size_t nseq, int parity) {
     NVR_HIP_CHECK(hipSetDevice(device));
-    if (!ahead_capable()) return nvr::fail(NVR_ERR_UNSUPPORTED, "execute_decode_ahead: runner not set up for launch-ahead");
+    if (tp > 1) RC(comm.prepare());
+    if (!ahead_ok(nseq)) return nvr::fail(NVR_ERR_UNSUPPORTED, "execute_decode_ahead: runner not set up for launch-ahead");
     if (tiled_dirty) return nvr::fail(NVR_ERR_UNSUPPORTED, "execute_decode_ahead: parameters changed, the tiled copies are rebuilt by a synchronous step");
     if (nseq == 0 || (int64_t)nseq > max_seqs) return nvr::fail(NVR_ERR_INVALID_ARG, "execute_decode_ahead: %zu sequences", nseq);
     char *hd = ahead_host[parity & 1];
@@ -790,13 +792,21 @@ int nvr_model_runner::execute_decode_ahead(nvr_seq *const *seqs, size_t nseq, in
 
 int nvr_model_runner::sample_launch(nvr_seq *const *seqs, size_t nseq, int parity) {
     NVR_HIP_CHECK(hipSetDevice(device));
-    if (!ahead_capable() || lm_parts <= 0) return nvr::fail(NVR_ERR_INVARIANT, "sample_launch: runner not set up for launch-ahead");
+    if (!ahead_capable() || lm_parts <= 0) return nvr::fail(NVR_ERR_UNSUPPORTED, "sample_launch: runner not set up for launch-ahead");
     if (nseq != last_rows) return nvr::fail(NVR_ERR_LEN_MISMATCH, "sample_tokens: %zu sequences but logits hold %zu rows", nseq, last_rows);
     int64_t *ht = ahead_tok[parity & 1];
     for (size_t i = 0; i < nseq; ++i) ht[i] = INT64_MIN;                  // (the kernel below has not been enqueued yet)
+    ht[max_seqs] = 0;
     // greedy_sample, sampler.rs:109-112: token ids to the pinned host buffer (device-visible mapping) AND to the next decode
     // step's input ids on the device
-    return k::argmax_partials(d_lm_pval, d_lm_pidx, lm_parts, (int64_t)nseq, ahead_tok_dev[parity & 1], nullptr, 0, stream, dd_ids);
+    if (tp == 1) return k::argmax_partials(d_lm_pval, d_lm_pidx, lm_parts, (int64_t)nseq, ahead_tok_dev[parity & 1], nullptr, 0, stream, dd_ids);
+    // vocabulary shards (embed_head.rs:321-336): this rank's (max, global arg-max) records -> all-gather through the peer arenas ->
+    // the same rank-ordered merge on every rank, all stream-ordered (no host round trip: the next step can be enqueued behind it)
+    if (!ahead_ok(nseq)) return nvr::fail(NVR_ERR_UNSUPPORTED, "sample_launch: %zu rows do not fit the peer-to-peer all-gather", nseq);
+    RC(k::argmax_partials(d_lm_pval, d_lm_pidx, lm_parts, (int64_t)nseq, d_tok, d_maxval, vocab_start, stream, nullptr, d_rec));
+    RC(comm.all_gather_bytes(d_rec, d_gather_rec, nseq * sizeof(k::TpArgmaxRec), stream));
+    return k::tp_argmax_merge(d_gather_rec, (int)tp, (int64_t)nseq, ahead_tok_dev[parity & 1], dd_ids, comm.p2p_words ? comm.p2p_words + 2 : nullptr,
+                              ahead_tok_dev[parity & 1] + max_seqs, stream);
 }
 
 int nvr_model_runner::sample_wait(size_t nseq, int parity, int64_t *out) {
@@ -812,6 +822,10 @@ int nvr_model_runner::sample_wait(size_t nseq, int parity, int64_t *out) {
             }
         }
         out[i] = ht[i];
+    }
+    if (tp > 1 && ht[max_seqs] != 0) {                                   // a collective of this step gave up on a peer: zeros stood in for its sums
+        (void)hipMemsetAsync(comm.p2p_words + 2, 0, 4, stream);
+        return nvr::fail(NVR_ERR_RCCL, "peer-to-peer all-reduce: a peer did not arrive (epoch %ld)", (long)ht[max_seqs]);
     }
     return NVR_OK;
 }

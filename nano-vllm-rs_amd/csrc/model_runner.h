@@ -12,6 +12,7 @@
 #include "sequence.h"
 #include "comm.h"
 #include "common.h"
+#include "kernels/kernels.h"
 
 struct nvr_model_runner {
     nvr::Env env;                          // NVR_* switches, read once in init()
@@ -60,6 +61,7 @@ struct nvr_model_runner {
     // TP exchange buffers for the greedy (max, idx) merge
     float *d_gather_val = nullptr; int64_t *d_gather_idx = nullptr;
     float *d_gather_logits = nullptr, *d_full_logits = nullptr; void *sample_ws_full = nullptr;   // stochastic sampling under TP (lazy)
+    nvr::k::TpArgmaxRec *d_rec = nullptr, *d_gather_rec = nullptr;     // greedy launch-ahead under TP: this rank's records, every rank's
 
     // decode chain (kernels/linear_decode.hip): one ticket counter per (column tile, token tile) of the row-parallel GEMMs
     unsigned int *chain_cnt = nullptr;
@@ -84,7 +86,12 @@ struct nvr_model_runner {
     // Launch-ahead of greedy decode steps (nvr_config.async_decode, engine.cpp): the sampled tokens of step k go straight into
     // step k+1's device-side input ids, and step k+1 is enqueued before step k's tokens have reached the host.
     int32_t lm_parts_of_last_step() const { return lm_parts; }
-    bool ahead_capable() const { return tp == 1 && !comm.active() && lm_fused && h_tok_dev != nullptr && ahead_tok[0] != nullptr; }
+    // single rank, or tensor-parallel ranks whose collectives are the stream-ordered peer-to-peer kernels (no host rendezvous): every
+    // rank takes the same decisions from the same scheduler state and merges the same gathered (max, arg-max) records on the device
+    bool ahead_capable() const {
+        return lm_fused && h_tok_dev != nullptr && ahead_tok[0] != nullptr && ((tp == 1 && !comm.active()) || (tp > 1 && comm.p2p_ready));
+    }
+    bool ahead_ok(size_t nseq) const { return ahead_capable() && (tp == 1 || nseq * sizeof(nvr::k::TpArgmaxRec) <= (size_t)nvr::P2P_GATHER_BYTES); }
     int sample_launch(nvr_seq *const *seqs, size_t nseq, int parity);        // greedy rows: arg-max merge -> pinned ahead_tok[parity] and dd_ids
     int sample_wait(size_t nseq, int parity, int64_t *out);                  // spins on the pinned buffer (no stream synchronisation)
     int execute_decode_ahead(nvr_seq *const *seqs, size_t nseq, int parity); // decode step whose ids are already on the device

@@ -415,6 +415,7 @@ void nvr_engine_last_step(const nvr_engine_t *e, const uint64_t **ids, const int
 size_t nvr_engine_take_finished(nvr_engine_t *e, nvr_seq_t **out, size_t cap) { return e->scheduler->impl.take_finished(out, cap); }
 int nvr_engine_abort_last_batch(nvr_engine_t *e) { NVR_GUARD_BEGIN e->abort_last_batch(); return NVR_OK; NVR_GUARD_END(NVR_ERR_INVARIANT) }
 uint64_t nvr_engine_ahead_declined(const nvr_engine_t *e) { return e->ahead_declined; }
+uint64_t nvr_engine_ahead_launched(const nvr_engine_t *e) { return e->ahead_launched; }
 size_t nvr_engine_last_batch(const nvr_engine_t *e, nvr_seq_t **out, size_t cap) {
     size_t n = 0;
     for (nvr_seq *s : e->batch) if (s->status != NVR_SEQ_FINISHED && n < cap) out[n++] = s;

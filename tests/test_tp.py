@@ -228,6 +228,7 @@ def _tp_ranks_vs_oracle(tp, m, ecfg, prompts, sps, product_kw=None, min_steps=5)
                     near += 1
     assert near <= 2
     assert o.scheduler.is_finished()
+    _tp_ranks_vs_oracle.ahead_launched = [e.ahead_launched() for e in engines]
     return shared_seen
 
 
@@ -498,3 +499,63 @@ def test_peer_that_never_arrives_fails_the_step_and_the_group_recovers():
     # (a numerical near-tie between the sharded and the single-rank sums may send ONE sequence down another path)
     diverged = {col for ra, rr in zip(a, ref) for col, (x, y) in enumerate(zip(ra, rr)) if x != y}
     assert len(diverged) <= 1, (a, ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tp", [2, 4])
+def test_tensor_parallel_launch_ahead_is_transparent(tp):
+    """Row g: launch-ahead (nvr_config.async_decode) on tensor-parallel ranks.  The vocabulary-sharded greedy tokens are merged on the
+    DEVICE (every rank's (max, arg-max) records all-gathered through the peer arenas, rank-ordered merge, ids straight into the next
+    step's device-side input ids), so the next decode step is enqueued before the host has seen the current tokens — on every rank, from
+    the same scheduler state.  Per step: the same batch, tokens and finished counts on every rank and the same as the SYNCHRONOUS
+    tensor-parallel ranks (async_decode = 0; those are checked against the oracle's tensor-parallel engine by the tests above), with a
+    request arriving in the middle (cancels the step in flight on every rank); and steps WERE launched ahead on every rank."""
+    import threading
+    import oracle
+    from oracle import model_oracle as mo
+    sys.path.insert(0, ROOT)
+    import nvr_import
+    nvr = nvr_import.load()
+    m = mo.small(seed=26, num_attention_heads=8, num_key_value_heads=4, head_dim=64, hidden_size=256, intermediate_size=512)
+    mc = nvr.ModelConfig(vocab_size=m.vocab_size, hidden_size=m.hidden_size, intermediate_size=m.intermediate_size,
+                         num_hidden_layers=m.num_hidden_layers, num_attention_heads=m.num_attention_heads,
+                         num_key_value_heads=m.num_key_value_heads, head_dim=m.head_dim, max_position_embeddings=m.max_position_embeddings,
+                         rms_norm_eps=m.rms_norm_eps, rope_theta=m.rope_theta, tie_word_embeddings=m.tie_word_embeddings,
+                         init_std=m.init_std, seed=m.seed)
+    ecfg = dict(max_num_seqs=4, max_num_batched_tokens=256, max_model_len=160, kvcache_block_size=64, num_kvcache_blocks=16, skip_block_size_check=1)
+    reqs = [(oracle.fill_tokens(n, 5, i, m.vocab_size).tolist(), mt) for i, (n, mt) in enumerate([(9, 30), (40, 22), (17, 30)])]
+    late = (oracle.fill_tokens(11, 5, 9, m.vocab_size).tolist(), 12)
+
+    def run(async_on):
+        group = nvr.LocalGroup(tp)
+        engines = []
+        for r in range(tp):
+            e = nvr.LLMEngine(nvr.Config(tensor_parallel_size=tp, tensor_parallel_rank=r, async_decode=async_on, **ecfg), mc)
+            group.attach(e.model_runner)
+            nvr.lib().nvr_seq_reset_id_counter()
+            for pr, mt in reqs:
+                e.add_request(pr, nvr.SamplingParams(temperature=0.0, max_tokens=mt, ignore_eos=True))
+            engines.append(e)
+        traces, errors = [[] for _ in range(tp)], []
+
+        def drive(r):
+            try:
+                e, steps = engines[r], 0
+                while not e.is_finished():
+                    if steps == 9:
+                        e.add_request(late[0], nvr.SamplingParams(temperature=0.0, max_tokens=late[1], ignore_eos=True))
+                    rec = e.step()
+                    traces[r].append((rec["is_prefill"], len(rec["seq_ids"]), tuple(rec["tokens"]), rec["num_finished"]))   # (ids of the late request depend on thread timing: one global counter in this process)
+                    steps += 1
+            except BaseException as ex:                                                 # noqa: BLE001
+                errors.append((r, ex))
+        threads = [threading.Thread(target=drive, args=(r,)) for r in range(tp)]
+        for t in threads: t.start()
+        for t in threads: t.join(300)
+        assert not errors, errors
+        assert all(tr == traces[0] for tr in traces), "ranks disagree"
+        return traces[0], [e.ahead_launched() for e in engines]
+    ta, launched = run(1)
+    ts, none = run(0)
+    assert ta == ts and len(ta) > 25
+    assert all(n >= 10 for n in launched) and len(set(launched)) == 1 and not any(none), (launched, none)
