@@ -223,12 +223,12 @@ def prefill_flops(c, lens) -> float:
 
 
 def side_decode(nvr, preset: str, steps: int = 16, warmup: int = 4, tp_size: int = 1, tp_rank: int = 0, device: int = 0,
-                attach=None, barrier=None, reduce_max=None) -> dict:
+                attach=None, barrier=None, reduce_max=None, batch: int = None, prompt_len: int = None) -> dict:
     """One more BASELINE workload measured next to the headline (same engine path: prefill untimed, W warm-up steps, K timed decode
     steps): used for BASELINE.json configs[3] (Qwen3-8B, bs 32 x 2048; src/models/qwen3.rs:70-125 with the 8B numbers) on one GPU and,
     in a tensor-parallel child, over the N GPUs (attach = communicator set-up of the engine's runner)."""
     w = MODELS[preset]
-    B, P = w["batch"], w["prompt_len"]
+    B, P = batch or w["batch"], prompt_len or w["prompt_len"]
     mc = nvr.ModelConfig(preset)
     total_new = warmup + steps + 1
     t0 = time.perf_counter()
@@ -268,8 +268,9 @@ def side_decode(nvr, preset: str, steps: int = 16, warmup: int = 4, tp_size: int
     kv_tok = c.num_hidden_layers * 2 * c.num_key_value_heads * Dh * 2
     step_bytes = weights + B * ctx_mean * kv_tok + B * kv_tok
     ms = el * 1e3 / steps
+    which = f"(BASELINE.json configs[{w['baseline_config']}])" if (batch is None and prompt_len is None) else "(batch-size sweep of the headline workload)"
     out = dict(workload=f"{w['label']} fp16 random-init, bs={B} x {P}-token prompts, greedy paged-attention decode, hipGraph steps "
-                        f"(BASELINE.json configs[{w['baseline_config']}]), {'one GPU' if tp_size == 1 else f'tensor parallel over {tp_size} GPUs'}",
+                        f"{which}, {'one GPU' if tp_size == 1 else f'tensor parallel over {tp_size} GPUs'}",
                parallelism=f"tp{tp_size}", ms_per_step=round(ms, 4), tokens_per_s=round(B * steps / el, 1), steps=steps, warmup=warmup,
                step_algorithmic_bytes=int(step_bytes), step_hbm_frac_per_gpu=round(step_bytes / tp_size / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                prefill_steps=npre, prefill_plus_first_decode_seconds=round(t_pre, 3),
@@ -358,6 +359,7 @@ def main() -> None:
                          "(bs 32 x 2048; --gpus 1: the whole model on one GPU, --gpus 8: tensor parallel over xGMI)")
     ap.add_argument("--no-configs3", action="store_true", help="skip the Qwen3-8B side measurement (configs3 block of the default line)")
     ap.add_argument("--no-prefill-sweep", action="store_true", help="skip the configs[2] prefill sweep (prefill_sweep block)")
+    ap.add_argument("--no-batch-sweep", action="store_true", help="skip the bs 64 / 128 decode side measurements (batch_sweep block)")
     ap.add_argument("--sync-decode", action="store_true",
                     help="nvr_config.async_decode = 0: wait for every step's tokens on the host before the next step is scheduled "
                          "(default: the next greedy decode step is launched ahead; same batches, tokens and statistics)")
@@ -637,6 +639,16 @@ def main() -> None:
         except Exception as ex:                                              # noqa: BLE001
             configs3 = {"error": str(ex)[:300]}
     configs3_tp = args.gpus > 1 and parallelism.startswith("tp") and not args.no_configs3 and args.model == "qwen3-0.6b"
+    batch_sweep = None
+    if args.gpus == 1 and rank == 0 and not args.no_batch_sweep and args.model == "qwen3-0.6b":
+        # the same engine path at larger batches: the step's share of the HBM roofline grows with the K/V bytes per launch
+        batch_sweep = []
+        for bsz in (64, 128):
+            try:
+                r = side_decode(nvr, "qwen3-0.6b", batch=bsz, prompt_len=1024)
+                batch_sweep.append({k: r[k] for k in ("workload", "ms_per_step", "tokens_per_s", "step_algorithmic_bytes", "step_hbm_frac_per_gpu")})
+            except Exception as ex:                                          # noqa: BLE001
+                batch_sweep.append({"batch": bsz, "error": str(ex)[:200]})
     sweep = None
     if args.gpus == 1 and rank == 0 and not args.no_prefill_sweep and args.model == "qwen3-0.6b":
         try:
@@ -698,6 +710,8 @@ def main() -> None:
             out["shared_prefix"] = shared_prefix
         if configs3 is not None:
             out["configs3"] = configs3
+        if batch_sweep is not None:
+            out["batch_sweep"] = batch_sweep
         if sweep is not None:
             out["prefill_sweep"] = sweep
         if args.gpus == 1 and not args.no_cpu_baseline:

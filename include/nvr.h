@@ -110,9 +110,14 @@ typedef struct nvr_config {
     char device[16];                   /* config.rs:48, validated like :108-111 plus "hip": "hip" (default) | "cuda" (the reference's
                                           default, taken as "the GPU") | "cpu" | "metal"; a runner exists only for "hip" / "cuda" —
                                           there is no CPU path in this library (NVR_ERR_UNSUPPORTED) */
-    char dtype[16];                    /* config.rs:51,:113-116: "float16" (default) | "bfloat16" | "float32"; the kernels compute in
-                                          fp16 storage / f32 accumulate only (others: NVR_ERR_UNSUPPORTED at runner creation;
-                                          bf16 / f32 checkpoints are converted on load) */
+    char dtype[16];                    /* config.rs:51,:113-116: "float16" (default) | "bfloat16" | "float32".  A runner exists for the two
+                                          16-bit types: every kernel and collective of the library is built twice (fp16 and bf16 storage,
+                                          f32 accumulation, MFMA at the same rate) and the runner picks one build at creation — weights,
+                                          activations, KV cache and the residual stream are all of that type, logits are f32;
+                                          nvr_runner_load_tensor converts any of f16 / bf16 / f32 to it (bf16 checkpoints into a bf16
+                                          runner bit for bit), nvr_runner_copy_weight returns its raw 16-bit elements.  "float32":
+                                          NVR_ERR_UNSUPPORTED at runner creation (f32 checkpoints load into either type).  The stateless
+                                          op entry points below (nvr_linear, nvr_paged_attn_*, ...) take fp16 buffers */
 } nvr_config;
 NVR_API void nvr_config_default(nvr_config *cfg);                    /* config.rs:54-71 */
 NVR_API int nvr_config_validate(const nvr_config *cfg);              /* config.rs:83-119 */

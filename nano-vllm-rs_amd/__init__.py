@@ -568,6 +568,7 @@ class ModelRunner:
 
     def __init__(self, config: Config, model_config: ModelConfig, _handle=None):
         self.vocab_local = model_config.c.vocab_size // max(1, config.c.tensor_parallel_size) if _handle is None else 0
+        self.bf16 = bytes(config.c.dtype).split(b"\0")[0] == b"bfloat16"    # the runner's 16-bit type (Config.dtype, config.rs:51)
         if _handle is not None:
             self.h, self.owned = _handle, False
             return
@@ -636,11 +637,14 @@ class ModelRunner:
         return skipped
 
     def weight(self, local_name: str) -> np.ndarray:
-        """A local packed tensor as fp16: "embed", "lm_head", "norm", "layers.N.{qkv,o,gate_up,down,ln1,ln2}"."""
+        """A local packed tensor: "embed", "lm_head", "norm", "layers.N.{qkv,o,gate_up,down,ln1,ln2}" — as fp16, or, from a bfloat16
+        runner (numpy has no bf16), as the f32 values of its bf16 elements (exact)."""
         r, c = C.c_int64(), C.c_int64()
         check(lib().nvr_runner_copy_weight(self.h, local_name.encode(), None, 0, C.byref(r), C.byref(c)))
-        out = np.empty((r.value, c.value), np.float16)
+        out = np.empty((r.value, c.value), np.uint16 if self.bf16 else np.float16)
         check(lib().nvr_runner_copy_weight(self.h, local_name.encode(), out.ctypes.data, out.size, C.byref(r), C.byref(c)))
+        if self.bf16:
+            out = (out.astype(np.uint32) << 16).view(np.float32)
         return out[:, 0] if c.value == 1 else out
 
     def num_kvcache_blocks(self) -> int:

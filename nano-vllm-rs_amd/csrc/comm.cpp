@@ -99,7 +99,6 @@ static int local_p2p_ready(Comm &c) {
     return c.p2p_attach_ptrs(c.local->arenas);
 }
 int Comm::prepare() { return local_p2p_ready(*this); }
-int local_sum_f16(const void *const *ptrs, int n, void *out, size_t count, hipStream_t s);     // comm_local.hip
 
 // ---- peer-to-peer arenas (kernels/comm_p2p.hip) ----------------------------------------------------------------------
 static size_t p2p_flags_offset() { return 2 * 8 * Comm::kP2PSlotBytes; }
@@ -184,7 +183,7 @@ int Comm::all_reduce_add_rmsnorm(const void *in, void *h, const void *wn, float 
     p2p_fill(*this, a);
     a.in = (const p2p_half *)in; a.count = (size_t)rows * Hd; a.Hd = Hd;
     a.h = (p2p_half *)h; a.wn = (const p2p_half *)wn; a.eps = eps; a.out = (p2p_half *)out;
-    return p2p_allreduce_launch(a, rows, s);
+    return bf16 ? kb::p2p_allreduce_launch(a, rows, s) : k::p2p_allreduce_launch(a, rows, s);
 }
 int Comm::p2p_check_error(hipStream_t s) {
     if (!p2p_ready) return NVR_OK;
@@ -212,7 +211,7 @@ int Comm::all_reduce_sum_f16(void *buf, size_t count, hipStream_t s) {
             P2PArgs a{};
             p2p_fill(*this, a);
             a.in = (const p2p_half *)buf; a.count = count; a.Hd = Hd; a.out = (p2p_half *)p2p_tmp;
-            if (int rc = p2p_allreduce_launch(a, (int)(count / (size_t)Hd), s)) return rc;
+            if (int rc = bf16 ? kb::p2p_allreduce_launch(a, (int)(count / (size_t)Hd), s) : k::p2p_allreduce_launch(a, (int)(count / (size_t)Hd), s)) return rc;
             NVR_HIP_CHECK(hipMemcpyAsync(buf, p2p_tmp, count * 2, hipMemcpyDeviceToDevice, s));
             return NVR_OK;
         }
@@ -233,7 +232,7 @@ int Comm::all_reduce_sum_f16(void *buf, size_t count, hipStream_t s) {
         if (int rc = local->rendezvous(rank, buf)) return rc;           // everyone's are, and their addresses are known
         std::vector<const void *> peers;
         { std::lock_guard<std::mutex> lk(local->m); peers = local->ptrs; }
-        if (int rc = local_sum_f16(peers.data(), nranks, local_tmp, count, s)) return rc;
+        if (int rc = bf16 ? kb::local_sum_16(peers.data(), nranks, local_tmp, count, s) : k::local_sum_16(peers.data(), nranks, local_tmp, count, s)) return rc;
         NVR_HIP_CHECK(hipStreamSynchronize(s));
         if (int rc = local->rendezvous(rank, buf)) return rc;           // every rank has read every input
         NVR_HIP_CHECK(hipMemcpyAsync(buf, local_tmp, count * 2, hipMemcpyDeviceToDevice, s));
@@ -241,14 +240,14 @@ int Comm::all_reduce_sum_f16(void *buf, size_t count, hipStream_t s) {
     }
     if (!comm || !g_api.AllReduce)
         return fail(NVR_ERR_RCCL, "all-reduce of %zu fp16 values: no RCCL communicator, and the peer-to-peer arenas take multiples of 4 values only", count);
-    NVR_NCCL(g_api.AllReduce(buf, buf, count, ncclFloat16, ncclSum, (ncclComm_t)comm, s));
+    NVR_NCCL(g_api.AllReduce(buf, buf, count, bf16 ? ncclBfloat16 : ncclFloat16, ncclSum, (ncclComm_t)comm, s));
     return NVR_OK;
 }
 int Comm::all_gather_bytes(const void *send, void *recv, size_t bytes, hipStream_t s) {
     if (p2p_ready && bytes % 4 == 0 && bytes <= (size_t)P2P_GATHER_BYTES) {
         P2PArgs a{};
         p2p_fill(*this, a);
-        return p2p_allgather_launch(a, send, recv, bytes, s);
+        return k::p2p_allgather_launch(a, send, recv, bytes, s);          // bytes: one build serves both types
     }
     if (p2p_ready && !comm && bytes % 8 == 0) {
         // no other backend (peer-to-peer arenas only): a large record (vocabulary-shard logits of stochastic sampling, greedy
@@ -262,7 +261,7 @@ int Comm::all_gather_bytes(const void *send, void *recv, size_t bytes, hipStream
             p2p_fill(*this, a);
             a.in = (const p2p_half *)send + off; a.count = cnt; a.Hd = Hd;
             a.out = (p2p_half *)recv + off; a.gather_stride = total;
-            if (int rc = p2p_allreduce_launch(a, (int)(cnt / (size_t)Hd), s)) return rc;
+            if (int rc = k::p2p_allreduce_launch(a, (int)(cnt / (size_t)Hd), s)) return rc;     // gather form: elements are moved, never summed
         }
         return NVR_OK;
     }

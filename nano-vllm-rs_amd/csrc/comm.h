@@ -40,7 +40,7 @@ struct LocalGroup {
 // flags[2][8][P2P_PUSH_SPLIT] (uint32 epochs); the private words (epoch, done, err) live in ordinary device memory.
 constexpr int P2P_PUSH_SPLIT = 4;
 constexpr int P2P_GATHER_BYTES = 4096;                           // all-gather record per rank (gslots[2][8][4096], gflags[2][8])
-typedef _Float16 p2p_half;
+typedef unsigned short p2p_half;                                 // a 16-bit element (fp16 or bfloat16: the kernel build decides, Comm::bf16 picks the build)
 struct P2PArgs {
     p2p_half *peer_slots[8]; unsigned int *peer_flags[8];       // every rank's arena as mapped into THIS process ([rank] = my own)
     p2p_half *slots; unsigned int *flags;                        // my own arena (what my reduce workgroups read)
@@ -54,10 +54,17 @@ struct P2PArgs {
     p2p_half *h; const p2p_half *wn; float eps;                  // fused residual + RMSNorm (h == nullptr: plain all-reduce into out)
     p2p_half *out;
 };
-int p2p_allreduce_launch(const P2PArgs &a, int rows, hipStream_t s);
-int p2p_allgather_launch(const P2PArgs &a, const void *send, void *recv, size_t bytes, hipStream_t s);
+// kernels/comm_p2p.hip and comm_local.hip exist twice like the other kernels (device_utils.h): sums rounded to fp16 (k) or bfloat16 (kb)
+#define NVR_COMM_DECLS \
+    int p2p_allreduce_launch(const P2PArgs &a, int rows, hipStream_t s); \
+    int p2p_allgather_launch(const P2PArgs &a, const void *send, void *recv, size_t bytes, hipStream_t s); \
+    int local_sum_16(const void *const *ptrs, int n, void *out, size_t count, hipStream_t s);
+namespace k { NVR_COMM_DECLS }
+namespace kb { NVR_COMM_DECLS }
+#undef NVR_COMM_DECLS
 
 struct Comm {
+    bool bf16 = false;                                           // the 16-bit type of the payloads (Config.dtype = "bfloat16"); set by the runner before any collective
     // ---- peer-to-peer arenas
     static constexpr size_t kP2PSlotBytes = 1u << 20;            // payload per (parity, source): decode-sized messages only
     void *arena = nullptr; size_t arena_bytes = 0;               // mine (fine-grained HBM when the allocator offers it)

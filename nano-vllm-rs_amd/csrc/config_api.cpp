@@ -30,12 +30,12 @@ static bool cfg_str_in(const char *v, size_t cap, std::initializer_list<const ch
     for (const char *s : set) if (!std::strcmp(v, s)) return true;
     return false;
 }
-// a runner / engine can be built for this config (the HIP path, fp16): validate() only checks the names, like the reference
+// a runner / engine can be built for this config (the HIP path, fp16 or bf16): validate() only checks the names, like the reference
 int nvr_config_runnable(const nvr_config *c) {
     if (!cfg_str_in(c->device, sizeof c->device, {"hip", "cuda"}))
         return nvr::fail(NVR_ERR_UNSUPPORTED, "device '%s': this library is the MI355X (HIP) path; there is no CPU or Metal path", c->device);
-    if (std::strcmp(c->dtype, "float16") != 0)
-        return nvr::fail(NVR_ERR_UNSUPPORTED, "dtype '%s': the kernels compute on fp16 storage with f32 accumulation (bf16 / f32 checkpoints are converted on load)", c->dtype);
+    if (std::strcmp(c->dtype, "float16") != 0 && std::strcmp(c->dtype, "bfloat16") != 0)
+        return nvr::fail(NVR_ERR_UNSUPPORTED, "dtype '%s': the kernels compute on 16-bit storage (float16 or bfloat16) with f32 accumulation (f32 checkpoints are converted on load)", c->dtype);
     return NVR_OK;
 }
 int nvr_config_validate(const nvr_config *c) {                       // config.rs:83-119 (model_path checks n/a)

@@ -24,7 +24,7 @@
 #include "device_utils.h"
 #include "../common.h"
 
-namespace nvr { namespace k {
+namespace nvr { namespace NVR_DT_NS {
 
 struct AttnParams {
     const half_t *q; int64_t ldq;
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(WAVES * 64) void attn_rows_kernel(AttnParams p) {
                 float d = 0.f;
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    d = __builtin_amdgcn_fdot2((half2_t){kk[u][2 * j], kk[u][2 * j + 1]}, qv[i][j], d, false);
+                    d = dot2((half2_t){kk[u][2 * j], kk[u][2 * j + 1]}, qv[i][j], d);
                 d = row_sum<LPR>(d);
                 s[u][i] = valid ? d * p.scale : -INFINITY;
             }
@@ -455,4 +455,4 @@ int attention(const AttnArgs &a, bool paged, hipStream_t s) {
                      a.D, G);
 }
 
-}}  // namespace nvr::k
+}}  // namespace nvr::k / nvr::kb (NVR_DT_NS)

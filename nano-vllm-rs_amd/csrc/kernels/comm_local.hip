@@ -4,7 +4,7 @@
 #include "device_utils.h"
 #include "../common.h"
 
-namespace nvr {
+namespace nvr { namespace NVR_DT_NS {
 
 struct LocalPtrs { const half_t *p[8]; };
 
@@ -16,8 +16,8 @@ __global__ void local_sum_kernel(LocalPtrs in, int n, half_t *__restrict__ out, 
     }
 }
 
-int local_sum_f16(const void *const *ptrs, int n, void *out, size_t count, hipStream_t s) {
-    if (n < 1 || n > 8) return fail(NVR_ERR_INVALID_ARG, "local_sum_f16: %d ranks (1..8)", n);
+int local_sum_16(const void *const *ptrs, int n, void *out, size_t count, hipStream_t s) {
+    if (n < 1 || n > 8) return fail(NVR_ERR_INVALID_ARG, "local_sum_16: %d ranks (1..8)", n);
     if (count == 0) return NVR_OK;
     LocalPtrs lp{};
     for (int r = 0; r < n; ++r) lp.p[r] = (const half_t *)ptrs[r];
@@ -28,4 +28,4 @@ int local_sum_f16(const void *const *ptrs, int n, void *out, size_t count, hipSt
     return NVR_OK;
 }
 
-}  // namespace nvr
+}}  // namespace nvr::NVR_DT_NS

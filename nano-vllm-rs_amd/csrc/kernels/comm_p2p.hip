@@ -24,7 +24,11 @@
 #include "../common.h"
 #include "../comm.h"
 
-namespace nvr {
+namespace nvr { namespace NVR_DT_NS {
+
+// P2PArgs carries 16-bit payload pointers untyped (comm.h); this build reads them as its half_t (fp16, or bfloat16 with -DNVR_BF16)
+#define HP(p) reinterpret_cast<half_t *>(p)
+#define CHP(p) reinterpret_cast<const half_t *>(p)
 
 __device__ __forceinline__ unsigned long long p2p_now() { return wall_clock64(); }   // s_memrealtime: 100 MHz, independent of the shader clock
 
@@ -42,7 +46,7 @@ __global__ __launch_bounds__(256) void p2p_allreduce_kernel(P2PArgs a) {
         const int peer = pi < a.rank ? pi : pi + 1;
         const size_t total16 = (a.count * 2 + 15) / 16;                        // 16-byte pieces of the payload
         const size_t per = (total16 + P2P_PUSH_SPLIT - 1) / P2P_PUSH_SPLIT, lo = sub * per, hi = min(total16, lo + per);
-        half_t *dst = a.peer_slots[peer] + ((size_t)parity * 8 + a.rank) * slot_elems;
+        half_t *dst = HP(a.peer_slots[peer]) + ((size_t)parity * 8 + a.rank) * slot_elems;
         const auto rs = __builtin_amdgcn_make_buffer_rsrc(dst, 0, (int)(total16 * 16), 0x00020000);
         typedef unsigned int u4 __attribute__((ext_vector_type(4)));
         for (size_t i = lo + tid; i < hi; i += 256) {
@@ -77,7 +81,7 @@ __global__ __launch_bounds__(256) void p2p_allreduce_kernel(P2PArgs a) {
         }
         __syncthreads();
         const bool ok = ok_s != 0;
-        const auto rs = __builtin_amdgcn_make_buffer_rsrc(a.slots + (size_t)parity * 8 * slot_elems, 0, (int)(8 * a.slot_bytes), 0x00020000);
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc(HP(a.slots) + (size_t)parity * 8 * slot_elems, 0, (int)(8 * a.slot_bytes), 0x00020000);
         constexpr int C = 4;                                                       // up to 4 chunks of 256*P elements per row
         hp_t v[C], g[C];
         float ss = 0.f;
@@ -90,7 +94,7 @@ __global__ __launch_bounds__(256) void p2p_allreduce_kernel(P2PArgs a) {
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
                     if (r >= a.nranks || (r != a.rank && !ok)) { for (int j = 0; j < P; ++j) x[r][j] = (half_t)0.f; }
-                    else if (r == a.rank) x[r] = *reinterpret_cast<const hp_t *>(a.in + rbase + c);
+                    else if (r == a.rank) x[r] = *reinterpret_cast<const hp_t *>(CHP(a.in) + rbase + c);
                     else if constexpr (P == 8) {
                         x[r] = __builtin_bit_cast(hp_t, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(((size_t)r * slot_elems + rbase + c) * 2), 0, 17));
                     } else {
@@ -100,7 +104,7 @@ __global__ __launch_bounds__(256) void p2p_allreduce_kernel(P2PArgs a) {
                 if (a.gather_stride) {                                             // all-gather form: every rank's piece, unreduced
 #pragma unroll
                     for (int r = 0; r < 8; ++r)
-                        if (r < a.nranks) *reinterpret_cast<hp_t *>(a.out + (size_t)r * a.gather_stride + rbase + c) = x[r];
+                        if (r < a.nranks) *reinterpret_cast<hp_t *>(HP(a.out) + (size_t)r * a.gather_stride + rbase + c) = x[r];
                     continue;
                 }
                 float acc[P];                                                      // rank order: the same sum on every rank
@@ -116,13 +120,13 @@ __global__ __launch_bounds__(256) void p2p_allreduce_kernel(P2PArgs a) {
 #pragma unroll
                 for (int j = 0; j < P; ++j) y[j] = to_half_rn(acc[j]);
                 if (a.h) {                                                         // residual add, layernorm.rs:170-176
-                    v[i] = *reinterpret_cast<const hp_t *>(a.h + rbase + c);
-                    g[i] = *reinterpret_cast<const hp_t *>(a.wn + c);
+                    v[i] = *reinterpret_cast<const hp_t *>(CHP(a.h) + rbase + c);
+                    g[i] = *reinterpret_cast<const hp_t *>(CHP(a.wn) + c);
 #pragma unroll
                     for (int j = 0; j < P; ++j) { v[i][j] = to_half_rn((float)v[i][j] + (float)y[j]); const float f = (float)v[i][j]; ss += f * f; }
-                    *reinterpret_cast<hp_t *>(a.h + rbase + c) = v[i];
+                    *reinterpret_cast<hp_t *>(HP(a.h) + rbase + c) = v[i];
                 } else {
-                    *reinterpret_cast<hp_t *>(a.out + rbase + c) = y;              // plain all-reduce (in place allowed: own row only)
+                    *reinterpret_cast<hp_t *>(HP(a.out) + rbase + c) = y;              // plain all-reduce (in place allowed: own row only)
                 }
             }
         }
@@ -138,7 +142,7 @@ __global__ __launch_bounds__(256) void p2p_allreduce_kernel(P2PArgs a) {
                     hp_t o;
 #pragma unroll
                     for (int j = 0; j < P; ++j) o[j] = to_half_rn(__fmul_rn(__fdiv_rn((float)v[i][j], rms), (float)g[i][j]));
-                    *reinterpret_cast<hp_t *>(a.out + rbase + c) = o;
+                    *reinterpret_cast<hp_t *>(HP(a.out) + rbase + c) = o;
                 }
             }
         }
@@ -232,4 +236,4 @@ int p2p_allreduce_launch(const P2PArgs &a, int rows, hipStream_t s) {
     return NVR_OK;
 }
 
-}  // namespace nvr
+}}  // namespace nvr::NVR_DT_NS

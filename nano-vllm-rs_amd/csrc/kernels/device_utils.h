@@ -5,17 +5,57 @@
 
 namespace nvr {
 
+// The 16-bit storage / MFMA operand type of a kernel file is chosen when the file is COMPILED: every kernel source is built twice,
+// once for fp16 (namespace nvr::k) and once with -DNVR_BF16 for bfloat16 (namespace nvr::kb; Config.dtype = "bfloat16",
+// reference src/config.rs:51,113-116).  half_t is that type in both builds; the few instructions that name the type go through the
+// wrappers below (same MFMA rate, same LDS images and swizzles: both are 16-bit).
+#ifdef NVR_BF16
+typedef __bf16 half_t;
+typedef __bf16 half2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 half4_t __attribute__((ext_vector_type(4)));
+typedef __bf16 half8_t __attribute__((ext_vector_type(8)));
+#define NVR_DT_NS kb
+#else
 typedef _Float16 half_t;
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
 typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+#define NVR_DT_NS k
+#endif
 typedef float float4_t __attribute__((ext_vector_type(4)));
 typedef float float2_t __attribute__((ext_vector_type(2)));
 typedef float float16_t __attribute__((ext_vector_type(16)));
 
 constexpr int kWave = 64;
 
-// f32 -> fp16, round-to-nearest-even, as a standalone conversion.  The empty asm makes the f32 value
+// D = A(16 x 32) . B(32 x 16) + C on the matrix cores, f32 accumulate (v_mfma_f32_16x16x32_f16 / _bf16)
+__device__ __forceinline__ float4_t mfma16(half8_t a, half8_t b, float4_t c) {
+#ifdef NVR_BF16
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+#else
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+#endif
+}
+// c + a.x * b.x + a.y * b.y in f32 (v_dot2_f32_f16 / v_dot2c_f32_bf16)
+__device__ __forceinline__ float dot2(half2_t a, half2_t b, float c) {
+#ifdef NVR_BF16
+    return __builtin_amdgcn_fdot2_f32_bf16(a, b, c, false);
+#else
+    return __builtin_amdgcn_fdot2(a, b, c, false);
+#endif
+}
+// ds_read_b64_tr_b16: the hardware-transposed LDS read of 4 rows x 16 columns of 16-bit elements (cdna guide T10)
+__device__ __forceinline__ half4_t lds_read_tr16(const char *lds_addr) {
+#ifdef NVR_BF16
+    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) half4_t *)lds_addr);
+#else
+    typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
+    const fp16x4_t r = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t *)lds_addr);
+    return (half4_t){(half_t)r[0], (half_t)r[1], (half_t)r[2], (half_t)r[3]};
+#endif
+}
+
+// f32 -> fp16 (bf16 build: -> bfloat16), round-to-nearest-even, as a standalone conversion.  The empty asm makes the f32 value
 // opaque so that hipcc (-ffp-contract=fast) cannot fold the producing multiply/add into a single-rounding
 // v_fma_mixlo_f16: the oracle rounds twice (f32 op, then fp16), and bit-exact parity needs the same.
 __device__ __forceinline__ half_t to_half_rn(float f) {

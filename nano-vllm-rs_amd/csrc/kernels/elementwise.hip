@@ -6,7 +6,7 @@
 #include "device_utils.h"
 #include "../common.h"
 
-namespace nvr { namespace k {
+namespace nvr { namespace NVR_DT_NS {
 
 #define LAUNCH_CHECK()                                                                                   \
     do {                                                                                                 \
@@ -571,4 +571,4 @@ int fill_const(half_bits *dst, int64_t n, float v, hipStream_t s) {
     return 0;
 }
 
-}}  // namespace nvr::k
+}}  // namespace nvr::k / nvr::kb (NVR_DT_NS)

@@ -26,7 +26,7 @@
 #include "device_utils.h"
 #include "../common.h"
 
-namespace nvr { namespace k {
+namespace nvr { namespace NVR_DT_NS {
 
 struct FlashParams {
     const half_t *q; int64_t ldq;
@@ -44,7 +44,6 @@ struct FlashParams {
     const int32_t *srows, *scount;     // optional: only the rows srows[0 .. *scount) of the batch share the prefix (row srows[0] names its blocks)
 };
 
-typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
 
 template <int D>
 __device__ __forceinline__ int v_swz(int row) { return D == 128 ? ((row & 7) << 1) : (((row >> 1) & 3) << 1); }
@@ -292,7 +291,7 @@ __global__ __launch_bounds__(64 * FLASH_WAVES, 8 / FLASH_WAVES) void flash_prefi
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
-                for (int t = 0; t < NQT; ++t) s[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[mt & 1][ks], qf[t][ks], s[t][mt], 0, 0, 0);
+                for (int t = 0; t < NQT; ++t) s[t][mt] = mfma16(kf[mt & 1][ks], qf[t][ks], s[t][mt]);
             __builtin_amdgcn_sched_barrier(0);
         }
         // causal mask only on steps that reach past the tile's first query (keys kt + mt*16 + g4*4 + e)
@@ -339,17 +338,16 @@ __global__ __launch_bounds__(64 * FLASH_WAVES, 8 / FLASH_WAVES) void flash_prefi
             const int row0 = (2 * k2) * 16 + g4 * 4 + (r >> 2), row1 = row0 + 16;
             const int sw = v_swz<D>(row0);                      // same for row1 (row1 = row0 + 16)
 #pragma unroll
-            for (int t = 0; t < NQT; ++t) ol[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, pf[t][k2], ol[t], 0, 0, 0);
+            for (int t = 0; t < NQT; ++t) ol[t] = mfma16(ones, pf[t][k2], ol[t]);
 #pragma unroll
             for (int dt = 0; dt < NDT; ++dt) {
                 const int cb = ((((dt * 2 + ((r & 3) >> 1)) ^ sw) << 4) | ((r & 1) << 3));   // byte offset inside the row
-                const fp16x4_t a0 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t *)(vl + row0 * (D * 2) + cb));
-                const fp16x4_t a1 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t *)(vl + row1 * (D * 2) + cb));
+                const half4_t a0 = lds_read_tr16(vl + row0 * (D * 2) + cb), a1 = lds_read_tr16(vl + row1 * (D * 2) + cb);
                 half8_t vf;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { vf[e] = (half_t)a0[e]; vf[4 + e] = (half_t)a1[e]; }
+                for (int e = 0; e < 4; ++e) { vf[e] = a0[e]; vf[4 + e] = a1[e]; }
 #pragma unroll
-                for (int t = 0; t < NQT; ++t) o[t][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[t][k2], o[t][dt], 0, 0, 0);
+                for (int t = 0; t < NQT; ++t) o[t][dt] = mfma16(vf, pf[t][k2], o[t][dt]);
             }
         }
         }   // kt <= wave_last
@@ -466,4 +464,4 @@ int flash_shared_prefix(const half_bits *q, int64_t ldq, const half_bits *k_cach
     return 0;
 }
 
-}}  // namespace nvr::k
+}}  // namespace nvr::k / nvr::kb (NVR_DT_NS)

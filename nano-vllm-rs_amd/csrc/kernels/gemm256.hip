@@ -30,7 +30,7 @@
 #include "device_utils.h"
 #include "../common.h"
 
-namespace nvr { namespace k {
+namespace nvr { namespace NVR_DT_NS {
 
 enum { GEPI_F16 = 0, GEPI_RESID = 1, GEPI_SILU = 2, GEPI_ROPE = 3 };   // RESID: y is the residual stream: y <- fp16(y + fp16(x·Wᵀ)) (qwen3.rs:382,389)
 
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const half_t *__restrict__
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    c[i][hB][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][ks], bf[j][ks], c[i][hB][j], 0, 0, 0);
+                    c[i][hB][j] = mfma16(af[i][ks], bf[j][ks], c[i][hB][j]);
     };
 
     // The two wave groups (waves 0-3 and 4-7: one wave of each per SIMD) run ONE barrier interval apart, and a phase is
@@ -520,4 +520,4 @@ extern "C" __attribute__((visibility("default"))) int nvr_debug_g256_stamps(unsi
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g256_dbg), sizeof(g256_dbg));
 }
 #endif
-}}  // namespace nvr::k
+}}  // namespace nvr::k / nvr::kb (NVR_DT_NS)

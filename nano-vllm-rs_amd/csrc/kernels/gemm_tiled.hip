@@ -20,7 +20,7 @@
 #include "device_utils.h"
 #include "../common.h"
 
-namespace nvr { namespace k {
+namespace nvr { namespace NVR_DT_NS {
 
 enum { TEPI_F16 = 0, TEPI_SILU = 2, TEPI_ROPE = 3, TEPI_LMHEAD = 4, TEPI_SLAB = 5 };
 
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(const half_t *__restric
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < MT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = mfma16(a[i], b[j], acc[i][j]);
         }
         if (NS == 2) __syncthreads();
     }
@@ -397,4 +397,4 @@ int gemm_tiled_qkv_rope_store(const half_bits *x, int64_t ldx, const half_bits *
     return tiled_check("gemm_tiled_qkv_rope_store");
 }
 
-}}  // namespace nvr::k
+}}  // namespace nvr::k / nvr::kb (NVR_DT_NS)

@@ -27,7 +27,7 @@
 #include "device_utils.h"
 #include "../common.h"
 
-namespace nvr { namespace k {
+namespace nvr { namespace NVR_DT_NS {
 
 enum { EPI_F16 = 0, EPI_F32 = 1, EPI_SILU = 2, EPI_ROPE = 3, EPI_SLAB = 4 };
 
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(WAVES * 64) void linear_skinny_kernel(const half_t 
             for (int i = 0; i < NT; ++i)
 #pragma unroll
                 for (int j = 0; j < MT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[u][i], b[u][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = mfma16(a[u][i], b[u][j], acc[i][j]);
     }
 
     // cross-wave (split-k) reduction through LDS: part[wave][tile][lane] as float4
@@ -390,4 +390,4 @@ int linear_qkv_rope_store(const half_bits *x, int64_t ldx, const half_bits *W, i
     return launch_check("linear_qkv_rope_store");
 }
 
-}}  // namespace nvr::k
+}}  // namespace nvr::k / nvr::kb (NVR_DT_NS)

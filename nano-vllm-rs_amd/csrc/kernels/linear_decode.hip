@@ -27,7 +27,7 @@
 #include "device_utils.h"
 #include "../common.h"
 
-namespace nvr { namespace k {
+namespace nvr { namespace NVR_DT_NS {
 
 enum { DEPI_SILU = 0, DEPI_ROPE = 1, DEPI_RESID = 2 };
 
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(WAVES * 64) void decode_linear_kernel(const half_t 
         for (int i = 0; i < NT; ++i)
 #pragma unroll
             for (int j = 0; j < MT; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[u][i], b[u][j], acc[i][j], 0, 0, 0);
+                acc[i][j] = mfma16(a[u][i], b[u][j], acc[i][j]);
 
     // cross-wave reduction through LDS (wave order)
 #pragma unroll
@@ -455,4 +455,4 @@ int linear_qkv_rope_store_normed(const half_bits *h, int64_t ldx, const half_bit
     return dec_launch_check("linear_qkv_rope_store_normed");
 }
 
-}}  // namespace nvr::k
+}}  // namespace nvr::k / nvr::kb (NVR_DT_NS)

@@ -18,7 +18,7 @@
 #include "device_utils.h"
 #include "../common.h"
 
-namespace nvr { namespace k {
+namespace nvr { namespace NVR_DT_NS {
 
 enum { SEPI_F16 = 0, SEPI_SILU = 2, SEPI_ROPE = 3 };
 
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(WAVES * 64) void linear_stream_kernel(const half_t 
                             const half8_t b = *reinterpret_cast<const half8_t *>(smem + ((int64_t)row * cpr + (ch ^ (r & 7))) * 16);
 #pragma unroll
                             for (int nt = 0; nt < NTT; ++nt)
-                                acc[i][nt][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[u][nt], b, acc[i][nt][j], 0, 0, 0);
+                                acc[i][nt][j] = mfma16(a[u][nt], b, acc[i][nt][j]);
                         }
                     }
                 }
@@ -264,4 +264,4 @@ int linear_stream_qkv_rope_store(const half_bits *x, int64_t ldx, const half_bit
     return stream_launch<1, 2, 4, SEPI_ROPE>((const half_t *)x, ldx, (const half_t *)W, (int)T, (int)K, N, N / 16, (half_t *)qkv, e, s);
 }
 
-}}  // namespace nvr::k
+}}  // namespace nvr::k / nvr::kb (NVR_DT_NS)

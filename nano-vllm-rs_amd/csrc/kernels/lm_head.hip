@@ -20,7 +20,7 @@
 #include <cstdio>
 #include <cstdlib>
 
-namespace nvr { namespace k {
+namespace nvr { namespace NVR_DT_NS {
 
 __device__ __forceinline__ void take_better(float &bv, int &bi, float v, int i) {
     if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(WAVES * 64) void lm_head_kernel(const half_t *__res
                 for (int j = 0; j < MT; ++j) {
                     const int row = j * 16 + r;
                     const half8_t b = *reinterpret_cast<const half8_t *>(smem + ((int64_t)row * cpr + (ch ^ (r & 7))) * 16);
-                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[u], b, acc[j], 0, 0, 0);
+                    acc[j] = mfma16(a[u], b, acc[j]);
                 }
             }
         }
@@ -248,4 +248,4 @@ int argmax_partials(const float *part_val, const int32_t *part_idx, int32_t npar
     return 0;
 }
 
-}}  // namespace nvr::k
+}}  // namespace nvr::k / nvr::kb (NVR_DT_NS)

@@ -20,7 +20,7 @@
 #include "device_utils.h"
 #include "../common.h"
 
-namespace nvr { namespace k {
+namespace nvr { namespace NVR_DT_NS {
 
 namespace {
 
@@ -594,4 +594,4 @@ int sample(const float *logits, int64_t B, int64_t V, const float *temperature, 
     return 0;
 }
 
-}}  // namespace nvr::k
+}}  // namespace nvr::k / nvr::kb (NVR_DT_NS)

@@ -13,6 +13,9 @@
 #include "kernels/device_utils.h"
 
 namespace k = nvr::k;
+// dtype dispatch: the kernels exist twice (fp16 in nvr::k, bfloat16 in nvr::kb: kernels/device_utils.h); `bf16` is the runner's
+// Config.dtype == "bfloat16" (reference src/config.rs:51,113-116).  Argument structs and constants are shared (nvr::kt via nvr::k).
+#define KD(call) (bf16 ? nvr::kb::call : nvr::k::call)
 
 // tensor ids of the synthetic weight generator (twin of oracle/model_oracle.py)
 enum { TID_QKV = 0, TID_O = 1, TID_GATE_UP = 2, TID_DOWN = 3 };
@@ -55,6 +58,8 @@ nvr_model_runner::~nvr_model_runner() {
 int nvr_model_runner::init() {                                       // ModelRunner::new, :67-102
     env = nvr::Env::read();                                          // the only place the runner looks at the environment
     tp = (int64_t)cfg.tensor_parallel_size; rank = (int64_t)cfg.tensor_parallel_rank;
+    bf16 = std::strcmp(cfg.dtype, "bfloat16") == 0;                               // config.rs:51 (fp16 otherwise; "float32" is refused earlier)
+    comm.bf16 = bf16;                                                              // the collectives round their sums to the same 16-bit type
     if (tp < 1 || rank >= tp) return nvr::fail(NVR_ERR_INVALID_ARG, "bad tensor parallel rank %ld of %ld", (long)rank, (long)tp);
     RC(nvr_model_config_validate(&mc, (uint64_t)tp));
     Hd = mc.hidden_size; L = mc.num_hidden_layers; V = mc.vocab_size;
@@ -104,8 +109,8 @@ int nvr_model_runner::init() {                                       // ModelRun
     allow_missing_comm = env.tp_no_comm;                                               // compute-only profiling of one rank
     if (!env.tp_graph && tp > 1) graphs_disabled = true;
     comm.force = env.tp_force_comm; comm.timeout_ms = env.p2p_timeout_ms;
-    RC(k::linear_stream_prepare());
-    RC(k::gemm_tiled_prepare());
+    RC(KD(linear_stream_prepare()));
+    RC(KD(gemm_tiled_prepare()));
     lazy_logits = env.lazy_logits;
     {   // arg-max partials [parts][rows]: <= LM_HEAD_MAX_PARTS x 32 rows (lm_head_kernel), or one per 128 vocabulary columns x all rows
         const size_t pe = std::max<size_t>((size_t)k::LM_HEAD_MAX_PARTS * 32, (size_t)((Vl + 127) / 128) * (size_t)max_seqs);
@@ -113,7 +118,7 @@ int nvr_model_runner::init() {                                       // ModelRun
     }
     // the hipGraph decode path launches attention with max_ctx = the 256-token context bucket, which can exceed max_pos:
     // the split-KV workspace is sized for the largest bucket (launch_attn checks the bytes it is given)
-    attn_ws_bytes = k::attn_workspace_bytes(max_seqs, H, D, (max_pos + 255) / 256 * 256);
+    attn_ws_bytes = KD(attn_workspace_bytes(max_seqs, H, D, (max_pos + 255) / 256 * 256));
     NVR_HIP_CHECK(hipMalloc(&attn_ws, attn_ws_bytes));
     // step-input arena
     auto carve = [&](size_t &off, size_t bytes) { off = in_bytes; in_bytes += (bytes + 255) / 256 * 256; };
@@ -152,7 +157,7 @@ int nvr_model_runner::init() {                                       // ModelRun
     }
     RC(dmalloc(&d_temp, max_seqs)); RC(dmalloc(&d_topk, max_seqs)); RC(dmalloc(&d_topp, max_seqs)); RC(dmalloc(&d_keys, max_seqs));
     NVR_HIP_CHECK(hipHostMalloc((void **)&samp_host, max_seqs * 24, hipHostMallocDefault));
-    NVR_HIP_CHECK(hipMalloc(&sample_ws, k::sample_workspace_bytes(max_seqs, Vl)));
+    NVR_HIP_CHECK(hipMalloc(&sample_ws, KD(sample_workspace_bytes(max_seqs, Vl))));
     RC(dmalloc(&d_gather_val, tp * max_seqs)); RC(dmalloc(&d_gather_idx, tp * max_seqs));   // (max, argmax) pairs of every rank
     if (tp > 1) { RC(dmalloc(&d_rec, max_seqs)); RC(dmalloc(&d_gather_rec, tp * max_seqs)); }
 
@@ -184,12 +189,12 @@ int nvr_model_runner::retile_all() {
     const bool gemm_ok = Hd % 32 == 0 && (H * D) % 32 == 0 && I % 32 == 0 && QKV % 16 == 0 && Hd % 16 == 0 && I % 16 == 0 && D % 16 == 0;
     for (auto &w : layers) {
         if (!gemm_ok || !w.qkv_t) continue;
-        RC(k::retile_weight(w.qkv, w.qkv_t, QKV, Hd, mc.qk_norm ? 0 : 1, H, KVH, D, stream));   // qk_norm: plain GEMM, rows in place
-        RC(k::retile_weight(w.o, w.o_t, Hd, H * D, 0, 0, 0, 0, stream));
-        RC(k::retile_weight(w.gate_up, w.gate_up_t, 2 * I, Hd, 0, 0, 0, 0, stream));
-        RC(k::retile_weight(w.down, w.down_t, Hd, I, 0, 0, 0, 0, stream));
+        RC(KD(retile_weight(w.qkv, w.qkv_t, QKV, Hd, mc.qk_norm ? 0 : 1, H, KVH, D, stream)));   // qk_norm: plain GEMM, rows in place
+        RC(KD(retile_weight(w.o, w.o_t, Hd, H * D, 0, 0, 0, 0, stream)));
+        RC(KD(retile_weight(w.gate_up, w.gate_up_t, 2 * I, Hd, 0, 0, 0, 0, stream)));
+        RC(KD(retile_weight(w.down, w.down_t, Hd, I, 0, 0, 0, 0, stream)));
     }
-    if (lm_head_t) RC(k::retile_weight(lm_head, lm_head_t, Vl, Hd, 0, 0, 0, 0, stream));
+    if (lm_head_t) RC(KD(retile_weight(lm_head, lm_head_t, Vl, Hd, 0, 0, 0, 0, stream)));
     NVR_HIP_CHECK(hipStreamSynchronize(stream));
     return NVR_OK;
 }
@@ -208,32 +213,32 @@ int nvr_model_runner::gen_weights() {
         w.qkv_t = w.o_t = w.gate_up_t = w.down_t = w.q_norm = w.k_norm = nullptr;
         if (mc.qk_norm) {
             RC(dmalloc(&w.q_norm, D)); RC(dmalloc(&w.k_norm, D));
-            RC(k::fill_const(w.q_norm, D, 1.0f, stream)); RC(k::fill_const(w.k_norm, D, 1.0f, stream));
+            RC(KD(fill_const(w.q_norm, D, 1.0f, stream))); RC(KD(fill_const(w.k_norm, D, 1.0f, stream)));
         }
         if (tiled_weights) {
             RC(dmalloc(&w.qkv_t, QKV * Hd)); RC(dmalloc(&w.o_t, Hd * H * D)); RC(dmalloc(&w.gate_up_t, 2 * I * Hd)); RC(dmalloc(&w.down_t, Hd * I));
         }
         // QKVParallelLinear, linear.rs:300-340: global rows [q heads | k heads | v heads], per-rank head slices
-        RC(k::fill_weight(w.qkv, H * D, Hd, Hd, Hd, rank * H * D, 0, key(TID_QKV), sc, stream));
-        RC(k::fill_weight(w.qkv + H * D * Hd, KVH * D, Hd, Hd, Hd, Hg * D + rank * KVH * D, 0, key(TID_QKV), sc, stream));
-        RC(k::fill_weight(w.qkv + (H + KVH) * D * Hd, KVH * D, Hd, Hd, Hd, (Hg + KVHg) * D + rank * KVH * D, 0, key(TID_QKV), sc, stream));
+        RC(KD(fill_weight(w.qkv, H * D, Hd, Hd, Hd, rank * H * D, 0, key(TID_QKV), sc, stream)));
+        RC(KD(fill_weight(w.qkv + H * D * Hd, KVH * D, Hd, Hd, Hd, Hg * D + rank * KVH * D, 0, key(TID_QKV), sc, stream)));
+        RC(KD(fill_weight(w.qkv + (H + KVH) * D * Hd, KVH * D, Hd, Hd, Hd, (Hg + KVHg) * D + rank * KVH * D, 0, key(TID_QKV), sc, stream)));
         // RowParallelLinear o_proj, linear.rs:180-268: global [Hd, H*D], input columns sharded
-        RC(k::fill_weight(w.o, Hd, H * D, H * D, Hg * D, 0, rank * H * D, key(TID_O), sc, stream));
+        RC(KD(fill_weight(w.o, Hd, H * D, H * D, Hg * D, 0, rank * H * D, key(TID_O), sc, stream)));
         // MergedColumnParallelLinear, linear.rs:378-454: global rows [gate | up], each sharded
-        RC(k::fill_weight(w.gate_up, I, Hd, Hd, Hd, rank * I, 0, key(TID_GATE_UP), sc, stream));
-        RC(k::fill_weight(w.gate_up + I * Hd, I, Hd, Hd, Hd, Ig + rank * I, 0, key(TID_GATE_UP), sc, stream));
-        RC(k::fill_weight(w.down, Hd, I, I, Ig, 0, rank * I, key(TID_DOWN), sc, stream));
-        RC(k::fill_const(w.ln1, Hd, 1.0f, stream)); RC(k::fill_const(w.ln2, Hd, 1.0f, stream));   // layernorm.rs:29
+        RC(KD(fill_weight(w.gate_up, I, Hd, Hd, Hd, rank * I, 0, key(TID_GATE_UP), sc, stream)));
+        RC(KD(fill_weight(w.gate_up + I * Hd, I, Hd, Hd, Hd, Ig + rank * I, 0, key(TID_GATE_UP), sc, stream)));
+        RC(KD(fill_weight(w.down, Hd, I, I, Ig, 0, rank * I, key(TID_DOWN), sc, stream)));
+        RC(KD(fill_const(w.ln1, Hd, 1.0f, stream))); RC(KD(fill_const(w.ln2, Hd, 1.0f, stream)));   // layernorm.rs:29
     }
     // embedding replicated (SURVEY §8e skips C2); LM head vocab-sharded, tied when tie_word_embeddings (qwen3.rs:461-473)
     RC(dmalloc(&embed, V * Hd));
-    RC(k::fill_weight(embed, V, Hd, Hd, Hd, 0, 0, nvr_weight_key_impl(mc.seed, TID_EMBED), sc, stream));
+    RC(KD(fill_weight(embed, V, Hd, Hd, Hd, 0, 0, nvr_weight_key_impl(mc.seed, TID_EMBED), sc, stream)));
     if (mc.tie_word_embeddings) lm_head = embed + vocab_start * Hd;
     else {
         RC(dmalloc(&lm_head, Vl * Hd));
-        RC(k::fill_weight(lm_head, Vl, Hd, Hd, Hd, vocab_start, 0, nvr_weight_key_impl(mc.seed, TID_LM_HEAD), sc, stream));
+        RC(KD(fill_weight(lm_head, Vl, Hd, Hd, Hd, vocab_start, 0, nvr_weight_key_impl(mc.seed, TID_LM_HEAD), sc, stream)));
     }
-    RC(dmalloc(&norm, Hd)); RC(k::fill_const(norm, Hd, 1.0f, stream));
+    RC(dmalloc(&norm, Hd)); RC(KD(fill_const(norm, Hd, 1.0f, stream)));
     if (tiled_weights && Vl % 16 == 0) RC(dmalloc(&lm_head_t, Vl * Hd));
     NVR_HIP_CHECK(hipStreamSynchronize(stream));
     return retile_all();
@@ -248,7 +253,13 @@ int nvr_model_runner::gen_weights() {
 // ([gate | up] rows), o_proj / down_proj (input columns) and the vocabulary shard of the LM head.
 namespace {
 inline uint16_t f32_to_f16_bits(float f) { _Float16 h = (_Float16)f; uint16_t b; std::memcpy(&b, &h, 2); return b; }
+inline float f16_bits_to_f32(uint16_t b) { _Float16 h; std::memcpy(&h, &b, 2); return (float)h; }
 inline float bf16_bits_to_f32(uint16_t b) { uint32_t u = (uint32_t)b << 16; float f; std::memcpy(&f, &u, 4); return f; }
+inline uint16_t f32_to_bf16_bits(float f) {                                       // round to nearest even; NaN stays NaN
+    uint32_t u; std::memcpy(&u, &f, 4);
+    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)((u >> 16) | 0x40);
+    return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
 bool match_layer(const char *name, const char *suffix, int64_t *layer) {          // "layers.<l>.<suffix>"
     if (std::strncmp(name, "layers.", 7) != 0) return false;
     char *end = nullptr;
@@ -280,10 +291,13 @@ int nvr_model_runner::load_tensor(const char *name_in, int dtype, const int64_t 
         for (int64_t r = 0; r < nr; ++r)
             for (int64_t c = 0; c < nc; ++c) {
                 const size_t si = (size_t)((r0 + r) * Cc + c0 + c);
-                uint16_t b;
-                if (dtype == 0) b = ((const uint16_t *)data)[si];
-                else if (dtype == 1) b = f32_to_f16_bits(bf16_bits_to_f32(((const uint16_t *)data)[si]));
-                else b = f32_to_f16_bits(((const float *)data)[si]);
+                uint16_t b;                                               // the checkpoint value in the runner's 16-bit type
+                if (dtype == (bf16 ? 1 : 0)) b = ((const uint16_t *)data)[si];
+                else {
+                    const float f = dtype == 0 ? f16_bits_to_f32(((const uint16_t *)data)[si])
+                                  : dtype == 1 ? bf16_bits_to_f32(((const uint16_t *)data)[si]) : ((const float *)data)[si];
+                    b = bf16 ? f32_to_bf16_bits(f) : f32_to_f16_bits(f);
+                }
                 st[(size_t)(r * nc + c)] = b;
             }
         NVR_HIP_CHECK(hipStreamSynchronize(stream));
@@ -358,27 +372,27 @@ int nvr_model_runner::copy_weight(const char *ln, uint16_t *out, size_t cap, int
 // writes fp16 `proj` (+ all-reduce when tensor parallel) and add_rmsnorm follows.
 int nvr_model_runner::row_parallel_norm(const uint16_t *x, int64_t K, const uint16_t *W, const uint16_t *Wt, int64_t T, const uint16_t *wn) {
     int64_t S = 1;
-    if (!comm.active() && tp == 1 && T <= 64 && T <= k::stream_row_limit() && Hd <= 2048) {
-        S = k::decode_splitk_slices(T, K, Hd);
+    if (!comm.active() && tp == 1 && T <= 64 && T <= KD(stream_row_limit()) && Hd <= 2048) {
+        S = KD(decode_splitk_slices(T, K, Hd));
     } else if (!comm.active() && tp == 1 && T <= 32 && Hd <= 8192 && Hd % 64 == 0 && Hd * K * 2 >= (24ll << 20) && K % 128 == 0) {
         S = 4;                                       // large weights: 64-column workgroups x 4 k-slices (linear_splitk)
-    } else if (!comm.active() && tp == 1 && T > k::stream_row_limit() && T <= slab_rows && Hd <= 8192 && ((Hd + 127) / 128) * ((T + 127) / 128) <= 64 &&
-               k::gemm_tiled_splitk_ok(T, K, Hd, 4, K)) {
+    } else if (!comm.active() && tp == 1 && T > KD(stream_row_limit()) && T <= slab_rows && Hd <= 8192 && ((Hd + 127) / 128) * ((T + 127) / 128) <= 64 &&
+               KD(gemm_tiled_splitk_ok(T, K, Hd, 4, K))) {
         S = 4;                                       // 97..1024 rows, few 128x128 tiles: k-split of the tiled kernel (gemm_tiled_splitk;
                                                      // bs = 256 / 512 decode 4.04 -> 3.67 / 6.18 -> 5.33 ms in r01; with the 32- / 64-token
                                                      // tiles of r02 it also wins from 97 rows on: same boundary as prefer_stream, linear.hip)
     }
     if (S > 1) {
-        RC(k::linear_splitk(x, K, W, T, K, Hd, S, slabs, stream, Wt));
-        return k::add_rmsnorm_slabs(h, slabs, S, wn, mc.rms_norm_eps, T, Hd, n, stream);
+        RC(KD(linear_splitk(x, K, W, T, K, Hd, S, slabs, stream, Wt)));
+        return KD(add_rmsnorm_slabs(h, slabs, S, wn, mc.rms_norm_eps, T, Hd, n, stream));
     }
-    if (!comm.active() && tp == 1 && k::gemm256_preferred(T, K, Hd, K)) {
+    if (!comm.active() && tp == 1 && KD(gemm256_preferred(T, K, Hd, K))) {
         // prefill-sized steps on one rank: the residual add rides in the 256x256 GEMM's epilogue (h <- fp16(h + fp16(x W^T)), the same
         // rounding points), and the norm reads one tensor instead of h and the projection (r02: 41.6 -> ~21 us per norm at 32 x 1024)
-        RC(k::gemm256_resid(x, K, W, T, K, Hd, h, stream));
-        return k::rmsnorm(h, wn, mc.rms_norm_eps, T, Hd, n, stream);
+        RC(KD(gemm256_resid(x, K, W, T, K, Hd, h, stream)));
+        return KD(rmsnorm(h, wn, mc.rms_norm_eps, T, Hd, n, stream));
     }
-    RC(k::linear(x, K, W, T, K, Hd, proj, false, stream, Wt));
+    RC(KD(linear(x, K, W, T, K, Hd, proj, false, stream, Wt)));
     // linear.rs:236-238 (all-reduce) + qwen3.rs:382-389 (residual, norm): one launch over the peer-mapped arenas when the
     // message fits a slot (decode-sized steps), else the communicator's all-reduce followed by add+RMSNorm
     // (T <= 64: the fused kernel reduces a row's squares exactly like the decode-sized add+RMSNorm kernel, so fused and unfused
@@ -386,14 +400,14 @@ int nvr_model_runner::row_parallel_norm(const uint16_t *x, int64_t K, const uint
     if (comm.active() && T <= 64 && comm.p2p_usable((size_t)(T * Hd)))
         return comm.all_reduce_add_rmsnorm(proj, h, wn, mc.rms_norm_eps, (int)T, (int)Hd, n, stream);
     if (comm.active()) RC(comm.all_reduce_sum_f16(proj, (size_t)(T * Hd), stream));
-    return k::add_rmsnorm(h, proj, wn, mc.rms_norm_eps, T, Hd, n, stream);
+    return KD(add_rmsnorm(h, proj, wn, mc.rms_norm_eps, T, Hd, n, stream));
 }
 
 // The four-launch decode chain (kernels/linear_decode.hip) runs single-rank decode-sized steps of models whose hidden rows fit
 // the norm-prologue kernels; everything else (prefill, tensor-parallel ranks with their all-reduce between GEMM and residual,
 // Qwen3-8B-class weights with their streaming kernels) keeps the six-launch chain.
 bool nvr_model_runner::use_chain4(int64_t T, bool is_prefill) const {
-    return chain4 && !mc.qk_norm && !is_prefill && tp == 1 && !comm.active() && k::decode_chain_ok(T, Hd, QKV, I, D) &&
+    return chain4 && !mc.qk_norm && !is_prefill && tp == 1 && !comm.active() && KD(decode_chain_ok(T, Hd, QKV, I, D)) &&
            H * D <= 4096 && I <= 8192 && Hd * std::max(H * D, I) * 2 < (24ll << 20);
 }
 
@@ -408,7 +422,7 @@ int64_t nvr_model_runner::shared_prefix_plan(nvr_seq *const *seqs, size_t nseq, 
     *members = 0;
     const int64_t min_seqs = cfg.shared_prefix_min_seqs == 0 ? 32 : cfg.shared_prefix_min_seqs;
     if (min_seqs < 0 || (int64_t)nseq < min_seqs || nseq < 2) return 0;
-    if (block_size < 64 || (block_size & (block_size - 1)) || !k::flash_prefill_ok((int)D, (int)H, (int)KVH)) return 0;
+    if (block_size < 64 || (block_size & (block_size - 1)) || !KD(flash_prefill_ok((int)D, (int)H, (int)KVH))) return 0;
     auto full_blocks = [&](const nvr_seq &s) {                            // full blocks below the token of this step
         return std::min<size_t>(s.block_table.size(), (size_t)(((int64_t)s.len() - 1) / block_size));
     };
@@ -470,22 +484,22 @@ int nvr_model_runner::forward(int64_t T, int64_t B, bool is_prefill, int64_t max
     const int32_t *bt = dd_bt;
     const bool c4 = use_chain4(T, is_prefill);
     const bool tl = tiled_weights && T <= 64;                            // decode-sized steps stream the tiled weight copies
-    const bool embed_norm = !c4 && L > 0 && k::embedding_rmsnorm_ok(T, Hd);                    // decode-sized: K1 + the first norm in one launch
-    if (embed_norm) RC(k::embedding_rmsnorm(ids, T, embed, layers[0].ln1, mc.rms_norm_eps, Hd, h, n, st));
-    else RC(k::embedding(ids, T, embed, Hd, h, st));
+    const bool embed_norm = !c4 && L > 0 && KD(embedding_rmsnorm_ok(T, Hd));                    // decode-sized: K1 + the first norm in one launch
+    if (embed_norm) RC(KD(embedding_rmsnorm(ids, T, embed, layers[0].ln1, mc.rms_norm_eps, Hd, h, n, st)));
+    else RC(KD(embedding(ids, T, embed, Hd, h, st)));
     for (int64_t l = 0; l < L; ++l) {
         const Layer &w = layers[l];
         if (c4) {                                    // input norm :378 in the prologue of the qkv GEMM (K2..K6 in one launch)
-            RC(k::linear_qkv_rope_store_normed(h, Hd, w.ln1, mc.rms_norm_eps, w.qkv, T, Hd, H, KVH, D, pos, slots, cos_t, sin_t, qkv,
-                                               k_cache(l), v_cache(l), st, tl ? w.qkv_t : nullptr));
+            RC(KD(linear_qkv_rope_store_normed(h, Hd, w.ln1, mc.rms_norm_eps, w.qkv, T, Hd, H, KVH, D, pos, slots, cos_t, sin_t, qkv,
+                                               k_cache(l), v_cache(l), st, tl ? w.qkv_t : nullptr)));
         } else {
-            if (l == 0 && !embed_norm) RC(k::rmsnorm(h, w.ln1, mc.rms_norm_eps, T, Hd, n, st));   // later layers: see down_proj
+            if (l == 0 && !embed_norm) RC(KD(rmsnorm(h, w.ln1, mc.rms_norm_eps, T, Hd, n, st)));   // later layers: see down_proj
             if (mc.qk_norm) {                        // A-27: the head norms sit between the projection and RoPE: plain GEMM, then one
-                RC(k::linear(n, Hd, w.qkv, T, Hd, QKV, qkv, false, st, tl ? w.qkv_t : nullptr));      // norm + RoPE + KV-store launch
-                RC(k::rope_store_kv(qkv, pos, slots, T, H, KVH, D, cos_t, sin_t, k_cache(l), v_cache(l), st, w.q_norm, w.k_norm, mc.rms_norm_eps));
+                RC(KD(linear(n, Hd, w.qkv, T, Hd, QKV, qkv, false, st, tl ? w.qkv_t : nullptr)));      // norm + RoPE + KV-store launch
+                RC(KD(rope_store_kv(qkv, pos, slots, T, H, KVH, D, cos_t, sin_t, k_cache(l), v_cache(l), st, w.q_norm, w.k_norm, mc.rms_norm_eps)));
             } else {
                 // qkv GEMM with the RoPE + KV-store epilogue (K3..K6 in one launch)
-                RC(k::linear_qkv_rope_store(n, Hd, w.qkv, T, Hd, H, KVH, D, pos, slots, cos_t, sin_t, qkv, k_cache(l), v_cache(l), st, tl ? w.qkv_t : nullptr));
+                RC(KD(linear_qkv_rope_store(n, Hd, w.qkv, T, Hd, H, KVH, D, pos, slots, cos_t, sin_t, qkv, k_cache(l), v_cache(l), st, tl ? w.qkv_t : nullptr)));
             }
         }
         k::AttnArgs a{};
@@ -500,10 +514,10 @@ int nvr_model_runner::forward(int64_t T, int64_t B, bool is_prefill, int64_t max
             } else { f.k = qkv + H * D; f.v = qkv + (H + KVH) * D; f.ldkv = QKV; }
             f.tiles = (const k::FlashTile *)(in_dev + off_tiles); f.ntiles = (int32_t)n_tiles;
             f.H = (int32_t)H; f.KVH = (int32_t)KVH; f.D = (int32_t)D; f.scale = scale; f.out = attn;
-            RC(k::flash_prefill(f, prefill_paged, st));
+            RC(KD(flash_prefill(f, prefill_paged, st)));
         } else if (is_prefill) {                                     // head shapes outside the MFMA kernel: row kernel
             a.k = qkv + H * D; a.v = qkv + (H + KVH) * D; a.ldkv = QKV; a.kv_base = d_kvbase; a.workspace = nullptr;
-            RC(k::attention(a, false, st));
+            RC(KD(attention(a, false, st)));
         } else {                                                     // flash_attention_decode, attention.rs:225-235
             a.k = k_cache(l); a.v = v_cache(l); a.block_tables = bt; a.max_blocks = (int32_t)max_blocks_per_seq;
             a.block_size = (int32_t)block_size; a.workspace = attn_ws; a.workspace_bytes = attn_ws_bytes;
@@ -512,30 +526,30 @@ int nvr_model_runner::forward(int64_t T, int64_t B, bool is_prefill, int64_t max
                 a.shared_kv0 = (const int32_t *)(in_dev + off_dec + dof_skv0); a.shared_rows = (const int32_t *)(in_dev + off_dec + dof_srows);
                 a.shared_count = (const int32_t *)(in_dev + off_dec + dof_scount);
             }
-            RC(k::attention(a, true, st));
+            RC(KD(attention(a, true, st)));
         }
         if (c4) {
             // o_proj + residual :382 (the split-k reduction's last arriver adds h); post-attention norm :385 in the prologue of
             // gate_up + SiluAndMul; down_proj + residual :389.  The next layer's input norm is the next qkv launch's prologue.
-            RC(k::linear_resid(attn, H * D, w.o, T, H * D, Hd, k::decode_splitk_slices(T, H * D, Hd), slabs, chain_cnt, h, st, tl ? w.o_t : nullptr));
-            RC(k::linear_silu_mul_normed(h, Hd, w.ln2, mc.rms_norm_eps, w.gate_up, T, Hd, I, act, st, tl ? w.gate_up_t : nullptr));
-            RC(k::linear_resid(act, I, w.down, T, I, Hd, k::decode_splitk_slices(T, I, Hd), slabs, chain_cnt, h, st, tl ? w.down_t : nullptr));
+            RC(KD(linear_resid(attn, H * D, w.o, T, H * D, Hd, k::decode_splitk_slices(T, H * D, Hd), slabs, chain_cnt, h, st, tl ? w.o_t : nullptr)));
+            RC(KD(linear_silu_mul_normed(h, Hd, w.ln2, mc.rms_norm_eps, w.gate_up, T, Hd, I, act, st, tl ? w.gate_up_t : nullptr)));
+            RC(KD(linear_resid(act, I, w.down, T, I, Hd, k::decode_splitk_slices(T, I, Hd), slabs, chain_cnt, h, st, tl ? w.down_t : nullptr)));
         } else {
             RC(row_parallel_norm(attn, H * D, w.o, tl ? w.o_t : nullptr, T, w.ln2));         // o_proj, residual :382, norm :385
-            RC(k::linear_silu_mul(n, Hd, w.gate_up, T, Hd, I, act, st, tl ? w.gate_up_t : nullptr));   // K12 + K13 in one launch
+            RC(KD(linear_silu_mul(n, Hd, w.gate_up, T, Hd, I, act, st, tl ? w.gate_up_t : nullptr)));   // K12 + K13 in one launch
             // down_proj, residual :389 and the NEXT layer's input norm :378 (or the final norm :501)
             RC(row_parallel_norm(act, I, w.down, tl ? w.down_t : nullptr, T, l + 1 < L ? layers[l + 1].ln1 : norm));
         }
     }
-    if (c4 || L == 0) RC(k::rmsnorm(h, norm, mc.rms_norm_eps, T, Hd, n, st));                  // final norm :501
+    if (c4 || L == 0) RC(KD(rmsnorm(h, norm, mc.rms_norm_eps, T, Hd, n, st)));                  // final norm :501
     const uint16_t *hl = n;
-    if (is_prefill) { RC(k::select_last_tokens(n, d_cu, B, Hd, nlast, st)); hl = nlast; }      // embed_head.rs:272-289
+    if (is_prefill) { RC(KD(select_last_tokens(n, d_cu, B, Hd, nlast, st))); hl = nlast; }      // embed_head.rs:272-289
     if (lm_parts > 0) {                                                                        // f32 logits (A-21) + arg-max partials
         int32_t np = 0;
-        RC(k::lm_head(hl, Hd, lm_head, B, Hd, Vl, logits, d_lm_pval, d_lm_pidx, &np, st, want_logits, (tiled_weights && B <= 32) ? lm_head_t : nullptr));
+        RC(KD(lm_head(hl, Hd, lm_head, B, Hd, Vl, logits, d_lm_pval, d_lm_pidx, &np, st, want_logits, (tiled_weights && B <= 32) ? lm_head_t : nullptr)));
         if (np != lm_parts) return nvr::fail(NVR_ERR_INVARIANT, "lm_head produced %d partials, planned %d", np, lm_parts);
     } else {
-        RC(k::linear(hl, Hd, lm_head, B, Hd, Vl, logits, true, st));
+        RC(KD(linear(hl, Hd, lm_head, B, Hd, Vl, logits, true, st)));
     }
     return NVR_OK;
 }
@@ -567,7 +581,7 @@ int nvr_model_runner::execute(nvr_seq *const *seqs, size_t nseq, bool is_prefill
         // (K8, attention.rs:211-222).  At least the last token is always computed (its logits are the step's output).
         // With enable_chunked_prefill (A-23) a sequence contributes the token range [chunk_start, chunk_start + chunk_len) the
         // scheduler gave it; earlier tokens are reached through the block table exactly like a cached prefix.
-        const bool flash_ok = k::flash_prefill_ok((int)D, (int)H, (int)KVH);
+        const bool flash_ok = KD(flash_prefill_ok((int)D, (int)H, (int)KVH));
         const bool chunked = cfg.enable_chunked_prefill != 0;
         auto range_of = [&](const nvr_seq &sq, int64_t *lo, int64_t *hi) {        // rows fed through the model for this sequence
             const int64_t len = (int64_t)sq.len();
@@ -588,7 +602,7 @@ int nvr_model_runner::execute(nvr_seq *const *seqs, size_t nseq, bool is_prefill
             total += hi - lo;
         }
         if (total > max_tokens) return nvr::fail(NVR_ERR_INVALID_ARG, "prefill of %ld tokens exceeds max_num_batched_tokens %ld", (long)total, (long)max_tokens);
-        const int qb = flash_ok ? k::flash_tile_positions((int)H, (int)KVH) : 1;
+        const int qb = flash_ok ? KD(flash_tile_positions((int)H, (int)KVH)) : 1;
         {   // the step's arrays back to back at the start of the arena (sized by THIS step's token count): one upload instead of seven
             size_t o = 0;
             auto sub = [&](size_t &f, size_t bytes) { f = o; o += (bytes + 63) / 64 * 64; };
@@ -691,7 +705,7 @@ int nvr_model_runner::execute(nvr_seq *const *seqs, size_t nseq, bool is_prefill
     last_rows = nseq; last_prefill = is_prefill; last_tokens = T;
     // arg-max partials come with the logits when the whole batch goes through one lm_head launch (a pure function of
     // the shapes, so a replayed graph and this bookkeeping always agree)
-    lm_parts = lm_fused ? k::lm_head_parts((int64_t)nseq, Hd, Vl, Hd) : 0;
+    lm_parts = lm_fused ? KD(lm_head_parts((int64_t)nseq, Hd, Vl, Hd)) : 0;
     // a batch that samples greedily everywhere takes its tokens from the arg-max partials: the f32 logits are then written
     // only on demand (ensure_logits: execute_model callers that ask for them, copy_logits)
     want_logits = !lazy_logits || lm_parts == 0;
@@ -763,7 +777,7 @@ int nvr_model_runner::execute_decode_ahead(nvr_seq *const *seqs, size_t nseq, in
                                            &decode_shared_rows);
     NVR_HIP_CHECK(hipMemcpyAsync(in_dev + off_dec + dof_pos, hd + dof_pos, dof_bt + nseq * max_blocks_per_seq * 4 - dof_pos, hipMemcpyHostToDevice, stream));
     last_rows = nseq; last_prefill = false; last_tokens = (int64_t)nseq;
-    lm_parts = k::lm_head_parts((int64_t)nseq, Hd, Vl, Hd);
+    lm_parts = KD(lm_head_parts((int64_t)nseq, Hd, Vl, Hd));
     if (lm_parts <= 0) return nvr::fail(NVR_ERR_UNSUPPORTED, "execute_decode_ahead: the fused LM head does not take this batch");
     want_logits = !lazy_logits; logits_valid = want_logits; lm_input = n;
     const int64_t T = (int64_t)nseq;
@@ -799,14 +813,14 @@ int nvr_model_runner::sample_launch(nvr_seq *const *seqs, size_t nseq, int parit
     ht[max_seqs] = 0;
     // greedy_sample, sampler.rs:109-112: token ids to the pinned host buffer (device-visible mapping) AND to the next decode
     // step's input ids on the device
-    if (tp == 1) return k::argmax_partials(d_lm_pval, d_lm_pidx, lm_parts, (int64_t)nseq, ahead_tok_dev[parity & 1], nullptr, 0, stream, dd_ids);
+    if (tp == 1) return KD(argmax_partials(d_lm_pval, d_lm_pidx, lm_parts, (int64_t)nseq, ahead_tok_dev[parity & 1], nullptr, 0, stream, dd_ids));
     // vocabulary shards (embed_head.rs:321-336): this rank's (max, global arg-max) records -> all-gather through the peer arenas ->
     // the same rank-ordered merge on every rank, all stream-ordered (no host round trip: the next step can be enqueued behind it)
     if (!ahead_ok(nseq)) return nvr::fail(NVR_ERR_UNSUPPORTED, "sample_launch: %zu rows do not fit the peer-to-peer all-gather", nseq);
-    RC(k::argmax_partials(d_lm_pval, d_lm_pidx, lm_parts, (int64_t)nseq, d_tok, d_maxval, vocab_start, stream, nullptr, d_rec));
+    RC(KD(argmax_partials(d_lm_pval, d_lm_pidx, lm_parts, (int64_t)nseq, d_tok, d_maxval, vocab_start, stream, nullptr, d_rec)));
     RC(comm.all_gather_bytes(d_rec, d_gather_rec, nseq * sizeof(k::TpArgmaxRec), stream));
-    return k::tp_argmax_merge(d_gather_rec, (int)tp, (int64_t)nseq, ahead_tok_dev[parity & 1], dd_ids, comm.p2p_words ? comm.p2p_words + 2 : nullptr,
-                              ahead_tok_dev[parity & 1] + max_seqs, stream);
+    return KD(tp_argmax_merge(d_gather_rec, (int)tp, (int64_t)nseq, ahead_tok_dev[parity & 1], dd_ids, comm.p2p_words ? comm.p2p_words + 2 : nullptr,
+                              ahead_tok_dev[parity & 1] + max_seqs, stream));
 }
 
 int nvr_model_runner::sample_wait(size_t nseq, int parity, int64_t *out) {
@@ -878,8 +892,8 @@ int nvr_model_runner::ensure_logits() {
     if (logits_valid) return NVR_OK;
     NVR_HIP_CHECK(hipSetDevice(device));
     int32_t np = 0;
-    RC(k::lm_head(lm_input, Hd, lm_head, (int64_t)last_rows, Hd, Vl, logits, d_lm_pval, d_lm_pidx, &np, stream, true,
-                  (tiled_weights && last_rows <= 32) ? lm_head_t : nullptr));
+    RC(KD(lm_head(lm_input, Hd, lm_head, (int64_t)last_rows, Hd, Vl, logits, d_lm_pval, d_lm_pidx, &np, stream, true,
+                  (tiled_weights && last_rows <= 32) ? lm_head_t : nullptr)));
     logits_valid = true;
     return NVR_OK;
 }
@@ -895,17 +909,17 @@ int nvr_model_runner::sample(nvr_seq *const *seqs, size_t nseq, int64_t *out) {
             if (lm_parts > 0 && h_tok_dev) {
                 // the merge kernel writes the token ids straight into the pinned host buffer (device-visible mapping): no
                 // device-to-host copy (a blit kernel of its own) between the last kernel of the step and the host's wake-up
-                RC(k::argmax_partials(d_lm_pval, d_lm_pidx, lm_parts, B, h_tok_dev, nullptr, 0, stream));
+                RC(KD(argmax_partials(d_lm_pval, d_lm_pidx, lm_parts, B, h_tok_dev, nullptr, 0, stream)));
                 NVR_HIP_CHECK(hipStreamSynchronize(stream));
                 std::memcpy(out, h_tok, B * 8);
                 return NVR_OK;
             }
-            if (lm_parts > 0) RC(k::argmax_partials(d_lm_pval, d_lm_pidx, lm_parts, B, d_tok, nullptr, 0, stream));
-            else RC(k::argmax(logits, B, Vl, d_tok, nullptr, 0, stream));
+            if (lm_parts > 0) RC(KD(argmax_partials(d_lm_pval, d_lm_pidx, lm_parts, B, d_tok, nullptr, 0, stream)));
+            else RC(KD(argmax(logits, B, Vl, d_tok, nullptr, 0, stream)));
         } else {
             // vocab-sharded greedy (embed_head.rs:321-336): all-gather (max, argmax) pairs, then lowest index wins
-            if (lm_parts > 0) RC(k::argmax_partials(d_lm_pval, d_lm_pidx, lm_parts, B, d_tok, d_maxval, vocab_start, stream));
-            else RC(k::argmax(logits, B, Vl, d_tok, d_maxval, vocab_start, stream));
+            if (lm_parts > 0) RC(KD(argmax_partials(d_lm_pval, d_lm_pidx, lm_parts, B, d_tok, d_maxval, vocab_start, stream)));
+            else RC(KD(argmax(logits, B, Vl, d_tok, d_maxval, vocab_start, stream)));
             RC(comm.all_gather_bytes(d_maxval, d_gather_val, (size_t)B * 4, stream));
             RC(comm.all_gather_bytes(d_tok, d_gather_idx, (size_t)B * 8, stream));
             std::vector<float> gv(tp * B); std::vector<int64_t> gi(tp * B);
@@ -931,11 +945,11 @@ int nvr_model_runner::sample(nvr_seq *const *seqs, size_t nseq, int64_t *out) {
             if (V % tp) return nvr::fail(NVR_ERR_UNSUPPORTED, "stochastic sampling under tensor parallelism needs vocab %% tp == 0");
             if (!d_full_logits) {
                 RC(dmalloc(&d_gather_logits, tp * max_seqs * Vl)); RC(dmalloc(&d_full_logits, max_seqs * V));
-                NVR_HIP_CHECK(hipMalloc(&sample_ws_full, k::sample_workspace_bytes(max_seqs, V)));
+                NVR_HIP_CHECK(hipMalloc(&sample_ws_full, KD(sample_workspace_bytes(max_seqs, V))));
             }
             RC(comm.all_gather_bytes(logits, d_gather_logits, (size_t)(B * Vl) * 4, stream));
             RC(comm.p2p_check_error(stream));                            // (synchronises) a peer that never arrived this step
-            RC(k::concat_vocab_shards(d_gather_logits, tp, B, Vl, d_full_logits, stream));
+            RC(KD(concat_vocab_shards(d_gather_logits, tp, B, Vl, d_full_logits, stream)));
             lg = d_full_logits; Vs = V; ws = sample_ws_full;
         }
         int64_t *tk = (int64_t *)samp_host; uint64_t *ky = (uint64_t *)(samp_host + max_seqs * 8);      // 8-byte arrays first
@@ -954,7 +968,7 @@ int nvr_model_runner::sample(nvr_seq *const *seqs, size_t nseq, int64_t *out) {
         NVR_HIP_CHECK(hipMemcpyAsync(d_topk, tk, B * 8, hipMemcpyHostToDevice, stream));
         NVR_HIP_CHECK(hipMemcpyAsync(d_topp, tpv, B * 4, hipMemcpyHostToDevice, stream));
         NVR_HIP_CHECK(hipMemcpyAsync(d_keys, ky, B * 8, hipMemcpyHostToDevice, stream));
-        RC(k::sample(lg, B, Vs, d_temp, d_topk, d_topp, d_keys, d_tok, ws, stream, false));
+        RC(KD(sample(lg, B, Vs, d_temp, d_topk, d_topp, d_keys, d_tok, ws, stream, false)));
     }
     NVR_HIP_CHECK(hipMemcpyAsync(h_tok, d_tok, B * 8, hipMemcpyDeviceToHost, stream));      // to_vec1 :152
     NVR_HIP_CHECK(hipStreamSynchronize(stream));

@@ -20,6 +20,7 @@ struct nvr_model_runner {
     nvr_model_config mc{};
     // derived, per rank (qwen3.rs:158-159, linear.rs:300-304)
     int64_t tp = 1, rank = 0;
+    bool bf16 = false;                     // Config.dtype == "bfloat16": the nvr::kb build of the kernels; 16-bit words are bfloat16 everywhere
     int64_t Hd = 0, H = 0, KVH = 0, D = 0, I = 0, V = 0, Vl = 0, vocab_start = 0, L = 0, QKV = 0;
     int64_t block_size = 256, num_blocks = 0, max_tokens = 0, max_seqs = 0, max_blocks_per_seq = 0, max_pos = 0;
     float scale = 1.f;

@@ -130,6 +130,19 @@ def round_f16(a: np.ndarray) -> np.ndarray:
     return out
 
 
+def round_bf16(a: np.ndarray) -> np.ndarray:
+    """f32 -> bfloat16 -> f32, round to nearest even (the rounding points of the product's bfloat16 build, Config.dtype = "bfloat16",
+    reference src/config.rs:51,113-116).  Finite inputs only."""
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    u = a.view(np.uint32).astype(np.uint64)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16
+    return r.astype(np.uint32).view(np.float32).reshape(a.shape)
+
+
+def to_bf16_bits(a: np.ndarray) -> np.ndarray:
+    return (round_bf16(a).view(np.uint32) >> 16).astype(np.uint16)
+
+
 def to_f16_bits(a: np.ndarray) -> np.ndarray:
     a = f32(a)
     out = np.empty(a.shape, dtype=np.uint16)

@@ -25,7 +25,7 @@ import copy
 import numpy as np
 
 from . import (add, attn_paged, attn_prefill_varlen, embedding, fill_tokens, fill_weight, kv_store, linear,
-               rmsnorm, rope_apply, rope_table, round_f16, sample, sample_key, silu_and_mul, weight_key,
+               rmsnorm, rope_apply, rope_table, round_bf16, round_f16, sample, sample_key, silu_and_mul, weight_key,
                weight_scale)
 from . import engine_oracle as eo
 
@@ -115,8 +115,11 @@ class OracleModel:
     """One tensor-parallel rank of the Qwen3 graph with synthetic weights."""
 
     def __init__(self, cfg: ModelConfig, num_blocks: int, block_size: int, fp16: bool = True,
-                 tp_rank: int = 0, tp_size: int = 1, max_pos: Optional[int] = None, compact: bool = False):
+                 tp_rank: int = 0, tp_size: int = 1, max_pos: Optional[int] = None, compact: bool = False, bf16: bool = False):
         cfg.validate(tp_size)
+        if bf16:
+            fp16 = False                       # bf16 = True: the 16-bit type of every rounding point is bfloat16 (Config.dtype "bfloat16")
+        self.bf16 = bf16
         if compact and not fp16:
             raise ValueError("compact weight storage is exact only in fp16 mode")
         self.compact = compact
@@ -143,20 +146,25 @@ class OracleModel:
         sc = weight_scale(c.init_std)
         Hg, KVHg, D, Hd, Ig = c.num_attention_heads, c.num_key_value_heads, self.D, self.Hd, c.intermediate_size
         f16 = self.fp16
+        if self.bf16:                          # generated unrounded, then rounded to bfloat16 like the product's fill_weight
+            _fw = fill_weight
+            fill_w = lambda *a: round_bf16(_fw(*a[:-1], False))
+        else:
+            fill_w = fill_weight
         self.layers: List[Dict[str, np.ndarray]] = []
         for l in range(c.num_hidden_layers):
             key = lambda tid: weight_key(c.seed, l * 8 + tid)
             # QKVParallelLinear (linear.rs:300-340): global rows [q heads | k heads | v heads]
-            q = fill_weight(self.H * D, Hd, Hd, r * self.H * D, 0, key(TID_QKV), sc, f16)
-            k = fill_weight(self.KVH * D, Hd, Hd, Hg * D + r * self.KVH * D, 0, key(TID_QKV), sc, f16)
-            v = fill_weight(self.KVH * D, Hd, Hd, (Hg + KVHg) * D + r * self.KVH * D, 0, key(TID_QKV), sc, f16)
+            q = fill_w(self.H * D, Hd, Hd, r * self.H * D, 0, key(TID_QKV), sc, f16)
+            k = fill_w(self.KVH * D, Hd, Hd, Hg * D + r * self.KVH * D, 0, key(TID_QKV), sc, f16)
+            v = fill_w(self.KVH * D, Hd, Hd, (Hg + KVHg) * D + r * self.KVH * D, 0, key(TID_QKV), sc, f16)
             # RowParallelLinear o_proj (linear.rs:180-268): global [Hd, H*D], columns sharded
-            o = fill_weight(Hd, self.H * D, Hg * D, 0, r * self.H * D, key(TID_O), sc, f16)
+            o = fill_w(Hd, self.H * D, Hg * D, 0, r * self.H * D, key(TID_O), sc, f16)
             # MergedColumnParallelLinear (linear.rs:378-454): global rows [gate | up], each sharded
-            g = fill_weight(self.I, Hd, Hd, r * self.I, 0, key(TID_GATE_UP), sc, f16)
-            u = fill_weight(self.I, Hd, Hd, Ig + r * self.I, 0, key(TID_GATE_UP), sc, f16)
+            g = fill_w(self.I, Hd, Hd, r * self.I, 0, key(TID_GATE_UP), sc, f16)
+            u = fill_w(self.I, Hd, Hd, Ig + r * self.I, 0, key(TID_GATE_UP), sc, f16)
             # down_proj row-parallel: global [Hd, I], columns sharded
-            d = fill_weight(Hd, self.I, Ig, 0, r * self.I, key(TID_DOWN), sc, f16)
+            d = fill_w(Hd, self.I, Ig, 0, r * self.I, key(TID_DOWN), sc, f16)
             W = _CompactLayer() if self.compact else {}
             for name, val in dict(qkv=np.concatenate([q, k, v], 0), o=o, gate_up=np.concatenate([g, u], 0), down=d,
                                   ln1=np.ones(Hd, np.float32), ln2=np.ones(Hd, np.float32),
@@ -165,14 +173,14 @@ class OracleModel:
             self.layers.append(W)
         # Embedding replicated on every rank (skip C2); LM head vocab-sharded
         # (embed_head.rs:57-59), tied to the embedding when tie_word_embeddings (qwen3.rs:461-473).
-        self.embed = fill_weight(self.V, Hd, Hd, 0, 0, weight_key(c.seed, TID_EMBED), sc, f16)
+        self.embed = fill_w(self.V, Hd, Hd, 0, 0, weight_key(c.seed, TID_EMBED), sc, f16)
         vs = self.V // tp
         self.vocab_start = r * vs
         self.vocab_end = self.V if r == tp - 1 else (r + 1) * vs
         if c.tie_word_embeddings:
             self.lm_head = self.embed[self.vocab_start:self.vocab_end]
         else:
-            self.lm_head = fill_weight(self.vocab_end - self.vocab_start, Hd, Hd, self.vocab_start, 0,
+            self.lm_head = fill_w(self.vocab_end - self.vocab_start, Hd, Hd, self.vocab_start, 0,
                                        weight_key(c.seed, TID_LM_HEAD), sc, f16)
         self.norm = np.ones(Hd, np.float32)
 
@@ -245,7 +253,10 @@ class OracleModel:
         return skipped
 
     def _r(self, x: np.ndarray) -> np.ndarray:
-        return round_f16(x) if self.fp16 else x
+        return round_bf16(x) if self.bf16 else (round_f16(x) if self.fp16 else x)
+
+    def _add(self, a: np.ndarray, b: np.ndarray) -> np.ndarray:   # residual add, qwen3.rs:382,389, rounded to the storage type
+        return round_bf16(add(a, b, round16=False)) if self.bf16 else add(a, b, round16=self.fp16)
 
     # -- one layer, split at the two all-reduce points so TP can be simulated --
     def attn_part(self, l: int, h: np.ndarray, positions, meta: dict) -> np.ndarray:
@@ -303,10 +314,10 @@ def forward_tp(ranks: List[OracleModel], ids, positions, meta: dict) -> np.ndarr
     for l in range(m0.cfg.num_hidden_layers):
         parts = [m.attn_part(l, h, positions, meta) for m in ranks]
         o = parts[0] if len(parts) == 1 else m0._r(np.sum(parts, axis=0, dtype=np.float32))
-        h = add(h, o, round16=m0.fp16)                                   # qwen3.rs:382
+        h = m0._add(h, o)                                                # qwen3.rs:382
         parts = [m.mlp_part(l, h) for m in ranks]
         d = parts[0] if len(parts) == 1 else m0._r(np.sum(parts, axis=0, dtype=np.float32))
-        h = add(h, d, round16=m0.fp16)                                   # qwen3.rs:389
+        h = m0._add(h, d)                                                # qwen3.rs:389
     return np.concatenate([m.head_part(h, meta) for m in ranks], axis=1)
 
 
@@ -330,11 +341,11 @@ class OracleEngine:
     """LLMEngine::step loop (llm_engine.rs:155-197): schedule -> execute -> sample -> postprocess."""
 
     def __init__(self, cfg: ModelConfig, config: eo.Config, fp16: bool = True, tp_size: int = 1,
-                 sample_seed: int = 0, max_pos: Optional[int] = None, compact: bool = False):
+                 sample_seed: int = 0, max_pos: Optional[int] = None, compact: bool = False, bf16: bool = False):
         self.config = config
         self.scheduler = eo.Scheduler(config)
         nb = config.num_kvcache_blocks if config.num_kvcache_blocks is not None else 1000
-        self.ranks = [OracleModel(cfg, nb, config.kvcache_block_size, fp16, r, tp_size, max_pos, compact)
+        self.ranks = [OracleModel(cfg, nb, config.kvcache_block_size, fp16, r, tp_size, max_pos, compact, bf16)
                       for r in range(tp_size)]
         self.sample_seed = sample_seed
         self.step_count = 0

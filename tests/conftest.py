@@ -17,3 +17,23 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+import gc
+
+import pytest
+
+
+@pytest.fixture(autouse=True)
+def _no_collector_inside_a_test():
+    """Engines of earlier tests that are still waiting for the cycle collector are destroyed HERE, between tests, and the collector stays
+    off while a test runs.  Destroying an engine frees device memory, and hipFree waits for every stream of the device; in the
+    in-process tensor-parallel tests (several ranks of ONE process on ONE GPU, one host thread each) a collection that fires on rank A's
+    thread would then wait for rank B's kernel, which waits inside its one-shot collective for the launch rank A's thread has not made
+    yet — a deadlock of the test arrangement (ranks of the product are one process per GPU: a rank's hipFree only ever waits for itself)."""
+    gc.collect()
+    gc.disable()
+    try:
+        yield
+    finally:
+        gc.enable()

@@ -31,6 +31,7 @@ pytestmark = pytest.mark.gpu
 
 LOGIT_TOL = 2e-2            # product fp16 pipeline vs fp16-faithful oracle (f32 logits, fp16 activations)
 CPU_PATH_TOL = 8e-2         # product fp16 pipeline vs the reference's f32 CPU path (weights and activations unrounded)
+BF16_TOL = 1.6e-1          # Config.dtype = "bfloat16" against the bf16-faithful oracle: 8 x LOGIT_TOL (8 mantissa bits against 11); measured 4.5e-2 on Qwen3-0.6B
 LOGIT_TOL_8B = 6e-2         # Qwen3-8B (36 layers, K = 4096 / 12 288): summation-order noise grows ~ sqrt(depth); the fp16-faithful oracle itself is
                             # 6.1e-2 from exact f32 arithmetic on the same weights, the product 4.3e-2 from the oracle (profiles/r03_parity_8b_stats.txt)
 V = 151936
@@ -53,7 +54,8 @@ def _pair(ecfg, prompts, max_tokens, fp16=True, tol=LOGIT_TOL, model="qwen3-0.6b
     eo.reset_sequence_counter(); nvr.lib().nvr_seq_reset_id_counter()
     mcfg = mo.qwen3_0_6b() if model == "qwen3-0.6b" else mo.qwen3_8b()
     t0 = time.time()
-    o = mo.OracleEngine(mcfg, eo.Config(**ecfg), fp16=fp16, max_pos=ecfg["max_model_len"], compact=(model != "qwen3-0.6b"))
+    bf16 = kw.get("dtype") == "bfloat16"                 # the product's bf16 build against the oracle's bf16-faithful mode
+    o = mo.OracleEngine(mcfg, eo.Config(**ecfg), fp16=fp16 and not bf16, bf16=bf16, max_pos=ecfg["max_model_len"], compact=(model != "qwen3-0.6b"))
     p = nvr.LLMEngine(nvr.Config(**ecfg, **kw), nvr.ModelConfig(model))
     t_build = time.time() - t0
     for pr in prompts:
@@ -153,6 +155,18 @@ def test_configs4_shared_system_prompt_vs_oracle():
     bm = p.scheduler.block_manager.get_stats()
     st["kv_blocks_total"] = int(bm["total_blocks"])
     _report("configs4_shared_prefix_48seqs", st)
+
+
+def test_bfloat16_qwen3_0_6b_bs32_seq1024_vs_bf16_oracle():
+    """Config.dtype = "bfloat16" (config.rs:51,113-116) at BASELINE configs[1]'s full size: the bf16 build of the 256^2 MFMA GEMMs, the
+    flash prefill kernel, the weight-streaming decode GEMMs, paged attention and the fused LM head over 28 layers, against the oracle
+    with bf16 at every 16-bit rounding point — 32 x 1024-token prompts + 4 hipGraph decode steps."""
+    ecfg = dict(max_num_seqs=32, max_num_batched_tokens=32768, max_model_len=1040, kvcache_block_size=256, num_kvcache_blocks=170)
+    prompts = [nvr.synthetic_tokens(1024, 1, i, V).tolist() for i in range(32)]
+    st, o, p = _pair(ecfg, prompts, 5, tol=BF16_TOL, dtype="bfloat16")
+    assert st["steps"] == 5 and st["prefill_steps"] == 1 and st["rows"] == 160
+    assert st["near_ties"] <= 4, st
+    _report("bf16_configs1_bs32_seq1024", st)
 
 
 def test_configs3_qwen3_8b_full_depth_vs_oracle():

@@ -361,3 +361,33 @@ def test_qk_norm_extension_is_off_by_default_and_changes_the_graph():
         h = m.embed_tokens(ids)
         out[on] = m.attn_part(0, h, np.arange(4, dtype=np.int64), meta)
     assert np.abs(out[True] - out[False]).max() > 1e-3
+
+
+def test_round_bf16_matches_torch_and_the_oracle_bf16_mode_rounds_everywhere():
+    """The bf16-faithful oracle mode (Config.dtype "bfloat16", config.rs:51,113-116): oracle.round_bf16 is round-to-nearest-even to 8
+    significant bits — pinned against torch's bfloat16 cast on random values, every tie case and the range ends — and an OracleModel
+    built with bf16=True holds only bf16-representable weights and activations, distinct from the fp16 mode's."""
+    import torch
+    from oracle import model_oracle as mo
+    rng = np.random.default_rng(5)
+    x = np.concatenate([rng.standard_normal(20000).astype(np.float32) * np.float32(10.0) ** rng.integers(-30, 30, 20000).astype(np.float32),
+                        np.asarray([0.0, -0.0, 1.0, 1.0 + 2.0 ** -8, 1.0 + 3 * 2.0 ** -8, -(1.0 + 2.0 ** -8), 65504.0, 3.0e38, 1e-40, 2.0 ** -133,
+                                    3.3895314e38], np.float32)])
+    want = torch.from_numpy(x).to(torch.bfloat16).to(torch.float32).numpy()
+    got = oracle.round_bf16(x)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert np.array_equal(oracle.to_bf16_bits(x), (want.view(np.uint32) >> 16).astype(np.uint16))
+    assert oracle.round_bf16(np.float32([1.0 + 2.0 ** -8, 1.0 + 3 * 2.0 ** -8])).tolist() == [1.0, 1.0 + 2.0 ** -6]     # ties to even, both ways
+    ids = np.asarray([5, 9, 200, 31], np.int64)
+    meta = dict(is_prefill=True, cu_seqlens_q=np.asarray([0, 4], np.int32), slot_mapping=np.arange(4, dtype=np.int32), block_tables=None, context_lens=None)
+    outs = {}
+    for mode in ("fp16", "bf16"):
+        m = mo.OracleModel(mo.tiny(), num_blocks=2, block_size=16, fp16=(mode == "fp16"), bf16=(mode == "bf16"), max_pos=64)
+        o = m.attn_part(0, m.embed_tokens(ids), np.arange(4, dtype=np.int64), meta)
+        outs[mode] = o
+        if mode == "bf16":
+            for w in (m.embed, m.layers[0]["qkv"], m.layers[0]["down"], m.norm, o, m.k_cache[0][:1]):
+                w = np.asarray(w, np.float32)
+                assert np.array_equal(w, oracle.round_bf16(w))
+    d = np.abs(outs["fp16"] - outs["bf16"]).max()
+    assert 1e-5 < d < 5e-2, d
