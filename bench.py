@@ -223,7 +223,7 @@ def prefill_flops(c, lens) -> float:
 
 
 def side_decode(nvr, preset: str, steps: int = 16, warmup: int = 4, tp_size: int = 1, tp_rank: int = 0, device: int = 0,
-                attach=None, barrier=None, reduce_max=None, batch: int = None, prompt_len: int = None) -> dict:
+                attach=None, barrier=None, reduce_max=None, batch: int = None, prompt_len: int = None, dtype: str = "float16") -> dict:
     """One more BASELINE workload measured next to the headline (same engine path: prefill untimed, W warm-up steps, K timed decode
     steps): used for BASELINE.json configs[3] (Qwen3-8B, bs 32 x 2048; src/models/qwen3.rs:70-125 with the 8B numbers) on one GPU and,
     in a tensor-parallel child, over the N GPUs (attach = communicator set-up of the engine's runner)."""
@@ -234,7 +234,7 @@ def side_decode(nvr, preset: str, steps: int = 16, warmup: int = 4, tp_size: int
     t0 = time.perf_counter()
     eng = nvr.LLMEngine(nvr.Config(max_num_seqs=B, max_num_batched_tokens=32768, max_model_len=P + total_new + 16, kvcache_block_size=BLOCK,
                                    num_kvcache_blocks=B * ((P + total_new + 16) // BLOCK + 2), tensor_parallel_size=tp_size,
-                                   tensor_parallel_rank=tp_rank, device_ordinal=device, async_decode=1), mc)
+                                   tensor_parallel_rank=tp_rank, device_ordinal=device, async_decode=1, dtype=dtype), mc)
     if attach is not None:
         ok, desc = attach(eng)
         if not ok:
@@ -269,7 +269,9 @@ def side_decode(nvr, preset: str, steps: int = 16, warmup: int = 4, tp_size: int
     step_bytes = weights + B * ctx_mean * kv_tok + B * kv_tok
     ms = el * 1e3 / steps
     which = f"(BASELINE.json configs[{w['baseline_config']}])" if (batch is None and prompt_len is None) else "(batch-size sweep of the headline workload)"
-    out = dict(workload=f"{w['label']} fp16 random-init, bs={B} x {P}-token prompts, greedy paged-attention decode, hipGraph steps "
+    if dtype != "float16":
+        which = f"(the headline workload on the {dtype} build of the kernels)"
+    out = dict(workload=f"{w['label']} {'fp16' if dtype == 'float16' else 'bf16'} random-init, bs={B} x {P}-token prompts, greedy paged-attention decode, hipGraph steps "
                         f"{which}, {'one GPU' if tp_size == 1 else f'tensor parallel over {tp_size} GPUs'}",
                parallelism=f"tp{tp_size}", ms_per_step=round(ms, 4), tokens_per_s=round(B * steps / el, 1), steps=steps, warmup=warmup,
                step_algorithmic_bytes=int(step_bytes), step_hbm_frac_per_gpu=round(step_bytes / tp_size / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
@@ -649,6 +651,14 @@ def main() -> None:
                 batch_sweep.append({k: r[k] for k in ("workload", "ms_per_step", "tokens_per_s", "step_algorithmic_bytes", "step_hbm_frac_per_gpu")})
             except Exception as ex:                                          # noqa: BLE001
                 batch_sweep.append({"batch": bsz, "error": str(ex)[:200]})
+    bf16_block = None
+    if args.gpus == 1 and rank == 0 and not args.no_batch_sweep and args.model == "qwen3-0.6b":
+        # Config.dtype = "bfloat16" (config.rs:51,113-116): the same workload on the bf16 build of every kernel (same bytes, same MFMA rate)
+        try:
+            r = side_decode(nvr, "qwen3-0.6b", batch=BATCH, prompt_len=PROMPT_LEN, dtype="bfloat16")
+            bf16_block = {k: r[k] for k in ("workload", "ms_per_step", "tokens_per_s", "step_hbm_frac_per_gpu", "prefill_plus_first_decode_seconds")}
+        except Exception as ex:                                              # noqa: BLE001
+            bf16_block = {"error": str(ex)[:200]}
     sweep = None
     if args.gpus == 1 and rank == 0 and not args.no_prefill_sweep and args.model == "qwen3-0.6b":
         try:
@@ -712,6 +722,8 @@ def main() -> None:
             out["configs3"] = configs3
         if batch_sweep is not None:
             out["batch_sweep"] = batch_sweep
+        if bf16_block is not None:
+            out["bf16"] = bf16_block
         if sweep is not None:
             out["prefill_sweep"] = sweep
         if args.gpus == 1 and not args.no_cpu_baseline:

@@ -61,6 +61,7 @@ def _declare(l: C.CDLL) -> None:
     l.nvo_round_f16.argtypes = [C.c_float]
     l.nvo_round_f16_array.argtypes = [_f32p, C.c_size_t]
     l.nvo_round_f16_copy.argtypes = [_f32p, _f32p, C.c_size_t]
+    l.nvo_round_bf16_copy.argtypes = [_f32p, _f32p, C.c_size_t]
     l.nvo_f32_to_f16.argtypes = [_f32p, _u16p, C.c_size_t]
     l.nvo_f16_to_f32.argtypes = [_u16p, _f32p, C.c_size_t]
     l.nvo_num_threads.restype = C.c_int
@@ -132,11 +133,12 @@ def round_f16(a: np.ndarray) -> np.ndarray:
 
 def round_bf16(a: np.ndarray) -> np.ndarray:
     """f32 -> bfloat16 -> f32, round to nearest even (the rounding points of the product's bfloat16 build, Config.dtype = "bfloat16",
-    reference src/config.rs:51,113-116).  Finite inputs only."""
-    a = np.ascontiguousarray(a, dtype=np.float32)
-    u = a.view(np.uint32).astype(np.uint64)
-    r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16
-    return r.astype(np.uint32).view(np.float32).reshape(a.shape)
+    reference src/config.rs:51,113-116).  Finite inputs only.  (u + 0x7FFF + lowest kept bit) with the low half cleared; pinned against
+    torch's bfloat16 cast in tests/test_oracle_kat.py."""
+    a = f32(a)
+    out = np.empty_like(a)
+    lib().nvo_round_bf16_copy(_f(a), _f(out), a.size)
+    return out
 
 
 def to_bf16_bits(a: np.ndarray) -> np.ndarray:

@@ -56,6 +56,16 @@ NVO_API void nvo_round_f16_copy(const float *x, float *y, size_t n) {     /* y =
     for (size_t i = n8 * 8; i < n; ++i) y[i] = f16_bits_to_f32(f32_to_f16_bits(x[i]));
 }
 NVO_API void nvo_round_f16_array(float *x, size_t n) { nvo_round_f16_copy(x, x, n); }
+/* y = f32(bf16_rne(x)): round to nearest even at 8 significant bits (the 16-bit type of Config.dtype = "bfloat16", reference
+ * src/config.rs:51,113-116); finite inputs; x == y allowed.  Integer form: add 0x7FFF + the lowest kept bit, clear the low half. */
+NVO_API void nvo_round_bf16_copy(const float *x, float *y, size_t n) {
+#pragma omp parallel for schedule(static) if (n > 65536)
+    for (size_t i = 0; i < n; ++i) {
+        uint32_t u; memcpy(&u, x + i, 4);
+        u = (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u;
+        memcpy(y + i, &u, 4);
+    }
+}
 NVO_API void nvo_f32_to_f16(const float *x, uint16_t *y, size_t n) {
 #pragma omp parallel for schedule(static) if (n > 65536)
     for (size_t i = 0; i < n; ++i) y[i] = f32_to_f16_bits(x[i]);

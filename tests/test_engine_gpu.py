@@ -570,8 +570,7 @@ def test_config_device_and_dtype_gate_the_runner():
     base = dict(skip_block_size_check=1, max_num_seqs=2, max_num_batched_tokens=64, max_model_len=64, kvcache_block_size=16, num_kvcache_blocks=4)
     for ok in (dict(), dict(device="cuda"), dict(device="hip", dtype="float16"), dict(dtype="bfloat16")):
         nvr.ModelRunner(nvr.Config(**base, **ok), _model_cfgs(mcfg))
-    for bad in (dict(device="cpu"), dict(device="metal"), dict(dtype="float32"),
-                dict(dtype="bfloat16", tensor_parallel_size=2, tensor_parallel_rank=0)):       # the peer-to-peer exchange kernels are fp16
+    for bad in (dict(device="cpu"), dict(device="metal"), dict(dtype="float32")):
         with pytest.raises(nvr.NvrError) as e:
             nvr.ModelRunner(nvr.Config(**base, **bad), _model_cfgs(mcfg))
         assert e.value.code == -10
