@@ -10,7 +10,7 @@ The oracle is teacher-forced with the product's tokens so a tie cannot cascade.
   configs[0]  bs 1, 128-token prompt, 64 greedy steps       vs the fp16-faithful oracle AND vs the f32 "CPU path" oracle
   configs[1]  bs 32 x 1024-token prompts, prefill + 4 decode steps (hipGraph decode, 8-wave attention, V = 151 936 head)
   configs[2]  one 32 768-token prefill batch mixing 4 x 4096 ... 16 x 128 (42 sequences, the reference's token budget,
-              config.rs:58) + one decode step
+              config.rs:58) + one decode step; and 256 sequences x 200 tokens over two budget batches with chunked prefill on
   configs[3]  Qwen3-8B (36 layers, V = 151 936) on one GPU: product vs oracle at full depth on a reduced batch (2 x 256 + 3 decode
               steps), and the full 32 x 2048 workload as in-process tensor-parallel ranks (tp 8) against the single-rank product
 A JSON summary of what was measured lands in gpurun_out/parity_r03.json (copied to profiles/ by hand)."""
@@ -73,7 +73,9 @@ def _pair(ecfg, prompts, max_tokens, fp16=True, tol=LOGIT_TOL, model="qwen3-0.6b
         for ot, ps in zip(orec["block_tables"], p.last_batch()):          # a finished sequence has been deallocated (empty table)
             pt = list(ps.block_table)
             assert not pt or pt == ot, f"step {st['steps']}: block tables differ"
-        err = float(np.abs(logits - orec["logits"]).max())
+        assert [t == -1 for t in rec["tokens"]] == [t == -1 for t in orec["tokens"]], f"step {st['steps']}: unfinished prompts differ"
+        live = [i for i, t in enumerate(rec["tokens"]) if t != -1]          # a prompt chunk that does not finish its prompt samples nothing (A-23)
+        err = float(np.abs(logits[live] - orec["logits"][live]).max()) if live else 0.0
         st["max_abs_logit_err"] = max(st["max_abs_logit_err"], err)
         assert err < tol, f"step {st['steps']}: logits differ from the oracle by {err}"
         srt = np.sort(orec["logits"], axis=1)
@@ -136,6 +138,23 @@ def test_configs2_mixed_length_32768_token_prefill_vs_oracle():
     assert st["steps"] == 2 and st["prefill_steps"] == 1 and st["rows"] == 84
     assert st["near_ties"] <= 2, st
     _report("configs2_mixed_32768", st)
+
+
+def test_configs2_256_sequences_over_budget_batches_chunked_vs_oracle():
+    """BASELINE configs[2]'s OWN shape — 256 sequences of one length against the 32 768-token budget (scheduler.rs:119-168), several
+    prefill batches — with chunked prefill on (A-23): 256 x 200 tokens = 51 200: step 1 takes 163 whole prompts + the first 168 tokens of
+    the 164th, step 2 its last 32 tokens (attending to the first chunk through the block table) + the other 92 prompts; then one decode
+    step over all 256.  Batch composition, block tables, which rows sample, logits and ids against the oracle's chunked engine."""
+    n, L = 256, 200
+    ecfg = dict(max_num_seqs=n, max_num_batched_tokens=32768, max_model_len=256, kvcache_block_size=256, num_kvcache_blocks=n + 4,
+                enable_chunked_prefill=True)
+    prompts = [nvr.synthetic_tokens(L, 1, i, V).tolist() for i in range(n)]
+    st, o, p = _pair(ecfg, prompts, 2)
+    assert st["steps"] == 3 and st["prefill_steps"] == 2 and st["rows"] == 164 + 93 + 256
+    assert st["near_ties"] <= 4, st
+    sst = p.scheduler.get_stats()
+    assert sst["prefill_batches"] == 2 and sst["decode_batches"] == 1
+    _report("configs2_256seqs_x200_chunked", st)
 
 
 def test_configs4_shared_system_prompt_vs_oracle():
