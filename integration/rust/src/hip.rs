@@ -151,6 +151,12 @@ impl LLMEngine {
         check(unsafe { ffi::nvr_runner_p2p_export(ffi::nvr_engine_runner(self.h), h.as_mut_ptr()) })?;
         Ok(h)
     }
+    /// After a step failed with NVR_ERR_RCCL (a peer never arrived inside a one-shot collective): EVERY rank calls this, then the
+    /// control plane barriers, then the same engines take new requests (nvr.h, "recovery").
+    pub fn recover_from_failed_collective(&mut self) -> anyhow::Result<()> {
+        check(unsafe { ffi::nvr_engine_abort_last_batch(self.h) })?;
+        check(unsafe { ffi::nvr_runner_p2p_reset(ffi::nvr_engine_runner(self.h)) })
+    }
 }
 impl Drop for LLMEngine { fn drop(&mut self) { unsafe { ffi::nvr_engine_destroy(self.h) } } }
 unsafe impl Send for LLMEngine {}
