@@ -117,7 +117,7 @@ typedef struct nvr_config {
                                           nvr_runner_load_tensor converts any of f16 / bf16 / f32 to it (bf16 checkpoints into a bf16
                                           runner bit for bit), nvr_runner_copy_weight returns its raw 16-bit elements.  "float32":
                                           NVR_ERR_UNSUPPORTED at runner creation (f32 checkpoints load into either type).  The stateless
-                                          op entry points below (nvr_linear, nvr_paged_attn_*, ...) take fp16 buffers */
+                                          op entry points (nvr_linear, nvr_paged_attn_*, ...) take their type from nvr_ops_set_dtype */
 } nvr_config;
 NVR_API void nvr_config_default(nvr_config *cfg);                    /* config.rs:54-71 */
 NVR_API int nvr_config_validate(const nvr_config *cfg);              /* config.rs:83-119 */
@@ -401,9 +401,15 @@ NVR_API int nvr_graph_destroy(void *graph_exec);
 
 /* ------------------------------------------------ stateless op entry points ---- */
 /* One per kernel-shaped op site of the hot path.  All tensors are
- * device pointers; activations/weights/caches are fp16 (nvr_half = uint16_t bits) unless
- * noted; math is f32 inside an op.  `stream` is a hipStream_t (NULL = default stream). */
+ * device pointers; activations/weights/caches are 16-bit (nvr_half = uint16_t bits: fp16 by
+ * default, bfloat16 after nvr_ops_set_dtype("bfloat16")) unless noted; math is f32 inside an
+ * op.  `stream` is a hipStream_t (NULL = default stream). */
 typedef uint16_t nvr_half;
+/* Config.dtype (config.rs:51,113-116) for the stateless entry points below: "float16" | "bfloat16" select the fp16 / bf16 build of the
+ * kernels for the CALLING THREAD (thread-local, like nvr_last_error); anything else: NVR_ERR_UNSUPPORTED.  Runners and engines take their
+ * type from nvr_config.dtype and are not affected. */
+NVR_API int nvr_ops_set_dtype(const char *dtype);
+NVR_API const char *nvr_ops_dtype(void);
 
 /* Attention metadata of one step = Context, src/utils/context.rs:11-35 (explicit, not global) */
 typedef struct nvr_attn_meta {

@@ -246,6 +246,7 @@ _SIGS = {
     "nvr_fill_weight": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_uint64,
                                   C.c_float, _P]),
     "nvr_fill_const": (C.c_int, [_P, C.c_int64, C.c_float, _P]),
+    "nvr_ops_set_dtype": (C.c_int, [C.c_char_p]), "nvr_ops_dtype": (C.c_char_p, []),
 }
 
 

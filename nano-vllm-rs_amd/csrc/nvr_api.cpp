@@ -466,94 +466,104 @@ int nvr_graph_launch(void *exec, void *s) { NVR_HIP_CHECK(hipGraphLaunch((hipGra
 int nvr_graph_destroy(void *exec) { NVR_HIP_CHECK(hipGraphExecDestroy((hipGraphExec_t)exec)); return NVR_OK; }
 
 // ------------------------------------------------------------------ stateless ops
+// The 16-bit type of the stateless entry points' buffers: fp16 (default) or bfloat16 — per calling thread, like nvr_last_error.
+// Every kernel exists in both builds (kernels/device_utils.h); KO() picks the namespace per call.
+static thread_local bool g_ops_bf16 = false;
+#define KO(call) (g_ops_bf16 ? nvr::kb::call : nvr::k::call)
+int nvr_ops_set_dtype(const char *dtype) {
+    if (dtype && std::strcmp(dtype, "float16") == 0) { g_ops_bf16 = false; return NVR_OK; }
+    if (dtype && std::strcmp(dtype, "bfloat16") == 0) { g_ops_bf16 = true; return NVR_OK; }
+    return nvr::fail(NVR_ERR_UNSUPPORTED, "nvr_ops_set_dtype: '%s' (float16 | bfloat16)", dtype ? dtype : "(null)");
+}
+const char *nvr_ops_dtype(void) { return g_ops_bf16 ? "bfloat16" : "float16"; }
 int nvr_embedding(const int64_t *ids, int64_t T, const nvr_half *E, int64_t Hd, nvr_half *out, void *s) {
-    return k::embedding(ids, T, E, Hd, out, (hipStream_t)s);
+    return KO(embedding(ids, T, E, Hd, out, (hipStream_t)s));
 }
 int nvr_rmsnorm(const nvr_half *x, const nvr_half *w, float eps, int64_t T, int64_t Hd, nvr_half *out, void *s) {
-    return k::rmsnorm(x, w, eps, T, Hd, out, (hipStream_t)s);
+    return KO(rmsnorm(x, w, eps, T, Hd, out, (hipStream_t)s));
 }
 int nvr_add_rmsnorm(nvr_half *h, const nvr_half *y, const nvr_half *w, float eps, int64_t T, int64_t Hd, nvr_half *out, void *s) {
-    return k::add_rmsnorm(h, y, w, eps, T, Hd, out, (hipStream_t)s);
+    return KO(add_rmsnorm(h, y, w, eps, T, Hd, out, (hipStream_t)s));
 }
 int nvr_linear(const nvr_half *x, int64_t ldx, const nvr_half *W, int64_t T, int64_t K, int64_t N, void *y, int f32, void *s) {
-    return k::linear(x, ldx, W, T, K, N, y, f32 != 0, (hipStream_t)s);
+    return KO(linear(x, ldx, W, T, K, N, y, f32 != 0, (hipStream_t)s));
 }
 int nvr_lm_head(const nvr_half *x, int64_t ldx, const nvr_half *W, int64_t T, int64_t K, int64_t N, float *logits, float *part_val,
                 int32_t *part_idx, int32_t *nparts, void *s) {
     if (!nparts) return nvr::fail(NVR_ERR_INVALID_ARG, "nvr_lm_head: nparts is null");
-    return k::lm_head(x, ldx, W, T, K, N, logits, part_val, part_idx, nparts, (hipStream_t)s, logits != nullptr);
+    return KO(lm_head(x, ldx, W, T, K, N, logits, part_val, part_idx, nparts, (hipStream_t)s, logits != nullptr));
 }
 int nvr_argmax_partials(const float *part_val, const int32_t *part_idx, int32_t nparts, int64_t T, int64_t *out_idx, float *out_val,
                         int64_t idx_offset, void *s) {
-    return k::argmax_partials(part_val, part_idx, nparts, T, out_idx, out_val, idx_offset, (hipStream_t)s);
+    return KO(argmax_partials(part_val, part_idx, nparts, T, out_idx, out_val, idx_offset, (hipStream_t)s));
 }
 int nvr_linear_splitk(const nvr_half *x, int64_t ldx, const nvr_half *W, int64_t T, int64_t K, int64_t N, int64_t S, float *slabs, void *s) {
-    return k::linear_splitk(x, ldx, W, T, K, N, S, slabs, (hipStream_t)s);
+    return KO(linear_splitk(x, ldx, W, T, K, N, S, slabs, (hipStream_t)s));
 }
 int nvr_add_rmsnorm_slabs(nvr_half *h, const float *slabs, int64_t S, const nvr_half *w, float eps, int64_t T, int64_t Hd, nvr_half *out, void *s) {
-    return k::add_rmsnorm_slabs(h, slabs, S, w, eps, T, Hd, out, (hipStream_t)s);
+    return KO(add_rmsnorm_slabs(h, slabs, S, w, eps, T, Hd, out, (hipStream_t)s));
 }
 int nvr_linear_tiled(const nvr_half *x, int64_t ldx, const nvr_half *W, const nvr_half *Wt, int64_t T, int64_t K, int64_t N, void *y, int f32,
                      void *s) {
-    return k::linear(x, ldx, W, T, K, N, y, f32 != 0, (hipStream_t)s, Wt);
+    return KO(linear(x, ldx, W, T, K, N, y, f32 != 0, (hipStream_t)s, Wt));
 }
 int nvr_linear_splitk_tiled(const nvr_half *x, int64_t ldx, const nvr_half *W, const nvr_half *Wt, int64_t T, int64_t K, int64_t N, int64_t S,
                             float *slabs, void *s) {
-    return k::linear_splitk(x, ldx, W, T, K, N, S, slabs, (hipStream_t)s, Wt);
+    return KO(linear_splitk(x, ldx, W, T, K, N, S, slabs, (hipStream_t)s, Wt));
 }
 int nvr_linear_silu_mul_tiled(const nvr_half *x, int64_t ldx, const nvr_half *W, const nvr_half *Wt, int64_t T, int64_t K, int64_t I,
                               nvr_half *out, void *s) {
-    return k::linear_silu_mul(x, ldx, W, T, K, I, out, (hipStream_t)s, Wt);
+    return KO(linear_silu_mul(x, ldx, W, T, K, I, out, (hipStream_t)s, Wt));
 }
 int nvr_linear_qkv_rope_store_tiled(const nvr_half *x, int64_t ldx, const nvr_half *W, const nvr_half *Wt, int64_t T, int64_t K, int64_t H,
                                     int64_t KVH, int64_t D, const int64_t *pos, const int32_t *slots, const float *c, const float *sn,
                                     nvr_half *qkv, nvr_half *kc, nvr_half *vc, void *s) {
-    return k::linear_qkv_rope_store(x, ldx, W, T, K, H, KVH, D, pos, slots, c, sn, qkv, kc, vc, (hipStream_t)s, Wt);
+    return KO(linear_qkv_rope_store(x, ldx, W, T, K, H, KVH, D, pos, slots, c, sn, qkv, kc, vc, (hipStream_t)s, Wt));
 }
 int nvr_lm_head_tiled(const nvr_half *x, int64_t ldx, const nvr_half *W, const nvr_half *Wt, int64_t T, int64_t K, int64_t N, float *logits,
                       float *part_val, int32_t *part_idx, int32_t *nparts, void *s) {
     if (!nparts) return nvr::fail(NVR_ERR_INVALID_ARG, "nvr_lm_head_tiled: nparts is null");
-    return k::lm_head(x, ldx, W, T, K, N, logits, part_val, part_idx, nparts, (hipStream_t)s, logits != nullptr, Wt);
+    return KO(lm_head(x, ldx, W, T, K, N, logits, part_val, part_idx, nparts, (hipStream_t)s, logits != nullptr, Wt));
 }
 int nvr_retile_weight(const nvr_half *src, nvr_half *dst, int64_t N, int64_t K, int mode, int64_t H, int64_t KVH, int64_t D, void *s) {
-    return k::retile_weight(src, dst, N, K, mode, H, KVH, D, (hipStream_t)s);
+    return KO(retile_weight(src, dst, N, K, mode, H, KVH, D, (hipStream_t)s));
 }
 int nvr_linear_add_residual(const nvr_half *x, int64_t ldx, const nvr_half *W, int64_t T, int64_t K, int64_t N, nvr_half *h, void *s) {
     if (!k::gemm256_preferred(T, K, N, ldx))
         return nvr::fail(NVR_ERR_UNSUPPORTED, "nvr_linear_add_residual: T=%ld K=%ld N=%ld is not a shape of the 256x256 prefill GEMM", (long)T, (long)K, (long)N);
-    return k::gemm256_resid(x, ldx, W, T, K, N, h, (hipStream_t)s);
+    return KO(gemm256_resid(x, ldx, W, T, K, N, h, (hipStream_t)s));
 }
 int nvr_linear_resid(const nvr_half *x, int64_t ldx, const nvr_half *W, const nvr_half *Wt, int64_t T, int64_t K, int64_t N, int64_t S,
                      float *slabs, uint32_t *counters, nvr_half *h, void *s) {
-    return k::linear_resid(x, ldx, W, T, K, N, S, slabs, counters, h, (hipStream_t)s, Wt);
+    return KO(linear_resid(x, ldx, W, T, K, N, S, slabs, counters, h, (hipStream_t)s, Wt));
 }
 int nvr_decode_splitk_slices(int64_t T, int64_t K, int64_t N) { return k::decode_splitk_slices(T, K, N); }
 int nvr_linear_silu_mul_normed(const nvr_half *h, int64_t ldx, const nvr_half *wn, float eps, const nvr_half *W, const nvr_half *Wt, int64_t T,
                                int64_t K, int64_t I, nvr_half *out, void *s) {
-    return k::linear_silu_mul_normed(h, ldx, wn, eps, W, T, K, I, out, (hipStream_t)s, Wt);
+    return KO(linear_silu_mul_normed(h, ldx, wn, eps, W, T, K, I, out, (hipStream_t)s, Wt));
 }
 int nvr_linear_qkv_rope_store_normed(const nvr_half *h, int64_t ldx, const nvr_half *wn, float eps, const nvr_half *W, const nvr_half *Wt,
                                      int64_t T, int64_t K, int64_t H, int64_t KVH, int64_t D, const int64_t *pos, const int32_t *slots,
                                      const float *cos_t, const float *sin_t, nvr_half *qkv, nvr_half *kc, nvr_half *vc, void *s) {
-    return k::linear_qkv_rope_store_normed(h, ldx, wn, eps, W, T, K, H, KVH, D, pos, slots, cos_t, sin_t, qkv, kc, vc, (hipStream_t)s, Wt);
+    return KO(linear_qkv_rope_store_normed(h, ldx, wn, eps, W, T, K, H, KVH, D, pos, slots, cos_t, sin_t, qkv, kc, vc, (hipStream_t)s, Wt));
 }
 int nvr_linear_silu_mul(const nvr_half *x, int64_t ldx, const nvr_half *W, int64_t T, int64_t K, int64_t I, nvr_half *out, void *s) {
-    return k::linear_silu_mul(x, ldx, W, T, K, I, out, (hipStream_t)s);
+    return KO(linear_silu_mul(x, ldx, W, T, K, I, out, (hipStream_t)s));
 }
 int nvr_linear_qkv_rope_store(const nvr_half *x, int64_t ldx, const nvr_half *W, int64_t T, int64_t K, int64_t H, int64_t KVH,
                               int64_t D, const int64_t *pos, const int32_t *slots, const float *c, const float *sn,
                               nvr_half *qkv, nvr_half *kc, nvr_half *vc, void *s) {
-    return k::linear_qkv_rope_store(x, ldx, W, T, K, H, KVH, D, pos, slots, c, sn, qkv, kc, vc, (hipStream_t)s);
+    return KO(linear_qkv_rope_store(x, ldx, W, T, K, H, KVH, D, pos, slots, c, sn, qkv, kc, vc, (hipStream_t)s));
 }
 int nvr_rope_store_kv(nvr_half *qkv, const int64_t *pos, const int32_t *slots, int64_t T, int64_t H, int64_t KVH, int64_t D,
                       const float *c, const float *sn, nvr_half *kc, nvr_half *vc, void *s) {
-    return k::rope_store_kv(qkv, pos, slots, T, H, KVH, D, c, sn, kc, vc, (hipStream_t)s);
+    return KO(rope_store_kv(qkv, pos, slots, T, H, KVH, D, c, sn, kc, vc, (hipStream_t)s));
 }
 int nvr_qk_norm_rope_store_kv(nvr_half *qkv, const int64_t *pos, const int32_t *slots, int64_t T, int64_t H, int64_t KVH, int64_t D,
                               const float *c, const float *sn, const nvr_half *qw, const nvr_half *kw, float eps, nvr_half *kc, nvr_half *vc,
                               void *s) {
     if (!qw || !kw) return nvr::fail(NVR_ERR_INVALID_ARG, "nvr_qk_norm_rope_store_kv: norm weights are null");
-    return k::rope_store_kv(qkv, pos, slots, T, H, KVH, D, c, sn, kc, vc, (hipStream_t)s, qw, kw, eps);
+    return KO(rope_store_kv(qkv, pos, slots, T, H, KVH, D, c, sn, kc, vc, (hipStream_t)s, qw, kw, eps));
 }
 int nvr_rope_table(int64_t D, int64_t max_pos, double theta, float *cos_dev, float *sin_dev) {   // rotary_embedding.rs:74-119 (A-14)
     NVR_GUARD_BEGIN
@@ -577,7 +587,7 @@ int nvr_paged_attn_decode(const nvr_half *q, int64_t ldq, const nvr_half *kc, co
     a.q = q; a.ldq = ldq; a.k = kc; a.v = vc; a.ctx_lens = m->context_lens; a.block_tables = m->block_tables;
     a.max_blocks = m->max_blocks; a.block_size = (int32_t)bs; a.nq = m->batch; a.H = (int32_t)H; a.KVH = (int32_t)KVH;
     a.D = (int32_t)D; a.scale = scale; a.max_ctx = m->max_context_len; a.out = out; a.workspace = ws;
-    return k::attention(a, true, (hipStream_t)s);
+    return KO(attention(a, true, (hipStream_t)s));
 }
 int nvr_paged_attn_decode_shared(const nvr_half *q, int64_t ldq, const nvr_half *kc, const nvr_half *vc, const nvr_attn_meta *m,
                                  int64_t H, int64_t KVH, int64_t D, int64_t bs, float scale, int64_t shared_len, const int32_t *rows,
@@ -587,7 +597,7 @@ int nvr_paged_attn_decode_shared(const nvr_half *q, int64_t ldq, const nvr_half 
     a.max_blocks = m->max_blocks; a.block_size = (int32_t)bs; a.nq = m->batch; a.H = (int32_t)H; a.KVH = (int32_t)KVH;
     a.D = (int32_t)D; a.scale = scale; a.max_ctx = m->max_context_len; a.out = out; a.workspace = ws;
     a.shared_len = (int32_t)shared_len; a.shared_rows = rows; a.shared_kv0 = kv0; a.shared_count = count;
-    return k::attention(a, true, (hipStream_t)s);
+    return KO(attention(a, true, (hipStream_t)s));
 }
 // host-side tile list for the flash kernels from cu_seqlens_q (+ context lens for the paged variant)
 static int run_prefill_attn(const nvr_half *q, int64_t ldq, const nvr_half *kk, const nvr_half *v, int64_t ldkv, const nvr_attn_meta *m,
@@ -613,7 +623,7 @@ static int run_prefill_attn(const nvr_half *q, int64_t ldq, const nvr_half *kk, 
         f.q = q; f.ldq = ldq; f.k = kk; f.v = v; f.ldkv = ldkv; f.block_tables = m->block_tables; f.max_blocks = m->max_blocks;
         f.block_size = (int32_t)bs; f.tiles = d; f.ntiles = (int32_t)tiles.size(); f.H = (int32_t)H; f.KVH = (int32_t)KVH; f.D = (int32_t)D;
         f.scale = scale; f.out = out;
-        rc = k::flash_prefill(f, paged, st);
+        rc = KO(flash_prefill(f, paged, st));
         hipStreamSynchronize(st);
         hipFree(d);
     } else {
@@ -633,7 +643,7 @@ static int run_prefill_attn(const nvr_half *q, int64_t ldq, const nvr_half *kk, 
         if (paged) { a.seq_of_q = d + T; a.block_tables = m->block_tables; a.max_blocks = m->max_blocks; a.block_size = (int32_t)bs; }
         else a.kv_base = d + T;
         a.H = (int32_t)H; a.KVH = (int32_t)KVH; a.D = (int32_t)D; a.scale = scale; a.max_ctx = maxc; a.out = out;
-        rc = k::attention(a, paged, st);
+        rc = KO(attention(a, paged, st));
         hipStreamSynchronize(st);
         hipFree(d);
     }
@@ -651,15 +661,15 @@ int nvr_attn_prefill_paged(const nvr_half *q, int64_t ldq, const nvr_half *kc, c
     return run_prefill_attn(q, ldq, kc, vc, 0, m, true, bs, T, H, KVH, D, scale, out, (hipStream_t)s);
     NVR_GUARD_END(NVR_ERR_INVARIANT)
 }
-int nvr_silu_and_mul(const nvr_half *x, int64_t T, int64_t I, nvr_half *out, void *s) { return k::silu_and_mul(x, T, I, out, (hipStream_t)s); }
+int nvr_silu_and_mul(const nvr_half *x, int64_t T, int64_t I, nvr_half *out, void *s) { return KO(silu_and_mul(x, T, I, out, (hipStream_t)s)); }
 int nvr_select_last_tokens(const nvr_half *h, const int32_t *cu, int64_t B, int64_t Hd, nvr_half *out, void *s) {
-    return k::select_last_tokens(h, cu, B, Hd, out, (hipStream_t)s);
+    return KO(select_last_tokens(h, cu, B, Hd, out, (hipStream_t)s));
 }
 int nvr_argmax(const float *logits, int64_t B, int64_t V, int64_t *out, void *s) { return k::argmax(logits, B, V, out, nullptr, 0, (hipStream_t)s); }
 size_t nvr_sample_workspace_bytes(int64_t B, int64_t V) { return k::sample_workspace_bytes(B, V); }
 int nvr_sample(const float *logits, int64_t B, int64_t V, const float *temp, const int64_t *top_k, const float *top_p,
                const uint64_t *keys, int64_t *out, void *ws, void *s) {
-    return k::sample(logits, B, V, temp, top_k, top_p, keys, out, ws, (hipStream_t)s);
+    return KO(sample(logits, B, V, temp, top_k, top_p, keys, out, ws, (hipStream_t)s));
 }
 uint64_t nvr_sample_key(uint64_t seed, uint64_t seq_id, uint64_t step) {
     return nvr::splitmix64(nvr_weight_key_impl(seed, seq_id) + step * 0xA24BAED4963EE407ULL);
@@ -668,8 +678,8 @@ uint64_t nvr_weight_key(uint64_t seed, uint64_t tid) { return nvr_weight_key_imp
 float nvr_weight_scale(double std) { return nvr_weight_scale_impl(std); }
 int nvr_fill_weight(nvr_half *dst, int64_t rows, int64_t cols, int64_t ld, int64_t gcols, int64_t row0, int64_t col0,
                     uint64_t key, float scale, void *s) {
-    return k::fill_weight(dst, rows, cols, ld, gcols, row0, col0, key, scale, (hipStream_t)s);
+    return KO(fill_weight(dst, rows, cols, ld, gcols, row0, col0, key, scale, (hipStream_t)s));
 }
-int nvr_fill_const(nvr_half *dst, int64_t n, float v, void *s) { return k::fill_const(dst, n, v, (hipStream_t)s); }
+int nvr_fill_const(nvr_half *dst, int64_t n, float v, void *s) { return KO(fill_const(dst, n, v, (hipStream_t)s)); }
 
 }  // extern "C"
