@@ -296,6 +296,11 @@ def prefill_sweep(nvr, lens=(128, 256, 512, 1024, 2048, 4096), nseq: int = 256) 
             nvr.lib().nvr_seq_reset_id_counter()
             eng = nvr.LLMEngine(nvr.Config(max_num_seqs=nseq, max_num_batched_tokens=32768, max_model_len=L + 16, kvcache_block_size=BLOCK,
                                            num_kvcache_blocks=nseq * nblk + 8, enable_chunked_prefill=chunked), mc)
+            for i in range(nseq):                                            # warm pass: same shape, other tokens, finishes with its prefill
+                eng.add_request(nvr.synthetic_tokens(L, 3, i, mc.c.vocab_size).tolist(), nvr.SamplingParams(temperature=0.0, max_tokens=1, ignore_eos=True))
+            while not eng.is_finished():
+                eng.step()
+            eng.take_finished()
             for i in range(nseq):
                 eng.add_request(nvr.synthetic_tokens(L, 1, i, mc.c.vocab_size).tolist(), nvr.SamplingParams(temperature=0.0, max_tokens=2, ignore_eos=True))
             nvr.synchronize(); steps = 0; dt = 0.0
@@ -446,9 +451,12 @@ def main() -> None:
 
     def run_decode(eng):
         """prefill (untimed), W warm-up steps, K timed steps between barriers; max over ranks"""
-        # a warm engine, as in serving: one 512-token request run to completion first, so that the measured prefill step does not pay
-        # the first-launch cost of every kernel (code-object loading: 2.5 ms of host time in front of a 36 ms step, r03 host trace)
-        eng.add_request(nvr.synthetic_tokens(512, 3, 0, mc.c.vocab_size).tolist(), nvr.SamplingParams(temperature=0.0, max_tokens=2, ignore_eos=True))
+        # a warm engine, as in serving: the same-shape prefill run once first on other tokens (seed 3; one new token per sequence, so
+        # the batch finishes with its prefill and its blocks return to the pool), so that the measured prefill step does not pay
+        # first-use costs — code-object loading of the kernels this shape routes to and first-touch of the workspaces: 2.5 ms of a
+        # first 32 x 1024 prefill against 35.2-35.3 ms for every later one (scratch/prefill_wall.py)
+        for i in range(BATCH):
+            eng.add_request(nvr.synthetic_tokens(PROMPT_LEN, 3, i, mc.c.vocab_size).tolist(), nvr.SamplingParams(temperature=0.0, max_tokens=1, ignore_eos=True))
         while not eng.is_finished():
             eng.step()
         eng.take_finished()
@@ -692,7 +700,7 @@ def main() -> None:
             "prefill": {"tokens": BATCH * PROMPT_LEN, "seconds": round(t_prefill, 4), "tokens_per_s": round(BATCH * PROMPT_LEN / t_prefill, 1),
                         "tflop_per_s": round(prefill_flop / t_prefill / 1e12, 1), "mfma_frac_of_2500": round(prefill_flop / t_prefill / 2.5e15, 4),
                         "mfma_busy_frac_pmc": _pmc_prefill_busy(),
-                        "note": "one untimed engine prefill step on a warm engine (wall clock, includes host input preparation and upload; a 512-token warm-up "
+                        "note": "one untimed engine prefill step on a warm engine (wall clock, includes host input preparation and upload; a same-shape warm-up prefill on other tokens "
                                 "request ran before it); "
                                 "mfma_busy_frac_pmc = matrix-pipe busy cycles / available cycles at the clock the chip held, from the "
                                 "committed counter pass profiles/pmc_mfma_prefill_latest.json (tp1 kernels)"},
