@@ -49,9 +49,21 @@ __global__ __launch_bounds__(256) void p2p_allreduce_kernel(P2PArgs a) {
         half_t *dst = HP(a.peer_slots[peer]) + ((size_t)parity * 8 + a.rank) * slot_elems;
         const auto rs = __builtin_amdgcn_make_buffer_rsrc(dst, 0, (int)(total16 * 16), 0x00020000);
         typedef unsigned int u4 __attribute__((ext_vector_type(4)));
-        for (size_t i = lo + tid; i < hi; i += 256) {
-            const u4 v = *reinterpret_cast<const u4 *>(reinterpret_cast<const char *>(a.in) + i * 16);
-            __builtin_amdgcn_raw_buffer_store_b128(v, rs, (int)(i * 16), 0, 17);                 // sc0 sc1: system scope, write-through
+        // PB pieces requested per thread before the first store: as a plain load / store loop every iteration waits for its own load
+        // (one round trip per 4 KiB of this workgroup's quarter: 4 for a 64 KiB message, 16 for 256 KiB)
+        constexpr int PB = 8;
+        for (size_t i0 = lo + tid; i0 < hi; i0 += 256 * PB) {
+            u4 v[PB];
+#pragma unroll
+            for (int f = 0; f < PB; ++f) {
+                const size_t i = i0 + (size_t)f * 256;
+                v[f] = *reinterpret_cast<const u4 *>(reinterpret_cast<const char *>(a.in) + (i < hi ? i : hi - 1) * 16);
+            }
+#pragma unroll
+            for (int f = 0; f < PB; ++f) {
+                const size_t i = i0 + (size_t)f * 256;
+                if (i < hi) __builtin_amdgcn_raw_buffer_store_b128(v[f], rs, (int)(i * 16), 0, 17);   // sc0 sc1: system scope, write-through
+            }
         }
         __threadfence_system();
         __syncthreads();

@@ -44,6 +44,30 @@ __device__ __forceinline__ float dot2(half2_t a, half2_t b, float c) {
     return __builtin_amdgcn_fdot2(a, b, c, false);
 #endif
 }
+// Activation block x[T, cols] (row stride ldx, columns col0 .. col0 + 8*cpr) -> LDS image of ROWS rows x cpr 16-byte chunks, chunk ch of
+// row r at slot ch ^ (r & 7) (conflict-free ds_read_b128 of MFMA B fragments); rows >= T repeat row T-1.  FB loads are requested per
+// thread before the first LDS write: written as a plain load / store loop hipcc keeps ONE load in flight per thread (load, s_waitcnt
+// vmcnt(0), ds_write, branch), i.e. one L2 round trip per 8 KiB of the image (r03: 16 round trips per 128 KiB chunk of the streaming
+// GEMMs, 8 in front of the LM head).
+template <int ROWS, int THREADS, int FB>
+__device__ __forceinline__ void fill_x_image(char *smem, const half_t *__restrict__ x, int64_t ldx, int col0, int cpr, int T, int tid) {
+    const int total = ROWS * cpr;
+    for (int c0 = tid; c0 < total; c0 += THREADS * FB) {
+        half8_t v[FB];
+        int slot[FB];
+#pragma unroll
+        for (int f = 0; f < FB; ++f) {
+            const int c = c0 + f * THREADS, cc = c < total ? c : total - 1;       // (clamped: the load is unconditional, only the write is guarded)
+            const int row = cc / cpr, ch = cc - row * cpr;
+            const int m = row < T ? row : T - 1;
+            v[f] = *reinterpret_cast<const half8_t *>(x + (int64_t)m * ldx + col0 + ch * 8);
+            slot[f] = c < total ? row * cpr + (ch ^ (row & 7)) : -1;
+        }
+#pragma unroll
+        for (int f = 0; f < FB; ++f)
+            if (slot[f] >= 0) *reinterpret_cast<half8_t *>(smem + (int64_t)slot[f] * 16) = v[f];
+    }
+}
 // ds_read_b64_tr_b16: the hardware-transposed LDS read of 4 rows x 16 columns of 16-bit elements (cdna guide T10)
 __device__ __forceinline__ half4_t lds_read_tr16(const char *lds_addr) {
 #ifdef NVR_BF16

@@ -60,12 +60,7 @@ __global__ __launch_bounds__(WAVES * 64) void linear_stream_kernel(const half_t 
 
     for (int kc0 = 0; kc0 < K; kc0 += KC) {
         __syncthreads();                                                     // the previous chunk's readers are done
-        for (int c = tid; c < ROWS * cpr; c += WAVES * 64) {
-            const int row = c / cpr, ch = c - row * cpr;
-            const int m = row < T ? row : T - 1;
-            const half8_t v = *reinterpret_cast<const half8_t *>(x + (int64_t)m * ldx + kc0 + ch * 8);
-            *reinterpret_cast<half8_t *>(smem + ((int64_t)row * cpr + (ch ^ (row & 7))) * 16) = v;
-        }
+        fill_x_image<ROWS, WAVES * 64, 8>(smem, x, ldx, kc0, cpr, T, tid);
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < TMAX; ++i) {

@@ -35,12 +35,7 @@ __global__ __launch_bounds__(WAVES * 64) void lm_head_kernel(const half_t *__res
     constexpr int ROWS = MT * 16;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 15, q = lane >> 4;
     const int cpr = K / 8;                                       // 16-byte chunks per activation row
-    for (int c = tid; c < ROWS * cpr; c += WAVES * 64) {
-        const int row = c / cpr, ch = c - row * cpr;
-        const int m = row < T ? row : T - 1;
-        const half8_t v = *reinterpret_cast<const half8_t *>(x + (int64_t)m * ldx + ch * 8);
-        *reinterpret_cast<half8_t *>(smem + ((int64_t)row * cpr + (ch ^ (row & 7))) * 16) = v;
-    }
+    fill_x_image<ROWS, WAVES * 64, 8>(smem, x, ldx, 0, cpr, T, tid);
     __syncthreads();
 
     const int ntiles = N / 16, nw = gridDim.x * WAVES;
