@@ -103,6 +103,94 @@ __global__ __launch_bounds__(WAVES * 64) void lm_head_kernel(const half_t *__res
     }
 }
 
+// K > 2048 (hidden 4096-class models: 32 x K fp16 no longer fits the LDS): the activation block passes through LDS in chunks of KC
+// columns and every wave keeps the f32 accumulators of ALL its tiles (at most TPW: tiles w, w + nw, ...) in registers across the
+// chunks — the weights are still streamed exactly once, tile by tile inside a chunk, and the epilogue is the one above (logits on
+// demand, arg-max partials, tiles ascending so that the first maximum is kept).
+template <int MT, int WAVES, int U, int TPW>
+__global__ __launch_bounds__(WAVES * 64) void lm_head_kchunk_kernel(const half_t *__restrict__ x, int64_t ldx,
+                                                                    const half_t *__restrict__ W, int T, int K, int N, int KC,
+                                                                    float *__restrict__ y, float *__restrict__ pval,
+                                                                    int32_t *__restrict__ pidx, int flags) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int ROWS = MT * 16;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 15, q = lane >> 4;
+    const int cpr = KC / 8;
+    const int ntiles = N / 16, nw = gridDim.x * WAVES, w0 = blockIdx.x * WAVES + wave;
+    const bool tiled = flags & 2;
+    const int kmul = tiled ? 16 : 1;
+    float4_t acc[TPW][MT];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
+    for (int kc0 = 0; kc0 < K; kc0 += KC) {
+        __syncthreads();                                                     // the previous chunk's readers are done
+        fill_x_image<ROWS, WAVES * 64, 8>(smem, x, ldx, kc0, cpr, T, tid);
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+            const int tile = w0 + i * nw;
+            if (tile >= ntiles) break;                                       // wave-uniform
+            const half_t *wr = tiled ? W + ((int64_t)tile * (K / 32) + kc0 / 32) * 512 + r * 32 + q * 8 : W + ((int64_t)tile * 16 + r) * K + kc0 + q * 8;
+            for (int k0 = 0; k0 < KC; k0 += 32 * U) {
+                half8_t a[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) a[u] = __builtin_nontemporal_load(reinterpret_cast<const half8_t *>(wr + (int64_t)(k0 + u * 32) * kmul));
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int ch = (k0 >> 3) + u * 4 + q;
+#pragma unroll
+                    for (int j = 0; j < MT; ++j) {
+                        const int row = j * 16 + r;
+                        const half8_t b = *reinterpret_cast<const half8_t *>(smem + ((int64_t)row * cpr + (ch ^ (r & 7))) * 16);
+                        acc[i][j] = mfma16(a[u], b, acc[i][j]);
+                    }
+                }
+            }
+        }
+    }
+    float best[MT]; int besti[MT];
+#pragma unroll
+    for (int j = 0; j < MT; ++j) { best[j] = -INFINITY; besti[j] = 0x7fffffff; }
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        const int tile = w0 + i * nw;
+        if (tile >= ntiles) break;
+        const int n0 = tile * 16 + q * 4;
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+            const int m = j * 16 + r;
+            if (m < T && !(flags & 1)) *reinterpret_cast<float4_t *>(y + (int64_t)m * N + n0) = acc[i][j];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (acc[i][j][e] > best[j]) { best[j] = acc[i][j][e]; besti[j] = n0 + e; }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < MT; ++j)
+#pragma unroll
+        for (int o = 16; o < 64; o <<= 1) {
+            const float v = __shfl_xor(best[j], o, 64);
+            const int i2 = __shfl_xor(besti[j], o, 64);
+            take_better(best[j], besti[j], v, i2);
+        }
+    __syncthreads();
+    float *sv = reinterpret_cast<float *>(smem);
+    int *si = reinterpret_cast<int *>(smem + WAVES * ROWS * 4);
+    if (q == 0) {
+#pragma unroll
+        for (int j = 0; j < MT; ++j) { sv[wave * ROWS + j * 16 + r] = best[j]; si[wave * ROWS + j * 16 + r] = besti[j]; }
+    }
+    __syncthreads();
+    if (tid < T) {
+        float bv = sv[tid]; int bi = si[tid];
+        for (int w2 = 1; w2 < WAVES; ++w2) take_better(bv, bi, sv[w2 * ROWS + tid], si[w2 * ROWS + tid]);
+        pval[(int64_t)blockIdx.x * T + tid] = bv;
+        pidx[(int64_t)blockIdx.x * T + tid] = bi;
+    }
+}
+
 __global__ __launch_bounds__(64) void argmax_partials_kernel(const float *__restrict__ pval, const int32_t *__restrict__ pidx,
                                                              int nparts, int T, int64_t *__restrict__ out_idx,
                                                              float *__restrict__ out_val, int64_t idx_offset, int64_t *__restrict__ out_idx2,
@@ -147,15 +235,19 @@ __global__ __launch_bounds__(256) void tp_argmax_merge_kernel(const TpArgmaxRec 
     out_host[b] = bi;
 }
 
+constexpr int LM_KC = 2048, LM_TPW = 8;                             // K-chunked form: columns per chunk, tiles per wave held in registers
+static bool lm_kchunk(int64_t K) { return K > LM_KC; }
 bool lm_head_ok(int64_t T, int64_t K, int64_t N, int64_t ldx) {
-    return T >= 1 && T <= 32 && K % 256 == 0 && K <= 2048 && N % 16 == 0 && N >= 16 && ldx % 8 == 0 && N < (1ll << 31);
+    if (!(T >= 1 && T <= 32 && K % 256 == 0 && N % 16 == 0 && N >= 16 && ldx % 8 == 0 && N < (1ll << 31))) return false;
+    if (!lm_kchunk(K)) return true;
+    return K % LM_KC == 0 && K <= 8192 && N / 16 <= 256ll * 8 * LM_TPW;       // every wave's tiles fit its accumulator registers
 }
 
 struct LmPlan { int mt, waves, U; int64_t nwg; };
 static LmPlan lm_plan(int64_t T, int64_t K, int64_t N) {
     LmPlan pl;
     pl.mt = T <= 16 ? 1 : 2;
-    const size_t lds = (size_t)pl.mt * 16 * K * 2;
+    const size_t lds = (size_t)pl.mt * 16 * (lm_kchunk(K) ? LM_KC : K) * 2;
     int per_cu = 1;
     if ((size_t)per_cu * lds > 160 * 1024) per_cu = (int)(160 * 1024 / lds);
     pl.waves = 8; pl.U = 4;
@@ -172,8 +264,7 @@ int32_t lm_head_parts(int64_t T, int64_t K, int64_t N, int64_t ldx) {
 }
 
 // every compiled (MT, WAVES, U) instance, as X(mt, waves, U)
-#define NVR_LM_INSTANCES(X) X(1, 8, 4) X(2, 8, 4) X(1, 4, 8) X(2, 4, 8) X(1, 4, 4) X(2, 4, 4) X(1, 8, 8) X(2, 8, 8) \
-                            X(1, 8, 2) X(2, 8, 2) X(2, 16, 2) X(2, 16, 4) X(2, 4, 2)
+#define NVR_LM_INSTANCES(X) X(1, 8, 4) X(2, 8, 4)
 
 // > 64 KiB of dynamic LDS needs an opt-in per kernel; done for all instances on the first (never captured: a
 // sequence is prefilled eagerly before any decode graph exists) call
@@ -188,6 +279,8 @@ static int lm_allow_big_lds() {
     }
     NVR_LM_INSTANCES(NVR_LM_ATTR)
 #undef NVR_LM_ATTR
+    for (const void *f : {reinterpret_cast<const void *>(&lm_head_kchunk_kernel<1, 8, 4, LM_TPW>), reinterpret_cast<const void *>(&lm_head_kchunk_kernel<2, 8, 4, LM_TPW>)})
+        if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return nvr::fail(NVR_ERR_HIP, "lm_head: hipFuncSetAttribute (K-chunked form)");
     done = true;
     return 0;
 }
@@ -198,7 +291,7 @@ int lm_head(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int6
     if (!lm_head_ok(T, K, N, ldx)) {
         if (gemm_tiled_lm_head_ok(T, K, N, ldx))                       // more than 32 rows: 128x128 tiles, same outputs
             return gemm_tiled_lm_head(x, ldx, W, T, K, N, store_logits ? logits : nullptr, part_val, part_idx, nparts, s);
-        return nvr::fail(NVR_ERR_UNSUPPORTED, "lm_head: T=%ld K=%ld N=%ld (T <= 32: K multiple of 256 and <= 2048; T > 32: K multiple of 64, "
+        return nvr::fail(NVR_ERR_UNSUPPORTED, "lm_head: T=%ld K=%ld N=%ld (T <= 32: K multiple of 256 up to 2048, or of 2048 up to 8192; T > 32: K multiple of 64, "
                          "N <= 128 * %d; N multiple of 16)", (long)T, (long)K, (long)N, LM_HEAD_MAX_PARTS);
     }
     const LmPlan pl = lm_plan(T, K, N);
@@ -207,9 +300,15 @@ int lm_head(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int6
     *nparts = (int32_t)nwg;
     const half_t *xx = (const half_t *)x, *ww = (const half_t *)(Wt ? Wt : W);
     if (int rc0 = lm_allow_big_lds()) return rc0;
-    const size_t lds = (size_t)mt * 16 * K * 2;
+    const size_t lds = (size_t)mt * 16 * (lm_kchunk(K) ? LM_KC : K) * 2;
     bool launched = false;
     const int dbg_flags = (store_logits ? 0 : 1) | (Wt ? 2 : 0);   // bit 0: skip the f32 logit stores (arg-max partials only); bit 1: tiled W
+    if (lm_kchunk(K)) {
+        if (nwg * waves * LM_TPW < N / 16) return nvr::fail(NVR_ERR_INVARIANT, "lm_head: %ld tiles on %ld waves", (long)(N / 16), (long)(nwg * waves));
+        if (mt == 1) lm_head_kchunk_kernel<1, 8, 4, LM_TPW><<<dim3((unsigned)nwg), dim3(512), lds, s>>>(xx, ldx, ww, (int)T, (int)K, (int)N, LM_KC, logits, part_val, part_idx, dbg_flags);
+        else lm_head_kchunk_kernel<2, 8, 4, LM_TPW><<<dim3((unsigned)nwg), dim3(512), lds, s>>>(xx, ldx, ww, (int)T, (int)K, (int)N, LM_KC, logits, part_val, part_idx, dbg_flags);
+        launched = true;
+    }
 #define NVR_LM(MT_, WV_, U_)                                                                                          \
     if (!launched && mt == MT_ && waves == WV_ && U == U_) {                                                          \
         lm_head_kernel<MT_, WV_, U_><<<dim3((unsigned)nwg), dim3(WV_ * 64), lds, s>>>(xx, ldx, ww, (int)T, (int)K, (int)N, logits, \

@@ -256,7 +256,8 @@ def test_attn_prefill_varlen(H, KVH, D, lens):
     assert_close_bf16(out16(d_out, (T, H, D)), ref, ulps=2, atol=1.6e-2, what="varlen prefill attention (bf16)")
 
 
-@pytest.mark.parametrize("T,K,N", [(32, 1024, 151936), (7, 1024, 18992), (16, 2048, 4096), (128, 1024, 151936), (33, 4096, 2064)])
+@pytest.mark.parametrize("T,K,N", [(32, 1024, 151936), (7, 1024, 18992), (16, 2048, 4096), (128, 1024, 151936), (33, 4096, 2064), (32, 4096, 151936),
+                                   (5, 6144, 2064)])
 def test_lm_head_logits_and_argmax_partials(T, K, N):
     rng = np.random.default_rng(31)
     x, xb = b16(rng.standard_normal((T, K)))
