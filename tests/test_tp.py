@@ -521,8 +521,8 @@ def test_peer_that_never_arrives_fails_the_step_and_the_group_recovers():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("tp", [2, 4])
-def test_tensor_parallel_launch_ahead_is_transparent(tp):
+@pytest.mark.parametrize("tp,hidden", [(2, 256), (4, 256), (2, 4096)])       # hidden 4096: the K-chunked fused LM head of 8B-class models
+def test_tensor_parallel_launch_ahead_is_transparent(tp, hidden):
     """Row g: launch-ahead (nvr_config.async_decode) on tensor-parallel ranks.  The vocabulary-sharded greedy tokens are merged on the
     DEVICE (every rank's (max, arg-max) records all-gathered through the peer arenas, rank-ordered merge, ids straight into the next
     step's device-side input ids), so the next decode step is enqueued before the host has seen the current tokens — on every rank, from
@@ -535,7 +535,7 @@ def test_tensor_parallel_launch_ahead_is_transparent(tp):
     sys.path.insert(0, ROOT)
     import nvr_import
     nvr = nvr_import.load()
-    m = mo.small(seed=26, num_attention_heads=8, num_key_value_heads=4, head_dim=64, hidden_size=256, intermediate_size=512)
+    m = mo.small(seed=26, num_attention_heads=8, num_key_value_heads=4, head_dim=64, hidden_size=hidden, intermediate_size=512)
     mc = nvr.ModelConfig(vocab_size=m.vocab_size, hidden_size=m.hidden_size, intermediate_size=m.intermediate_size,
                          num_hidden_layers=m.num_hidden_layers, num_attention_heads=m.num_attention_heads,
                          num_key_value_heads=m.num_key_value_heads, head_dim=m.head_dim, max_position_embeddings=m.max_position_embeddings,
