@@ -261,7 +261,11 @@ NVR_API int nvr_runner_comm_selftest(nvr_model_runner_t *r);
 /* In-process stand-in for the communicator (tests / bring-up on a one-GPU box; no performance claim): the ranks are N runners
  * of ONE process on ONE device, each driven by its own host thread; a collective is a host rendezvous plus a device sum /
  * copies over the peers' buffers.  Same call sites and results as the RCCL path (linear.rs:236-238, embed_head.rs:321-336);
- * decode steps run eagerly.  The group outlives its runners' use of it. */
+ * decode steps run eagerly.  The group outlives its runners' use of it.
+ * Ranks that share a device wait for each other INSIDE kernels (the one-shot collectives), so while the ranks are stepping no thread
+ * of the process may make a call that waits for the whole device — hipDeviceSynchronize, hipFree / hipMalloc, a default-stream copy,
+ * destroying another engine (a garbage collector doing so counts): it would wait for a peer's kernel that waits for the caller's own
+ * next launch, until NVR_P2P_TIMEOUT_MS ends the wait with NVR_ERR_RCCL.  One process per GPU (the deployment) has no such coupling. */
 typedef struct nvr_local_group nvr_local_group_t;
 NVR_API nvr_local_group_t *nvr_local_group_create(int nranks);
 NVR_API void nvr_local_group_destroy(nvr_local_group_t *g);

@@ -197,7 +197,17 @@ __global__ __launch_bounds__(64) void argmax_partials_kernel(const float *__rest
                                                              TpArgmaxRec *__restrict__ out_rec) {
     const int m = blockIdx.x, lane = threadIdx.x;
     float bv = -INFINITY; int bi = 0x7fffffff;
-    for (int p = lane; p < nparts; p += 64) take_better(bv, bi, pval[(int64_t)p * T + m], pidx[(int64_t)p * T + m]);
+    for (int p0 = lane; p0 < nparts; p0 += 256) {                 // 4 partials per lane requested together (256 partials: one round trip)
+        float pv[4]; int pi[4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            const int p = p0 + f * 64, pp = p < nparts ? p : nparts - 1;
+            pv[f] = pval[(int64_t)pp * T + m]; pi[f] = pidx[(int64_t)pp * T + m];
+        }
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+            if (p0 + f * 64 < nparts) take_better(bv, bi, pv[f], pi[f]);
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         const float v = __shfl_xor(bv, o, 64);
