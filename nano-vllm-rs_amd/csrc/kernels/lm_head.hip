@@ -245,19 +245,25 @@ __global__ __launch_bounds__(256) void tp_argmax_merge_kernel(const TpArgmaxRec 
     out_host[b] = bi;
 }
 
-constexpr int LM_KC = 2048, LM_TPW = 8;                             // K-chunked form: columns per chunk, tiles per wave held in registers
+constexpr int LM_KC = 2048, LM_TPW = 8;                             // K-chunked form: columns per chunk (at most), tiles per wave held in registers
 static bool lm_kchunk(int64_t K) { return K > LM_KC; }
+// chunk width: K in the fewest equal chunks of <= 2048 columns that are multiples of 256 (4096 -> 2048, 5120 -> 1280, 6144 -> 2048); 0: none
+static int lm_kc(int64_t K) {
+    for (int64_t n = (K + LM_KC - 1) / LM_KC; n * 256 <= K; ++n)
+        if (K % n == 0 && (K / n) % 256 == 0) return (int)(K / n);
+    return 0;
+}
 bool lm_head_ok(int64_t T, int64_t K, int64_t N, int64_t ldx) {
     if (!(T >= 1 && T <= 32 && K % 256 == 0 && N % 16 == 0 && N >= 16 && ldx % 8 == 0 && N < (1ll << 31))) return false;
     if (!lm_kchunk(K)) return true;
-    return K % LM_KC == 0 && K <= 8192 && N / 16 <= 256ll * 8 * LM_TPW;       // every wave's tiles fit its accumulator registers
+    return K <= 16384 && lm_kc(K) > 0 && N / 16 <= 256ll * 8 * LM_TPW;        // every wave's tiles fit its accumulator registers
 }
 
 struct LmPlan { int mt, waves, U; int64_t nwg; };
 static LmPlan lm_plan(int64_t T, int64_t K, int64_t N) {
     LmPlan pl;
     pl.mt = T <= 16 ? 1 : 2;
-    const size_t lds = (size_t)pl.mt * 16 * (lm_kchunk(K) ? LM_KC : K) * 2;
+    const size_t lds = (size_t)pl.mt * 16 * (lm_kchunk(K) ? lm_kc(K) : K) * 2;
     int per_cu = 1;
     if ((size_t)per_cu * lds > 160 * 1024) per_cu = (int)(160 * 1024 / lds);
     pl.waves = 8; pl.U = 4;
@@ -301,7 +307,7 @@ int lm_head(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int6
     if (!lm_head_ok(T, K, N, ldx)) {
         if (gemm_tiled_lm_head_ok(T, K, N, ldx))                       // more than 32 rows: 128x128 tiles, same outputs
             return gemm_tiled_lm_head(x, ldx, W, T, K, N, store_logits ? logits : nullptr, part_val, part_idx, nparts, s);
-        return nvr::fail(NVR_ERR_UNSUPPORTED, "lm_head: T=%ld K=%ld N=%ld (T <= 32: K multiple of 256 up to 2048, or of 2048 up to 8192; T > 32: K multiple of 64, "
+        return nvr::fail(NVR_ERR_UNSUPPORTED, "lm_head: T=%ld K=%ld N=%ld (T <= 32: K multiple of 256 (above 2048: in equal chunks of <= 2048 that are multiples of 256); T > 32: K multiple of 64, "
                          "N <= 128 * %d; N multiple of 16)", (long)T, (long)K, (long)N, LM_HEAD_MAX_PARTS);
     }
     const LmPlan pl = lm_plan(T, K, N);
@@ -310,13 +316,13 @@ int lm_head(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int6
     *nparts = (int32_t)nwg;
     const half_t *xx = (const half_t *)x, *ww = (const half_t *)(Wt ? Wt : W);
     if (int rc0 = lm_allow_big_lds()) return rc0;
-    const size_t lds = (size_t)mt * 16 * (lm_kchunk(K) ? LM_KC : K) * 2;
+    const size_t lds = (size_t)mt * 16 * (lm_kchunk(K) ? lm_kc(K) : K) * 2;
     bool launched = false;
     const int dbg_flags = (store_logits ? 0 : 1) | (Wt ? 2 : 0);   // bit 0: skip the f32 logit stores (arg-max partials only); bit 1: tiled W
     if (lm_kchunk(K)) {
         if (nwg * waves * LM_TPW < N / 16) return nvr::fail(NVR_ERR_INVARIANT, "lm_head: %ld tiles on %ld waves", (long)(N / 16), (long)(nwg * waves));
-        if (mt == 1) lm_head_kchunk_kernel<1, 8, 4, LM_TPW><<<dim3((unsigned)nwg), dim3(512), lds, s>>>(xx, ldx, ww, (int)T, (int)K, (int)N, LM_KC, logits, part_val, part_idx, dbg_flags);
-        else lm_head_kchunk_kernel<2, 8, 4, LM_TPW><<<dim3((unsigned)nwg), dim3(512), lds, s>>>(xx, ldx, ww, (int)T, (int)K, (int)N, LM_KC, logits, part_val, part_idx, dbg_flags);
+        if (mt == 1) lm_head_kchunk_kernel<1, 8, 4, LM_TPW><<<dim3((unsigned)nwg), dim3(512), lds, s>>>(xx, ldx, ww, (int)T, (int)K, (int)N, lm_kc(K), logits, part_val, part_idx, dbg_flags);
+        else lm_head_kchunk_kernel<2, 8, 4, LM_TPW><<<dim3((unsigned)nwg), dim3(512), lds, s>>>(xx, ldx, ww, (int)T, (int)K, (int)N, lm_kc(K), logits, part_val, part_idx, dbg_flags);
         launched = true;
     }
 #define NVR_LM(MT_, WV_, U_)                                                                                          \

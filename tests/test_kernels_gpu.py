@@ -337,7 +337,7 @@ def test_argmax_exact_with_ties():
                                    (128, 1024, 151936), (100, 512, 5008), (300, 256, 1000 * 16), (33, 4096, 2064),
                                    # K > 2048 (Qwen3-8B: hidden 4096): the activation block goes through LDS in 2048-column chunks, every wave
                                    # keeps its tiles' accumulators in registers across the chunks
-                                   (32, 4096, 151936), (7, 4096, 18992), (16, 6144, 4096), (1, 8192, 48), (32, 4096, 16 * 2048 * 8)])
+                                   (32, 4096, 151936), (7, 4096, 18992), (16, 6144, 4096), (1, 8192, 48), (32, 4096, 16 * 2048 * 8), (8, 5120, 4096), (20, 2560, 1024)])
 def test_lm_head_logits_and_argmax_partials(T, K, N):
     """lm_head: f32 logits == oracle linear (f32 sums in another order), and the arg-max that rides along in the epilogue
     is EXACTLY the lowest-index arg-max of the logits the kernel itself wrote (ties included)."""
