@@ -864,23 +864,26 @@ int nvr_model_runner::comm_selftest() {
     if (!comm.comm && !comm.local && !comm.p2p_ready) return nvr::fail(NVR_ERR_RCCL, "comm_selftest: communicator not initialised");
     const int n = 4096;
     std::vector<uint16_t> hbuf(n);
-    for (int i = 0; i < n; ++i) hbuf[i] = 0x3C00;                 // fp16 1.0
+    for (int i = 0; i < n; ++i) hbuf[i] = bf16 ? 0x3F80 : 0x3C00; // 1.0 in the runner's 16-bit type
     NVR_HIP_CHECK(hipMemcpyAsync(proj, hbuf.data(), n * 2, hipMemcpyHostToDevice, stream));
     RC(comm.all_reduce_sum_f16(proj, n, stream));
     NVR_HIP_CHECK(hipMemcpyAsync(hbuf.data(), proj, n * 2, hipMemcpyDeviceToHost, stream));
     NVR_HIP_CHECK(hipStreamSynchronize(stream));
-    const uint16_t want[9] = {0, 0x3C00, 0x4000, 0x4200, 0x4400, 0x4500, 0x4600, 0x4700, 0x4800};   // fp16 of 0..8
+    const uint16_t want_h[9] = {0, 0x3C00, 0x4000, 0x4200, 0x4400, 0x4500, 0x4600, 0x4700, 0x4800};   // fp16 of 0..8
+    const uint16_t want_b[9] = {0, 0x3F80, 0x4000, 0x4040, 0x4080, 0x40A0, 0x40C0, 0x40E0, 0x4100};   // bf16 of 0..8
+    const uint16_t *want = bf16 ? want_b : want_h;
     for (int i = 0; i < n; ++i)
         if (hbuf[i] != want[comm.nranks]) return nvr::fail(NVR_ERR_RCCL, "comm_selftest: all-reduce gave 0x%04x at %d, want 0x%04x", hbuf[i], i, want[comm.nranks]);
     if (tp > 1) {
-        std::vector<int64_t> mine(8, rank), all(8 * tp, -1);
-        NVR_HIP_CHECK(hipMemcpyAsync(d_tok, mine.data(), 64, hipMemcpyHostToDevice, stream));
-        RC(comm.all_gather_bytes(d_tok, d_gather_idx, 64, stream));
-        NVR_HIP_CHECK(hipMemcpyAsync(all.data(), d_gather_idx, 64 * tp, hipMemcpyDeviceToHost, stream));
+        const int64_t nr = std::min<int64_t>(8, max_seqs);                 // the token buffers hold max_num_seqs entries per rank
+        std::vector<int64_t> mine(nr, rank), all(nr * tp, -1);
+        NVR_HIP_CHECK(hipMemcpyAsync(d_tok, mine.data(), nr * 8, hipMemcpyHostToDevice, stream));
+        RC(comm.all_gather_bytes(d_tok, d_gather_idx, (size_t)nr * 8, stream));
+        NVR_HIP_CHECK(hipMemcpyAsync(all.data(), d_gather_idx, nr * 8 * tp, hipMemcpyDeviceToHost, stream));
         NVR_HIP_CHECK(hipStreamSynchronize(stream));
         for (int64_t r = 0; r < tp; ++r)
-            for (int j = 0; j < 8; ++j)
-                if (all[r * 8 + j] != r) return nvr::fail(NVR_ERR_RCCL, "comm_selftest: all-gather slot %ld holds %ld", (long)r, (long)all[r * 8 + j]);
+            for (int64_t j = 0; j < nr; ++j)
+                if (all[r * nr + j] != r) return nvr::fail(NVR_ERR_RCCL, "comm_selftest: all-gather slot %ld holds %ld", (long)r, (long)all[r * nr + j]);
     }
     return comm.p2p_check_error(stream);
 }

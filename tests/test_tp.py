@@ -578,3 +578,100 @@ def test_tensor_parallel_launch_ahead_is_transparent(tp, hidden):
     ts, none = run(0)
     assert ta == ts and len(ta) > 25
     assert all(n >= 10 for n in launched) and len(set(launched)) == 1 and not any(none), (launched, none)
+
+
+_IPC_WORKER = r'''
+import os, sys, json
+sys.path.insert(0, os.environ["NVR_ROOT"])
+import nvr_import
+nvr = nvr_import.load()                      # (libnvr.so and the HIP runtime before torch)
+import torch, torch.distributed as dist
+import oracle
+from oracle import model_oracle as mo
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+m = mo.small(seed=31, num_attention_heads=8, num_key_value_heads=4, head_dim=64, hidden_size=256, intermediate_size=512)
+mc = nvr.ModelConfig(vocab_size=m.vocab_size, hidden_size=m.hidden_size, intermediate_size=m.intermediate_size, num_hidden_layers=m.num_hidden_layers,
+                     num_attention_heads=m.num_attention_heads, num_key_value_heads=m.num_key_value_heads, head_dim=m.head_dim,
+                     max_position_embeddings=m.max_position_embeddings, rms_norm_eps=m.rms_norm_eps, rope_theta=m.rope_theta,
+                     tie_word_embeddings=m.tie_word_embeddings, init_std=m.init_std, seed=m.seed)
+dtype = os.environ.get("NVR_TEST_DTYPE", "float16")
+eng = nvr.LLMEngine(nvr.Config(skip_block_size_check=1, max_num_seqs=4, max_num_batched_tokens=256, max_model_len=160, kvcache_block_size=64, num_kvcache_blocks=16,
+                               tensor_parallel_size=world, tensor_parallel_rank=rank, device_ordinal=0, async_decode=1, dtype=dtype), mc)
+gathered = [None] * world
+dist.all_gather_object(gathered, (eng.model_runner.p2p_export(), 0))        # hipIpc handle of my arena; every rank sits on device 0
+eng.model_runner.p2p_attach([g[0] for g in gathered], [g[1] for g in gathered])
+dist.barrier()
+eng.model_runner.comm_selftest()
+dist.barrier()
+for i, (n, mt) in enumerate([(9, 30), (40, 22), (17, 30)]):
+    eng.add_request(oracle.fill_tokens(n, 5, i, m.vocab_size).tolist(), nvr.SamplingParams(temperature=0.0, max_tokens=mt, ignore_eos=True))
+trace = []
+while not eng.is_finished():
+    rec = eng.step()
+    trace.append([bool(rec["is_prefill"]), len(rec["seq_ids"]), list(rec["tokens"])])
+out = [None] * world
+dist.all_gather_object(out, (trace, eng.ahead_launched()))
+if rank == 0:
+    json.dump(out, open(os.environ["NVR_OUT"], "w"))
+dist.barrier()
+del eng
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["float16", "bfloat16"])
+def test_two_processes_sharing_the_gpu_exchange_over_hipipc(tmp_path, dtype):
+    """The DEPLOYMENT form of tensor parallel — one PROCESS per rank, arenas exported with hipIpcGetMemHandle and mapped with
+    hipIpcOpenMemHandle (nvr_runner_p2p_export / _attach), control plane over gloo — on the one GPU a test box has: both ranks on device 0.
+    The one-shot collectives, the device-side arg-max merge and launch-ahead then run across process boundaries; both ranks must report
+    the same per-step batches and tokens, steps must have been launched ahead, and the token streams must be bit-identical to the
+    in-process group's (same kernels, same rank-ordered sums: only the way the arenas were mapped differs)."""
+    import json
+    import threading
+    sys.path.insert(0, ROOT)
+    import nvr_import
+    import oracle
+    from oracle import model_oracle as mo
+    nvr = nvr_import.load()
+    script = tmp_path / "ipc_worker.py"
+    script.write_text(_IPC_WORKER)
+    outp = tmp_path / "ipc.json"
+    env = dict(os.environ, NVR_ROOT=ROOT, NVR_OUT=str(outp), NVR_TEST_DTYPE=dtype, OMP_NUM_THREADS="2")
+    port = 29700 + os.getpid() % 2000
+    subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                    "--master-port", str(port), str(script)], check=True, env=env, timeout=300, cwd=ROOT)
+    got = json.load(open(outp))
+    (t0, a0), (t1, a1) = got
+    assert t0 == t1 and len(t0) > 25, "the two processes disagree"
+    assert a0 == a1 and a0 >= 10, (a0, a1)
+    # the same two ranks as runners of THIS process
+    m = mo.small(seed=31, num_attention_heads=8, num_key_value_heads=4, head_dim=64, hidden_size=256, intermediate_size=512)
+    mc = nvr.ModelConfig(vocab_size=m.vocab_size, hidden_size=m.hidden_size, intermediate_size=m.intermediate_size, num_hidden_layers=m.num_hidden_layers,
+                         num_attention_heads=m.num_attention_heads, num_key_value_heads=m.num_key_value_heads, head_dim=m.head_dim,
+                         max_position_embeddings=m.max_position_embeddings, rms_norm_eps=m.rms_norm_eps, rope_theta=m.rope_theta,
+                         tie_word_embeddings=m.tie_word_embeddings, init_std=m.init_std, seed=m.seed)
+    group = nvr.LocalGroup(2)
+    engines, traces, errors = [], [[], []], []
+    for r in range(2):
+        e = nvr.LLMEngine(nvr.Config(skip_block_size_check=1, max_num_seqs=4, max_num_batched_tokens=256, max_model_len=160, kvcache_block_size=64,
+                                     num_kvcache_blocks=16, tensor_parallel_size=2, tensor_parallel_rank=r, async_decode=1, dtype=dtype), mc)
+        group.attach(e.model_runner)
+        nvr.lib().nvr_seq_reset_id_counter()
+        for i, (n, mt) in enumerate([(9, 30), (40, 22), (17, 30)]):
+            e.add_request(oracle.fill_tokens(n, 5, i, m.vocab_size).tolist(), nvr.SamplingParams(temperature=0.0, max_tokens=mt, ignore_eos=True))
+        engines.append(e)
+
+    def drive(r):
+        try:
+            while not engines[r].is_finished():
+                rec = engines[r].step()
+                traces[r].append([bool(rec["is_prefill"]), len(rec["seq_ids"]), list(rec["tokens"])])
+        except BaseException as ex:                                                     # noqa: BLE001
+            errors.append((r, ex))
+    ths = [threading.Thread(target=drive, args=(r,)) for r in range(2)]
+    for t in ths: t.start()
+    for t in ths: t.join(120)
+    assert not errors, errors
+    assert traces[0] == traces[1] == t0, "two processes over hipIpc and two in-process ranks must sample the same tokens"
