@@ -296,11 +296,6 @@ def prefill_sweep(nvr, lens=(128, 256, 512, 1024, 2048, 4096), nseq: int = 256) 
             nvr.lib().nvr_seq_reset_id_counter()
             eng = nvr.LLMEngine(nvr.Config(max_num_seqs=nseq, max_num_batched_tokens=32768, max_model_len=L + 16, kvcache_block_size=BLOCK,
                                            num_kvcache_blocks=nseq * nblk + 8, enable_chunked_prefill=chunked), mc)
-            for i in range(nseq):                                            # warm pass: same shape, other tokens, finishes with its prefill
-                eng.add_request(nvr.synthetic_tokens(L, 3, i, mc.c.vocab_size).tolist(), nvr.SamplingParams(temperature=0.0, max_tokens=1, ignore_eos=True))
-            while not eng.is_finished():
-                eng.step()
-            eng.take_finished()
             for i in range(nseq):
                 eng.add_request(nvr.synthetic_tokens(L, 1, i, mc.c.vocab_size).tolist(), nvr.SamplingParams(temperature=0.0, max_tokens=2, ignore_eos=True))
             nvr.synchronize(); steps = 0; dt = 0.0
@@ -439,7 +434,10 @@ def main() -> None:
 
     def make_engine(tp_size: int, tp_rank: int):
         cfg = nvr.Config(max_num_seqs=BATCH, max_num_batched_tokens=min(BATCH * PROMPT_LEN, 32768), max_model_len=PROMPT_LEN + total_new + 16,
-                         kvcache_block_size=BLOCK, num_kvcache_blocks=BATCH * ((PROMPT_LEN + total_new + 16) // BLOCK + 2),
+                         # the pool holds the batch twice: the measured batch then takes never-used, consecutive blocks after the warm-up
+                         # prefill's have gone to the back of the free list (its attention reads K/V as contiguous cache rows; on a
+                         # recycled free list it walks the block tables: +1.1 ms per 32 x 1024 prefill, prefill.kv_source says which)
+                         kvcache_block_size=BLOCK, num_kvcache_blocks=2 * BATCH * ((PROMPT_LEN + total_new + 16) // BLOCK + 2),
                          tensor_parallel_size=tp_size, tensor_parallel_rank=tp_rank,
                          device_ordinal=local_rank, enforce_eager=args.eager, async_decode=0 if args.sync_decode else 1)
         return nvr.LLMEngine(cfg, mc)
@@ -448,6 +446,8 @@ def main() -> None:
         nvr.synchronize()
         if dist is not None:
             dist.barrier()
+
+    kv_source = [-1]
 
     def run_decode(eng):
         """prefill (untimed), W warm-up steps, K timed steps between barriers; max over ranks"""
@@ -472,6 +472,7 @@ def main() -> None:
             pre_seqs += info["num_seqs"]
         nvr.synchronize()
         t_pre = time.perf_counter() - t0
+        kv_source[0] = eng.model_runner.last_prefill_kv_source()
         for _ in range(args.warmup):
             info = eng.step()
             assert not info["is_prefill"] and info["num_seqs"] == BATCH
@@ -700,6 +701,7 @@ def main() -> None:
             "prefill": {"tokens": BATCH * PROMPT_LEN, "seconds": round(t_prefill, 4), "tokens_per_s": round(BATCH * PROMPT_LEN / t_prefill, 1),
                         "tflop_per_s": round(prefill_flop / t_prefill / 1e12, 1), "mfma_frac_of_2500": round(prefill_flop / t_prefill / 2.5e15, 4),
                         "mfma_busy_frac_pmc": _pmc_prefill_busy(),
+                        "kv_source": {0: "the step's qkv buffer", 1: "the cache rows, contiguous (consecutive blocks)", 2: "the caches through the block tables"}.get(kv_source[0], "n/a"),
                         "note": "one untimed engine prefill step on a warm engine (wall clock, includes host input preparation and upload; a same-shape warm-up prefill on other tokens "
                                 "request ran before it); "
                                 "mfma_busy_frac_pmc = matrix-pipe busy cycles / available cycles at the clock the chip held, from the "

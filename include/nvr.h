@@ -292,6 +292,10 @@ NVR_API int nvr_runner_p2p_reset(nvr_model_runner_t *r);
 NVR_API int nvr_runner_comm_drop_rccl(nvr_model_runner_t *r);
 /* tokens of the last decode step that went through the shared-prefix attention pass (nvr_config.shared_prefix_min_seqs); 0 = plain */
 NVR_API int64_t nvr_runner_last_shared_prefix_len(const nvr_model_runner_t *r);
+/* Where the last PREFILL step's attention read K / V (attention.rs:177-222): 0 = the step's qkv buffer (FlashAttention::forward_varlen on
+ * the fresh projections), 1 = the cache rows themselves, contiguous (whole prompts whose blocks are consecutive: the qkv GEMM then writes
+ * K / V once, into the caches), 2 = the caches through the block tables (cached prefixes, prompt chunks); -1 = the last step was a decode */
+NVR_API int nvr_runner_last_prefill_kv_source(const nvr_model_runner_t *r);
 NVR_API int64_t nvr_runner_last_shared_prefix_rows(const nvr_model_runner_t *r);   /* sequences of that step inside the sharing group */
 
 /* -------------------------------------------------------------------- Engine ---- */

@@ -183,6 +183,7 @@ _SIGS = {
     "nvr_runner_p2p_disable": (C.c_int, [_P]), "nvr_runner_p2p_active": (C.c_int, [_P]),
     "nvr_runner_p2p_reset": (C.c_int, [_P]), "nvr_runner_comm_drop_rccl": (C.c_int, [_P]),
     "nvr_engine_abort_last_batch": (C.c_int, [_P]), "nvr_engine_ahead_declined": (C.c_uint64, [_P]), "nvr_engine_ahead_launched": (C.c_uint64, [_P]),
+    "nvr_runner_last_prefill_kv_source": (C.c_int, [_P]),
     "nvr_runner_last_shared_prefix_len": (C.c_int64, [_P]), "nvr_runner_last_shared_prefix_rows": (C.c_int64, [_P]),
     "nvr_engine_last_step": (None, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(C.c_size_t)]),
     "nvr_engine_take_finished": (C.c_size_t, [_P, C.POINTER(_P), C.c_size_t]),
@@ -687,6 +688,10 @@ class ModelRunner:
 
     def comm_drop_rccl(self) -> None:
         check(lib().nvr_runner_comm_drop_rccl(self.h))
+
+    def last_prefill_kv_source(self) -> int:
+        """0: the last prefill's attention read K/V from the qkv buffer, 1: from contiguous cache rows, 2: through the block tables; -1: decode."""
+        return int(lib().nvr_runner_last_prefill_kv_source(self.h))
 
     def last_shared_prefix_len(self) -> int:
         """Tokens of the last decode step that went through the shared-prefix attention pass (0: plain paged attention)."""

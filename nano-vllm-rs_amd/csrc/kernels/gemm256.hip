@@ -38,6 +38,7 @@ struct G256Epi {
     const int64_t *pos; const int32_t *slots; const float *cos_t, *sin_t;
     half_t *kc, *vc;
     int32_t H, KVH, D;
+    int32_t kv_cache_only;             // GEPI_ROPE: k and v rows go to the caches only (the attention that follows reads them there)
 };
 
 #ifndef G256_STAMPS
@@ -395,8 +396,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const half_t *__restrict__
                     }
                     if (m >= T) continue;
                     half_t *yrow = y + (int64_t)m * ldy + bx * OUTC;
-                    *reinterpret_cast<half8_t *>(yrow + ch1 * 8) = o1;
-                    *reinterpret_cast<half8_t *>(yrow + ch2 * 8) = o2;
+                    if (rhead < epi.H || !epi.kv_cache_only) {
+                        *reinterpret_cast<half8_t *>(yrow + ch1 * 8) = o1;
+                        *reinterpret_cast<half8_t *>(yrow + ch2 * 8) = o2;
+                    }
                     if (rhead >= epi.H && rslot[kk] >= 0) {
                         const bool is_k = rhead < epi.H + epi.KVH;
                         const int kvh = is_k ? rhead - epi.H : rhead - epi.H - epi.KVH;
@@ -498,13 +501,14 @@ int gemm256_silu_mul(const half_bits *x, int64_t ldx, const half_bits *W, int64_
 }
 int gemm256_qkv_rope_store(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t H, int64_t KVH, int64_t D,
                            const int64_t *positions, const int32_t *slots, const float *cos_t, const float *sin_t, half_bits *qkv,
-                           half_bits *k_cache, half_bits *v_cache, hipStream_t s) {
+                           half_bits *k_cache, half_bits *v_cache, hipStream_t s, bool kv_cache_only) {
     if (!gemm256_rope_ok(T, K, H, KVH, D, ldx)) return nvr::fail(NVR_ERR_UNSUPPORTED, "gemm256_qkv_rope_store: T=%ld K=%ld D=%ld", (long)T, (long)K, (long)D);
     if (int rc = g256_prepare()) return rc;
     const int64_t N = (H + 2 * KVH) * D;
     G256Epi e{};
     e.pos = positions; e.slots = slots; e.cos_t = cos_t; e.sin_t = sin_t; e.kc = (half_t *)k_cache; e.vc = (half_t *)v_cache;
     e.H = (int32_t)H; e.KVH = (int32_t)KVH; e.D = (int32_t)D;
+    e.kv_cache_only = (kv_cache_only && slots && k_cache && v_cache) ? 1 : 0;
     const int tx = (int)(N / 256), tt = tx * (int)((T + 255) / 256);
     if (D == 128)
         gemm256_kernel<GEPI_ROPE, 128><<<dim3((unsigned)g256_grid(tt)), dim3(512), 2 * G_BUF + 4096, s>>>((const half_t *)x, ldx, (const half_t *)W, (int)T, (int)K,

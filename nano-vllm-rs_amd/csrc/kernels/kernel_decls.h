@@ -60,7 +60,9 @@ int linear_silu_mul(const half_bits *x, int64_t ldx, const half_bits *W, int64_t
 int linear_qkv_rope_store(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t H,
                           int64_t KVH, int64_t D, const int64_t *positions, const int32_t *slots, const float *cos_t,
                           const float *sin_t, half_bits *qkv, half_bits *k_cache, half_bits *v_cache, hipStream_t s,
-                          const half_bits *Wt = nullptr);
+                          const half_bits *Wt = nullptr, bool kv_cache_only = false);
+// kv_cache_only: the caller's attention reads K / V from the caches only, so the k and v columns of qkv need not be written (the 256^2
+// prefill kernel then skips those stores: a third of its output bytes; the other routes write them anyway)
 
 // The decode chain in four launches per layer (linear_decode.hip): the residual add rides on the split-k reduction of the
 // row-parallel GEMMs (last arriver of a tile), the RMSNorm in the prologue of the GEMM that consumes it.
@@ -118,7 +120,7 @@ bool gemm256_preferred(int64_t T, int64_t K, int64_t N, int64_t ldx);     // lin
 int gemm256_silu_mul(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t I, half_bits *out, hipStream_t s);
 int gemm256_qkv_rope_store(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t H, int64_t KVH, int64_t D,
                            const int64_t *positions, const int32_t *slots, const float *cos_t, const float *sin_t, half_bits *qkv,
-                           half_bits *k_cache, half_bits *v_cache, hipStream_t s);
+                           half_bits *k_cache, half_bits *v_cache, hipStream_t s, bool kv_cache_only = false);
 
 size_t attn_workspace_bytes(int64_t nq, int64_t H, int64_t D, int64_t max_ctx);
 int attention(const AttnArgs &a, bool paged, hipStream_t s);

@@ -359,12 +359,13 @@ int linear_silu_mul(const half_bits *x, int64_t ldx, const half_bits *W, int64_t
 // qkv GEMM + RoPE on q,k heads + store of k,v rows into the paged caches
 int linear_qkv_rope_store(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t H,
                           int64_t KVH, int64_t D, const int64_t *positions, const int32_t *slots, const float *cos_t,
-                          const float *sin_t, half_bits *qkv, half_bits *k_cache, half_bits *v_cache, hipStream_t s, const half_bits *Wt) {
+                          const float *sin_t, half_bits *qkv, half_bits *k_cache, half_bits *v_cache, hipStream_t s, const half_bits *Wt,
+                          bool kv_cache_only) {
     if (K % 32 || D % 16 || ldx % 8)
         return nvr::fail(NVR_ERR_UNSUPPORTED, "linear_qkv_rope_store: K=%ld must be a multiple of 32, D=%ld of 16", (long)K, (long)D);
     if (T == 0) return 0;
     if (gemm256_rope_ok(T, K, H, KVH, D, ldx) && prefer_256(T, K, (H + 2 * KVH) * D))                                  // see linear()
-        return gemm256_qkv_rope_store(x, ldx, W, T, K, H, KVH, D, positions, slots, cos_t, sin_t, qkv, k_cache, v_cache, s);
+        return gemm256_qkv_rope_store(x, ldx, W, T, K, H, KVH, D, positions, slots, cos_t, sin_t, qkv, k_cache, v_cache, s, kv_cache_only);
     if (gemm_tiled_ok(T, K, (H + 2 * KVH) * D, ldx) && 128 % D == 0 && !prefer_stream(T, (H + 2 * KVH) * D))
         return gemm_tiled_qkv_rope_store(x, ldx, W, T, K, H, KVH, D, positions, slots, cos_t, sin_t, qkv, k_cache, v_cache, s);
     if (linear_stream_rope_ok(T, K, H, KVH, D, ldx))                                                                  // large weights

@@ -89,6 +89,7 @@ struct nvr_model_runner {
     int32_t lm_parts_of_last_step() const { return lm_parts; }
     // single rank, or tensor-parallel ranks whose collectives are the stream-ordered peer-to-peer kernels (no host rendezvous): every
     // rank takes the same decisions from the same scheduler state and merges the same gathered (max, arg-max) records on the device
+    int last_prefill_kv_source() const { return !last_prefill ? -1 : prefill_paged ? 2 : (prefill_kv_cache && n_tiles > 0) ? 1 : 0; }
     bool ahead_capable() const {
         return lm_fused && h_tok_dev != nullptr && ahead_tok[0] != nullptr && ((tp == 1 && !comm.active()) || (tp > 1 && comm.p2p_ready));
     }
@@ -113,6 +114,7 @@ private:
     // sharing group of a decode batch (0 = none / too small: plain paged attention); fills kv0[nseq], rows[nseq], *count of the arena
     int64_t shared_prefix_plan(nvr_seq *const *seqs, size_t nseq, int32_t *kv0, int32_t *rows, int32_t *count, int64_t *members) const;
     mutable std::vector<int32_t> plan_keys, plan_cnt;    // scratch of the plan (first-block id -> count)
+    bool prefill_kv_cache = false;                  // whole-prompt prefill whose K/V the flash kernel reads from the (contiguous) cache rows
     bool prefill_paged = false;                          // this prefill step skips cached prefixes (K/V via block tables)
     bool lazy_logits = true, want_logits = true, logits_valid = true; const uint16_t *lm_input = nullptr;
     bool lm_fused = true; int32_t lm_parts = 0;          // lm_head arg-max partials of the last step (0: none)

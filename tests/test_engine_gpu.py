@@ -899,3 +899,62 @@ def test_shared_prefix_group_is_the_most_common_prompt():
         if not rec["is_prefill"]:
             seen.add((rec["num_seqs"], p.model_runner.last_shared_prefix_len(), p.model_runner.last_shared_prefix_rows()))
     assert (13, 128, 5) in seen, seen
+
+
+def test_prefill_reads_kv_from_the_caches_contiguous_rows_or_block_tables():
+    """The flash prefill kernel takes K / V from the caches, never from the step's qkv buffer (the 256^2 qkv GEMM then writes them once and
+    skips the k / v columns of the qkv buffer).  A whole-prompt prefill whose sequences all sit in consecutive cache blocks reads the cache
+    rows in the kernel's contiguous form (nvr_runner_last_prefill_kv_source = 1); once the free list has been recycled the block tables are
+    no longer consecutive and the kernel walks them (2), as it does behind a cached prefix (2).  The forms see the same bits: logits of the
+    prefill and of the following decode steps are IDENTICAL whichever way K / V reached the attention kernel, and in parity with the
+    oracle.  Shape: hidden 512, 4:2 heads x 128 (qkv width 1024, K 512: the 256^2 GEMM route for batches of >= 256 rows)."""
+    mcfg = mo.small(seed=12, hidden_size=512, num_attention_heads=4, num_key_value_heads=2, head_dim=128, intermediate_size=768)
+    V = mcfg.vocab_size
+    # 64 blocks: the three prompts need 19 + 5 + 33; after the scrambling requests (24 blocks, freed interleaved) the allocations run past
+    # the never-used blocks into the freed ones
+    ecfg = dict(max_num_seqs=8, max_num_batched_tokens=2048, max_model_len=640, kvcache_block_size=16, num_kvcache_blocks=64)
+    prompts = [oracle.fill_tokens(n, 6, i, V).tolist() for i, n in enumerate([300, 70, 513])]
+    sps = [dict(temperature=0.0, max_tokens=4, ignore_eos=True)] * 3
+
+    def run(scramble, **kw):
+        nvr.lib().nvr_seq_reset_id_counter()
+        p = nvr.LLMEngine(nvr.Config(skip_block_size_check=1, **ecfg, **kw), _model_cfgs(mcfg))
+        if scramble:          # requests of different lengths that finish at different steps: their blocks return to the free list interleaved
+            for i, (n, mt) in enumerate([(40, 3), (90, 9), (20, 5), (150, 2), (33, 7)]):
+                p.add_request(oracle.fill_tokens(n, 7, 50 + i, V).tolist(), nvr.SamplingParams(temperature=0.0, max_tokens=mt, ignore_eos=True))
+            while not p.is_finished():
+                p.step()
+            p.take_finished()
+        for pr, sp in zip(prompts, sps):
+            p.add_request(pr, nvr.SamplingParams(**sp))
+        out, src, tables = [], None, None
+        while not p.is_finished():
+            rec = p.step()
+            if rec["is_prefill"]:
+                src = p.model_runner.last_prefill_kv_source()
+                tables = [list(s.block_table) for s in p.last_batch()]
+            else:
+                assert p.model_runner.last_prefill_kv_source() == -1
+            out.append((rec["is_prefill"], tuple(rec["tokens"]), p.model_runner.logits(rec["num_seqs"]).copy()))
+        return out, src, tables
+    fresh, src_f, tab_f = run(False)
+    scr, src_s, tab_s = run(True)
+    consecutive = lambda t: all(b == a + 1 for a, b in zip(t, t[1:]))
+    assert src_f == 1 and all(consecutive(t) for t in tab_f), (src_f, tab_f)
+    assert src_s == 2 and not all(consecutive(t) for t in tab_s), (src_s, tab_s)
+    assert len(fresh) == len(scr) == 4
+    for a, b in zip(fresh, scr):
+        assert a[:2] == b[:2] and np.array_equal(a[2], b[2]), "K/V from contiguous cache rows and through the block tables must give identical logits"
+    # the longest prompt again behind a cached prefix of 25 full blocks: through the block tables, same last-token logits
+    nvr.lib().nvr_seq_reset_id_counter()
+    p = nvr.LLMEngine(nvr.Config(skip_block_size_check=1, **ecfg), _model_cfgs(mcfg))
+    p.add_request(prompts[2][:400], nvr.SamplingParams(temperature=0.0, max_tokens=6, ignore_eos=True))     # stays alive: its blocks keep their hashes
+    assert p.step()["is_prefill"]
+    p.add_request(prompts[2], nvr.SamplingParams(**sps[2]))
+    rec = p.step()
+    assert rec["is_prefill"] and rec["num_tokens"] == 513 - 400, rec
+    assert p.model_runner.last_prefill_kv_source() == 2
+    assert rec["tokens"][0] == fresh[0][1][2]
+    # and against the oracle
+    r = _run_pair(mcfg, ecfg, prompts, sps)
+    assert r["near_ties"] <= 1, r
