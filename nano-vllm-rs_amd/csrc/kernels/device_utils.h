@@ -44,6 +44,11 @@ __device__ __forceinline__ float dot2(half2_t a, half2_t b, float c) {
     return __builtin_amdgcn_fdot2(a, b, c, false);
 #endif
 }
+// sigmoid of SiluAndMul (activation.rs:46-63) for every kernel that applies it (the fused and the unfused forms must agree bit for bit):
+// v_exp_f32 + v_rcp_f32 (1 ulp each in f32, far below the fp16 / bf16 rounding that follows) instead of the ~10-instruction IEEE division
+// — the epilogue of the 256^2 gate_up GEMM is not overlapped with matrix work: -3..5 % on that kernel.
+__device__ __forceinline__ float sigmoid_fast(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+
 // Activation block x[T, cols] (row stride ldx, columns col0 .. col0 + 8*cpr) -> LDS image of ROWS rows x cpr 16-byte chunks, chunk ch of
 // row r at slot ch ^ (r & 7) (conflict-free ds_read_b128 of MFMA B fragments); rows >= T repeat row T-1.  FB loads are requested per
 // thread before the first LDS write: written as a plain load / store loop hipcc keeps ONE load in flight per thread (load, s_waitcnt

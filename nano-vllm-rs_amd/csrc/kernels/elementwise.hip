@@ -316,7 +316,7 @@ __global__ void silu_mul_kernel(const half_t *__restrict__ x, int I, half_t *__r
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             float gf = (float)g[j];
-            float sg = 1.0f / (1.0f + __expf(-gf));
+            float sg = sigmoid_fast(gf);
             o[j] = to_half_rn(__fmul_rn(__fmul_rn(gf, sg), (float)u[j]));
         }
         *reinterpret_cast<half8_t *>(out + t * I + c) = o;

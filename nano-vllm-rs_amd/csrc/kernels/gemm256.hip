@@ -338,7 +338,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const half_t *__restrict__
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const float gf = (float)to_half_rn(acc[0][i][hB][j][e]), uf = (float)to_half_rn(acc[1][i][hB][j][e]);
-                            const float sg = 1.0f / (1.0f + __expf(-gf));
+                            const float sg = sigmoid_fast(gf);
                             h[e] = to_half_rn(__fmul_rn(__fmul_rn(gf, sg), uf));
                         }
                         put(ml, wn * 64 + i * 16 + q * 4, h);

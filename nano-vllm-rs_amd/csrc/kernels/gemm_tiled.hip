@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(const half_t *__restric
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float gf = (float)to_half_rn(acc[i][j][e]), uf = (float)to_half_rn(acc[i + 2][j][e]);
-                    const float sg = 1.0f / (1.0f + __expf(-gf));
+                    const float sg = sigmoid_fast(gf);
                     h[e] = to_half_rn(__fmul_rn(__fmul_rn(gf, sg), uf));
                 }
                 stash(ml, wn * 32 + i * 16 + q * 4, h);

@@ -137,7 +137,7 @@ __global__ __launch_bounds__(WAVES * 64) void linear_stream_kernel(const half_t 
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float gf = (float)to_half_rn(g4[e]), uf = (float)to_half_rn(u4[e]);
-                        const float sg = 1.0f / (1.0f + __expf(-gf));
+                        const float sg = sigmoid_fast(gf);
                         h[e] = to_half_rn(__fmul_rn(__fmul_rn(gf, sg), uf));
                     }
                     *reinterpret_cast<half4_t *>(y + (int64_t)m * N + n) = h;
