@@ -170,12 +170,20 @@ __global__ __launch_bounds__(64 * FLASH_WAVES, 8 / FLASH_WAVES) void flash_prefi
     const int wave_last = SHARED ? kv_end - 1
         : __builtin_amdgcn_readfirstlane(tile.pos0 + min(tile.nq - 1, (G == 1 ? wave * 2 + 1 : (G == 2 ? wave : (wave >> 1))) * 16 + 15));
     int bt_reg = 0, bt_chunk = -1;                                    // UB: register copy of 64 block-table entries
+    // The chunk is fetched by an inline-asm load that waits for itself: a compiler-visible load inside the step loop (the reload of a
+    // context longer than 64 blocks) makes hipcc put s_waitcnt vmcnt(0) in front of EVERY v_readlane of bt_reg, i.e. into every step —
+    // and that wait also drains the K/V tiles in flight by LDS-DMA (which the compiler does not see): the ring then runs one tile deep
+    // (paged form 258 vs 217 us per layer at 32 x 1024).  The reload itself is rare (once per 64 blocks) and may block.
     auto load_bt_chunk = [&](int c) {
         bt_chunk = c;
-        const int idx = (c << 6) + lane;
-        bt_reg = idx < p.max_blocks ? p.block_tables[(int64_t)tile.kv_ref * p.max_blocks + idx] : 0;
+        const int idx = min((c << 6) + lane, p.max_blocks - 1);                  // (entries past the table are never selected)
+        const int32_t *src = p.block_tables + (int64_t)tile.kv_ref * p.max_blocks + idx;
+        asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(bt_reg) : "v"(src) : "memory");
     };
+    // (the first chunk as an ordinary load, overlapped with the query loads, was measured: hipcc then waits for it in every step again,
+    // 36.7 ms per 32 x 1024 prefill against 35.1 with the blocking asm load)
     if (PAGED && UB) load_bt_chunk(0);
+
     // Source addresses of a tile.  Contiguous K/V and block-aligned paged steps (UB) are "scalar base of the step + a per-thread
     // constant": one 64-bit add per 16-byte piece (the general form below costs a 64-bit multiply chain per piece, ~50 VALU
     // instructions per step next to 68 MFMAs).  Keys beyond the last visible one (the final step of a tile) are clamped to it.
