@@ -366,7 +366,7 @@ int nvr_model_runner::copy_weight(const char *ln, uint16_t *out, size_t cap, int
 }
 
 // RowParallelLinear::forward (o_proj / down_proj, linear.rs:228-239) + the residual add and the next RMSNorm
-// (qwen3.rs:382-389) of the SIX-launch chain (prefill, tensor-parallel ranks, large models, NVR_DECODE_CHAIN=6): decode-sized
+// (qwen3.rs:382-389) of the SIX-launch chain (prefill, tensor-parallel ranks, large models, decode_chain = 6): decode-sized
 // steps on one GPU split k over S workgroups per output tile so that the N = hidden GEMMs reach all 256 CUs; the f32 partial
 // slabs are summed, added to the residual and normalised by the following add_rmsnorm_slabs launch.  Otherwise the plain kernel
 // writes fp16 `proj` (+ all-reduce when tensor parallel) and add_rmsnorm follows.
