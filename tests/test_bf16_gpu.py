@@ -165,3 +165,27 @@ def test_bfloat16_holds_magnitudes_fp16_cannot():
     o.add_request(prompt, eo.SamplingParams(temperature=0.0, max_tokens=2, ignore_eos=True))
     ol = o.step()["logits"]
     assert np.abs(out["bfloat16"] - ol).max() <= BF16_TOL * np.abs(ol).max()
+
+
+@pytest.mark.parametrize("seed", [111, 222, 333])
+def test_bfloat16_random_workloads_end_to_end(seed):
+    """The randomised soak of the fp16 build (test_engine_gpu.test_random_workloads_end_to_end) on the bf16 build: prompt lengths from one
+    token to several blocks, shared prefixes of whole blocks (cached prefixes: K/V through the block tables), an EOS id some sequences
+    honour, a KV pool small enough to preempt, more requests than max_num_seqs — batches, logits and tokens against the bf16 oracle."""
+    rng = np.random.default_rng(seed)
+    mcfg = mo.small(seed=seed % 7)
+    bs = int(rng.choice([16, 32]))
+    nreq = int(rng.integers(5, 11))
+    ecfg = dict(max_num_seqs=int(rng.integers(3, 7)), max_num_batched_tokens=int(rng.choice([160, 256, 512])), max_model_len=256,
+                kvcache_block_size=bs, num_kvcache_blocks=int(rng.integers(14, 30)) * (32 // bs), eos_token_id=int(rng.integers(0, mcfg.vocab_size)))
+    shared = oracle.fill_tokens(2 * bs, seed, 9999, mcfg.vocab_size).tolist()
+    prompts, sps = [], []
+    for i in range(nreq):
+        own = oracle.fill_tokens(int(rng.integers(1, 70)), seed, i, mcfg.vocab_size).tolist()
+        pr = (shared[:bs * int(rng.integers(1, 3))] + own) if rng.random() < 0.5 else own
+        prompts.append(pr[:ecfg["max_num_batched_tokens"] - 1])
+        sps.append(dict(temperature=0.0, max_tokens=int(rng.integers(1, 40)), ignore_eos=bool(rng.random() < 0.6)))
+    r = _run_pair(mcfg, ecfg, prompts, sps, max_steps=2000, **BF)
+    assert len(r["finished"]) == nreq and r["near_ties"] <= 8, r
+    for sid, toks in r["finished"].items():
+        assert toks[:len(prompts[sid])] == prompts[sid] and 1 <= len(toks) - len(prompts[sid]) <= sps[sid]["max_tokens"]
