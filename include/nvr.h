@@ -332,8 +332,8 @@ NVR_API void nvr_engine_last_step(const nvr_engine_t *e, const uint64_t **seq_id
 NVR_API size_t nvr_engine_take_finished(nvr_engine_t *e, nvr_seq_t **out, size_t cap);   /* caller destroys */
 /* Control-plane abort (tensor-parallel ranks after a peer reported NVR_ERR_RCCL; the reference's step has no error path,
  * llm_engine.rs:155-197): the sequences of the batch this engine scheduled last that are still alive leave the engine as finished,
- * their blocks returned — what a failed model step does on the rank that saw the failure.  Call before taking that step's
- * finished sequences. */
+ * their blocks returned — what a failed model step does on the rank that saw the failure.  Safe before or after
+ * taking (and destroying) that step's finished sequences: the batch is matched against the scheduler's queues by handle, never dereferenced. */
 NVR_API int nvr_engine_abort_last_batch(nvr_engine_t *e);
 /* nvr_config.async_decode: decode steps whose successor could not be enqueued ahead and therefore ran synchronously (diagnostic) */
 NVR_API uint64_t nvr_engine_ahead_declined(const nvr_engine_t *e);

@@ -111,7 +111,10 @@ int nvr_engine::step_async(nvr_step_info *info) {
             ++ahead_declined;                                            // (diagnostic counter; the step itself succeeded)
         }
     } else {
-        if (parity >= 0) { int rc = runner->sample_wait(batch.size(), parity, last_tokens.data()); if (rc) return rc; }
+        if (parity >= 0) {
+            int rc = runner->sample_wait(batch.size(), parity, last_tokens.data());
+            if (rc) { scheduler->impl.abort_batch(batch.data(), batch.size()); return rc; }   // as the synchronous step and the launch-ahead branch
+        }
         for (size_t i = 0; i < batch.size(); ++i) if (batch[i]->chunk_is_partial()) last_tokens[i] = -1;
         int rc = scheduler->impl.postprocess(batch.data(), last_tokens.data(), batch.size());
         if (rc) return rc;
@@ -130,7 +133,9 @@ int nvr_engine::step_async(nvr_step_info *info) {
 void nvr_engine::abort_last_batch() {
     cancel_ahead();
     std::vector<nvr_seq *> live;
-    for (nvr_seq *s : batch) if (s->status != NVR_SEQ_FINISHED) live.push_back(s);
+    // by membership, not through the handles: sequences that finished in that step may have been taken (and destroyed) by the caller —
+    // step -> take_finished -> learn of the peer's failure -> abort is the natural order of an external control plane
+    for (nvr_seq *s : batch) if (scheduler->impl.is_live(s)) live.push_back(s);
     if (!live.empty()) scheduler->impl.abort_batch(live.data(), live.size());
     batch.clear();
 }

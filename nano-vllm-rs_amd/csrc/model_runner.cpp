@@ -624,7 +624,9 @@ int nvr_model_runner::execute(nvr_seq *const *seqs, size_t nseq, bool is_prefill
             auto sub = [&](size_t &f, size_t bytes) { f = o; o += (bytes + 63) / 64 * 64; };
             sub(off_ids, (size_t)total * 8); sub(off_pos, (size_t)total * 8); sub(off_slots, (size_t)total * 4); sub(off_ctx, (size_t)total * 4);
             sub(off_kvbase, (size_t)total * 4); sub(off_cu, (nseq + 1) * 4);
-            sub(off_tiles, (size_t)(total / qb + (int64_t)nseq + 1) * sizeof(k::FlashTile));
+            // (tiles exist only for the flash kernel; the row-kernel path — GQA group 8, head_dim outside 64 / 128 — reserves none: with
+            //  qb = 1 a tile per token would not fit what init() carved, max_tokens / 16 tiles)
+            sub(off_tiles, flash_ok ? (size_t)(total / qb + (int64_t)nseq + 1) * sizeof(k::FlashTile) : 0);
             prefill_bytes = o;
             if (prefill_bytes > off_dec) return nvr::fail(NVR_ERR_INVARIANT, "prefill input region: %zu bytes needed, %zu carved", prefill_bytes, off_dec);
             d_ids = (int64_t *)(in_dev + off_ids); d_pos = (int64_t *)(in_dev + off_pos); d_slots = (int32_t *)(in_dev + off_slots);

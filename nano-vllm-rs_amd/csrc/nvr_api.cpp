@@ -419,7 +419,7 @@ uint64_t nvr_engine_ahead_declined(const nvr_engine_t *e) { return e->ahead_decl
 uint64_t nvr_engine_ahead_launched(const nvr_engine_t *e) { return e->ahead_launched; }
 size_t nvr_engine_last_batch(const nvr_engine_t *e, nvr_seq_t **out, size_t cap) {
     size_t n = 0;
-    for (nvr_seq *s : e->batch) if (s->status != NVR_SEQ_FINISHED && n < cap) out[n++] = s;
+    for (nvr_seq *s : e->batch) if (e->scheduler->impl.is_live(s) && n < cap) out[n++] = s;
     return n;
 }
 
@@ -429,7 +429,9 @@ int nvr_device_set(int o) { NVR_HIP_CHECK(hipSetDevice(o)); return NVR_OK; }
 int nvr_device_name(char *buf, size_t cap) {
     int d = 0; NVR_HIP_CHECK(hipGetDevice(&d));
     hipDeviceProp_t p; NVR_HIP_CHECK(hipGetDeviceProperties(&p, d));
-    std::snprintf(buf, cap, "%s (%s)", p.name, p.gcnArchName);
+    // (the marketing name comes from a driver table that minimal container images lack: the architecture, CU count and memory always identify the part)
+    std::snprintf(buf, cap, "%s (%s, %d CUs, %.0f GiB)", p.name[0] ? p.name : "AMD GPU", p.gcnArchName, p.multiProcessorCount,
+                  (double)p.totalGlobalMem / (double)(1ull << 30));
     return NVR_OK;
 }
 int nvr_device_mem_info(uint64_t *f, uint64_t *t) { size_t a = 0, b = 0; NVR_HIP_CHECK(hipMemGetInfo(&a, &b)); *f = a; *t = b; return NVR_OK; }

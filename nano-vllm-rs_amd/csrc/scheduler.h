@@ -36,6 +36,12 @@ public:
     const BlockManager &block_manager() const { return bm_->impl; }
     nvr_block_manager *block_manager_handle() { return bm_.get(); }
     size_t max_num_seqs() const { return max_num_seqs_; }
+    // a handle the scheduler still schedules (finished sequences may already be with — and destroyed by — the caller: never dereferenced here)
+    bool is_live(const nvr_seq *s) const {
+        for (const nvr_seq *r : running_) if (r == s) return true;
+        for (const nvr_seq *w : waiting_) if (w == s) return true;
+        return false;
+    }
     size_t waiting_len() const { return waiting_.size(); }
     size_t running_len() const { return running_.size(); }
     double memory_pressure() const;                                                     // :322

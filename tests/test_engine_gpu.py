@@ -164,6 +164,7 @@ def test_cached_prefix_skipping_is_bit_identical():
     # hidden, inter, heads, kv heads, head_dim, vocab, block size, prompt lengths
     dict(h=128, i=256, H=2, KVH=2, D=64, V=512, bs=4, lens=[3, 9, 21, 70]),          # G=1, tiny blocks (row groups straddle blocks)
     dict(h=256, i=384, H=8, KVH=1, D=64, V=1008, bs=16, lens=[40, 5, 17]),           # G=8: outside the MFMA flash kernel (row-kernel prefill)
+    dict(h=256, i=384, H=8, KVH=1, D=64, V=1008, bs=16, lens=[200, 200, 90]),        # the same, one prefill of 490 of the 512 budgeted tokens (no flash tiles are laid out on this path)
     dict(h=512, i=768, H=4, KVH=4, D=128, V=2048, bs=48, lens=[100, 47, 140, 1]),    # non-power-of-two block size, G=1, D=128
     dict(h=2048, i=1024, H=16, KVH=4, D=128, V=4096, bs=32, lens=[33, 64, 2]),       # hidden 2048 (16-wave GEMMs, 4 row chunks in the slab norm)
     dict(h=4096, i=512, H=8, KVH=8, D=64, V=256, bs=16, lens=[20, 8]),               # hidden 4096: no split-k slabs, plain norm path, LM head K > 2048

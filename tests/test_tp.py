@@ -521,6 +521,68 @@ def test_peer_that_never_arrives_fails_the_step_and_the_group_recovers():
 
 
 @pytest.mark.gpu
+def test_failed_token_wait_without_a_step_in_flight_aborts_the_batch():
+    """csrc/engine.cpp step_async, the tail that is NOT launching ahead (the step may be a sequence's last: max_tokens reached): when the
+    stream-ordered sampling never delivers (the peer stayed away: bounded wait -> NVR_ERR_RCCL) the batch is aborted — blocks returned,
+    nothing left in the running queue — exactly as the synchronous step and the launch-ahead branch do; a batch left scheduled would be
+    rescheduled against peers whose epochs differ.  Also: nvr_engine_abort_last_batch after the step's finished sequences were taken
+    AND destroyed by the caller (the natural order of an external control plane) touches no dead handle."""
+    import oracle
+    from oracle import model_oracle as mo
+    sys.path.insert(0, ROOT)
+    import nvr_import
+    nvr = nvr_import.load()
+    m = mo.small(seed=16, num_attention_heads=8, num_key_value_heads=4, head_dim=64, hidden_size=256, intermediate_size=512)
+    mc = nvr.ModelConfig(vocab_size=m.vocab_size, hidden_size=m.hidden_size, intermediate_size=m.intermediate_size,
+                         num_hidden_layers=m.num_hidden_layers, num_attention_heads=m.num_attention_heads,
+                         num_key_value_heads=m.num_key_value_heads, head_dim=m.head_dim, max_position_embeddings=m.max_position_embeddings,
+                         rms_norm_eps=m.rms_norm_eps, rope_theta=m.rope_theta, tie_word_embeddings=m.tie_word_embeddings,
+                         init_std=m.init_std, seed=m.seed)
+    ecfg = dict(max_num_seqs=4, max_num_batched_tokens=256, max_model_len=128, kvcache_block_size=16, num_kvcache_blocks=24,
+                skip_block_size_check=1, async_decode=1)
+    prompts = [oracle.fill_tokens(n, 5, i, m.vocab_size).tolist() for i, n in enumerate([9, 21])]
+    os.environ["NVR_P2P_TIMEOUT_MS"] = "150"
+    try:
+        group = nvr.LocalGroup(2)
+        engines = []
+        for r in range(2):
+            e = nvr.LLMEngine(nvr.Config(tensor_parallel_size=2, tensor_parallel_rank=r, **ecfg), mc)
+            group.attach(e.model_runner)
+            engines.append(e)
+    finally:
+        os.environ.pop("NVR_P2P_TIMEOUT_MS", None)
+    import threading
+    # sequence 0 stops after its 2nd token, sequence 1 goes on: the decode step after the prefill may be sequence 0's last, so it is
+    # not followed by a step launched ahead (can_launch_ahead: "this token could be the last") and ends in the plain sample_wait tail
+    sps = [dict(temperature=0.0, max_tokens=2, ignore_eos=True), dict(temperature=0.0, max_tokens=6, ignore_eos=True)]
+    for e in engines:
+        nvr.lib().nvr_seq_reset_id_counter()
+        for pr, sp in zip(prompts, sps):
+            e.add_request(pr, nvr.SamplingParams(**sp))
+    out = [None, None]
+    ts = [threading.Thread(target=lambda r=r: out.__setitem__(r, engines[r].step()["tokens"])) for r in range(2)]
+    for t in ts: t.start()
+    for t in ts: t.join(120)
+    assert out[0] == out[1] and out[0] is not None                       # the prefill, together
+    free_before = engines[0].scheduler.get_block_stats()["free_blocks"]
+    with pytest.raises(nvr.NvrError) as ei:                              # rank 1 stays away from the decode step
+        engines[0].step()
+    assert ei.value.code == -9, ei.value                                 # NVR_ERR_RCCL
+    assert engines[0].ahead_launched() == 0
+    assert engines[0].is_finished(), "the batch stayed scheduled after the failed wait"
+    st = engines[0].scheduler.get_block_stats()
+    assert st["free_blocks"] > free_before and st["free_blocks"] == st["total_blocks"]
+    # control plane on the failing rank, in the order take -> destroy -> abort
+    fin = engines[0].take_finished()
+    assert len(fin) == 2
+    del fin
+    import gc; gc.collect()
+    engines[0].abort_last_batch()                                        # nothing of that batch is live: a no-op that touches no handle
+    engines[1].abort_last_batch()
+    assert engines[1].is_finished()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("tp,hidden", [(2, 256), (4, 256), (2, 4096)])       # hidden 4096: the K-chunked fused LM head of 8B-class models
 def test_tensor_parallel_launch_ahead_is_transparent(tp, hidden):
     """Row g: launch-ahead (nvr_config.async_decode) on tensor-parallel ranks.  The vocabulary-sharded greedy tokens are merged on the
