@@ -456,10 +456,10 @@ def main() -> None:
         arm("rendezvous")
         if world != args.gpus:
             raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run)")
-        nvr.preload_rccl()                 # ROCm's librccl before torch's bundled copy can claim the soname
-        import torch.distributed as dist   # control plane only (gloo): unique-id broadcast, barrier, max
+        # control plane only (unique-id broadcast, handle exchange, agreements, barrier, max): a small TCP rendezvous on MASTER_ADDR /
+        # MASTER_PORT (nano-vllm-rs_amd/ctrl.py) — a rank process holds ONE ROCm stack (libnvr.so's) and exits normally
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist = nvr_import.load_ctrl().SocketGroup(rank=rank, world=world, timeout=100.0 if os.environ.get("NVR_BENCH_CHILD") == "1" else 300.0)
 
     total_new = args.warmup + args.steps + 1
     mc = nvr.ModelConfig(args.model)
@@ -517,10 +517,7 @@ def main() -> None:
         el = time.perf_counter() - t0
         barrier()
         if dist is not None:
-            import torch
-            t = torch.tensor([el], dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            el = float(t.item())
+            el = dist.max(el)
         return el, t_pre
 
     parallelism, scaling, jobs = "tp1", "strong", 1
@@ -531,26 +528,21 @@ def main() -> None:
 
     def init_tensor_parallel(eng):
         """Communicators of a tensor-parallel engine: RCCL (large messages, fallback) and the one-shot peer-to-peer arenas
-        (hipIpc handles gathered over the gloo control plane).  Every decision is agreed by all ranks (MIN over ranks).
+        (hipIpc handles gathered over the TCP control plane).  Every decision is agreed by all ranks (MIN over ranks).
         Returns (ok, description)."""
-        import torch
-
-        def all_ok(flag: bool) -> bool:
-            t = torch.tensor([1 if flag else 0], dtype=torch.int32)
-            dist.all_reduce(t, op=dist.ReduceOp.MIN)
-            return bool(int(t.item()))
-        uid = torch.zeros(128, dtype=torch.uint8)
+        all_ok = dist.all_ok
+        uid = bytes(128)
         if rank == 0:
             try:
-                uid = torch.frombuffer(bytearray(nvr.comm_unique_id()), dtype=torch.uint8).clone()
+                uid = bytes(nvr.comm_unique_id())
             except Exception:                                                    # noqa: BLE001
                 pass
-        dist.broadcast(uid, 0)
+        uid = dist.broadcast(uid, 0)
         rccl_ok, why = True, ""
         try:
             if os.environ.get("NVR_BENCH_RCCL", "1") == "0":
                 raise RuntimeError("disabled by NVR_BENCH_RCCL=0")
-            eng.model_runner.init_comm(bytes(uid.numpy().tobytes()))             # RCCL communicator + collective self-test
+            eng.model_runner.init_comm(uid)                                      # RCCL communicator + collective self-test
         except Exception as ex:                                                  # noqa: BLE001
             rccl_ok, why = False, str(ex)
         mine = rccl_ok
@@ -563,8 +555,7 @@ def main() -> None:
             handle = eng.model_runner.p2p_export() if p2p_ok else b"\0" * 64
         except Exception as ex:                                                  # noqa: BLE001
             handle, p2p_ok, why2 = b"\0" * 64, False, str(ex)
-        gathered = [None] * world
-        dist.all_gather_object(gathered, (handle, local_rank))
+        gathered = dist.all_gather((handle, local_rank))
         p2p_ok = all_ok(p2p_ok)
         if p2p_ok:
             try:
@@ -595,8 +586,8 @@ def main() -> None:
         if not ok:
             if rank == 0:
                 print(json.dumps({"error": "tensor-parallel communicators could not be built on this node: " + collective}), flush=True)
-            dist.barrier(); dist.destroy_process_group()
-            sys.stdout.flush(); os._exit(0 if child else 3)
+            dist.barrier(); dist.close()
+            sys.stdout.flush(); sys.exit(0 if child else 3)
         parallelism, scaling, jobs = f"tp{args.gpus}", "strong", 1
         arm("tensor-parallel decode")
         elapsed, t_prefill = run_decode(eng)
@@ -611,7 +602,7 @@ def main() -> None:
         elapsed, t_prefill = r_el, r_pre
         if args.parallel == "both":
             # the north star's tensor-parallel configuration, measured on the same ranks right after in a CHILD process per rank
-            # (its own gloo group on the next port); first with the peer-to-peer kernels, then — if that attempt died — RCCL only
+            # (its own rendezvous on the next port); first with the peer-to-peer kernels, then — if that attempt died — RCCL only
             import subprocess
             tp_errors = []
             for attempt, extra_env in enumerate(({}, {"NVR_BENCH_P2P": "0"})):
@@ -619,8 +610,8 @@ def main() -> None:
                 env["MASTER_PORT"] = str(int(env.get("MASTER_PORT", "29500")) + 1 + attempt)
                 env["NVR_BENCH_CHILD"] = "1"
                 env.update(extra_env)
-                for k in [k for k in env if k.startswith("TORCHELASTIC_")]:   # the children rendezvous on their own store (rank 0 hosts it),
-                    del env[k]                                                # not on the launcher agent's
+                for k in [k for k in env if k.startswith("TORCHELASTIC_")]:   # (the children are plain processes, not the launcher agent's workers)
+                    del env[k]
                 cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup),
                        "--parallel", "tp", "--no-cpu-baseline", "--attn-reps", "1"] + (["--eager"] if args.eager else [])
                 child_out, child_err, child_rc = "", "", None
@@ -641,11 +632,9 @@ def main() -> None:
                         done = 1
                     else:
                         tp_errors.append((cj or {}).get("error") or f"child exit code {child_rc}: {child_err.strip()[-400:]}")
-                import torch
-                t = torch.tensor([done], dtype=torch.int32)
-                dist.broadcast(t, 0)
+                done = dist.broadcast(done, 0)
                 barrier()
-                if int(t.item()):
+                if done:
                     break
             if rank == 0 and tensor_parallel is None:
                 tensor_parallel = {"error": " | ".join(tp_errors)}
@@ -810,10 +799,7 @@ def main() -> None:
         arm("configs[3] tensor-parallel side block", 90.0)
 
         def rmax(v):
-            import torch
-            t = torch.tensor([v], dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            return float(t.item())
+            return dist.max(v)
         try:
             c3 = side_decode(nvr, "qwen3-8b", tp_size=args.gpus, tp_rank=rank, device=local_rank, attach=init_tensor_parallel, barrier=barrier, reduce_max=rmax)
         except Exception as ex:                                              # noqa: BLE001
@@ -824,14 +810,9 @@ def main() -> None:
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
-        dist.destroy_process_group()
-        # Two ROCm stacks live in a multi-rank process (this image's 7.2 libraries behind libnvr.so and the 7.0 copies
-        # bundled with torch); their static destructors abort at interpreter exit ("double free") after all work is
-        # done.  Everything is flushed and released above: leave without running them.
+        dist.close()
         if watchdog is not None:
             watchdog.cancel()
-        sys.stdout.flush(); sys.stderr.flush()
-        os._exit(0)
 
 
 if __name__ == "__main__":

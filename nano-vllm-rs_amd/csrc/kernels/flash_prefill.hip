@@ -22,6 +22,10 @@
 // 32-byte bank segments (un-swizzled, all 8 keys share one segment: 8-way conflicts, the first version's bottleneck).
 // Steps whose 64 keys all precede the tile's first query skip the causal compare.
 #include <type_traits>
+#include <vector>
+#include <map>
+#include <algorithm>
+#include <cstdio>
 #include "kernels.h"
 #include "device_utils.h"
 #include "../common.h"
@@ -33,6 +37,7 @@ struct FlashParams {
     const half_t *k, *v; int64_t ldkv;
     const int32_t *block_tables; int32_t max_blocks, block_size, bs_shift;
     const FlashTile *tiles;
+    const int32_t *lanes; int32_t nlanes;    // flash2: per-workgroup tile lists, [nlanes + 1 starts | tile indices] (flash_lanes)
     int32_t H, KVH;
     float scale;
     half_t *out;
@@ -414,12 +419,533 @@ __global__ __launch_bounds__(64 * FLASH_WAVES, 8 / FLASH_WAVES) void flash_prefi
     }
 }
 
+
+// ======================================================================================================================================
+// Second-generation prefill kernel (r04), head_dim 128: PERSISTENT workgroups of 256 query rows, 32x32x16 MFMAs, a 4-slot LDS-DMA ring.
+//
+// Why (profiles/r04_flash_prefill.txt): the kernel above moves 64 KiB of K/V per CU and 64-key step from L2 into LDS for 2 x 128 query
+// rows with ONE tile in flight per workgroup (request at the start of a step, s_waitcnt vmcnt(0) at its end) and runs QKᵀ -> softmax ->
+// P·V strictly one after the other in every wave on 16x16x32 MFMAs, which hold the SIMD's issue port for 8 of their 16 cycles: 32 %
+// matrix-pipe busy.  Here
+//   * one workgroup = 8 waves = 256 query rows (256 / G positions x the G heads of a kv head): half the L2 -> LDS bytes per FLOP;
+//   * a wave owns 32 query rows and works on 32x32x16 MFMAs (24 of 32 cycles free for vector instructions of either wave of the SIMD):
+//       Sᵀ[key, q] = K·Qᵀ   A = K rows (ds_read_b128, chunk ^ (row & 15): conflict-free), B = the lane's Q row (registers, 8 fragments)
+//                           accumulator: query on the lane (l & 31), 16 keys of a 32-key half in the registers, the other 16 in lane l ^ 32
+//       Oᵀ[d, q] += Vᵀ·Pᵀ   B = the exp'd accumulators packed to 16 bits IN PLACE (registers 8s..8s+7 = k-step s, k order
+//                           16s + 8(j>>2) + 4h + (j&3); cdna guide §3 "an accumulator tile as the next MFMA's operand"), A = Vᵀ by two
+//                           ds_read_b64_tr_b16 in that same key order (V image: 16-byte chunk ^ ((key & 3) << 2): the 32 lanes of a half
+//                           touch 32 different 8-byte bank slots);
+//     row max = 15 in-lane v_max + one v_permlane32_swap, row sum = in-lane f32 adds (halves combined once in the epilogue);
+//   * software pipeline over 32-key halves with two named score states: QKᵀ of half u+1 is issued next to the exp / pack of half u and
+//     P·V of half u, every operand fragment read from LDS one group of four MFMAs ahead (guide T15); the running max is only raised
+//     when a row's maximum grew by more than 2^6 (guide T13: one wave-uniform, rarely taken rescale branch instead of 64 multiplies);
+//   * K/V tiles by LDS-DMA into NBUF slots of 32 KiB, requested NBUF-1 steps ahead, counted vmcnt + ONE barrier per 64-key step;
+//   * PERSISTENT: a workgroup is one (lane, kv head) of the launch and walks the lane's list of tiles (built on the host: tiles dealt to the
+//     least-loaded lane in list order, flash_lanes).  The first build launched one workgroup per tile: 8.0 us between two workgroups of
+//     a CU (128 KiB of LDS per workgroup), 10 k cycles of prologue per tile and a 39 us tail of idle CUs in a 311 us launch.  Here the
+//     K/V requests run ahead ACROSS tile boundaries (a request cursor of its own) and the next tile's Q rows are loaded during the
+//     last step of the current one.
+constexpr int F2_ROWS = 256;                 // query rows per workgroup
+constexpr float F2_DEFER = 6.0f;             // log2 units a row maximum may run ahead of the running max before the rescale branch is taken
+
+__device__ __forceinline__ float16_t mfma32(half8_t a, half8_t b, float16_t c) {
+#ifdef NVR_BF16
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+#else
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+#endif
+}
+
+#ifdef NVR_F2_STAMPS   // diagnostic build only (tools/build_variant.sh): shader-clock sums per phase of wave 0 of every workgroup
+__device__ unsigned long long f2_stamp_buf[1024 * 12];
+#define F2_STAMP(var) unsigned long long var; __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0)
+#else
+#define F2_STAMP(var)
+#endif
+// MODE 0: K/V rows contiguous (p.ldkv apart, first row tile.kv_ref); 1: block tables, any block size; 2: block tables, block size a
+// power of two and a multiple of the 64-key step (a step lies inside one block)
+template <int G, int MODE, int NBUF>
+__global__ __launch_bounds__(512, 2) void flash2_kernel(FlashParams p) {
+    constexpr int D = 128, NT = 512, KT = 64, CPR = 16, PIECES = 2;
+    constexpr int STAGE = 2 * KT * D * 2, V_OFF = KT * D * 2;
+    constexpr int PPW = 32 / G;                                       // query positions per wave
+    constexpr bool PAGED = MODE != 0, UB = MODE == 2;
+    static_assert(V_OFF == PIECES * NT * 16, "the pieces of the K image, then of the V image, NT * 16 bytes apart");
+    static_assert(NBUF == 4, "ring depth: K of step t+1 is read during step t (two steps ahead must have landed), one more tile may fly");
+    extern __shared__ __attribute__((aligned(16))) char smem[];       // NBUF x [K image | V image]
+
+    F2_STAMP(ts0);
+    const int g = blockIdx.x % p.KVH, my_lane = blockIdx.x / p.KVH;
+    const int it0 = p.lanes[my_lane], it1 = p.lanes[my_lane + 1];     // this workgroup's tiles: items[it0 .. it1)
+    if (it0 >= it1) return;
+    const int32_t *items = p.lanes + p.nlanes + 1;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c = lane & 31, h = lane >> 5;
+    const int head = g * G + c / PPW;                                 // the wave's 32 columns are PPW positions x G heads
+    const int qi = wave * PPW + c % PPW;                              // the lane's query position inside a tile
+
+    // ---- request cursor: the K/V tile of (item rq_i, step rq_t) goes to ring slot rq_gs % NBUF -------------------------------------------
+    int rq_i = it0, rq_t = 0, rq_gs = 0;
+    FlashTile rq = p.tiles[items[it0]];
+    int rq_end = rq.pos0 + rq.nq, rq_steps = (rq_end + KT - 1) / KT;
+    int bt_reg = 0, bt_chunk = -1;                                    // UB: register copy of 64 block-table entries of the request cursor's sequence
+    auto load_bt_chunk = [&](int cidx) {
+        bt_chunk = cidx;
+        const int idx = min((cidx << 6) + lane, p.max_blocks - 1);
+        const int32_t *src = p.block_tables + (int64_t)rq.kv_ref * p.max_blocks + idx;
+        asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(bt_reg) : "v"(src) : "memory");
+    };
+    // the ring starts on a 256-byte boundary (an LDS bank row = one K/V row): the read addresses below are formed with XORs
+    const unsigned lds_ring = ((unsigned)(size_t)(__attribute__((address_space(3))) char *)smem + 255u) & ~255u;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    int64_t kconst[PIECES], vconst[PIECES];                           // element offsets of this thread's pieces inside a step
+#pragma unroll
+    for (int i = 0; i < PIECES; ++i) {
+        const int idx = i * NT + threadIdx.x, row = idx / CPR, cc = idx % CPR;
+        const int64_t rowoff = UB ? ((int64_t)row * p.KVH + g) * D : (int64_t)row * p.ldkv + (int64_t)g * D;
+        kconst[i] = rowoff + (cc ^ (row & 15)) * 8;
+        vconst[i] = rowoff + (cc ^ ((row & 3) << 2)) * 8;
+    }
+    // A request = the four 1-KiB-per-wave pieces of one K/V tile: addressed by stage(), sent as its K half and its V half by issue_k / issue_v
+    // (the loop puts one half into each of a step's two matrix phases: an LDS-DMA piece costs ~150 cycles of issue inside a vector phase,
+    // ~60 among bare MFMAs)
+    const half_t *src[2 * PIECES];
+    unsigned rq_dst = 0;
+    auto stage = [&](int buf, int kt) {                               // the request cursor's tile, keys kt .. kt+63, into ring slot buf
+        const bool whole = kt + KT <= rq_end;                         // uniform: no key of this step is clamped
+        if ((!PAGED || UB) && whole) {
+            int64_t sbase;
+            if (PAGED) {
+                const int bi = kt >> p.bs_shift;
+                if ((bi >> 6) != bt_chunk) load_bt_chunk(bi >> 6);
+                sbase = ((int64_t)__builtin_amdgcn_readlane(bt_reg, bi & 63) * p.block_size + (kt & (p.block_size - 1))) * p.KVH * D;
+            } else sbase = (int64_t)(rq.kv_ref + kt) * p.ldkv;
+#pragma unroll
+            for (int i = 0; i < PIECES; ++i) { src[i] = p.k + sbase + kconst[i]; src[PIECES + i] = p.v + sbase + vconst[i]; }
+        } else {
+            int64_t blk_row0 = 0;
+            if (UB) {
+                const int bi = kt >> p.bs_shift;
+                if ((bi >> 6) != bt_chunk) load_bt_chunk(bi >> 6);
+                blk_row0 = (int64_t)__builtin_amdgcn_readlane(bt_reg, bi & 63) * p.block_size;
+            }
+#pragma unroll
+            for (int i = 0; i < PIECES; ++i) {
+                const int idx = i * NT + threadIdx.x, row = idx / CPR, cc = idx % CPR;
+                int key = kt + row; if (key > rq_end - 1) key = rq_end - 1;
+                int64_t off;
+                if (UB) {
+                    off = ((blk_row0 + (key & (p.block_size - 1))) * p.KVH + g) * D;
+                } else if (PAGED) {
+                    int bi, bo;
+                    if (p.bs_shift >= 0) { bi = key >> p.bs_shift; bo = key & (p.block_size - 1); }
+                    else { bi = key / p.block_size; bo = key - bi * p.block_size; }
+                    const int64_t rr = (int64_t)p.block_tables[(int64_t)rq.kv_ref * p.max_blocks + bi] * p.block_size + bo;
+                    off = (rr * p.KVH + g) * D;
+                } else {
+                    off = (int64_t)(rq.kv_ref + key) * p.ldkv + (int64_t)g * D;
+                }
+                src[i] = p.k + off + (cc ^ (row & 15)) * 8;
+                src[PIECES + i] = p.v + off + (cc ^ ((row & 3) << 2)) * 8;
+            }
+        }
+        rq_dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_ring + buf * STAGE + wave_u * 1024));
+    };
+    bool rq_open = false;                                             // a staged request whose V half has not gone out yet
+    auto request_k = [&]() {                                          // one virtual step further (across tile boundaries): address it, send the K half
+        rq_open = rq_i < it1;
+        if (!rq_open) return;
+        stage(__builtin_amdgcn_readfirstlane(rq_gs % NBUF), rq_t * KT);
+        ++rq_gs;
+        if (++rq_t == rq_steps) {
+            rq_t = 0; bt_chunk = -1;
+            if (++rq_i < it1) { rq = p.tiles[items[rq_i]]; rq_end = rq.pos0 + rq.nq; rq_steps = (rq_end + KT - 1) / KT; }
+        }
+        const half_t *const ks[PIECES] = {src[0], src[1]};
+        glds_pieces<PIECES, NT * 16>(ks, rq_dst);
+    };
+    auto request_v = [&]() {
+        if (!rq_open) return;
+        const half_t *const vs[PIECES] = {src[PIECES], src[PIECES + 1]};
+        glds_pieces<PIECES, NT * 16>(vs, rq_dst + V_OFF);
+        rq_open = false;
+    };
+    auto request_next = [&]() { request_k(); request_v(); };
+
+    // ---- per-tile lane data and the Q fragments ----------------------------------------------------------------------------------------------
+    FlashTile tile = rq;                                              // the compute cursor's tile (= the first one)
+    half8_t qf[8];
+    bool qvalid; int qpos, qrow;
+    auto lane_of_tile = [&](const FlashTile &t, bool &valid, int &pos, int &row) {
+        valid = qi < t.nq;
+        const int qc = valid ? qi : t.nq - 1;
+        pos = t.pos0 + qc;                                            // absolute position = last visible key
+        row = t.q_row0 + qc;
+    };
+    // The Q rows are loaded by inline asm and waited for by hand (q_wait): as ordinary loads hipcc places the wait itself and, unable to tell the
+    // first tile (nothing behind the loads) from the later ones (the previous tile's 8 output stores behind them), waits for vmcnt(0) at every tile
+    // boundary — the stores' round trip to HBM.  Nothing touches qf between the two statements (checked in the ISA: guide §5.7 form (ii)).
+    auto load_q = [&](int row) {
+        const half_t *qptr = p.q + (int64_t)row * p.ldq + (int64_t)head * D + h * 8;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(qf[ks]) : "v"(qptr + ks * 16) : "memory");
+    };
+#define F2_Q_WAIT(N) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3]), "+v"(qf[4]), "+v"(qf[5]), "+v"(qf[6]), "+v"(qf[7]) :: "memory")
+    lane_of_tile(tile, qvalid, qpos, qrow);
+    load_q(qrow);
+    if (UB) load_bt_chunk(0);
+#pragma unroll
+    for (int b = 0; b < NBUF - 1; ++b) request_next();
+
+    // LDS read addresses of this lane inside ring slot 0
+    const unsigned kbase = lds_ring + c * 256 + ((h ^ (c & 15)) << 4);   // K row c (+ 32 mt), 16-byte chunk (2 ks + h) ^ (row & 15): ^ (ks << 5)
+    const int vq = (lane & 15) >> 2, vp = lane & 3, vg = (lane >> 4) & 1;
+    const unsigned vbase = lds_ring + V_OFF + (4 * h + vq) * 256 + ((((vq << 2) | (vg << 1) | (vp >> 1)) << 4) | ((vp & 1) << 3));   // ^ (dt << 6)
+
+    float16_t o[4];
+    float m, mneg, lsum[4];                                           // (four partial row sums: no 16-deep dependent add chain per half)
+    const float c2 = p.scale * 1.44269504088896340736f;
+
+    // causal mask of 32 keys from k0 on (only where they reach past the tile's first query: a small wave-uniform branch that touches S alone)
+    auto mask = [&](float16_t &S, int k0) {
+        if (k0 + 31 > tile.pos0) {
+            const int lim = qpos - k0 - 4 * h;                        // key k0 + (e & 3) + 8 (e >> 2) + 4 h is visible iff <= qpos
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                if ((e & 3) + 8 * (e >> 2) > lim) S[e] = -INFINITY;
+        }
+    };
+    // row maximum and the rare raise of the running maximum; FIRST: the tile's first keys (nothing accumulated yet: the maximum is taken as it is)
+    auto stats = [&](auto first_c, const float16_t &S) {
+        float mx = fmaxf(S[0], S[1]);
+#pragma unroll
+        for (int e = 2; e < 16; e += 2) mx = fmaxf(fmaxf(mx, S[e]), S[e + 1]);
+        mx = xor32_partner_max(mx);
+        if constexpr (decltype(first_c)::value) { m = mx; mneg = -mx * c2; }     // (key 0 is visible to every query: mx is finite)
+        else {
+            const bool need = (mx - m) * c2 > F2_DEFER;
+            if (__any(need)) {                                        // wave-uniform
+                const float mn = fmaxf(m, mx);
+                const float alpha = __builtin_amdgcn_exp2f((m - mn) * c2);
+                m = mn; mneg = -mn * c2;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) lsum[i] *= alpha;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) o[dt][e] *= alpha;
+            }
+        }
+    };
+    // operand fragments are read from LDS a whole phase ahead of their MFMAs
+    auto load_v = [&](int slot, int mt, int s2, half8_t (&vf)[4]) {         // Vᵀ fragments of k-step s2 of key half (slot, mt), d tiles 0..3
+        const unsigned vl = vbase + slot * STAGE + (32 * mt + 16 * s2) * 256;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            const unsigned a = vl ^ (unsigned)(dt << 6);
+            const half4_t a0 = lds_read_tr16(a), a1 = lds_read_tr16(a + 8 * 256);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { vf[dt][e] = a0[e]; vf[dt][4 + e] = a1[e]; }
+        }
+    };
+    // Two kinds of phases alternate in every wave, separated by workgroup barriers, and waves 4..7 run ONE PHASE BEHIND waves 0..3 (they pass
+    // one extra barrier at the start, waves 0..3 one at the end): on every SIMD one wave is in a matrix phase (16 MFMAs back to back: 512
+    // cycles of the matrix pipe, 128 of the issue port) while its partner is in a vector phase (mask / max / exp / pack of the next 32 keys,
+    // ~110 vector instructions, and the LDS reads of ITS next matrix phase) — the ping-pong of guide T16 with whole-wave roles instead of a
+    // compiler-scheduled mix (first r04 build: interleaved in one stream, both waves of a SIMD stalled on the same pipe at the same time,
+    // 44 % matrix-pipe busy inside the loop).  One score state S: a matrix phase overwrites it with QKᵀ of the NEXT half after the vector
+    // phase has turned the current one into the 16-bit P fragments.
+    float16_t S;
+    half8_t kf[8], vfa[4], vfb[4], pf[2];
+#ifdef NVR_F2_VSTAMPS
+    unsigned long long vacc[4] = {0, 0, 0, 0};
+#endif
+    // Vector phase.  A wave may have 15 LDS reads outstanding (lgkmcnt): the 24 fragment reads of the next matrix phase are therefore cut into
+    // four batches with a quarter of the vector work behind each — issued as one block in front, the wave sat ~670 cycles in the issue of its own
+    // reads (all four vector-phase waves of the CU asking the LDS at once) before its first vector instruction.
+    auto load_k4 = [&](auto lo_c, int slot, int mt) {                       // K fragments ks = LO .. LO+3 of key half (slot, mt)
+        constexpr int LO = decltype(lo_c)::value;
+        const unsigned kl = kbase + slot * STAGE + mt * 8192;
+#pragma unroll
+        for (int ks = LO; ks < LO + 4; ++ks) kf[ks] = *lds_ptr<const half8_t>(kl ^ (unsigned)(ks << 5));
+    };
+    auto expo8 = [&](auto e0_c) {                                           // p = 2^((s - m) c2) of registers E0 .. E0+7 = k-step E0 / 8, row sums
+        constexpr int E0 = decltype(e0_c)::value;
+#pragma unroll
+        for (int e = E0; e < E0 + 8; ++e) {
+#ifdef NVR_F2_X_NOEXP
+            const float pe = fmaf(S[e], c2, mneg);
+#else
+            const float pe = __builtin_amdgcn_exp2f(fmaf(S[e], c2, mneg));
+#endif
+            lsum[e & 3] += pe;
+            pf[e >> 3][e & 7] = (half_t)pe;
+        }
+    };
+    using I0 = std::integral_constant<int, 0>; using I4 = std::integral_constant<int, 4>; using I8 = std::integral_constant<int, 8>;
+    auto v_phase = [&](auto first_c, auto has_next_c, int slot, int mt, int slot_kn, int mtn, int k0) {
+        constexpr bool HAS_NEXT = decltype(has_next_c)::value;
+#ifdef NVR_F2_VSTAMPS
+        F2_STAMP(v0);
+#endif
+        load_v(slot, mt, 0, vfa);                                     // operands of the matrix phase that follows: P·V of this half ...
+        mask(S, k0);
+        __builtin_amdgcn_sched_barrier(0);
+#ifdef NVR_F2_VSTAMPS
+        F2_STAMP(v1);
+#endif
+        load_v(slot, mt, 1, vfb);
+        stats(first_c, S);
+        __builtin_amdgcn_sched_barrier(0);
+#ifdef NVR_F2_VSTAMPS
+        F2_STAMP(v2);
+#endif
+        if constexpr (HAS_NEXT) load_k4(I0{}, slot_kn, mtn);          // ... and QKᵀ of the next one
+        expo8(I0{});
+        __builtin_amdgcn_sched_barrier(0);
+#ifdef NVR_F2_VSTAMPS
+        F2_STAMP(v3);
+#endif
+        if constexpr (HAS_NEXT) load_k4(I4{}, slot_kn, mtn);
+        expo8(I8{});
+#ifdef NVR_F2_VSTAMPS
+        F2_STAMP(v4);
+        vacc[0] += v1 - v0; vacc[1] += v2 - v1; vacc[2] += v3 - v2; vacc[3] += v4 - v3;
+#endif
+    };
+    // Matrix phase: 16 MFMAs back to back; DMA = 1 / 2: the K / V half of the next K/V request rides among them
+    auto m_phase = [&](auto has_next_c, auto dma_c) {
+        constexpr int DMA = decltype(dma_c)::value;
+#ifndef NVR_F2_X_NOPRIO
+        __builtin_amdgcn_s_setprio(1);
+#endif
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = mfma32(vfa[dt], pf[0], o[dt]);
+        if constexpr (DMA == 1) request_k();
+        if constexpr (DMA == 2) request_v();
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = mfma32(vfb[dt], pf[1], o[dt]);
+        if constexpr (decltype(has_next_c)::value) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) S[e] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) S = mfma32(kf[ks], qf[ks], S);
+        }
+#ifndef NVR_F2_X_NOPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
+    };
+    auto slot_of = [&](int gs) { return __builtin_amdgcn_readfirstlane(gs % NBUF); };
+    // (lgkmcnt(0): a wave's LDS reads have EXECUTED when it reaches the barrier — the next request into the slot they read follows this barrier)
+    auto phase_end = [&]() {
+        __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0);
+    };
+#ifdef NVR_F2_X_NOLAG
+    const bool late = false;
+#else
+    const bool late = __builtin_amdgcn_readfirstlane(wave) >= 4;
+#endif
+
+    // the first three K/V tiles and the first Q rows: landed for every wave (own wait, then a barrier both groups have passed)
+    F2_Q_WAIT(0);                                                     // (all but the N youngest vector-memory operations of this wave are done)
+    phase_end();
+    if (late) phase_end();                                            // waves 4..7: one phase behind from here on
+
+#ifdef NVR_F2_STAMPS
+    unsigned long long acc_bound = 0, acc_req = 0, acc_h0 = 0, acc_h1 = 0, acc_wait = 0, acc_last = 0, acc_epi = 0, n_steps = 0;
+#endif
+    int gs = 0;                                                       // global (virtual) step of the compute cursor
+    for (int it = it0; it < it1; ++it) {
+        F2_STAMP(tb0);
+        const int kv_end = tile.pos0 + tile.nq, nsteps = (kv_end + KT - 1) / KT;
+        // Tile boundary.  The K/V tile of the first step landed long ago (the wait in the previous tile's last step, or the one above); the Q rows
+        // were requested behind the previous tile's last matrix phase, in front of its 8 output stores: vmcnt(8) leaves exactly those in flight.
+        if (it != it0) F2_Q_WAIT(8);
+        m = -INFINITY; mneg = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) lsum[i] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) o[dt][e] = 0.f;
+        load_k4(I0{}, slot_of(gs), 0); load_k4(I4{}, slot_of(gs), 0);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) S[e] = 0.f;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) S = mfma32(kf[ks], qf[ks], S);
+        __builtin_amdgcn_s_setprio(0);
+        phase_end();
+        F2_STAMP(tb1);
+        // end of a step's first vector phase: the NEXT step's K/V tile has landed for this wave (everything requested behind it may fly)
+        // (the request of the step three ahead went out in the previous step's two matrix phases: one tile may fly behind the one waited for)
+        auto step_wait = [&]() {
+            if (rq_gs - 1 > gs + 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PIECES) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        };
+        // V(0, 0): the tile's first keys
+        v_phase(std::true_type{}, std::true_type{}, slot_of(gs), 0, slot_of(gs), 1, 0);
+        step_wait();
+        phase_end();
+        for (int t = 0; t + 1 < nsteps; ++t) {                        // [M(t,0) V(t,1) M(t,1) V(t+1,0)]: no branch around the matrix work
+            F2_STAMP(ta);
+            const int sl = slot_of(gs), sn = slot_of(gs + 1);
+            m_phase(std::true_type{}, std::integral_constant<int, 1>{});   // P·V(t, 0), QKᵀ(t, 1); K half of the request of step t + 3
+            F2_STAMP(ta2);
+            phase_end();
+            F2_STAMP(tb);
+            v_phase(std::false_type{}, std::true_type{}, sl, 1, sn, 0, t * KT + 32);
+            F2_STAMP(tb2);
+            phase_end();
+            F2_STAMP(tc);
+            m_phase(std::true_type{}, std::integral_constant<int, 2>{});   // P·V(t, 1), QKᵀ(t+1, 0); V half of the request
+            phase_end();
+            F2_STAMP(td);
+            ++gs;
+            F2_STAMP(td2);
+            v_phase(std::false_type{}, std::true_type{}, sn, 0, sn, 1, (t + 1) * KT);
+            F2_STAMP(td3);
+            step_wait();
+            phase_end();
+            F2_STAMP(te);
+#ifdef NVR_F2_STAMPS
+            acc_req += ta2 - ta; acc_h0 += tb - ta2; acc_h1 += tb2 - tb; acc_wait += tc - tb2; acc_last += td2 - td; acc_bound += td3 - td2; acc_epi += te - td3; ++n_steps;
+#endif
+        }
+        {                                                             // the last step's M(·,0) V(·,1) M(·,1)
+            const int sl = slot_of(gs);
+            m_phase(std::true_type{}, std::integral_constant<int, 1>{});
+            phase_end();
+            v_phase(std::false_type{}, std::false_type{}, sl, 1, 0, 0, (nsteps - 1) * KT + 32);
+            phase_end();
+            m_phase(std::false_type{}, std::integral_constant<int, 2>{});   // the tile's last matrix work; Q is dead from here on
+            phase_end();
+            ++gs;
+        }
+        F2_STAMP(tl1);
+        // the next tile's Q rows (requested before this tile's output stores: see the boundary wait)
+        const bool done_valid = qvalid; const int done_row = qrow;
+        if (it + 1 < it1) {
+            tile = p.tiles[items[it + 1]];
+            lane_of_tile(tile, qvalid, qpos, qrow);
+            load_q(qrow);
+        }
+        (void)done_valid;
+        {
+            // Every lane stores (rows past the tile's last query are copies of that query: identical bytes to the same address), so that a wave
+            // issues exactly 8 stores: the boundary wait counts on it.  A query's row is split over lanes l and l ^ 32 (d 8b+4h .. +3 each): one
+            // v_permlane32_swap per dword of two neighbouring groups leaves 16 contiguous bytes in each lane (guide T21).
+            const float ls = xor32_partner_sum((lsum[0] + lsum[1]) + (lsum[2] + lsum[3]));   // (the halves of a query swap their sums)
+            const float inv = ls > 0.f ? 1.0f / ls : 0.f;
+            char *orow = reinterpret_cast<char *>(p.out + ((int64_t)done_row * p.H + head) * D) + 16 * h;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int b = 0; b < 4; b += 2) {                      // registers 4b..4b+3 = d 32 dt + 8 b + 4 h + 0..3
+                    union { half4_t v; unsigned u[2]; } ga, gb;
+                    ga.v = (half4_t){(half_t)(o[dt][4 * b] * inv), (half_t)(o[dt][4 * b + 1] * inv), (half_t)(o[dt][4 * b + 2] * inv), (half_t)(o[dt][4 * b + 3] * inv)};
+                    gb.v = (half4_t){(half_t)(o[dt][4 * b + 4] * inv), (half_t)(o[dt][4 * b + 5] * inv), (half_t)(o[dt][4 * b + 6] * inv), (half_t)(o[dt][4 * b + 7] * inv)};
+                    const auto r0 = __builtin_amdgcn_permlane32_swap(ga.u[0], gb.u[0], false, false);
+                    const auto r1 = __builtin_amdgcn_permlane32_swap(ga.u[1], gb.u[1], false, false);
+                    // lanes 0..31: d 8b .. 8b+7 = [own group b | partner's group b]; lanes 32..63: d 8b+8 .. 8b+15 = [partner's group b+1 | own group b+1]
+                    uint4 w; w.x = r0[0]; w.y = r1[0]; w.z = r0[1]; w.w = r1[1];
+                    *reinterpret_cast<uint4 *>(orow + (32 * dt + 8 * b) * 2) = w;
+                }
+        }
+        F2_STAMP(tl2);
+
+    }
+#ifndef NVR_F2_X_NOLAG
+    if (!late) phase_end();                                           // waves 0..3: the barrier waves 4..7 passed at the start
+#endif
+#ifdef NVR_F2_STAMPS
+    F2_STAMP(ts9);
+    if (threadIdx.x == 0 && blockIdx.x < 1024) {
+        unsigned long long *d = f2_stamp_buf + (size_t)blockIdx.x * 12;
+#ifdef NVR_F2_VSTAMPS
+        acc_req = vacc[0]; acc_h0 = vacc[1]; acc_h1 = vacc[2]; acc_wait = vacc[3]; n_steps = n_steps * 2 + (it1 - it0) * 2;
+#endif
+        d[0] = acc_bound; d[1] = acc_req; d[2] = acc_h0; d[3] = acc_h1; d[4] = acc_wait; d[5] = acc_last; d[6] = acc_epi; d[7] = n_steps; d[8] = it1 - it0; d[9] = ts9 - ts0;
+    }
+#endif
+}
+
 bool flash_prefill_ok(int D, int H, int KVH) {
     if (KVH <= 0 || H % KVH) return false;
     const int G = H / KVH;
     return (D == 64 || D == 128) && (G == 1 || G == 2 || G == 4);
 }
-int flash_tile_positions(int H, int KVH) { return 32 * FLASH_WAVES / (H / KVH); }
+#ifndef NVR_F2_ENABLE
+#define NVR_F2_ENABLE 1
+#endif
+static bool flash2_shape(int D) { return NVR_F2_ENABLE && D == 128; }
+// query positions of one tile of the prefill kernels
+int flash_tile_positions(int H, int KVH, int D) { return (flash2_shape(D) ? F2_ROWS : 32 * FLASH_WAVES) / (H / KVH); }
+// sequences per workgroup of the shared-prefix pass (flash_prefill_kernel<.., SHARED>)
+int flash_shared_rows(int H, int KVH) { return 32 * FLASH_WAVES / (H / KVH); }
+
+// Per-workgroup tile lists of the persistent kernel.  The launch has nlanes x KVH workgroups, workgroup w = (lane w / KVH, kv head w % KVH):
+// with KVH = 8 a kv head's workgroups share one XCD (workgroups are dealt round-robin to the 8 XCDs: speed only), so the tiles of one
+// sequence, which read the same K/V rows, meet in one L2.  Tiles are dealt IN LIST ORDER (the caller keeps sequences together) to the lane
+// with the least work so far — cost = 64-key steps + 2 for the tile boundary — so that every lane ends at about the same time and a lane's
+// tiles follow the list's time order.  out: [nlanes + 1 starts | ntiles tile indices], flash_lanes_ints(ntiles) ints; 0 when D takes the
+// non-persistent kernel.
+size_t flash_lanes_ints(int ntiles) { return (size_t)ntiles + 258; }
+int flash_lanes(const FlashTile *tiles, int ntiles, int KVH, int D, int ncu, int32_t *out) {
+    if (!flash2_shape(D) || ntiles <= 0) return 0;
+    int nlanes = ncu / (KVH > 0 ? KVH : 1);
+    if (nlanes > 256) nlanes = 256;
+    if (nlanes > ntiles) nlanes = ntiles;
+    if (nlanes < 1) nlanes = 1;
+    std::vector<int64_t> load(nlanes, 0);
+    std::vector<int32_t> owner(ntiles), count(nlanes, 0);
+    // (a binary heap keyed by (load, lane): ntiles x log nlanes)
+    std::vector<std::pair<int64_t, int>> heap(nlanes);
+    for (int j = 0; j < nlanes; ++j) heap[j] = {0, j};
+    auto cmp = [](const std::pair<int64_t, int> &a, const std::pair<int64_t, int> &b) { return a > b; };
+    std::make_heap(heap.begin(), heap.end(), cmp);
+    for (int i = 0; i < ntiles; ++i) {
+        std::pop_heap(heap.begin(), heap.end(), cmp);
+        auto &top = heap.back();
+        owner[i] = top.second; ++count[top.second];
+        top.first += (tiles[i].pos0 + tiles[i].nq + NVR_FLASH_KT - 1) / NVR_FLASH_KT + 2;
+        std::push_heap(heap.begin(), heap.end(), cmp);
+    }
+    out[0] = 0;
+    for (int j = 0; j < nlanes; ++j) out[j + 1] = out[j] + count[j];
+    std::vector<int32_t> fill(out, out + nlanes);
+    for (int i = 0; i < ntiles; ++i) out[nlanes + 1 + fill[owner[i]]++] = i;
+    return nlanes;
+}
+
+template <int G, int MODE>
+static int flash2_launch(const FlashParams &p, dim3 grid, hipStream_t s) {
+    constexpr int NBUF = 4;
+    constexpr int LDS = NBUF * 2 * NVR_FLASH_KT * 128 * 2 + 256;
+    static bool ready = false;                                        // > 64 KiB of dynamic LDS: opt-in once per kernel
+    if (!ready) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&flash2_kernel<G, MODE, NBUF>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return nvr::fail(NVR_ERR_HIP, "flash_prefill: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        ready = true;
+    }
+    flash2_kernel<G, MODE, NBUF><<<grid, dim3(512), LDS, s>>>(p);
+#ifdef NVR_F2_STAMPS
+    {
+        static int calls = 0;
+        hipStreamSynchronize(s);
+        if (++calls == 8) {
+            const size_t n = grid.x < 1024 ? grid.x : 1024;
+            std::vector<unsigned long long> hbuf(n * 12);
+            hipMemcpyFromSymbol(hbuf.data(), HIP_SYMBOL(f2_stamp_buf), n * 12 * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
+            double sum[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, life_max = 0;
+            for (size_t i = 0; i < n; ++i) { for (int j = 0; j < 10; ++j) sum[j] += (double)hbuf[i * 12 + j]; life_max = std::max(life_max, (double)hbuf[i * 12 + 9]); }
+            std::fprintf(stderr, "[f2 stamps] %zu workgroups, %.1f tiles each, %.1f loop steps each | per loop step (wave 0): M work %.0f, barrier %.0f, V work %.0f, barrier %.0f, request %.0f, V(step start) work %.0f, counted wait + barrier %.0f | lifetime mean %.0f max %.0f cycles\n",
+                         n, sum[8] / n, sum[7] / n, sum[1] / sum[7], sum[2] / sum[7], sum[3] / sum[7], sum[4] / sum[7], sum[5] / sum[7], sum[0] / sum[7], sum[6] / sum[7], sum[9] / n, life_max);
+        }
+    }
+#endif
+    return 0;
+}
 
 int flash_prefill(const FlashArgs &a, bool paged, hipStream_t s) {
     if (a.ntiles == 0) return 0;
@@ -430,16 +956,32 @@ int flash_prefill(const FlashArgs &a, bool paged, hipStream_t s) {
     p.bs_shift = (a.block_size > 0 && (a.block_size & (a.block_size - 1)) == 0) ? __builtin_ctz(a.block_size) : -1;
     p.tiles = a.tiles; p.H = a.H; p.KVH = a.KVH; p.scale = a.scale; p.out = (half_t *)a.out;
     const int G = a.H / a.KVH;
-    dim3 grid((unsigned)((int64_t)a.ntiles * a.KVH)), block(64 * FLASH_WAVES);
     const bool ub = paged && p.bs_shift >= 0 && a.block_size % NVR_FLASH_KT == 0;
+    if (flash2_shape(a.D)) {
+        if (!a.lanes || a.nlanes <= 0) return nvr::fail(NVR_ERR_INVALID_ARG, "flash_prefill: head_dim 128 takes per-workgroup tile lists (flash_lanes)");
+        p.lanes = a.lanes; p.nlanes = a.nlanes;
+        dim3 grid((unsigned)((int64_t)a.nlanes * a.KVH));
+        int rc = 0;
+#define NVR_FLASH2(GG)                                                              \
+        if (G == GG) rc = ub ? flash2_launch<GG, 2>(p, grid, s) : paged ? flash2_launch<GG, 1>(p, grid, s) : flash2_launch<GG, 0>(p, grid, s);
+        NVR_FLASH2(1) NVR_FLASH2(2) NVR_FLASH2(4)
+#undef NVR_FLASH2
+        if (rc) return rc;
+    } else {
+    dim3 grid((unsigned)((int64_t)a.ntiles * a.KVH)), block(64 * FLASH_WAVES);
 #define NVR_FLASH(DD, GG)                                                                             \
     if (a.D == DD && G == GG) {                                                                       \
         if (ub) flash_prefill_kernel<DD, GG, true, true><<<grid, block, 0, s>>>(p);                   \
         else if (paged) flash_prefill_kernel<DD, GG, true><<<grid, block, 0, s>>>(p);                 \
         else flash_prefill_kernel<DD, GG, false><<<grid, block, 0, s>>>(p);                           \
     }
+#if NVR_F2_ENABLE
+    NVR_FLASH(64, 1) NVR_FLASH(64, 2) NVR_FLASH(64, 4)
+#else
     NVR_FLASH(128, 1) NVR_FLASH(128, 2) NVR_FLASH(128, 4) NVR_FLASH(64, 1) NVR_FLASH(64, 2) NVR_FLASH(64, 4)
+#endif
 #undef NVR_FLASH
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return nvr::fail(NVR_ERR_HIP, "flash_prefill launch failed: %s", hipGetErrorString(e));
     return 0;
@@ -462,7 +1004,7 @@ int flash_shared_prefix(const half_bits *q, int64_t ldq, const half_bits *k_cach
     p.block_tables = block_tables; p.max_blocks = max_blocks; p.block_size = block_size; p.bs_shift = __builtin_ctz(block_size);
     p.H = H; p.KVH = KVH; p.scale = scale; p.nq_total = nq; p.shared_len = shared_len; p.num_parts = num_parts;
     p.part_o = part_o; p.part_ml = part_ml; p.srows = rows; p.scount = count;
-    const int G = H / KVH, qb = flash_tile_positions(H, KVH);
+    const int G = H / KVH, qb = flash_shared_rows(H, KVH);
     dim3 grid((unsigned)((int64_t)((nq + qb - 1) / qb) * KVH), (unsigned)sparts), block(64 * FLASH_WAVES);
 #define NVR_FLASH_S(DD, GG) if (D == DD && G == GG) flash_prefill_kernel<DD, GG, true, true, true><<<grid, block, 0, s>>>(p);
     NVR_FLASH_S(128, 1) NVR_FLASH_S(128, 2) NVR_FLASH_S(128, 4) NVR_FLASH_S(64, 1) NVR_FLASH_S(64, 2) NVR_FLASH_S(64, 4)

@@ -552,9 +552,10 @@ def test_failed_token_wait_without_a_step_in_flight_aborts_the_batch():
     finally:
         os.environ.pop("NVR_P2P_TIMEOUT_MS", None)
     import threading
-    # sequence 0 stops after its 2nd token, sequence 1 goes on: the decode step after the prefill may be sequence 0's last, so it is
-    # not followed by a step launched ahead (can_launch_ahead: "this token could be the last") and ends in the plain sample_wait tail
-    sps = [dict(temperature=0.0, max_tokens=2, ignore_eos=True), dict(temperature=0.0, max_tokens=6, ignore_eos=True)]
+    # Sequence 1 stops with the prefill's token: the prefill is not followed by a step launched ahead (can_launch_ahead: "this token
+    # could be the last"), so the decode step after it is scheduled and executed by ITS OWN call; sequence 0 stops after that step's
+    # token, so that step does not launch ahead either and ends in the plain sample_wait tail.
+    sps = [dict(temperature=0.0, max_tokens=2, ignore_eos=True), dict(temperature=0.0, max_tokens=1, ignore_eos=True)]
     for e in engines:
         nvr.lib().nvr_seq_reset_id_counter()
         for pr, sp in zip(prompts, sps):
