@@ -465,10 +465,10 @@ __device__ unsigned long long f2_stamp_buf[1024 * 12];
 // MODE 0: K/V rows contiguous (p.ldkv apart, first row tile.kv_ref); 1: block tables, any block size; 2: block tables, block size a
 // power of two and a multiple of the 64-key step (a step lies inside one block)
 template <int G, int MODE, int NBUF>
-__global__ __launch_bounds__(512, 2) void flash2_kernel(FlashParams p) {
-    constexpr int D = 128, NT = 512, KT = 64, CPR = 16, PIECES = 2;
+__global__ __launch_bounds__(256, 1) void flash2_kernel(FlashParams p) {   // ONE wave per SIMD: the whole 512-register file per wave
+    constexpr int D = 128, NT = 256, KT = 64, CPR = 16, PIECES = 4, NQ = 2;
     constexpr int STAGE = 2 * KT * D * 2, V_OFF = KT * D * 2;
-    constexpr int PPW = 32 / G;                                       // query positions per wave
+    constexpr int PPW = 32 / G;                                       // query positions per 32-row query tile
     constexpr bool PAGED = MODE != 0, UB = MODE == 2;
     static_assert(V_OFF == PIECES * NT * 16, "the pieces of the K image, then of the V image, NT * 16 bytes apart");
     static_assert(NBUF == 4, "ring depth: K of step t+1 is read during step t (two steps ahead must have landed), one more tile may fly");
@@ -481,8 +481,10 @@ __global__ __launch_bounds__(512, 2) void flash2_kernel(FlashParams p) {
     const int32_t *items = p.lanes + p.nlanes + 1;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int c = lane & 31, h = lane >> 5;
-    const int head = g * G + c / PPW;                                 // the wave's 32 columns are PPW positions x G heads
-    const int qi = wave * PPW + c % PPW;                              // the lane's query position inside a tile
+    const int head = g * G + c / PPW;                                 // a query tile's 32 columns are PPW positions x G heads
+    int qi[NQ];                                                       // the lane's query positions inside a workgroup tile (query tiles 2 wave, 2 wave + 1)
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) qi[j] = (wave * NQ + j) * PPW + c % PPW;
 
     // ---- request cursor: the K/V tile of (item rq_i, step rq_t) goes to ring slot rq_gs % NBUF -------------------------------------------
     int rq_i = it0, rq_t = 0, rq_gs = 0;
@@ -498,17 +500,16 @@ __global__ __launch_bounds__(512, 2) void flash2_kernel(FlashParams p) {
     // the ring starts on a 256-byte boundary (an LDS bank row = one K/V row): the read addresses below are formed with XORs
     const unsigned lds_ring = ((unsigned)(size_t)(__attribute__((address_space(3))) char *)smem + 255u) & ~255u;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    int64_t kconst[PIECES], vconst[PIECES];                           // element offsets of this thread's pieces inside a step
+    int kconst[PIECES], vconst[PIECES];                               // element offsets of this thread's pieces inside a step (< 2^31: checked by the launcher)
 #pragma unroll
     for (int i = 0; i < PIECES; ++i) {
         const int idx = i * NT + threadIdx.x, row = idx / CPR, cc = idx % CPR;
-        const int64_t rowoff = UB ? ((int64_t)row * p.KVH + g) * D : (int64_t)row * p.ldkv + (int64_t)g * D;
+        const int rowoff = UB ? (row * p.KVH + g) * D : row * (int)p.ldkv + g * D;
         kconst[i] = rowoff + (cc ^ (row & 15)) * 8;
         vconst[i] = rowoff + (cc ^ ((row & 3) << 2)) * 8;
     }
-    // A request = the four 1-KiB-per-wave pieces of one K/V tile: addressed by stage(), sent as its K half and its V half by issue_k / issue_v
-    // (the loop puts one half into each of a step's two matrix phases: an LDS-DMA piece costs ~150 cycles of issue inside a vector phase,
-    // ~60 among bare MFMAs)
+    // A request = the eight 1-KiB-per-wave pieces of one K/V tile: addressed by stage(), sent as its K half and its V half (request_k / request_v:
+    // the loop puts one half behind each of a step's two halves)
     const half_t *src[2 * PIECES];
     unsigned rq_dst = 0;
     auto stage = [&](int buf, int kt) {                               // the request cursor's tile, keys kt .. kt+63, into ring slot buf
@@ -561,290 +562,290 @@ __global__ __launch_bounds__(512, 2) void flash2_kernel(FlashParams p) {
             rq_t = 0; bt_chunk = -1;
             if (++rq_i < it1) { rq = p.tiles[items[rq_i]]; rq_end = rq.pos0 + rq.nq; rq_steps = (rq_end + KT - 1) / KT; }
         }
-        const half_t *const ks[PIECES] = {src[0], src[1]};
+        const half_t *const ks[PIECES] = {src[0], src[1], src[2], src[3]};
         glds_pieces<PIECES, NT * 16>(ks, rq_dst);
     };
     auto request_v = [&]() {
         if (!rq_open) return;
-        const half_t *const vs[PIECES] = {src[PIECES], src[PIECES + 1]};
+        const half_t *const vs[PIECES] = {src[PIECES], src[PIECES + 1], src[PIECES + 2], src[PIECES + 3]};
         glds_pieces<PIECES, NT * 16>(vs, rq_dst + V_OFF);
         rq_open = false;
     };
-    auto request_next = [&]() { request_k(); request_v(); };
 
     // ---- per-tile lane data and the Q fragments ----------------------------------------------------------------------------------------------
     FlashTile tile = rq;                                              // the compute cursor's tile (= the first one)
-    half8_t qf[8];
-    bool qvalid; int qpos, qrow;
-    auto lane_of_tile = [&](const FlashTile &t, bool &valid, int &pos, int &row) {
-        valid = qi < t.nq;
-        const int qc = valid ? qi : t.nq - 1;
-        pos = t.pos0 + qc;                                            // absolute position = last visible key
-        row = t.q_row0 + qc;
-    };
-    // The Q rows are loaded by inline asm and waited for by hand (q_wait): as ordinary loads hipcc places the wait itself and, unable to tell the
-    // first tile (nothing behind the loads) from the later ones (the previous tile's 8 output stores behind them), waits for vmcnt(0) at every tile
-    // boundary — the stores' round trip to HBM.  Nothing touches qf between the two statements (checked in the ISA: guide §5.7 form (ii)).
-    auto load_q = [&](int row) {
-        const half_t *qptr = p.q + (int64_t)row * p.ldq + (int64_t)head * D + h * 8;
+    half8_t qf[NQ][8];
+    int qpos[NQ], qrow[NQ];
+    auto lane_of_tile = [&](const FlashTile &t) {
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(qf[ks]) : "v"(qptr + ks * 16) : "memory");
+        for (int j = 0; j < NQ; ++j) {
+            const int qc = qi[j] < t.nq ? qi[j] : t.nq - 1;           // rows past the tile's last query are copies of that query
+            qpos[j] = t.pos0 + qc;                                    // absolute position = last visible key
+            qrow[j] = t.q_row0 + qc;
+        }
     };
-#define F2_Q_WAIT(N) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3]), "+v"(qf[4]), "+v"(qf[5]), "+v"(qf[6]), "+v"(qf[7]) :: "memory")
-    lane_of_tile(tile, qvalid, qpos, qrow);
-    load_q(qrow);
+    // The Q rows are loaded by inline asm STRAIGHT INTO ACCUMULATOR REGISTERS (the MFMA takes its B operand from there) and waited for by hand
+    // (F2_Q_WAIT): as ordinary loads hipcc places the wait itself and, unable to tell the first tile (nothing behind the loads) from the later ones
+    // (the previous tile's 16 output stores behind them), waits for vmcnt(0) at every tile boundary — the stores' round trip to HBM.  Nothing
+    // touches qf between the two statements (guide §5.7 form (ii)).
+    auto load_q = [&]() {
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            const half_t *qptr = p.q + (int64_t)qrow[j] * p.ldq + (int64_t)head * D + h * 8;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(qf[j][ks]) : "v"(qptr + ks * 16) : "memory");
+        }
+    };
+#define F2_Q_WAIT(N) asm volatile("s_waitcnt vmcnt(" #N ")" : "+a"(qf[0][0]), "+a"(qf[0][1]), "+a"(qf[0][2]), "+a"(qf[0][3]), "+a"(qf[0][4]), "+a"(qf[0][5]), "+a"(qf[0][6]), "+a"(qf[0][7]), \
+                                                     "+a"(qf[1][0]), "+a"(qf[1][1]), "+a"(qf[1][2]), "+a"(qf[1][3]), "+a"(qf[1][4]), "+a"(qf[1][5]), "+a"(qf[1][6]), "+a"(qf[1][7]) :: "memory")
+    lane_of_tile(tile);
+    load_q();
     if (UB) load_bt_chunk(0);
 #pragma unroll
-    for (int b = 0; b < NBUF - 1; ++b) request_next();
+    for (int b = 0; b < NBUF - 1; ++b) { request_k(); request_v(); }
 
     // LDS read addresses of this lane inside ring slot 0
     const unsigned kbase = lds_ring + c * 256 + ((h ^ (c & 15)) << 4);   // K row c (+ 32 mt), 16-byte chunk (2 ks + h) ^ (row & 15): ^ (ks << 5)
     const int vq = (lane & 15) >> 2, vp = lane & 3, vg = (lane >> 4) & 1;
     const unsigned vbase = lds_ring + V_OFF + (4 * h + vq) * 256 + ((((vq << 2) | (vg << 1) | (vp >> 1)) << 4) | ((vp & 1) << 3));   // ^ (dt << 6)
 
-    float16_t o[4];
-    float m, mneg, lsum[4];                                           // (four partial row sums: no 16-deep dependent add chain per half)
+    float16_t o[NQ][4];
+    float m[NQ], mneg[NQ], lsum[NQ][4];                               // (four partial row sums: no 16-deep dependent add chain per half)
     const float c2 = p.scale * 1.44269504088896340736f;
 
     // causal mask of 32 keys from k0 on (only where they reach past the tile's first query: a small wave-uniform branch that touches S alone)
-    auto mask = [&](float16_t &S, int k0) {
+    auto mask = [&](float16_t &S, int j, int k0) {
         if (k0 + 31 > tile.pos0) {
-            const int lim = qpos - k0 - 4 * h;                        // key k0 + (e & 3) + 8 (e >> 2) + 4 h is visible iff <= qpos
+            const int lim = qpos[j] - k0 - 4 * h;                     // key k0 + (e & 3) + 8 (e >> 2) + 4 h is visible iff <= qpos
 #pragma unroll
             for (int e = 0; e < 16; ++e)
                 if ((e & 3) + 8 * (e >> 2) > lim) S[e] = -INFINITY;
         }
     };
-    // row maximum and the rare raise of the running maximum; FIRST: the tile's first keys (nothing accumulated yet: the maximum is taken as it is)
-    auto stats = [&](auto first_c, const float16_t &S) {
+    // row maximum and the rare raise of the running maximum; first (wave-uniform): the tile's first keys — nothing accumulated yet, the maximum is
+    // taken as it is (key 0 is visible to every query: it is finite)
+    auto stats = [&](bool first, const float16_t &S, int j) {
         float mx = fmaxf(S[0], S[1]);
 #pragma unroll
         for (int e = 2; e < 16; e += 2) mx = fmaxf(fmaxf(mx, S[e]), S[e + 1]);
         mx = xor32_partner_max(mx);
-        if constexpr (decltype(first_c)::value) { m = mx; mneg = -mx * c2; }     // (key 0 is visible to every query: mx is finite)
-        else {
-            const bool need = (mx - m) * c2 > F2_DEFER;
-            if (__any(need)) {                                        // wave-uniform
-                const float mn = fmaxf(m, mx);
-                const float alpha = __builtin_amdgcn_exp2f((m - mn) * c2);
-                m = mn; mneg = -mn * c2;
+        const bool need = !first && (mx - m[j]) * c2 > F2_DEFER;
+        if (__any(need)) {                                            // wave-uniform, rare
+            const float mn = fmaxf(m[j], mx);
+            const float alpha = __builtin_amdgcn_exp2f((m[j] - mn) * c2);
+            m[j] = mn; mneg[j] = -mn * c2;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) lsum[i] *= alpha;
+            for (int i = 0; i < 4; ++i) lsum[j][i] *= alpha;
+            // (the empty statements pin the accumulator-file reads and writes INSIDE this rare branch: hipcc otherwise hoists the 64
+            //  v_accvgpr_read of a tile's output above the branch, into every half)
 #pragma unroll
-                for (int dt = 0; dt < 4; ++dt)
+            for (int dt = 0; dt < 4; ++dt) {
+                asm volatile("s_nop 7\n\ts_nop 3" : "+a"(o[j][dt]));
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) o[dt][e] *= alpha;
+                for (int e = 0; e < 16; ++e) o[j][dt][e] *= alpha;
+                asm volatile("" : "+a"(o[j][dt]));
             }
         }
+        if (first) { m[j] = mx; mneg[j] = -mx * c2; }
     };
-    // operand fragments are read from LDS a whole phase ahead of their MFMAs
-    auto load_v = [&](int slot, int mt, int s2, half8_t (&vf)[4]) {         // Vᵀ fragments of k-step s2 of key half (slot, mt), d tiles 0..3
-        const unsigned vl = vbase + slot * STAGE + (32 * mt + 16 * s2) * 256;
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            const unsigned a = vl ^ (unsigned)(dt << 6);
-            const half4_t a0 = lds_read_tr16(a), a1 = lds_read_tr16(a + 8 * 256);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { vf[dt][e] = a0[e]; vf[dt][4 + e] = a1[e]; }
-        }
-    };
-    // Two kinds of phases alternate in every wave, separated by workgroup barriers, and waves 4..7 run ONE PHASE BEHIND waves 0..3 (they pass
-    // one extra barrier at the start, waves 0..3 one at the end): on every SIMD one wave is in a matrix phase (16 MFMAs back to back: 512
-    // cycles of the matrix pipe, 128 of the issue port) while its partner is in a vector phase (mask / max / exp / pack of the next 32 keys,
-    // ~110 vector instructions, and the LDS reads of ITS next matrix phase) — the ping-pong of guide T16 with whole-wave roles instead of a
-    // compiler-scheduled mix (first r04 build: interleaved in one stream, both waves of a SIMD stalled on the same pipe at the same time,
-    // 44 % matrix-pipe busy inside the loop).  One score state S: a matrix phase overwrites it with QKᵀ of the NEXT half after the vector
-    // phase has turned the current one into the 16-bit P fragments.
-    float16_t S;
-    half8_t kf[8], vfa[4], vfb[4], pf[2];
-#ifdef NVR_F2_VSTAMPS
-    unsigned long long vacc[4] = {0, 0, 0, 0};
-#endif
-    // Vector phase.  A wave may have 15 LDS reads outstanding (lgkmcnt): the 24 fragment reads of the next matrix phase are therefore cut into
-    // four batches with a quarter of the vector work behind each — issued as one block in front, the wave sat ~670 cycles in the issue of its own
-    // reads (all four vector-phase waves of the CU asking the LDS at once) before its first vector instruction.
-    auto load_k4 = [&](auto lo_c, int slot, int mt) {                       // K fragments ks = LO .. LO+3 of key half (slot, mt)
-        constexpr int LO = decltype(lo_c)::value;
-        const unsigned kl = kbase + slot * STAGE + mt * 8192;
-#pragma unroll
-        for (int ks = LO; ks < LO + 4; ++ks) kf[ks] = *lds_ptr<const half8_t>(kl ^ (unsigned)(ks << 5));
-    };
-    auto expo8 = [&](auto e0_c) {                                           // p = 2^((s - m) c2) of registers E0 .. E0+7 = k-step E0 / 8, row sums
-        constexpr int E0 = decltype(e0_c)::value;
-#pragma unroll
-        for (int e = E0; e < E0 + 8; ++e) {
-#ifdef NVR_F2_X_NOEXP
-            const float pe = fmaf(S[e], c2, mneg);
+    // ---- the matrix work is issued by inline asm -----------------------------------------------------------------------------------------------
+    // One wave per SIMD owns 512 registers, but hipcc's allocator does not split them by role: as builtins the MFMAs got their score
+    // accumulators in the accumulator file and the Q operands in the vector file, and ~2000 v_accvgpr moves per step shuttled scores to the
+    // vector ALU.  As asm statements the classes are stated: O and Q live in accumulator registers ("a"), the scores, the K / V fragments and P in
+    // vector registers ("v").  An asm statement is also a scheduling boundary for hipcc: the source order below IS the issue order — one MFMA,
+    // then the slice of vector work and LDS reads that its 32 cycles hide (guide: <= 5 single-issue instructions per gap, one of them a v_exp).
+    // Hazards hipcc does not see (guide §5.7 item 2): a P fragment written by the vector ALU just before the MFMA that reads it (s_nop 1 opens
+    // the P·V statements); MFMA results read by anything but the next MFMA of the chain need 12 wait states (mfma_settle / instruction distance).
+#ifdef NVR_BF16
+#define F2_MFMA "v_mfma_f32_32x32x16_bf16"
 #else
-            const float pe = __builtin_amdgcn_exp2f(fmaf(S[e], c2, mneg));
+#define F2_MFMA "v_mfma_f32_32x32x16_f16"
 #endif
-            lsum[e & 3] += pe;
-            pf[e >> 3][e & 7] = (half_t)pe;
-        }
+    half8_t kf[8], vf[2][4];                                          // K fragments of one key half; V fragments of one key half ([k-step][d tile])
+    float16_t S[NQ];                                                  // ONE score state per query tile
+    half2_t pw[NQ][2][4];                                             // 16-bit P fragments per query tile ([k-step][dword])
+    auto mfma_settle = [&]() { asm volatile("s_nop 11" ::: "memory"); };
+    // (sched_barrier(0) in front of every MFMA: the vector work written behind the previous one stays there)
+    auto qk_first = [&](int j) { __builtin_amdgcn_sched_barrier(0); asm volatile(F2_MFMA " %0, %1, %2, 0" : "=&v"(S[j]) : "v"(kf[0]), "a"(qf[j][0])); };
+    auto qk_more = [&](int j, int ks) { __builtin_amdgcn_sched_barrier(0); asm volatile(F2_MFMA " %0, %1, %2, %0" : "+v"(S[j]) : "v"(kf[ks]), "a"(qf[j][ks])); };
+    auto pv_one = [&](int j, int s2, int dt) {
+        half8_t pfrag;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { pfrag[2 * w] = pw[j][s2][w][0]; pfrag[2 * w + 1] = pw[j][s2][w][1]; }
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_nop 1\n\t" F2_MFMA " %0, %1, %2, %0" : "+a"(o[j][dt]) : "v"(vf[s2][dt]), "v"(pfrag));
     };
-    using I0 = std::integral_constant<int, 0>; using I4 = std::integral_constant<int, 4>; using I8 = std::integral_constant<int, 8>;
-    auto v_phase = [&](auto first_c, auto has_next_c, int slot, int mt, int slot_kn, int mtn, int k0) {
+    auto read_k = [&](int ks, int slot, int mt) {                     // K fragment ks of key half (slot, mt)
+        const unsigned kl = kbase + slot * STAGE + mt * 8192;
+        kf[ks] = *lds_ptr<const half8_t>(kl ^ (unsigned)(ks << 5));
+    };
+    auto read_v = [&](int s2, int dt, int slot, int mt) {             // Vᵀ fragment (k-step s2, d tile dt) of key half (slot, mt): two transposing reads
+        const unsigned a = (vbase + slot * STAGE + (32 * mt + 16 * s2) * 256) ^ (unsigned)(dt << 6);
+        const half4_t a0 = lds_read_tr16(a), a1 = lds_read_tr16(a + 8 * 256);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { vf[s2][dt][e] = a0[e]; vf[s2][dt][4 + e] = a1[e]; }
+    };
+    // p = 2^((s - m) c2) of accumulator registers e, e+1 of tile j (k-step e >> 3), their row sums, packed into the P fragment
+    auto expo2 = [&](int j, int e) {
+        const float p0 = __builtin_amdgcn_exp2f(fmaf(S[j][e], c2, mneg[j])), p1 = __builtin_amdgcn_exp2f(fmaf(S[j][e + 1], c2, mneg[j]));
+        lsum[j][e & 3] += p0; lsum[j][(e + 1) & 3] += p1;
+        pw[j][e >> 3][(e & 7) >> 1] = (half2_t){(half_t)p0, (half_t)p1};
+    };
+    // One wave per SIMD has no partner to fill its matrix pipe while it does the softmax, so its TWO query tiles take turns: they run half a
+    // 32-key half apart, each with ONE score state, and every group of eight MFMAs of one tile carries half of the other tile's softmax:
+    //   g0: S1 = QKᵀ(q1, u)        | softmax(q0, u) second part: exp of registers 8..15                  | reads: V(u), 16 transposing reads
+    //   g1: O0 += P·V(q0, u)       | softmax(q1, u) first part: mask, row max (rare rescale), exp 0..7    | reads: K(u+1), 8 b128
+    //   g2: S0 = QKᵀ(q0, u+1)      | softmax(q1, u) second part                                           | (+ the K half of a K/V request)
+    //   g3: O1 += P·V(q1, u)       | softmax(q0, u+1) first part                                          | (+ the V half)
+    // In g1 / g3 the scores were finished by the group before: the first two gaps carry the LDS reads / the request, the row max follows.
+    auto half_step = [&](bool first, auto has_next_c, auto dma_c, int slot, int mt, int slot_n, int mtn, int k0, int k0n) {
         constexpr bool HAS_NEXT = decltype(has_next_c)::value;
-#ifdef NVR_F2_VSTAMPS
-        F2_STAMP(v0);
-#endif
-        load_v(slot, mt, 0, vfa);                                     // operands of the matrix phase that follows: P·V of this half ...
-        mask(S, k0);
-        __builtin_amdgcn_sched_barrier(0);
-#ifdef NVR_F2_VSTAMPS
-        F2_STAMP(v1);
-#endif
-        load_v(slot, mt, 1, vfb);
-        stats(first_c, S);
-        __builtin_amdgcn_sched_barrier(0);
-#ifdef NVR_F2_VSTAMPS
-        F2_STAMP(v2);
-#endif
-        if constexpr (HAS_NEXT) load_k4(I0{}, slot_kn, mtn);          // ... and QKᵀ of the next one
-        expo8(I0{});
-        __builtin_amdgcn_sched_barrier(0);
-#ifdef NVR_F2_VSTAMPS
-        F2_STAMP(v3);
-#endif
-        if constexpr (HAS_NEXT) load_k4(I4{}, slot_kn, mtn);
-        expo8(I8{});
-#ifdef NVR_F2_VSTAMPS
-        F2_STAMP(v4);
-        vacc[0] += v1 - v0; vacc[1] += v2 - v1; vacc[2] += v3 - v2; vacc[3] += v4 - v3;
-#endif
-    };
-    // Matrix phase: 16 MFMAs back to back; DMA = 1 / 2: the K / V half of the next K/V request rides among them
-    auto m_phase = [&](auto has_next_c, auto dma_c) {
         constexpr int DMA = decltype(dma_c)::value;
-#ifndef NVR_F2_X_NOPRIO
-        __builtin_amdgcn_s_setprio(1);
-#endif
+        // g0
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) o[dt] = mfma32(vfa[dt], pf[0], o[dt]);
-        if constexpr (DMA == 1) request_k();
-        if constexpr (DMA == 2) request_v();
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) o[dt] = mfma32(vfb[dt], pf[1], o[dt]);
-        if constexpr (decltype(has_next_c)::value) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) S[e] = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < 8; ++ks) S = mfma32(kf[ks], qf[ks], S);
+        for (int i = 0; i < 8; i += 2) {
+            if (i == 0) qk_first(1); else qk_more(1, i);
+            read_v(i >> 2, i & 3, slot, mt);
+            expo2(0, 8 + i);                                          // (registers 8+i, 9+i: one pair per two gaps)
+            qk_more(1, i + 1);
+            read_v((i + 1) >> 2, (i + 1) & 3, slot, mt);
         }
-#ifndef NVR_F2_X_NOPRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
+        // g1
+        pv_one(0, 0, 0);
+        if constexpr (HAS_NEXT) { read_k(0, slot_n, mtn); read_k(1, slot_n, mtn); read_k(2, slot_n, mtn); read_k(3, slot_n, mtn); }
+        pv_one(0, 0, 1);
+        if constexpr (HAS_NEXT) { read_k(4, slot_n, mtn); read_k(5, slot_n, mtn); read_k(6, slot_n, mtn); read_k(7, slot_n, mtn); }
+        pv_one(0, 0, 2);
+        mask(S[1], 1, k0);
+        stats(first, S[1], 1);
+        pv_one(0, 0, 3);
+        expo2(1, 0);
+        pv_one(0, 1, 0);
+        expo2(1, 2);
+        pv_one(0, 1, 1);
+        expo2(1, 4);
+        pv_one(0, 1, 2);
+        expo2(1, 6);
+        pv_one(0, 1, 3);
+        // g2
+        if constexpr (HAS_NEXT) {
+#pragma unroll
+            for (int i = 0; i < 8; i += 2) {
+                if (i == 0) qk_first(0); else qk_more(0, i);
+                expo2(1, 8 + i);
+                qk_more(0, i + 1);
+                if (DMA == 1 && i == 2) request_k();
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; i += 2) expo2(1, 8 + i);
+            if constexpr (DMA == 1) request_k();
+        }
+        // g3
+        pv_one(1, 0, 0);
+        if constexpr (DMA == 2) request_v();
+        pv_one(1, 0, 1);
+        pv_one(1, 0, 2);
+        if constexpr (HAS_NEXT) { mask(S[0], 0, k0n); stats(false, S[0], 0); }
+        pv_one(1, 0, 3);
+        if constexpr (HAS_NEXT) expo2(0, 0);
+        pv_one(1, 1, 0);
+        if constexpr (HAS_NEXT) expo2(0, 2);
+        pv_one(1, 1, 1);
+        if constexpr (HAS_NEXT) expo2(0, 4);
+        pv_one(1, 1, 2);
+        if constexpr (HAS_NEXT) expo2(0, 6);
+        pv_one(1, 1, 3);
     };
     auto slot_of = [&](int gs) { return __builtin_amdgcn_readfirstlane(gs % NBUF); };
-    // (lgkmcnt(0): a wave's LDS reads have EXECUTED when it reaches the barrier — the next request into the slot they read follows this barrier)
-    auto phase_end = [&]() {
-        __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0);
-    };
-#ifdef NVR_F2_X_NOLAG
-    const bool late = false;
-#else
-    const bool late = __builtin_amdgcn_readfirstlane(wave) >= 4;
-#endif
 
-    // the first three K/V tiles and the first Q rows: landed for every wave (own wait, then a barrier both groups have passed)
+    // the first three K/V tiles and the first Q rows have landed for every wave
     F2_Q_WAIT(0);                                                     // (all but the N youngest vector-memory operations of this wave are done)
-    phase_end();
-    if (late) phase_end();                                            // waves 4..7: one phase behind from here on
+    __builtin_amdgcn_s_barrier();
 
 #ifdef NVR_F2_STAMPS
-    unsigned long long acc_bound = 0, acc_req = 0, acc_h0 = 0, acc_h1 = 0, acc_wait = 0, acc_last = 0, acc_epi = 0, n_steps = 0;
+    unsigned long long acc_bound = 0, acc_h0 = 0, acc_h1 = 0, acc_wait = 0, acc_last = 0, acc_epi = 0, n_steps = 0;
 #endif
     int gs = 0;                                                       // global (virtual) step of the compute cursor
     for (int it = it0; it < it1; ++it) {
         F2_STAMP(tb0);
         const int kv_end = tile.pos0 + tile.nq, nsteps = (kv_end + KT - 1) / KT;
-        // Tile boundary.  The K/V tile of the first step landed long ago (the wait in the previous tile's last step, or the one above); the Q rows
-        // were requested behind the previous tile's last matrix phase, in front of its 8 output stores: vmcnt(8) leaves exactly those in flight.
-        if (it != it0) F2_Q_WAIT(8);
-        m = -INFINITY; mneg = 0.f;
+        // Tile boundary.  The K/V tile of the first step landed long ago (the wait of the previous tile's last loop step, or the one above); the Q
+        // rows were requested behind the previous tile's last matrix work, in front of its 16 output stores: vmcnt(16) leaves exactly those in flight.
+        if (it != it0) F2_Q_WAIT(16);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) lsum[i] = 0.f;
+        for (int j = 0; j < NQ; ++j) {
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
+            for (int i = 0; i < 4; ++i) lsum[j][i] = 0.f;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) o[dt][e] = 0.f;
-        load_k4(I0{}, slot_of(gs), 0); load_k4(I4{}, slot_of(gs), 0);
+            for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) S[e] = 0.f;
-        __builtin_amdgcn_s_setprio(1);
+                for (int e = 0; e < 16; ++e) o[j][dt][e] = 0.f;
+        }
+        {   // query tile 0 runs ahead: its scores of the first half and the first part of their softmax
+            const int sl = slot_of(gs);
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) S = mfma32(kf[ks], qf[ks], S);
-        __builtin_amdgcn_s_setprio(0);
-        phase_end();
+            for (int ks = 0; ks < 8; ++ks) read_k(ks, sl, 0);
+            qk_first(0);
+#pragma unroll
+            for (int ks = 1; ks < 8; ++ks) qk_more(0, ks);
+            mfma_settle();
+            mask(S[0], 0, 0);
+            stats(true, S[0], 0);
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) expo2(0, e);
+        }
         F2_STAMP(tb1);
-        // end of a step's first vector phase: the NEXT step's K/V tile has landed for this wave (everything requested behind it may fly)
-        // (the request of the step three ahead went out in the previous step's two matrix phases: one tile may fly behind the one waited for)
-        auto step_wait = [&]() {
-            if (rq_gs - 1 > gs + 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PIECES) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        };
-        // V(0, 0): the tile's first keys
-        v_phase(std::true_type{}, std::true_type{}, slot_of(gs), 0, slot_of(gs), 1, 0);
-        step_wait();
-        phase_end();
-        for (int t = 0; t + 1 < nsteps; ++t) {                        // [M(t,0) V(t,1) M(t,1) V(t+1,0)]: no branch around the matrix work
+        for (int t = 0; t + 1 < nsteps; ++t, ++gs) {
             F2_STAMP(ta);
             const int sl = slot_of(gs), sn = slot_of(gs + 1);
-            m_phase(std::true_type{}, std::integral_constant<int, 1>{});   // P·V(t, 0), QKᵀ(t, 1); K half of the request of step t + 3
-            F2_STAMP(ta2);
-            phase_end();
-            F2_STAMP(tb);
-            v_phase(std::false_type{}, std::true_type{}, sl, 1, sn, 0, t * KT + 32);
-            F2_STAMP(tb2);
-            phase_end();
+            half_step(t == 0, std::true_type{}, std::integral_constant<int, 1>{}, sl, 0, sl, 1, t * KT, t * KT + 32);
             F2_STAMP(tc);
-            m_phase(std::true_type{}, std::integral_constant<int, 2>{});   // P·V(t, 1), QKᵀ(t+1, 0); V half of the request
-            phase_end();
+            half_step(false, std::true_type{}, std::integral_constant<int, 2>{}, sl, 1, sn, 0, t * KT + 32, (t + 1) * KT);
             F2_STAMP(td);
-            ++gs;
-            F2_STAMP(td2);
-            v_phase(std::false_type{}, std::true_type{}, sn, 0, sn, 1, (t + 1) * KT);
-            F2_STAMP(td3);
-            step_wait();
-            phase_end();
+            // end of step: virtual step gs + 2 (K of the step after the next) has landed for this wave; the request sent during this step may fly
+            if (rq_gs - 1 > gs + 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PIECES) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // (this wave's LDS reads have executed: the next request into the slot they read follows the barrier)
+            __builtin_amdgcn_s_barrier();
             F2_STAMP(te);
 #ifdef NVR_F2_STAMPS
-            acc_req += ta2 - ta; acc_h0 += tb - ta2; acc_h1 += tb2 - tb; acc_wait += tc - tb2; acc_last += td2 - td; acc_bound += td3 - td2; acc_epi += te - td3; ++n_steps;
+            acc_h0 += tc - ta; acc_h1 += td - tc; acc_wait += te - td; ++n_steps;
 #endif
         }
-        {                                                             // the last step's M(·,0) V(·,1) M(·,1)
+        F2_STAMP(tl0);
+        {   // last step of the tile: no scores behind its second half
             const int sl = slot_of(gs);
-            m_phase(std::true_type{}, std::integral_constant<int, 1>{});
-            phase_end();
-            v_phase(std::false_type{}, std::false_type{}, sl, 1, 0, 0, (nsteps - 1) * KT + 32);
-            phase_end();
-            m_phase(std::false_type{}, std::integral_constant<int, 2>{});   // the tile's last matrix work; Q is dead from here on
-            phase_end();
+            half_step(nsteps == 1, std::true_type{}, std::integral_constant<int, 1>{}, sl, 0, sl, 1, (nsteps - 1) * KT, (nsteps - 1) * KT + 32);
+            half_step(false, std::false_type{}, std::integral_constant<int, 2>{}, sl, 1, 0, 0, (nsteps - 1) * KT + 32, 0);
             ++gs;
         }
+        mfma_settle();                                                // (the output accumulators are read by ordinary code from here on)
         F2_STAMP(tl1);
-        // the next tile's Q rows (requested before this tile's output stores: see the boundary wait)
-        const bool done_valid = qvalid; const int done_row = qrow;
+        // the next tile's Q rows (requested before this tile's output stores: see the boundary wait); Q is dead since the last QKᵀ
+        int done_row[NQ];
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) done_row[j] = qrow[j];
         if (it + 1 < it1) {
             tile = p.tiles[items[it + 1]];
-            lane_of_tile(tile, qvalid, qpos, qrow);
-            load_q(qrow);
+            lane_of_tile(tile);
+            load_q();
         }
-        (void)done_valid;
-        {
-            // Every lane stores (rows past the tile's last query are copies of that query: identical bytes to the same address), so that a wave
-            // issues exactly 8 stores: the boundary wait counts on it.  A query's row is split over lanes l and l ^ 32 (d 8b+4h .. +3 each): one
-            // v_permlane32_swap per dword of two neighbouring groups leaves 16 contiguous bytes in each lane (guide T21).
-            const float ls = xor32_partner_sum((lsum[0] + lsum[1]) + (lsum[2] + lsum[3]));   // (the halves of a query swap their sums)
+        // Every lane stores (rows past the tile's last query are copies of that query: identical bytes to the same address), so that a wave
+        // issues exactly 16 stores: the boundary wait counts on it.  A query's row is split over lanes l and l ^ 32 (d 8b+4h .. +3 each): one
+        // v_permlane32_swap per dword of two neighbouring groups leaves 16 contiguous bytes in each lane (guide T21).
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            const float ls = xor32_partner_sum((lsum[j][0] + lsum[j][1]) + (lsum[j][2] + lsum[j][3]));   // (the halves of a query swap their sums)
             const float inv = ls > 0.f ? 1.0f / ls : 0.f;
-            char *orow = reinterpret_cast<char *>(p.out + ((int64_t)done_row * p.H + head) * D) + 16 * h;
+            char *orow = reinterpret_cast<char *>(p.out + ((int64_t)done_row[j] * p.H + head) * D) + 16 * h;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
                 for (int b = 0; b < 4; b += 2) {                      // registers 4b..4b+3 = d 32 dt + 8 b + 4 h + 0..3
                     union { half4_t v; unsigned u[2]; } ga, gb;
-                    ga.v = (half4_t){(half_t)(o[dt][4 * b] * inv), (half_t)(o[dt][4 * b + 1] * inv), (half_t)(o[dt][4 * b + 2] * inv), (half_t)(o[dt][4 * b + 3] * inv)};
-                    gb.v = (half4_t){(half_t)(o[dt][4 * b + 4] * inv), (half_t)(o[dt][4 * b + 5] * inv), (half_t)(o[dt][4 * b + 6] * inv), (half_t)(o[dt][4 * b + 7] * inv)};
+                    ga.v = (half4_t){(half_t)(o[j][dt][4 * b] * inv), (half_t)(o[j][dt][4 * b + 1] * inv), (half_t)(o[j][dt][4 * b + 2] * inv), (half_t)(o[j][dt][4 * b + 3] * inv)};
+                    gb.v = (half4_t){(half_t)(o[j][dt][4 * b + 4] * inv), (half_t)(o[j][dt][4 * b + 5] * inv), (half_t)(o[j][dt][4 * b + 6] * inv), (half_t)(o[j][dt][4 * b + 7] * inv)};
                     const auto r0 = __builtin_amdgcn_permlane32_swap(ga.u[0], gb.u[0], false, false);
                     const auto r1 = __builtin_amdgcn_permlane32_swap(ga.u[1], gb.u[1], false, false);
                     // lanes 0..31: d 8b .. 8b+7 = [own group b | partner's group b]; lanes 32..63: d 8b+8 .. 8b+15 = [partner's group b+1 | own group b+1]
@@ -853,19 +854,18 @@ __global__ __launch_bounds__(512, 2) void flash2_kernel(FlashParams p) {
                 }
         }
         F2_STAMP(tl2);
-
-    }
-#ifndef NVR_F2_X_NOLAG
-    if (!late) phase_end();                                           // waves 0..3: the barrier waves 4..7 passed at the start
+#ifdef NVR_F2_STAMPS
+        acc_bound += tb1 - tb0; acc_last += tl1 - tl0; acc_epi += tl2 - tl1;
 #endif
+        // the slot of this tile's last step is requested again by the next tile's first step: its reads (above) are ordered before that by a barrier
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
 #ifdef NVR_F2_STAMPS
     F2_STAMP(ts9);
     if (threadIdx.x == 0 && blockIdx.x < 1024) {
         unsigned long long *d = f2_stamp_buf + (size_t)blockIdx.x * 12;
-#ifdef NVR_F2_VSTAMPS
-        acc_req = vacc[0]; acc_h0 = vacc[1]; acc_h1 = vacc[2]; acc_wait = vacc[3]; n_steps = n_steps * 2 + (it1 - it0) * 2;
-#endif
-        d[0] = acc_bound; d[1] = acc_req; d[2] = acc_h0; d[3] = acc_h1; d[4] = acc_wait; d[5] = acc_last; d[6] = acc_epi; d[7] = n_steps; d[8] = it1 - it0; d[9] = ts9 - ts0;
+        d[0] = acc_bound; d[1] = 0; d[2] = acc_h0; d[3] = acc_h1; d[4] = acc_wait; d[5] = acc_last; d[6] = acc_epi; d[7] = n_steps; d[8] = it1 - it0; d[9] = ts9 - ts0;
     }
 #endif
 }
@@ -928,7 +928,7 @@ static int flash2_launch(const FlashParams &p, dim3 grid, hipStream_t s) {
         if (e != hipSuccess) return nvr::fail(NVR_ERR_HIP, "flash_prefill: hipFuncSetAttribute: %s", hipGetErrorString(e));
         ready = true;
     }
-    flash2_kernel<G, MODE, NBUF><<<grid, dim3(512), LDS, s>>>(p);
+    flash2_kernel<G, MODE, NBUF><<<grid, dim3(256), LDS, s>>>(p);
 #ifdef NVR_F2_STAMPS
     {
         static int calls = 0;
@@ -939,8 +939,8 @@ static int flash2_launch(const FlashParams &p, dim3 grid, hipStream_t s) {
             hipMemcpyFromSymbol(hbuf.data(), HIP_SYMBOL(f2_stamp_buf), n * 12 * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
             double sum[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, life_max = 0;
             for (size_t i = 0; i < n; ++i) { for (int j = 0; j < 10; ++j) sum[j] += (double)hbuf[i * 12 + j]; life_max = std::max(life_max, (double)hbuf[i * 12 + 9]); }
-            std::fprintf(stderr, "[f2 stamps] %zu workgroups, %.1f tiles each, %.1f loop steps each | per loop step (wave 0): M work %.0f, barrier %.0f, V work %.0f, barrier %.0f, request %.0f, V(step start) work %.0f, counted wait + barrier %.0f | lifetime mean %.0f max %.0f cycles\n",
-                         n, sum[8] / n, sum[7] / n, sum[1] / sum[7], sum[2] / sum[7], sum[3] / sum[7], sum[4] / sum[7], sum[5] / sum[7], sum[0] / sum[7], sum[6] / sum[7], sum[9] / n, life_max);
+            std::fprintf(stderr, "[f2 stamps] %zu workgroups, %.1f tiles each, %.1f loop steps each | per tile: boundary %.0f, last step %.0f, epilogue %.0f | per loop step (wave 0): half0 %.0f half1 %.0f wait+barrier %.0f | lifetime mean %.0f max %.0f cycles\n",
+                         n, sum[8] / n, sum[7] / n, sum[0] / sum[8], sum[5] / sum[8], sum[6] / sum[8], sum[2] / sum[7], sum[3] / sum[7], sum[4] / sum[7], sum[9] / n, life_max);
         }
     }
 #endif
