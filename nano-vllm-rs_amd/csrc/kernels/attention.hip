@@ -389,7 +389,7 @@ static int launch_attn(const AttnArgs &a, bool paged, hipStream_t s) {
         // the shared keys [0, shared_len) are cut into sparts equal partitions (64-key granularity) until the MFMA launch has ~256
         // workgroups; the keys behind them are partitioned like a context of their own (one partition per pair when there are
         // enough pairs, else ~256 workgroups)
-        const int qb = flash_shared_rows(a.H, a.KVH);
+        const int qb = flash_tile_positions(a.H, a.KVH);
         const int64_t wgs = (int64_t)((a.nq + qb - 1) / qb) * a.KVH, n64 = a.shared_len / 64;
         int64_t c = std::min<int64_t>(std::max<int64_t>(1, (256 + wgs - 1) / wgs), n64);
         while (n64 % c) --c;

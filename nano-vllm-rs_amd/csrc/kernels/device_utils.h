@@ -84,27 +84,6 @@ __device__ __forceinline__ half4_t lds_read_tr16(const char *lds_addr) {
 #endif
 }
 
-// an LDS byte address (a 32-bit integer, as the DS instructions take it) as a pointer: no generic -> local address-space cast (a compare and
-// a select per access) in front of every read.  (The host pass of hipcc sees 64-bit pointers here and never runs this.)
-template <typename T>
-__device__ __forceinline__ __attribute__((address_space(3))) T *lds_ptr(unsigned lds_byte_addr) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return (__attribute__((address_space(3))) T *)lds_byte_addr;
-#else
-    return (__attribute__((address_space(3))) T *)(size_t)lds_byte_addr;
-#endif
-}
-// the transposing read from an LDS byte address
-__device__ __forceinline__ half4_t lds_read_tr16(unsigned lds_byte_addr) {
-#ifdef NVR_BF16
-    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16(lds_ptr<half4_t>(lds_byte_addr));
-#else
-    typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
-    const fp16x4_t r = __builtin_amdgcn_ds_read_tr16_b64_v4f16(lds_ptr<fp16x4_t>(lds_byte_addr));
-    return (half4_t){(half_t)r[0], (half_t)r[1], (half_t)r[2], (half_t)r[3]};
-#endif
-}
-
 // f32 -> fp16 (bf16 build: -> bfloat16), round-to-nearest-even, as a standalone conversion.  The empty asm makes the f32 value
 // opaque so that hipcc (-ffp-contract=fast) cannot fold the producing multiply/add into a single-rounding
 // v_fma_mixlo_f16: the oracle rounds twice (f32 op, then fp16), and bit-exact parity needs the same.

@@ -126,10 +126,7 @@ size_t attn_workspace_bytes(int64_t nq, int64_t H, int64_t D, int64_t max_ctx);
 int attention(const AttnArgs &a, bool paged, hipStream_t s);
 
 bool flash_prefill_ok(int D, int H, int KVH);
-int flash_tile_positions(int H, int KVH, int D);      // query positions per tile of flash_prefill (FlashArgs::tiles are built for it)
-int flash_shared_rows(int H, int KVH);                // sequences per workgroup of flash_shared_prefix
-size_t flash_lanes_ints(int ntiles);                  // ints of the per-workgroup tile lists below
-int flash_lanes(const FlashTile *tiles, int ntiles, int KVH, int D, int ncu, int32_t *out);   // host: -> nlanes (0: this head_dim needs none)
+int flash_tile_positions(int H, int KVH);
 int flash_prefill(const FlashArgs &a, bool paged, hipStream_t s);
 int flash_shared_prefix(const half_bits *q, int64_t ldq, const half_bits *k_cache, const half_bits *v_cache, const int32_t *block_tables,
                         int32_t max_blocks, int32_t block_size, int32_t nq, int32_t H, int32_t KVH, int32_t D, float scale,

@@ -40,7 +40,7 @@ struct AttnArgs {
     const int32_t *shared_rows, *shared_kv0, *shared_count;
 };
 
-// MFMA flash prefill attention.  A tile = up to flash_tile_positions() consecutive query positions of one sequence.
+// MFMA flash prefill attention.  A tile = up to 64/G consecutive query positions of one sequence.
 struct FlashTile { int32_t q_row0, nq, pos0, kv_ref; };   // first q row, #queries, absolute position of the first query,
                                                           // contiguous: first key row of the sequence / paged: block-table row
 struct FlashArgs {
@@ -48,7 +48,6 @@ struct FlashArgs {
     const half_bits *k, *v; int64_t ldkv;                  // contiguous rows (stride ldkv) or paged caches [NB, bs, KVH, D]
     const int32_t *block_tables; int32_t max_blocks, block_size;
     const FlashTile *tiles; int32_t ntiles;                // device array
-    const int32_t *lanes; int32_t nlanes;                  // device array from flash_lanes (head_dim 128: persistent workgroups), else null / 0
     int32_t H, KVH, D; float scale;
     half_bits *out;                                        // [rows, H, D]
 };

@@ -118,7 +118,6 @@ int nvr_model_runner::init() {                                       // ModelRun
     }
     // the hipGraph decode path launches attention with max_ctx = the 256-token context bucket, which can exceed max_pos:
     // the split-KV workspace is sized for the largest bucket (launch_attn checks the bytes it is given)
-    { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && v > 0) num_cus = v; }
     attn_ws_bytes = KD(attn_workspace_bytes(max_seqs, H, D, (max_pos + 255) / 256 * 256));
     NVR_HIP_CHECK(hipMalloc(&attn_ws, attn_ws_bytes));
     // step-input arena
@@ -128,7 +127,7 @@ int nvr_model_runner::init() {                                       // ModelRun
     carve(off_ids, max_tokens * 8); carve(off_pos, max_tokens * 8); carve(off_slots, max_tokens * 4);
     carve(off_cu, (max_seqs + 1) * 4); carve(off_ctx, std::max(max_tokens, max_seqs) * 4);
     carve(off_kvbase, max_tokens * 4); carve(off_bt, 16);
-    carve(off_tiles, (size_t)(max_tokens / 16 + max_seqs + 1) * (sizeof(k::FlashTile) + 4) + 260 * 4);   // tiles + the per-workgroup tile lists (flash_lanes)
+    carve(off_tiles, (size_t)(max_tokens / 16 + max_seqs + 1) * sizeof(k::FlashTile));
     {
         size_t o = 0;
         auto sub = [&](size_t &f, size_t bytes) { f = o; o += (bytes + 15) / 16 * 16; };
@@ -517,7 +516,6 @@ int nvr_model_runner::forward(int64_t T, int64_t B, bool is_prefill, int64_t max
                 f.k = k_cache(l); f.v = v_cache(l); f.ldkv = KVH * D;
             } else { f.k = qkv + H * D; f.v = qkv + (H + KVH) * D; f.ldkv = QKV; }
             f.tiles = (const k::FlashTile *)(in_dev + off_tiles); f.ntiles = (int32_t)n_tiles;
-            f.lanes = flash_nlanes ? (const int32_t *)(f.tiles + n_tiles) : nullptr; f.nlanes = flash_nlanes;
             f.H = (int32_t)H; f.KVH = (int32_t)KVH; f.D = (int32_t)D; f.scale = scale; f.out = attn;
             RC(KD(flash_prefill(f, prefill_paged, st)));
         } else if (is_prefill) {                                     // head shapes outside the MFMA kernel: row kernel
@@ -620,7 +618,7 @@ int nvr_model_runner::execute(nvr_seq *const *seqs, size_t nseq, bool is_prefill
                 if (sq.block_table[j] != sq.block_table[j - 1] + 1) { prefill_kv_cache = false; break; }
         }
         if (flash_ok && !prefill_paged && !mc.qk_norm && !prefill_kv_cache) prefill_paged = true;
-        const int qb = flash_ok ? KD(flash_tile_positions((int)H, (int)KVH, (int)D)) : 1;
+        const int qb = flash_ok ? KD(flash_tile_positions((int)H, (int)KVH)) : 1;
         {   // the step's arrays back to back at the start of the arena (sized by THIS step's token count): one upload instead of seven
             size_t o = 0;
             auto sub = [&](size_t &f, size_t bytes) { f = o; o += (bytes + 63) / 64 * 64; };
@@ -628,7 +626,7 @@ int nvr_model_runner::execute(nvr_seq *const *seqs, size_t nseq, bool is_prefill
             sub(off_kvbase, (size_t)total * 4); sub(off_cu, (nseq + 1) * 4);
             // (tiles exist only for the flash kernel; the row-kernel path — GQA group 8, head_dim outside 64 / 128 — reserves none: with
             //  qb = 1 a tile per token would not fit what init() carved, max_tokens / 16 tiles)
-            sub(off_tiles, flash_ok ? (size_t)(total / qb + (int64_t)nseq + 1) * (sizeof(k::FlashTile) + 4) + 260 * 4 : 0);
+            sub(off_tiles, flash_ok ? (size_t)(total / qb + (int64_t)nseq + 1) * sizeof(k::FlashTile) : 0);
             prefill_bytes = o;
             if (prefill_bytes > off_dec) return nvr::fail(NVR_ERR_INVARIANT, "prefill input region: %zu bytes needed, %zu carved", prefill_bytes, off_dec);
             d_ids = (int64_t *)(in_dev + off_ids); d_pos = (int64_t *)(in_dev + off_pos); d_slots = (int32_t *)(in_dev + off_slots);
@@ -693,8 +691,6 @@ int nvr_model_runner::execute(nvr_seq *const *seqs, size_t nseq, bool is_prefill
                     t0 = t1;
                 }
             }
-            // head_dim 128: persistent workgroups, each with its list of tiles (behind the tile array, same upload)
-            flash_nlanes = KD(flash_lanes(tl, (int)n_tiles, (int)KVH, (int)D, num_cus, (int32_t *)(tl + n_tiles)));
         }
     } else {
         for (size_t b = 0; b < nseq; ++b) {
@@ -720,8 +716,7 @@ int nvr_model_runner::execute(nvr_seq *const *seqs, size_t nseq, bool is_prefill
     // one H2D per array actually used this step (K19)
     auto up = [&](size_t off, size_t bytes) { return hipMemcpyAsync(in_dev + off, in_host + off, bytes, hipMemcpyHostToDevice, stream); };
     if (is_prefill) {
-        NVR_HIP_CHECK(up(0, n_tiles ? off_tiles + (size_t)n_tiles * sizeof(k::FlashTile) + (flash_nlanes ? (size_t)(n_tiles + flash_nlanes + 1) * 4 : 0)
-                                    : prefill_bytes));   // ids | pos | slots | ctx | kv base | cu | tiles | tile lists
+        NVR_HIP_CHECK(up(0, n_tiles ? off_tiles + (size_t)n_tiles * sizeof(k::FlashTile) : prefill_bytes));   // ids | pos | slots | ctx | kv base | cu | tiles
         if (prefill_paged) NVR_HIP_CHECK(up(off_dec + dof_bt, nseq * max_blocks_per_seq * 4));
     } else NVR_HIP_CHECK(up(off_dec, dof_bt + nseq * max_blocks_per_seq * 4));
 

@@ -50,8 +50,6 @@ struct nvr_model_runner {
             *d_kvbase = nullptr, *d_bt = nullptr;
     size_t off_ids = 0, off_pos = 0, off_slots = 0, off_cu = 0, off_ctx = 0, off_kvbase = 0, off_bt = 0, off_tiles = 0;
     int64_t n_tiles = 0;                   // flash prefill tiles of the current step
-    int flash_nlanes = 0;                  // ... and the lanes (persistent workgroups per kv head) they were dealt to; 0: one workgroup per tile
-    int num_cus = 256;                     // compute units of the device (grid of the persistent kernels)
     // decode steps use one compact region (ids|pos|slots|ctx|block tables) uploaded with a single memcpy (K19)
     size_t off_dec = 0, dec_bytes = 0, dof_ids = 0, dof_pos = 0, dof_slots = 0, dof_ctx = 0, dof_bt = 0;
     size_t dof_skv0 = 0, dof_srows = 0, dof_scount = 0;  // shared-prefix group of the step: kv0 per row, member rows, member count

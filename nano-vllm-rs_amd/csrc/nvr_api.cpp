@@ -611,30 +611,18 @@ static int run_prefill_attn(const nvr_half *q, int64_t ldq, const nvr_half *kk, 
     if (paged) NVR_HIP_CHECK(hipMemcpy(ctxl.data(), m->context_lens, ctxl.size() * 4, hipMemcpyDeviceToHost));
     int rc;
     if (k::flash_prefill_ok((int)D, (int)H, (int)KVH)) {
-        const int qb = k::flash_tile_positions((int)H, (int)KVH, (int)D);
+        const int qb = k::flash_tile_positions((int)H, (int)KVH);
         std::vector<k::FlashTile> tiles;
-        size_t group0 = 0;
         for (int b = 0; b < m->batch; ++b) {
             const int nq = cu[b + 1] - cu[b], p0 = paged ? ctxl[b] - nq : 0;      // query i sits at position p0 + i
             if (p0 < 0) return nvr::fail(NVR_ERR_INVALID_ARG, "sequence %d: %d queries but context %d", b, nq, ctxl[b]);
             for (int q0 = 0; q0 < nq; q0 += qb)
                 tiles.push_back(k::FlashTile{cu[b] + q0, std::min(qb, nq - q0), p0 + q0, paged ? b : cu[b]});
-            if ((b & 3) == 3 || b + 1 == m->batch) {      // as the runner orders them: sequences in groups of 4, longest key ranges of a group first
-                std::stable_sort(tiles.begin() + (long)group0, tiles.end(), [](const k::FlashTile &x, const k::FlashTile &y) { return x.pos0 + x.nq > y.pos0 + y.nq; });
-                group0 = tiles.size();
-            }
         }
         k::FlashTile *d = nullptr;
-        std::vector<int32_t> lanes(k::flash_lanes_ints((int)tiles.size()));
-        int dev = 0, ncu = 256;
-        NVR_HIP_CHECK(hipGetDevice(&dev));
-        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
-        const int nlanes = k::flash_lanes(tiles.data(), (int)tiles.size(), (int)KVH, (int)D, ncu, lanes.data());   // (same list builder for both 16-bit builds)
-        NVR_HIP_CHECK(hipMalloc((void **)&d, tiles.size() * sizeof(k::FlashTile) + lanes.size() * 4 + 16));
+        NVR_HIP_CHECK(hipMalloc((void **)&d, tiles.size() * sizeof(k::FlashTile) + 16));
         NVR_HIP_CHECK(hipMemcpy(d, tiles.data(), tiles.size() * sizeof(k::FlashTile), hipMemcpyHostToDevice));
-        if (nlanes) NVR_HIP_CHECK(hipMemcpy(d + tiles.size(), lanes.data(), (tiles.size() + nlanes + 1) * 4, hipMemcpyHostToDevice));
         k::FlashArgs f{};
-        f.lanes = nlanes ? (const int32_t *)(d + tiles.size()) : nullptr; f.nlanes = nlanes;
         f.q = q; f.ldq = ldq; f.k = kk; f.v = v; f.ldkv = ldkv; f.block_tables = m->block_tables; f.max_blocks = m->max_blocks;
         f.block_size = (int32_t)bs; f.tiles = d; f.ntiles = (int32_t)tiles.size(); f.H = (int32_t)H; f.KVH = (int32_t)KVH; f.D = (int32_t)D;
         f.scale = scale; f.out = out;
