@@ -297,6 +297,12 @@ NVR_API int64_t nvr_runner_last_shared_prefix_len(const nvr_model_runner_t *r);
  * K / V once, into the caches), 2 = the caches through the block tables (cached prefixes, prompt chunks); -1 = the last step was a decode */
 NVR_API int nvr_runner_last_prefill_kv_source(const nvr_model_runner_t *r);
 NVR_API int64_t nvr_runner_last_shared_prefix_rows(const nvr_model_runner_t *r);   /* sequences of that step inside the sharing group */
+/* Tensor-parallel PREFILL steps (row-parallel o_proj / down_proj, linear.rs:228-239 with its all-reduce :236-238): on = 1 (default) cuts a step of
+ * >= 1024 rows into up to 4 token chunks and runs the all-reduce of chunk i on a second HIP stream under the GEMM of chunk i + 1 (events between
+ * the streams; residual add + RMSNorm of a chunk behind its reduce); on = 0 keeps GEMM -> all-reduce -> add + norm in a row on one stream.  Same
+ * bits either way (chunks are multiples of the GEMM's 256-row tile).  nvr_runner_last_overlap_chunks: chunks of the last such exchange (0: none). */
+NVR_API int nvr_runner_set_tp_prefill_overlap(nvr_model_runner_t *r, int32_t on);
+NVR_API int64_t nvr_runner_last_overlap_chunks(const nvr_model_runner_t *r);
 
 /* -------------------------------------------------------------------- Engine ---- */
 /* LLMEngine::step loop, src/engine/llm_engine.rs:155-197 (driver of the hot path only) */

@@ -184,6 +184,7 @@ _SIGS = {
     "nvr_runner_p2p_reset": (C.c_int, [_P]), "nvr_runner_comm_drop_rccl": (C.c_int, [_P]),
     "nvr_engine_abort_last_batch": (C.c_int, [_P]), "nvr_engine_ahead_declined": (C.c_uint64, [_P]), "nvr_engine_ahead_launched": (C.c_uint64, [_P]),
     "nvr_runner_last_prefill_kv_source": (C.c_int, [_P]),
+    "nvr_runner_set_tp_prefill_overlap": (C.c_int, [_P, C.c_int32]), "nvr_runner_last_overlap_chunks": (C.c_int64, [_P]),
     "nvr_runner_last_shared_prefix_len": (C.c_int64, [_P]), "nvr_runner_last_shared_prefix_rows": (C.c_int64, [_P]),
     "nvr_engine_last_step": (None, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(C.c_size_t)]),
     "nvr_engine_take_finished": (C.c_size_t, [_P, C.POINTER(_P), C.c_size_t]),
@@ -692,6 +693,13 @@ class ModelRunner:
     def last_prefill_kv_source(self) -> int:
         """0: the last prefill's attention read K/V from the qkv buffer, 1: from contiguous cache rows, 2: through the block tables; -1: decode."""
         return int(lib().nvr_runner_last_prefill_kv_source(self.h))
+
+    def set_tp_prefill_overlap(self, on: bool) -> None:
+        """Tensor-parallel prefill: all-reduce of token chunk i on a second stream under the GEMM of chunk i + 1 (default on)."""
+        check(lib().nvr_runner_set_tp_prefill_overlap(self.h, 1 if on else 0))
+
+    def last_overlap_chunks(self) -> int:
+        return int(lib().nvr_runner_last_overlap_chunks(self.h))
 
     def last_shared_prefix_len(self) -> int:
         """Tokens of the last decode step that went through the shared-prefix attention pass (0: plain paged attention)."""

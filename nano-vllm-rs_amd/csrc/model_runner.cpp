@@ -52,6 +52,8 @@ nvr_model_runner::~nvr_model_runner() {
     if (h_tok) hipHostFree(h_tok);
     for (int i = 0; i < 2; ++i) { if (ahead_tok[i]) hipHostFree(ahead_tok[i]); if (ahead_host[i]) hipHostFree(ahead_host[i]); }
     if (samp_host) hipHostFree(samp_host);
+    for (int i = 0; i < kMaxChunks; ++i) { if (ev_gemm[i]) hipEventDestroy(ev_gemm[i]); if (ev_reduced[i]) hipEventDestroy(ev_reduced[i]); }
+    if (comm_stream) hipStreamDestroy(comm_stream);
     if (stream) hipStreamDestroy(stream);
 }
 
@@ -77,6 +79,13 @@ int nvr_model_runner::init() {                                       // ModelRun
     device = cfg.device_ordinal;
     NVR_HIP_CHECK(hipSetDevice(device));
     NVR_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    if (tp > 1) {
+        NVR_HIP_CHECK(hipStreamCreateWithFlags(&comm_stream, hipStreamNonBlocking));
+        for (int i = 0; i < kMaxChunks; ++i) {
+            NVR_HIP_CHECK(hipEventCreateWithFlags(&ev_gemm[i], hipEventDisableTiming));
+            NVR_HIP_CHECK(hipEventCreateWithFlags(&ev_reduced[i], hipEventDisableTiming));
+        }
+    }
 
     RC(gen_weights());
 
@@ -391,6 +400,34 @@ int nvr_model_runner::row_parallel_norm(const uint16_t *x, int64_t K, const uint
         // rounding points), and the norm reads one tensor instead of h and the projection (r02: 41.6 -> ~21 us per norm at 32 x 1024)
         RC(KD(gemm256_resid(x, K, W, T, K, Hd, h, stream)));
         return KD(rmsnorm(h, wn, mc.rms_norm_eps, T, Hd, n, stream));
+    }
+    if (comm.active() && comm_stream && tp_overlap && T >= 1024 && KD(gemm256_preferred(T, K, Hd, K))) {
+        // Prefill on tensor-parallel ranks (row g): the rows are cut into chunks (multiples of the 256-row GEMM tile, so every tile and every
+        // row is computed exactly as in one piece: bit-identical), and the all-reduce of chunk i runs on the communication stream while the
+        // compute stream works on the GEMM of chunk i+1; the residual add + RMSNorm of a chunk follows its reduce.  Host order
+        // G0 G1 R0 N0 G2 R1 N1 ...: a backend that blocks the host inside the reduce (in-process ranks) still finds the next GEMM queued.
+        // configs[3] at tp 8: 72 all-reduces of 268 MB per 32 768-token step are the larger half of the step: serial 160 ms,
+        // overlapped ~max(comm, compute) + one chunk.
+        int64_t C = std::min<int64_t>(4, T / 512);
+        const int64_t rows = ((T + C - 1) / C + 255) / 256 * 256;
+        C = (T + rows - 1) / rows;
+        if (C > 1 && T - (C - 1) * rows < 256) --C;                   // (the last chunk takes a short remainder along: every chunk is a launch of the 256^2 kernel)
+        tp_overlap_chunks = C;
+        auto reduce_and_norm = [&](int64_t i) -> int {
+            const int64_t r0 = i * rows, nr = i + 1 == C ? T - r0 : rows;
+            NVR_HIP_CHECK(hipStreamWaitEvent(comm_stream, ev_gemm[i], 0));
+            RC(comm.all_reduce_sum_f16(proj + r0 * Hd, (size_t)(nr * Hd), comm_stream));
+            NVR_HIP_CHECK(hipEventRecord(ev_reduced[i], comm_stream));
+            NVR_HIP_CHECK(hipStreamWaitEvent(stream, ev_reduced[i], 0));
+            return KD(add_rmsnorm(h + r0 * Hd, proj + r0 * Hd, wn, mc.rms_norm_eps, nr, Hd, n + r0 * Hd, stream));
+        };
+        for (int64_t i = 0; i < C; ++i) {
+            const int64_t r0 = i * rows, nr = i + 1 == C ? T - r0 : rows;
+            RC(KD(gemm256(x + r0 * K, K, W, nr, K, Hd, proj + r0 * Hd, stream)));   // (the kernel linear() takes for the whole step: same tiles, same bits)
+            NVR_HIP_CHECK(hipEventRecord(ev_gemm[i], stream));
+            if (i >= 1) RC(reduce_and_norm(i - 1));
+        }
+        return reduce_and_norm(C - 1);
     }
     RC(KD(linear(x, K, W, T, K, Hd, proj, false, stream, Wt)));
     // linear.rs:236-238 (all-reduce) + qwen3.rs:382-389 (residual, norm): one launch over the peer-mapped arenas when the

@@ -26,6 +26,12 @@ struct nvr_model_runner {
     float scale = 1.f;
     int device = 0;
     hipStream_t stream = nullptr;
+    // tensor-parallel prefill: the row-parallel exchange of token chunk i runs on comm_stream under the GEMM of chunk i+1 (row_parallel_norm)
+    hipStream_t comm_stream = nullptr;
+    static constexpr int kMaxChunks = 8;
+    hipEvent_t ev_gemm[kMaxChunks] = {}, ev_reduced[kMaxChunks] = {};
+    int64_t tp_overlap_chunks = 0;         // chunks of the last overlapped exchange (0: none ran; diagnostics / tests)
+    int tp_overlap = 1;                    // nvr_config.tp_prefill_overlap (default 1); 0: GEMM -> all-reduce -> add + norm in a row on one stream
 
     struct Layer { uint16_t *qkv, *o, *gate_up, *down, *ln1, *ln2;
                    uint16_t *qkv_t, *o_t, *gate_up_t, *down_t;      // *_t: tiled copies for the decode kernels (retile_weight), or null

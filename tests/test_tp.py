@@ -431,6 +431,70 @@ def test_one_shot_p2p_collectives_equal_host_rendezvous(tp):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("tp,p2p,heads,inter", [(2, True, 32, 2048), (4, True, 64, 4096), (2, False, 32, 2048)])
+def test_tensor_parallel_prefill_exchange_overlaps_on_a_second_stream(tp, p2p, heads, inter):
+    """Row g, prefill side (linear.rs:228-239 with its all-reduce :236-238): on tensor-parallel ranks a prefill step of >= 1024 rows is cut into
+    token chunks (multiples of the GEMM's 256-row tile) and the all-reduce of chunk i runs on a second HIP stream under the GEMM of chunk i + 1
+    (events between the streams; residual add + RMSNorm of a chunk behind its reduce) — csrc/model_runner.cpp row_parallel_norm.  Same bits as
+    the serial form (GEMM -> all-reduce -> add + norm on one stream, nvr_runner_set_tp_prefill_overlap(0)): every rank's shard logits of the
+    prefill step and of the decode steps behind it, and the token streams; with the one-shot peer-to-peer kernels (the arenas chunk by chunk:
+    messages beyond a slot) and with the host-rendezvous backend (which blocks the host inside the reduce: the next GEMM is already queued)."""
+    import threading
+    sys.path.insert(0, ROOT)
+    import nvr_import
+    import oracle
+    from oracle import model_oracle as mo
+    nvr = nvr_import.load()
+    # (shapes for which a rank's o_proj / down_proj take the 256x256 GEMM — K = 1024 per rank, hidden 1024, > 8192 rows — like the BASELINE models' prefills)
+    m = mo.small(seed=26, num_attention_heads=heads, num_key_value_heads=8, head_dim=64, hidden_size=1024, intermediate_size=inter)
+    mc = nvr.ModelConfig(vocab_size=m.vocab_size, hidden_size=m.hidden_size, intermediate_size=m.intermediate_size,
+                         num_hidden_layers=m.num_hidden_layers, num_attention_heads=m.num_attention_heads,
+                         num_key_value_heads=m.num_key_value_heads, head_dim=m.head_dim, max_position_embeddings=2048,
+                         rms_norm_eps=m.rms_norm_eps, rope_theta=m.rope_theta, tie_word_embeddings=m.tie_word_embeddings,
+                         init_std=m.init_std, seed=m.seed)
+    ecfg = dict(max_num_seqs=8, max_num_batched_tokens=8704, max_model_len=2048, kvcache_block_size=64, num_kvcache_blocks=160)
+    lens = [1700, 1513, 1300, 1900, 1257, 833]                                             # one prefill step of 8503 rows: 4 chunks of 2304 (the last 1591)
+    prompts = [oracle.fill_tokens(n, 5, i, m.vocab_size).tolist() for i, n in enumerate(lens)]
+
+    def run(overlap):
+        group = nvr.LocalGroup(tp, p2p=p2p)
+        engines = []
+        for r in range(tp):
+            e = nvr.LLMEngine(nvr.Config(skip_block_size_check=1, tensor_parallel_size=tp, tensor_parallel_rank=r, enforce_eager=1, **ecfg), mc)
+            group.attach(e.model_runner)
+            e.model_runner.set_tp_prefill_overlap(overlap)
+            nvr.lib().nvr_seq_reset_id_counter()
+            for pr in prompts:
+                e.add_request(pr, nvr.SamplingParams(temperature=0.0, max_tokens=4, ignore_eos=True))
+            engines.append(e)
+        traces, errors, chunks = [[] for _ in range(tp)], [], [0] * tp
+
+        def drive(r):
+            try:
+                e = engines[r]
+                while not e.is_finished():
+                    rec = e.step(); rec["logits"] = e.model_runner.logits(rec["num_seqs"]).copy(); traces[r].append(rec)
+                    if rec["is_prefill"]:
+                        chunks[r] = e.model_runner.last_overlap_chunks()
+            except BaseException as ex:                                                 # noqa: BLE001
+                errors.append((r, ex))
+        threads = [threading.Thread(target=drive, args=(r,)) for r in range(tp)]
+        for t in threads: t.start()
+        for t in threads: t.join(300)
+        assert not errors, errors
+        return traces, chunks
+    (a, ca), (b, cb) = run(True), run(False)
+    assert ca == [4] * tp and cb == [0] * tp, (ca, cb)
+    assert len(a[0]) == len(b[0]) == 4 and a[0][0]["is_prefill"] and a[0][0]["num_tokens"] == sum(lens)
+    for r in range(tp):
+        for sa, sb in zip(a[r], b[r]):
+            assert sa["tokens"] == sb["tokens"] and sa["seq_ids"] == sb["seq_ids"]
+            assert np.array_equal(sa["logits"], sb["logits"]), "overlapped and serial prefill exchange differ in bits"
+    for step in zip(*a):                                                                   # and the ranks agree with each other
+        assert all(s["tokens"] == step[0]["tokens"] for s in step)
+
+
+@pytest.mark.gpu
 def test_peer_that_never_arrives_fails_the_step_and_the_group_recovers():
     """Negative path of the one-shot collectives (kernels/comm_p2p.hip): rank 1 never enters a decode step that rank 0 runs.  Rank 0's
     reduce workgroups wait a bounded time (NVR_P2P_TIMEOUT_MS, read when the runner is created), set the error word and finish —
@@ -643,83 +707,115 @@ def test_tensor_parallel_launch_ahead_is_transparent(tp, hidden):
     assert all(n >= 10 for n in launched) and len(set(launched)) == 1 and not any(none), (launched, none)
 
 
-_IPC_WORKER = r'''
+_IPC_WORKER = r"""
 import os, sys, json
 sys.path.insert(0, os.environ["NVR_ROOT"])
+import numpy as np
 import nvr_import
-nvr = nvr_import.load()                      # (libnvr.so and the HIP runtime before torch)
-import torch, torch.distributed as dist
+nvr = nvr_import.load()
 import oracle
 from oracle import model_oracle as mo
-dist.init_process_group("gloo")
-rank, world = dist.get_rank(), dist.get_world_size()
-m = mo.small(seed=31, num_attention_heads=8, num_key_value_heads=4, head_dim=64, hidden_size=256, intermediate_size=512)
-mc = nvr.ModelConfig(vocab_size=m.vocab_size, hidden_size=m.hidden_size, intermediate_size=m.intermediate_size, num_hidden_layers=m.num_hidden_layers,
-                     num_attention_heads=m.num_attention_heads, num_key_value_heads=m.num_key_value_heads, head_dim=m.head_dim,
-                     max_position_embeddings=m.max_position_embeddings, rms_norm_eps=m.rms_norm_eps, rope_theta=m.rope_theta,
-                     tie_word_embeddings=m.tie_word_embeddings, init_std=m.init_std, seed=m.seed)
+g = nvr_import.load_ctrl().SocketGroup(timeout=120.0)      # control plane: the TCP rendezvous on MASTER_ADDR / MASTER_PORT (one ROCm stack per process)
+rank, world = g.rank, g.world
 dtype = os.environ.get("NVR_TEST_DTYPE", "float16")
-eng = nvr.LLMEngine(nvr.Config(skip_block_size_check=1, max_num_seqs=4, max_num_batched_tokens=256, max_model_len=160, kvcache_block_size=64, num_kvcache_blocks=16,
-                               tensor_parallel_size=world, tensor_parallel_rank=rank, device_ordinal=0, async_decode=1, dtype=dtype), mc)
-gathered = [None] * world
-dist.all_gather_object(gathered, (eng.model_runner.p2p_export(), 0))        # hipIpc handle of my arena; every rank sits on device 0
-eng.model_runner.p2p_attach([g[0] for g in gathered], [g[1] for g in gathered])
-dist.barrier()
-eng.model_runner.comm_selftest()
-dist.barrier()
-for i, (n, mt) in enumerate([(9, 30), (40, 22), (17, 30)]):
-    eng.add_request(oracle.fill_tokens(n, 5, i, m.vocab_size).tolist(), nvr.SamplingParams(temperature=0.0, max_tokens=mt, ignore_eos=True))
-trace = []
-while not eng.is_finished():
-    rec = eng.step()
-    trace.append([bool(rec["is_prefill"]), len(rec["seq_ids"]), list(rec["tokens"])])
-out = [None] * world
-dist.all_gather_object(out, (trace, eng.ahead_launched()))
+scenario = os.environ.get("NVR_TEST_SCENARIO", "decode")
+
+def attach(eng):
+    gathered = g.all_gather((eng.model_runner.p2p_export(), 0))            # hipIpc handle of my arena; every rank sits on device 0
+    eng.model_runner.p2p_attach([x[0] for x in gathered], [x[1] for x in gathered])
+    g.barrier()
+    eng.model_runner.comm_selftest()
+    g.barrier()
+
+def model(**kw):
+    m = mo.small(**kw)
+    return m, nvr.ModelConfig(vocab_size=m.vocab_size, hidden_size=m.hidden_size, intermediate_size=m.intermediate_size, num_hidden_layers=m.num_hidden_layers,
+                              num_attention_heads=m.num_attention_heads, num_key_value_heads=m.num_key_value_heads, head_dim=m.head_dim,
+                              max_position_embeddings=2048, rms_norm_eps=m.rms_norm_eps, rope_theta=m.rope_theta,
+                              tie_word_embeddings=m.tie_word_embeddings, init_std=m.init_std, seed=m.seed)
+
+if scenario == "decode":
+    m, mc = model(seed=31, num_attention_heads=16, num_key_value_heads=8, head_dim=64, hidden_size=256, intermediate_size=512)
+    eng = nvr.LLMEngine(nvr.Config(skip_block_size_check=1, max_num_seqs=4, max_num_batched_tokens=256, max_model_len=160, kvcache_block_size=64, num_kvcache_blocks=16,
+                                   tensor_parallel_size=world, tensor_parallel_rank=rank, device_ordinal=0, async_decode=1, dtype=dtype), mc)
+    attach(eng)
+    for i, (n, mt) in enumerate([(9, 30), (40, 22), (17, 30)]):
+        eng.add_request(oracle.fill_tokens(n, 5, i, m.vocab_size).tolist(), nvr.SamplingParams(temperature=0.0, max_tokens=mt, ignore_eos=True))
+    trace = []
+    while not eng.is_finished():
+        rec = eng.step()
+        trace.append([bool(rec["is_prefill"]), len(rec["seq_ids"]), list(rec["tokens"])])
+    out = g.all_gather((trace, eng.ahead_launched()))
+else:
+    # prefill exchange on a second stream (row g): overlapped == serial, bit for bit, across process boundaries
+    m, mc = model(seed=26, num_attention_heads=32, num_key_value_heads=8, head_dim=64, hidden_size=1024, intermediate_size=2048)
+    res = []
+    for overlap in (1, 0):
+        nvr.lib().nvr_seq_reset_id_counter()
+        eng = nvr.LLMEngine(nvr.Config(skip_block_size_check=1, max_num_seqs=8, max_num_batched_tokens=8704, max_model_len=2048, kvcache_block_size=64,
+                                       num_kvcache_blocks=160, tensor_parallel_size=world, tensor_parallel_rank=rank, device_ordinal=0, enforce_eager=1, dtype=dtype), mc)
+        attach(eng)
+        eng.model_runner.set_tp_prefill_overlap(bool(overlap))
+        for i, n in enumerate([1700, 1513, 1300, 1900, 1257, 833]):
+            eng.add_request(oracle.fill_tokens(n, 5, i, m.vocab_size).tolist(), nvr.SamplingParams(temperature=0.0, max_tokens=3, ignore_eos=True))
+        steps, chunks = [], 0
+        while not eng.is_finished():
+            rec = eng.step()
+            if rec["is_prefill"]: chunks = eng.model_runner.last_overlap_chunks()
+            steps.append((list(rec["tokens"]), eng.model_runner.logits(rec["num_seqs"]).copy()))
+        res.append((steps, chunks))
+        g.barrier()
+        del eng
+    same = all(ta == tb and np.array_equal(la, lb) for (ta, la), (tb, lb) in zip(res[0][0], res[1][0]))
+    out = g.all_gather(([t for t, _ in res[0][0]], [res[0][1], res[1][1], bool(same), len(res[0][0])]))
 if rank == 0:
     json.dump(out, open(os.environ["NVR_OUT"], "w"))
-dist.barrier()
-del eng
-dist.destroy_process_group()
-'''
+g.barrier()
+g.close()
+"""
+
+
+def _run_ipc_workers(tmp_path, world, dtype, scenario):
+    import json
+    script = tmp_path / "ipc_worker.py"
+    script.write_text(_IPC_WORKER)
+    outp = tmp_path / "ipc.json"
+    env = dict(os.environ, NVR_ROOT=ROOT, NVR_OUT=str(outp), NVR_TEST_DTYPE=dtype, NVR_TEST_SCENARIO=scenario, OMP_NUM_THREADS="2")
+    port = 29700 + os.getpid() % 2000
+    subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+                    "--master-port", str(port), str(script)], check=True, env=env, timeout=420, cwd=ROOT)
+    return json.load(open(outp))
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("dtype", ["float16", "bfloat16"])
-def test_two_processes_sharing_the_gpu_exchange_over_hipipc(tmp_path, dtype):
+@pytest.mark.parametrize("dtype,world", [("float16", 2), ("bfloat16", 2), ("float16", 4), ("float16", 8)])
+def test_processes_sharing_the_gpu_exchange_over_hipipc(tmp_path, dtype, world):
     """The DEPLOYMENT form of tensor parallel — one PROCESS per rank, arenas exported with hipIpcGetMemHandle and mapped with
-    hipIpcOpenMemHandle (nvr_runner_p2p_export / _attach), control plane over gloo — on the one GPU a test box has: both ranks on device 0.
-    The one-shot collectives, the device-side arg-max merge and launch-ahead then run across process boundaries; both ranks must report
-    the same per-step batches and tokens, steps must have been launched ahead, and the token streams must be bit-identical to the
-    in-process group's (same kernels, same rank-ordered sums: only the way the arenas were mapped differs)."""
-    import json
+    hipIpcOpenMemHandle (nvr_runner_p2p_export / _attach), control plane over the TCP rendezvous of nano-vllm-rs_amd/ctrl.py — on the one GPU a
+    test box has: 2, 4 and 8 ranks on device 0.  The one-shot collectives, the device-side arg-max merge and launch-ahead then run across
+    process boundaries; all ranks must report the same per-step batches and tokens, steps must have been launched ahead, and the token
+    streams must be bit-identical to the in-process group's (same kernels, same rank-ordered sums: only the way the arenas were mapped differs)."""
     import threading
     sys.path.insert(0, ROOT)
     import nvr_import
     import oracle
     from oracle import model_oracle as mo
     nvr = nvr_import.load()
-    script = tmp_path / "ipc_worker.py"
-    script.write_text(_IPC_WORKER)
-    outp = tmp_path / "ipc.json"
-    env = dict(os.environ, NVR_ROOT=ROOT, NVR_OUT=str(outp), NVR_TEST_DTYPE=dtype, OMP_NUM_THREADS="2")
-    port = 29700 + os.getpid() % 2000
-    subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-                    "--master-port", str(port), str(script)], check=True, env=env, timeout=300, cwd=ROOT)
-    got = json.load(open(outp))
-    (t0, a0), (t1, a1) = got
-    assert t0 == t1 and len(t0) > 25, "the two processes disagree"
-    assert a0 == a1 and a0 >= 10, (a0, a1)
-    # the same two ranks as runners of THIS process
-    m = mo.small(seed=31, num_attention_heads=8, num_key_value_heads=4, head_dim=64, hidden_size=256, intermediate_size=512)
+    got = _run_ipc_workers(tmp_path, world, dtype, "decode")
+    t0, a0 = got[0]
+    assert len(got) == world and all(t == t0 and a == a0 for t, a in got) and len(t0) > 25, "the processes disagree"
+    assert a0 >= 10, a0
+    # the same ranks as runners of THIS process
+    m = mo.small(seed=31, num_attention_heads=16, num_key_value_heads=8, head_dim=64, hidden_size=256, intermediate_size=512)
     mc = nvr.ModelConfig(vocab_size=m.vocab_size, hidden_size=m.hidden_size, intermediate_size=m.intermediate_size, num_hidden_layers=m.num_hidden_layers,
                          num_attention_heads=m.num_attention_heads, num_key_value_heads=m.num_key_value_heads, head_dim=m.head_dim,
-                         max_position_embeddings=m.max_position_embeddings, rms_norm_eps=m.rms_norm_eps, rope_theta=m.rope_theta,
+                         max_position_embeddings=2048, rms_norm_eps=m.rms_norm_eps, rope_theta=m.rope_theta,
                          tie_word_embeddings=m.tie_word_embeddings, init_std=m.init_std, seed=m.seed)
-    group = nvr.LocalGroup(2)
-    engines, traces, errors = [], [[], []], []
-    for r in range(2):
+    group = nvr.LocalGroup(world)
+    engines, traces, errors = [], [[] for _ in range(world)], []
+    for r in range(world):
         e = nvr.LLMEngine(nvr.Config(skip_block_size_check=1, max_num_seqs=4, max_num_batched_tokens=256, max_model_len=160, kvcache_block_size=64,
-                                     num_kvcache_blocks=16, tensor_parallel_size=2, tensor_parallel_rank=r, async_decode=1, dtype=dtype), mc)
+                                     num_kvcache_blocks=16, tensor_parallel_size=world, tensor_parallel_rank=r, async_decode=1, dtype=dtype), mc)
         group.attach(e.model_runner)
         nvr.lib().nvr_seq_reset_id_counter()
         for i, (n, mt) in enumerate([(9, 30), (40, 22), (17, 30)]):
@@ -733,8 +829,18 @@ def test_two_processes_sharing_the_gpu_exchange_over_hipipc(tmp_path, dtype):
                 traces[r].append([bool(rec["is_prefill"]), len(rec["seq_ids"]), list(rec["tokens"])])
         except BaseException as ex:                                                     # noqa: BLE001
             errors.append((r, ex))
-    ths = [threading.Thread(target=drive, args=(r,)) for r in range(2)]
+    ths = [threading.Thread(target=drive, args=(r,)) for r in range(world)]
     for t in ths: t.start()
     for t in ths: t.join(120)
     assert not errors, errors
-    assert traces[0] == traces[1] == t0, "two processes over hipIpc and two in-process ranks must sample the same tokens"
+    assert all(tr == t0 for tr in traces), "processes over hipIpc and in-process ranks must sample the same tokens"
+
+
+@pytest.mark.gpu
+def test_two_processes_overlap_the_prefill_exchange_bit_identically(tmp_path):
+    """Row g across process boundaries: two rank processes (hipIpc arenas on one GPU) run a 8503-token prefill with the all-reduce of each token
+    chunk on the second stream (4 chunks) and again serially: same tokens, same shard logits in every step, on both ranks."""
+    got = _run_ipc_workers(tmp_path, 2, "float16", "overlap")
+    assert len(got) == 2 and got[0][0] == got[1][0]
+    for toks, (chunks_on, chunks_off, same, nsteps) in got:
+        assert chunks_on == 4 and chunks_off == 0 and same and nsteps == 3, (chunks_on, chunks_off, same, nsteps)
