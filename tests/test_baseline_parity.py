@@ -232,27 +232,32 @@ def test_configs3_qwen3_8b_bs32_seq2048_tp8_in_process_equals_tp1():
     assert [r["is_prefill"] for r in ref] == [True, True, False, False, False] and all(r["num_seqs"] == (16 if r["is_prefill"] else 32) for r in ref)
 
     tp = 8
-    t0 = time.time()
-    group = nvr.LocalGroup(tp, p2p=False)          # eight kernels of one process spinning on each other would share the GPU's queues
-    engines = []
-    for r in range(tp):
-        e = nvr.LLMEngine(nvr.Config(tensor_parallel_size=tp, tensor_parallel_rank=r, **ecfg), mc)
-        group.attach(e.model_runner)
-        nvr.lib().nvr_seq_reset_id_counter()
-        for pr in prompts:
-            e.add_request(pr, nvr.SamplingParams(**sp))
-        engines.append(e)
-    traces, errors = [[] for _ in range(tp)], []
 
-    def go(r):
-        try:
-            drive(engines[r], traces[r])
-        except BaseException as ex:                                                     # noqa: BLE001
-            errors.append((r, ex))
-    threads = [threading.Thread(target=go, args=(r,)) for r in range(tp)]
-    for t in threads: t.start()
-    for t in threads: t.join(900)
-    assert not errors, errors
+    def run_ranks(p2p):
+        group = nvr.LocalGroup(tp, p2p=p2p)
+        engines = []
+        for r in range(tp):
+            e = nvr.LLMEngine(nvr.Config(tensor_parallel_size=tp, tensor_parallel_rank=r, **ecfg), mc)
+            group.attach(e.model_runner)
+            nvr.lib().nvr_seq_reset_id_counter()
+            for pr in prompts:
+                e.add_request(pr, nvr.SamplingParams(**sp))
+            engines.append(e)
+        traces, errors = [[] for _ in range(tp)], []
+
+        def go(r):
+            try:
+                drive(engines[r], traces[r])
+            except BaseException as ex:                                                 # noqa: BLE001
+                errors.append((r, ex))
+        threads = [threading.Thread(target=go, args=(r,)) for r in range(tp)]
+        for t in threads: t.start()
+        for t in threads: t.join(900)
+        assert not errors, errors
+        assert all(e.model_runner.p2p_active() == p2p for e in engines)
+        return traces
+    t0 = time.time()
+    traces = run_ranks(False)                        # host-rendezvous collectives (RCCL-shaped data path: whole-buffer sums)
     t_tp = time.time() - t0
     assert all(len(tr) == len(ref) for tr in traces)
     st = dict(steps=len(ref), rows=0, near_ties=0, id_mismatch_outside_ties=0, max_abs_logit_err=0.0, single_s=round(t_single, 1), tp8_s=round(t_tp, 1))
@@ -280,4 +285,16 @@ def test_configs3_qwen3_8b_bs32_seq2048_tp8_in_process_equals_tp1():
                 else:
                     st["id_mismatch_outside_ties"] += 1
     assert st["id_mismatch_outside_ties"] == 0 and st["near_ties"] <= 2, st
+    # ... and the same eight ranks on the one-shot peer-to-peer kernels (fused all-reduce + residual + RMSNorm in the decode steps, the arenas
+    # slot by slot in the 32 768-row prefill steps incl. the chunk-overlapped exchange, device-side arg-max merge): rank-ordered sums in both
+    # backends, so every rank's shard logits and tokens are the host-rendezvous run's, bit for bit, at FULL size
+    t0 = time.time()
+    p2p_traces = run_ranks(True)
+    st["tp8_p2p_s"] = round(time.time() - t0, 1)
+    for r in range(tp):
+        assert len(p2p_traces[r]) == len(traces[r])
+        for a, b in zip(p2p_traces[r], traces[r]):
+            assert a["tokens"] == b["tokens"] and a["seq_ids"] == b["seq_ids"]
+            assert np.array_equal(a["logits"], b["logits"]), "peer-to-peer and host-rendezvous collectives differ in bits at full size"
+    st["p2p_equals_host_rendezvous_bitwise"] = True
     _report("configs3_qwen3_8b_bs32_seq2048_tp8_in_process_vs_tp1", st)
