@@ -107,7 +107,7 @@ def time_attention_kernel(nvr, eng, mc, reps: int) -> dict:
     return dict(us_per_launch=us, launches=launches, alg_bytes=alg_bytes, ctx_sum=int(ctx.sum()))
 
 
-def time_decode_chain(nvr, mc, reps: int = 20) -> dict:
+def time_decode_chain(nvr, mc, reps: int = 20, mlp_engine: bool = False) -> dict:
     """The decode step's GEMM / norm chain without attention (per layer: qkv+RoPE+store, o_proj split-k, add+RMSNorm,
     gate_up+SiLU, down split-k, add+RMSNorm — the six launches of the default chain) as one captured hipGraph of L layers with
     their own weights (HBM-cold every replay), replayed back to back on its own stream: microseconds per layer."""
@@ -143,7 +143,7 @@ def time_decode_chain(nvr, mc, reps: int = 20) -> dict:
     rng = np.random.default_rng(0)
     h = arr(rng.standard_normal((T, Hd)).astype(np.float16)); n = buf(T * Hd * 2); g = arr(np.ones(Hd, np.float16))
     qkv, attn, act = buf(T * QKV * 2), arr(rng.standard_normal((T, H * D)).astype(np.float16) * 0.1), buf(T * I * 2)
-    slabs = buf(4 * T * Hd * 4)
+    slabs = buf(4 * T * Hd * 4); sync = buf(256)
     pos = arr(np.arange(T, dtype=np.int64) + 1000); slots = arr(np.arange(T, dtype=np.int32))
     cos = arr(np.ones((2048, D // 2), np.float32)); sin = arr(np.zeros((2048, D // 2), np.float32))
     kc, vc = buf(64 * KVH * D * 2), buf(64 * KVH * D * 2)
@@ -156,6 +156,10 @@ def time_decode_chain(nvr, mc, reps: int = 20) -> dict:
                                                     qkv.ptr, kc.ptr, vc.ptr, st))
         nvr.check(l.nvr_linear_splitk_tiled(attn.ptr, H * D, Wo[i].ptr, To[i], T, H * D, Hd, So, slabs.ptr, st))
         nvr.check(l.nvr_add_rmsnorm_slabs(h.ptr, slabs.ptr, So, g.ptr, 1e-6, T, Hd, n.ptr, st))
+        if mlp_engine:                                     # decode_chain = 5: gate_up+SiLU and down as one persistent launch (kernels/mlp_engine.hip)
+            nvr.check(l.nvr_mlp_engine(n.ptr, Hd, Tgu[i], Td[i], T, Hd, I, act.ptr, slabs.ptr, sync.ptr, st))
+            nvr.check(l.nvr_add_rmsnorm_slabs(h.ptr, slabs.ptr, 4, g.ptr, 1e-6, T, Hd, n.ptr, st))
+            continue
         nvr.check(l.nvr_linear_silu_mul_tiled(n.ptr, Hd, Wgu[i].ptr, Tgu[i], T, Hd, I, act.ptr, st))
         nvr.check(l.nvr_linear_splitk_tiled(act.ptr, I, Wd[i].ptr, Td[i], T, I, Hd, Sd, slabs.ptr, st))
         nvr.check(l.nvr_add_rmsnorm_slabs(h.ptr, slabs.ptr, Sd, g.ptr, 1e-6, T, Hd, n.ptr, st))
@@ -657,6 +661,8 @@ def main() -> None:
     if args.gpus == 1 and rank == 0 and not args.no_chain and args.model == "qwen3-0.6b":
         try:
             chain = time_decode_chain(nvr, mc)
+            if nvr.lib().nvr_mlp_engine_ok(BATCH, mc.c.hidden_size, mc.c.intermediate_size):
+                chain["us_per_layer_mlp_engine"] = time_decode_chain(nvr, mc, mlp_engine=True)["us_per_layer"]
         except Exception as ex:                                              # noqa: BLE001
             print(f"[bench] decode chain timing failed: {ex}", file=sys.stderr, flush=True)
     shared_prefix = None
@@ -764,6 +770,10 @@ def main() -> None:
                                      "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "us_per_layer": round(chain["us_per_layer"], 2),
                                      "algorithmic_bytes_per_layer": int(chain["alg_bytes_per_layer"]),
                                      "note": "one hipGraph of 28 layers with their own weights (HBM-cold), replayed back to back (HIP events on its stream)"}
+            if "us_per_layer_mlp_engine" in chain:
+                out["roofline_chain"]["us_per_layer_with_mlp_engine"] = round(chain["us_per_layer_mlp_engine"], 2)
+                out["roofline_chain"]["mlp_engine_note"] = ("the same chain with gate_up+SiLU and down as ONE persistent launch (kernels/mlp_engine.hip, "
+                                                            "nvr_config.decode_chain = 5, opt-in): five launches per layer")
         if shared_prefix is not None:
             out["shared_prefix"] = shared_prefix
         if configs3 is not None:

@@ -87,7 +87,9 @@ typedef struct nvr_config {
     uint32_t decode_chain;             /* GEMM / norm chain of single-rank decode steps: 0 or 6 = six launches per layer (qkv+RoPE,
                                           o_proj split-k, add+RMSNorm, gate_up+SiLU, down split-k, add+RMSNorm; default: measured
                                           0.8 % faster per step), 4 = four launches (kernels/linear_decode.hip: norms in the GEMM
-                                          prologues, residual adds on the split-k reductions); profiles/r02_decode_chain_ablation.txt */
+                                          prologues, residual adds on the split-k reductions); profiles/r02_decode_chain_ablation.txt;
+                                          5 = the six-launch chain with gate_up+SiLU and down as ONE persistent launch (kernels/mlp_engine.hip,
+                                          steps of <= 32 rows of shapes nvr_mlp_engine_ok accepts, else 6); profiles/r04_mlp_engine.txt */
     int32_t recompute_cached_prefix;   /* 0 (default): a prefill step computes only the tokens after a sequence's
                                           cached prefix (num_cached_tokens, block_manager.rs:187) and attends to the
                                           prefix through the block table (K8, attention.rs:211-222) — SURVEY §8f row 2;
@@ -503,6 +505,19 @@ NVR_API int nvr_lm_head_tiled(const nvr_half *x, int64_t ldx, const nvr_half *W,
 NVR_API int nvr_linear_resid(const nvr_half *x, int64_t ldx, const nvr_half *W, const nvr_half *Wt, int64_t T, int64_t K, int64_t N,
                              int64_t S, float *slabs, uint32_t *counters, nvr_half *h, void *stream);
 NVR_API int nvr_decode_splitk_slices(int64_t T, int64_t K, int64_t N);
+/* The MLP pair of a decode layer (Qwen3MLP::forward, qwen3.rs:305-314: gate_up_proj :307, SiluAndMul :310, down_proj :313) as ONE persistent
+ * launch (kernels/mlp_engine.hip; nvr_config.decode_chain = 5): per CU one workgroup of 1 LDS-DMA loader wave + 3 MFMA consumer waves; the
+ * loader streams the gate / up weight tiles and, AHEAD of the in-launch hand-off, the workgroup's down_proj k-slice; act tiles are handed
+ * over write-through with one arrival counter per k-slice (bounded poll on the 100 MHz clock: a timeout sets sync[4], the GPU never hangs).
+ * x [T, Hd] (T <= 32); gate_up_tiled / down_tiled: nvr_retile_weight (mode 0) copies of W_gate_up [2I, Hd] / W_down [Hd, I]; act [T, I];
+ * slabs [4][T][Hd] f32 (the k-slice partial sums nvr_linear_splitk writes with S = 4: consumed by nvr_add_rmsnorm_slabs); sync:
+ * nvr_mlp_engine_sync_bytes() of device memory (zeroed by the call itself).  Same rounding points as nvr_linear_silu_mul + nvr_linear_splitk;
+ * f32 summation order differs (tolerance as between any two GEMM routes).  nvr_mlp_engine_ok: the shape is instantiated and every workgroup
+ * can be resident on this device (the only shapes the call accepts: NVR_ERR_UNSUPPORTED otherwise). */
+NVR_API int nvr_mlp_engine_ok(int64_t T, int64_t Hd, int64_t I);
+NVR_API size_t nvr_mlp_engine_sync_bytes(void);
+NVR_API int nvr_mlp_engine(const nvr_half *x, int64_t ldx, const nvr_half *gate_up_tiled, const nvr_half *down_tiled, int64_t T, int64_t Hd,
+                           int64_t I, nvr_half *act, float *slabs, uint32_t *sync, void *stream);
 /* Prefill-sized twin of nvr_linear_resid: h[T,N] <- fp16(h + fp16(x · Wᵀ)) with the residual add (qwen3.rs:382,389) in the epilogue of the
  * 256x256 MFMA GEMM; only for shapes that kernel takes (T >= 256, N % 256 == 0, K % 64 == 0 and preferred by the routing of nvr_linear:
  * NVR_ERR_UNSUPPORTED otherwise).  Bit-identical to nvr_linear into a scratch tensor followed by the add of nvr_add_rmsnorm. */

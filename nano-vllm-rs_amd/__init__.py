@@ -183,6 +183,8 @@ _SIGS = {
     "nvr_runner_p2p_disable": (C.c_int, [_P]), "nvr_runner_p2p_active": (C.c_int, [_P]),
     "nvr_runner_p2p_reset": (C.c_int, [_P]), "nvr_runner_comm_drop_rccl": (C.c_int, [_P]),
     "nvr_engine_abort_last_batch": (C.c_int, [_P]), "nvr_engine_ahead_declined": (C.c_uint64, [_P]), "nvr_engine_ahead_launched": (C.c_uint64, [_P]),
+    "nvr_mlp_engine_ok": (C.c_int, [C.c_int64, C.c_int64, C.c_int64]), "nvr_mlp_engine_sync_bytes": (C.c_size_t, []),
+    "nvr_mlp_engine": (C.c_int, [_P, C.c_int64, _P, _P, C.c_int64, C.c_int64, C.c_int64, _P, _P, _P, _P]),
     "nvr_runner_last_prefill_kv_source": (C.c_int, [_P]),
     "nvr_runner_set_tp_prefill_overlap": (C.c_int, [_P, C.c_int32]), "nvr_runner_last_overlap_chunks": (C.c_int64, [_P]),
     "nvr_runner_last_shared_prefix_len": (C.c_int64, [_P]), "nvr_runner_last_shared_prefix_rows": (C.c_int64, [_P]),

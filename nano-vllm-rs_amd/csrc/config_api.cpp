@@ -50,8 +50,8 @@ int nvr_config_validate(const nvr_config *c) {                       // config.r
         return nvr::fail(NVR_ERR_INVALID_ARG, "Unsupported device: %.15s", c->device);
     if (!cfg_str_in(c->dtype, sizeof c->dtype, {"float16", "bfloat16", "float32"}))                      // config.rs:113-116
         return nvr::fail(NVR_ERR_INVALID_ARG, "Unsupported dtype: %.15s", c->dtype);
-    if (c->decode_chain != 0 && c->decode_chain != 4 && c->decode_chain != 6)
-        return nvr::fail(NVR_ERR_INVALID_ARG, "decode_chain must be 0, 4 or 6, got %u", c->decode_chain);
+    if (c->decode_chain != 0 && c->decode_chain != 4 && c->decode_chain != 5 && c->decode_chain != 6)
+        return nvr::fail(NVR_ERR_INVALID_ARG, "decode_chain must be 0, 4, 5 or 6, got %u", c->decode_chain);
     return NVR_OK;
 }
 }  // extern "C"

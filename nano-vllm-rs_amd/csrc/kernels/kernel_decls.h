@@ -122,6 +122,12 @@ int gemm256_qkv_rope_store(const half_bits *x, int64_t ldx, const half_bits *W, 
                            const int64_t *positions, const int32_t *slots, const float *cos_t, const float *sin_t, half_bits *qkv,
                            half_bits *k_cache, half_bits *v_cache, hipStream_t s, bool kv_cache_only = false);
 
+// the MLP pair of a decode layer as one persistent launch (kernels/mlp_engine.hip): act = SiluAndMul(x·W_gate_upᵀ), slabs[4] = k-slices of act·W_downᵀ
+bool mlp_engine_ok(int64_t T, int64_t Hd, int64_t I, int ncu);
+size_t mlp_engine_sync_bytes();
+int mlp_engine(const half_bits *x, int64_t ldx, const half_bits *gate_up_t, const half_bits *down_t, int64_t T, int64_t Hd, int64_t I,
+               half_bits *act, float *slabs, unsigned *sync, hipStream_t s);
+
 size_t attn_workspace_bytes(int64_t nq, int64_t H, int64_t D, int64_t max_ctx);
 int attention(const AttnArgs &a, bool paged, hipStream_t s);
 

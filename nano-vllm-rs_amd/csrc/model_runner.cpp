@@ -41,6 +41,7 @@ nvr_model_runner::~nvr_model_runner() {
     for (auto &g : graphs) hipGraphExecDestroy(g.second);
     comm.destroy();
     if (chain_cnt) hipFree(chain_cnt);
+    if (mlp_sync) hipFree(mlp_sync);
     for (auto &l : layers) { hipFree(l.qkv); hipFree(l.o); hipFree(l.gate_up); hipFree(l.down); hipFree(l.ln1); hipFree(l.ln2);
                              void *ts[] = {l.qkv_t, l.o_t, l.gate_up_t, l.down_t, l.q_norm, l.k_norm}; for (void *t : ts) if (t) hipFree(t); }
     if (lm_head_t) hipFree(lm_head_t);
@@ -113,6 +114,9 @@ int nvr_model_runner::init() {                                       // ModelRun
     slab_rows = std::max<int64_t>(64, std::min<int64_t>(1024, std::max<int64_t>(max_seqs, 256)));
     RC(dmalloc(&slabs, 4 * slab_rows * Hd));
     chain4 = cfg.decode_chain == 4;
+    chain5 = cfg.decode_chain == 5;
+    { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && v > 0) num_cus = v; }
+    if (chain5) NVR_HIP_CHECK(hipMalloc((void **)&mlp_sync, 256));
     NVR_HIP_CHECK(hipMalloc((void **)&chain_cnt, 4096 * sizeof(unsigned int)));
     NVR_HIP_CHECK(hipMemset(chain_cnt, 0, 4096 * sizeof(unsigned int)));
     allow_missing_comm = env.tp_no_comm;                                               // compute-only profiling of one rank
@@ -448,6 +452,12 @@ bool nvr_model_runner::use_chain4(int64_t T, bool is_prefill) const {
            H * D <= 4096 && I <= 8192 && Hd * std::max(H * D, I) * 2 < (24ll << 20);
 }
 
+// decode_chain = 5: the MLP pair of a single-rank decode step of <= 32 rows as one persistent launch, when the shape is instantiated, every
+// workgroup fits the device at once and the tiled weight copies exist (the loader streams those)
+bool nvr_model_runner::use_mlp_engine(int64_t T, bool is_prefill) const {
+    return chain5 && !is_prefill && tp == 1 && !comm.active() && tiled_weights && T <= 32 && T <= slab_rows && KD(mlp_engine_ok(T, Hd, I, num_cus));
+}
+
 // Decode batches in which many sequences start with the same cache blocks (prefix-cache hits of BlockManager::allocate,
 // block_manager.rs:181-197: one system prompt in front of the requests, BASELINE configs[4]).  The GROUP is the set of sequences
 // whose first block is the batch's most common first block; its shared length is the run of full blocks all members have in common.  The
@@ -576,6 +586,12 @@ int nvr_model_runner::forward(int64_t T, int64_t B, bool is_prefill, int64_t max
             RC(KD(linear_resid(act, I, w.down, T, I, Hd, k::decode_splitk_slices(T, I, Hd), slabs, chain_cnt, h, st, tl ? w.down_t : nullptr)));
         } else {
             RC(row_parallel_norm(attn, H * D, w.o, tl ? w.o_t : nullptr, T, w.ln2));         // o_proj, residual :382, norm :385
+            if (use_mlp_engine(T, is_prefill)) {
+                // K12 + K13 + K14 in ONE persistent launch (loader / consumer engine, in-launch hand-off of the activations), then the add + norm launch
+                RC(KD(mlp_engine(n, Hd, w.gate_up_t, w.down_t, T, Hd, I, act, slabs, mlp_sync, st)));
+                RC(KD(add_rmsnorm_slabs(h, slabs, 4, l + 1 < L ? layers[l + 1].ln1 : norm, mc.rms_norm_eps, T, Hd, n, st)));
+                continue;
+            }
             RC(KD(linear_silu_mul(n, Hd, w.gate_up, T, Hd, I, act, st, tl ? w.gate_up_t : nullptr)));   // K12 + K13 in one launch
             // down_proj, residual :389 and the NEXT layer's input norm :378 (or the final norm :501)
             RC(row_parallel_norm(act, I, w.down, tl ? w.down_t : nullptr, T, l + 1 < L ? layers[l + 1].ln1 : norm));

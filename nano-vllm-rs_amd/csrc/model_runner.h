@@ -73,6 +73,10 @@ struct nvr_model_runner {
     // decode chain (kernels/linear_decode.hip): one ticket counter per (column tile, token tile) of the row-parallel GEMMs
     unsigned int *chain_cnt = nullptr;
     bool chain4 = false;                   // nvr_config.decode_chain == 4: the four-launch chain of linear_decode.hip
+    bool chain5 = false;                   // nvr_config.decode_chain == 5: gate_up+SiLU and down as one persistent launch (kernels/mlp_engine.hip)
+    unsigned int *mlp_sync = nullptr;      // its arrival counters + timeout word (zeroed by every launch)
+    int num_cus = 256;                     // compute units of the device (every workgroup of that launch must be resident)
+    bool use_mlp_engine(int64_t T, bool is_prefill) const;
     std::map<uint64_t, hipGraphExec_t> graphs;
     size_t last_rows = 0; bool last_prefill = false; int64_t last_tokens = 0;
     int64_t decode_shared_len = 0;                       // the last decode step: tokens its sharing group holds in the same leading blocks

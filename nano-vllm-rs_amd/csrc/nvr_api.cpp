@@ -505,6 +505,16 @@ int nvr_argmax_partials(const float *part_val, const int32_t *part_idx, int32_t 
 int nvr_linear_splitk(const nvr_half *x, int64_t ldx, const nvr_half *W, int64_t T, int64_t K, int64_t N, int64_t S, float *slabs, void *s) {
     return KO(linear_splitk(x, ldx, W, T, K, N, S, slabs, (hipStream_t)s));
 }
+int nvr_mlp_engine_ok(int64_t T, int64_t Hd, int64_t I) {
+    int dev = 0, ncu = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    return k::mlp_engine_ok(T, Hd, I, ncu) ? 1 : 0;
+}
+size_t nvr_mlp_engine_sync_bytes(void) { return k::mlp_engine_sync_bytes(); }
+int nvr_mlp_engine(const nvr_half *x, int64_t ldx, const nvr_half *gut, const nvr_half *dt, int64_t T, int64_t Hd, int64_t I, nvr_half *act,
+                   float *slabs, uint32_t *sync, void *s) {
+    return KO(mlp_engine(x, ldx, gut, dt, T, Hd, I, act, slabs, sync, (hipStream_t)s));
+}
 int nvr_add_rmsnorm_slabs(nvr_half *h, const float *slabs, int64_t S, const nvr_half *w, float eps, int64_t T, int64_t Hd, nvr_half *out, void *s) {
     return KO(add_rmsnorm_slabs(h, slabs, S, w, eps, T, Hd, out, (hipStream_t)s));
 }

@@ -69,7 +69,7 @@ def test_config_and_params_validation():             # config.rs:194-217, sampli
     with pytest.raises(nvr.NvrError, match="Unsupported dtype: int8"):
         nvr.Config(dtype="int8").validate()
     with pytest.raises(nvr.NvrError):
-        nvr.Config(decode_chain=5).validate()
+        nvr.Config(decode_chain=7).validate()
     for bad in (dict(temperature=-1.0), dict(max_tokens=0), dict(top_p=1.5), dict(top_k=0)):
         with pytest.raises(nvr.NvrError):
             nvr.SamplingParams(**bad).validate()

@@ -1267,3 +1267,53 @@ def test_paged_attn_decode_shared_prefix_group(seed):
     nvr.check(nvr.lib().nvr_paged_attn_decode(d_q.ptr, H * D, d_k.ptr, d_v.ptr, C.byref(meta), H, KVH, D, bs, scale, d_plain.ptr, ws.ptr, None))
     assert_close_f16(d_out.to_numpy((B, H, D), F16), d_plain.to_numpy((B, H, D), F16), ulps=3, atol=1e-3,
                      what=f"D={D} G={G} KVH={KVH} bs={bs} P={P} B={B} members={len(rows)}")
+
+
+# ------------------------------------------------------------------------------------------- K12 + K13 + K14 as one persistent launch
+@pytest.mark.parametrize("T,Hd,I", [(32, 1024, 3072), (7, 1024, 3072), (17, 256, 512), (32, 512, 1024), (1, 256, 512)])
+def test_mlp_engine_matches_the_two_launches_and_the_oracle(T, Hd, I):
+    """kernels/mlp_engine.hip (nvr_mlp_engine; decode_chain = 5): gate_up + SiluAndMul and the down_proj k-slices in ONE persistent launch
+    (loader wave + 3 consumer waves per workgroup, the act tiles handed over in-launch through write-through stores and an arrival counter per
+    k-slice).  Same rounding points as nvr_linear_silu_mul + nvr_linear_splitk (S = 4): act within 2 fp16 ulp of the launches' and of the oracle's
+    (f32 summation order), the summed slabs = act_engine · W_downᵀ to f32 rounding; the timeout word stays 0; repeated launches (poisoned
+    outputs in between) give the same bits — the counters are re-initialised by every call."""
+    l = nvr.lib()
+    if not l.nvr_mlp_engine_ok(T, Hd, I):
+        pytest.skip("shape not instantiated / not enough CUs on this device")
+    rng = np.random.default_rng(70 + T)
+    x, xb = h16(rng.standard_normal((T, Hd)))
+    wgu, wgub = h16(rng.standard_normal((2 * I, Hd)) * 0.05)
+    wd, wdb = h16(rng.standard_normal((Hd, I)) * 0.05)
+    d_x, d_wgu, d_wd = dev(xb), dev(wgub), dev(wdb)
+    t_gu, t_d = nvr.DeviceBuffer(2 * I * Hd * 2), nvr.DeviceBuffer(Hd * I * 2)
+    nvr.check(l.nvr_retile_weight(d_wgu.ptr, t_gu.ptr, 2 * I, Hd, 0, 0, 0, 0, None))
+    nvr.check(l.nvr_retile_weight(d_wd.ptr, t_d.ptr, Hd, I, 0, 0, 0, 0, None))
+    act_e, slabs_e, sync = nvr.DeviceBuffer(T * I * 2), nvr.DeviceBuffer(4 * T * Hd * 4), nvr.DeviceBuffer(256)
+    outs = []
+    for rep in range(3):
+        nvr.check(l.nvr_device_memset(act_e.ptr, 0x7f, T * I * 2)); nvr.check(l.nvr_device_memset(slabs_e.ptr, 0x7f, 4 * T * Hd * 4))
+        nvr.check(l.nvr_mlp_engine(d_x.ptr, Hd, t_gu.ptr, t_d.ptr, T, Hd, I, act_e.ptr, slabs_e.ptr, sync.ptr, None))
+        nvr.synchronize()
+        assert sync.to_numpy((8,), np.uint32)[4] == 0, "the seam timed out"
+        outs.append((act_e.to_numpy((T, I), F16).copy(), slabs_e.to_numpy((4, T, Hd), np.float32).copy()))
+    for a2, s2 in outs[1:]:
+        assert np.array_equal(a2.view(np.uint16), outs[0][0].view(np.uint16)) and np.array_equal(s2, outs[0][1])
+    act, slabs = outs[0]
+    # the two launches it replaces
+    act_l, slabs_l = nvr.DeviceBuffer(T * I * 2), nvr.DeviceBuffer(4 * T * Hd * 4)
+    nvr.check(l.nvr_linear_silu_mul_tiled(d_x.ptr, Hd, d_wgu.ptr, t_gu.ptr, T, Hd, I, act_l.ptr, None))
+    nvr.check(l.nvr_linear_splitk_tiled(act_l.ptr, I, d_wd.ptr, t_d.ptr, T, I, Hd, 4, slabs_l.ptr, None))
+    nvr.synchronize()
+    ref_act = oracle.round_f16(oracle.silu_and_mul(oracle.round_f16(oracle.linear(x, wgu))))
+    # (g and u are rounded to fp16 before SiLU·u is: a last-bit difference of the f32 sums in either can move the product by 2 ulp)
+    assert_close_f16(act, act_l.to_numpy((T, I), F16), ulps=2, atol=1e-6, what="engine act vs linear_silu_mul")
+    assert_close_f16(act, ref_act, ulps=2, atol=1e-6, what="engine act vs oracle")
+    # slabs: k-slices of the engine's OWN act times W_down, f32 (exact reference in f64 from the fp16 values)
+    a64, w64 = act.astype(np.float64), wd.astype(np.float64)
+    ks = I // 4
+    for z in range(4):
+        want = a64[:, z * ks:(z + 1) * ks] @ w64[:, z * ks:(z + 1) * ks].T
+        err = np.abs(slabs[z] - want).max()
+        assert err <= 1e-4 * max(1.0, np.abs(want).max()), (z, err)
+    tot_l = slabs_l.to_numpy((4, T, Hd), np.float32).sum(0)
+    assert np.abs(slabs.sum(0) - tot_l).max() <= 2e-2 * max(1.0, np.abs(tot_l).max())      # (the launches' act may differ by an ulp from the engine's)
