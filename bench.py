@@ -143,7 +143,7 @@ def time_decode_chain(nvr, mc, reps: int = 20, mlp_engine: bool = False) -> dict
     rng = np.random.default_rng(0)
     h = arr(rng.standard_normal((T, Hd)).astype(np.float16)); n = buf(T * Hd * 2); g = arr(np.ones(Hd, np.float16))
     qkv, attn, act = buf(T * QKV * 2), arr(rng.standard_normal((T, H * D)).astype(np.float16) * 0.1), buf(T * I * 2)
-    slabs = buf(4 * T * Hd * 4); sync = buf(256)
+    slabs = buf(4 * T * Hd * 4); sync = buf(l.nvr_mlp_engine_sync_bytes())
     pos = arr(np.arange(T, dtype=np.int64) + 1000); slots = arr(np.arange(T, dtype=np.int32))
     cos = arr(np.ones((2048, D // 2), np.float32)); sin = arr(np.zeros((2048, D // 2), np.float32))
     kc, vc = buf(64 * KVH * D * 2), buf(64 * KVH * D * 2)

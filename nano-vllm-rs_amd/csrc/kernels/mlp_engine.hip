@@ -21,6 +21,9 @@
 // Placement-independent: nothing assumes which CU or XCD a workgroup runs on; it needs every workgroup RESIDENT (grid <= CU count, one
 // workgroup per CU by its LDS footprint) — the launcher refuses other shapes, the poll is bounded.
 #include <cstdint>
+#include <cstdio>
+#include <vector>
+#include <algorithm>
 #include "kernels.h"
 #include "device_utils.h"
 #include "../common.h"
@@ -33,7 +36,7 @@ struct MlpArgs {
     int32_t T, Hd, I;
     half_t *act;                             // [T, I]
     float *slabs;                            // [4][T][Hd]
-    unsigned *sync;                          // [0..4) arrival counters of the k-slices, [4] timeout word; zeroed before every launch
+    unsigned *sync;                          // [4] timeout word, [8 ...) arrival flags (tile, token tile); zeroed before every launch
     unsigned timeout_ticks;                  // 100 MHz ticks a workgroup waits at the seam
 };
 
@@ -47,6 +50,12 @@ __device__ __forceinline__ void dma_kstep(const half_t *tile_kstep, unsigned lds
                  : "=&s"(keep) : "v"(src), "s"(lds_dst) : "memory");
 }
 
+#ifdef NVR_MLP_STAMPS   // diagnostic build (tools/build_variant.sh): 100 MHz wall-clock stamps of wave 1 of every workgroup -> profiles/r04_mlp_engine.txt
+__device__ unsigned long long mlp_stamp_buf[512 * 8];
+#define MLP_STAMP(i) do { if (threadIdx.x == 64) mlp_stamp_buf[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define MLP_STAMP(i) do { } while (0)
+#endif
 template <int MT, int KB1, int KB2>
 __global__ __launch_bounds__(256, 1) void mlp_engine_kernel(MlpArgs a) {
     constexpr int NI1 = (KB1 + 2) / 3, NI2 = (KB2 + 2) / 3;          // k-steps per consumer wave
@@ -60,6 +69,7 @@ __global__ __launch_bounds__(256, 1) void mlp_engine_kernel(MlpArgs a) {
     const bool has_tile = w < a.I / 16, has_down = w < (a.Hd / 16) * MLP_S;
     const int j2 = w / MLP_S, sl = w % MLP_S;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
+    MLP_STAMP(0);
     if (threadIdx.x == 0) *ready = 0;
     __syncthreads();
 
@@ -121,7 +131,9 @@ __global__ __launch_bounds__(256, 1) void mlp_engine_kernel(MlpArgs a) {
 #pragma unroll
         for (int j = 0; j < MT; ++j) { part[j * 64 + lane] = accg[j]; part[(2 + j) * 64 + lane] = accu[j]; }
     }
+    MLP_STAMP(1);
     __syncthreads();                                                  // (1) partials of the three consumers are in LDS
+    MLP_STAMP(2);
     if (has_tile && wave >= 1 && wave <= MT) {
         // act tile of token tile j = wave - 1: C layout row (n) = q*4 + reg, column (token) = r
         const int j = wave - 1;
@@ -138,26 +150,35 @@ __global__ __launch_bounds__(256, 1) void mlp_engine_kernel(MlpArgs a) {
         if (m < a.T)                                                  // write-through: the consumers of this tile sit on other CUs (guide G16 R1)
             __hip_atomic_store(reinterpret_cast<unsigned long long *>(a.act + (int64_t)m * a.I + n), hv.u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's stores have left
-        if (lane == 0) __hip_atomic_fetch_add(a.sync + (w * 16) / (a.I / MLP_S), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // arrival: ONE write-through flag word per (tile, token tile) — no atomics (first build: an arrival counter per k-slice; 96 atomic adds
+        // on one word while 64 workgroups polled it: the last arrival became visible 4-6 us after it was issued, profiles/r04_mlp_engine.txt)
+        if (lane == 0) __hip_atomic_store(a.sync + 8 + w * 2 + j, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (wave == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the down_proj k-slice is in LDS
+    MLP_STAMP(3);
     // ---- seam: every tile of my k-slice has arrived (MT arrivals per tile), or the wait ran out
     if (has_down && wave == 1) {
-        const unsigned target = (unsigned)((a.I / MLP_S / 16) * MT);
+        // the flags of my k-slice are consecutive words: the whole wave sweeps them with one or two loads per poll
+        const int tiles = a.I / MLP_S / 16, nflag = tiles * 2;       // (tile, token tile) words; token tile 1 is unused when MT == 1
+        const unsigned *fl = a.sync + 8 + sl * nflag;
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
         for (;;) {
-            const unsigned seen = __hip_atomic_load(a.sync + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (seen >= target) break;
+            bool ok = true;
+            for (int i = lane; i < nflag; i += 64)
+                if (MT == 2 || (i & 1) == 0) ok &= __hip_atomic_load(fl + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+            if (__all(ok)) break;
             if (__builtin_amdgcn_s_memrealtime() - t0 > a.timeout_ticks) {
                 if (lane == 0) __hip_atomic_store(a.sync + MLP_S, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 break;
             }
-            __builtin_amdgcn_s_sleep(2);
+            __builtin_amdgcn_s_sleep(4);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    MLP_STAMP(4);
     __syncthreads();                                                  // (2)
+    MLP_STAMP(5);
     float4_t accd[MT];
 #pragma unroll
     for (int j = 0; j < MT; ++j) accd[j] = (float4_t){0.f, 0.f, 0.f, 0.f};
@@ -186,6 +207,7 @@ __global__ __launch_bounds__(256, 1) void mlp_engine_kernel(MlpArgs a) {
 #pragma unroll
         for (int j = 0; j < MT; ++j) part[j * 64 + lane] = accd[j];
     }
+    MLP_STAMP(6);
     __syncthreads();                                                  // (3)
     if (has_down && wave >= 1 && wave <= MT) {
         const int j = wave - 1;
@@ -194,6 +216,7 @@ __global__ __launch_bounds__(256, 1) void mlp_engine_kernel(MlpArgs a) {
         const int m = j * 16 + r, n = j2 * 16 + q * 4;
         if (m < a.T) *reinterpret_cast<float4_t *>(a.slabs + ((int64_t)sl * a.T + m) * a.Hd + n) = s4;
     }
+    MLP_STAMP(7);
 }
 
 static size_t mlp_lds_bytes(int64_t Hd, int64_t I) { return (size_t)(Hd / 32) * 2048 + (size_t)(I / (32 * MLP_S)) * 1024 + 3 * 4096 + 16; }
@@ -204,14 +227,14 @@ static size_t mlp_lds_bytes(int64_t Hd, int64_t I) { return (size_t)(Hd / 32) * 
 bool mlp_engine_ok(int64_t T, int64_t Hd, int64_t I, int ncu) {
     if (T < 1 || T > 32 || Hd % 32 || I % (32 * MLP_S) || I % 16) return false;
     const int64_t grid = std::max(I / 16, (Hd / 16) * MLP_S);
-    if (grid > ncu || mlp_lds_bytes(Hd, I) > 160 * 1024 || I / (32 * MLP_S) > 60) return false;   // every workgroup resident; the loader's counted wait fits vmcnt
+    if (grid > ncu || mlp_lds_bytes(Hd, I) > 160 * 1024 || I / (32 * MLP_S) > 60 || I / 16 > 512) return false;   // every workgroup resident; the loader's counted wait fits vmcnt
     bool inst = false;
 #define X(A, B) inst |= (Hd / 32 == A && I / (32 * MLP_S) == B);
     NVR_MLP_SHAPES(X)
 #undef X
     return inst;
 }
-size_t mlp_engine_sync_bytes() { return 32; }
+size_t mlp_engine_sync_bytes() { return 32 + 512 * 2 * 4; }     // [4 spare | timeout | 3 pad] + one flag word per (gate/up tile <= 512, token tile)
 
 int mlp_engine(const half_bits *x, int64_t ldx, const half_bits *gate_up_t, const half_bits *down_t, int64_t T, int64_t Hd, int64_t I,
                half_bits *act, float *slabs, unsigned *sync, hipStream_t s) {
@@ -242,6 +265,34 @@ int mlp_engine(const half_bits *x, int64_t ldx, const half_bits *gate_up_t, cons
 #undef X
     e = hipGetLastError();
     if (e != hipSuccess) return nvr::fail(NVR_ERR_HIP, "mlp_engine launch failed: %s", hipGetErrorString(e));
+#ifdef NVR_MLP_STAMPS
+    {
+        static int calls = 0;
+        if (++calls == 6) {
+            hipStreamSynchronize(s);
+            std::vector<unsigned long long> hb(grid * 8);
+            hipMemcpyFromSymbol(hb.data(), HIP_SYMBOL(mlp_stamp_buf), grid * 8 * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
+            unsigned long long t0 = ~0ull, t1 = 0; double d[7] = {0, 0, 0, 0, 0, 0, 0}, start = 0;
+            for (unsigned i = 0; i < grid; ++i) { t0 = std::min(t0, hb[i * 8]); t1 = std::max(t1, hb[i * 8 + 7]); }
+            const unsigned np = (unsigned)(I / 16);
+            for (unsigned i = 0; i < grid; ++i) { start += (double)(hb[i * 8] - t0); for (int j = 0; j < 7; ++j) d[j] += (double)(hb[i * 8 + j + 1] - hb[i * 8 + j]); }
+            {
+                std::vector<double> p1, sm, endp1;
+                for (unsigned i = 0; i < grid; ++i) {
+                    if (i < np) { p1.push_back((double)(hb[i * 8 + 1] - hb[i * 8]) / 100.0); endp1.push_back((double)(hb[i * 8 + 3] - t0) / 100.0); }
+                    sm.push_back((double)(hb[i * 8 + 4] - hb[i * 8 + 3]) / 100.0);
+                }
+                std::sort(p1.begin(), p1.end()); std::sort(sm.begin(), sm.end()); std::sort(endp1.begin(), endp1.end());
+                std::fprintf(stderr, "[mlp stamps] phase-1 k loop of the %zu producing workgroups: min %.2f median %.2f p90 %.2f max %.2f us; their act tiles signalled at (from launch start) median %.2f p90 %.2f max %.2f us; "
+                             "seam wait: min %.2f median %.2f max %.2f us\n", p1.size(), p1.front(), p1[p1.size() / 2], p1[p1.size() * 9 / 10], p1.back(),
+                             endp1[endp1.size() / 2], endp1[endp1.size() * 9 / 10], endp1.back(), sm.front(), sm[sm.size() / 2], sm.back());
+            }
+            std::fprintf(stderr, "[mlp stamps] %u workgroups (%u with a gate/up tile): kernel span %.2f us; mean start skew %.2f us; per workgroup (wave 1, us): phase-1 k loop %.2f, barrier %.2f, act tile + signal %.2f, "
+                         "seam poll + acquire %.2f, barrier %.2f, phase-2 k loop %.2f, barrier + slab store %.2f\n", grid, np, (double)(t1 - t0) / 100.0, start / grid / 100.0,
+                         d[0] / grid / 100.0, d[1] / grid / 100.0, d[2] / grid / 100.0, d[3] / grid / 100.0, d[4] / grid / 100.0, d[5] / grid / 100.0, d[6] / grid / 100.0);
+        }
+    }
+#endif
     return 0;
 }
 

@@ -116,7 +116,7 @@ int nvr_model_runner::init() {                                       // ModelRun
     chain4 = cfg.decode_chain == 4;
     chain5 = cfg.decode_chain == 5;
     { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && v > 0) num_cus = v; }
-    if (chain5) NVR_HIP_CHECK(hipMalloc((void **)&mlp_sync, 256));
+    if (chain5) NVR_HIP_CHECK(hipMalloc((void **)&mlp_sync, KD(mlp_engine_sync_bytes())));
     NVR_HIP_CHECK(hipMalloc((void **)&chain_cnt, 4096 * sizeof(unsigned int)));
     NVR_HIP_CHECK(hipMemset(chain_cnt, 0, 4096 * sizeof(unsigned int)));
     allow_missing_comm = env.tp_no_comm;                                               // compute-only profiling of one rank

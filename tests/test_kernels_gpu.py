@@ -1288,7 +1288,7 @@ def test_mlp_engine_matches_the_two_launches_and_the_oracle(T, Hd, I):
     t_gu, t_d = nvr.DeviceBuffer(2 * I * Hd * 2), nvr.DeviceBuffer(Hd * I * 2)
     nvr.check(l.nvr_retile_weight(d_wgu.ptr, t_gu.ptr, 2 * I, Hd, 0, 0, 0, 0, None))
     nvr.check(l.nvr_retile_weight(d_wd.ptr, t_d.ptr, Hd, I, 0, 0, 0, 0, None))
-    act_e, slabs_e, sync = nvr.DeviceBuffer(T * I * 2), nvr.DeviceBuffer(4 * T * Hd * 4), nvr.DeviceBuffer(256)
+    act_e, slabs_e, sync = nvr.DeviceBuffer(T * I * 2), nvr.DeviceBuffer(4 * T * Hd * 4), nvr.DeviceBuffer(l.nvr_mlp_engine_sync_bytes())
     outs = []
     for rep in range(3):
         nvr.check(l.nvr_device_memset(act_e.ptr, 0x7f, T * I * 2)); nvr.check(l.nvr_device_memset(slabs_e.ptr, 0x7f, 4 * T * Hd * 4))
