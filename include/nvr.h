@@ -138,6 +138,10 @@ typedef struct nvr_model_config {
     int32_t qk_norm;                   /* extension (0 = the reference graph): RMSNorm over head_dim on every q and k head before
                                         * RoPE, weights "layers.N.self_attn.q_norm.weight" / "k_norm.weight" (real Qwen3 checkpoints;
                                         * SURVEY §8f row 1, DESIGN A-27) */
+    int32_t use_bias;                  /* Qwen3Config::use_bias (qwen3.rs:54-55, default false :82): a bias on qkv_proj :167, o_proj :178,
+                                        * gate_up_proj :276 and down_proj :287 (row-parallel ones on rank 0 only, linear.rs:206); tensors
+                                        * "...q_proj.bias" etc.  A-30: y = 16bit(16bit(x·Wᵀ) + b), candle_nn::Linear's two tensor ops.  Such a
+                                        * model runs the plain GEMMs + one bias launch each (the fused epilogues carry no bias) */
 } nvr_model_config;
 NVR_API void nvr_model_config_default(nvr_model_config *mc);         /* qwen3.rs:70-89 */
 NVR_API void nvr_model_config_qwen3_0_6b(nvr_model_config *mc);
@@ -580,6 +584,10 @@ NVR_API int nvr_attn_prefill_paged(const nvr_half *q, int64_t ldq, const nvr_hal
                                    float scale, nvr_half *out, void *stream);
 /* K13 SiluAndMul, activation.rs:46-63: [T,2I] -> [T,I] */
 NVR_API int nvr_silu_and_mul(const nvr_half *x, int64_t T, int64_t I, nvr_half *out, void *stream);
+/* The bias of a Linear with Qwen3Config::use_bias (A-30): y[T,N] <- 16bit(y + b[N]) in place, N % 8 == 0 — candle_nn::Linear::forward is
+ * matmul, then broadcast_add, each rounding to the tensor dtype; linear.rs:124-139 (column-parallel: the local slice of b),
+ * :206 / :228-239 (row-parallel: rank 0 only, before the all-reduce) */
+NVR_API int nvr_add_bias(nvr_half *y, const nvr_half *b, int64_t T, int64_t N, void *stream);
 /* K15 last-token select, embed_head.rs:272-289 */
 NVR_API int nvr_select_last_tokens(const nvr_half *h, const int32_t *cu_seqlens_q, int64_t B, int64_t Hd,
                                    nvr_half *out, void *stream);

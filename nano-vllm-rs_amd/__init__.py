@@ -63,7 +63,7 @@ class ModelConfigC(C.Structure):
                 ("num_hidden_layers", C.c_uint64), ("num_attention_heads", C.c_uint64),
                 ("num_key_value_heads", C.c_uint64), ("head_dim", C.c_uint64), ("max_position_embeddings", C.c_uint64),
                 ("rms_norm_eps", C.c_float), ("rope_theta", C.c_double), ("tie_word_embeddings", C.c_int32),
-                ("init_std", C.c_float), ("seed", C.c_uint64), ("qk_norm", C.c_int32)]
+                ("init_std", C.c_float), ("seed", C.c_uint64), ("qk_norm", C.c_int32), ("use_bias", C.c_int32)]
 
 
 class EngineStatsC(C.Structure):
@@ -241,6 +241,7 @@ _SIGS = {
     "nvr_attn_prefill_paged": (C.c_int, [_P, C.c_int64, _P, _P, C.POINTER(AttnMetaC), C.c_int64, C.c_int64, C.c_int64, C.c_int64,
                                          C.c_int64, C.c_float, _P, _P]),
     "nvr_silu_and_mul": (C.c_int, [_P, C.c_int64, C.c_int64, _P, _P]),
+    "nvr_add_bias": (C.c_int, [_P, _P, C.c_int64, C.c_int64, _P]),
     "nvr_select_last_tokens": (C.c_int, [_P, _P, C.c_int64, C.c_int64, _P, _P]),
     "nvr_argmax": (C.c_int, [_P, C.c_int64, C.c_int64, _P, _P]),
     "nvr_sample_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),
@@ -623,7 +624,7 @@ class ModelRunner:
     def load_safetensors(self, path: str, strict: bool = False) -> List[str]:
         """Every tensor of a .safetensors file (or of all such files in a directory); bf16 — the dtype of the published
         Qwen3 checkpoints — goes down as its 16-bit patterns and is converted on load (iter_safetensors).  Returns the names
-        that are not part of the graph (biases; q_norm / k_norm unless ModelConfig(qk_norm=1), A-27) and warns about them (a
+        that are not part of the graph (biases unless ModelConfig(use_bias=1), A-30; q_norm / k_norm unless ModelConfig(qk_norm=1), A-27) and warns about them (a
         real Qwen3 checkpoint loaded without qk_norm runs WITHOUT its attention norms, SURVEY A-17); strict=True raises."""
         import warnings
         files = sorted(os.path.join(path, f) for f in os.listdir(path) if f.endswith(".safetensors")) if os.path.isdir(path) else [path]
@@ -638,11 +639,11 @@ class ModelRunner:
                     skipped.append(name)
         if skipped:
             warnings.warn(f"load_safetensors: {len(skipped)} tensors are outside the reference's Qwen3 graph and were NOT loaded "
-                          f"(e.g. {skipped[0]}): biases are not applied, q/k-norm only with ModelConfig(qk_norm=1) (SURVEY A-17)", RuntimeWarning, stacklevel=2)
+                          f"(e.g. {skipped[0]}): biases only with ModelConfig(use_bias=1), q/k-norm only with ModelConfig(qk_norm=1) (SURVEY A-17)", RuntimeWarning, stacklevel=2)
         return skipped
 
     def weight(self, local_name: str) -> np.ndarray:
-        """A local packed tensor: "embed", "lm_head", "norm", "layers.N.{qkv,o,gate_up,down,ln1,ln2}" — as fp16, or, from a bfloat16
+        """A local packed tensor: "embed", "lm_head", "norm", "layers.N.{qkv,o,gate_up,down,ln1,ln2}" (+ q_norm / k_norm with qk_norm, qkv_b / gate_up_b and, on rank 0, o_b / down_b with use_bias) — as fp16, or, from a bfloat16
         runner (numpy has no bf16), as the f32 values of its bf16 elements (exact)."""
         r, c = C.c_int64(), C.c_int64()
         check(lib().nvr_runner_copy_weight(self.h, local_name.encode(), None, 0, C.byref(r), C.byref(c)))

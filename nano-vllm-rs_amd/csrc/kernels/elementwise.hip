@@ -332,6 +332,29 @@ int silu_and_mul(const half_bits *x, int64_t T, int64_t I, half_bits *out, hipSt
     return 0;
 }
 
+// ---------------------------------------------------------------- bias of a projection (Qwen3Config::use_bias, qwen3.rs:54-55)
+// reference: candle_nn::Linear::forward behind src/layers/linear.rs:12-24 — the matmul's 16-bit result, then broadcast_add(bias): y <- 16bit(y + b)
+// (A-30: two tensor ops, two roundings; row kernels carry no FMA contraction, so this is the oracle's add bit for bit)
+__global__ void add_bias_kernel(half_t *__restrict__ y, const half_t *__restrict__ b, int N, int64_t total8) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total8; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % (N / 8)) * 8;
+        half8_t v = *reinterpret_cast<const half8_t *>(y + i * 8);
+        const half8_t bb = *reinterpret_cast<const half8_t *>(b + c);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = to_half_rn(__fadd_rn((float)v[e], (float)bb[e]));
+        *reinterpret_cast<half8_t *>(y + i * 8) = v;
+    }
+}
+int add_bias(half_bits *y, const half_bits *b, int64_t T, int64_t N, hipStream_t s) {
+    if (N % 8) return nvr::fail(NVR_ERR_UNSUPPORTED, "add_bias: %ld output features are not a multiple of 8", (long)N);
+    const int64_t total8 = T * (N / 8);
+    if (total8 == 0) return 0;
+    int64_t blocks = (total8 + 255) / 256; if (blocks > 4096) blocks = 4096;
+    add_bias_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>((half_t *)y, (const half_t *)b, (int)N, total8);
+    LAUNCH_CHECK();
+    return 0;
+}
+
 // ---------------------------------------------------------------- K15 last-token select
 // reference: ParallelLMHead::extract_last_tokens, src/layers/embed_head.rs:272-289
 __global__ void select_last_kernel(const half_t *__restrict__ h, const int32_t *__restrict__ cu, int Hd,

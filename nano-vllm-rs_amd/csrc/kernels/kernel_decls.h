@@ -12,6 +12,7 @@ int rmsnorm(const half_bits *x, const half_bits *w, float eps, int64_t T, int64_
 int add_rmsnorm(half_bits *h, const half_bits *y, const half_bits *w, float eps, int64_t T, int64_t Hd,
                 half_bits *out, hipStream_t s);
 int silu_and_mul(const half_bits *x, int64_t T, int64_t I, half_bits *out, hipStream_t s);
+int add_bias(half_bits *y, const half_bits *b, int64_t T, int64_t N, hipStream_t s);   // y[T, N] <- 16bit(y + b[N]) (use_bias, A-30)
 int select_last_tokens(const half_bits *h, const int32_t *cu, int64_t B, int64_t Hd, half_bits *out, hipStream_t s);
 int rope_store_kv(half_bits *qkv, const int64_t *positions, const int32_t *slots, int64_t T, int64_t H, int64_t KVH,
                   int64_t D, const float *cos_t, const float *sin_t, half_bits *k_cache, half_bits *v_cache,

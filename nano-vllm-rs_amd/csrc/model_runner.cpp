@@ -18,7 +18,7 @@ namespace k = nvr::k;
 #define KD(call) (bf16 ? nvr::kb::call : nvr::k::call)
 
 // tensor ids of the synthetic weight generator (twin of oracle/model_oracle.py)
-enum { TID_QKV = 0, TID_O = 1, TID_GATE_UP = 2, TID_DOWN = 3 };
+enum { TID_QKV = 0, TID_O = 1, TID_GATE_UP = 2, TID_DOWN = 3, TID_BIAS = 4 };   // TID_BIAS + id: the bias of that projection (use_bias)
 static const uint64_t TID_EMBED = 1ull << 20, TID_LM_HEAD = (1ull << 20) + 1;
 
 uint64_t nvr_weight_key_impl(uint64_t seed, uint64_t tid) {
@@ -43,7 +43,7 @@ nvr_model_runner::~nvr_model_runner() {
     if (chain_cnt) hipFree(chain_cnt);
     if (mlp_sync) hipFree(mlp_sync);
     for (auto &l : layers) { hipFree(l.qkv); hipFree(l.o); hipFree(l.gate_up); hipFree(l.down); hipFree(l.ln1); hipFree(l.ln2);
-                             void *ts[] = {l.qkv_t, l.o_t, l.gate_up_t, l.down_t, l.q_norm, l.k_norm}; for (void *t : ts) if (t) hipFree(t); }
+                             void *ts[] = {l.qkv_t, l.o_t, l.gate_up_t, l.down_t, l.q_norm, l.k_norm, l.qkv_b, l.o_b, l.gate_up_b, l.down_b}; for (void *t : ts) if (t) hipFree(t); }
     if (lm_head_t) hipFree(lm_head_t);
     void *ptrs[] = {embed, mc.tie_word_embeddings ? nullptr : lm_head, norm, cos_t, sin_t, kv_pool, h, n, qkv, attn,
                     proj, gu, act, nlast, logits, attn_ws, slabs, in_dev, d_tok, d_maxval, d_temp, d_topk, d_topp, d_keys,
@@ -202,7 +202,7 @@ int nvr_model_runner::retile_all() {
     const bool gemm_ok = Hd % 32 == 0 && (H * D) % 32 == 0 && I % 32 == 0 && QKV % 16 == 0 && Hd % 16 == 0 && I % 16 == 0 && D % 16 == 0;
     for (auto &w : layers) {
         if (!gemm_ok || !w.qkv_t) continue;
-        RC(KD(retile_weight(w.qkv, w.qkv_t, QKV, Hd, mc.qk_norm ? 0 : 1, H, KVH, D, stream)));   // qk_norm: plain GEMM, rows in place
+        RC(KD(retile_weight(w.qkv, w.qkv_t, QKV, Hd, (mc.qk_norm || mc.use_bias) ? 0 : 1, H, KVH, D, stream)));   // qk_norm / use_bias: plain GEMM, rows in place
         RC(KD(retile_weight(w.o, w.o_t, Hd, H * D, 0, 0, 0, 0, stream)));
         RC(KD(retile_weight(w.gate_up, w.gate_up_t, 2 * I, Hd, 0, 0, 0, 0, stream)));
         RC(KD(retile_weight(w.down, w.down_t, Hd, I, 0, 0, 0, 0, stream)));
@@ -224,6 +224,22 @@ int nvr_model_runner::gen_weights() {
         RC(dmalloc(&w.qkv, QKV * Hd)); RC(dmalloc(&w.o, Hd * H * D)); RC(dmalloc(&w.gate_up, 2 * I * Hd));
         RC(dmalloc(&w.down, Hd * I)); RC(dmalloc(&w.ln1, Hd)); RC(dmalloc(&w.ln2, Hd));
         w.qkv_t = w.o_t = w.gate_up_t = w.down_t = w.q_norm = w.k_norm = nullptr;
+        w.qkv_b = w.o_b = w.gate_up_b = w.down_b = nullptr;
+        if (mc.use_bias) {
+            // Qwen3Config::use_bias: one value per output feature, generated like a one-column weight indexed by the GLOBAL output row (shards
+            // take their slices); the row-parallel projections hold theirs on rank 0 only (linear.rs:206)
+            RC(dmalloc(&w.qkv_b, QKV)); RC(dmalloc(&w.gate_up_b, 2 * I));
+            RC(KD(fill_weight(w.qkv_b, H * D, 1, 1, 1, rank * H * D, 0, key(TID_BIAS + TID_QKV), sc, stream)));
+            RC(KD(fill_weight(w.qkv_b + H * D, KVH * D, 1, 1, 1, Hg * D + rank * KVH * D, 0, key(TID_BIAS + TID_QKV), sc, stream)));
+            RC(KD(fill_weight(w.qkv_b + (H + KVH) * D, KVH * D, 1, 1, 1, (Hg + KVHg) * D + rank * KVH * D, 0, key(TID_BIAS + TID_QKV), sc, stream)));
+            RC(KD(fill_weight(w.gate_up_b, I, 1, 1, 1, rank * I, 0, key(TID_BIAS + TID_GATE_UP), sc, stream)));
+            RC(KD(fill_weight(w.gate_up_b + I, I, 1, 1, 1, Ig + rank * I, 0, key(TID_BIAS + TID_GATE_UP), sc, stream)));
+            if (rank == 0) {
+                RC(dmalloc(&w.o_b, Hd)); RC(dmalloc(&w.down_b, Hd));
+                RC(KD(fill_weight(w.o_b, Hd, 1, 1, 1, 0, 0, key(TID_BIAS + TID_O), sc, stream)));
+                RC(KD(fill_weight(w.down_b, Hd, 1, 1, 1, 0, 0, key(TID_BIAS + TID_DOWN), sc, stream)));
+            }
+        }
         if (mc.qk_norm) {
             RC(dmalloc(&w.q_norm, D)); RC(dmalloc(&w.k_norm, D));
             RC(KD(fill_const(w.q_norm, D, 1.0f, stream))); RC(KD(fill_const(w.k_norm, D, 1.0f, stream)));
@@ -342,6 +358,15 @@ int nvr_model_runner::load_tensor(const char *name_in, int dtype, const int64_t 
         return put(layers[l].qkv + (H + KVH) * D * Hd, Hd, (Hg + KVHg) * D + rank * KVH * D, KVH * D, 0, Hd);
     }
     if (match_layer(name, "self_attn.o_proj.weight", &l)) { RC(layer_ok()); RC(want(Hd, Hg * D)); return put(layers[l].o, H * D, 0, Hd, rank * H * D, H * D); }   // :249-267
+    if (mc.use_bias) {                                                    // Qwen3Config::use_bias: output-feature slices like the weight rows; row-parallel biases live on rank 0 (linear.rs:206)
+        if (match_layer(name, "self_attn.q_proj.bias", &l)) { RC(layer_ok()); RC(want(Hg * D, 1)); return put(layers[l].qkv_b, 1, rank * H * D, H * D, 0, 1); }
+        if (match_layer(name, "self_attn.k_proj.bias", &l)) { RC(layer_ok()); RC(want(KVHg * D, 1)); return put(layers[l].qkv_b + H * D, 1, rank * KVH * D, KVH * D, 0, 1); }
+        if (match_layer(name, "self_attn.v_proj.bias", &l)) { RC(layer_ok()); RC(want(KVHg * D, 1)); return put(layers[l].qkv_b + (H + KVH) * D, 1, rank * KVH * D, KVH * D, 0, 1); }
+        if (match_layer(name, "self_attn.o_proj.bias", &l)) { RC(layer_ok()); RC(want(Hd, 1)); return rank == 0 ? put(layers[l].o_b, 1, 0, Hd, 0, 1) : NVR_OK; }
+        if (match_layer(name, "mlp.gate_proj.bias", &l)) { RC(layer_ok()); RC(want(Ig, 1)); return put(layers[l].gate_up_b, 1, rank * I, I, 0, 1); }
+        if (match_layer(name, "mlp.up_proj.bias", &l)) { RC(layer_ok()); RC(want(Ig, 1)); return put(layers[l].gate_up_b + I, 1, rank * I, I, 0, 1); }
+        if (match_layer(name, "mlp.down_proj.bias", &l)) { RC(layer_ok()); RC(want(Hd, 1)); return rank == 0 ? put(layers[l].down_b, 1, 0, Hd, 0, 1) : NVR_OK; }
+    }
     // MergedColumnParallelLinear: local rows [gate | up] (linear.rs:378-454)
     if (match_layer(name, "mlp.gate_proj.weight", &l)) { RC(layer_ok()); RC(want(Ig, Hd)); return put(layers[l].gate_up, Hd, rank * I, I, 0, Hd); }
     if (match_layer(name, "mlp.up_proj.weight", &l)) { RC(layer_ok()); RC(want(Ig, Hd)); return put(layers[l].gate_up + I * Hd, Hd, rank * I, I, 0, Hd); }
@@ -351,7 +376,7 @@ int nvr_model_runner::load_tensor(const char *name_in, int dtype, const int64_t 
         return put(layers[l].gate_up + I * Hd, Hd, Ig + rank * I, I, 0, Hd);
     }
     if (match_layer(name, "mlp.down_proj.weight", &l)) { RC(layer_ok()); RC(want(Hd, Ig)); return put(layers[l].down, I, 0, Hd, rank * I, I); }
-    return nvr::fail(NVR_ERR_UNSUPPORTED, "load_tensor: no parameter named '%s' in this graph (biases are not part of the reference's Qwen3 graph; q_norm / k_norm need nvr_model_config.qk_norm, SURVEY A-17)", name_in);
+    return nvr::fail(NVR_ERR_UNSUPPORTED, "load_tensor: no parameter named '%s' in this graph (biases need nvr_model_config.use_bias, q_norm / k_norm nvr_model_config.qk_norm, SURVEY A-17)", name_in);
 }
 
 int nvr_model_runner::copy_weight(const char *ln, uint16_t *out, size_t cap, int64_t *rows, int64_t *cols) {
@@ -368,6 +393,10 @@ int nvr_model_runner::copy_weight(const char *ln, uint16_t *out, size_t cap, int
     else if (match_layer(ln, "ln2", &l) && l >= 0 && l < L) { src = layers[l].ln2; r = Hd; c = 1; }
     else if (mc.qk_norm && match_layer(ln, "q_norm", &l) && l >= 0 && l < L) { src = layers[l].q_norm; r = D; c = 1; }
     else if (mc.qk_norm && match_layer(ln, "k_norm", &l) && l >= 0 && l < L) { src = layers[l].k_norm; r = D; c = 1; }
+    else if (mc.use_bias && match_layer(ln, "qkv_b", &l) && l >= 0 && l < L) { src = layers[l].qkv_b; r = QKV; c = 1; }
+    else if (mc.use_bias && match_layer(ln, "gate_up_b", &l) && l >= 0 && l < L) { src = layers[l].gate_up_b; r = 2 * I; c = 1; }
+    else if (mc.use_bias && rank == 0 && match_layer(ln, "o_b", &l) && l >= 0 && l < L) { src = layers[l].o_b; r = Hd; c = 1; }
+    else if (mc.use_bias && rank == 0 && match_layer(ln, "down_b", &l) && l >= 0 && l < L) { src = layers[l].down_b; r = Hd; c = 1; }
     else return nvr::fail(NVR_ERR_INVALID_ARG, "copy_weight: unknown local tensor '%s'", ln);
     if (rows) *rows = r;
     if (cols) *cols = c;
@@ -383,7 +412,18 @@ int nvr_model_runner::copy_weight(const char *ln, uint16_t *out, size_t cap, int
 // steps on one GPU split k over S workgroups per output tile so that the N = hidden GEMMs reach all 256 CUs; the f32 partial
 // slabs are summed, added to the residual and normalised by the following add_rmsnorm_slabs launch.  Otherwise the plain kernel
 // writes fp16 `proj` (+ all-reduce when tensor parallel) and add_rmsnorm follows.
-int nvr_model_runner::row_parallel_norm(const uint16_t *x, int64_t K, const uint16_t *W, const uint16_t *Wt, int64_t T, const uint16_t *wn) {
+int nvr_model_runner::row_parallel_norm(const uint16_t *x, int64_t K, const uint16_t *W, const uint16_t *Wt, int64_t T, const uint16_t *wn,
+                                        const uint16_t *bias) {
+    if (mc.use_bias) {
+        // Qwen3Config::use_bias (A-30): candle's Linear is matmul, then broadcast_add — two roundings —, and the row-parallel bias is added on
+        // rank 0 BEFORE the all-reduce (linear.rs:206, :228-239): the GEMM keeps its plain epilogue and the bias is a launch of its own
+        RC(KD(linear(x, K, W, T, K, Hd, proj, false, stream, Wt)));
+        if (bias) RC(KD(add_bias(proj, bias, T, Hd, stream)));
+        if (comm.active() && T <= 64 && comm.p2p_usable((size_t)(T * Hd)))
+            return comm.all_reduce_add_rmsnorm(proj, h, wn, mc.rms_norm_eps, (int)T, (int)Hd, n, stream);
+        if (comm.active()) RC(comm.all_reduce_sum_f16(proj, (size_t)(T * Hd), stream));
+        return KD(add_rmsnorm(h, proj, wn, mc.rms_norm_eps, T, Hd, n, stream));
+    }
     int64_t S = 1;
     if (!comm.active() && tp == 1 && T <= 64 && T <= KD(stream_row_limit()) && Hd <= 2048) {
         S = KD(decode_splitk_slices(T, K, Hd));
@@ -448,7 +488,7 @@ int nvr_model_runner::row_parallel_norm(const uint16_t *x, int64_t K, const uint
 // the norm-prologue kernels; everything else (prefill, tensor-parallel ranks with their all-reduce between GEMM and residual,
 // Qwen3-8B-class weights with their streaming kernels) keeps the six-launch chain.
 bool nvr_model_runner::use_chain4(int64_t T, bool is_prefill) const {
-    return chain4 && !mc.qk_norm && !is_prefill && tp == 1 && !comm.active() && KD(decode_chain_ok(T, Hd, QKV, I, D)) &&
+    return chain4 && !mc.qk_norm && !mc.use_bias && !is_prefill && tp == 1 && !comm.active() && KD(decode_chain_ok(T, Hd, QKV, I, D)) &&
            H * D <= 4096 && I <= 8192 && Hd * std::max(H * D, I) * 2 < (24ll << 20);
 }
 
@@ -541,8 +581,9 @@ int nvr_model_runner::forward(int64_t T, int64_t B, bool is_prefill, int64_t max
                                                k_cache(l), v_cache(l), st, tl ? w.qkv_t : nullptr)));
         } else {
             if (l == 0 && !embed_norm) RC(KD(rmsnorm(h, w.ln1, mc.rms_norm_eps, T, Hd, n, st)));   // later layers: see down_proj
-            if (mc.qk_norm) {                        // A-27: the head norms sit between the projection and RoPE: plain GEMM, then one
+            if (mc.qk_norm || mc.use_bias) {         // A-27: the head norms sit between the projection and RoPE: plain GEMM, then one
                 RC(KD(linear(n, Hd, w.qkv, T, Hd, QKV, qkv, false, st, tl ? w.qkv_t : nullptr)));      // norm + RoPE + KV-store launch
+                if (mc.use_bias) RC(KD(add_bias(qkv, w.qkv_b, T, QKV, st)));                            // A-30: the bias precedes the norms and RoPE (qwen3.rs:208-222)
                 RC(KD(rope_store_kv(qkv, pos, slots, T, H, KVH, D, cos_t, sin_t, k_cache(l), v_cache(l), st, w.q_norm, w.k_norm, mc.rms_norm_eps)));
             } else {
                 // qkv GEMM with the RoPE + KV-store epilogue (K3..K6 in one launch)
@@ -585,7 +626,14 @@ int nvr_model_runner::forward(int64_t T, int64_t B, bool is_prefill, int64_t max
             RC(KD(linear_silu_mul_normed(h, Hd, w.ln2, mc.rms_norm_eps, w.gate_up, T, Hd, I, act, st, tl ? w.gate_up_t : nullptr)));
             RC(KD(linear_resid(act, I, w.down, T, I, Hd, k::decode_splitk_slices(T, I, Hd), slabs, chain_cnt, h, st, tl ? w.down_t : nullptr)));
         } else {
-            RC(row_parallel_norm(attn, H * D, w.o, tl ? w.o_t : nullptr, T, w.ln2));         // o_proj, residual :382, norm :385
+            RC(row_parallel_norm(attn, H * D, w.o, tl ? w.o_t : nullptr, T, w.ln2, w.o_b));  // o_proj, residual :382, norm :385
+            if (mc.use_bias) {                       // A-30: gate_up_proj, its bias, then SiluAndMul on the biased halves (qwen3.rs:305-314)
+                RC(KD(linear(n, Hd, w.gate_up, T, Hd, 2 * I, gu, false, st, tl ? w.gate_up_t : nullptr)));
+                RC(KD(add_bias(gu, w.gate_up_b, T, 2 * I, st)));
+                RC(KD(silu_and_mul(gu, T, I, act, st)));
+                RC(row_parallel_norm(act, I, w.down, tl ? w.down_t : nullptr, T, l + 1 < L ? layers[l + 1].ln1 : norm, w.down_b));
+                continue;
+            }
             if (use_mlp_engine(T, is_prefill)) {
                 // K12 + K13 + K14 in ONE persistent launch (loader / consumer engine, in-launch hand-off of the activations), then the add + norm launch
                 RC(KD(mlp_engine(n, Hd, w.gate_up_t, w.down_t, T, Hd, I, act, slabs, mlp_sync, st)));
@@ -663,14 +711,14 @@ int nvr_model_runner::execute(nvr_seq *const *seqs, size_t nseq, bool is_prefill
         // the free list in order until it has been recycled) token p of a sequence sits at cache row table[0] * bs + p and the kernel runs in
         // its contiguous form (-1.7 ms of a 32 x 1024 prefill); otherwise it walks the block tables like a prefill behind a cached prefix
         // (-0.5 ms).  q/k-norm models keep the qkv buffer (their norm + RoPE launch writes both anyway).
-        prefill_kv_cache = flash_ok && !prefill_paged && !mc.qk_norm;
+        prefill_kv_cache = flash_ok && !prefill_paged && !mc.qk_norm && !mc.use_bias;
         for (size_t b = 0; b < nseq && prefill_kv_cache; ++b) {
             const nvr_seq &sq = *seqs[b];
             const size_t nb = std::min(sq.block_table.size(), (size_t)(((int64_t)sq.len() + bs - 1) / bs));
             for (size_t j = 1; j < nb; ++j)
                 if (sq.block_table[j] != sq.block_table[j - 1] + 1) { prefill_kv_cache = false; break; }
         }
-        if (flash_ok && !prefill_paged && !mc.qk_norm && !prefill_kv_cache) prefill_paged = true;
+        if (flash_ok && !prefill_paged && !mc.qk_norm && !mc.use_bias && !prefill_kv_cache) prefill_paged = true;
         const int qb = flash_ok ? KD(flash_tile_positions((int)H, (int)KVH)) : 1;
         {   // the step's arrays back to back at the start of the arena (sized by THIS step's token count): one upload instead of seven
             size_t o = 0;

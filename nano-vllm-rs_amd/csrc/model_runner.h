@@ -35,7 +35,8 @@ struct nvr_model_runner {
 
     struct Layer { uint16_t *qkv, *o, *gate_up, *down, *ln1, *ln2;
                    uint16_t *qkv_t, *o_t, *gate_up_t, *down_t;      // *_t: tiled copies for the decode kernels (retile_weight), or null
-                   uint16_t *q_norm, *k_norm; };                    // mc.qk_norm: [D] each (ones until loaded), else null
+                   uint16_t *q_norm, *k_norm;                       // mc.qk_norm: [D] each (ones until loaded), else null
+                   uint16_t *qkv_b, *o_b, *gate_up_b, *down_b; };   // mc.use_bias: [QKV] / [Hd] (rank 0, else null) / [2I] / [Hd] (rank 0), else null
     std::vector<Layer> layers;
     uint16_t *embed = nullptr, *lm_head = nullptr, *norm = nullptr;
     uint16_t *lm_head_t = nullptr;         // tiled copy of the LM head (decode-sized steps)
@@ -117,7 +118,7 @@ struct nvr_model_runner {
 private:
     int forward(int64_t T, int64_t B, bool is_prefill, int64_t max_ctx);
     int gen_weights();
-    int row_parallel_norm(const uint16_t *x, int64_t K, const uint16_t *W, const uint16_t *Wt, int64_t T, const uint16_t *wn);
+    int row_parallel_norm(const uint16_t *x, int64_t K, const uint16_t *W, const uint16_t *Wt, int64_t T, const uint16_t *wn, const uint16_t *bias = nullptr);
     bool use_chain4(int64_t T, bool is_prefill) const;
     int64_t *h_tok_dev = nullptr;                        // device-visible address of the pinned token buffer h_tok
     int64_t slab_rows = 64;           // rows the split-k slab buffers hold (row_parallel_norm)

@@ -677,6 +677,7 @@ int nvr_attn_prefill_paged(const nvr_half *q, int64_t ldq, const nvr_half *kc, c
     NVR_GUARD_END(NVR_ERR_INVARIANT)
 }
 int nvr_silu_and_mul(const nvr_half *x, int64_t T, int64_t I, nvr_half *out, void *s) { return KO(silu_and_mul(x, T, I, out, (hipStream_t)s)); }
+int nvr_add_bias(nvr_half *y, const nvr_half *b, int64_t T, int64_t N, void *s) { return KO(add_bias(y, b, T, N, (hipStream_t)s)); }
 int nvr_select_last_tokens(const nvr_half *h, const int32_t *cu, int64_t B, int64_t Hd, nvr_half *out, void *s) {
     return KO(select_last_tokens(h, cu, B, Hd, out, (hipStream_t)s));
 }

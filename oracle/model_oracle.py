@@ -32,6 +32,7 @@ from . import engine_oracle as eo
 # tensor ids of the synthetic weight generator (shared with the product:
 # nano-vllm-rs_amd/csrc/weights.h)
 TID_QKV, TID_O, TID_GATE_UP, TID_DOWN = 0, 1, 2, 3
+TID_BIAS = 4                                  # + tensor id: the bias of that projection (use_bias)
 TID_EMBED, TID_LM_HEAD = 1 << 20, (1 << 20) + 1
 
 
@@ -55,6 +56,10 @@ class ModelConfig:
     # checkpoints carry self_attn.q_norm / k_norm, an RMSNorm over head_dim on every q and k head between the projection and
     # RoPE.  They are restated with the reference's own RMSNorm::forward_simple (layernorm.rs:58-75) and rms_norm_eps.
     qk_norm: bool = False
+    # Qwen3Config::use_bias (qwen3.rs:54-55,82: default false): a bias on the four projections of a layer — qkv_proj :167, o_proj :178,
+    # gate_up_proj :276, down_proj :287; the row-parallel ones hold it on rank 0 only (linear.rs:206).  A-30: candle_nn::Linear::forward is a
+    # matmul and a broadcast_add, two tensor ops, so the 16-bit modes round the product and then the sum (x·Wᵀ -> 16 bit, + b -> 16 bit).
+    use_bias: bool = False
 
     def hd(self) -> int:                       # qwen3.rs:101-103
         return self.head_dim if self.head_dim else self.hidden_size // self.num_attention_heads
@@ -166,6 +171,14 @@ class OracleModel:
             # down_proj row-parallel: global [Hd, I], columns sharded
             d = fill_w(Hd, self.I, Ig, 0, r * self.I, key(TID_DOWN), sc, f16)
             W = _CompactLayer() if self.compact else {}
+            if c.use_bias:
+                # one value per output feature, generated like a one-column weight (row = the GLOBAL output row: shards take their slices)
+                bias = lambda rows, row0, tid: fill_w(rows, 1, 1, row0, 0, key(TID_BIAS + tid), sc, f16).reshape(rows)
+                W["qkv_b"] = np.concatenate([bias(self.H * D, r * self.H * D, TID_QKV), bias(self.KVH * D, Hg * D + r * self.KVH * D, TID_QKV),
+                                             bias(self.KVH * D, (Hg + KVHg) * D + r * self.KVH * D, TID_QKV)])
+                W["gate_up_b"] = np.concatenate([bias(self.I, r * self.I, TID_GATE_UP), bias(self.I, Ig + r * self.I, TID_GATE_UP)])
+                W["o_b"] = bias(Hd, 0, TID_O) if r == 0 else None             # linear.rs:206: only rank 0 has the bias
+                W["down_b"] = bias(Hd, 0, TID_DOWN) if r == 0 else None
             for name, val in dict(qkv=np.concatenate([q, k, v], 0), o=o, gate_up=np.concatenate([g, u], 0), down=d,
                                   ln1=np.ones(Hd, np.float32), ln2=np.ones(Hd, np.float32),
                                   q_norm=np.ones(D, np.float32), k_norm=np.ones(D, np.float32)).items():
@@ -246,11 +259,34 @@ class OracleModel:
                     W["gate_up"][I:] = w[Ig + r * I:Ig + (r + 1) * I]
                 elif rest == "mlp.down_proj.weight":
                     W["down"] = np.ascontiguousarray(want(a, (Hd, Ig), full)[:, r * I:(r + 1) * I])
+                elif c.use_bias and rest.endswith(".bias"):
+                    if rest == "self_attn.q_proj.bias":
+                        W["qkv_b"][:H * D] = want(a, (Hg * D,), full)[r * H * D:(r + 1) * H * D]
+                    elif rest == "self_attn.k_proj.bias":
+                        W["qkv_b"][H * D:(H + KVH) * D] = want(a, (KVHg * D,), full)[r * KVH * D:(r + 1) * KVH * D]
+                    elif rest == "self_attn.v_proj.bias":
+                        W["qkv_b"][(H + KVH) * D:] = want(a, (KVHg * D,), full)[r * KVH * D:(r + 1) * KVH * D]
+                    elif rest == "self_attn.o_proj.bias":
+                        if r == 0: W["o_b"] = want(a, (Hd,), full)
+                    elif rest == "mlp.gate_proj.bias":
+                        W["gate_up_b"][:I] = want(a, (Ig,), full)[r * I:(r + 1) * I]
+                    elif rest == "mlp.up_proj.bias":
+                        W["gate_up_b"][I:] = want(a, (Ig,), full)[r * I:(r + 1) * I]
+                    elif rest == "mlp.down_proj.bias":
+                        if r == 0: W["down_b"] = want(a, (Hd,), full)
+                    else:
+                        skipped.append(full)
                 else:
                     skipped.append(full)
             else:
                 skipped.append(full)
         return skipped
+
+    def _lin(self, x: np.ndarray, W: dict, name: str) -> np.ndarray:
+        """candle_nn::Linear::forward (linear.rs:12-24 wraps it): x·Wᵀ, then + bias when the layer has one (A-30: two tensor ops, two roundings)."""
+        y = self._r(linear(x, W[name]))
+        b = W.get(name + "_b") if self.cfg.use_bias else None
+        return y if b is None else self._add(y, np.broadcast_to(b, y.shape).copy())
 
     def _r(self, x: np.ndarray) -> np.ndarray:
         return round_bf16(x) if self.bf16 else (round_f16(x) if self.fp16 else x)
@@ -263,7 +299,7 @@ class OracleModel:
         """input_layernorm -> qkv -> rope -> store -> attention -> o_proj partial (qwen3.rs:208-240,378-381)."""
         W = self.layers[l]
         n = self._r(rmsnorm(h, W["ln1"], self.cfg.rms_norm_eps))
-        qkv = self._r(linear(n, W["qkv"]))
+        qkv = self._lin(n, W, "qkv")
         T = h.shape[0]
         qd, kd = self.H * self.D, self.KVH * self.D
         q = qkv[:, :qd].reshape(T, self.H, self.D)                       # split_qkv linear.rs:331-340
@@ -283,15 +319,15 @@ class OracleModel:
             a = attn_paged(q, cu, self.k_cache[l], self.v_cache[l], meta["block_tables"],
                            meta["context_lens"], self.scale)             # attention.rs:211-235
         a = self._r(a).reshape(T, qd)
-        return self._r(linear(a, W["o"]))
+        return self._lin(a, W, "o")
 
     def mlp_part(self, l: int, h: np.ndarray) -> np.ndarray:
         """post_attention_layernorm -> gate_up -> SiluAndMul -> down partial (qwen3.rs:305-314,385-388)."""
         W = self.layers[l]
         n = self._r(rmsnorm(h, W["ln2"], self.cfg.rms_norm_eps))
-        gu = self._r(linear(n, W["gate_up"]))
+        gu = self._lin(n, W, "gate_up")
         act = self._r(silu_and_mul(gu))
-        return self._r(linear(act, W["down"]))
+        return self._lin(act, W, "down")
 
     def head_part(self, h: np.ndarray, meta: dict) -> np.ndarray:
         """final norm + last-token select + LM head shard (qwen3.rs:501-504, embed_head.rs:250-306)."""

@@ -31,7 +31,7 @@ def _model_cfgs(mcfg: mo.ModelConfig):
                         head_dim=mcfg.head_dim or 0, max_position_embeddings=mcfg.max_position_embeddings,
                         rms_norm_eps=mcfg.rms_norm_eps, rope_theta=mcfg.rope_theta,
                         tie_word_embeddings=mcfg.tie_word_embeddings, init_std=mcfg.init_std, seed=mcfg.seed,
-                        qk_norm=mcfg.qk_norm)
+                        qk_norm=mcfg.qk_norm, use_bias=mcfg.use_bias)
     return m
 
 
@@ -818,6 +818,62 @@ def test_qk_norm_checkpoint_end_to_end(tmp_path, shape):
         assert sorted(p.model_runner.load_safetensors(path)) == sorted(sd)
     with pytest.raises(nvr.NvrError):
         p.model_runner.load_safetensors(path, strict=True)
+
+
+@pytest.mark.parametrize("shape,dtype", [("small", "float16"), ("gqa2_d128", "float16"), ("small", "bfloat16")])
+def test_use_bias_engine_parity_and_checkpoint(tmp_path, shape, dtype):
+    """A-30: Qwen3Config::use_bias (qwen3.rs:54-55; qkv_proj :167, o_proj :178, gate_up_proj :276, down_proj :287).  candle's Linear is
+    matmul, then broadcast_add — y = 16bit(16bit(x W^T) + b) —, so the product's use_bias graph runs plain GEMMs with a bias launch
+    behind each (and SiluAndMul as its own launch on the biased halves).  Synthetic biases (generated like weights, keyed
+    TID_BIAS + projection) and a checkpoint with *.bias tensors both run in parity with the oracle, graph and eager agree, the
+    bias really changes the tokens, and without the flag the bias tensors are refused."""
+    from safetensors.numpy import save_file
+    kw = {} if shape == "small" else dict(hidden_size=512, num_attention_heads=4, num_key_value_heads=2, head_dim=128, intermediate_size=768)
+    mcfg = mo.small(seed=11, use_bias=True, **kw)
+    V, L = mcfg.vocab_size, mcfg.num_hidden_layers
+    ecfg = dict(max_num_seqs=4, max_num_batched_tokens=256, max_model_len=128, kvcache_block_size=16, num_kvcache_blocks=40)
+    prompts = [oracle.fill_tokens(n, 8, i, V).tolist() for i, n in enumerate([23, 70, 5])]
+    sps = [dict(temperature=0.0, max_tokens=14, ignore_eos=True)] * 3
+    r = _run_pair(mcfg, ecfg, prompts, sps, dtype=dtype)
+    assert r["near_ties"] <= 2 and r["decode_steps"] >= 13, r
+    e = _run_pair(mcfg, ecfg, prompts, sps, enforce_eager=True, dtype=dtype)
+    assert e["finished"] == r["finished"]
+    plain = _run_pair(mo.small(seed=11, **kw), ecfg, prompts, sps, dtype=dtype)
+    assert plain["finished"] != r["finished"]
+    if dtype != "float16":
+        return
+    # a checkpoint's biases (HF names, separate q / k / v and gate / up), mixed dtypes
+    rng = np.random.default_rng(79)
+    D, H, KVH, Hd, I = mcfg.hd(), mcfg.num_attention_heads, mcfg.num_key_value_heads, mcfg.hidden_size, mcfg.intermediate_size
+    sd = {}
+    for l in range(L):
+        pre = f"model.layers.{l}."
+        sd[pre + "self_attn.q_proj.bias"] = (0.1 * rng.standard_normal(H * D)).astype(np.float16)
+        sd[pre + "self_attn.k_proj.bias"] = (0.1 * rng.standard_normal(KVH * D)).astype(np.float32)
+        sd[pre + "self_attn.v_proj.bias"] = (0.1 * rng.standard_normal(KVH * D)).astype(np.float16)
+        sd[pre + "self_attn.o_proj.bias"] = (0.05 * rng.standard_normal(Hd)).astype(np.float16)
+        sd[pre + "mlp.gate_proj.bias"] = (0.1 * rng.standard_normal(I)).astype(np.float16)
+        sd[pre + "mlp.up_proj.bias"] = (0.1 * rng.standard_normal(I)).astype(np.float32)
+        sd[pre + "mlp.down_proj.bias"] = (0.05 * rng.standard_normal(Hd)).astype(np.float16)
+    path = str(tmp_path / "bias.safetensors")
+    save_file(sd, path)
+    c = _run_pair(mcfg, ecfg, prompts, sps, checkpoint=(sd, path))
+    assert c["near_ties"] <= 2 and c["finished"] != r["finished"], c
+    # what landed: the packed local biases are the checkpoint's values in the runner's type
+    nvr.lib().nvr_seq_reset_id_counter()
+    p = nvr.LLMEngine(nvr.Config(skip_block_size_check=1, **ecfg), _model_cfgs(mcfg))
+    assert p.model_runner.load_safetensors(path, strict=True) == []
+    qkv_b = p.model_runner.weight("layers.1.qkv_b")
+    want = np.concatenate([sd["model.layers.1.self_attn.q_proj.bias"].astype(np.float16), sd["model.layers.1.self_attn.k_proj.bias"].astype(np.float16),
+                           sd["model.layers.1.self_attn.v_proj.bias"]])
+    assert np.array_equal(qkv_b, want)
+    assert np.array_equal(p.model_runner.weight("layers.0.down_b"), sd["model.layers.0.mlp.down_proj.bias"])
+    with pytest.raises(nvr.NvrError):
+        p.model_runner.load_tensor("model.layers.0.mlp.down_proj.bias", np.zeros(Hd + 8, np.float16))
+    # the reference's default graph (use_bias false) has no such parameters
+    q = nvr.LLMEngine(nvr.Config(skip_block_size_check=1, **ecfg), _model_cfgs(mo.small(seed=11, **kw)))
+    with pytest.warns(RuntimeWarning):
+        assert sorted(q.model_runner.load_safetensors(path)) == sorted(sd)
 
 
 @pytest.mark.parametrize("shape", ["d64_g2", "d128_g2"])

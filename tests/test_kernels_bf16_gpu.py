@@ -276,3 +276,14 @@ def test_lm_head_logits_and_argmax_partials(T, K, N):
     want = np.asarray([oracle.argmax(y[t]) for t in range(T)])
     assert d_tok.to_numpy((T,), np.int64).tolist() == want.tolist() and want[0] == 5
     assert np.array_equal(d_val.to_numpy((T,), np.float32), y[np.arange(T), want])
+
+
+def test_add_bias_bf16():
+    """A-30 in bfloat16: y <- bf16(y + b), exact against the oracle's rounding."""
+    rng = np.random.default_rng(41)
+    T, N = 33, 1024
+    y, yb = b16(rng.standard_normal((T, N)) * 3)
+    b, bb = b16(rng.standard_normal(N))
+    d_y = dev(yb)
+    nvr.check(nvr.lib().nvr_add_bias(d_y.ptr, dev(bb).ptr, T, N, None))
+    assert np.array_equal(out16(d_y, (T, N)), oracle.round_bf16(y + b[None, :]))

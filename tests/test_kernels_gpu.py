@@ -292,6 +292,18 @@ def test_attn_prefill_varlen(H, KVH, D, lens):
     assert_close_f16(d_out.to_numpy((T, H, D), F16), ref, ulps=2, atol=2e-3, what="varlen prefill attention")
 
 
+@pytest.mark.parametrize("T,N", [(1, 8), (7, 2560), (300, 3072)])
+def test_add_bias_is_the_second_rounding_of_a_linear_with_bias(T, N):
+    """nvr_add_bias (A-30): y <- fp16(y + b) in place, bit for bit the oracle's add of the already-rounded matmul result."""
+    rng = np.random.default_rng(40 + T)
+    y, yb = h16(rng.standard_normal((T, N)) * 3)
+    b, bb = h16(rng.standard_normal(N))
+    d_y = dev(yb)
+    nvr.check(nvr.lib().nvr_add_bias(d_y.ptr, dev(bb).ptr, T, N, None))
+    assert np.array_equal(d_y.to_numpy((T, N), F16), oracle.add(y, np.broadcast_to(b, y.shape).copy(), round16=True).astype(F16))
+    assert nvr.lib().nvr_add_bias(d_y.ptr, dev(bb).ptr, T, 12, None) == -10
+
+
 # ------------------------------------------------------------------------------------------- K13 / K15
 def test_silu_and_mul():
     rng = np.random.default_rng(10)

@@ -391,3 +391,33 @@ def test_round_bf16_matches_torch_and_the_oracle_bf16_mode_rounds_everywhere():
                 assert np.array_equal(w, oracle.round_bf16(w))
     d = np.abs(outs["fp16"] - outs["bf16"]).max()
     assert 1e-5 < d < 5e-2, d
+
+
+def test_use_bias_is_off_by_default_and_follows_the_reference_sharding():
+    """A-30: Qwen3Config::use_bias (qwen3.rs:54-55, default false :82).  With it on, the oracle adds a bias after each of the four
+    projections as a second rounded op (candle_nn::Linear: matmul, then broadcast_add); on tensor-parallel ranks the column-parallel
+    biases are slices of the global vector and the row-parallel ones exist on rank 0 only (linear.rs:206), so that the all-reduced
+    sum carries the bias once: the two-rank partial sums add up to the single-rank projection."""
+    from oracle import model_oracle as mo
+    assert not mo.qwen3_0_6b().use_bias and not mo.qwen3_8b().use_bias and not mo.tiny().use_bias
+    ids = np.asarray([5, 9, 200, 31], np.int64)
+    meta = lambda: dict(is_prefill=True, cu_seqlens_q=np.asarray([0, 4], np.int32), slot_mapping=np.arange(4, dtype=np.int32),
+                        block_tables=None, context_lens=None)
+    pos = np.arange(4, dtype=np.int64)
+    one = mo.OracleModel(mo.tiny(use_bias=True), num_blocks=2, block_size=16, fp16=False, max_pos=64)
+    off = mo.OracleModel(mo.tiny(), num_blocks=2, block_size=16, fp16=False, max_pos=64)
+    h = one.embed_tokens(ids)
+    full = one.attn_part(0, h, pos, meta())
+    assert np.abs(full - off.attn_part(0, h, pos, meta())).max() > 1e-3
+    ranks = [mo.OracleModel(mo.tiny(use_bias=True), num_blocks=2, block_size=16, fp16=False, max_pos=64, tp_size=2, tp_rank=r) for r in range(2)]
+    assert ranks[1].layers[0]["o_b"] is None and ranks[1].layers[0]["down_b"] is None and ranks[0].layers[0]["o_b"] is not None
+    np.testing.assert_array_equal(np.concatenate([ranks[0].layers[0]["gate_up_b"][:ranks[0].I], ranks[1].layers[0]["gate_up_b"][:ranks[1].I]]),
+                                  one.layers[0]["gate_up_b"][:one.I])
+    parts = sum(r.attn_part(0, h, pos, meta()) for r in ranks)
+    np.testing.assert_allclose(parts, full, rtol=2e-5, atol=2e-6)
+    # checkpoint names
+    sd = {"model.layers.0.mlp.down_proj.bias": np.arange(one.Hd, dtype=np.float32) * 1e-3,
+          "model.layers.1.self_attn.q_proj.bias": np.ones(one.H * one.D, np.float32)}
+    assert one.load_state_dict(sd) == [] and sorted(off.load_state_dict(sd)) == sorted(sd)
+    assert np.array_equal(one.layers[0]["down_b"], sd["model.layers.0.mlp.down_proj.bias"])
+    assert np.array_equal(one.layers[1]["qkv_b"][:one.H * one.D], np.ones(one.H * one.D, np.float32))

@@ -168,7 +168,7 @@ def _tp_ranks_vs_oracle(tp, m, ecfg, prompts, sps, product_kw=None, min_steps=5,
                          num_hidden_layers=m.num_hidden_layers, num_attention_heads=m.num_attention_heads,
                          num_key_value_heads=m.num_key_value_heads, head_dim=m.head_dim, max_position_embeddings=m.max_position_embeddings,
                          rms_norm_eps=m.rms_norm_eps, rope_theta=m.rope_theta, tie_word_embeddings=m.tie_word_embeddings,
-                         init_std=m.init_std, seed=m.seed, qk_norm=m.qk_norm)
+                         init_std=m.init_std, seed=m.seed, qk_norm=m.qk_norm, use_bias=m.use_bias)
     temps = [sp["temperature"] for sp in sps]
     product_kw = product_kw or {}
     group = nvr.LocalGroup(tp, p2p=p2p)
@@ -270,10 +270,11 @@ def test_bfloat16_tensor_parallel_ranks_match_the_bf16_oracle(tp, p2p, temps):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("feature", ["qk_norm", "shared_prefix"])
+@pytest.mark.parametrize("feature", ["qk_norm", "shared_prefix", "use_bias"])
 def test_tensor_parallel_ranks_with_r02_graph_extensions(feature):
-    """The r02 graph extensions on tensor-parallel ranks (tp = 2, in-process): q/k head norms (norm weights replicated, heads
-    sharded) and the shared-prefix decode attention pass (every rank sees the same block tables, so every rank takes it)."""
+    """The graph extensions on tensor-parallel ranks (tp = 2, in-process): q/k head norms (norm weights replicated, heads
+    sharded), the shared-prefix decode attention pass (every rank sees the same block tables, so every rank takes it) and the
+    projections' biases (use_bias)."""
     import oracle
     from oracle import model_oracle as mo
     V = 1024
@@ -283,6 +284,13 @@ def test_tensor_parallel_ranks_with_r02_graph_extensions(feature):
         prompts = [oracle.fill_tokens(n, 5, i, V).tolist() for i, n in enumerate([9, 40, 17])]
         sps = [dict(temperature=0.0, max_tokens=10, ignore_eos=True)] * 3
         assert _tp_ranks_vs_oracle(2, m, ecfg, prompts, sps) == {0}
+    elif feature == "use_bias":                 # A-30: column-parallel biases are sharded with their rows, row-parallel ones live on rank 0 (linear.rs:206)
+        m = mo.small(seed=12, num_attention_heads=8, num_key_value_heads=4, head_dim=64, hidden_size=256, intermediate_size=512, use_bias=True)
+        ecfg = dict(max_num_seqs=4, max_num_batched_tokens=256, max_model_len=128, kvcache_block_size=16, num_kvcache_blocks=24)
+        prompts = [oracle.fill_tokens(n, 5, i, V).tolist() for i, n in enumerate([9, 40, 17])]
+        sps = [dict(temperature=0.0, max_tokens=10, ignore_eos=True)] * 3
+        assert _tp_ranks_vs_oracle(2, m, ecfg, prompts, sps) == {0}
+        assert _tp_ranks_vs_oracle(2, m, ecfg, prompts, sps, p2p=False) == {0}
     else:
         m = mo.small(seed=8, num_attention_heads=8, num_key_value_heads=4, head_dim=64, hidden_size=256, intermediate_size=512)
         ecfg = dict(max_num_seqs=8, max_num_batched_tokens=2048, max_model_len=384, kvcache_block_size=64, num_kvcache_blocks=40)
