@@ -101,6 +101,31 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(const half_t *__restric
 #pragma unroll
         for (int j = 0; j < MT; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
 
+    // TEPI_ROPE on the 32- / 64-token tiles (decode batches of 65..~1000 rows: one wave of workgroups, every microsecond of the tile is a
+    // microsecond of the launch): the epilogue's inputs arrive UNDER the K loop instead of as three dependent round trips behind it
+    // (position -> cos / sin row -> rotate; cache slot -> store: 15.9 us against 10.95 for the same GEMM with a plain epilogue, T = 512,
+    // profiles/r04_mid_batch_gemm.txt).  Positions and slots are requested here, in front of the first operand tile; the cos / sin
+    // pieces in K-step 0, once the positions are in (they are older than the tile that step has just waited for).
+    constexpr bool PRE = EPI == TEPI_ROPE && MT <= 2;
+    constexpr int NWO = (BMt * 16) / 256;                                 // write-out rounds of the epilogue: round i stores row i*16 + tid/16
+    int64_t pre_pos[MT];
+    int pre_slot[NWO];
+    float4_t pre_cs[MT][4], pre_sn[MT][4];
+    const int rope_head = PRE ? (int)(blockIdx.x * 8 + wn * 4) / (epi.D / 16) : 0;    // the head of this wave's four n-tiles (16 | D)
+    const bool rope_rot = PRE && rope_head < epi.H + epi.KVH;
+    if (PRE) {
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+            // (as inline asm: a compiler-visible load whose first use sits in the K loop makes hipcc drain vmcnt(0) there, operand tiles in
+            //  flight included; the value is complete once K-step 0 has waited for its tile, which is younger — see the pin there)
+            const int m = m0 + wm * (16 * MT) + j * 16 + r;
+            const int64_t *src = epi.pos + (m < T ? m : T - 1);
+            asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(pre_pos[j]) : "v"(src) : "memory");
+        }
+#pragma unroll
+        for (int i = 0; i < NWO; ++i) { const int m = m0 + i * 16 + (int)(threadIdx.x >> 4); pre_slot[i] = (epi.slots && m < T) ? epi.slots[m] : -1; }
+    }
+
     const int KT = (EPI == TEPI_SLAB ? epi.kslice : K) / BK;
     if (NS == 2) {
         stage(0, 0);
@@ -116,12 +141,28 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(const half_t *__restric
         } else {
             // K-tile kt has landed once at most the 4 + MT loads per thread of each younger K-tile in flight are outstanding
             const int younger = min(NS - 2, KT - 1 - kt);
-            if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (4 + MT)) : "memory");
+            // (K-step 1 of a rotating TEPI_ROPE wave: the 8 * MT cos / sin requests of K-step 0 are younger than the two tiles that may stay in
+            //  flight and may stay in flight with them; later steps find them landed)
+            if (PRE && kt == 1 && rope_rot && younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (4 + MT) + 8 * MT) : "memory");
+            else if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (4 + MT)) : "memory");
             else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + MT) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                                 // every thread's pieces are in; buffer (kt-1) % NS is free
             cur = kt % NS;
             if (kt + NS - 1 < KT) stage((kt + NS - 1) % NS, (kt + NS - 1) * BK);
+        }
+        if (PRE && kt == 0 && rope_rot) {
+            const int tph = epi.D / 16, half_d = epi.D / 2;
+#pragma unroll
+            for (int j = 0; j < MT; ++j) asm volatile("" : "+v"(pre_pos[j]));   // uses stay behind this step's counted wait (volatile asm keeps its order)
+#pragma unroll
+            for (int j = 0; j < MT; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int jj = ((int)(blockIdx.x * 8 + wn * 4 + i) % tph) * 8 + (q & 1) * 4;
+                    pre_cs[j][i] = *reinterpret_cast<const float4_t *>(epi.cos_t + pre_pos[j] * half_d + jj);
+                    pre_sn[j][i] = *reinterpret_cast<const float4_t *>(epi.sin_t + pre_pos[j] * half_d + jj);
+                }
         }
         const char *a_lds = smem + cur * BUF, *b_lds = a_lds + BN * BK * 2;
 #pragma unroll
@@ -228,7 +269,7 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(const half_t *__restric
             }
         } else {                                                          // TEPI_ROPE
             const int tph = epi.D / 16, half_d = epi.D / 2;
-            const int64_t p = epi.pos[mc];
+            const int64_t p = PRE ? pre_pos[j] : epi.pos[mc];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int g = blockIdx.x * 8 + wn * 4 + i, head = g / tph, c = g % tph;
@@ -239,8 +280,8 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(const half_t *__restric
                 half4_t h; int col;
                 if (head < epi.H + epi.KVH) {
                     const int jj = c * 8 + (q & 1) * 4;
-                    const float4_t cs = *reinterpret_cast<const float4_t *>(epi.cos_t + p * half_d + jj);
-                    const float4_t sn = *reinterpret_cast<const float4_t *>(epi.sin_t + p * half_d + jj);
+                    const float4_t cs = PRE ? pre_cs[j][i] : *reinterpret_cast<const float4_t *>(epi.cos_t + p * half_d + jj);
+                    const float4_t sn = PRE ? pre_sn[j][i] : *reinterpret_cast<const float4_t *>(epi.sin_t + p * half_d + jj);
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         h[e] = (q < 2) ? to_half_rn(__fsub_rn(__fmul_rn(v[e], cs[e]), __fmul_rn(pv[e], sn[e])))
@@ -270,7 +311,7 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(const half_t *__restric
         if (EPI == TEPI_ROPE) {
             const int head = col / epi.D;
             if (head >= epi.H) {
-                const int slot = epi.slots ? epi.slots[m] : -1;
+                const int slot = PRE ? pre_slot[i] : (epi.slots ? epi.slots[m] : -1);
                 if (slot >= 0) {
                     const bool is_k = head < epi.H + epi.KVH;
                     const int kvh = is_k ? head - epi.H : head - epi.H - epi.KVH;
