@@ -1,0 +1,16 @@
+"""Build-time guard of the kernels whose LDS-DMA requests and vmcnt waits are hand-written: the generated gfx950 ISA of
+every flash_prefill_kernel instantiation has no spills / scratch traffic, no compiler-visible vector-memory instruction inside the
+MFMA blocks of the step loop, and only the hand-written counted waits there.  Needs hipcc (cross-compiles without a GPU)."""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+@pytest.mark.skipif(not os.path.exists(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")), reason="hipcc not installed")
+def test_flash_prefill_isa_keeps_the_hand_counted_ring_intact():
+    import check_kernel_isa
+    assert check_kernel_isa.check_flash(verbose=False) == []
