@@ -13,7 +13,7 @@ The oracle is teacher-forced with the product's tokens so a tie cannot cascade.
               config.rs:58) + one decode step; and 256 sequences x 200 tokens over two budget batches with chunked prefill on
   configs[3]  Qwen3-8B (36 layers, V = 151 936) on one GPU: product vs oracle at full depth on a reduced batch (2 x 256 + 3 decode
               steps), and the full 32 x 2048 workload as in-process tensor-parallel ranks (tp 8) against the single-rank product
-A JSON summary of what was measured lands in gpurun_out/parity_r03.json (copied to profiles/ by hand)."""
+A JSON summary of what was measured lands in gpurun_out/parity_r04.json (copied to profiles/ by hand)."""
 import json
 import os
 import time
@@ -41,7 +41,7 @@ def _report(name, rec):
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     try:
         os.makedirs(out, exist_ok=True)
-        path = os.path.join(out, "parity_r03.json")
+        path = os.path.join(out, "parity_r04.json")
         cur = json.load(open(path)) if os.path.exists(path) else {}
         cur[name] = rec
         json.dump(cur, open(path, "w"), indent=1, sort_keys=True)
