@@ -212,8 +212,8 @@ def shared_prefix_decode(nvr, mc, nseq: int = 512, steps: int = 24) -> dict:
     return out
 
 
-MODELS = {"qwen3-0.6b": dict(batch=32, prompt_len=1024, label="Qwen3-0.6B", baseline_config=1),
-          "qwen3-8b": dict(batch=32, prompt_len=2048, label="Qwen3-8B", baseline_config=3)}
+MODELS = {"qwen3-0.6b": dict(batch=32, prompt_len=1024, label="Qwen3-0.6B", baseline_config=1, shape=dict(h=16, kvh=8, d=128, layers=28)),
+          "qwen3-8b": dict(batch=32, prompt_len=2048, label="Qwen3-8B", baseline_config=3, shape=dict(h=32, kvh=8, d=128, layers=36))}
 
 
 def prefill_flops(c, lens) -> float:
@@ -348,6 +348,95 @@ def prefill_recycled(nvr, preset: str = "qwen3-0.6b") -> dict:
     return out
 
 
+def _pmc_child(model: str, counters, steps: int, warm: int, timeout_s: float = 240.0):
+    """One counter pass of this workload in a CHILD process: `rocprofv3 --kernel-trace --pmc <counters> -- python3 bench.py ...` with nothing but
+    --kernel-trace beside --pmc (MI355X_MICROARCH.md: counters in their own run), eager synchronous decode steps (every launch its own
+    dispatch), started BEFORE this process touches the GPU.  Returns the rows of the counter table (dicts) or a string saying why not."""
+    import csv, glob, shutil, subprocess, tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return "rocprofv3 not found"
+    if any(k.startswith("ROCPROF") or k.startswith("ROCP_") for k in os.environ):
+        return "this process already runs under a profiler"
+    out = tempfile.mkdtemp(prefix="nvr_pmc_", dir="/tmp")
+    cmd = [exe, "--kernel-trace", "--pmc", *counters, "--output-format", "csv", "-d", out, "-o", "pmc", "--",
+           sys.executable, os.path.abspath(__file__), "--steps", str(steps), "--warmup", str(warm), "--model", model, "--no-cpu-baseline", "--no-chain",
+           "--no-shared-prefix", "--no-configs3", "--no-prefill-sweep", "--no-batch-sweep", "--no-default-engine", "--sync-decode", "--eager",
+           "--no-live-pmc", "--attn-reps", "1"]
+    try:
+        r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout_s)
+        files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+        if r.returncode != 0 or not files:
+            return f"counter pass failed (rc {r.returncode})"
+        return list(csv.DictReader(open(files[0])))
+    except subprocess.TimeoutExpired:
+        return "counter pass timed out"
+    except Exception as ex:                                                      # noqa: BLE001
+        return f"counter pass: {str(ex)[:120]}"
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+
+
+def live_pmc_attention(model: str):
+    """HBM traffic of the dominant kernel counted IN THIS RUN (FETCH_SIZE pass).  gfx950: FETCH_SIZE counts KiB at 64 B per 128-byte
+    request of a 16-B-per-lane streaming read -> bytes = FETCH_SIZE * 1024 * 2.  Returns a dict or a string saying why there is no live
+    number (the committed pass under profiles/ is quoted then)."""
+    import statistics
+    steps, warm = 6, 2
+    rows = _pmc_child(model, ["FETCH_SIZE"], steps, warm)
+    if isinstance(rows, str):
+        return rows
+    vals = [float(r["Counter_Value"]) for r in rows if r.get("Counter_Name") == "FETCH_SIZE" and "attn_rows_kernel" in r.get("Kernel_Name", "")]
+    m = MODELS[model]
+    mc = m["shape"]
+    # dispatches of the pass: n = warm + steps engine decode steps at contexts P+1 .. P+n (one launch per layer each), then the 2 x layers
+    # launches of the live kernel timing at the final context P+n+1: mean FETCH_SIZE over ALL of them against their mean algorithmic bytes
+    n, P, L = warm + steps, m["prompt_len"], mc["layers"]
+    if len(vals) != L * (n + 2):
+        return f"counter pass saw {len(vals)} attention dispatches, expected {L * (n + 2)}"
+    kib = statistics.fmean(vals)
+    ctx = (n * P + n * (n + 1) / 2.0 + 2 * (P + n + 1)) / (n + 2)
+    alg = m["batch"] * ctx * mc["kvh"] * mc["d"] * 2 * 2 + 2 * m["batch"] * mc["h"] * mc["d"] * 2
+    return {"fetch_size_kib_mean": round(kib, 1), "dispatches": len(vals), "hbm_bytes_per_launch": int(kib * 1024 * 2),
+            "algorithmic_bytes_per_launch": int(alg), "traffic_over_algorithmic": round(kib * 1024 * 2 / alg, 4), "mean_context": round(ctx, 2)}
+
+
+def live_pmc_prefill(model: str):
+    """Matrix-pipe busy share of the measured prefill step counted IN THIS RUN: SQ_VALU_MFMA_BUSY_CYCLES (16 cycles per 16x16x32 MFMA, summed
+    over the SIMDs) against GRBM_GUI_ACTIVE (summed over the 8 XCDs: cycles = GRBM / 8) per dispatch: busy = BUSY / (1024 SIMDs x cycles).
+    The step = the dispatches from the last prefill embedding launch to the first decode step.  Returns a dict or a string."""
+    import collections
+    rows = _pmc_child(model, ["SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"], 1, 0)
+    if isinstance(rows, str):
+        return rows
+    disp = collections.OrderedDict()
+    for r in sorted(rows, key=lambda r: int(r["Dispatch_Id"])):
+        d = disp.setdefault(r["Dispatch_Id"], {"name": r["Kernel_Name"]})
+        d[r["Counter_Name"]] = float(r["Counter_Value"])
+    ds = list(disp.values())
+    emb = [i for i, d in enumerate(ds) if "embedding_kernel" in d["name"]]
+    if not emb:
+        return "no prefill step in the counter pass"
+    step = []
+    for d in ds[emb[-1]:]:
+        if "embed_rmsnorm" in d["name"]:
+            break
+        step.append(d)
+    agg = collections.OrderedDict()
+    for d in step:
+        nm = d["name"].split("(")[0]
+        for tag in ("gemm256_kernelILi2", "gemm256_kernelILi3", "gemm256_kernelILi1", "flash_prefill_kernel", "rmsnorm_kernel"):
+            if tag in nm:
+                a = agg.setdefault(tag, [0.0, 0.0, 0]); a[0] += d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0); a[1] += d.get("GRBM_GUI_ACTIVE", 0.0) / 8; a[2] += 1
+    busy = sum(d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) for d in step); cyc = sum(d.get("GRBM_GUI_ACTIVE", 0.0) / 8 for d in step)
+    if cyc <= 0:
+        return "no cycles counted"
+    names = {"gemm256_kernelILi2": "gate_up+SiLU", "gemm256_kernelILi3": "qkv+RoPE+store", "gemm256_kernelILi1": "o / down + residual",
+             "flash_prefill_kernel": "flash_prefill", "rmsnorm_kernel": "rmsnorm"}
+    return {"step_weighted": round(busy / (1024 * cyc), 4), "dispatches": len(step),
+            "per_kernel": {names[k]: round(a[0] / (1024 * a[1]), 4) for k, a in agg.items() if a[1] > 0}}
+
+
 def _pmc_prefill_busy():
     """Counter-based MFMA utilisation of the prefill step (separate rocprofv3 --pmc pass, committed under profiles/)."""
     try:
@@ -410,13 +499,20 @@ def main() -> None:
     ap.add_argument("--materialize-logits", action="store_true",
                     help="write the f32 logits of every step to HBM (default: a greedy batch takes its tokens from the arg-max "
                          "partials of the LM-head epilogue and the logits are written only when someone asks for them)")
+    ap.add_argument("--no-live-pmc", action="store_true",
+                    help="do not run the child rocprofv3 --pmc FETCH_SIZE pass that counts roofline.traffic in this run (N = 1; "
+                         "NVR_BENCH_LIVE_PMC=0 does the same): the committed pass under profiles/ is quoted instead")
     args = ap.parse_args()
     global BATCH, PROMPT_LEN
     BATCH, PROMPT_LEN = MODELS[args.model]["batch"], MODELS[args.model]["prompt_len"]
     if args.materialize_logits:
         os.environ["NVR_LAZY_LOGITS"] = "0"
 
-    nvr = nvr_import.load()                # loads libnvr.so (and the ROCm HIP runtime) before torch
+    live_pmc = live_prefill = None
+    if args.gpus == 1 and not args.no_live_pmc and os.environ.get("NVR_BENCH_LIVE_PMC", "1") != "0" and int(os.environ.get("WORLD_SIZE", "1")) == 1:
+        live_pmc = live_pmc_attention(args.model)                                # child processes, before this one initialises the GPU
+        live_prefill = live_pmc_prefill(args.model)
+    nvr = nvr_import.load()                # loads libnvr.so (and the ROCm HIP runtime)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -721,7 +817,10 @@ def main() -> None:
     achieved = attn["alg_bytes"] / (attn["us_per_launch"] * 1e-6) / 1e9
     traffic = None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_attn_latest.json")
-    if os.path.exists(pmc_path):
+    traffic_live = isinstance(live_pmc, dict)
+    if traffic_live:
+        traffic = int(round(live_pmc["traffic_over_algorithmic"] * attn["alg_bytes"]))
+    elif os.path.exists(pmc_path):
         try:
             # PMC pass (profiles/): HBM bytes / algorithmic bytes of this kernel, scaled to this run's launch
             traffic = int(round(json.load(open(pmc_path))["traffic_over_algorithmic"] * attn["alg_bytes"]))
@@ -748,8 +847,8 @@ def main() -> None:
                         "kv_source": {0: "the step's qkv buffer", 1: "the cache rows, contiguous (consecutive blocks)", 2: "the caches through the block tables"}.get(kv_source[0], "n/a"),
                         "note": "one untimed engine prefill step on a warm engine (wall clock, includes host input preparation and upload; a same-shape warm-up prefill on other tokens "
                                 "request ran before it); "
-                                "mfma_busy_frac_pmc = matrix-pipe busy cycles / available cycles at the clock the chip held, from the "
-                                "committed counter pass profiles/pmc_mfma_prefill_latest.json (tp1 kernels)"},
+                                "mfma_busy_frac_pmc = matrix-pipe busy cycles / available cycles at the clock the chip held (counter pass: see "
+                                "mfma_busy_frac_pmc_source)"},
             "step_hbm_frac": round(step_gbs / HBM_PEAK_GBS, 4),
             "step_algorithmic_bytes": int(step_bytes),
             "roofline": {"kernel": "attn_rows_kernel (paged decode attention, K9)", "bound": "hbm", "achieved": round(achieved, 1),
@@ -757,10 +856,23 @@ def main() -> None:
                          "us_per_launch": round(attn["us_per_launch"], 2), "launches_timed": attn["launches"],
                          "algorithmic_bytes_per_launch": int(attn["alg_bytes"])},
         }
-        if traffic is not None:
+        if traffic_live:
+            out["roofline"]["traffic_source"] = ("counted in this run: a child `rocprofv3 --kernel-trace --pmc FETCH_SIZE` pass of eager decode steps "
+                                                 "(FETCH_SIZE KiB x 1024 x 2 on gfx950), HBM bytes / algorithmic bytes over its attention dispatches, "
+                                                 "scaled to the algorithmic bytes of the timed launches")
+            out["roofline"]["traffic_pass"] = live_pmc
+        elif traffic is not None:
             out["roofline"]["traffic_source"] = ("profiles/pmc_attn_latest.json (separate rocprofv3 --pmc FETCH_SIZE pass of this kernel: HBM bytes / "
-                                                 "algorithmic bytes), scaled by this run's algorithmic bytes — not counted in this run")
-        out["prefill"]["mfma_busy_frac_pmc_source"] = "profiles/pmc_mfma_prefill_latest.json (separate rocprofv3 --pmc pass, not counted in this run)"
+                                                 "algorithmic bytes), scaled by this run's algorithmic bytes — not counted in this run"
+                                                 + (f" ({live_pmc})" if isinstance(live_pmc, str) else ""))
+        if isinstance(live_prefill, dict):
+            out["prefill"]["mfma_busy_frac_pmc"] = live_prefill["step_weighted"]
+            out["prefill"]["mfma_busy_frac_pmc_per_kernel"] = live_prefill["per_kernel"]
+            out["prefill"]["mfma_busy_frac_pmc_source"] = ("counted in this run: a child `rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE` pass of "
+                                                           f"the same prefill step ({live_prefill['dispatches']} dispatches; profiled clocks run ~3 % below un-profiled ones)")
+        else:
+            out["prefill"]["mfma_busy_frac_pmc_source"] = ("profiles/pmc_mfma_prefill_latest.json (separate rocprofv3 --pmc pass, not counted in this run"
+                                                           + (f": {live_prefill}" if isinstance(live_prefill, str) else "") + ")")
         if collective is not None:
             out["config"]["collectives"] = collective
         if chain is not None:

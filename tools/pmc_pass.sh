@@ -9,7 +9,7 @@ out=$GRAFT_REPO_ROOT/gpurun_out/pmc_$tag
 rm -rf $out && mkdir -p $out
 cd $GRAFT_REPO_ROOT
 for ctr in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $out/$ctr -o pmc -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-chain --no-shared-prefix --no-configs3 --no-prefill-sweep --no-batch-sweep --no-default-engine --sync-decode --eager > $out/$ctr.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $out/$ctr -o pmc -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-chain --no-shared-prefix --no-configs3 --no-prefill-sweep --no-batch-sweep --no-default-engine --no-live-pmc --sync-decode --eager > $out/$ctr.log 2>&1
   echo "$ctr rc=$?"
 done
 python3 - $out <<'PY'
