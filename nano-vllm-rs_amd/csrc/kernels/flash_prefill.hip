@@ -103,25 +103,9 @@ __device__ __forceinline__ float max_over_rows(float v) {
     return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
 }
 
-#ifdef NVR_FLASH_STAMPS                 // diagnostic build only (tools/build_variant.sh): shader-clock stamps of wave 0 of two workgroups per step
-__device__ unsigned long long flash_dbg[2 * 64 * 8];
-#define FSTAMP(i) if (NVR_FLASH_STAMPS && threadIdx.x == 0 && (blockIdx.x == 120 || blockIdx.x == 2168) && it < 64) \
-    flash_dbg[((blockIdx.x != 120) * 64 + it) * 8 + (i)] = __builtin_readcyclecounter();
-#else
-#define FSTAMP(i)
-#endif
 #ifndef NVR_FLASH_KT
 #define NVR_FLASH_KT 64
 #define NVR_FLASH_NBUF 2
-#endif
-#ifndef NVR_FLASH_STAGE_AT
-#define NVR_FLASH_STAGE_AT 0            // where a step requests the next K/V tile: 0 = first thing (product), 1 = behind the QK MFMAs, 2 = behind the softmax
-#endif
-#ifndef NVR_FLASH_KSETS
-#define NVR_FLASH_KSETS 3               // K fragment sets in registers: the reads run KSETS - 1 key tiles ahead of the MFMAs
-#endif
-#ifndef NVR_FLASH_VAHEAD
-#define NVR_FLASH_VAHEAD 1              // 1: the first half's V fragments are requested in front of the softmax arithmetic
 #endif
 #ifndef NVR_FLASH_WAVES
 #define NVR_FLASH_WAVES 4              // measured: 8 waves (one 256-row workgroup per CU) 252 us vs 4 waves x 2 workgroups 240 us per layer
@@ -290,48 +274,34 @@ __global__ __launch_bounds__(64 * FLASH_WAVES, 8 / FLASH_WAVES) void flash_prefi
         constexpr int cur = decltype(cur_c)::value;
         const int kt = kv_start + it * KT;
         const bool more = it + NBUF - 1 < nsteps;
-        FSTAMP(0)
-#ifdef NVR_FLASH_ABL
-        if (NVR_FLASH_ABL != 5)         // 5 = no K/V staging in the loop (arithmetic on whatever LDS holds)
-#endif
-        if (more && (NVR_FLASH_STAGE_AT == 0 || kt > wave_last)) stage((cur + NBUF - 1) % NBUF, kt + (NBUF - 1) * KT);
-        FSTAMP(1)
+        if (more) stage((cur + NBUF - 1) % NBUF, kt + (NBUF - 1) * KT);
         const char *kl = smem + cur * STAGE, *vl = kl + KT * D * 2;
-#ifdef NVR_FLASH_ABL
-        if (NVR_FLASH_ABL != 4)
-#endif
         if (kt <= wave_last) {
 
         // Sᵀ tiles: NMT x (16 keys x 16 queries) per query tile; one K fragment read feeds both
         float4_t s[NQT][NMT];
         // K fragments of key tile mt+1 are requested before the MFMAs of key tile mt (two fragment sets in registers):
         // without this the compiler emits {2 reads, wait, 4 MFMAs} eight times and every LDS latency is exposed
-        // (r04: TWO key tiles ahead, three fragment sets — stamps of the step showed the QK phase at 3.4 x its MFMA time with one tile
-        //  ahead: 8 MFMAs = 128 cycles do not cover an LDS read behind the other seven waves' bursts)
-        constexpr int KSETS = NVR_FLASH_KSETS;
-        half8_t kf[KSETS][NKS];
+        half8_t kf[2][NKS];
         auto read_k = [&](int mt, half8_t (&dst)[NKS]) {
             const int row = mt * 16 + r;
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks)
                 dst[ks] = *reinterpret_cast<const half8_t *>(kl + (row * CPR + ((ks * 4 + g4) ^ (row & (CPR - 1)))) * 16);
         };
-#pragma unroll
-        for (int a = 0; a < KSETS - 1; ++a) if (a < NMT) read_k(a, kf[a]);
+        read_k(0, kf[0]);
 #pragma unroll
         for (int mt = 0; mt < NMT; ++mt) {
-            if (mt + KSETS - 1 < NMT) read_k(mt + KSETS - 1, kf[(mt + KSETS - 1) % KSETS]);
+            if (mt + 1 < NMT) read_k(mt + 1, kf[(mt + 1) & 1]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int t = 0; t < NQT; ++t) s[t][mt] = (float4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
-                for (int t = 0; t < NQT; ++t) s[t][mt] = mfma16(kf[mt % KSETS][ks], qf[t][ks], s[t][mt]);
+                for (int t = 0; t < NQT; ++t) s[t][mt] = mfma16(kf[mt & 1][ks], qf[t][ks], s[t][mt]);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (NVR_FLASH_STAGE_AT == 1 && more) stage((cur + NBUF - 1) % NBUF, kt + (NBUF - 1) * KT);   // (experiment: requests behind the QK MFMAs)
-        FSTAMP(2)
         // causal mask only on steps that reach past the tile's first query (keys kt + mt*16 + g4*4 + e)
         if (!SHARED && kt + KT - 1 > tile.pos0) {
 #pragma unroll
@@ -342,22 +312,6 @@ __global__ __launch_bounds__(64 * FLASH_WAVES, 8 / FLASH_WAVES) void flash_prefi
                     for (int e = 0; e < 4; ++e)
                         if (kt + mt * 16 + g4 * 4 + e > qpos[t]) s[t][mt][e] = -INFINITY;
         }
-        // V fragments (r04): the stamps showed the P.V phase at 6 x its MFMA time — every fragment (two transposing reads) was waited for in
-        // front of its two MFMAs.  Half 0's NDT fragments are requested HERE, ahead of the max / exp arithmetic that does not need them;
-        // half 1's ahead of half 0's MFMAs (the score registers are dead by then and hold them).
-        half8_t vfr[NK2][NDT];
-        auto read_v = [&](int k2) {
-            const int row0 = (2 * k2) * 16 + g4 * 4 + (r >> 2), row1 = row0 + 16;
-            const int sw = v_swz<D>(row0);                      // same for row1 (row1 = row0 + 16)
-#pragma unroll
-            for (int dt = 0; dt < NDT; ++dt) {
-                const int cb = ((((dt * 2 + ((r & 3) >> 1)) ^ sw) << 4) | ((r & 1) << 3));   // byte offset inside the row
-                const half4_t a0 = lds_read_tr16(vl + row0 * (D * 2) + cb), a1 = lds_read_tr16(vl + row1 * (D * 2) + cb);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { vfr[k2][dt][e] = a0[e]; vfr[k2][dt][4 + e] = a1[e]; }
-            }
-        };
-        if (NVR_FLASH_VAHEAD) { read_v(0); __builtin_amdgcn_sched_barrier(0); }
         half8_t pf[NQT][NK2];
         bool moved = false;
         float alpha[NQT];
@@ -378,8 +332,6 @@ __global__ __launch_bounds__(64 * FLASH_WAVES, 8 / FLASH_WAVES) void flash_prefi
                 for (int e = 0; e < 4; ++e)
                     pf[t][mt >> 1][(mt & 1) * 4 + e] = (half_t)__builtin_amdgcn_exp2f(fmaf(s[t][mt][e], c2, mc));
         }
-        if (NVR_FLASH_STAGE_AT == 2 && more) stage((cur + NBUF - 1) % NBUF, kt + (NBUF - 1) * KT);   // (experiment: requests behind the softmax)
-        FSTAMP(3)
         if (__any(moved)) {                                     // wave-uniform: the running max settles after a few steps
 #pragma unroll
             for (int t = 0; t < NQT; ++t) {
@@ -389,24 +341,24 @@ __global__ __launch_bounds__(64 * FLASH_WAVES, 8 / FLASH_WAVES) void flash_prefi
             }
         }
         // Oᵀ += Vᵀ·Pᵀ per 32-key half; one V fragment (two transposing reads) feeds both query tiles
-        if (!NVR_FLASH_VAHEAD) read_v(0);
 #pragma unroll
         for (int k2 = 0; k2 < NK2; ++k2) {
-            if (k2 + 1 < NK2) read_v(k2 + 1);
-            __builtin_amdgcn_sched_barrier(0);
+            const int row0 = (2 * k2) * 16 + g4 * 4 + (r >> 2), row1 = row0 + 16;
+            const int sw = v_swz<D>(row0);                      // same for row1 (row1 = row0 + 16)
 #pragma unroll
             for (int t = 0; t < NQT; ++t) ol[t] = mfma16(ones, pf[t][k2], ol[t]);
 #pragma unroll
-            for (int dt = 0; dt < NDT; ++dt)
+            for (int dt = 0; dt < NDT; ++dt) {
+                const int cb = ((((dt * 2 + ((r & 3) >> 1)) ^ sw) << 4) | ((r & 1) << 3));   // byte offset inside the row
+                const half4_t a0 = lds_read_tr16(vl + row0 * (D * 2) + cb), a1 = lds_read_tr16(vl + row1 * (D * 2) + cb);
+                half8_t vf;
 #pragma unroll
-                for (int t = 0; t < NQT; ++t) o[t][dt] = mfma16(vfr[k2][dt], pf[t][k2], o[t][dt]);
-            __builtin_amdgcn_sched_barrier(0);
+                for (int e = 0; e < 4; ++e) { vf[e] = a0[e]; vf[4 + e] = a1[e]; }
+#pragma unroll
+                for (int t = 0; t < NQT; ++t) o[t][dt] = mfma16(vf, pf[t][k2], o[t][dt]);
+            }
         }
         }   // kt <= wave_last
-        FSTAMP(4)
-#ifdef NVR_FLASH_ABL                    // timing-only ablations (wrong results): 1 = no wait for the next tile, 4 = no arithmetic at all
-        if (NVR_FLASH_ABL == 1) { __builtin_amdgcn_s_barrier(); return; }
-#endif
         if (it + NBUF < nsteps) {                               // NBUF-1 younger tiles were requested: leave NBUF-2 of them flying
             if (NBUF == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             else if (NBUF == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 * 2 * PIECES) : "memory");
@@ -414,9 +366,7 @@ __global__ __launch_bounds__(64 * FLASH_WAVES, 8 / FLASH_WAVES) void flash_prefi
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        FSTAMP(5)
         __builtin_amdgcn_s_barrier();
-        FSTAMP(6)
     };
 
 #pragma unroll
@@ -523,9 +473,3 @@ int flash_shared_prefix(const half_bits *q, int64_t ldq, const half_bits *k_cach
 }
 
 }}  // namespace nvr::k / nvr::kb (NVR_DT_NS)
-
-#if defined(NVR_FLASH_STAMPS) && !defined(NVR_BF16)
-extern "C" __attribute__((visibility("default"))) int nvr_debug_flash_stamps(unsigned long long *out) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(nvr::k::flash_dbg), sizeof(unsigned long long) * 2 * 64 * 8);
-}
-#endif
