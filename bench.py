@@ -245,6 +245,27 @@ def side_decode(nvr, preset: str, steps: int = 16, warmup: int = 4, tp_size: int
         if not ok:
             return {"error": desc}
     nvr.synchronize(); t_init = time.perf_counter() - t0
+    exchange_modes = None
+    if tp_size > 1:
+        # row g on real links: the same prefill (B x P tokens, one token sampled per sequence: the sequences finish and free their blocks)
+        # under the three forms of the tensor-parallel prefill exchange — serial on one stream, token chunks of one GEMM on a second
+        # stream (default), two micro-batches under each other's compute (nvr_runner_set_tp_prefill_overlap 0 / 1 / 2; same bits)
+        exchange_modes = {}
+        for mode, name in ((1, "warm_up"), (0, "serial"), (1, "chunks"), (2, "two_microbatches")):
+            eng.model_runner.set_tp_prefill_overlap(mode)
+            for i in range(B):
+                eng.add_request(nvr.synthetic_tokens(P, 1, 1000 * (mode + 1) + i, mc.c.vocab_size).tolist(),
+                                nvr.SamplingParams(temperature=0.0, max_tokens=1, ignore_eos=True))
+            if barrier: barrier()
+            nvr.synchronize(); t1 = time.perf_counter(); forms = []
+            while not eng.is_finished():
+                rec = eng.step(); forms.append(eng.model_runner.last_overlap_chunks() if rec["is_prefill"] else -1)
+            nvr.synchronize(); dt = time.perf_counter() - t1
+            if reduce_max: dt = reduce_max(dt)
+            eng.take_finished()
+            if name != "warm_up":
+                exchange_modes[name] = {"seconds": round(dt, 4), "prefill_steps": len(forms), "chunks_or_microbatches_per_step": forms}
+        eng.model_runner.set_tp_prefill_overlap(1)
     for i in range(B):
         eng.add_request(nvr.synthetic_tokens(P, 1, i, mc.c.vocab_size).tolist(),
                         nvr.SamplingParams(temperature=0.0, max_tokens=total_new + 8, ignore_eos=True))
@@ -283,6 +304,8 @@ def side_decode(nvr, preset: str, steps: int = 16, warmup: int = 4, tp_size: int
                prefill_steps=npre, prefill_plus_first_decode_seconds=round(t_pre, 3),
                prefill_tflop_per_s_lower_bound=round(prefill_flops(c, [P] * B) / t_pre / 1e12, 1), init_seconds=round(t_init, 1),
                async_decode="opt-in (default 0), on here" if async_decode else "off (the default engine)")
+    if exchange_modes is not None:
+        out["prefill_exchange_forms"] = exchange_modes
     del eng
     return out
 

@@ -698,8 +698,9 @@ class ModelRunner:
         return int(lib().nvr_runner_last_prefill_kv_source(self.h))
 
     def set_tp_prefill_overlap(self, on: bool) -> None:
-        """Tensor-parallel prefill: all-reduce of token chunk i on a second stream under the GEMM of chunk i + 1 (default on)."""
-        check(lib().nvr_runner_set_tp_prefill_overlap(self.h, 1 if on else 0))
+        """Tensor-parallel prefill exchange: 1 / True (default) = all-reduce of token chunk i on a second stream under the GEMM of chunk i + 1;
+        2 = two micro-batches of whole sequences, each exchange under the other one's compute; 0 / False = serial on one stream."""
+        check(lib().nvr_runner_set_tp_prefill_overlap(self.h, 2 if on == 2 else 1 if on else 0))
 
     def last_overlap_chunks(self) -> int:
         return int(lib().nvr_runner_last_overlap_chunks(self.h))

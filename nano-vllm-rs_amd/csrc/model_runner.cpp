@@ -563,12 +563,98 @@ static inline uint64_t graph_key(bool want_logits, size_t nseq, int64_t bucket, 
     return ((uint64_t)want_logits << 63) | ((uint64_t)group << 62) | ((uint64_t)nseq << 44) | ((uint64_t)(shared_len / 64) << 24) | (uint64_t)(bucket / 256);
 }
 
+// Prefill on tensor-parallel ranks as TWO micro-batches of whole sequences (row g, nvr_runner_set_tp_prefill_overlap(r, 2)): rows [0, mb_rows)
+// and [mb_rows, T) go through every layer one behind the other on the compute stream, and each row-parallel exchange (o_proj, down_proj:
+// linear.rs:236-238) runs on the communication stream under the OTHER micro-batch's compute segment:
+//     compute:  attn(A) attn(B) | mlp(A)      mlp(B)      | post(A) attn'(A) post(B) attn'(B) | ...
+//     comm:            AR(oA)    AR(oB)  AR(dA)      AR(dB) ...
+// (attn = [input norm,] qkv + RoPE + store, flash attention, o_proj; mlp = residual + post-attention norm, gate_up + SiLU, down_proj; post =
+// residual + the next layer's input norm).  With chunks of one GEMM (mode 1) an exchange hides only behind that GEMM; here it hides behind a
+// third of a layer, which is what a TP-8 prefill of configs[3] needs (its exchanges are the larger half of the step).
+// Every op is a row-wise kernel, a 256-row-tile GEMM (each part is big enough to take the same kernel as the whole step) or attention
+// over whole sequences, so the bits are those of the serial form.  Host order keeps one segment queued ahead of every reduce (a backend
+// that blocks the host inside the reduce still finds work queued).
+int nvr_model_runner::forward_prefill_two(int64_t T, int64_t B) {
+    hipStream_t st = stream;
+    const int64_t r0s[2] = {0, mb_rows}, nrs[2] = {mb_rows, T - mb_rows};
+    const int64_t t0s[2] = {0, mb_tiles}, nts[2] = {mb_tiles, n_tiles - mb_tiles};
+    RC(KD(embedding(d_ids, T, embed, Hd, h, st)));
+    auto attn_part = [&](int64_t l, int m) -> int {
+        const Layer &w = layers[l];
+        const int64_t r0 = r0s[m], nr = nrs[m];
+        if (l == 0) RC(KD(rmsnorm(h + r0 * Hd, w.ln1, mc.rms_norm_eps, nr, Hd, n + r0 * Hd, st)));
+        if (mb_route[0] == 0) RC(KD(gemm256_qkv_rope_store(n + r0 * Hd, Hd, w.qkv, nr, Hd, H, KVH, D, d_pos + r0, d_slots + r0, cos_t, sin_t, qkv + r0 * QKV,
+                                                           k_cache(l), v_cache(l), st, prefill_paged || prefill_kv_cache)));
+        else RC(KD(gemm_tiled_qkv_rope_store(n + r0 * Hd, Hd, w.qkv, nr, Hd, H, KVH, D, d_pos + r0, d_slots + r0, cos_t, sin_t, qkv + r0 * QKV, k_cache(l), v_cache(l), st)));
+        k::FlashArgs f{};
+        f.q = qkv; f.ldq = QKV;
+        if (prefill_paged) {
+            f.k = k_cache(l); f.v = v_cache(l); f.block_tables = dd_bt; f.max_blocks = (int32_t)max_blocks_per_seq; f.block_size = (int32_t)block_size;
+        } else if (prefill_kv_cache) { f.k = k_cache(l); f.v = v_cache(l); f.ldkv = KVH * D; }
+        else { f.k = qkv + H * D; f.v = qkv + (H + KVH) * D; f.ldkv = QKV; }
+        f.tiles = (const k::FlashTile *)(in_dev + off_tiles) + t0s[m]; f.ntiles = (int32_t)nts[m];
+        f.H = (int32_t)H; f.KVH = (int32_t)KVH; f.D = (int32_t)D; f.scale = scale; f.out = attn;
+        RC(KD(flash_prefill(f, prefill_paged, st)));
+        return mb_route[1] == 0 ? KD(gemm256(attn + r0 * H * D, H * D, w.o, nr, H * D, Hd, proj + r0 * Hd, st))
+                                : KD(gemm_tiled(attn + r0 * H * D, H * D, w.o, nr, H * D, Hd, proj + r0 * Hd, st));
+    };
+    auto mlp_part = [&](int64_t l, int m) -> int {
+        const Layer &w = layers[l];
+        const int64_t r0 = r0s[m], nr = nrs[m];
+        RC(KD(add_rmsnorm(h + r0 * Hd, proj + r0 * Hd, w.ln2, mc.rms_norm_eps, nr, Hd, n + r0 * Hd, st)));
+        if (mb_route[2] == 0) RC(KD(gemm256_silu_mul(n + r0 * Hd, Hd, w.gate_up, nr, Hd, I, act + r0 * I, st)));
+        else RC(KD(gemm_tiled_silu_mul(n + r0 * Hd, Hd, w.gate_up, nr, Hd, I, act + r0 * I, st)));
+        return mb_route[3] == 0 ? KD(gemm256(act + r0 * I, I, w.down, nr, I, Hd, proj + r0 * Hd, st))
+                                : KD(gemm_tiled(act + r0 * I, I, w.down, nr, I, Hd, proj + r0 * Hd, st));
+    };
+    auto post_part = [&](int64_t l, int m) -> int {
+        const int64_t r0 = r0s[m], nr = nrs[m];
+        return KD(add_rmsnorm(h + r0 * Hd, proj + r0 * Hd, l + 1 < L ? layers[l + 1].ln1 : norm, mc.rms_norm_eps, nr, Hd, n + r0 * Hd, st));
+    };
+    // exchange of micro-batch m's projection rows on the communication stream, bracketed by events (slot e = 2 * m + which)
+    auto exchange = [&](int m, int e) -> int {
+        NVR_HIP_CHECK(hipStreamWaitEvent(comm_stream, ev_gemm[e], 0));
+        RC(comm.all_reduce_sum_f16(proj + r0s[m] * Hd, (size_t)(nrs[m] * Hd), comm_stream));
+        NVR_HIP_CHECK(hipEventRecord(ev_reduced[e], comm_stream));
+        return NVR_OK;
+    };
+    tp_overlap_chunks = 2;
+    for (int64_t l = 0; l < L; ++l) {
+        // (post(l-1) of a micro-batch runs in front of its attn(l): the order below is per micro-batch A, B inside every stage)
+        for (int m = 0; m < 2; ++m) {
+            if (l > 0) { NVR_HIP_CHECK(hipStreamWaitEvent(st, ev_reduced[2 * m + 1], 0)); RC(post_part(l - 1, m)); }
+            RC(attn_part(l, m));
+            NVR_HIP_CHECK(hipEventRecord(ev_gemm[2 * m], st));
+            if (m == 1) { RC(exchange(0, 0)); }                       // AR(o, A) goes out once attn(B) is queued behind it
+        }
+        RC(exchange(1, 2));
+        for (int m = 0; m < 2; ++m) {
+            NVR_HIP_CHECK(hipStreamWaitEvent(st, ev_reduced[2 * m], 0));
+            RC(mlp_part(l, m));
+            NVR_HIP_CHECK(hipEventRecord(ev_gemm[2 * m + 1], st));
+            if (m == 1) { RC(exchange(0, 1)); }
+        }
+        RC(exchange(1, 3));
+    }
+    for (int m = 0; m < 2; ++m) { NVR_HIP_CHECK(hipStreamWaitEvent(st, ev_reduced[2 * m + 1], 0)); RC(post_part(L - 1, m)); }
+    RC(KD(select_last_tokens(n, d_cu, B, Hd, nlast, st)));                                       // embed_head.rs:272-289
+    if (lm_parts > 0) {
+        int32_t np = 0;
+        RC(KD(lm_head(nlast, Hd, lm_head, B, Hd, Vl, logits, d_lm_pval, d_lm_pidx, &np, st, want_logits, (tiled_weights && B <= 32) ? lm_head_t : nullptr)));
+        if (np != lm_parts) return nvr::fail(NVR_ERR_INVARIANT, "lm_head produced %d partials, planned %d", np, lm_parts);
+    } else {
+        RC(KD(linear(nlast, Hd, lm_head, B, Hd, Vl, logits, true, st)));
+    }
+    return NVR_OK;
+}
+
 // Qwen3Model::forward, src/models/qwen3.rs:487-505; layer wiring :372-392; attention :208-240; MLP :305-314.
 int nvr_model_runner::forward(int64_t T, int64_t B, bool is_prefill, int64_t max_ctx) {
     hipStream_t st = stream;
     const int64_t *ids = is_prefill ? d_ids : dd_ids, *pos = is_prefill ? d_pos : dd_pos;
     const int32_t *slots = is_prefill ? d_slots : dd_slots, *ctx = is_prefill ? d_ctx : dd_ctx;
     const int32_t *bt = dd_bt;
+    if (is_prefill && tp_overlap == 2 && mb_rows > 0) return forward_prefill_two(T, B);
     const bool c4 = use_chain4(T, is_prefill);
     const bool tl = tiled_weights && T <= 64;                            // decode-sized steps stream the tiled weight copies
     const bool embed_norm = !c4 && L > 0 && KD(embedding_rmsnorm_ok(T, Hd));                    // decode-sized: K1 + the first norm in one launch
@@ -699,6 +785,8 @@ int nvr_model_runner::execute(nvr_seq *const *seqs, size_t nseq, bool is_prefill
             for (size_t b = 0; b < nseq; ++b)
                 if (seqs[b]->chunk_start > 0) return nvr::fail(NVR_ERR_UNSUPPORTED, "chunked prefill needs the paged flash kernel (head_dim 64/128)");
         prefill_paged = false;
+        mb_rows = mb_tiles = 0;
+        tp_overlap_chunks = 0;
         int64_t total = 0;
         for (size_t b = 0; b < nseq; ++b) {
             int64_t lo, hi; range_of(*seqs[b], &lo, &hi);
@@ -790,7 +878,28 @@ int nvr_model_runner::execute(nvr_seq *const *seqs, size_t nseq, bool is_prefill
                     while (t1 < (size_t)n_tiles && tl[t1].q_row0 < row_end) ++t1;
                     std::stable_sort(tl + t0, tl + t1, [](const k::FlashTile &a, const k::FlashTile &b) { return a.pos0 + a.nq > b.pos0 + b.nq; });
                     t0 = t1;
+                    // two micro-batches (tp_overlap = 2): cut at the boundary between two groups of four sequences that is closest to half the rows
+                    if (b0 + 4 < nseq && (mb_rows == 0 || std::llabs(2 * (int64_t)row_end - total) < std::llabs(2 * mb_rows - total))) {
+                        mb_rows = row_end; mb_tiles = (int64_t)t1;
+                    }
                 }
+            }
+            // (every GEMM of a part must run the kernel the WHOLE step would run — 256-row or 128-row tiles, by linear.hip's cost rule for the whole
+            //  step's shape — so the parts call that kernel directly; the plain graph only: see forward_prefill_two)
+            {
+                const int64_t rest = total - mb_rows;
+                bool ok = tp_overlap == 2 && comm.active() && comm_stream && !mc.qk_norm && !mc.use_bias && !chunked && mb_rows >= 512 && rest >= 512;
+                // kinds: 0 qkv (+RoPE), 1 o_proj, 2 gate_up (+SiLU), 3 down_proj
+                const int64_t Ks[4] = {Hd, H * D, Hd, I}, Ns[4] = {QKV, Hd, 2 * I, Hd};
+                for (int kd = 0; kd < 4 && ok; ++kd) {
+                    auto ok256 = [&](int64_t rows) { return kd == 0 ? KD(gemm256_rope_ok(rows, Hd, H, KVH, D, Hd)) : kd == 2 ? KD(gemm256_silu_ok(rows, Hd, I, Hd))
+                                                                                                                             : KD(gemm256_ok(rows, Ks[kd], Ns[kd], Ks[kd])); };
+                    auto ok128 = [&](int64_t rows) { return KD(gemm_tiled_ok(rows, Ks[kd], kd == 2 ? I : Ns[kd], Ks[kd])) && (kd != 0 || 128 % D == 0) && (kd != 2 || I % 64 == 0); };
+                    if (ok256(total) && KD(gemm256_preferred(total, Ks[kd], Ns[kd], Ks[kd]))) { mb_route[kd] = 0; ok = ok256(mb_rows) && ok256(rest); }
+                    else if (ok128(total)) { mb_route[kd] = 1; ok = ok128(mb_rows) && ok128(rest); }
+                    else ok = false;
+                }
+                if (!ok) mb_rows = mb_tiles = 0;
             }
         }
     } else {

@@ -31,7 +31,10 @@ struct nvr_model_runner {
     static constexpr int kMaxChunks = 8;
     hipEvent_t ev_gemm[kMaxChunks] = {}, ev_reduced[kMaxChunks] = {};
     int64_t tp_overlap_chunks = 0;         // chunks of the last overlapped exchange (0: none ran; diagnostics / tests)
-    int tp_overlap = 1;                    // nvr_config.tp_prefill_overlap (default 1); 0: GEMM -> all-reduce -> add + norm in a row on one stream
+    int tp_overlap = 1;                    // nvr_runner_set_tp_prefill_overlap: 1 (default) chunks of one GEMM; 2 two micro-batches per step; 0: serial on one stream
+    int mb_route[4] = {0, 0, 0, 0};         // tp_overlap = 2: kernel of the step's qkv / o / gate_up / down GEMMs (0: 256-row tiles, 1: 128-row tiles)
+    int64_t mb_rows = 0, mb_tiles = 0;     // tp_overlap = 2: rows / flash tiles of the first micro-batch of the current prefill step (0: not split)
+    int forward_prefill_two(int64_t T, int64_t B);
 
     struct Layer { uint16_t *qkv, *o, *gate_up, *down, *ln1, *ln2;
                    uint16_t *qkv_t, *o_t, *gate_up_t, *down_t;      // *_t: tiled copies for the decode kernels (retile_weight), or null

@@ -491,8 +491,12 @@ def test_tensor_parallel_prefill_exchange_overlaps_on_a_second_stream(tp, p2p, h
         for t in threads: t.join(300)
         assert not errors, errors
         return traces, chunks
-    (a, ca), (b, cb) = run(True), run(False)
-    assert ca == [4] * tp and cb == [0] * tp, (ca, cb)
+    (a, ca), (b, cb), (c, cc) = run(1), run(0), run(2)
+    two = 2 if (heads // tp) // (8 // tp) in (1, 2, 4) else 4          # (mode 2 needs the MFMA attention kernel's tiles; GQA group 8 falls back to the chunks)
+    assert ca == [4] * tp and cb == [0] * tp and cc == [two] * tp, (ca, cb, cc)
+    for r in range(tp):                                                                    # mode 2: two micro-batches of whole sequences, same bits again
+        for sc, sb in zip(c[r], b[r]):
+            assert sc["tokens"] == sb["tokens"] and np.array_equal(sc["logits"], sb["logits"]), "two-micro-batch and serial prefill differ in bits"
     assert len(a[0]) == len(b[0]) == 4 and a[0][0]["is_prefill"] and a[0][0]["num_tokens"] == sum(lens)
     for r in range(tp):
         for sa, sb in zip(a[r], b[r]):
@@ -758,12 +762,12 @@ else:
     # prefill exchange on a second stream (row g): overlapped == serial, bit for bit, across process boundaries
     m, mc = model(seed=26, num_attention_heads=32, num_key_value_heads=8, head_dim=64, hidden_size=1024, intermediate_size=2048)
     res = []
-    for overlap in (1, 0):
+    for overlap in (1, 0, 2):
         nvr.lib().nvr_seq_reset_id_counter()
         eng = nvr.LLMEngine(nvr.Config(skip_block_size_check=1, max_num_seqs=8, max_num_batched_tokens=8704, max_model_len=2048, kvcache_block_size=64,
                                        num_kvcache_blocks=160, tensor_parallel_size=world, tensor_parallel_rank=rank, device_ordinal=0, enforce_eager=1, dtype=dtype), mc)
         attach(eng)
-        eng.model_runner.set_tp_prefill_overlap(bool(overlap))
+        eng.model_runner.set_tp_prefill_overlap(overlap)
         for i, n in enumerate([1700, 1513, 1300, 1900, 1257, 833]):
             eng.add_request(oracle.fill_tokens(n, 5, i, m.vocab_size).tolist(), nvr.SamplingParams(temperature=0.0, max_tokens=3, ignore_eos=True))
         steps, chunks = [], 0
@@ -775,7 +779,8 @@ else:
         g.barrier()
         del eng
     same = all(ta == tb and np.array_equal(la, lb) for (ta, la), (tb, lb) in zip(res[0][0], res[1][0]))
-    out = g.all_gather(([t for t, _ in res[0][0]], [res[0][1], res[1][1], bool(same), len(res[0][0])]))
+    same2 = all(ta == tb and np.array_equal(la, lb) for (ta, la), (tb, lb) in zip(res[2][0], res[1][0]))
+    out = g.all_gather(([t for t, _ in res[0][0]], [res[0][1], res[1][1], bool(same), len(res[0][0]), res[2][1], bool(same2)]))
 if rank == 0:
     json.dump(out, open(os.environ["NVR_OUT"], "w"))
 g.barrier()
@@ -847,8 +852,10 @@ def test_processes_sharing_the_gpu_exchange_over_hipipc(tmp_path, dtype, world):
 @pytest.mark.gpu
 def test_two_processes_overlap_the_prefill_exchange_bit_identically(tmp_path):
     """Row g across process boundaries: two rank processes (hipIpc arenas on one GPU) run a 8503-token prefill with the all-reduce of each token
-    chunk on the second stream (4 chunks) and again serially: same tokens, same shard logits in every step, on both ranks."""
+    chunk on the second stream (4 chunks), serially, and as two micro-batches whose exchanges run under each other's compute: same tokens, same shard
+    logits in every step, on both ranks."""
     got = _run_ipc_workers(tmp_path, 2, "float16", "overlap")
     assert len(got) == 2 and got[0][0] == got[1][0]
-    for toks, (chunks_on, chunks_off, same, nsteps) in got:
+    for toks, (chunks_on, chunks_off, same, nsteps, chunks_two, same_two) in got:
         assert chunks_on == 4 and chunks_off == 0 and same and nsteps == 3, (chunks_on, chunks_off, same, nsteps)
+        assert chunks_two == 2 and same_two, (chunks_two, same_two)          # two micro-batches of whole sequences: the same bits again
