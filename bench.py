@@ -404,11 +404,15 @@ def live_pmc_attention(model: str):
     """HBM traffic of the dominant kernel counted IN THIS RUN (FETCH_SIZE pass).  gfx950: FETCH_SIZE counts KiB at 64 B per 128-byte
     request of a 16-B-per-lane streaming read -> bytes = FETCH_SIZE * 1024 * 2.  Returns a dict or a string saying why there is no live
     number (the committed pass under profiles/ is quoted then)."""
-    import statistics
     steps, warm = 6, 2
     rows = _pmc_child(model, ["FETCH_SIZE"], steps, warm)
-    if isinstance(rows, str):
-        return rows
+    return rows if isinstance(rows, str) else attention_traffic_from_rows(rows, model, steps, warm)
+
+
+def attention_traffic_from_rows(rows, model: str, steps: int, warm: int):
+    """The FETCH_SIZE rows of a counter pass (dicts of rocprofv3's counter_collection.csv) -> HBM bytes over algorithmic bytes of the
+    decode attention dispatches (pure function: tests/test_bench_counters.py feeds it synthetic tables)."""
+    import statistics
     vals = [float(r["Counter_Value"]) for r in rows if r.get("Counter_Name") == "FETCH_SIZE" and "attn_rows_kernel" in r.get("Kernel_Name", "")]
     m = MODELS[model]
     mc = m["shape"]
@@ -428,10 +432,13 @@ def live_pmc_prefill(model: str):
     """Matrix-pipe busy share of the measured prefill step counted IN THIS RUN: SQ_VALU_MFMA_BUSY_CYCLES (16 cycles per 16x16x32 MFMA, summed
     over the SIMDs) against GRBM_GUI_ACTIVE (summed over the 8 XCDs: cycles = GRBM / 8) per dispatch: busy = BUSY / (1024 SIMDs x cycles).
     The step = the dispatches from the last prefill embedding launch to the first decode step.  Returns a dict or a string."""
-    import collections
     rows = _pmc_child(model, ["SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"], 1, 0)
-    if isinstance(rows, str):
-        return rows
+    return rows if isinstance(rows, str) else prefill_busy_from_rows(rows)
+
+
+def prefill_busy_from_rows(rows):
+    """Counter rows of a pass over the bench workload -> matrix-pipe busy share of its LAST prefill step (pure function, see above)."""
+    import collections
     disp = collections.OrderedDict()
     for r in sorted(rows, key=lambda r: int(r["Dispatch_Id"])):
         d = disp.setdefault(r["Dispatch_Id"], {"name": r["Kernel_Name"]})
