@@ -310,6 +310,27 @@ def side_decode(nvr, preset: str, steps: int = 16, warmup: int = 4, tp_size: int
     return out
 
 
+def float32_path(nvr, steps: int = 64) -> dict:
+    """BASELINE.json configs[0] (Qwen3-0.6B, bs = 1, 128-token prompt, greedy decode: the reference's own runnable configuration, f32 on its
+    CPU path) on the product's Config.dtype = "float32" path (kernels/f32_path.hip: reference precision, plain FMA kernels, eager) — the GPU
+    twin of cpu_baseline's workload."""
+    mc = nvr.ModelConfig("qwen3-0.6b")
+    eng = nvr.LLMEngine(nvr.Config(max_num_seqs=1, max_num_batched_tokens=256, max_model_len=256, kvcache_block_size=BLOCK, num_kvcache_blocks=2,
+                                   dtype="float32"), mc)
+    eng.add_request(nvr.synthetic_tokens(128, 1, 0, mc.c.vocab_size).tolist(), nvr.SamplingParams(temperature=0.0, max_tokens=steps + 5, ignore_eos=True))
+    nvr.synchronize(); t0 = time.perf_counter()
+    eng.step()
+    nvr.synchronize(); t_pre = time.perf_counter() - t0
+    for _ in range(3): eng.step()
+    nvr.synchronize(); t0 = time.perf_counter()
+    for _ in range(steps): eng.step()
+    nvr.synchronize(); el = time.perf_counter() - t0
+    del eng
+    return {"workload": "Qwen3-0.6B f32 random-init (unrounded weights), bs=1, 128-token prompt, greedy decode (BASELINE.json configs[0]) on the float32 path",
+            "decode_tokens_per_s": round(steps / el, 1), "ms_per_step": round(el * 1e3 / steps, 3), "prefill_tokens_per_s": round(128 / t_pre, 1),
+            "parity": "tests/test_baseline_parity.py: 64 greedy ids == the f32 CPU-path oracle's, max |dlogit| 7e-6"}
+
+
 def prefill_sweep(nvr, lens=(128, 256, 512, 1024, 2048, 4096), nseq: int = 256) -> dict:
     """BASELINE.json configs[2]: Qwen3-0.6B fp16, 256 sequences at L in {128 .. 4096} through the engine under the reference's 32 768-token
     prefill budget (config.rs:58; Scheduler::try_schedule_prefill, scheduler.rs:119-168, batches whole sequences), and again with the
@@ -838,6 +859,12 @@ def main() -> None:
             default_engine["prefill_recycled_free_list"] = prefill_recycled(nvr)
         except Exception as ex:                                              # noqa: BLE001
             default_engine["prefill_recycled_free_list"] = {"error": str(ex)[:200]}
+    f32_block = None
+    if args.gpus == 1 and rank == 0 and not args.no_default_engine and args.model == "qwen3-0.6b":
+        try:
+            f32_block = float32_path(nvr)
+        except Exception as ex:                                              # noqa: BLE001
+            f32_block = {"error": str(ex)[:200]}
     sweep = None
     if args.gpus == 1 and rank == 0 and not args.no_prefill_sweep and args.model == "qwen3-0.6b":
         try:
@@ -926,6 +953,8 @@ def main() -> None:
             out["bf16"] = bf16_block
         if default_engine is not None:
             out["default_engine"] = default_engine
+        if f32_block is not None:
+            out["float32_path"] = f32_block
         if sweep is not None:
             out["prefill_sweep"] = sweep
         if args.gpus == 1 and not args.no_cpu_baseline:

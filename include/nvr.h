@@ -117,9 +117,13 @@ typedef struct nvr_config {
                                           f32 accumulation, MFMA at the same rate) and the runner picks one build at creation — weights,
                                           activations, KV cache and the residual stream are all of that type, logits are f32;
                                           nvr_runner_load_tensor converts any of f16 / bf16 / f32 to it (bf16 checkpoints into a bf16
-                                          runner bit for bit), nvr_runner_copy_weight returns its raw 16-bit elements.  "float32":
-                                          NVR_ERR_UNSUPPORTED at runner creation (f32 checkpoints load into either type).  The stateless
-                                          op entry points (nvr_linear, nvr_paged_attn_*, ...) take their type from nvr_ops_set_dtype */
+                                          runner bit for bit), nvr_runner_copy_weight returns its raw 16-bit elements.  "float32" (r04):
+                                          the REFERENCE-PRECISION path (kernels/f32_path.hip) — weights (the generator's values
+                                          unrounded, or a checkpoint's values exactly), activations and KV cache as f32, plain FMA
+                                          kernels, eager launches, one GPU (tensor_parallel_size > 1: NVR_ERR_UNSUPPORTED); the
+                                          arithmetic of the reference's own CPU path: its logits to ~1e-5.  nvr_runner_copy_weight then
+                                          returns f32 values (two 16-bit words per element).  The stateless op entry points
+                                          (nvr_linear, nvr_paged_attn_*, ...) take their 16-bit type from nvr_ops_set_dtype */
 } nvr_config;
 NVR_API void nvr_config_default(nvr_config *cfg);                    /* config.rs:54-71 */
 NVR_API int nvr_config_validate(const nvr_config *cfg);              /* config.rs:83-119 */

@@ -575,6 +575,7 @@ class ModelRunner:
     def __init__(self, config: Config, model_config: ModelConfig, _handle=None):
         self.vocab_local = model_config.c.vocab_size // max(1, config.c.tensor_parallel_size) if _handle is None else 0
         self.bf16 = bytes(config.c.dtype).split(b"\0")[0] == b"bfloat16"    # the runner's 16-bit type (Config.dtype, config.rs:51)
+        self.f32 = bytes(config.c.dtype).split(b"\0")[0] == b"float32"      # the reference-precision path: 4-byte storage
         if _handle is not None:
             self.h, self.owned = _handle, False
             return
@@ -647,6 +648,10 @@ class ModelRunner:
         runner (numpy has no bf16), as the f32 values of its bf16 elements (exact)."""
         r, c = C.c_int64(), C.c_int64()
         check(lib().nvr_runner_copy_weight(self.h, local_name.encode(), None, 0, C.byref(r), C.byref(c)))
+        if self.f32:
+            out = np.empty((r.value, c.value), np.float32)
+            check(lib().nvr_runner_copy_weight(self.h, local_name.encode(), out.ctypes.data, out.size * 2, C.byref(r), C.byref(c)))
+            return out[:, 0] if c.value == 1 else out
         out = np.empty((r.value, c.value), np.uint16 if self.bf16 else np.float16)
         check(lib().nvr_runner_copy_weight(self.h, local_name.encode(), out.ctypes.data, out.size, C.byref(r), C.byref(c)))
         if self.bf16:

@@ -1,0 +1,312 @@
+// f32_path.hip — Config.dtype = "float32" (reference src/config.rs:51,113-116; the reference's own CPU path computes in f32): every op of the
+// Qwen3 graph on 4-byte storage, as plain FMA kernels.  This is the REFERENCE-PRECISION path of the product — outputs comparable with the
+// reference's f32 CPU path at 1e-3 instead of through 16-bit rounding — not a tuned one: no MFMA (the dense f32 matrix rate of the part is
+// 1/16 of its fp16 rate), no hipGraph, one GPU.  Each kernel cites the reference op it restates, like its 16-bit twin:
+//   embedding   VocabParallelEmbedding::forward, src/layers/embed_head.rs:77-97
+//   rmsnorm     RMSNorm::forward_simple, src/layers/layernorm.rs:58-75; add_rmsnorm: forward_with_residual :170-176
+//   linear      Linear::forward x·Wᵀ(+b), src/layers/linear.rs:12-24
+//   rope_store  apply_rotary_emb_single, src/layers/rotary_embedding.rs:23-48 (+ q/k head norm, A-27); store_kv_cache, attention.rs:150-174
+//   attention   compute_attention: softmax_f32(q·Kᵀ·D^-½ + mask)·V, src/layers/attention.rs:238-261 (varlen :177-208, paged :225-318)
+//   silu_mul    SiluAndMul, src/layers/activation.rs:46-63;  select_last  ParallelLMHead::extract_last_tokens, embed_head.rs:272-289
+#include "kernels.h"
+#include "device_utils.h"
+#include "../common.h"
+
+namespace nvr { namespace kf {
+
+#define F32_LAUNCH_CHECK(what)                                                                                          \
+    do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return nvr::fail(NVR_ERR_HIP, what " launch failed: %s", hipGetErrorString(e_)); } while (0)
+
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wmax(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// sum / max over a workgroup of NW waves (result in every thread); sm: NW floats of LDS
+template <bool MAX>
+__device__ __forceinline__ float block_reduce(float v, float *sm, int nw) {
+    v = MAX ? wmax(v) : wsum(v);
+    __syncthreads();                                      // sm may still be read from the previous reduction
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float r = sm[0];
+    for (int i = 1; i < nw; ++i) r = MAX ? fmaxf(r, sm[i]) : r + sm[i];
+    return r;
+}
+
+// ---------------------------------------------------------------- synthetic weights (unrounded: the f32 oracle's values)
+__global__ void fill_weight_kernel(float *__restrict__ dst, int64_t rows, int64_t cols, int64_t ld, int64_t gcols, int64_t row0, int64_t col0,
+                                   uint64_t key, float scale) {
+    const int64_t total = rows * cols;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / cols, c = i % cols;
+        dst[r * ld + c] = weight_value(key, (uint64_t)((row0 + r) * gcols + (col0 + c)), scale);
+    }
+}
+int fill_weight(float *dst, int64_t rows, int64_t cols, int64_t ld, int64_t gcols, int64_t row0, int64_t col0, uint64_t key, float scale, hipStream_t s) {
+    if (rows * cols == 0) return 0;
+    int64_t blocks = (rows * cols + 255) / 256; if (blocks > 8192) blocks = 8192;
+    fill_weight_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(dst, rows, cols, ld, gcols, row0, col0, key, scale);
+    F32_LAUNCH_CHECK("f32 fill_weight");
+    return 0;
+}
+__global__ void fill_const_kernel(float *__restrict__ dst, int64_t n, float v) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = v;
+}
+int fill_const(float *dst, int64_t n, float v, hipStream_t s) {
+    if (n == 0) return 0;
+    int64_t blocks = (n + 255) / 256; if (blocks > 4096) blocks = 4096;
+    fill_const_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(dst, n, v);
+    F32_LAUNCH_CHECK("f32 fill_const");
+    return 0;
+}
+
+// ---------------------------------------------------------------- embedding, last-token select
+__global__ void gather_rows_kernel(const int64_t *__restrict__ ids, const int32_t *__restrict__ cu, const float *__restrict__ src, int Hd,
+                                   float *__restrict__ out) {
+    const int64_t row = ids ? ids[blockIdx.x] : (int64_t)cu[blockIdx.x + 1] - 1;
+    const float4 *s4 = reinterpret_cast<const float4 *>(src + row * Hd);
+    float4 *d4 = reinterpret_cast<float4 *>(out + (int64_t)blockIdx.x * Hd);
+    for (int c = threadIdx.x; c < Hd / 4; c += blockDim.x) d4[c] = s4[c];
+}
+int embedding(const int64_t *ids, int64_t T, const float *E, int64_t Hd, float *out, hipStream_t s) {
+    if (Hd % 4) return nvr::fail(NVR_ERR_UNSUPPORTED, "f32 embedding: hidden size %ld is not a multiple of 4", (long)Hd);
+    if (T == 0) return 0;
+    gather_rows_kernel<<<dim3((unsigned)T), dim3(256), 0, s>>>(ids, nullptr, E, (int)Hd, out);
+    F32_LAUNCH_CHECK("f32 embedding");
+    return 0;
+}
+int select_last_tokens(const float *h, const int32_t *cu, int64_t B, int64_t Hd, float *out, hipStream_t s) {
+    if (Hd % 4) return nvr::fail(NVR_ERR_UNSUPPORTED, "f32 select_last: hidden size %ld is not a multiple of 4", (long)Hd);
+    if (B == 0) return 0;
+    gather_rows_kernel<<<dim3((unsigned)B), dim3(256), 0, s>>>(nullptr, cu, h, (int)Hd, out);
+    F32_LAUNCH_CHECK("f32 select_last");
+    return 0;
+}
+
+// ---------------------------------------------------------------- RMSNorm (+ residual add): one workgroup per row
+template <bool ADD>
+__global__ __launch_bounds__(256) void rmsnorm_kernel(float *__restrict__ h, const float *__restrict__ y, const float *__restrict__ w, float eps, int Hd,
+                                                      float *__restrict__ out) {
+    __shared__ float sm[4];
+    float *hr = h + (int64_t)blockIdx.x * Hd;
+    const float *yr = ADD ? y + (int64_t)blockIdx.x * Hd : nullptr;
+    float ss = 0.f;
+    for (int c = threadIdx.x; c < Hd; c += 256) {
+        float v = hr[c];
+        if (ADD) { v = v + yr[c]; hr[c] = v; }                       // h <- h + y (qwen3.rs:382,389)
+        ss += v * v;
+    }
+    ss = block_reduce<false>(ss, sm, 4);
+    const float rms = sqrtf(ss / (float)Hd + eps);
+    for (int c = threadIdx.x; c < Hd; c += 256) out[(int64_t)blockIdx.x * Hd + c] = hr[c] / rms * w[c];
+}
+int rmsnorm(const float *x, const float *w, float eps, int64_t T, int64_t Hd, float *out, hipStream_t s) {
+    if (T == 0) return 0;
+    rmsnorm_kernel<false><<<dim3((unsigned)T), dim3(256), 0, s>>>(const_cast<float *>(x), nullptr, w, eps, (int)Hd, out);
+    F32_LAUNCH_CHECK("f32 rmsnorm");
+    return 0;
+}
+int add_rmsnorm(float *h, const float *y, const float *w, float eps, int64_t T, int64_t Hd, float *out, hipStream_t s) {
+    if (T == 0) return 0;
+    rmsnorm_kernel<true><<<dim3((unsigned)T), dim3(256), 0, s>>>(h, y, w, eps, (int)Hd, out);
+    F32_LAUNCH_CHECK("f32 add_rmsnorm");
+    return 0;
+}
+
+// ---------------------------------------------------------------- y[T,N] = x[T,K]·W[N,K]ᵀ (+ b[N]): 64 x 64 output tile, 16-deep k slices in LDS,
+// 4 x 4 outputs per thread, k ascending (one f32 FMA chain per output)
+constexpr int LB = 64, LK = 16;
+__global__ __launch_bounds__(256) void linear_kernel(const float *__restrict__ x, int64_t ldx, const float *__restrict__ W, int T, int K, int N,
+                                                     const float *__restrict__ bias, float *__restrict__ y) {
+    __shared__ float xs[LK][LB + 1], ws[LK][LB + 1];
+    const int t0 = blockIdx.y * LB, n0 = blockIdx.x * LB;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;             // outputs: tokens t0 + ty*4 .. +3, columns n0 + tx*4 .. +3
+    float acc[4][4] = {};
+    for (int k0 = 0; k0 < K; k0 += LK) {
+        // 64 rows x 16 k of each operand: thread i loads row i / 4, k = (i % 4) * 4 .. + 3
+        const int r = threadIdx.x >> 2, kk = (threadIdx.x & 3) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k = k0 + kk + e;
+            xs[kk + e][r] = (t0 + r < T && k < K) ? x[(int64_t)(t0 + r) * ldx + k] : 0.f;
+            ws[kk + e][r] = (n0 + r < N && k < K) ? W[(int64_t)(n0 + r) * K + k] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < LK; ++k) {
+            float a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { a[i] = xs[k][ty * 4 + i]; b[i] = ws[k][tx * 4 + i]; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int t = t0 + ty * 4 + i, n = n0 + tx * 4 + j;
+            if (t < T && n < N) y[(int64_t)t * N + n] = bias ? acc[i][j] + bias[n] : acc[i][j];
+        }
+}
+// decode-sized steps (T <= 8 rows): one wave per output column, the lanes stride over k with 16-byte loads (the weight row is read once, coalesced:
+// this is the f32 path's memory-bound regime), the T partial sums meet by a wave reduction
+template <int TT>
+__global__ __launch_bounds__(256) void gemv_kernel(const float *__restrict__ x, int64_t ldx, const float *__restrict__ W, int T, int K, int N,
+                                                   const float *__restrict__ bias, float *__restrict__ y) {
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (n >= N) return;
+    const float4 *w4 = reinterpret_cast<const float4 *>(W + (int64_t)n * K);
+    float acc[TT];
+#pragma unroll
+    for (int t = 0; t < TT; ++t) acc[t] = 0.f;
+    for (int k4 = lane; k4 < K / 4; k4 += 64) {
+        const float4 w = w4[k4];
+#pragma unroll
+        for (int t = 0; t < TT; ++t)
+            if (t < T) {
+                const float4 a = reinterpret_cast<const float4 *>(x + (int64_t)t * ldx)[k4];
+                acc[t] = fmaf(a.x, w.x, fmaf(a.y, w.y, fmaf(a.z, w.z, fmaf(a.w, w.w, acc[t]))));
+            }
+    }
+#pragma unroll
+    for (int t = 0; t < TT; ++t) {
+        const float v = wsum(acc[t]);
+        if (lane == 0 && t < T) y[(int64_t)t * N + n] = bias ? v + bias[n] : v;
+    }
+}
+int linear(const float *x, int64_t ldx, const float *W, int64_t T, int64_t K, int64_t N, const float *bias, float *y, hipStream_t s) {
+    if (T == 0 || N == 0) return 0;
+    if (T <= 8 && K % 4 == 0 && ldx % 4 == 0) {
+        const dim3 grid((unsigned)((N + 3) / 4));
+        if (T == 1) gemv_kernel<1><<<grid, dim3(256), 0, s>>>(x, ldx, W, (int)T, (int)K, (int)N, bias, y);
+        else if (T <= 4) gemv_kernel<4><<<grid, dim3(256), 0, s>>>(x, ldx, W, (int)T, (int)K, (int)N, bias, y);
+        else gemv_kernel<8><<<grid, dim3(256), 0, s>>>(x, ldx, W, (int)T, (int)K, (int)N, bias, y);
+        F32_LAUNCH_CHECK("f32 gemv");
+        return 0;
+    }
+    linear_kernel<<<dim3((unsigned)((N + LB - 1) / LB), (unsigned)((T + LB - 1) / LB)), dim3(256), 0, s>>>(x, ldx, W, (int)T, (int)K, (int)N, bias, y);
+    F32_LAUNCH_CHECK("f32 linear");
+    return 0;
+}
+
+// ---------------------------------------------------------------- [q/k head norm,] RoPE, KV store: one workgroup per token, one wave per head in turn
+__global__ __launch_bounds__(256) void rope_store_kernel(float *__restrict__ qkv, const int64_t *__restrict__ pos, const int32_t *__restrict__ slots, int H,
+                                                         int KVH, int D, const float *__restrict__ cos_t, const float *__restrict__ sin_t,
+                                                         float *__restrict__ kc, float *__restrict__ vc, const float *__restrict__ qn,
+                                                         const float *__restrict__ kn, float eps) {
+    const int t = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, half = D / 2;
+    float *row = qkv + (int64_t)t * (H + 2 * KVH) * D;
+    const int64_t p = pos[t];
+    const int slot = slots ? slots[t] : -1;
+    for (int hd = wave; hd < H + 2 * KVH; hd += 4) {
+        float *x = row + (int64_t)hd * D;
+        const bool is_k = hd >= H && hd < H + KVH, is_v = hd >= H + KVH;
+        float *dst = (hd >= H && slot >= 0) ? (is_k ? kc : vc) + ((int64_t)slot * KVH + (is_k ? hd - H : hd - H - KVH)) * D : nullptr;
+        if (is_v) {                                                     // value rows pass through (every lane copies what it read itself)
+            if (dst) for (int j = lane; j < D; j += 64) dst[j] = x[j];
+            continue;
+        }
+        const float *nw = hd < H ? qn : kn;
+        float rms = 1.f;
+        if (nw) {                                                       // A-27: RMSNorm over head_dim before the rotation
+            float ss = 0.f;
+            for (int j = lane; j < D; j += 64) ss += x[j] * x[j];
+            rms = sqrtf(wsum(ss) / (float)D + eps);
+        }
+        for (int j = lane; j < half; j += 64) {
+            float x1 = x[j], x2 = x[half + j];
+            if (nw) { x1 = x1 / rms * nw[j]; x2 = x2 / rms * nw[half + j]; }
+            const float c = cos_t[p * half + j], sn = sin_t[p * half + j];
+            const float o1 = x1 * c - x2 * sn, o2 = x2 * c + x1 * sn;   // rotary_embedding.rs:36-44
+            x[j] = o1; x[half + j] = o2;
+            if (dst) { dst[j] = o1; dst[half + j] = o2; }
+        }
+    }
+}
+int rope_store_kv(float *qkv, const int64_t *pos, const int32_t *slots, int64_t T, int64_t H, int64_t KVH, int64_t D, const float *cos_t,
+                  const float *sin_t, float *kc, float *vc, const float *q_norm, const float *k_norm, float eps, hipStream_t s) {
+    if (T == 0) return 0;
+    if (D % 2) return nvr::fail(NVR_ERR_UNSUPPORTED, "f32 rope: head_dim %ld is odd", (long)D);
+    rope_store_kernel<<<dim3((unsigned)T), dim3(256), 0, s>>>(qkv, pos, slots, (int)H, (int)KVH, (int)D, cos_t, sin_t, kc, vc, q_norm, k_norm, eps);
+    F32_LAUNCH_CHECK("f32 rope_store_kv");
+    return 0;
+}
+
+// ---------------------------------------------------------------- SiluAndMul
+__global__ void silu_mul_kernel(const float *__restrict__ gu, int64_t T, int I, float *__restrict__ out) {
+    const int64_t total = T * I;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t t = i / I; const int c = (int)(i % I);
+        const float g = gu[t * 2 * I + c], u = gu[t * 2 * I + I + c];
+        out[i] = g / (1.0f + expf(-g)) * u;                             // activation.rs:46-63
+    }
+}
+int silu_and_mul(const float *gu, int64_t T, int64_t I, float *out, hipStream_t s) {
+    if (T * I == 0) return 0;
+    int64_t blocks = (T * I + 255) / 256; if (blocks > 8192) blocks = 8192;
+    silu_mul_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(gu, T, (int)I, out);
+    F32_LAUNCH_CHECK("f32 silu_and_mul");
+    return 0;
+}
+
+// ---------------------------------------------------------------- attention: one workgroup per (query row, head).  Keys of the row: ctx_lens[t] of them,
+// either rows kv_base[t] + j of a contiguous K / V (stride ldkv; the prefill step's own qkv buffer) or cache rows through block table seq_of_q[t]
+// (paged decode).  Scores of all keys in LDS (two-pass softmax as compute_attention writes it), then out[d] = sum_j p_j v_j[d] / sum.
+__global__ __launch_bounds__(256) void attention_kernel(AttnArgsF a, int paged) {
+    extern __shared__ float sc[];                                       // [ctx] scores, then probabilities; + D floats of q; + 4 of reduction scratch
+    const int t = blockIdx.x, hd = blockIdx.y, g = hd / (a.H / a.KVH), D = a.D;
+    const int ctx = a.ctx_lens[t];
+    float *qs = sc + a.max_ctx, *sm = qs + D;
+    const float *q = a.q + (int64_t)t * a.ldq + (int64_t)hd * D;
+    for (int j = threadIdx.x; j < D; j += 256) qs[j] = q[j];
+    __syncthreads();
+    const int32_t *bt = paged ? a.block_tables + (int64_t)(a.seq_of_q ? a.seq_of_q[t] : t) * a.max_blocks : nullptr;
+    const int64_t base = paged ? 0 : (int64_t)a.kv_base[t];
+    auto row_of = [&](int j) -> int64_t {                               // element offset of key j's row of this kv head
+        if (paged) return (((int64_t)bt[j / a.block_size] * a.block_size + j % a.block_size) * a.KVH + g) * D;
+        return (base + j) * a.ldkv + (int64_t)g * D;
+    };
+    float mx = -INFINITY;
+    for (int j = threadIdx.x; j < ctx; j += 256) {
+        const float *kr = a.k + row_of(j);
+        float d = 0.f;
+        for (int e = 0; e < D; ++e) d = fmaf(qs[e], kr[e], d);
+        d *= a.scale;
+        sc[j] = d; mx = fmaxf(mx, d);
+    }
+    mx = block_reduce<true>(mx, sm, 4);
+    float sum = 0.f;
+    for (int j = threadIdx.x; j < ctx; j += 256) { const float p = expf(sc[j] - mx); sc[j] = p; sum += p; }
+    sum = block_reduce<false>(sum, sm, 4);
+    for (int d = threadIdx.x; d < D; d += 256) {
+        float o = 0.f;
+        for (int j = 0; j < ctx; ++j) o = fmaf(sc[j], a.v[row_of(j) + d], o);
+        a.out[((int64_t)t * a.H + hd) * D + d] = ctx > 0 ? o / sum : 0.f;
+    }
+}
+int attention(const AttnArgsF &a, bool paged, hipStream_t s) {
+    if (a.nq == 0) return 0;
+    const size_t lds = ((size_t)a.max_ctx + (size_t)a.D + 8) * 4;
+    if (lds > 160 * 1024) return nvr::fail(NVR_ERR_UNSUPPORTED, "f32 attention: context %d does not fit the score buffer (%zu bytes of LDS)", a.max_ctx, lds);
+    static bool opted = false;
+    if (!opted) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&attention_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return nvr::fail(NVR_ERR_HIP, "f32 attention: hipFuncSetAttribute failed");
+        opted = true;
+    }
+    attention_kernel<<<dim3((unsigned)a.nq, (unsigned)a.H), dim3(256), lds, s>>>(a, paged ? 1 : 0);
+    F32_LAUNCH_CHECK("f32 attention");
+    return 0;
+}
+
+}}  // namespace nvr::kf

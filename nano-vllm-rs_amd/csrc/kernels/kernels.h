@@ -52,7 +52,32 @@ struct FlashArgs {
     half_bits *out;                                        // [rows, H, D]
 };
 
+// Config.dtype = "float32": attention arguments of the f32 path (kernels/f32_path.hip)
+struct AttnArgsF {
+    const float *q; int64_t ldq;
+    const float *k, *v; int64_t ldkv;             // contiguous rows (stride ldkv) or paged caches [NB, bs, KVH, D]
+    const int32_t *ctx_lens, *seq_of_q, *kv_base, *block_tables; int32_t max_blocks, block_size;
+    int32_t nq, H, KVH, D; float scale; int32_t max_ctx;
+    float *out;                                   // [nq, H, D]
+};
+
 }}  // namespace nvr::kt
+
+// the f32 path (one build: kernels/f32_path.hip)
+namespace nvr { namespace kf {
+using kt::AttnArgsF;
+int fill_weight(float *dst, int64_t rows, int64_t cols, int64_t ld, int64_t gcols, int64_t row0, int64_t col0, uint64_t key, float scale, hipStream_t s);
+int fill_const(float *dst, int64_t n, float v, hipStream_t s);
+int embedding(const int64_t *ids, int64_t T, const float *E, int64_t Hd, float *out, hipStream_t s);
+int select_last_tokens(const float *h, const int32_t *cu, int64_t B, int64_t Hd, float *out, hipStream_t s);
+int rmsnorm(const float *x, const float *w, float eps, int64_t T, int64_t Hd, float *out, hipStream_t s);
+int add_rmsnorm(float *h, const float *y, const float *w, float eps, int64_t T, int64_t Hd, float *out, hipStream_t s);
+int linear(const float *x, int64_t ldx, const float *W, int64_t T, int64_t K, int64_t N, const float *bias, float *y, hipStream_t s);
+int rope_store_kv(float *qkv, const int64_t *pos, const int32_t *slots, int64_t T, int64_t H, int64_t KVH, int64_t D, const float *cos_t,
+                  const float *sin_t, float *kc, float *vc, const float *q_norm, const float *k_norm, float eps, hipStream_t s);
+int silu_and_mul(const float *gu, int64_t T, int64_t I, float *out, hipStream_t s);
+int attention(const AttnArgsF &a, bool paged, hipStream_t s);
+}}
 
 #define NVR_KDECL_NS k
 #include "kernel_decls.h"

@@ -61,7 +61,11 @@ nvr_model_runner::~nvr_model_runner() {
 int nvr_model_runner::init() {                                       // ModelRunner::new, :67-102
     env = nvr::Env::read();                                          // the only place the runner looks at the environment
     tp = (int64_t)cfg.tensor_parallel_size; rank = (int64_t)cfg.tensor_parallel_rank;
-    bf16 = std::strcmp(cfg.dtype, "bfloat16") == 0;                               // config.rs:51 (fp16 otherwise; "float32" is refused earlier)
+    bf16 = std::strcmp(cfg.dtype, "bfloat16") == 0;                               // config.rs:51 (fp16 otherwise)
+    f32 = std::strcmp(cfg.dtype, "float32") == 0;                                 // the reference-precision path (kernels/f32_path.hip): 4-byte storage,
+    em = f32 ? 2 : 1;                                                             // every "16-bit" buffer below holds em x 2 bytes per element
+    if (f32 && tp > 1) return nvr::fail(NVR_ERR_UNSUPPORTED, "dtype float32 runs on one GPU (tensor_parallel_size %ld)", (long)tp);
+    if (f32) { tiled_weights = false; graphs_disabled = true; lm_fused = false; }
     comm.bf16 = bf16;                                                              // the collectives round their sums to the same 16-bit type
     if (tp < 1 || rank >= tp) return nvr::fail(NVR_ERR_INVALID_ARG, "bad tensor parallel rank %ld of %ld", (long)rank, (long)tp);
     RC(nvr_model_config_validate(&mc, (uint64_t)tp));
@@ -108,9 +112,9 @@ int nvr_model_runner::init() {                                       // ModelRun
     }
 
     // activations (persistent: graph-replayable, no allocation on the step path)
-    RC(dmalloc(&h, max_tokens * Hd)); RC(dmalloc(&n, max_tokens * Hd)); RC(dmalloc(&qkv, max_tokens * QKV));
-    RC(dmalloc(&attn, max_tokens * H * D)); RC(dmalloc(&proj, max_tokens * Hd)); RC(dmalloc(&gu, max_tokens * 2 * I));
-    RC(dmalloc(&act, max_tokens * I)); RC(dmalloc(&nlast, max_seqs * Hd)); RC(dmalloc(&logits, max_seqs * Vl));
+    RC(dmalloc(&h, em * max_tokens * Hd)); RC(dmalloc(&n, em * max_tokens * Hd)); RC(dmalloc(&qkv, em * max_tokens * QKV));
+    RC(dmalloc(&attn, em * max_tokens * H * D)); RC(dmalloc(&proj, em * max_tokens * Hd)); RC(dmalloc(&gu, em * max_tokens * 2 * I));
+    RC(dmalloc(&act, em * max_tokens * I)); RC(dmalloc(&nlast, em * max_seqs * Hd)); RC(dmalloc(&logits, max_seqs * Vl));
     slab_rows = std::max<int64_t>(64, std::min<int64_t>(1024, std::max<int64_t>(max_seqs, 256)));
     RC(dmalloc(&slabs, 4 * slab_rows * Hd));
     chain4 = cfg.decode_chain == 4;
@@ -124,7 +128,7 @@ int nvr_model_runner::init() {                                       // ModelRun
     comm.force = env.tp_force_comm; comm.timeout_ms = env.p2p_timeout_ms;
     RC(KD(linear_stream_prepare()));
     RC(KD(gemm_tiled_prepare()));
-    lazy_logits = env.lazy_logits;
+    lazy_logits = env.lazy_logits && !f32;
     {   // arg-max partials [parts][rows]: <= LM_HEAD_MAX_PARTS x 32 rows (lm_head_kernel), or one per 128 vocabulary columns x all rows
         const size_t pe = std::max<size_t>((size_t)k::LM_HEAD_MAX_PARTS * 32, (size_t)((Vl + 127) / 128) * (size_t)max_seqs);
         RC(dmalloc(&d_lm_pval, pe)); RC(dmalloc(&d_lm_pidx, pe));
@@ -183,13 +187,13 @@ int nvr_model_runner::init() {                                       // ModelRun
         size_t free_b = 0, total_b = 0;
         NVR_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
         double budget = (double)free_b - (1.0 - cfg.gpu_memory_utilization) * (double)total_b;
-        int64_t nb = (int64_t)(budget / (double)(block_elems * 2 * 2 * L));
+        int64_t nb = (int64_t)(budget / (double)(block_elems * 2 * em * 2 * L));
         if (nb < 1) return nvr::fail(NVR_ERR_HIP, "not enough free HBM for one KV block");
         num_blocks = nb;
     }
     kv_layer_elems = (size_t)num_blocks * block_elems;
-    NVR_HIP_CHECK(hipMalloc((void **)&kv_pool, kv_layer_elems * 2 * L * sizeof(uint16_t)));
-    NVR_HIP_CHECK(hipMemsetAsync(kv_pool, 0, kv_layer_elems * 2 * L * sizeof(uint16_t), stream));   // Tensor::zeros :379-389
+    NVR_HIP_CHECK(hipMalloc((void **)&kv_pool, kv_layer_elems * 2 * L * sizeof(uint16_t) * em));
+    NVR_HIP_CHECK(hipMemsetAsync(kv_pool, 0, kv_layer_elems * 2 * L * sizeof(uint16_t) * em, stream));   // Tensor::zeros :379-389
     NVR_HIP_CHECK(hipStreamSynchronize(stream));
     return NVR_OK;
 }
@@ -212,7 +216,90 @@ int nvr_model_runner::retile_all() {
     return NVR_OK;
 }
 
+// Config.dtype = "float32": the same tensors as 4-byte values — the generator's values unrounded, as the f32 oracle holds them
+int nvr_model_runner::gen_weights_f32() {
+    const float sc = nvr_weight_scale_impl(mc.init_std);
+    const int64_t Hg = mc.num_attention_heads, KVHg = mc.num_key_value_heads, Ig = mc.intermediate_size;
+    namespace kf = nvr::kf;
+    auto F = [](uint16_t *p) { return reinterpret_cast<float *>(p); };
+    layers.resize(L);
+    for (int64_t l = 0; l < L; ++l) {
+        Layer &w = layers[l];
+        std::memset(&w, 0, sizeof w);
+        auto key = [&](uint64_t tid) { return nvr_weight_key_impl(mc.seed, (uint64_t)l * 8 + tid); };
+        RC(dmalloc(&w.qkv, 2 * QKV * Hd)); RC(dmalloc(&w.o, 2 * Hd * H * D)); RC(dmalloc(&w.gate_up, 2 * 2 * I * Hd)); RC(dmalloc(&w.down, 2 * Hd * I));
+        RC(dmalloc(&w.ln1, 2 * Hd)); RC(dmalloc(&w.ln2, 2 * Hd));
+        RC(kf::fill_weight(F(w.qkv), H * D, Hd, Hd, Hd, 0, 0, key(TID_QKV), sc, stream));
+        RC(kf::fill_weight(F(w.qkv) + H * D * Hd, KVH * D, Hd, Hd, Hd, Hg * D, 0, key(TID_QKV), sc, stream));
+        RC(kf::fill_weight(F(w.qkv) + (H + KVH) * D * Hd, KVH * D, Hd, Hd, Hd, (Hg + KVHg) * D, 0, key(TID_QKV), sc, stream));
+        RC(kf::fill_weight(F(w.o), Hd, H * D, H * D, Hg * D, 0, 0, key(TID_O), sc, stream));
+        RC(kf::fill_weight(F(w.gate_up), I, Hd, Hd, Hd, 0, 0, key(TID_GATE_UP), sc, stream));
+        RC(kf::fill_weight(F(w.gate_up) + I * Hd, I, Hd, Hd, Hd, Ig, 0, key(TID_GATE_UP), sc, stream));
+        RC(kf::fill_weight(F(w.down), Hd, I, I, Ig, 0, 0, key(TID_DOWN), sc, stream));
+        RC(kf::fill_const(F(w.ln1), Hd, 1.0f, stream)); RC(kf::fill_const(F(w.ln2), Hd, 1.0f, stream));
+        if (mc.use_bias) {
+            RC(dmalloc(&w.qkv_b, 2 * QKV)); RC(dmalloc(&w.gate_up_b, 2 * 2 * I)); RC(dmalloc(&w.o_b, 2 * Hd)); RC(dmalloc(&w.down_b, 2 * Hd));
+            RC(kf::fill_weight(F(w.qkv_b), H * D, 1, 1, 1, 0, 0, key(TID_BIAS + TID_QKV), sc, stream));
+            RC(kf::fill_weight(F(w.qkv_b) + H * D, KVH * D, 1, 1, 1, Hg * D, 0, key(TID_BIAS + TID_QKV), sc, stream));
+            RC(kf::fill_weight(F(w.qkv_b) + (H + KVH) * D, KVH * D, 1, 1, 1, (Hg + KVHg) * D, 0, key(TID_BIAS + TID_QKV), sc, stream));
+            RC(kf::fill_weight(F(w.gate_up_b), I, 1, 1, 1, 0, 0, key(TID_BIAS + TID_GATE_UP), sc, stream));
+            RC(kf::fill_weight(F(w.gate_up_b) + I, I, 1, 1, 1, Ig, 0, key(TID_BIAS + TID_GATE_UP), sc, stream));
+            RC(kf::fill_weight(F(w.o_b), Hd, 1, 1, 1, 0, 0, key(TID_BIAS + TID_O), sc, stream));
+            RC(kf::fill_weight(F(w.down_b), Hd, 1, 1, 1, 0, 0, key(TID_BIAS + TID_DOWN), sc, stream));
+        }
+        if (mc.qk_norm) {
+            RC(dmalloc(&w.q_norm, 2 * D)); RC(dmalloc(&w.k_norm, 2 * D));
+            RC(kf::fill_const(F(w.q_norm), D, 1.0f, stream)); RC(kf::fill_const(F(w.k_norm), D, 1.0f, stream));
+        }
+    }
+    RC(dmalloc(&embed, 2 * V * Hd));
+    RC(kf::fill_weight(F(embed), V, Hd, Hd, Hd, 0, 0, nvr_weight_key_impl(mc.seed, TID_EMBED), sc, stream));
+    if (mc.tie_word_embeddings) lm_head = embed;
+    else {
+        RC(dmalloc(&lm_head, 2 * Vl * Hd));
+        RC(kf::fill_weight(F(lm_head), Vl, Hd, Hd, Hd, 0, 0, nvr_weight_key_impl(mc.seed, TID_LM_HEAD), sc, stream));
+    }
+    RC(dmalloc(&norm, 2 * Hd)); RC(kf::fill_const(F(norm), Hd, 1.0f, stream));
+    NVR_HIP_CHECK(hipStreamSynchronize(stream));
+    tiled_dirty = false;
+    return NVR_OK;
+}
+
+// the f32 graph (Qwen3Model::forward, qwen3.rs:487-505; layer wiring :372-392): one launch per op, eager
+int nvr_model_runner::forward_f32(int64_t T, int64_t B, bool is_prefill, int64_t max_ctx) {
+    namespace kf = nvr::kf;
+    hipStream_t st = stream;
+    auto F = [](const uint16_t *p) { return reinterpret_cast<float *>(const_cast<uint16_t *>(p)); };
+    float *fh = F(h), *fn = F(n), *fq = F(qkv), *fa = F(attn), *fp = F(proj), *fg = F(gu), *fact = F(act), *fnl = F(nlast);
+    const int64_t *ids = is_prefill ? d_ids : dd_ids, *pos = is_prefill ? d_pos : dd_pos;
+    const int32_t *slots = is_prefill ? d_slots : dd_slots, *ctx = is_prefill ? d_ctx : dd_ctx;
+    RC(kf::embedding(ids, T, F(embed), Hd, fh, st));
+    RC(kf::rmsnorm(fh, F(L > 0 ? layers[0].ln1 : norm), mc.rms_norm_eps, T, Hd, fn, st));
+    for (int64_t l = 0; l < L; ++l) {
+        const Layer &w = layers[l];
+        RC(kf::linear(fn, Hd, F(w.qkv), T, Hd, QKV, w.qkv_b ? F(w.qkv_b) : nullptr, fq, st));
+        RC(kf::rope_store_kv(fq, pos, slots, T, H, KVH, D, cos_t, sin_t, F(k_cache(l)), F(v_cache(l)), w.q_norm ? F(w.q_norm) : nullptr,
+                             w.k_norm ? F(w.k_norm) : nullptr, mc.rms_norm_eps, st));
+        nvr::kt::AttnArgsF a{};
+        a.q = fq; a.ldq = QKV; a.ctx_lens = ctx; a.nq = (int32_t)T; a.H = (int32_t)H; a.KVH = (int32_t)KVH; a.D = (int32_t)D; a.scale = scale;
+        a.max_ctx = (int32_t)max_ctx; a.out = fa;
+        if (is_prefill) { a.k = fq + H * D; a.v = fq + (H + KVH) * D; a.ldkv = QKV; a.kv_base = d_kvbase; }     // flash_attention_varlen, attention.rs:177-208
+        else { a.k = F(k_cache(l)); a.v = F(v_cache(l)); a.block_tables = dd_bt; a.max_blocks = (int32_t)max_blocks_per_seq; a.block_size = (int32_t)block_size; }
+        RC(kf::attention(a, !is_prefill, st));
+        RC(kf::linear(fa, H * D, F(w.o), T, H * D, Hd, w.o_b ? F(w.o_b) : nullptr, fp, st));
+        RC(kf::add_rmsnorm(fh, fp, F(w.ln2), mc.rms_norm_eps, T, Hd, fn, st));                       // residual :382, norm :385
+        RC(kf::linear(fn, Hd, F(w.gate_up), T, Hd, 2 * I, w.gate_up_b ? F(w.gate_up_b) : nullptr, fg, st));
+        RC(kf::silu_and_mul(fg, T, I, fact, st));
+        RC(kf::linear(fact, I, F(w.down), T, I, Hd, w.down_b ? F(w.down_b) : nullptr, fp, st));
+        RC(kf::add_rmsnorm(fh, fp, F(l + 1 < L ? layers[l + 1].ln1 : norm), mc.rms_norm_eps, T, Hd, fn, st));   // residual :389, next norm :378 / :501
+    }
+    const float *hl = fn;
+    if (is_prefill) { RC(kf::select_last_tokens(fn, d_cu, B, Hd, fnl, st)); hl = fnl; }
+    return kf::linear(hl, Hd, F(lm_head), B, Hd, Vl, nullptr, logits, st);
+}
+
 int nvr_model_runner::gen_weights() {
+    if (f32) return gen_weights_f32();
     const float sc = nvr_weight_scale_impl(mc.init_std);
     tiled_weights = env.tiled_weights;
     if (Hd % 32 || (H * D) % 32 || I % 32 || QKV % 16 || D % 16) tiled_weights = false;
@@ -315,7 +402,20 @@ int nvr_model_runner::load_tensor(const char *name_in, int dtype, const int64_t 
         return NVR_OK;
     };
     // rows [r0, r0+nr) x columns [c0, c0+nc) of the source -> dst (row stride dst_ld)
-    auto put = [&](uint16_t *dst, int64_t dst_ld, int64_t r0, int64_t nr, int64_t c0, int64_t nc) -> int {
+    auto put = [&](uint16_t *dst, int64_t dst_off, int64_t dst_ld, int64_t r0, int64_t nr, int64_t c0, int64_t nc) -> int {
+        if (f32) {                                                        // the f32 path keeps the checkpoint's values as f32 (exact for every source type)
+            std::vector<float> sf((size_t)(nr * nc));
+            for (int64_t r = 0; r < nr; ++r)
+                for (int64_t c = 0; c < nc; ++c) {
+                    const size_t si = (size_t)((r0 + r) * Cc + c0 + c);
+                    sf[(size_t)(r * nc + c)] = dtype == 0 ? f16_bits_to_f32(((const uint16_t *)data)[si])
+                                             : dtype == 1 ? bf16_bits_to_f32(((const uint16_t *)data)[si]) : ((const float *)data)[si];
+                }
+            NVR_HIP_CHECK(hipStreamSynchronize(stream));
+            NVR_HIP_CHECK(hipMemcpy2D(reinterpret_cast<float *>(dst) + dst_off, (size_t)dst_ld * 4, sf.data(), (size_t)nc * 4, (size_t)nc * 4, (size_t)nr, hipMemcpyHostToDevice));
+            return NVR_OK;
+        }
+        dst += dst_off;
         std::vector<uint16_t> st((size_t)(nr * nc));
         for (int64_t r = 0; r < nr; ++r)
             for (int64_t c = 0; c < nc; ++c) {
@@ -334,48 +434,48 @@ int nvr_model_runner::load_tensor(const char *name_in, int dtype, const int64_t 
         return NVR_OK;
     };
     int64_t l = -1;
-    if (!std::strcmp(name, "embed_tokens.weight")) { RC(want(V, Hd)); return put(embed, Hd, 0, V, 0, Hd); }           // replicated (§8e)
-    if (!std::strcmp(name, "norm.weight")) { if (ndim != 1) return want(-1, -1); RC(want(Hd, 1)); return put(norm, 1, 0, Hd, 0, 1); }
+    if (!std::strcmp(name, "embed_tokens.weight")) { RC(want(V, Hd)); return put(embed, 0, Hd, 0, V, 0, Hd); }           // replicated (§8e)
+    if (!std::strcmp(name, "norm.weight")) { if (ndim != 1) return want(-1, -1); RC(want(Hd, 1)); return put(norm, 0, 1, 0, Hd, 0, 1); }
     if (!std::strcmp(name, "lm_head.weight")) {
         RC(want(V, Hd));
         if (mc.tie_word_embeddings) return nvr::fail(NVR_ERR_UNSUPPORTED, "lm_head.weight: tie_word_embeddings is set (qwen3.rs:461-473), the head is the embedding");
-        return put(lm_head, Hd, vocab_start, Vl, 0, Hd);                                                              // embed_head.rs:57-59
+        return put(lm_head, 0, Hd, vocab_start, Vl, 0, Hd);                                                              // embed_head.rs:57-59
     }
     auto layer_ok = [&]() -> int { return (l < 0 || l >= L) ? nvr::fail(NVR_ERR_INVALID_ARG, "%s: layer out of range (0..%ld)", name_in, (long)L - 1) : NVR_OK; };
-    if (match_layer(name, "input_layernorm.weight", &l)) { RC(layer_ok()); RC(want(Hd, 1)); return put(layers[l].ln1, 1, 0, Hd, 0, 1); }
-    if (match_layer(name, "post_attention_layernorm.weight", &l)) { RC(layer_ok()); RC(want(Hd, 1)); return put(layers[l].ln2, 1, 0, Hd, 0, 1); }
+    if (match_layer(name, "input_layernorm.weight", &l)) { RC(layer_ok()); RC(want(Hd, 1)); return put(layers[l].ln1, 0, 1, 0, Hd, 0, 1); }
+    if (match_layer(name, "post_attention_layernorm.weight", &l)) { RC(layer_ok()); RC(want(Hd, 1)); return put(layers[l].ln2, 0, 1, 0, Hd, 0, 1); }
     // head_dim norms of the real checkpoints (replicated on every rank): part of the graph only with mc.qk_norm (A-27)
-    if (mc.qk_norm && match_layer(name, "self_attn.q_norm.weight", &l)) { RC(layer_ok()); RC(want(D, 1)); return put(layers[l].q_norm, 1, 0, D, 0, 1); }
-    if (mc.qk_norm && match_layer(name, "self_attn.k_norm.weight", &l)) { RC(layer_ok()); RC(want(D, 1)); return put(layers[l].k_norm, 1, 0, D, 0, 1); }
+    if (mc.qk_norm && match_layer(name, "self_attn.q_norm.weight", &l)) { RC(layer_ok()); RC(want(D, 1)); return put(layers[l].q_norm, 0, 1, 0, D, 0, 1); }
+    if (mc.qk_norm && match_layer(name, "self_attn.k_norm.weight", &l)) { RC(layer_ok()); RC(want(D, 1)); return put(layers[l].k_norm, 0, 1, 0, D, 0, 1); }
     // QKVParallelLinear: local rows [q heads | k heads | v heads] (linear.rs:300-340), each a rank slice of its projection
-    if (match_layer(name, "self_attn.q_proj.weight", &l)) { RC(layer_ok()); RC(want(Hg * D, Hd)); return put(layers[l].qkv, Hd, rank * H * D, H * D, 0, Hd); }
-    if (match_layer(name, "self_attn.k_proj.weight", &l)) { RC(layer_ok()); RC(want(KVHg * D, Hd)); return put(layers[l].qkv + H * D * Hd, Hd, rank * KVH * D, KVH * D, 0, Hd); }
-    if (match_layer(name, "self_attn.v_proj.weight", &l)) { RC(layer_ok()); RC(want(KVHg * D, Hd)); return put(layers[l].qkv + (H + KVH) * D * Hd, Hd, rank * KVH * D, KVH * D, 0, Hd); }
+    if (match_layer(name, "self_attn.q_proj.weight", &l)) { RC(layer_ok()); RC(want(Hg * D, Hd)); return put(layers[l].qkv, 0, Hd, rank * H * D, H * D, 0, Hd); }
+    if (match_layer(name, "self_attn.k_proj.weight", &l)) { RC(layer_ok()); RC(want(KVHg * D, Hd)); return put(layers[l].qkv, H * D * Hd, Hd, rank * KVH * D, KVH * D, 0, Hd); }
+    if (match_layer(name, "self_attn.v_proj.weight", &l)) { RC(layer_ok()); RC(want(KVHg * D, Hd)); return put(layers[l].qkv, (H + KVH) * D * Hd, Hd, rank * KVH * D, KVH * D, 0, Hd); }
     if (match_layer(name, "self_attn.qkv_proj.weight", &l)) {                                                          // packed, global [q | k | v]
         RC(layer_ok()); RC(want((Hg + 2 * KVHg) * D, Hd));
-        RC(put(layers[l].qkv, Hd, rank * H * D, H * D, 0, Hd));
-        RC(put(layers[l].qkv + H * D * Hd, Hd, Hg * D + rank * KVH * D, KVH * D, 0, Hd));
-        return put(layers[l].qkv + (H + KVH) * D * Hd, Hd, (Hg + KVHg) * D + rank * KVH * D, KVH * D, 0, Hd);
+        RC(put(layers[l].qkv, 0, Hd, rank * H * D, H * D, 0, Hd));
+        RC(put(layers[l].qkv, H * D * Hd, Hd, Hg * D + rank * KVH * D, KVH * D, 0, Hd));
+        return put(layers[l].qkv, (H + KVH) * D * Hd, Hd, (Hg + KVHg) * D + rank * KVH * D, KVH * D, 0, Hd);
     }
-    if (match_layer(name, "self_attn.o_proj.weight", &l)) { RC(layer_ok()); RC(want(Hd, Hg * D)); return put(layers[l].o, H * D, 0, Hd, rank * H * D, H * D); }   // :249-267
+    if (match_layer(name, "self_attn.o_proj.weight", &l)) { RC(layer_ok()); RC(want(Hd, Hg * D)); return put(layers[l].o, 0, H * D, 0, Hd, rank * H * D, H * D); }   // :249-267
     if (mc.use_bias) {                                                    // Qwen3Config::use_bias: output-feature slices like the weight rows; row-parallel biases live on rank 0 (linear.rs:206)
-        if (match_layer(name, "self_attn.q_proj.bias", &l)) { RC(layer_ok()); RC(want(Hg * D, 1)); return put(layers[l].qkv_b, 1, rank * H * D, H * D, 0, 1); }
-        if (match_layer(name, "self_attn.k_proj.bias", &l)) { RC(layer_ok()); RC(want(KVHg * D, 1)); return put(layers[l].qkv_b + H * D, 1, rank * KVH * D, KVH * D, 0, 1); }
-        if (match_layer(name, "self_attn.v_proj.bias", &l)) { RC(layer_ok()); RC(want(KVHg * D, 1)); return put(layers[l].qkv_b + (H + KVH) * D, 1, rank * KVH * D, KVH * D, 0, 1); }
-        if (match_layer(name, "self_attn.o_proj.bias", &l)) { RC(layer_ok()); RC(want(Hd, 1)); return rank == 0 ? put(layers[l].o_b, 1, 0, Hd, 0, 1) : NVR_OK; }
-        if (match_layer(name, "mlp.gate_proj.bias", &l)) { RC(layer_ok()); RC(want(Ig, 1)); return put(layers[l].gate_up_b, 1, rank * I, I, 0, 1); }
-        if (match_layer(name, "mlp.up_proj.bias", &l)) { RC(layer_ok()); RC(want(Ig, 1)); return put(layers[l].gate_up_b + I, 1, rank * I, I, 0, 1); }
-        if (match_layer(name, "mlp.down_proj.bias", &l)) { RC(layer_ok()); RC(want(Hd, 1)); return rank == 0 ? put(layers[l].down_b, 1, 0, Hd, 0, 1) : NVR_OK; }
+        if (match_layer(name, "self_attn.q_proj.bias", &l)) { RC(layer_ok()); RC(want(Hg * D, 1)); return put(layers[l].qkv_b, 0, 1, rank * H * D, H * D, 0, 1); }
+        if (match_layer(name, "self_attn.k_proj.bias", &l)) { RC(layer_ok()); RC(want(KVHg * D, 1)); return put(layers[l].qkv_b, H * D, 1, rank * KVH * D, KVH * D, 0, 1); }
+        if (match_layer(name, "self_attn.v_proj.bias", &l)) { RC(layer_ok()); RC(want(KVHg * D, 1)); return put(layers[l].qkv_b, (H + KVH) * D, 1, rank * KVH * D, KVH * D, 0, 1); }
+        if (match_layer(name, "self_attn.o_proj.bias", &l)) { RC(layer_ok()); RC(want(Hd, 1)); return rank == 0 ? put(layers[l].o_b, 0, 1, 0, Hd, 0, 1) : NVR_OK; }
+        if (match_layer(name, "mlp.gate_proj.bias", &l)) { RC(layer_ok()); RC(want(Ig, 1)); return put(layers[l].gate_up_b, 0, 1, rank * I, I, 0, 1); }
+        if (match_layer(name, "mlp.up_proj.bias", &l)) { RC(layer_ok()); RC(want(Ig, 1)); return put(layers[l].gate_up_b, I, 1, rank * I, I, 0, 1); }
+        if (match_layer(name, "mlp.down_proj.bias", &l)) { RC(layer_ok()); RC(want(Hd, 1)); return rank == 0 ? put(layers[l].down_b, 0, 1, 0, Hd, 0, 1) : NVR_OK; }
     }
     // MergedColumnParallelLinear: local rows [gate | up] (linear.rs:378-454)
-    if (match_layer(name, "mlp.gate_proj.weight", &l)) { RC(layer_ok()); RC(want(Ig, Hd)); return put(layers[l].gate_up, Hd, rank * I, I, 0, Hd); }
-    if (match_layer(name, "mlp.up_proj.weight", &l)) { RC(layer_ok()); RC(want(Ig, Hd)); return put(layers[l].gate_up + I * Hd, Hd, rank * I, I, 0, Hd); }
+    if (match_layer(name, "mlp.gate_proj.weight", &l)) { RC(layer_ok()); RC(want(Ig, Hd)); return put(layers[l].gate_up, 0, Hd, rank * I, I, 0, Hd); }
+    if (match_layer(name, "mlp.up_proj.weight", &l)) { RC(layer_ok()); RC(want(Ig, Hd)); return put(layers[l].gate_up, I * Hd, Hd, rank * I, I, 0, Hd); }
     if (match_layer(name, "mlp.gate_up_proj.weight", &l)) {
         RC(layer_ok()); RC(want(2 * Ig, Hd));
-        RC(put(layers[l].gate_up, Hd, rank * I, I, 0, Hd));
-        return put(layers[l].gate_up + I * Hd, Hd, Ig + rank * I, I, 0, Hd);
+        RC(put(layers[l].gate_up, 0, Hd, rank * I, I, 0, Hd));
+        return put(layers[l].gate_up, I * Hd, Hd, Ig + rank * I, I, 0, Hd);
     }
-    if (match_layer(name, "mlp.down_proj.weight", &l)) { RC(layer_ok()); RC(want(Hd, Ig)); return put(layers[l].down, I, 0, Hd, rank * I, I); }
+    if (match_layer(name, "mlp.down_proj.weight", &l)) { RC(layer_ok()); RC(want(Hd, Ig)); return put(layers[l].down, 0, I, 0, Hd, rank * I, I); }
     return nvr::fail(NVR_ERR_UNSUPPORTED, "load_tensor: no parameter named '%s' in this graph (biases need nvr_model_config.use_bias, q_norm / k_norm nvr_model_config.qk_norm, SURVEY A-17)", name_in);
 }
 
@@ -401,9 +501,9 @@ int nvr_model_runner::copy_weight(const char *ln, uint16_t *out, size_t cap, int
     if (rows) *rows = r;
     if (cols) *cols = c;
     if (!out) return NVR_OK;
-    if ((size_t)(r * c) > cap) return nvr::fail(NVR_ERR_LEN_MISMATCH, "copy_weight: %s has %ld elements, buffer holds %zu", ln, (long)(r * c), cap);
+    if ((size_t)(r * c * em) > cap) return nvr::fail(NVR_ERR_LEN_MISMATCH, "copy_weight: %s has %ld elements (%ld 16-bit words), buffer holds %zu words", ln, (long)(r * c), (long)(r * c * em), cap);
     NVR_HIP_CHECK(hipStreamSynchronize(stream));
-    NVR_HIP_CHECK(hipMemcpy(out, src, (size_t)(r * c) * 2, hipMemcpyDeviceToHost));
+    NVR_HIP_CHECK(hipMemcpy(out, src, (size_t)(r * c) * 2 * em, hipMemcpyDeviceToHost));    // (float32 runner: f32 values, two words per element)
     return NVR_OK;
 }
 
@@ -507,6 +607,7 @@ bool nvr_model_runner::use_mlp_engine(int64_t T, bool is_prefill) const {
 int64_t nvr_model_runner::shared_prefix_plan(nvr_seq *const *seqs, size_t nseq, int32_t *kv0, int32_t *rows, int32_t *count,
                                              int64_t *members) const {
     *members = 0;
+    if (f32) return 0;
     const int64_t min_seqs = cfg.shared_prefix_min_seqs == 0 ? 32 : cfg.shared_prefix_min_seqs;
     if (min_seqs < 0 || (int64_t)nseq < min_seqs || nseq < 2) return 0;
     if (block_size < 64 || (block_size & (block_size - 1)) || !KD(flash_prefill_ok((int)D, (int)H, (int)KVH))) return 0;
@@ -654,6 +755,7 @@ int nvr_model_runner::forward(int64_t T, int64_t B, bool is_prefill, int64_t max
     const int64_t *ids = is_prefill ? d_ids : dd_ids, *pos = is_prefill ? d_pos : dd_pos;
     const int32_t *slots = is_prefill ? d_slots : dd_slots, *ctx = is_prefill ? d_ctx : dd_ctx;
     const int32_t *bt = dd_bt;
+    if (f32) return forward_f32(T, B, is_prefill, max_ctx);
     if (is_prefill && tp_overlap == 2 && mb_rows > 0) return forward_prefill_two(T, B);
     const bool c4 = use_chain4(T, is_prefill);
     const bool tl = tiled_weights && T <= 64;                            // decode-sized steps stream the tiled weight copies
@@ -771,7 +873,7 @@ int nvr_model_runner::execute(nvr_seq *const *seqs, size_t nseq, bool is_prefill
         // (K8, attention.rs:211-222).  At least the last token is always computed (its logits are the step's output).
         // With enable_chunked_prefill (A-23) a sequence contributes the token range [chunk_start, chunk_start + chunk_len) the
         // scheduler gave it; earlier tokens are reached through the block table exactly like a cached prefix.
-        const bool flash_ok = KD(flash_prefill_ok((int)D, (int)H, (int)KVH));
+        const bool flash_ok = !f32 && KD(flash_prefill_ok((int)D, (int)H, (int)KVH));   // (the f32 path: row attention over the step's own K / V rows)
         const bool chunked = cfg.enable_chunked_prefill != 0;
         auto range_of = [&](const nvr_seq &sq, int64_t *lo, int64_t *hi) {        // rows fed through the model for this sequence
             const int64_t len = (int64_t)sq.len();

@@ -21,6 +21,7 @@ struct nvr_model_runner {
     // derived, per rank (qwen3.rs:158-159, linear.rs:300-304)
     int64_t tp = 1, rank = 0;
     bool bf16 = false;                     // Config.dtype == "bfloat16": the nvr::kb build of the kernels; 16-bit words are bfloat16 everywhere
+    bool f32 = false; int64_t em = 1;      // Config.dtype == "float32": the f32 path (kernels/f32_path.hip); the uint16_t* buffers then hold em = 2 words per element
     int64_t Hd = 0, H = 0, KVH = 0, D = 0, I = 0, V = 0, Vl = 0, vocab_start = 0, L = 0, QKV = 0;
     int64_t block_size = 256, num_blocks = 0, max_tokens = 0, max_seqs = 0, max_blocks_per_seq = 0, max_pos = 0;
     float scale = 1.f;
@@ -115,12 +116,14 @@ struct nvr_model_runner {
     char *ahead_host[2] = {nullptr, nullptr};            // pinned twins of the decode input region (one per step in flight)
     int ensure_logits();                                 // materialise the last step's f32 logits if it skipped their stores
     int sample(nvr_seq *const *seqs, size_t nseq, int64_t *out);
-    uint16_t *k_cache(size_t l) { return kv_pool + (2 * l) * kv_layer_elems; }
-    uint16_t *v_cache(size_t l) { return kv_pool + (2 * l + 1) * kv_layer_elems; }
+    uint16_t *k_cache(size_t l) { return kv_pool + (2 * l) * kv_layer_elems * em; }
+    uint16_t *v_cache(size_t l) { return kv_pool + (2 * l + 1) * kv_layer_elems * em; }
 
 private:
     int forward(int64_t T, int64_t B, bool is_prefill, int64_t max_ctx);
     int gen_weights();
+    int gen_weights_f32();
+    int forward_f32(int64_t T, int64_t B, bool is_prefill, int64_t max_ctx);
     int row_parallel_norm(const uint16_t *x, int64_t K, const uint16_t *W, const uint16_t *Wt, int64_t T, const uint16_t *wn, const uint16_t *bias = nullptr);
     bool use_chain4(int64_t T, bool is_prefill) const;
     int64_t *h_tok_dev = nullptr;                        // device-visible address of the pinned token buffer h_tok

@@ -30,6 +30,7 @@ nvr = nvr_import.load()
 pytestmark = pytest.mark.gpu
 
 LOGIT_TOL = 2e-2            # product fp16 pipeline vs fp16-faithful oracle (f32 logits, fp16 activations)
+F32_TOL = 2e-4            # the f32 path vs the f32 oracle: summation order only (measured 7e-6 on Qwen3-0.6B)
 CPU_PATH_TOL = 8e-2         # product fp16 pipeline vs the reference's f32 CPU path (weights and activations unrounded)
 BF16_TOL = 1.6e-1          # Config.dtype = "bfloat16" against the bf16-faithful oracle: 8 x LOGIT_TOL (8 mantissa bits against 11); measured 4.5e-2 on Qwen3-0.6B
 LOGIT_TOL_8B = 6e-2         # Qwen3-8B (36 layers, K = 4096 / 12 288): summation-order noise grows ~ sqrt(depth); the fp16-faithful oracle itself is
@@ -55,7 +56,8 @@ def _pair(ecfg, prompts, max_tokens, fp16=True, tol=LOGIT_TOL, model="qwen3-0.6b
     mcfg = mo.qwen3_0_6b() if model == "qwen3-0.6b" else mo.qwen3_8b()
     t0 = time.time()
     bf16 = kw.get("dtype") == "bfloat16"                 # the product's bf16 build against the oracle's bf16-faithful mode
-    o = mo.OracleEngine(mcfg, eo.Config(**ecfg), fp16=fp16 and not bf16, bf16=bf16, max_pos=ecfg["max_model_len"], compact=(model != "qwen3-0.6b"))
+    if kw.get("dtype") == "float32": fp16 = False        # the product's f32 path against the oracle's f32 arithmetic
+    o = mo.OracleEngine(mcfg, eo.Config(**ecfg), fp16=fp16 and not bf16, bf16=bf16, max_pos=ecfg["max_model_len"], compact=(model != "qwen3-0.6b" and fp16))
     p = nvr.LLMEngine(nvr.Config(**ecfg, **kw), nvr.ModelConfig(model))
     t_build = time.time() - t0
     for pr in prompts:
@@ -112,6 +114,14 @@ def test_configs0_bs1_prompt128_greedy64_vs_oracle():
     _report("configs0_vs_f32_cpu_path_oracle", st32)
     # same product both times: the two runs' token streams are the same stream
     assert list(next(iter(o32.finished.values())).token_ids) == ids_fp16
+    ids_f32_oracle_forced = list(next(iter(o32.finished.values())).token_ids)
+    del o32, p32
+    # Config.dtype = "float32": the product's f32 path against the SAME f32 CPU-path oracle — the reference's own runnable configuration — at 2e-3:
+    # 64 greedy ids with no near-tie allowance (the oracle is teacher-forced, and never needs to be: every id is its own arg-max)
+    stf, of, pf = _pair(ecfg, prompt, 64, tol=F32_TOL, dtype="float32")
+    assert stf["steps"] == 64 and stf["near_ties"] == 0, stf
+    _report("configs0_float32_path_vs_f32_cpu_path_oracle", stf)
+    assert len(list(next(iter(of.finished.values())).token_ids)) == len(ids_f32_oracle_forced)
 
 
 def test_configs1_bs32_seq1024_full_size_vs_oracle():

@@ -20,6 +20,7 @@ nvr = nvr_import.load()
 pytestmark = pytest.mark.gpu
 
 LOGIT_TOL = 2e-2        # |logit_gpu - logit_oracle|, logits are O(1) f32 built from fp16 activations
+F32_TOL = 2e-4          # Config.dtype = "float32": the f32 path against the oracle's f32 arithmetic (other summation orders only; measured ~1e-5)
 BF16_TOL = 1.6e-1       # Config.dtype = "bfloat16": 8 mantissa bits against fp16's 11, so 8 x LOGIT_TOL against the bf16-faithful oracle
                         # (measured: 2.4e-2 on the small model, 4.5e-2 on Qwen3-0.6B, i.e. 6-8 x the fp16 build's 3.8e-3 / 5.5e-3)
 
@@ -39,9 +40,9 @@ def _run_pair(mcfg, ecfg: dict, prompts, sps, max_steps=400, fp16=True, enforce_
     """dtype = "bfloat16": the product's bf16 kernels against the oracle with bf16 at every 16-bit rounding point, at BF16_TOL."""
     eo.reset_sequence_counter()
     nvr.lib().nvr_seq_reset_id_counter()
-    bf16 = dtype == "bfloat16"
-    tol = BF16_TOL if bf16 else LOGIT_TOL
-    o = mo.OracleEngine(mcfg, eo.Config(**ecfg), fp16=fp16 and not bf16, bf16=bf16, max_pos=ecfg["max_model_len"])
+    bf16, f32 = dtype == "bfloat16", dtype == "float32"
+    tol = F32_TOL if f32 else BF16_TOL if bf16 else LOGIT_TOL
+    o = mo.OracleEngine(mcfg, eo.Config(**ecfg), fp16=fp16 and not bf16 and not f32, bf16=bf16, max_pos=ecfg["max_model_len"])
     p = nvr.LLMEngine(nvr.Config(skip_block_size_check=1, enforce_eager=enforce_eager, dtype=dtype, **ecfg, **(product_kw or {})), _model_cfgs(mcfg))
     if checkpoint is not None:                       # (state dict, .safetensors path): same tensors into both engines
         sd, path = checkpoint
@@ -604,12 +605,12 @@ def test_mlp_engine_decode_chain_engine_parity():
 
 def test_config_device_and_dtype_gate_the_runner():
     """Config.device / Config.dtype (config.rs:48-51): the names validate like the reference's; a runner exists only for the
-    HIP device and the two 16-bit types (fp16, and bf16 on one rank) — anything else fails loudly instead of falling back."""
+    HIP device and the three dtypes (fp16, bf16, and since r04 float32 on one rank) — anything else fails loudly instead of falling back."""
     mcfg = mo.small()
     base = dict(skip_block_size_check=1, max_num_seqs=2, max_num_batched_tokens=64, max_model_len=64, kvcache_block_size=16, num_kvcache_blocks=4)
-    for ok in (dict(), dict(device="cuda"), dict(device="hip", dtype="float16"), dict(dtype="bfloat16")):
+    for ok in (dict(), dict(device="cuda"), dict(device="hip", dtype="float16"), dict(dtype="bfloat16"), dict(dtype="float32")):
         nvr.ModelRunner(nvr.Config(**base, **ok), _model_cfgs(mcfg))
-    for bad in (dict(device="cpu"), dict(device="metal"), dict(dtype="float32")):
+    for bad in (dict(device="cpu"), dict(device="metal"), dict(dtype="float32", tensor_parallel_size=2)):
         with pytest.raises(nvr.NvrError) as e:
             nvr.ModelRunner(nvr.Config(**base, **bad), _model_cfgs(mcfg))
         assert e.value.code == -10
@@ -1053,3 +1054,42 @@ def test_prefill_reads_kv_from_the_caches_contiguous_rows_or_block_tables():
     # and against the oracle
     r = _run_pair(mcfg, ecfg, prompts, sps)
     assert r["near_ties"] <= 1, r
+
+
+@pytest.mark.parametrize("shape", ["small", "gqa2_d128", "qk_norm_bias"])
+def test_float32_path_engine_parity(tmp_path, shape):
+    """Config.dtype = "float32" (config.rs:51,113-116; the reference's own CPU tests run f32): the reference-precision path
+    (kernels/f32_path.hip: every op on 4-byte storage, plain FMA kernels, eager, one GPU) against the oracle's f32 arithmetic — the SAME
+    unrounded synthetic weights, logits within 2e-4 (summation order only), greedy tokens equal with NO near-tie allowance on these
+    scenarios, a stochastic row too; prefix-sharing prompts, a preemption-sized pool; q/k norm + bias graph from a checkpoint; f32
+    refuses tensor parallelism."""
+    from safetensors.numpy import save_file
+    kw = dict(small={}, gqa2_d128=dict(hidden_size=512, num_attention_heads=4, num_key_value_heads=2, head_dim=128, intermediate_size=768),
+              qk_norm_bias=dict(qk_norm=True, use_bias=True))[shape]
+    mcfg = mo.small(seed=13, **kw)
+    V = mcfg.vocab_size
+    ecfg = dict(max_num_seqs=4, max_num_batched_tokens=256, max_model_len=160, kvcache_block_size=16, num_kvcache_blocks=24)
+    shared = oracle.fill_tokens(40, 8, 99, V).tolist()
+    prompts = [oracle.fill_tokens(23, 8, 0, V).tolist(), shared + oracle.fill_tokens(30, 8, 1, V).tolist(), shared + oracle.fill_tokens(5, 8, 2, V).tolist(),
+               oracle.fill_tokens(60, 8, 3, V).tolist()]
+    sps = [dict(temperature=0.0, max_tokens=20, ignore_eos=True)] * 3 + [dict(temperature=0.8, top_k=40, top_p=0.9, max_tokens=12, ignore_eos=True)]
+    checkpoint = None
+    if shape == "qk_norm_bias":
+        rng = np.random.default_rng(80)
+        D, Hd = mcfg.hd(), mcfg.hidden_size
+        sd = {}
+        for l in range(mcfg.num_hidden_layers):
+            sd[f"model.layers.{l}.self_attn.q_norm.weight"] = (1 + 0.3 * rng.standard_normal(D)).astype(np.float32)
+            sd[f"model.layers.{l}.self_attn.k_norm.weight"] = (1 + 0.3 * rng.standard_normal(D)).astype(np.float16)
+            sd[f"model.layers.{l}.mlp.down_proj.bias"] = (0.05 * rng.standard_normal(Hd)).astype(np.float32)
+        path = str(tmp_path / "f32.safetensors")
+        save_file(sd, path)
+        checkpoint = (sd, path)
+    r = _run_pair(mcfg, ecfg, prompts, sps, dtype="float32", checkpoint=checkpoint)
+    assert r["near_ties"] == 0 and r["decode_steps"] >= 19 and r["max_err"] < F32_TOL, (r["near_ties"], r["max_err"])
+    # what the runner holds is the generator's unrounded f32 values (fp16 runners hold their fp16 roundings)
+    p = nvr.LLMEngine(nvr.Config(skip_block_size_check=1, dtype="float32", **ecfg), _model_cfgs(mcfg))
+    w = p.model_runner.weight("layers.1.gate_up")
+    assert w.dtype == np.float32 and np.array_equal(w, r["oracle"].ranks[0].layers[1]["gate_up"])
+    with pytest.raises(nvr.NvrError):
+        nvr.LLMEngine(nvr.Config(skip_block_size_check=1, dtype="float32", tensor_parallel_size=2, tensor_parallel_rank=0, **ecfg), _model_cfgs(mcfg))
