@@ -135,6 +135,17 @@ def test_configs1_bs32_seq1024_full_size_vs_oracle():
     _report("configs1_bs32_seq1024", st)
 
 
+def test_configs1_on_the_float32_path_vs_f32_cpu_path_oracle():
+    """BASELINE configs[1]'s workload (32 x 1024-token prompts, then decode) on Config.dtype = "float32" against the oracle's f32 arithmetic — the
+    reference's CPU-path numerics at the benchmark's size: logits within 2e-4 and EVERY greedy id equal (no near-tie allowance needed)."""
+    ecfg = dict(max_num_seqs=32, max_num_batched_tokens=32768, max_model_len=1040, kvcache_block_size=256, num_kvcache_blocks=170)
+    prompts = [nvr.synthetic_tokens(1024, 1, i, V).tolist() for i in range(32)]
+    st, o, p = _pair(ecfg, prompts, 4, tol=F32_TOL, dtype="float32")
+    assert st["steps"] == 4 and st["prefill_steps"] == 1 and st["rows"] == 128
+    assert st["near_ties"] == 0, st
+    _report("configs1_float32_path_vs_f32_cpu_path_oracle", st)
+
+
 def test_configs2_mixed_length_32768_token_prefill_vs_oracle():
     """BASELINE configs[2]: the prefill sweep's lengths in ONE budget-bound batch — 4 x 4096, 2 x 2048, 4 x 1024, 8 x 512,
     8 x 256, 16 x 128 = 32 768 tokens = max_num_batched_tokens (config.rs:58), 42 sequences — last-token logits of every
