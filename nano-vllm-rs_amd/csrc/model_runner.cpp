@@ -283,9 +283,13 @@ int nvr_model_runner::forward_f32(int64_t T, int64_t B, bool is_prefill, int64_t
         nvr::kt::AttnArgsF a{};
         a.q = fq; a.ldq = QKV; a.ctx_lens = ctx; a.nq = (int32_t)T; a.H = (int32_t)H; a.KVH = (int32_t)KVH; a.D = (int32_t)D; a.scale = scale;
         a.max_ctx = (int32_t)max_ctx; a.out = fa;
-        if (is_prefill) { a.k = fq + H * D; a.v = fq + (H + KVH) * D; a.ldkv = QKV; a.kv_base = d_kvbase; }     // flash_attention_varlen, attention.rs:177-208
-        else { a.k = F(k_cache(l)); a.v = F(v_cache(l)); a.block_tables = dd_bt; a.max_blocks = (int32_t)max_blocks_per_seq; a.block_size = (int32_t)block_size; }
-        RC(kf::attention(a, !is_prefill, st));
+        const bool paged = !is_prefill || prefill_paged;                    // decode, or a prefill step that skips cached prefixes / continues a chunked prompt
+        if (!paged) { a.k = fq + H * D; a.v = fq + (H + KVH) * D; a.ldkv = QKV; a.kv_base = d_kvbase; }          // flash_attention_varlen, attention.rs:177-208
+        else {                                                              // ..._with_cache :211-222 / flash_attention_decode :225-235: every key through the block table
+            a.k = F(k_cache(l)); a.v = F(v_cache(l)); a.block_tables = dd_bt; a.max_blocks = (int32_t)max_blocks_per_seq; a.block_size = (int32_t)block_size;
+            if (is_prefill) a.seq_of_q = d_kvbase;
+        }
+        RC(kf::attention(a, paged, st));
         RC(kf::linear(fa, H * D, F(w.o), T, H * D, Hd, w.o_b ? F(w.o_b) : nullptr, fp, st));
         RC(kf::add_rmsnorm(fh, fp, F(w.ln2), mc.rms_norm_eps, T, Hd, fn, st));                       // residual :382, norm :385
         RC(kf::linear(fn, Hd, F(w.gate_up), T, Hd, 2 * I, w.gate_up_b ? F(w.gate_up_b) : nullptr, fg, st));
@@ -879,11 +883,12 @@ int nvr_model_runner::execute(nvr_seq *const *seqs, size_t nseq, bool is_prefill
             const int64_t len = (int64_t)sq.len();
             int64_t a0 = 0, b0 = len;
             if (chunked && sq.chunk_len > 0) { a0 = (int64_t)sq.chunk_start; b0 = a0 + (int64_t)sq.chunk_len; }
-            int64_t c = (cfg.recompute_cached_prefix || !flash_ok) ? 0 : std::min<int64_t>((int64_t)sq.num_cached_tokens, b0 - 1);
-            if (!flash_ok) a0 = 0;                                                // (row-kernel attention has no paged prefill form)
+            const bool paged_ok = flash_ok || f32;                                // (the 16-bit row kernel has no paged prefill form; the f32 path's has)
+            int64_t c = (cfg.recompute_cached_prefix || !paged_ok) ? 0 : std::min<int64_t>((int64_t)sq.num_cached_tokens, b0 - 1);
+            if (!paged_ok) a0 = 0;
             *lo = std::max<int64_t>(a0, std::max<int64_t>(c, 0)); *hi = b0;
         };
-        if (chunked && !flash_ok)
+        if (chunked && !flash_ok && !f32)
             for (size_t b = 0; b < nseq; ++b)
                 if (seqs[b]->chunk_start > 0) return nvr::fail(NVR_ERR_UNSUPPORTED, "chunked prefill needs the paged flash kernel (head_dim 64/128)");
         prefill_paged = false;
@@ -945,7 +950,8 @@ int nvr_model_runner::execute(nvr_seq *const *seqs, size_t nseq, bool is_prefill
                 for (int64_t i = 0; i < n; ++i) pos[T + i] = c0 + i;
                 for (int64_t i = 0; i < n; ++i) ctx[T + i] = (int32_t)(c0 + i + 1);
                 const int32_t cub = cu[b];
-                for (int64_t i = 0; i < n; ++i) kvb[T + i] = cub;
+                if (f32 && prefill_paged) { for (int64_t i = 0; i < n; ++i) kvb[T + i] = (int32_t)b; }   // f32 paged prefill: the row's block table (seq_of_q)
+                else for (int64_t i = 0; i < n; ++i) kvb[T + i] = cub;
                 for (int64_t p = c0; p < end;) {                              // slot(pos) = table[pos / bs] * bs + pos % bs, block by block
                     const int64_t blk = p / bs, stop = std::min(end, (blk + 1) * bs);
                     const int32_t base = (int32_t)((int64_t)s.block_table[blk] * bs - blk * bs);

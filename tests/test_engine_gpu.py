@@ -1056,19 +1056,22 @@ def test_prefill_reads_kv_from_the_caches_contiguous_rows_or_block_tables():
     assert r["near_ties"] <= 1, r
 
 
-@pytest.mark.parametrize("shape", ["small", "gqa2_d128", "qk_norm_bias"])
+@pytest.mark.parametrize("shape", ["small", "gqa2_d128", "qk_norm_bias", "chunked"])
 def test_float32_path_engine_parity(tmp_path, shape):
     """Config.dtype = "float32" (config.rs:51,113-116; the reference's own CPU tests run f32): the reference-precision path
     (kernels/f32_path.hip: every op on 4-byte storage, plain FMA kernels, eager, one GPU) against the oracle's f32 arithmetic — the SAME
     unrounded synthetic weights, logits within 2e-4 (summation order only), greedy tokens equal with NO near-tie allowance on these
     scenarios, a stochastic row too; prefix-sharing prompts, a preemption-sized pool; q/k norm + bias graph from a checkpoint; f32
-    refuses tensor parallelism."""
+    refuses tensor parallelism.  Cached prefixes are skipped and chunked prompts continue through the block tables (the f32 attention kernel's paged
+    form), as on the 16-bit path."""
     from safetensors.numpy import save_file
     kw = dict(small={}, gqa2_d128=dict(hidden_size=512, num_attention_heads=4, num_key_value_heads=2, head_dim=128, intermediate_size=768),
-              qk_norm_bias=dict(qk_norm=True, use_bias=True))[shape]
+              qk_norm_bias=dict(qk_norm=True, use_bias=True), chunked={})[shape]
     mcfg = mo.small(seed=13, **kw)
     V = mcfg.vocab_size
     ecfg = dict(max_num_seqs=4, max_num_batched_tokens=256, max_model_len=160, kvcache_block_size=16, num_kvcache_blocks=24)
+    if shape == "chunked":                                # A-23 on the f32 path: prompts cut by a 48-token budget, later chunks through the block tables
+        ecfg.update(max_num_batched_tokens=48, enable_chunked_prefill=True)
     shared = oracle.fill_tokens(40, 8, 99, V).tolist()
     prompts = [oracle.fill_tokens(23, 8, 0, V).tolist(), shared + oracle.fill_tokens(30, 8, 1, V).tolist(), shared + oracle.fill_tokens(5, 8, 2, V).tolist(),
                oracle.fill_tokens(60, 8, 3, V).tolist()]
