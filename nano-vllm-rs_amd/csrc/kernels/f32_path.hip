@@ -294,16 +294,16 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgsF a, int paged) 
         a.out[((int64_t)t * a.H + hd) * D + d] = ctx > 0 ? o / sum : 0.f;
     }
 }
+// opt the attention kernel in to > 64 KiB of dynamic LDS (runner init: never inside a stream capture)
+int prepare() {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&attention_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        return nvr::fail(NVR_ERR_HIP, "f32 attention: hipFuncSetAttribute failed");
+    return 0;
+}
 int attention(const AttnArgsF &a, bool paged, hipStream_t s) {
     if (a.nq == 0) return 0;
     const size_t lds = ((size_t)a.max_ctx + (size_t)a.D + 8) * 4;
     if (lds > 160 * 1024) return nvr::fail(NVR_ERR_UNSUPPORTED, "f32 attention: context %d does not fit the score buffer (%zu bytes of LDS)", a.max_ctx, lds);
-    static bool opted = false;
-    if (!opted) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&attention_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            return nvr::fail(NVR_ERR_HIP, "f32 attention: hipFuncSetAttribute failed");
-        opted = true;
-    }
     attention_kernel<<<dim3((unsigned)a.nq, (unsigned)a.H), dim3(256), lds, s>>>(a, paged ? 1 : 0);
     F32_LAUNCH_CHECK("f32 attention");
     return 0;

@@ -77,6 +77,7 @@ int rope_store_kv(float *qkv, const int64_t *pos, const int32_t *slots, int64_t 
                   const float *sin_t, float *kc, float *vc, const float *q_norm, const float *k_norm, float eps, hipStream_t s);
 int silu_and_mul(const float *gu, int64_t T, int64_t I, float *out, hipStream_t s);
 int attention(const AttnArgsF &a, bool paged, hipStream_t s);
+int prepare();
 }}
 
 #define NVR_KDECL_NS k

@@ -65,7 +65,7 @@ int nvr_model_runner::init() {                                       // ModelRun
     f32 = std::strcmp(cfg.dtype, "float32") == 0;                                 // the reference-precision path (kernels/f32_path.hip): 4-byte storage,
     em = f32 ? 2 : 1;                                                             // every "16-bit" buffer below holds em x 2 bytes per element
     if (f32 && tp > 1) return nvr::fail(NVR_ERR_UNSUPPORTED, "dtype float32 runs on one GPU (tensor_parallel_size %ld)", (long)tp);
-    if (f32) { tiled_weights = false; graphs_disabled = true; lm_fused = false; }
+    if (f32) { tiled_weights = false; lm_fused = false; RC(nvr::kf::prepare()); }   // (decode steps of the f32 path replay a captured graph like the 16-bit ones)
     comm.bf16 = bf16;                                                              // the collectives round their sums to the same 16-bit type
     if (tp < 1 || rank >= tp) return nvr::fail(NVR_ERR_INVALID_ARG, "bad tensor parallel rank %ld of %ld", (long)rank, (long)tp);
     RC(nvr_model_config_validate(&mc, (uint64_t)tp));
