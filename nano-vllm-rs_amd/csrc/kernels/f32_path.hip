@@ -263,10 +263,11 @@ int silu_and_mul(const float *gu, int64_t T, int64_t I, float *out, hipStream_t 
 // either rows kv_base[t] + j of a contiguous K / V (stride ldkv; the prefill step's own qkv buffer) or cache rows through block table seq_of_q[t]
 // (paged decode).  Scores of all keys in LDS (two-pass softmax as compute_attention writes it), then out[d] = sum_j p_j v_j[d] / sum.
 __global__ __launch_bounds__(256) void attention_kernel(AttnArgsF a, int paged) {
-    extern __shared__ float sc[];                                       // [ctx] scores, then probabilities; + D floats of q; + 4 of reduction scratch
+    extern __shared__ float sc[];                                       // [max_ctx] scores, then probabilities | q [D] | partial outputs [4][D] | 8 of reduction scratch
     const int t = blockIdx.x, hd = blockIdx.y, g = hd / (a.H / a.KVH), D = a.D;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int ctx = a.ctx_lens[t];
-    float *qs = sc + a.max_ctx, *sm = qs + D;
+    float *qs = sc + a.max_ctx, *part = qs + D, *sm = part + 4 * D;
     const float *q = a.q + (int64_t)t * a.ldq + (int64_t)hd * D;
     for (int j = threadIdx.x; j < D; j += 256) qs[j] = q[j];
     __syncthreads();
@@ -276,21 +277,41 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgsF a, int paged) 
         if (paged) return (((int64_t)bt[j / a.block_size] * a.block_size + j % a.block_size) * a.KVH + g) * D;
         return (base + j) * a.ldkv + (int64_t)g * D;
     };
+    // scores: a thread per key (256 keys in flight per workgroup: a decode step has one query row per sequence, so the parallelism has to come from the keys)
     float mx = -INFINITY;
     for (int j = threadIdx.x; j < ctx; j += 256) {
-        const float *kr = a.k + row_of(j);
+        const float4 *kr = reinterpret_cast<const float4 *>(a.k + row_of(j));
         float d = 0.f;
-        for (int e = 0; e < D; ++e) d = fmaf(qs[e], kr[e], d);
+        for (int e = 0; e < D / 4; ++e) { const float4 kk = kr[e]; d = fmaf(qs[4 * e], kk.x, fmaf(qs[4 * e + 1], kk.y, fmaf(qs[4 * e + 2], kk.z, fmaf(qs[4 * e + 3], kk.w, d)))); }
         d *= a.scale;
         sc[j] = d; mx = fmaxf(mx, d);
     }
     mx = block_reduce<true>(mx, sm, 4);
     float sum = 0.f;
     for (int j = threadIdx.x; j < ctx; j += 256) { const float p = expf(sc[j] - mx); sc[j] = p; sum += p; }
-    sum = block_reduce<false>(sum, sm, 4);
+    sum = block_reduce<false>(sum, sm, 4);                              // (its barriers also publish the probabilities)
+    // P.V: wave w takes keys w, w + 4, ...; a lane holds output columns lane, lane + 64, ... (head_dim <= 256); the four partial rows meet in LDS
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int j0 = wave; j0 < ctx; j0 += 4 * 8) {                        // eight of the wave's keys requested before the first FMA
+        float vv[8][4], pp[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int j = j0 + 4 * u;
+            pp[u] = j < ctx ? sc[j] : 0.f;
+            const float *vr = a.v + row_of(j < ctx ? j : ctx - 1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { const int e = lane + 64 * i; vv[u][i] = e < D ? vr[e] : 0.f; }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = fmaf(pp[u], vv[u][i], acc[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int e = lane + 64 * i; if (e < D) part[wave * D + e] = acc[i]; }
+    __syncthreads();
     for (int d = threadIdx.x; d < D; d += 256) {
-        float o = 0.f;
-        for (int j = 0; j < ctx; ++j) o = fmaf(sc[j], a.v[row_of(j) + d], o);
+        const float o = (part[d] + part[D + d]) + (part[2 * D + d] + part[3 * D + d]);
         a.out[((int64_t)t * a.H + hd) * D + d] = ctx > 0 ? o / sum : 0.f;
     }
 }
@@ -302,7 +323,8 @@ int prepare() {
 }
 int attention(const AttnArgsF &a, bool paged, hipStream_t s) {
     if (a.nq == 0) return 0;
-    const size_t lds = ((size_t)a.max_ctx + (size_t)a.D + 8) * 4;
+    if (a.D > 256 || a.D % 4) return nvr::fail(NVR_ERR_UNSUPPORTED, "f32 attention: head_dim %d (multiples of 4 up to 256)", a.D);
+    const size_t lds = ((size_t)a.max_ctx + 5 * (size_t)a.D + 8) * 4;
     if (lds > 160 * 1024) return nvr::fail(NVR_ERR_UNSUPPORTED, "f32 attention: context %d does not fit the score buffer (%zu bytes of LDS)", a.max_ctx, lds);
     attention_kernel<<<dim3((unsigned)a.nq, (unsigned)a.H), dim3(256), lds, s>>>(a, paged ? 1 : 0);
     F32_LAUNCH_CHECK("f32 attention");
