@@ -120,7 +120,7 @@ typedef struct nvr_config {
                                           runner bit for bit), nvr_runner_copy_weight returns its raw 16-bit elements.  "float32" (r04):
                                           the REFERENCE-PRECISION path (kernels/f32_path.hip) — weights (the generator's values
                                           unrounded, or a checkpoint's values exactly), activations and KV cache as f32, plain FMA
-                                          kernels, eager launches, one GPU (tensor_parallel_size > 1: NVR_ERR_UNSUPPORTED); the
+                                          kernels, one GPU (tensor_parallel_size > 1: NVR_ERR_UNSUPPORTED); the
                                           arithmetic of the reference's own CPU path: its logits to ~1e-5.  nvr_runner_copy_weight then
                                           returns f32 values (two 16-bit words per element).  The stateless op entry points
                                           (nvr_linear, nvr_paged_attn_*, ...) take their 16-bit type from nvr_ops_set_dtype */

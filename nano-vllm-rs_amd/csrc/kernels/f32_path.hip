@@ -1,7 +1,7 @@
 // f32_path.hip — Config.dtype = "float32" (reference src/config.rs:51,113-116; the reference's own CPU path computes in f32): every op of the
 // Qwen3 graph on 4-byte storage, as plain FMA kernels.  This is the REFERENCE-PRECISION path of the product — outputs comparable with the
 // reference's f32 CPU path at 1e-3 instead of through 16-bit rounding — not a tuned one: no MFMA (the dense f32 matrix rate of the part is
-// 1/16 of its fp16 rate), no hipGraph, one GPU.  Each kernel cites the reference op it restates, like its 16-bit twin:
+// 1/16 of its fp16 rate), one GPU.  Each kernel cites the reference op it restates, like its 16-bit twin:
 //   embedding   VocabParallelEmbedding::forward, src/layers/embed_head.rs:77-97
 //   rmsnorm     RMSNorm::forward_simple, src/layers/layernorm.rs:58-75; add_rmsnorm: forward_with_residual :170-176
 //   linear      Linear::forward x·Wᵀ(+b), src/layers/linear.rs:12-24
