@@ -434,8 +434,11 @@ NVR_API int nvr_graph_destroy(void *graph_exec);
  * op.  `stream` is a hipStream_t (NULL = default stream). */
 typedef uint16_t nvr_half;
 /* Config.dtype (config.rs:51,113-116) for the stateless entry points below: "float16" | "bfloat16" select the fp16 / bf16 build of the
- * kernels for the CALLING THREAD (thread-local, like nvr_last_error); anything else: NVR_ERR_UNSUPPORTED.  Runners and engines take their
- * type from nvr_config.dtype and are not affected. */
+ * kernels for the CALLING THREAD (thread-local, like nvr_last_error); "float32" (r04) selects the ops of the reference-precision path — the
+ * nvr_half pointers of nvr_embedding, nvr_rmsnorm, nvr_add_rmsnorm, nvr_linear, nvr_rope_store_kv, nvr_qk_norm_rope_store_kv, nvr_silu_and_mul,
+ * nvr_select_last_tokens, nvr_attn_prefill_varlen / _paged, nvr_paged_attn_decode, nvr_fill_weight (unrounded values) and nvr_fill_const then
+ * address f32 elements; the ops that exist only as fused 16-bit kernels answer NVR_ERR_UNSUPPORTED; anything else: NVR_ERR_UNSUPPORTED.
+ * Runners and engines take their type from nvr_config.dtype and are not affected. */
 NVR_API int nvr_ops_set_dtype(const char *dtype);
 NVR_API const char *nvr_ops_dtype(void);
 

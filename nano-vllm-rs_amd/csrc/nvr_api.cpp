@@ -473,28 +473,39 @@ int nvr_graph_destroy(void *exec) { NVR_HIP_CHECK(hipGraphExecDestroy((hipGraphE
 // ------------------------------------------------------------------ stateless ops
 // The 16-bit type of the stateless entry points' buffers: fp16 (default) or bfloat16 — per calling thread, like nvr_last_error.
 // Every kernel exists in both builds (kernels/device_utils.h); KO() picks the namespace per call.
-static thread_local bool g_ops_bf16 = false;
+// "float32" (r04): the ops of the reference-precision path (kernels/f32_path.hip) — the nvr_half pointers then address f32 elements; the ops that
+// exist only as fused 16-bit kernels (nvr_linear_qkv_rope_store, nvr_linear_silu_mul, nvr_lm_head, the *_tiled / split-k / shared-prefix forms,
+// nvr_mlp_engine) answer NVR_ERR_UNSUPPORTED: the f32 graph runs their unfused parts.
+static thread_local bool g_ops_bf16 = false, g_ops_f32 = false;
 #define KO(call) (g_ops_bf16 ? nvr::kb::call : nvr::k::call)
+#define FP(p) reinterpret_cast<float *>(const_cast<nvr_half *>(p))
+#define NO_F32(name) if (g_ops_f32) return nvr::fail(NVR_ERR_UNSUPPORTED, name ": a fused 16-bit kernel; nvr_ops_set_dtype(\"float32\") has its unfused parts")
 int nvr_ops_set_dtype(const char *dtype) {
-    if (dtype && std::strcmp(dtype, "float16") == 0) { g_ops_bf16 = false; return NVR_OK; }
-    if (dtype && std::strcmp(dtype, "bfloat16") == 0) { g_ops_bf16 = true; return NVR_OK; }
-    return nvr::fail(NVR_ERR_UNSUPPORTED, "nvr_ops_set_dtype: '%s' (float16 | bfloat16)", dtype ? dtype : "(null)");
+    if (dtype && std::strcmp(dtype, "float16") == 0) { g_ops_bf16 = false; g_ops_f32 = false; return NVR_OK; }
+    if (dtype && std::strcmp(dtype, "bfloat16") == 0) { g_ops_bf16 = true; g_ops_f32 = false; return NVR_OK; }
+    if (dtype && std::strcmp(dtype, "float32") == 0) { g_ops_bf16 = false; g_ops_f32 = true; return nvr::kf::prepare(); }
+    return nvr::fail(NVR_ERR_UNSUPPORTED, "nvr_ops_set_dtype: '%s' (float16 | bfloat16 | float32)", dtype ? dtype : "(null)");
 }
-const char *nvr_ops_dtype(void) { return g_ops_bf16 ? "bfloat16" : "float16"; }
+const char *nvr_ops_dtype(void) { return g_ops_f32 ? "float32" : g_ops_bf16 ? "bfloat16" : "float16"; }
 int nvr_embedding(const int64_t *ids, int64_t T, const nvr_half *E, int64_t Hd, nvr_half *out, void *s) {
+    if (g_ops_f32) return nvr::kf::embedding(ids, T, FP(E), Hd, FP(out), (hipStream_t)s);
     return KO(embedding(ids, T, E, Hd, out, (hipStream_t)s));
 }
 int nvr_rmsnorm(const nvr_half *x, const nvr_half *w, float eps, int64_t T, int64_t Hd, nvr_half *out, void *s) {
+    if (g_ops_f32) return nvr::kf::rmsnorm(FP(x), FP(w), eps, T, Hd, FP(out), (hipStream_t)s);
     return KO(rmsnorm(x, w, eps, T, Hd, out, (hipStream_t)s));
 }
 int nvr_add_rmsnorm(nvr_half *h, const nvr_half *y, const nvr_half *w, float eps, int64_t T, int64_t Hd, nvr_half *out, void *s) {
+    if (g_ops_f32) return nvr::kf::add_rmsnorm(FP(h), FP(y), FP(w), eps, T, Hd, FP(out), (hipStream_t)s);
     return KO(add_rmsnorm(h, y, w, eps, T, Hd, out, (hipStream_t)s));
 }
 int nvr_linear(const nvr_half *x, int64_t ldx, const nvr_half *W, int64_t T, int64_t K, int64_t N, void *y, int f32, void *s) {
+    if (g_ops_f32) return nvr::kf::linear(FP(x), ldx, FP(W), T, K, N, nullptr, (float *)y, (hipStream_t)s);      // (y is f32 either way)
     return KO(linear(x, ldx, W, T, K, N, y, f32 != 0, (hipStream_t)s));
 }
 int nvr_lm_head(const nvr_half *x, int64_t ldx, const nvr_half *W, int64_t T, int64_t K, int64_t N, float *logits, float *part_val,
                 int32_t *part_idx, int32_t *nparts, void *s) {
+    NO_F32("nvr_lm_head");
     if (!nparts) return nvr::fail(NVR_ERR_INVALID_ARG, "nvr_lm_head: nparts is null");
     return KO(lm_head(x, ldx, W, T, K, N, logits, part_val, part_idx, nparts, (hipStream_t)s, logits != nullptr));
 }
@@ -503,6 +514,7 @@ int nvr_argmax_partials(const float *part_val, const int32_t *part_idx, int32_t 
     return KO(argmax_partials(part_val, part_idx, nparts, T, out_idx, out_val, idx_offset, (hipStream_t)s));
 }
 int nvr_linear_splitk(const nvr_half *x, int64_t ldx, const nvr_half *W, int64_t T, int64_t K, int64_t N, int64_t S, float *slabs, void *s) {
+    NO_F32("nvr_linear_splitk");
     return KO(linear_splitk(x, ldx, W, T, K, N, S, slabs, (hipStream_t)s));
 }
 int nvr_mlp_engine_ok(int64_t T, int64_t Hd, int64_t I) {
@@ -513,71 +525,87 @@ int nvr_mlp_engine_ok(int64_t T, int64_t Hd, int64_t I) {
 size_t nvr_mlp_engine_sync_bytes(void) { return k::mlp_engine_sync_bytes(); }
 int nvr_mlp_engine(const nvr_half *x, int64_t ldx, const nvr_half *gut, const nvr_half *dt, int64_t T, int64_t Hd, int64_t I, nvr_half *act,
                    float *slabs, uint32_t *sync, void *s) {
+    NO_F32("nvr_mlp_engine");
     return KO(mlp_engine(x, ldx, gut, dt, T, Hd, I, act, slabs, sync, (hipStream_t)s));
 }
 int nvr_add_rmsnorm_slabs(nvr_half *h, const float *slabs, int64_t S, const nvr_half *w, float eps, int64_t T, int64_t Hd, nvr_half *out, void *s) {
+    NO_F32("nvr_add_rmsnorm_slabs");
     return KO(add_rmsnorm_slabs(h, slabs, S, w, eps, T, Hd, out, (hipStream_t)s));
 }
 int nvr_linear_tiled(const nvr_half *x, int64_t ldx, const nvr_half *W, const nvr_half *Wt, int64_t T, int64_t K, int64_t N, void *y, int f32,
                      void *s) {
+    NO_F32("nvr_linear_tiled");
     return KO(linear(x, ldx, W, T, K, N, y, f32 != 0, (hipStream_t)s, Wt));
 }
 int nvr_linear_splitk_tiled(const nvr_half *x, int64_t ldx, const nvr_half *W, const nvr_half *Wt, int64_t T, int64_t K, int64_t N, int64_t S,
                             float *slabs, void *s) {
+    NO_F32("nvr_linear_splitk_tiled");
     return KO(linear_splitk(x, ldx, W, T, K, N, S, slabs, (hipStream_t)s, Wt));
 }
 int nvr_linear_silu_mul_tiled(const nvr_half *x, int64_t ldx, const nvr_half *W, const nvr_half *Wt, int64_t T, int64_t K, int64_t I,
                               nvr_half *out, void *s) {
+    NO_F32("nvr_linear_silu_mul_tiled");
     return KO(linear_silu_mul(x, ldx, W, T, K, I, out, (hipStream_t)s, Wt));
 }
 int nvr_linear_qkv_rope_store_tiled(const nvr_half *x, int64_t ldx, const nvr_half *W, const nvr_half *Wt, int64_t T, int64_t K, int64_t H,
                                     int64_t KVH, int64_t D, const int64_t *pos, const int32_t *slots, const float *c, const float *sn,
                                     nvr_half *qkv, nvr_half *kc, nvr_half *vc, void *s) {
+    NO_F32("nvr_linear_qkv_rope_store_tiled");
     return KO(linear_qkv_rope_store(x, ldx, W, T, K, H, KVH, D, pos, slots, c, sn, qkv, kc, vc, (hipStream_t)s, Wt));
 }
 int nvr_lm_head_tiled(const nvr_half *x, int64_t ldx, const nvr_half *W, const nvr_half *Wt, int64_t T, int64_t K, int64_t N, float *logits,
                       float *part_val, int32_t *part_idx, int32_t *nparts, void *s) {
+    NO_F32("nvr_lm_head_tiled");
     if (!nparts) return nvr::fail(NVR_ERR_INVALID_ARG, "nvr_lm_head_tiled: nparts is null");
     return KO(lm_head(x, ldx, W, T, K, N, logits, part_val, part_idx, nparts, (hipStream_t)s, logits != nullptr, Wt));
 }
 int nvr_retile_weight(const nvr_half *src, nvr_half *dst, int64_t N, int64_t K, int mode, int64_t H, int64_t KVH, int64_t D, void *s) {
+    NO_F32("nvr_retile_weight");
     return KO(retile_weight(src, dst, N, K, mode, H, KVH, D, (hipStream_t)s));
 }
 int nvr_linear_add_residual(const nvr_half *x, int64_t ldx, const nvr_half *W, int64_t T, int64_t K, int64_t N, nvr_half *h, void *s) {
+    NO_F32("nvr_linear_add_residual");
     if (!k::gemm256_preferred(T, K, N, ldx))
         return nvr::fail(NVR_ERR_UNSUPPORTED, "nvr_linear_add_residual: T=%ld K=%ld N=%ld is not a shape of the 256x256 prefill GEMM", (long)T, (long)K, (long)N);
     return KO(gemm256_resid(x, ldx, W, T, K, N, h, (hipStream_t)s));
 }
 int nvr_linear_resid(const nvr_half *x, int64_t ldx, const nvr_half *W, const nvr_half *Wt, int64_t T, int64_t K, int64_t N, int64_t S,
                      float *slabs, uint32_t *counters, nvr_half *h, void *s) {
+    NO_F32("nvr_linear_resid");
     return KO(linear_resid(x, ldx, W, T, K, N, S, slabs, counters, h, (hipStream_t)s, Wt));
 }
 int nvr_decode_splitk_slices(int64_t T, int64_t K, int64_t N) { return k::decode_splitk_slices(T, K, N); }
 int nvr_linear_silu_mul_normed(const nvr_half *h, int64_t ldx, const nvr_half *wn, float eps, const nvr_half *W, const nvr_half *Wt, int64_t T,
                                int64_t K, int64_t I, nvr_half *out, void *s) {
+    NO_F32("nvr_linear_silu_mul_normed");
     return KO(linear_silu_mul_normed(h, ldx, wn, eps, W, T, K, I, out, (hipStream_t)s, Wt));
 }
 int nvr_linear_qkv_rope_store_normed(const nvr_half *h, int64_t ldx, const nvr_half *wn, float eps, const nvr_half *W, const nvr_half *Wt,
                                      int64_t T, int64_t K, int64_t H, int64_t KVH, int64_t D, const int64_t *pos, const int32_t *slots,
                                      const float *cos_t, const float *sin_t, nvr_half *qkv, nvr_half *kc, nvr_half *vc, void *s) {
+    NO_F32("nvr_linear_qkv_rope_store_normed");
     return KO(linear_qkv_rope_store_normed(h, ldx, wn, eps, W, T, K, H, KVH, D, pos, slots, cos_t, sin_t, qkv, kc, vc, (hipStream_t)s, Wt));
 }
 int nvr_linear_silu_mul(const nvr_half *x, int64_t ldx, const nvr_half *W, int64_t T, int64_t K, int64_t I, nvr_half *out, void *s) {
+    NO_F32("nvr_linear_silu_mul");
     return KO(linear_silu_mul(x, ldx, W, T, K, I, out, (hipStream_t)s));
 }
 int nvr_linear_qkv_rope_store(const nvr_half *x, int64_t ldx, const nvr_half *W, int64_t T, int64_t K, int64_t H, int64_t KVH,
                               int64_t D, const int64_t *pos, const int32_t *slots, const float *c, const float *sn,
                               nvr_half *qkv, nvr_half *kc, nvr_half *vc, void *s) {
+    NO_F32("nvr_linear_qkv_rope_store");
     return KO(linear_qkv_rope_store(x, ldx, W, T, K, H, KVH, D, pos, slots, c, sn, qkv, kc, vc, (hipStream_t)s));
 }
 int nvr_rope_store_kv(nvr_half *qkv, const int64_t *pos, const int32_t *slots, int64_t T, int64_t H, int64_t KVH, int64_t D,
                       const float *c, const float *sn, nvr_half *kc, nvr_half *vc, void *s) {
+    if (g_ops_f32) return nvr::kf::rope_store_kv(FP(qkv), pos, slots, T, H, KVH, D, c, sn, FP(kc), FP(vc), nullptr, nullptr, 0.f, (hipStream_t)s);
     return KO(rope_store_kv(qkv, pos, slots, T, H, KVH, D, c, sn, kc, vc, (hipStream_t)s));
 }
 int nvr_qk_norm_rope_store_kv(nvr_half *qkv, const int64_t *pos, const int32_t *slots, int64_t T, int64_t H, int64_t KVH, int64_t D,
                               const float *c, const float *sn, const nvr_half *qw, const nvr_half *kw, float eps, nvr_half *kc, nvr_half *vc,
                               void *s) {
     if (!qw || !kw) return nvr::fail(NVR_ERR_INVALID_ARG, "nvr_qk_norm_rope_store_kv: norm weights are null");
+    if (g_ops_f32) return nvr::kf::rope_store_kv(FP(qkv), pos, slots, T, H, KVH, D, c, sn, FP(kc), FP(vc), FP(qw), FP(kw), eps, (hipStream_t)s);
     return KO(rope_store_kv(qkv, pos, slots, T, H, KVH, D, c, sn, kc, vc, (hipStream_t)s, qw, kw, eps));
 }
 int nvr_rope_table(int64_t D, int64_t max_pos, double theta, float *cos_dev, float *sin_dev) {   // rotary_embedding.rs:74-119 (A-14)
@@ -598,6 +626,13 @@ int nvr_rope_table(int64_t D, int64_t max_pos, double theta, float *cos_dev, flo
 size_t nvr_paged_attn_workspace_bytes(int64_t B, int64_t H, int64_t D, int64_t max_ctx) { return k::attn_workspace_bytes(B, H, D, max_ctx); }
 int nvr_paged_attn_decode(const nvr_half *q, int64_t ldq, const nvr_half *kc, const nvr_half *vc, const nvr_attn_meta *m,
                           int64_t H, int64_t KVH, int64_t D, int64_t bs, float scale, nvr_half *out, void *ws, void *s) {
+    if (g_ops_f32) {
+        nvr::kt::AttnArgsF f{};
+        f.q = FP(q); f.ldq = ldq; f.k = FP(kc); f.v = FP(vc); f.ctx_lens = m->context_lens; f.block_tables = m->block_tables; f.max_blocks = m->max_blocks;
+        f.block_size = (int32_t)bs; f.nq = m->batch; f.H = (int32_t)H; f.KVH = (int32_t)KVH; f.D = (int32_t)D; f.scale = scale; f.max_ctx = m->max_context_len;
+        f.out = FP(out);
+        return nvr::kf::attention(f, true, (hipStream_t)s);
+    }
     k::AttnArgs a{};
     a.q = q; a.ldq = ldq; a.k = kc; a.v = vc; a.ctx_lens = m->context_lens; a.block_tables = m->block_tables;
     a.max_blocks = m->max_blocks; a.block_size = (int32_t)bs; a.nq = m->batch; a.H = (int32_t)H; a.KVH = (int32_t)KVH;
@@ -607,6 +642,7 @@ int nvr_paged_attn_decode(const nvr_half *q, int64_t ldq, const nvr_half *kc, co
 int nvr_paged_attn_decode_shared(const nvr_half *q, int64_t ldq, const nvr_half *kc, const nvr_half *vc, const nvr_attn_meta *m,
                                  int64_t H, int64_t KVH, int64_t D, int64_t bs, float scale, int64_t shared_len, const int32_t *rows,
                                  const int32_t *kv0, const int32_t *count, nvr_half *out, void *ws, void *s) {
+    NO_F32("nvr_paged_attn_decode_shared");
     k::AttnArgs a{};
     a.q = q; a.ldq = ldq; a.k = kc; a.v = vc; a.ctx_lens = m->context_lens; a.block_tables = m->block_tables;
     a.max_blocks = m->max_blocks; a.block_size = (int32_t)bs; a.nq = m->batch; a.H = (int32_t)H; a.KVH = (int32_t)KVH;
@@ -622,7 +658,7 @@ static int run_prefill_attn(const nvr_half *q, int64_t ldq, const nvr_half *kk, 
     if (cu[m->batch] != T) return nvr::fail(NVR_ERR_LEN_MISMATCH, "cu_seqlens_q ends at %d but T=%ld", cu[m->batch], (long)T);
     if (paged) NVR_HIP_CHECK(hipMemcpy(ctxl.data(), m->context_lens, ctxl.size() * 4, hipMemcpyDeviceToHost));
     int rc;
-    if (k::flash_prefill_ok((int)D, (int)H, (int)KVH)) {
+    if (!g_ops_f32 && k::flash_prefill_ok((int)D, (int)H, (int)KVH)) {
         const int qb = k::flash_tile_positions((int)H, (int)KVH);
         std::vector<k::FlashTile> tiles;
         for (int b = 0; b < m->batch; ++b) {
@@ -653,6 +689,17 @@ static int run_prefill_attn(const nvr_half *q, int64_t ldq, const nvr_half *kk, 
         NVR_HIP_CHECK(hipMalloc((void **)&d, (size_t)(2 * T + 4) * 4));
         NVR_HIP_CHECK(hipMemcpy(d, ctx.data(), T * 4, hipMemcpyHostToDevice));
         NVR_HIP_CHECK(hipMemcpy(d + T, ref.data(), T * 4, hipMemcpyHostToDevice));
+        if (g_ops_f32) {
+            nvr::kt::AttnArgsF f{};
+            f.q = FP(q); f.ldq = ldq; f.k = FP(kk); f.v = FP(v); f.ldkv = ldkv; f.ctx_lens = d; f.nq = (int32_t)T;
+            if (paged) { f.seq_of_q = d + T; f.block_tables = m->block_tables; f.max_blocks = m->max_blocks; f.block_size = (int32_t)bs; }
+            else f.kv_base = d + T;
+            f.H = (int32_t)H; f.KVH = (int32_t)KVH; f.D = (int32_t)D; f.scale = scale; f.max_ctx = maxc; f.out = FP(out);
+            rc = nvr::kf::attention(f, paged, st);
+            hipStreamSynchronize(st);
+            hipFree(d);
+            return rc;
+        }
         k::AttnArgs a{};
         a.q = q; a.ldq = ldq; a.k = kk; a.v = v; a.ldkv = ldkv; a.ctx_lens = d; a.nq = (int32_t)T;
         if (paged) { a.seq_of_q = d + T; a.block_tables = m->block_tables; a.max_blocks = m->max_blocks; a.block_size = (int32_t)bs; }
@@ -676,9 +723,16 @@ int nvr_attn_prefill_paged(const nvr_half *q, int64_t ldq, const nvr_half *kc, c
     return run_prefill_attn(q, ldq, kc, vc, 0, m, true, bs, T, H, KVH, D, scale, out, (hipStream_t)s);
     NVR_GUARD_END(NVR_ERR_INVARIANT)
 }
-int nvr_silu_and_mul(const nvr_half *x, int64_t T, int64_t I, nvr_half *out, void *s) { return KO(silu_and_mul(x, T, I, out, (hipStream_t)s)); }
-int nvr_add_bias(nvr_half *y, const nvr_half *b, int64_t T, int64_t N, void *s) { return KO(add_bias(y, b, T, N, (hipStream_t)s)); }
+int nvr_silu_and_mul(const nvr_half *x, int64_t T, int64_t I, nvr_half *out, void *s) {
+    if (g_ops_f32) return nvr::kf::silu_and_mul(FP(x), T, I, FP(out), (hipStream_t)s);
+    return KO(silu_and_mul(x, T, I, out, (hipStream_t)s));
+}
+int nvr_add_bias(nvr_half *y, const nvr_half *b, int64_t T, int64_t N, void *s) {
+    NO_F32("nvr_add_bias");                                              // (the f32 linear takes its bias as an argument inside the runner)
+    return KO(add_bias(y, b, T, N, (hipStream_t)s));
+}
 int nvr_select_last_tokens(const nvr_half *h, const int32_t *cu, int64_t B, int64_t Hd, nvr_half *out, void *s) {
+    if (g_ops_f32) return nvr::kf::select_last_tokens(FP(h), cu, B, Hd, FP(out), (hipStream_t)s);
     return KO(select_last_tokens(h, cu, B, Hd, out, (hipStream_t)s));
 }
 int nvr_argmax(const float *logits, int64_t B, int64_t V, int64_t *out, void *s) { return k::argmax(logits, B, V, out, nullptr, 0, (hipStream_t)s); }
@@ -694,8 +748,12 @@ uint64_t nvr_weight_key(uint64_t seed, uint64_t tid) { return nvr_weight_key_imp
 float nvr_weight_scale(double std) { return nvr_weight_scale_impl(std); }
 int nvr_fill_weight(nvr_half *dst, int64_t rows, int64_t cols, int64_t ld, int64_t gcols, int64_t row0, int64_t col0,
                     uint64_t key, float scale, void *s) {
+    if (g_ops_f32) return nvr::kf::fill_weight(FP(dst), rows, cols, ld, gcols, row0, col0, key, scale, (hipStream_t)s);   // unrounded values
     return KO(fill_weight(dst, rows, cols, ld, gcols, row0, col0, key, scale, (hipStream_t)s));
 }
-int nvr_fill_const(nvr_half *dst, int64_t n, float v, void *s) { return KO(fill_const(dst, n, v, (hipStream_t)s)); }
+int nvr_fill_const(nvr_half *dst, int64_t n, float v, void *s) {
+    if (g_ops_f32) return nvr::kf::fill_const(FP(dst), n, v, (hipStream_t)s);
+    return KO(fill_const(dst, n, v, (hipStream_t)s));
+}
 
 }  // extern "C"
