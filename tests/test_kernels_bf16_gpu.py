@@ -54,9 +54,9 @@ def assert_close_bf16(got, ref, ulps=2, atol=1e-3, what=""):
     bad = np.abs(got - ref) > tol
     assert not bad.any(), f"{what}: {bad.sum()} / {bad.size} elements off, max err {np.abs(got - ref).max()}"
 
-    assert nvr.lib().nvr_ops_set_dtype(b"int8") == -10 and nvr.lib().nvr_ops_dtype() == b"bfloat16"   # ("float32" selects the f32 ops since r04: tests/test_kernels_f32_gpu.py)
+
 def test_dtype_switch_is_validated_and_thread_local():
-    assert nvr.lib().nvr_ops_set_dtype(b"float32") == -10 and nvr.lib().nvr_ops_dtype() == b"bfloat16"
+    assert nvr.lib().nvr_ops_set_dtype(b"int8") == -10 and nvr.lib().nvr_ops_dtype() == b"bfloat16"   # ("float32" selects the f32 ops since r04: tests/test_kernels_f32_gpu.py)
     import threading
     seen = []
     t = threading.Thread(target=lambda: seen.append(nvr.lib().nvr_ops_dtype()))
