@@ -251,7 +251,8 @@ def side_decode(nvr, preset: str, steps: int = 16, warmup: int = 4, tp_size: int
         # under the three forms of the tensor-parallel prefill exchange — serial on one stream, token chunks of one GEMM on a second
         # stream (default), two micro-batches under each other's compute (nvr_runner_set_tp_prefill_overlap 0 / 1 / 2; same bits)
         exchange_modes = {}
-        for mode, name in ((1, "warm_up"), (0, "serial"), (1, "chunks"), (2, "two_microbatches")):
+        try:
+          for mode, name in ((1, "warm_up"), (0, "serial"), (1, "chunks"), (2, "two_microbatches")):
             eng.model_runner.set_tp_prefill_overlap(mode)
             for i in range(B):
                 eng.add_request(nvr.synthetic_tokens(P, 1, 1000 * (mode + 1) + i, mc.c.vocab_size).tolist(),
@@ -265,6 +266,12 @@ def side_decode(nvr, preset: str, steps: int = 16, warmup: int = 4, tp_size: int
             eng.take_finished()
             if name != "warm_up":
                 exchange_modes[name] = {"seconds": round(dt, 4), "prefill_steps": len(forms), "chunks_or_microbatches_per_step": forms}
+        except Exception as ex:                                              # noqa: BLE001 (every rank fails alike: the schedule is deterministic)
+            exchange_modes["error"] = str(ex)[:200]
+            while not eng.is_finished():
+                try: eng.step()
+                except Exception: break                                      # noqa: BLE001
+            eng.take_finished()
         eng.model_runner.set_tp_prefill_overlap(1)
     for i in range(B):
         eng.add_request(nvr.synthetic_tokens(P, 1, i, mc.c.vocab_size).tolist(),
