@@ -30,6 +30,10 @@ def test_attention_traffic_is_bytes_over_algorithmic_bytes_of_the_pass():
     over = bench.attention_traffic_from_rows([dict(r, Counter_Value=str(float(r["Counter_Value"]) * 1.07)) for r in rows], "qwen3-0.6b", steps, warm)
     assert abs(over["traffic_over_algorithmic"] - 1.07) < 1e-3
     assert isinstance(bench.attention_traffic_from_rows(rows[:-20], "qwen3-0.6b", steps, warm), str)
+    # the live timing as a replayed graph adds one more sweep at the final context
+    more = _rows("void nvr::k::attn_rows_kernel<128, 2, ...>(AttnParams)", "FETCH_SIZE", [alg(P + n + 1) / 2048.0] * L, first_id=5000)
+    got3 = bench.attention_traffic_from_rows(rows + more, "qwen3-0.6b", steps, warm)
+    assert got3["dispatches"] == L * (n + 3) and abs(got3["traffic_over_algorithmic"] - 1.0) < 2e-4, got3
 
 
 def test_prefill_busy_share_takes_the_last_prefill_step_only():
