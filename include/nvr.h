@@ -308,9 +308,9 @@ NVR_API int64_t nvr_runner_last_shared_prefix_len(const nvr_model_runner_t *r);
 NVR_API int nvr_runner_last_prefill_kv_source(const nvr_model_runner_t *r);
 NVR_API int64_t nvr_runner_last_shared_prefix_rows(const nvr_model_runner_t *r);   /* sequences of that step inside the sharing group */
 /* Tensor-parallel PREFILL steps (row-parallel o_proj / down_proj, linear.rs:228-239 with its all-reduce :236-238): on = 1 (default) cuts a step of
- * >= 1024 rows into up to 4 token chunks and runs the all-reduce of chunk i on a second HIP stream under the GEMM of chunk i + 1 (events between
+ * >= 512 rows into up to 4 token chunks and runs the all-reduce of chunk i on a second HIP stream under the GEMM of chunk i + 1 (events between
  * the streams; residual add + RMSNorm of a chunk behind its reduce); on = 0 keeps GEMM -> all-reduce -> add + norm in a row on one stream.  Same
- * bits either way (chunks are multiples of the GEMM's 256-row tile).  on = 2: the step runs as TWO micro-batches of whole sequences, one behind the
+ * bits either way (chunks are whole tiles of the GEMM kernel the step is routed to: 256 or 128 rows).  on = 2: the step runs as TWO micro-batches of whole sequences, one behind the
  * other through every layer, and each exchange runs on the second stream under the OTHER micro-batch's compute segment (a third of a layer
  * instead of one GEMM: what a step needs whose exchanges outweigh its compute, e.g. configs[3] at tp 8); steps it does not fit (one group of
  * sequences, GQA groups outside the MFMA attention kernel, q/k norm or bias graphs, chunked prefill) take the chunks of mode 1.  Same bits again.

@@ -549,17 +549,20 @@ int nvr_model_runner::row_parallel_norm(const uint16_t *x, int64_t K, const uint
         RC(KD(gemm256_resid(x, K, W, T, K, Hd, h, stream)));
         return KD(rmsnorm(h, wn, mc.rms_norm_eps, T, Hd, n, stream));
     }
-    if (comm.active() && comm_stream && tp_overlap && T >= 1024 && KD(gemm256_preferred(T, K, Hd, K))) {
+    // (the step's GEMM kernel by linear.hip's routing: 256-row tiles when its cost rule prefers them, else the 128-row kernel; the chunks call THAT kernel)
+    const bool big = KD(gemm256_preferred(T, K, Hd, K));
+    if (comm.active() && comm_stream && tp_overlap && ((big && T >= 1024) || (!big && T >= 512 && T * Hd > 384 * 1024 && KD(gemm_tiled_ok(T, K, Hd, K))))) {   // (T * N <= 384 Ki: linear() streams the weights instead)
         // Prefill on tensor-parallel ranks (row g): the rows are cut into chunks (multiples of the 256-row GEMM tile, so every tile and every
         // row is computed exactly as in one piece: bit-identical), and the all-reduce of chunk i runs on the communication stream while the
         // compute stream works on the GEMM of chunk i+1; the residual add + RMSNorm of a chunk follows its reduce.  Host order
         // G0 G1 R0 N0 G2 R1 N1 ...: a backend that blocks the host inside the reduce (in-process ranks) still finds the next GEMM queued.
         // configs[3] at tp 8: 72 all-reduces of 268 MB per 32 768-token step are the larger half of the step: serial 160 ms,
         // overlapped ~max(comm, compute) + one chunk.
-        int64_t C = std::min<int64_t>(4, T / 512);
-        const int64_t rows = ((T + C - 1) / C + 255) / 256 * 256;
+        const int64_t gran = big ? 256 : 128;                         // rows of a GEMM tile: chunks are whole tiles
+        int64_t C = std::min<int64_t>(4, T / (2 * gran));
+        const int64_t rows = ((T + C - 1) / C + gran - 1) / gran * gran;
         C = (T + rows - 1) / rows;
-        if (C > 1 && T - (C - 1) * rows < 256) --C;                   // (the last chunk takes a short remainder along: every chunk is a launch of the 256^2 kernel)
+        if (C > 1 && T - (C - 1) * rows < gran) --C;                  // (the last chunk takes a short remainder along: every chunk is a launch of the same kernel)
         tp_overlap_chunks = C;
         auto reduce_and_norm = [&](int64_t i) -> int {
             const int64_t r0 = i * rows, nr = i + 1 == C ? T - r0 : rows;
@@ -571,7 +574,8 @@ int nvr_model_runner::row_parallel_norm(const uint16_t *x, int64_t K, const uint
         };
         for (int64_t i = 0; i < C; ++i) {
             const int64_t r0 = i * rows, nr = i + 1 == C ? T - r0 : rows;
-            RC(KD(gemm256(x + r0 * K, K, W, nr, K, Hd, proj + r0 * Hd, stream)));   // (the kernel linear() takes for the whole step: same tiles, same bits)
+            if (big) RC(KD(gemm256(x + r0 * K, K, W, nr, K, Hd, proj + r0 * Hd, stream)));   // (the kernel linear() takes for the whole step: same tiles, same bits)
+            else RC(KD(gemm_tiled(x + r0 * K, K, W, nr, K, Hd, proj + r0 * Hd, stream)));
             NVR_HIP_CHECK(hipEventRecord(ev_gemm[i], stream));
             if (i >= 1) RC(reduce_and_norm(i - 1));
         }
