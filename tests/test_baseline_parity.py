@@ -197,6 +197,28 @@ def test_configs4_shared_system_prompt_vs_oracle():
     _report("configs4_shared_prefix_48seqs", st)
 
 
+def test_configs2_and_configs4_on_the_float32_path_vs_f32_cpu_path_oracle():
+    """The other two single-GPU BASELINE workloads on Config.dtype = "float32" against the oracle's f32 arithmetic: configs[2]'s mixed-length
+    32 768-token prefill (4096-token sequences down to 128) + a decode step, and configs[4]'s shared 512-token system prompt (48 sequences: the
+    prefix blocks shared by BlockManager::allocate, the cached prefix skipped through the f32 attention kernel's paged form) — logits within
+    2e-4, every greedy id equal."""
+    lens = [4096] * 4 + [2048] * 2 + [1024] * 4 + [512] * 8 + [256] * 8 + [128] * 16
+    nblk = sum((n + 1 + 255) // 256 for n in lens) + 2
+    ecfg = dict(max_num_seqs=64, max_num_batched_tokens=32768, max_model_len=4100, kvcache_block_size=256, num_kvcache_blocks=nblk)
+    prompts = [nvr.synthetic_tokens(n, 1, i, V).tolist() for i, n in enumerate(lens)]
+    st, o, p = _pair(ecfg, prompts, 2, tol=F32_TOL, dtype="float32")
+    assert st["steps"] == 2 and st["prefill_steps"] == 1 and st["rows"] == 84 and st["near_ties"] == 0, st
+    _report("configs2_mixed_32768_float32_path_vs_f32_cpu_path_oracle", st)
+    del o, p
+    n = 48
+    ecfg = dict(max_num_seqs=n, max_num_batched_tokens=32768, max_model_len=640, kvcache_block_size=256, num_kvcache_blocks=n + 8)
+    shared = nvr.synthetic_tokens(512, 2, 0, V).tolist()
+    prompts = [shared + nvr.synthetic_tokens(64, 1, i, V).tolist() for i in range(n)]
+    st, o, p = _pair(ecfg, prompts, 4, tol=F32_TOL, dtype="float32")
+    assert st["steps"] == 4 and st["prefill_steps"] == 1 and st["rows"] == 4 * n and st["near_ties"] == 0, st
+    _report("configs4_shared_prefix_48seqs_float32_path_vs_f32_cpu_path_oracle", st)
+
+
 def test_bfloat16_qwen3_0_6b_bs32_seq1024_vs_bf16_oracle():
     """Config.dtype = "bfloat16" (config.rs:51,113-116) at BASELINE configs[1]'s full size: the bf16 build of the 256^2 MFMA GEMMs, the
     flash prefill kernel, the weight-streaming decode GEMMs, paged attention and the fused LM head over 28 layers, against the oracle
