@@ -122,7 +122,7 @@ def time_attention_kernel(nvr, eng, mc, reps: int) -> dict:
     return dict(us_per_launch=us, launches=launches, alg_bytes=alg_bytes, ctx_sum=int(ctx.sum()), as_graph=captured)
 
 
-def time_decode_chain(nvr, mc, reps: int = 20, mlp_engine: bool = False) -> dict:
+def time_decode_chain(nvr, mc, reps: int = 20) -> dict:
     """The decode step's GEMM / norm chain without attention (per layer: qkv+RoPE+store, o_proj split-k, add+RMSNorm,
     gate_up+SiLU, down split-k, add+RMSNorm — the six launches of the default chain) as one captured hipGraph of L layers with
     their own weights (HBM-cold every replay), replayed back to back on its own stream: microseconds per layer."""
@@ -158,7 +158,7 @@ def time_decode_chain(nvr, mc, reps: int = 20, mlp_engine: bool = False) -> dict
     rng = np.random.default_rng(0)
     h = arr(rng.standard_normal((T, Hd)).astype(np.float16)); n = buf(T * Hd * 2); g = arr(np.ones(Hd, np.float16))
     qkv, attn, act = buf(T * QKV * 2), arr(rng.standard_normal((T, H * D)).astype(np.float16) * 0.1), buf(T * I * 2)
-    slabs = buf(4 * T * Hd * 4); sync = buf(l.nvr_mlp_engine_sync_bytes())
+    slabs = buf(4 * T * Hd * 4)
     pos = arr(np.arange(T, dtype=np.int64) + 1000); slots = arr(np.arange(T, dtype=np.int32))
     cos = arr(np.ones((2048, D // 2), np.float32)); sin = arr(np.zeros((2048, D // 2), np.float32))
     kc, vc = buf(64 * KVH * D * 2), buf(64 * KVH * D * 2)
@@ -171,10 +171,6 @@ def time_decode_chain(nvr, mc, reps: int = 20, mlp_engine: bool = False) -> dict
                                                     qkv.ptr, kc.ptr, vc.ptr, st))
         nvr.check(l.nvr_linear_splitk_tiled(attn.ptr, H * D, Wo[i].ptr, To[i], T, H * D, Hd, So, slabs.ptr, st))
         nvr.check(l.nvr_add_rmsnorm_slabs(h.ptr, slabs.ptr, So, g.ptr, 1e-6, T, Hd, n.ptr, st))
-        if mlp_engine:                                     # decode_chain = 5: gate_up+SiLU and down as one persistent launch (kernels/mlp_engine.hip)
-            nvr.check(l.nvr_mlp_engine(n.ptr, Hd, Tgu[i], Td[i], T, Hd, I, act.ptr, slabs.ptr, sync.ptr, st))
-            nvr.check(l.nvr_add_rmsnorm_slabs(h.ptr, slabs.ptr, 4, g.ptr, 1e-6, T, Hd, n.ptr, st))
-            continue
         nvr.check(l.nvr_linear_silu_mul_tiled(n.ptr, Hd, Wgu[i].ptr, Tgu[i], T, Hd, I, act.ptr, st))
         nvr.check(l.nvr_linear_splitk_tiled(act.ptr, I, Wd[i].ptr, Td[i], T, I, Hd, Sd, slabs.ptr, st))
         nvr.check(l.nvr_add_rmsnorm_slabs(h.ptr, slabs.ptr, Sd, g.ptr, 1e-6, T, Hd, n.ptr, st))
@@ -243,7 +239,7 @@ def prefill_flops(c, lens) -> float:
 
 def side_decode(nvr, preset: str, steps: int = 16, warmup: int = 4, tp_size: int = 1, tp_rank: int = 0, device: int = 0,
                 attach=None, barrier=None, reduce_max=None, batch: int = None, prompt_len: int = None, dtype: str = "float16",
-                async_decode: int = 1) -> dict:
+                async_decode=None) -> dict:
     """One more BASELINE workload measured next to the headline (same engine path: prefill untimed, W warm-up steps, K timed decode
     steps): used for BASELINE.json configs[3] (Qwen3-8B, bs 32 x 2048; src/models/qwen3.rs:70-125 with the 8B numbers) on one GPU and,
     in a tensor-parallel child, over the N GPUs (attach = communicator set-up of the engine's runner)."""
@@ -254,7 +250,7 @@ def side_decode(nvr, preset: str, steps: int = 16, warmup: int = 4, tp_size: int
     t0 = time.perf_counter()
     eng = nvr.LLMEngine(nvr.Config(max_num_seqs=B, max_num_batched_tokens=32768, max_model_len=P + total_new + 16, kvcache_block_size=BLOCK,
                                    num_kvcache_blocks=B * ((P + total_new + 16) // BLOCK + 2), tensor_parallel_size=tp_size,
-                                   tensor_parallel_rank=tp_rank, device_ordinal=device, async_decode=async_decode, dtype=dtype), mc)
+                                   tensor_parallel_rank=tp_rank, device_ordinal=device, dtype=dtype, **({} if async_decode is None else {"async_decode": async_decode})), mc)
     if attach is not None:
         ok, desc = attach(eng)
         if not ok:
@@ -325,7 +321,7 @@ def side_decode(nvr, preset: str, steps: int = 16, warmup: int = 4, tp_size: int
                step_algorithmic_bytes=int(step_bytes), step_hbm_frac_per_gpu=round(step_bytes / tp_size / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                prefill_steps=npre, prefill_plus_first_decode_seconds=round(t_pre, 3),
                prefill_tflop_per_s_lower_bound=round(prefill_flops(c, [P] * B) / t_pre / 1e12, 1), init_seconds=round(t_init, 1),
-               async_decode="opt-in (default 0), on here" if async_decode else "off (the default engine)")
+               async_decode="off (nvr_config.async_decode = 0)" if async_decode == 0 else "on (the nvr_config default)")
     if exchange_modes is not None:
         out["prefill_exchange_forms"] = exchange_modes
     del eng
@@ -561,7 +557,7 @@ def main() -> None:
     ap.add_argument("--no-prefill-sweep", action="store_true", help="skip the configs[2] prefill sweep (prefill_sweep block)")
     ap.add_argument("--no-batch-sweep", action="store_true", help="skip the bs 64 / 128 decode side measurements (batch_sweep block)")
     ap.add_argument("--no-default-engine", action="store_true",
-                    help="skip the default_engine block (async_decode = 0 decode steps; the prefill on a recycled free list)")
+                    help="skip the default_engine block (a fresh default engine, async_decode = 0 decode steps, the prefill on a recycled free list)")
     ap.add_argument("--sync-decode", action="store_true",
                     help="nvr_config.async_decode = 0: wait for every step's tokens on the host before the next step is scheduled "
                          "(default: the next greedy decode step is launched ahead; same batches, tokens and statistics)")
@@ -646,7 +642,7 @@ def main() -> None:
                          # recycled free list it walks the block tables: +1.1 ms per 32 x 1024 prefill, prefill.kv_source says which)
                          kvcache_block_size=BLOCK, num_kvcache_blocks=2 * BATCH * ((PROMPT_LEN + total_new + 16) // BLOCK + 2),
                          tensor_parallel_size=tp_size, tensor_parallel_rank=tp_rank,
-                         device_ordinal=local_rank, enforce_eager=args.eager, async_decode=0 if args.sync_decode else 1)
+                         device_ordinal=local_rank, enforce_eager=args.eager, **({"async_decode": 0} if args.sync_decode else {}))   # (default: launch-ahead on, nvr_config_default)
         return nvr.LLMEngine(cfg, mc)
 
     def barrier():
@@ -831,8 +827,6 @@ def main() -> None:
     if args.gpus == 1 and rank == 0 and not args.no_chain and args.model == "qwen3-0.6b":
         try:
             chain = time_decode_chain(nvr, mc)
-            if nvr.lib().nvr_mlp_engine_ok(BATCH, mc.c.hidden_size, mc.c.intermediate_size):
-                chain["us_per_layer_mlp_engine"] = time_decode_chain(nvr, mc, mlp_engine=True)["us_per_layer"]
         except Exception as ex:                                              # noqa: BLE001
             print(f"[bench] decode chain timing failed: {ex}", file=sys.stderr, flush=True)
     shared_prefix = None
@@ -868,10 +862,13 @@ def main() -> None:
             bf16_block = {"error": str(ex)[:200]}
     default_engine = None
     if args.gpus == 1 and rank == 0 and not args.no_default_engine and args.model == "qwen3-0.6b":
-        # the two favourable conditions of the headline, quantified in the line itself: the engine as nvr_config defaults build it
-        # (async_decode = 0: the host waits for every step's tokens) and the prefill on a recycled free list (block tables, not contiguous rows)
-        default_engine = {}
+        # the headline engine IS the engine nvr_config_default builds (r05: async_decode defaults to 1); measured again here on a fresh engine of
+        # its own, next to the opt-out (async_decode = 0: the host waits for every step's tokens before it schedules the next step) and the
+        # prefill on a recycled free list (block tables, not contiguous rows)
+        default_engine = {"note": "nvr_config_default() + the workload's sizes, nothing else set: the same configuration as the headline line"}
         try:
+            r = side_decode(nvr, "qwen3-0.6b", steps=max(16, min(args.steps, 64)), warmup=4, batch=BATCH, prompt_len=PROMPT_LEN)
+            default_engine["ms_per_step"] = r["ms_per_step"]; default_engine["tokens_per_s"] = r["tokens_per_s"]
             r = side_decode(nvr, "qwen3-0.6b", steps=max(16, min(args.steps, 64)), warmup=4, batch=BATCH, prompt_len=PROMPT_LEN, async_decode=0)
             default_engine["sync_decode_ms_per_step"] = r["ms_per_step"]
             default_engine["sync_decode_tokens_per_s"] = r["tokens_per_s"]
@@ -918,7 +915,7 @@ def main() -> None:
                                    f"block_size=256, hipGraph decode steps (BASELINE.json configs[{MODELS[args.model]['baseline_config']}])",
                        "batch": BATCH, "prompt_len": PROMPT_LEN, "mean_context": ctx_mean,
                        "parallelism": parallelism, "hipgraph": not args.eager,
-                       "async_decode": ("opt-in (nvr_config.async_decode, default 0): "
+                       "async_decode": ("nvr_config.async_decode (default 1 since r05): "
                                         + ("on" if (not args.sync_decode and (args.gpus == 1 or parallelism.startswith("replicas") or TP_ASYNC)) else "off")),
                        "logits": "materialised every step" if args.materialize_logits else "greedy arg-max fused into the LM head; f32 logits on demand"},
             "prefill": {"tokens": BATCH * PROMPT_LEN, "seconds": round(t_prefill, 4), "tokens_per_s": round(BATCH * PROMPT_LEN / t_prefill, 1),
@@ -963,10 +960,6 @@ def main() -> None:
                                      "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "us_per_layer": round(chain["us_per_layer"], 2),
                                      "algorithmic_bytes_per_layer": int(chain["alg_bytes_per_layer"]),
                                      "note": "one hipGraph of 28 layers with their own weights (HBM-cold), replayed back to back (HIP events on its stream)"}
-            if "us_per_layer_mlp_engine" in chain:
-                out["roofline_chain"]["us_per_layer_with_mlp_engine"] = round(chain["us_per_layer_mlp_engine"], 2)
-                out["roofline_chain"]["mlp_engine_note"] = ("the same chain with gate_up+SiLU and down as ONE persistent launch (kernels/mlp_engine.hip, "
-                                                            "nvr_config.decode_chain = 5, opt-in): five launches per layer")
         if shared_prefix is not None:
             out["shared_prefix"] = shared_prefix
         if configs3 is not None:

@@ -84,12 +84,10 @@ typedef struct nvr_config {
     uint64_t sample_seed;              /* A-20 counter-RNG seed */
     int32_t skip_block_size_check;     /* reference unit tests use block sizes 4/16 that
                                           Config::validate would reject (config.rs:94) */
-    uint32_t decode_chain;             /* GEMM / norm chain of single-rank decode steps: 0 or 6 = six launches per layer (qkv+RoPE,
-                                          o_proj split-k, add+RMSNorm, gate_up+SiLU, down split-k, add+RMSNorm; default: measured
-                                          0.8 % faster per step), 4 = four launches (kernels/linear_decode.hip: norms in the GEMM
-                                          prologues, residual adds on the split-k reductions); profiles/r02_decode_chain_ablation.txt;
-                                          5 = the six-launch chain with gate_up+SiLU and down as ONE persistent launch (kernels/mlp_engine.hip,
-                                          steps of <= 32 rows of shapes nvr_mlp_engine_ok accepts, else 6); profiles/r04_mlp_engine.txt */
+    uint32_t decode_chain;             /* reserved (0).  r01-r04 selected alternative launch chains of the decode step's GEMMs here (4: norms in
+                                          the GEMM prologues + last-arriver residual adds, 5: the MLP pair as one persistent launch); both were
+                                          measured a wash / a loss against the default six launches and left the library in r05 (sources and
+                                          measurements: scratch/r04_decode_chain/, profiles/r02_decode_chain_ablation.txt, r04_mlp_engine.txt) */
     int32_t recompute_cached_prefix;   /* 0 (default): a prefill step computes only the tokens after a sequence's
                                           cached prefix (num_cached_tokens, block_manager.rs:187) and attends to the
                                           prefix through the block table (K8, attention.rs:211-222) — SURVEY §8f row 2;
@@ -104,7 +102,7 @@ typedef struct nvr_config {
                                           lengths), whenever that is provably the step the reference would schedule: nothing waiting,
                                           no sequence able to stop, no block boundary.  Same batches, tokens and statistics as 0 (a
                                           request added in between cancels the step launched ahead); the logits accessors then refer to
-                                          the newest launched step.  Default 0. */
+                                          the newest launched step: a caller that reads every step's logits sets 0.  Default 1 (r05; 0 in r02-r04). */
     int32_t shared_prefix_min_seqs;    /* decode batches of at least this many sequences that ALL begin with the same cache blocks
                                           (prefix-cache hits, block_manager.rs:181-197; BASELINE configs[4]) attend to those blocks in one
                                           MFMA pass for the whole batch (nvr_paged_attn_decode_shared) instead of once per sequence; same
@@ -506,44 +504,13 @@ NVR_API int nvr_linear_qkv_rope_store_tiled(const nvr_half *x, int64_t ldx, cons
                                             nvr_half *qkv, nvr_half *k_cache, nvr_half *v_cache, void *stream);
 NVR_API int nvr_lm_head_tiled(const nvr_half *x, int64_t ldx, const nvr_half *W, const nvr_half *Wt, int64_t T, int64_t K, int64_t N,
                               float *logits, float *part_val, int32_t *part_idx, int32_t *nparts, void *stream);
-/* The decode chain in four launches per layer (kernels/linear_decode.hip; Qwen3DecoderLayer::forward qwen3.rs:372-392):
- * nvr_linear_resid: h[T,N] <- fp16(h + fp16(x · Wᵀ)) — RowParallelLinear::forward (linear.rs:228-239) plus the residual add
- * (qwen3.rs:382,389) in one launch: k is split over S workgroups per 16-column tile (S = nvr_decode_splitk_slices), each
- * publishes its f32 partial tile in slabs[S][T][N] and takes a ticket from the tile's counter; the workgroup that draws the
- * last ticket sums the slabs in slab order (bit-identical to nvr_linear_splitk + the add of nvr_add_rmsnorm_slabs) and adds
- * the residual.  counters: (N/16)*ceil(T/32) zero-initialised uint32 (left zeroed).  T <= 64, K/S <= 2048.
- * nvr_linear_silu_mul_normed / nvr_linear_qkv_rope_store_normed: nvr_linear_silu_mul / nvr_linear_qkv_rope_store with
- * RMSNorm::forward_simple (layernorm.rs:58-75) of their input rows in the prologue (x = the residual stream h, w_norm the
- * norm weight): n = fp16(h * (1/rms) * w) per fragment, within 1 fp16 ulp of nvr_rmsnorm's rows.  T <= 64, K <= 2048.
- * Wt (may be NULL): the nvr_retile_weight copy of W (mode 1 for qkv, else 0), read instead of W; same bits either way.
- * nvr_linear_resid with S = 0: 8-row weight tiles, one workgroup per (8 columns, 16 tokens), no k split, slabs / counters unused. */
-NVR_API int nvr_linear_resid(const nvr_half *x, int64_t ldx, const nvr_half *W, const nvr_half *Wt, int64_t T, int64_t K, int64_t N,
-                             int64_t S, float *slabs, uint32_t *counters, nvr_half *h, void *stream);
+/* k-slices S of nvr_linear_splitk for the N = hidden GEMMs of a decode-sized step (o_proj, down_proj): enough to reach ~256 workgroups */
 NVR_API int nvr_decode_splitk_slices(int64_t T, int64_t K, int64_t N);
-/* The MLP pair of a decode layer (Qwen3MLP::forward, qwen3.rs:305-314: gate_up_proj :307, SiluAndMul :310, down_proj :313) as ONE persistent
- * launch (kernels/mlp_engine.hip; nvr_config.decode_chain = 5): per CU one workgroup of 1 LDS-DMA loader wave + 3 MFMA consumer waves; the
- * loader streams the gate / up weight tiles and, AHEAD of the in-launch hand-off, the workgroup's down_proj k-slice; act tiles are handed
- * over write-through with one arrival counter per k-slice (bounded poll on the 100 MHz clock: a timeout sets sync[4], the GPU never hangs).
- * x [T, Hd] (T <= 32); gate_up_tiled / down_tiled: nvr_retile_weight (mode 0) copies of W_gate_up [2I, Hd] / W_down [Hd, I]; act [T, I];
- * slabs [4][T][Hd] f32 (the k-slice partial sums nvr_linear_splitk writes with S = 4: consumed by nvr_add_rmsnorm_slabs); sync:
- * nvr_mlp_engine_sync_bytes() of device memory (zeroed by the call itself).  Same rounding points as nvr_linear_silu_mul + nvr_linear_splitk;
- * f32 summation order differs (tolerance as between any two GEMM routes).  nvr_mlp_engine_ok: the shape is instantiated and every workgroup
- * can be resident on this device (the only shapes the call accepts: NVR_ERR_UNSUPPORTED otherwise). */
-NVR_API int nvr_mlp_engine_ok(int64_t T, int64_t Hd, int64_t I);
-NVR_API size_t nvr_mlp_engine_sync_bytes(void);
-NVR_API int nvr_mlp_engine(const nvr_half *x, int64_t ldx, const nvr_half *gate_up_tiled, const nvr_half *down_tiled, int64_t T, int64_t Hd,
-                           int64_t I, nvr_half *act, float *slabs, uint32_t *sync, void *stream);
-/* Prefill-sized twin of nvr_linear_resid: h[T,N] <- fp16(h + fp16(x · Wᵀ)) with the residual add (qwen3.rs:382,389) in the epilogue of the
+/* h[T,N] <- fp16(h + fp16(x · Wᵀ)) with the residual add (qwen3.rs:382,389) in the epilogue of the
  * 256x256 MFMA GEMM; only for shapes that kernel takes (T >= 256, N % 256 == 0, K % 64 == 0 and preferred by the routing of nvr_linear:
  * NVR_ERR_UNSUPPORTED otherwise).  Bit-identical to nvr_linear into a scratch tensor followed by the add of nvr_add_rmsnorm. */
 NVR_API int nvr_linear_add_residual(const nvr_half *x, int64_t ldx, const nvr_half *W, int64_t T, int64_t K, int64_t N, nvr_half *h,
                                     void *stream);
-NVR_API int nvr_linear_silu_mul_normed(const nvr_half *h, int64_t ldx, const nvr_half *w_norm, float eps, const nvr_half *W,
-                                       const nvr_half *Wt, int64_t T, int64_t K, int64_t I, nvr_half *out, void *stream);
-NVR_API int nvr_linear_qkv_rope_store_normed(const nvr_half *h, int64_t ldx, const nvr_half *w_norm, float eps, const nvr_half *W,
-                                             const nvr_half *Wt, int64_t T, int64_t K, int64_t H, int64_t KVH, int64_t D, const int64_t *positions,
-                                             const int32_t *slot_mapping, const float *cos_t, const float *sin_t,
-                                             nvr_half *qkv, nvr_half *k_cache, nvr_half *v_cache, void *stream);
 /* K12+K13 fused: out[T,I] = SiluAndMul(x · W_gate_upᵀ), W [2I,K] gate rows then up rows
  * (MergedColumnParallelLinear::forward linear.rs:437-439 + SiluAndMul::forward activation.rs:46-63) */
 NVR_API int nvr_linear_silu_mul(const nvr_half *x, int64_t ldx, const nvr_half *W, int64_t T, int64_t K, int64_t I,
@@ -572,6 +539,13 @@ NVR_API size_t nvr_paged_attn_workspace_bytes(int64_t B, int64_t H, int64_t D, i
 NVR_API int nvr_paged_attn_decode(const nvr_half *q, int64_t ldq, const nvr_half *k_cache, const nvr_half *v_cache,
                                   const nvr_attn_meta *meta, int64_t H, int64_t KVH, int64_t D, int64_t block_size,
                                   float scale, nvr_half *out, void *workspace, void *stream);
+/* The same in ONE launch when the context is cut into split-KV partitions (batches with fewer than ~192 (sequence, kv head) pairs: small
+ * batches, tensor-parallel ranks holding 1-4 kv heads): the last partition workgroup of a (sequence, kv head) to finish merges the pair's
+ * partials, instead of a second (merge) launch; bit-identical to nvr_paged_attn_decode.  tickets: [B * KVH] device words, ZERO before the
+ * first call and owned by these calls afterwards (the kernel re-arms them; one call at a time per array). */
+NVR_API int nvr_paged_attn_decode_fused(const nvr_half *q, int64_t ldq, const nvr_half *k_cache, const nvr_half *v_cache,
+                                        const nvr_attn_meta *meta, int64_t H, int64_t KVH, int64_t D, int64_t block_size,
+                                        float scale, nvr_half *out, void *workspace, uint32_t *tickets, void *stream);
 /* The same when EVERY sequence of the batch holds its first shared_len tokens (a multiple of block_size) in the cache blocks that
  * block-table row 0 starts with (prefix-cache hits of BlockManager::allocate, block_manager.rs:181-197; BASELINE configs[4]): the
  * shared keys go through one MFMA pass for the whole batch, the remainder per sequence, merged as split-KV partials.  Same

@@ -183,8 +183,6 @@ _SIGS = {
     "nvr_runner_p2p_disable": (C.c_int, [_P]), "nvr_runner_p2p_active": (C.c_int, [_P]),
     "nvr_runner_p2p_reset": (C.c_int, [_P]), "nvr_runner_comm_drop_rccl": (C.c_int, [_P]),
     "nvr_engine_abort_last_batch": (C.c_int, [_P]), "nvr_engine_ahead_declined": (C.c_uint64, [_P]), "nvr_engine_ahead_launched": (C.c_uint64, [_P]),
-    "nvr_mlp_engine_ok": (C.c_int, [C.c_int64, C.c_int64, C.c_int64]), "nvr_mlp_engine_sync_bytes": (C.c_size_t, []),
-    "nvr_mlp_engine": (C.c_int, [_P, C.c_int64, _P, _P, C.c_int64, C.c_int64, C.c_int64, _P, _P, _P, _P]),
     "nvr_runner_last_prefill_kv_source": (C.c_int, [_P]),
     "nvr_runner_set_tp_prefill_overlap": (C.c_int, [_P, C.c_int32]), "nvr_runner_last_overlap_chunks": (C.c_int64, [_P]),
     "nvr_runner_last_shared_prefix_len": (C.c_int64, [_P]), "nvr_runner_last_shared_prefix_rows": (C.c_int64, [_P]),
@@ -218,12 +216,8 @@ _SIGS = {
                                                   _P, _P, _P, _P]),
     "nvr_lm_head_tiled": (C.c_int, [_P, C.c_int64, _P, _P, C.c_int64, C.c_int64, C.c_int64, _P, _P, _P, _P, _P]),
     "nvr_retile_weight": (C.c_int, [_P, _P, C.c_int64, C.c_int64, C.c_int, C.c_int64, C.c_int64, C.c_int64, _P]),
-    "nvr_linear_resid": (C.c_int, [_P, C.c_int64, _P, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _P, _P, _P, _P]),
     "nvr_decode_splitk_slices": (C.c_int, [C.c_int64, C.c_int64, C.c_int64]),
     "nvr_linear_add_residual": (C.c_int, [_P, C.c_int64, _P, C.c_int64, C.c_int64, C.c_int64, _P, _P]),
-    "nvr_linear_silu_mul_normed": (C.c_int, [_P, C.c_int64, _P, C.c_float, _P, _P, C.c_int64, C.c_int64, C.c_int64, _P, _P]),
-    "nvr_linear_qkv_rope_store_normed": (C.c_int, [_P, C.c_int64, _P, C.c_float, _P, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _P, _P,
-                                                   _P, _P, _P, _P, _P, _P]),
     "nvr_add_rmsnorm_slabs": (C.c_int, [_P, _P, C.c_int64, _P, C.c_float, C.c_int64, C.c_int64, _P, _P]),
     "nvr_linear_silu_mul": (C.c_int, [_P, C.c_int64, _P, C.c_int64, C.c_int64, C.c_int64, _P, _P]),
     "nvr_linear_qkv_rope_store": (C.c_int, [_P, C.c_int64, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _P, _P, _P, _P,
@@ -234,6 +228,8 @@ _SIGS = {
     "nvr_paged_attn_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int64, C.c_int64]),
     "nvr_paged_attn_decode": (C.c_int, [_P, C.c_int64, _P, _P, C.POINTER(AttnMetaC), C.c_int64, C.c_int64, C.c_int64,
                                         C.c_int64, C.c_float, _P, _P, _P]),
+    "nvr_paged_attn_decode_fused": (C.c_int, [_P, C.c_int64, _P, _P, C.POINTER(AttnMetaC), C.c_int64, C.c_int64, C.c_int64,
+                                              C.c_int64, C.c_float, _P, _P, _P, _P]),
     "nvr_paged_attn_decode_shared": (C.c_int, [_P, C.c_int64, _P, _P, C.POINTER(AttnMetaC), C.c_int64, C.c_int64, C.c_int64,
                                                C.c_int64, C.c_float, C.c_int64, _P, _P, _P, _P, _P, _P]),
     "nvr_attn_prefill_varlen": (C.c_int, [_P, _P, _P, C.c_int64, C.POINTER(AttnMetaC), C.c_int64, C.c_int64, C.c_int64,

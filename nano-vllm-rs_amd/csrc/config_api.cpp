@@ -23,6 +23,7 @@ void nvr_config_default(nvr_config *c) {                             // config.r
     c->max_num_batched_tokens = 32768; c->max_num_seqs = 512; c->max_model_len = 4096;
     c->gpu_memory_utilization = 0.9f; c->tensor_parallel_size = 1; c->enforce_eager = 0;
     c->has_eos = 0; c->kvcache_block_size = 256; c->num_kvcache_blocks = -1;
+    c->async_decode = 1;                                                  // launch-ahead of greedy decode steps: transparent (same batches, tokens, statistics)
     std::strcpy(c->device, "hip"); std::strcpy(c->dtype, "float16");     // config.rs:67-68 ("cuda" there)
 }
 static bool cfg_str_in(const char *v, size_t cap, std::initializer_list<const char *> set) {
@@ -52,8 +53,8 @@ int nvr_config_validate(const nvr_config *c) {                       // config.r
         return nvr::fail(NVR_ERR_INVALID_ARG, "Unsupported device: %.15s", c->device);
     if (!cfg_str_in(c->dtype, sizeof c->dtype, {"float16", "bfloat16", "float32"}))                      // config.rs:113-116
         return nvr::fail(NVR_ERR_INVALID_ARG, "Unsupported dtype: %.15s", c->dtype);
-    if (c->decode_chain != 0 && c->decode_chain != 4 && c->decode_chain != 5 && c->decode_chain != 6)
-        return nvr::fail(NVR_ERR_INVALID_ARG, "decode_chain must be 0, 4, 5 or 6, got %u", c->decode_chain);
+    if (c->decode_chain != 0 && c->decode_chain != 6)
+        return nvr::fail(NVR_ERR_INVALID_ARG, "decode_chain must be 0 (reserved; 6 = the same six-launch chain), got %u", c->decode_chain);
     return NVR_OK;
 }
 }  // extern "C"

@@ -39,6 +39,7 @@ struct AttnParams {
     const int32_t *kv0_rows;           // per-query kv0 (shared-prefix groups: members shared_len, others 0) or null = p.kv0 for all
     float *part_o; float *part_ml;     // [nq, H, num_parts, D], [nq, H, num_parts, 2]
     half_t *out;                       // [nq, H, D]
+    unsigned int *tickets;             // FUSE: one arrival counter per (query, kv head), zero between launches (the last arriver re-arms it)
 };
 
 template <bool NT>
@@ -70,7 +71,49 @@ __device__ __forceinline__ float groups_max(float x) {
 // block-table entry is a scalar read (v_readlane) from a register copy of the table (lane j holds entry
 // 64*c + j) and the row address is scalar base + small lane offset -- no dependent table load sits between the row
 // loads.
-template <int D, int G, bool PAGED, bool DIRECT_OUT, int U, int WAVES, bool NT, bool UB>
+// out = sum_p e^(m_p-M) o_p / sum_p e^(m_p-M) l_p over partitions [0, np) of ONE (query, head), 4 columns per thread: the partials of up
+// to 8 partitions are requested together (a runtime-count loop of dependent loads would pay one round trip per partition); sums run over
+// the partitions in ascending order for every column.  load_ml(i) / load_o(i): (max, sum) and the 4 columns of partition i — plain loads
+// in the merge kernel, sc1 loads in the last arriver of the fused form (the same arithmetic: the two forms agree bit for bit).
+template <class LoadML, class LoadO>
+__device__ __forceinline__ half4_t merge_partitions(int np, LoadML load_ml, LoadO load_o) {
+    float M = -INFINITY;
+    float4_t o = {0.f, 0.f, 0.f, 0.f};
+    float L = 0.f;
+    for (int i0 = 0; i0 < np; i0 += 8) {
+        float2_t ml[8]; float4_t po[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = min(i0 + u, np - 1);
+            ml[u] = load_ml(i);
+            po[u] = load_o(i);
+        }
+        float Mn = M;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (i0 + u < np) Mn = fmaxf(Mn, ml[u][0]);
+        if (i0 > 0 && Mn != M) { const float r = __expf(M - Mn); o *= r; L *= r; }     // (more than 8 partitions: rescale what is summed)
+        M = Mn;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (i0 + u < np) {
+                const float w = __expf(ml[u][0] - M);
+                o += w * po[u];
+                L += w * ml[u][1];
+            }
+        }
+    }
+    half4_t hv;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) hv[e] = (half_t)(L > 0.f ? o[e] / L : 0.f);
+    return hv;
+}
+
+// FUSE (split-KV, no shared-prefix pass): the merge of a (query, kv head)'s partitions rides on the LAST ARRIVER of its partition workgroups
+// instead of a second launch (cdna guide Guideline 16, counter form): every workgroup publishes its partials write-through (sc1), drains,
+// and one lane draws a ticket from the pair's counter; the workgroup whose ticket says it came last reads all partials back with sc1 loads
+// and merges them with merge_partitions — nobody polls.  On a tensor-parallel rank (1-2 kv heads) every kernel of the decode step sits on the
+// launch floor: one launch less per layer.
+template <int D, int G, bool PAGED, bool DIRECT_OUT, int U, int WAVES, bool NT, bool UB, bool FUSE = false>
 __global__ __launch_bounds__(WAVES * 64) void attn_rows_kernel(AttnParams p) {
     constexpr int LPR = D / 8;          // lanes per K/V row
     constexpr int RPI = 64 / LPR;       // rows per wave-instruction (= tokens per row group)
@@ -247,26 +290,71 @@ __global__ __launch_bounds__(WAVES * 64) void attn_rows_kernel(AttnParams p) {
         }
     }
     __syncthreads();
-    for (int idx = threadIdx.x; idx < G * D; idx += WAVES * 64) {
-        const int i = idx / D, d = idx % D;
-        float M = sm_ml[0][i][0];
+    if constexpr (DIRECT_OUT) {
+        for (int idx = threadIdx.x; idx < G * D; idx += WAVES * 64) {
+            const int i = idx / D, d = idx % D;
+            float M = sm_ml[0][i][0];
 #pragma unroll
-        for (int w2 = 1; w2 < WAVES; ++w2) M = fmaxf(M, sm_ml[w2][i][0]);
-        float o = 0.f, L = 0.f;
+            for (int w2 = 1; w2 < WAVES; ++w2) M = fmaxf(M, sm_ml[w2][i][0]);
+            float o = 0.f, L = 0.f;
 #pragma unroll
-        for (int w2 = 0; w2 < WAVES; ++w2) {
-            const float mw = sm_ml[w2][i][0];
-            const float wgt = (mw == -INFINITY) ? 0.f : __expf(mw - M);
-            o += wgt * sm_acc[w2][i][d];
-            L += wgt * sm_ml[w2][i][1];
-        }
-        const int h = g * G + i;
-        if (DIRECT_OUT) {
+            for (int w2 = 0; w2 < WAVES; ++w2) {
+                const float mw = sm_ml[w2][i][0];
+                const float wgt = (mw == -INFINITY) ? 0.f : __expf(mw - M);
+                o += wgt * sm_acc[w2][i][d];
+                L += wgt * sm_ml[w2][i][1];
+            }
+            const int h = g * G + i;
             p.out[((int64_t)t * p.H + h) * D + d] = (half_t)(L > 0.f ? o / L : 0.f);
-        } else {
-            const int64_t slot = ((int64_t)t * p.H + h) * p.num_parts + part;
-            p.part_o[slot * D + d] = o;
-            if (d == 0) { p.part_ml[slot * 2] = M; p.part_ml[slot * 2 + 1] = L; }
+        }
+    } else {
+        // partials of this partition: 4 columns per thread (the per-column arithmetic is the one of the scalar loop above)
+        constexpr int TPH = D / 4;                                // threads per head
+        static_assert(G * TPH <= WAVES * 64, "one pass over the (head, column group) pairs");
+        // the pair's partials are contiguous: [G heads][num_parts][D] (and [..][2]); buffer offsets stay small whatever the workspace size
+        const int64_t pair0 = ((int64_t)t * p.H + (int64_t)g * G) * p.num_parts;
+        const auto rs_o = __builtin_amdgcn_make_buffer_rsrc(p.part_o + pair0 * D, 0, (int)(G * p.num_parts * D * 4), 0x00020000);
+        const auto rs_ml = __builtin_amdgcn_make_buffer_rsrc(p.part_ml + pair0 * 2, 0, (int)(G * p.num_parts * 2 * 4), 0x00020000);
+        typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+        typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+        if (threadIdx.x < G * TPH) {
+            const int i = threadIdx.x / TPH, d = (threadIdx.x % TPH) * 4;
+            float M = sm_ml[0][i][0];
+#pragma unroll
+            for (int w2 = 1; w2 < WAVES; ++w2) M = fmaxf(M, sm_ml[w2][i][0]);
+            float4_t o = {0.f, 0.f, 0.f, 0.f};
+            float L = 0.f;
+#pragma unroll
+            for (int w2 = 0; w2 < WAVES; ++w2) {
+                const float mw = sm_ml[w2][i][0];
+                const float wgt = (mw == -INFINITY) ? 0.f : __expf(mw - M);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] += wgt * sm_acc[w2][i][d + e];
+                L += wgt * sm_ml[w2][i][1];
+            }
+            const int slot = i * p.num_parts + part;             // inside the pair's region
+            constexpr int AUX = FUSE ? 16 : 0;                    // sc1: write-through, no release fence needed
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, o), rs_o, (slot * D + d) * 4, 0, AUX);
+            if (d == 0) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, (float2_t){M, L}), rs_ml, slot * 8, 0, AUX);
+        }
+        if constexpr (FUSE) {
+            __shared__ unsigned int ticket_s;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // every storing wave drains its stores ...
+            __syncthreads();
+            unsigned int *cnt = p.tickets + (int64_t)t * p.KVH + g;
+            if (threadIdx.x == 0) ticket_s = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... one ticket
+            __syncthreads();
+            const int np = min(p.num_parts, (ctx + p.part_size - 1) / p.part_size);   // non-empty partitions of this query
+            if (ticket_s != (unsigned)(np - 1)) return;                       // not the last partition of this pair to finish: done
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");            // keeps the sc1 loads below the ticket
+            if (threadIdx.x < G * TPH) {
+                const int i = threadIdx.x / TPH, d = (threadIdx.x % TPH) * 4;
+                const half4_t hv = merge_partitions(np,
+                    [&](int pi) { return __builtin_bit_cast(float2_t, __builtin_amdgcn_raw_buffer_load_b64(rs_ml, (i * p.num_parts + pi) * 8, 0, 16)); },
+                    [&](int pi) { return __builtin_bit_cast(float4_t, __builtin_amdgcn_raw_buffer_load_b128(rs_o, ((i * p.num_parts + pi) * D + d) * 4, 0, 16)); });
+                *reinterpret_cast<half4_t *>(p.out + ((int64_t)t * p.H + g * G + i) * D + d) = hv;
+            }
+            if (threadIdx.x == 0) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch
         }
     }
 }
@@ -288,34 +376,9 @@ __global__ __launch_bounds__(256) void attn_merge_kernel(const float *__restrict
     const int first = (part0 > 0 && my_kv0 == 0) ? part0 : 0;   // a query outside the sharing group has no partials in the shared slots
     const int np = min(num_parts, part0 + (max(ctx_lens[t] - my_kv0, 0) + part_size - 1) / part_size) - first;
     const int64_t base = pair * num_parts + first;
-    float M = -INFINITY;
-    float4_t o = {0.f, 0.f, 0.f, 0.f};
-    float L = 0.f;
-    for (int i0 = 0; i0 < np; i0 += 8) {
-        float2_t ml[8]; float4_t po[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int i = min(i0 + u, np - 1);
-            ml[u] = *reinterpret_cast<const float2_t *>(part_ml + (base + i) * 2);
-            po[u] = *reinterpret_cast<const float4_t *>(part_o + (base + i) * D + d);
-        }
-        float Mn = M;
-#pragma unroll
-        for (int u = 0; u < 8; ++u) if (i0 + u < np) Mn = fmaxf(Mn, ml[u][0]);
-        if (i0 > 0 && Mn != M) { const float r = __expf(M - Mn); o *= r; L *= r; }     // (more than 8 partitions: rescale what is summed)
-        M = Mn;
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            if (i0 + u < np) {
-                const float w = __expf(ml[u][0] - M);
-                o += w * po[u];
-                L += w * ml[u][1];
-            }
-        }
-    }
-    half4_t hv;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) hv[e] = (half_t)(L > 0.f ? o[e] / L : 0.f);
+    const half4_t hv = merge_partitions(np,
+        [&](int i) { return *reinterpret_cast<const float2_t *>(part_ml + (base + i) * 2); },
+        [&](int i) { return *reinterpret_cast<const float4_t *>(part_o + (base + i) * D + d); });
     *reinterpret_cast<half4_t *>(out + pair * D + d) = hv;
 }
 
@@ -341,15 +404,17 @@ size_t attn_workspace_bytes(int64_t nq, int64_t H, int64_t D, int64_t max_ctx) {
 }
 
 template <int D, int G, int U, int WAVES, bool NT>
-static void launch_cfg(const AttnParams &p, bool paged, bool direct, int64_t nwg, hipStream_t s) {
+static void launch_cfg(const AttnParams &p, bool paged, bool direct, int64_t nwg, hipStream_t s, bool fuse = false) {
     dim3 grid((unsigned)nwg), block(WAVES * 64);
     constexpr int TPI = 64 / (D / 8) * U;
     const bool ub = paged && p.block_size % TPI == 0 && (p.num_parts == 1 || p.part_size % TPI == 0);
     if (ub) {
         if (direct) attn_rows_kernel<D, G, true, true, U, WAVES, NT, true><<<grid, block, 0, s>>>(p);
+        else if (fuse) attn_rows_kernel<D, G, true, false, U, WAVES, NT, true, true><<<grid, block, 0, s>>>(p);
         else attn_rows_kernel<D, G, true, false, U, WAVES, NT, true><<<grid, block, 0, s>>>(p);
     } else if (paged) {
         if (direct) attn_rows_kernel<D, G, true, true, U, WAVES, NT, false><<<grid, block, 0, s>>>(p);
+        else if (fuse) attn_rows_kernel<D, G, true, false, U, WAVES, NT, false, true><<<grid, block, 0, s>>>(p);
         else attn_rows_kernel<D, G, true, false, U, WAVES, NT, false><<<grid, block, 0, s>>>(p);
     } else {
         if (direct) attn_rows_kernel<D, G, false, true, U, WAVES, NT, false><<<grid, block, 0, s>>>(p);
@@ -427,15 +492,18 @@ static int launch_attn(const AttnArgs &a, bool paged, hipStream_t s) {
     }
     p.part0 = sparts; p.kv0 = shared ? a.shared_len : 0; p.kv0_rows = shared ? a.shared_kv0 : nullptr;
     const int64_t nwg = (int64_t)(p.num_parts - p.part0) * a.KVH * a.nq;
+    // split-KV without a shared-prefix pass: the last partition workgroup of a (query, kv head) to finish merges the pair (no merge launch)
+    const bool fuse = !direct && !shared && paged && a.tickets != nullptr;
+    p.tickets = a.tickets;
     if (shared)
         if (int rc = flash_shared_prefix(a.q, a.ldq, a.k, a.v, a.block_tables, a.max_blocks, a.block_size, a.nq, a.H, a.KVH, a.D, a.scale,
                                          shared_part, sparts, np, p.part_o, p.part_ml, s, a.shared_rows, a.shared_count)) return rc;
     {
-        if (waves == 8) launch_cfg<D, G, DU / 2, 8, true>(p, paged, direct, nwg, s);        // K/V streamed once: nt loads
-        else if (paged) launch_cfg<D, G, DU, 4, true>(p, paged, direct, nwg, s);
+        if (waves == 8) launch_cfg<D, G, DU / 2, 8, true>(p, paged, direct, nwg, s, fuse);  // K/V streamed once: nt loads
+        else if (paged) launch_cfg<D, G, DU, 4, true>(p, paged, direct, nwg, s, fuse);
         else launch_cfg<D, G, DU, 4, false>(p, paged, direct, nwg, s);                     // prefill: rows re-read from L2
     }
-    if (!direct)
+    if (!direct && !fuse)
         attn_merge_kernel<D><<<dim3((unsigned)(((int64_t)a.H * a.nq + 256 / (D / 4) - 1) / (256 / (D / 4)))), dim3(256), 0, s>>>(
             p.part_o, p.part_ml, a.ctx_lens, a.H, part_size, np, p.part0, p.kv0, p.kv0_rows, (int64_t)a.H * a.nq, p.out);
     hipError_t e = hipGetLastError();

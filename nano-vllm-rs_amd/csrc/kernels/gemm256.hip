@@ -41,15 +41,6 @@ struct G256Epi {
     int32_t kv_cache_only;             // GEPI_ROPE: k and v rows go to the caches only (the attention that follows reads them there)
 };
 
-#ifndef G256_STAMPS
-#define G256_STAMPS 0             // 1: diagnostic build only (shader-clock stamps of workgroup 0 into g256_dbg; never shipped): scratch/gemm_stamps.py
-#endif
-#if G256_STAMPS
-__device__ unsigned long long g256_dbg[2 * 64 * 8];
-#define G256_STAMP(i) if (blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 4) && tile_no < 64) g256_dbg[((wave >> 2) * 64 + tile_no) * 8 + (i)] = __builtin_readcyclecounter();
-#else
-#define G256_STAMP(i)
-#endif
 constexpr int G_BK = 64, G_HT = 128, G_HALF = G_HT * G_BK * 2;          // 16 KiB per half-tile
 constexpr int G_BUF = 4 * G_HALF;                                         // A0 A1 B0 B1
 
@@ -209,7 +200,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const half_t *__restrict__
 
     int tile_no = 0;
     for (int g = 0;; ) {
-        G256_STAMP(0)
+
         if (grp == 1) __builtin_amdgcn_s_barrier();                       // stagger
 #pragma unroll
         for (int a = 0; a < 2; ++a)
@@ -231,7 +222,6 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const half_t *__restrict__
             read_b(buf, 0); read_a(buf, 0);
             G256_S(0)
             G256_W(2)
-            if (kt == 0) { G256_STAMP(1) }
             G256_M(acc[0], 0)
             // phase 1: (A0, B1)
             read_b(buf, 1);
@@ -248,10 +238,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const half_t *__restrict__
             G256_S(1)
             G256_W(0)
             G256_M(acc[1], 0)
-            if (kt == 0) { G256_STAMP(2) }
         }
         if (grp == 0) __builtin_amdgcn_s_barrier();                       // re-align the groups
-        G256_STAMP(3)
+
 
         // ---- epilogue of `tile`: the buffer of the K-tile just consumed is dead: per 128-token half hB, stage
         // [token][column] there (16-byte chunks XOR-swizzled by the row) and write 16-byte pieces of contiguous rows,
@@ -361,7 +350,6 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const half_t *__restrict__
                 }
             }
             __syncthreads();
-            if (hB == 0) { G256_STAMP(4) }
             constexpr int CPR = OUTC / 8;                                 // 16-byte pieces per row
             if (EPI == GEPI_RESID) {
                 // h <- fp16(h + fp16(acc)): the rounding points of add_rmsnorm's add
@@ -409,7 +397,6 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const half_t *__restrict__
                     }
                 }
                 __syncthreads();
-                if (hB == 0) { G256_STAMP(5) } else { G256_STAMP(6) }
                 continue;
             }
 #pragma unroll
@@ -519,9 +506,4 @@ int gemm256_qkv_rope_store(const half_bits *x, int64_t ldx, const half_bits *W, 
     return g256_check("gemm256_qkv_rope_store");
 }
 
-#if G256_STAMPS
-extern "C" __attribute__((visibility("default"))) int nvr_debug_g256_stamps(unsigned long long *out) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g256_dbg), sizeof(g256_dbg));
-}
-#endif
 }}  // namespace nvr::k / nvr::kb (NVR_DT_NS)

@@ -65,19 +65,7 @@ int linear_qkv_rope_store(const half_bits *x, int64_t ldx, const half_bits *W, i
 // kv_cache_only: the caller's attention reads K / V from the caches only, so the k and v columns of qkv need not be written (the 256^2
 // prefill kernel then skips those stores: a third of its output bytes; the other routes write them anyway)
 
-// The decode chain in four launches per layer (linear_decode.hip): the residual add rides on the split-k reduction of the
-// row-parallel GEMMs (last arriver of a tile), the RMSNorm in the prologue of the GEMM that consumes it.
-bool decode_chain_ok(int64_t T, int64_t Hd, int64_t qkv_rows, int64_t I, int64_t D);
-int decode_splitk_slices(int64_t T, int64_t K, int64_t N);
-// h[T,N] <- fp16(h + fp16(x·Wᵀ)); slabs [S][T][N] f32 scratch; cnt: (N/16)*ceil(T/32) zeroed counters (left zeroed)
-int linear_resid(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t N, int64_t S, float *slabs,
-                 unsigned int *cnt, half_bits *h, hipStream_t s, const half_bits *Wt = nullptr);
-int linear_silu_mul_normed(const half_bits *h, int64_t ldx, const half_bits *wn, float eps, const half_bits *W, int64_t T, int64_t K,
-                           int64_t I, half_bits *out, hipStream_t s, const half_bits *Wt = nullptr);
-int linear_qkv_rope_store_normed(const half_bits *h, int64_t ldx, const half_bits *wn, float eps, const half_bits *W, int64_t T, int64_t K,
-                                 int64_t H, int64_t KVH, int64_t D, const int64_t *positions, const int32_t *slots, const float *cos_t,
-                                 const float *sin_t, half_bits *qkv, half_bits *k_cache, half_bits *v_cache, hipStream_t s,
-                                 const half_bits *Wt = nullptr);
+int decode_splitk_slices(int64_t T, int64_t K, int64_t N);     // k-slices of linear_splitk for the N = hidden GEMMs of a decode-sized step
 
 // decode GEMMs over large weights (T <= 32, K >= 2048, >= 24 MiB of weights): activation block in LDS, persistent workgroups
 // (linear_stream.hip); linear / linear_silu_mul / linear_qkv_rope_store route here when the shape test passes
@@ -122,12 +110,6 @@ int gemm256_silu_mul(const half_bits *x, int64_t ldx, const half_bits *W, int64_
 int gemm256_qkv_rope_store(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t H, int64_t KVH, int64_t D,
                            const int64_t *positions, const int32_t *slots, const float *cos_t, const float *sin_t, half_bits *qkv,
                            half_bits *k_cache, half_bits *v_cache, hipStream_t s, bool kv_cache_only = false);
-
-// the MLP pair of a decode layer as one persistent launch (kernels/mlp_engine.hip): act = SiluAndMul(x·W_gate_upᵀ), slabs[4] = k-slices of act·W_downᵀ
-bool mlp_engine_ok(int64_t T, int64_t Hd, int64_t I, int ncu);
-size_t mlp_engine_sync_bytes();
-int mlp_engine(const half_bits *x, int64_t ldx, const half_bits *gate_up_t, const half_bits *down_t, int64_t T, int64_t Hd, int64_t I,
-               half_bits *act, float *slabs, unsigned *sync, hipStream_t s);
 
 size_t attn_workspace_bytes(int64_t nq, int64_t H, int64_t D, int64_t max_ctx);
 int attention(const AttnArgs &a, bool paged, hipStream_t s);

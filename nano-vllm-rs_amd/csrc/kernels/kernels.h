@@ -38,6 +38,9 @@ struct AttnArgs {
     // ... or only SOME queries' (device arrays, all three or none): shared_rows[0 .. *shared_count) are the member rows (the
     // first one's block table names the shared blocks), shared_kv0[t] = shared_len for members, 0 for the others
     const int32_t *shared_rows, *shared_kv0, *shared_count;
+    // paged decode, split over partitions: [nq * KVH] arrival counters, ZERO between launches (the kernel re-arms them): the merge of a
+    // (query, kv head)'s partitions then rides on the last partition workgroup to finish instead of a second launch; null = merge launch
+    unsigned int *tickets;
 };
 
 // MFMA flash prefill attention.  A tile = up to 64/G consecutive query positions of one sequence.

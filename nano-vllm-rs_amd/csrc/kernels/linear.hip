@@ -244,6 +244,14 @@ static inline bool prefer_256(int64_t T, int64_t K, int64_t N) {
 // one rule for the plain and the fused launchers (N = output features), so that a fused GEMM and its unfused twin run the same kernel
 bool gemm256_preferred(int64_t T, int64_t K, int64_t N, int64_t ldx) { return gemm256_ok(T, K, N, ldx) && prefer_256(T, K, N); }
 int64_t stream_row_limit() { return 64; }
+// k-slices of the N = hidden GEMMs of a decode-sized step (linear_splitk): reach ~256 workgroups with slices of >= 256 columns that are
+// multiples of 64
+int decode_splitk_slices(int64_t T, int64_t K, int64_t N) {
+    int64_t S = 1;
+    const int64_t tiles = (N / 16) * ((T + 31) / 32);
+    while (S < 4 && tiles * S < 256 && K % (32 * S * 2) == 0 && K / (S * 2) >= 128) S *= 2;
+    return (int)S;
+}
 static inline bool prefer_stream(int64_t T, int64_t N) {
     // up to 64 rows the weight-streaming kernel; beyond, the LDS-tiled kernel with 32- / 64-token tiles and the 4-buffer ring (r02,
     // ctx 256: bs 66 2.20 -> 1.83 ms/step, bs 96 2.48 -> 2.15, bs 128 2.82 -> 2.23).

@@ -40,8 +40,7 @@ nvr_model_runner::~nvr_model_runner() {
     if (stream) hipStreamSynchronize(stream);
     for (auto &g : graphs) hipGraphExecDestroy(g.second);
     comm.destroy();
-    if (chain_cnt) hipFree(chain_cnt);
-    if (mlp_sync) hipFree(mlp_sync);
+    if (attn_tickets) hipFree(attn_tickets);
     for (auto &l : layers) { hipFree(l.qkv); hipFree(l.o); hipFree(l.gate_up); hipFree(l.down); hipFree(l.ln1); hipFree(l.ln2);
                              void *ts[] = {l.qkv_t, l.o_t, l.gate_up_t, l.down_t, l.q_norm, l.k_norm, l.qkv_b, l.o_b, l.gate_up_b, l.down_b}; for (void *t : ts) if (t) hipFree(t); }
     if (lm_head_t) hipFree(lm_head_t);
@@ -80,6 +79,15 @@ int nvr_model_runner::init() {                                       // ModelRun
     max_tokens = cfg.max_num_batched_tokens; max_seqs = cfg.max_num_seqs;
     max_pos = std::min<int64_t>(mc.max_position_embeddings, std::max<int64_t>(cfg.max_model_len, 1));
     max_blocks_per_seq = (max_pos + block_size - 1) / block_size + 1;
+    if (f32) {
+        // the f32 attention kernel keeps a query's scores in LDS (kernels/f32_path.hip): decode steps are launched for the 256-token context
+        // bucket, so refuse here what would otherwise fail at step time, inside a stream capture
+        const int64_t bucket = (max_pos + 255) / 256 * 256;
+        if ((bucket + 5 * D + 8) * 4 > 160 * 1024)
+            return nvr::fail(NVR_ERR_UNSUPPORTED, "dtype float32: max_model_len %ld (context bucket %ld) does not fit the attention kernel's score buffer "
+                             "(%ld bytes of LDS, 163840 available): at most %ld tokens at head_dim %ld", (long)max_pos, (long)bucket,
+                             (long)((bucket + 5 * D + 8) * 4), (long)((160 * 1024 / 4 - 5 * D - 8) / 256 * 256), (long)D);
+    }
 
     device = cfg.device_ordinal;
     NVR_HIP_CHECK(hipSetDevice(device));
@@ -117,12 +125,7 @@ int nvr_model_runner::init() {                                       // ModelRun
     RC(dmalloc(&act, em * max_tokens * I)); RC(dmalloc(&nlast, em * max_seqs * Hd)); RC(dmalloc(&logits, max_seqs * Vl));
     slab_rows = std::max<int64_t>(64, std::min<int64_t>(1024, std::max<int64_t>(max_seqs, 256)));
     RC(dmalloc(&slabs, 4 * slab_rows * Hd));
-    chain4 = cfg.decode_chain == 4;
-    chain5 = cfg.decode_chain == 5;
     { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && v > 0) num_cus = v; }
-    if (chain5) NVR_HIP_CHECK(hipMalloc((void **)&mlp_sync, KD(mlp_engine_sync_bytes())));
-    NVR_HIP_CHECK(hipMalloc((void **)&chain_cnt, 4096 * sizeof(unsigned int)));
-    NVR_HIP_CHECK(hipMemset(chain_cnt, 0, 4096 * sizeof(unsigned int)));
     allow_missing_comm = env.tp_no_comm;                                               // compute-only profiling of one rank
     if (!env.tp_graph && tp > 1) graphs_disabled = true;
     comm.force = env.tp_force_comm; comm.timeout_ms = env.p2p_timeout_ms;
@@ -137,6 +140,10 @@ int nvr_model_runner::init() {                                       // ModelRun
     // the split-KV workspace is sized for the largest bucket (launch_attn checks the bytes it is given)
     attn_ws_bytes = KD(attn_workspace_bytes(max_seqs, H, D, (max_pos + 255) / 256 * 256));
     NVR_HIP_CHECK(hipMalloc(&attn_ws, attn_ws_bytes));
+    if (env.attn_fused_merge && !f32) {
+        NVR_HIP_CHECK(hipMalloc((void **)&attn_tickets, (size_t)(max_seqs * KVH) * sizeof(unsigned int)));
+        NVR_HIP_CHECK(hipMemset(attn_tickets, 0, (size_t)(max_seqs * KVH) * sizeof(unsigned int)));
+    }
     // step-input arena
     auto carve = [&](size_t &off, size_t bytes) { off = in_bytes; in_bytes += (bytes + 255) / 256 * 256; };
     // prefill region (the start of the arena): capacity for the largest step; a step lays its arrays out back to back for its own
@@ -512,7 +519,7 @@ int nvr_model_runner::copy_weight(const char *ln, uint16_t *out, size_t cap, int
 }
 
 // RowParallelLinear::forward (o_proj / down_proj, linear.rs:228-239) + the residual add and the next RMSNorm
-// (qwen3.rs:382-389) of the SIX-launch chain (prefill, tensor-parallel ranks, large models, decode_chain = 6): decode-sized
+// (qwen3.rs:382-389): decode-sized
 // steps on one GPU split k over S workgroups per output tile so that the N = hidden GEMMs reach all 256 CUs; the f32 partial
 // slabs are summed, added to the residual and normalised by the following add_rmsnorm_slabs launch.  Otherwise the plain kernel
 // writes fp16 `proj` (+ all-reduce when tensor parallel) and add_rmsnorm follows.
@@ -590,20 +597,6 @@ int nvr_model_runner::row_parallel_norm(const uint16_t *x, int64_t K, const uint
         return comm.all_reduce_add_rmsnorm(proj, h, wn, mc.rms_norm_eps, (int)T, (int)Hd, n, stream);
     if (comm.active()) RC(comm.all_reduce_sum_f16(proj, (size_t)(T * Hd), stream));
     return KD(add_rmsnorm(h, proj, wn, mc.rms_norm_eps, T, Hd, n, stream));
-}
-
-// The four-launch decode chain (kernels/linear_decode.hip) runs single-rank decode-sized steps of models whose hidden rows fit
-// the norm-prologue kernels; everything else (prefill, tensor-parallel ranks with their all-reduce between GEMM and residual,
-// Qwen3-8B-class weights with their streaming kernels) keeps the six-launch chain.
-bool nvr_model_runner::use_chain4(int64_t T, bool is_prefill) const {
-    return chain4 && !mc.qk_norm && !mc.use_bias && !is_prefill && tp == 1 && !comm.active() && KD(decode_chain_ok(T, Hd, QKV, I, D)) &&
-           H * D <= 4096 && I <= 8192 && Hd * std::max(H * D, I) * 2 < (24ll << 20);
-}
-
-// decode_chain = 5: the MLP pair of a single-rank decode step of <= 32 rows as one persistent launch, when the shape is instantiated, every
-// workgroup fits the device at once and the tiled weight copies exist (the loader streams those)
-bool nvr_model_runner::use_mlp_engine(int64_t T, bool is_prefill) const {
-    return chain5 && !is_prefill && tp == 1 && !comm.active() && tiled_weights && T <= 32 && T <= slab_rows && KD(mlp_engine_ok(T, Hd, I, num_cus));
 }
 
 // Decode batches in which many sequences start with the same cache blocks (prefix-cache hits of BlockManager::allocate,
@@ -765,27 +758,21 @@ int nvr_model_runner::forward(int64_t T, int64_t B, bool is_prefill, int64_t max
     const int32_t *bt = dd_bt;
     if (f32) return forward_f32(T, B, is_prefill, max_ctx);
     if (is_prefill && tp_overlap == 2 && mb_rows > 0) return forward_prefill_two(T, B);
-    const bool c4 = use_chain4(T, is_prefill);
     const bool tl = tiled_weights && T <= 64;                            // decode-sized steps stream the tiled weight copies
-    const bool embed_norm = !c4 && L > 0 && KD(embedding_rmsnorm_ok(T, Hd));                    // decode-sized: K1 + the first norm in one launch
+    const bool embed_norm = L > 0 && KD(embedding_rmsnorm_ok(T, Hd));                    // decode-sized: K1 + the first norm in one launch
     if (embed_norm) RC(KD(embedding_rmsnorm(ids, T, embed, layers[0].ln1, mc.rms_norm_eps, Hd, h, n, st)));
     else RC(KD(embedding(ids, T, embed, Hd, h, st)));
     for (int64_t l = 0; l < L; ++l) {
         const Layer &w = layers[l];
-        if (c4) {                                    // input norm :378 in the prologue of the qkv GEMM (K2..K6 in one launch)
-            RC(KD(linear_qkv_rope_store_normed(h, Hd, w.ln1, mc.rms_norm_eps, w.qkv, T, Hd, H, KVH, D, pos, slots, cos_t, sin_t, qkv,
-                                               k_cache(l), v_cache(l), st, tl ? w.qkv_t : nullptr)));
+        if (l == 0 && !embed_norm) RC(KD(rmsnorm(h, w.ln1, mc.rms_norm_eps, T, Hd, n, st)));   // later layers: see down_proj
+        if (mc.qk_norm || mc.use_bias) {         // A-27: the head norms sit between the projection and RoPE: plain GEMM, then one
+            RC(KD(linear(n, Hd, w.qkv, T, Hd, QKV, qkv, false, st, tl ? w.qkv_t : nullptr)));      // norm + RoPE + KV-store launch
+            if (mc.use_bias) RC(KD(add_bias(qkv, w.qkv_b, T, QKV, st)));                            // A-30: the bias precedes the norms and RoPE (qwen3.rs:208-222)
+            RC(KD(rope_store_kv(qkv, pos, slots, T, H, KVH, D, cos_t, sin_t, k_cache(l), v_cache(l), st, w.q_norm, w.k_norm, mc.rms_norm_eps)));
         } else {
-            if (l == 0 && !embed_norm) RC(KD(rmsnorm(h, w.ln1, mc.rms_norm_eps, T, Hd, n, st)));   // later layers: see down_proj
-            if (mc.qk_norm || mc.use_bias) {         // A-27: the head norms sit between the projection and RoPE: plain GEMM, then one
-                RC(KD(linear(n, Hd, w.qkv, T, Hd, QKV, qkv, false, st, tl ? w.qkv_t : nullptr)));      // norm + RoPE + KV-store launch
-                if (mc.use_bias) RC(KD(add_bias(qkv, w.qkv_b, T, QKV, st)));                            // A-30: the bias precedes the norms and RoPE (qwen3.rs:208-222)
-                RC(KD(rope_store_kv(qkv, pos, slots, T, H, KVH, D, cos_t, sin_t, k_cache(l), v_cache(l), st, w.q_norm, w.k_norm, mc.rms_norm_eps)));
-            } else {
-                // qkv GEMM with the RoPE + KV-store epilogue (K3..K6 in one launch)
-                RC(KD(linear_qkv_rope_store(n, Hd, w.qkv, T, Hd, H, KVH, D, pos, slots, cos_t, sin_t, qkv, k_cache(l), v_cache(l), st, tl ? w.qkv_t : nullptr,
-                                            is_prefill && n_tiles > 0 && (prefill_paged || prefill_kv_cache))));
-            }
+            // qkv GEMM with the RoPE + KV-store epilogue (K3..K6 in one launch)
+            RC(KD(linear_qkv_rope_store(n, Hd, w.qkv, T, Hd, H, KVH, D, pos, slots, cos_t, sin_t, qkv, k_cache(l), v_cache(l), st, tl ? w.qkv_t : nullptr,
+                                        is_prefill && n_tiles > 0 && (prefill_paged || prefill_kv_cache))));
         }
         k::AttnArgs a{};
         a.q = qkv; a.ldq = QKV; a.ctx_lens = ctx; a.nq = (int32_t)T; a.H = (int32_t)H; a.KVH = (int32_t)KVH; a.D = (int32_t)D;
@@ -807,7 +794,7 @@ int nvr_model_runner::forward(int64_t T, int64_t B, bool is_prefill, int64_t max
             RC(KD(attention(a, false, st)));
         } else {                                                     // flash_attention_decode, attention.rs:225-235
             a.k = k_cache(l); a.v = v_cache(l); a.block_tables = bt; a.max_blocks = (int32_t)max_blocks_per_seq;
-            a.block_size = (int32_t)block_size; a.workspace = attn_ws; a.workspace_bytes = attn_ws_bytes;
+            a.block_size = (int32_t)block_size; a.workspace = attn_ws; a.workspace_bytes = attn_ws_bytes; a.tickets = attn_tickets;
             a.shared_len = (int32_t)decode_shared_len;
             if (decode_shared_len > 0 && decode_shared_rows < T) {     // a group inside the batch: per-row kv0, member rows, member count
                 a.shared_kv0 = (const int32_t *)(in_dev + off_dec + dof_skv0); a.shared_rows = (const int32_t *)(in_dev + off_dec + dof_srows);
@@ -815,33 +802,19 @@ int nvr_model_runner::forward(int64_t T, int64_t B, bool is_prefill, int64_t max
             }
             RC(KD(attention(a, true, st)));
         }
-        if (c4) {
-            // o_proj + residual :382 (the split-k reduction's last arriver adds h); post-attention norm :385 in the prologue of
-            // gate_up + SiluAndMul; down_proj + residual :389.  The next layer's input norm is the next qkv launch's prologue.
-            RC(KD(linear_resid(attn, H * D, w.o, T, H * D, Hd, k::decode_splitk_slices(T, H * D, Hd), slabs, chain_cnt, h, st, tl ? w.o_t : nullptr)));
-            RC(KD(linear_silu_mul_normed(h, Hd, w.ln2, mc.rms_norm_eps, w.gate_up, T, Hd, I, act, st, tl ? w.gate_up_t : nullptr)));
-            RC(KD(linear_resid(act, I, w.down, T, I, Hd, k::decode_splitk_slices(T, I, Hd), slabs, chain_cnt, h, st, tl ? w.down_t : nullptr)));
-        } else {
-            RC(row_parallel_norm(attn, H * D, w.o, tl ? w.o_t : nullptr, T, w.ln2, w.o_b));  // o_proj, residual :382, norm :385
-            if (mc.use_bias) {                       // A-30: gate_up_proj, its bias, then SiluAndMul on the biased halves (qwen3.rs:305-314)
-                RC(KD(linear(n, Hd, w.gate_up, T, Hd, 2 * I, gu, false, st, tl ? w.gate_up_t : nullptr)));
-                RC(KD(add_bias(gu, w.gate_up_b, T, 2 * I, st)));
-                RC(KD(silu_and_mul(gu, T, I, act, st)));
-                RC(row_parallel_norm(act, I, w.down, tl ? w.down_t : nullptr, T, l + 1 < L ? layers[l + 1].ln1 : norm, w.down_b));
-                continue;
-            }
-            if (use_mlp_engine(T, is_prefill)) {
-                // K12 + K13 + K14 in ONE persistent launch (loader / consumer engine, in-launch hand-off of the activations), then the add + norm launch
-                RC(KD(mlp_engine(n, Hd, w.gate_up_t, w.down_t, T, Hd, I, act, slabs, mlp_sync, st)));
-                RC(KD(add_rmsnorm_slabs(h, slabs, 4, l + 1 < L ? layers[l + 1].ln1 : norm, mc.rms_norm_eps, T, Hd, n, st)));
-                continue;
-            }
-            RC(KD(linear_silu_mul(n, Hd, w.gate_up, T, Hd, I, act, st, tl ? w.gate_up_t : nullptr)));   // K12 + K13 in one launch
-            // down_proj, residual :389 and the NEXT layer's input norm :378 (or the final norm :501)
-            RC(row_parallel_norm(act, I, w.down, tl ? w.down_t : nullptr, T, l + 1 < L ? layers[l + 1].ln1 : norm));
+        RC(row_parallel_norm(attn, H * D, w.o, tl ? w.o_t : nullptr, T, w.ln2, w.o_b));  // o_proj, residual :382, norm :385
+        if (mc.use_bias) {                       // A-30: gate_up_proj, its bias, then SiluAndMul on the biased halves (qwen3.rs:305-314)
+            RC(KD(linear(n, Hd, w.gate_up, T, Hd, 2 * I, gu, false, st, tl ? w.gate_up_t : nullptr)));
+            RC(KD(add_bias(gu, w.gate_up_b, T, 2 * I, st)));
+            RC(KD(silu_and_mul(gu, T, I, act, st)));
+            RC(row_parallel_norm(act, I, w.down, tl ? w.down_t : nullptr, T, l + 1 < L ? layers[l + 1].ln1 : norm, w.down_b));
+            continue;
         }
+        RC(KD(linear_silu_mul(n, Hd, w.gate_up, T, Hd, I, act, st, tl ? w.gate_up_t : nullptr)));   // K12 + K13 in one launch
+        // down_proj, residual :389 and the NEXT layer's input norm :378 (or the final norm :501)
+        RC(row_parallel_norm(act, I, w.down, tl ? w.down_t : nullptr, T, l + 1 < L ? layers[l + 1].ln1 : norm));
     }
-    if (c4 || L == 0) RC(KD(rmsnorm(h, norm, mc.rms_norm_eps, T, Hd, n, st)));                  // final norm :501
+    if (L == 0) RC(KD(rmsnorm(h, norm, mc.rms_norm_eps, T, Hd, n, st)));                  // final norm :501
     const uint16_t *hl = n;
     if (is_prefill) { RC(KD(select_last_tokens(n, d_cu, B, Hd, nlast, st))); hl = nlast; }      // embed_head.rs:272-289
     if (lm_parts > 0) {                                                                        // f32 logits (A-21) + arg-max partials
@@ -1052,7 +1025,18 @@ int nvr_model_runner::execute(nvr_seq *const *seqs, size_t nseq, bool is_prefill
     for (size_t i = 0; i < nseq && !want_logits; ++i) want_logits = seqs[i]->sampling.temperature != 0.0f;
     logits_valid = want_logits;
     lm_input = is_prefill ? nlast : n;                                   // the rows the LM head reads this step (forward())
-    if (is_prefill || cfg.enforce_eager || graphs_disabled) return forward(T, (int64_t)nseq, is_prefill, max_ctx);
+    if (is_prefill || cfg.enforce_eager || graphs_disabled) {
+        const int rc = forward(T, (int64_t)nseq, is_prefill, max_ctx);
+        if (rc && comm_stream) {
+            // a tensor-parallel prefill step that failed half way (row_parallel_norm's chunks, forward_prefill_two) leaves exchanges and events
+            // queued on the communication stream that the compute stream never joined: drain both, so that the next step's collectives are
+            // ordered against nothing left over (the engine aborts the batch, nvr_engine_abort_last_batch)
+            (void)hipStreamSynchronize(comm_stream);
+            (void)hipStreamSynchronize(stream);
+            (void)hipGetLastError();
+        }
+        return rc;
+    }
 
     // decode: replay a hipGraph captured per (batch size, context bucket) — execute_with_cuda_graph :303-326
     const int64_t bucket = (max_ctx + 255) / 256 * 256;

@@ -54,6 +54,7 @@ struct nvr_model_runner {
     uint16_t *h = nullptr, *n = nullptr, *qkv = nullptr, *attn = nullptr, *proj = nullptr, *gu = nullptr, *act = nullptr,
              *nlast = nullptr;
     float *logits = nullptr; void *attn_ws = nullptr; size_t attn_ws_bytes = 0;
+    unsigned int *attn_tickets = nullptr;  // [max_seqs * KVH] arrival counters of the split-KV decode attention (fused merge; zero between launches)
     float *slabs = nullptr;                // split-k partials of o_proj / down_proj for decode-sized steps: [4][64][Hd] f32
     // step inputs: one pinned host arena mirrored by one device arena
     char *in_host = nullptr, *in_dev = nullptr; size_t in_bytes = 0;
@@ -75,13 +76,7 @@ struct nvr_model_runner {
     float *d_gather_logits = nullptr, *d_full_logits = nullptr; void *sample_ws_full = nullptr;   // stochastic sampling under TP (lazy)
     nvr::k::TpArgmaxRec *d_rec = nullptr, *d_gather_rec = nullptr;     // greedy launch-ahead under TP: this rank's records, every rank's
 
-    // decode chain (kernels/linear_decode.hip): one ticket counter per (column tile, token tile) of the row-parallel GEMMs
-    unsigned int *chain_cnt = nullptr;
-    bool chain4 = false;                   // nvr_config.decode_chain == 4: the four-launch chain of linear_decode.hip
-    bool chain5 = false;                   // nvr_config.decode_chain == 5: gate_up+SiLU and down as one persistent launch (kernels/mlp_engine.hip)
-    unsigned int *mlp_sync = nullptr;      // its arrival counters + timeout word (zeroed by every launch)
-    int num_cus = 256;                     // compute units of the device (every workgroup of that launch must be resident)
-    bool use_mlp_engine(int64_t T, bool is_prefill) const;
+    int num_cus = 256;                     // compute units of the device
     std::map<uint64_t, hipGraphExec_t> graphs;
     size_t last_rows = 0; bool last_prefill = false; int64_t last_tokens = 0;
     int64_t decode_shared_len = 0;                       // the last decode step: tokens its sharing group holds in the same leading blocks
@@ -125,7 +120,6 @@ private:
     int gen_weights_f32();
     int forward_f32(int64_t T, int64_t B, bool is_prefill, int64_t max_ctx);
     int row_parallel_norm(const uint16_t *x, int64_t K, const uint16_t *W, const uint16_t *Wt, int64_t T, const uint16_t *wn, const uint16_t *bias = nullptr);
-    bool use_chain4(int64_t T, bool is_prefill) const;
     int64_t *h_tok_dev = nullptr;                        // device-visible address of the pinned token buffer h_tok
     int64_t slab_rows = 64;           // rows the split-k slab buffers hold (row_parallel_norm)
     // sharing group of a decode batch (0 = none / too small: plain paged attention); fills kv0[nseq], rows[nseq], *count of the arena

@@ -474,8 +474,8 @@ int nvr_graph_destroy(void *exec) { NVR_HIP_CHECK(hipGraphExecDestroy((hipGraphE
 // The 16-bit type of the stateless entry points' buffers: fp16 (default) or bfloat16 — per calling thread, like nvr_last_error.
 // Every kernel exists in both builds (kernels/device_utils.h); KO() picks the namespace per call.
 // "float32" (r04): the ops of the reference-precision path (kernels/f32_path.hip) — the nvr_half pointers then address f32 elements; the ops that
-// exist only as fused 16-bit kernels (nvr_linear_qkv_rope_store, nvr_linear_silu_mul, nvr_lm_head, the *_tiled / split-k / shared-prefix forms,
-// nvr_mlp_engine) answer NVR_ERR_UNSUPPORTED: the f32 graph runs their unfused parts.
+// exist only as fused 16-bit kernels (nvr_linear_qkv_rope_store, nvr_linear_silu_mul, nvr_lm_head, the *_tiled / split-k / shared-prefix forms)
+// answer NVR_ERR_UNSUPPORTED: the f32 graph runs their unfused parts.
 static thread_local bool g_ops_bf16 = false, g_ops_f32 = false;
 #define KO(call) (g_ops_bf16 ? nvr::kb::call : nvr::k::call)
 #define FP(p) reinterpret_cast<float *>(const_cast<nvr_half *>(p))
@@ -516,17 +516,6 @@ int nvr_argmax_partials(const float *part_val, const int32_t *part_idx, int32_t 
 int nvr_linear_splitk(const nvr_half *x, int64_t ldx, const nvr_half *W, int64_t T, int64_t K, int64_t N, int64_t S, float *slabs, void *s) {
     NO_F32("nvr_linear_splitk");
     return KO(linear_splitk(x, ldx, W, T, K, N, S, slabs, (hipStream_t)s));
-}
-int nvr_mlp_engine_ok(int64_t T, int64_t Hd, int64_t I) {
-    int dev = 0, ncu = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-    return k::mlp_engine_ok(T, Hd, I, ncu) ? 1 : 0;
-}
-size_t nvr_mlp_engine_sync_bytes(void) { return k::mlp_engine_sync_bytes(); }
-int nvr_mlp_engine(const nvr_half *x, int64_t ldx, const nvr_half *gut, const nvr_half *dt, int64_t T, int64_t Hd, int64_t I, nvr_half *act,
-                   float *slabs, uint32_t *sync, void *s) {
-    NO_F32("nvr_mlp_engine");
-    return KO(mlp_engine(x, ldx, gut, dt, T, Hd, I, act, slabs, sync, (hipStream_t)s));
 }
 int nvr_add_rmsnorm_slabs(nvr_half *h, const float *slabs, int64_t S, const nvr_half *w, float eps, int64_t T, int64_t Hd, nvr_half *out, void *s) {
     NO_F32("nvr_add_rmsnorm_slabs");
@@ -569,23 +558,7 @@ int nvr_linear_add_residual(const nvr_half *x, int64_t ldx, const nvr_half *W, i
         return nvr::fail(NVR_ERR_UNSUPPORTED, "nvr_linear_add_residual: T=%ld K=%ld N=%ld is not a shape of the 256x256 prefill GEMM", (long)T, (long)K, (long)N);
     return KO(gemm256_resid(x, ldx, W, T, K, N, h, (hipStream_t)s));
 }
-int nvr_linear_resid(const nvr_half *x, int64_t ldx, const nvr_half *W, const nvr_half *Wt, int64_t T, int64_t K, int64_t N, int64_t S,
-                     float *slabs, uint32_t *counters, nvr_half *h, void *s) {
-    NO_F32("nvr_linear_resid");
-    return KO(linear_resid(x, ldx, W, T, K, N, S, slabs, counters, h, (hipStream_t)s, Wt));
-}
 int nvr_decode_splitk_slices(int64_t T, int64_t K, int64_t N) { return k::decode_splitk_slices(T, K, N); }
-int nvr_linear_silu_mul_normed(const nvr_half *h, int64_t ldx, const nvr_half *wn, float eps, const nvr_half *W, const nvr_half *Wt, int64_t T,
-                               int64_t K, int64_t I, nvr_half *out, void *s) {
-    NO_F32("nvr_linear_silu_mul_normed");
-    return KO(linear_silu_mul_normed(h, ldx, wn, eps, W, T, K, I, out, (hipStream_t)s, Wt));
-}
-int nvr_linear_qkv_rope_store_normed(const nvr_half *h, int64_t ldx, const nvr_half *wn, float eps, const nvr_half *W, const nvr_half *Wt,
-                                     int64_t T, int64_t K, int64_t H, int64_t KVH, int64_t D, const int64_t *pos, const int32_t *slots,
-                                     const float *cos_t, const float *sin_t, nvr_half *qkv, nvr_half *kc, nvr_half *vc, void *s) {
-    NO_F32("nvr_linear_qkv_rope_store_normed");
-    return KO(linear_qkv_rope_store_normed(h, ldx, wn, eps, W, T, K, H, KVH, D, pos, slots, cos_t, sin_t, qkv, kc, vc, (hipStream_t)s, Wt));
-}
 int nvr_linear_silu_mul(const nvr_half *x, int64_t ldx, const nvr_half *W, int64_t T, int64_t K, int64_t I, nvr_half *out, void *s) {
     NO_F32("nvr_linear_silu_mul");
     return KO(linear_silu_mul(x, ldx, W, T, K, I, out, (hipStream_t)s));
@@ -637,6 +610,16 @@ int nvr_paged_attn_decode(const nvr_half *q, int64_t ldq, const nvr_half *kc, co
     a.q = q; a.ldq = ldq; a.k = kc; a.v = vc; a.ctx_lens = m->context_lens; a.block_tables = m->block_tables;
     a.max_blocks = m->max_blocks; a.block_size = (int32_t)bs; a.nq = m->batch; a.H = (int32_t)H; a.KVH = (int32_t)KVH;
     a.D = (int32_t)D; a.scale = scale; a.max_ctx = m->max_context_len; a.out = out; a.workspace = ws;
+    return KO(attention(a, true, (hipStream_t)s));
+}
+int nvr_paged_attn_decode_fused(const nvr_half *q, int64_t ldq, const nvr_half *kc, const nvr_half *vc, const nvr_attn_meta *m,
+                                int64_t H, int64_t KVH, int64_t D, int64_t bs, float scale, nvr_half *out, void *ws, uint32_t *tickets, void *s) {
+    NO_F32("nvr_paged_attn_decode_fused");
+    if (!tickets) return nvr::fail(NVR_ERR_INVALID_ARG, "nvr_paged_attn_decode_fused: tickets is null");
+    k::AttnArgs a{};
+    a.q = q; a.ldq = ldq; a.k = kc; a.v = vc; a.ctx_lens = m->context_lens; a.block_tables = m->block_tables;
+    a.max_blocks = m->max_blocks; a.block_size = (int32_t)bs; a.nq = m->batch; a.H = (int32_t)H; a.KVH = (int32_t)KVH;
+    a.D = (int32_t)D; a.scale = scale; a.max_ctx = m->max_context_len; a.out = out; a.workspace = ws; a.tickets = tickets;
     return KO(attention(a, true, (hipStream_t)s));
 }
 int nvr_paged_attn_decode_shared(const nvr_half *q, int64_t ldq, const nvr_half *kc, const nvr_half *vc, const nvr_attn_meta *m,

@@ -11,7 +11,7 @@ python3 - "$f" <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: -float(r["TotalDurationNs"]))
-for r in rows[:14]:
+for r in rows[:24]:
     print(f'{float(r["TotalDurationNs"])/1e6:9.2f} ms  n={int(r["Calls"]):6d}  avg {float(r["AverageNs"])/1e3:8.2f} us  {r["Name"][:110]}')
 PY
 find $out -name "*.csv" -delete

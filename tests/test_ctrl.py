@@ -66,3 +66,39 @@ def test_socket_group_single_rank_and_missing_peer():
         ctrl.SocketGroup(rank=0, world=2, addr="127.0.0.1", port=_free_port(), timeout=0.5)
     with pytest.raises(OSError):                                       # no listener: a rank gives up too
         ctrl.SocketGroup(rank=1, world=2, addr="127.0.0.1", port=_free_port(), timeout=0.5)
+
+
+def test_wire_format_is_plain_data_and_frames_are_authenticated(monkeypatch):
+    """nothing that arrives on the control-plane socket is unpickled.  The codec round-trips exactly the values the ranks
+    exchange (bytes, tuples, nested lists, None / bool / int / float / str), refuses anything else, and a decoded frame can only ever be
+    plain data; with NVR_CTRL_SECRET set a frame whose HMAC does not verify — or an oversized one — is refused."""
+    import struct
+    ctrl = nvr_import.load_ctrl()
+    vals = [None, True, 3, -2.5, "x", bytes(range(256)), (bytes(64), 1), [(b"\x00\xff", 0), (b"", 7)], {"a": [1, (2, 3)], "b": b"zz"},
+            ([[1, 2], [3]], [0, 1, True, 5, 2, False])]
+    for v in vals:
+        assert ctrl.loads(ctrl.dumps(v)) == v and type(ctrl.loads(ctrl.dumps(v))) is type(v)
+    import pickle
+    for bad in (object(), {1: 2}, {"__x": 1}, {1, 2}):
+        with pytest.raises(TypeError):
+            ctrl.dumps(bad)
+    with pytest.raises(ValueError):                                    # a pickle is not a frame
+        ctrl.loads(pickle.dumps({"a": 1}))
+    assert "pickle" not in open(ctrl.__file__).read().replace("unpickled", "")
+
+    a, b = socket.socketpair()
+    try:
+        monkeypatch.setenv("NVR_CTRL_SECRET", "s3cret")
+        g = ctrl.SocketGroup(rank=0, world=1)
+        g._send(a, ctrl.dumps(("ok", 1)))
+        assert ctrl.loads(g._recv(b)) == ("ok", 1)
+        monkeypatch.setenv("NVR_CTRL_SECRET", "other")
+        g._send(a, ctrl.dumps("forged"))                               # (sender still holds the first key: built before the change)
+        h = ctrl.SocketGroup(rank=0, world=1)
+        with pytest.raises(ConnectionError, match="does not verify"):
+            h._recv(b)
+        a.sendall(struct.pack("<q", ctrl.MAX_FRAME + 1))
+        with pytest.raises(ConnectionError, match="refused"):
+            h._recv(b)
+    finally:
+        a.close(); b.close()

@@ -3,6 +3,7 @@ and the product's C++ Sequence / BlockManager / Scheduler are bit-exact with the
 restatement of the reference (block ids, block tables, cached-token counts, batch composition,
 preemption order, statistics) — on the reference's own unit-test scenarios (file:line cited) and on
 randomised traces with prefix sharing, block pressure and preemption."""
+import ctypes as C
 import os
 import re
 
@@ -68,8 +69,12 @@ def test_config_and_params_validation():             # config.rs:194-217, sampli
         eo.Config(device="tpu").validate()
     with pytest.raises(nvr.NvrError, match="Unsupported dtype: int8"):
         nvr.Config(dtype="int8").validate()
-    with pytest.raises(nvr.NvrError):
-        nvr.Config(decode_chain=7).validate()
+    for chain in (4, 5, 7):                           # (4 / 5 selected launch chains that left the library in r05: scratch/r04_decode_chain/)
+        with pytest.raises(nvr.NvrError):
+            nvr.Config(decode_chain=chain).validate()
+    # the library's own default (the test suite's Config wrapper, conftest.py, is synchronous): launch-ahead is on since r05
+    raw = nvr.ConfigC(); nvr.lib().nvr_config_default(C.byref(raw))
+    assert raw.async_decode == 1 and raw.decode_chain == 0
     for bad in (dict(temperature=-1.0), dict(max_tokens=0), dict(top_p=1.5), dict(top_k=0)):
         with pytest.raises(nvr.NvrError):
             nvr.SamplingParams(**bad).validate()

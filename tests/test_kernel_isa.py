@@ -14,3 +14,11 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 def test_flash_prefill_isa_keeps_the_hand_counted_ring_intact():
     import check_kernel_isa
     assert check_kernel_isa.check_flash(verbose=False) == []
+
+
+@pytest.mark.skipif(not os.path.exists(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")), reason="hipcc not installed")
+def test_gemm_tiled_rope_position_requests_are_not_touched_before_their_wait():
+    """the inline-asm position prefetch of the mid-batch qkv GEMM's RoPE epilogue (kernels/gemm_tiled.hip) — no spills, and the
+    destination register pair is neither read nor written before the counted wait that covers the request."""
+    import check_kernel_isa
+    assert check_kernel_isa.check_gemm_tiled(verbose=False) == []

@@ -72,8 +72,72 @@ def check_flash(verbose=True):
     return bad
 
 
+def _vregs(tok):
+    """VGPR numbers named by one operand token (v7, v[8:9])"""
+    m = re.fullmatch(r"v(\d+)", tok)
+    if m:
+        return {int(m.group(1))}
+    m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+    return set(range(int(m.group(1)), int(m.group(2)) + 1)) if m else set()
+
+
+def check_gemm_tiled(verbose=True):
+    """the TEPI_ROPE epilogue's positions are requested by an inline-asm global_load_dwordx2 in front of the K loop and are only
+    complete after the counted wait of K-step 0 — the compiler believes the register pair is defined as soon as the asm has run.  Asserted here,
+    per instantiation that holds such a request: no spills / scratch (a spill of the pair would copy it before it has landed), and no
+    instruction reads or writes the destination pair between the request and the first s_waitcnt vmcnt(c) that covers it (at least c
+    vector-memory loads issued after it: vmcnt retires in issue order)."""
+    bad = []
+    for build in ((), ("-DNVR_BF16",)):                                  # the fp16 and the bf16 build of the file (Makefile)
+        bad += _check_gemm_tiled_build(compile_isa("kernels/gemm_tiled.hip", flags=("-ffp-contract=off",) + build), verbose)
+    return bad
+
+
+def _check_gemm_tiled_build(text, verbose):
+    bad = []
+    meta = {m.group(1): (int(m.group(2)), int(m.group(3))) for m in re.finditer(
+        r"\.name:\s+(\S+)\n(?:.*\n)*?\s+\.sgpr_spill_count:\s+(\d+)\n(?:.*\n)*?\s+\.vgpr_spill_count:\s+(\d+)", text)}
+    found = 0
+    for m in re.finditer(r"^(_Z\w*gemm_tiled_kernel\w*):[^\n]*\n(.*?)s_endpgm", text, re.S | re.M):
+        name, body = m.group(1), m.group(2)
+        lines = [l.strip() for l in body.split("\n")]
+        reqs = [i for i, l in enumerate(lines) if l.startswith("global_load_dwordx2") and i > 0 and lines[i - 1].startswith(";;#ASMSTART")]
+        if not reqs:
+            continue
+        found += 1
+        problems = []
+        if any(l.startswith("scratch_") for l in lines):
+            problems.append("scratch traffic")
+        if name in meta and (meta[name][0] or meta[name][1]):
+            problems.append(f"spills {meta[name]}")
+        for i in reqs:
+            dst = _vregs(lines[i].split()[1].rstrip(","))
+            younger, covered = 0, False
+            for l in lines[i + 1:]:
+                if not l or l.startswith((";", ".")):
+                    continue
+                w = re.match(r"s_waitcnt.*vmcnt\((\d+)\)", l)
+                if w and int(w.group(1)) <= younger:
+                    covered = True
+                    break
+                ops = re.findall(r"v\[\d+:\d+\]|v\d+", l)
+                if any(_vregs(o) & dst for o in ops):
+                    problems.append(f"v{sorted(dst)} touched before its wait: {l}")
+                    break
+                if l.startswith(("global_load", "buffer_load", "flat_load")):
+                    younger += 1
+            if not covered and not problems:
+                problems.append("no covering wait found")
+        if verbose:
+            print(f"{name[:90]:90s} {'OK' if not problems else '; '.join(sorted(set(problems)))}  ({len(reqs)} asm position requests)")
+        bad += [name + ": " + q for q in sorted(set(problems))]
+    if found < 2:
+        bad.append(f"only {found} gemm_tiled_kernel instantiations with an inline-asm position request found")
+    return bad
+
+
 if __name__ == "__main__":
-    problems = check_flash()
+    problems = check_flash() + check_gemm_tiled()
     for p in problems:
         print("FAIL", p)
     sys.exit(1 if problems else 0)
