@@ -652,6 +652,8 @@ def main() -> None:
 
     kv_source = [-1]
 
+    host_us = [None]                          # host us per timed step inside Scheduler::schedule / ::postprocess
+
     def run_decode(eng):
         """prefill (untimed), W warm-up steps, K timed steps between barriers; max over ranks"""
         # a warm engine, as in serving: the same-shape prefill run once first on other tokens (seed 3; one new token per sequence, so
@@ -680,11 +682,14 @@ def main() -> None:
             info = eng.step()
             assert not info["is_prefill"] and info["num_seqs"] == BATCH
         barrier()
+        h0 = eng.host_times()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             eng.step()
         nvr.synchronize()
         el = time.perf_counter() - t0
+        h1 = eng.host_times()
+        host_us[0] = {k: round((h1[k + "_us"] - h0[k + "_us"]) / max(1, h1["steps"] - h0["steps"]), 2) for k in ("schedule", "postprocess")}
         barrier()
         if dist is not None:
             el = dist.max(el)
@@ -911,6 +916,8 @@ def main() -> None:
             "value": round(tokens_per_s, 2), "unit": "tokens/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f16", "data": "synthetic",
+            "host_us_per_step": (dict(host_us[0], note="host time inside Scheduler::schedule / ::postprocess (block manager included) per timed decode step, "
+                                                       "rank 0 (SURVEY section 8d); with launch-ahead it runs while the GPU executes the previous step") if host_us[0] else None),
             "config": {"workload": f"{MODELS[args.model]['label']} fp16 random-init, bs={BATCH} x {PROMPT_LEN}-token prompts, greedy paged-attention decode, "
                                    f"block_size=256, hipGraph decode steps (BASELINE.json configs[{MODELS[args.model]['baseline_config']}])",
                        "batch": BATCH, "prompt_len": PROMPT_LEN, "mean_context": ctx_mean,

@@ -356,6 +356,9 @@ NVR_API int nvr_engine_abort_last_batch(nvr_engine_t *e);
 /* nvr_config.async_decode: decode steps whose successor could not be enqueued ahead and therefore ran synchronously (diagnostic) */
 NVR_API uint64_t nvr_engine_ahead_declined(const nvr_engine_t *e);
 NVR_API uint64_t nvr_engine_ahead_launched(const nvr_engine_t *e);   /* decode steps that were enqueued ahead */
+/* Host time of the integer side of the steps so far: out3[0] = microseconds inside Scheduler::schedule (scheduler.rs:103-223, block
+ * manager calls included), out3[1] = inside Scheduler::postprocess (:234-257), out3[2] = steps counted.  Always on (four clock reads per step). */
+NVR_API void nvr_engine_host_times(const nvr_engine_t *e, double *out3);
 /* sequences of the last step's batch (borrowed handles; finished ones are excluded) */
 NVR_API size_t nvr_engine_last_batch(const nvr_engine_t *e, nvr_seq_t **out, size_t cap);
 

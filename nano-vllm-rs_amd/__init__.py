@@ -183,6 +183,7 @@ _SIGS = {
     "nvr_runner_p2p_disable": (C.c_int, [_P]), "nvr_runner_p2p_active": (C.c_int, [_P]),
     "nvr_runner_p2p_reset": (C.c_int, [_P]), "nvr_runner_comm_drop_rccl": (C.c_int, [_P]),
     "nvr_engine_abort_last_batch": (C.c_int, [_P]), "nvr_engine_ahead_declined": (C.c_uint64, [_P]), "nvr_engine_ahead_launched": (C.c_uint64, [_P]),
+    "nvr_engine_host_times": (None, [_P, _P]),
     "nvr_runner_last_prefill_kv_source": (C.c_int, [_P]),
     "nvr_runner_set_tp_prefill_overlap": (C.c_int, [_P, C.c_int32]), "nvr_runner_last_overlap_chunks": (C.c_int64, [_P]),
     "nvr_runner_last_shared_prefix_len": (C.c_int64, [_P]), "nvr_runner_last_shared_prefix_rows": (C.c_int64, [_P]),
@@ -919,6 +920,12 @@ class LLMEngine:
 
     def ahead_launched(self) -> int:
         return int(lib().nvr_engine_ahead_launched(self.h))
+
+    def host_times(self) -> dict:
+        """microseconds spent inside Scheduler::schedule / ::postprocess so far and the steps counted (nvr_engine_host_times)"""
+        out = (C.c_double * 3)()
+        lib().nvr_engine_host_times(self.h, out)
+        return dict(schedule_us=out[0], postprocess_us=out[1], steps=int(out[2]))
 
 
 # ---------------------------------------------------------------------------------- device helpers

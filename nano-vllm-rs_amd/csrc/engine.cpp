@@ -14,6 +14,8 @@ nvr_engine::HostTrace::~HostTrace() {
 }
 namespace {
 inline double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+// a scheduler call with its host time added to acc
+template <class F> inline int timed(double &acc, F &&f) { const double t = now_us(); const int rc = f(); acc += now_us() - t; return rc; }
 }
 
 // ---- launch-ahead (nvr_config.async_decode) -------------------------------------------------------------------------------
@@ -53,7 +55,7 @@ int nvr_engine::step_async(nvr_step_info *info) {
     if (ahead.pending) {                                                 // this step was enqueued during the previous call
         batch = ahead.batch; parity = ahead.parity; ahead.pending = false;
     } else {
-        int rc = scheduler->impl.schedule(batch, &is_prefill);
+        int rc = timed(host_schedule_us, [&] { return scheduler->impl.schedule(batch, &is_prefill); });
         if (rc) return rc;
         rc = runner->execute(batch.data(), batch.size(), is_prefill);
         if (rc) { scheduler->impl.abort_batch(batch.data(), batch.size()); return rc; }
@@ -73,6 +75,7 @@ int nvr_engine::step_async(nvr_step_info *info) {
     const uint64_t ntok = is_prefill ? (uint64_t)runner->last_tokens : (uint64_t)batch.size();
     const uint64_t fin_before = scheduler->impl.stats().finished_sequences;
     last_tokens.resize(batch.size());
+    ++host_steps;
     if (parity >= 0 && can_launch_ahead(batch)) {
         // schedule the next step on placeholder tokens and enqueue it, THEN wait for this step's tokens.  Whatever happens to the
         // step launched ahead, the CURRENT step ends like a synchronous one: its tokens are collected and patched in.  If the
@@ -80,11 +83,11 @@ int nvr_engine::step_async(nvr_step_info *info) {
         // (cancel_ahead semantics: may_append was a no-op by construction, only the counters moved) and the next call takes the
         // synchronous path, which reports a persistent failure itself and aborts ITS batch.
         std::vector<int64_t> placeholder(batch.size(), -1);
-        int rc = scheduler->impl.postprocess(batch.data(), placeholder.data(), batch.size());
+        int rc = timed(host_postprocess_us, [&] { return scheduler->impl.postprocess(batch.data(), placeholder.data(), batch.size()); });
         if (rc) return rc;                                               // (cannot happen: nobody can stop on this token)
         ahead.stats_before = scheduler->impl.stats();
         bool pf = false;
-        int arc = scheduler->impl.schedule(ahead.batch, &pf);
+        int arc = timed(host_schedule_us, [&] { return scheduler->impl.schedule(ahead.batch, &pf); });
         const bool scheduled = arc == NVR_OK;
         if (scheduled && (pf || ahead.batch != batch)) arc = nvr::fail(NVR_ERR_INVARIANT, "launch-ahead: the scheduler built another batch than predicted");
         if (!arc) {
@@ -116,7 +119,7 @@ int nvr_engine::step_async(nvr_step_info *info) {
             if (rc) { scheduler->impl.abort_batch(batch.data(), batch.size()); return rc; }   // as the synchronous step and the launch-ahead branch
         }
         for (size_t i = 0; i < batch.size(); ++i) if (batch[i]->chunk_is_partial()) last_tokens[i] = -1;
-        int rc = scheduler->impl.postprocess(batch.data(), last_tokens.data(), batch.size());
+        int rc = timed(host_postprocess_us, [&] { return scheduler->impl.postprocess(batch.data(), last_tokens.data(), batch.size()); });
         if (rc) return rc;
     }
     last_ids.resize(batch.size());
@@ -144,8 +147,9 @@ int nvr_engine::step(nvr_step_info *info) {                          // LLMEngin
     if (cfg.async_decode) return step_async(info);
     bool is_prefill = false;
     const double t0 = trace.on ? now_us() : 0;
-    int rc = scheduler->impl.schedule(batch, &is_prefill);           // :160-166
+    int rc = timed(host_schedule_us, [&] { return scheduler->impl.schedule(batch, &is_prefill); });   // :160-166
     if (rc) return rc;
+    ++host_steps;
     const double t1 = trace.on ? now_us() : 0;
     // A model step that fails after schedule() has allocated blocks and moved the batch to running must not wedge the engine
     // (every later step would schedule the same sequences into the same failure): the batch is aborted — blocks returned,
@@ -163,7 +167,7 @@ int nvr_engine::step(nvr_step_info *info) {                          // LLMEngin
     for (size_t i = 0; i < batch.size(); ++i) last_ids[i] = batch[i]->seq_id;
     const uint64_t ntok = (uint64_t)runner->last_tokens;                 // rows fed through the model (a prefill skips cached prefixes)
     const uint64_t fin_before = scheduler->impl.stats().finished_sequences;
-    rc = scheduler->impl.postprocess(batch.data(), last_tokens.data(), batch.size());   // :188-189
+    rc = timed(host_postprocess_us, [&] { return scheduler->impl.postprocess(batch.data(), last_tokens.data(), batch.size()); });   // :188-189
     if (rc) return rc;
     if (trace.on) {
         const double t4 = now_us();

@@ -18,6 +18,10 @@ struct nvr_engine {
     std::vector<int64_t> last_tokens;
     bool is_running = true;                              // llm_engine.rs:37,353: cleared by shutdown()
     struct HostTrace { bool on = false; double acc[4] = {0, 0, 0, 0}; long n = 0; double pacc[4] = {0, 0, 0, 0}; long pn = 0; ~HostTrace(); } trace;
+    // host time of the integer side of every step ("BlockManager / scheduler: host-side, reported as us/step"): microseconds spent
+    // inside Scheduler::schedule and Scheduler::postprocess (block manager calls included), and the steps they belong to — always counted
+    // (four clock reads per step), read by nvr_engine_host_times
+    double host_schedule_us = 0, host_postprocess_us = 0; uint64_t host_steps = 0;
     int step(nvr_step_info *info);
     // launch-ahead of greedy decode steps (nvr_config.async_decode): the step enqueued behind the one being reported
     struct Ahead { bool pending = false; std::vector<nvr_seq *> batch; int parity = 0; nvr_sched_stats stats_before{}; } ahead;

@@ -290,53 +290,37 @@ __global__ __launch_bounds__(WAVES * 64) void attn_rows_kernel(AttnParams p) {
         }
     }
     __syncthreads();
-    if constexpr (DIRECT_OUT) {
-        for (int idx = threadIdx.x; idx < G * D; idx += WAVES * 64) {
-            const int i = idx / D, d = idx % D;
-            float M = sm_ml[0][i][0];
+    // the pair's partials are contiguous: [G heads][num_parts][D] (and [..][2]); buffer offsets stay small whatever the workspace size
+    const int64_t pair0 = DIRECT_OUT ? 0 : ((int64_t)t * p.H + (int64_t)g * G) * p.num_parts;
+    const auto rs_o = __builtin_amdgcn_make_buffer_rsrc(DIRECT_OUT ? nullptr : p.part_o + pair0 * D, 0, DIRECT_OUT ? 0 : (int)(G * p.num_parts * D * 4), 0x00020000);
+    const auto rs_ml = __builtin_amdgcn_make_buffer_rsrc(DIRECT_OUT ? nullptr : p.part_ml + pair0 * 2, 0, DIRECT_OUT ? 0 : (int)(G * p.num_parts * 2 * 4), 0x00020000);
+    constexpr int AUX = FUSE ? 16 : 0;                                    // sc1: write-through, so the hand-off needs no release fence
+    for (int idx = threadIdx.x; idx < G * D; idx += WAVES * 64) {
+        const int i = idx / D, d = idx % D;
+        float M = sm_ml[0][i][0];
 #pragma unroll
-            for (int w2 = 1; w2 < WAVES; ++w2) M = fmaxf(M, sm_ml[w2][i][0]);
-            float o = 0.f, L = 0.f;
+        for (int w2 = 1; w2 < WAVES; ++w2) M = fmaxf(M, sm_ml[w2][i][0]);
+        float o = 0.f, L = 0.f;
 #pragma unroll
-            for (int w2 = 0; w2 < WAVES; ++w2) {
-                const float mw = sm_ml[w2][i][0];
-                const float wgt = (mw == -INFINITY) ? 0.f : __expf(mw - M);
-                o += wgt * sm_acc[w2][i][d];
-                L += wgt * sm_ml[w2][i][1];
-            }
-            const int h = g * G + i;
+        for (int w2 = 0; w2 < WAVES; ++w2) {
+            const float mw = sm_ml[w2][i][0];
+            const float wgt = (mw == -INFINITY) ? 0.f : __expf(mw - M);
+            o += wgt * sm_acc[w2][i][d];
+            L += wgt * sm_ml[w2][i][1];
+        }
+        const int h = g * G + i;
+        if (DIRECT_OUT) {
             p.out[((int64_t)t * p.H + h) * D + d] = (half_t)(L > 0.f ? o / L : 0.f);
+        } else {
+            const int slot = i * p.num_parts + part;                     // inside the pair's region
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o), rs_o, (slot * D + d) * 4, 0, AUX);
+            if (d == 0) { __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(M), rs_ml, slot * 8, 0, AUX);
+                          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(L), rs_ml, slot * 8 + 4, 0, AUX); }
         }
-    } else {
-        // partials of this partition: 4 columns per thread (the per-column arithmetic is the one of the scalar loop above)
-        constexpr int TPH = D / 4;                                // threads per head
+    }
+    if constexpr (!DIRECT_OUT) {
+        constexpr int TPH = D / 4;                                // merging threads per head: 4 columns each (merge_partitions)
         static_assert(G * TPH <= WAVES * 64, "one pass over the (head, column group) pairs");
-        // the pair's partials are contiguous: [G heads][num_parts][D] (and [..][2]); buffer offsets stay small whatever the workspace size
-        const int64_t pair0 = ((int64_t)t * p.H + (int64_t)g * G) * p.num_parts;
-        const auto rs_o = __builtin_amdgcn_make_buffer_rsrc(p.part_o + pair0 * D, 0, (int)(G * p.num_parts * D * 4), 0x00020000);
-        const auto rs_ml = __builtin_amdgcn_make_buffer_rsrc(p.part_ml + pair0 * 2, 0, (int)(G * p.num_parts * 2 * 4), 0x00020000);
-        typedef unsigned int u4 __attribute__((ext_vector_type(4)));
-        typedef unsigned int u2 __attribute__((ext_vector_type(2)));
-        if (threadIdx.x < G * TPH) {
-            const int i = threadIdx.x / TPH, d = (threadIdx.x % TPH) * 4;
-            float M = sm_ml[0][i][0];
-#pragma unroll
-            for (int w2 = 1; w2 < WAVES; ++w2) M = fmaxf(M, sm_ml[w2][i][0]);
-            float4_t o = {0.f, 0.f, 0.f, 0.f};
-            float L = 0.f;
-#pragma unroll
-            for (int w2 = 0; w2 < WAVES; ++w2) {
-                const float mw = sm_ml[w2][i][0];
-                const float wgt = (mw == -INFINITY) ? 0.f : __expf(mw - M);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] += wgt * sm_acc[w2][i][d + e];
-                L += wgt * sm_ml[w2][i][1];
-            }
-            const int slot = i * p.num_parts + part;             // inside the pair's region
-            constexpr int AUX = FUSE ? 16 : 0;                    // sc1: write-through, no release fence needed
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, o), rs_o, (slot * D + d) * 4, 0, AUX);
-            if (d == 0) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, (float2_t){M, L}), rs_ml, slot * 8, 0, AUX);
-        }
         if constexpr (FUSE) {
             __shared__ unsigned int ticket_s;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // every storing wave drains its stores ...

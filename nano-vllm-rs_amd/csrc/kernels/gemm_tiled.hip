@@ -322,6 +322,106 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(const half_t *__restric
     }
 }
 
+// gate_up + SiluAndMul on 96 W rows (48 gate + 48 up = 48 output columns) x 128 tokens (r05).  At T = 512 the 128 x 128
+// tiles above give the gate_up GEMM of Qwen3-0.6B 48 x 4 = 192 workgroups — 64 CUs idle — and a launch of these GEMMs is paced by the operand
+// bytes a CU takes in through its L2 -> LDS path (profiles/r04_mid_batch_gemm.txt: ~52 GB/s per CU): 64 x 4 = 256 workgroups of (96 + 128) rows
+// x 2 KB = 458 KB each instead of 192 of 524 KB.  Four waves side by side over the tokens (wave w: tokens 32 w .. 32 w + 31, all six n-tiles:
+// 12 MFMA tiles per wave and k-step), the four-buffer ring with counted waits of gemm_tiled_kernel<.., 4, ..>, the same K order per output as
+// every other tiling of this file (same bits as the 128-row tiles and as the unfused GEMM + SiluAndMul).
+constexpr int S96_A = 96 * BK * 2, S96_BUF = S96_A + BM * BK * 2;        // bytes of the A image / of one ring buffer
+__global__ __launch_bounds__(256) void gemm_tiled_silu96_kernel(const half_t *__restrict__ x, int64_t ldx, const half_t *__restrict__ W, int T, int K, int I,
+                                                                half_t *__restrict__ y) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NS = 4;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = lane & 15, q = lane >> 4;
+    const int m0 = blockIdx.y * BM;
+    const half_t *asrc[3], *bsrc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = i * 256 + threadIdx.x, row = idx >> 3, c = (idx & 7) ^ (row & 7);
+        if (i < 3) {                                                      // A: local row = 16 t + rr, t = 0..2 gate tiles, 3..5 up tiles of the same columns
+            const int t = row >> 4, rr = row & 15;
+            const int wr = (t < 3 ? 0 : I) + (int)blockIdx.x * 48 + (t % 3) * 16 + rr;
+            asrc[i] = W + (int64_t)wr * K + c * 8;
+        }
+        int xr = m0 + row; if (xr > T - 1) xr = T - 1;
+        bsrc[i] = x + (int64_t)xr * ldx + c * 8;
+    }
+    auto stage = [&](int buf, int k0) {
+        char *a_dst = smem + buf * S96_BUF, *b_dst = a_dst + S96_A;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int piece = (i * 256 + wave * 64) * 16;               // wave-uniform LDS base; hardware adds lane*16
+            if (i < 3) __builtin_amdgcn_global_load_lds(asrc[i] + k0, (__attribute__((address_space(3))) void *)(a_dst + piece), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(bsrc[i] + k0, (__attribute__((address_space(3))) void *)(b_dst + piece), 16, 0, 0);
+        }
+    };
+    float4_t acc[6][2];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
+    const int KT = K / BK;
+#pragma unroll
+    for (int st = 0; st < NS - 1; ++st) if (st < KT) stage(st, st * BK);
+    for (int kt = 0; kt < KT; ++kt) {
+        // K-tile kt has landed once at most the 7 loads per thread of each younger K-tile in flight are outstanding
+        const int younger = min(NS - 2, KT - 1 - kt);
+        if (younger >= 2) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                     // every thread's pieces are in; buffer (kt-1) % NS is free
+        const int cur = kt % NS;
+        if (kt + NS - 1 < KT) stage((kt + NS - 1) % NS, (kt + NS - 1) * BK);
+        const char *a_lds = smem + cur * S96_BUF, *b_lds = a_lds + S96_A;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            half8_t a[6], b[2];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const int arow = i * 16 + r;
+                a[i] = *reinterpret_cast<const half8_t *>(a_lds + (arow * 8 + ((ks * 4 + q) ^ (arow & 7))) * 16);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int brow = wave * 32 + j * 16 + r;
+                b[j] = *reinterpret_cast<const half8_t *>(b_lds + (brow * 8 + ((ks * 4 + q) ^ (brow & 7))) * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = mfma16(a[i], b[j], acc[i][j]);
+        }
+    }
+    __syncthreads();                                                      // the epilogue reuses the operand buffers
+    // act = fp16(silu(fp16 g) * fp16 u) (activation.rs:46-63; the rounding points of the unfused graph), staged in LDS and written as 16-byte pieces
+    constexpr int OST = 112;                                              // bytes per staged row (48 fp16 + pad)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int ml = wave * 32 + j * 16 + r;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            half4_t h;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float gf = (float)to_half_rn(acc[c][j][e]), uf = (float)to_half_rn(acc[c + 3][j][e]);
+                const float sg = sigmoid_fast(gf);
+                h[e] = to_half_rn(__fmul_rn(__fmul_rn(gf, sg), uf));
+            }
+            *reinterpret_cast<half4_t *>(smem + ml * OST + (c * 16 + q * 4) * 2) = h;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < (BM * 6) / 256; ++i) {                            // 6 pieces per row
+        const int pidx = i * 256 + threadIdx.x, row = pidx / 6, ch = pidx % 6;
+        const int m = m0 + row;
+        if (m >= T) continue;
+        *reinterpret_cast<half8_t *>(y + (int64_t)m * I + blockIdx.x * 48 + ch * 8) = *reinterpret_cast<const half8_t *>(smem + row * OST + ch * 16);
+    }
+}
+
 static int tiled_check(const char *what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return nvr::fail(NVR_ERR_HIP, "%s launch failed: %s", what, hipGetErrorString(e));
@@ -372,6 +472,8 @@ int gemm_tiled_prepare() {
       if (e != hipSuccess) return nvr::fail(NVR_ERR_HIP, "gemm_tiled: LDS opt-in failed: %s", hipGetErrorString(e)); }
     NVR_TILED_ATTR(TEPI_F16) NVR_TILED_ATTR(TEPI_SILU) NVR_TILED_ATTR(TEPI_ROPE) NVR_TILED_ATTR(TEPI_LMHEAD) NVR_TILED_ATTR(TEPI_SLAB)
 #undef NVR_TILED_ATTR
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_tiled_silu96_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * S96_BUF) != hipSuccess)
+        return nvr::fail(NVR_ERR_HIP, "gemm_tiled: LDS opt-in failed (96-row SiLU tiles)");
     done = true;
     return 0;
 }
@@ -421,6 +523,13 @@ int gemm_tiled_silu_mul(const half_bits *x, int64_t ldx, const half_bits *W, int
     if (!gemm_tiled_ok(T, K, I, ldx) || I % 64) return nvr::fail(NVR_ERR_UNSUPPORTED, "gemm_tiled_silu_mul: T=%ld K=%ld I=%ld", (long)T, (long)K, (long)I);
     dim3 grid((unsigned)(I / 64), (unsigned)((T + BM - 1) / BM));
     if (int rc = gemm_tiled_prepare()) return rc;
+    {   // 96-row tiles when they put a workgroup on (nearly) every CU where the 128-row tiles leave a quarter of them idle (T = 512, I = 3072: 256 against 192)
+        const int64_t ty = (T + BM - 1) / BM, w128 = (I / 64) * ty, w96 = (I / 48) * ty;
+        if (I % 48 == 0 && tiled_mt(T, I / 64) == 4 && tiled_ring((unsigned)w128) && w96 <= 256 && w96 > w128 && w128 * 8 <= w96 * 7) {
+            gemm_tiled_silu96_kernel<<<dim3((unsigned)(I / 48), (unsigned)ty), dim3(256), 4 * S96_BUF, s>>>((const half_t *)x, ldx, (const half_t *)W, (int)T, (int)K, (int)I, (half_t *)out);
+            return tiled_check("gemm_tiled_silu_mul (96-row tiles)");
+        }
+    }
     NVR_TILED_LAUNCH(TEPI_SILU, grid, T, (const half_t *)x, ldx, (const half_t *)W, (int)T, (int)K, (int)I, (int)(2 * I), (half_t *)out, TileEpi{});
     return tiled_check("gemm_tiled_silu_mul");
 }

@@ -419,6 +419,7 @@ size_t nvr_engine_take_finished(nvr_engine_t *e, nvr_seq_t **out, size_t cap) { 
 int nvr_engine_abort_last_batch(nvr_engine_t *e) { NVR_GUARD_BEGIN e->abort_last_batch(); return NVR_OK; NVR_GUARD_END(NVR_ERR_INVARIANT) }
 uint64_t nvr_engine_ahead_declined(const nvr_engine_t *e) { return e->ahead_declined; }
 uint64_t nvr_engine_ahead_launched(const nvr_engine_t *e) { return e->ahead_launched; }
+void nvr_engine_host_times(const nvr_engine_t *e, double *out3) { out3[0] = e->host_schedule_us; out3[1] = e->host_postprocess_us; out3[2] = (double)e->host_steps; }
 size_t nvr_engine_last_batch(const nvr_engine_t *e, nvr_seq_t **out, size_t cap) {
     size_t n = 0;
     for (nvr_seq *s : e->batch) if (e->scheduler->impl.is_live(s) && n < cap) out[n++] = s;

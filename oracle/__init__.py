@@ -237,6 +237,13 @@ def rope_table(D, max_pos, theta):
     return c, s
 
 
+def rope_table_with_scaling(D, max_pos, base, scaling_factor):
+    """RotaryEmbedding::new_with_scaling, reference src/layers/rotary_embedding.rs:121-134: the table of `new` for base * scaling_factor.
+    Returns (scaled base, cos, sin)."""
+    scaled = float(base) * float(scaling_factor)
+    return (scaled,) + rope_table(D, max_pos, scaled)
+
+
 def rope_apply(x, pos, cos_t, sin_t) -> np.ndarray:
     x = f32(x).copy()
     pos = np.ascontiguousarray(pos, dtype=np.int64)

@@ -994,11 +994,13 @@ def test_tiled_entry_points_match_row_major_stream_shapes(T):
     assert_close_f16(ob.to_numpy((T, I), F16)[:, :64], ref, ulps=2, atol=3e-4, what="stream silu tiled vs oracle")
 
 
-@pytest.mark.parametrize("T", [70, 100, 200, 512])
+@pytest.mark.parametrize("T", [70, 100, 200, 400, 512])
 def test_gemm_tiled_tile_heights(T):
     """Decode batches of 65..512 rows take the LDS-tiled GEMM with 32-, 64- or 128-token tiles (the largest that reaches ~192
-    workgroups: T = 70 / 100 -> 32-token tiles for qkv, T = 512 -> 64-token tiles, gate_up at 512 -> 128): plain, SiLU, RoPE + KV
-    store and split-k epilogues on the Qwen3-0.6B shapes against the oracle."""
+    workgroups: T = 70 / 100 -> 32-token tiles for qkv, T = 512 -> 64-token tiles; gate_up at 385..512 rows -> the 96-row x 128-token
+    SiLU tiles of r05, 256 workgroups instead of 192; T = 400: a ragged last token tile): plain, SiLU, RoPE + KV store and split-k
+    epilogues on the Qwen3-0.6B shapes against the oracle, and the fused gate_up + SiluAndMul against the plain GEMM followed by
+    nvr_silu_and_mul bit for bit (every tiling keeps the K order of an output)."""
     rng = np.random.default_rng(60 + T)
     l = nvr.lib()
     Hd, H, KVH, D, I = 1024, 16, 8, 128, 3072
@@ -1035,6 +1037,11 @@ def test_gemm_tiled_tile_heights(T):
     nvr.check(l.nvr_linear_silu_mul(d_x.ptr, Hd, dev(Wgb).ptr, T, Hd, I, d_o.ptr, None))
     ref = oracle.round_f16(oracle.silu_and_mul(oracle.round_f16(oracle.linear(x, Wg))))
     assert_close_f16(d_o.to_numpy((T, I), F16), ref, ulps=2, atol=3e-4, what="silu")
+    d_gu, d_o2 = nvr.DeviceBuffer(T * 2 * I * 2), nvr.DeviceBuffer(T * I * 2)
+    _KEEP.extend([d_gu, d_o2])
+    nvr.check(l.nvr_linear(d_x.ptr, Hd, dev(Wgb).ptr, T, Hd, 2 * I, d_gu.ptr, 0, None))
+    nvr.check(l.nvr_silu_and_mul(d_gu.ptr, T, I, d_o2.ptr, None))
+    assert np.array_equal(d_o.to_numpy((T, I), np.uint16), d_o2.to_numpy((T, I), np.uint16)), "fused gate_up + SiLU differs from GEMM, then SiluAndMul"
     # split-k slabs (o_proj shape)
     a, ab = h16(rng.standard_normal((T, H * D)) * 0.3)
     Wo, Wob = h16(rng.standard_normal((Hd, H * D)) * 0.05)

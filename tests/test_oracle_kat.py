@@ -284,7 +284,7 @@ def test_rmsnorm_kats():                         # layernorm.rs:195-221,277-311
         assert np.isfinite(oracle.rmsnorm(np.full((1, 4), mag, np.float32), np.ones(4, np.float32), 1e-8)).all()
 
 
-def test_rope_kats():                            # rotary_embedding.rs:322-338,368-386,441-464
+def test_rope_kats():                            # rotary_embedding.rs:322-338,368-386,406-418,441-464
     cos, sin = oracle.rope_table(4, 3, 10000.0)
     assert cos.shape == (3, 2) and cos[0, 0] == 1.0 and sin[0, 0] == 0.0
     x = np.arange(2 * 1 * 4, dtype=np.float32).reshape(2, 1, 4)
@@ -297,6 +297,15 @@ def test_rope_kats():                            # rotary_embedding.rs:322-338,3
     c, s = cos[1], sin[1]
     np.testing.assert_allclose(y[0, 0], np.concatenate([x[0, 0, :2] * c - x[0, 0, 2:] * s,
                                                         x[0, 0, 2:] * c + x[0, 0, :2] * s]), rtol=1e-6)
+    # test_rotary_embedding_with_scaling :406-418: new_with_scaling(4, 10, 10000.0, 2.0) has base 20000 and a [positions, D/2] table
+    base, cs, sn = oracle.rope_table_with_scaling(4, 10, 10000.0, 2.0)
+    assert base == 20000.0
+    assert cs[[0, 1]].shape == (2, 2) and sn[[0, 1]].shape == (2, 2)
+    inv2 = 1.0 / 20000.0 ** (np.arange(0, 4, 2) / 4.0)        # = the unscaled constructor at the scaled base (:131-133)
+    np.testing.assert_allclose(cs, np.cos(np.arange(10)[:, None] * inv2[None]), atol=1e-5)
+    np.testing.assert_allclose(sn, np.sin(np.arange(10)[:, None] * inv2[None]), atol=1e-5)
+    c0, s0 = oracle.rope_table(4, 10, 20000.0)
+    assert np.array_equal(cs, c0) and np.array_equal(sn, s0)
 
 
 def test_silu_kats():                            # activation.rs:214-228,264-290,309-318

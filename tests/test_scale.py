@@ -233,3 +233,98 @@ def test_chunked_prefill_full_size_bit_identity():
     assert tc == tu
     for sid in lu:
         assert np.array_equal(lc[sid], lu[sid]), f"sequence {sid}: chunked and whole-prompt prefill differ in bits"
+
+
+@pytest.mark.gpu
+def test_configs2_256_x_4096_chunked_equals_whole_sequence_first_tokens():
+    """BASELINE configs[2] at its LARGEST point — 256 sequences x 4096 tokens = 1 048 576 prompt tokens against the 32 768-token budget
+    (what bench.py's prefill_sweep times) — as a property test: with chunked prefill on and a 20 000-token budget
+    (A-23: 4 whole prompts + a 3 616-token chunk per step, every later chunk reaching its predecessors through the block table) the first
+    sampled token of EVERY sequence equals the whole-sequence run's (8 prompts per 32 768-token step, the reference's batching,
+    scheduler.rs:119-168).  Last-token logits are bit-identical wherever both runs' steps take the same GEMM route; where a short last step
+    routes differently they agree to fp16 rounding and a token may differ only inside that distance of a tie (counted, bounded)."""
+    mc = nvr.ModelConfig("qwen3-0.6b")
+    n, L = 256, 4096
+    base = dict(max_num_seqs=n, max_model_len=L + 8, kvcache_block_size=256, num_kvcache_blocks=n * (L // 256 + 1) + 8)
+    prompts = [nvr.synthetic_tokens(L, 1, i, 151936).tolist() for i in range(n)]
+
+    def run(**kw):
+        nvr.lib().nvr_seq_reset_id_counter()
+        eng = nvr.LLMEngine(nvr.Config(**base, **kw), mc)
+        for pr in prompts:
+            eng.add_request(pr, nvr.SamplingParams(temperature=0.0, max_tokens=1, ignore_eos=True))
+        logits, toks, steps, rows = {}, {}, 0, 0
+        while not eng.is_finished():
+            rec = eng.step()
+            assert rec["is_prefill"]
+            lg = eng.model_runner.logits(rec["num_seqs"])
+            steps += 1; rows += rec["num_tokens"]
+            for i, (sid, t) in enumerate(zip(rec["seq_ids"], rec["tokens"])):
+                if t != -1:
+                    logits[sid] = lg[i].copy(); toks[sid] = t
+        del eng
+        return logits, toks, steps, rows
+    lw, tw, sw, rw = run(max_num_batched_tokens=32768)
+    lc, tc, sc, rc = run(max_num_batched_tokens=20000, enable_chunked_prefill=1)
+    assert rw == rc == n * L and sw == n * L // 32768 and sc == -(-n * L // 20000)
+    assert len(tw) == len(tc) == n
+    exact = near = 0
+    for sid in tw:
+        if np.array_equal(lw[sid], lc[sid]):
+            exact += 1
+            assert tw[sid] == tc[sid]
+            continue
+        d = float(np.abs(lw[sid] - lc[sid]).max())
+        assert d < 2e-2, f"sequence {sid}: chunked and whole-sequence logits differ by {d}"
+        if tw[sid] != tc[sid]:
+            srt = np.sort(lw[sid]); near += 1
+            assert srt[-1] - srt[-2] <= 2 * d, f"sequence {sid}: tokens differ outside a tie"
+    print(f"configs[2] 256 x 4096: {sw} whole-sequence steps vs {sc} chunked steps; {exact} of {n} last-token logit rows bit-identical, {near} near-tie tokens")
+    assert near <= 2 and exact >= n // 2
+
+
+@pytest.mark.gpu
+def test_configs4_512_sequences_equal_the_oracle_checked_48_sequence_run_on_the_shared_rows():
+    """BASELINE configs[4] at FULL size — 512 sequences = one 512-token system prompt + 64 own tokens — against the run that
+    test_configs4_shared_system_prompt_vs_oracle holds to the oracle (the first 48 of the same requests): on those 48 sequences the prefill's
+    first tokens and four decode steps of the 512-sequence engine (prefix blocks shared 512 ways, the group-wide MFMA pass over the shared
+    keys, mid-batch GEMM routes at 512 rows) give the 48-sequence engine's logits within the fp16-pipeline tolerance (other GEMM routes at
+    another batch size: summation order only) and the same greedy ids outside near-ties."""
+    mc = nvr.ModelConfig("qwen3-0.6b")
+    shared = nvr.synthetic_tokens(512, 2, 0, 151936).tolist()
+    prompts = [shared + nvr.synthetic_tokens(64, 1, i, 151936).tolist() for i in range(512)]
+
+    def run(n):
+        nvr.lib().nvr_seq_reset_id_counter()
+        eng = nvr.LLMEngine(nvr.Config(max_num_seqs=n, max_num_batched_tokens=65536, max_model_len=640, kvcache_block_size=256, num_kvcache_blocks=n + 8), mc)
+        for pr in prompts[:n]:
+            eng.add_request(pr, nvr.SamplingParams(temperature=0.0, max_tokens=5, ignore_eos=True))
+        out = []
+        while not eng.is_finished():
+            rec = eng.step()
+            lg = eng.model_runner.logits(rec["num_seqs"])
+            row = {sid: (t, lg[i].copy()) for i, (sid, t) in enumerate(zip(rec["seq_ids"], rec["tokens"])) if sid < 48}
+            if row:                                         # (the 512 prompts take five budget-bound prefill steps, scheduler.rs:135-138: the first holds the 48)
+                out.append(row)
+            if not rec["is_prefill"]:
+                assert eng.model_runner.last_shared_prefix_len() == 512
+        used = eng.scheduler.block_manager.get_stats()
+        del eng
+        return out, used
+    small, _ = run(48)
+    big, used = run(512)
+    assert len(small) == len(big) == 5
+    near, worst, diverged = 0, 0.0, set()
+    for a, b in zip(small, big):
+        assert set(a) == set(b) == set(range(48))
+        for sid in range(48):
+            if sid in diverged:
+                continue
+            d = float(np.abs(a[sid][1] - b[sid][1]).max()); worst = max(worst, d)
+            assert d < 2e-2, f"sequence {sid}: 512- and 48-sequence logits differ by {d}"
+            if a[sid][0] != b[sid][0]:
+                srt = np.sort(a[sid][1]); near += 1; diverged.add(sid)
+                assert srt[-1] - srt[-2] <= 2 * 2e-2, f"sequence {sid}: tokens differ outside a tie"
+    print(f"configs[4] 512 vs 48 sequences on the shared rows: max |d logit| {worst:.2e}, {near} near-tie tokens")
+    assert near <= 2
+
