@@ -872,12 +872,21 @@ def main() -> None:
         # prefill on a recycled free list (block tables, not contiguous rows)
         default_engine = {"note": "nvr_config_default() + the workload's sizes, nothing else set: the same configuration as the headline line"}
         try:
-            r = side_decode(nvr, "qwen3-0.6b", steps=max(16, min(args.steps, 64)), warmup=4, batch=BATCH, prompt_len=PROMPT_LEN)
+            # (two interleaved pairs, the faster of each kind: the side blocks of this line run minutes apart on a part whose clocks move with its
+            #  temperature — the bf16 block, the same step, differs from the headline by 1-2 % either way)
+            runs = {None: [], 0: []}
+            for _ in range(2):
+                for mode in (None, 0):
+                    runs[mode].append(side_decode(nvr, "qwen3-0.6b", steps=max(16, min(args.steps, 64)), warmup=args.warmup, batch=BATCH, prompt_len=PROMPT_LEN,
+                                                  async_decode=mode))
+            r = min(runs[None], key=lambda x: x["ms_per_step"])
             default_engine["ms_per_step"] = r["ms_per_step"]; default_engine["tokens_per_s"] = r["tokens_per_s"]
-            r = side_decode(nvr, "qwen3-0.6b", steps=max(16, min(args.steps, 64)), warmup=4, batch=BATCH, prompt_len=PROMPT_LEN, async_decode=0)
+            default_engine["ms_per_step_runs"] = [x["ms_per_step"] for x in runs[None]]
+            r = min(runs[0], key=lambda x: x["ms_per_step"])
             default_engine["sync_decode_ms_per_step"] = r["ms_per_step"]
             default_engine["sync_decode_tokens_per_s"] = r["tokens_per_s"]
             default_engine["sync_decode_step_hbm_frac"] = r["step_hbm_frac_per_gpu"]
+            default_engine["sync_decode_ms_per_step_runs"] = [x["ms_per_step"] for x in runs[0]]
         except Exception as ex:                                              # noqa: BLE001
             default_engine["sync_decode_error"] = str(ex)[:200]
         try:

@@ -35,8 +35,6 @@ static bool cfg_str_in(const char *v, size_t cap, std::initializer_list<const ch
 int nvr_config_runnable(const nvr_config *c) {
     if (!cfg_str_in(c->device, sizeof c->device, {"hip", "cuda"}))
         return nvr::fail(NVR_ERR_UNSUPPORTED, "device '%s': this library is the MI355X (HIP) path; there is no CPU or Metal path", c->device);
-    if (std::strcmp(c->dtype, "float32") == 0 && c->tensor_parallel_size > 1)
-        return nvr::fail(NVR_ERR_UNSUPPORTED, "dtype 'float32' (the reference-precision path) runs on one GPU; tensor parallel ranks take float16 or bfloat16");
     if (std::strcmp(c->dtype, "float16") != 0 && std::strcmp(c->dtype, "bfloat16") != 0 && std::strcmp(c->dtype, "float32") != 0)
         return nvr::fail(NVR_ERR_UNSUPPORTED, "dtype '%s': float16, bfloat16 or float32", c->dtype);
     return NVR_OK;

@@ -112,6 +112,31 @@ int rmsnorm(const float *x, const float *w, float eps, int64_t T, int64_t Hd, fl
     F32_LAUNCH_CHECK("f32 rmsnorm");
     return 0;
 }
+// tensor-parallel ranks: y = ((p_0 + p_1) + p_2) + ... over the ranks' partial sums parts[r * stride + ...] in rank order, then h <- h + y and
+// the norm, as rmsnorm_kernel<true>
+__global__ __launch_bounds__(256) void sum_ranks_rmsnorm_kernel(float *__restrict__ h, const float *__restrict__ parts, int nranks, int64_t stride,
+                                                                const float *__restrict__ w, float eps, int Hd, float *__restrict__ out) {
+    __shared__ float sm[4];
+    float *hr = h + (int64_t)blockIdx.x * Hd;
+    const float *pr = parts + (int64_t)blockIdx.x * Hd;
+    float ss = 0.f;
+    for (int c = threadIdx.x; c < Hd; c += 256) {
+        float y = pr[c];
+        for (int r = 1; r < nranks; ++r) y = y + pr[(int64_t)r * stride + c];
+        const float v = hr[c] + y;
+        hr[c] = v;
+        ss += v * v;
+    }
+    ss = block_reduce<false>(ss, sm, 4);
+    const float rms = sqrtf(ss / (float)Hd + eps);
+    for (int c = threadIdx.x; c < Hd; c += 256) out[(int64_t)blockIdx.x * Hd + c] = hr[c] / rms * w[c];
+}
+int sum_ranks_add_rmsnorm(float *h, const float *parts, int nranks, int64_t stride, const float *w, float eps, int64_t T, int64_t Hd, float *out, hipStream_t s) {
+    if (T == 0) return 0;
+    sum_ranks_rmsnorm_kernel<<<dim3((unsigned)T), dim3(256), 0, s>>>(h, parts, nranks, stride, w, eps, (int)Hd, out);
+    F32_LAUNCH_CHECK("f32 sum_ranks_add_rmsnorm");
+    return 0;
+}
 int add_rmsnorm(float *h, const float *y, const float *w, float eps, int64_t T, int64_t Hd, float *out, hipStream_t s) {
     if (T == 0) return 0;
     rmsnorm_kernel<true><<<dim3((unsigned)T), dim3(256), 0, s>>>(h, y, w, eps, (int)Hd, out);
@@ -169,13 +194,24 @@ __global__ __launch_bounds__(256) void gemv_kernel(const float *__restrict__ x, 
     float acc[TT];
 #pragma unroll
     for (int t = 0; t < TT; ++t) acc[t] = 0.f;
-    for (int k4 = lane; k4 < K / 4; k4 += 64) {
-        const float4 w = w4[k4];
+    // four 16-byte pieces of the weight row (and of every activation row) requested before the first FMA — a plain loop waits for each piece's own
+    // round trip (r04: 7.3 us per launch at K = 1024); the FMA chain of an output keeps its order: the same bits
+    const int n4 = K / 4;
+    for (int k0 = lane; k0 < n4; k0 += 256) {
+        float4 w[4], a[TT][4];
 #pragma unroll
-        for (int t = 0; t < TT; ++t)
-            if (t < T) {
-                const float4 a = reinterpret_cast<const float4 *>(x + (int64_t)t * ldx)[k4];
-                acc[t] = fmaf(a.x, w.x, fmaf(a.y, w.y, fmaf(a.z, w.z, fmaf(a.w, w.w, acc[t]))));
+        for (int u = 0; u < 4; ++u) {
+            const int k4 = min(k0 + 64 * u, n4 - 1);
+            w[u] = w4[k4];
+#pragma unroll
+            for (int t = 0; t < TT; ++t) a[t][u] = reinterpret_cast<const float4 *>(x + (int64_t)(t < T ? t : 0) * ldx)[k4];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (k0 + 64 * u < n4) {
+#pragma unroll
+                for (int t = 0; t < TT; ++t)
+                    if (t < T) acc[t] = fmaf(a[t][u].x, w[u].x, fmaf(a[t][u].y, w[u].y, fmaf(a[t][u].z, w[u].z, fmaf(a[t][u].w, w[u].w, acc[t]))));
             }
     }
 #pragma unroll
@@ -183,6 +219,59 @@ __global__ __launch_bounds__(256) void gemv_kernel(const float *__restrict__ x, 
         const float v = wsum(acc[t]);
         if (lane == 0 && t < T) y[(int64_t)t * N + n] = bias ? v + bias[n] : v;
     }
+}
+__device__ __forceinline__ float silu_mul_one(float g, float u) { return g / (1.0f + expf(-g)) * u; }          // SiluAndMul, activation.rs:46-63
+// gate_up projection + SiluAndMul of a decode-sized step in one launch (activation.rs:46-63 behind linear.rs:437-439): wave n forms gate column n and
+// up column I + n of every row with gemv_kernel's loads and FMA chains, then act = silu(g) * u as silu_mul_kernel writes it — the same bits as the two
+// launches (bias: added to g and u first, like Linear::forward)
+template <int TT>
+__global__ __launch_bounds__(256) void gemv_silu_kernel(const float *__restrict__ x, int64_t ldx, const float *__restrict__ W, int T, int K, int I,
+                                                        const float *__restrict__ bias, float *__restrict__ act) {
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (n >= I) return;
+    const float4 *g4 = reinterpret_cast<const float4 *>(W + (int64_t)n * K), *u4 = reinterpret_cast<const float4 *>(W + (int64_t)(I + n) * K);
+    float ag[TT], au[TT];
+#pragma unroll
+    for (int t = 0; t < TT; ++t) ag[t] = au[t] = 0.f;
+    const int n4 = K / 4;
+    for (int k0 = lane; k0 < n4; k0 += 256) {
+        float4 wg[4], wu[4], a[TT][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k4 = min(k0 + 64 * u, n4 - 1);
+            wg[u] = g4[k4]; wu[u] = u4[k4];
+#pragma unroll
+            for (int t = 0; t < TT; ++t) a[t][u] = reinterpret_cast<const float4 *>(x + (int64_t)(t < T ? t : 0) * ldx)[k4];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (k0 + 64 * u < n4) {
+#pragma unroll
+                for (int t = 0; t < TT; ++t)
+                    if (t < T) {
+                        ag[t] = fmaf(a[t][u].x, wg[u].x, fmaf(a[t][u].y, wg[u].y, fmaf(a[t][u].z, wg[u].z, fmaf(a[t][u].w, wg[u].w, ag[t]))));
+                        au[t] = fmaf(a[t][u].x, wu[u].x, fmaf(a[t][u].y, wu[u].y, fmaf(a[t][u].z, wu[u].z, fmaf(a[t][u].w, wu[u].w, au[t]))));
+                    }
+            }
+    }
+#pragma unroll
+    for (int t = 0; t < TT; ++t) {
+        float g = wsum(ag[t]), u = wsum(au[t]);
+        if (lane == 0 && t < T) {
+            if (bias) { g = g + bias[n]; u = u + bias[I + n]; }
+            act[(int64_t)t * I + n] = silu_mul_one(g, u);
+        }
+    }
+}
+bool linear_silu_ok(int64_t T, int64_t K, int64_t ldx) { return T >= 1 && T <= 8 && K % 4 == 0 && ldx % 4 == 0; }
+int linear_silu_mul(const float *x, int64_t ldx, const float *W, int64_t T, int64_t K, int64_t I, const float *bias, float *act, hipStream_t s) {
+    if (!linear_silu_ok(T, K, ldx)) return nvr::fail(NVR_ERR_UNSUPPORTED, "f32 linear_silu_mul: T=%ld K=%ld (decode-sized steps)", (long)T, (long)K);
+    const dim3 grid((unsigned)((I + 3) / 4));
+    if (T == 1) gemv_silu_kernel<1><<<grid, dim3(256), 0, s>>>(x, ldx, W, (int)T, (int)K, (int)I, bias, act);
+    else if (T <= 4) gemv_silu_kernel<4><<<grid, dim3(256), 0, s>>>(x, ldx, W, (int)T, (int)K, (int)I, bias, act);
+    else gemv_silu_kernel<8><<<grid, dim3(256), 0, s>>>(x, ldx, W, (int)T, (int)K, (int)I, bias, act);
+    F32_LAUNCH_CHECK("f32 gemv + silu");
+    return 0;
 }
 int linear(const float *x, int64_t ldx, const float *W, int64_t T, int64_t K, int64_t N, const float *bias, float *y, hipStream_t s) {
     if (T == 0 || N == 0) return 0;
@@ -248,7 +337,7 @@ __global__ void silu_mul_kernel(const float *__restrict__ gu, int64_t T, int I, 
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t t = i / I; const int c = (int)(i % I);
         const float g = gu[t * 2 * I + c], u = gu[t * 2 * I + I + c];
-        out[i] = g / (1.0f + expf(-g)) * u;                             // activation.rs:46-63
+        out[i] = silu_mul_one(g, u);
     }
 }
 int silu_and_mul(const float *gu, int64_t T, int64_t I, float *out, hipStream_t s) {
@@ -282,7 +371,18 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgsF a, int paged) 
     for (int j = threadIdx.x; j < ctx; j += 256) {
         const float4 *kr = reinterpret_cast<const float4 *>(a.k + row_of(j));
         float d = 0.f;
-        for (int e = 0; e < D / 4; ++e) { const float4 kk = kr[e]; d = fmaf(qs[4 * e], kk.x, fmaf(qs[4 * e + 1], kk.y, fmaf(qs[4 * e + 2], kk.z, fmaf(qs[4 * e + 3], kk.w, d)))); }
+        // sixteen 16-byte pieces of the row requested before the first FMA (as a plain loop every piece waited for its own round trip to HBM: 32 in
+        // a row at head_dim 128 — 29.6 us per launch at bs 1, r04); the FMA chain keeps its order: the same bits
+        for (int e0 = 0; e0 < D / 4; e0 += 16) {
+            float4 kk[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) kk[u] = kr[min(e0 + u, D / 4 - 1)];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int e = e0 + u;
+                if (e < D / 4) d = fmaf(qs[4 * e], kk[u].x, fmaf(qs[4 * e + 1], kk[u].y, fmaf(qs[4 * e + 2], kk[u].z, fmaf(qs[4 * e + 3], kk[u].w, d))));
+            }
+        }
         d *= a.scale;
         sc[j] = d; mx = fmaxf(mx, d);
     }
@@ -292,18 +392,20 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgsF a, int paged) 
     sum = block_reduce<false>(sum, sm, 4);                              // (its barriers also publish the probabilities)
     // P.V: wave w takes keys w, w + 4, ...; a lane holds output columns lane, lane + 64, ... (head_dim <= 256); the four partial rows meet in LDS
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int j0 = wave; j0 < ctx; j0 += 4 * 8) {                        // eight of the wave's keys requested before the first FMA
-        float vv[8][4], pp[8];
+    for (int j0 = wave; j0 < ctx; j0 += 4 * 16) {                       // sixteen of the wave's keys requested before the first FMA; their rows' block-table
+        float vv[16][4], pp[16];                                        // entries are looked up by sixteen lanes at once (one round trip, not one per key)
+        int64_t myrow = 0;
+        if (lane < 16) { const int j = j0 + 4 * lane; myrow = row_of(j < ctx ? j : ctx - 1); }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < 16; ++u) {
             const int j = j0 + 4 * u;
             pp[u] = j < ctx ? sc[j] : 0.f;
-            const float *vr = a.v + row_of(j < ctx ? j : ctx - 1);
+            const float *vr = a.v + __shfl(myrow, u, 64);
 #pragma unroll
             for (int i = 0; i < 4; ++i) { const int e = lane + 64 * i; vv[u][i] = e < D ? vr[e] : 0.f; }
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
+        for (int u = 0; u < 16; ++u)
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc[i] = fmaf(pp[u], vv[u][i], acc[i]);
     }

@@ -75,10 +75,13 @@ int embedding(const int64_t *ids, int64_t T, const float *E, int64_t Hd, float *
 int select_last_tokens(const float *h, const int32_t *cu, int64_t B, int64_t Hd, float *out, hipStream_t s);
 int rmsnorm(const float *x, const float *w, float eps, int64_t T, int64_t Hd, float *out, hipStream_t s);
 int add_rmsnorm(float *h, const float *y, const float *w, float eps, int64_t T, int64_t Hd, float *out, hipStream_t s);
+int sum_ranks_add_rmsnorm(float *h, const float *parts, int nranks, int64_t stride, const float *w, float eps, int64_t T, int64_t Hd, float *out, hipStream_t s);
 int linear(const float *x, int64_t ldx, const float *W, int64_t T, int64_t K, int64_t N, const float *bias, float *y, hipStream_t s);
 int rope_store_kv(float *qkv, const int64_t *pos, const int32_t *slots, int64_t T, int64_t H, int64_t KVH, int64_t D, const float *cos_t,
                   const float *sin_t, float *kc, float *vc, const float *q_norm, const float *k_norm, float eps, hipStream_t s);
 int silu_and_mul(const float *gu, int64_t T, int64_t I, float *out, hipStream_t s);
+bool linear_silu_ok(int64_t T, int64_t K, int64_t ldx);       // decode-sized steps: gate_up projection + SiluAndMul in one launch (the same bits as the two)
+int linear_silu_mul(const float *x, int64_t ldx, const float *W, int64_t T, int64_t K, int64_t I, const float *bias, float *act, hipStream_t s);
 int attention(const AttnArgsF &a, bool paged, hipStream_t s);
 int prepare();
 }}

@@ -46,7 +46,7 @@ nvr_model_runner::~nvr_model_runner() {
     if (lm_head_t) hipFree(lm_head_t);
     void *ptrs[] = {embed, mc.tie_word_embeddings ? nullptr : lm_head, norm, cos_t, sin_t, kv_pool, h, n, qkv, attn,
                     proj, gu, act, nlast, logits, attn_ws, slabs, in_dev, d_tok, d_maxval, d_temp, d_topk, d_topp, d_keys,
-                    sample_ws, d_gather_val, d_gather_idx, d_gather_logits, d_full_logits, sample_ws_full, d_lm_pval, d_lm_pidx, d_rec, d_gather_rec};
+                    sample_ws, d_gather_val, d_gather_idx, d_gather_logits, d_full_logits, sample_ws_full, d_lm_pval, d_lm_pidx, d_rec, d_gather_rec, f32_gather};
     for (void *p : ptrs) if (p) hipFree(p);
     if (in_host) hipHostFree(in_host);
     if (h_tok) hipHostFree(h_tok);
@@ -63,7 +63,6 @@ int nvr_model_runner::init() {                                       // ModelRun
     bf16 = std::strcmp(cfg.dtype, "bfloat16") == 0;                               // config.rs:51 (fp16 otherwise)
     f32 = std::strcmp(cfg.dtype, "float32") == 0;                                 // the reference-precision path (kernels/f32_path.hip): 4-byte storage,
     em = f32 ? 2 : 1;                                                             // every "16-bit" buffer below holds em x 2 bytes per element
-    if (f32 && tp > 1) return nvr::fail(NVR_ERR_UNSUPPORTED, "dtype float32 runs on one GPU (tensor_parallel_size %ld)", (long)tp);
     if (f32) { tiled_weights = false; lm_fused = false; RC(nvr::kf::prepare()); }   // (decode steps of the f32 path replay a captured graph like the 16-bit ones)
     comm.bf16 = bf16;                                                              // the collectives round their sums to the same 16-bit type
     if (tp < 1 || rank >= tp) return nvr::fail(NVR_ERR_INVALID_ARG, "bad tensor parallel rank %ld of %ld", (long)rank, (long)tp);
@@ -123,6 +122,9 @@ int nvr_model_runner::init() {                                       // ModelRun
     RC(dmalloc(&h, em * max_tokens * Hd)); RC(dmalloc(&n, em * max_tokens * Hd)); RC(dmalloc(&qkv, em * max_tokens * QKV));
     RC(dmalloc(&attn, em * max_tokens * H * D)); RC(dmalloc(&proj, em * max_tokens * Hd)); RC(dmalloc(&gu, em * max_tokens * 2 * I));
     RC(dmalloc(&act, em * max_tokens * I)); RC(dmalloc(&nlast, em * max_seqs * Hd)); RC(dmalloc(&logits, max_seqs * Vl));
+    // float32 tensor-parallel ranks gather every rank's partial sums before they add them (allocated here, not on first use: an allocation
+    // synchronises the device, and with the in-process group a peer's collective may already be spinning on it)
+    if (f32 && tp > 1) NVR_HIP_CHECK(hipMalloc((void **)&f32_gather, (size_t)tp * (size_t)max_tokens * (size_t)Hd * sizeof(float)));
     slab_rows = std::max<int64_t>(64, std::min<int64_t>(1024, std::max<int64_t>(max_seqs, 256)));
     RC(dmalloc(&slabs, 4 * slab_rows * Hd));
     { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && v > 0) num_cus = v; }
@@ -236,23 +238,27 @@ int nvr_model_runner::gen_weights_f32() {
         auto key = [&](uint64_t tid) { return nvr_weight_key_impl(mc.seed, (uint64_t)l * 8 + tid); };
         RC(dmalloc(&w.qkv, 2 * QKV * Hd)); RC(dmalloc(&w.o, 2 * Hd * H * D)); RC(dmalloc(&w.gate_up, 2 * 2 * I * Hd)); RC(dmalloc(&w.down, 2 * Hd * I));
         RC(dmalloc(&w.ln1, 2 * Hd)); RC(dmalloc(&w.ln2, 2 * Hd));
-        RC(kf::fill_weight(F(w.qkv), H * D, Hd, Hd, Hd, 0, 0, key(TID_QKV), sc, stream));
-        RC(kf::fill_weight(F(w.qkv) + H * D * Hd, KVH * D, Hd, Hd, Hd, Hg * D, 0, key(TID_QKV), sc, stream));
-        RC(kf::fill_weight(F(w.qkv) + (H + KVH) * D * Hd, KVH * D, Hd, Hd, Hd, (Hg + KVHg) * D, 0, key(TID_QKV), sc, stream));
-        RC(kf::fill_weight(F(w.o), Hd, H * D, H * D, Hg * D, 0, 0, key(TID_O), sc, stream));
-        RC(kf::fill_weight(F(w.gate_up), I, Hd, Hd, Hd, 0, 0, key(TID_GATE_UP), sc, stream));
-        RC(kf::fill_weight(F(w.gate_up) + I * Hd, I, Hd, Hd, Hd, Ig, 0, key(TID_GATE_UP), sc, stream));
-        RC(kf::fill_weight(F(w.down), Hd, I, I, Ig, 0, 0, key(TID_DOWN), sc, stream));
+        // this rank's slices, by the reference's shard rules (gen_weights below: the same rows / columns of the same global tensors)
+        RC(kf::fill_weight(F(w.qkv), H * D, Hd, Hd, Hd, rank * H * D, 0, key(TID_QKV), sc, stream));
+        RC(kf::fill_weight(F(w.qkv) + H * D * Hd, KVH * D, Hd, Hd, Hd, Hg * D + rank * KVH * D, 0, key(TID_QKV), sc, stream));
+        RC(kf::fill_weight(F(w.qkv) + (H + KVH) * D * Hd, KVH * D, Hd, Hd, Hd, (Hg + KVHg) * D + rank * KVH * D, 0, key(TID_QKV), sc, stream));
+        RC(kf::fill_weight(F(w.o), Hd, H * D, H * D, Hg * D, 0, rank * H * D, key(TID_O), sc, stream));
+        RC(kf::fill_weight(F(w.gate_up), I, Hd, Hd, Hd, rank * I, 0, key(TID_GATE_UP), sc, stream));
+        RC(kf::fill_weight(F(w.gate_up) + I * Hd, I, Hd, Hd, Hd, Ig + rank * I, 0, key(TID_GATE_UP), sc, stream));
+        RC(kf::fill_weight(F(w.down), Hd, I, I, Ig, 0, rank * I, key(TID_DOWN), sc, stream));
         RC(kf::fill_const(F(w.ln1), Hd, 1.0f, stream)); RC(kf::fill_const(F(w.ln2), Hd, 1.0f, stream));
         if (mc.use_bias) {
-            RC(dmalloc(&w.qkv_b, 2 * QKV)); RC(dmalloc(&w.gate_up_b, 2 * 2 * I)); RC(dmalloc(&w.o_b, 2 * Hd)); RC(dmalloc(&w.down_b, 2 * Hd));
-            RC(kf::fill_weight(F(w.qkv_b), H * D, 1, 1, 1, 0, 0, key(TID_BIAS + TID_QKV), sc, stream));
-            RC(kf::fill_weight(F(w.qkv_b) + H * D, KVH * D, 1, 1, 1, Hg * D, 0, key(TID_BIAS + TID_QKV), sc, stream));
-            RC(kf::fill_weight(F(w.qkv_b) + (H + KVH) * D, KVH * D, 1, 1, 1, (Hg + KVHg) * D, 0, key(TID_BIAS + TID_QKV), sc, stream));
-            RC(kf::fill_weight(F(w.gate_up_b), I, 1, 1, 1, 0, 0, key(TID_BIAS + TID_GATE_UP), sc, stream));
-            RC(kf::fill_weight(F(w.gate_up_b) + I, I, 1, 1, 1, Ig, 0, key(TID_BIAS + TID_GATE_UP), sc, stream));
-            RC(kf::fill_weight(F(w.o_b), Hd, 1, 1, 1, 0, 0, key(TID_BIAS + TID_O), sc, stream));
-            RC(kf::fill_weight(F(w.down_b), Hd, 1, 1, 1, 0, 0, key(TID_BIAS + TID_DOWN), sc, stream));
+            RC(dmalloc(&w.qkv_b, 2 * QKV)); RC(dmalloc(&w.gate_up_b, 2 * 2 * I));
+            RC(kf::fill_weight(F(w.qkv_b), H * D, 1, 1, 1, rank * H * D, 0, key(TID_BIAS + TID_QKV), sc, stream));
+            RC(kf::fill_weight(F(w.qkv_b) + H * D, KVH * D, 1, 1, 1, Hg * D + rank * KVH * D, 0, key(TID_BIAS + TID_QKV), sc, stream));
+            RC(kf::fill_weight(F(w.qkv_b) + (H + KVH) * D, KVH * D, 1, 1, 1, (Hg + KVHg) * D + rank * KVH * D, 0, key(TID_BIAS + TID_QKV), sc, stream));
+            RC(kf::fill_weight(F(w.gate_up_b), I, 1, 1, 1, rank * I, 0, key(TID_BIAS + TID_GATE_UP), sc, stream));
+            RC(kf::fill_weight(F(w.gate_up_b) + I, I, 1, 1, 1, Ig + rank * I, 0, key(TID_BIAS + TID_GATE_UP), sc, stream));
+            if (rank == 0) {                                              // row-parallel biases live on rank 0 (linear.rs:206)
+                RC(dmalloc(&w.o_b, 2 * Hd)); RC(dmalloc(&w.down_b, 2 * Hd));
+                RC(kf::fill_weight(F(w.o_b), Hd, 1, 1, 1, 0, 0, key(TID_BIAS + TID_O), sc, stream));
+                RC(kf::fill_weight(F(w.down_b), Hd, 1, 1, 1, 0, 0, key(TID_BIAS + TID_DOWN), sc, stream));
+            }
         }
         if (mc.qk_norm) {
             RC(dmalloc(&w.q_norm, 2 * D)); RC(dmalloc(&w.k_norm, 2 * D));
@@ -261,15 +267,28 @@ int nvr_model_runner::gen_weights_f32() {
     }
     RC(dmalloc(&embed, 2 * V * Hd));
     RC(kf::fill_weight(F(embed), V, Hd, Hd, Hd, 0, 0, nvr_weight_key_impl(mc.seed, TID_EMBED), sc, stream));
-    if (mc.tie_word_embeddings) lm_head = embed;
+    if (mc.tie_word_embeddings) lm_head = embed + vocab_start * Hd * 2;             // this rank's vocabulary rows (two 16-bit words per f32 element)
     else {
         RC(dmalloc(&lm_head, 2 * Vl * Hd));
-        RC(kf::fill_weight(F(lm_head), Vl, Hd, Hd, Hd, 0, 0, nvr_weight_key_impl(mc.seed, TID_LM_HEAD), sc, stream));
+        RC(kf::fill_weight(F(lm_head), Vl, Hd, Hd, Hd, vocab_start, 0, nvr_weight_key_impl(mc.seed, TID_LM_HEAD), sc, stream));
     }
     RC(dmalloc(&norm, 2 * Hd)); RC(kf::fill_const(F(norm), Hd, 1.0f, stream));
     NVR_HIP_CHECK(hipStreamSynchronize(stream));
     tiled_dirty = false;
     return NVR_OK;
+}
+
+// RowParallelLinear's exchange on the float32 path (linear.rs:236-238) + residual + RMSNorm: every rank's f32 partial sums [T, hidden] are
+// gathered (the communicator's all-gather: the one-shot arenas for decode-sized rows — bytes are moved, never summed there —, RCCL or the
+// in-process rendezvous otherwise), then summed in RANK ORDER in f32, added to the residual stream and normalised by one kernel: every rank holds
+// the same bits, equal to the f32 oracle's tensor-parallel sum.  One rank: the plain add + RMSNorm.
+int nvr_model_runner::row_parallel_norm_f32(int64_t T, const float *wn) {
+    namespace kf = nvr::kf;
+    float *fh = reinterpret_cast<float *>(h), *fn = reinterpret_cast<float *>(n), *fp = reinterpret_cast<float *>(proj);
+    if (!comm.active()) return kf::add_rmsnorm(fh, fp, wn, mc.rms_norm_eps, T, Hd, fn, stream);
+    if (!f32_gather) return nvr::fail(NVR_ERR_INVARIANT, "float32 tensor-parallel rank without its gather buffer");
+    RC(comm.all_gather_bytes(fp, f32_gather, (size_t)(T * Hd) * sizeof(float), stream));
+    return kf::sum_ranks_add_rmsnorm(fh, f32_gather, (int)tp, T * Hd, wn, mc.rms_norm_eps, T, Hd, fn, stream);
 }
 
 // the f32 graph (Qwen3Model::forward, qwen3.rs:487-505; layer wiring :372-392): one launch per op, eager
@@ -298,11 +317,15 @@ int nvr_model_runner::forward_f32(int64_t T, int64_t B, bool is_prefill, int64_t
         }
         RC(kf::attention(a, paged, st));
         RC(kf::linear(fa, H * D, F(w.o), T, H * D, Hd, w.o_b ? F(w.o_b) : nullptr, fp, st));
-        RC(kf::add_rmsnorm(fh, fp, F(w.ln2), mc.rms_norm_eps, T, Hd, fn, st));                       // residual :382, norm :385
-        RC(kf::linear(fn, Hd, F(w.gate_up), T, Hd, 2 * I, w.gate_up_b ? F(w.gate_up_b) : nullptr, fg, st));
-        RC(kf::silu_and_mul(fg, T, I, fact, st));
+        RC(row_parallel_norm_f32(T, F(w.ln2)));                                                      // (exchange,) residual :382, norm :385
+        if (kf::linear_silu_ok(T, Hd, Hd)) {                                                         // decode-sized: K12 + K13 in one launch
+            RC(kf::linear_silu_mul(fn, Hd, F(w.gate_up), T, Hd, I, w.gate_up_b ? F(w.gate_up_b) : nullptr, fact, st));
+        } else {
+            RC(kf::linear(fn, Hd, F(w.gate_up), T, Hd, 2 * I, w.gate_up_b ? F(w.gate_up_b) : nullptr, fg, st));
+            RC(kf::silu_and_mul(fg, T, I, fact, st));
+        }
         RC(kf::linear(fact, I, F(w.down), T, I, Hd, w.down_b ? F(w.down_b) : nullptr, fp, st));
-        RC(kf::add_rmsnorm(fh, fp, F(l + 1 < L ? layers[l + 1].ln1 : norm), mc.rms_norm_eps, T, Hd, fn, st));   // residual :389, next norm :378 / :501
+        RC(row_parallel_norm_f32(T, F(l + 1 < L ? layers[l + 1].ln1 : norm)));                       // (exchange,) residual :389, next norm :378 / :501
     }
     const float *hl = fn;
     if (is_prefill) { RC(kf::select_last_tokens(fn, d_cu, B, Hd, fnl, st)); hl = fnl; }

@@ -530,12 +530,13 @@ def test_graph_decode_small_max_model_len_full_batch(mml):
 
 def test_config_device_and_dtype_gate_the_runner():
     """Config.device / Config.dtype (config.rs:48-51): the names validate like the reference's; a runner exists only for the
-    HIP device and the three dtypes (fp16, bf16, and since r04 float32 on one rank) — anything else fails loudly instead of falling back."""
+    HIP device and the three dtypes (fp16, bf16, float32 — tensor-parallel ranks of any of them) — anything else fails loudly instead of falling back."""
     mcfg = mo.small()
     base = dict(skip_block_size_check=1, max_num_seqs=2, max_num_batched_tokens=64, max_model_len=64, kvcache_block_size=16, num_kvcache_blocks=4)
-    for ok in (dict(), dict(device="cuda"), dict(device="hip", dtype="float16"), dict(dtype="bfloat16"), dict(dtype="float32")):
+    for ok in (dict(), dict(device="cuda"), dict(device="hip", dtype="float16"), dict(dtype="bfloat16"), dict(dtype="float32"),
+               dict(dtype="float32", tensor_parallel_size=2, tensor_parallel_rank=1)):
         nvr.ModelRunner(nvr.Config(**base, **ok), _model_cfgs(mcfg))
-    for bad in (dict(device="cpu"), dict(device="metal"), dict(dtype="float32", tensor_parallel_size=2)):
+    for bad in (dict(device="cpu"), dict(device="metal")):
         with pytest.raises(nvr.NvrError) as e:
             nvr.ModelRunner(nvr.Config(**base, **bad), _model_cfgs(mcfg))
         assert e.value.code == -10
@@ -1019,5 +1020,8 @@ def test_float32_path_engine_parity(tmp_path, shape):
     p = nvr.LLMEngine(nvr.Config(skip_block_size_check=1, dtype="float32", **ecfg), _model_cfgs(mcfg))
     w = p.model_runner.weight("layers.1.gate_up")
     assert w.dtype == np.float32 and np.array_equal(w, r["oracle"].ranks[0].layers[1]["gate_up"])
-    with pytest.raises(nvr.NvrError):
-        nvr.LLMEngine(nvr.Config(skip_block_size_check=1, dtype="float32", tensor_parallel_size=2, tensor_parallel_rank=0, **ecfg), _model_cfgs(mcfg))
+    # a float32 tensor-parallel rank holds its slice of the same unrounded values (r05: tests/test_tp.py runs such ranks against the f32 oracle)
+    p1 = nvr.LLMEngine(nvr.Config(skip_block_size_check=1, dtype="float32", tensor_parallel_size=2, tensor_parallel_rank=1, **ecfg), _model_cfgs(mcfg))
+    I2 = mcfg.intermediate_size // 2
+    full = r["oracle"].ranks[0].layers[1]["gate_up"]
+    assert np.array_equal(p1.model_runner.weight("layers.1.gate_up"), np.concatenate([full[I2:2 * I2], full[3 * I2:]]))

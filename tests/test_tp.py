@@ -172,8 +172,8 @@ def _tp_ranks_vs_oracle(tp, m, ecfg, prompts, sps, product_kw=None, min_steps=5,
     temps = [sp["temperature"] for sp in sps]
     product_kw = product_kw or {}
     group = nvr.LocalGroup(tp, p2p=p2p)
-    bf16 = dtype == "bfloat16"
-    tol = 1.6e-1 if bf16 else 2e-2
+    bf16, f32 = dtype == "bfloat16", dtype == "float32"
+    tol = 1.6e-1 if bf16 else 2e-4 if f32 else 2e-2
     engines = []
     for r in range(tp):
         e = nvr.LLMEngine(nvr.Config(skip_block_size_check=1, tensor_parallel_size=tp, tensor_parallel_rank=r, sample_seed=11, dtype=dtype,
@@ -213,7 +213,7 @@ def _tp_ranks_vs_oracle(tp, m, ecfg, prompts, sps, product_kw=None, min_steps=5,
         assert all(s["tokens"] == step[0]["tokens"] and s["seq_ids"] == step[0]["seq_ids"] for s in step), "ranks disagree on the sampled tokens"
     # the oracle's tensor-parallel engine, teacher-forced with rank 0's tokens
     eo.reset_sequence_counter()
-    o = mo.OracleEngine(m, eo.Config(**ecfg), fp16=not bf16, bf16=bf16, tp_size=tp, max_pos=ecfg["max_model_len"], sample_seed=11)
+    o = mo.OracleEngine(m, eo.Config(**ecfg), fp16=not bf16 and not f32, bf16=bf16, tp_size=tp, max_pos=ecfg["max_model_len"], sample_seed=11)
     for pr, sp in zip(prompts, sps):
         o.add_request(pr, eo.SamplingParams(**sp))
     near = 0
@@ -233,6 +233,7 @@ def _tp_ranks_vs_oracle(tp, m, ecfg, prompts, sps, product_kw=None, min_steps=5,
     assert near <= 2
     assert o.scheduler.is_finished()
     _tp_ranks_vs_oracle.ahead_launched = [e.ahead_launched() for e in engines]
+    _tp_ranks_vs_oracle.rank0_tokens = [rec["tokens"] for rec in traces[0]]
     return shared_seen
 
 
@@ -267,6 +268,39 @@ def test_bfloat16_tensor_parallel_ranks_match_the_bf16_oracle(tp, p2p, temps):
     prompts = [oracle.fill_tokens(n, 5, i, m.vocab_size).tolist() for i, n in enumerate([9, 40, 17])]
     sps = [dict(temperature=t, max_tokens=10, ignore_eos=True, **({} if t == 0.0 else dict(top_k=30))) for t in temps]
     _tp_ranks_vs_oracle(tp, m, ecfg, prompts, sps, dtype="bfloat16", p2p=p2p)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tp,p2p,temps,bias", [(2, True, [0.0, 0.0, 0.0], False), (4, True, [0.0, 0.7, 0.0], False), (2, False, [0.0, 0.0, 0.0], True)])
+def test_float32_tensor_parallel_ranks_match_the_f32_oracle(tp, p2p, temps, bias):
+    """Config.dtype = "float32" on tensor-parallel ranks (r05; config.rs:51,113-116 with the dtype-agnostic TP classes of linear.rs:88-268): every
+    rank's f32 partial sums are gathered (the one-shot arenas' all-gather form for decode-sized rows — bytes moved, never summed there —, slot by
+    slot for prefill rows; the in-process rendezvous with p2p off) and summed in rank order in f32 by the add + RMSNorm kernel.  Ranks agree bit
+    for bit; shard logits within 2e-4 of the f32 oracle's tensor-parallel engine (summation order only); greedy ids with the fp16 tests' tie rule
+    at that tolerance.  The same requests on ONE float32 rank give the same greedy tokens."""
+    import oracle
+    from oracle import model_oracle as mo
+    m = mo.small(seed=6, num_attention_heads=8, num_key_value_heads=4, head_dim=64, hidden_size=256, intermediate_size=512, use_bias=bias,
+                 tie_word_embeddings=bias)                      # (third case: biases on rank 0 in front of the exchange, and the LM head = this rank's rows of the embedding)
+    ecfg = dict(max_num_seqs=4, max_num_batched_tokens=256, max_model_len=128, kvcache_block_size=16, num_kvcache_blocks=24)
+    prompts = [oracle.fill_tokens(n, 5, i, m.vocab_size).tolist() for i, n in enumerate([9, 40, 17])]
+    sps = [dict(temperature=t, max_tokens=10, ignore_eos=True, **({} if t == 0.0 else dict(top_k=30))) for t in temps]
+    _tp_ranks_vs_oracle(tp, m, ecfg, prompts, sps, dtype="float32", p2p=p2p)
+    if all(t == 0.0 for t in temps):
+        import nvr_import
+        nvr = nvr_import.load()
+        mc = nvr.ModelConfig(vocab_size=m.vocab_size, hidden_size=m.hidden_size, intermediate_size=m.intermediate_size, num_hidden_layers=m.num_hidden_layers,
+                             num_attention_heads=m.num_attention_heads, num_key_value_heads=m.num_key_value_heads, head_dim=m.head_dim,
+                             max_position_embeddings=m.max_position_embeddings, rms_norm_eps=m.rms_norm_eps, rope_theta=m.rope_theta,
+                             tie_word_embeddings=m.tie_word_embeddings, init_std=m.init_std, seed=m.seed, qk_norm=m.qk_norm, use_bias=m.use_bias)
+        nvr.lib().nvr_seq_reset_id_counter()
+        one = nvr.LLMEngine(nvr.Config(skip_block_size_check=1, sample_seed=11, dtype="float32", **ecfg), mc)
+        for pr, sp in zip(prompts, sps):
+            one.add_request(pr, nvr.SamplingParams(**sp))
+        single = []
+        while not one.is_finished():
+            single.append(one.step()["tokens"])
+        assert single == _tp_ranks_vs_oracle.rank0_tokens, "tensor-parallel float32 ranks and the single float32 rank sample different tokens"
 
 
 @pytest.mark.gpu
