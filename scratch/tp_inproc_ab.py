@@ -2,18 +2,21 @@
 batch: ms per step of the slowest rank.  The ranks share one GPU, so the absolute number means nothing; two builds / switches of the exchange
 path compared on the same box do (NVR_TP_FUSED=0/1, NVR_DBG).   usage: python3 scratch/tp_inproc_ab.py <tp> [model] [steps]"""
 import os, sys, time, threading
+NOCOMM = os.environ.get("NOCOMM") == "1"          # the same two ranks WITHOUT their exchanges (NVR_TP_NO_COMM): what the protocol adds = the difference
+if NOCOMM: os.environ["NVR_TP_NO_COMM"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, nvr_import
 nvr = nvr_import.load()
 tp = int(sys.argv[1]); model = sys.argv[2] if len(sys.argv) > 2 else "qwen3-0.6b"; steps = int(sys.argv[3]) if len(sys.argv) > 3 else 48
 P = 1024 if model == "qwen3-0.6b" else 2048
 mc = nvr.ModelConfig(model)
-group = nvr.LocalGroup(tp, p2p=True)
+group = None if NOCOMM else nvr.LocalGroup(tp, p2p=True)
 engines = []
 for r in range(tp):
     e = nvr.LLMEngine(nvr.Config(max_num_seqs=32, max_num_batched_tokens=32768, max_model_len=P + 200, kvcache_block_size=256, num_kvcache_blocks=32 * (P // 256 + 2),
                                  tensor_parallel_size=tp, tensor_parallel_rank=r, async_decode=int(os.environ.get("ASYNC", "1"))), mc)
-    group.attach(e.model_runner); engines.append(e)
+    if group is not None: group.attach(e.model_runner)
+    engines.append(e)
 for e in engines:
     nvr.lib().nvr_seq_reset_id_counter()
     for i in range(32):
@@ -33,7 +36,7 @@ import faulthandler; faulthandler.dump_traceback_later(80, exit=True)
 th = [threading.Thread(target=drive, args=(r,)) for r in range(tp)]
 [t.start() for t in th]; [t.join(600) for t in th]
 assert not errs, errs
-assert all(t == toks[0] for t in toks), "ranks disagree"
+assert NOCOMM or all(t == toks[0] for t in toks), "ranks disagree"
 import zlib
-print(f"{model} tp={tp} in-process: {max(times) / steps * 1e3:.3f} ms/step (slowest rank), tokens crc {zlib.crc32(str(toks[0]).encode()):08x}  FUSED={os.environ.get('NVR_TP_FUSED','1')} DBG={os.environ.get('NVR_DBG','0')}", flush=True)
+print(f"{model} tp={tp} in-process: {max(times) / steps * 1e3:.3f} ms/step (slowest rank), tokens crc {zlib.crc32(str(toks[0]).encode()):08x}  {'exchanges skipped (NVR_TP_NO_COMM)' if NOCOMM else 'peer-to-peer exchanges'}", flush=True)
 os._exit(0)
