@@ -35,6 +35,8 @@ import json
 import os
 import sys
 import time
+import zlib
+import array
 
 import numpy as np
 
@@ -652,6 +654,7 @@ def main() -> None:
 
     kv_source = [-1]
 
+    token_crc = [0]                           # crc32 over the tokens sampled in the timed steps (tensor-parallel ranks must agree on it)
     host_us = [None]                          # host us per timed step inside Scheduler::schedule / ::postprocess
 
     def run_decode(eng):
@@ -683,11 +686,13 @@ def main() -> None:
             assert not info["is_prefill"] and info["num_seqs"] == BATCH
         barrier()
         h0 = eng.host_times()
+        crc = 0
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            eng.step()
+            crc = zlib.crc32(array.array("q", eng.step()["tokens"]).tobytes(), crc)     # (~1 us of host time per step, next to a 1.4 ms step)
         nvr.synchronize()
         el = time.perf_counter() - t0
+        token_crc[0] = crc
         h1 = eng.host_times()
         host_us[0] = {k: round((h1[k + "_us"] - h0[k + "_us"]) / max(1, h1["steps"] - h0["steps"]), 2) for k in ("schedule", "postprocess")}
         barrier()
@@ -766,6 +771,15 @@ def main() -> None:
         parallelism, scaling, jobs = f"tp{args.gpus}", "strong", 1
         arm("tensor-parallel decode")
         elapsed, t_prefill = run_decode(eng)
+        # every rank adds the same partial sums in the same order and merges the same (max, arg-max) records: the ranks' token streams are identical
+        # or the exchange is broken on this node (stale peer data) — then this attempt reports an error and the parent tries the next backend
+        crcs = dist.all_gather(token_crc[0])
+        if len(set(crcs)) != 1:
+            if rank == 0:
+                print(json.dumps({"error": f"tensor-parallel ranks disagree on the sampled tokens ({collective}): token crc per rank {crcs}"}), flush=True)
+            dist.barrier(); dist.close()
+            sys.stdout.flush(); sys.exit(0 if child else 3)
+        collective += f"; the {args.gpus} ranks' token streams of the timed steps are identical (crc {crcs[0]:08x})"
     elif args.gpus > 1:
         eng = make_engine(1, 0)
         r_el, r_pre = run_decode(eng)

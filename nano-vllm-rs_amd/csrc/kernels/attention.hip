@@ -113,7 +113,10 @@ __device__ __forceinline__ half4_t merge_partitions(int np, LoadML load_ml, Load
 // and one lane draws a ticket from the pair's counter; the workgroup whose ticket says it came last reads all partials back with sc1 loads
 // and merges them with merge_partitions — nobody polls.  On a tensor-parallel rank (1-2 kv heads) every kernel of the decode step sits on the
 // launch floor: one launch less per layer.
-template <int D, int G, bool PAGED, bool DIRECT_OUT, int U, int WAVES, bool NT, bool UB, bool FUSE = false>
+// SHM (shared-prefix decode where EVERY query shares the prefix and its own keys fit one partition — BASELINE configs[4]): the partials of the shared
+// partitions [0, part0) were written by the launch in front of this one (flash_shared_prefix), so the single own-partition workgroup of a (query, kv head) IS
+// the last arriver by stream order: it merges the pair itself (own partial through LDS, the same merge_partitions: the merge launch's bits) — no merge launch.
+template <int D, int G, bool PAGED, bool DIRECT_OUT, int U, int WAVES, bool NT, bool UB, bool FUSE = false, bool SHM = false>
 __global__ __launch_bounds__(WAVES * 64) void attn_rows_kernel(AttnParams p) {
     constexpr int LPR = D / 8;          // lanes per K/V row
     constexpr int RPI = 64 / LPR;       // rows per wave-instruction (= tokens per row group)
@@ -138,8 +141,8 @@ __global__ __launch_bounds__(WAVES * 64) void attn_rows_kernel(AttnParams p) {
     }
 
     const int ctx = p.ctx_lens[t];
-    if (p0 >= ctx && !(DIRECT_OUT)) return;          // empty partition: the merge kernel skips it too
-    const int pend = min(ctx, p0 + p.part_size);
+    if (p0 >= ctx && !(DIRECT_OUT) && !SHM) return;  // empty partition: the merge kernel skips it too (SHM: this workgroup still merges the shared partitions)
+    const int pend = max(p0, min(ctx, p0 + p.part_size));
 
     // q slice of this lane for the G heads of kv head g (fp16 pairs for v_dot2)
     half2_t qv[G][4];
@@ -295,6 +298,8 @@ __global__ __launch_bounds__(WAVES * 64) void attn_rows_kernel(AttnParams p) {
     const auto rs_o = __builtin_amdgcn_make_buffer_rsrc(DIRECT_OUT ? nullptr : p.part_o + pair0 * D, 0, DIRECT_OUT ? 0 : (int)(G * p.num_parts * D * 4), 0x00020000);
     const auto rs_ml = __builtin_amdgcn_make_buffer_rsrc(DIRECT_OUT ? nullptr : p.part_ml + pair0 * 2, 0, DIRECT_OUT ? 0 : (int)(G * p.num_parts * 2 * 4), 0x00020000);
     constexpr int AUX = FUSE ? 16 : 0;                                    // sc1: write-through, so the hand-off needs no release fence
+    __shared__ float shm_o[SHM ? G : 1][SHM ? D : 1];                     // SHM: this workgroup's own partial, merged below with the shared partitions'
+    __shared__ float shm_ml[SHM ? G : 1][2];
     for (int idx = threadIdx.x; idx < G * D; idx += WAVES * 64) {
         const int i = idx / D, d = idx % D;
         float M = sm_ml[0][i][0];
@@ -311,6 +316,9 @@ __global__ __launch_bounds__(WAVES * 64) void attn_rows_kernel(AttnParams p) {
         const int h = g * G + i;
         if (DIRECT_OUT) {
             p.out[((int64_t)t * p.H + h) * D + d] = (half_t)(L > 0.f ? o / L : 0.f);
+        } else if (SHM) {
+            shm_o[i][d] = o;
+            if (d == 0) { shm_ml[i][0] = M; shm_ml[i][1] = L; }
         } else {
             const int slot = i * p.num_parts + part;                     // inside the pair's region
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o), rs_o, (slot * D + d) * 4, 0, AUX);
@@ -321,6 +329,20 @@ __global__ __launch_bounds__(WAVES * 64) void attn_rows_kernel(AttnParams p) {
     if constexpr (!DIRECT_OUT) {
         constexpr int TPH = D / 4;                                // merging threads per head: 4 columns each (merge_partitions)
         static_assert(G * TPH <= WAVES * 64, "one pass over the (head, column group) pairs");
+        if constexpr (SHM) {
+            __syncthreads();
+            if (threadIdx.x < G * TPH) {
+                const int i = threadIdx.x / TPH, d = (threadIdx.x % TPH) * 4;
+                const int own = part;                                         // = part0: the one partition of this launch
+                const int np = own + (ctx > p0 ? 1 : 0);                      // shared partitions, then the own one if the query has own keys
+                const int64_t base = ((int64_t)t * p.H + g * G + i) * p.num_parts;
+                const half4_t hv = merge_partitions(np,
+                    [&](int pi) { return pi < own ? *reinterpret_cast<const float2_t *>(p.part_ml + (base + pi) * 2) : (float2_t){shm_ml[i][0], shm_ml[i][1]}; },
+                    [&](int pi) { return pi < own ? *reinterpret_cast<const float4_t *>(p.part_o + (base + pi) * D + d)
+                                                  : (float4_t){shm_o[i][d], shm_o[i][d + 1], shm_o[i][d + 2], shm_o[i][d + 3]}; });
+                *reinterpret_cast<half4_t *>(p.out + ((int64_t)t * p.H + g * G + i) * D + d) = hv;
+            }
+        }
         if constexpr (FUSE) {
             __shared__ unsigned int ticket_s;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // every storing wave drains its stores ...
@@ -388,10 +410,15 @@ size_t attn_workspace_bytes(int64_t nq, int64_t H, int64_t D, int64_t max_ctx) {
 }
 
 template <int D, int G, int U, int WAVES, bool NT>
-static void launch_cfg(const AttnParams &p, bool paged, bool direct, int64_t nwg, hipStream_t s, bool fuse = false) {
+static void launch_cfg(const AttnParams &p, bool paged, bool direct, int64_t nwg, hipStream_t s, bool fuse = false, bool shm = false) {
     dim3 grid((unsigned)nwg), block(WAVES * 64);
     constexpr int TPI = 64 / (D / 8) * U;
     const bool ub = paged && p.block_size % TPI == 0 && (p.num_parts == 1 || p.part_size % TPI == 0);
+    if (shm) {                                                            // (paged, split, every query behind the shared prefix: launch_attn)
+        if (ub) attn_rows_kernel<D, G, true, false, U, WAVES, NT, true, false, true><<<grid, block, 0, s>>>(p);
+        else attn_rows_kernel<D, G, true, false, U, WAVES, NT, false, false, true><<<grid, block, 0, s>>>(p);
+        return;
+    }
     if (ub) {
         if (direct) attn_rows_kernel<D, G, true, true, U, WAVES, NT, true><<<grid, block, 0, s>>>(p);
         else if (fuse) attn_rows_kernel<D, G, true, false, U, WAVES, NT, true, true><<<grid, block, 0, s>>>(p);
@@ -479,15 +506,17 @@ static int launch_attn(const AttnArgs &a, bool paged, hipStream_t s) {
     // split-KV without a shared-prefix pass: the last partition workgroup of a (query, kv head) to finish merges the pair (no merge launch)
     const bool fuse = !direct && !shared && paged && a.tickets != nullptr;
     p.tickets = a.tickets;
+    // ... and with a shared-prefix pass in front whose group is the whole batch, one own partition per pair: that workgroup merges (SHM)
+    const bool shm = shared && paged && !a.shared_rows && np - sparts == 1 && a.tickets != nullptr;
     if (shared)
         if (int rc = flash_shared_prefix(a.q, a.ldq, a.k, a.v, a.block_tables, a.max_blocks, a.block_size, a.nq, a.H, a.KVH, a.D, a.scale,
                                          shared_part, sparts, np, p.part_o, p.part_ml, s, a.shared_rows, a.shared_count)) return rc;
     {
         if (waves == 8) launch_cfg<D, G, DU / 2, 8, true>(p, paged, direct, nwg, s, fuse);  // K/V streamed once: nt loads
-        else if (paged) launch_cfg<D, G, DU, 4, true>(p, paged, direct, nwg, s, fuse);
+        else if (paged) launch_cfg<D, G, DU, 4, true>(p, paged, direct, nwg, s, fuse, shm);
         else launch_cfg<D, G, DU, 4, false>(p, paged, direct, nwg, s);                     // prefill: rows re-read from L2
     }
-    if (!direct && !fuse)
+    if (!direct && !fuse && !shm)
         attn_merge_kernel<D><<<dim3((unsigned)(((int64_t)a.H * a.nq + 256 / (D / 4) - 1) / (256 / (D / 4)))), dim3(256), 0, s>>>(
             p.part_o, p.part_ml, a.ctx_lens, a.H, part_size, np, p.part0, p.kv0, p.kv0_rows, (int64_t)a.H * a.nq, p.out);
     hipError_t e = hipGetLastError();

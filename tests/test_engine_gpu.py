@@ -803,6 +803,45 @@ def test_use_bias_engine_parity_and_checkpoint(tmp_path, shape, dtype):
         assert sorted(q.model_runner.load_safetensors(path)) == sorted(sd)
 
 
+def test_split_kv_merges_ride_on_the_attention_launch_bit_identically():
+    """r05: decode attention that is cut into partitions merges them without a second launch — plain split-KV on the last partition workgroup of a
+    (sequence, kv head) to finish (tickets), and behind a batch-wide shared-prefix pass on the single own-partition workgroup (the shared partials come from
+    the launch in front of it).  Same partials, same merge_partitions: per-step logits are BIT-identical to the runner that keeps the merge launch
+    (NVR_ATTN_FUSED_MERGE=0, read when the runner is created), for a small batch (split-KV), a batch behind one system prompt (shared pass, whole batch)
+    and the same with a stranger in the batch (grouped: keeps the merge launch either way)."""
+    import os
+    mcfg = mo.small(seed=9, hidden_size=512, num_attention_heads=4, num_key_value_heads=2, head_dim=128, intermediate_size=768)
+    V = mcfg.vocab_size
+    ecfg = dict(max_num_seqs=12, max_num_batched_tokens=2048, max_model_len=512, kvcache_block_size=64, num_kvcache_blocks=60, shared_prefix_min_seqs=4)
+    system = oracle.fill_tokens(150, 4, 7, V).tolist()
+    cases = {"split_kv": [oracle.fill_tokens(90 + 40 * i, 4, 300 + i, V).tolist() for i in range(3)],
+             "shared_whole_batch": [system + oracle.fill_tokens(3 + 9 * i, 4, 100 + i, V).tolist() for i in range(9)],
+             "shared_group_and_a_stranger": [system + oracle.fill_tokens(3 + 9 * i, 4, 100 + i, V).tolist() for i in range(8)] + [oracle.fill_tokens(70, 4, 999, V).tolist()]}
+
+    def run(prompts, flag):
+        os.environ["NVR_ATTN_FUSED_MERGE"] = flag
+        try:
+            nvr.lib().nvr_seq_reset_id_counter()
+            p = nvr.LLMEngine(nvr.Config(skip_block_size_check=1, **ecfg), _model_cfgs(mcfg))
+        finally:
+            os.environ.pop("NVR_ATTN_FUSED_MERGE", None)
+        for pr in prompts:
+            p.add_request(pr, nvr.SamplingParams(temperature=0.0, max_tokens=10, ignore_eos=True))
+        out = []
+        while not p.is_finished():
+            rec = p.step()
+            out.append((rec["tokens"], p.model_runner.logits(rec["num_seqs"]).copy(), p.model_runner.last_shared_prefix_len() if not rec["is_prefill"] else -1))
+        return out
+    for name, prompts in cases.items():
+        a, b = run(prompts, "1"), run(prompts, "0")
+        assert len(a) == len(b) > 5
+        if name != "split_kv":
+            assert any(s > 0 for _, _, s in a), name                      # the shared pass did run
+        for (ta, la, sa), (tb, lb, sb) in zip(a, b):
+            assert ta == tb and sa == sb, name
+            assert np.array_equal(la, lb), f"{name}: logits differ between the merge riding on the attention launch and the merge launch"
+
+
 @pytest.mark.parametrize("shape", ["d64_g2", "d128_g2"])
 def test_shared_prefix_decode_attention_engine_parity(shape):
     """BASELINE configs[4] in small: every request starts with the same system prompt, BlockManager::allocate shares its full
