@@ -249,9 +249,10 @@ int Comm::all_gather_bytes(const void *send, void *recv, size_t bytes, hipStream
         p2p_fill(*this, a);
         return k::p2p_allgather_launch(a, send, recv, bytes, s);          // bytes: one build serves both types
     }
-    if (p2p_ready && !comm && bytes % 8 == 0) {
-        // no other backend (peer-to-peer arenas only): a large record (vocabulary-shard logits of stochastic sampling, greedy
-        // batches over 512 rows) goes through the all-reduce slots in its all-gather form, one slot-sized piece per launch
+    if (p2p_ready && bytes % 8 == 0 && (!comm || bytes <= kP2PSlotBytes)) {
+        // a record of up to one slot (the f32 partial sums of a float32 rank's decode step: 128 KB at 32 rows x 1024) goes through the all-reduce slots in
+        // their all-gather form — one launch, capturable — whatever other backend exists; with no other backend (peer-to-peer arenas only) so does a large
+        // record (vocabulary-shard logits of stochastic sampling, greedy batches over 512 rows), one slot-sized piece per launch
         const size_t total = bytes / 2, chunk = kP2PSlotBytes / 2;                  // in fp16-sized units
         for (size_t off = 0; off < total; off += chunk) {
             const size_t cnt = std::min(chunk, total - off);
