@@ -39,7 +39,9 @@ struct AttnArgs {
     // first one's block table names the shared blocks), shared_kv0[t] = shared_len for members, 0 for the others
     const int32_t *shared_rows, *shared_kv0, *shared_count;
     // paged decode, split over partitions: [nq * KVH] arrival counters, ZERO between launches (the kernel re-arms them): the merge of a
-    // (query, kv head)'s partitions then rides on the last partition workgroup to finish instead of a second launch; null = merge launch
+    // (query, kv head)'s partitions then rides on the last partition workgroup to finish instead of a second launch; null = merge launch.
+    // A caller that passes them also allows the other launch-free merge: behind a shared-prefix pass that covers the WHOLE batch, with one
+    // own partition per pair, that partition's workgroup merges the pair (it is the last arriver by stream order; no counter is touched)
     unsigned int *tickets;
 };
 

@@ -304,7 +304,10 @@ def test_engine_stats_health_and_shutdown():
         eng.add_request(oracle.fill_tokens(n, 7, i, mcfg.vocab_size).tolist(), nvr.SamplingParams(temperature=0.0, max_tokens=40, ignore_eos=True))
     st = eng.get_stats()
     assert st["is_running"] and st["scheduler"]["waiting_sequences"] == 3 and st["memory"] == dict(total_blocks=20, free_blocks=20, used_blocks=0, utilization=0.0)
+    assert eng.host_times() == dict(schedule_us=0.0, postprocess_us=0.0, steps=0)
     eng.step(); eng.step()
+    ht = eng.host_times()                                       # nvr_engine_host_times: the integer side of the two steps, always counted
+    assert ht["steps"] == 2 and 0.0 < ht["schedule_us"] < 5e4 and 0.0 < ht["postprocess_us"] < 5e4, ht
     st, h = eng.get_stats(), eng.health_check()
     used = 3 + 2 + 4                                            # ceil(34/16) + ceil(18/16) + ceil(51/16) blocks after one decode step
     assert st["memory"]["used_blocks"] == used and abs(st["memory"]["utilization"] - used / 20 * 100) < 1e-9

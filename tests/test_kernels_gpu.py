@@ -228,6 +228,47 @@ def _fused_merge_equals_two_launches(qb, kcb, vcb, meta, B, H, KVH, D, bs, scale
         nvr.check(nvr.lib().nvr_fill_const(ws.ptr, ws.nbytes // 2, C.c_float(float("nan")), None))
 
 
+def test_fused_split_kv_merge_under_uneven_load():
+    """The last-arriver merge of split-KV attention (sc1 partials + one ticket per workgroup, no acquire fence: cdna guide Guideline 16) held to
+    the guide's own test rule — uneven load, every word checked, many repetitions: while a second stream keeps the memory system busy with large
+    fills (the partition workgroups of a pair then finish far apart and in changing order), 60 back-to-back fused launches over ragged contexts
+    (1 .. 3000 keys: 1 .. 12 partitions per pair) must each reproduce the two-launch result bit for bit and leave every arrival counter at zero."""
+    rng = np.random.default_rng(77)
+    l = nvr.lib()
+    B, H, KVH, D, bs = 6, 8, 2, 128, 64
+    ctxs = [1, 63, 700, 3000, 1025, 2047]
+    NB = sum((c + bs - 1) // bs for c in ctxs) + 3
+    kc, kcb, vc, vcb, bt, max_blocks = _paged_case(rng, B, H, KVH, D, bs, ctxs, NB)
+    q, qb = h16(rng.standard_normal((B, H, D)))
+    ctx = np.asarray(ctxs, np.int32)
+    scale = float(np.float32(1.0) / np.sqrt(np.float32(D)))
+    meta = nvr.AttnMetaC()
+    d_ctx, d_bt = dev(ctx), dev(bt)
+    meta.context_lens, meta.block_tables, meta.max_blocks, meta.batch, meta.max_context_len = d_ctx.ptr, d_bt.ptr, max_blocks, B, int(max(ctxs))
+    ws = nvr.DeviceBuffer(l.nvr_paged_attn_workspace_bytes(B, H, D, int(max(ctxs)))); _KEEP.append(ws)
+    d_q, d_k, d_v = dev(qb), dev(kcb), dev(vcb)
+    d_ref = nvr.DeviceBuffer(B * H * D * 2); _KEEP.append(d_ref)
+    nvr.check(l.nvr_paged_attn_decode(d_q.ptr, H * D, d_k.ptr, d_v.ptr, C.byref(meta), H, KVH, D, bs, scale, d_ref.ptr, ws.ptr, None))
+    ref = d_ref.to_numpy((B, H, D), np.uint16)
+    assert_close_f16(ref.view(F16), oracle.round_f16(oracle.attn_decode(q, kc, vc, bt, ctx, scale)), ulps=2, atol=1e-3, what="two-launch reference")
+    sa, sb = C.c_void_p(), C.c_void_p()
+    nvr.check(l.nvr_stream_create(C.byref(sa))); nvr.check(l.nvr_stream_create(C.byref(sb)))
+    hog = nvr.DeviceBuffer(512 << 20); _KEEP.append(hog)
+    tickets = dev(np.zeros(B * KVH, np.uint32))
+    outs = [nvr.DeviceBuffer(B * H * D * 2) for _ in range(60)]; _KEEP.extend(outs)
+    try:
+        for i, d_o in enumerate(outs):
+            if i % 3 == 0:                                   # bursts of competing traffic on the other stream: load that comes and goes
+                nvr.check(l.nvr_fill_weight(hog.ptr, 16384, 16384, 16384, 16384, 0, 0, 9 + i, 1e-6, sb))
+            nvr.check(l.nvr_paged_attn_decode_fused(d_q.ptr, H * D, d_k.ptr, d_v.ptr, C.byref(meta), H, KVH, D, bs, scale, d_o.ptr, ws.ptr, tickets.ptr, sa))
+        nvr.check(l.nvr_stream_synchronize(sa)); nvr.check(l.nvr_stream_synchronize(sb))
+    finally:
+        l.nvr_stream_destroy(sa); l.nvr_stream_destroy(sb)
+    for i, d_o in enumerate(outs):
+        assert np.array_equal(d_o.to_numpy((B, H, D), np.uint16), ref), f"fused launch {i} differs from the two-launch result"
+    assert not tickets.to_numpy((B * KVH,), np.uint32).any()
+
+
 def test_paged_attn_ignores_garbage_beyond_context():
     """A-8: exactly context_lens[b] keys are visible; poison everything else (incl. -1 padded table slots)."""
     rng = np.random.default_rng(7)
@@ -371,7 +412,7 @@ def test_lm_head_logits_and_argmax_partials(T, K, N):
     is EXACTLY the lowest-index arg-max of the logits the kernel itself wrote (ties included)."""
     rng = np.random.default_rng(31)
     x, xb = h16(rng.standard_normal((T, K)))
-    W, Wb = h16(rng.standard_normal((N, K)) * 0.05)
+    W, Wb = h16(rng.standard_normal((N, K), dtype=np.float32) * np.float32(0.05))   # (f32 draws: the 262 144 x 4096 case holds a billion of them)
     W[N // 3] = W[5]; Wb[N // 3] = Wb[5]                   # identical rows: equal logits -> exact ties
     W[N - 1] = W[5]; Wb[N - 1] = Wb[5]
     x[0], xb[0] = h16(W[5] * 8)                            # make that tied logit the row maximum of token 0
