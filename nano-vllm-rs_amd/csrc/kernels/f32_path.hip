@@ -351,6 +351,7 @@ int silu_and_mul(const float *gu, int64_t T, int64_t I, float *out, hipStream_t 
 // ---------------------------------------------------------------- attention: one workgroup per (query row, head).  Keys of the row: ctx_lens[t] of them,
 // either rows kv_base[t] + j of a contiguous K / V (stride ldkv; the prefill step's own qkv buffer) or cache rows through block table seq_of_q[t]
 // (paged decode).  Scores of all keys in LDS (two-pass softmax as compute_attention writes it), then out[d] = sum_j p_j v_j[d] / sum.
+template <int NV>   // output columns per lane: head_dim <= 64 * NV
 __global__ __launch_bounds__(256) void attention_kernel(AttnArgsF a, int paged) {
     extern __shared__ float sc[];                                       // [max_ctx] scores, then probabilities | q [D] | partial outputs [4][D] | 8 of reduction scratch
     const int t = blockIdx.x, hd = blockIdx.y, g = hd / (a.H / a.KVH), D = a.D;
@@ -366,6 +367,22 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgsF a, int paged) 
         if (paged) return (((int64_t)bt[j / a.block_size] * a.block_size + j % a.block_size) * a.KVH + g) * D;
         return (base + j) * a.ldkv + (int64_t)g * D;
     };
+    // P.V below: wave w takes keys w, w + 4, ...; a lane holds output columns lane, lane + 64, ... .  KB of the wave's keys are requested per round trip (their
+    // rows' block-table entries looked up by KB lanes at once), and the FIRST batch goes out here, in front of the scores: the V rows depend on the block
+    // table only, so their HBM round trip runs under the score phase (r05; the FMA order of an output is unchanged: the same bits)
+    constexpr int KB = 64 / NV;                                          // 64 registers of V per lane
+    float vv[KB][NV];
+    auto request_v = [&](int j0) {
+        int64_t myrow = 0;
+        if (lane < KB) { const int j = j0 + 4 * lane; myrow = row_of(j < ctx ? j : ctx - 1); }
+#pragma unroll
+        for (int u = 0; u < KB; ++u) {
+            const float *vr = a.v + __shfl(myrow, u, 64);
+#pragma unroll
+            for (int i = 0; i < NV; ++i) { const int e = lane + 64 * i; vv[u][i] = e < D ? vr[e] : 0.f; }
+        }
+    };
+    if (wave < ctx) request_v(wave);
     // scores: a thread per key (256 keys in flight per workgroup: a decode step has one query row per sequence, so the parallelism has to come from the keys)
     float mx = -INFINITY;
     for (int j = threadIdx.x; j < ctx; j += 256) {
@@ -390,24 +407,16 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgsF a, int paged) 
     float sum = 0.f;
     for (int j = threadIdx.x; j < ctx; j += 256) { const float p = expf(sc[j] - mx); sc[j] = p; sum += p; }
     sum = block_reduce<false>(sum, sm, 4);                              // (its barriers also publish the probabilities)
-    // P.V: wave w takes keys w, w + 4, ...; a lane holds output columns lane, lane + 64, ... (head_dim <= 256); the four partial rows meet in LDS
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int j0 = wave; j0 < ctx; j0 += 4 * 16) {                       // sixteen of the wave's keys requested before the first FMA; their rows' block-table
-        float vv[16][4], pp[16];                                        // entries are looked up by sixteen lanes at once (one round trip, not one per key)
-        int64_t myrow = 0;
-        if (lane < 16) { const int j = j0 + 4 * lane; myrow = row_of(j < ctx ? j : ctx - 1); }
+    for (int j0 = wave; j0 < ctx; j0 += 4 * KB) {
+        if (j0 != wave) request_v(j0);                                   // (the first batch is already in flight or landed)
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
+        for (int u = 0; u < KB; ++u) {
             const int j = j0 + 4 * u;
-            pp[u] = j < ctx ? sc[j] : 0.f;
-            const float *vr = a.v + __shfl(myrow, u, 64);
+            const float pp = j < ctx ? sc[j] : 0.f;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { const int e = lane + 64 * i; vv[u][i] = e < D ? vr[e] : 0.f; }
+            for (int i = 0; i < NV; ++i) acc[i] = fmaf(pp, vv[u][i], acc[i]);
         }
-#pragma unroll
-        for (int u = 0; u < 16; ++u)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[i] = fmaf(pp[u], vv[u][i], acc[i]);
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) { const int e = lane + 64 * i; if (e < D) part[wave * D + e] = acc[i]; }
@@ -419,8 +428,11 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgsF a, int paged) 
 }
 // opt the attention kernel in to > 64 KiB of dynamic LDS (runner init: never inside a stream capture)
 int prepare() {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&attention_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-        return nvr::fail(NVR_ERR_HIP, "f32 attention: hipFuncSetAttribute failed");
+    const void *fns[] = {reinterpret_cast<const void *>(&attention_kernel<1>), reinterpret_cast<const void *>(&attention_kernel<2>),
+                         reinterpret_cast<const void *>(&attention_kernel<4>)};
+    for (const void *f : fns)
+        if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return nvr::fail(NVR_ERR_HIP, "f32 attention: hipFuncSetAttribute failed");
     return 0;
 }
 int attention(const AttnArgsF &a, bool paged, hipStream_t s) {
@@ -428,7 +440,10 @@ int attention(const AttnArgsF &a, bool paged, hipStream_t s) {
     if (a.D > 256 || a.D % 4) return nvr::fail(NVR_ERR_UNSUPPORTED, "f32 attention: head_dim %d (multiples of 4 up to 256)", a.D);
     const size_t lds = ((size_t)a.max_ctx + 5 * (size_t)a.D + 8) * 4;
     if (lds > 160 * 1024) return nvr::fail(NVR_ERR_UNSUPPORTED, "f32 attention: context %d does not fit the score buffer (%zu bytes of LDS)", a.max_ctx, lds);
-    attention_kernel<<<dim3((unsigned)a.nq, (unsigned)a.H), dim3(256), lds, s>>>(a, paged ? 1 : 0);
+    const dim3 grid((unsigned)a.nq, (unsigned)a.H);
+    if (a.D <= 64) attention_kernel<1><<<grid, dim3(256), lds, s>>>(a, paged ? 1 : 0);
+    else if (a.D <= 128) attention_kernel<2><<<grid, dim3(256), lds, s>>>(a, paged ? 1 : 0);
+    else attention_kernel<4><<<grid, dim3(256), lds, s>>>(a, paged ? 1 : 0);
     F32_LAUNCH_CHECK("f32 attention");
     return 0;
 }

@@ -1222,6 +1222,26 @@ int nvr_model_runner::comm_selftest() {
     for (int i = 0; i < n; ++i)
         if (hbuf[i] != want[comm.nranks]) return nvr::fail(NVR_ERR_RCCL, "comm_selftest: all-reduce gave 0x%04x at %d, want 0x%04x", hbuf[i], i, want[comm.nranks]);
     if (tp > 1) {
+        // ... and 48 more rounds whose payload CHANGES every round and differs per rank (small integers: exact in fp16 and bf16): the one-shot
+        // exchange reuses its two slot parities, so a rank that read a peer's slot before the peer's write-through stores had landed (the failure a
+        // fence-free protocol would show on links that do not order payload and flag) returns the round-before-last's value and fails here, at
+        // communicator set-up, not as diverging token streams later
+        auto enc = [&](int v) -> uint16_t { return bf16 ? f32_to_bf16_bits((float)v) : f32_to_f16_bits((float)v); };
+        for (int round = 0; round < 48; ++round) {
+            for (int i = 0; i < n; ++i) hbuf[i] = enc((round * 5 + (int)rank * 3 + i % 7) % 29);
+            NVR_HIP_CHECK(hipMemcpyAsync(proj, hbuf.data(), n * 2, hipMemcpyHostToDevice, stream));
+            RC(comm.all_reduce_sum_f16(proj, n, stream));
+            NVR_HIP_CHECK(hipMemcpyAsync(hbuf.data(), proj, n * 2, hipMemcpyDeviceToHost, stream));
+            NVR_HIP_CHECK(hipStreamSynchronize(stream));
+            for (int i = 0; i < n; ++i) {
+                int sum = 0;
+                for (int64_t r = 0; r < tp; ++r) sum += (round * 5 + (int)r * 3 + i % 7) % 29;
+                if (hbuf[i] != enc(sum))
+                    return nvr::fail(NVR_ERR_RCCL, "comm_selftest: round %d: all-reduce gave 0x%04x at %d, want %d (a peer's slot was read before its data had landed?)", round, hbuf[i], i, sum);
+            }
+        }
+    }
+    if (tp > 1) {
         const int64_t nr = std::min<int64_t>(8, max_seqs);                 // the token buffers hold max_num_seqs entries per rank
         std::vector<int64_t> mine(nr, rank), all(nr * tp, -1);
         NVR_HIP_CHECK(hipMemcpyAsync(d_tok, mine.data(), nr * 8, hipMemcpyHostToDevice, stream));
