@@ -5,12 +5,14 @@ rm -rf $out && mkdir -p $out
 cd $GRAFT_REPO_ROOT
 rocprofv3 --kernel-trace --stats --output-format csv -d $out -o r -- python3 scratch/f32_step.py > $out/run.log 2>&1
 tail -3 $out/run.log
-f=$(find $out -name "*kernel_stats.csv" | head -1)
+f=$(find $out -name "*kernel_trace.csv" | head -1)
 python3 - "$f" <<'PY'
-import csv, sys
-rows = list(csv.DictReader(open(sys.argv[1])))
-rows.sort(key=lambda r: -float(r["TotalDurationNs"]))
-for r in rows[:14]:
-    print(f'{float(r["TotalDurationNs"])/1e6:9.2f} ms  n={int(r["Calls"]):6d}  avg {float(r["AverageNs"])/1e3:8.2f} us  {r["Name"][:110]}')
+import csv, sys, collections, statistics
+d = collections.defaultdict(list)
+for r in csv.DictReader(open(sys.argv[1])):
+    d[r["Kernel_Name"]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+rows = sorted(d.items(), key=lambda kv: -sum(kv[1]))
+for name, v in rows[:12]:
+    print(f'{sum(v)/1e3:9.2f} ms  n={len(v):6d}  median {statistics.median(v):8.2f}  min {min(v):8.2f}  max {max(v):8.2f} us  {name[:90]}')
 PY
 find $out -name "*.csv" -delete
