@@ -140,11 +140,31 @@ __global__ __launch_bounds__(WAVES * 64) void attn_rows_kernel(AttnParams p) {
         load_bt_chunk(b0 >> 6);
     }
 
-    const int ctx = p.ctx_lens[t];
-    if (p0 >= ctx && !(DIRECT_OUT) && !SHM) return;  // empty partition: the merge kernel skips it too (SHM: this workgroup still merges the shared partitions)
-    const int pend = max(p0, min(ctx, p0 + p.part_size));
-
-    // q slice of this lane for the G heads of kv head g (fp16 pairs for v_dot2)
+    // SHM: the shared partitions' partials [G heads][part0][D] (+ their (max, sum) pairs) go straight into LDS by LDS-DMA, requested HERE, with ctx and
+    // the block table: as loads of the merge at the end of the kernel they were a third dependent round trip in the life of a workgroup whose own
+    // keys are two chunks per wave (configs[4]: 4096 workgroups of ~94 own tokens, 43 us per layer = 0.57 of HBM; profiles/r05_priced_levers.txt 7.)
+    constexpr int SHP = 4;                            // shared partitions whose partials are staged (more: the merge reads them from global memory)
+    __shared__ __attribute__((aligned(16))) float shm_po[SHM ? G * SHP * D : 4];
+    __shared__ float shm_pml[SHM ? G * SHP * 2 : 1];
+    const bool staged = SHM && p.part0 <= SHP;
+    if (SHM && staged) {
+        const int per_head = p.part0 * (D / 4), total = G * per_head;            // 16-byte pieces, lane-linear in LDS: [head][partition][D]
+        const float *src0 = p.part_o + ((int64_t)t * p.H + (int64_t)g * G) * p.num_parts * D;
+        for (int x0 = wave * 64; x0 < total; x0 += WAVES * 64) {
+            const int x = x0 + lane;
+            if (x < total) {
+                const int i = x / per_head, rem = x - i * per_head;
+                __builtin_amdgcn_global_load_lds(src0 + ((int64_t)i * p.num_parts * (D / 4) + rem) * 4,
+                                                 (__attribute__((address_space(3))) void *)(shm_po + x0 * 4), 16, 0, 0);
+            }
+        }
+        if (wave == WAVES - 1 && lane < G * p.part0 * 2) {
+            const int i = lane / (p.part0 * 2), rem = lane - i * (p.part0 * 2);
+            __builtin_amdgcn_global_load_lds(p.part_ml + (((int64_t)t * p.H + (int64_t)g * G + i) * p.num_parts) * 2 + rem,
+                                             (__attribute__((address_space(3))) void *)shm_pml, 4, 0, 0);
+        }
+    }
+    // q slice of this lane for the G heads of kv head g (fp16 pairs for v_dot2); requested in front of ctx's first use
     half2_t qv[G][4];
     {
         const half_t *qrow = p.q + (int64_t)t * p.ldq + (int64_t)g * G * D + dc * 8;
@@ -155,6 +175,9 @@ __global__ __launch_bounds__(WAVES * 64) void attn_rows_kernel(AttnParams p) {
             for (int j = 0; j < 4; ++j) qv[i][j] = (half2_t){h[2 * j], h[2 * j + 1]};
         }
     }
+    const int ctx = p.ctx_lens[t];
+    if (p0 >= ctx && !(DIRECT_OUT) && !SHM) return;  // empty partition: the merge kernel skips it too (SHM: this workgroup still merges the shared partitions)
+    const int pend = max(p0, min(ctx, p0 + p.part_size));
     const int64_t base_row = PAGED ? 0 : (int64_t)p.kv_base[t];
     const int row_elems = p.KVH * D;
 
@@ -231,8 +254,7 @@ __global__ __launch_bounds__(WAVES * 64) void attn_rows_kernel(AttnParams p) {
     const int ng = (pend - p0 + RPI - 1) / RPI;      // row groups of this partition, the last one possibly partial
     const int R = (pend - p0) / (TPI * WAVES);       // full rounds: every wave gets a complete chunk
     const int gt0 = R * (WAVES * U) + wave;          // this wave's remainder groups: gt0, gt0 + WAVES, ..
-    half8_t kt[U], vt[U];
-    auto issue_remainder = [&]() {
+    auto issue_remainder = [&](half8_t (&kt)[U], half8_t (&vt)[U]) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int gt = gt0 + u * WAVES;
@@ -253,7 +275,8 @@ __global__ __launch_bounds__(WAVES * 64) void attn_rows_kernel(AttnParams p) {
         }
     };
 
-    if (R == 0) issue_remainder();
+    half8_t kt[U], vt[U];
+    if (R == 0) issue_remainder(kt, vt);
     for (int r = 0; r < R; ++r) {
         const int tb = p0 + (r * WAVES + wave) * TPI;
         half8_t kk[U], vv[U];
@@ -271,14 +294,18 @@ __global__ __launch_bounds__(WAVES * 64) void attn_rows_kernel(AttnParams p) {
 #pragma unroll
             for (int u = 0; u < U; ++u) { kk[u] = load_row16<NT>(p.k + off[u]); vv[u] = load_row16<NT>(p.v + off[u]); }
         }
-        if (r == R - 1) issue_remainder();
+        if (r == R - 1) issue_remainder(kt, vt);
         process(std::false_type{}, kk, vv, 0);
     }
     if (gt0 < ng) process(std::true_type{}, kt, vt, p0 + gt0 * RPI);
 
     // bring the row-group slots of the wave to their common max and sum them, then merge the waves through LDS
-    __shared__ float sm_acc[WAVES][G][D];
+    constexpr bool ONE = SHM && WAVES == 1;                               // one wave per workgroup: its sums ARE the partition's partial (the cross-wave
+                                                                          // merge below would multiply them by exp(0) = 1 and add them to 0)
+    __shared__ float sm_acc[ONE ? 1 : WAVES][ONE ? 1 : G][ONE ? 1 : D];
     __shared__ float sm_ml[WAVES][G][2];
+    __shared__ float shm_o[SHM ? G : 1][SHM ? D : 1];                     // SHM: this workgroup's own partial, merged below with the shared partitions'
+    __shared__ float shm_ml[SHM ? G : 1][2];
 #pragma unroll
     for (int i = 0; i < G; ++i) {
         const float M = groups_max<LPR>(m[i]);
@@ -287,19 +314,24 @@ __global__ __launch_bounds__(WAVES * 64) void attn_rows_kernel(AttnParams p) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[i][j] = groups_sum<LPR>(acc[i][j] * w);
         if (tg == 0) {
+            if constexpr (ONE) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) sm_acc[wave][i][dc * 8 + j] = acc[i][j];
-            if (dc == 0) { sm_ml[wave][i][0] = M; sm_ml[wave][i][1] = l[i]; }
+                for (int j = 0; j < 8; ++j) shm_o[i][dc * 8 + j] = acc[i][j];
+                if (dc == 0) { shm_ml[i][0] = M; shm_ml[i][1] = l[i]; }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) sm_acc[wave][i][dc * 8 + j] = acc[i][j];
+                if (dc == 0) { sm_ml[wave][i][0] = M; sm_ml[wave][i][1] = l[i]; }
+            }
         }
     }
-    __syncthreads();
+    if constexpr (!ONE) __syncthreads();
     // the pair's partials are contiguous: [G heads][num_parts][D] (and [..][2]); buffer offsets stay small whatever the workspace size
     const int64_t pair0 = DIRECT_OUT ? 0 : ((int64_t)t * p.H + (int64_t)g * G) * p.num_parts;
     const auto rs_o = __builtin_amdgcn_make_buffer_rsrc(DIRECT_OUT ? nullptr : p.part_o + pair0 * D, 0, DIRECT_OUT ? 0 : (int)(G * p.num_parts * D * 4), 0x00020000);
     const auto rs_ml = __builtin_amdgcn_make_buffer_rsrc(DIRECT_OUT ? nullptr : p.part_ml + pair0 * 2, 0, DIRECT_OUT ? 0 : (int)(G * p.num_parts * 2 * 4), 0x00020000);
     constexpr int AUX = FUSE ? 16 : 0;                                    // sc1: write-through, so the hand-off needs no release fence
-    __shared__ float shm_o[SHM ? G : 1][SHM ? D : 1];                     // SHM: this workgroup's own partial, merged below with the shared partitions'
-    __shared__ float shm_ml[SHM ? G : 1][2];
+    if constexpr (!ONE)
     for (int idx = threadIdx.x; idx < G * D; idx += WAVES * 64) {
         const int i = idx / D, d = idx % D;
         float M = sm_ml[0][i][0];
@@ -330,16 +362,24 @@ __global__ __launch_bounds__(WAVES * 64) void attn_rows_kernel(AttnParams p) {
         constexpr int TPH = D / 4;                                // merging threads per head: 4 columns each (merge_partitions)
         static_assert(G * TPH <= WAVES * 64, "one pass over the (head, column group) pairs");
         if constexpr (SHM) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the LDS-DMA requests of the shared partitions' partials (long landed)
             __syncthreads();
             if (threadIdx.x < G * TPH) {
                 const int i = threadIdx.x / TPH, d = (threadIdx.x % TPH) * 4;
                 const int own = part;                                         // = part0: the one partition of this launch
                 const int np = own + (ctx > p0 ? 1 : 0);                      // shared partitions, then the own one if the query has own keys
                 const int64_t base = ((int64_t)t * p.H + g * G + i) * p.num_parts;
-                const half4_t hv = merge_partitions(np,
-                    [&](int pi) { return pi < own ? *reinterpret_cast<const float2_t *>(p.part_ml + (base + pi) * 2) : (float2_t){shm_ml[i][0], shm_ml[i][1]}; },
-                    [&](int pi) { return pi < own ? *reinterpret_cast<const float4_t *>(p.part_o + (base + pi) * D + d)
-                                                  : (float4_t){shm_o[i][d], shm_o[i][d + 1], shm_o[i][d + 2], shm_o[i][d + 3]}; });
+                const float2_t own_ml = {shm_ml[i][0], shm_ml[i][1]};
+                const float4_t own_o = {shm_o[i][d], shm_o[i][d + 1], shm_o[i][d + 2], shm_o[i][d + 3]};
+                half4_t hv;
+                if (staged)
+                    hv = merge_partitions(np,
+                        [&](int pi) { return pi < own ? *reinterpret_cast<const float2_t *>(shm_pml + (i * own + pi) * 2) : own_ml; },
+                        [&](int pi) { return pi < own ? *reinterpret_cast<const float4_t *>(shm_po + (i * own + pi) * D + d) : own_o; });
+                else
+                    hv = merge_partitions(np,
+                        [&](int pi) { return pi < own ? *reinterpret_cast<const float2_t *>(p.part_ml + (base + pi) * 2) : own_ml; },
+                        [&](int pi) { return pi < own ? *reinterpret_cast<const float4_t *>(p.part_o + (base + pi) * D + d) : own_o; });
                 *reinterpret_cast<half4_t *>(p.out + ((int64_t)t * p.H + g * G + i) * D + d) = hv;
             }
         }
@@ -483,7 +523,13 @@ static int launch_attn(const AttnArgs &a, bool paged, hipStream_t s) {
         want = std::max<int64_t>(1, std::min<int64_t>(want, cap - sparts));
         part_size = (int)(((rest + want - 1) / want + 63) / 64 * 64);
         np = sparts + (int)((rest + part_size - 1) / part_size);
-        waves = 4;
+        // waves per (query, kv head, own partition) workgroup: 4 while that gives the chip its ~4096 waves; with more workgroups than that
+        // (configs[4]: 512 x 8 pairs of ~94 own keys) a workgroup's life is mostly the part with no K/V request in flight — cross-wave merge,
+        // two barriers, the partition merge behind 24 keys per wave (r05 stamps: ~4 of ~9 us, four rounds of 1024 workgroups) — so one wave
+        // streams the whole partition and 16 independent waves per CU cover each other's tails
+        const int64_t own_wgs = pairs * (np - sparts);
+        const int min_waves = (G * (D / 4) + 63) / 64;                    // the merge takes one pass over (head, 4-column group)
+        waves = std::max(min_waves, own_wgs >= 4096 ? 1 : own_wgs >= 2048 ? 2 : 4);
     } else if (a.workspace) {
         if (waves >= 8) {
             int64_t want = pairs >= 192 ? 1 : (256 + pairs - 1) / pairs;
@@ -513,6 +559,8 @@ static int launch_attn(const AttnArgs &a, bool paged, hipStream_t s) {
                                          shared_part, sparts, np, p.part_o, p.part_ml, s, a.shared_rows, a.shared_count)) return rc;
     {
         if (waves == 8) launch_cfg<D, G, DU / 2, 8, true>(p, paged, direct, nwg, s, fuse);  // K/V streamed once: nt loads
+        else if (paged && waves == 1) { if constexpr (G * (D / 4) <= 64) launch_cfg<D, G, DU, 1, true>(p, paged, direct, nwg, s, fuse, shm); }   // (U = 2: 3.18-3.20 against 3.14-3.17 ms per configs[4] step)
+        else if (paged && waves == 2) { if constexpr (G * (D / 4) <= 128) launch_cfg<D, G, DU, 2, true>(p, paged, direct, nwg, s, fuse, shm); }
         else if (paged) launch_cfg<D, G, DU, 4, true>(p, paged, direct, nwg, s, fuse, shm);
         else launch_cfg<D, G, DU, 4, false>(p, paged, direct, nwg, s);                     // prefill: rows re-read from L2
     }
