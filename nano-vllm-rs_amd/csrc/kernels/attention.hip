@@ -42,6 +42,12 @@ struct AttnParams {
     unsigned int *tickets;             // FUSE: one arrival counter per (query, kv head), zero between launches (the last arriver re-arms it)
 };
 
+// a * b rounded, then + c rounded: never contracted into an fma, whatever kernel this is inlined into
+__device__ __forceinline__ float mul_then_add(float a, float b, float c) {
+#pragma clang fp contract(off)
+    return a * b + c;
+}
+
 template <bool NT>
 __device__ __forceinline__ half8_t load_row16(const half_t *p) {
     if (NT) return __builtin_nontemporal_load(reinterpret_cast<const half8_t *>(p));
@@ -97,8 +103,11 @@ __device__ __forceinline__ half4_t merge_partitions(int np, LoadML load_ml, Load
         for (int u = 0; u < 8; ++u) {
             if (i0 + u < np) {
                 const float w = __expf(ml[u][0] - M);
-                o += w * po[u];
-                L += w * ml[u][1];
+                // (spelled out as fused multiply-adds: under -ffp-contract=fast hipcc decides per INSTANTIATION whether "a += w * b" becomes an fma,
+                //  and this function is inlined into three kernels whose results are promised to agree bit for bit; fma is what the merge kernel got)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = __fmaf_rn(w, po[u][e], o[e]);
+                L = __fmaf_rn(w, ml[u][1], L);
             }
         }
     }
@@ -247,7 +256,7 @@ __global__ __launch_bounds__(WAVES * 64) void attn_rows_kernel(AttnParams p) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) acc[i][j] = fmaf(pr, (float)vv[u][j], acc[i][j]);
             }
-            l[i] = l[i] * alpha + ps;
+            l[i] = __fmaf_rn(l[i], alpha, ps);                         // (pinned: see the cross-wave merge below)
         }
     };
 
@@ -342,8 +351,12 @@ __global__ __launch_bounds__(WAVES * 64) void attn_rows_kernel(AttnParams p) {
         for (int w2 = 0; w2 < WAVES; ++w2) {
             const float mw = sm_ml[w2][i][0];
             const float wgt = (mw == -INFINITY) ? 0.f : __expf(mw - M);
-            o += wgt * sm_acc[w2][i][d];
-            L += wgt * sm_ml[w2][i][1];
+            // (multiply, THEN add, spelled out: left to -ffp-contract=fast the SHM instantiation of this loop got fmas where the instantiation in front of
+            //  the merge launch got v_pk_mul + v_add — a 1-ulp difference that flipped ~1 output in 10^5 between two forms promised to be bit-identical
+            //  (r05, found at 300 sequences; the 9-sequence test was too small to see it).  Unfused is what the partial-writing instantiations always were;
+            //  HIP's __fmul_rn / __fadd_rn are plain * and + and contract like them, hence the helper with contraction switched off.)
+            o = mul_then_add(wgt, sm_acc[w2][i][d], o);
+            L = mul_then_add(wgt, sm_ml[w2][i][1], L);
         }
         const int h = g * G + i;
         if (DIRECT_OUT) {
@@ -495,6 +508,19 @@ static int launch_attn(const AttnArgs &a, bool paged, hipStream_t s) {
     // 64-token-granular partitions + merge kernel (B=32, ctx 1044: KVH=1 10.9 us vs 14.6 us for the 4-wave path, KVH=2
     // 12.7 vs 14.6, KVH=4 17.5 vs 19.7; scratch/attn_tp_shape.py)
     int waves = (paged && a.workspace && pairs * ((mc + 63) / 64) >= 256) ? 8 : 4;
+    // Waves per workgroup when there are >= 2048 pairs (batches of >= 256 sequences at 8 kv heads): enough for the chip's ~4096 waves, and by the bound
+    // on the keys a workgroup walks (the 256-token context bucket: the contexts themselves are shorter) — with eight waves on a short context a
+    // workgroup's life is mostly start-up, barriers and the cross-wave merge, not K/V requests (scratch/attn_batch_shape.py, ragged contexts, us per
+    // launch at 8 / 4 / 2 / 1 waves: 512 x <= 100: 45.0 / 37.0 / 35.7 / 32.8; 1024 x <= 100: 83.9 / 70.1 / 64.7 / 63.4; 256 x <= 200: 37.9 / 35.9 /
+    // 33.8 / 42.3; 512 x <= 300: 92.3 / 89.2 / 90.0 / 91.1; 256 x 1024: 149 / 153 / 152 / 161; configs[4]'s own partitions, bound 256: 2 waves 3.23, 1 wave 3.13 ms / step)
+    constexpr int min_waves = (G * (D / 4) + 63) / 64;                    // the merge takes one pass over (head, 4-column group)
+    auto waves_for = [&](int64_t wgs, int64_t keys, int cap) {
+        const int64_t want = std::max<int64_t>({(4096 + wgs - 1) / wgs, keys <= 256 ? 1 : keys <= 512 ? 4 : 8, (int64_t)min_waves});
+        int w = 1;
+        while (w < want && w < cap) w *= 2;
+        return w;
+    };
+    if (paged && a.workspace && a.shared_len <= 0 && pairs >= 2048) waves = waves_for(pairs, mc, 8);
     int part_size = 0x3fffffff, np = 1, sparts = 0, shared_part = 0;
     const bool shared = a.shared_len > 0;
     if (shared) {
@@ -528,8 +554,7 @@ static int launch_attn(const AttnArgs &a, bool paged, hipStream_t s) {
         // two barriers, the partition merge behind 24 keys per wave (r05 stamps: ~4 of ~9 us, four rounds of 1024 workgroups) — so one wave
         // streams the whole partition and 16 independent waves per CU cover each other's tails
         const int64_t own_wgs = pairs * (np - sparts);
-        const int min_waves = (G * (D / 4) + 63) / 64;                    // the merge takes one pass over (head, 4-column group)
-        waves = std::max(min_waves, own_wgs >= 4096 ? 1 : own_wgs >= 2048 ? 2 : 4);
+        waves = own_wgs >= 2048 ? waves_for(own_wgs, part_size, 4) : 4;
     } else if (a.workspace) {
         if (waves >= 8) {
             int64_t want = pairs >= 192 ? 1 : (256 + pairs - 1) / pairs;

@@ -87,6 +87,20 @@ __device__ __forceinline__ half4_t lds_read_tr16(const char *lds_addr) {
 // f32 -> fp16 (bf16 build: -> bfloat16), round-to-nearest-even, as a standalone conversion.  The empty asm makes the f32 value
 // opaque so that hipcc (-ffp-contract=fast) cannot fold the producing multiply/add into a single-rounding
 // v_fma_mixlo_f16: the oracle rounds twice (f32 op, then fp16), and bit-exact parity needs the same.
+// a*b - c*d and a*b + c*d with every product and the sum rounded on its own (RotaryEmbedding::apply_rotary_emb_single, rotary_embedding.rs:128-158, as the
+// oracle evaluates it): HIP's __fmul_rn / __fadd_rn / __fsub_rn are plain * + - and, under the device default -ffp-contract=fast, may or may not become an fma
+// depending on the kernel they are inlined into (r05: two instantiations of one attention loop disagreed by 1 ulp) — the RoPE rotation exists in five kernels
+// whose results are promised to agree bit for bit, so contraction is switched off where it is written down.
+__device__ __forceinline__ float mul_sub_unfused(float a, float b, float c, float d) {
+#pragma clang fp contract(off)
+    const float x = a * b, y = c * d;
+    return x - y;
+}
+__device__ __forceinline__ float mul_add_unfused(float a, float b, float c, float d) {
+#pragma clang fp contract(off)
+    const float x = a * b, y = c * d;
+    return x + y;
+}
 __device__ __forceinline__ half_t to_half_rn(float f) {
     asm volatile("" : "+v"(f));
     return (half_t)f;

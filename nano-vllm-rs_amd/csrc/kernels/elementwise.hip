@@ -399,8 +399,8 @@ __global__ __launch_bounds__(256) void rope_store_kernel(half_t *__restrict__ qk
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float a = (float)x1[e], b = (float)x2[e], cs = c[j + e], si = sn[j + e];
-                o1[e] = to_half_rn(__fsub_rn(__fmul_rn(a, cs), __fmul_rn(b, si)));
-                o2[e] = to_half_rn(__fadd_rn(__fmul_rn(b, cs), __fmul_rn(a, si)));
+                o1[e] = to_half_rn(mul_sub_unfused(a, cs, b, si));
+                o2[e] = to_half_rn(mul_add_unfused(b, cs, a, si));
             }
             *reinterpret_cast<half8_t *>(x + j) = o1;
             *reinterpret_cast<half8_t *>(x + j + half_d) = o2;
@@ -441,8 +441,8 @@ __global__ __launch_bounds__(256) void qknorm_rope_store_kernel(half_t *__restri
             const float a = (float)to_half_rn(__fmul_rn(__fdiv_rn((float)x[j], rms), (float)g[j]));
             const float b = (float)to_half_rn(__fmul_rn(__fdiv_rn((float)x[j + half_d], rms), (float)g[j + half_d]));
             const float cs = cos_t[p * half_d + j], si = sin_t[p * half_d + j];
-            const half_t o1 = to_half_rn(__fsub_rn(__fmul_rn(a, cs), __fmul_rn(b, si)));
-            const half_t o2 = to_half_rn(__fadd_rn(__fmul_rn(b, cs), __fmul_rn(a, si)));
+            const half_t o1 = to_half_rn(mul_sub_unfused(a, cs, b, si));
+            const half_t o2 = to_half_rn(mul_add_unfused(b, cs, a, si));
             x[j] = o1; x[j + half_d] = o2;
             if (head >= H && slot >= 0) {
                 half_t *dst = kc + ((int64_t)slot * KVH + (head - H)) * D;

@@ -378,8 +378,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const half_t *__restrict__
 #pragma unroll
                         for (int e = 0; e < 8; ++e) {
                             const float a = (float)x1[e], b = (float)x2[e], cc = cs[kk][e >> 2][e & 3], ss = sn[kk][e >> 2][e & 3];
-                            o1[e] = to_half_rn(__fsub_rn(__fmul_rn(a, cc), __fmul_rn(b, ss)));
-                            o2[e] = to_half_rn(__fadd_rn(__fmul_rn(b, cc), __fmul_rn(a, ss)));
+                            o1[e] = to_half_rn(mul_sub_unfused(a, cc, b, ss));
+                            o2[e] = to_half_rn(mul_add_unfused(b, cc, a, ss));
                         }
                     }
                     if (m >= T) continue;

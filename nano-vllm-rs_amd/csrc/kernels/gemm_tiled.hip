@@ -284,8 +284,8 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(const half_t *__restric
                     const float4_t sn = PRE ? pre_sn[j][i] : *reinterpret_cast<const float4_t *>(epi.sin_t + p * half_d + jj);
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        h[e] = (q < 2) ? to_half_rn(__fsub_rn(__fmul_rn(v[e], cs[e]), __fmul_rn(pv[e], sn[e])))
-                                       : to_half_rn(__fadd_rn(__fmul_rn(v[e], cs[e]), __fmul_rn(pv[e], sn[e])));
+                        h[e] = (q < 2) ? to_half_rn(mul_sub_unfused(v[e], cs[e], pv[e], sn[e]))
+                                       : to_half_rn(mul_add_unfused(v[e], cs[e], pv[e], sn[e]));
                     col = (q < 2) ? jj : half_d + jj;
                 } else {
 #pragma unroll

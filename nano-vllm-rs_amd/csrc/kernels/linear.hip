@@ -201,8 +201,8 @@ __global__ __launch_bounds__(WAVES * 64) void linear_skinny_kernel(const half_t 
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     // rotary_embedding.rs:36-44: out1 = x1*c - x2*s ; out2 = x2*c + x1*s
-                    h[e] = (q < 2) ? to_half_rn(__fsub_rn(__fmul_rn(v[e], cs[e]), __fmul_rn(pv[e], sn[e])))
-                                   : to_half_rn(__fadd_rn(__fmul_rn(v[e], cs[e]), __fmul_rn(pv[e], sn[e])));
+                    h[e] = (q < 2) ? to_half_rn(mul_sub_unfused(v[e], cs[e], pv[e], sn[e]))
+                                   : to_half_rn(mul_add_unfused(v[e], cs[e], pv[e], sn[e]));
                 }
                 col = (q < 2) ? jj : half_d + jj;
             } else {

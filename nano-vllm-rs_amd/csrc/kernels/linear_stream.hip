@@ -157,8 +157,8 @@ __global__ __launch_bounds__(WAVES * 64) void linear_stream_kernel(const half_t 
                     const float4_t sn = *reinterpret_cast<const float4_t *>(epi.sin_t + epi.pos[mc] * half_d + jj);
 #pragma unroll
                     for (int e = 0; e < 4; ++e)                              // rotary_embedding.rs:36-44
-                        h[e] = (q < 2) ? to_half_rn(__fsub_rn(__fmul_rn(v[e], cs[e]), __fmul_rn(pv[e], sn[e])))
-                                       : to_half_rn(__fadd_rn(__fmul_rn(v[e], cs[e]), __fmul_rn(pv[e], sn[e])));
+                        h[e] = (q < 2) ? to_half_rn(mul_sub_unfused(v[e], cs[e], pv[e], sn[e]))
+                                       : to_half_rn(mul_add_unfused(v[e], cs[e], pv[e], sn[e]));
                     col = (q < 2) ? jj : half_d + jj;
                 } else {
 #pragma unroll

@@ -845,6 +845,47 @@ def test_split_kv_merges_ride_on_the_attention_launch_bit_identically():
             assert np.array_equal(la, lb), f"{name}: logits differ between the merge riding on the attention launch and the merge launch"
 
 
+@pytest.mark.parametrize("nseq", [512, 300])
+def test_shared_prefix_own_partitions_on_one_and_two_wave_workgroups_merge_bit_identically(nseq):
+    """r05, BASELINE configs[4]'s geometry (8 kv heads): with >= 4096 (sequence, kv head) pairs behind the shared pass a ONE-wave workgroup streams a pair's
+    own keys (>= 2048: two waves) and, as the last arriver by stream order, merges the pair with the shared partitions' partials (staged in LDS when the
+    kernel starts).  Per-step logits are BIT-identical to the runner that keeps the merge launch (NVR_ATTN_FUSED_MERGE=0: the same one- / two-wave kernel,
+    partials through the workspace, attn_merge_kernel), and the batch's tokens equal the plain paged path's (no shared pass) wherever the plain logits are
+    not a near tie.  (The 512-sequence form is checked against the oracle through test_scale's configs[4] test, the kernel through test_kernels_gpu.)"""
+    import os
+    mcfg = mo.small(seed=21, hidden_size=256, num_attention_heads=16, num_key_value_heads=8, head_dim=128, intermediate_size=512, num_hidden_layers=2)
+    V = mcfg.vocab_size
+    ecfg = dict(max_num_seqs=nseq, max_num_batched_tokens=1 << 17, max_model_len=320, kvcache_block_size=64, num_kvcache_blocks=nseq * 2 + 8)
+    system = oracle.fill_tokens(128, 4, 7, V).tolist()
+    prompts = [system + oracle.fill_tokens(3 + (7 * i) % 50, 4, 100 + i, V).tolist() for i in range(nseq)]
+
+    def run(flag, min_seqs):
+        os.environ["NVR_ATTN_FUSED_MERGE"] = flag
+        try:
+            nvr.lib().nvr_seq_reset_id_counter()
+            p = nvr.LLMEngine(nvr.Config(skip_block_size_check=1, shared_prefix_min_seqs=min_seqs, **ecfg), _model_cfgs(mcfg))
+        finally:
+            os.environ.pop("NVR_ATTN_FUSED_MERGE", None)
+        for pr in prompts:
+            p.add_request(pr, nvr.SamplingParams(temperature=0.0, max_tokens=6, ignore_eos=True))
+        out = []
+        while not p.is_finished():
+            rec = p.step()
+            if not rec["is_prefill"]:
+                out.append((rec["tokens"], p.model_runner.logits(rec["num_seqs"]).copy(), p.model_runner.last_shared_prefix_len()))
+        return out
+    a, b, plain = run("1", 4), run("0", 4), run("1", -1)
+    assert len(a) == len(b) == len(plain) >= 5
+    for (ta, la, sa), (tb, lb, sb), (tp, lp, sp) in zip(a, b, plain):
+        assert sa == sb == 128 and sp == 0
+        assert ta == tb and np.array_equal(la, lb), "logits differ between the merge on the own-partition workgroup and the merge launch"
+        top2 = np.sort(lp, axis=1)[:, -2:]
+        clear = (top2[:, 1] - top2[:, 0]) > 2e-2
+        assert clear.sum() > nseq // 2
+        assert np.array_equal(np.asarray(ta)[clear], np.asarray(tp)[clear]), "shared pass vs plain paged attention: tokens differ off a near tie"
+        if not np.array_equal(np.asarray(ta), np.asarray(tp)): break       # (token streams have parted at a near tie: later steps are not comparable)
+
+
 @pytest.mark.parametrize("shape", ["d64_g2", "d128_g2"])
 def test_shared_prefix_decode_attention_engine_parity(shape):
     """BASELINE configs[4] in small: every request starts with the same system prompt, BlockManager::allocate shares its full

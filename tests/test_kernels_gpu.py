@@ -947,6 +947,8 @@ def test_qk_norm_rope_store(T, H, KVH, D):
     (130, 8, 8, 128, 64, 3, [(7 * i) % 200 for i in range(130)]),   # group 1: 128 sequences per workgroup + a ragged last tile
     (33, 8, 2, 128, 128, 1, [5 + i for i in range(33)]),            # group 4
     (2, 16, 8, 128, 256, 1, [0, 0]),                    # only the shared partition exists
+    (512, 16, 8, 128, 64, 1, [(11 * i) % 120 for i in range(512)]),   # 4096 (sequence, kv head) pairs: ONE-wave workgroups stream the own keys (r05)
+    (300, 16, 8, 128, 64, 1, [(13 * i) % 125 for i in range(300)]),   # 2400 pairs: two-wave workgroups
 ])
 def test_paged_attn_decode_shared_prefix(B, H, KVH, D, bs, P, own):
     """nvr_paged_attn_decode_shared: every sequence's first P blocks are the SAME cache blocks (prefix-cache hits); the shared
