@@ -55,14 +55,16 @@ __device__ __forceinline__ float sigmoid_fast(float x) { return __builtin_amdgcn
 // vmcnt(0), ds_write, branch), i.e. one L2 round trip per 8 KiB of the image (r03: 16 round trips per 128 KiB chunk of the streaming
 // GEMMs, 8 in front of the LM head).
 template <int ROWS, int THREADS, int FB>
-__device__ __forceinline__ void fill_x_image(char *smem, const half_t *__restrict__ x, int64_t ldx, int col0, int cpr, int T, int tid) {
+__device__ __forceinline__ void fill_x_image(char *smem, const half_t *__restrict__ x, int64_t ldx, int col0, int cpr, int T, int tid, int rot = 0) {
     const int total = ROWS * cpr;
     for (int c0 = tid; c0 < total; c0 += THREADS * FB) {
         half8_t v[FB];
         int slot[FB];
 #pragma unroll
         for (int f = 0; f < FB; ++f) {
-            const int c = c0 + f * THREADS, cc = c < total ? c : total - 1;       // (clamped: the load is unconditional, only the write is guarded)
+            const int c = c0 + f * THREADS;
+            int cc = c < total ? c : total - 1;                                   // (clamped: the load is unconditional, only the write is guarded)
+            cc += rot; if (cc >= total) cc -= total;                              // rot < total: where this workgroup starts its walk over the block
             const int row = cc / cpr, ch = cc - row * cpr;
             const int m = row < T ? row : T - 1;
             v[f] = *reinterpret_cast<const half8_t *>(x + (int64_t)m * ldx + col0 + ch * 8);

@@ -41,7 +41,12 @@ __device__ __forceinline__ int s_w_row(int t, int nt, int r, int N, const Stream
     return t * 16 + r;
 }
 
-template <int NTT, int MT, int WAVES, int U, int EPI, int TMAX>
+// PRE (r05; NTT = 1, at most PRE tiles per workgroup, KC <= 8 k-steps per wave): the launch was a chain of dependent round trips, not a stream — per
+// K chunk the image fill (two rounds of 8 loads per thread) and then, per tile, two rounds of U weight pieces per wave: 12 round trips for a workgroup
+// with two tiles of Qwen3-8B's qkv (50 MB in 21.3 us = 2.4 TB/s, scratch/prof_8b.sh).  The weight pieces depend on nothing: with PRE every wave
+// requests ALL its pieces of the chunk (PRE tiles x 8 k-steps, 64 registers) in front of the fill, and the fill asks for its 16 pieces per thread
+// at once — one round trip per chunk.  The MFMAs of an accumulator run over the k-steps in the order they always had: the same bits.
+template <int NTT, int MT, int WAVES, int U, int EPI, int TMAX, int PRE = 0>
 __global__ __launch_bounds__(WAVES * 64) void linear_stream_kernel(const half_t *__restrict__ x, int64_t ldx,
                                                                    const half_t *__restrict__ W, int T, int K, int N, int KC,
                                                                    int ntiles, half_t *__restrict__ y, StreamEpi epi) {
@@ -49,6 +54,19 @@ __global__ __launch_bounds__(WAVES * 64) void linear_stream_kernel(const half_t 
     constexpr int ROWS = MT * 16;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 15, q = lane >> 4;
     const int cpr = KC / 8;                                                  // 16-byte chunks per row of the image
+
+    // SEPI_ROPE: the epilogue of a tile was position -> cos / sin row -> rotate and slot -> cache store: two dependent round trips per tile behind the
+    // stream (r05: ~4 us per tile of the 19 us launch).  The token's position and cache slot do not depend on the tile: the epilogue waves (wave j
+    // owns tokens 16 j + r) request them HERE (inline asm: a compiler-visible load would be sunk to its use); they have landed when the first image
+    // fill has been waited for (they are older than it).  The cos / sin pieces of ALL the workgroup's tiles are then requested together in front of
+    // the first tile's reduction.
+    int64_t pos_pre = 0; int slot_pre = -1;
+    if (EPI == SEPI_ROPE && wave < MT) {
+        const int m = wave * 16 + r;
+        const int64_t *psrc = epi.pos + (m < T ? m : T - 1);
+        asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(pos_pre) : "v"(psrc) : "memory");
+        if (epi.slots) { const int32_t *ssrc = epi.slots + (m < T ? m : T - 1); asm volatile("global_load_dword %0, %1, off" : "=v"(slot_pre) : "v"(ssrc) : "memory"); }
+    }
 
     float4_t acc[TMAX][NTT][MT];
 #pragma unroll
@@ -59,6 +77,46 @@ __global__ __launch_bounds__(WAVES * 64) void linear_stream_kernel(const half_t 
             for (int j = 0; j < MT; ++j) acc[i][nt][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
 
     for (int kc0 = 0; kc0 < K; kc0 += KC) {
+        if constexpr (PRE > 0) {
+            static_assert(NTT == 1 && PRE <= TMAX, "PRE: one weight part per tile");
+            constexpr int KPW = 8;                                           // k-steps per wave and chunk (host: KC <= KPW * WAVES * 32)
+            half8_t a[PRE][KPW];
+            const int kmul = epi.tiled ? 16 : 1;
+#pragma unroll
+            for (int i = 0; i < PRE; ++i) {
+                const int tile = blockIdx.x + i * gridDim.x;
+                const bool live = tile < ntiles;
+                const int tl = live ? tile : 0;
+                const half_t *wr = epi.tiled ? W + ((int64_t)tl * (K / 32) + kc0 / 32) * 512 + r * 32 + q * 8
+                                             : W + (int64_t)s_w_row<EPI>(tl, 0, r, N, epi) * K + kc0 + q * 8;
+#pragma unroll
+                for (int u = 0; u < KPW; ++u) {
+                    const int kk = wave * 32 + u * WAVES * 32;
+                    a[i][u] = live && kk < KC ? __builtin_nontemporal_load(reinterpret_cast<const half8_t *>(wr + (int64_t)kk * kmul)) : (half8_t)(half_t)0;
+                }
+            }
+            __syncthreads();                                                 // the previous chunk's readers are done
+            fill_x_image<ROWS, WAVES * 64, 16>(smem, x, ldx, kc0, cpr, T, tid, (int)((blockIdx.x >> 3) * (cpr + 8)) % (ROWS * cpr));
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < PRE; ++i) {
+                if ((int)(blockIdx.x + i * gridDim.x) >= ntiles) break;
+#pragma unroll
+                for (int u = 0; u < KPW; ++u) {
+                    const int kk = wave * 32 + u * WAVES * 32;
+                    if (kk < KC) {
+                        const int ch = (kk >> 3) + q;
+#pragma unroll
+                        for (int j = 0; j < MT; ++j) {
+                            const int row = j * 16 + r;
+                            const half8_t b = *reinterpret_cast<const half8_t *>(smem + ((int64_t)row * cpr + (ch ^ (r & 7))) * 16);
+                            acc[i][0][j] = mfma16(a[i][u], b, acc[i][0][j]);
+                        }
+                    }
+                }
+            }
+            continue;
+        }
         __syncthreads();                                                     // the previous chunk's readers are done
         fill_x_image<ROWS, WAVES * 64, 8>(smem, x, ldx, kc0, cpr, T, tid);
         __syncthreads();
@@ -108,6 +166,20 @@ __global__ __launch_bounds__(WAVES * 64) void linear_stream_kernel(const half_t 
         for (int w2 = 1; w2 < WAVES; ++w2) s += part[(w2 * NTT * MT + slot) * 64 + lane];
         return s;
     };
+    constexpr int ET = PRE > 0 ? PRE : TMAX;                                 // tiles a workgroup can hold
+    float4_t cs_pre[EPI == SEPI_ROPE ? ET : 1], sn_pre[EPI == SEPI_ROPE ? ET : 1];
+    if (EPI == SEPI_ROPE && wave < MT) {
+        asm volatile("" : "+v"(pos_pre), "+v"(slot_pre));                    // (landed: older than the image fills that have been waited for)
+        const int tph = epi.D / 16, half_d = epi.D / 2;
+#pragma unroll
+        for (int i = 0; i < ET; ++i) {
+            const int tile = blockIdx.x + i * gridDim.x;
+            const int tl = tile < ntiles ? tile : 0;
+            const int jj = (tl % tph) * 8 + (q & 1) * 4;
+            cs_pre[i] = *reinterpret_cast<const float4_t *>(epi.cos_t + pos_pre * half_d + jj);
+            sn_pre[i] = *reinterpret_cast<const float4_t *>(epi.sin_t + pos_pre * half_d + jj);
+        }
+    }
 #pragma unroll
     for (int i = 0; i < TMAX; ++i) {
         const int tile = blockIdx.x + i * gridDim.x;
@@ -120,7 +192,6 @@ __global__ __launch_bounds__(WAVES * 64) void linear_stream_kernel(const half_t 
         __syncthreads();
         for (int j = wave; j < MT; j += WAVES) {
             const int m = j * 16 + r;
-            const int mc = m < T ? m : T - 1;
             if (EPI == SEPI_F16) {
                 const float4_t s = reduce(j);
                 const int n = tile * 16 + q * 4;
@@ -153,8 +224,7 @@ __global__ __launch_bounds__(WAVES * 64) void linear_stream_kernel(const half_t 
                 int col;                                                     // first of the lane's 4 consecutive head columns
                 if (head < epi.H + epi.KVH) {
                     const int jj = c * 8 + (q & 1) * 4;                      // index inside the half dimension
-                    const float4_t cs = *reinterpret_cast<const float4_t *>(epi.cos_t + epi.pos[mc] * half_d + jj);
-                    const float4_t sn = *reinterpret_cast<const float4_t *>(epi.sin_t + epi.pos[mc] * half_d + jj);
+                    const float4_t cs = cs_pre[i < ET ? i : 0], sn = sn_pre[i < ET ? i : 0];   // (requested in front of the tile loop)
 #pragma unroll
                     for (int e = 0; e < 4; ++e)                              // rotary_embedding.rs:36-44
                         h[e] = (q < 2) ? to_half_rn(mul_sub_unfused(v[e], cs[e], pv[e], sn[e]))
@@ -167,7 +237,7 @@ __global__ __launch_bounds__(WAVES * 64) void linear_stream_kernel(const half_t 
                 }
                 if (m < T) {
                     *reinterpret_cast<half4_t *>(y + (int64_t)m * ldq + head * epi.D + col) = h;
-                    const int slot = epi.slots ? epi.slots[m] : -1;
+                    const int slot = epi.slots ? slot_pre : -1;
                     if (slot >= 0 && head >= epi.H) {
                         const bool is_k = head < epi.H + epi.KVH;
                         const int kvh = is_k ? head - epi.H : head - epi.H - epi.KVH;
@@ -212,6 +282,14 @@ static int stream_launch(const half_t *x, int64_t ldx, const half_t *W, int T, i
     const size_t scratch = (size_t)S_WAVES * NTT * MT * 64 * 16;
     if (lds < scratch) lds = scratch;
     const int nwg = ntiles < 256 ? ntiles : 256;
+    if constexpr (NTT == 1) {
+        if (kc <= 8 * S_WAVES * 32 && ntiles <= 2 * nwg) {                   // all weight pieces of a chunk requested in front of the fill (PRE)
+            linear_stream_kernel<NTT, MT, S_WAVES, U, EPI, S_TMAX, 2><<<dim3((unsigned)nwg), dim3(S_WAVES * 64), lds, s>>>(x, ldx, W, T, K, N, kc, ntiles, y, e);
+            hipError_t er = hipGetLastError();
+            if (er != hipSuccess) return nvr::fail(NVR_ERR_HIP, "linear_stream launch failed: %s", hipGetErrorString(er));
+            return 0;
+        }
+    }
     linear_stream_kernel<NTT, MT, S_WAVES, U, EPI, S_TMAX><<<dim3((unsigned)nwg), dim3(S_WAVES * 64), lds, s>>>(x, ldx, W, T, K, N, kc, ntiles, y, e);
     hipError_t er = hipGetLastError();
     if (er != hipSuccess) return nvr::fail(NVR_ERR_HIP, "linear_stream launch failed: %s", hipGetErrorString(er));
@@ -223,7 +301,9 @@ int linear_stream_prepare() {
     const void *fns[] = {
         reinterpret_cast<const void *>(&linear_stream_kernel<1, 1, S_WAVES, 4, SEPI_F16, S_TMAX>), reinterpret_cast<const void *>(&linear_stream_kernel<1, 2, S_WAVES, 4, SEPI_F16, S_TMAX>),
         reinterpret_cast<const void *>(&linear_stream_kernel<2, 1, S_WAVES, 2, SEPI_SILU, S_TMAX>), reinterpret_cast<const void *>(&linear_stream_kernel<2, 2, S_WAVES, 2, SEPI_SILU, S_TMAX>),
-        reinterpret_cast<const void *>(&linear_stream_kernel<1, 1, S_WAVES, 4, SEPI_ROPE, S_TMAX>), reinterpret_cast<const void *>(&linear_stream_kernel<1, 2, S_WAVES, 4, SEPI_ROPE, S_TMAX>)};
+        reinterpret_cast<const void *>(&linear_stream_kernel<1, 1, S_WAVES, 4, SEPI_ROPE, S_TMAX>), reinterpret_cast<const void *>(&linear_stream_kernel<1, 2, S_WAVES, 4, SEPI_ROPE, S_TMAX>),
+        reinterpret_cast<const void *>(&linear_stream_kernel<1, 1, S_WAVES, 4, SEPI_F16, S_TMAX, 2>), reinterpret_cast<const void *>(&linear_stream_kernel<1, 2, S_WAVES, 4, SEPI_F16, S_TMAX, 2>),
+        reinterpret_cast<const void *>(&linear_stream_kernel<1, 1, S_WAVES, 4, SEPI_ROPE, S_TMAX, 2>), reinterpret_cast<const void *>(&linear_stream_kernel<1, 2, S_WAVES, 4, SEPI_ROPE, S_TMAX, 2>)};
     for (const void *f : fns) {
         hipError_t er = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (er != hipSuccess) return nvr::fail(NVR_ERR_HIP, "linear_stream: hipFuncSetAttribute: %s", hipGetErrorString(er));
