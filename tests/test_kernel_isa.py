@@ -22,3 +22,12 @@ def test_gemm_tiled_rope_position_requests_are_not_touched_before_their_wait():
     destination register pair is neither read nor written before the counted wait that covers the request."""
     import check_kernel_isa
     assert check_kernel_isa.check_gemm_tiled(verbose=False) == []
+
+
+@pytest.mark.skipif(not os.path.exists(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")), reason="hipcc not installed")
+def test_attention_merge_arithmetic_has_one_form_in_every_instantiation():
+    """r05: the split-KV merge in its three homes (merge launch, last-arriver workgroup, own-partition workgroup) is promised to be bit-identical; hipcc's
+    per-instantiation choice between fma and multiply + add broke that once (1 output in 10^5, found at 300 sequences).  The source pins both forms; this
+    reads the generated ISA of every attn_rows_kernel / attn_merge_kernel instantiation."""
+    import check_kernel_isa
+    assert check_kernel_isa.check_attention_merge_forms(verbose=False) == []

@@ -72,6 +72,41 @@ def check_flash(verbose=True):
     return bad
 
 
+def check_attention_merge_forms(verbose=True):
+    """r05: the cross-wave merge of attn_rows_kernel and merge_partitions are inlined into kernels whose results are promised to agree bit for bit
+    (partial-writing form + attn_merge_kernel == last-arriver form == own-partition form).  Under -ffp-contract=fast hipcc chooses per INSTANTIATION
+    whether "a += w * b" becomes an fma; the source now spells both out (mul_then_add with contraction off; explicit fmas in merge_partitions).  This
+    check reads the ISA: no fused multiply-add in the cross-wave merge (between the first two workgroup barriers) of every instantiation that does not
+    divide there, and no separate add anywhere in the merge kernel (the merges inlined into attn_rows_kernel share its source and are compared with it at
+    scale by tests/test_engine_gpu.py and tests/test_kernels_gpu.py: block layout makes their region unreliable to cut out of the ISA)."""
+    bad = []
+    for flags in ((),):                                                     # (the bfloat16 build shares every line of it; one compile is ~100 s)
+        text = compile_isa("kernels/attention.hip", flags)
+        ks = kernels(text, "attn_rows_kernel")
+        if len(ks) < 20:
+            bad.append(f"only {len(ks)} attn_rows_kernel instantiations found")
+        for name, blocks in ks.items():
+            m = re.search(r"attn_rows_kernelILi(\d+)ELi(\d+)ELb(\d)ELb(\d)ELi(\d+)ELi(\d+)ELb(\d)ELb(\d)ELb(\d)ELb(\d)E", name)
+            if not m:
+                bad.append(f"{name}: template arguments not recognised"); continue
+            D, G, paged, direct, U, waves, nt, ub, fuse, shm = (int(x) for x in m.groups())
+            flat = [i for b in blocks for i in b]
+            bars = [k for k, i in enumerate(flat) if i.startswith("s_barrier")]
+            fused = ("v_fma_f32", "v_fmac_f32", "v_pk_fma_f32", "v_fmamk_f32", "v_fmaak_f32")
+            if not direct and not (shm and waves == 1) and bars:
+                end = bars[1] if len(bars) > 1 else len(flat)
+                n = sum(1 for i in flat[bars[0]:end] if i.split()[0].startswith(fused))
+                if n:
+                    bad.append(f"{name}: {n} fused multiply-add(s) in the cross-wave merge")
+        for name, blocks in kernels(text, "attn_merge_kernel").items():
+            n = sum(1 for b in blocks for i in b if i.split()[0].startswith(("v_add_f32", "v_pk_add_f32")))
+            if n:
+                bad.append(f"{name}: {n} separate add(s) in the partition merge")
+        if verbose:
+            print(f"attention.hip {' '.join(flags) or 'fp16'}: {len(ks)} attn_rows_kernel instantiations checked")
+    return bad
+
+
 def _vregs(tok):
     """VGPR numbers named by one operand token (v7, v[8:9])"""
     m = re.fullmatch(r"v(\d+)", tok)
@@ -137,7 +172,7 @@ def _check_gemm_tiled_build(text, verbose):
 
 
 if __name__ == "__main__":
-    problems = check_flash() + check_gemm_tiled()
+    problems = check_flash() + check_gemm_tiled() + check_attention_merge_forms()
     for p in problems:
         print("FAIL", p)
     sys.exit(1 if problems else 0)
