@@ -467,20 +467,24 @@ static void launch_cfg(const AttnParams &p, bool paged, bool direct, int64_t nwg
     dim3 grid((unsigned)nwg), block(WAVES * 64);
     constexpr int TPI = 64 / (D / 8) * U;
     const bool ub = paged && p.block_size % TPI == 0 && (p.num_parts == 1 || p.part_size % TPI == 0);
-    if (shm) {                                                            // (paged, split, every query behind the shared prefix: launch_attn)
-        if (ub) attn_rows_kernel<D, G, true, false, U, WAVES, NT, true, false, true><<<grid, block, 0, s>>>(p);
-        else attn_rows_kernel<D, G, true, false, U, WAVES, NT, false, false, true><<<grid, block, 0, s>>>(p);
-        return;
+    if constexpr (WAVES <= 4 && NT) {                                     // (only instantiated where launch_attn can ask for it)
+        if (shm) {                                                        // (paged, split, every query behind the shared prefix: launch_attn)
+            if (ub) attn_rows_kernel<D, G, true, false, U, WAVES, NT, true, false, true><<<grid, block, 0, s>>>(p);
+            else attn_rows_kernel<D, G, true, false, U, WAVES, NT, false, false, true><<<grid, block, 0, s>>>(p);
+            return;
+        }
     }
-    if (ub) {
-        if (direct) attn_rows_kernel<D, G, true, true, U, WAVES, NT, true><<<grid, block, 0, s>>>(p);
-        else if (fuse) attn_rows_kernel<D, G, true, false, U, WAVES, NT, true, true><<<grid, block, 0, s>>>(p);
-        else attn_rows_kernel<D, G, true, false, U, WAVES, NT, true><<<grid, block, 0, s>>>(p);
-    } else if (paged) {
-        if (direct) attn_rows_kernel<D, G, true, true, U, WAVES, NT, false><<<grid, block, 0, s>>>(p);
-        else if (fuse) attn_rows_kernel<D, G, true, false, U, WAVES, NT, false, true><<<grid, block, 0, s>>>(p);
-        else attn_rows_kernel<D, G, true, false, U, WAVES, NT, false><<<grid, block, 0, s>>>(p);
-    } else {
+    if constexpr (NT) {                                                   // the cache through block tables (every paged call site streams: nt loads)
+        if (ub) {
+            if (direct) attn_rows_kernel<D, G, true, true, U, WAVES, NT, true><<<grid, block, 0, s>>>(p);
+            else if (fuse) attn_rows_kernel<D, G, true, false, U, WAVES, NT, true, true><<<grid, block, 0, s>>>(p);
+            else attn_rows_kernel<D, G, true, false, U, WAVES, NT, true><<<grid, block, 0, s>>>(p);
+        } else if (paged) {
+            if (direct) attn_rows_kernel<D, G, true, true, U, WAVES, NT, false><<<grid, block, 0, s>>>(p);
+            else if (fuse) attn_rows_kernel<D, G, true, false, U, WAVES, NT, false, true><<<grid, block, 0, s>>>(p);
+            else attn_rows_kernel<D, G, true, false, U, WAVES, NT, false><<<grid, block, 0, s>>>(p);
+        }
+    } else {                                           // contiguous K / V (prefill): rows re-read from L2, 4-wave workgroups only
         if (direct) attn_rows_kernel<D, G, false, true, U, WAVES, NT, false><<<grid, block, 0, s>>>(p);
         else attn_rows_kernel<D, G, false, false, U, WAVES, NT, false><<<grid, block, 0, s>>>(p);
     }
