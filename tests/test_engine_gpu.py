@@ -1108,3 +1108,13 @@ def test_float32_path_engine_parity(tmp_path, shape):
     I2 = mcfg.intermediate_size // 2
     full = r["oracle"].ranks[0].layers[1]["gate_up"]
     assert np.array_equal(p1.model_runner.weight("layers.1.gate_up"), np.concatenate([full[I2:2 * I2], full[3 * I2:]]))
+
+
+def test_graft_entry_smoke_runs_in_a_fresh_process():
+    """The driver's round-end check, as the driver runs it: __graft_entry__.smoke() in a process of its own — outside this suite's conftest, which creates
+    engines with async_decode = 0 unless a test says otherwise (r05: smoke() read per-step logits from the DEFAULT engine, whose next decode step is
+    already in flight, and nothing in the suite could see it)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke()"], cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0 and "smoke ok" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
