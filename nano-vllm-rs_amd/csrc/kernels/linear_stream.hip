@@ -57,8 +57,8 @@ __global__ __launch_bounds__(WAVES * 64) void linear_stream_kernel(const half_t 
 
     // SEPI_ROPE: the epilogue of a tile was position -> cos / sin row -> rotate and slot -> cache store: two dependent round trips per tile behind the
     // stream (r05: ~4 us per tile of the 19 us launch).  The token's position and cache slot do not depend on the tile: the epilogue waves (wave j
-    // owns tokens 16 j + r) request them HERE (inline asm: a compiler-visible load would be sunk to its use); they have landed when the first image
-    // fill has been waited for (they are older than it).  The cos / sin pieces of ALL the workgroup's tiles are then requested together in front of
+    // owns tokens 16 j + r) request them HERE (inline asm: a compiler-visible load would be sunk to its use; the covering s_waitcnt sits in front of
+    // their first use, at the start of the epilogue).  The cos / sin pieces of ALL the workgroup's tiles are then requested together in front of
     // the first tile's reduction.
     int64_t pos_pre = 0; int slot_pre = -1;
     if (EPI == SEPI_ROPE && wave < MT) {
@@ -169,7 +169,9 @@ __global__ __launch_bounds__(WAVES * 64) void linear_stream_kernel(const half_t 
     constexpr int ET = PRE > 0 ? PRE : TMAX;                                 // tiles a workgroup can hold
     float4_t cs_pre[EPI == SEPI_ROPE ? ET : 1], sn_pre[EPI == SEPI_ROPE ? ET : 1];
     if (EPI == SEPI_ROPE && wave < MT) {
-        asm volatile("" : "+v"(pos_pre), "+v"(slot_pre));                    // (landed: older than the image fills that have been waited for)
+        // (landed long ago — they are older than the image fills that have been waited for — but the compiler cannot know that of an asm load: the
+        //  wait is written down here, where nothing is in flight and it costs nothing, and the values are tied to it)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(pos_pre), "+v"(slot_pre) : : "memory");
         const int tph = epi.D / 16, half_d = epi.D / 2;
 #pragma unroll
         for (int i = 0; i < ET; ++i) {
