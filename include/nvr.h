@@ -438,7 +438,8 @@ typedef uint16_t nvr_half;
  * kernels for the CALLING THREAD (thread-local, like nvr_last_error); "float32" (r04) selects the ops of the reference-precision path — the
  * nvr_half pointers of nvr_embedding, nvr_rmsnorm, nvr_add_rmsnorm, nvr_linear, nvr_rope_store_kv, nvr_qk_norm_rope_store_kv, nvr_silu_and_mul,
  * nvr_select_last_tokens, nvr_attn_prefill_varlen / _paged, nvr_paged_attn_decode, nvr_fill_weight (unrounded values) and nvr_fill_const then
- * address f32 elements; the ops that exist only as fused 16-bit kernels answer NVR_ERR_UNSUPPORTED; anything else: NVR_ERR_UNSUPPORTED.
+ * address f32 elements; nvr_linear_qkv_rope_store and nvr_linear_silu_mul exist there for decode-sized steps (1..8 rows: r05, the bits of their parts;
+ * NVR_ERR_UNSUPPORTED for more rows); the ops that exist only as fused 16-bit kernels answer NVR_ERR_UNSUPPORTED; anything else: NVR_ERR_UNSUPPORTED.
  * Runners and engines take their type from nvr_config.dtype and are not affected. */
 NVR_API int nvr_ops_set_dtype(const char *dtype);
 NVR_API const char *nvr_ops_dtype(void);

@@ -288,6 +288,93 @@ int linear(const float *x, int64_t ldx, const float *W, int64_t T, int64_t K, in
     return 0;
 }
 
+// x1 c - x2 s and x2 c + x1 s with every product rounded on its own (rotary_embedding.rs:36-44 as the oracle evaluates it; the same bits in the two kernels
+// below, whatever hipcc's per-kernel choice between fma and multiply + add would have been: see attention.hip mul_then_add)
+__device__ __forceinline__ float rot_sub(float a, float b, float c, float d) {
+#pragma clang fp contract(off)
+    const float x = a * b, y = c * d;
+    return x - y;
+}
+__device__ __forceinline__ float rot_add(float a, float b, float c, float d) {
+#pragma clang fp contract(off)
+    const float x = a * b, y = c * d;
+    return x + y;
+}
+// qkv projection + RoPE + KV store of a decode-sized step in one launch (linear.rs:354-356, rotary_embedding.rs:23-48, attention.rs:150-174; models
+// without q / k head norms): wave w forms columns j and D/2 + j of one head — the two halves of a rotation pair — with gemv_kernel's loads and FMA
+// chains, rotates them (value heads pass through) and writes the qkv row and the cache row: the bits of gemv_kernel + rope_store_kernel.
+template <int TT>
+__global__ __launch_bounds__(256) void gemv_rope_kernel(const float *__restrict__ x, int64_t ldx, const float *__restrict__ W, int T, int K, int H, int KVH, int D,
+                                                        const float *__restrict__ bias, const int64_t *__restrict__ pos, const int32_t *__restrict__ slots,
+                                                        const float *__restrict__ cos_t, const float *__restrict__ sin_t, float *__restrict__ qkv,
+                                                        float *__restrict__ kc, float *__restrict__ vc) {
+    const int half = D / 2, N = (H + 2 * KVH) * D;
+    const int pair = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (pair >= N / 2) return;
+    const int hd = pair / half, j = pair - hd * half;
+    const int n1 = hd * D + j, n2 = n1 + half;
+    // position / slot of every row: requested with the weights, used after the reduction
+    int64_t p[TT]; int sl[TT];
+#pragma unroll
+    for (int t = 0; t < TT; ++t) { p[t] = pos[t < T ? t : 0]; sl[t] = slots ? slots[t < T ? t : 0] : -1; }
+    const float4 *g4 = reinterpret_cast<const float4 *>(W + (int64_t)n1 * K), *u4 = reinterpret_cast<const float4 *>(W + (int64_t)n2 * K);
+    float a1[TT], a2[TT];
+#pragma unroll
+    for (int t = 0; t < TT; ++t) a1[t] = a2[t] = 0.f;
+    const int n4 = K / 4;
+    for (int k0 = lane; k0 < n4; k0 += 256) {
+        float4 w1[4], w2[4], a[TT][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k4 = min(k0 + 64 * u, n4 - 1);
+            w1[u] = g4[k4]; w2[u] = u4[k4];
+#pragma unroll
+            for (int t = 0; t < TT; ++t) a[t][u] = reinterpret_cast<const float4 *>(x + (int64_t)(t < T ? t : 0) * ldx)[k4];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (k0 + 64 * u < n4) {
+#pragma unroll
+                for (int t = 0; t < TT; ++t)
+                    if (t < T) {
+                        a1[t] = fmaf(a[t][u].x, w1[u].x, fmaf(a[t][u].y, w1[u].y, fmaf(a[t][u].z, w1[u].z, fmaf(a[t][u].w, w1[u].w, a1[t]))));
+                        a2[t] = fmaf(a[t][u].x, w2[u].x, fmaf(a[t][u].y, w2[u].y, fmaf(a[t][u].z, w2[u].z, fmaf(a[t][u].w, w2[u].w, a2[t]))));
+                    }
+            }
+    }
+    const bool is_k = hd >= H && hd < H + KVH, is_v = hd >= H + KVH;
+#pragma unroll
+    for (int t = 0; t < TT; ++t) {
+        float x1 = wsum(a1[t]), x2 = wsum(a2[t]);
+        if (lane == 0 && t < T) {
+            if (bias) { x1 = x1 + bias[n1]; x2 = x2 + bias[n2]; }
+            float o1 = x1, o2 = x2;
+            if (!is_v) {
+                const float c = cos_t[p[t] * half + j], sn = sin_t[p[t] * half + j];
+                o1 = rot_sub(x1, c, x2, sn); o2 = rot_add(x2, c, x1, sn);
+            }
+            float *row = qkv + (int64_t)t * N;
+            row[n1] = o1; row[n2] = o2;
+            if (hd >= H && sl[t] >= 0) {
+                float *dst = (is_k ? kc : vc) + ((int64_t)sl[t] * KVH + (is_k ? hd - H : hd - H - KVH)) * D;
+                dst[j] = o1; dst[half + j] = o2;
+            }
+        }
+    }
+}
+bool linear_qkv_rope_ok(int64_t T, int64_t K, int64_t D, int64_t ldx) { return T >= 1 && T <= 8 && K % 4 == 0 && ldx % 4 == 0 && D % 2 == 0; }
+int linear_qkv_rope_store(const float *x, int64_t ldx, const float *W, int64_t T, int64_t K, int64_t H, int64_t KVH, int64_t D, const float *bias,
+                          const int64_t *pos, const int32_t *slots, const float *cos_t, const float *sin_t, float *qkv, float *kc, float *vc, hipStream_t s) {
+    if (!linear_qkv_rope_ok(T, K, D, ldx)) return nvr::fail(NVR_ERR_UNSUPPORTED, "f32 linear_qkv_rope_store: T=%ld K=%ld D=%ld (decode-sized steps)", (long)T, (long)K, (long)D);
+    const int64_t pairs = (H + 2 * KVH) * D / 2;
+    const dim3 grid((unsigned)((pairs + 3) / 4));
+#define NVR_GR(TT_) gemv_rope_kernel<TT_><<<grid, dim3(256), 0, s>>>(x, ldx, W, (int)T, (int)K, (int)H, (int)KVH, (int)D, bias, pos, slots, cos_t, sin_t, qkv, kc, vc)
+    if (T == 1) NVR_GR(1); else if (T <= 4) NVR_GR(4); else NVR_GR(8);
+#undef NVR_GR
+    F32_LAUNCH_CHECK("f32 gemv + rope + store");
+    return 0;
+}
+
 // ---------------------------------------------------------------- [q/k head norm,] RoPE, KV store: one workgroup per token, one wave per head in turn
 __global__ __launch_bounds__(256) void rope_store_kernel(float *__restrict__ qkv, const int64_t *__restrict__ pos, const int32_t *__restrict__ slots, int H,
                                                          int KVH, int D, const float *__restrict__ cos_t, const float *__restrict__ sin_t,
@@ -316,7 +403,7 @@ __global__ __launch_bounds__(256) void rope_store_kernel(float *__restrict__ qkv
             float x1 = x[j], x2 = x[half + j];
             if (nw) { x1 = x1 / rms * nw[j]; x2 = x2 / rms * nw[half + j]; }
             const float c = cos_t[p * half + j], sn = sin_t[p * half + j];
-            const float o1 = x1 * c - x2 * sn, o2 = x2 * c + x1 * sn;   // rotary_embedding.rs:36-44
+            const float o1 = rot_sub(x1, c, x2, sn), o2 = rot_add(x2, c, x1, sn);   // rotary_embedding.rs:36-44
             x[j] = o1; x[half + j] = o2;
             if (dst) { dst[j] = o1; dst[half + j] = o2; }
         }

@@ -303,9 +303,14 @@ int nvr_model_runner::forward_f32(int64_t T, int64_t B, bool is_prefill, int64_t
     RC(kf::rmsnorm(fh, F(L > 0 ? layers[0].ln1 : norm), mc.rms_norm_eps, T, Hd, fn, st));
     for (int64_t l = 0; l < L; ++l) {
         const Layer &w = layers[l];
-        RC(kf::linear(fn, Hd, F(w.qkv), T, Hd, QKV, w.qkv_b ? F(w.qkv_b) : nullptr, fq, st));
-        RC(kf::rope_store_kv(fq, pos, slots, T, H, KVH, D, cos_t, sin_t, F(k_cache(l)), F(v_cache(l)), w.q_norm ? F(w.q_norm) : nullptr,
-                             w.k_norm ? F(w.k_norm) : nullptr, mc.rms_norm_eps, st));
+        if (!w.q_norm && !w.k_norm && kf::linear_qkv_rope_ok(T, Hd, D, Hd)) {                      // decode-sized: K3..K6 in one launch
+            RC(kf::linear_qkv_rope_store(fn, Hd, F(w.qkv), T, Hd, H, KVH, D, w.qkv_b ? F(w.qkv_b) : nullptr, pos, slots, cos_t, sin_t, fq,
+                                         F(k_cache(l)), F(v_cache(l)), st));
+        } else {
+            RC(kf::linear(fn, Hd, F(w.qkv), T, Hd, QKV, w.qkv_b ? F(w.qkv_b) : nullptr, fq, st));
+            RC(kf::rope_store_kv(fq, pos, slots, T, H, KVH, D, cos_t, sin_t, F(k_cache(l)), F(v_cache(l)), w.q_norm ? F(w.q_norm) : nullptr,
+                                 w.k_norm ? F(w.k_norm) : nullptr, mc.rms_norm_eps, st));
+        }
         nvr::kt::AttnArgsF a{};
         a.q = fq; a.ldq = QKV; a.ctx_lens = ctx; a.nq = (int32_t)T; a.H = (int32_t)H; a.KVH = (int32_t)KVH; a.D = (int32_t)D; a.scale = scale;
         a.max_ctx = (int32_t)max_ctx; a.out = fa;

@@ -561,13 +561,19 @@ int nvr_linear_add_residual(const nvr_half *x, int64_t ldx, const nvr_half *W, i
 }
 int nvr_decode_splitk_slices(int64_t T, int64_t K, int64_t N) { return k::decode_splitk_slices(T, K, N); }
 int nvr_linear_silu_mul(const nvr_half *x, int64_t ldx, const nvr_half *W, int64_t T, int64_t K, int64_t I, nvr_half *out, void *s) {
-    NO_F32("nvr_linear_silu_mul");
+    if (g_ops_f32) {                                                    // float32: the decode-sized form exists (gemv + SiluAndMul in one launch)
+        if (!nvr::kf::linear_silu_ok(T, K, ldx)) return nvr::fail(NVR_ERR_UNSUPPORTED, "nvr_linear_silu_mul: float32 ops fuse decode-sized steps only (1..8 rows); nvr_linear + nvr_silu_and_mul otherwise");
+        return nvr::kf::linear_silu_mul(FP(x), ldx, FP(W), T, K, I, nullptr, FP(out), (hipStream_t)s);
+    }
     return KO(linear_silu_mul(x, ldx, W, T, K, I, out, (hipStream_t)s));
 }
 int nvr_linear_qkv_rope_store(const nvr_half *x, int64_t ldx, const nvr_half *W, int64_t T, int64_t K, int64_t H, int64_t KVH,
                               int64_t D, const int64_t *pos, const int32_t *slots, const float *c, const float *sn,
                               nvr_half *qkv, nvr_half *kc, nvr_half *vc, void *s) {
-    NO_F32("nvr_linear_qkv_rope_store");
+    if (g_ops_f32) {                                                    // float32: the decode-sized form exists (gemv + RoPE + KV store in one launch)
+        if (!nvr::kf::linear_qkv_rope_ok(T, K, D, ldx)) return nvr::fail(NVR_ERR_UNSUPPORTED, "nvr_linear_qkv_rope_store: float32 ops fuse decode-sized steps only (1..8 rows); nvr_linear + nvr_rope_store_kv otherwise");
+        return nvr::kf::linear_qkv_rope_store(FP(x), ldx, FP(W), T, K, H, KVH, D, nullptr, pos, slots, c, sn, FP(qkv), FP(kc), FP(vc), (hipStream_t)s);
+    }
     return KO(linear_qkv_rope_store(x, ldx, W, T, K, H, KVH, D, pos, slots, c, sn, qkv, kc, vc, (hipStream_t)s));
 }
 int nvr_rope_store_kv(nvr_half *qkv, const int64_t *pos, const int32_t *slots, int64_t T, int64_t H, int64_t KVH, int64_t D,

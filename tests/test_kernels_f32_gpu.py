@@ -134,6 +134,54 @@ def C_byref(x):
     return ctypes.byref(x)
 
 
+@pytest.mark.parametrize("T,H,KVH,D,K", [(1, 16, 8, 128, 1024), (3, 4, 2, 64, 256), (8, 8, 1, 128, 512)])
+def test_decode_sized_fused_forms_equal_their_parts_bit_for_bit(T, H, KVH, D, K):
+    """r05: the float32 path fuses what a decode-sized step (1..8 rows) launches back to back — the qkv projection with RoPE + KV store
+    (linear.rs:354-356, rotary_embedding.rs:23-48, attention.rs:150-174) and the gate_up projection with SiluAndMul (linear.rs:437-439,
+    activation.rs:46-63).  Same loads, same FMA chains, the rotation written with contraction off in both kernels: the fused launches give the BITS of
+    their parts, and the parts are checked against float64 / the oracle."""
+    rng = np.random.default_rng(T * 100 + D)
+    N = (H + 2 * KVH) * D
+    x = rng.standard_normal((T, K)).astype(F32); W = (rng.standard_normal((N, K)) * 0.05).astype(F32)
+    pos = rng.integers(0, 60, T).astype(np.int64); slots = (np.arange(T) * 3 + 1).astype(np.int32); slots[-1] = -1 if T > 1 else slots[-1]
+    cos, sin = oracle.rope_table(D, 64, 10000.0)
+    d_x, d_W, d_pos, d_slots, d_cos, d_sin = dev(x), dev(W), dev(pos), dev(slots), dev(cos), dev(sin)
+    nslots = int(T * 3 + 2)
+
+    def caches():
+        kc, vc = nvr.DeviceBuffer(nslots * KVH * D * 4), nvr.DeviceBuffer(nslots * KVH * D * 4)
+        nvr.check(nvr.lib().nvr_fill_const(kc.ptr, nslots * KVH * D, 0.0, None)); nvr.check(nvr.lib().nvr_fill_const(vc.ptr, nslots * KVH * D, 0.0, None))
+        return kc, vc
+    ya, kca, vca = nvr.DeviceBuffer(T * N * 4), *caches()
+    nvr.check(nvr.lib().nvr_linear(d_x.ptr, K, d_W.ptr, T, K, N, ya.ptr, 1, None))
+    nvr.check(nvr.lib().nvr_rope_store_kv(ya.ptr, d_pos.ptr, d_slots.ptr, T, H, KVH, D, d_cos.ptr, d_sin.ptr, kca.ptr, vca.ptr, None))
+    yb, kcb, vcb = nvr.DeviceBuffer(T * N * 4), *caches()
+    nvr.check(nvr.lib().nvr_linear_qkv_rope_store(d_x.ptr, K, d_W.ptr, T, K, H, KVH, D, d_pos.ptr, d_slots.ptr, d_cos.ptr, d_sin.ptr, yb.ptr, kcb.ptr, vcb.ptr, None))
+    a, b = ya.to_numpy((T, N), np.uint32), yb.to_numpy((T, N), np.uint32)
+    assert np.array_equal(a, b), "qkv + RoPE: fused launch differs from gemv followed by rope_store"
+    assert np.array_equal(kca.to_numpy((nslots, KVH * D), np.uint32), kcb.to_numpy((nslots, KVH * D), np.uint32))
+    assert np.array_equal(vca.to_numpy((nslots, KVH * D), np.uint32), vcb.to_numpy((nslots, KVH * D), np.uint32))
+    ref = (x.astype(np.float64) @ W.astype(np.float64).T).astype(F32)
+    q = oracle.rope_apply(ref[:, :H * D].reshape(T, H, D), pos, cos, sin)
+    close(yb.to_numpy((T, N), F32)[:, :H * D].reshape(T, H, D), q, rtol=3e-5, atol=3e-5, what="fused qkv + RoPE vs float64 GEMM + oracle rotation")
+    kcn = kcb.to_numpy((nslots, KVH, D), F32)
+    k = oracle.rope_apply(ref[:, H * D:(H + KVH) * D].reshape(T, KVH, D), pos, cos, sin)
+    live = slots >= 0
+    close(kcn[slots[live]], k[live], rtol=3e-5, atol=3e-5, what="cache rows of the fused launch")
+    assert not kcn[np.setdiff1d(np.arange(nslots), slots[live])].any()                                  # nothing else written (the row with slot -1 included)
+    # gate_up + SiluAndMul
+    I = 3 * D
+    Wg = (rng.standard_normal((2 * I, K)) * 0.05).astype(F32); d_Wg = dev(Wg)
+    gu, act_a, act_b = nvr.DeviceBuffer(T * 2 * I * 4), nvr.DeviceBuffer(T * I * 4), nvr.DeviceBuffer(T * I * 4)
+    nvr.check(nvr.lib().nvr_linear(d_x.ptr, K, d_Wg.ptr, T, K, 2 * I, gu.ptr, 1, None))
+    nvr.check(nvr.lib().nvr_silu_and_mul(gu.ptr, T, I, act_a.ptr, None))
+    nvr.check(nvr.lib().nvr_linear_silu_mul(d_x.ptr, K, d_Wg.ptr, T, K, I, act_b.ptr, None))
+    assert np.array_equal(act_a.to_numpy((T, I), np.uint32), act_b.to_numpy((T, I), np.uint32)), "gate_up + SiluAndMul: fused launch differs from its parts"
+    # steps that are not decode-sized keep the unfused parts
+    assert nvr.lib().nvr_linear_silu_mul(d_x.ptr, K, d_Wg.ptr, 9, K, I, act_b.ptr, None) == -10
+    assert nvr.lib().nvr_linear_qkv_rope_store(d_x.ptr, K, d_W.ptr, 9, K, H, KVH, D, d_pos.ptr, d_slots.ptr, d_cos.ptr, d_sin.ptr, yb.ptr, kcb.ptr, vcb.ptr, None) == -10
+
+
 def test_fused_16_bit_ops_say_so_and_weights_are_unrounded():
     assert nvr.lib().nvr_linear_silu_mul(None, 0, None, 0, 0, 0, None, None) == -10
     out = nvr.DeviceBuffer(8 * 16 * 4)
