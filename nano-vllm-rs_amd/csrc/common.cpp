@@ -29,6 +29,7 @@ Env Env::read() {
     e.tp_force_comm = flag("NVR_TP_FORCE_COMM", false);
     e.tp_graph = flag("NVR_TP_GRAPH", true);
     e.attn_fused_merge = flag("NVR_ATTN_FUSED_MERGE", true);
+    e.f32_fused_norm = flag("NVR_F32_FUSED_NORM", true);
     e.max_graphs = num("NVR_MAX_GRAPHS", 256, 1, 1 << 20);
     e.p2p_timeout_ms = num("NVR_P2P_TIMEOUT_MS", 20000, 1, 3600000);
     return e;

@@ -20,6 +20,7 @@ struct Env {
     bool tp_no_comm = false;      // NVR_TP_NO_COMM=1     one tensor-parallel rank's compute without its collectives (profiling)
     bool tp_force_comm = false;   // NVR_TP_FORCE_COMM=1  enqueue the RCCL collectives even with one rank (tests on a 1-GPU box)
     bool tp_graph = true;         // NVR_TP_GRAPH=0       tensor-parallel decode steps run eagerly
+    bool f32_fused_norm = true;   // NVR_F32_FUSED_NORM=0 float32 decode-sized steps keep the add + RMSNorm launch in front of their GEMVs (bit-identical; A/B, tests)
     bool attn_fused_merge = true; // NVR_ATTN_FUSED_MERGE=0 split-KV decode attention keeps its merge launch (bit-identical; A/B, tests)
     int max_graphs = 256;         // NVR_MAX_GRAPHS=n     captured decode graphs kept before the cache is flushed (test hook)
     int p2p_timeout_ms = 20000;   // NVR_P2P_TIMEOUT_MS=n how long a peer-to-peer collective waits for a peer before it gives up

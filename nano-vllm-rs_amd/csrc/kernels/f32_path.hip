@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(float *__restrict__ h, con
     for (int c = threadIdx.x; c < Hd; c += 256) {
         float v = hr[c];
         if (ADD) { v = v + yr[c]; hr[c] = v; }                       // h <- h + y (qwen3.rs:382,389)
-        ss += v * v;
+        ss = fmaf(v, v, ss);                                         // (pinned: add_norm_rows_to_lds below promises these bits)
     }
     ss = block_reduce<false>(ss, sm, 4);
     const float rms = sqrtf(ss / (float)Hd + eps);
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void sum_ranks_rmsnorm_kernel(float *__restric
         for (int r = 1; r < nranks; ++r) y = y + pr[(int64_t)r * stride + c];
         const float v = hr[c] + y;
         hr[c] = v;
-        ss += v * v;
+        ss = fmaf(v, v, ss);
     }
     ss = block_reduce<false>(ss, sm, 4);
     const float rms = sqrtf(ss / (float)Hd + eps);
@@ -183,6 +183,46 @@ __global__ __launch_bounds__(256) void linear_kernel(const float *__restrict__ x
             if (t < T && n < N) y[(int64_t)t * N + n] = bias ? acc[i][j] + bias[n] : acc[i][j];
         }
 }
+// h + y and its RMSNorm for the T <= TT rows of a decode-sized step, INTO LDS (xs [TT][K]) — what rmsnorm_kernel<true> writes to memory, with its
+// arithmetic (a thread's columns c = tid, tid + 256, ..; fma chain of squares; wave sums, then the four waves in order; v / rms * w): the same bits.
+// Every workgroup of a consumer GEMV does this for itself (K floats per row: nothing beside the weight rows it streams), so the add + norm launch in
+// front of the GEMV disappears; h_out (given to ONE workgroup) receives the new residual stream — a second buffer, the others are still reading h_in.
+template <int TT>
+__device__ __forceinline__ void add_norm_rows_to_lds(const float *__restrict__ h_in, const float *__restrict__ y, const float *__restrict__ nw, float eps, int T,
+                                                     int K, float *__restrict__ h_out, float *xs, float *sm) {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    float ss[TT];
+#pragma unroll
+    for (int t = 0; t < TT; ++t) ss[t] = 0.f;
+    for (int c = tid; c < K; c += 256) {
+        float hv[TT], yv[TT];
+#pragma unroll
+        for (int t = 0; t < TT; ++t) { const int64_t o = (int64_t)(t < T ? t : 0) * K + c; hv[t] = h_in[o]; yv[t] = y[o]; }
+#pragma unroll
+        for (int t = 0; t < TT; ++t) { const float v = hv[t] + yv[t]; xs[t * K + c] = v; ss[t] = fmaf(v, v, ss[t]); }
+    }
+#pragma unroll
+    for (int t = 0; t < TT; ++t) { const float v = wsum(ss[t]); if (lane == 0) sm[t * 4 + wave] = v; }
+    __syncthreads();
+    float rms[TT];
+#pragma unroll
+    for (int t = 0; t < TT; ++t) {
+        float r = sm[t * 4];
+        for (int i = 1; i < 4; ++i) r = r + sm[t * 4 + i];
+        rms[t] = sqrtf(r / (float)K + eps);
+    }
+    for (int c = tid; c < K; c += 256) {
+        const float w = nw[c];
+#pragma unroll
+        for (int t = 0; t < TT; ++t)
+            if (t < T) {
+                const float v = xs[t * K + c];
+                if (h_out) h_out[(int64_t)t * K + c] = v;
+                xs[t * K + c] = v / rms[t] * w;
+            }
+    }
+    __syncthreads();
+}
 // decode-sized steps (T <= 8 rows): one wave per output column, the lanes stride over k with 16-byte loads (the weight row is read once, coalesced:
 // this is the f32 path's memory-bound regime), the T partial sums meet by a wave reduction
 template <int TT>
@@ -224,22 +264,33 @@ __device__ __forceinline__ float silu_mul_one(float g, float u) { return g / (1.
 // gate_up projection + SiluAndMul of a decode-sized step in one launch (activation.rs:46-63 behind linear.rs:437-439): wave n forms gate column n and
 // up column I + n of every row with gemv_kernel's loads and FMA chains, then act = silu(g) * u as silu_mul_kernel writes it — the same bits as the two
 // launches (bias: added to g and u first, like Linear::forward)
-template <int TT>
+// NORM: x = RMSNorm(h_in + y) formed by the workgroup itself (add_norm_rows_to_lds); workgroup 0 writes the new residual stream to h_out
+template <int TT, bool NORM = false>
 __global__ __launch_bounds__(256) void gemv_silu_kernel(const float *__restrict__ x, int64_t ldx, const float *__restrict__ W, int T, int K, int I,
-                                                        const float *__restrict__ bias, float *__restrict__ act) {
-    const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (n >= I) return;
+                                                        const float *__restrict__ bias, float *__restrict__ act, const float *__restrict__ h_in = nullptr,
+                                                        const float *__restrict__ y = nullptr, const float *__restrict__ nw = nullptr, float eps = 0.f,
+                                                        float *__restrict__ h_out = nullptr) {
+    extern __shared__ float xs[];                                       // NORM: [TT][K] normalised rows, then 4 * TT of reduction scratch
+    const int n_ = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int n = n_ < I ? n_ : I - 1;                                  // (a wave past the end still helps with the norm)
     const float4 *g4 = reinterpret_cast<const float4 *>(W + (int64_t)n * K), *u4 = reinterpret_cast<const float4 *>(W + (int64_t)(I + n) * K);
+    const int n4 = K / 4;
+    float4 wg0[4], wu0[4];                                              // NORM: the first weight pieces are requested in front of the norm (they depend on nothing)
+    if (NORM) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int k4 = min(lane + 64 * u, n4 - 1); wg0[u] = g4[k4]; wu0[u] = u4[k4]; }
+        add_norm_rows_to_lds<TT>(h_in, y, nw, eps, T, K, blockIdx.x == 0 ? h_out : nullptr, xs, xs + TT * K); x = xs; ldx = K;
+    }
+    if (n_ >= I) return;
     float ag[TT], au[TT];
 #pragma unroll
     for (int t = 0; t < TT; ++t) ag[t] = au[t] = 0.f;
-    const int n4 = K / 4;
     for (int k0 = lane; k0 < n4; k0 += 256) {
         float4 wg[4], wu[4], a[TT][4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int k4 = min(k0 + 64 * u, n4 - 1);
-            wg[u] = g4[k4]; wu[u] = u4[k4];
+            if (NORM && k0 == lane) { wg[u] = wg0[u]; wu[u] = wu0[u]; } else { wg[u] = g4[k4]; wu[u] = u4[k4]; }
 #pragma unroll
             for (int t = 0; t < TT; ++t) a[t][u] = reinterpret_cast<const float4 *>(x + (int64_t)(t < T ? t : 0) * ldx)[k4];
         }
@@ -273,6 +324,20 @@ int linear_silu_mul(const float *x, int64_t ldx, const float *W, int64_t T, int6
     F32_LAUNCH_CHECK("f32 gemv + silu");
     return 0;
 }
+// rows of the launch's template instance (1 / 4 / 8) and whether their normalised image fits the LDS a kernel gets without an opt-in
+static int gemv_rows(int64_t T) { return T == 1 ? 1 : T <= 4 ? 4 : 8; }
+bool fused_norm_ok(int64_t T, int64_t K) { return T >= 1 && T <= 8 && K % 4 == 0 && (size_t)gemv_rows(T) * (K + 4) * 4 <= 48 * 1024; }
+int add_norm_linear_silu_mul(const float *h_in, const float *y, const float *nw, float eps, float *h_out, const float *W, int64_t T, int64_t K, int64_t I,
+                             const float *bias, float *act, hipStream_t s) {
+    if (!fused_norm_ok(T, K)) return nvr::fail(NVR_ERR_UNSUPPORTED, "f32 add + norm + gate_up + silu: T=%ld K=%ld", (long)T, (long)K);
+    const dim3 grid((unsigned)((I + 3) / 4));
+    const size_t lds = (size_t)gemv_rows(T) * (K + 4) * 4;
+#define NVR_GS(TT_) gemv_silu_kernel<TT_, true><<<grid, dim3(256), lds, s>>>(nullptr, 0, W, (int)T, (int)K, (int)I, bias, act, h_in, y, nw, eps, h_out)
+    if (T == 1) NVR_GS(1); else if (T <= 4) NVR_GS(4); else NVR_GS(8);
+#undef NVR_GS
+    F32_LAUNCH_CHECK("f32 add + norm + gemv + silu");
+    return 0;
+}
 int linear(const float *x, int64_t ldx, const float *W, int64_t T, int64_t K, int64_t N, const float *bias, float *y, hipStream_t s) {
     if (T == 0 || N == 0) return 0;
     if (T <= 8 && K % 4 == 0 && ldx % 4 == 0) {
@@ -303,14 +368,17 @@ __device__ __forceinline__ float rot_add(float a, float b, float c, float d) {
 // qkv projection + RoPE + KV store of a decode-sized step in one launch (linear.rs:354-356, rotary_embedding.rs:23-48, attention.rs:150-174; models
 // without q / k head norms): wave w forms columns j and D/2 + j of one head — the two halves of a rotation pair — with gemv_kernel's loads and FMA
 // chains, rotates them (value heads pass through) and writes the qkv row and the cache row: the bits of gemv_kernel + rope_store_kernel.
-template <int TT>
+template <int TT, bool NORM = false>
 __global__ __launch_bounds__(256) void gemv_rope_kernel(const float *__restrict__ x, int64_t ldx, const float *__restrict__ W, int T, int K, int H, int KVH, int D,
                                                         const float *__restrict__ bias, const int64_t *__restrict__ pos, const int32_t *__restrict__ slots,
                                                         const float *__restrict__ cos_t, const float *__restrict__ sin_t, float *__restrict__ qkv,
-                                                        float *__restrict__ kc, float *__restrict__ vc) {
+                                                        float *__restrict__ kc, float *__restrict__ vc, const float *__restrict__ h_in = nullptr,
+                                                        const float *__restrict__ y = nullptr, const float *__restrict__ nw = nullptr, float eps = 0.f,
+                                                        float *__restrict__ h_out = nullptr) {
+    extern __shared__ float xs[];                                       // NORM: as gemv_silu_kernel
     const int half = D / 2, N = (H + 2 * KVH) * D;
-    const int pair = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (pair >= N / 2) return;
+    const int pair_ = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int pair = pair_ < N / 2 ? pair_ : N / 2 - 1;
     const int hd = pair / half, j = pair - hd * half;
     const int n1 = hd * D + j, n2 = n1 + half;
     // position / slot of every row: requested with the weights, used after the reduction
@@ -318,16 +386,23 @@ __global__ __launch_bounds__(256) void gemv_rope_kernel(const float *__restrict_
 #pragma unroll
     for (int t = 0; t < TT; ++t) { p[t] = pos[t < T ? t : 0]; sl[t] = slots ? slots[t < T ? t : 0] : -1; }
     const float4 *g4 = reinterpret_cast<const float4 *>(W + (int64_t)n1 * K), *u4 = reinterpret_cast<const float4 *>(W + (int64_t)n2 * K);
+    const int n4 = K / 4;
+    float4 w10[4], w20[4];
+    if (NORM) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int k4 = min(lane + 64 * u, n4 - 1); w10[u] = g4[k4]; w20[u] = u4[k4]; }
+        add_norm_rows_to_lds<TT>(h_in, y, nw, eps, T, K, blockIdx.x == 0 ? h_out : nullptr, xs, xs + TT * K); x = xs; ldx = K;
+    }
+    if (pair_ >= N / 2) return;
     float a1[TT], a2[TT];
 #pragma unroll
     for (int t = 0; t < TT; ++t) a1[t] = a2[t] = 0.f;
-    const int n4 = K / 4;
     for (int k0 = lane; k0 < n4; k0 += 256) {
         float4 w1[4], w2[4], a[TT][4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int k4 = min(k0 + 64 * u, n4 - 1);
-            w1[u] = g4[k4]; w2[u] = u4[k4];
+            if (NORM && k0 == lane) { w1[u] = w10[u]; w2[u] = w20[u]; } else { w1[u] = g4[k4]; w2[u] = u4[k4]; }
 #pragma unroll
             for (int t = 0; t < TT; ++t) a[t][u] = reinterpret_cast<const float4 *>(x + (int64_t)(t < T ? t : 0) * ldx)[k4];
         }
@@ -372,6 +447,21 @@ int linear_qkv_rope_store(const float *x, int64_t ldx, const float *W, int64_t T
     if (T == 1) NVR_GR(1); else if (T <= 4) NVR_GR(4); else NVR_GR(8);
 #undef NVR_GR
     F32_LAUNCH_CHECK("f32 gemv + rope + store");
+    return 0;
+}
+
+int add_norm_linear_qkv_rope_store(const float *h_in, const float *y, const float *nw, float eps, float *h_out, const float *W, int64_t T, int64_t K, int64_t H,
+                                   int64_t KVH, int64_t D, const float *bias, const int64_t *pos, const int32_t *slots, const float *cos_t, const float *sin_t,
+                                   float *qkv, float *kc, float *vc, hipStream_t s) {
+    if (!fused_norm_ok(T, K) || D % 2) return nvr::fail(NVR_ERR_UNSUPPORTED, "f32 add + norm + qkv + rope: T=%ld K=%ld D=%ld", (long)T, (long)K, (long)D);
+    const int64_t pairs = (H + 2 * KVH) * D / 2;
+    const dim3 grid((unsigned)((pairs + 3) / 4));
+    const size_t lds = (size_t)gemv_rows(T) * (K + 4) * 4;
+#define NVR_GR(TT_) gemv_rope_kernel<TT_, true><<<grid, dim3(256), lds, s>>>(nullptr, 0, W, (int)T, (int)K, (int)H, (int)KVH, (int)D, bias, pos, slots, cos_t, sin_t, \
+                                                                            qkv, kc, vc, h_in, y, nw, eps, h_out)
+    if (T == 1) NVR_GR(1); else if (T <= 4) NVR_GR(4); else NVR_GR(8);
+#undef NVR_GR
+    F32_LAUNCH_CHECK("f32 add + norm + gemv + rope + store");
     return 0;
 }
 

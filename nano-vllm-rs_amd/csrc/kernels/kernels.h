@@ -85,6 +85,14 @@ int silu_and_mul(const float *gu, int64_t T, int64_t I, float *out, hipStream_t 
 bool linear_qkv_rope_ok(int64_t T, int64_t K, int64_t D, int64_t ldx);   // decode-sized steps, no q / k head norms: qkv projection + RoPE + KV store in one launch (the same bits as the two)
 int linear_qkv_rope_store(const float *x, int64_t ldx, const float *W, int64_t T, int64_t K, int64_t H, int64_t KVH, int64_t D, const float *bias,
                           const int64_t *pos, const int32_t *slots, const float *cos_t, const float *sin_t, float *qkv, float *kc, float *vc, hipStream_t s);
+// r05: the residual add + RMSNorm in front of a decode-sized consumer GEMV done by the GEMV's workgroups themselves (h_out: the new residual stream, a buffer
+// other than h_in; the bits of add_rmsnorm followed by the consumer)
+bool fused_norm_ok(int64_t T, int64_t K);
+int add_norm_linear_silu_mul(const float *h_in, const float *y, const float *nw, float eps, float *h_out, const float *W, int64_t T, int64_t K, int64_t I,
+                             const float *bias, float *act, hipStream_t s);
+int add_norm_linear_qkv_rope_store(const float *h_in, const float *y, const float *nw, float eps, float *h_out, const float *W, int64_t T, int64_t K, int64_t H,
+                                   int64_t KVH, int64_t D, const float *bias, const int64_t *pos, const int32_t *slots, const float *cos_t, const float *sin_t,
+                                   float *qkv, float *kc, float *vc, hipStream_t s);
 bool linear_silu_ok(int64_t T, int64_t K, int64_t ldx);       // decode-sized steps: gate_up projection + SiluAndMul in one launch (the same bits as the two)
 int linear_silu_mul(const float *x, int64_t ldx, const float *W, int64_t T, int64_t K, int64_t I, const float *bias, float *act, hipStream_t s);
 int attention(const AttnArgsF &a, bool paged, hipStream_t s);

@@ -46,7 +46,7 @@ nvr_model_runner::~nvr_model_runner() {
     if (lm_head_t) hipFree(lm_head_t);
     void *ptrs[] = {embed, mc.tie_word_embeddings ? nullptr : lm_head, norm, cos_t, sin_t, kv_pool, h, n, qkv, attn,
                     proj, gu, act, nlast, logits, attn_ws, slabs, in_dev, d_tok, d_maxval, d_temp, d_topk, d_topp, d_keys,
-                    sample_ws, d_gather_val, d_gather_idx, d_gather_logits, d_full_logits, sample_ws_full, d_lm_pval, d_lm_pidx, d_rec, d_gather_rec, f32_gather};
+                    sample_ws, d_gather_val, d_gather_idx, d_gather_logits, d_full_logits, sample_ws_full, d_lm_pval, d_lm_pidx, d_rec, d_gather_rec, f32_gather, f32_h2};
     for (void *p : ptrs) if (p) hipFree(p);
     if (in_host) hipHostFree(in_host);
     if (h_tok) hipHostFree(h_tok);
@@ -124,6 +124,7 @@ int nvr_model_runner::init() {                                       // ModelRun
     RC(dmalloc(&act, em * max_tokens * I)); RC(dmalloc(&nlast, em * max_seqs * Hd)); RC(dmalloc(&logits, max_seqs * Vl));
     // float32 tensor-parallel ranks gather every rank's partial sums before they add them (allocated here, not on first use: an allocation
     // synchronises the device, and with the in-process group a peer's collective may already be spinning on it)
+    if (f32 && tp == 1 && env.f32_fused_norm) NVR_HIP_CHECK(hipMalloc((void **)&f32_h2, (size_t)8 * (size_t)Hd * sizeof(float)));
     if (f32 && tp > 1) NVR_HIP_CHECK(hipMalloc((void **)&f32_gather, (size_t)tp * (size_t)max_tokens * (size_t)Hd * sizeof(float)));
     slab_rows = std::max<int64_t>(64, std::min<int64_t>(1024, std::max<int64_t>(max_seqs, 256)));
     RC(dmalloc(&slabs, 4 * slab_rows * Hd));
@@ -301,9 +302,19 @@ int nvr_model_runner::forward_f32(int64_t T, int64_t B, bool is_prefill, int64_t
     const int32_t *slots = is_prefill ? d_slots : dd_slots, *ctx = is_prefill ? d_ctx : dd_ctx;
     RC(kf::embedding(ids, T, F(embed), Hd, fh, st));
     RC(kf::rmsnorm(fh, F(L > 0 ? layers[0].ln1 : norm), mc.rms_norm_eps, T, Hd, fn, st));
+    // Decode-sized steps on one rank (r05): the residual add + RMSNorm in front of a consumer GEMV is done by that launch's workgroups themselves
+    // (kf::add_norm_*: the bits of add_rmsnorm + consumer) — the residual stream then alternates between h and f32_h2, because the workgroups of
+    // the launch still read the old one while one of them writes the new one.  `owed`: the add of `proj` + the norm of the next layer, left to its qkv launch.
+    const bool ride = f32_h2 && !comm.active() && kf::fused_norm_ok(T, Hd);
+    float *hc = fh, *hn = f32_h2;
+    bool owed = false;
     for (int64_t l = 0; l < L; ++l) {
         const Layer &w = layers[l];
-        if (!w.q_norm && !w.k_norm && kf::linear_qkv_rope_ok(T, Hd, D, Hd)) {                      // decode-sized: K3..K6 in one launch
+        if (owed) {
+            RC(kf::add_norm_linear_qkv_rope_store(hc, fp, F(w.ln1), mc.rms_norm_eps, hn, F(w.qkv), T, Hd, H, KVH, D, w.qkv_b ? F(w.qkv_b) : nullptr, pos, slots,
+                                                  cos_t, sin_t, fq, F(k_cache(l)), F(v_cache(l)), st));
+            std::swap(hc, hn); owed = false;
+        } else if (!w.q_norm && !w.k_norm && kf::linear_qkv_rope_ok(T, Hd, D, Hd)) {               // decode-sized: K3..K6 in one launch
             RC(kf::linear_qkv_rope_store(fn, Hd, F(w.qkv), T, Hd, H, KVH, D, w.qkv_b ? F(w.qkv_b) : nullptr, pos, slots, cos_t, sin_t, fq,
                                          F(k_cache(l)), F(v_cache(l)), st));
         } else {
@@ -322,6 +333,10 @@ int nvr_model_runner::forward_f32(int64_t T, int64_t B, bool is_prefill, int64_t
         }
         RC(kf::attention(a, paged, st));
         RC(kf::linear(fa, H * D, F(w.o), T, H * D, Hd, w.o_b ? F(w.o_b) : nullptr, fp, st));
+        if (ride) {                                                                                  // residual :382, norm :385, K12 + K13: one launch
+            RC(kf::add_norm_linear_silu_mul(hc, fp, F(w.ln2), mc.rms_norm_eps, hn, F(w.gate_up), T, Hd, I, w.gate_up_b ? F(w.gate_up_b) : nullptr, fact, st));
+            std::swap(hc, hn);
+        } else {
         RC(row_parallel_norm_f32(T, F(w.ln2)));                                                      // (exchange,) residual :382, norm :385
         if (kf::linear_silu_ok(T, Hd, Hd)) {                                                         // decode-sized: K12 + K13 in one launch
             RC(kf::linear_silu_mul(fn, Hd, F(w.gate_up), T, Hd, I, w.gate_up_b ? F(w.gate_up_b) : nullptr, fact, st));
@@ -329,8 +344,11 @@ int nvr_model_runner::forward_f32(int64_t T, int64_t B, bool is_prefill, int64_t
             RC(kf::linear(fn, Hd, F(w.gate_up), T, Hd, 2 * I, w.gate_up_b ? F(w.gate_up_b) : nullptr, fg, st));
             RC(kf::silu_and_mul(fg, T, I, fact, st));
         }
+        }
         RC(kf::linear(fact, I, F(w.down), T, I, Hd, w.down_b ? F(w.down_b) : nullptr, fp, st));
-        RC(row_parallel_norm_f32(T, F(l + 1 < L ? layers[l + 1].ln1 : norm)));                       // (exchange,) residual :389, next norm :378 / :501
+        if (ride && l + 1 < L && !layers[l + 1].q_norm && !layers[l + 1].k_norm) owed = true;        // residual :389 + next norm :378: on the next layer's qkv launch
+        else if (ride) RC(kf::add_rmsnorm(hc, fp, F(l + 1 < L ? layers[l + 1].ln1 : norm), mc.rms_norm_eps, T, Hd, fn, st));
+        else RC(row_parallel_norm_f32(T, F(l + 1 < L ? layers[l + 1].ln1 : norm)));                   // (exchange,) residual :389, next norm :378 / :501
     }
     const float *hl = fn;
     if (is_prefill) { RC(kf::select_last_tokens(fn, d_cu, B, Hd, fnl, st)); hl = fnl; }

@@ -120,6 +120,8 @@ private:
     int gen_weights_f32();
     int forward_f32(int64_t T, int64_t B, bool is_prefill, int64_t max_ctx);
     int row_parallel_norm_f32(int64_t T, const float *wn);
+    float *f32_h2 = nullptr;                             // float32, one rank: second residual-stream buffer [8][hidden] of the decode-sized steps whose add + norm
+                                                         // rides on the consumer GEMV (the workgroups of that launch still read the first while one of them writes)
     float *f32_gather = nullptr;                         // float32 tensor-parallel ranks: every rank's partial sums [tp][max tokens][hidden] (lazy)
     int row_parallel_norm(const uint16_t *x, int64_t K, const uint16_t *W, const uint16_t *Wt, int64_t T, const uint16_t *wn, const uint16_t *bias = nullptr);
     int64_t *h_tok_dev = nullptr;                        // device-visible address of the pinned token buffer h_tok

@@ -1110,6 +1110,43 @@ def test_float32_path_engine_parity(tmp_path, shape):
     assert np.array_equal(p1.model_runner.weight("layers.1.gate_up"), np.concatenate([full[I2:2 * I2], full[3 * I2:]]))
 
 
+@pytest.mark.parametrize("shape", ["gqa2_d128", "qk_norm_bias"])
+def test_float32_decode_sized_steps_fuse_add_norm_into_their_gemvs_bit_identically(shape):
+    """r05: on a float32 runner a decode-sized step (1..8 rows) forms the residual add + RMSNorm inside the workgroups of the GEMV that consumes it (qkv + RoPE +
+    KV store, gate_up + SiluAndMul), the residual stream alternating between two buffers.  Per-step logits are BIT-identical to the runner that keeps the
+    add + norm launches (NVR_F32_FUSED_NORM=0, read when the runner is created) — decode batches of 1, 3 and 4 rows, eager and as hipGraph replays; with q / k
+    head norms the qkv side keeps its parts and only the MLP side fuses."""
+    import os
+    kw = dict(gqa2_d128=dict(hidden_size=512, num_attention_heads=4, num_key_value_heads=2, head_dim=128, intermediate_size=768), qk_norm_bias=dict(qk_norm=True, use_bias=True))[shape]
+    mcfg = mo.small(seed=17, **kw)
+    V = mcfg.vocab_size
+    prompts = [oracle.fill_tokens(9 + 7 * i, 8, 40 + i, V).tolist() for i in range(4)]
+
+    def run(flag, eager):
+        os.environ["NVR_F32_FUSED_NORM"] = flag
+        try:
+            nvr.lib().nvr_seq_reset_id_counter()
+            p = nvr.LLMEngine(nvr.Config(skip_block_size_check=1, dtype="float32", max_num_seqs=4, max_num_batched_tokens=256, max_model_len=128, kvcache_block_size=16,
+                                         num_kvcache_blocks=40, enforce_eager=eager), _model_cfgs(mcfg))
+        finally:
+            os.environ.pop("NVR_F32_FUSED_NORM", None)
+        for i, pr in enumerate(prompts):
+            p.add_request(pr, nvr.SamplingParams(temperature=0.0, max_tokens=4 + 5 * i, ignore_eos=True))      # the batch shrinks 4 -> 3 -> 2 -> 1 rows
+        out = []
+        while not p.is_finished():
+            rec = p.step()
+            out.append((rec["is_prefill"], rec["num_seqs"], rec["tokens"], p.model_runner.logits(rec["num_seqs"]).copy()))
+        return out
+    ref = run("0", True)
+    assert {n for pre, n, _, _ in ref if not pre} == {1, 2, 3, 4}
+    for eager in (True, False):
+        got = run("1", eager)
+        assert len(got) == len(ref)
+        for (pa, na, ta, la), (pb, nb, tb, lb) in zip(got, ref):
+            assert (pa, na, ta) == (pb, nb, tb)
+            assert np.array_equal(la.view(np.uint32), lb.view(np.uint32)), f"float32 logits differ between the fused and the unfused add + norm (eager={eager}, rows={na})"
+
+
 def test_graft_entry_smoke_runs_in_a_fresh_process():
     """The driver's round-end check, as the driver runs it: __graft_entry__.smoke() in a process of its own — outside this suite's conftest, which creates
     engines with async_decode = 0 unless a test says otherwise (r05: smoke() read per-step logits from the DEFAULT engine, whose next decode step is
