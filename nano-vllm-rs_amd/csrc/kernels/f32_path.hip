@@ -533,37 +533,59 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgsF a, int paged) 
     extern __shared__ float sc[];                                       // [max_ctx] scores, then probabilities | q [D] | partial outputs [4][D] | 8 of reduction scratch
     const int t = blockIdx.x, hd = blockIdx.y, g = hd / (a.H / a.KVH), D = a.D;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int ctx = a.ctx_lens[t];
     float *qs = sc + a.max_ctx, *part = qs + D, *sm = part + 4 * D;
+    // At a small batch this launch is a chain of dependent round trips (r05 stamps, bs 1: ctx -> table entry -> V rows issued, table entry -> K rows, ..,
+    // table entry -> second batch of V rows: six of ~2 us).  What only needs the block table is therefore looked up BEFORE the context length is
+    // known: the rows of the first 256 keys (scores) and of the first two V batches.  A key index past the context reads a table entry that may be
+    // stale; the row offset made from it is never dereferenced (every K / V load is predicated on key < ctx).  Trips: (ctx, q, table) -> (K, V) -> (V 2).
+    const int32_t *bt = paged ? a.block_tables + (int64_t)(a.seq_of_q ? a.seq_of_q[t] : t) * a.max_blocks : nullptr;
+    const int64_t base = paged ? 0 : (int64_t)a.kv_base[t];
+    auto row_of = [&](int j) -> int64_t {                               // element offset of key j's row of this kv head (any j >= 0)
+        if (paged) return (((int64_t)max(bt[min(j / a.block_size, a.max_blocks - 1)], 0) * a.block_size + j % a.block_size) * a.KVH + g) * D;
+        return (base + j) * a.ldkv + (int64_t)g * D;
+    };
+    // P.V: wave w takes keys w, w + 4, ...; a lane holds output columns lane, lane + 64, ... .  KB of the wave's keys are requested per round trip (their
+    // rows' block-table entries looked up by KB lanes at once); the FIRST batch goes out in front of the scores (the FMA order of an output is unchanged)
+    constexpr int KB = 64 / NV;                                          // 64 registers of V per lane
+    // (paged: any table entry >= 0 names a block of the pool, so a row made from a stale entry is a valid address and the loads below stay unconditional —
+    //  what they return for a key past the context is replaced by 0; contiguous K / V: the rows are arithmetic, formed once ctx is known, clamped to the last key)
+    int64_t k_row0 = paged ? row_of(threadIdx.x) : 0;
+    int64_t v_row0 = paged ? row_of(wave + 4 * (lane < KB ? lane : 0)) : 0;
+    int64_t v_next = paged ? row_of(wave + 4 * KB + 4 * (lane < KB ? lane : 0)) : 0;
+    const int ctx = a.ctx_lens[t];
+    if (!paged) {
+        const int last = max(ctx - 1, 0);
+        k_row0 = row_of(min((int)threadIdx.x, last));
+        v_row0 = row_of(min(wave + 4 * (lane < KB ? lane : 0), last));
+        v_next = row_of(min(wave + 4 * KB + 4 * (lane < KB ? lane : 0), last));
+    }
     const float *q = a.q + (int64_t)t * a.ldq + (int64_t)hd * D;
     for (int j = threadIdx.x; j < D; j += 256) qs[j] = q[j];
     __syncthreads();
-    const int32_t *bt = paged ? a.block_tables + (int64_t)(a.seq_of_q ? a.seq_of_q[t] : t) * a.max_blocks : nullptr;
-    const int64_t base = paged ? 0 : (int64_t)a.kv_base[t];
-    auto row_of = [&](int j) -> int64_t {                               // element offset of key j's row of this kv head
-        if (paged) return (((int64_t)bt[j / a.block_size] * a.block_size + j % a.block_size) * a.KVH + g) * D;
-        return (base + j) * a.ldkv + (int64_t)g * D;
-    };
-    // P.V below: wave w takes keys w, w + 4, ...; a lane holds output columns lane, lane + 64, ... .  KB of the wave's keys are requested per round trip (their
-    // rows' block-table entries looked up by KB lanes at once), and the FIRST batch goes out here, in front of the scores: the V rows depend on the block
-    // table only, so their HBM round trip runs under the score phase (r05; the FMA order of an output is unchanged: the same bits)
-    constexpr int KB = 64 / NV;                                          // 64 registers of V per lane
-    float vv[KB][NV];
-    auto request_v = [&](int j0) {
-        int64_t myrow = 0;
-        if (lane < KB) { const int j = j0 + 4 * lane; myrow = row_of(j < ctx ? j : ctx - 1); }
+    float vv[KB][NV], vv2[KB][NV];                                      // the first two V batches (a one-workgroup-per-CU launch: registers are free)
+    auto request_v = [&](float (&dst)[KB][NV], int j0, int64_t myrow) { // myrow: lane u's row of key j0 + 4 u
 #pragma unroll
         for (int u = 0; u < KB; ++u) {
             const float *vr = a.v + __shfl(myrow, u, 64);
 #pragma unroll
-            for (int i = 0; i < NV; ++i) { const int e = lane + 64 * i; vv[u][i] = e < D ? vr[e] : 0.f; }
+            for (int i = 0; i < NV; ++i) { const int e = lane + 64 * i; dst[u][i] = vr[e < D ? e : 0]; }
         }
     };
-    if (wave < ctx) request_v(wave);
+    auto mask_v = [&](float (&dst)[KB][NV], int j0) {                   // (after the loads have been issued: what a dead key returned becomes 0)
+#pragma unroll
+        for (int u = 0; u < KB; ++u) {
+            const bool live = j0 + 4 * u < ctx;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) if (!live || lane + 64 * i >= D) dst[u][i] = 0.f;
+        }
+    };
+    request_v(vv, wave, v_row0);
+    const bool two = wave + 4 * KB < ctx;                               // a second batch exists: requested now too (ctx <= 8 KB keys then needs no third trip)
+    if (two) request_v(vv2, wave + 4 * KB, v_next);
     // scores: a thread per key (256 keys in flight per workgroup: a decode step has one query row per sequence, so the parallelism has to come from the keys)
     float mx = -INFINITY;
     for (int j = threadIdx.x; j < ctx; j += 256) {
-        const float4 *kr = reinterpret_cast<const float4 *>(a.k + row_of(j));
+        const float4 *kr = reinterpret_cast<const float4 *>(a.k + (j == (int)threadIdx.x ? k_row0 : row_of(j)));
         float d = 0.f;
         // sixteen 16-byte pieces of the row requested before the first FMA (as a plain loop every piece waited for its own round trip to HBM: 32 in
         // a row at head_dim 128 — 29.6 us per launch at bs 1, r04); the FMA chain keeps its order: the same bits
@@ -585,15 +607,24 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgsF a, int paged) 
     for (int j = threadIdx.x; j < ctx; j += 256) { const float p = expf(sc[j] - mx); sc[j] = p; sum += p; }
     sum = block_reduce<false>(sum, sm, 4);                              // (its barriers also publish the probabilities)
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int j0 = wave; j0 < ctx; j0 += 4 * KB) {
-        if (j0 != wave) request_v(j0);                                   // (the first batch is already in flight or landed)
+    auto consume = [&](const float (&src)[KB][NV], int j0) {
 #pragma unroll
         for (int u = 0; u < KB; ++u) {
             const int j = j0 + 4 * u;
             const float pp = j < ctx ? sc[j] : 0.f;
 #pragma unroll
-            for (int i = 0; i < NV; ++i) acc[i] = fmaf(pp, vv[u][i], acc[i]);
+            for (int i = 0; i < NV; ++i) acc[i] = fmaf(pp, src[u][i], acc[i]);
         }
+    };
+    if (wave < ctx) {
+        if (wave + 8 * KB < ctx) v_next = row_of(min(wave + 8 * KB + 4 * (lane < KB ? lane : 0), ctx - 1));   // a third batch: rows looked up under the first two's FMAs
+        mask_v(vv, wave); consume(vv, wave);
+        if (two) { mask_v(vv2, wave + 4 * KB); consume(vv2, wave + 4 * KB); }
+    }
+    for (int j0 = wave + 8 * KB; j0 < ctx; j0 += 4 * KB) {               // keys 8 KB.. : one batch per round trip, the next batch's rows looked up under the FMAs
+        request_v(vv, j0, v_next);
+        if (j0 + 4 * KB < ctx) v_next = row_of(min(j0 + 4 * KB + 4 * (lane < KB ? lane : 0), ctx - 1));
+        mask_v(vv, j0); consume(vv, j0);
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) { const int e = lane + 64 * i; if (e < D) part[wave * D + e] = acc[i]; }
