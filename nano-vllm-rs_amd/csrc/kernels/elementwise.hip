@@ -485,10 +485,20 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const float *__restrict__ 
     const float *x = logits + (int64_t)blockIdx.x * V;
     float bv = -INFINITY; int bi = 0x7fffffff;
     const int V4 = ((reinterpret_cast<uintptr_t>(x) & 15) == 0) ? V / 4 : 0;
-    for (int i = threadIdx.x; i < V4; i += blockDim.x) {
-        float4_t v = *reinterpret_cast<const float4_t *>(x + 4 * i);
+    // eight 16-byte pieces requested before the first comparison (as a plain loop hipcc keeps one in flight per thread: 37 round trips for a
+    // 151 936-column row, 24 us per launch — r05, the float32 path's greedy step); the winner does not depend on the order of the comparisons
+    for (int i0 = threadIdx.x; i0 < V4; i0 += 8 * blockDim.x) {
+        float4_t v[8];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) amax_merge(bv, bi, v[j], 4 * i + j);
+        for (int u = 0; u < 8; ++u) { const int i = min(i0 + u * (int)blockDim.x, V4 - 1); v[u] = *reinterpret_cast<const float4_t *>(x + 4 * i); }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * (int)blockDim.x;
+            if (i < V4) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) amax_merge(bv, bi, v[u][j], 4 * i + j);
+            }
+        }
     }
     for (int i = V4 * 4 + threadIdx.x; i < V; i += blockDim.x) amax_merge(bv, bi, x[i], i);
 #pragma unroll
