@@ -191,6 +191,10 @@ def _paged_case(rng, B, H, KVH, D, bs, ctx_lens, NB):
     (40, 16, 8, 128, 16, [1100 + 3 * i for i in range(40)]),   # same, on the one-workgroup-per-pair (direct) path
     (2, 16, 8, 128, 256, [20000, 300]),                 # 79 blocks of 256 tokens
     (3, 8, 4, 64, 8, [700, 64, 1]),                     # D=64 (8-token row groups), block size = one row group
+    (512, 16, 8, 128, 64, [1 + (37 * i) % 120 for i in range(512)]),    # r05: >= 2048 (sequence, kv head) pairs — 4096 pairs, context bound 256: ONE-wave workgroups
+    (300, 16, 8, 128, 64, [1 + (41 * i) % 250 for i in range(300)]),    # 2400 pairs: two waves
+    (260, 16, 8, 128, 64, [1 + (43 * i) % 500 for i in range(260)]),    # context bound 512: four waves
+    (520, 8, 4, 64, 32, [1 + (29 * i) % 200 for i in range(520)]),      # D=64, 2080 pairs
 ])
 def test_paged_attn_decode(B, H, KVH, D, bs, ctxs):
     rng = np.random.default_rng(6)
