@@ -537,7 +537,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgsF a, int paged) 
     // At a small batch this launch is a chain of dependent round trips (r05 stamps, bs 1: ctx -> table entry -> V rows issued, table entry -> K rows, ..,
     // table entry -> second batch of V rows: six of ~2 us).  What only needs the block table is therefore looked up BEFORE the context length is
     // known: the rows of the first 256 keys (scores) and of the first two V batches.  A key index past the context reads a table entry that may be
-    // stale; the row offset made from it is never dereferenced (every K / V load is predicated on key < ctx).  Trips: (ctx, q, table) -> (K, V) -> (V 2).
+    // stale; the row offset made from it is never dereferenced (key 0's row takes its place once ctx is in).  Trips: (ctx, q, table) -> (K, V).
     const int32_t *bt = paged ? a.block_tables + (int64_t)(a.seq_of_q ? a.seq_of_q[t] : t) * a.max_blocks : nullptr;
     const int64_t base = paged ? 0 : (int64_t)a.kv_base[t];
     auto row_of = [&](int j) -> int64_t {                               // element offset of key j's row of this kv head (any j >= 0)
@@ -547,17 +547,22 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgsF a, int paged) 
     // P.V: wave w takes keys w, w + 4, ...; a lane holds output columns lane, lane + 64, ... .  KB of the wave's keys are requested per round trip (their
     // rows' block-table entries looked up by KB lanes at once); the FIRST batch goes out in front of the scores (the FMA order of an output is unchanged)
     constexpr int KB = 64 / NV;                                          // 64 registers of V per lane
-    // (paged: any table entry >= 0 names a block of the pool, so a row made from a stale entry is a valid address and the loads below stay unconditional —
-    //  what they return for a key past the context is replaced by 0; contiguous K / V: the rows are arithmetic, formed once ctx is known, clamped to the last key)
+    // (paged: the loads below stay unconditional — a key past the context reads key 0's row, and what it returns is replaced by 0; the entries behind a
+    //  sequence's blocks are read but never turned into an address that is used.  Contiguous K / V: the rows are arithmetic, formed once ctx is known)
     int64_t k_row0 = paged ? row_of(threadIdx.x) : 0;
     int64_t v_row0 = paged ? row_of(wave + 4 * (lane < KB ? lane : 0)) : 0;
     int64_t v_next = paged ? row_of(wave + 4 * KB + 4 * (lane < KB ? lane : 0)) : 0;
+    const int64_t key0_row = paged ? row_of(0) : 0;
     const int ctx = a.ctx_lens[t];
     if (!paged) {
         const int last = max(ctx - 1, 0);
         k_row0 = row_of(min((int)threadIdx.x, last));
         v_row0 = row_of(min(wave + 4 * (lane < KB ? lane : 0), last));
         v_next = row_of(min(wave + 4 * KB + 4 * (lane < KB ? lane : 0), last));
+    } else {                                                            // a key past the context: key 0's row instead of what its (unused) table entry says
+        if ((int)threadIdx.x >= ctx) k_row0 = key0_row;
+        if (wave + 4 * (lane < KB ? lane : 0) >= ctx) v_row0 = key0_row;
+        if (wave + 4 * KB + 4 * (lane < KB ? lane : 0) >= ctx) v_next = key0_row;
     }
     const float *q = a.q + (int64_t)t * a.ldq + (int64_t)hd * D;
     for (int j = threadIdx.x; j < D; j += 256) qs[j] = q[j];
