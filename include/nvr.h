@@ -101,8 +101,11 @@ typedef struct nvr_config {
                                           the host (their ids go device to device; positions / slots / block tables follow from the
                                           lengths), whenever that is provably the step the reference would schedule: nothing waiting,
                                           no sequence able to stop, no block boundary.  Same batches, tokens and statistics as 0 (a
-                                          request added in between cancels the step launched ahead); the logits accessors then refer to
-                                          the newest launched step: a caller that reads every step's logits sets 0.  Default 1 (r05; 0 in r02-r04). */
+                                          request added in between cancels the step launched ahead).  The logits accessors of the engine's
+                                          runner (nvr_runner_copy_logits) refer to the step nvr_engine_step has just RETURNED, as
+                                          ModelRunner::execute_model does (model_runner.rs:105-128), never to the step launched behind it
+                                          (r06: the LM head's input rows are kept per step in flight and the logits are produced from them on
+                                          demand, bit-identical to the step's own).  Default 1 (r05; 0 in r02-r04). */
     int32_t shared_prefix_min_seqs;    /* decode batches of at least this many sequences that ALL begin with the same cache blocks
                                           (prefix-cache hits, block_manager.rs:181-197; BASELINE configs[4]) attend to those blocks in one
                                           MFMA pass for the whole batch (nvr_paged_attn_decode_shared) instead of once per sequence; same

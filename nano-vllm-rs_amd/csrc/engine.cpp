@@ -122,6 +122,8 @@ int nvr_engine::step_async(nvr_step_info *info) {
         int rc = timed(host_postprocess_us, [&] { return scheduler->impl.postprocess(batch.data(), last_tokens.data(), batch.size()); });
         if (rc) return rc;
     }
+    // the logits accessors (nvr_runner_copy_logits, the borrowed pointer) refer to the step being returned, not to the one launched behind it
+    if (parity >= 0) runner->present_step(parity, batch.size());
     last_ids.resize(batch.size());
     for (size_t i = 0; i < batch.size(); ++i) last_ids[i] = batch[i]->seq_id;
     if (info) {

@@ -40,8 +40,10 @@ int32_t lm_head_parts(int64_t T, int64_t K, int64_t N, int64_t ldx);      // par
 // store_logits = false: only the partials are written (a greedy batch never reads its 4·T·N logit bytes)
 int lm_head(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t N, float *logits,
             float *part_val, int32_t *part_idx, int32_t *nparts, hipStream_t s, bool store_logits = true, const half_bits *Wt = nullptr);
+// snap_dst (nullable): row m of snap_src (snap_ld_bytes apart) is copied to snap_dst + m * snap_row_bytes by the same launch (16-byte granular)
 int argmax_partials(const float *part_val, const int32_t *part_idx, int32_t nparts, int64_t T, int64_t *out_idx, float *out_val,
-                    int64_t idx_offset, hipStream_t s, int64_t *out_idx2 = nullptr, TpArgmaxRec *out_rec = nullptr);
+                    int64_t idx_offset, hipStream_t s, int64_t *out_idx2 = nullptr, TpArgmaxRec *out_rec = nullptr, const void *snap_src = nullptr,
+                    int64_t snap_ld_bytes = 0, void *snap_dst = nullptr, int64_t snap_row_bytes = 0);
 // cross-rank merge of gathered records recs[tp][B] (largest value, lowest index on ties, rank order): token ids to out_host (and out_dev),
 // *err (the collectives' error word, nullable) to *err_out (nullable) before token 0
 int tp_argmax_merge(const TpArgmaxRec *recs, int tp, int64_t B, int64_t *out_host, int64_t *out_dev, const unsigned int *err, int64_t *err_out,

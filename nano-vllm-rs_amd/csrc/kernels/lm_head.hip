@@ -194,7 +194,8 @@ __global__ __launch_bounds__(WAVES * 64) void lm_head_kchunk_kernel(const half_t
 __global__ __launch_bounds__(64) void argmax_partials_kernel(const float *__restrict__ pval, const int32_t *__restrict__ pidx,
                                                              int nparts, int T, int64_t *__restrict__ out_idx,
                                                              float *__restrict__ out_val, int64_t idx_offset, int64_t *__restrict__ out_idx2,
-                                                             TpArgmaxRec *__restrict__ out_rec) {
+                                                             TpArgmaxRec *__restrict__ out_rec, const uint4 *__restrict__ snap_src, int64_t snap_ld16,
+                                                             uint4 *__restrict__ snap_dst, int snap_chunks) {
     const int m = blockIdx.x, lane = threadIdx.x;
     float bv = -INFINITY; int bi = 0x7fffffff;
     for (int p0 = lane; p0 < nparts; p0 += 256) {                 // 4 partials per lane requested together (256 partials: one round trip)
@@ -221,6 +222,11 @@ __global__ __launch_bounds__(64) void argmax_partials_kernel(const float *__rest
         if (out_val) out_val[m] = bv;
         if (out_rec) { TpArgmaxRec rc; rc.val = bv; rc.pad = 0; rc.idx = tok; out_rec[m] = rc; }   // one record per row for the cross-rank merge
     }
+    // launch-ahead (engine.cpp): row m of the LM head's input is kept per step in flight, so that the logits of the step the engine has
+    // just handed back can still be produced after the next step has overwritten the hidden rows (ModelRunner::execute_model returns THAT
+    // step's logits, model_runner.rs:105-128).  Behind the token store: the host's wake-up does not wait for it.
+    if (snap_dst)
+        for (int c = lane; c < snap_chunks; c += 64) snap_dst[(int64_t)m * snap_chunks + c] = snap_src[(int64_t)m * snap_ld16 + c];
 }
 
 // Vocabulary-sharded greedy sampling (ParallelLMHead::gather_logits + Sampler::greedy, reference src/layers/embed_head.rs:321-336,
@@ -349,10 +355,14 @@ int tp_argmax_merge(const TpArgmaxRec *recs, int tp, int64_t B, int64_t *out_hos
 }
 
 int argmax_partials(const float *part_val, const int32_t *part_idx, int32_t nparts, int64_t T, int64_t *out_idx, float *out_val,
-                    int64_t idx_offset, hipStream_t s, int64_t *out_idx2, TpArgmaxRec *out_rec) {
+                    int64_t idx_offset, hipStream_t s, int64_t *out_idx2, TpArgmaxRec *out_rec, const void *snap_src, int64_t snap_ld_bytes,
+                    void *snap_dst, int64_t snap_row_bytes) {
     if (T == 0) return 0;
     if (nparts < 1) return nvr::fail(NVR_ERR_INVALID_ARG, "argmax_partials: nparts=%d", nparts);
-    argmax_partials_kernel<<<dim3((unsigned)T), dim3(64), 0, s>>>(part_val, part_idx, nparts, (int)T, out_idx, out_val, idx_offset, out_idx2, out_rec);
+    if (snap_dst && (!snap_src || snap_row_bytes % 16 || snap_ld_bytes % 16 || ((uintptr_t)snap_src | (uintptr_t)snap_dst) % 16))
+        return nvr::fail(NVR_ERR_INVALID_ARG, "argmax_partials: row snapshot of %ld bytes (stride %ld) is not 16-byte granular", (long)snap_row_bytes, (long)snap_ld_bytes);
+    argmax_partials_kernel<<<dim3((unsigned)T), dim3(64), 0, s>>>(part_val, part_idx, nparts, (int)T, out_idx, out_val, idx_offset, out_idx2, out_rec,
+                                                                  (const uint4 *)snap_src, snap_ld_bytes / 16, (uint4 *)snap_dst, (int)(snap_row_bytes / 16));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return nvr::fail(NVR_ERR_HIP, "argmax_partials launch failed: %s", hipGetErrorString(e));
     return 0;

@@ -50,7 +50,7 @@ nvr_model_runner::~nvr_model_runner() {
     for (void *p : ptrs) if (p) hipFree(p);
     if (in_host) hipHostFree(in_host);
     if (h_tok) hipHostFree(h_tok);
-    for (int i = 0; i < 2; ++i) { if (ahead_tok[i]) hipHostFree(ahead_tok[i]); if (ahead_host[i]) hipHostFree(ahead_host[i]); }
+    for (int i = 0; i < 2; ++i) { if (ahead_tok[i]) hipHostFree(ahead_tok[i]); if (ahead_host[i]) hipHostFree(ahead_host[i]); if (lm_snap[i]) hipFree(lm_snap[i]); }
     if (samp_host) hipHostFree(samp_host);
     for (int i = 0; i < kMaxChunks; ++i) { if (ev_gemm[i]) hipEventDestroy(ev_gemm[i]); if (ev_reduced[i]) hipEventDestroy(ev_reduced[i]); }
     if (comm_stream) hipStreamDestroy(comm_stream);
@@ -180,6 +180,7 @@ int nvr_model_runner::init() {                                       // ModelRun
             NVR_HIP_CHECK(hipHostMalloc((void **)&ahead_tok[i], (max_seqs + 1) * 8, hipHostMallocDefault));   // + the collectives' error word
             NVR_HIP_CHECK(hipHostGetDevicePointer((void **)&ahead_tok_dev[i], ahead_tok[i], 0));
             NVR_HIP_CHECK(hipHostMalloc((void **)&ahead_host[i], dec_bytes, hipHostMallocDefault));
+            RC(dmalloc(&lm_snap[i], em * max_seqs * Hd));                   // the LM head's input rows of the step with this parity (present_step)
         }
     }
     RC(dmalloc(&d_temp, max_seqs)); RC(dmalloc(&d_topk, max_seqs)); RC(dmalloc(&d_topp, max_seqs)); RC(dmalloc(&d_keys, max_seqs));
@@ -882,6 +883,7 @@ int nvr_model_runner::execute(nvr_seq *const *seqs, size_t nseq, bool is_prefill
         return nvr::fail(NVR_ERR_RCCL, "execute_model: tensor_parallel_size %ld but no communicator is attached (nvr_runner_init_comm / "
                          "nvr_local_group_attach); partial sums would be returned as results", (long)tp);
     if (nseq == 0) return nvr::fail(NVR_ERR_INVALID_ARG, "execute_model: empty batch");
+    facts_shown_valid = false;                                           // the accessors follow this step until the engine presents another
     if ((int64_t)nseq > max_seqs) return nvr::fail(NVR_ERR_INVALID_ARG, "execute_model: %zu sequences > max_num_seqs %ld", nseq, (long)max_seqs);
     char *hd = in_host + off_dec;
     int64_t *ids = (int64_t *)(hd + dof_ids), *pos = (int64_t *)(hd + dof_pos);
@@ -1179,18 +1181,34 @@ int nvr_model_runner::sample_launch(nvr_seq *const *seqs, size_t nseq, int parit
     if (!ahead_capable() || lm_parts <= 0) return nvr::fail(NVR_ERR_UNSUPPORTED, "sample_launch: runner not set up for launch-ahead");
     if (nseq != last_rows) return nvr::fail(NVR_ERR_LEN_MISMATCH, "sample_tokens: %zu sequences but logits hold %zu rows", nseq, last_rows);
     int64_t *ht = ahead_tok[parity & 1];
+    facts_kept[parity & 1] = facts_now();                                 // (called right behind the step's execute / execute_decode_ahead)
     for (size_t i = 0; i < nseq; ++i) ht[i] = INT64_MIN;                  // (the kernel below has not been enqueued yet)
     ht[max_seqs] = 0;
     // greedy_sample, sampler.rs:109-112: token ids to the pinned host buffer (device-visible mapping) AND to the next decode
     // step's input ids on the device
-    if (tp == 1) return KD(argmax_partials(d_lm_pval, d_lm_pidx, lm_parts, (int64_t)nseq, ahead_tok_dev[parity & 1], nullptr, 0, stream, dd_ids));
+    // ... and (same launch) the rows this step's LM head read to lm_snap[parity]: the logits of this step stay reproducible while the
+    // next one, launched ahead, overwrites the hidden rows (present_step / ensure_logits)
+    const int64_t row_bytes = Hd * 2 * em;
+    if (tp == 1) return KD(argmax_partials(d_lm_pval, d_lm_pidx, lm_parts, (int64_t)nseq, ahead_tok_dev[parity & 1], nullptr, 0, stream, dd_ids, nullptr,
+                                           lm_input, row_bytes, lm_snap[parity & 1], row_bytes));
     // vocabulary shards (embed_head.rs:321-336): this rank's (max, global arg-max) records -> all-gather through the peer arenas ->
     // the same rank-ordered merge on every rank, all stream-ordered (no host round trip: the next step can be enqueued behind it)
     if (!ahead_ok(nseq)) return nvr::fail(NVR_ERR_UNSUPPORTED, "sample_launch: %zu rows do not fit the peer-to-peer all-gather", nseq);
-    RC(KD(argmax_partials(d_lm_pval, d_lm_pidx, lm_parts, (int64_t)nseq, d_tok, d_maxval, vocab_start, stream, nullptr, d_rec)));
+    RC(KD(argmax_partials(d_lm_pval, d_lm_pidx, lm_parts, (int64_t)nseq, d_tok, d_maxval, vocab_start, stream, nullptr, d_rec,
+                          lm_input, row_bytes, lm_snap[parity & 1], row_bytes)));
     RC(comm.all_gather_bytes(d_rec, d_gather_rec, nseq * sizeof(k::TpArgmaxRec), stream));
     return KD(tp_argmax_merge(d_gather_rec, (int)tp, (int64_t)nseq, ahead_tok_dev[parity & 1], dd_ids, comm.p2p_words ? comm.p2p_words + 2 : nullptr,
                               ahead_tok_dev[parity & 1] + max_seqs, stream));
+}
+
+// The step the engine hands back to its caller is not always the step the runner executed last (launch-ahead: its successor is already
+// enqueued, and has reused the hidden rows and, unless lazy, the logits buffer).  The logits accessors must refer to the step just returned
+// (ModelRunner::execute_model returns that step's logits, model_runner.rs:105-128; LLMEngine::step, llm_engine.rs:155-197): they are
+// recomputed on demand from the rows sample_launch kept for that step — same kernel, same rows, same bits as the step's own LM head.
+void nvr_model_runner::present_step(int parity, size_t rows) {
+    if (!lm_snap[parity & 1]) return;
+    lm_input = lm_snap[parity & 1]; logits_valid = false; last_rows = rows;
+    facts_shown = facts_kept[parity & 1]; facts_shown_valid = true;
 }
 
 int nvr_model_runner::sample_wait(size_t nseq, int parity, int64_t *out) {

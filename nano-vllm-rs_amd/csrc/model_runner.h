@@ -100,6 +100,16 @@ struct nvr_model_runner {
     // single rank, or tensor-parallel ranks whose collectives are the stream-ordered peer-to-peer kernels (no host rendezvous): every
     // rank takes the same decisions from the same scheduler state and merges the same gathered (max, arg-max) records on the device
     int last_prefill_kv_source() const { return !last_prefill ? -1 : prefill_paged ? 2 : (prefill_kv_cache && n_tiles > 0) ? 1 : 0; }
+    // what the diagnostic accessors report about "the last step" (nvr_runner_last_*): of the step the engine has just returned — kept per step in
+    // flight like the LM head's input rows (present_step) — or, for a caller that drives execute_model itself, of the step executed last
+    struct StepFacts { int kv_source = -1; int64_t shared_len = 0, shared_rows = 0, overlap_chunks = 0; };
+    StepFacts facts_now() const {
+        StepFacts f; f.kv_source = last_prefill_kv_source(); f.overlap_chunks = tp_overlap_chunks;
+        f.shared_len = last_prefill ? 0 : decode_shared_len; f.shared_rows = (last_prefill || decode_shared_len == 0) ? 0 : decode_shared_rows;
+        return f;
+    }
+    StepFacts facts_kept[2], facts_shown; bool facts_shown_valid = false;
+    StepFacts facts() const { return facts_shown_valid ? facts_shown : facts_now(); }
     bool ahead_capable() const {
         return lm_fused && h_tok_dev != nullptr && ahead_tok[0] != nullptr && ((tp == 1 && !comm.active()) || (tp > 1 && comm.p2p_ready));
     }
@@ -109,6 +119,8 @@ struct nvr_model_runner {
     int execute_decode_ahead(nvr_seq *const *seqs, size_t nseq, int parity); // decode step whose ids are already on the device
     int64_t *ahead_tok[2] = {nullptr, nullptr}, *ahead_tok_dev[2] = {nullptr, nullptr};
     char *ahead_host[2] = {nullptr, nullptr};            // pinned twins of the decode input region (one per step in flight)
+    uint16_t *lm_snap[2] = {nullptr, nullptr};           // [max_seqs][hidden]: the LM head's input rows of the step sampled with this parity
+    void present_step(int parity, size_t rows);          // the logits accessors now refer to THAT step, whatever has been launched behind it
     int ensure_logits();                                 // materialise the last step's f32 logits if it skipped their stores
     int sample(nvr_seq *const *seqs, size_t nseq, int64_t *out);
     uint16_t *k_cache(size_t l) { return kv_pool + (2 * l) * kv_layer_elems * em; }

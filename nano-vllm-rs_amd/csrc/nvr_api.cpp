@@ -244,11 +244,11 @@ int nvr_runner_p2p_reset(nvr_model_runner_t *r) {
     NVR_GUARD_END(NVR_ERR_INVARIANT)
 }
 int nvr_runner_comm_drop_rccl(nvr_model_runner_t *r) { r->comm.drop_rccl(); return NVR_OK; }
-int64_t nvr_runner_last_shared_prefix_len(const nvr_model_runner_t *r) { return r->last_prefill ? 0 : r->decode_shared_len; }
-int nvr_runner_last_prefill_kv_source(const nvr_model_runner_t *r) { return r->last_prefill_kv_source(); }
+int64_t nvr_runner_last_shared_prefix_len(const nvr_model_runner_t *r) { return r->facts().shared_len; }
+int nvr_runner_last_prefill_kv_source(const nvr_model_runner_t *r) { return r->facts().kv_source; }
 int nvr_runner_set_tp_prefill_overlap(nvr_model_runner_t *r, int32_t mode) { r->tp_overlap = mode == 2 ? 2 : mode ? 1 : 0; return NVR_OK; }
-int64_t nvr_runner_last_overlap_chunks(const nvr_model_runner_t *r) { return r->tp_overlap_chunks; }
-int64_t nvr_runner_last_shared_prefix_rows(const nvr_model_runner_t *r) { return (r->last_prefill || r->decode_shared_len == 0) ? 0 : r->decode_shared_rows; }
+int64_t nvr_runner_last_overlap_chunks(const nvr_model_runner_t *r) { return r->facts().overlap_chunks; }
+int64_t nvr_runner_last_shared_prefix_rows(const nvr_model_runner_t *r) { return r->facts().shared_rows; }
 
 // in-process communicator (comm.h LocalGroup): N runners of one process on one device, one host thread each
 struct nvr_local_group { nvr::LocalGroup g; explicit nvr_local_group(int n) : g(n) {} };

@@ -39,21 +39,6 @@ def _no_collector_inside_a_test():
         gc.enable()
 
 
-@pytest.fixture(autouse=True, scope="session")
-def _parity_tests_read_every_steps_logits():
-    """nvr_config.async_decode defaults to 1 since r05 (launch-ahead of greedy decode steps: the engine bench.py measures).  With it on, the
-    logits accessors refer to the newest LAUNCHED step, and nearly every parity test here reads the logits of the step it was just handed to
-    compare them with the oracle's — so inside the test suite a Config is synchronous unless the test says otherwise.  What launch-ahead
-    itself must guarantee (same batches, tokens, finished sets, statistics as the synchronous engine) is what test_async_decode_*,
-    test_tensor_parallel_launch_ahead_is_transparent and the hipIpc process tests check with async_decode = 1 spelled out;
-    test_config_defaults (CPU) pins the library default."""
-    import nvr_import
-    nvr = nvr_import.load()
-    orig = nvr.Config.__init__
-
-    def init(self, **kw):
-        kw.setdefault("async_decode", 0)
-        orig(self, **kw)
-    nvr.Config.__init__ = init
-    yield
-    nvr.Config.__init__ = orig
+# (r02-r05 forced nvr_config.async_decode = 0 on every Config of the suite here, because the logits accessors used to refer to the step launched
+# ahead.  Since r06 they refer to the step just returned (model_runner.cpp: present_step), so the suite runs the engine nvr_config_default builds —
+# launch-ahead on — against the oracle, per-step logits included; the tests that need the synchronous engine spell async_decode=0 out.)

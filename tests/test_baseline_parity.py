@@ -13,7 +13,7 @@ The oracle is teacher-forced with the product's tokens so a tie cannot cascade.
               config.rs:58) + one decode step; and 256 sequences x 150 tokens over two budget batches with chunked prefill on
   configs[3]  Qwen3-8B (36 layers, V = 151 936) on one GPU: product vs oracle at full depth on a reduced batch (2 x 256 + 2 decode
               steps), and the full 32 x 2048 workload as in-process tensor-parallel ranks (tp 8) against the single-rank product
-A JSON summary of what was measured lands in gpurun_out/parity_r05.json (copied to profiles/ by hand)."""
+A JSON summary of what was measured lands in gpurun_out/parity_r06.json (copied to profiles/ by hand)."""
 import json
 import os
 import time
@@ -42,7 +42,7 @@ def _report(name, rec):
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     try:
         os.makedirs(out, exist_ok=True)
-        path = os.path.join(out, "parity_r05.json")
+        path = os.path.join(out, "parity_r06.json")
         cur = json.load(open(path)) if os.path.exists(path) else {}
         cur[name] = rec
         json.dump(cur, open(path, "w"), indent=1, sort_keys=True)
@@ -133,6 +133,56 @@ def test_configs1_bs32_seq1024_full_size_vs_oracle():
     assert st["steps"] == 5 and st["prefill_steps"] == 1 and st["rows"] == 160
     assert st["near_ties"] <= 2, st
     _report("configs1_bs32_seq1024", st)
+
+
+def _trace(ecfg, prompts, max_tokens, **kw):
+    """(is_prefill, seq_ids, tokens, logits of the step as the logits accessor returns them AFTER nvr_engine_step) of every step + the engine"""
+    nvr.lib().nvr_seq_reset_id_counter()
+    e = nvr.LLMEngine(nvr.Config(**ecfg, **kw), nvr.ModelConfig("qwen3-0.6b"))
+    for pr in prompts:
+        e.add_request(pr, nvr.SamplingParams(temperature=0.0, max_tokens=max_tokens, ignore_eos=True))
+    out = []
+    while not e.is_finished():
+        rec = e.step()
+        out.append((rec["is_prefill"], rec["seq_ids"], rec["tokens"], e.model_runner.logits(rec["num_seqs"]).copy()))
+    return out, e
+
+
+def _default_equals_synchronous(ecfg, prompts, max_tokens, name, min_ahead):
+    got, e = _trace(ecfg, prompts, max_tokens)                         # nvr_config_default: launch-ahead on
+    assert e.config.c.async_decode == 1
+    ahead = e.ahead_launched()
+    assert ahead >= min_ahead, f"{name}: only {ahead} steps were launched ahead"
+    del e
+    ref, e0 = _trace(ecfg, prompts, max_tokens, async_decode=0)
+    assert e0.ahead_launched() == 0
+    del e0
+    assert len(got) == len(ref)
+    for k, (a, b) in enumerate(zip(got, ref)):
+        assert a[:3] == b[:3], f"{name}: step {k}: batch / tokens differ between the default and the synchronous engine"
+        assert np.array_equal(a[3].view(np.uint32), b[3].view(np.uint32)), f"{name}: step {k}: the logits read after the step differ in bits"
+    _report(name, dict(steps=len(got), steps_launched_ahead=int(ahead), rows=int(sum(len(a[1]) for a in got)), logits_bit_identical=True))
+
+
+def test_configs1_default_engine_returns_each_steps_own_logits_and_the_synchronous_stream():
+    """BASELINE configs[1] (32 x 1024-token prompts) + 9 decode steps on the engine nvr_config_default builds (launch-ahead of
+    greedy decode steps) against the synchronous engine (async_decode = 0): same batches, same tokens, and the logits read through the runner after
+    every nvr_engine_step are THAT step's — bit for bit — although the next step has been enqueued behind it (ModelRunner::execute_model returns the
+    step's own logits, model_runner.rs:105-128; LLMEngine::step, llm_engine.rs:155-197).  The default engine's stream itself is checked against the
+    oracle by test_configs1_bs32_seq1024_full_size_vs_oracle above (the suite's engines are default engines since r06)."""
+    ecfg = dict(max_num_seqs=32, max_num_batched_tokens=32768, max_model_len=1040, kvcache_block_size=256, num_kvcache_blocks=170)
+    prompts = [nvr.synthetic_tokens(1024, 1, i, V).tolist() for i in range(32)]
+    _default_equals_synchronous(ecfg, prompts, 10, "configs1_default_engine_vs_synchronous", min_ahead=6)
+
+
+def test_configs4_default_engine_returns_each_steps_own_logits_and_the_synchronous_stream():
+    """... and BASELINE configs[4]'s geometry (64 sequences = one 512-token system prompt + 64 own tokens; shared-prefix attention pass in every decode
+    step, prefix blocks shared by BlockManager::allocate) over 10 decode steps."""
+    n = 64
+    ecfg = dict(max_num_seqs=n, max_num_batched_tokens=32768 + 4096, max_model_len=640, kvcache_block_size=256, num_kvcache_blocks=n + 8)
+    shared = nvr.synthetic_tokens(512, 2, 0, V).tolist()
+    prompts = [shared + nvr.synthetic_tokens(64, 1, i, V).tolist() for i in range(n)]
+    _default_equals_synchronous(ecfg, prompts, 11, "configs4_default_engine_vs_synchronous", min_ahead=6)
 
 
 def test_configs1_on_the_float32_path_vs_f32_cpu_path_oracle():

@@ -548,13 +548,15 @@ def test_tensor_parallel_prefill_exchange_overlaps_on_a_second_stream(tp, p2p, h
 
 
 @pytest.mark.gpu
-def test_peer_that_never_arrives_fails_the_step_and_the_group_recovers():
+@pytest.mark.parametrize("async_on", [0, 1])
+def test_peer_that_never_arrives_fails_the_step_and_the_group_recovers(async_on):
     """Negative path of the one-shot collectives (kernels/comm_p2p.hip): rank 1 never enters a decode step that rank 0 runs.  Rank 0's
     reduce workgroups wait a bounded time (NVR_P2P_TIMEOUT_MS, read when the runner is created), set the error word and finish —
     the GPU does not hang — and the step fails with NVR_ERR_RCCL at the ABI instead of returning sums with zeros in place of the
     peer's (the batch is aborted on the failing rank).  Recovery as nvr.h documents it: every rank aborts that batch
     (nvr_engine_abort_last_batch), resets its arena words (nvr_runner_p2p_reset), the control plane barriers, and the SAME engines
-    serve new requests: both ranks sample the same tokens, equal to the single-rank product's."""
+    serve new requests: both ranks sample the same tokens, equal to the single-rank product's.  async_on = 1 (the default engine): the step both
+    ranks launched ahead completes normally on rank 0's next call; the one only rank 0 launches behind it is the step that fails, one call later."""
     import threading
     import oracle
     from oracle import model_oracle as mo
@@ -577,7 +579,7 @@ def test_peer_that_never_arrives_fails_the_step_and_the_group_recovers():
         group = nvr.LocalGroup(2)
         engines = []
         for r in range(2):
-            e = nvr.LLMEngine(nvr.Config(tensor_parallel_size=2, tensor_parallel_rank=r, **ecfg), mc)
+            e = nvr.LLMEngine(nvr.Config(tensor_parallel_size=2, tensor_parallel_rank=r, async_decode=async_on, **ecfg), mc)
             group.attach(e.model_runner)
             engines.append(e)
     finally:
@@ -605,6 +607,9 @@ def test_peer_that_never_arrives_fails_the_step_and_the_group_recovers():
     assert a == b
     # rank 1 stays away from the next step
     t0 = __import__("time").perf_counter()
+    if async_on:                                                         # the step BOTH ranks had enqueued behind the third one: complete, and correct
+        assert engines[0].ahead_launched() == 3 and engines[1].ahead_launched() == 3
+        assert len(engines[0].step()["tokens"]) == 2
     with pytest.raises(nvr.NvrError) as ei:
         engines[0].step()
     assert ei.value.code == -9, ei.value                                 # NVR_ERR_RCCL
