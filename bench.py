@@ -210,15 +210,18 @@ def shared_prefix_decode(nvr, mc, nseq: int = 512, steps: int = 24) -> dict:
     nvr.synchronize(); t_pre = time.perf_counter() - t0
     for _ in range(4):
         eng.step()
+    h0 = eng.host_times()
     nvr.synchronize(); t0 = time.perf_counter()
     for _ in range(steps):
         eng.step()
     nvr.synchronize(); dt = (time.perf_counter() - t0) / steps
+    h1 = eng.host_times()
     st = eng.scheduler.block_manager.get_stats()
     out = dict(workload=f"{nseq} sequences x (512 shared + 64 own prompt tokens), greedy decode (BASELINE.json configs[4])",
                ms_per_step=round(dt * 1e3, 4), tokens_per_s=round(nseq / dt, 1), steps=steps,
                shared_prefix_tokens=eng.model_runner.last_shared_prefix_len(), prefill_steps=npre,
-               prefill_seconds=round(t_pre, 4), prompt_tokens=nseq * 576)
+               prefill_seconds=round(t_pre, 4), prompt_tokens=nseq * 576,
+               host_us_per_step={k: round((h1[k + "_us"] - h0[k + "_us"]) / max(1, h1["steps"] - h0["steps"]), 2) for k in ("schedule", "postprocess")})
     if st:
         out["kv_blocks_used"] = int(st.get("used_blocks", 0))
     del eng
@@ -296,12 +299,13 @@ def side_decode(nvr, preset: str, steps: int = 16, warmup: int = 4, tp_size: int
             break
         npre += 1
     nvr.synchronize(); t_pre = time.perf_counter() - t0       # (includes the first decode step and its graph capture)
+    crc = zlib.crc32(array.array("q", rec["tokens"]).tobytes(), 0)          # crc32 over the tokens of every decode step from the first
     for _ in range(warmup - 1):
-        eng.step()
+        crc = zlib.crc32(array.array("q", eng.step()["tokens"]).tobytes(), crc)
     if barrier: barrier()
     nvr.synchronize(); t0 = time.perf_counter()
     for _ in range(steps):
-        eng.step()
+        crc = zlib.crc32(array.array("q", eng.step()["tokens"]).tobytes(), crc)
     nvr.synchronize(); el = time.perf_counter() - t0
     if barrier: barrier()
     if reduce_max: el = reduce_max(el)
@@ -323,7 +327,8 @@ def side_decode(nvr, preset: str, steps: int = 16, warmup: int = 4, tp_size: int
                step_algorithmic_bytes=int(step_bytes), step_hbm_frac_per_gpu=round(step_bytes / tp_size / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                prefill_steps=npre, prefill_plus_first_decode_seconds=round(t_pre, 3),
                prefill_tflop_per_s_lower_bound=round(prefill_flops(c, [P] * B) / t_pre / 1e12, 1), init_seconds=round(t_init, 1),
-               async_decode="off (nvr_config.async_decode = 0)" if async_decode == 0 else "on (the nvr_config default)")
+               async_decode="off (nvr_config.async_decode = 0)" if async_decode == 0 else "on (the nvr_config default)",
+               decode_token_crc=f"{crc:08x}", decode_steps_in_crc=warmup + steps)
     if exchange_modes is not None:
         out["prefill_exchange_forms"] = exchange_modes
     del eng
@@ -655,6 +660,7 @@ def main() -> None:
     kv_source = [-1]
 
     token_crc = [0]                           # crc32 over the tokens sampled in the timed steps (tensor-parallel ranks must agree on it)
+    stream_crc = [0]                          # ... and over every decode step from the first (warm-up steps included): comparable between engines
     host_us = [None]                          # host us per timed step inside Scheduler::schedule / ::postprocess
 
     def run_decode(eng):
@@ -681,18 +687,21 @@ def main() -> None:
         nvr.synchronize()
         t_pre = time.perf_counter() - t0
         kv_source[0] = eng.model_runner.last_prefill_kv_source()
+        scrc = 0
         for _ in range(args.warmup):
             info = eng.step()
             assert not info["is_prefill"] and info["num_seqs"] == BATCH
+            scrc = zlib.crc32(array.array("q", info["tokens"]).tobytes(), scrc)
         barrier()
         h0 = eng.host_times()
         crc = 0
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            crc = zlib.crc32(array.array("q", eng.step()["tokens"]).tobytes(), crc)     # (~1 us of host time per step, next to a 1.4 ms step)
+            toks = array.array("q", eng.step()["tokens"]).tobytes()                     # (~1 us of host time per step, next to a 1.4 ms step)
+            crc = zlib.crc32(toks, crc); scrc = zlib.crc32(toks, scrc)
         nvr.synchronize()
         el = time.perf_counter() - t0
-        token_crc[0] = crc
+        token_crc[0] = crc; stream_crc[0] = scrc
         h1 = eng.host_times()
         host_us[0] = {k: round((h1[k + "_us"] - h0[k + "_us"]) / max(1, h1["steps"] - h0["steps"]), 2) for k in ("schedule", "postprocess")}
         barrier()
@@ -901,6 +910,16 @@ def main() -> None:
             default_engine["sync_decode_tokens_per_s"] = r["tokens_per_s"]
             default_engine["sync_decode_step_hbm_frac"] = r["step_hbm_frac_per_gpu"]
             default_engine["sync_decode_ms_per_step_runs"] = [x["ms_per_step"] for x in runs[0]]
+            # the token stream of the timed (launch-ahead) engine against the synchronous engine's — the one the parity suite checks against the oracle
+            # step by step (tests/test_baseline_parity.py: configs[1] vs the oracle, default engine == synchronous engine bit for bit)
+            sync_crc = {x["decode_token_crc"] for x in runs[0]}; ahead_crc = {x["decode_token_crc"] for x in runs[None]}
+            same_window = runs[0][0]["decode_steps_in_crc"] == args.warmup + args.steps
+            default_engine["token_stream"] = {
+                "timed_engine_crc_all_decode_steps": f"{stream_crc[0]:08x}", "timed_engine_crc_timed_steps": f"{token_crc[0]:08x}",
+                "fresh_default_engine_crc": sorted(ahead_crc), "synchronous_engine_crc": sorted(sync_crc), "decode_steps_in_crc": runs[0][0]["decode_steps_in_crc"],
+                "equal": bool(len(sync_crc) == 1 and ahead_crc == sync_crc and (not same_window or f"{stream_crc[0]:08x}" in sync_crc)),
+                "note": "crc32 over the sampled token ids of every decode step from the first; 'equal' = launch-ahead engines (the timed one when its window is the "
+                        "same) and synchronous engines produced the same stream"}
         except Exception as ex:                                              # noqa: BLE001
             default_engine["sync_decode_error"] = str(ex)[:200]
         try:

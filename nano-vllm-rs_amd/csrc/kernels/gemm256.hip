@@ -32,13 +32,18 @@
 
 namespace nvr { namespace NVR_DT_NS {
 
-enum { GEPI_F16 = 0, GEPI_RESID = 1, GEPI_SILU = 2, GEPI_ROPE = 3 };   // RESID: y is the residual stream: y <- fp16(y + fp16(x·Wᵀ)) (qwen3.rs:382,389)
+enum { GEPI_F16 = 0, GEPI_RESID = 1, GEPI_SILU = 2, GEPI_ROPE = 3, GEPI_LMHEAD = 4 };   // RESID: y is the residual stream: y <- fp16(y + fp16(x·Wᵀ)) (qwen3.rs:382,389)
+// LMHEAD (r06): the LM head over >= 128 rows (ParallelLMHead::compute_logits, embed_head.rs:292-306, + the greedy branch of Sampler::forward,
+// sampler.rs:109-112): W = the [V, hidden] head, nothing is written as fp16 — every tile leaves (max, lowest vocabulary index) of its 256
+// columns per token row (pval / pidx [column tile][T], merged by argmax_partials) and, on demand, the f32 logits straight from the accumulators;
+// the vocabulary need not be a multiple of 256 (the last column tile clamps its row loads and masks its columns)
 
 struct G256Epi {
     const int64_t *pos; const int32_t *slots; const float *cos_t, *sin_t;
     half_t *kc, *vc;
     int32_t H, KVH, D;
     int32_t kv_cache_only;             // GEPI_ROPE: k and v rows go to the caches only (the attention that follows reads them there)
+    float *logits; float *pval; int32_t *pidx;   // GEPI_LMHEAD: f32 logits [T][N] (nullable), arg-max partials [tiles_x][T]
 };
 
 constexpr int G_BK = 64, G_HT = 128, G_HALF = G_HT * G_BK * 2;          // 16 KiB per half-tile
@@ -86,8 +91,19 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const half_t *__restrict__
         n_u = nbx * ((tiles_y - rg + RG - 1) / RG);                       // tiles of this XCD
         u = blockIdx.x >> 3; xcd_step = gridDim.x >> 3;
     }
-    auto tile_of = [&](int uu) { return CG > 0 ? (rg + RG * (uu / nbx)) * tiles_x + bx0 + uu % nbx : uu; };
-    auto have = [&](int uu) { return CG > 0 ? uu < n_u : uu < tiles_total; };
+    // LM head: W (the [V, hidden] head: 311 MB on Qwen3-0.6B) is the stream and x (T rows) sits in every L2, so the tiles_y row blocks of ONE
+    // column tile run at the same time on the SAME XCD (workgroups w, w + 8, ...: index uu -> XCD uu & 7, slot uu >> 3; tiles_y consecutive
+    // slots share a column tile): its 512 KiB of W rows are fetched from HBM once and found in that XCD's L2 by the others.  The index space is
+    // padded to whole groups of 8 column tiles; the holes (only in the last group) end a workgroup's walk.
+    auto lm_bx = [&](int uu) { return ((uu >> 3) / tiles_y) * 8 + (uu & 7); };
+    auto tile_of = [&](int uu) {
+        if (EPI == GEPI_LMHEAD) return ((uu >> 3) % tiles_y) * tiles_x + lm_bx(uu);
+        return CG > 0 ? (rg + RG * (uu / nbx)) * tiles_x + bx0 + uu % nbx : uu;
+    };
+    auto have = [&](int uu) {
+        if (EPI == GEPI_LMHEAD) return uu < ((tiles_x + 7) / 8) * 8 * tiles_y && lm_bx(uu) < tiles_x;
+        return CG > 0 ? uu < n_u : uu < tiles_total;
+    };
     if (CG <= 0) { u = blockIdx.x; xcd_step = gridDim.x; }
     if (!have(u)) return;
     // staging sources: thread copies pieces idx = i*512 + tid (i = 0,1) of each half-tile: row = idx/8 = r0 + 64 i, LDS slot idx%8.
@@ -98,11 +114,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const half_t *__restrict__
     const int64_t a_thr = (int64_t)g_w_thr<EPI, RD>(r0) * K + cch, b_thr = (int64_t)r0 * ldx + cch;
     const half_t *wb = W, *xb = x;                                         // of the tile being STAGED (the next one during a tile's last K-tile)
     int rows_left = 0x3fffffff;                                            // T - 1 - m0 when the tile's row block is ragged
+    int wrows_left = 0x3fffffff;                                           // LM head: N - 1 - bx * 256 when the tile's vocabulary block is ragged
     auto set_sources = [&](int tile) {
         const int bx = tile % tiles_x, m0 = (tile / tiles_x) * 256;
         wb = W + (int64_t)bx * ((EPI == GEPI_SILU) ? 128 : 256) * K;
         xb = x + (int64_t)m0 * ldx;
         rows_left = m0 + 256 > T ? T - 1 - m0 : 0x3fffffff;
+        if (EPI == GEPI_LMHEAD) wrows_left = bx * 256 + 256 > N ? N - 1 - bx * 256 : 0x3fffffff;
     };
     // half-tile ids: 0 = A0, 1 = A1, 2 = B0, 3 = B1; kt = K-tile index inside the (current or next) tile, g = stream index
     auto stage = [&](int ht, int kt, int g) {
@@ -111,8 +129,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const half_t *__restrict__
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const half_t *src;
-            if (ht < 2) src = wb + (int64_t)g_w_uni<EPI, RD>(ht & 1, i, N) * K + a_thr + k0;
-            else {
+            if (ht < 2) {
+                src = wb + (int64_t)g_w_uni<EPI, RD>(ht & 1, i, N) * K + a_thr + k0;
+                if (EPI == GEPI_LMHEAD && wrows_left != 0x3fffffff && (ht & 1) * 128 + i * 64 + r0 > wrows_left) src = wb + (int64_t)wrows_left * K + cch + k0;   // clamp
+            } else {
                 const int rowu = (ht & 1) * 128 + i * 64;
                 src = xb + (int64_t)rowu * ldx + b_thr + k0;
                 if (rows_left != 0x3fffffff && rowu + r0 > rows_left) src = xb + (int64_t)rows_left * ldx + cch + k0;   // ragged last row block: clamp
@@ -257,6 +277,53 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const half_t *__restrict__
         asm volatile("" : "+v"(etid));
         const int tid = etid, wave = tid >> 6, lane = tid & 63, r = lane & 15, q = lane >> 4, wn = wave >> 2, wm = wave & 3;
         (void)wave; (void)lane;
+        if (EPI == GEPI_LMHEAD) {
+            // C layout of an MFMA: lane (r, q) holds 4 consecutive vocabulary entries (W rows q*4 .. q*4+3 of the 16-row tile) of token r.
+            // Per token row: (max, lowest index) over this lane's 32 entries in ascending column order (strict >: the first maximum stays),
+            // then over the 4 lanes of the token (larger value, else lower index), then over the two wave columns through LDS.
+            float *sv = reinterpret_cast<float *>(scratch); int *si = reinterpret_cast<int *>(scratch + 1024);
+            const int n_base = bx * 256 + wn * 64 + q * 4;
+            float bestv[2][2]; int besti[2][2];
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int ml = b * 128 + wm * 32 + j * 16 + r, m = m0 + ml;
+                    float bv = -INFINITY; int bi = 0x7fffffff;
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int c0 = n_base + a * 128 + i * 16;
+                            const float4_t v = acc[a][i][b][j];
+                            if (epi.logits && m < T && c0 < N) *reinterpret_cast<float4_t *>(epi.logits + (int64_t)m * N + c0) = v;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (c0 + e < N && v[e] > bv) { bv = v[e]; bi = c0 + e; }
+                        }
+#pragma unroll
+                    for (int o = 16; o < 64; o <<= 1) {
+                        const float v2 = __shfl_xor(bv, o, 64); const int i2 = __shfl_xor(bi, o, 64);
+                        if (v2 > bv || (v2 == bv && i2 < bi)) { bv = v2; bi = i2; }
+                    }
+                    bestv[b][j] = bv; besti[b][j] = bi;
+                    if (wn == 1 && q == 0) { sv[ml] = bv; si[ml] = bi; }
+                }
+            __syncthreads();
+            if (wn == 0 && q == 0) {
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int ml = b * 128 + wm * 32 + j * 16 + r, m = m0 + ml;
+                        float bv = bestv[b][j]; int bi = besti[b][j];
+                        const float v2 = sv[ml]; const int i2 = si[ml];
+                        if (v2 > bv || (v2 == bv && i2 < bi)) { bv = v2; bi = i2; }
+                        if (m < T) { epi.pval[(int64_t)bx * T + m] = bv; epi.pidx[(int64_t)bx * T + m] = bi; }
+                    }
+            }
+            __syncthreads();                                              // the next tile's second K-tile is staged into this buffer
+        }
         auto put = [&](int ml, int col, half4_t h) {                      // 4 consecutive columns (col % 4 == 0) of token row ml
             *reinterpret_cast<half4_t *>(scratch + ml * (OUTC * 2) + ((((col >> 3) ^ (ml & 15)) << 4) | ((col & 4) << 1))) = h;
         };
@@ -281,7 +348,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const half_t *__restrict__
         // halves stage below), so that the second half's results do not sit in f32 under the first half's store phase: the RoPE
         // store phase holds 64 registers of cos / sin next to them, and a spill here is a global-memory round trip (scratch)
         half4_t pk[2][4][2][2];
-        if (EPI != GEPI_SILU) {
+        if (EPI != GEPI_SILU && EPI != GEPI_LMHEAD) {
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -295,7 +362,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const half_t *__restrict__
                         }
         }
 #pragma unroll
-        for (int hB = 0; hB < 2; ++hB) {
+        for (int hB = 0; hB < (EPI == GEPI_LMHEAD ? 0 : 2); ++hB) {
             // GEPI_RESID: the residual pieces this thread will add to are requested first; their latency runs under the conversion
             // of the accumulators, the LDS staging and the barrier
             constexpr int RPC = (EPI == GEPI_RESID) ? (128 * (OUTC / 8)) / 512 : 1;
@@ -426,7 +493,7 @@ static int g256_prepare() {                                               // 128
     if (done) return 0;
     const void *fns[] = {reinterpret_cast<const void *>(&gemm256_kernel<GEPI_F16>), reinterpret_cast<const void *>(&gemm256_kernel<GEPI_SILU>),
                          reinterpret_cast<const void *>(&gemm256_kernel<GEPI_ROPE, 128>), reinterpret_cast<const void *>(&gemm256_kernel<GEPI_ROPE, 64>),
-                         reinterpret_cast<const void *>(&gemm256_kernel<GEPI_RESID>)};
+                         reinterpret_cast<const void *>(&gemm256_kernel<GEPI_RESID>), reinterpret_cast<const void *>(&gemm256_kernel<GEPI_LMHEAD>)};
     for (const void *f : fns) {
         hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G_BUF + 4096);
         if (e != hipSuccess) return nvr::fail(NVR_ERR_HIP, "gemm256: hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -504,6 +571,27 @@ int gemm256_qkv_rope_store(const half_bits *x, int64_t ldx, const half_bits *W, 
         gemm256_kernel<GEPI_ROPE, 64><<<dim3((unsigned)g256_grid(tt)), dim3(512), 2 * G_BUF + 4096, s>>>((const half_t *)x, ldx, (const half_t *)W, (int)T, (int)K,
                                                                                                  (int)N, (int)N, (half_t *)qkv, e, tx, tt / tx, g256_cg(tx, tt / tx, true));
     return g256_check("gemm256_qkv_rope_store");
+}
+
+// LM head over >= G256_LM_MIN_T (192) rows (large decode batches — BASELINE configs[4]: 512 sequences — and many-sequence prefills): f32 logits on demand,
+// one (max, lowest index) partial per 256-column tile and row; N any multiple of 16
+constexpr int64_t G256_LM_MIN_T = 192;     // (measured: 128x128 tiles 78 us at 128 rows, 136 us at 255; these tiles 102 us up to 256 rows)
+bool gemm256_lm_head_ok(int64_t T, int64_t K, int64_t N, int64_t ldx) {
+    return g256_enabled() && T >= G256_LM_MIN_T && T <= 65536 && K % G_BK == 0 && K >= 2 * G_BK && N % 16 == 0 && N >= 256 && ldx % 8 == 0 &&
+           (N + 255) / 256 <= LM_HEAD_MAX_PARTS && N < (1ll << 31) && ((N + 255) / 256) * ((T + 255) / 256) < (1ll << 30);
+}
+int gemm256_lm_head(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t N, float *logits, float *part_val,
+                    int32_t *part_idx, int32_t *nparts, hipStream_t s) {
+    if (!gemm256_lm_head_ok(T, K, N, ldx)) return nvr::fail(NVR_ERR_UNSUPPORTED, "gemm256_lm_head: T=%ld K=%ld N=%ld", (long)T, (long)K, (long)N);
+    if (int rc = g256_prepare()) return rc;
+    G256Epi e{};
+    e.logits = logits; e.pval = part_val; e.pidx = part_idx;
+    const int tx = (int)((N + 255) / 256), tt = tx * (int)((T + 255) / 256);
+    *nparts = tx;
+    const int padded = (tx + 7) / 8 * 8 * (tt / tx);                        // index space of the XCD-paired tile order (kernel: lm_bx)
+    gemm256_kernel<GEPI_LMHEAD><<<dim3((unsigned)g256_grid(padded)), dim3(512), 2 * G_BUF, s>>>((const half_t *)x, ldx, (const half_t *)W, (int)T, (int)K,
+                                                                                           (int)N, (int)N, nullptr, e, tx, tt / tx, 0);
+    return g256_check("gemm256_lm_head");
 }
 
 }}  // namespace nvr::k / nvr::kb (NVR_DT_NS)

@@ -107,6 +107,10 @@ bool gemm256_silu_ok(int64_t T, int64_t K, int64_t I, int64_t ldx);
 bool gemm256_rope_ok(int64_t T, int64_t K, int64_t H, int64_t KVH, int64_t D, int64_t ldx);
 int gemm256(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t N, half_bits *y, hipStream_t s);
 int gemm256_resid(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t N, half_bits *h, hipStream_t s);
+// LM head over >= 192 rows on the 256x256 tiles (f32 logits on demand + one arg-max partial per 256-column tile; any N % 16 == 0)
+bool gemm256_lm_head_ok(int64_t T, int64_t K, int64_t N, int64_t ldx);
+int gemm256_lm_head(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t N, float *logits, float *part_val,
+                    int32_t *part_idx, int32_t *nparts, hipStream_t s);
 bool gemm256_preferred(int64_t T, int64_t K, int64_t N, int64_t ldx);     // linear() would take the 256x256 kernel for this shape
 int gemm256_silu_mul(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t I, half_bits *out, hipStream_t s);
 int gemm256_qkv_rope_store(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t H, int64_t KVH, int64_t D,

@@ -281,6 +281,7 @@ static LmPlan lm_plan(int64_t T, int64_t K, int64_t N) {
 }
 int32_t lm_head_parts(int64_t T, int64_t K, int64_t N, int64_t ldx) {
     if (lm_head_ok(T, K, N, ldx)) return (int32_t)lm_plan(T, K, N).nwg;
+    if (gemm256_lm_head_ok(T, K, N, ldx)) return (int32_t)((N + 255) / 256);              // one partial per 256-column tile (>= 256 rows)
     if (gemm_tiled_lm_head_ok(T, K, N, ldx)) return (int32_t)((N + 127) / 128);          // one partial per 128-column tile
     return 0;
 }
@@ -311,6 +312,8 @@ static int lm_allow_big_lds() {
 int lm_head(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t N, float *logits,
             float *part_val, int32_t *part_idx, int32_t *nparts, hipStream_t s, bool store_logits, const half_bits *Wt) {
     if (!lm_head_ok(T, K, N, ldx)) {
+        if (gemm256_lm_head_ok(T, K, N, ldx))                          // >= 256 rows: 256x256 tiles (r06), same outputs
+            return gemm256_lm_head(x, ldx, W, T, K, N, store_logits ? logits : nullptr, part_val, part_idx, nparts, s);
         if (gemm_tiled_lm_head_ok(T, K, N, ldx))                       // more than 32 rows: 128x128 tiles, same outputs
             return gemm_tiled_lm_head(x, ldx, W, T, K, N, store_logits ? logits : nullptr, part_val, part_idx, nparts, s);
         return nvr::fail(NVR_ERR_UNSUPPORTED, "lm_head: T=%ld K=%ld N=%ld (T <= 32: K multiple of 256 (above 2048: in equal chunks of <= 2048 that are multiples of 256); T > 32: K multiple of 64, "

@@ -78,7 +78,7 @@ bool Scheduler::try_schedule_prefill_chunked(std::vector<nvr_seq *> &out, int *r
         done.push_back(s);
     }
     if (out.empty()) return false;
-    for (nvr_seq *s : done) running_.push_back(s);
+    for (nvr_seq *s : done) { running_.push_back(s); s->in_running = true; }
     return true;
 }
 
@@ -103,7 +103,7 @@ bool Scheduler::try_schedule_prefill(std::vector<nvr_seq *> &out, int *rc) {   /
         out.push_back(s);
     }
     if (out.empty()) return false;
-    for (nvr_seq *s : out) running_.push_back(s);                    // :163-165
+    for (nvr_seq *s : out) { running_.push_back(s); s->in_running = true; }   // :163-165
     return true;
 }
 
@@ -111,6 +111,8 @@ int Scheduler::try_schedule_decode(std::vector<nvr_seq *> &out) {    // :171-223
     BlockManager &bm = bm_->impl;
     size_t num_seqs = 0;
     std::vector<nvr_seq *> reschedule;
+    // (an error return leaves the popped sequences outside the queue, as the reference's early `?` returns do: their membership flag follows)
+    auto lost = [&](nvr_seq *cur, int rc) { cur->in_running = false; for (nvr_seq *q : out) q->in_running = false; for (nvr_seq *q : reschedule) q->in_running = false; return rc; };
     while (!running_.empty()) {
         nvr_seq *s = running_.front(); running_.pop_front();
         if (num_seqs >= max_num_seqs_) { reschedule.push_back(s); continue; }   // :179-182
@@ -120,13 +122,13 @@ int Scheduler::try_schedule_decode(std::vector<nvr_seq *> &out) {    // :171-223
             if (!running_.empty()) { nvr_seq *v = running_.back(); running_.pop_back(); rc = preempt_sequence(v); }
             else if (!out.empty()) { nvr_seq *v = out.back(); out.pop_back(); rc = preempt_sequence(v); }
             else { rc = preempt_sequence(s); self_preempted = true; }
-            if (rc) return rc;
+            if (rc) return lost(s, rc);
             if (self_preempted) break;
         }
         if (!self_preempted && bm.can_append(*s)) {                  // :201-205
             num_seqs += 1;
             int rc = bm.may_append(*s);
-            if (rc) return rc;
+            if (rc) return lost(s, rc);
             s->chunk_start = s->len() - 1; s->chunk_len = 1;
             out.push_back(s);
         }
@@ -139,7 +141,7 @@ int Scheduler::try_schedule_decode(std::vector<nvr_seq *> &out) {    // :171-223
 }
 
 int Scheduler::preempt_sequence(nvr_seq *s) {                        // :226-231
-    s->status = NVR_SEQ_PREEMPTED;
+    s->status = NVR_SEQ_PREEMPTED; s->in_running = false;             // (every caller has taken it out of running_)
     int rc = bm_->impl.deallocate(*s);
     s->num_computed_tokens = 0; s->chunk_start = s->chunk_len = 0;  // recompute-style preemption: nothing of it is in the cache any more
     waiting_.push_front(s);
@@ -164,12 +166,17 @@ int Scheduler::postprocess(nvr_seq *const *seqs, const int64_t *token_ids, size_
             s->status = NVR_SEQ_FINISHED;
             int rc = bm_->impl.deallocate(*s);
             if (rc) return rc;
-            auto it = std::find(running_.begin(), running_.end(), s);   // remove_from_running :260-262
-            if (it != running_.end()) running_.erase(it);
+            // remove_from_running :260-262.  Membership is a flag kept with every queue operation (the reference scans the queue by seq_id for
+            // every sequence of every step, :260-274: O(n^2) per step, 0.1 ms at 512 sequences); batches finish front to back
+            if (s->in_running) {
+                if (!running_.empty() && running_.front() == s) running_.pop_front();
+                else { auto it = std::find(running_.begin(), running_.end(), s); if (it != running_.end()) running_.erase(it); }
+                s->in_running = false;
+            }
             finished_.push_back(s);
             stats_.finished_sequences += 1;
-        } else if (std::find(running_.begin(), running_.end(), s) == running_.end()) {
-            running_.push_back(s);                                   // update_running_sequence fallback :272-273
+        } else if (!s->in_running) {
+            running_.push_back(s); s->in_running = true;             // update_running_sequence fallback :272-273
         }
     }
     update_stats();
@@ -179,8 +186,8 @@ int Scheduler::postprocess(nvr_seq *const *seqs, const int64_t *token_ids, size_
 void Scheduler::abort_batch(nvr_seq *const *seqs, size_t n) {
     for (size_t i = 0; i < n; ++i) {
         nvr_seq *s = seqs[i];
-        auto it = std::find(running_.begin(), running_.end(), s);
-        if (it != running_.end()) running_.erase(it);
+        auto it = running_.end();
+        if (s->in_running) { it = std::find(running_.begin(), running_.end(), s); if (it != running_.end()) running_.erase(it); s->in_running = false; }
         it = std::find(waiting_.begin(), waiting_.end(), s);          // a partially prefilled prompt lives at the front of waiting
         if (it != waiting_.end()) waiting_.erase(it);
         if (!s->block_table.empty()) (void)bm_->impl.deallocate(*s);

@@ -19,6 +19,7 @@ struct nvr_seq {
     nvr_sampling_params sampling{};
     size_t block_size = 256;
     bool owned_by_scheduler = false;
+    bool in_running = false;               // member of the scheduler's running queue (kept by every queue operation: O(1) membership in postprocess)
     // chunked prefill (extension A-23; the reference schedules whole sequences, scheduler.rs:135-138): tokens whose K/V are in
     // the cache, and the token range [chunk_start, chunk_start + chunk_len) the sequence contributes to the step it is in
     size_t num_computed_tokens = 0, chunk_start = 0, chunk_len = 0;

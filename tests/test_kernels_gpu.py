@@ -408,6 +408,9 @@ def test_argmax_exact_with_ties():
 @pytest.mark.parametrize("T,K,N", [(32, 1024, 151936), (7, 1024, 18992), (16, 2048, 4096), (17, 256, 48), (1, 512, 16), (32, 1024, 100000),
                                    # more than 32 rows (large decode batches, many-sequence prefills): 128x128 tiles, one partial per tile
                                    (128, 1024, 151936), (100, 512, 5008), (300, 256, 1000 * 16), (33, 4096, 2064),
+                                   # r06: >= 256 rows go through the 256x256 tiles (one partial per 256-column tile; the vocabulary's last tile ragged:
+                                   # 151 936 = 593 x 256 + 128, 18 992 = 74 x 256 + 48 (a tp-8 shard), 2064 = 8 x 256 + 16; ragged row blocks: 300, 257, 700)
+                                   (512, 1024, 151936), (256, 1024, 18992), (257, 4096, 2064), (700, 128, 4096), (1024, 1024, 75968),
                                    # K > 2048 (Qwen3-8B: hidden 4096): the activation block goes through LDS in 2048-column chunks, every wave
                                    # keeps its tiles' accumulators in registers across the chunks
                                    (32, 4096, 151936), (7, 4096, 18992), (16, 6144, 4096), (1, 8192, 48), (32, 4096, 16 * 2048 * 8), (8, 5120, 4096), (20, 2560, 1024)])
@@ -441,6 +444,14 @@ def test_lm_head_logits_and_argmax_partials(T, K, N):
     d_t2 = nvr.DeviceBuffer(T * 8)
     nvr.check(nvr.lib().nvr_argmax(d_y.ptr, T, N, d_t2.ptr, None))
     assert d_t2.to_numpy((T,), np.int64).tolist() == want.tolist()
+    # logits == NULL (what a greedy step asks for): the same partials without the f32 stores
+    d_pv2, d_pi2 = nvr.DeviceBuffer(P * T * 4), nvr.DeviceBuffer(P * T * 4)
+    np2 = C.c_int32(0)
+    nvr.check(nvr.lib().nvr_lm_head(d_x.ptr, K, d_W.ptr, T, K, N, None, d_pv2.ptr, d_pi2.ptr, C.byref(np2), None))
+    assert np2.value == nparts.value
+    n = nparts.value * T
+    assert np.array_equal(d_pv2.to_numpy((P * T,), np.float32)[:n].view(np.uint32), d_pv.to_numpy((P * T,), np.float32)[:n].view(np.uint32))
+    assert np.array_equal(d_pi2.to_numpy((P * T,), np.int32)[:n], d_pi.to_numpy((P * T,), np.int32)[:n])
     # shapes neither kernel takes are refused, not approximated: N not a multiple of 16
     assert nvr.lib().nvr_lm_head(d_x.ptr, K, d_W.ptr, T, K, N - 8, d_y.ptr, d_pv.ptr, d_pi.ptr, C.byref(nparts), None) == -10
 
