@@ -603,7 +603,7 @@ def main() -> None:
         # the multi-rank path cannot be exercised on the 1-GPU development boxes: never hang the driver — if a rank is still
         # stuck (a collective that never completes, a rendezvous that never forms) after 7 minutes (a tensor-parallel child: 110 s), every rank exits
         import threading
-        wd_secs = 110.0 if os.environ.get("NVR_BENCH_CHILD") == "1" else 420.0
+        wd_secs = 150.0 if os.environ.get("NVR_BENCH_CHILD") == "1" else 1500.0   # (parent: its phases include the children's limits, 420 + 300 + 300 s)
 
         def _bail():
             print(f"[bench] rank {rank}: multi-GPU run made no progress in its current phase ({fallback_state.get('phase', '?')}), giving up", file=sys.stderr, flush=True)
@@ -636,7 +636,9 @@ def main() -> None:
         # control plane only (unique-id broadcast, handle exchange, agreements, barrier, max): a small TCP rendezvous on MASTER_ADDR /
         # MASTER_PORT (nano-vllm-rs_amd/ctrl.py) — a rank process holds ONE ROCm stack (libnvr.so's) and exits normally
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist = nvr_import.load_ctrl().SocketGroup(rank=rank, world=world, timeout=100.0 if os.environ.get("NVR_BENCH_CHILD") == "1" else 300.0)
+        dist = nvr_import.load_ctrl().SocketGroup(rank=rank, world=world, timeout=140.0 if os.environ.get("NVR_BENCH_CHILD") == "1" else 1400.0)
+        if os.environ.get("NVR_BENCH_INJECT") == "child_hang" and os.environ.get("NVR_BENCH_CHILD") == "1" and os.environ.get("NVR_BENCH_ATTEMPT", "0") == "0":
+            time.sleep(100000)                                               # (fallback dry run: the first child never gets anywhere; its watchdog ends it)
 
     total_new = args.warmup + args.steps + 1
     mc = nvr.ModelConfig(args.model)
@@ -713,6 +715,7 @@ def main() -> None:
     replicas = None                           # N > 1: the no-exchange measurement (N independent engines), always taken first
     tensor_parallel = None
     collective = None
+    backend_info: dict = {}                   # which collective backend the tensor-parallel engine ended up on (init_tensor_parallel)
     child = os.environ.get("NVR_BENCH_CHILD") == "1"
 
     def init_tensor_parallel(eng):
@@ -753,17 +756,39 @@ def main() -> None:
                 p2p_ok, why2 = False, str(ex)
         p2p_ok = all_ok(p2p_ok)
         dist.barrier()                                                           # every rank has mapped every arena (or nobody uses them)
+        # the chain fence-free -> fenced -> RCCL: the communicator self-test (all-reduce + all-gather through the arenas, then the
+        # largest decode message back to back on both slot parities) decides, every rank alike; a protocol that fails it is never timed
+        protocol, tried = None, []
         if p2p_ok:
-            try:
-                eng.model_runner.comm_selftest()                                 # all-reduce + all-gather through the arenas
-            except Exception as ex:                                              # noqa: BLE001
-                p2p_ok, why2 = False, str(ex)
+            for proto in (("fenced",) if eng.model_runner.p2p_fenced() else ("fence_free", "fenced")):
+                if proto == "fenced" and not eng.model_runner.p2p_fenced():
+                    try:
+                        eng.model_runner.p2p_reset()                             # (a timed-out self-test leaves the ranks' epochs apart)
+                    except Exception:                                            # noqa: BLE001
+                        pass
+                    dist.barrier()
+                    eng.model_runner.p2p_set_fenced(True)
+                    dist.barrier()
+                ok1, err1 = True, ""
+                try:
+                    eng.model_runner.comm_selftest()
+                except Exception as ex:                                          # noqa: BLE001
+                    ok1, err1 = False, str(ex)
+                ok1 = all_ok(ok1)
+                tried.append({"protocol": proto, "selftest": "passed" if ok1 else ("failed: " + (err1 or "on a peer"))[:200]})
+                if ok1:
+                    protocol = proto
+                    break
+                why2 = err1 or why2
+            p2p_ok = protocol is not None
         p2p_ok = all_ok(p2p_ok)
         if not p2p_ok:
             eng.model_runner.p2p_disable()
+        backend_info.update({"collective_backend": ("p2p_" + protocol) if p2p_ok else ("rccl" if rccl_ok else "none"),
+                             "rccl_nranks": args.gpus if rccl_ok else 0, "p2p_protocols_tried": tried})
         if not rccl_ok and not p2p_ok:
             return False, f"no collective backend: RCCL: {why or 'a peer failed'}; peer-to-peer: {why2 or 'a peer failed'}"
-        desc = ("one-shot peer-to-peer kernels over xGMI (all-reduce + residual + RMSNorm in one launch, captured in the decode graph)"
+        desc = (f"one-shot peer-to-peer kernels over xGMI, {protocol.replace('_', '-')} protocol (all-reduce + residual + RMSNorm in one launch, captured in the decode graph)"
                 + ("; RCCL for messages larger than an arena slot" if rccl_ok else "")) if p2p_ok else "RCCL all-reduce (peer-to-peer arenas unavailable: " + (why2 or "a peer failed") + ")"
         return True, desc
 
@@ -783,6 +808,8 @@ def main() -> None:
         # every rank adds the same partial sums in the same order and merges the same (max, arg-max) records: the ranks' token streams are identical
         # or the exchange is broken on this node (stale peer data) — then this attempt reports an error and the parent tries the next backend
         crcs = dist.all_gather(token_crc[0])
+        if os.environ.get("NVR_BENCH_INJECT") == "crc_mismatch" and os.environ.get("NVR_BENCH_ATTEMPT", "0") == "0":
+            crcs = [c ^ (1 if i == 1 else 0) for i, c in enumerate(crcs)]     # (fallback dry run: the first attempt's ranks 'disagree')
         if len(set(crcs)) != 1:
             if rank == 0:
                 print(json.dumps({"error": f"tensor-parallel ranks disagree on the sampled tokens ({collective}): token crc per rank {crcs}"}), flush=True)
@@ -796,6 +823,7 @@ def main() -> None:
                     "scaling": "weak", "parallelism": f"replicas{args.gpus}",
                     "note": f"{args.gpus} independent engines (one full model and its own 32 sequences per GPU), no exchange between ranks"}
         fallback_state["replicas"] = replicas
+        arm("tensor-parallel children", 1150.0)                              # (their limits: 420 + 300 + 300 s)
         parallelism, scaling, jobs = f"replicas{args.gpus}", "weak", args.gpus
         elapsed, t_prefill = r_el, r_pre
         if args.parallel == "both":
@@ -803,21 +831,29 @@ def main() -> None:
             # (its own rendezvous on the next port); first with the peer-to-peer kernels, then — if that attempt died — RCCL only
             import subprocess
             tp_errors = []
-            for attempt, extra_env in enumerate(({}, {"NVR_BENCH_P2P": "0"})):
+            # attempt 0 walks the chain fence-free -> fenced -> RCCL by itself (self-tests, every rank alike); the later attempts are for a child
+            # that DIED, HUNG or whose ranks disagreed on the tokens: start fenced, then RCCL alone.  Time limits: 8-rank RCCL init + Qwen3-0.6B,
+            # then Qwen3-8B with its own communicator and the three prefill exchange forms; 420 + 300 + 300 s fit the driver's 1800 s with the
+            # replicas phase in front
+            attempts = (({}, 420), ({"NVR_P2P_FENCED": "1"}, 300), ({"NVR_BENCH_P2P": "0"}, 300))
+            for attempt, (extra_env, limit) in enumerate(attempts):
                 env = dict(os.environ)
                 env["MASTER_PORT"] = str(int(env.get("MASTER_PORT", "29500")) + 1 + attempt)
-                env["NVR_BENCH_CHILD"] = "1"
+                env["NVR_BENCH_CHILD"] = "1"; env["NVR_BENCH_ATTEMPT"] = str(attempt)
                 env.update(extra_env)
                 for k in [k for k in env if k.startswith("TORCHELASTIC_")]:   # (the children are plain processes, not the launcher agent's workers)
                     del env[k]
                 cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup),
                        "--parallel", "tp", "--no-cpu-baseline", "--attn-reps", "1"] + (["--eager"] if args.eager else [])
                 child_out, child_err, child_rc = "", "", None
+                txt = lambda b: b.decode("utf-8", "replace") if isinstance(b, (bytes, bytearray)) else (b or "")   # noqa: E731
                 try:
-                    cp = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+                    cp = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=limit)
                     child_out, child_err, child_rc = cp.stdout, cp.stderr, cp.returncode
                 except subprocess.TimeoutExpired as te:
-                    child_err = "timed out after 120 s: " + str((te.stderr or b"")[-300:])
+                    # what the child printed before the limit counts: it prints its tensor-parallel line as soon as that is measured
+                    child_out = txt(te.stdout)
+                    child_err = f"timed out after {limit} s: " + txt(te.stderr)[-300:]
                 done = 0
                 if rank == 0:
                     line = next((l for l in reversed(child_out.splitlines()) if l.startswith("{")), None)
@@ -827,9 +863,11 @@ def main() -> None:
                         cj = None
                     if cj and cj.get("config", {}).get("parallelism") == f"tp{args.gpus}":
                         tensor_parallel = cj
+                        if tp_errors:
+                            tensor_parallel["config"]["earlier_attempts"] = list(tp_errors)
                         done = 1
                     else:
-                        tp_errors.append((cj or {}).get("error") or f"child exit code {child_rc}: {child_err.strip()[-400:]}")
+                        tp_errors.append(f"attempt {attempt} ({extra_env or 'default chain'}): " + ((cj or {}).get("error") or f"child exit code {child_rc}: {child_err.strip()[-400:]}"))
                 done = dist.broadcast(done, 0)
                 barrier()
                 if done:
@@ -1002,6 +1040,8 @@ def main() -> None:
                                                            + (f": {live_prefill}" if isinstance(live_prefill, str) else "") + ")")
         if collective is not None:
             out["config"]["collectives"] = collective
+            out["config"].update(backend_info)
+            out["config"]["tp_attempt"] = int(os.environ.get("NVR_BENCH_ATTEMPT", "0"))
         if chain is not None:
             gbs = chain["alg_bytes_per_layer"] / (chain["us_per_layer"] * 1e-6) / 1e9
             out["roofline_chain"] = {"kernel": "decode GEMM / norm chain, 6 launches per layer (linear_skinny_kernel x4, add_rmsnorm_slabs_kernel x2), "
@@ -1043,7 +1083,10 @@ def main() -> None:
         # BASELINE.json configs[3] on the same ranks: Qwen3-8B, bs 32 x 2048, tensor parallel over the N GPUs (every rank takes part;
         # a hang here costs nothing already measured: the watchdog prints the line as it stands)
         fallback_state["line"] = line
-        arm("configs[3] tensor-parallel side block", 90.0)
+        if rank == 0 and line is not None:
+            # partial result first: a parent that has to cut this child short still has the tensor-parallel headline
+            print(json.dumps(dict(line, partial="the configs[3] tensor-parallel side block was still running")), flush=True)
+        arm("configs[3] tensor-parallel side block", 240.0)
 
         def rmax(v):
             return dist.max(v)

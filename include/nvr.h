@@ -293,6 +293,14 @@ NVR_API int nvr_runner_p2p_export(nvr_model_runner_t *r, uint8_t handle[64]);
 NVR_API int nvr_runner_p2p_attach(nvr_model_runner_t *r, const uint8_t *handles /* [tp][64] */, const int32_t *devices /* [tp] or NULL */);
 NVR_API int nvr_runner_p2p_disable(nvr_model_runner_t *r);
 NVR_API int nvr_runner_p2p_active(const nvr_model_runner_t *r);
+/* Protocol of the one-shot collectives (kernels/comm_p2p.hip).  0 (default): FENCE-FREE — every payload byte is a system-scope write-through
+ * store and a system-scope load, ordered by the writers' s_waitcnt vmcnt(0) + barrier in front of the flag store; 1: FENCED — r04's release /
+ * acquire fences around every hand-off (the conservative form: slower by ~11 % of a two-rank step measured on one device).  The fence-free form
+ * has been measured on ranks sharing ONE GPU only; nvr_runner_comm_selftest exercises whichever is set with the largest decode message, back to back
+ * on both slot parities, and a control plane falls back fence-free -> fenced -> RCCL (bench.py does; NVR_P2P_FENCED=1 starts fenced).  Every rank
+ * of a group must use the same setting; switching drops the captured decode graphs (they hold the old protocol). */
+NVR_API int nvr_runner_p2p_set_fenced(nvr_model_runner_t *r, int32_t on);
+NVR_API int nvr_runner_p2p_fenced(const nvr_model_runner_t *r);
 /* A collective whose peer never arrived (bounded wait, NVR_P2P_TIMEOUT_MS, default 20 s) fails its step with NVR_ERR_RCCL on the
  * waiting rank (the batch is aborted, linear.rs:236-238 has no error path of its own).  The ranks' epochs then differ: the caller's
  * control plane tells EVERY rank to abort that batch (nvr_engine_abort_last_batch), to call nvr_runner_p2p_reset (epoch words and

@@ -181,6 +181,7 @@ _SIGS = {
     "nvr_runner_init_comm_local": (C.c_int, [_P, _P]), "nvr_local_group_set_p2p": (C.c_int, [_P, C.c_int]),
     "nvr_runner_p2p_export": (C.c_int, [_P, _P]), "nvr_runner_p2p_attach": (C.c_int, [_P, _P, _P]),
     "nvr_runner_p2p_disable": (C.c_int, [_P]), "nvr_runner_p2p_active": (C.c_int, [_P]),
+    "nvr_runner_p2p_set_fenced": (C.c_int, [_P, C.c_int32]), "nvr_runner_p2p_fenced": (C.c_int, [_P]),
     "nvr_runner_p2p_reset": (C.c_int, [_P]), "nvr_runner_comm_drop_rccl": (C.c_int, [_P]),
     "nvr_engine_abort_last_batch": (C.c_int, [_P]), "nvr_engine_ahead_declined": (C.c_uint64, [_P]), "nvr_engine_ahead_launched": (C.c_uint64, [_P]),
     "nvr_engine_host_times": (None, [_P, _P]),
@@ -686,6 +687,13 @@ class ModelRunner:
 
     def p2p_active(self) -> bool:
         return bool(lib().nvr_runner_p2p_active(self.h))
+
+    def p2p_set_fenced(self, on: bool) -> None:
+        """protocol of the one-shot collectives: False = fence-free (default), True = r04's release / acquire fences; every rank alike"""
+        check(lib().nvr_runner_p2p_set_fenced(self.h, 1 if on else 0))
+
+    def p2p_fenced(self) -> bool:
+        return bool(lib().nvr_runner_p2p_fenced(self.h))
 
     def p2p_reset(self) -> None:
         """After a collective timed out (NVR_ERR_RCCL): epochs and arrival flags back to their initial state; every rank calls it,

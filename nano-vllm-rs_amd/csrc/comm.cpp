@@ -176,6 +176,7 @@ static void p2p_fill(const Comm &c, P2PArgs &a) {
     // a peer that never arrives: far longer than any host-side stall of a live peer (graph instantiation, first-launch code
     // loading), so that a slow rank is waited for and only a dead one sets the error word
     a.timeout_ticks = (unsigned long long)c.timeout_ms * 100000ull;      // wall clock at 100 MHz
+    a.fenced = c.p2p_fenced ? 1 : 0;
 }
 int Comm::all_reduce_add_rmsnorm(const void *in, void *h, const void *wn, float eps, int rows, int Hd, void *out, hipStream_t s) {
     if (!p2p_usable((size_t)rows * Hd)) return fail(NVR_ERR_INVALID_ARG, "all_reduce_add_rmsnorm: peer arenas not attached or message too large");

@@ -53,6 +53,7 @@ struct P2PArgs {
     size_t gather_stride;                                        // all-gather form (h == nullptr): out[r * gather_stride + i] = rank r's in[i]; 0 = all-reduce
     p2p_half *h; const p2p_half *wn; float eps;                  // fused residual + RMSNorm (h == nullptr: plain all-reduce into out)
     p2p_half *out;
+    int fenced;                                                  // r04's release / acquire fences around the hand-offs (comm_p2p.hip header); 0: fence-free (r05)
 };
 // kernels/comm_p2p.hip and comm_local.hip exist twice like the other kernels (device_utils.h): sums rounded to fp16 (k) or bfloat16 (kb)
 #define NVR_COMM_DECLS \
@@ -73,6 +74,7 @@ struct Comm {
     unsigned int *p2p_words = nullptr;                           // epoch, done, err
     void *p2p_tmp = nullptr; size_t p2p_tmp_bytes = 0;           // output of the plain (unfused) all-reduce
     bool p2p_ready = false;
+    bool p2p_fenced = false;                                     // Env::p2p_fenced / nvr_runner_p2p_set_fenced: the fenced form of the one-shot collectives
     int p2p_alloc(int nranks_, int rank_);                       // allocate + zero my arena
     int p2p_export(uint8_t handle[64]);                          // hipIpcGetMemHandle of my arena
     int p2p_attach_ipc(const uint8_t *handles /* [nranks][64] */, const int *devices /* [nranks] HIP ordinals */);

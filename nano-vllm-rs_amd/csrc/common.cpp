@@ -32,6 +32,8 @@ Env Env::read() {
     e.f32_fused_norm = flag("NVR_F32_FUSED_NORM", true);
     e.max_graphs = num("NVR_MAX_GRAPHS", 256, 1, 1 << 20);
     e.p2p_timeout_ms = num("NVR_P2P_TIMEOUT_MS", 20000, 1, 3600000);
+    e.p2p_fenced = flag("NVR_P2P_FENCED", false);
+    e.selftest_inject = num("NVR_SELFTEST_INJECT", 0, 0, 16);
     return e;
 }
 }

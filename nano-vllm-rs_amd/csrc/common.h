@@ -24,6 +24,8 @@ struct Env {
     bool attn_fused_merge = true; // NVR_ATTN_FUSED_MERGE=0 split-KV decode attention keeps its merge launch (bit-identical; A/B, tests)
     int max_graphs = 256;         // NVR_MAX_GRAPHS=n     captured decode graphs kept before the cache is flushed (test hook)
     int p2p_timeout_ms = 20000;   // NVR_P2P_TIMEOUT_MS=n how long a peer-to-peer collective waits for a peer before it gives up
+    bool p2p_fenced = false;      // NVR_P2P_FENCED=1     the one-shot collectives keep r04's release / acquire fences (kernels/comm_p2p.hip; nvr_runner_p2p_set_fenced)
+    int selftest_inject = 0;      // NVR_SELFTEST_INJECT=n test hook: nvr_runner_comm_selftest reports a failure on its first n calls of this runner (fallback dry runs)
     static Env read();
 };
 

@@ -31,6 +31,12 @@
 // system-scope acquire per reduce workgroup, __threadfence + acq_rel per workgroup at the end): measured with a real peer on the same device
 // (two in-process ranks, Qwen3-0.6B bs 32 x 1024, 57 collectives per step) 2.19 -> 1.95 ms/step, Qwen3-8B 7.37 -> 7.12
 // (profiles/r05_tp_exchange.txt).
+//
+// The FENCED form (r06: P2PArgs::fenced, Comm::p2p_fenced, NVR_P2P_FENCED=1 / nvr_runner_p2p_set_fenced) is r04's protocol, compiled into the same
+// kernels behind one uniform branch: __threadfence_system in front of a RELEASE flag store, a system-scope ACQUIRE fence behind the poll, release /
+// acq_rel on the epoch words.  The fence-free form rests on "acknowledged write-through store => visible at the peer before the later flag store", which
+// was measured on one device only (peers sharing HBM); until a run over real xGMI links has passed, the fenced form is what a failing self-test falls
+// back to BEFORE RCCL (bench.py: fence-free -> fenced -> RCCL, recorded in config.collective_backend).
 #include "kernels.h"
 #include "device_utils.h"
 #include "../common.h"
@@ -43,6 +49,20 @@ namespace nvr { namespace NVR_DT_NS {
 #define CHP(p) reinterpret_cast<const half_t *>(p)
 
 __device__ __forceinline__ unsigned long long p2p_now() { return wall_clock64(); }   // s_memrealtime: 100 MHz, independent of the shader clock
+
+// the last workgroup of a launch to get here stores epoch + 1 (every workgroup of the launch has read the epoch word by then); one lane per workgroup
+__device__ __forceinline__ void p2p_advance_epoch(const P2PArgs &a, unsigned epoch) {
+    if (a.fenced) {
+        __threadfence();
+        if (__hip_atomic_fetch_add(a.done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
+            __hip_atomic_store(a.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(a.epoch, epoch + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    } else if (__hip_atomic_fetch_add(a.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
+        __hip_atomic_store(a.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(a.epoch, epoch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
 
 template <int P>   // P = 8 or 4 fp16 elements per thread and chunk
 __global__ __launch_bounds__(256) void p2p_allreduce_kernel(P2PArgs a) {
@@ -78,10 +98,13 @@ __global__ __launch_bounds__(256) void p2p_allreduce_kernel(P2PArgs a) {
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // every storing wave: its write-through stores are acknowledged
+        if (a.fenced) __threadfence_system();
         __syncthreads();
-        if (tid == 0)
-            __hip_atomic_store(a.peer_flags[peer] + ((size_t)parity * 8 + a.rank) * P2P_PUSH_SPLIT + sub, epoch, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_SYSTEM);
+        if (tid == 0) {
+            unsigned int *fl = a.peer_flags[peer] + ((size_t)parity * 8 + a.rank) * P2P_PUSH_SPLIT + sub;
+            if (a.fenced) __hip_atomic_store(fl, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            else __hip_atomic_store(fl, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     } else {
         // ---- reduce row `row` of [rows][Hd]
         const int row = blockIdx.x - npush;
@@ -101,8 +124,9 @@ __global__ __launch_bounds__(256) void p2p_allreduce_kernel(P2PArgs a) {
             }
             ok = __all(ok);
             if (tid == 0) { ok_s = ok; if (!ok) __hip_atomic_store(a.err, epoch ? epoch : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+            if (a.fenced) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");          // system scope: the pushed payload is visible
         }
-        __syncthreads();                                                         // (every payload load below is a system-scope load: no acquire fence)
+        __syncthreads();                                                         // (fence-free: every payload load below is a system-scope load)
         const bool ok = ok_s != 0;
         const auto rs = __builtin_amdgcn_make_buffer_rsrc(HP(a.slots) + (size_t)parity * 8 * slot_elems, 0, (int)(8 * a.slot_bytes), 0x00020000);
         constexpr int C = 4;                                                       // up to 4 chunks of 256*P elements per row
@@ -172,12 +196,7 @@ __global__ __launch_bounds__(256) void p2p_allreduce_kernel(P2PArgs a) {
     }
     // ---- the last workgroup to finish advances the epoch (every workgroup of the launch has read it by then)
     __syncthreads();
-    if (tid == 0) {
-        if (__hip_atomic_fetch_add(a.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
-            __hip_atomic_store(a.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(a.epoch, epoch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
+    if (tid == 0) p2p_advance_epoch(a, epoch);
 }
 
 // All-gather of a small per-rank record (greedy sampling under vocabulary sharding: (max, argmax) pairs, reference
@@ -195,9 +214,12 @@ __global__ __launch_bounds__(256) void p2p_allgather_kernel(P2PArgs a, const cha
         for (int i = tid * 4; i < bytes; i += 1024)
             __builtin_amdgcn_raw_buffer_store_b32(*reinterpret_cast<const unsigned *>(send + i), rs, i, 0, 17);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (a.fenced) __threadfence_system();
         __syncthreads();
-        if (tid == 0)
-            __hip_atomic_store(a.peer_gflags[peer] + parity * 8 + a.rank, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (tid == 0) {
+            if (a.fenced) __hip_atomic_store(a.peer_gflags[peer] + parity * 8 + a.rank, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            else __hip_atomic_store(a.peer_gflags[peer] + parity * 8 + a.rank, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     } else {
         __shared__ int ok_s;
         if (tid < 64) {
@@ -213,6 +235,7 @@ __global__ __launch_bounds__(256) void p2p_allgather_kernel(P2PArgs a, const cha
             }
             ok = __all(ok);
             if (tid == 0) { ok_s = ok; if (!ok) __hip_atomic_store(a.err, epoch ? epoch : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+            if (a.fenced) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
         }
         __syncthreads();
         const auto rs = __builtin_amdgcn_make_buffer_rsrc(a.gslots + (size_t)parity * 8 * P2P_GATHER_BYTES, 0, 8 * P2P_GATHER_BYTES, 0x00020000);
@@ -225,12 +248,7 @@ __global__ __launch_bounds__(256) void p2p_allgather_kernel(P2PArgs a, const cha
             }
     }
     __syncthreads();
-    if (tid == 0) {
-        if (__hip_atomic_fetch_add(a.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
-            __hip_atomic_store(a.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(a.epoch, epoch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
+    if (tid == 0) p2p_advance_epoch(a, epoch);
 }
 
 int p2p_allgather_launch(const P2PArgs &a, const void *send, void *recv, size_t bytes, hipStream_t s) {

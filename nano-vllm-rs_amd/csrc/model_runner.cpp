@@ -125,13 +125,14 @@ int nvr_model_runner::init() {                                       // ModelRun
     // float32 tensor-parallel ranks gather every rank's partial sums before they add them (allocated here, not on first use: an allocation
     // synchronises the device, and with the in-process group a peer's collective may already be spinning on it)
     if (f32 && tp == 1 && env.f32_fused_norm) NVR_HIP_CHECK(hipMalloc((void **)&f32_h2, (size_t)8 * (size_t)Hd * sizeof(float)));
-    if (f32 && tp > 1) NVR_HIP_CHECK(hipMalloc((void **)&f32_gather, (size_t)tp * (size_t)max_tokens * (size_t)Hd * sizeof(float)));
+    f32_gather_rows = std::min<int64_t>(max_tokens, std::max<int64_t>(max_seqs, 2048));
+    if (f32 && tp > 1) NVR_HIP_CHECK(hipMalloc((void **)&f32_gather, (size_t)tp * (size_t)f32_gather_rows * (size_t)Hd * sizeof(float)));
     slab_rows = std::max<int64_t>(64, std::min<int64_t>(1024, std::max<int64_t>(max_seqs, 256)));
     RC(dmalloc(&slabs, 4 * slab_rows * Hd));
     { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && v > 0) num_cus = v; }
     allow_missing_comm = env.tp_no_comm;                                               // compute-only profiling of one rank
     if (!env.tp_graph && tp > 1) graphs_disabled = true;
-    comm.force = env.tp_force_comm; comm.timeout_ms = env.p2p_timeout_ms;
+    comm.force = env.tp_force_comm; comm.timeout_ms = env.p2p_timeout_ms; comm.p2p_fenced = env.p2p_fenced;
     RC(KD(linear_stream_prepare()));
     RC(KD(gemm_tiled_prepare()));
     lazy_logits = env.lazy_logits && !f32;
@@ -289,8 +290,14 @@ int nvr_model_runner::row_parallel_norm_f32(int64_t T, const float *wn) {
     float *fh = reinterpret_cast<float *>(h), *fn = reinterpret_cast<float *>(n), *fp = reinterpret_cast<float *>(proj);
     if (!comm.active()) return kf::add_rmsnorm(fh, fp, wn, mc.rms_norm_eps, T, Hd, fn, stream);
     if (!f32_gather) return nvr::fail(NVR_ERR_INVARIANT, "float32 tensor-parallel rank without its gather buffer");
-    RC(comm.all_gather_bytes(fp, f32_gather, (size_t)(T * Hd) * sizeof(float), stream));
-    return kf::sum_ranks_add_rmsnorm(fh, f32_gather, (int)tp, T * Hd, wn, mc.rms_norm_eps, T, Hd, fn, stream);
+    // in pieces of at most f32_gather_rows rows (the buffer holds tp x that many rows: sized for a decode batch and a few thousand prefill rows, not for
+    // tp x max_num_batched_tokens x hidden x 4 bytes — 4.3 GB per rank on Qwen3-8B at tp 8); rows are independent: same bits
+    for (int64_t r0 = 0; r0 < T; r0 += f32_gather_rows) {
+        const int64_t nr = std::min(f32_gather_rows, T - r0);
+        RC(comm.all_gather_bytes(fp + r0 * Hd, f32_gather, (size_t)(nr * Hd) * sizeof(float), stream));
+        RC(kf::sum_ranks_add_rmsnorm(fh + r0 * Hd, f32_gather, (int)tp, nr * Hd, wn, mc.rms_norm_eps, nr, Hd, fn + r0 * Hd, stream));
+    }
+    return NVR_OK;
 }
 
 // the f32 graph (Qwen3Model::forward, qwen3.rs:487-505; layer wiring :372-392): one launch per op, eager
@@ -1083,6 +1090,7 @@ int nvr_model_runner::execute(nvr_seq *const *seqs, size_t nseq, bool is_prefill
             (void)hipStreamSynchronize(stream);
             (void)hipGetLastError();
         }
+        if (rc) (void)rearm_tickets();                                   // (a launch that never ran its last arriver would leave a counter behind: ADVICE r05)
         return rc;
     }
 
@@ -1245,11 +1253,32 @@ int nvr_model_runner::replay_last_decode_graph(int n) {
     return nvr::fail(NVR_ERR_INVALID_ARG, "replay_last_decode_graph: the graph was evicted");
 }
 
+int nvr_model_runner::set_p2p_fenced(bool on) {
+    NVR_HIP_CHECK(hipSetDevice(device));
+    if (comm.p2p_fenced == on) return NVR_OK;
+    NVR_HIP_CHECK(hipStreamSynchronize(stream));
+    for (auto &kv : graphs) hipGraphExecDestroy(kv.second);               // their kernel nodes carry P2PArgs::fenced of the old setting
+    graphs.clear(); last_decode_graph = nullptr;
+    comm.p2p_fenced = on;
+    return rearm_tickets();
+}
+
+// The split-KV attention's arrival counters must read zero between launches; each launch's last arriver re-arms its own.  After anything that may
+// have cut a launch short (a failed step, a reset of the collectives after a timed-out peer, a protocol switch) they are zeroed wholesale.
+int nvr_model_runner::rearm_tickets() {
+    if (!attn_tickets) return NVR_OK;
+    NVR_HIP_CHECK(hipMemsetAsync(attn_tickets, 0, (size_t)(max_seqs * KVH) * sizeof(unsigned int), stream));
+    return NVR_OK;
+}
+
 // all-reduce and all-gather of a known pattern on this runner's communicator (tests; collective over all ranks)
 int nvr_model_runner::comm_selftest() {
     NVR_HIP_CHECK(hipSetDevice(device));
     if (tp > 1) RC(comm.prepare());
     if (!comm.comm && !comm.local && !comm.p2p_ready) return nvr::fail(NVR_ERR_RCCL, "comm_selftest: communicator not initialised");
+    // (test hook: the collectives below still run, every rank alike; counted on runners whose peer arenas are attached — the self-test inside
+    //  nvr_runner_init_comm, before the arenas exist, is not one of the calls)
+    const bool inject = comm.p2p_ready && comm_selftest_calls++ < env.selftest_inject;
     const int n = 4096;
     std::vector<uint16_t> hbuf(n);
     for (int i = 0; i < n; ++i) hbuf[i] = bf16 ? 0x3F80 : 0x3C00; // 1.0 in the runner's 16-bit type
@@ -1293,7 +1322,49 @@ int nvr_model_runner::comm_selftest() {
             for (int64_t j = 0; j < nr; ++j)
                 if (all[r * nr + j] != r) return nvr::fail(NVR_ERR_RCCL, "comm_selftest: all-gather slot %ld holds %ld", (long)r, (long)all[r * nr + j]);
     }
-    return comm.p2p_check_error(stream);
+    RC(comm.p2p_check_error(stream));
+    if (tp > 1 && comm.p2p_ready && !f32) {
+        // ... and what a decode step does to the arenas: its LARGEST message (max_num_seqs rows x hidden), R collectives BACK TO BACK with
+        // no host synchronisation in between (consecutive epochs: both slot parities, a peer up to two collectives ahead), alternating the fused
+        // all-reduce + residual + RMSNorm launch of the decode graph and the plain all-reduce, every round's payload its own (small integers: sums
+        // exact in fp16 and bf16), all results checked after ONE synchronisation at the end.  A protocol that lets a rank read a slot before the
+        // peer's payload has landed, or lets a peer overwrite a slot that is still being read, returns another round's values here.
+        const int64_t rows = std::min<int64_t>(max_seqs, (int64_t)(nvr::Comm::kP2PSlotBytes / 2) / Hd);
+        const int64_t R = std::min<int64_t>(32, max_tokens / std::max<int64_t>(rows, 1));
+        if (rows >= 1 && R >= 2 && Hd % 4 == 0) {
+            const size_t ne = (size_t)(rows * Hd);
+            auto enc = [&](int v) -> uint16_t { return bf16 ? f32_to_bf16_bits((float)v) : f32_to_f16_bits((float)v); };
+            auto val = [&](int64_t round, int64_t rk, size_t i) { return (int)((round * 5 + rk * 3 + (int64_t)(i % 7) + (int64_t)(i / (size_t)Hd)) % 29); };
+            std::vector<uint16_t> hin((size_t)R * ne), hout((size_t)R * ne), ones((size_t)Hd, enc(1));
+            for (int64_t r2 = 0; r2 < R; ++r2) for (size_t i = 0; i < ne; ++i) hin[(size_t)r2 * ne + i] = enc(val(r2, rank, i));
+            // inputs in proj, the residual rows of the fused rounds in h (zero: h <- 0 + sum), the norm output in n, norm weights in act (all activations: idle now)
+            NVR_HIP_CHECK(hipMemcpyAsync(proj, hin.data(), hin.size() * 2, hipMemcpyHostToDevice, stream));
+            NVR_HIP_CHECK(hipMemsetAsync(h, 0, (size_t)R * ne * 2, stream));
+            NVR_HIP_CHECK(hipMemcpyAsync(act, ones.data(), ones.size() * 2, hipMemcpyHostToDevice, stream));
+            for (int64_t r2 = 0; r2 < R; ++r2) {
+                uint16_t *in_r = proj + (size_t)r2 * ne, *h_r = h + (size_t)r2 * ne;
+                if (r2 & 1) RC(comm.all_reduce_add_rmsnorm(in_r, h_r, act, mc.rms_norm_eps, (int)rows, (int)Hd, this->n, stream));
+                else RC(comm.all_reduce_sum_f16(in_r, ne, stream));
+            }
+            // plain rounds leave their sums in proj, fused rounds in h
+            NVR_HIP_CHECK(hipMemcpyAsync(hin.data(), proj, hin.size() * 2, hipMemcpyDeviceToHost, stream));
+            NVR_HIP_CHECK(hipMemcpyAsync(hout.data(), h, hout.size() * 2, hipMemcpyDeviceToHost, stream));
+            NVR_HIP_CHECK(hipStreamSynchronize(stream));
+            RC(comm.p2p_check_error(stream));
+            for (int64_t r2 = 0; r2 < R; ++r2)
+                for (size_t i = 0; i < ne; ++i) {
+                    int sum = 0;
+                    for (int64_t rk = 0; rk < tp; ++rk) sum += val(r2, rk, i);
+                    const uint16_t got = (r2 & 1) ? hout[(size_t)r2 * ne + i] : hin[(size_t)r2 * ne + i];
+                    if (got != enc(sum))
+                        return nvr::fail(NVR_ERR_RCCL, "comm_selftest: back-to-back round %ld of %ld (%s, %s protocol, %ld rows x %ld): element %zu is 0x%04x, want %d — a slot was read "
+                                         "before its payload had landed, or overwritten while it was read", (long)r2, (long)R, (r2 & 1) ? "all-reduce + residual + norm" : "plain all-reduce",
+                                         comm.p2p_fenced ? "fenced" : "fence-free", (long)rows, (long)Hd, i, got, sum);
+                }
+        }
+    }
+    if (inject) return nvr::fail(NVR_ERR_RCCL, "comm_selftest: failure injected by NVR_SELFTEST_INJECT (call %d)", comm_selftest_calls);
+    return NVR_OK;
 }
 
 // sample_tokens :131-156 -> Sampler::batch_sample, src/layers/sampler.rs:221-254

@@ -84,6 +84,9 @@ struct nvr_model_runner {
     nvr::Comm comm;
     bool graphs_disabled = false;   // set when capture with RCCL nodes fails: fall back to eager launches
     int comm_selftest();
+    int comm_selftest_calls = 0;           // (Env::selftest_inject)
+    int rearm_tickets();                   // zero the split-KV attention's arrival counters (failure paths)
+    int set_p2p_fenced(bool on);           // switch the one-shot collectives' protocol (captured decode graphs hold the old one: dropped)
 
     ~nvr_model_runner();
     int init();
@@ -134,7 +137,7 @@ private:
     int row_parallel_norm_f32(int64_t T, const float *wn);
     float *f32_h2 = nullptr;                             // float32, one rank: second residual-stream buffer [8][hidden] of the decode-sized steps whose add + norm
                                                          // rides on the consumer GEMV (the workgroups of that launch still read the first while one of them writes)
-    float *f32_gather = nullptr;                         // float32 tensor-parallel ranks: every rank's partial sums [tp][max tokens][hidden] (lazy)
+    float *f32_gather = nullptr; int64_t f32_gather_rows = 0;   // float32 tensor-parallel ranks: every rank's partial sums [tp][f32_gather_rows][hidden], a piece of the step's rows at a time
     int row_parallel_norm(const uint16_t *x, int64_t K, const uint16_t *W, const uint16_t *Wt, int64_t T, const uint16_t *wn, const uint16_t *bias = nullptr);
     int64_t *h_tok_dev = nullptr;                        // device-visible address of the pinned token buffer h_tok
     int64_t slab_rows = 64;           // rows the split-k slab buffers hold (row_parallel_norm)

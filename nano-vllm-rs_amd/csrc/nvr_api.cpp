@@ -237,10 +237,13 @@ int nvr_runner_p2p_attach(nvr_model_runner_t *r, const uint8_t *handles, const i
 }
 int nvr_runner_p2p_disable(nvr_model_runner_t *r) { r->comm.p2p_ready = false; return NVR_OK; }
 int nvr_runner_p2p_active(const nvr_model_runner_t *r) { return r->comm.p2p_ready ? 1 : 0; }
+int nvr_runner_p2p_set_fenced(nvr_model_runner_t *r, int32_t on) { NVR_GUARD_BEGIN return r->set_p2p_fenced(on != 0); NVR_GUARD_END(NVR_ERR_INVARIANT) }
+int nvr_runner_p2p_fenced(const nvr_model_runner_t *r) { return r->comm.p2p_fenced ? 1 : 0; }
 int nvr_runner_p2p_reset(nvr_model_runner_t *r) {
     NVR_GUARD_BEGIN
     NVR_HIP_CHECK(hipSetDevice(r->device));
-    return r->comm.p2p_reset();
+    if (int rc = r->comm.p2p_reset()) return rc;
+    return r->rearm_tickets();
     NVR_GUARD_END(NVR_ERR_INVARIANT)
 }
 int nvr_runner_comm_drop_rccl(nvr_model_runner_t *r) { r->comm.drop_rccl(); return NVR_OK; }

@@ -473,6 +473,94 @@ def test_one_shot_p2p_collectives_equal_host_rendezvous(tp):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("tp,dtype", [(2, "float16"), (4, "float16"), (2, "bfloat16")])
+def test_fenced_protocol_is_a_drop_in_for_the_fence_free_one_and_the_selftest_chain_falls_back(tp, dtype):
+    """VERDICT r05 item 3 / ADVICE r05: the one-shot collectives exist in two protocols in ONE build (kernels/comm_p2p.hip): fence-free (default) and r04's
+    fenced form (nvr_runner_p2p_set_fenced / NVR_P2P_FENCED=1) — the fallback BETWEEN fence-free and RCCL.  In-process ranks: (1) the communicator
+    self-test passes under both, including its back-to-back part (the largest decode message, 32 collectives on consecutive epochs with no host
+    synchronisation, fused and plain launches alternating, every round's payload its own); (2) a fenced run's shard logits and tokens are the
+    fence-free run's bit for bit, in replayed decode graphs; (3) the control plane's chain: a self-test that FAILS under fence-free (injected on
+    every rank by NVR_SELFTEST_INJECT=1) -> p2p_reset -> set_fenced(1) -> the self-test passes -> the engines serve, fenced, with the same stream."""
+    import threading
+    sys.path.insert(0, ROOT)
+    import nvr_import
+    import oracle
+    from oracle import model_oracle as mo
+    nvr = nvr_import.load()
+    m = mo.small(seed=6, num_attention_heads=8, num_key_value_heads=4, head_dim=64, hidden_size=256, intermediate_size=512)
+    mc = nvr.ModelConfig(vocab_size=m.vocab_size, hidden_size=m.hidden_size, intermediate_size=m.intermediate_size,
+                         num_hidden_layers=m.num_hidden_layers, num_attention_heads=m.num_attention_heads,
+                         num_key_value_heads=m.num_key_value_heads, head_dim=m.head_dim, max_position_embeddings=m.max_position_embeddings,
+                         rms_norm_eps=m.rms_norm_eps, rope_theta=m.rope_theta, tie_word_embeddings=m.tie_word_embeddings,
+                         init_std=m.init_std, seed=m.seed)
+    ecfg = dict(max_num_seqs=8, max_num_batched_tokens=512, max_model_len=128, kvcache_block_size=16, num_kvcache_blocks=40, dtype=dtype)
+    prompts = [oracle.fill_tokens(n, 5, i, m.vocab_size).tolist() for i, n in enumerate([9, 40, 17, 3, 26])]
+
+    def run(mode):
+        """mode: 'free' | 'fenced' | 'chain' (fence-free self-test fails by injection, the ranks fall back to fenced)"""
+        if mode == "chain": os.environ["NVR_SELFTEST_INJECT"] = "1"
+        try:
+            group = nvr.LocalGroup(tp, p2p=True)
+            engines = []
+            for r in range(tp):
+                e = nvr.LLMEngine(nvr.Config(skip_block_size_check=1, tensor_parallel_size=tp, tensor_parallel_rank=r, **ecfg), mc)
+                group.attach(e.model_runner)
+                nvr.lib().nvr_seq_reset_id_counter()
+                for pr in prompts:
+                    e.add_request(pr, nvr.SamplingParams(temperature=0.0, max_tokens=24, ignore_eos=True))
+                engines.append(e)
+        finally:
+            os.environ.pop("NVR_SELFTEST_INJECT", None)
+        traces, errors, backend = [[] for _ in range(tp)], [], [None] * tp
+        gate = threading.Barrier(tp)
+
+        def drive(r):
+            try:
+                e = engines[r]; mr = e.model_runner
+                assert not mr.p2p_fenced()
+                if mode == "fenced":
+                    mr.p2p_set_fenced(True)
+                    gate.wait(60)
+                    mr.comm_selftest()
+                elif mode == "chain":
+                    failed = False
+                    try:
+                        mr.comm_selftest()
+                    except nvr.NvrError as ex:
+                        failed = True
+                        assert ex.code == -9 and "injected" in str(ex)
+                    assert failed
+                    gate.wait(60)                                                # (the control plane's all_ok: every rank saw the failure)
+                    mr.p2p_reset(); mr.p2p_set_fenced(True)
+                    gate.wait(60)
+                    mr.comm_selftest()                                           # passes: the ranks go on, fenced
+                else:
+                    mr.comm_selftest()
+                backend[r] = "fenced" if mr.p2p_fenced() else "fence-free"
+                while not e.is_finished():
+                    rec = e.step(); rec["logits"] = mr.logits(rec["num_seqs"]).copy(); traces[r].append(rec)
+                assert mr.p2p_active()
+            except BaseException as ex:                                                 # noqa: BLE001
+                errors.append((r, ex))
+                gate.abort()
+        threads = [threading.Thread(target=drive, args=(r,)) for r in range(tp)]
+        for t in threads: t.start()
+        for t in threads: t.join(300)
+        assert not errors, errors
+        return traces, backend
+    free, b0 = run("free")
+    assert b0 == ["fence-free"] * tp and len(free[0]) > 20
+    for mode in ("fenced", "chain"):
+        got, b1 = run(mode)
+        assert b1 == ["fenced"] * tp
+        for r in range(tp):
+            assert len(got[r]) == len(free[r])
+            for sa, sb in zip(got[r], free[r]):
+                assert sa["tokens"] == sb["tokens"] and sa["seq_ids"] == sb["seq_ids"]
+                assert np.array_equal(sa["logits"].view(np.uint32), sb["logits"].view(np.uint32)), f"{mode}: the fenced protocol changed bits"
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("tp,p2p,heads,inter,shared", [(2, True, 32, 2048, False), (4, True, 64, 4096, False), (2, False, 32, 2048, False), (2, True, 32, 2048, True)])
 def test_tensor_parallel_prefill_exchange_overlaps_on_a_second_stream(tp, p2p, heads, inter, shared):
     """Row g, prefill side (linear.rs:228-239 with its all-reduce :236-238): on tensor-parallel ranks a prefill step of >= 1024 rows is cut into
