@@ -335,6 +335,79 @@ def side_decode(nvr, preset: str, steps: int = 16, warmup: int = 4, tp_size: int
     return out
 
 
+def stochastic_decode(nvr, mc, steps: int = 16, warmup: int = 4, check: bool = True) -> dict:
+    """The non-greedy branch of the path (Sampler::forward top-k / top-p / Gumbel-max, src/layers/sampler.rs:71-218; named in north_star) on the
+    headline workload: BASELINE.json configs[1] with temperature 0.8, top_k 50, top_p 0.9 on every sequence.  A stochastic step has no launch-ahead
+    (its tokens are needed on the host before the next step can be built) and no fused arg-max head: the LM head writes the 32 x 151 936 f32 logits
+    (19.4 MB) and the sampler reads them back.  Reports ms per step next to the greedy step, the sampler launch timed alone (HIP events on its stream,
+    20 back-to-back launches on one step's logits) with its algorithmic bytes, and — check — one step's sampled ids against the CPU oracle's kept
+    sets (temperature scaling, top-k, top-p restated on the CPU from the same logits; the checker, outside every timed region)."""
+    B, P, V = BATCH, PROMPT_LEN, mc.c.vocab_size
+    sp = dict(temperature=0.8, top_k=50, top_p=0.9, ignore_eos=True)
+    total_new = warmup + steps + 4
+    nvr.lib().nvr_seq_reset_id_counter()
+    eng = nvr.LLMEngine(nvr.Config(max_num_seqs=B, max_num_batched_tokens=32768, max_model_len=P + total_new + 16, kvcache_block_size=BLOCK,
+                                   num_kvcache_blocks=B * ((P + total_new + 16) // BLOCK + 2), sample_seed=1234), mc)
+    for i in range(B):
+        eng.add_request(nvr.synthetic_tokens(P, 1, i, V).tolist(), nvr.SamplingParams(max_tokens=total_new, **sp))
+    while True:
+        rec = eng.step()
+        if not rec["is_prefill"]:
+            break
+    for _ in range(warmup - 1):
+        eng.step()
+    nvr.synchronize(); t0 = time.perf_counter()
+    for _ in range(steps):
+        rec = eng.step()
+    nvr.synchronize(); ms = (time.perf_counter() - t0) * 1e3 / steps
+    out = {"workload": f"{MODELS['qwen3-0.6b']['label']} fp16, bs={B} x {P}-token prompts, temperature 0.8 / top_k 50 / top_p 0.9 on every sequence (BASELINE.json configs[1], "
+                       "the sampler's stochastic branch)", "ms_per_step": round(ms, 4), "tokens_per_s": round(B / ms * 1e3, 1), "steps": steps,
+           "steps_launched_ahead": eng.ahead_launched(),
+           "note": "no launch-ahead and no fused arg-max head on a stochastic step: f32 logits written (19.4 MB) and read back by sample_rows_kernel; "
+                   "the host waits for the tokens before it schedules the next step"}
+    # the last step's logits and tokens: the sampler launch timed alone on them, and the kept-set check
+    logits = eng.model_runner.logits(B).copy()
+    toks = list(rec["tokens"])
+    seqs = eng.last_batch()
+    keys = np.asarray([nvr.lib().nvr_sample_key(1234, s.seq_id, s.num_completion_tokens() - 1) for s in seqs], np.uint64)
+    l = nvr.lib()
+    d_lg = nvr.DeviceBuffer.from_numpy(logits)
+    d_t = nvr.DeviceBuffer.from_numpy(np.full(B, 0.8, np.float32)); d_k = nvr.DeviceBuffer.from_numpy(np.full(B, 50, np.int64))
+    d_p = nvr.DeviceBuffer.from_numpy(np.full(B, 0.9, np.float32)); d_keys = nvr.DeviceBuffer.from_numpy(keys)
+    d_out = nvr.DeviceBuffer(B * 8); ws = nvr.DeviceBuffer(l.nvr_sample_workspace_bytes(B, V))
+    st = C.c_void_p(); nvr.check(l.nvr_stream_create(C.byref(st)))
+    e0, e1 = C.c_void_p(), C.c_void_p(); nvr.check(l.nvr_event_create(C.byref(e0))); nvr.check(l.nvr_event_create(C.byref(e1)))
+    launch = lambda: nvr.check(l.nvr_sample(d_lg.ptr, B, V, d_t.ptr, d_k.ptr, d_p.ptr, d_keys.ptr, d_out.ptr, ws.ptr, st))   # noqa: E731
+    for _ in range(3): launch()
+    nvr.check(l.nvr_stream_synchronize(st))
+    reps = 20
+    nvr.check(l.nvr_event_record(e0, st))
+    for _ in range(reps): launch()
+    nvr.check(l.nvr_event_record(e1, st)); nvr.check(l.nvr_stream_synchronize(st))
+    msv = C.c_float(); nvr.check(l.nvr_event_elapsed_ms(e0, e1, C.byref(msv)))
+    us = msv.value * 1e3 / reps
+    alg = B * V * 4
+    out["sampler_launch"] = {"kernel": "sample_rows_kernel (temperature, radix-select top-k, top-p, Gumbel-max; one launch)", "us_per_launch": round(us, 2),
+                             "algorithmic_bytes": alg, "achieved_gbs": round(alg / (us * 1e-6) / 1e9, 1), "hbm_frac": round(alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                             "note": "eager back-to-back launches incl. the filtered-row stores of the stateless entry point (the engine's launch skips them); "
+                                     "19.4 MB of logits resident in the 256 MB Infinity Cache between launches"}
+    again = d_out.to_numpy((B,), np.int64).tolist()
+    out["sampler_launch"]["replayed_ids_equal_the_steps"] = bool(again == toks)
+    l.nvr_event_destroy(e0); l.nvr_event_destroy(e1); l.nvr_stream_destroy(st)
+    if check:
+        import oracle                                                        # the checker (CPU restatement), never timed
+        inside, exact = 0, 0
+        for b in range(B):
+            a = logits[b] / np.float32(0.8)
+            kept = np.isfinite(oracle.top_p(oracle.top_k(a, 50), 0.9))
+            inside += int(kept[toks[b]])
+            exact += int(oracle.sample(logits[b], 0.8, 50, 0.9, int(keys[b])) == toks[b])
+        out["oracle_check"] = {"rows": B, "sampled_id_inside_the_oracles_kept_set": inside, "sampled_id_equals_the_oracles": exact,
+                               "note": "one step: ids against oracle.top_k / top_p kept sets and oracle.sample (same counter RNG key) on the step's own logits"}
+    del eng
+    return out
+
+
 def float32_path(nvr, steps: int = 64) -> dict:
     """BASELINE.json configs[0] (Qwen3-0.6B, bs = 1, 128-token prompt, greedy decode: the reference's own runnable configuration, f32 on its
     CPU path) on the product's Config.dtype = "float32" path (kernels/f32_path.hip: reference precision, plain FMA kernels, eager) — the GPU
@@ -912,12 +985,22 @@ def main() -> None:
     if args.gpus == 1 and rank == 0 and not args.no_batch_sweep and args.model == "qwen3-0.6b":
         # the same engine path at larger batches: the step's share of the HBM roofline grows with the K/V bytes per launch
         batch_sweep = []
-        for bsz in (64, 128):
+        for preset, bsz, plen in (("qwen3-0.6b", 64, 1024), ("qwen3-0.6b", 128, 1024), ("qwen3-0.6b", 256, 1024), ("qwen3-0.6b", 512, 1024),
+                                  ("qwen3-8b", 64, 2048), ("qwen3-8b", 128, 2048)):
             try:
-                r = side_decode(nvr, "qwen3-0.6b", batch=bsz, prompt_len=1024)
-                batch_sweep.append({k: r[k] for k in ("workload", "ms_per_step", "tokens_per_s", "step_algorithmic_bytes", "step_hbm_frac_per_gpu")})
+                r = side_decode(nvr, preset, batch=bsz, prompt_len=plen, steps=8, warmup=3)
+                row = {k: r[k] for k in ("workload", "ms_per_step", "tokens_per_s", "step_algorithmic_bytes", "step_hbm_frac_per_gpu")}
+                row["model"], row["batch"] = preset, bsz
+                batch_sweep.append(row)
             except Exception as ex:                                          # noqa: BLE001
-                batch_sweep.append({"batch": bsz, "error": str(ex)[:200]})
+                batch_sweep.append({"model": preset, "batch": bsz, "error": str(ex)[:200]})
+    stochastic = None
+    if args.gpus == 1 and rank == 0 and not args.no_batch_sweep and args.model == "qwen3-0.6b":
+        try:
+            stochastic = stochastic_decode(nvr, mc, check=not args.no_cpu_baseline)
+            stochastic["greedy_ms_per_step"] = round(ms_per_step, 4)
+        except Exception as ex:                                              # noqa: BLE001
+            stochastic = {"error": str(ex)[:300]}
     bf16_block = None
     if args.gpus == 1 and rank == 0 and not args.no_batch_sweep and args.model == "qwen3-0.6b":
         # Config.dtype = "bfloat16" (config.rs:51,113-116): the same workload on the bf16 build of every kernel (same bytes, same MFMA rate)
@@ -1055,6 +1138,18 @@ def main() -> None:
             out["configs3"] = configs3
         if batch_sweep is not None:
             out["batch_sweep"] = batch_sweep
+            # the north star's 0.70 of the decode-step HBM roofline: the smallest measured batch that reaches it, per model (the headline's own
+            # fraction is step_hbm_frac, the 8B headline configs3.step_hbm_frac_per_gpu)
+            reach = {}
+            pts = {"qwen3-0.6b": [(BATCH, out["step_hbm_frac"])], "qwen3-8b": ([(32, configs3["step_hbm_frac_per_gpu"])] if configs3 and "step_hbm_frac_per_gpu" in configs3 else [])}
+            for row in batch_sweep:
+                if "error" not in row: pts[row["model"]].append((row["batch"], row["step_hbm_frac_per_gpu"]))
+            for mdl, pp in pts.items():
+                ok = sorted(b for b, f in pp if f >= 0.70)
+                reach[mdl] = {"smallest_batch_with_step_hbm_frac_ge_0.70": ok[0] if ok else None, "measured": {str(b): f for b, f in sorted(pp)}}
+            out["batch_for_0.70_of_step_roofline"] = reach
+        if stochastic is not None:
+            out["stochastic"] = stochastic
         if bf16_block is not None:
             out["bf16"] = bf16_block
         if default_engine is not None:

@@ -43,7 +43,10 @@ impl Drop for Sequence { fn drop(&mut self) { if self.owned { unsafe { ffi::nvr_
 
 // ---- SamplingParams (src/engine/sampling_params.rs:10-28)
 #[derive(Clone, Debug)]
-pub struct SamplingParams { pub temperature: f32, pub max_tokens: usize, pub ignore_eos: bool, pub top_p: Option<f32>, pub top_k: Option<usize> }
+pub struct SamplingParams {
+    pub temperature: f32, pub max_tokens: usize, pub ignore_eos: bool, pub top_p: Option<f32>, pub top_k: Option<usize>,
+    pub repetition_penalty: Option<f32>,                                                                      // :27 (carried and validated, :112-117; the reference's sampler never reads it)
+}
 impl SamplingParams {
     pub fn to_c(&self) -> ffi::nvr_sampling_params {
         let mut c = unsafe { std::mem::zeroed::<ffi::nvr_sampling_params>() };
@@ -51,6 +54,7 @@ impl SamplingParams {
         c.temperature = self.temperature; c.max_tokens = self.max_tokens as u64; c.ignore_eos = self.ignore_eos as i32;
         if let Some(p) = self.top_p { c.has_top_p = 1; c.top_p = p; }
         if let Some(k) = self.top_k { c.has_top_k = 1; c.top_k = k as u64; }
+        if let Some(r) = self.repetition_penalty { c.has_repetition_penalty = 1; c.repetition_penalty = r; }
         c
     }
     pub fn validate(&self) -> anyhow::Result<()> { check(unsafe { ffi::nvr_sampling_params_validate(&self.to_c()) }) }   // :91-119

@@ -168,10 +168,12 @@ __global__ __launch_bounds__(WAVES * 64) void linear_stream_kernel(const half_t 
     };
     constexpr int ET = PRE > 0 ? PRE : TMAX;                                 // tiles a workgroup can hold
     float4_t cs_pre[EPI == SEPI_ROPE ? ET : 1], sn_pre[EPI == SEPI_ROPE ? ET : 1];
+    // (landed long ago — they are older than the image fills that have been waited for — but the compiler cannot know that of an asm load: the wait is
+    //  written down here, where nothing is in flight and it costs nothing, and the values are tied to it.  By EVERY wave, outside the branch of the
+    //  requesting waves: every control-flow path from a request to a use of its register passes this wait, which tools/check_kernel_isa.py verifies
+    //  on the ISA without having to know that `wave < MT` below is the condition the requests were issued under — ADVICE r05)
+    if (EPI == SEPI_ROPE) asm volatile("s_waitcnt vmcnt(0)" : "+v"(pos_pre), "+v"(slot_pre) : : "memory");
     if (EPI == SEPI_ROPE && wave < MT) {
-        // (landed long ago — they are older than the image fills that have been waited for — but the compiler cannot know that of an asm load: the
-        //  wait is written down here, where nothing is in flight and it costs nothing, and the values are tied to it)
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(pos_pre), "+v"(slot_pre) : : "memory");
         const int tph = epi.D / 16, half_d = epi.D / 2;
 #pragma unroll
         for (int i = 0; i < ET; ++i) {

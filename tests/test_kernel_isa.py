@@ -31,3 +31,11 @@ def test_attention_merge_arithmetic_has_one_form_in_every_instantiation():
     reads the generated ISA of every attn_rows_kernel / attn_merge_kernel instantiation."""
     import check_kernel_isa
     assert check_kernel_isa.check_attention_merge_forms(verbose=False) == []
+
+
+@pytest.mark.skipif(not os.path.exists(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")), reason="hipcc not installed")
+def test_linear_stream_rope_requests_are_not_touched_before_their_wait():
+    """the inline-asm position / slot prefetch of the streaming qkv GEMM's RoPE epilogue (kernels/linear_stream.hip, both builds) — no scratch,
+    no spilled VGPRs, and the destination registers are neither read nor written before the vmcnt wait that covers the requests."""
+    import check_kernel_isa
+    assert check_kernel_isa.check_linear_stream(verbose=False) == []

@@ -171,8 +171,79 @@ def _check_gemm_tiled_build(text, verbose):
     return bad
 
 
+def check_linear_stream(verbose=True):
+    """linear_stream_kernel<.., SEPI_ROPE, ..> asks for its rows' RoPE positions (global_load_dwordx2) and cache slots (global_load_dword) by
+    inline asm in front of the weight stream and ties the registers to an explicit s_waitcnt vmcnt(0) in the epilogue; until then the compiler believes they
+    are defined.  Per instantiation holding such requests, both builds: no scratch traffic, no spilled VGPRs (SGPR spills to VGPR lanes are register moves
+    and are reported, not failed: the PRE = 2 instantiations carry 4-6), and no instruction reads or writes a destination register between its request and
+    the first vmcnt wait that covers it."""
+    bad = []
+    for build in ((), ("-DNVR_BF16",)):
+        text = compile_isa("kernels/linear_stream.hip", flags=("-ffp-contract=off",) + build)
+        meta = {m.group(1): (int(m.group(2)), int(m.group(3))) for m in re.finditer(
+            r"\.name:\s+(\S+)\n(?:.*\n)*?\s+\.sgpr_spill_count:\s+(\d+)\n(?:.*\n)*?\s+\.vgpr_spill_count:\s+(\d+)", text)}
+        found = 0
+        for m in re.finditer(r"^(_Z\w*linear_stream_kernel\w*):[^\n]*\n(.*?)s_endpgm", text, re.S | re.M):
+            name, body = m.group(1), m.group(2)
+            lines = [l.strip() for l in body.split("\n")]
+            reqs = [i for i, l in enumerate(lines) if l.startswith(("global_load_dwordx2", "global_load_dword ")) and i > 0 and lines[i - 1].startswith(";;#ASMSTART")]
+            if not reqs:
+                continue
+            found += 1
+            problems = []
+            if any(l.startswith("scratch_") for l in lines):
+                problems.append("scratch traffic")
+            if name in meta and meta[name][1]:
+                problems.append(f"{meta[name][1]} spilled VGPRs")
+            labels = {l[:-1]: k for k, l in enumerate(lines) if re.match(r"^\.LBB\d+_\d+:$", l)}
+            for i in reqs:
+                # every control-flow path from the request (the requests sit in branches of their own: `if (epi.slots)` has an else that sets the register
+                # to -1 and is never on the request's path) until a vmcnt wait that covers it
+                dst = _vregs(lines[i].split()[1].rstrip(","))
+                work, seen, uncovered = [(i + 1, 0)], set(), False
+                while work and not problems:
+                    k, younger = work.pop()
+                    while k < len(lines):
+                        if k in seen:
+                            break
+                        seen.add(k)
+                        l = lines[k]; k += 1
+                        if not l or l.startswith((";", ".")):
+                            continue
+                        w = re.match(r"s_waitcnt.*vmcnt\((\d+)\)", l)
+                        if w and int(w.group(1)) <= younger:
+                            break                                            # covered on this path
+                        br = re.match(r"(s_branch|s_cbranch_\w+)\s+(\.LBB\d+_\d+)", l)
+                        if br:
+                            if br.group(2) in labels:
+                                work.append((labels[br.group(2)], younger))
+                            if br.group(1) == "s_branch":
+                                break
+                            continue
+                        if l.startswith("s_endpgm"):
+                            uncovered = True
+                            break
+                        ops = re.findall(r"v\[\d+:\d+\]|v\d+", l)
+                        if any(_vregs(o) & dst for o in ops):
+                            problems.append(f"v{sorted(dst)} touched before its wait: {l}")
+                            break
+                        if l.startswith(("global_load", "buffer_load", "flat_load")):
+                            younger += 1
+                    else:
+                        uncovered = True
+                if uncovered and not problems:
+                    problems.append("a path from the request reaches the end of the kernel without a covering wait")
+            if verbose:
+                sg = meta.get(name, (0, 0))[0]
+                print(f"{name[:100]:100s} {'OK' if not problems else '; '.join(sorted(set(problems)))}  ({len(reqs)} asm requests, {sg} SGPR spills)")
+            bad += [name + ": " + q for q in sorted(set(problems))]
+        if found < 2:
+            bad.append(f"only {found} linear_stream_kernel instantiations with inline-asm requests found ({' '.join(build) or 'fp16'})")
+    return bad
+
+
 if __name__ == "__main__":
-    problems = check_flash() + check_gemm_tiled() + check_attention_merge_forms()
+    problems = check_flash() + check_gemm_tiled() + check_linear_stream() + check_attention_merge_forms()
     for p in problems:
         print("FAIL", p)
     sys.exit(1 if problems else 0)
