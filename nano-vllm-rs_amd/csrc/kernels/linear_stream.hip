@@ -13,6 +13,8 @@
 // split the k-steps of each tile (wave j takes k-steps j, j+8, ...: neighbouring waves read neighbouring 64-byte pieces of the
 // same weight rows, U pieces in flight per wave = 32 KiB per CU) and the partial sums meet in LDS once per tile at the end.
 // Roofline: HBM, algorithmic bytes 2·N·K.  Rounding points as in linear.hip.
+#include <algorithm>
+#include <type_traits>
 #include <cstdlib>
 #include "kernels.h"
 #include "device_utils.h"
@@ -46,7 +48,21 @@ __device__ __forceinline__ int s_w_row(int t, int nt, int r, int N, const Stream
 // with two tiles of Qwen3-8B's qkv (50 MB in 21.3 us = 2.4 TB/s, scratch/prof_8b.sh).  The weight pieces depend on nothing: with PRE every wave
 // requests ALL its pieces of the chunk (PRE tiles x 8 k-steps, 64 registers) in front of the fill, and the fill asks for its 16 pieces per thread
 // at once — one round trip per chunk.  The MFMAs of an accumulator run over the k-steps in the order they always had: the same bits.
-template <int NTT, int MT, int WAVES, int U, int EPI, int TMAX, int PRE = 0>
+//
+// IMG (r06; at most IMG tiles per workgroup, KC = 1024): the activation image leaves the critical path.  r05's ablation of the Qwen3-8B qkv launch (19.2 us)
+// put ~6 us on the two image fills — a stage of their own per chunk: an L2 round trip under load, 128 KiB of LDS writes and a barrier, with the weight
+// pieces already landed and waiting (profiles/r05_priced_levers.txt 8., 14.).  Here the image is double-buffered in LDS (2 x 32 rows x 1024 columns =
+// 128 KiB) and filled by LDS-DMA (global_load_lds: no registers, no ds_write): chunk c + 1's image is requested right behind the barrier that opens
+// chunk c and flies under that chunk's MFMAs and the weight round trip behind them; a chunk boundary is ONE barrier.  The weight pieces keep r05's
+// shape (every wave requests all its pieces of a chunk at once); where two register sets fit (one weight part per tile: 2 x IMG x 4 pieces = 64
+// registers) chunk c + 2's pieces are requested as soon as chunk c's MFMAs have read theirs, so two chunks of weights (128 KiB per CU) are in flight
+// all the time, counted s_waitcnt vmcnt(pieces of one chunk) leaving the younger one in flight (vmcnt retires in issue order: image c was requested
+// before the weights of chunk c + 1).  gate_up (two parts per tile, three tiles) has one register set: issue, wait, barrier, MFMAs per chunk, the image
+// of the next chunk under all of it.  A wave's k-steps are those it always had (k = 32 wave mod 256, ascending), the cross-wave order too: the same bits.
+// NC = K / 1024 is a template argument and the chunk sequence straight-line code: given these loads inside a LOOP next to the LDS-DMA requests, hipcc's
+// s_waitcnt pass drains vmcnt(0) in front of every MFMA block and every new request (one chunk in flight, the next image exposed), and weight pieces
+// requested by inline asm to hide them from that pass get COPIED at the loop's phi nodes while still in flight (caught by tools/check_kernel_isa.py).
+template <int NTT, int MT, int WAVES, int U, int EPI, int TMAX, int PRE = 0, int IMG = 0, int NC = 0>
 __global__ __launch_bounds__(WAVES * 64) void linear_stream_kernel(const half_t *__restrict__ x, int64_t ldx,
                                                                    const half_t *__restrict__ W, int T, int K, int N, int KC,
                                                                    int ntiles, half_t *__restrict__ y, StreamEpi epi) {
@@ -68,15 +84,134 @@ __global__ __launch_bounds__(WAVES * 64) void linear_stream_kernel(const half_t 
         if (epi.slots) { const int32_t *ssrc = epi.slots + (m < T ? m : T - 1); asm volatile("global_load_dword %0, %1, off" : "=v"(slot_pre) : "v"(ssrc) : "memory"); }
     }
 
-    float4_t acc[TMAX][NTT][MT];
+    constexpr int TT = IMG > 0 ? IMG : TMAX;                                 // tiles (accumulator sets) a workgroup can hold
+    float4_t acc[TT][NTT][MT];
 #pragma unroll
-    for (int i = 0; i < TMAX; ++i)
+    for (int i = 0; i < TT; ++i)
 #pragma unroll
         for (int nt = 0; nt < NTT; ++nt)
 #pragma unroll
             for (int j = 0; j < MT; ++j) acc[i][nt][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
 
-    for (int kc0 = 0; kc0 < K; kc0 += KC) {
+    if constexpr (IMG > 0) {
+        static_assert(IMG <= TMAX && IMG <= 3 && PRE == 0 && NC >= 1, "IMG: tiles held by a workgroup, NC chunks of 1024 columns");
+        constexpr int KPW2 = 4;                                              // k-steps per wave and chunk
+        constexpr int KC2 = KPW2 * WAVES * 32, cpr2 = KC2 / 8;               // 1024 columns (the host passes KC = KC2, K = NC * KC2)
+        const int kmul = epi.tiled ? 16 : 1;
+        constexpr int img_bytes = ROWS * KC2 * 2;
+        int ntl = 0;                                                         // live tiles of this workgroup (uniform)
+#pragma unroll
+        for (int i = 0; i < IMG; ++i) ntl += (int)(blockIdx.x + i * gridDim.x) < ntiles ? 1 : 0;
+        // this thread's byte offset inside a 16-row weight tile: row r (through the epilogue's row map: s_w_row(tile, nt, r) - s_w_row(tile, nt, 0), the same
+        // for every tile but, row-major RoPE weights, different for rotary and value heads), 16-byte piece q, this wave's first k-step
+        const int rot_r = (EPI == SEPI_ROPE) ? (r < 8 ? r : epi.D / 2 + (r - 8)) : r;
+        const unsigned voff = epi.tiled ? (unsigned)((r * 32 + q * 8 + wave * 512) * 2) : (unsigned)(((int64_t)rot_r * K + q * 8 + wave * 32) * 2);
+        const unsigned voff_v = (unsigned)(((int64_t)r * K + q * 8 + wave * 32) * 2);
+        auto issue_img = [&](int c, int buf) {
+            char *dst = smem + buf * img_bytes;
+            constexpr int total = ROWS * cpr2;                               // 16-byte pieces, lane-linear in LDS: slot p = row * cpr2 + s holds chunk s ^ (row & 7)
+            static_assert(total % (WAVES * 64) == 0, "whole rounds of image pieces");
+#pragma unroll
+            for (int it = 0; it < total / (WAVES * 64); ++it) {
+                const int p0 = it * WAVES * 64 + wave * 64, p = p0 + lane, row = p / cpr2, ch = (p % cpr2) ^ (row & 7);
+                const half_t *src = x + (int64_t)(row < T ? row : T - 1) * ldx + c * KC2 + ch * 8;
+                __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void *)(dst + p0 * 16), 16, 0, 0);
+            }
+        };
+        // One straight-line body per number of live tiles NTL (1 .. IMG), picked once: no loop and no branch between a request and its wait.  The weight
+        // pieces are requested by inline asm and waited for by hand-counted s_waitcnt: shown to the compiler next to the LDS-DMA requests, its own
+        // s_waitcnt pass treats vmcnt as out of order (global_load_lds touches two address spaces) and drains vmcnt(0) in front of every MFMA block — one
+        // chunk in flight, the next image exposed.  An inline-asm load is only safe while nothing copies its destination before it has landed: with loops
+        // or uniform branches in between hipcc puts such copies at the phi nodes (seen; tools/check_kernel_isa.py reads the ISA of every instantiation:
+        // no scratch, every destination untouched until the wait that covers it).
+        auto body = [&](auto ntl_c) {
+            constexpr int NTL = decltype(ntl_c)::value;
+            constexpr bool DB = NTL * NTT * KPW2 * 2 <= 16;                  // two register sets of weight pieces (<= 64 VGPRs)
+            constexpr int NW = NTL * NTT * KPW2;                             // vector-memory requests of one chunk of weight pieces, per wave
+            // address of a piece = a UNIFORM base (tile, part, chunk, k-step: scalar registers) + the thread's byte offset inside a 16-row tile (one VGPR
+            // for the whole kernel; two for row-major qkv weights, whose rotary and value heads order their rows differently): as 64-bit per-thread
+            // pointers the NC x NTL x NTT x 4 addresses were hoisted and spilled (gate_up: 96 pointers per chunk)
+            auto issue_w = [&](half8_t (&a)[NTL][NTT][KPW2], int c) {
+#pragma unroll
+                for (int i = 0; i < NTL; ++i) {
+                    const int tile = blockIdx.x + i * gridDim.x;
+#pragma unroll
+                    for (int nt = 0; nt < NTT; ++nt) {
+                        const half_t *base = epi.tiled ? W + ((int64_t)(EPI == SEPI_SILU ? nt * (N / 16) + tile : tile) * (K / 32) + (c * KC2) / 32) * 512
+                                                       : W + (int64_t)s_w_row<EPI>(tile, nt, 0, N, epi) * K + c * KC2;
+                        const unsigned vo = (EPI == SEPI_ROPE && !epi.tiled && tile / (epi.D / 16) >= epi.H + epi.KVH) ? voff_v : voff;
+#pragma unroll
+                        for (int u = 0; u < KPW2; ++u) {
+                            const half_t *bu = base + (int64_t)(u * WAVES * 32) * kmul;
+                            asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(a[i][nt][u]) : "v"(vo), "s"(bu) : "memory");
+                        }
+                    }
+                }
+            };
+            auto pin = [&](half8_t (&a)[NTL][NTT][KPW2]) {                   // uses of the pieces stay behind the wait in front of this (volatile asms keep their order)
+#pragma unroll
+                for (int i = 0; i < NTL; ++i)
+#pragma unroll
+                    for (int nt = 0; nt < NTT; ++nt)
+#pragma unroll
+                        for (int u = 0; u < KPW2; ++u) asm volatile("" : "+v"(a[i][nt][u]));
+            };
+            auto mfmas = [&](const half8_t (&a)[NTL][NTT][KPW2], int buf) {
+                const char *img = smem + buf * img_bytes;
+#pragma unroll
+                for (int i = 0; i < NTL; ++i)
+#pragma unroll
+                    for (int u = 0; u < KPW2; ++u) {
+                        const int ch = ((wave * 32 + u * WAVES * 32) >> 3) + q;
+#pragma unroll
+                        for (int j = 0; j < MT; ++j) {
+                            const int row = j * 16 + r;
+                            const half8_t b = *reinterpret_cast<const half8_t *>(img + (row * cpr2 + (ch ^ (r & 7))) * 16);
+#pragma unroll
+                            for (int nt = 0; nt < NTT; ++nt) acc[i][nt][j] = mfma16(a[i][nt][u], b, acc[i][nt][j]);
+                        }
+                    }
+            };
+            issue_img(0, 0);
+            if constexpr (DB) {
+                // issue order: img 0, w 0, w 1 | chunk c: [wait: all but the youngest NW = w c+1] barrier, img c+1, MFMAs c, w c+2 — so at the top of chunk
+                // c + 1 the requests in flight are, oldest first, w c+1, img c+1, w c+2: vmcnt(NW) leaves exactly w c+2
+                half8_t a0[NTL][NTT][KPW2], a1[NTL][NTT][KPW2];
+                issue_w(a0, 0);
+                if constexpr (NC > 1) issue_w(a1, 1);
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    auto &a = (c & 1) ? a1 : a0;
+                    if (c + 1 < NC) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    pin(a);
+                    __builtin_amdgcn_s_barrier();                            // image c complete; nobody reads buffer (c + 1) & 1 any more
+                    if (c + 1 < NC) issue_img(c + 1, (c + 1) & 1);
+                    __builtin_amdgcn_sched_barrier(0);                       // (the counted waits rest on the ISSUE ORDER image c + 1, then weights c + 2)
+                    mfmas(a, c & 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (c + 2 < NC) issue_w(a, c + 2);
+                }
+            } else {
+                half8_t a[NTL][NTT][KPW2];
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    issue_w(a, c);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // image c (older) and this chunk's pieces
+                    pin(a);
+                    __builtin_amdgcn_s_barrier();
+                    if (c + 1 < NC) issue_img(c + 1, (c + 1) & 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfmas(a, c & 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        };
+        if (ntl <= 1) body(std::integral_constant<int, 1>{});
+        else if (IMG >= 2 && ntl == 2) body(std::integral_constant<int, (IMG >= 2 ? 2 : 1)>{});
+        else body(std::integral_constant<int, IMG>{});
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // (nothing is in flight here; written down for every path)
+    }
+    for (int kc0 = 0; IMG == 0 && kc0 < K; kc0 += KC) {
         if constexpr (PRE > 0) {
             static_assert(NTT == 1 && PRE <= TMAX, "PRE: one weight part per tile");
             constexpr int KPW = 8;                                           // k-steps per wave and chunk (host: KC <= KPW * WAVES * 32)
@@ -121,7 +256,7 @@ __global__ __launch_bounds__(WAVES * 64) void linear_stream_kernel(const half_t 
         fill_x_image<ROWS, WAVES * 64, 8>(smem, x, ldx, kc0, cpr, T, tid);
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < TMAX; ++i) {
+        for (int i = 0; i < TT; ++i) {
             const int tile = blockIdx.x + i * gridDim.x;
             if (tile >= ntiles) break;
             const half_t *wr[NTT];
@@ -166,7 +301,7 @@ __global__ __launch_bounds__(WAVES * 64) void linear_stream_kernel(const half_t 
         for (int w2 = 1; w2 < WAVES; ++w2) s += part[(w2 * NTT * MT + slot) * 64 + lane];
         return s;
     };
-    constexpr int ET = PRE > 0 ? PRE : TMAX;                                 // tiles a workgroup can hold
+    constexpr int ET = IMG > 0 ? IMG : PRE > 0 ? PRE : TMAX;                 // tiles a workgroup can hold
     float4_t cs_pre[EPI == SEPI_ROPE ? ET : 1], sn_pre[EPI == SEPI_ROPE ? ET : 1];
     // (landed long ago — they are older than the image fills that have been waited for — but the compiler cannot know that of an asm load: the wait is
     //  written down here, where nothing is in flight and it costs nothing, and the values are tied to it.  By EVERY wave, outside the branch of the
@@ -185,7 +320,7 @@ __global__ __launch_bounds__(WAVES * 64) void linear_stream_kernel(const half_t 
         }
     }
 #pragma unroll
-    for (int i = 0; i < TMAX; ++i) {
+    for (int i = 0; i < TT; ++i) {
         const int tile = blockIdx.x + i * gridDim.x;
         if (tile >= ntiles) break;
         __syncthreads();                                                     // image / previous tile's scratch no longer read
@@ -286,6 +421,17 @@ static int stream_launch(const half_t *x, int64_t ldx, const half_t *W, int T, i
     const size_t scratch = (size_t)S_WAVES * NTT * MT * 64 * 16;
     if (lds < scratch) lds = scratch;
     const int nwg = ntiles < 256 ? ntiles : 256;
+    {   // r06: double-buffered LDS-DMA image, 1024-column chunks (IMG): up to 2 tiles per workgroup with one weight part each (qkv, plain), 3 with two (gate_up)
+        constexpr int IMGT = NTT == 1 ? 2 : 3;
+        if ((K == 2048 || K == 4096) && ntiles <= IMGT * nwg) {               // (NC = 2: hidden 2048; NC = 4: hidden 4096 — Qwen3-8B; other widths keep the r05 kernels)
+            const size_t lds2 = std::max<size_t>((size_t)2 * MT * 16 * 1024 * 2, scratch);
+            if (K == 4096) linear_stream_kernel<NTT, MT, S_WAVES, U, EPI, S_TMAX, 0, IMGT, 4><<<dim3((unsigned)nwg), dim3(S_WAVES * 64), lds2, s>>>(x, ldx, W, T, K, N, 1024, ntiles, y, e);
+            else linear_stream_kernel<NTT, MT, S_WAVES, U, EPI, S_TMAX, 0, IMGT, 2><<<dim3((unsigned)nwg), dim3(S_WAVES * 64), lds2, s>>>(x, ldx, W, T, K, N, 1024, ntiles, y, e);
+            hipError_t er = hipGetLastError();
+            if (er != hipSuccess) return nvr::fail(NVR_ERR_HIP, "linear_stream launch failed: %s", hipGetErrorString(er));
+            return 0;
+        }
+    }
     if constexpr (NTT == 1) {
         if (kc <= 8 * S_WAVES * 32 && ntiles <= 2 * nwg) {                   // all weight pieces of a chunk requested in front of the fill (PRE)
             linear_stream_kernel<NTT, MT, S_WAVES, U, EPI, S_TMAX, 2><<<dim3((unsigned)nwg), dim3(S_WAVES * 64), lds, s>>>(x, ldx, W, T, K, N, kc, ntiles, y, e);
@@ -307,7 +453,13 @@ int linear_stream_prepare() {
         reinterpret_cast<const void *>(&linear_stream_kernel<2, 1, S_WAVES, 2, SEPI_SILU, S_TMAX>), reinterpret_cast<const void *>(&linear_stream_kernel<2, 2, S_WAVES, 2, SEPI_SILU, S_TMAX>),
         reinterpret_cast<const void *>(&linear_stream_kernel<1, 1, S_WAVES, 4, SEPI_ROPE, S_TMAX>), reinterpret_cast<const void *>(&linear_stream_kernel<1, 2, S_WAVES, 4, SEPI_ROPE, S_TMAX>),
         reinterpret_cast<const void *>(&linear_stream_kernel<1, 1, S_WAVES, 4, SEPI_F16, S_TMAX, 2>), reinterpret_cast<const void *>(&linear_stream_kernel<1, 2, S_WAVES, 4, SEPI_F16, S_TMAX, 2>),
-        reinterpret_cast<const void *>(&linear_stream_kernel<1, 1, S_WAVES, 4, SEPI_ROPE, S_TMAX, 2>), reinterpret_cast<const void *>(&linear_stream_kernel<1, 2, S_WAVES, 4, SEPI_ROPE, S_TMAX, 2>)};
+        reinterpret_cast<const void *>(&linear_stream_kernel<1, 1, S_WAVES, 4, SEPI_ROPE, S_TMAX, 2>), reinterpret_cast<const void *>(&linear_stream_kernel<1, 2, S_WAVES, 4, SEPI_ROPE, S_TMAX, 2>),
+#define NVR_LS_IMG(NC_) \
+        reinterpret_cast<const void *>(&linear_stream_kernel<1, 1, S_WAVES, 4, SEPI_F16, S_TMAX, 0, 2, NC_>), reinterpret_cast<const void *>(&linear_stream_kernel<1, 2, S_WAVES, 4, SEPI_F16, S_TMAX, 0, 2, NC_>), \
+        reinterpret_cast<const void *>(&linear_stream_kernel<1, 1, S_WAVES, 4, SEPI_ROPE, S_TMAX, 0, 2, NC_>), reinterpret_cast<const void *>(&linear_stream_kernel<1, 2, S_WAVES, 4, SEPI_ROPE, S_TMAX, 0, 2, NC_>), \
+        reinterpret_cast<const void *>(&linear_stream_kernel<2, 1, S_WAVES, 2, SEPI_SILU, S_TMAX, 0, 3, NC_>), reinterpret_cast<const void *>(&linear_stream_kernel<2, 2, S_WAVES, 2, SEPI_SILU, S_TMAX, 0, 3, NC_>)
+        NVR_LS_IMG(2), NVR_LS_IMG(4)};
+#undef NVR_LS_IMG
     for (const void *f : fns) {
         hipError_t er = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (er != hipSuccess) return nvr::fail(NVR_ERR_HIP, "linear_stream: hipFuncSetAttribute: %s", hipGetErrorString(er));

@@ -172,7 +172,8 @@ def _check_gemm_tiled_build(text, verbose):
 
 
 def check_linear_stream(verbose=True):
-    """linear_stream_kernel<.., SEPI_ROPE, ..> asks for its rows' RoPE positions (global_load_dwordx2) and cache slots (global_load_dword) by
+    """(r06: also the weight pieces of the IMG instantiations — global_load_dwordx4 by inline asm, two chunks in flight behind hand-counted waits.)
+    ADVICE r05: linear_stream_kernel<.., SEPI_ROPE, ..> asks for its rows' RoPE positions (global_load_dwordx2) and cache slots (global_load_dword) by
     inline asm in front of the weight stream and ties the registers to an explicit s_waitcnt vmcnt(0) in the epilogue; until then the compiler believes they
     are defined.  Per instantiation holding such requests, both builds: no scratch traffic, no spilled VGPRs (SGPR spills to VGPR lanes are register moves
     and are reported, not failed: the PRE = 2 instantiations carry 4-6), and no instruction reads or writes a destination register between its request and
@@ -186,7 +187,7 @@ def check_linear_stream(verbose=True):
         for m in re.finditer(r"^(_Z\w*linear_stream_kernel\w*):[^\n]*\n(.*?)s_endpgm", text, re.S | re.M):
             name, body = m.group(1), m.group(2)
             lines = [l.strip() for l in body.split("\n")]
-            reqs = [i for i, l in enumerate(lines) if l.startswith(("global_load_dwordx2", "global_load_dword ")) and i > 0 and lines[i - 1].startswith(";;#ASMSTART")]
+            reqs = [i for i, l in enumerate(lines) if l.startswith(("global_load_dwordx2", "global_load_dword ", "global_load_dwordx4")) and i > 0 and lines[i - 1].startswith(";;#ASMSTART")]
             if not reqs:
                 continue
             found += 1
@@ -200,13 +201,13 @@ def check_linear_stream(verbose=True):
                 # every control-flow path from the request (the requests sit in branches of their own: `if (epi.slots)` has an else that sets the register
                 # to -1 and is never on the request's path) until a vmcnt wait that covers it
                 dst = _vregs(lines[i].split()[1].rstrip(","))
-                work, seen, uncovered = [(i + 1, 0)], set(), False
+                work, seen, uncovered = [(i + 1, 0)], {}, False
                 while work and not problems:
                     k, younger = work.pop()
                     while k < len(lines):
-                        if k in seen:
+                        if seen.get(k, 1 << 30) <= younger:                  # (reached before with no more requests behind the one checked: nothing new)
                             break
-                        seen.add(k)
+                        seen[k] = younger
                         l = lines[k]; k += 1
                         if not l or l.startswith((";", ".")):
                             continue
