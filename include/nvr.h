@@ -584,6 +584,16 @@ NVR_API int nvr_attn_prefill_paged(const nvr_half *q, int64_t ldq, const nvr_hal
                                    float scale, nvr_half *out, void *stream);
 /* K13 SiluAndMul, activation.rs:46-63: [T,2I] -> [T,I] */
 NVR_API int nvr_silu_and_mul(const nvr_half *x, int64_t T, int64_t I, nvr_half *out, void *stream);
+/* The rest of src/layers/activation.rs (r06; not on the Qwen3 path, which uses SiluAndMul only): ActivationType (:111-117), its FromStr (:169-182) and
+ * Activation::forward (:147-159).  nvr_activation: [T, cols] -> [T, cols] for NVR_ACT_SILU (:12-15), NVR_ACT_GELU (:20-22: candle's tanh form) and
+ * NVR_ACT_RELU (:25-27); [T, cols] -> [T, cols / 2] = act(x[:, :cols/2]) * x[:, cols/2:] for NVR_ACT_SILU_AND_MUL (:46-63) and NVR_ACT_GELU_AND_MUL
+ * (:74-100) — an odd cols is NVR_ERR_INVALID_ARG with the reference's message (:50-52, :88-90); output columns % 8 == 0.  f32 inside, one rounding to
+ * the ops' 16-bit type at the store; under nvr_ops_set_dtype("float32") the pointers address f32 elements.  nvr_activation_type_from_str: "silu" |
+ * "swish" | "gelu" | "relu" | "silu_and_mul" | "siluandmul" | "gelu_and_mul" | "geluandmul", case-insensitive; anything else NVR_ERR_INVALID_ARG
+ * ("Unknown activation function: ..."). */
+typedef enum nvr_activation_type { NVR_ACT_SILU = 0, NVR_ACT_GELU = 1, NVR_ACT_RELU = 2, NVR_ACT_SILU_AND_MUL = 3, NVR_ACT_GELU_AND_MUL = 4 } nvr_activation_type;
+NVR_API int nvr_activation_type_from_str(const char *name, int32_t *type_out);
+NVR_API int nvr_activation(int32_t type, const nvr_half *x, int64_t T, int64_t cols, nvr_half *out, void *stream);
 /* The bias of a Linear with Qwen3Config::use_bias (A-30): y[T,N] <- 16bit(y + b[N]) in place, N % 8 == 0 — candle_nn::Linear::forward is
  * matmul, then broadcast_add, each rounding to the tensor dtype; linear.rs:124-139 (column-parallel: the local slice of b),
  * :206 / :228-239 (row-parallel: rank 0 only, before the all-reduce) */

@@ -239,6 +239,7 @@ _SIGS = {
     "nvr_attn_prefill_paged": (C.c_int, [_P, C.c_int64, _P, _P, C.POINTER(AttnMetaC), C.c_int64, C.c_int64, C.c_int64, C.c_int64,
                                          C.c_int64, C.c_float, _P, _P]),
     "nvr_silu_and_mul": (C.c_int, [_P, C.c_int64, C.c_int64, _P, _P]),
+    "nvr_activation": (C.c_int, [C.c_int32, _P, C.c_int64, C.c_int64, _P, _P]), "nvr_activation_type_from_str": (C.c_int, [C.c_char_p, C.POINTER(C.c_int32)]),
     "nvr_add_bias": (C.c_int, [_P, _P, C.c_int64, C.c_int64, _P]),
     "nvr_select_last_tokens": (C.c_int, [_P, _P, C.c_int64, C.c_int64, _P, _P]),
     "nvr_argmax": (C.c_int, [_P, C.c_int64, C.c_int64, _P, _P]),

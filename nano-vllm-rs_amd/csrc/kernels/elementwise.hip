@@ -332,6 +332,46 @@ int silu_and_mul(const half_bits *x, int64_t T, int64_t I, half_bits *out, hipSt
     return 0;
 }
 
+// ---------------------------------------------------------------- the rest of src/layers/activation.rs: silu (:12-15), gelu (:20-22, candle's tanh
+// form 0.5 x (1 + tanh(sqrt(2/pi) x (1 + 0.044715 x^2)))), relu (:25-27), GeluAndMul (:74-100) and the ActivationType dispatch (:111-163).
+// One launch for every type: 8 elements per thread, f32 inside, one rounding to the 16-bit type at the store (A-22).  kind: 0 silu, 1 gelu, 2 relu
+// ([T, cols] -> [T, cols]); 3 SiluAndMul, 4 GeluAndMul ([T, 2 I] -> [T, I]: act(x[:, :I]) * x[:, I:]).  SiluAndMul here is the exact-division form of the
+// oracle (the K13 kernel above keeps its v_exp + v_rcp sigmoid: the GEMM epilogues share it bit for bit).
+__device__ __forceinline__ float act_one(int kind, float g) {
+    if (kind == 1 || kind == 4) { const float inner = 0.7978845608028654f * g * (1.0f + 0.044715f * g * g); return 0.5f * g * (1.0f + tanhf(inner)); }
+    if (kind == 2) return fmaxf(g, 0.0f);
+    return g * (1.0f / (1.0f + expf(-g)));
+}
+__global__ void activation_kernel(int kind, const half_t *__restrict__ x, int cols_in, int cols_out, half_t *__restrict__ out, int64_t total8) {
+    const int per_row = cols_out / 8;
+    const bool mul = kind >= 3;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total8; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t t = i / per_row; const int c = (int)(i % per_row) * 8;
+        const half8_t g = *reinterpret_cast<const half8_t *>(x + t * cols_in + c);
+        half8_t u = g;
+        if (mul) u = *reinterpret_cast<const half8_t *>(x + t * cols_in + cols_out + c);
+        half8_t o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float a = act_one(kind, (float)g[j]);
+            o[j] = to_half_rn(mul ? a * (float)u[j] : a);
+        }
+        *reinterpret_cast<half8_t *>(out + t * cols_out + c) = o;
+    }
+}
+int activation(int kind, const half_bits *x, int64_t T, int64_t cols, half_bits *out, hipStream_t s) {
+    if (kind < 0 || kind > 4) return nvr::fail(NVR_ERR_INVALID_ARG, "activation: unknown type %d", kind);
+    if (kind >= 3 && cols % 2) return nvr::fail(NVR_ERR_INVALID_ARG, "Input dimension must be even for %s, got %ld", kind == 3 ? "SiluAndMul" : "GeluAndMul", (long)cols);
+    const int64_t cols_out = kind >= 3 ? cols / 2 : cols;
+    if (cols_out % 8) return nvr::fail(NVR_ERR_UNSUPPORTED, "activation: %ld output columns are not a multiple of 8", (long)cols_out);
+    const int64_t total8 = T * (cols_out / 8);
+    if (total8 == 0) return 0;
+    int64_t blocks = (total8 + 255) / 256; if (blocks > 4096) blocks = 4096;
+    activation_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(kind, (const half_t *)x, (int)cols, (int)cols_out, (half_t *)out, total8);
+    LAUNCH_CHECK();
+    return 0;
+}
+
 // ---------------------------------------------------------------- bias of a projection (Qwen3Config::use_bias, qwen3.rs:54-55)
 // reference: candle_nn::Linear::forward behind src/layers/linear.rs:12-24 — the matmul's 16-bit result, then broadcast_add(bias): y <- 16bit(y + b)
 // (A-30: two tensor ops, two roundings; row kernels carry no FMA contraction, so this is the oracle's add bit for bit)

@@ -1,7 +1,7 @@
 // f32_path.hip — Config.dtype = "float32" (reference src/config.rs:51,113-116; the reference's own CPU path computes in f32): every op of the
 // Qwen3 graph on 4-byte storage, as plain FMA kernels.  This is the REFERENCE-PRECISION path of the product — outputs comparable with the
-// reference's f32 CPU path at 1e-3 instead of through 16-bit rounding — not a tuned one: no MFMA (the dense f32 matrix rate of the part is
-// 1/16 of its fp16 rate), one GPU.  Each kernel cites the reference op it restates, like its 16-bit twin:
+// reference's f32 CPU path at 1e-3 instead of through 16-bit rounding — a parity vehicle first: FMA kernels for the decode-sized steps, the f32
+// matrix cores (v_mfma_f32_32x32x2_f32, 1/16 of the fp16 rate) for the GEMMs of prefill-sized steps since r06.  Each kernel cites the reference op it restates, like its 16-bit twin:
 //   embedding   VocabParallelEmbedding::forward, src/layers/embed_head.rs:77-97
 //   rmsnorm     RMSNorm::forward_simple, src/layers/layernorm.rs:58-75; add_rmsnorm: forward_with_residual :170-176
 //   linear      Linear::forward x·Wᵀ(+b), src/layers/linear.rs:12-24
@@ -183,6 +183,84 @@ __global__ __launch_bounds__(256) void linear_kernel(const float *__restrict__ x
             if (t < T && n < N) y[(int64_t)t * N + n] = bias ? acc[i][j] + bias[n] : acc[i][j];
         }
 }
+// ---------------------------------------------------------------- the same GEMM on the matrix cores (r06): prefill-sized steps
+// (T > 8) of the float32 path ran the FMA kernel above at ~4 TFLOP/s (4.6 k prompt tokens/s on Qwen3-0.6B: 200 x under the fp16 build).
+// v_mfma_f32_32x32x2_f32: A = 32 W rows x 2 k, B = 2 k x 32 tokens, 16 f32 accumulators per lane; workgroup = 4 waves = 64 W rows x 64 tokens, BK = 32:
+// both operand tiles go global -> registers -> LDS as 16-byte pieces (row stride 36 floats: the 8-row groups of a ds_read_b128 land on different
+// banks), two LDS buffers, the next K-tile's global loads in flight under the MFMAs.  A lane owns ONE row of each operand (row = lane % 32) and the k
+// range [16 h, 16 h + 16) of the K-tile (h = lane / 32): four 16-byte LDS reads per operand give it the sixteen (a, b) pairs of sixteen MFMA steps — the
+// two halves of a wave cover k and k + 16 in the same instruction.  Sums are f32 throughout, in another order than the FMA chain's (the f32 oracle's
+// tolerance, 2e-4, is for exactly that); bias as before.  C layout: lane (h, token t = lane % 32) holds features 8 b + 4 h + e (b = reg / 4, e = reg % 4).
+constexpr int MB = 64, MKT = 32, MLD = MKT + 4;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(256) void linear_mfma_kernel(const float *__restrict__ x, int64_t ldx, const float *__restrict__ W, int T, int K, int N,
+                                                          const float *__restrict__ bias, float *__restrict__ y) {
+    __shared__ __attribute__((aligned(16))) float as[2][MB][MLD], bs[2][MB][MLD];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l32 = lane & 31, h = lane >> 5;
+    const int wn = wave >> 1, wm = wave & 1;                              // this wave: W rows n0 + 32 wn .., tokens t0 + 32 wm ..
+    const int t0 = blockIdx.y * MB, n0 = blockIdx.x * MB;
+    // staging: thread -> rows r and r + 32 of each tile, 16-byte piece c of the 128-byte K-tile row
+    const int r = tid >> 3, c = tid & 7;
+    const float *wsrc[2], *xsrc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        wsrc[i] = W + (int64_t)min(n0 + r + 32 * i, N - 1) * K + c * 4;
+        xsrc[i] = x + (int64_t)min(t0 + r + 32 * i, T - 1) * ldx + c * 4;
+    }
+    float4 wv[2], xv[2];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { wv[i] = *reinterpret_cast<const float4 *>(wsrc[i] + k0); xv[i] = *reinterpret_cast<const float4 *>(xsrc[i] + k0); }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            *reinterpret_cast<float4 *>(&as[buf][r + 32 * i][c * 4]) = wv[i];
+            *reinterpret_cast<float4 *>(&bs[buf][r + 32 * i][c * 4]) = xv[i];
+        }
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    const int KT = K / MKT;
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    for (int kt = 0; kt < KT; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < KT) fetch((kt + 1) * MKT);
+        float4 a4[4], b4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            a4[j] = *reinterpret_cast<const float4 *>(&as[cur][wn * 32 + l32][h * 16 + j * 4]);
+            b4[j] = *reinterpret_cast<const float4 *>(&bs[cur][wm * 32 + l32][h * 16 + j * 4]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j].x, b4[j].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j].y, b4[j].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j].z, b4[j].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j].w, b4[j].w, acc, 0, 0, 0);
+        }
+        if (kt + 1 < KT) stash(cur ^ 1);                                  // (the other buffer: last read in step kt - 1, before the barrier that ended it)
+        __syncthreads();
+    }
+    const int t = t0 + wm * 32 + l32;
+    if (t < T) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int n = n0 + wn * 32 + 8 * b + 4 * h;
+            if (n + 3 < N) {
+                float4 o = {acc[4 * b], acc[4 * b + 1], acc[4 * b + 2], acc[4 * b + 3]};
+                if (bias) { o.x += bias[n]; o.y += bias[n + 1]; o.z += bias[n + 2]; o.w += bias[n + 3]; }
+                *reinterpret_cast<float4 *>(y + (int64_t)t * N + n) = o;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (n + e < N) y[(int64_t)t * N + n + e] = bias ? acc[4 * b + e] + bias[n + e] : acc[4 * b + e];
+            }
+        }
+    }
+}
 // h + y and its RMSNorm for the T <= TT rows of a decode-sized step, INTO LDS (xs [TT][K]) — what rmsnorm_kernel<true> writes to memory, with its
 // arithmetic (a thread's columns c = tid, tid + 256, ..; fma chain of squares; wave sums, then the four waves in order; v / rms * w): the same bits.
 // Every workgroup of a consumer GEMV does this for itself (K floats per row: nothing beside the weight rows it streams), so the add + norm launch in
@@ -346,6 +424,11 @@ int linear(const float *x, int64_t ldx, const float *W, int64_t T, int64_t K, in
         else if (T <= 4) gemv_kernel<4><<<grid, dim3(256), 0, s>>>(x, ldx, W, (int)T, (int)K, (int)N, bias, y);
         else gemv_kernel<8><<<grid, dim3(256), 0, s>>>(x, ldx, W, (int)T, (int)K, (int)N, bias, y);
         F32_LAUNCH_CHECK("f32 gemv");
+        return 0;
+    }
+    if (K % MKT == 0 && ldx % 4 == 0 && N % 4 == 0 && ((uintptr_t)x | (uintptr_t)W | (uintptr_t)y) % 16 == 0) {     // matrix cores (r06)
+        linear_mfma_kernel<<<dim3((unsigned)((N + MB - 1) / MB), (unsigned)((T + MB - 1) / MB)), dim3(256), 0, s>>>(x, ldx, W, (int)T, (int)K, (int)N, bias, y);
+        F32_LAUNCH_CHECK("f32 linear (mfma)");
         return 0;
     }
     linear_kernel<<<dim3((unsigned)((N + LB - 1) / LB), (unsigned)((T + LB - 1) / LB)), dim3(256), 0, s>>>(x, ldx, W, (int)T, (int)K, (int)N, bias, y);
@@ -522,6 +605,30 @@ int silu_and_mul(const float *gu, int64_t T, int64_t I, float *out, hipStream_t 
     int64_t blocks = (T * I + 255) / 256; if (blocks > 8192) blocks = 8192;
     silu_mul_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(gu, T, (int)I, out);
     F32_LAUNCH_CHECK("f32 silu_and_mul");
+    return 0;
+}
+
+// ---------------------------------------------------------------- silu / gelu / relu / SiluAndMul / GeluAndMul (activation.rs:12-27,74-100,147-159), f32
+__global__ void activation_kernel(int kind, const float *__restrict__ x, int cols_in, int cols_out, float *__restrict__ out, int64_t total) {
+    const bool mul = kind >= 3;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t t = i / cols_out; const int c = (int)(i % cols_out);
+        const float g = x[t * cols_in + c];
+        float a;
+        if (kind == 1 || kind == 4) { const float inner = 0.7978845608028654f * g * (1.0f + 0.044715f * g * g); a = 0.5f * g * (1.0f + tanhf(inner)); }
+        else if (kind == 2) a = fmaxf(g, 0.0f);
+        else a = g * (1.0f / (1.0f + expf(-g)));
+        out[i] = mul ? a * x[t * cols_in + cols_out + c] : a;
+    }
+}
+int activation(int kind, const float *x, int64_t T, int64_t cols, float *out, hipStream_t s) {
+    if (kind < 0 || kind > 4) return nvr::fail(NVR_ERR_INVALID_ARG, "activation: unknown type %d", kind);
+    if (kind >= 3 && cols % 2) return nvr::fail(NVR_ERR_INVALID_ARG, "Input dimension must be even for %s, got %ld", kind == 3 ? "SiluAndMul" : "GeluAndMul", (long)cols);
+    const int64_t cols_out = kind >= 3 ? cols / 2 : cols, total = T * cols_out;
+    if (total == 0) return 0;
+    int64_t blocks = (total + 255) / 256; if (blocks > 8192) blocks = 8192;
+    activation_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(kind, x, (int)cols, (int)cols_out, out, total);
+    F32_LAUNCH_CHECK("f32 activation");
     return 0;
 }
 

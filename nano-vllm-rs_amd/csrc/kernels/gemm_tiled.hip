@@ -36,6 +36,34 @@ struct TileEpi {
 };
 
 constexpr int BM = 128, BN = 128, BK = 64;
+// ring depths of the mid-batch instances (one workgroup per CU): K-tiles in flight = depth - 1.  r04 read the launches of these GEMMs as "3.4 us + the
+// workgroup's operand bytes at 50-56 GB/s per CU"; that rate is bytes in flight over the L2 round trip (3 K-tiles x 24 KiB per CU in the 4-deep ring)
+#ifndef NVR_RING64
+#define NVR_RING64 4
+#endif
+#ifndef NVR_RING32
+#define NVR_RING32 4
+#endif
+#ifndef NVR_RING96
+#define NVR_RING96 4
+#endif
+constexpr int RING64 = NVR_RING64, RING32 = NVR_RING32, RING96 = NVR_RING96;
+
+// s_waitcnt vmcnt(younger x PER + EXTRA): K-tile kt has landed once at most the PER requests per thread of each of the `younger` K-tiles behind it (and EXTRA
+// requests issued after them) are outstanding
+template <int PER, int EXTRA = 0>
+__device__ __forceinline__ void wait_ring(int younger) {
+    static_assert(6 * PER + EXTRA <= 63, "vmcnt is a 6-bit count");
+    switch (younger) {
+    case 0: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(EXTRA) : "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER + EXTRA) : "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER + EXTRA) : "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PER + EXTRA) : "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * PER + EXTRA) : "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * PER + EXTRA) : "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 * PER + EXTRA) : "memory"); break;
+    }
+}
 
 // W row of local row r (0..15) of the workgroup's 16-row n-tile `t` (0..7)
 template <int EPI>
@@ -143,10 +171,8 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(const half_t *__restric
             const int younger = min(NS - 2, KT - 1 - kt);
             // (K-step 1 of a rotating TEPI_ROPE wave: the 8 * MT cos / sin requests of K-step 0 are younger than the two tiles that may stay in
             //  flight and may stay in flight with them; later steps find them landed)
-            if (PRE && kt == 1 && rope_rot && younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (4 + MT) + 8 * MT) : "memory");
-            else if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (4 + MT)) : "memory");
-            else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + MT) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (PRE && kt == 1 && rope_rot) wait_ring<4 + MT, (PRE ? 8 * MT : 0)>(younger);
+            else wait_ring<4 + MT>(younger);
             __builtin_amdgcn_s_barrier();                                 // every thread's pieces are in; buffer (kt-1) % NS is free
             cur = kt % NS;
             if (kt + NS - 1 < KT) stage((kt + NS - 1) % NS, (kt + NS - 1) * BK);
@@ -332,7 +358,7 @@ constexpr int S96_A = 96 * BK * 2, S96_BUF = S96_A + BM * BK * 2;        // byte
 __global__ __launch_bounds__(256) void gemm_tiled_silu96_kernel(const half_t *__restrict__ x, int64_t ldx, const half_t *__restrict__ W, int T, int K, int I,
                                                                 half_t *__restrict__ y) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int NS = 4;
+    constexpr int NS = RING96;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int r = lane & 15, q = lane >> 4;
     const int m0 = blockIdx.y * BM;
@@ -368,9 +394,7 @@ __global__ __launch_bounds__(256) void gemm_tiled_silu96_kernel(const half_t *__
     for (int kt = 0; kt < KT; ++kt) {
         // K-tile kt has landed once at most the 7 loads per thread of each younger K-tile in flight are outstanding
         const int younger = min(NS - 2, KT - 1 - kt);
-        if (younger >= 2) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
-        else if (younger == 1) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wait_ring<7>(younger);
         __builtin_amdgcn_s_barrier();                                     // every thread's pieces are in; buffer (kt-1) % NS is free
         const int cur = kt % NS;
         if (kt + NS - 1 < KT) stage((kt + NS - 1) % NS, (kt + NS - 1) * BK);
@@ -448,10 +472,10 @@ constexpr size_t kStageBytes32 = (BN + 32) * BK * 2;                     // MT =
         (grid).y = (unsigned)(((T_) + 32 * mt_ - 1) / (32 * mt_));                                                 \
         const unsigned wgs_ = (grid).x * (grid).y * (grid).z;                                                      \
         if (mt_ == 1) {                                                                                            \
-            if (tiled_ring(wgs_ / 2)) gemm_tiled_kernel<EPI_, 4, 1><<<grid, dim3(256), 4 * kStageBytes32, s>>>(__VA_ARGS__); \
+            if (tiled_ring(wgs_ / 2)) gemm_tiled_kernel<EPI_, RING32, 1><<<grid, dim3(256), RING32 * kStageBytes32, s>>>(__VA_ARGS__); \
             else gemm_tiled_kernel<EPI_, 2, 1><<<grid, dim3(256), 2 * kStageBytes32, s>>>(__VA_ARGS__);           \
         } else if (mt_ == 2) {                                                                                     \
-            if (tiled_ring(wgs_ / 2)) gemm_tiled_kernel<EPI_, 4, 2><<<grid, dim3(256), 4 * kStageBytes64, s>>>(__VA_ARGS__); \
+            if (tiled_ring(wgs_ / 2)) gemm_tiled_kernel<EPI_, RING64, 2><<<grid, dim3(256), RING64 * kStageBytes64, s>>>(__VA_ARGS__); \
             else gemm_tiled_kernel<EPI_, 2, 2><<<grid, dim3(256), 2 * kStageBytes64, s>>>(__VA_ARGS__);           \
         } else {                                                                                                   \
             if (tiled_ring(wgs_)) gemm_tiled_kernel<EPI_, 4><<<grid, dim3(256), 4 * kStageBytes, s>>>(__VA_ARGS__); \
@@ -465,14 +489,14 @@ int gemm_tiled_prepare() {
 #define NVR_TILED_ATTR(EPI_)                                                                                          \
     { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_tiled_kernel<EPI_, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                          (int)(4 * kStageBytes));                                                    \
-      if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_tiled_kernel<EPI_, 4, 2>),   \
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * kStageBytes64)); \
-      if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_tiled_kernel<EPI_, 4, 1>),   \
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * kStageBytes32)); \
+      if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_tiled_kernel<EPI_, RING64, 2>),   \
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(RING64 * kStageBytes64)); \
+      if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_tiled_kernel<EPI_, RING32, 1>),   \
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(RING32 * kStageBytes32)); \
       if (e != hipSuccess) return nvr::fail(NVR_ERR_HIP, "gemm_tiled: LDS opt-in failed: %s", hipGetErrorString(e)); }
     NVR_TILED_ATTR(TEPI_F16) NVR_TILED_ATTR(TEPI_SILU) NVR_TILED_ATTR(TEPI_ROPE) NVR_TILED_ATTR(TEPI_LMHEAD) NVR_TILED_ATTR(TEPI_SLAB)
 #undef NVR_TILED_ATTR
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_tiled_silu96_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * S96_BUF) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_tiled_silu96_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, RING96 * S96_BUF) != hipSuccess)
         return nvr::fail(NVR_ERR_HIP, "gemm_tiled: LDS opt-in failed (96-row SiLU tiles)");
     done = true;
     return 0;
@@ -526,7 +550,7 @@ int gemm_tiled_silu_mul(const half_bits *x, int64_t ldx, const half_bits *W, int
     {   // 96-row tiles when they put a workgroup on (nearly) every CU where the 128-row tiles leave a quarter of them idle (T = 512, I = 3072: 256 against 192)
         const int64_t ty = (T + BM - 1) / BM, w128 = (I / 64) * ty, w96 = (I / 48) * ty;
         if (I % 48 == 0 && tiled_mt(T, I / 64) == 4 && tiled_ring((unsigned)w128) && w96 <= 256 && w96 > w128 && w128 * 8 <= w96 * 7) {
-            gemm_tiled_silu96_kernel<<<dim3((unsigned)(I / 48), (unsigned)ty), dim3(256), 4 * S96_BUF, s>>>((const half_t *)x, ldx, (const half_t *)W, (int)T, (int)K, (int)I, (half_t *)out);
+            gemm_tiled_silu96_kernel<<<dim3((unsigned)(I / 48), (unsigned)ty), dim3(256), RING96 * S96_BUF, s>>>((const half_t *)x, ldx, (const half_t *)W, (int)T, (int)K, (int)I, (half_t *)out);
             return tiled_check("gemm_tiled_silu_mul (96-row tiles)");
         }
     }

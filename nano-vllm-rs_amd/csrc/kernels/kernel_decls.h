@@ -12,6 +12,8 @@ int rmsnorm(const half_bits *x, const half_bits *w, float eps, int64_t T, int64_
 int add_rmsnorm(half_bits *h, const half_bits *y, const half_bits *w, float eps, int64_t T, int64_t Hd,
                 half_bits *out, hipStream_t s);
 int silu_and_mul(const half_bits *x, int64_t T, int64_t I, half_bits *out, hipStream_t s);
+// Activation::forward (activation.rs:147-159): kind 0 silu, 1 gelu (tanh form), 2 relu: [T, cols] -> [T, cols]; 3 SiluAndMul, 4 GeluAndMul: [T, cols] -> [T, cols / 2]
+int activation(int kind, const half_bits *x, int64_t T, int64_t cols, half_bits *out, hipStream_t s);
 int add_bias(half_bits *y, const half_bits *b, int64_t T, int64_t N, hipStream_t s);   // y[T, N] <- 16bit(y + b[N]) (use_bias, A-30)
 int select_last_tokens(const half_bits *h, const int32_t *cu, int64_t B, int64_t Hd, half_bits *out, hipStream_t s);
 int rope_store_kv(half_bits *qkv, const int64_t *positions, const int32_t *slots, int64_t T, int64_t H, int64_t KVH,

@@ -82,6 +82,7 @@ int linear(const float *x, int64_t ldx, const float *W, int64_t T, int64_t K, in
 int rope_store_kv(float *qkv, const int64_t *pos, const int32_t *slots, int64_t T, int64_t H, int64_t KVH, int64_t D, const float *cos_t,
                   const float *sin_t, float *kc, float *vc, const float *q_norm, const float *k_norm, float eps, hipStream_t s);
 int silu_and_mul(const float *gu, int64_t T, int64_t I, float *out, hipStream_t s);
+int activation(int kind, const float *x, int64_t T, int64_t cols, float *out, hipStream_t s);
 bool linear_qkv_rope_ok(int64_t T, int64_t K, int64_t D, int64_t ldx);   // decode-sized steps, no q / k head norms: qkv projection + RoPE + KV store in one launch (the same bits as the two)
 int linear_qkv_rope_store(const float *x, int64_t ldx, const float *W, int64_t T, int64_t K, int64_t H, int64_t KVH, int64_t D, const float *bias,
                           const int64_t *pos, const int32_t *slots, const float *cos_t, const float *sin_t, float *qkv, float *kc, float *vc, hipStream_t s);

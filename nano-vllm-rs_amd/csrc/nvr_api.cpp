@@ -716,6 +716,22 @@ int nvr_attn_prefill_paged(const nvr_half *q, int64_t ldq, const nvr_half *kc, c
     return run_prefill_attn(q, ldq, kc, vc, 0, m, true, bs, T, H, KVH, D, scale, out, (hipStream_t)s);
     NVR_GUARD_END(NVR_ERR_INVARIANT)
 }
+int nvr_activation_type_from_str(const char *name, int32_t *type_out) {                       // ActivationType::from_str, activation.rs:169-182
+    if (!name || !type_out) return nvr::fail(NVR_ERR_INVALID_ARG, "nvr_activation_type_from_str: null argument");
+    std::string s(name);
+    for (char &c : s) c = (char)std::tolower((unsigned char)c);
+    if (s == "silu" || s == "swish") *type_out = NVR_ACT_SILU;
+    else if (s == "gelu") *type_out = NVR_ACT_GELU;
+    else if (s == "relu") *type_out = NVR_ACT_RELU;
+    else if (s == "silu_and_mul" || s == "siluandmul") *type_out = NVR_ACT_SILU_AND_MUL;
+    else if (s == "gelu_and_mul" || s == "geluandmul") *type_out = NVR_ACT_GELU_AND_MUL;
+    else return nvr::fail(NVR_ERR_INVALID_ARG, "Unknown activation function: %s", name);
+    return NVR_OK;
+}
+int nvr_activation(int32_t type, const nvr_half *x, int64_t T, int64_t cols, nvr_half *out, void *s) {   // Activation::forward, activation.rs:147-159
+    if (g_ops_f32) return nvr::kf::activation(type, FP(x), T, cols, FP(out), (hipStream_t)s);
+    return KO(activation(type, x, T, cols, out, (hipStream_t)s));
+}
 int nvr_silu_and_mul(const nvr_half *x, int64_t T, int64_t I, nvr_half *out, void *s) {
     if (g_ops_f32) return nvr::kf::silu_and_mul(FP(x), T, I, FP(out), (hipStream_t)s);
     return KO(silu_and_mul(x, T, I, out, (hipStream_t)s));

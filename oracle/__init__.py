@@ -92,6 +92,7 @@ def _declare(l: C.CDLL) -> None:
     l.nvo_attn_paged.argtypes = [_f32p, _i32p, _f32p, _f32p, _i32p, C.c_int64, _i32p, C.c_int64,
                                  C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_float, _f32p]
     l.nvo_silu_and_mul.argtypes = [_f32p, C.c_int64, C.c_int64, _f32p]
+    l.nvo_activation.argtypes = [C.c_int, _f32p, C.c_int64, C.c_int64, _f32p]
     l.nvo_argmax.restype = C.c_int64
     l.nvo_argmax.argtypes = [_f32p, C.c_int64]
     l.nvo_top_k.argtypes = [_f32p, C.c_int64, C.c_int64, _f32p]
@@ -293,6 +294,22 @@ def silu_and_mul(x) -> np.ndarray:
     T, I2 = x.shape
     out = np.empty((T, I2 // 2), dtype=np.float32)
     lib().nvo_silu_and_mul(_f(x), T, I2 // 2, _f(out))
+    return out
+
+
+ACTIVATION_TYPES = {"silu": 0, "gelu": 1, "relu": 2, "silu_and_mul": 3, "gelu_and_mul": 4}      # ActivationType, src/layers/activation.rs:111-117
+
+
+def activation(kind, x) -> np.ndarray:
+    """Activation::forward (src/layers/activation.rs:147-159): silu :12-15, gelu :20-22 (candle's tanh form), relu :25-27 on [T, cols]; SiluAndMul :46-63 and
+    GeluAndMul :74-100 on [T, 2 I] -> [T, I].  An odd last dimension of the two fused types is the reference's error (:50-52, :88-90)."""
+    k = ACTIVATION_TYPES[kind] if isinstance(kind, str) else int(kind)
+    x = f32(x)
+    T, cols = x.shape
+    if k >= 3 and cols % 2:
+        raise ValueError(f"Input dimension must be even for {'SiluAndMul' if k == 3 else 'GeluAndMul'}, got {cols}")
+    out = np.empty((T, cols // 2 if k >= 3 else cols), np.float32)
+    lib().nvo_activation(k, _f(x), T, cols, _f(out))
     return out
 
 

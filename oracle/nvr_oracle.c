@@ -484,6 +484,26 @@ NVO_API void nvo_silu_and_mul(const float *x, int64_t T, int64_t I, float *out) 
 }
 
 /* ------------------------------------------------------------------------- */
+/* The rest of src/layers/activation.rs: silu :12-15, gelu :20-22 (candle's   */
+/* tanh form), relu :25-27, GeluAndMul :74-100, Activation::forward :147-159. */
+/* kind 0 silu, 1 gelu, 2 relu: out [T, cols]; 3 SiluAndMul, 4 GeluAndMul:    */
+/* out [T, cols / 2] = act(x[:, :cols/2]) * x[:, cols/2:]                     */
+/* ------------------------------------------------------------------------- */
+static float nvo_act_one(int kind, float g) {
+    if (kind == 1 || kind == 4) { const float inner = 0.7978845608028654f * g * (1.0f + 0.044715f * g * g); return 0.5f * g * (1.0f + tanhf(inner)); }
+    if (kind == 2) return g > 0.0f ? g : 0.0f;
+    return g * (1.0f / (1.0f + expf(-g)));
+}
+NVO_API void nvo_activation(int kind, const float *x, int64_t T, int64_t cols, float *out) {
+    const int64_t co = kind >= 3 ? cols / 2 : cols;
+    for (int64_t t = 0; t < T; ++t)
+        for (int64_t i = 0; i < co; ++i) {
+            const float a = nvo_act_one(kind, x[t * cols + i]);
+            out[t * co + i] = kind >= 3 ? a * x[t * cols + co + i] : a;
+        }
+}
+
+/* ------------------------------------------------------------------------- */
 /* K17 greedy argmax — src/layers/sampler.rs:109-112, A-12 lowest index wins  */
 /* ------------------------------------------------------------------------- */
 NVO_API int64_t nvo_argmax(const float *x, int64_t n) {

@@ -372,3 +372,16 @@ def test_schedule_capacity_is_bounded_by_live_sequences():
     assert sc.get_queue_lengths() == (2, 0)
     nvr.check(l.nvr_sched_schedule(sc.h, out, 2, C.byref(n), C.byref(pf)))
     assert n.value == 2 and pf.value == 1
+
+
+def test_activation_type_from_str():
+    """ActivationType::from_str, src/layers/activation.rs:169-182 (case-insensitive, the aliases, the error text) through the C ABI (no GPU needed)."""
+    import ctypes as C
+    l = nvr.lib()
+    want = {"silu": 0, "swish": 0, "SiLU": 0, "gelu": 1, "GELU": 1, "relu": 2, "silu_and_mul": 3, "SiluAndMul": 3, "gelu_and_mul": 4, "geluandmul": 4}
+    for name, kind in want.items():
+        out = C.c_int32(-1)
+        assert l.nvr_activation_type_from_str(name.encode(), C.byref(out)) == 0 and out.value == kind, name
+    out = C.c_int32(-1)
+    assert l.nvr_activation_type_from_str(b"tanh", C.byref(out)) == -7            # NVR_ERR_INVALID_ARG
+    assert "Unknown activation function: tanh" in nvr.last_error()

@@ -376,6 +376,33 @@ def test_silu_and_mul():
     assert_close_f16(d_out.to_numpy((T, I), F16), oracle.round_f16(oracle.silu_and_mul(x)), ulps=1, atol=1e-6)
 
 
+@pytest.mark.parametrize("kind", ["silu", "gelu", "relu", "silu_and_mul", "gelu_and_mul"])
+def test_activation_types(kind):
+    """nvr_activation = Activation::forward (activation.rs:147-159) for every ActivationType against the oracle: f32 inside, one fp16 rounding at the store
+    (device expf / tanhf against the host's: <= 1 fp16 ulp); relu exactly; the reference's KAT inputs; an odd width of the fused types is refused with the
+    reference's message (:50-52, :88-90)."""
+    rng = np.random.default_rng(12)
+    T, cols = 33, 2 * 3072
+    x, xb = h16(rng.standard_normal((T, cols)) * 2)
+    x[0, :5] = [-2, -1, 0, 1, 2]; xb[0, :5] = oracle.to_f16_bits(np.asarray([-2, -1, 0, 1, 2], np.float32))
+    k = oracle.ACTIVATION_TYPES[kind]
+    co = cols // 2 if k >= 3 else cols
+    d_out = nvr.DeviceBuffer(T * co * 2)
+    nvr.check(nvr.lib().nvr_activation(k, dev(xb).ptr, T, cols, d_out.ptr, None))
+    got, ref = d_out.to_numpy((T, co), F16), oracle.round_f16(oracle.activation(kind, x))
+    if kind == "relu":
+        assert np.array_equal(got.astype(np.float32), ref)
+        assert got[0, :5].tolist() == [0.0, 0.0, 0.0, 1.0, 2.0]
+    else:
+        assert_close_f16(got, ref, ulps=1, atol=1e-6)
+    if kind in ("silu", "gelu"):
+        assert got[0, 2] == 0.0
+    if k >= 3:
+        assert nvr.lib().nvr_activation(k, dev(xb).ptr, T, 4097, d_out.ptr, None) == -7
+        assert f"Input dimension must be even for {'SiluAndMul' if k == 3 else 'GeluAndMul'}, got 4097" in nvr.last_error()
+    assert nvr.lib().nvr_activation(7, dev(xb).ptr, T, cols, d_out.ptr, None) == -7
+
+
 def test_select_last_tokens_exact():
     rng = np.random.default_rng(11)
     lens, Hd = [3, 1, 7], 128

@@ -321,6 +321,24 @@ def test_silu_kats():                            # activation.rs:214-228,264-290
         oracle.silu_and_mul(np.zeros((1, 3), np.float32))
 
 
+def test_activation_kats():                      # the rest of activation.rs: gelu / relu / GeluAndMul / Activation (:231-261, :293-334)
+    g = np.array([[-2, -1, 0, 1, 2]], np.float32)
+    y = oracle.activation("gelu", g)[0]
+    assert abs(y[2]) < 1e-6 and np.all(np.diff(y[1:]) > 0)                      # GELU(0) = 0; increasing on [-1, 2] (:231-245 asserts it from -2: the tanh
+    assert y[0] < 0 and y[0] > y[1]                                             # form dips: gelu(-2) = -0.0454 > gelu(-1) = -0.1588 — candle's own values)
+    np.testing.assert_allclose(y, 0.5 * g[0] * (1 + np.tanh(np.sqrt(2 / np.pi) * (g[0] + 0.044715 * g[0] ** 3))), rtol=2e-6, atol=1e-7)
+    assert oracle.activation("relu", g)[0].tolist() == [0.0, 0.0, 0.0, 1.0, 2.0]     # :248-261
+    s = oracle.activation("silu", g)[0]
+    assert s[2] == 0.0 and np.all(np.diff(s[1:]) > 0)                           # :214-228
+    x = np.array([[1, 2, 3, .5, 1.5, 2.5]], np.float32)
+    assert oracle.activation("gelu_and_mul", x).shape == (1, 3)                 # :293-307
+    np.testing.assert_allclose(oracle.activation("gelu_and_mul", x)[0], oracle.activation("gelu", x[:, :3])[0] * x[0, 3:], rtol=1e-6)
+    np.testing.assert_allclose(oracle.activation("silu_and_mul", x), oracle.silu_and_mul(x), rtol=1e-6)    # :264-290 (the Activation enum's arm, :321-334)
+    for kind in ("silu_and_mul", "gelu_and_mul"):
+        with pytest.raises(ValueError, match="must be even"):                   # :309-318
+            oracle.activation(kind, np.zeros((1, 3), np.float32))
+
+
 def test_linear_shape_rules():                   # linear.rs:476-559 (TP shape partitioning)
     assert 256 // 2 == 128                                    # column/row parallel split
     H, KVH, D = 8, 8, 64
