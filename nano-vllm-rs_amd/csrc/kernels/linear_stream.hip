@@ -95,8 +95,9 @@ __global__ __launch_bounds__(WAVES * 64) void linear_stream_kernel(const half_t 
 
     if constexpr (IMG > 0) {
         static_assert(IMG <= TMAX && IMG <= 3 && PRE == 0 && NC >= 1, "IMG: tiles held by a workgroup, NC chunks of 1024 columns");
-        constexpr int KPW2 = 4;                                              // k-steps per wave and chunk
-        constexpr int KC2 = KPW2 * WAVES * 32, cpr2 = KC2 / 8;               // 1024 columns (the host passes KC = KC2, K = NC * KC2)
+        constexpr int KPW2 = MT <= 2 ? 4 : 2;                                // k-steps per wave and chunk
+        constexpr int KC2 = KPW2 * WAVES * 32, cpr2 = KC2 / 8;               // 1024 columns (33..64 rows, MT = 4: 512, so that two 64-row images fit the LDS); the
+                                                                             // host passes KC = KC2, K = NC * KC2
         const int kmul = epi.tiled ? 16 : 1;
         constexpr int img_bytes = ROWS * KC2 * 2;
         int ntl = 0;                                                         // live tiles of this workgroup (uniform)
@@ -107,15 +108,29 @@ __global__ __launch_bounds__(WAVES * 64) void linear_stream_kernel(const half_t 
         const int rot_r = (EPI == SEPI_ROPE) ? (r < 8 ? r : epi.D / 2 + (r - 8)) : r;
         const unsigned voff = epi.tiled ? (unsigned)((r * 32 + q * 8 + wave * 512) * 2) : (unsigned)(((int64_t)rot_r * K + q * 8 + wave * 32) * 2);
         const unsigned voff_v = (unsigned)(((int64_t)r * K + q * 8 + wave * 32) * 2);
+        // Image pieces by LDS-DMA, 16 bytes per lane, lane-linear in LDS: slot p = row * cpr2 + s holds chunk s ^ (row & 7) of its row.  A wave-instruction
+        // covers 64 consecutive slots of ONE row (cpr2 = 64 or 128 slots per row), so the row — and with it the clamp to T - 1 and the row's address — is
+        // uniform: scalar base (x + row * ldx + chunk) + ONE per-lane byte offset (two when a row takes two instructions: the swizzle term row & 7 then
+        // alternates with the round), instead of eight 64-bit per-thread pointers kept (and, next to gate_up's 96 accumulators, spilled) across the chunks.
+        // As inline asm: all vector-memory traffic of this loop is counted by hand (see body); M0 (the LDS destination) is saved and restored.
+        constexpr int RPI = (WAVES * 64) / cpr2;                             // image rows per round of the workgroup's waves (8 or 4)
+        constexpr int IMG_IT = ROWS / RPI;                                   // rounds = requests per wave and image (8)
+        static_assert(ROWS % RPI == 0 && (cpr2 == 64 || cpr2 == 128) && RPI % 4 == 0, "a wave-instruction stays inside one image row");
+        const int wave_u = __builtin_amdgcn_readfirstlane(wave);                // (uniform by construction; said so, for the scalar bases below)
+        const int row_w = cpr2 == 64 ? wave_u : wave_u >> 1, slot_w = cpr2 == 64 ? lane : (wave_u & 1) * 64 + lane;   // row inside a round, first slot's index in the row
+        // (row & 7) of round `it` = (it * RPI + row_w) & 7: RPI = 8 -> row_w & 7 for every round; RPI = 4 -> alternates between row_w and row_w + 4
+        const unsigned ioff0 = (unsigned)((slot_w ^ (row_w & 7)) * 16), ioff1 = (unsigned)((slot_w ^ ((row_w + 4) & 7)) * 16);
+        const unsigned lds_img = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
         auto issue_img = [&](int c, int buf) {
-            char *dst = smem + buf * img_bytes;
-            constexpr int total = ROWS * cpr2;                               // 16-byte pieces, lane-linear in LDS: slot p = row * cpr2 + s holds chunk s ^ (row & 7)
-            static_assert(total % (WAVES * 64) == 0, "whole rounds of image pieces");
 #pragma unroll
-            for (int it = 0; it < total / (WAVES * 64); ++it) {
-                const int p0 = it * WAVES * 64 + wave * 64, p = p0 + lane, row = p / cpr2, ch = (p % cpr2) ^ (row & 7);
-                const half_t *src = x + (int64_t)(row < T ? row : T - 1) * ldx + c * KC2 + ch * 8;
-                __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void *)(dst + p0 * 16), 16, 0, 0);
+            for (int it = 0; it < IMG_IT; ++it) {
+                const int row = it * RPI + row_w;
+                const half_t *base = x + (int64_t)(row < T ? row : T - 1) * ldx + c * KC2;
+                const unsigned m0v = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_img + buf * img_bytes + (it * WAVES * 64 + wave_u * 64) * 16));
+                const unsigned vo = (RPI == 4 && (it & 1)) ? ioff1 : ioff0;
+                unsigned keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(vo), "s"(base), "s"(m0v) : "memory");
             }
         };
         // One straight-line body per number of live tiles NTL (1 .. IMG), picked once: no loop and no branch between a request and its wait.  The weight
@@ -399,15 +414,19 @@ static int stream_kc(int64_t T, int64_t K) {                                 // 
 // worth it and expressible: large weights, whole chunks, more tiles than workgroups (with one tile per workgroup the
 // activation-chunk fills weigh as much as the weight stream and the skinny kernel is as fast: scratch/stream_bench.py, Qwen3-8B
 // shapes: gate_up 48 vs 63 us, qkv 23.6 vs 28.5 us, but o_proj 17.0 vs 15.5 us), at most TMAX tiles per workgroup
-static bool stream_shape_ok(int64_t T, int64_t K, int64_t tiles, int64_t weight_bytes, int64_t ldx) {
+static bool stream_shape_ok(int64_t T, int64_t K, int64_t tiles, int64_t weight_bytes, int64_t ldx, int parts) {
+    // 33..64 rows (r06): only the double-buffered-image instantiations exist (64-row images of 512 columns), i.e. hidden 2048 / 4096 and at most 2 (one weight
+    // part per tile) or 3 (gate_up) tiles per workgroup — before, such batches of an 8B-class model fell to the skinny kernel over two 32-row blocks
+    // (Qwen3-8B bs 64: 0.36 of its step roofline between 0.58 at bs 32 and 0.60 at bs 128)
+    if (T > 32) return stream_enabled() && T <= 64 && ldx % 8 == 0 && (K == 2048 || K == 4096) && weight_bytes >= (24ll << 20) && tiles >= 320 && tiles <= (parts == 1 ? 2 : 3) * 256;
     if (!stream_enabled() || T < 1 || T > 32 || ldx % 8 || K < 2048 || weight_bytes < (24ll << 20)) return false;
     const int kc = stream_kc(T, K);
     return K % kc == 0 && kc % (S_WAVES * 32) == 0 && tiles >= 320 && tiles <= 256 * S_TMAX;
 }
-bool linear_stream_ok(int64_t T, int64_t K, int64_t N, int64_t ldx) { return N % 16 == 0 && stream_shape_ok(T, K, N / 16, N * K * 2, ldx); }
-bool linear_stream_silu_ok(int64_t T, int64_t K, int64_t I, int64_t ldx) { return I % 16 == 0 && stream_shape_ok(T, K, I / 16, 2 * I * K * 2, ldx); }
+bool linear_stream_ok(int64_t T, int64_t K, int64_t N, int64_t ldx) { return N % 16 == 0 && stream_shape_ok(T, K, N / 16, N * K * 2, ldx, 1); }
+bool linear_stream_silu_ok(int64_t T, int64_t K, int64_t I, int64_t ldx) { return I % 16 == 0 && stream_shape_ok(T, K, I / 16, 2 * I * K * 2, ldx, 2); }
 bool linear_stream_rope_ok(int64_t T, int64_t K, int64_t H, int64_t KVH, int64_t D, int64_t ldx) {
-    return D % 16 == 0 && stream_shape_ok(T, K, (H + 2 * KVH) * D / 16, (H + 2 * KVH) * D * K * 2, ldx);
+    return D % 16 == 0 && stream_shape_ok(T, K, (H + 2 * KVH) * D / 16, (H + 2 * KVH) * D * K * 2, ldx, 1);
 }
 
 int linear_stream_prepare();
@@ -424,14 +443,17 @@ static int stream_launch(const half_t *x, int64_t ldx, const half_t *W, int T, i
     {   // r06: double-buffered LDS-DMA image, 1024-column chunks (IMG): up to 2 tiles per workgroup with one weight part each (qkv, plain), 3 with two (gate_up)
         constexpr int IMGT = NTT == 1 ? 2 : 3;
         if ((K == 2048 || K == 4096) && ntiles <= IMGT * nwg) {               // (NC = 2: hidden 2048; NC = 4: hidden 4096 — Qwen3-8B; other widths keep the r05 kernels)
-            const size_t lds2 = std::max<size_t>((size_t)2 * MT * 16 * 1024 * 2, scratch);
-            if (K == 4096) linear_stream_kernel<NTT, MT, S_WAVES, U, EPI, S_TMAX, 0, IMGT, 4><<<dim3((unsigned)nwg), dim3(S_WAVES * 64), lds2, s>>>(x, ldx, W, T, K, N, 1024, ntiles, y, e);
-            else linear_stream_kernel<NTT, MT, S_WAVES, U, EPI, S_TMAX, 0, IMGT, 2><<<dim3((unsigned)nwg), dim3(S_WAVES * 64), lds2, s>>>(x, ldx, W, T, K, N, 1024, ntiles, y, e);
+            constexpr int KC2 = MT <= 2 ? 1024 : 512;                         // chunk width (kernel: KPW2 * WAVES * 32)
+            const size_t lds2 = std::max<size_t>((size_t)2 * MT * 16 * KC2 * 2, scratch);
+            if (K == 4096) linear_stream_kernel<NTT, MT, S_WAVES, U, EPI, S_TMAX, 0, IMGT, 4096 / KC2><<<dim3((unsigned)nwg), dim3(S_WAVES * 64), lds2, s>>>(x, ldx, W, T, K, N, KC2, ntiles, y, e);
+            else linear_stream_kernel<NTT, MT, S_WAVES, U, EPI, S_TMAX, 0, IMGT, 2048 / KC2><<<dim3((unsigned)nwg), dim3(S_WAVES * 64), lds2, s>>>(x, ldx, W, T, K, N, KC2, ntiles, y, e);
             hipError_t er = hipGetLastError();
             if (er != hipSuccess) return nvr::fail(NVR_ERR_HIP, "linear_stream launch failed: %s", hipGetErrorString(er));
             return 0;
         }
     }
+    if constexpr (MT > 2) return nvr::fail(NVR_ERR_UNSUPPORTED, "linear_stream: %d rows need hidden 2048 / 4096 (K = %d)", T, K);
+    else {
     if constexpr (NTT == 1) {
         if (kc <= 8 * S_WAVES * 32 && ntiles <= 2 * nwg) {                   // all weight pieces of a chunk requested in front of the fill (PRE)
             linear_stream_kernel<NTT, MT, S_WAVES, U, EPI, S_TMAX, 2><<<dim3((unsigned)nwg), dim3(S_WAVES * 64), lds, s>>>(x, ldx, W, T, K, N, kc, ntiles, y, e);
@@ -444,6 +466,7 @@ static int stream_launch(const half_t *x, int64_t ldx, const half_t *W, int T, i
     hipError_t er = hipGetLastError();
     if (er != hipSuccess) return nvr::fail(NVR_ERR_HIP, "linear_stream launch failed: %s", hipGetErrorString(er));
     return 0;
+    }
 }
 
 // opt every instance in to > 64 KiB of dynamic LDS up front (runner init: never inside a stream capture)
@@ -458,7 +481,12 @@ int linear_stream_prepare() {
         reinterpret_cast<const void *>(&linear_stream_kernel<1, 1, S_WAVES, 4, SEPI_F16, S_TMAX, 0, 2, NC_>), reinterpret_cast<const void *>(&linear_stream_kernel<1, 2, S_WAVES, 4, SEPI_F16, S_TMAX, 0, 2, NC_>), \
         reinterpret_cast<const void *>(&linear_stream_kernel<1, 1, S_WAVES, 4, SEPI_ROPE, S_TMAX, 0, 2, NC_>), reinterpret_cast<const void *>(&linear_stream_kernel<1, 2, S_WAVES, 4, SEPI_ROPE, S_TMAX, 0, 2, NC_>), \
         reinterpret_cast<const void *>(&linear_stream_kernel<2, 1, S_WAVES, 2, SEPI_SILU, S_TMAX, 0, 3, NC_>), reinterpret_cast<const void *>(&linear_stream_kernel<2, 2, S_WAVES, 2, SEPI_SILU, S_TMAX, 0, 3, NC_>)
-        NVR_LS_IMG(2), NVR_LS_IMG(4)};
+        NVR_LS_IMG(2), NVR_LS_IMG(4),
+#define NVR_LS_IMG4(NC_) \
+        reinterpret_cast<const void *>(&linear_stream_kernel<1, 4, S_WAVES, 4, SEPI_F16, S_TMAX, 0, 2, NC_>), reinterpret_cast<const void *>(&linear_stream_kernel<1, 4, S_WAVES, 4, SEPI_ROPE, S_TMAX, 0, 2, NC_>), \
+        reinterpret_cast<const void *>(&linear_stream_kernel<2, 4, S_WAVES, 2, SEPI_SILU, S_TMAX, 0, 3, NC_>)
+        NVR_LS_IMG4(4), NVR_LS_IMG4(8)};
+#undef NVR_LS_IMG4
 #undef NVR_LS_IMG
     for (const void *f : fns) {
         hipError_t er = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -472,6 +500,7 @@ int linear_stream(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T
     StreamEpi e{};
     if (Wt) { W = Wt; e.tiled = 1; }
     if (T <= 16) return stream_launch<1, 1, 4, SEPI_F16>((const half_t *)x, ldx, (const half_t *)W, (int)T, (int)K, (int)N, (int)(N / 16), (half_t *)y, e, s);
+    if (T > 32) return stream_launch<1, 4, 4, SEPI_F16>((const half_t *)x, ldx, (const half_t *)W, (int)T, (int)K, (int)N, (int)(N / 16), (half_t *)y, e, s);
     return stream_launch<1, 2, 4, SEPI_F16>((const half_t *)x, ldx, (const half_t *)W, (int)T, (int)K, (int)N, (int)(N / 16), (half_t *)y, e, s);
 }
 int linear_stream_silu_mul(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t I, half_bits *out, hipStream_t s,
@@ -480,6 +509,7 @@ int linear_stream_silu_mul(const half_bits *x, int64_t ldx, const half_bits *W, 
     StreamEpi e{};
     if (Wt) { W = Wt; e.tiled = 1; }
     if (T <= 16) return stream_launch<2, 1, 2, SEPI_SILU>((const half_t *)x, ldx, (const half_t *)W, (int)T, (int)K, (int)I, (int)(I / 16), (half_t *)out, e, s);
+    if (T > 32) return stream_launch<2, 4, 2, SEPI_SILU>((const half_t *)x, ldx, (const half_t *)W, (int)T, (int)K, (int)I, (int)(I / 16), (half_t *)out, e, s);
     return stream_launch<2, 2, 2, SEPI_SILU>((const half_t *)x, ldx, (const half_t *)W, (int)T, (int)K, (int)I, (int)(I / 16), (half_t *)out, e, s);
 }
 int linear_stream_qkv_rope_store(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t H, int64_t KVH, int64_t D,
@@ -492,6 +522,7 @@ int linear_stream_qkv_rope_store(const half_bits *x, int64_t ldx, const half_bit
     if (Wt) { W = Wt; e.tiled = 1; }
     const int N = (int)((H + 2 * KVH) * D);
     if (T <= 16) return stream_launch<1, 1, 4, SEPI_ROPE>((const half_t *)x, ldx, (const half_t *)W, (int)T, (int)K, N, N / 16, (half_t *)qkv, e, s);
+    if (T > 32) return stream_launch<1, 4, 4, SEPI_ROPE>((const half_t *)x, ldx, (const half_t *)W, (int)T, (int)K, N, N / 16, (half_t *)qkv, e, s);
     return stream_launch<1, 2, 4, SEPI_ROPE>((const half_t *)x, ldx, (const half_t *)W, (int)T, (int)K, N, N / 16, (half_t *)qkv, e, s);
 }
 

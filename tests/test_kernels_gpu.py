@@ -383,8 +383,9 @@ def test_activation_types(kind):
     reference's message (:50-52, :88-90)."""
     rng = np.random.default_rng(12)
     T, cols = 33, 2 * 3072
-    x, xb = h16(rng.standard_normal((T, cols)) * 2)
-    x[0, :5] = [-2, -1, 0, 1, 2]; xb[0, :5] = oracle.to_f16_bits(np.asarray([-2, -1, 0, 1, 2], np.float32))
+    raw = rng.standard_normal((T, cols)) * 2
+    raw[0, :5] = [-2, -1, 0, 1, 2]                                               # the inputs of the reference's own tests (activation.rs:214-261)
+    x, xb = h16(raw)
     k = oracle.ACTIVATION_TYPES[kind]
     co = cols // 2 if k >= 3 else cols
     d_out = nvr.DeviceBuffer(T * co * 2)
@@ -593,12 +594,20 @@ def test_fill_weight_bit_exact_with_oracle():
     assert abs(ref.std() - 0.02) < 0.003
 
 
-@pytest.mark.parametrize("T", [32, 9])
+@pytest.mark.parametrize("T", [32, 9, 48, 64, 33])
 def test_decode_gemms_over_large_weights(T):
     """linear_stream.hip (Qwen3-8B-class shapes: >= 24 MiB of weights, K >= 2048): plain, SiLU and RoPE+store epilogues
     against the oracle compositions; several K chunks (K = 6144 -> 3 chunks of 2048 at T > 16) and several tiles per
-    workgroup (N = 8192 -> 512 tiles on 256 workgroups)."""
+    workgroup (N = 8192 -> 512 tiles on 256 workgroups).  r06: K = 2048 / 4096 take the double-buffered LDS-DMA image (two chunks of weight
+    pieces in flight), and 33..64 rows stay on the streaming kernels there (64-row images of 512 columns) instead of two 32-row skinny blocks."""
     rng = np.random.default_rng(61)
+    # plain, hidden 4096 and 2048 (the IMG instantiations: NC = 4 / 2, 8 / 4 at more than 32 rows): 512 and 1024 tiles -> one or two per workgroup
+    for K, N in ((4096, 8192), (2048, 8192)):
+        x, xb = h16(rng.standard_normal((T, K)))
+        W, Wb = h16(rng.standard_normal((N, K)) * 0.02)
+        d_y = nvr.DeviceBuffer(T * N * 2)
+        nvr.check(nvr.lib().nvr_linear(dev(xb).ptr, K, dev(Wb).ptr, T, K, N, d_y.ptr, 0, None))
+        assert_close_f16(d_y.to_numpy((T, N), F16), oracle.round_f16(oracle.linear(x, W)), ulps=1, atol=3e-4, what=f"stream plain K={K}")
     # plain: K = 6144, N = 8192 (512 tiles: two per workgroup)
     K, N = 6144, 8192
     x, xb = h16(rng.standard_normal((T, K)))
@@ -1032,7 +1041,7 @@ def test_paged_attn_decode_shared_prefix(B, H, KVH, D, bs, P, own):
                                                   None, None, None, d_out.ptr, ws.ptr, None) == -7
 
 
-@pytest.mark.parametrize("T", [8, 32])
+@pytest.mark.parametrize("T", [8, 32, 40, 64])
 def test_tiled_entry_points_match_row_major_stream_shapes(T):
     """The same on Qwen3-8B shapes, where linear / silu / qkv route to linear_stream_kernel (>= 24 MiB of weights, K = 4096): the
     tiled copy must give the bits of the row-major weights there too."""
