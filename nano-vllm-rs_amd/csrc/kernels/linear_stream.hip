@@ -95,7 +95,8 @@ __global__ __launch_bounds__(WAVES * 64) void linear_stream_kernel(const half_t 
 
     if constexpr (IMG > 0) {
         static_assert(IMG <= TMAX && IMG <= 3 && PRE == 0 && NC >= 1, "IMG: tiles held by a workgroup, NC chunks of 1024 columns");
-        constexpr int KPW2 = MT <= 2 ? 4 : 2;                                // k-steps per wave and chunk
+        constexpr int KPW2 = (MT <= 2 && NTT == 1) ? 4 : 2;                  // k-steps per wave and chunk (gate_up, two weight parts per tile: 2, so that TWO sets
+                                                                             // of its 3 x 2 x 2 pieces fit the registers and no chunk boundary drains the stream)
         constexpr int KC2 = KPW2 * WAVES * 32, cpr2 = KC2 / 8;               // 1024 columns (33..64 rows, MT = 4: 512, so that two 64-row images fit the LDS); the
                                                                              // host passes KC = KC2, K = NC * KC2
         const int kmul = epi.tiled ? 16 : 1;
@@ -141,7 +142,8 @@ __global__ __launch_bounds__(WAVES * 64) void linear_stream_kernel(const half_t 
         // no scratch, every destination untouched until the wait that covers it).
         auto body = [&](auto ntl_c) {
             constexpr int NTL = decltype(ntl_c)::value;
-            constexpr bool DB = NTL * NTT * KPW2 * 2 <= 16;                  // two register sets of weight pieces (<= 64 VGPRs)
+            constexpr bool DB = NTL * NTT * KPW2 * 2 <= 16 || (MT <= 2 && NTL * NTT * KPW2 * 2 <= 24);   // two register sets of weight pieces (<= 64 VGPRs; 96 beside
+                                                                                                         // the 48 accumulators of gate_up at <= 32 rows)
             constexpr int NW = NTL * NTT * KPW2;                             // vector-memory requests of one chunk of weight pieces, per wave
             // address of a piece = a UNIFORM base (tile, part, chunk, k-step: scalar registers) + the thread's byte offset inside a 16-row tile (one VGPR
             // for the whole kernel; two for row-major qkv weights, whose rotary and value heads order their rows differently): as 64-bit per-thread
@@ -443,7 +445,7 @@ static int stream_launch(const half_t *x, int64_t ldx, const half_t *W, int T, i
     {   // r06: double-buffered LDS-DMA image, 1024-column chunks (IMG): up to 2 tiles per workgroup with one weight part each (qkv, plain), 3 with two (gate_up)
         constexpr int IMGT = NTT == 1 ? 2 : 3;
         if ((K == 2048 || K == 4096) && ntiles <= IMGT * nwg) {               // (NC = 2: hidden 2048; NC = 4: hidden 4096 — Qwen3-8B; other widths keep the r05 kernels)
-            constexpr int KC2 = MT <= 2 ? 1024 : 512;                         // chunk width (kernel: KPW2 * WAVES * 32)
+            constexpr int KC2 = (MT <= 2 && NTT == 1) ? 1024 : 512;           // chunk width (kernel: KPW2 * WAVES * 32)
             const size_t lds2 = std::max<size_t>((size_t)2 * MT * 16 * KC2 * 2, scratch);
             if (K == 4096) linear_stream_kernel<NTT, MT, S_WAVES, U, EPI, S_TMAX, 0, IMGT, 4096 / KC2><<<dim3((unsigned)nwg), dim3(S_WAVES * 64), lds2, s>>>(x, ldx, W, T, K, N, KC2, ntiles, y, e);
             else linear_stream_kernel<NTT, MT, S_WAVES, U, EPI, S_TMAX, 0, IMGT, 2048 / KC2><<<dim3((unsigned)nwg), dim3(S_WAVES * 64), lds2, s>>>(x, ldx, W, T, K, N, KC2, ntiles, y, e);
@@ -480,7 +482,7 @@ int linear_stream_prepare() {
 #define NVR_LS_IMG(NC_) \
         reinterpret_cast<const void *>(&linear_stream_kernel<1, 1, S_WAVES, 4, SEPI_F16, S_TMAX, 0, 2, NC_>), reinterpret_cast<const void *>(&linear_stream_kernel<1, 2, S_WAVES, 4, SEPI_F16, S_TMAX, 0, 2, NC_>), \
         reinterpret_cast<const void *>(&linear_stream_kernel<1, 1, S_WAVES, 4, SEPI_ROPE, S_TMAX, 0, 2, NC_>), reinterpret_cast<const void *>(&linear_stream_kernel<1, 2, S_WAVES, 4, SEPI_ROPE, S_TMAX, 0, 2, NC_>), \
-        reinterpret_cast<const void *>(&linear_stream_kernel<2, 1, S_WAVES, 2, SEPI_SILU, S_TMAX, 0, 3, NC_>), reinterpret_cast<const void *>(&linear_stream_kernel<2, 2, S_WAVES, 2, SEPI_SILU, S_TMAX, 0, 3, NC_>)
+        reinterpret_cast<const void *>(&linear_stream_kernel<2, 1, S_WAVES, 2, SEPI_SILU, S_TMAX, 0, 3, 2 * NC_>), reinterpret_cast<const void *>(&linear_stream_kernel<2, 2, S_WAVES, 2, SEPI_SILU, S_TMAX, 0, 3, 2 * NC_>)
         NVR_LS_IMG(2), NVR_LS_IMG(4),
 #define NVR_LS_IMG4(NC_) \
         reinterpret_cast<const void *>(&linear_stream_kernel<1, 4, S_WAVES, 4, SEPI_F16, S_TMAX, 0, 2, NC_>), reinterpret_cast<const void *>(&linear_stream_kernel<1, 4, S_WAVES, 4, SEPI_ROPE, S_TMAX, 0, 2, NC_>), \
