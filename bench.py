@@ -1184,8 +1184,9 @@ def main() -> None:
         # BASELINE.json configs[3] on the same ranks: Qwen3-8B, bs 32 x 2048, tensor parallel over the N GPUs (every rank takes part;
         # a hang here costs nothing already measured: the watchdog prints the line as it stands)
         fallback_state["line"] = line
-        if rank == 0 and line is not None:
-            # partial result first: a parent that has to cut this child short still has the tensor-parallel headline
+        if rank == 0 and line is not None and child:
+            # partial result first (children only: their stdout is read by the parent, which prints ONE line): a parent that has to cut this child
+            # short still has the tensor-parallel headline
             print(json.dumps(dict(line, partial="the configs[3] tensor-parallel side block was still running")), flush=True)
         arm("configs[3] tensor-parallel side block", 240.0)
 

@@ -438,7 +438,7 @@ def test_argmax_exact_with_ties():
                                    (128, 1024, 151936), (100, 512, 5008), (300, 256, 1000 * 16), (33, 4096, 2064),
                                    # r06: >= 256 rows go through the 256x256 tiles (one partial per 256-column tile; the vocabulary's last tile ragged:
                                    # 151 936 = 593 x 256 + 128, 18 992 = 74 x 256 + 48 (a tp-8 shard), 2064 = 8 x 256 + 16; ragged row blocks: 300, 257, 700)
-                                   (512, 1024, 151936), (256, 1024, 18992), (257, 4096, 2064), (700, 128, 4096), (1024, 1024, 75968),
+                                   (512, 1024, 151936), (256, 1024, 18992), (257, 4096, 2064), (700, 128, 4096), (1024, 1024, 75968), (200, 1024, 18992), (192, 512, 4112),
                                    # K > 2048 (Qwen3-8B: hidden 4096): the activation block goes through LDS in 2048-column chunks, every wave
                                    # keeps its tiles' accumulators in registers across the chunks
                                    (32, 4096, 151936), (7, 4096, 18992), (16, 6144, 4096), (1, 8192, 48), (32, 4096, 16 * 2048 * 8), (8, 5120, 4096), (20, 2560, 1024)])
