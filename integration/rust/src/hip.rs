@@ -161,6 +161,34 @@ impl LLMEngine {
         check(unsafe { ffi::nvr_engine_abort_last_batch(self.h) })?;
         check(unsafe { ffi::nvr_runner_p2p_reset(ffi::nvr_engine_runner(self.h)) })
     }
+    /// The one-shot collectives' protocol (kernels/comm_p2p.hip): false = fence-free (default), true = r04's release / acquire fences.  Every rank alike, before
+    /// the first step (the captured decode graphs are dropped); a control plane falls back fence-free -> fenced -> RCCL on a failed self-test.
+    pub fn set_p2p_fenced(&mut self, on: bool) -> anyhow::Result<()> {
+        check(unsafe { ffi::nvr_runner_p2p_set_fenced(ffi::nvr_engine_runner(self.h), on as i32) })
+    }
+    pub fn comm_selftest(&mut self) -> anyhow::Result<()> { check(unsafe { ffi::nvr_runner_comm_selftest(ffi::nvr_engine_runner(self.h)) }) }
 }
 impl Drop for LLMEngine { fn drop(&mut self) { unsafe { ffi::nvr_engine_destroy(self.h) } } }
 unsafe impl Send for LLMEngine {}
+
+// ---- Activation (src/layers/activation.rs:103-182): the enum, its FromStr and forward over device rows of the ops' 16-bit type
+#[derive(Clone, Copy, Debug, PartialEq)]
+pub enum ActivationType { SiLU = 0, GELU = 1, ReLU = 2, SiluAndMul = 3, GeluAndMul = 4 }
+impl std::str::FromStr for ActivationType {                                                                  // :169-182 (the library owns the table: one spelling of it)
+    type Err = anyhow::Error;
+    fn from_str(s: &str) -> anyhow::Result<Self> {
+        let c = std::ffi::CString::new(s)?;
+        let mut t = -1i32;
+        check(unsafe { ffi::nvr_activation_type_from_str(c.as_ptr(), &mut t) })?;
+        Ok(match t { 0 => Self::SiLU, 1 => Self::GELU, 2 => Self::ReLU, 3 => Self::SiluAndMul, _ => Self::GeluAndMul })
+    }
+}
+pub struct Activation { activation_type: ActivationType }
+impl Activation {
+    pub fn new(activation_type: ActivationType) -> Self { Self { activation_type } }                          // :121-145
+    pub fn activation_type(&self) -> &ActivationType { &self.activation_type }                               // :162-164
+    /// forward :147-159 on `rows` device rows of `cols` 16-bit elements; out has cols (SiLU / GELU / ReLU) or cols / 2 (the two fused types) columns
+    pub unsafe fn forward(&self, x: *const u16, rows: i64, cols: i64, out: *mut u16, stream: *mut c_void) -> anyhow::Result<()> {
+        check(ffi::nvr_activation(self.activation_type as i32, x, rows, cols, out, stream))
+    }
+}
