@@ -39,3 +39,43 @@ def test_linear_stream_rope_requests_are_not_touched_before_their_wait():
     no spilled VGPRs, and the destination registers are neither read nor written before the vmcnt wait that covers the requests."""
     import check_kernel_isa
     assert check_kernel_isa.check_linear_stream(verbose=False) == []
+
+
+def test_the_request_walker_follows_control_flow():
+    """tools/check_kernel_isa.py request_problems on hand-written ISA (no compiler needed): a covering wait on every path passes; a register copy of the
+    destination in front of the wait, a path that branches around the wait, and a wait that leaves the request itself in flight are reported."""
+    import check_kernel_isa as c
+    ok = """;;#ASMSTART
+global_load_dwordx4 v[10:13], v[2:3], off nt
+;;#ASMEND
+global_load_dwordx4 v[20:23], v[4:5], off
+s_cbranch_scc1 .LBB0_2
+v_add_u32_e32 v1, v2, v3
+.LBB0_2:
+s_waitcnt vmcnt(1)
+v_mov_b32_e32 v30, v10
+s_endpgm""".split("\n")
+    assert c.request_problems(ok, 1) == []
+    copied = list(ok); copied.insert(5, "v_mov_b32_e32 v40, v11")           # on the fall-through path, before the wait
+    assert any("touched before its wait" in p for p in c.request_problems(copied, 1))
+    around = """;;#ASMSTART
+global_load_dwordx4 v[10:13], v[2:3], off nt
+;;#ASMEND
+s_cbranch_execz .LBB0_3
+s_waitcnt vmcnt(0)
+.LBB0_3:
+v_mov_b32_e32 v30, v10
+s_endpgm""".split("\n")
+    assert any("touched before its wait" in p for p in c.request_problems(around, 1))     # the branch skips the wait
+    loose = """;;#ASMSTART
+global_load_dwordx4 v[10:13], v[2:3], off nt
+;;#ASMEND
+s_waitcnt vmcnt(1)
+v_mov_b32_e32 v30, v10
+s_endpgm""".split("\n")
+    assert any("touched before its wait" in p for p in c.request_problems(loose, 1))      # vmcnt(1) with nothing younger leaves the request in flight
+    nowait = """;;#ASMSTART
+global_load_dwordx4 v[10:13], v[2:3], off nt
+;;#ASMEND
+s_endpgm""".split("\n")
+    assert any("without a covering wait" in p for p in c.request_problems(nowait, 1))

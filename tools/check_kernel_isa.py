@@ -171,6 +171,49 @@ def _check_gemm_tiled_build(text, verbose):
     return bad
 
 
+def request_problems(lines, i):
+    """lines[i] is a vector-memory request issued by inline asm (destination VGPRs = its first operand).  Walks EVERY control-flow path from it (both outcomes of
+    each conditional branch, the target of each unconditional one) until a s_waitcnt vmcnt(c) that covers the request (at least c vector-memory loads issued
+    behind it on that path: vmcnt retires in issue order) and reports a destination register read or written before that wait, or a path that reaches the end of
+    the kernel without one.  The walk knows nothing about which branch outcomes are correlated: code that wants to pass it puts the covering wait on every path."""
+    labels = {l[:-1]: k for k, l in enumerate(lines) if re.match(r"^\.LBB\d+_\d+:$", l)}
+    dst = _vregs(lines[i].split()[1].rstrip(","))
+    problems, work, seen, uncovered = [], [(i + 1, 0)], {}, False
+    while work and not problems:
+        k, younger = work.pop()
+        while k < len(lines):
+            if seen.get(k, 1 << 30) <= younger:                  # (reached before with no more requests behind the one checked: nothing new)
+                break
+            seen[k] = younger
+            l = lines[k]; k += 1
+            if not l or l.startswith((";", ".")):
+                continue
+            w = re.match(r"s_waitcnt.*vmcnt\((\d+)\)", l)
+            if w and int(w.group(1)) <= younger:
+                break                                            # covered on this path
+            br = re.match(r"(s_branch|s_cbranch_\w+)\s+(\.LBB\d+_\d+)", l)
+            if br:
+                if br.group(2) in labels:
+                    work.append((labels[br.group(2)], younger))
+                if br.group(1) == "s_branch":
+                    break
+                continue
+            if l.startswith("s_endpgm"):
+                uncovered = True
+                break
+            ops = re.findall(r"v\[\d+:\d+\]|v\d+", l)
+            if any(_vregs(o) & dst for o in ops):
+                problems.append(f"v{sorted(dst)} touched before its wait: {l}")
+                break
+            if l.startswith(("global_load", "buffer_load", "flat_load")):
+                younger += 1
+        else:
+            uncovered = True
+    if uncovered and not problems:
+        problems.append("a path from the request reaches the end of the kernel without a covering wait")
+    return problems
+
+
 def check_linear_stream(verbose=True):
     """(r06: also the weight pieces of the IMG instantiations — global_load_dwordx4 by inline asm, two chunks in flight behind hand-counted waits.)
     ADVICE r05: linear_stream_kernel<.., SEPI_ROPE, ..> asks for its rows' RoPE positions (global_load_dwordx2) and cache slots (global_load_dword) by
@@ -196,44 +239,8 @@ def check_linear_stream(verbose=True):
                 problems.append("scratch traffic")
             if name in meta and meta[name][1]:
                 problems.append(f"{meta[name][1]} spilled VGPRs")
-            labels = {l[:-1]: k for k, l in enumerate(lines) if re.match(r"^\.LBB\d+_\d+:$", l)}
             for i in reqs:
-                # every control-flow path from the request (the requests sit in branches of their own: `if (epi.slots)` has an else that sets the register
-                # to -1 and is never on the request's path) until a vmcnt wait that covers it
-                dst = _vregs(lines[i].split()[1].rstrip(","))
-                work, seen, uncovered = [(i + 1, 0)], {}, False
-                while work and not problems:
-                    k, younger = work.pop()
-                    while k < len(lines):
-                        if seen.get(k, 1 << 30) <= younger:                  # (reached before with no more requests behind the one checked: nothing new)
-                            break
-                        seen[k] = younger
-                        l = lines[k]; k += 1
-                        if not l or l.startswith((";", ".")):
-                            continue
-                        w = re.match(r"s_waitcnt.*vmcnt\((\d+)\)", l)
-                        if w and int(w.group(1)) <= younger:
-                            break                                            # covered on this path
-                        br = re.match(r"(s_branch|s_cbranch_\w+)\s+(\.LBB\d+_\d+)", l)
-                        if br:
-                            if br.group(2) in labels:
-                                work.append((labels[br.group(2)], younger))
-                            if br.group(1) == "s_branch":
-                                break
-                            continue
-                        if l.startswith("s_endpgm"):
-                            uncovered = True
-                            break
-                        ops = re.findall(r"v\[\d+:\d+\]|v\d+", l)
-                        if any(_vregs(o) & dst for o in ops):
-                            problems.append(f"v{sorted(dst)} touched before its wait: {l}")
-                            break
-                        if l.startswith(("global_load", "buffer_load", "flat_load")):
-                            younger += 1
-                    else:
-                        uncovered = True
-                if uncovered and not problems:
-                    problems.append("a path from the request reaches the end of the kernel without a covering wait")
+                problems += request_problems(lines, i)
             if verbose:
                 sg = meta.get(name, (0, 0))[0]
                 print(f"{name[:100]:100s} {'OK' if not problems else '; '.join(sorted(set(problems)))}  ({len(reqs)} asm requests, {sg} SGPR spills)")
