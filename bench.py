@@ -992,7 +992,7 @@ def main() -> None:
         # the same engine path at larger batches: the step's share of the HBM roofline grows with the K/V bytes per launch
         batch_sweep = []
         for preset, bsz, plen in (("qwen3-0.6b", 64, 1024), ("qwen3-0.6b", 128, 1024), ("qwen3-0.6b", 256, 1024), ("qwen3-0.6b", 512, 1024),
-                                  ("qwen3-8b", 64, 2048), ("qwen3-8b", 128, 2048)):
+                                  ("qwen3-0.6b", 1024, 1024), ("qwen3-8b", 64, 2048), ("qwen3-8b", 128, 2048), ("qwen3-8b", 256, 2048)):
             try:
                 r = side_decode(nvr, preset, batch=bsz, prompt_len=plen, steps=8, warmup=3)
                 row = {k: r[k] for k in ("workload", "ms_per_step", "tokens_per_s", "step_algorithmic_bytes", "step_hbm_frac_per_gpu")}
