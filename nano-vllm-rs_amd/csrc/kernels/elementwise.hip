@@ -292,13 +292,13 @@ __global__ __launch_bounds__(WAVES * 64) void add_rmsnorm_slabs_kernel(half_t *_
 int add_rmsnorm_slabs(half_bits *h, const float *slabs, int64_t S, const half_bits *w, float eps, int64_t T, int64_t Hd,
                       half_bits *out, hipStream_t s) {
     if (Hd % 8 || Hd > 8192) return nvr::fail(NVR_ERR_UNSUPPORTED, "add_rmsnorm_slabs: hidden size %ld must be a multiple of 8, <= 8192", (long)Hd);
-    if (S != 2 && S != 4) return nvr::fail(NVR_ERR_UNSUPPORTED, "add_rmsnorm_slabs: S=%ld must be 2 or 4", (long)S);
+    if (S != 2 && S != 4 && S != 8) return nvr::fail(NVR_ERR_UNSUPPORTED, "add_rmsnorm_slabs: S=%ld must be 2, 4 or 8", (long)S);
     if (T == 0) return 0;
 #define NVR_SLABN(SS, CC, PP) add_rmsnorm_slabs_kernel<SS, 4, CC, PP><<<dim3((unsigned)T), dim3(256), 0, s>>>( \
         (half_t *)h, slabs, T * Hd, (const half_t *)w, eps, (int)Hd, (half_t *)out)
-    if (Hd <= 1024) { if (S == 2) NVR_SLABN(2, 1, 4); else NVR_SLABN(4, 1, 4); }
-    else if (Hd <= 2048) { if (S == 2) NVR_SLABN(2, 1, 8); else NVR_SLABN(4, 1, 8); }
-    else { if (S == 2) NVR_SLABN(2, 4, 8); else NVR_SLABN(4, 4, 8); }
+    if (Hd <= 1024) { if (S == 2) NVR_SLABN(2, 1, 4); else if (S == 4) NVR_SLABN(4, 1, 4); else NVR_SLABN(8, 1, 4); }
+    else if (Hd <= 2048) { if (S == 2) NVR_SLABN(2, 1, 8); else if (S == 4) NVR_SLABN(4, 1, 8); else NVR_SLABN(8, 1, 8); }
+    else { if (S == 2) NVR_SLABN(2, 4, 8); else if (S == 4) NVR_SLABN(4, 4, 8); else NVR_SLABN(8, 4, 8); }
 #undef NVR_SLABN
     LAUNCH_CHECK();
     return 0;

@@ -457,8 +457,8 @@ static bool tiled_ring(unsigned tiles) { return tiles < 256; }
 // 64- or 32-token tiles when 128-token tiles would leave CUs without a workgroup: the largest tile that reaches ~192 workgroups
 // Returns the m-tiles per wave (4, 2, 1).
 static int tiled_mt(int64_t T, int64_t nx_nz) {
-    if (T <= 32 || nx_nz * ((T + 127) / 128) >= 192) return 4;   // (192 workgroups of 128 tokens beat 384 of 64: 15.6 vs 19.3 us, gate_up at T = 512)
-    if (nx_nz * ((T + 63) / 64) >= 192) return 2;
+    if (T > 64 && nx_nz * ((T + 127) / 128) >= 192) return 4;    // (192 workgroups of 128 tokens beat 384 of 64: 15.6 vs 19.3 us, gate_up at T = 512)
+    if (nx_nz * ((T + 63) / 64) >= 192) return 2;                 // (33..64 rows never take a 128-token tile: half of it would be masked rows)
     return 1;
 }
 constexpr size_t kStageBytes = 2 * BM * BK * 2;                          // MT = 4

@@ -52,6 +52,7 @@ int tp_argmax_merge(const TpArgmaxRec *recs, int tp, int64_t B, int64_t *out_hos
                     hipStream_t s);
 
 int64_t stream_row_limit();    // rows up to which the weight-streaming kernels are preferred over the LDS-tiled GEMM (linear.hip)
+bool splitk_prefers_tiles(int64_t T, int64_t K, int64_t N);   // linear_splitk takes the LDS-tiled kernel (gemm_tiled_splitk) for this shape
 int linear_splitk(const half_bits *x, int64_t ldx, const half_bits *W, int64_t T, int64_t K, int64_t N, int64_t S,
                   float *slabs, hipStream_t s, const half_bits *Wt = nullptr);
 // h = fp16(h + fp16(sum_z slabs[z])), out = rmsnorm(h)*w

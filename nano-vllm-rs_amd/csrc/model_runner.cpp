@@ -592,6 +592,11 @@ int nvr_model_runner::row_parallel_norm(const uint16_t *x, int64_t K, const uint
     int64_t S = 1;
     if (!comm.active() && tp == 1 && T <= 64 && T <= KD(stream_row_limit()) && Hd <= 2048) {
         S = KD(decode_splitk_slices(T, K, Hd));
+    } else if (!comm.active() && tp == 1 && T > 32 && T <= 64 && Hd <= 8192 && KD(splitk_prefers_tiles(T, K, Hd)) && 8 * T <= 4 * slab_rows &&
+               KD(gemm_tiled_splitk_ok(T, K, Hd, 4, K))) {
+        // 33..64 rows over large weights (Qwen3-8B bs 64): one 64-token tile per 128 weight rows, k split until ~256 workgroups stream the
+        // weights ONCE (the streaming split-k kernel below walks them once per 32-row block: o + down 92 -> 27 us per layer)
+        S = (((Hd + 127) / 128) * 8 <= 320 && KD(gemm_tiled_splitk_ok(T, K, Hd, 8, K))) ? 8 : 4;
     } else if (!comm.active() && tp == 1 && T <= 32 && Hd <= 8192 && Hd % 64 == 0 && Hd * K * 2 >= (24ll << 20) && K % 128 == 0) {
         S = 4;                                       // large weights: 64-column workgroups x 4 k-slices (linear_splitk)
     } else if (!comm.active() && tp == 1 && T > KD(stream_row_limit()) && T <= slab_rows && Hd <= 8192 && ((Hd + 127) / 128) * ((T + 127) / 128) <= 64 &&

@@ -55,7 +55,7 @@ struct nvr_model_runner {
              *nlast = nullptr;
     float *logits = nullptr; void *attn_ws = nullptr; size_t attn_ws_bytes = 0;
     unsigned int *attn_tickets = nullptr;  // [max_seqs * KVH] arrival counters of the split-KV decode attention (fused merge; zero between launches)
-    float *slabs = nullptr;                // split-k partials of o_proj / down_proj for decode-sized steps: [4][64][Hd] f32
+    float *slabs = nullptr;                // split-k partials of o_proj / down_proj: [S][T][Hd] f32, S * T <= 4 * slab_rows
     // step inputs: one pinned host arena mirrored by one device arena
     char *in_host = nullptr, *in_dev = nullptr; size_t in_bytes = 0;
     int64_t *d_ids = nullptr, *d_pos = nullptr; int32_t *d_slots = nullptr, *d_cu = nullptr, *d_ctx = nullptr,

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, nvr_import
 nvr = nvr_import.load()
 mc = nvr.ModelConfig("qwen3-8b")
-B, P, steps = 32, int(os.environ.get("PROMPT", "2048")), 24
+B, P, steps = int(os.environ.get("BATCH", "32")), int(os.environ.get("PROMPT", "2048")), 24
 TP = int(os.environ.get("TP", "1"))
 t0 = time.perf_counter()
 eng = nvr.LLMEngine(nvr.Config(max_num_seqs=B, max_num_batched_tokens=32768, max_model_len=P + 64, kvcache_block_size=256,

@@ -770,7 +770,9 @@ def _retiled(d_W, N, K, mode=0, H=0, KVH=0, D=0):
 
 @pytest.mark.parametrize("T,K,N,S", [(32, 2048, 1024, 4), (32, 3072, 1024, 4), (5, 256, 64, 2), (40, 512, 256, 4),
                                      (32, 4096, 4096, 4), (9, 12288, 4096, 4), (32, 4096, 8192, 2),   # large weights: 64-column workgroups, wide rows
-                                     (130, 2048, 1024, 4), (300, 3072, 1024, 4), (70, 512, 256, 2), (512, 1024, 2048, 4)])   # > 64 rows: k-split of the 128x128 kernel
+                                     (130, 2048, 1024, 4), (300, 3072, 1024, 4), (70, 512, 256, 2), (512, 1024, 2048, 4),   # > 64 rows: k-split of the 128x128 kernel
+                                     (64, 4096, 4096, 8), (40, 12288, 4096, 8), (48, 4096, 4096, 4),     # 33..64 rows over large weights: the tiles too (r06), 8 slices
+                                     (40, 1024, 256, 8), (33, 2048, 2048, 8)])                           # 8 slices on the streaming kernel, every slab-norm width
 def test_linear_splitk_and_slab_norm(T, K, N, S):
     """split-k slabs + add_rmsnorm_slabs == linear -> fp16 -> add -> rmsnorm (the unfused graph order)."""
     rng = np.random.default_rng(22)

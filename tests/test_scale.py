@@ -93,6 +93,20 @@ def test_qwen3_8b_geometry_two_layers():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("nseq", [40, 64])
+def test_qwen3_8b_geometry_decode_batches_of_33_to_64_rows(nseq):
+    """The same two layers with 40 / 64 sequences in the decode batch: qkv and gate_up on the streaming kernels' 64-row images, o_proj /
+    down_proj on the split-k LDS tiles with 8 k-slices (r06: the streaming split-k kernel walked the weights once per 32-row block)."""
+    mcfg = mo.ModelConfig(vocab_size=4096, hidden_size=4096, intermediate_size=12288, num_hidden_layers=2, num_attention_heads=32,
+                          num_key_value_heads=8, head_dim=128, rope_theta=1e6, tie_word_embeddings=False,
+                          max_position_embeddings=1024, init_std=0.02, seed=21)
+    ecfg = dict(max_num_seqs=nseq, max_num_batched_tokens=2048, max_model_len=256, kvcache_block_size=256, num_kvcache_blocks=nseq + 4)
+    prompts = [nvr.synthetic_tokens(6 + i % 9, 1, i, 4096).tolist() for i in range(nseq)]
+    ties, worst = _parity(mcfg, ecfg, prompts, 4)
+    assert ties <= 2
+
+
+@pytest.mark.gpu
 def test_qwen3_0_6b_full_size_spot_check():
     """The benchmark model itself (28 layers, V=151936, tied head) against the oracle on two short prompts."""
     mcfg = mo.qwen3_0_6b()
