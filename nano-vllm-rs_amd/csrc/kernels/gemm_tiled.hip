@@ -454,12 +454,19 @@ static int tiled_check(const char *what) {
 
 // ring (NS = 4) when the grid leaves CUs idle anyway
 static bool tiled_ring(unsigned tiles) { return tiles < 256; }
-// 64- or 32-token tiles when 128-token tiles would leave CUs without a workgroup: the largest tile that reaches ~192 workgroups
-// Returns the m-tiles per wave (4, 2, 1).
+// 64- or 32-token tiles when 128-token tiles would leave CUs without a workgroup: the largest tile that reaches ~192 workgroups — unless that count
+// needs a second, mostly empty round: with the 4-buffer ring a 64-token workgroup is alone on its CU (96 KB of LDS), so 257..511 of them run as one full
+// round + a tail while half as many tiles of twice the height finish in one (scratch/route_scan.py: Qwen3-0.6B bs 384 -> 385 got FASTER, 3.87 -> 3.67
+// ms/step; r06: bs 321..384 -3..5 %, bs 513 -4 %).  Returns the m-tiles per wave (4, 2, 1).
 static int tiled_mt(int64_t T, int64_t nx_nz) {
-    if (T > 64 && nx_nz * ((T + 127) / 128) >= 192) return 4;    // (192 workgroups of 128 tokens beat 384 of 64: 15.6 vs 19.3 us, gate_up at T = 512)
-    if (nx_nz * ((T + 63) / 64) >= 192) return 2;                 // (33..64 rows never take a 128-token tile: half of it would be masked rows)
-    return 1;
+    int mt = 1;
+    if (T > 64 && nx_nz * ((T + 127) / 128) >= 192) mt = 4;       // (192 workgroups of 128 tokens beat 384 of 64: 15.6 vs 19.3 us, gate_up at T = 512)
+    else if (nx_nz * ((T + 63) / 64) >= 192) mt = 2;              // (33..64 rows never take a 128-token tile: half of it would be masked rows)
+    if (mt == 2 && T > 64) {
+        const int64_t wgs = nx_nz * ((T + 63) / 64), taller = nx_nz * ((T + 127) / 128);
+        if (wgs > 256 && wgs < 512 && taller >= 128) mt = 4;      // (< 512: NVR_TILED_LAUNCH gives them the ring, one workgroup per CU)
+    }
+    return mt;
 }
 constexpr size_t kStageBytes = 2 * BM * BK * 2;                          // MT = 4
 constexpr size_t kStageBytes64 = (BN + 64) * BK * 2;                     // MT = 2
@@ -547,7 +554,8 @@ int gemm_tiled_silu_mul(const half_bits *x, int64_t ldx, const half_bits *W, int
     if (!gemm_tiled_ok(T, K, I, ldx) || I % 64) return nvr::fail(NVR_ERR_UNSUPPORTED, "gemm_tiled_silu_mul: T=%ld K=%ld I=%ld", (long)T, (long)K, (long)I);
     dim3 grid((unsigned)(I / 64), (unsigned)((T + BM - 1) / BM));
     if (int rc = gemm_tiled_prepare()) return rc;
-    {   // 96-row tiles when they put a workgroup on (nearly) every CU where the 128-row tiles leave a quarter of them idle (T = 512, I = 3072: 256 against 192)
+    {   // 96-row tiles when they put a workgroup on (nearly) every CU where the 128-row tiles leave a quarter of them idle (T = 512, I = 3072: 256 against 192;
+        // T = 321..384: 192 against 144)
         const int64_t ty = (T + BM - 1) / BM, w128 = (I / 64) * ty, w96 = (I / 48) * ty;
         if (I % 48 == 0 && tiled_mt(T, I / 64) == 4 && tiled_ring((unsigned)w128) && w96 <= 256 && w96 > w128 && w128 * 8 <= w96 * 7) {
             gemm_tiled_silu96_kernel<<<dim3((unsigned)(I / 48), (unsigned)ty), dim3(256), RING96 * S96_BUF, s>>>((const half_t *)x, ldx, (const half_t *)W, (int)T, (int)K, (int)I, (half_t *)out);
