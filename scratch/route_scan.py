@@ -21,4 +21,4 @@ for B in map(int, sys.argv[3:]):
     print(f"{preset} ctx {P}: bs {B:4d}  {ms:7.3f} ms/step  {ms / B * 1e3:7.2f} us per sequence{flag}", flush=True)
     prev = (B, ms)
     del eng
-os._exit(0)
+if not os.environ.get("NVR_NO_EXIT"): os._exit(0)
