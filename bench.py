@@ -661,6 +661,13 @@ def main() -> None:
     args = ap.parse_args()
     global BATCH, PROMPT_LEN
     BATCH, PROMPT_LEN = MODELS[args.model]["batch"], MODELS[args.model]["prompt_len"]
+    # Control-plane dry runs of 4 / 8 rank PROCESSES on ONE GPU only (tools/tp_dryrun.sh, NRANKS >= 4): every cross-process rendezvous of a one-shot collective
+    # then costs a scheduling quantum of the shared device (~30 ms), and the 3 584 slot-sized launches of a 32 x 1024 prefill without RCCL (which refuses two ranks
+    # on one device) outlast the 30 s token wait.  Short prompts keep the dry run a test of the flow — rendezvous, self-tests, protocol chain, token crc, the
+    # configs[3] child — and the line says so (config.workload, config.dry_run).  Ignored unless NVR_BENCH_SHARED_GPU is set: never in a measurement.
+    dry_prompt = int(os.environ.get("NVR_BENCH_DRYRUN_PROMPT_LEN", "0")) if os.environ.get("NVR_BENCH_SHARED_GPU") else 0
+    if dry_prompt > 0:
+        PROMPT_LEN = dry_prompt
     if args.materialize_logits:
         os.environ["NVR_LAZY_LOGITS"] = "0"
 
@@ -731,7 +738,10 @@ def main() -> None:
                          kvcache_block_size=BLOCK, num_kvcache_blocks=2 * BATCH * ((PROMPT_LEN + total_new + 16) // BLOCK + 2),
                          tensor_parallel_size=tp_size, tensor_parallel_rank=tp_rank,
                          device_ordinal=local_rank, enforce_eager=args.eager, **({"async_decode": 0} if args.sync_decode else {}))   # (default: launch-ahead on, nvr_config_default)
-        return nvr.LLMEngine(cfg, mc)
+        e = nvr.LLMEngine(cfg, mc)
+        if tp_size > 1 and os.environ.get("NVR_BENCH_TP_PREFILL_OVERLAP"):   # (0 = serial prefill exchange on the compute stream: see tools/tp_dryrun.sh, NRANKS >= 4)
+            e.model_runner.set_tp_prefill_overlap(int(os.environ["NVR_BENCH_TP_PREFILL_OVERLAP"]))
+        return e
 
     def barrier():
         nvr.synchronize()
@@ -1090,6 +1100,7 @@ def main() -> None:
             "config": {"workload": f"{MODELS[args.model]['label']} fp16 random-init, bs={BATCH} x {PROMPT_LEN}-token prompts, greedy paged-attention decode, "
                                    f"block_size=256, hipGraph decode steps (BASELINE.json configs[{MODELS[args.model]['baseline_config']}])",
                        "batch": BATCH, "prompt_len": PROMPT_LEN, "mean_context": ctx_mean,
+                       **({"dry_run": f"control-plane dry run: {world} rank processes on ONE GPU, prompts shortened to {dry_prompt} tokens (NVR_BENCH_DRYRUN_PROMPT_LEN); not a measurement"} if dry_prompt > 0 else {}),
                        "parallelism": parallelism, "hipgraph": not args.eager,
                        "async_decode": ("nvr_config.async_decode (default 1 since r05): "
                                         + ("on" if (not args.sync_decode and (args.gpus == 1 or parallelism.startswith("replicas") or TP_ASYNC)) else "off")),
@@ -1193,7 +1204,8 @@ def main() -> None:
         def rmax(v):
             return dist.max(v)
         try:
-            c3 = side_decode(nvr, "qwen3-8b", tp_size=args.gpus, tp_rank=rank, device=local_rank, attach=init_tensor_parallel, barrier=barrier, reduce_max=rmax)
+            c3 = side_decode(nvr, "qwen3-8b", tp_size=args.gpus, tp_rank=rank, device=local_rank, attach=init_tensor_parallel, barrier=barrier, reduce_max=rmax,
+                             prompt_len=dry_prompt or None)
         except Exception as ex:                                              # noqa: BLE001
             c3 = {"error": str(ex)[:300]}
         if line is not None:

@@ -1,6 +1,6 @@
 #!/bin/bash
 # r06: dry runs of `bench.py --gpus 2` as two PROCESSES sharing one GPU (NVR_BENCH_SHARED_GPU=1), one per fallback edge of the tensor-parallel phase
-# (VERDICT r05 item 3).  Each run's JSON line goes to gpurun_out/r06_dryrun_<name>.json (copied to profiles/ by hand), stderr next to it.
+# (NRANKS=4 / 8 in the environment: the same with 4 / 8 processes).  Each run's JSON line goes to gpurun_out/r06_dryrun_<name>.json (copied to profiles/ by hand), stderr next to it.
 #   default                   fence-free self-test passes: the tensor-parallel line, collective_backend = p2p_fence_free
 #   selftest_fence_free_fails NVR_SELFTEST_INJECT=1: every rank's first self-test fails -> p2p_reset -> fenced -> passes: p2p_fenced
 #   selftest_p2p_fails        NVR_SELFTEST_INJECT=2: both protocols fail -> RCCL alone (two ranks on ONE device: RCCL refuses; the line falls back to replicas)
@@ -14,8 +14,8 @@ run() {
     name=$1; shift
     port=$((port + 10))
     t0=$(date +%s)
-    env "$@" timeout 1500 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port $port \
-        bench.py --gpus 2 --steps 20 --warmup 5 > gpurun_out/r06_dryrun_$name.json 2> gpurun_out/r06_dryrun_$name.err
+    env "$@" timeout 1500 python -m torch.distributed.run --nnodes=1 --nproc-per-node ${NRANKS:-2} --master-addr 127.0.0.1 --master-port $port \
+        bench.py --gpus ${NRANKS:-2} --steps 20 --warmup 5 $BENCH_ARGS > gpurun_out/r06_dryrun_$name.json 2> gpurun_out/r06_dryrun_$name.err
     echo "$name: rc $? in $(( $(date +%s) - t0 )) s: $(python - <<PY
 import json
 try:
