@@ -1090,11 +1090,13 @@ def test_tiled_entry_points_match_row_major_stream_shapes(T):
     assert_close_f16(ob.to_numpy((T, I), F16)[:, :64], ref, ulps=2, atol=3e-4, what="stream silu tiled vs oracle")
 
 
-@pytest.mark.parametrize("T", [70, 100, 200, 400, 512])
+@pytest.mark.parametrize("T", [70, 100, 200, 352, 400, 512, 600])
 def test_gemm_tiled_tile_heights(T):
-    """Decode batches of 65..512 rows take the LDS-tiled GEMM with 32-, 64- or 128-token tiles (the largest that reaches ~192
+    """Decode batches of 65..512 rows (and beyond) take the LDS-tiled GEMM with 32-, 64- or 128-token tiles (the largest that reaches ~192
     workgroups: T = 70 / 100 -> 32-token tiles for qkv, T = 512 -> 64-token tiles; gate_up at 385..512 rows -> the 96-row x 128-token
-    SiLU tiles of r05, 256 workgroups instead of 192; T = 400: a ragged last token tile): plain, SiLU, RoPE + KV store and split-k
+    SiLU tiles of r05, 256 workgroups instead of 192; T = 400: a ragged last token tile; r06: 257..511 ring workgroups of 64 tokens become
+    half as many 128-token tiles — T = 352: gate_up on three 96-row tiles, the last one ragged; T = 600: qkv and split-k on five 128-token
+    tiles): plain, SiLU, RoPE + KV store and split-k
     epilogues on the Qwen3-0.6B shapes against the oracle, and the fused gate_up + SiluAndMul against the plain GEMM followed by
     nvr_silu_and_mul bit for bit (every tiling keeps the K order of an output)."""
     rng = np.random.default_rng(60 + T)
