@@ -127,7 +127,9 @@ int nvr_model_runner::init() {                                       // ModelRun
     if (f32 && tp == 1 && env.f32_fused_norm) NVR_HIP_CHECK(hipMalloc((void **)&f32_h2, (size_t)8 * (size_t)Hd * sizeof(float)));
     f32_gather_rows = std::min<int64_t>(max_tokens, std::max<int64_t>(max_seqs, 2048));
     if (f32 && tp > 1) NVR_HIP_CHECK(hipMalloc((void **)&f32_gather, (size_t)tp * (size_t)f32_gather_rows * (size_t)Hd * sizeof(float)));
-    slab_rows = std::max<int64_t>(64, std::min<int64_t>(1024, std::max<int64_t>(max_seqs, 256)));
+    // (rows of a STEP, prefill steps included: sized by max_seqs alone, a prefill of 257..1024 tokens on an engine of few sequences lost the split-k route
+    //  and fell to 9-12 row blocks of the streaming kernel — Qwen3-0.6B, 8 sequences: 257 tokens 2.38 ms against 1.49 ms for 256; scratch/prefill_scan.py)
+    slab_rows = std::max<int64_t>(64, std::min<int64_t>(1024, std::max<int64_t>({max_seqs, max_tokens, 256})));
     RC(dmalloc(&slabs, 4 * slab_rows * Hd));
     { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && v > 0) num_cus = v; }
     allow_missing_comm = env.tp_no_comm;                                               // compute-only profiling of one rank
