@@ -8,7 +8,8 @@ preset, P = sys.argv[1], int(sys.argv[2])
 mc = nvr.ModelConfig(preset)
 prev = None
 for B in map(int, sys.argv[3:]):
-    eng = nvr.LLMEngine(nvr.Config(max_num_seqs=B, max_num_batched_tokens=32768, max_model_len=P + 64, kvcache_block_size=256, num_kvcache_blocks=B * (P // 256 + 2)), mc)
+    eng = nvr.LLMEngine(nvr.Config(max_num_seqs=B, max_num_batched_tokens=32768, max_model_len=P + 64, kvcache_block_size=256, num_kvcache_blocks=B * (P // 256 + 2),
+                                   tensor_parallel_size=int(os.environ.get("TP", "1")), tensor_parallel_rank=0), mc)   # TP=n with NVR_TP_NO_COMM=1: ONE rank's compute, exchanges skipped
     for i in range(B):
         eng.add_request(nvr.synthetic_tokens(P, 1, i, 151936).tolist(), nvr.SamplingParams(temperature=0.0, max_tokens=40, ignore_eos=True))
     while eng.step()["is_prefill"]: pass
