@@ -441,7 +441,222 @@ __global__ __launch_bounds__(256) void attn_merge_kernel(const float *__restrict
     *reinterpret_cast<half4_t *>(out + pair * D + d) = hv;
 }
 
+// ---- work-balanced form (r06) ---------------------------------------------------------------------------------------
+// attn_rows_kernel gives every (query, kv head) pair its own workgroup(s): 264 pairs on 256 CUs (33 sequences x 8 kv heads) run as one full round and a tail,
+// 35.6 us per layer where 256 pairs take 24.5 (profiles/r06_priced_levers.txt 9.).  Here the launch is nw workgroups (one per CU) and the WORK is cut evenly: the
+// keys of all pairs, in units of CH = WAVES * TPI keys (one full round of a workgroup), pair after pair (query-major), form one line of U_tot units; workgroup w
+// walks the units [w * U_tot / nw, (w + 1) * U_tot / nw) — a suffix of one pair, whole pairs, a prefix of another.  A pair that lies inside one share is written
+// directly; a pair cut by share boundaries leaves one f32 partial per share (slot = share index - first share of the pair) and the LAST of its shares to finish
+// merges them (the ticket scheme of FUSE above: sc1 partials, one counter per pair, nobody polls; merge_partitions: the same arithmetic).
+// Paged K/V through block tables whose block size is a power of two >= TPI (the scalar block-table form), nt loads; per-segment arithmetic = attn_rows_kernel's.
+template <int D, int G, int U, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void attn_share_kernel(AttnParams p, int nq, int nw) {
+    constexpr int LPR = D / 8, RPI = 64 / LPR, TPI = RPI * U, CH = TPI * WAVES;
+    static_assert(G * D <= WAVES * 64 && G * (D / 4) <= WAVES * 64, "one pass over the (head, column) pairs");
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int dc = lane % LPR, tg = lane / LPR;
+    __shared__ int pre[1025];                               // pre[t] = units of the queries in front of t (a query's KVH pairs have the same count)
+    __shared__ float sm_acc[WAVES][G][D];
+    __shared__ float sm_ml[WAVES][G][2];
+    __shared__ unsigned int ticket_s;
+    if (wave == 0) {
+        int base = 0;
+        for (int k = 0; k < nq; k += 64) {
+            const int t = k + lane;
+            int un = t < nq ? (p.ctx_lens[t] + CH - 1) / CH : 0;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(un, o, 64); if (lane >= o) un += v; }
+            if (t < nq) pre[t + 1] = base + un;
+            base += __shfl(un, 63, 64);
+        }
+        if (lane == 0) pre[0] = 0;
+    }
+    __syncthreads();
+    const long long utot = (long long)p.KVH * pre[nq];
+    const long long ub = (long long)blockIdx.x * utot / nw, ue = (long long)(blockIdx.x + 1) * utot / nw;
+    const int row_elems = p.KVH * D;
+    for (long long u = ub; u < ue;) {
+        // the query of unit u: the last t with KVH * pre[t] <= u (queries without keys own no unit and are never found)
+        int lo = 0, hi = nq;
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((long long)p.KVH * pre[mid] <= u) lo = mid; else hi = mid; }
+        const int t = lo, ut = pre[t + 1] - pre[t];
+        const int rem = (int)(u - (long long)p.KVH * pre[t]);
+        const int g = rem / ut, lu = rem - g * ut;
+        const int seg = (int)min((long long)(ut - lu), ue - u);
+        u += seg;
+        // shares that touch this pair: unit x belongs to share floor(((x + 1) * nw - 1) / utot)
+        const long long S = (long long)p.KVH * pre[t] + (long long)g * ut, E = S + ut - 1;
+        const int wf = (int)(((S + 1) * nw - 1) / utot), wl = (int)(((E + 1) * nw - 1) / utot);
+        const int np = wl - wf + 1, slot = (int)blockIdx.x - wf;
+
+        const int32_t *bt = p.block_tables + (int64_t)t * p.max_blocks;
+        const int ctx = p.ctx_lens[t];
+        const int p0 = lu * CH, pend = min(ctx, (lu + seg) * CH);
+        int bt_chunk = (p0 >> p.bs_shift) >> 6, bt_reg;
+        { const int idx = (bt_chunk << 6) + lane; bt_reg = idx < p.max_blocks ? bt[idx] : 0; }
+        half2_t qv[G][4];
+        {
+            const half_t *qrow = p.q + (int64_t)t * p.ldq + (int64_t)g * G * D + dc * 8;
+#pragma unroll
+            for (int i = 0; i < G; ++i) {
+                const half8_t h = *reinterpret_cast<const half8_t *>(qrow + i * D);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) qv[i][j] = (half2_t){h[2 * j], h[2 * j + 1]};
+            }
+        }
+        auto block_base = [&](int tb) -> int64_t {              // element offset of (scalar token tb, kv head g, d = 0)
+            const int bi = tb >> p.bs_shift, bo = tb & (p.block_size - 1);
+            if ((bi >> 6) != bt_chunk) { bt_chunk = bi >> 6; const int idx = (bt_chunk << 6) + lane; bt_reg = idx < p.max_blocks ? bt[idx] : 0; }
+            const int blk = __builtin_amdgcn_readlane(bt_reg, bi & 63);
+            return (((int64_t)blk * p.block_size + bo) * p.KVH + g) * D;
+        };
+        float m[G], l[G], acc[G][8];
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            m[i] = -INFINITY; l[i] = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[i][j] = 0.f;
+        }
+        auto process = [&](auto check, const half8_t (&kk)[U], const half8_t (&vv)[U], int tok0) {
+            constexpr bool CHECK = decltype(check)::value;
+            float sc[U][G];
+#pragma unroll
+            for (int x = 0; x < U; ++x) {
+                const bool valid = !CHECK || tok0 + x * (WAVES * RPI) + tg < pend;
+#pragma unroll
+                for (int i = 0; i < G; ++i) {
+                    float d = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) d = dot2((half2_t){kk[x][2 * j], kk[x][2 * j + 1]}, qv[i][j], d);
+                    d = row_sum<LPR>(d);
+                    sc[x][i] = valid ? d * p.scale : -INFINITY;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < G; ++i) {
+                float mx = sc[0][i];
+#pragma unroll
+                for (int x = 1; x < U; ++x) mx = fmaxf(mx, sc[x][i]);
+                const float mn = fmaxf(m[i], mx);
+                const float ms = (CHECK && mn == -INFINITY) ? 0.f : mn;
+                const float alpha = __expf(m[i] - ms);
+                m[i] = mn;
+                float ps = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[i][j] *= alpha;
+#pragma unroll
+                for (int x = 0; x < U; ++x) {
+                    const float pr = __expf(sc[x][i] - ms);
+                    ps += pr;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[i][j] = fmaf(pr, (float)vv[x][j], acc[i][j]);
+                }
+                l[i] = __fmaf_rn(l[i], alpha, ps);
+            }
+        };
+        const int ng = (pend - p0 + RPI - 1) / RPI;
+        const int R = (pend - p0) / CH;
+        const int gt0 = R * (WAVES * U) + wave;
+        auto issue_remainder = [&](half8_t (&kt)[U], half8_t (&vt)[U]) {
+#pragma unroll
+            for (int x = 0; x < U; ++x) {
+                const int gt = gt0 + x * WAVES;
+                if (gt < ng) {
+                    const int tb = p0 + gt * RPI;
+                    const int64_t base = block_base(tb);
+                    const unsigned off = (unsigned)(min(tg, pend - 1 - tb) * row_elems + dc * 8);
+                    kt[x] = load_row16<true>(p.k + base + off); vt[x] = load_row16<true>(p.v + base + off);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { kt[x][j] = (half_t)0.f; vt[x][j] = (half_t)0.f; }
+                }
+            }
+        };
+        half8_t kt[U], vt[U];
+        if (R == 0) issue_remainder(kt, vt);
+        for (int r = 0; r < R; ++r) {
+            const int tb = p0 + (r * WAVES + wave) * TPI;
+            half8_t kk[U], vv[U];
+            const int64_t base = block_base(tb);
+#pragma unroll
+            for (int x = 0; x < U; ++x) {
+                const unsigned off = (unsigned)((x * RPI + tg) * row_elems + dc * 8);
+                kk[x] = load_row16<true>(p.k + base + off); vv[x] = load_row16<true>(p.v + base + off);
+            }
+            if (r == R - 1) issue_remainder(kt, vt);
+            process(std::false_type{}, kk, vv, 0);
+        }
+        if (gt0 < ng) process(std::true_type{}, kt, vt, p0 + gt0 * RPI);
+
+        // row-group slots of the wave -> the wave's sums; waves -> the segment's partial (attn_rows_kernel's arithmetic)
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            const float M = groups_max<LPR>(m[i]);
+            const float w = (m[i] == -INFINITY) ? 0.f : __expf(m[i] - M);
+            l[i] = groups_sum<LPR>(l[i] * w);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[i][j] = groups_sum<LPR>(acc[i][j] * w);
+            if (tg == 0) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) sm_acc[wave][i][dc * 8 + j] = acc[i][j];
+                if (dc == 0) { sm_ml[wave][i][0] = M; sm_ml[wave][i][1] = l[i]; }
+            }
+        }
+        __syncthreads();
+        const int64_t pair0 = ((int64_t)t * p.H + (int64_t)g * G) * p.num_parts;
+        const auto rs_o = __builtin_amdgcn_make_buffer_rsrc(p.part_o + pair0 * D, 0, (int)(G * p.num_parts * D * 4), 0x00020000);
+        const auto rs_ml = __builtin_amdgcn_make_buffer_rsrc(p.part_ml + pair0 * 2, 0, (int)(G * p.num_parts * 2 * 4), 0x00020000);
+        if (threadIdx.x < G * D) {
+            const int i = threadIdx.x / D, d = threadIdx.x % D;
+            float M = sm_ml[0][i][0];
+#pragma unroll
+            for (int w2 = 1; w2 < WAVES; ++w2) M = fmaxf(M, sm_ml[w2][i][0]);
+            float o = 0.f, L = 0.f;
+#pragma unroll
+            for (int w2 = 0; w2 < WAVES; ++w2) {
+                const float mw = sm_ml[w2][i][0];
+                const float wgt = (mw == -INFINITY) ? 0.f : __expf(mw - M);
+                o = mul_then_add(wgt, sm_acc[w2][i][d], o);
+                L = mul_then_add(wgt, sm_ml[w2][i][1], L);
+            }
+            if (np == 1) {
+                p.out[((int64_t)t * p.H + g * G + i) * D + d] = (half_t)(L > 0.f ? o / L : 0.f);
+            } else {
+                const int sl = i * p.num_parts + slot;
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o), rs_o, (sl * D + d) * 4, 0, 16);
+                if (d == 0) { __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(M), rs_ml, sl * 8, 0, 16);
+                              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(L), rs_ml, sl * 8 + 4, 0, 16); }
+            }
+        }
+        if (np > 1) {                                                         // (workgroup-uniform)
+            constexpr int TPH = D / 4;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // every storing wave drains its stores ...
+            __syncthreads();
+            unsigned int *cnt = p.tickets + (int64_t)t * p.KVH + g;
+            if (threadIdx.x == 0) ticket_s = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... one ticket
+            __syncthreads();
+            if (ticket_s == (unsigned)(np - 1)) {                             // the last of the pair's shares to finish merges it
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");        // keeps the sc1 loads below the ticket
+                if (threadIdx.x < G * TPH) {
+                    const int i = threadIdx.x / TPH, d = (threadIdx.x % TPH) * 4;
+                    const half4_t hv = merge_partitions(np,
+                        [&](int pi) { return __builtin_bit_cast(float2_t, __builtin_amdgcn_raw_buffer_load_b64(rs_ml, (i * p.num_parts + pi) * 8, 0, 16)); },
+                        [&](int pi) { return __builtin_bit_cast(float4_t, __builtin_amdgcn_raw_buffer_load_b128(rs_o, ((i * p.num_parts + pi) * D + d) * 4, 0, 16)); });
+                    *reinterpret_cast<half4_t *>(p.out + ((int64_t)t * p.H + g * G + i) * D + d) = hv;
+                }
+                if (threadIdx.x == 0) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch
+            }
+        }
+        __syncthreads();                                                      // sm_acc / sm_ml / ticket_s are the next segment's too
+    }
+}
+
 // ---- launch configuration ------------------------------------------------------------------------
+static bool share_enabled() { static const bool v = !(getenv("NVR_ATTN_SHARE") && getenv("NVR_ATTN_SHARE")[0] == '0'); return v; }
+static int share_workgroups() {                                           // one workgroup per CU of the current device
+    static const int v = [] { int dev = 0, n = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256; return n; }();
+    return v;
+}
 static inline int parts_for(int64_t nq, int64_t KVH, int64_t max_ctx, int waves, int *part_size) {
     // aim at ~4096 waves over the 256 CUs; partitions are multiples of 64 tokens
     const int64_t want_wgs = 4096 / waves;
@@ -565,6 +780,22 @@ static int launch_attn(const AttnArgs &a, bool paged, hipStream_t s) {
             int64_t ps = ((mc + want - 1) / want + 63) / 64 * 64;
             part_size = (int)ps; np = (int)((mc + ps - 1) / ps);
         } else np = parts_for(a.nq, a.KVH, mc, waves, &part_size);
+    }
+    // Work-balanced form (attn_share_kernel): a pair count whose last round of one-workgroup-per-pair launches would be mostly empty — 257..2047 pairs with
+    // >= 15 % of the rounds' slots unused (33..37 and 65..74 sequences at 8 kv heads, ...), contexts long enough for the stream to matter.  NVR_ATTN_SHARE=0: off.
+    if constexpr (G * D <= 512)
+    if (!shared && paged && a.workspace && a.tickets && !a.seq_of_q && waves == 8 && p.bs_shift >= 0 && a.block_size >= 8 && a.nq <= 1024 && share_enabled()) {
+        const int64_t nw = share_workgroups(), rounds = (pairs + nw - 1) / nw, units = (mc + 63) / 64;
+        const int64_t cap = a.workspace_bytes ? (int64_t)(a.workspace_bytes / ((size_t)a.nq * a.H * (D + 2) * sizeof(float))) : units;
+        if (pairs > nw && pairs < 2048 && rounds * nw * 100 >= pairs * 115 && mc >= 256 && cap >= units) {
+            p.part_size = 64; p.num_parts = (int32_t)cap;
+            p.part_o = (float *)a.workspace; p.part_ml = p.part_o + (int64_t)a.nq * a.H * cap * D;
+            p.part0 = 0; p.kv0 = 0; p.kv0_rows = nullptr; p.tickets = a.tickets;
+            attn_share_kernel<D, G, DU / 2, 8><<<dim3((unsigned)nw), dim3(512), 0, s>>>(p, (int)a.nq, (int)nw);
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) return nvr::fail(NVR_ERR_HIP, "attention (work-balanced) launch failed: %s", hipGetErrorString(e));
+            return 0;
+        }
     }
     const bool direct = np <= 1;
     if (!direct && a.workspace_bytes && (size_t)a.nq * a.H * np * (D + 2) * sizeof(float) > a.workspace_bytes)

@@ -4,6 +4,7 @@ device pointers, against the CPU oracle on the same seeded inputs.  fp16 storage
 outputs (token ids, cache contents of pure copies) are bit-exact; fp16 outputs may differ by
 fp16 rounding of f32 results that differ in summation order (<= 1-2 fp16 ulp)."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -195,6 +196,11 @@ def _paged_case(rng, B, H, KVH, D, bs, ctx_lens, NB):
     (300, 16, 8, 128, 64, [1 + (41 * i) % 250 for i in range(300)]),    # 2400 pairs: two waves
     (260, 16, 8, 128, 64, [1 + (43 * i) % 500 for i in range(260)]),    # context bound 512: four waves
     (520, 8, 4, 64, 32, [1 + (29 * i) % 200 for i in range(520)]),      # D=64, 2080 pairs
+    (33, 16, 8, 128, 256, [1 + (389 * i) % 2000 for i in range(33)]),   # r06: 264 pairs on 256 CUs -> the work-balanced form (fused entry), ragged contexts
+    (37, 16, 8, 128, 64, [900 + (53 * i) % 300 for i in range(37)]),    # 296 pairs, blocks of 64
+    (70, 16, 8, 128, 256, [600 + i for i in range(70)]),                # 560 pairs: three rounds' worth on two and a bit
+    (48, 32, 8, 128, 256, [1500 - 7 * i for i in range(48)]),           # group of 4 (Qwen3-8B heads), 384 pairs
+    (40, 8, 8, 64, 32, [1 + (61 * i) % 700 for i in range(40)]),        # D=64, MHA, 320 pairs, some one-key contexts
 ])
 def test_paged_attn_decode(B, H, KVH, D, bs, ctxs):
     rng = np.random.default_rng(6)
@@ -222,12 +228,24 @@ def _fused_merge_equals_two_launches(qb, kcb, vcb, meta, B, H, KVH, D, bs, scale
     """nvr_paged_attn_decode_fused (the merge of a pair's split-KV partitions on its last partition workgroup to finish) == the partition
     launch + merge launch, bit for bit; called twice on one ticket array (the kernel re-arms the counters) with the workspace poisoned in between."""
     tickets = dev(np.zeros(B * KVH, np.uint32))
+    # r06: pair counts that leave the last round of one-workgroup-per-pair launches mostly empty take the WORK-BALANCED form through the fused entry
+    # (attn_share_kernel: 256 workgroups, each an equal share of all pairs' 64-key units): a pair cut by a share boundary is merged from partials whose key ranges
+    # are not the two-launch form's — equal within the rounding of one f32 merge, not bit for bit; its own launches must agree bit for bit (slot-ordered merge)
+    pairs, mc = B * KVH, int(meta.max_context_len)
+    balanced = (256 < pairs < 2048 and -(-pairs // 256) * 256 * 100 >= pairs * 115 and mc >= 256 and B <= 1024 and (H // KVH) * D <= 512
+                and bs >= 8 and bs & (bs - 1) == 0 and os.environ.get("NVR_ATTN_SHARE", "1") != "0")
+    first = None
     for rep in range(2):
         d_o = nvr.DeviceBuffer(B * H * D * 2); _KEEP.append(d_o)
         nvr.check(nvr.lib().nvr_paged_attn_decode_fused(dev(qb).ptr, H * D, dev(kcb).ptr, dev(vcb).ptr, C.byref(meta), H, KVH, D, bs,
                                                         scale, d_o.ptr, ws.ptr, tickets.ptr, None))
         f = d_o.to_numpy((B, H, D), F16)
-        assert np.array_equal(f.view(np.uint16), np.asarray(two_launch_out).view(np.uint16)), f"fused merge differs from the merge launch (call {rep})"
+        if balanced:
+            assert_close_f16(f, np.asarray(two_launch_out), ulps=2, atol=1e-3, what="work-balanced form vs the two-launch form")
+            first = f.copy() if first is None else first
+            assert np.array_equal(f.view(np.uint16), first.view(np.uint16)), "two launches of the work-balanced form differ"
+        else:
+            assert np.array_equal(f.view(np.uint16), np.asarray(two_launch_out).view(np.uint16)), f"fused merge differs from the merge launch (call {rep})"
         assert not tickets.to_numpy((B * KVH,), np.uint32).any(), "arrival counters not re-armed"
         nvr.check(nvr.lib().nvr_fill_const(ws.ptr, ws.nbytes // 2, C.c_float(float("nan")), None))
 

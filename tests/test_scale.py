@@ -122,6 +122,19 @@ def test_prefill_steps_of_257_to_1024_tokens_on_an_engine_of_few_sequences(lens)
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("nseq,kvh", [(36, 8), (70, 4)])
+def test_decode_batches_between_the_multiples_of_32_take_the_work_balanced_attention(nseq, kvh):
+    """36 sequences x 8 kv heads = 288 (sequence, kv head) pairs, 70 x 4 = 280: more than the 256 CUs, far from the next multiple — the decode
+    attention of such steps runs as 256 equal shares of all pairs' keys (attn_share_kernel, r06) instead of one workgroup per pair; contexts of
+    257..400 keys, ragged.  Logits of every step against the oracle (the prefill fills the caches the shares walk)."""
+    mcfg = mo.small(seed=29, num_attention_heads=16, num_key_value_heads=kvh, head_dim=64, hidden_size=256, intermediate_size=512)
+    ecfg = dict(max_num_seqs=nseq, max_num_batched_tokens=4096, max_model_len=512, kvcache_block_size=256, num_kvcache_blocks=nseq * 2 + 4)
+    prompts = [nvr.synthetic_tokens(257 + (37 * i) % 140, 1, i, mcfg.vocab_size).tolist() for i in range(nseq)]
+    ties, worst = _parity(mcfg, ecfg, prompts, 4)
+    assert ties <= 2
+
+
+@pytest.mark.gpu
 def test_qwen3_0_6b_full_size_spot_check():
     """The benchmark model itself (28 layers, V=151936, tied head) against the oracle on two short prompts."""
     mcfg = mo.qwen3_0_6b()
