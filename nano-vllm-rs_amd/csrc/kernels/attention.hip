@@ -456,6 +456,7 @@ __global__ __launch_bounds__(WAVES * 64) void attn_share_kernel(AttnParams p, in
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int dc = lane % LPR, tg = lane / LPR;
     __shared__ int pre[1025];                               // pre[t] = units of the queries in front of t (a query's KVH pairs have the same count)
+    __shared__ int cx[1024];                                // ctx_lens[t]
     __shared__ float sm_acc[WAVES][G][D];
     __shared__ float sm_ml[WAVES][G][2];
     __shared__ unsigned int ticket_s;
@@ -463,10 +464,11 @@ __global__ __launch_bounds__(WAVES * 64) void attn_share_kernel(AttnParams p, in
         int base = 0;
         for (int k = 0; k < nq; k += 64) {
             const int t = k + lane;
-            int un = t < nq ? (p.ctx_lens[t] + CH - 1) / CH : 0;
+            const int c = t < nq ? p.ctx_lens[t] : 0;
+            int un = (c + CH - 1) / CH;
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(un, o, 64); if (lane >= o) un += v; }
-            if (t < nq) pre[t + 1] = base + un;
+            if (t < nq) { pre[t + 1] = base + un; cx[t] = c; }
             base += __shfl(un, 63, 64);
         }
         if (lane == 0) pre[0] = 0;
@@ -474,42 +476,76 @@ __global__ __launch_bounds__(WAVES * 64) void attn_share_kernel(AttnParams p, in
     __syncthreads();
     const long long utot = (long long)p.KVH * pre[nq];
     const long long ub = (long long)blockIdx.x * utot / nw, ue = (long long)(blockIdx.x + 1) * utot / nw;
+    if (ub >= ue) return;                                   // (fewer units than workgroups: an empty share)
     const int row_elems = p.KVH * D;
-    for (long long u = ub; u < ue;) {
-        // the query of unit u: the last t with KVH * pre[t] <= u (queries without keys own no unit and are never found)
-        int lo = 0, hi = nq;
+
+    // ---- state of the segment being streamed (set by `open`, which also REQUESTS its first K/V rows: a segment is opened under the tail of the one in front) ----
+    int t = 0, g = 0, np = 1, slot = 0, p0 = 0, pend = 0, R = 0, ng = 0, gt0 = 0, bt_chunk = -1, bt_reg = 0;
+    const int32_t *bt = p.block_tables;
+    half2_t qv[G][4];
+    half8_t k0[U], v0[U], kt[U], vt[U];                     // round 0 of the segment; its remainder groups
+    auto block_base = [&](int tb) -> int64_t {              // element offset of (scalar token tb, kv head g, d = 0)
+        const int bi = tb >> p.bs_shift, bo = tb & (p.block_size - 1);
+        if ((bi >> 6) != bt_chunk) { bt_chunk = bi >> 6; const int idx = (bt_chunk << 6) + lane; bt_reg = idx < p.max_blocks ? bt[idx] : 0; }
+        const int blk = __builtin_amdgcn_readlane(bt_reg, bi & 63);
+        return (((int64_t)blk * p.block_size + bo) * p.KVH + g) * D;
+    };
+    auto issue_remainder = [&]() {
+#pragma unroll
+        for (int x = 0; x < U; ++x) {
+            const int gt = gt0 + x * WAVES;
+            if (gt < ng) {
+                const int tb = p0 + gt * RPI;
+                const int64_t base = block_base(tb);
+                const unsigned off = (unsigned)(min(tg, pend - 1 - tb) * row_elems + dc * 8);
+                kt[x] = load_row16<true>(p.k + base + off); vt[x] = load_row16<true>(p.v + base + off);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { kt[x][j] = (half_t)0.f; vt[x][j] = (half_t)0.f; }
+            }
+        }
+    };
+    auto load_round = [&](int r, half8_t (&kk)[U], half8_t (&vv)[U]) {
+        const int64_t base = block_base(p0 + (r * WAVES + wave) * TPI);
+#pragma unroll
+        for (int x = 0; x < U; ++x) {
+            const unsigned off = (unsigned)((x * RPI + tg) * row_elems + dc * 8);
+            kk[x] = load_row16<true>(p.k + base + off); vv[x] = load_row16<true>(p.v + base + off);
+        }
+    };
+    // opens the segment that starts at unit u (u < ue); returns its length in units
+    auto open = [&](long long u) -> int {
+        int lo = 0, hi = nq;                                // the query of unit u: the last t with KVH * pre[t] <= u (queries without keys own no unit)
         while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((long long)p.KVH * pre[mid] <= u) lo = mid; else hi = mid; }
-        const int t = lo, ut = pre[t + 1] - pre[t];
-        const int rem = (int)(u - (long long)p.KVH * pre[t]);
-        const int g = rem / ut, lu = rem - g * ut;
-        const int seg = (int)min((long long)(ut - lu), ue - u);
-        u += seg;
+        t = lo;
+        const int ut = pre[t + 1] - pre[t], rem = (int)(u - (long long)p.KVH * pre[t]);
+        g = rem / ut;
+        const int lu = rem - g * ut, seg = (int)min((long long)(ut - lu), ue - u);
         // shares that touch this pair: unit x belongs to share floor(((x + 1) * nw - 1) / utot)
         const long long S = (long long)p.KVH * pre[t] + (long long)g * ut, E = S + ut - 1;
         const int wf = (int)(((S + 1) * nw - 1) / utot), wl = (int)(((E + 1) * nw - 1) / utot);
-        const int np = wl - wf + 1, slot = (int)blockIdx.x - wf;
-
-        const int32_t *bt = p.block_tables + (int64_t)t * p.max_blocks;
-        const int ctx = p.ctx_lens[t];
-        const int p0 = lu * CH, pend = min(ctx, (lu + seg) * CH);
-        int bt_chunk = (p0 >> p.bs_shift) >> 6, bt_reg;
+        np = wl - wf + 1; slot = (int)blockIdx.x - wf;
+        p0 = lu * CH; pend = min(cx[t], (lu + seg) * CH);
+        ng = (pend - p0 + RPI - 1) / RPI; R = (pend - p0) / CH; gt0 = R * (WAVES * U) + wave;
+        bt = p.block_tables + (int64_t)t * p.max_blocks;
+        bt_chunk = (p0 >> p.bs_shift) >> 6;
         { const int idx = (bt_chunk << 6) + lane; bt_reg = idx < p.max_blocks ? bt[idx] : 0; }
-        half2_t qv[G][4];
-        {
-            const half_t *qrow = p.q + (int64_t)t * p.ldq + (int64_t)g * G * D + dc * 8;
+        const half_t *qrow = p.q + (int64_t)t * p.ldq + (int64_t)g * G * D + dc * 8;
 #pragma unroll
-            for (int i = 0; i < G; ++i) {
-                const half8_t h = *reinterpret_cast<const half8_t *>(qrow + i * D);
+        for (int i = 0; i < G; ++i) {
+            const half8_t h = *reinterpret_cast<const half8_t *>(qrow + i * D);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) qv[i][j] = (half2_t){h[2 * j], h[2 * j + 1]};
-            }
+            for (int j = 0; j < 4; ++j) qv[i][j] = (half2_t){h[2 * j], h[2 * j + 1]};
         }
-        auto block_base = [&](int tb) -> int64_t {              // element offset of (scalar token tb, kv head g, d = 0)
-            const int bi = tb >> p.bs_shift, bo = tb & (p.block_size - 1);
-            if ((bi >> 6) != bt_chunk) { bt_chunk = bi >> 6; const int idx = (bt_chunk << 6) + lane; bt_reg = idx < p.max_blocks ? bt[idx] : 0; }
-            const int blk = __builtin_amdgcn_readlane(bt_reg, bi & 63);
-            return (((int64_t)blk * p.block_size + bo) * p.KVH + g) * D;
-        };
+        if (R >= 1) load_round(0, k0, v0);
+        if (R <= 1) issue_remainder();                      // (requested before the arithmetic of the last full round, as in attn_rows_kernel)
+        asm volatile("" ::: "memory");                      // the requests stay HERE: hipcc would sink them to their first use, behind the tail of the segment in front
+        return seg;
+    };
+
+    long long u = ub;
+    u += open(u);
+    for (;;) {
         float m[G], l[G], acc[G][8];
 #pragma unroll
         for (int i = 0; i < G; ++i) {
@@ -554,39 +590,20 @@ __global__ __launch_bounds__(WAVES * 64) void attn_share_kernel(AttnParams p, in
                 l[i] = __fmaf_rn(l[i], alpha, ps);
             }
         };
-        const int ng = (pend - p0 + RPI - 1) / RPI;
-        const int R = (pend - p0) / CH;
-        const int gt0 = R * (WAVES * U) + wave;
-        auto issue_remainder = [&](half8_t (&kt)[U], half8_t (&vt)[U]) {
-#pragma unroll
-            for (int x = 0; x < U; ++x) {
-                const int gt = gt0 + x * WAVES;
-                if (gt < ng) {
-                    const int tb = p0 + gt * RPI;
-                    const int64_t base = block_base(tb);
-                    const unsigned off = (unsigned)(min(tg, pend - 1 - tb) * row_elems + dc * 8);
-                    kt[x] = load_row16<true>(p.k + base + off); vt[x] = load_row16<true>(p.v + base + off);
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) { kt[x][j] = (half_t)0.f; vt[x][j] = (half_t)0.f; }
-                }
-            }
-        };
-        half8_t kt[U], vt[U];
-        if (R == 0) issue_remainder(kt, vt);
-        for (int r = 0; r < R; ++r) {
-            const int tb = p0 + (r * WAVES + wave) * TPI;
+        if (R >= 1) process(std::false_type{}, k0, v0, 0);
+        for (int r = 1; r < R; ++r) {
             half8_t kk[U], vv[U];
-            const int64_t base = block_base(tb);
-#pragma unroll
-            for (int x = 0; x < U; ++x) {
-                const unsigned off = (unsigned)((x * RPI + tg) * row_elems + dc * 8);
-                kk[x] = load_row16<true>(p.k + base + off); vv[x] = load_row16<true>(p.v + base + off);
-            }
-            if (r == R - 1) issue_remainder(kt, vt);
+            load_round(r, kk, vv);
+            if (r == R - 1) issue_remainder();
             process(std::false_type{}, kk, vv, 0);
         }
         if (gt0 < ng) process(std::true_type{}, kt, vt, p0 + gt0 * RPI);
+
+        // the segment is in the accumulators: what its tail needs of the state, then the NEXT segment is opened (its query, block table and first K/V rows
+        // are on their way while this one is merged and handed over)
+        const int st = t, sg = g, snp = np, sslot = slot;
+        const bool more = u < ue;
+        if (more) u += open(u);
 
         // row-group slots of the wave -> the wave's sums; waves -> the segment's partial (attn_rows_kernel's arithmetic)
 #pragma unroll
@@ -603,7 +620,7 @@ __global__ __launch_bounds__(WAVES * 64) void attn_share_kernel(AttnParams p, in
             }
         }
         __syncthreads();
-        const int64_t pair0 = ((int64_t)t * p.H + (int64_t)g * G) * p.num_parts;
+        const int64_t pair0 = ((int64_t)st * p.H + (int64_t)sg * G) * p.num_parts;
         const auto rs_o = __builtin_amdgcn_make_buffer_rsrc(p.part_o + pair0 * D, 0, (int)(G * p.num_parts * D * 4), 0x00020000);
         const auto rs_ml = __builtin_amdgcn_make_buffer_rsrc(p.part_ml + pair0 * 2, 0, (int)(G * p.num_parts * 2 * 4), 0x00020000);
         if (threadIdx.x < G * D) {
@@ -619,34 +636,35 @@ __global__ __launch_bounds__(WAVES * 64) void attn_share_kernel(AttnParams p, in
                 o = mul_then_add(wgt, sm_acc[w2][i][d], o);
                 L = mul_then_add(wgt, sm_ml[w2][i][1], L);
             }
-            if (np == 1) {
-                p.out[((int64_t)t * p.H + g * G + i) * D + d] = (half_t)(L > 0.f ? o / L : 0.f);
+            if (snp == 1) {
+                p.out[((int64_t)st * p.H + sg * G + i) * D + d] = (half_t)(L > 0.f ? o / L : 0.f);
             } else {
-                const int sl = i * p.num_parts + slot;
+                const int sl = i * p.num_parts + sslot;
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o), rs_o, (sl * D + d) * 4, 0, 16);
                 if (d == 0) { __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(M), rs_ml, sl * 8, 0, 16);
                               __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(L), rs_ml, sl * 8 + 4, 0, 16); }
             }
         }
-        if (np > 1) {                                                         // (workgroup-uniform)
+        if (snp > 1) {                                                        // (workgroup-uniform)
             constexpr int TPH = D / 4;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // every storing wave drains its stores ...
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // every storing wave drains its stores (and the next segment's first rows land) ...
             __syncthreads();
-            unsigned int *cnt = p.tickets + (int64_t)t * p.KVH + g;
+            unsigned int *cnt = p.tickets + (int64_t)st * p.KVH + sg;
             if (threadIdx.x == 0) ticket_s = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... one ticket
             __syncthreads();
-            if (ticket_s == (unsigned)(np - 1)) {                             // the last of the pair's shares to finish merges it
+            if (ticket_s == (unsigned)(snp - 1)) {                            // the last of the pair's shares to finish merges it
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");        // keeps the sc1 loads below the ticket
                 if (threadIdx.x < G * TPH) {
                     const int i = threadIdx.x / TPH, d = (threadIdx.x % TPH) * 4;
-                    const half4_t hv = merge_partitions(np,
+                    const half4_t hv = merge_partitions(snp,
                         [&](int pi) { return __builtin_bit_cast(float2_t, __builtin_amdgcn_raw_buffer_load_b64(rs_ml, (i * p.num_parts + pi) * 8, 0, 16)); },
                         [&](int pi) { return __builtin_bit_cast(float4_t, __builtin_amdgcn_raw_buffer_load_b128(rs_o, ((i * p.num_parts + pi) * D + d) * 4, 0, 16)); });
-                    *reinterpret_cast<half4_t *>(p.out + ((int64_t)t * p.H + g * G + i) * D + d) = hv;
+                    *reinterpret_cast<half4_t *>(p.out + ((int64_t)st * p.H + sg * G + i) * D + d) = hv;
                 }
                 if (threadIdx.x == 0) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch
             }
         }
+        if (!more) break;
         __syncthreads();                                                      // sm_acc / sm_ml / ticket_s are the next segment's too
     }
 }
