@@ -187,6 +187,7 @@ _SIGS = {
     "nvr_engine_host_times": (None, [_P, _P]),
     "nvr_runner_last_prefill_kv_source": (C.c_int, [_P]),
     "nvr_runner_set_tp_prefill_overlap": (C.c_int, [_P, C.c_int32]), "nvr_runner_last_overlap_chunks": (C.c_int64, [_P]),
+    "nvr_runner_last_decode_ragged": (C.c_int32, [_P]),
     "nvr_runner_last_shared_prefix_len": (C.c_int64, [_P]), "nvr_runner_last_shared_prefix_rows": (C.c_int64, [_P]),
     "nvr_engine_last_step": (None, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(C.c_size_t)]),
     "nvr_engine_take_finished": (C.c_size_t, [_P, C.POINTER(_P), C.c_size_t]),
@@ -715,6 +716,10 @@ class ModelRunner:
 
     def last_overlap_chunks(self) -> int:
         return int(lib().nvr_runner_last_overlap_chunks(self.h))
+
+    def last_decode_ragged(self) -> bool:
+        """The last decode step took the work-balanced attention launch for its ragged contexts (nvr_runner_last_decode_ragged)."""
+        return bool(lib().nvr_runner_last_decode_ragged(self.h))
 
     def last_shared_prefix_len(self) -> int:
         """Tokens of the last decode step that went through the shared-prefix attention pass (0: plain paged attention)."""

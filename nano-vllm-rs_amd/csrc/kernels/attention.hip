@@ -670,7 +670,8 @@ __global__ __launch_bounds__(WAVES * 64) void attn_share_kernel(AttnParams p, in
 }
 
 // ---- launch configuration ------------------------------------------------------------------------
-static bool share_enabled() { static const bool v = !(getenv("NVR_ATTN_SHARE") && getenv("NVR_ATTN_SHARE")[0] == '0'); return v; }
+static int share_mode() { static const int v = getenv("NVR_ATTN_SHARE") ? atoi(getenv("NVR_ATTN_SHARE")) : 1; return v; }   // 0: never, 1: by the rule, 2: whenever it can run (probes)
+static bool share_enabled() { return share_mode() != 0; }
 static int share_workgroups() {                                           // one workgroup per CU of the current device
     static const int v = [] { int dev = 0, n = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256; return n; }();
     return v;
@@ -800,12 +801,15 @@ static int launch_attn(const AttnArgs &a, bool paged, hipStream_t s) {
         } else np = parts_for(a.nq, a.KVH, mc, waves, &part_size);
     }
     // Work-balanced form (attn_share_kernel): a pair count whose last round of one-workgroup-per-pair launches would be mostly empty — 257..2047 pairs with
-    // >= 15 % of the rounds' slots unused (33..37 and 65..74 sequences at 8 kv heads, ...), contexts long enough for the stream to matter.  NVR_ATTN_SHARE=0: off.
+    // >= 15 % of the rounds' slots unused (33..37 and 65..74 sequences at 8 kv heads, ...), contexts long enough for the stream to matter — or a RAGGED batch of up to
+    // 1.5 pairs per CU (balance_hint: the caller knows the sum of the contexts; per-pair launches size every pair's partitions by the LONGEST context and leave the
+    // short sequences' workgroups idle: 32 sequences of 256..8192 keys 4.09 -> 2.63 ms per Qwen3-0.6B step; with >= 2 pairs per CU the dispatcher balances the per-pair
+    // launch by itself: 64 ragged sequences 3.26 against 3.62).  NVR_ATTN_SHARE=0: off.
     if constexpr (G * D <= 512)
     if (!shared && paged && a.workspace && a.tickets && !a.seq_of_q && waves == 8 && p.bs_shift >= 0 && a.block_size >= 8 && a.nq <= 1024 && share_enabled()) {
         const int64_t nw = share_workgroups(), rounds = (pairs + nw - 1) / nw, units = (mc + 63) / 64;
         const int64_t cap = a.workspace_bytes ? (int64_t)(a.workspace_bytes / ((size_t)a.nq * a.H * (D + 2) * sizeof(float))) : units;
-        if (pairs > nw && pairs < 2048 && rounds * nw * 100 >= pairs * 115 && mc >= 256 && cap >= units) {
+        if (((pairs > nw && pairs < 2048 && rounds * nw * 100 >= pairs * 115 && mc >= 256) || (a.balance_hint && pairs * 2 <= nw * 3) || share_mode() == 2) && cap >= units) {
             p.part_size = 64; p.num_parts = (int32_t)cap;
             p.part_o = (float *)a.workspace; p.part_ml = p.part_o + (int64_t)a.nq * a.H * cap * D;
             p.part0 = 0; p.kv0 = 0; p.kv0_rows = nullptr; p.tickets = a.tickets;

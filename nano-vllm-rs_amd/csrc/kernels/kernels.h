@@ -43,6 +43,9 @@ struct AttnArgs {
     // A caller that passes them also allows the other launch-free merge: behind a shared-prefix pass that covers the WHOLE batch, with one
     // own partition per pair, that partition's workgroup merges the pair (it is the last arriver by stream order; no counter is touched)
     unsigned int *tickets;
+    // paged decode with `tickets`: the caller knows the contexts are RAGGED (their sum is well below nq * max_ctx) — take the work-balanced form
+    // (attn_share_kernel: one workgroup per CU, equal shares of all pairs' keys) wherever it can run, not only where the pair count asks for it
+    int32_t balance_hint;
 };
 
 // MFMA flash prefill attention.  A tile = up to 64/G consecutive query positions of one sequence.

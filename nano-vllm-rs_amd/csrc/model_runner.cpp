@@ -722,8 +722,17 @@ int64_t nvr_model_runner::shared_prefix_plan(nvr_seq *const *seqs, size_t nseq, 
 }
 
 // a captured decode step is a function of (batch size, context bucket, shared-prefix length, whole batch or a group of it, logits wanted)
-static inline uint64_t graph_key(bool want_logits, size_t nseq, int64_t bucket, int64_t shared_len, bool group) {
-    return ((uint64_t)want_logits << 63) | ((uint64_t)group << 62) | ((uint64_t)nseq << 44) | ((uint64_t)(shared_len / 64) << 24) | (uint64_t)(bucket / 256);
+static inline uint64_t graph_key(bool want_logits, size_t nseq, int64_t bucket, int64_t shared_len, bool group, bool ragged) {
+    return ((uint64_t)want_logits << 63) | ((uint64_t)group << 62) | ((uint64_t)ragged << 61) | ((uint64_t)nseq << 44) | ((uint64_t)(shared_len / 64) << 24) | (uint64_t)(bucket / 256);
+}
+// A decode batch whose contexts are ragged: the attention launch sizes every (sequence, kv head) pair's partitions by the LONGEST context of the step (its bucket, under
+// a captured graph), so with up to ~1.5 pairs per CU the short sequences' workgroups idle while the long ones stream — the work-balanced launch (attn_share_kernel) cuts the
+// keys evenly instead.  Ragged = the contexts sum to less than 1 / 1.3 of batch x bound, and there is a 64-key unit of work for every CU.  (float32 runners and
+// shared-prefix steps keep their own launches.)
+bool nvr_model_runner::ragged_batch(size_t nseq, int64_t sum_ctx, int64_t max_ctx) const {
+    if (f32 || nseq == 0 || decode_shared_len > 0) return false;
+    const int64_t pairs = (int64_t)nseq * KVH;
+    return pairs * 2 <= (int64_t)num_cus * 3 && max_ctx * (int64_t)nseq * 100 >= sum_ctx * 130 && sum_ctx * KVH / 64 >= num_cus;
 }
 
 // Prefill on tensor-parallel ranks as TWO micro-batches of whole sequences (row g, nvr_runner_set_tp_prefill_overlap(r, 2)): rows [0, mb_rows)
@@ -857,6 +866,7 @@ int nvr_model_runner::forward(int64_t T, int64_t B, bool is_prefill, int64_t max
             a.k = k_cache(l); a.v = v_cache(l); a.block_tables = bt; a.max_blocks = (int32_t)max_blocks_per_seq;
             a.block_size = (int32_t)block_size; a.workspace = attn_ws; a.workspace_bytes = attn_ws_bytes; a.tickets = attn_tickets;
             a.shared_len = (int32_t)decode_shared_len;
+            a.balance_hint = decode_ragged ? 1 : 0;
             if (decode_shared_len > 0 && decode_shared_rows < T) {     // a group inside the batch: per-row kv0, member rows, member count
                 a.shared_kv0 = (const int32_t *)(in_dev + off_dec + dof_skv0); a.shared_rows = (const int32_t *)(in_dev + off_dec + dof_srows);
                 a.shared_count = (const int32_t *)(in_dev + off_dec + dof_scount);
@@ -904,7 +914,7 @@ int nvr_model_runner::execute(nvr_seq *const *seqs, size_t nseq, bool is_prefill
     int32_t *slots = (int32_t *)(hd + dof_slots), *ctx = (int32_t *)(hd + dof_ctx);
     int32_t *cu = nullptr, *kvb = nullptr, *bt = (int32_t *)(hd + dof_bt);
     size_t prefill_bytes = 0;                                            // bytes of the prefill region this step uploads (one copy)
-    int64_t T = 0, max_ctx = 0;
+    int64_t T = 0, max_ctx = 0, sum_ctx = 0;
     const int64_t bs = block_size;
     NVR_HIP_CHECK(hipStreamSynchronize(stream));   // staging arena is reused: previous uploads must have landed
     if (is_prefill) {
@@ -1064,11 +1074,12 @@ int nvr_model_runner::execute(nvr_seq *const *seqs, size_t nseq, bool is_prefill
             const size_t nb = s.block_table.size();
             std::memcpy(row, s.block_table.data(), nb * 4);
             for (int64_t j = (int64_t)nb; j < max_blocks_per_seq; ++j) row[j] = -1;
-            max_ctx = std::max(max_ctx, len);
+            max_ctx = std::max(max_ctx, len); sum_ctx += len;
         }
         T = (int64_t)nseq;
         decode_shared_len = shared_prefix_plan(seqs, nseq, (int32_t *)(hd + dof_skv0), (int32_t *)(hd + dof_srows), (int32_t *)(hd + dof_scount),
                                                &decode_shared_rows);
+        decode_ragged = ragged_batch(nseq, sum_ctx, (cfg.enforce_eager || graphs_disabled) ? max_ctx : (max_ctx + 255) / 256 * 256);
     }
     // one H2D per array actually used this step (K19)
     auto up = [&](size_t off, size_t bytes) { return hipMemcpyAsync(in_dev + off, in_host + off, bytes, hipMemcpyHostToDevice, stream); };
@@ -1103,7 +1114,7 @@ int nvr_model_runner::execute(nvr_seq *const *seqs, size_t nseq, bool is_prefill
 
     // decode: replay a hipGraph captured per (batch size, context bucket) — execute_with_cuda_graph :303-326
     const int64_t bucket = (max_ctx + 255) / 256 * 256;
-    const uint64_t key = graph_key(want_logits, nseq, bucket, decode_shared_len, decode_shared_len > 0 && decode_shared_rows < (int64_t)nseq);
+    const uint64_t key = graph_key(want_logits, nseq, bucket, decode_shared_len, decode_shared_len > 0 && decode_shared_rows < (int64_t)nseq, decode_ragged);
     auto it = graphs.find(key);
     if (it == graphs.end()) {
         if (graphs.size() >= (size_t)env.max_graphs) {   // a long-lived engine sees many (batch size, bucket) pairs: bound the cache
@@ -1145,7 +1156,7 @@ int nvr_model_runner::execute_decode_ahead(nvr_seq *const *seqs, size_t nseq, in
     int64_t *pos = (int64_t *)(hd + dof_pos);
     int32_t *slots = (int32_t *)(hd + dof_slots), *ctx = (int32_t *)(hd + dof_ctx), *bt = (int32_t *)(hd + dof_bt);
     const int64_t bs = block_size;
-    int64_t max_ctx = 0;
+    int64_t max_ctx = 0, sum_ctx = 0;
     for (size_t b = 0; b < nseq; ++b) {
         const nvr_seq &s = *seqs[b];
         const int64_t len = (int64_t)s.len();                             // includes the token the host has not seen yet
@@ -1158,10 +1169,11 @@ int nvr_model_runner::execute_decode_ahead(nvr_seq *const *seqs, size_t nseq, in
         const size_t nb = s.block_table.size();
         std::memcpy(row, s.block_table.data(), nb * 4);
         for (int64_t j = (int64_t)nb; j < max_blocks_per_seq; ++j) row[j] = -1;
-        max_ctx = std::max(max_ctx, len);
+        max_ctx = std::max(max_ctx, len); sum_ctx += len;
     }
     decode_shared_len = shared_prefix_plan(seqs, nseq, (int32_t *)(hd + dof_skv0), (int32_t *)(hd + dof_srows), (int32_t *)(hd + dof_scount),
                                            &decode_shared_rows);
+    decode_ragged = ragged_batch(nseq, sum_ctx, (cfg.enforce_eager || graphs_disabled) ? max_ctx : (max_ctx + 255) / 256 * 256);
     NVR_HIP_CHECK(hipMemcpyAsync(in_dev + off_dec + dof_pos, hd + dof_pos, dof_bt + nseq * max_blocks_per_seq * 4 - dof_pos, hipMemcpyHostToDevice, stream));
     last_rows = nseq; last_prefill = false; last_tokens = (int64_t)nseq;
     lm_parts = KD(lm_head_parts((int64_t)nseq, Hd, Vl, Hd));
@@ -1170,7 +1182,7 @@ int nvr_model_runner::execute_decode_ahead(nvr_seq *const *seqs, size_t nseq, in
     const int64_t T = (int64_t)nseq;
     if (cfg.enforce_eager || graphs_disabled) return forward(T, T, false, max_ctx);
     const int64_t bucket = (max_ctx + 255) / 256 * 256;
-    const uint64_t key = graph_key(want_logits, nseq, bucket, decode_shared_len, decode_shared_len > 0 && decode_shared_rows < (int64_t)nseq);
+    const uint64_t key = graph_key(want_logits, nseq, bucket, decode_shared_len, decode_shared_len > 0 && decode_shared_rows < (int64_t)nseq, decode_ragged);
     auto it = graphs.find(key);
     if (it == graphs.end()) {
         // flushing the cache needs an idle stream, and the current step is still running: decline — the engine rolls the

@@ -80,6 +80,8 @@ struct nvr_model_runner {
     std::map<uint64_t, hipGraphExec_t> graphs;
     size_t last_rows = 0; bool last_prefill = false; int64_t last_tokens = 0;
     int64_t decode_shared_len = 0;                       // the last decode step: tokens its sharing group holds in the same leading blocks
+    bool decode_ragged = false;                          // the decode step's contexts are ragged enough for the work-balanced attention launch (ragged_batch)
+    bool ragged_batch(size_t nseq, int64_t sum_ctx, int64_t max_ctx) const;
     int64_t decode_shared_rows = 0;                      // ... and how many of the step's sequences belong to that group (== batch: all)
     nvr::Comm comm;
     bool graphs_disabled = false;   // set when capture with RCCL nodes fails: fall back to eager launches
@@ -105,10 +107,11 @@ struct nvr_model_runner {
     int last_prefill_kv_source() const { return !last_prefill ? -1 : prefill_paged ? 2 : (prefill_kv_cache && n_tiles > 0) ? 1 : 0; }
     // what the diagnostic accessors report about "the last step" (nvr_runner_last_*): of the step the engine has just returned — kept per step in
     // flight like the LM head's input rows (present_step) — or, for a caller that drives execute_model itself, of the step executed last
-    struct StepFacts { int kv_source = -1; int64_t shared_len = 0, shared_rows = 0, overlap_chunks = 0; };
+    struct StepFacts { int kv_source = -1; int64_t shared_len = 0, shared_rows = 0, overlap_chunks = 0; bool ragged = false; };
     StepFacts facts_now() const {
         StepFacts f; f.kv_source = last_prefill_kv_source(); f.overlap_chunks = tp_overlap_chunks;
         f.shared_len = last_prefill ? 0 : decode_shared_len; f.shared_rows = (last_prefill || decode_shared_len == 0) ? 0 : decode_shared_rows;
+        f.ragged = !last_prefill && decode_ragged;
         return f;
     }
     StepFacts facts_kept[2], facts_shown; bool facts_shown_valid = false;

@@ -251,6 +251,7 @@ int64_t nvr_runner_last_shared_prefix_len(const nvr_model_runner_t *r) { return 
 int nvr_runner_last_prefill_kv_source(const nvr_model_runner_t *r) { return r->facts().kv_source; }
 int nvr_runner_set_tp_prefill_overlap(nvr_model_runner_t *r, int32_t mode) { r->tp_overlap = mode == 2 ? 2 : mode ? 1 : 0; return NVR_OK; }
 int64_t nvr_runner_last_overlap_chunks(const nvr_model_runner_t *r) { return r->facts().overlap_chunks; }
+int32_t nvr_runner_last_decode_ragged(const nvr_model_runner_t *r) { return r->facts().ragged ? 1 : 0; }
 int64_t nvr_runner_last_shared_prefix_rows(const nvr_model_runner_t *r) { return r->facts().shared_rows; }
 
 // in-process communicator (comm.h LocalGroup): N runners of one process on one device, one host thread each
