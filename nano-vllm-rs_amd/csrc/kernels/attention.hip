@@ -476,6 +476,10 @@ __global__ __launch_bounds__(WAVES * 64) void attn_share_kernel(AttnParams p, in
     __syncthreads();
     const long long utot = (long long)p.KVH * pre[nq];
     const long long ub = (long long)blockIdx.x * utot / nw, ue = (long long)(blockIdx.x + 1) * utot / nw;
+    // a query without keys owns no unit: its output row is zero, as in attn_rows_kernel (L == 0)
+    for (int t0 = blockIdx.x; t0 < nq; t0 += nw)
+        if (cx[t0] == 0)
+            for (int x = threadIdx.x; x < p.H * D; x += WAVES * 64) p.out[(int64_t)t0 * p.H * D + x] = (half_t)0.f;
     if (ub >= ue) return;                                   // (fewer units than workgroups: an empty share)
     const int row_elems = p.KVH * D;
 

@@ -250,6 +250,34 @@ def _fused_merge_equals_two_launches(qb, kcb, vcb, meta, B, H, KVH, D, bs, scale
         nvr.check(nvr.lib().nvr_fill_const(ws.ptr, ws.nbytes // 2, C.c_float(float("nan")), None))
 
 
+def test_work_balanced_attention_writes_zero_rows_for_queries_without_keys():
+    """A query whose context is empty owns no unit of the work-balanced launch (attn_share_kernel): its output row must still be written — zeros, as the
+    per-pair form writes them — and the other rows must equal the per-pair form's within the rounding of one f32 merge."""
+    rng = np.random.default_rng(91)
+    l = nvr.lib()
+    B, H, KVH, D, bs = 36, 16, 8, 128, 64
+    ctxs = [0 if i % 9 == 4 else 300 + 11 * i for i in range(B)]
+    NB = sum((c + bs - 1) // bs for c in ctxs) + 3
+    kc, kcb, vc, vcb, bt, max_blocks = _paged_case(rng, B, H, KVH, D, bs, ctxs, NB)
+    q, qb = h16(rng.standard_normal((B, H, D)))
+    scale = float(np.float32(1.0) / np.sqrt(np.float32(D)))
+    meta = nvr.AttnMetaC()
+    d_ctx, d_bt = dev(np.asarray(ctxs, np.int32)), dev(bt)
+    meta.context_lens, meta.block_tables, meta.max_blocks, meta.batch, meta.max_context_len = d_ctx.ptr, d_bt.ptr, max_blocks, B, int(max(ctxs))
+    ws = nvr.DeviceBuffer(l.nvr_paged_attn_workspace_bytes(B, H, D, int(max(ctxs))))
+    d_q, d_k, d_v = dev(qb), dev(kcb), dev(vcb)
+    d_ref, d_out = nvr.DeviceBuffer(B * H * D * 2), nvr.DeviceBuffer(B * H * D * 2)
+    nvr.check(l.nvr_fill_const(d_out.ptr, B * H * D, C.c_float(float("nan")), None))               # (poison: a row nobody writes would show)
+    nvr.check(l.nvr_paged_attn_decode(d_q.ptr, H * D, d_k.ptr, d_v.ptr, C.byref(meta), H, KVH, D, bs, scale, d_ref.ptr, ws.ptr, None))
+    tickets = dev(np.zeros(B * KVH, np.uint32))
+    nvr.check(l.nvr_paged_attn_decode_fused(d_q.ptr, H * D, d_k.ptr, d_v.ptr, C.byref(meta), H, KVH, D, bs, scale, d_out.ptr, ws.ptr, tickets.ptr, None))
+    ref, got = d_ref.to_numpy((B, H, D), F16), d_out.to_numpy((B, H, D), F16)
+    empty = [i for i, c in enumerate(ctxs) if c == 0]
+    assert len(empty) == 4 and not got[empty].view(np.uint16).any() and not ref[empty].view(np.uint16).any()
+    assert_close_f16(got, ref, ulps=2, atol=1e-3, what="work-balanced form vs the per-pair form")
+    assert not tickets.to_numpy((B * KVH,), np.uint32).any()
+
+
 def test_fused_split_kv_merge_under_uneven_load():
     """The last-arriver merge of split-KV attention (sc1 partials + one ticket per workgroup, no acquire fence: cdna guide Guideline 16) held to
     the guide's own test rule — uneven load, every word checked, many repetitions: while a second stream keeps the memory system busy with large
