@@ -805,15 +805,19 @@ static int launch_attn(const AttnArgs &a, bool paged, hipStream_t s) {
         } else np = parts_for(a.nq, a.KVH, mc, waves, &part_size);
     }
     // Work-balanced form (attn_share_kernel): a pair count whose last round of one-workgroup-per-pair launches would be mostly empty — 257..2047 pairs with
-    // >= 15 % of the rounds' slots unused (33..37 and 65..74 sequences at 8 kv heads, ...), contexts long enough for the stream to matter — or a RAGGED batch of up to
-    // 1.5 pairs per CU (balance_hint: the caller knows the sum of the contexts; per-pair launches size every pair's partitions by the LONGEST context and leave the
-    // short sequences' workgroups idle: 32 sequences of 256..8192 keys 4.09 -> 2.63 ms per Qwen3-0.6B step; with >= 2 pairs per CU the dispatcher balances the per-pair
-    // launch by itself: 64 ragged sequences 3.26 against 3.62).  NVR_ATTN_SHARE=0: off.
+    // >= 15 % of the rounds' slots unused (33..37 and 65..74 sequences at 8 kv heads, ...), contexts long enough for the stream to matter — or a RAGGED batch
+    // (balance_hint: the caller knows the sum of the contexts; per-pair launches size every pair's partitions by the LONGEST context and leave the short sequences'
+    // workgroups idle, or — with several pairs per CU — end on the long sequences' workgroups: 32 sequences of 256..8192 keys 4.09 -> 2.43 ms per Qwen3-0.6B step,
+    // 64 of 64..4096 keys 3.26 -> 2.78).  NVR_ATTN_SHARE=0: off.
     if constexpr (G * D <= 512)
     if (!shared && paged && a.workspace && a.tickets && !a.seq_of_q && waves == 8 && p.bs_shift >= 0 && a.block_size >= 8 && a.nq <= 1024 && share_enabled()) {
-        const int64_t nw = share_workgroups(), rounds = (pairs + nw - 1) / nw, units = (mc + 63) / 64;
+        const int64_t cus = share_workgroups(), rounds = (pairs + cus - 1) / cus, units = (mc + 63) / 64;
         const int64_t cap = a.workspace_bytes ? (int64_t)(a.workspace_bytes / ((size_t)a.nq * a.H * (D + 2) * sizeof(float))) : units;
-        if (((pairs > nw && pairs < 2048 && rounds * nw * 100 >= pairs * 115 && mc >= 256) || (a.balance_hint && pairs * 2 <= nw * 3) || share_mode() == 2) && cap >= units) {
+        const bool by_count = pairs > cus && rounds * cus * 100 >= pairs * 115 && mc >= 256;
+        // shares: one per CU for the pair-count case (uniform contexts: a second segment per share buys nothing); two per CU for ragged batches (co-resident: twice
+        // the rows in flight, and the dispatcher evens out what the static cut leaves), three from 2 pairs per CU on (measured: profiles/r06_priced_levers.txt 14.)
+        const int64_t nw = (a.balance_hint || share_mode() == 2) ? cus * (pairs <= 2 * cus ? 2 : 3) : cus;
+        if ((by_count || a.balance_hint || share_mode() == 2) && pairs < 2048 && cap >= units) {
             p.part_size = 64; p.num_parts = (int32_t)cap;
             p.part_o = (float *)a.workspace; p.part_ml = p.part_o + (int64_t)a.nq * a.H * cap * D;
             p.part0 = 0; p.kv0 = 0; p.kv0_rows = nullptr; p.tickets = a.tickets;

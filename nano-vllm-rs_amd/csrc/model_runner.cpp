@@ -726,13 +726,13 @@ static inline uint64_t graph_key(bool want_logits, size_t nseq, int64_t bucket, 
     return ((uint64_t)want_logits << 63) | ((uint64_t)group << 62) | ((uint64_t)ragged << 61) | ((uint64_t)nseq << 44) | ((uint64_t)(shared_len / 64) << 24) | (uint64_t)(bucket / 256);
 }
 // A decode batch whose contexts are ragged: the attention launch sizes every (sequence, kv head) pair's partitions by the LONGEST context of the step (its bucket, under
-// a captured graph), so with up to ~1.5 pairs per CU the short sequences' workgroups idle while the long ones stream — the work-balanced launch (attn_share_kernel) cuts the
-// keys evenly instead.  Ragged = the contexts sum to less than 1 / 1.3 of batch x bound, and there is a 64-key unit of work for every CU.  (float32 runners and
-// shared-prefix steps keep their own launches.)
+// a captured graph): the short sequences' workgroups idle (or finish early) while the long ones stream — the work-balanced launch (attn_share_kernel) cuts the keys
+// evenly instead.  Ragged = the contexts sum to less than 1 / 1.3 of batch x bound, and there are two 64-key units of work for every CU.  (float32 runners,
+// shared-prefix steps and batches of > 1024 pairs — 4+ workgroups per CU, which the dispatcher balances: 200 ragged sequences 3.96 per-pair against 4.12 — keep their launches.)
 bool nvr_model_runner::ragged_batch(size_t nseq, int64_t sum_ctx, int64_t max_ctx) const {
     if (f32 || nseq == 0 || decode_shared_len > 0) return false;
     const int64_t pairs = (int64_t)nseq * KVH;
-    return pairs * 2 <= (int64_t)num_cus * 3 && max_ctx * (int64_t)nseq * 100 >= sum_ctx * 130 && sum_ctx * KVH / 64 >= num_cus;
+    return pairs <= 1024 && max_ctx * (int64_t)nseq * 100 >= sum_ctx * 130 && sum_ctx * KVH / 64 >= 2 * (int64_t)num_cus;
 }
 
 // Prefill on tensor-parallel ranks as TWO micro-batches of whole sequences (row g, nvr_runner_set_tp_prefill_overlap(r, 2)): rows [0, mb_rows)
