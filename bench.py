@@ -335,6 +335,46 @@ def side_decode(nvr, preset: str, steps: int = 16, warmup: int = 4, tp_size: int
     return out
 
 
+def ragged_decode(nvr, mc, steps: int = 16, warmup: int = 4, lo: int = 256, hi: int = 8192) -> dict:
+    """A decode batch as serving sees it: the headline's 32 sequences, but with contexts spread geometrically between `lo` and `hi` keys (every BASELINE config is
+    uniform).  The runner passes the attention launch its balance hint (nvr_runner_last_decode_ragged) and the launch cuts ALL pairs' keys into equal shares
+    (attn_share_kernel, r06) instead of sizing every pair's workgroups by the longest context.  Same engine path as the headline; the step's roofline fraction is
+    over its own algorithmic bytes (weights + the K/V actually visible)."""
+    B, V, c = BATCH, mc.c.vocab_size, mc.c
+    lens = [int(lo * (hi / lo) ** (i / (B - 1))) for i in range(B)]
+    total_new = warmup + steps + 4
+    nvr.lib().nvr_seq_reset_id_counter()
+    eng = nvr.LLMEngine(nvr.Config(max_num_seqs=B, max_num_batched_tokens=32768, max_model_len=hi + total_new + 16, kvcache_block_size=BLOCK,
+                                   num_kvcache_blocks=sum((n + total_new + 16) // BLOCK + 2 for n in lens)), mc)
+    for i, n in enumerate(lens):
+        eng.add_request(nvr.synthetic_tokens(n, 1, i, V).tolist(), nvr.SamplingParams(temperature=0.0, max_tokens=total_new, ignore_eos=True))
+    while True:
+        rec = eng.step()
+        if not rec["is_prefill"]:
+            break
+    for _ in range(warmup - 1):
+        eng.step()
+    nvr.synchronize(); t0 = time.perf_counter()
+    for _ in range(steps):
+        eng.step()
+    nvr.synchronize(); ms = (time.perf_counter() - t0) * 1e3 / steps
+    Dh = c.head_dim or c.hidden_size // c.num_attention_heads
+    per_layer = 2 * ((c.num_attention_heads + 2 * c.num_key_value_heads) * Dh * c.hidden_size + c.hidden_size * c.num_attention_heads * Dh
+                     + 3 * c.intermediate_size * c.hidden_size + 2 * c.hidden_size)
+    weights = per_layer * c.num_hidden_layers + 2 * c.hidden_size + 2 * c.vocab_size * c.hidden_size
+    kv_tok = c.num_hidden_layers * 2 * c.num_key_value_heads * Dh * 2
+    ctx_sum = sum(lens) + B * (1 + warmup + (steps - 1) / 2.0)
+    step_bytes = weights + ctx_sum * kv_tok + B * kv_tok
+    return {"workload": f"{MODELS['qwen3-0.6b']['label']} fp16, bs={B}, contexts spread geometrically over {lo}..{hi} keys (sum {sum(lens)}: the K/V bytes of a uniform "
+                        f"batch of {sum(lens) // B}-key contexts), greedy decode, hipGraph steps",
+            "ms_per_step": round(ms, 4), "tokens_per_s": round(B / ms * 1e3, 1), "steps": steps,
+            "step_algorithmic_bytes": int(step_bytes), "step_hbm_frac": round(step_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "attention_launch": "work-balanced (attn_share_kernel: equal shares of all pairs' keys)" if eng.model_runner.last_decode_ragged()
+                                else "one workgroup (set) per (sequence, kv head) pair",
+            "steps_launched_ahead": eng.ahead_launched(),
+            "note": "per-pair launches (NVR_ATTN_SHARE=0) take 4.09 ms for this step: profiles/r06_priced_levers.txt 14."}
+
+
 def stochastic_decode(nvr, mc, steps: int = 16, warmup: int = 4, check: bool = True) -> dict:
     """The non-greedy branch of the path (Sampler::forward top-k / top-p / Gumbel-max, src/layers/sampler.rs:71-218; named in north_star) on the
     headline workload: BASELINE.json configs[1] with temperature 0.8, top_k 50, top_p 0.9 on every sequence.  A stochastic step has no launch-ahead
@@ -1010,6 +1050,12 @@ def main() -> None:
                 batch_sweep.append(row)
             except Exception as ex:                                          # noqa: BLE001
                 batch_sweep.append({"model": preset, "batch": bsz, "error": str(ex)[:200]})
+    ragged = None
+    if args.gpus == 1 and rank == 0 and not args.no_batch_sweep and args.model == "qwen3-0.6b":
+        try:
+            ragged = ragged_decode(nvr, mc)
+        except Exception as ex:                                              # noqa: BLE001
+            ragged = {"error": str(ex)[:300]}
     stochastic = None
     if args.gpus == 1 and rank == 0 and not args.no_batch_sweep and args.model == "qwen3-0.6b":
         try:
@@ -1165,6 +1211,8 @@ def main() -> None:
                 ok = sorted(b for b, f in pp if f >= 0.70)
                 reach[mdl] = {"smallest_batch_with_step_hbm_frac_ge_0.70": ok[0] if ok else None, "measured": {str(b): f for b, f in sorted(pp)}}
             out["batch_for_0.70_of_step_roofline"] = reach
+        if ragged is not None:
+            out["ragged_batch"] = ragged
         if stochastic is not None:
             out["stochastic"] = stochastic
         if bf16_block is not None:
