@@ -319,6 +319,46 @@ def test_fused_split_kv_merge_under_uneven_load():
     assert not tickets.to_numpy((B * KVH,), np.uint32).any()
 
 
+def test_work_balanced_attention_under_uneven_load():
+    """attn_share_kernel's hand-over (sc1 partials of a pair cut by share boundaries + one ticket per share, merged by the last share to finish) under the same
+    rule as the split-KV form above: 60 back-to-back launches over ragged contexts while a second stream keeps the memory system busy — the shares of a pair then
+    finish far apart and in changing order.  The merge is slot-ordered, so every launch must reproduce the first one bit for bit, stay within the rounding of one
+    f32 merge of the per-pair form, and leave every arrival counter at zero."""
+    rng = np.random.default_rng(78)
+    l = nvr.lib()
+    B, H, KVH, D, bs = 40, 16, 8, 128, 64
+    ctxs = [1 + (977 * i) % 2600 for i in range(B)]
+    NB = sum((c + bs - 1) // bs for c in ctxs) + 3
+    kc, kcb, vc, vcb, bt, max_blocks = _paged_case(rng, B, H, KVH, D, bs, ctxs, NB)
+    q, qb = h16(rng.standard_normal((B, H, D)))
+    scale = float(np.float32(1.0) / np.sqrt(np.float32(D)))
+    meta = nvr.AttnMetaC()
+    d_ctx, d_bt = dev(np.asarray(ctxs, np.int32)), dev(bt)
+    meta.context_lens, meta.block_tables, meta.max_blocks, meta.batch, meta.max_context_len = d_ctx.ptr, d_bt.ptr, max_blocks, B, int(max(ctxs))
+    ws = nvr.DeviceBuffer(l.nvr_paged_attn_workspace_bytes(B, H, D, int(max(ctxs)))); _KEEP.append(ws)
+    d_q, d_k, d_v = dev(qb), dev(kcb), dev(vcb)
+    d_ref = nvr.DeviceBuffer(B * H * D * 2); _KEEP.append(d_ref)
+    nvr.check(l.nvr_paged_attn_decode(d_q.ptr, H * D, d_k.ptr, d_v.ptr, C.byref(meta), H, KVH, D, bs, scale, d_ref.ptr, ws.ptr, None))
+    sa, sb = C.c_void_p(), C.c_void_p()
+    nvr.check(l.nvr_stream_create(C.byref(sa))); nvr.check(l.nvr_stream_create(C.byref(sb)))
+    hog = nvr.DeviceBuffer(512 << 20); _KEEP.append(hog)
+    tickets = dev(np.zeros(B * KVH, np.uint32))
+    outs = [nvr.DeviceBuffer(B * H * D * 2) for _ in range(60)]; _KEEP.extend(outs)
+    try:
+        for i, d_o in enumerate(outs):
+            if i % 3 == 0:
+                nvr.check(l.nvr_fill_weight(hog.ptr, 16384, 16384, 16384, 16384, 0, 0, 9 + i, 1e-6, sb))
+            nvr.check(l.nvr_paged_attn_decode_fused(d_q.ptr, H * D, d_k.ptr, d_v.ptr, C.byref(meta), H, KVH, D, bs, scale, d_o.ptr, ws.ptr, tickets.ptr, sa))
+        nvr.check(l.nvr_stream_synchronize(sa)); nvr.check(l.nvr_stream_synchronize(sb))
+    finally:
+        l.nvr_stream_destroy(sa); l.nvr_stream_destroy(sb)
+    first = outs[0].to_numpy((B, H, D), np.uint16)
+    assert_close_f16(first.view(F16), d_ref.to_numpy((B, H, D), F16), ulps=2, atol=1e-3, what="work-balanced form vs the per-pair form")
+    for i, d_o in enumerate(outs[1:], 1):
+        assert np.array_equal(d_o.to_numpy((B, H, D), np.uint16), first), f"work-balanced launch {i} differs from launch 0"
+    assert not tickets.to_numpy((B * KVH,), np.uint32).any()
+
+
 def test_paged_attn_ignores_garbage_beyond_context():
     """A-8: exactly context_lens[b] keys are visible; poison everything else (incl. -1 padded table slots)."""
     rng = np.random.default_rng(7)
