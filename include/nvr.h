@@ -316,7 +316,7 @@ NVR_API int64_t nvr_runner_last_shared_prefix_len(const nvr_model_runner_t *r);
  * K / V once, into the caches), 2 = the caches through the block tables (cached prefixes, prompt chunks); -1 = the last step was a decode */
 NVR_API int nvr_runner_last_prefill_kv_source(const nvr_model_runner_t *r);
 NVR_API int64_t nvr_runner_last_shared_prefix_rows(const nvr_model_runner_t *r);   /* sequences of that step inside the sharing group */
-/* 1 when the last decode step's contexts were RAGGED enough (their sum < batch x longest / 1.3, up to 1024 (sequence, kv head) pairs) for the
+/* 1 when the last decode step's contexts were RAGGED enough (their sum < batch x longest / 1.3, up to 1024 (sequence, kv head) pairs, >= 6 x 64 keys per CU) for the
  * work-balanced attention launch — two or three workgroups per CU walking equal shares of all pairs' keys instead of workgroups per pair sized by the longest
  * context (Attention::flash_attention_decode, attention.rs:225-235: same result within one f32 merge); 0 otherwise, and for prefill steps. */
 NVR_API int32_t nvr_runner_last_decode_ragged(const nvr_model_runner_t *r);

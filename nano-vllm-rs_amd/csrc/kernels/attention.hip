@@ -814,9 +814,10 @@ static int launch_attn(const AttnArgs &a, bool paged, hipStream_t s) {
         const int64_t cus = share_workgroups(), rounds = (pairs + cus - 1) / cus, units = (mc + 63) / 64;
         const int64_t cap = a.workspace_bytes ? (int64_t)(a.workspace_bytes / ((size_t)a.nq * a.H * (D + 2) * sizeof(float))) : units;
         const bool by_count = pairs > cus && rounds * cus * 100 >= pairs * 115 && mc >= 256;
-        // shares: one per CU for the pair-count case (uniform contexts: a second segment per share buys nothing); two per CU for ragged batches (co-resident: twice
-        // the rows in flight, and the dispatcher evens out what the static cut leaves), three from 2 pairs per CU on (measured: profiles/r06_priced_levers.txt 14.)
-        const int64_t nw = (a.balance_hint || share_mode() == 2) ? cus * (pairs <= 2 * cus ? 2 : 3) : cus;
+        // shares: one per CU for the pair-count case (uniform contexts: a second segment per share buys nothing); for ragged batches the caller's count — two per CU
+        // (co-resident: twice the rows in flight, and the dispatcher evens out what the static cut leaves), three from 2 pairs per CU on, fewer while a share would
+        // hold less than four 64-key units (measured: profiles/r06_priced_levers.txt 14.)
+        const int64_t nw = a.balance_hint > 0 ? a.balance_hint : share_mode() == 2 ? cus * (pairs <= 2 * cus ? 2 : 3) : cus;
         if ((by_count || a.balance_hint || share_mode() == 2) && pairs < 2048 && cap >= units) {
             p.part_size = 64; p.num_parts = (int32_t)cap;
             p.part_o = (float *)a.workspace; p.part_ml = p.part_o + (int64_t)a.nq * a.H * cap * D;

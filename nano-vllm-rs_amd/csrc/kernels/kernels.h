@@ -43,8 +43,8 @@ struct AttnArgs {
     // A caller that passes them also allows the other launch-free merge: behind a shared-prefix pass that covers the WHOLE batch, with one
     // own partition per pair, that partition's workgroup merges the pair (it is the last arriver by stream order; no counter is touched)
     unsigned int *tickets;
-    // paged decode with `tickets`: the caller knows the contexts are RAGGED (their sum is well below nq * max_ctx) — take the work-balanced form
-    // (attn_share_kernel: one workgroup per CU, equal shares of all pairs' keys) wherever it can run, not only where the pair count asks for it
+    // paged decode with `tickets`: > 0 = the caller knows the contexts are RAGGED (their sum is well below nq * max_ctx) and asks for the work-balanced form
+    // (attn_share_kernel) with this many equal shares of all pairs' keys, wherever it can run — not only where the pair count asks for it
     int32_t balance_hint;
 };
 

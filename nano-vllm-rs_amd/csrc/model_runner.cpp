@@ -729,10 +729,15 @@ static inline uint64_t graph_key(bool want_logits, size_t nseq, int64_t bucket, 
 // a captured graph): the short sequences' workgroups idle (or finish early) while the long ones stream — the work-balanced launch (attn_share_kernel) cuts the keys
 // evenly instead.  Ragged = the contexts sum to less than 1 / 1.3 of batch x bound, and there are two 64-key units of work for every CU.  (float32 runners,
 // shared-prefix steps and batches of > 1024 pairs — 4+ workgroups per CU, which the dispatcher balances: 200 ragged sequences 3.96 per-pair against 4.12 — keep their launches.)
-bool nvr_model_runner::ragged_batch(size_t nseq, int64_t sum_ctx, int64_t max_ctx) const {
+bool nvr_model_runner::ragged_batch(size_t nseq, int64_t sum_ctx, int64_t max_ctx) {
     if (f32 || nseq == 0 || decode_shared_len > 0) return false;
-    const int64_t pairs = (int64_t)nseq * KVH;
-    return pairs <= 1024 && max_ctx * (int64_t)nseq * 100 >= sum_ctx * 130 && sum_ctx * KVH / 64 >= 2 * (int64_t)num_cus;
+    const int64_t pairs = (int64_t)nseq * KVH, units = sum_ctx * KVH / 64, cus = num_cus;
+    // shares: two per CU (three from 2 pairs per CU on), but none of less than four units (a tensor-parallel rank with one kv head: 32 sequences of 256..8192
+    // keys are 1176 units — 512 shares of 2.3 units lost 2-5 % to the per-pair launch)
+    decode_shares = (int32_t)std::max<int64_t>(64, std::min<int64_t>(cus * (pairs <= 2 * cus ? 2 : 3), units / 4));
+    // ... and not below six units per CU in all: the step is then launch-bound and the per-pair launch's shorter ramp wins (12 sequences of 20..1500 keys: 1.08
+    // against 1.24 ms per step; 8 of 64..8192 keys — 2040 units — 1.65 -> 1.33 the other way)
+    return pairs <= 1024 && max_ctx * (int64_t)nseq * 100 >= sum_ctx * 130 && units >= 6 * cus;
 }
 
 // Prefill on tensor-parallel ranks as TWO micro-batches of whole sequences (row g, nvr_runner_set_tp_prefill_overlap(r, 2)): rows [0, mb_rows)
@@ -866,7 +871,7 @@ int nvr_model_runner::forward(int64_t T, int64_t B, bool is_prefill, int64_t max
             a.k = k_cache(l); a.v = v_cache(l); a.block_tables = bt; a.max_blocks = (int32_t)max_blocks_per_seq;
             a.block_size = (int32_t)block_size; a.workspace = attn_ws; a.workspace_bytes = attn_ws_bytes; a.tickets = attn_tickets;
             a.shared_len = (int32_t)decode_shared_len;
-            a.balance_hint = decode_ragged ? 1 : 0;
+            a.balance_hint = decode_ragged ? decode_shares : 0;
             if (decode_shared_len > 0 && decode_shared_rows < T) {     // a group inside the batch: per-row kv0, member rows, member count
                 a.shared_kv0 = (const int32_t *)(in_dev + off_dec + dof_skv0); a.shared_rows = (const int32_t *)(in_dev + off_dec + dof_srows);
                 a.shared_count = (const int32_t *)(in_dev + off_dec + dof_scount);

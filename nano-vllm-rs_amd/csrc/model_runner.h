@@ -81,7 +81,8 @@ struct nvr_model_runner {
     size_t last_rows = 0; bool last_prefill = false; int64_t last_tokens = 0;
     int64_t decode_shared_len = 0;                       // the last decode step: tokens its sharing group holds in the same leading blocks
     bool decode_ragged = false;                          // the decode step's contexts are ragged enough for the work-balanced attention launch (ragged_batch)
-    bool ragged_batch(size_t nseq, int64_t sum_ctx, int64_t max_ctx) const;
+    bool ragged_batch(size_t nseq, int64_t sum_ctx, int64_t max_ctx);   // (also sets decode_shares)
+    int32_t decode_shares = 0;                           // ... and the number of shares its launch is asked for
     int64_t decode_shared_rows = 0;                      // ... and how many of the step's sequences belong to that group (== batch: all)
     nvr::Comm comm;
     bool graphs_disabled = false;   // set when capture with RCCL nodes fails: fall back to eager launches

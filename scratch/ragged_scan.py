@@ -6,7 +6,8 @@ nvr = nvr_import.load()
 preset, B, lo, hi = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
 mc = nvr.ModelConfig(preset)
 lens = [int(lo * (hi / lo) ** (i / max(1, B - 1))) for i in range(B)]
-eng = nvr.LLMEngine(nvr.Config(max_num_seqs=B, max_num_batched_tokens=32768, max_model_len=hi + 64, kvcache_block_size=256, num_kvcache_blocks=sum((n + 64) // 256 + 2 for n in lens)), mc)
+eng = nvr.LLMEngine(nvr.Config(max_num_seqs=B, max_num_batched_tokens=32768, max_model_len=hi + 64, kvcache_block_size=256, num_kvcache_blocks=sum((n + 64) // 256 + 2 for n in lens),
+                               tensor_parallel_size=int(os.environ.get("TP", "1")), tensor_parallel_rank=0), mc)   # TP=n with NVR_TP_NO_COMM=1: one rank's compute
 for i, n in enumerate(lens):
     eng.add_request(nvr.synthetic_tokens(n, 1, i, 151936).tolist(), nvr.SamplingParams(temperature=0.0, max_tokens=40, ignore_eos=True))
 while eng.step()["is_prefill"]: pass
